@@ -1,0 +1,115 @@
+"""Pins the oracle (oracle/unet.py, schedule values) against golden vectors
+produced by importing the reference (tests/golden/make_golden.py).  CPU only."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from param_gen import gen_param, normal
+from make_golden_cases import UNET_CASES
+from oracle import losses as Ls
+from oracle import unet as U
+
+FWD = dict(rtol=1e-4, atol=1e-5)
+GRAD = dict(rtol=1e-3, atol=1e-5)
+
+
+def _load(golden_dir, name):
+    return np.load(os.path.join(golden_dir, name), allow_pickle=False)
+
+
+def test_timestep_embedding(golden_dir):
+    g = _load(golden_dir, "timestep_embedding.npz")
+    e = U.timestep_embedding(torch.from_numpy(g["t"]), 128)
+    np.testing.assert_allclose(e.numpy(), g["emb"], rtol=1e-6, atol=1e-6)
+
+
+def test_qkv_attention(golden_dir):
+    g = _load(golden_dir, "qkv_attention.npz")
+    qkv = torch.from_numpy(normal(tuple(g["shape"]), seed=int(g["seed_qkv"]))).requires_grad_(True)
+    a = U.qkv_attention(qkv)
+    a.backward(torch.from_numpy(normal(tuple(a.shape), seed=int(g["seed_dy"]))))
+    np.testing.assert_allclose(a.detach().numpy(), g["out"], **FWD)
+    np.testing.assert_allclose(qkv.grad.numpy(), g["dqkv"], **GRAD)
+
+
+RES = {"plain": (32, 32, ""), "skip": (32, 64, ""), "wide_in": (96, 32, ""), "down": (32, 32, "down"), "up": (64, 64, "up")}
+
+
+@pytest.mark.parametrize("name", list(RES))
+def test_resblock(golden_dir, name):
+    g = _load(golden_dir, "resblocks.npz")
+    ci, co, flag = RES[name]
+    sw, sx, se, sdy = [int(v) for v in g[name + ":seeds"]]
+    shapes = {"in_layers.0.weight": (ci,), "in_layers.0.bias": (ci,), "in_layers.2.weight": (co, ci, 3),
+              "in_layers.2.bias": (co,), "emb_layers.1.weight": (co, 128), "emb_layers.1.bias": (co,),
+              "out_layers.0.weight": (co,), "out_layers.0.bias": (co,), "out_layers.3.weight": (co, co, 3),
+              "out_layers.3.bias": (co,)}
+    if ci != co:
+        shapes["skip_connection.weight"] = (co, ci, 1); shapes["skip_connection.bias"] = (co,)
+    sd = {k: torch.from_numpy(gen_param(sw, k, s)).requires_grad_(True) for k, s in shapes.items()}
+    x = torch.from_numpy(normal((2, ci, 32), seed=sx)).requires_grad_(True)
+    emb = torch.from_numpy(normal((2, 128), seed=se)).requires_grad_(True)
+    y = U.resblock(sd, "", x, emb, up=flag == "up", down=flag == "down")
+    y.backward(torch.from_numpy(normal(tuple(y.shape), seed=sdy)))
+    np.testing.assert_allclose(y.detach().numpy(), g[name + ":y"], **FWD)
+    np.testing.assert_allclose(x.grad.numpy(), g[name + ":dx"], **GRAD)
+    np.testing.assert_allclose(emb.grad.numpy(), g[name + ":demb"], **GRAD)
+    for k in shapes:
+        np.testing.assert_allclose(sd[k].grad.numpy(), g[name + ":g:" + k], rtol=1e-3, atol=1e-4)
+
+
+def test_attention_block(golden_dir):
+    g = _load(golden_dir, "attention_block.npz")
+    sw, sx, sdy = [int(v) for v in g["seeds"]]
+    shapes = {"norm.weight": (64,), "norm.bias": (64,), "qkv.weight": (192, 64, 1), "qkv.bias": (192,),
+              "proj_out.weight": (64, 64, 1), "proj_out.bias": (64,)}
+    sd = {k: torch.from_numpy(gen_param(sw, k, s)).requires_grad_(True) for k, s in shapes.items()}
+    x = torch.from_numpy(normal((2, 64, 24), seed=sx)).requires_grad_(True)
+    y = U.attention_block(sd, "", x)
+    y.backward(torch.from_numpy(normal(tuple(y.shape), seed=sdy)))
+    np.testing.assert_allclose(y.detach().numpy(), g["y"], **FWD)
+    np.testing.assert_allclose(x.grad.numpy(), g["dx"], **GRAD)
+    for k in shapes:
+        np.testing.assert_allclose(sd[k].grad.numpy(), g["g:" + k], rtol=1e-3, atol=1e-4)
+
+
+@pytest.mark.parametrize("name", list(UNET_CASES))
+def test_unet_vs_reference(golden_dir, name):
+    g = _load(golden_dir, f"unet_{name}.npz")
+    cfg, B, L = UNET_CASES[name]
+    sw, sx, _st, sdy = [int(v) for v in g["seeds"]]
+    shapes = U.unet_param_shapes(cfg)
+    assert list(shapes.keys()) == [str(k) for k in g["keys"]]          # state-dict key order/naming pinned
+    assert sum(int(np.prod(s)) for s in shapes.values()) == int(g["n_params"])
+    sd = {k: torch.from_numpy(gen_param(sw, k, s)).requires_grad_(True) for k, s in shapes.items()}
+    x = torch.from_numpy(normal((B, cfg["in_channels"], L), seed=sx)).requires_grad_(True)
+    y = U.unet_forward(sd, cfg, x, torch.from_numpy(g["t"]))
+    y.backward(torch.from_numpy(normal(tuple(y.shape), seed=sdy)))
+    np.testing.assert_allclose(y.detach().numpy(), g["y"], **FWD)
+    np.testing.assert_allclose(x.grad.numpy(), g["dx"], **GRAD)
+    for k in shapes:
+        gr = sd[k].grad.double().reshape(-1)
+        np.testing.assert_allclose(gr[:32].float().numpy(), g["g_head:" + k], rtol=2e-3, atol=2e-4)
+        assert abs(float(gr.norm()) - float(g["g_l2:" + k])) <= 1e-3 * float(g["g_l2:" + k]) + 1e-5
+
+
+def test_full_size_key_list(golden_dir):
+    g = _load(golden_dir, "unet_full_keys.npz")
+    cfg = dict(image_size=768, in_channels=1, out_channels=1, model_channels=128, num_res_blocks=2,
+               attention_resolutions=[8, 4], channel_mult=[1, 2, 4], resblock_updown=True)
+    shapes = U.unet_param_shapes(cfg)
+    assert [str(k) for k in g["keys"]] == list(shapes.keys())
+    assert [",".join(str(d) for d in s) for s in shapes.values()] == [str(s) for s in g["shapes"]]
+    assert int(g["n_params"]) == 30533121 == sum(int(np.prod(s)) for s in shapes.values())
+
+
+@pytest.mark.parametrize("name,b0,b1", [("train_0.0015_0.0195", 0.0015, 0.0195), ("sample_0.0015_0.0205", 0.0015, 0.0205)])
+def test_scaled_linear_schedule(golden_dir, name, b0, b1):
+    g = _load(golden_dir, "schedules.npz")
+    acp = Ls.alphas_cumprod("scaled_linear_beta", 1000, b0, b1).double().numpy()
+    np.testing.assert_allclose(acp, g[name + ":alphas_cumprod"], rtol=2e-5)
+    # SURVEY §8c known answers
+    ref = {"train_0.0015_0.0195": (0.99850, 0.115844, 1.42304e-4), "sample_0.0015_0.0205": (0.99850, 0.108576, 9.69109e-5)}[name]
+    np.testing.assert_allclose(acp[[0, 499, 999]], ref, rtol=2e-4)
