@@ -1,0 +1,13 @@
+"""Importable alias for the product package.
+
+The package directory carries the repository's mandated name
+(`synthetic-sleep-eeg-signal-generation-using-latent-diffusion-models_amd/`), which is
+not a valid Python identifier; this stub makes it importable as `eegldm`.
+"""
+import os as _os
+
+_PKG = _os.path.join(_os.path.dirname(_os.path.dirname(_os.path.abspath(__file__))),
+                     "synthetic-sleep-eeg-signal-generation-using-latent-diffusion-models_amd")
+__path__.insert(0, _PKG)
+
+from ._lib import lib, LibraryMissing, check, Context, default_context  # noqa: E402,F401

@@ -1,0 +1,179 @@
+/* eegldm.h -- C ABI of libeegldm.so: MI355X (gfx950) kernels and model executors for
+ * the latent-diffusion hot path of the reference repository
+ * (AutoencoderKL + PatchDiscriminator train step, UNet denoiser train step, DDIM sampling).
+ *
+ * The reference has no FFI layer: its boundary is the PyTorch nn.Module / callable
+ * protocol of its entry scripts.  Each group below names the reference interface it
+ * stands behind (file:line under /root/reference).  A Python binding mirroring those
+ * classes lives in the package (`eegldm/`); INTEGRATION.md shows the ctypes stub a
+ * reference maintainer would add.
+ *
+ * Conventions
+ *  - Every pointer is a DEVICE pointer unless the name ends in _host.  The caller owns
+ *    all tensors, parameters, gradients and optimizer state; the library owns only the
+ *    context workspace and the opaque handles.  No hidden host copies.
+ *  - All calls enqueue on the context's HIP stream and return; a context is not
+ *    thread-safe; one context + one process per GPU.
+ *  - Return value 0 = ok, negative = error code; eegldm_last_error() gives the
+ *    thread-local message.  No C++ exception crosses this ABI.  Shapes / dtypes are
+ *    validated before any launch.
+ *  - "NCL" = the reference's contiguous (batch, channel, length) tensors.
+ *    "NLC" = the engine's internal layout: rows = (sample, position), channels
+ *    contiguous, explicit leading dimension `ld` in elements (so channel-concats are
+ *    views).  Model-level entry points take/return NCL fp32 like the reference;
+ *    primitive entry points work on NLC.
+ *  - Convolution weights are held packed as [K][Cout][Cin] (tap-major); eegldm_pack_*
+ *    converts from/to the reference (Cout, Cin, K) layout.
+ *  - Random draws (noise, eps, timesteps) are inputs, so device and oracle runs see
+ *    identical values; eegldm_randn / eegldm_randint fill them on-device for perf runs.
+ */
+#ifndef EEGLDM_H
+#define EEGLDM_H
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define EEGLDM_ABI_VERSION 1
+
+enum { EEGLDM_F32 = 0, EEGLDM_BF16 = 1 };
+enum {
+  EEGLDM_OK = 0,
+  EEGLDM_ERR_INVALID = -1,
+  EEGLDM_ERR_HIP = -2,
+  EEGLDM_ERR_UNSUPPORTED = -3,
+  EEGLDM_ERR_NOMEM = -4
+};
+enum { EEGLDM_PRED_EPSILON = 0, EEGLDM_PRED_V = 1, EEGLDM_PRED_SAMPLE = 2 };
+
+typedef struct eegldm_ctx eegldm_ctx;
+typedef struct eegldm_unet eegldm_unet;
+typedef struct eegldm_aekl eegldm_aekl;
+typedef struct eegldm_disc eegldm_disc;
+
+/* ------------------------------------------------------------------ library / context */
+int eegldm_abi_version(void);
+const char* eegldm_last_error(void);
+/* hip_stream: the hipStream_t to enqueue on (e.g. torch's current stream; NULL = the
+ * device's default stream, which is what torch uses unless told otherwise).
+ * own_stream != 0: ignore hip_stream and create a private non-blocking stream. */
+int eegldm_ctx_create(int hip_device, void* hip_stream, int own_stream, eegldm_ctx** out);
+int eegldm_ctx_destroy(eegldm_ctx* ctx);
+int eegldm_ctx_sync(eegldm_ctx* ctx);
+/* HIP-event timing on the context's stream (bench.py measures kernels with these, since
+ * torch.cuda.Event only sees torch's current stream). */
+int eegldm_timer_start(eegldm_ctx* ctx);
+int eegldm_timer_stop_ms(eegldm_ctx* ctx, float* ms_host);
+
+/* ------------------------------------------------------------------ layout / packing */
+int eegldm_ncl_to_nlc(eegldm_ctx*, const float* src_ncl, void* dst_nlc, long ld_dst, int B, int C, int L, int dst_dtype);
+int eegldm_nlc_to_ncl(eegldm_ctx*, const void* src_nlc, long ld_src, float* dst_ncl, int B, int C, int L, int src_dtype);
+/* (Cout,Cin,K) fp32  <->  [K][Cout][Cin] fp32 */
+int eegldm_pack_conv_weight(eegldm_ctx*, const float* w_ref, float* w_packed, int Cout, int Cin, int K);
+int eegldm_unpack_conv_weight(eegldm_ctx*, const float* w_packed, float* w_ref, int Cout, int Cin, int K);
+/* fp32 -> compute dtype copy (n elements) */
+int eegldm_cast(eegldm_ctx*, const float* src, void* dst, long n, int dst_dtype);
+
+/* ------------------------------------------------------------------ primitives (NLC)
+ * nn.Conv1d as used at unet.py:263,291,302,385,504 and inside MONAI AutoencoderKL /
+ * PatchDiscriminator.  w: packed [K][Cout][Cin] in `dtype`;
+ * bias / rowvec / dw / dbias: fp32.  Output length Lout = (Lin + pad_l + pad_r - K)/stride + 1.
+ * rowvec (optional): per-sample vector [B][ld_rowvec] added to every position (the
+ * timestep-embedding add, unet.py:316-325).  resid (optional): tensor added in the
+ * epilogue (residual / skip, unet.py:327). */
+int eegldm_conv1d_fwd(eegldm_ctx*, const void* x, long ldx, const void* w, const float* bias,
+                      void* y, long ldy, int B, int Lin, int Cin, int Cout, int K, int stride,
+                      int pad_l, int pad_r, const float* rowvec, long ld_rowvec,
+                      const void* resid, long ld_resid, int dtype);
+int eegldm_conv1d_bwd_data(eegldm_ctx*, const void* dy, long lddy, const void* w, void* dx, long lddx,
+                           int B, int Lin, int Cin, int Cout, int K, int stride, int pad_l, int pad_r,
+                           const void* resid, long ld_resid, int dtype);
+/* dw += ..., dbias += ... (fp32 accumulators; dbias may be NULL) */
+int eegldm_conv1d_bwd_weight(eegldm_ctx*, const void* x, long ldx, const void* dy, long lddy,
+                             float* dw, float* dbias, int B, int Lin, int Cin, int Cout, int K,
+                             int stride, int pad_l, int pad_r, int dtype);
+/* nn.Linear (unet.py:373-377, 277-285): y[M][N] = x[M][K] w[N][K]^T + bias; y is fp32 when out_f32 */
+int eegldm_linear_fwd(eegldm_ctx*, const void* x, long ldx, const void* w, const float* bias, void* y, long ldy,
+                      int M, int N, int K, int dtype, int out_f32);
+
+/* nn.GroupNorm(G, C, eps) [+ SiLU] (unet.py:71-74; MONAI norm_num_groups, eps 1e-6).
+ * stats: [B][G][2] fp32 (mean, rstd), written by fwd and consumed by bwd.
+ * resample: 0 none, 1 = AvgPool1d(2,2) after the activation, 2 = nearest x2 after the
+ * activation (the up/down ResBlock, unet.py:308-313); then y has L/2 or 2L rows and
+ * xr (optional) receives the equally resampled raw x. */
+int eegldm_groupnorm_fwd(eegldm_ctx*, const void* x, long ldx, const float* gamma, const float* beta,
+                         void* y, long ldy, float* stats, int B, int L, int C, int G, float eps,
+                         int fuse_silu, int resample, void* xr, long ldxr, int dtype);
+int eegldm_groupnorm_bwd(eegldm_ctx*, const void* x, long ldx, const float* gamma, const float* beta,
+                         const float* stats, const void* dy, long lddy, void* dx, long lddx,
+                         float* dgamma, float* dbeta, int B, int L, int C, int G, int fuse_silu,
+                         int resample, const void* dxr, long lddxr, int dtype);
+
+/* single-head QKV attention (unet.py:107-125): qkv [B*T][3C] (q|k|v), out [B*T][C].
+ * probs: caller-provided [B][T][T] `dtype` buffer (kept for backward);
+ * scratch_*: caller-provided work buffers, [B][T][T] fp32 (logits / dprobs) and
+ * [B][T][T] `dtype` (dlogits). */
+int eegldm_attention_fwd(eegldm_ctx*, const void* qkv, long ldqkv, void* out, long ldo, void* probs,
+                         float* scratch_logits, int B, int T, int C, int dtype);
+int eegldm_attention_bwd(eegldm_ctx*, const void* qkv, long ldqkv, const void* probs, const void* dout, long lddo,
+                         void* dqkv, long lddqkv, float* scratch_dprobs, void* scratch_dlogits,
+                         int B, int T, int C, int dtype);
+
+/* ------------------------------------------------------------------ schedulers / losses / optimizer
+ * DDPMScheduler.add_noise / get_velocity (training.py:429-436), DDIMScheduler.step
+ * (sample_trials.py:163), F.mse_loss (training.py:437), torch.optim.Adam (train_ldm.py:208). */
+int eegldm_add_noise(eegldm_ctx*, const float* x, const float* noise, const int64_t* t, const float* acp,
+                     float* out, int B, long n_per_sample);
+int eegldm_get_velocity(eegldm_ctx*, const float* x, const float* noise, const int64_t* t, const float* acp,
+                        float* out, int B, long n_per_sample);
+int eegldm_ddim_step(eegldm_ctx*, const float* model_out, const float* sample, float a_t, float a_prev,
+                     int pred_type, int clip_sample, float* prev_sample, float* pred_x0, long n);
+/* loss = mean((pred-target)^2); dpred = 2 (pred-target) / n * grad_scale (nullable) */
+int eegldm_mse_loss(eegldm_ctx*, const float* pred, const float* target, float* loss, float* dpred, long n, float grad_scale);
+int eegldm_adam_step(eegldm_ctx*, float* p, const float* g, float* m, float* v, long n, float lr, float beta1,
+                     float beta2, float eps, int step, float grad_inv_scale);
+int eegldm_randn(eegldm_ctx*, float* out, long n, uint64_t seed, uint64_t offset);
+int eegldm_randint(eegldm_ctx*, int64_t* out, long n, int64_t high, uint64_t seed, uint64_t offset);
+
+/* ------------------------------------------------------------------ UNet denoiser
+ * UNetModel(image_size, in_channels, model_channels, out_channels, num_res_blocks,
+ * attention_resolutions, dropout=0, channel_mult, num_heads=1, use_scale_shift_norm=False,
+ * resblock_updown=True) -- /root/reference/src/models/unet.py:330-563, config_ldm.yaml:30-43. */
+typedef struct {
+  int in_channels, out_channels, model_channels, num_res_blocks;
+  int n_mult; int channel_mult[8];
+  int n_attn; int attention_resolutions[8];
+  int num_heads;           /* only 1 is implemented (all reference configs) */
+  int dtype;               /* storage/compute dtype of activations: EEGLDM_F32 or EEGLDM_BF16 */
+} eegldm_unet_cfg;
+
+int eegldm_unet_create(eegldm_ctx*, const eegldm_unet_cfg* cfg, eegldm_unet** out);
+int eegldm_unet_destroy(eegldm_unet*);
+/* Parameter table: entry i <-> one reference state_dict key, stored at [offset, offset+numel)
+ * of the flat fp32 parameter / gradient buffers.  Conv weights (ndim 3) are stored packed
+ * [K][Cout][Cin]; `shape` reports the reference shape (Cout, Cin, K). */
+int eegldm_unet_num_entries(const eegldm_unet*);
+long eegldm_unet_num_params(const eegldm_unet*);
+int eegldm_unet_entry(const eegldm_unet*, int i, char* name, int name_cap, long* offset, long* numel,
+                      int* ndim, int shape[3]);
+/* Bind caller-owned flat fp32 buffers (grads may be NULL for inference). */
+int eegldm_unet_bind(eegldm_unet*, float* params, float* grads);
+/* Refresh the compute-dtype weight copies after `params` changed (no-op for fp32). */
+int eegldm_unet_sync_weights(eegldm_unet*);
+/* forward(x, timesteps): x, y are NCL fp32 (B, C, L); t int64 (B).  training != 0 keeps
+ * activations for eegldm_unet_backward. */
+int eegldm_unet_forward(eegldm_unet*, const float* x, const int64_t* t, float* y, int B, int L, int training);
+/* grads += d loss / d params; dx (nullable) = d loss / d x.  Gradients accumulate: zero the
+ * flat gradient buffer (eegldm_fill) between steps, as optimizer.zero_grad does. */
+int eegldm_unet_backward(eegldm_unet*, const float* dy, float* dx);
+int eegldm_fill(eegldm_ctx*, float* p, long n, float value);
+
+/* The body of train_epoch_ldm (training.py:419-443) after the frozen encoder: add_noise,
+ * UNet forward, MSE vs noise / velocity, backward.  loss: device scalar. */
+int eegldm_ldm_train_step(eegldm_unet*, const float* latents, const float* noise, const int64_t* t,
+                          const float* acp, int pred_type, int B, int L, float grad_scale, float* loss);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* EEGLDM_H */

@@ -1,0 +1,140 @@
+"""ctypes binding of libeegldm.so (the C ABI declared in include/eegldm.h).
+
+The HIP library is the product: if it is missing or fails to load this module
+raises -- there is no CPU or PyTorch fallback for any compute entry point.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libeegldm.so")
+
+F32, BF16 = 0, 1
+PRED = {"epsilon": 0, "v_prediction": 1, "sample": 2}
+
+
+class LibraryMissing(RuntimeError):
+    pass
+
+
+def _load():
+    if not os.path.exists(LIB_PATH):
+        raise LibraryMissing(f"{LIB_PATH} not found: build it with `make` (python -c 'import __graft_entry__ as g; g.build()')")
+    return C.CDLL(LIB_PATH)
+
+
+lib = _load()
+lib.eegldm_last_error.restype = C.c_char_p
+if hasattr(lib, 'eegldm_unet_num_params'):
+    lib.eegldm_unet_num_params.restype = C.c_long
+
+# (name, argtypes) -- every symbol include/eegldm.h declares; tests/test_abi.py checks the list against the header
+_vp, _i, _l, _f = C.c_void_p, C.c_int, C.c_long, C.c_float
+SIGNATURES = {
+    "eegldm_abi_version": [],
+    "eegldm_last_error": [],
+    "eegldm_ctx_create": [_i, _vp, _i, C.POINTER(_vp)],
+    "eegldm_ctx_destroy": [_vp],
+    "eegldm_ctx_sync": [_vp],
+    "eegldm_timer_start": [_vp],
+    "eegldm_timer_stop_ms": [_vp, C.POINTER(_f)],
+    "eegldm_ncl_to_nlc": [_vp, _vp, _vp, _l, _i, _i, _i, _i],
+    "eegldm_nlc_to_ncl": [_vp, _vp, _l, _vp, _i, _i, _i, _i],
+    "eegldm_pack_conv_weight": [_vp, _vp, _vp, _i, _i, _i],
+    "eegldm_unpack_conv_weight": [_vp, _vp, _vp, _i, _i, _i],
+    "eegldm_cast": [_vp, _vp, _vp, _l, _i],
+    "eegldm_conv1d_fwd": [_vp, _vp, _l, _vp, _vp, _vp, _l, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _l, _vp, _l, _i],
+    "eegldm_conv1d_bwd_data": [_vp, _vp, _l, _vp, _vp, _l, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _l, _i],
+    "eegldm_conv1d_bwd_weight": [_vp, _vp, _l, _vp, _l, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i],
+    "eegldm_linear_fwd": [_vp, _vp, _l, _vp, _vp, _vp, _l, _i, _i, _i, _i, _i],
+    "eegldm_groupnorm_fwd": [_vp, _vp, _l, _vp, _vp, _vp, _l, _vp, _i, _i, _i, _i, _f, _i, _i, _vp, _l, _i],
+    "eegldm_groupnorm_bwd": [_vp, _vp, _l, _vp, _vp, _vp, _vp, _l, _vp, _l, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _l, _i],
+    "eegldm_attention_fwd": [_vp, _vp, _l, _vp, _l, _vp, _vp, _i, _i, _i, _i],
+    "eegldm_attention_bwd": [_vp, _vp, _l, _vp, _vp, _l, _vp, _l, _vp, _vp, _i, _i, _i, _i],
+    "eegldm_add_noise": [_vp, _vp, _vp, _vp, _vp, _vp, _i, _l],
+    "eegldm_get_velocity": [_vp, _vp, _vp, _vp, _vp, _vp, _i, _l],
+    "eegldm_ddim_step": [_vp, _vp, _vp, _f, _f, _i, _i, _vp, _vp, _l],
+    "eegldm_mse_loss": [_vp, _vp, _vp, _vp, _vp, _l, _f],
+    "eegldm_adam_step": [_vp, _vp, _vp, _vp, _vp, _l, _f, _f, _f, _f, _i, _f],
+    "eegldm_randn": [_vp, _vp, _l, C.c_uint64, C.c_uint64],
+    "eegldm_randint": [_vp, _vp, _l, C.c_int64, C.c_uint64, C.c_uint64],
+    "eegldm_fill": [_vp, _vp, _l, _f],
+    "eegldm_unet_create": [_vp, _vp, C.POINTER(_vp)],
+    "eegldm_unet_destroy": [_vp],
+    "eegldm_unet_num_entries": [_vp],
+    "eegldm_unet_num_params": [_vp],
+    "eegldm_unet_entry": [_vp, _i, C.c_char_p, _i, C.POINTER(_l), C.POINTER(_l), C.POINTER(_i), C.POINTER(_i)],
+    "eegldm_unet_bind": [_vp, _vp, _vp],
+    "eegldm_unet_sync_weights": [_vp],
+    "eegldm_unet_forward": [_vp, _vp, _vp, _vp, _i, _i, _i],
+    "eegldm_unet_backward": [_vp, _vp, _vp],
+    "eegldm_ldm_train_step": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _f, _vp],
+}
+
+
+class UNetCfg(C.Structure):
+    _fields_ = [("in_channels", _i), ("out_channels", _i), ("model_channels", _i), ("num_res_blocks", _i),
+                ("n_mult", _i), ("channel_mult", _i * 8), ("n_attn", _i), ("attention_resolutions", _i * 8),
+                ("num_heads", _i), ("dtype", _i)]
+
+
+def _bind():
+    for name, args in SIGNATURES.items():
+        fn = getattr(lib, name, None)
+        if fn is None:
+            continue          # reported by tests/test_abi.py; compute calls fail loudly below
+        fn.argtypes = args
+
+
+_bind()
+
+
+def check(rc):
+    if rc != 0:
+        raise RuntimeError(f"libeegldm error {rc}: {lib.eegldm_last_error().decode(errors='replace')}")
+
+
+def ptr(t):
+    """Device pointer of a torch tensor (or None)."""
+    return None if t is None else C.c_void_p(t.data_ptr())
+
+
+class Context:
+    """One per process / GPU; enqueues on torch's current stream so torch ops and library
+    kernels are ordered with respect to each other."""
+
+    def __init__(self, device=0, use_torch_stream=True):
+        import torch
+        if not torch.cuda.is_available():
+            raise RuntimeError("eegldm needs an MI355X (gfx950) GPU: no HIP device is visible; there is no CPU fallback")
+        self.device = device
+        stream = torch.cuda.current_stream(device).cuda_stream if use_torch_stream else 0
+        h = C.c_void_p()
+        check(lib.eegldm_ctx_create(device, C.c_void_p(stream), 0 if use_torch_stream else 1, C.byref(h)))
+        self.h = h
+
+    def sync(self):
+        check(lib.eegldm_ctx_sync(self.h))
+
+    def timer_start(self):
+        check(lib.eegldm_timer_start(self.h))
+
+    def timer_stop_ms(self):
+        ms = C.c_float()
+        check(lib.eegldm_timer_stop_ms(self.h, C.byref(ms)))
+        return ms.value
+
+    def __del__(self):
+        try:
+            lib.eegldm_ctx_destroy(self.h)
+        except Exception:
+            pass
+
+
+_default = {}
+
+
+def default_context(device=0):
+    if device not in _default:
+        _default[device] = Context(device)
+    return _default[device]

@@ -1,0 +1,55 @@
+// Library plumbing: thread-local error string, context, HIP-event timer.
+#include "common.h"
+
+static thread_local std::string g_err;
+void eegldm_set_error(const std::string& msg) { g_err = msg; }
+
+struct TimerState { hipEvent_t a = nullptr, b = nullptr; };
+static thread_local TimerState g_timer;
+
+extern "C" int eegldm_abi_version(void) { return EEGLDM_ABI_VERSION; }
+extern "C" const char* eegldm_last_error(void) { return g_err.c_str(); }
+
+extern "C" int eegldm_ctx_create(int device, void* stream, int own_stream, eegldm_ctx** out) {
+  EEG_CHECK(out != nullptr, "out is null");
+  HIP_TRY(hipSetDevice(device));
+  hipDeviceProp_t prop;
+  HIP_TRY(hipGetDeviceProperties(&prop, device));
+  if (std::string(prop.gcnArchName).find("gfx950") == std::string::npos)
+    EEG_FAIL(EEGLDM_ERR_UNSUPPORTED, "libeegldm is built for gfx950 only; device %d is %s", device, prop.gcnArchName);
+  eegldm_ctx* c = new eegldm_ctx();
+  c->device = device;
+  c->num_cu = prop.multiProcessorCount;
+  if (own_stream) { HIP_TRY(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking)); c->owns_stream = true; }
+  else { c->stream = (hipStream_t)stream; c->owns_stream = false; }
+  c->scratch_bytes = 8u << 20;
+  HIP_TRY(hipMalloc(&c->scratch, c->scratch_bytes));
+  *out = c;
+  return 0;
+}
+extern "C" int eegldm_ctx_destroy(eegldm_ctx* c) {
+  if (!c) return 0;
+  hipSetDevice(c->device);
+  if (c->scratch) hipFree(c->scratch);
+  if (c->owns_stream) hipStreamDestroy(c->stream);
+  delete c;
+  return 0;
+}
+extern "C" int eegldm_ctx_sync(eegldm_ctx* c) {
+  EEG_CHECK(c, "null ctx");
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  return 0;
+}
+extern "C" int eegldm_timer_start(eegldm_ctx* c) {
+  EEG_CHECK(c, "null ctx");
+  if (!g_timer.a) { HIP_TRY(hipEventCreate(&g_timer.a)); HIP_TRY(hipEventCreate(&g_timer.b)); }
+  HIP_TRY(hipEventRecord(g_timer.a, c->stream));
+  return 0;
+}
+extern "C" int eegldm_timer_stop_ms(eegldm_ctx* c, float* ms) {
+  EEG_CHECK(c && ms && g_timer.a, "timer not started");
+  HIP_TRY(hipEventRecord(g_timer.b, c->stream));
+  HIP_TRY(hipEventSynchronize(g_timer.b));
+  HIP_TRY(hipEventElapsedTime(ms, g_timer.a, g_timer.b));
+  return 0;
+}

@@ -1,0 +1,106 @@
+// Shared declarations for the eegldm HIP library (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string>
+
+#include "../../include/eegldm.h"
+
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) short s16x4;
+typedef unsigned short bf16_t;  // storage type for bf16 tensors
+
+// ---------------------------------------------------------------- errors
+void eegldm_set_error(const std::string& msg);
+#define EEG_FAIL(code, ...)                                  \
+  do {                                                       \
+    char _b[512];                                            \
+    snprintf(_b, sizeof(_b), __VA_ARGS__);                   \
+    eegldm_set_error(std::string(__func__) + ": " + _b);     \
+    return (code);                                           \
+  } while (0)
+#define EEG_CHECK(cond, ...) \
+  do { if (!(cond)) EEG_FAIL(EEGLDM_ERR_INVALID, __VA_ARGS__); } while (0)
+#define HIP_TRY(expr)                                                          \
+  do {                                                                         \
+    hipError_t _e = (expr);                                                    \
+    if (_e != hipSuccess) EEG_FAIL(EEGLDM_ERR_HIP, "%s -> %s", #expr, hipGetErrorString(_e)); \
+  } while (0)
+#define EEG_TRY(expr) do { int _r = (expr); if (_r != 0) return _r; } while (0)
+#define LAUNCH_CHECK() HIP_TRY(hipGetLastError())
+
+// ---------------------------------------------------------------- context
+struct eegldm_ctx {
+  int device;
+  hipStream_t stream;
+  bool owns_stream;
+  // scratch for small reductions / flags (device)
+  void* scratch;
+  size_t scratch_bytes;
+  int num_cu;
+};
+
+static inline size_t dtype_size(int dt) { return dt == EEGLDM_F32 ? 4 : 2; }
+
+// ---------------------------------------------------------------- device helpers
+__device__ __forceinline__ float bf16_to_f32(bf16_t v) { return __uint_as_float(((unsigned)v) << 16); }
+__device__ __forceinline__ bf16_t f32_to_bf16(float f) {  // round-to-nearest-even, NaN preserved
+  unsigned u = __float_as_uint(f);
+  if ((u & 0x7fffffffu) > 0x7f800000u) return (bf16_t)((u >> 16) | 0x40);
+  u += 0x7fffu + ((u >> 16) & 1u);
+  return (bf16_t)(u >> 16);
+}
+template <typename T> __device__ __forceinline__ float ld_f32(const T* p);
+template <> __device__ __forceinline__ float ld_f32<float>(const float* p) { return *p; }
+template <> __device__ __forceinline__ float ld_f32<bf16_t>(const bf16_t* p) { return bf16_to_f32(*p); }
+template <typename T> __device__ __forceinline__ void st_f32(T* p, float v);
+template <> __device__ __forceinline__ void st_f32<float>(float* p, float v) { *p = v; }
+template <> __device__ __forceinline__ void st_f32<bf16_t>(bf16_t* p, float v) { *p = f32_to_bf16(v); }
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ double wave_sum_d(double v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ float silu_f(float z) { return z / (1.0f + __expf(-z)); }
+__device__ __forceinline__ float silu_grad_f(float z) {
+  float s = 1.0f / (1.0f + __expf(-z));
+  return s * (1.0f + z * (1.0f - s));
+}
+
+// ---------------------------------------------------------------- internal GEMM interface (gemm.hip)
+enum { GA_PLAIN = 0, GA_CONV = 1, GA_TR = 2 };
+enum { GB_NT = 0, GB_TR = 1 };
+
+struct GemmArgs {
+  int dtype;             // EEGLDM_F32 / EEGLDM_BF16 (storage type of A, B, resid, and C unless out_f32)
+  int amode, bmode;
+  const void* A; long lda; long sAb;            // batch stride (elements)
+  const void* B; long ldb; long sBb; long sBt;  // batch / tap strides (elements)
+  void* C; long ldc; long sCb; long sCt;        // sCt: per-tap output stride (wgrad-by-tap)
+  int M, N, K;           // per batch (and per tap); K = reduction length
+  int batch;
+  int taps;              // taps folded in the K loop (conv fwd/dgrad): 1 or 3
+  int ztaps;             // taps spread over grid.z (wgrad): 1 or 3
+  int tap_flip;          // use W[taps-1-t] for tap t (dgrad)
+  // conv geometry (GA_CONV rows, or GB_TR/GA_TR row map when conv_map)
+  int Lout, Lin, stride, pad_l;
+  int ups;               // GA_CONV: A is a virtual zero-upsampled signal (transposed conv): 1 or 2
+  int Lsrc;              // rows per sample of the real source when ups > 1
+  int conv_map;          // wgrad: map K index (output row) -> input row for B
+  int splitk;            // >1: partial K ranges atomically added into f32 C
+  float alpha;
+  const float* bias;     // [N] or null
+  const float* rowvec; long ld_rowvec; int rows_per_vec;  // per-sample vector add (time embedding)
+  const void* resid; long ldr;                            // residual add (dtype)
+  int out_f32;           // C is float regardless of dtype
+  int atomic_out;        // C += result via float atomics (requires out_f32)
+};
+int gemm_launch(eegldm_ctx* ctx, const GemmArgs& a);

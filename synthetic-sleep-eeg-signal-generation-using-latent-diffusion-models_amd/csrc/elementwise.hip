@@ -1,0 +1,363 @@
+// HBM-bound elementwise / small-reduction kernels of the hot path: layout conversion,
+// weight packing, timestep embedding, SiLU, per-sample column sums, softmax, scheduler
+// arithmetic, MSE, Adam, Philox RNG.  One pass over the data each, 16-byte accesses where
+// the layout allows.  Reference call sites are cited at each entry point.
+#include "common.h"
+
+namespace {
+constexpr int NT = 256;
+
+inline int grid1d(long n, eegldm_ctx* ctx, int per_thread = 1) {
+  long blocks = (n + (long)NT * per_thread - 1) / ((long)NT * per_thread);
+  long cap = (long)ctx->num_cu * 16;
+  if (blocks < 1) blocks = 1;
+  return (int)(blocks < cap ? blocks : cap);
+}
+#define GRID_STRIDE(i, n) for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < (n); i += (long)gridDim.x * blockDim.x)
+
+// ------------------------------------------------------------------ layout
+// (B,C,L) fp32 -> rows (b,l) x C in T.  One block handles a 64(l) x 64(c) tile via LDS so both
+// sides are coalesced; for tiny C (1..4) the tile degenerates gracefully.
+template <typename T>
+__global__ __launch_bounds__(NT) void ncl_to_nlc_kernel(const float* __restrict__ src, T* __restrict__ dst, long ld, int C, int L) {
+  __shared__ float tile[64][65];
+  const int b = blockIdx.z, l0 = blockIdx.x * 64, c0 = blockIdx.y * 64;
+  for (int i = threadIdx.x; i < 64 * 64; i += NT) {
+    const int cc = i / 64, ll = i % 64;
+    if (c0 + cc < C && l0 + ll < L) tile[cc][ll] = src[((long)b * C + c0 + cc) * L + l0 + ll];
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < 64 * 64; i += NT) {
+    const int ll = i / 64, cc = i % 64;
+    if (c0 + cc < C && l0 + ll < L) st_f32(dst + ((long)b * L + l0 + ll) * ld + c0 + cc, tile[cc][ll]);
+  }
+}
+template <typename T>
+__global__ __launch_bounds__(NT) void nlc_to_ncl_kernel(const T* __restrict__ src, long ld, float* __restrict__ dst, int C, int L) {
+  __shared__ float tile[64][65];
+  const int b = blockIdx.z, l0 = blockIdx.x * 64, c0 = blockIdx.y * 64;
+  for (int i = threadIdx.x; i < 64 * 64; i += NT) {
+    const int ll = i / 64, cc = i % 64;
+    if (c0 + cc < C && l0 + ll < L) tile[cc][ll] = ld_f32(src + ((long)b * L + l0 + ll) * ld + c0 + cc);
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < 64 * 64; i += NT) {
+    const int cc = i / 64, ll = i % 64;
+    if (c0 + cc < C && l0 + ll < L) dst[((long)b * C + c0 + cc) * L + l0 + ll] = tile[cc][ll];
+  }
+}
+
+__global__ void pack_w_kernel(const float* __restrict__ w, float* __restrict__ p, int Cout, int Cin, int K, int unpack) {
+  const long n = (long)Cout * Cin * K;
+  GRID_STRIDE(i, n) {  // i indexes the packed layout [K][Cout][Cin]
+    const int ci = (int)(i % Cin); const long r = i / Cin; const int co = (int)(r % Cout); const int k = (int)(r / Cout);
+    const long ref = ((long)co * Cin + ci) * K + k;
+    if (unpack) p[ref] = w[i]; else p[i] = w[ref];
+  }
+}
+template <typename T> __global__ void cast_kernel(const float* __restrict__ s, T* __restrict__ d, long n) {
+  GRID_STRIDE(i, n) st_f32(d + i, s[i]);
+}
+__global__ void fill_kernel(float* p, long n, float v) { GRID_STRIDE(i, n) p[i] = v; }
+
+// ------------------------------------------------------------------ timestep embedding (unet.py:12-36)
+template <typename T>
+__global__ void temb_kernel(const int64_t* __restrict__ t, T* __restrict__ out, int B, int dim) {
+  const int half = dim / 2;
+  GRID_STRIDE(i, (long)B * dim) {
+    const int b = (int)(i / dim), j = (int)(i % dim);
+    float v = 0.f;
+    if (j < 2 * half) {
+      const int f = j < half ? j : j - half;
+      const float freq = expf(-logf(10000.0f) * (float)f / (float)half);
+      const float a = (float)t[b] * freq;
+      v = j < half ? cosf(a) : sinf(a);
+    }
+    st_f32(out + i, v);
+  }
+}
+// y = silu(x) ; x fp32 [n] -> T
+template <typename T> __global__ void silu_kernel(const float* __restrict__ x, T* __restrict__ y, long n) {
+  GRID_STRIDE(i, n) st_f32(y + i, silu_f(x[i]));
+}
+// dx = dy * silu'(x): dy fp32, x fp32 -> T
+template <typename T> __global__ void silu_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ x, T* __restrict__ dx, long n) {
+  GRID_STRIDE(i, n) st_f32(dx + i, dy[i] * silu_grad_f(x[i]));
+}
+
+// ------------------------------------------------------------------ column sums
+// per-sample: out[b][c] (=|+=) sum_l X[b][l][c]; grid (ceil(C/64), LSPLIT, B)
+template <typename T, typename TO>
+__global__ __launch_bounds__(NT) void colsum_kernel(const T* __restrict__ x, long ldx, TO* __restrict__ out, long ldo,
+                                                    float* __restrict__ total, int L, int C, int rows_per_block) {
+  __shared__ float red[4][64];
+  const int c = blockIdx.x * 64 + (threadIdx.x & 63), ry = threadIdx.x >> 6;
+  const int b = blockIdx.z, l0 = blockIdx.y * rows_per_block, l1 = min(L, l0 + rows_per_block);
+  float s = 0.f;
+  if (c < C) for (int l = l0 + ry; l < l1; l += 4) s += ld_f32(x + ((long)b * L + l) * ldx + c);
+  red[ry][threadIdx.x & 63] = s;
+  __syncthreads();
+  if (ry == 0 && c < C) {
+    s = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
+    if (out) st_f32(out + (long)b * ldo + c, s);   // written, not accumulated: single L split only
+    if (total) atomicAdd(total + c, s);
+  }
+}
+
+// ------------------------------------------------------------------ softmax over rows (unet.py:123)
+// one wave per row; S fp32 [rows][n] -> P (T) [rows][n]
+template <typename T>
+__global__ __launch_bounds__(NT) void softmax_kernel(const float* __restrict__ S, T* __restrict__ P, long rows, int n) {
+  const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  if (row >= rows) return;
+  const float* s = S + row * n;
+  float mx = -INFINITY;
+  for (int i = lane; i < n; i += 64) mx = fmaxf(mx, s[i]);
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
+  float sum = 0.f;
+  for (int i = lane; i < n; i += 64) sum += expf(s[i] - mx);
+  sum = wave_sum(sum);
+  const float inv = 1.0f / sum;
+  for (int i = lane; i < n; i += 64) st_f32(P + row * n + i, expf(s[i] - mx) * inv);
+}
+// dS = alpha * P o (dP - sum(dP o P)) ; dP fp32, P (T) -> dS (T)
+template <typename T>
+__global__ __launch_bounds__(NT) void softmax_bwd_kernel(const float* __restrict__ dP, const T* __restrict__ P, T* __restrict__ dS,
+                                                         long rows, int n, float alpha) {
+  const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  if (row >= rows) return;
+  float dot = 0.f;
+  for (int i = lane; i < n; i += 64) dot += dP[row * n + i] * ld_f32(P + row * n + i);
+  dot = wave_sum(dot);
+  for (int i = lane; i < n; i += 64) {
+    const float p = ld_f32(P + row * n + i);
+    st_f32(dS + row * n + i, alpha * p * (dP[row * n + i] - dot));
+  }
+}
+
+// dst[r][c] += src[r][c] (both T, own leading dims)
+template <typename T>
+__global__ void add_rows_kernel(T* __restrict__ dst, long ldd, const T* __restrict__ src, long lds, long rows, int C) {
+  GRID_STRIDE(i, rows * C) {
+    const long r = i / C; const int c = (int)(i - r * C);
+    T* d = dst + r * ldd + c;
+    st_f32(d, ld_f32(d) + ld_f32(src + r * lds + c));
+  }
+}
+template <typename T>
+__global__ void copy_rows_kernel(T* __restrict__ dst, long ldd, const T* __restrict__ src, long lds, long rows, int C) {
+  GRID_STRIDE(i, rows * C) {
+    const long r = i / C; const int c = (int)(i - r * C);
+    dst[r * ldd + c] = src[r * lds + c];
+  }
+}
+
+// ------------------------------------------------------------------ schedulers (training.py:429-436, sample_trials.py:163)
+__global__ void add_noise_kernel(const float* __restrict__ x, const float* __restrict__ nz, const int64_t* __restrict__ t,
+                                 const float* __restrict__ acp, float* __restrict__ out, long n, long per, int velocity) {
+  GRID_STRIDE(i, n) {
+    const float a = acp[t[i / per]];
+    const float sa = sqrtf(a), sb = sqrtf(1.0f - a);
+    out[i] = velocity ? (sa * nz[i] - sb * x[i]) : (sa * x[i] + sb * nz[i]);
+  }
+}
+__global__ void ddim_step_kernel(const float* __restrict__ mo, const float* __restrict__ x, float a_t, float a_prev, int pred,
+                                 int clip, float* __restrict__ prev, float* __restrict__ x0o, long n) {
+  const float sa = sqrtf(a_t), sb = sqrtf(1.0f - a_t), sap = sqrtf(a_prev), sbp = sqrtf(1.0f - a_prev);
+  GRID_STRIDE(i, n) {
+    const float o = mo[i], s = x[i];
+    float x0, e;
+    if (pred == EEGLDM_PRED_EPSILON) { x0 = (s - sb * o) / sa; e = o; }
+    else if (pred == EEGLDM_PRED_V) { x0 = sa * s - sb * o; e = sa * o + sb * s; }
+    else { x0 = o; e = (s - sa * x0) / sb; }
+    if (clip) x0 = fminf(1.0f, fmaxf(-1.0f, x0));
+    prev[i] = sap * x0 + sbp * e;
+    if (x0o) x0o[i] = x0;
+  }
+}
+
+// ------------------------------------------------------------------ MSE (training.py:437)
+__global__ __launch_bounds__(NT) void mse_kernel(const float* __restrict__ p, const float* __restrict__ t, float* __restrict__ loss,
+                                                 float* __restrict__ dp, long n, float inv_n, float gscale) {
+  float s = 0.f;
+  GRID_STRIDE(i, n) {
+    const float d = p[i] - t[i];
+    s += d * d;
+    if (dp) dp[i] = 2.0f * d * inv_n * gscale;
+  }
+  s = wave_sum(s);
+  __shared__ float red[4];
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) atomicAdd(loss, (red[0] + red[1] + red[2] + red[3]) * inv_n);
+}
+
+// ------------------------------------------------------------------ Adam (torch.optim.Adam defaults, train_ldm.py:208)
+__global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
+                            long n, float lr, float b1, float b2, float eps, float bc1, float bc2_sqrt, float ginv) {
+  GRID_STRIDE(i, n) {
+    const float gi = g[i] * ginv;
+    const float mi = b1 * m[i] + (1.0f - b1) * gi;
+    const float vi = b2 * v[i] + (1.0f - b2) * gi * gi;
+    m[i] = mi; v[i] = vi;
+    const float denom = sqrtf(vi) / bc2_sqrt + eps;
+    p[i] -= (lr / bc1) * (mi / denom);
+  }
+}
+
+// ------------------------------------------------------------------ Philox4x32-10 (perf-path RNG; parity runs pass noise in)
+__device__ __forceinline__ void philox_round(unsigned& c0, unsigned& c1, unsigned& c2, unsigned& c3, unsigned k0, unsigned k1) {
+  const unsigned long long p0 = (unsigned long long)0xD2511F53u * c0, p1 = (unsigned long long)0xCD9E8D57u * c2;
+  const unsigned n0 = (unsigned)(p1 >> 32) ^ c1 ^ k0, n1 = (unsigned)p1, n2 = (unsigned)(p0 >> 32) ^ c3 ^ k1, n3 = (unsigned)p0;
+  c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+}
+__device__ __forceinline__ void philox(unsigned long long seed, unsigned long long ctr, unsigned r[4]) {
+  unsigned c0 = (unsigned)ctr, c1 = (unsigned)(ctr >> 32), c2 = 0, c3 = 0;
+  unsigned k0 = (unsigned)seed, k1 = (unsigned)(seed >> 32);
+#pragma unroll
+  for (int i = 0; i < 10; i++) { philox_round(c0, c1, c2, c3, k0, k1); k0 += 0x9E3779B9u; k1 += 0xBB67AE85u; }
+  r[0] = c0; r[1] = c1; r[2] = c2; r[3] = c3;
+}
+__global__ void randn_kernel(float* __restrict__ out, long n, unsigned long long seed, unsigned long long offset) {
+  const long nq = (n + 3) / 4;
+  GRID_STRIDE(i, nq) {
+    unsigned r[4]; philox(seed, offset + (unsigned long long)i, r);
+    float z[4];
+#pragma unroll
+    for (int h = 0; h < 2; h++) {
+      const float u1 = ((float)r[2 * h] + 1.0f) * 2.3283064365386963e-10f;   // (0,1]
+      const float u2 = (float)r[2 * h + 1] * 2.3283064365386963e-10f;
+      const float rad = sqrtf(-2.0f * logf(u1));
+      z[2 * h] = rad * cosf(6.283185307179586f * u2); z[2 * h + 1] = rad * sinf(6.283185307179586f * u2);
+    }
+#pragma unroll
+    for (int k = 0; k < 4; k++) if (i * 4 + k < n) out[i * 4 + k] = z[k];
+  }
+}
+__global__ void randint_kernel(int64_t* __restrict__ out, long n, int64_t high, unsigned long long seed, unsigned long long offset) {
+  GRID_STRIDE(i, n) {
+    unsigned r[4]; philox(seed, offset + (unsigned long long)i, r);
+    const unsigned long long v = ((unsigned long long)r[0] << 32) | r[1];
+    out[i] = (int64_t)(v % (unsigned long long)high);
+  }
+}
+}  // namespace
+
+// ================================================================== internal launchers (used by the executors)
+#define DISPATCH_T(dtype, ...)                                            \
+  do {                                                                    \
+    if ((dtype) == EEGLDM_F32) { typedef float T; __VA_ARGS__; }          \
+    else if ((dtype) == EEGLDM_BF16) { typedef bf16_t T; __VA_ARGS__; }   \
+    else EEG_FAIL(EEGLDM_ERR_UNSUPPORTED, "dtype %d", (int)(dtype));      \
+  } while (0)
+
+int ew_temb(eegldm_ctx* ctx, const int64_t* t, void* out, int B, int dim, int dtype) {
+  DISPATCH_T(dtype, hipLaunchKernelGGL((temb_kernel<T>), dim3(grid1d((long)B * dim, ctx)), dim3(NT), 0, ctx->stream, t, (T*)out, B, dim));
+  LAUNCH_CHECK(); return 0;
+}
+int ew_silu(eegldm_ctx* ctx, const float* x, void* y, long n, int dtype) {
+  DISPATCH_T(dtype, hipLaunchKernelGGL((silu_kernel<T>), dim3(grid1d(n, ctx)), dim3(NT), 0, ctx->stream, x, (T*)y, n));
+  LAUNCH_CHECK(); return 0;
+}
+int ew_silu_bwd(eegldm_ctx* ctx, const float* dy, const float* x, void* dx, long n, int dtype) {
+  DISPATCH_T(dtype, hipLaunchKernelGGL((silu_bwd_kernel<T>), dim3(grid1d(n, ctx)), dim3(NT), 0, ctx->stream, dy, x, (T*)dx, n));
+  LAUNCH_CHECK(); return 0;
+}
+// out_ps: per-sample sums [B][ldo] in dtype (written; single L split) or NULL; total: fp32 [C] accumulated (+=) or NULL
+int ew_colsum(eegldm_ctx* ctx, const void* x, long ldx, void* out_ps, long ldo, float* total, int B, int L, int C, int dtype) {
+  int lsplit = 1, rpb = L;
+  if (!out_ps) {  // free to split L when only the fp32 atomic total is wanted
+    int want = (ctx->num_cu * 4) / (B * ((C + 63) / 64)) ; if (want < 1) want = 1;
+    int maxs = (L + 31) / 32; lsplit = want > maxs ? maxs : want; rpb = (L + lsplit - 1) / lsplit; lsplit = (L + rpb - 1) / rpb;
+  }
+  dim3 grid((C + 63) / 64, lsplit, B);
+  DISPATCH_T(dtype, hipLaunchKernelGGL((colsum_kernel<T, T>), grid, dim3(NT), 0, ctx->stream, (const T*)x, ldx, (T*)out_ps, ldo, total, L, C, rpb));
+  LAUNCH_CHECK(); return 0;
+}
+int ew_softmax(eegldm_ctx* ctx, const float* S, void* P, long rows, int n, int dtype) {
+  DISPATCH_T(dtype, hipLaunchKernelGGL((softmax_kernel<T>), dim3((unsigned)((rows + 3) / 4)), dim3(NT), 0, ctx->stream, S, (T*)P, rows, n));
+  LAUNCH_CHECK(); return 0;
+}
+int ew_softmax_bwd(eegldm_ctx* ctx, const float* dP, const void* P, void* dS, long rows, int n, float alpha, int dtype) {
+  DISPATCH_T(dtype, hipLaunchKernelGGL((softmax_bwd_kernel<T>), dim3((unsigned)((rows + 3) / 4)), dim3(NT), 0, ctx->stream, dP, (const T*)P, (T*)dS, rows, n, alpha));
+  LAUNCH_CHECK(); return 0;
+}
+int ew_add_rows(eegldm_ctx* ctx, void* dst, long ldd, const void* src, long lds, long rows, int C, int dtype) {
+  DISPATCH_T(dtype, hipLaunchKernelGGL((add_rows_kernel<T>), dim3(grid1d(rows * C, ctx)), dim3(NT), 0, ctx->stream, (T*)dst, ldd, (const T*)src, lds, rows, C));
+  LAUNCH_CHECK(); return 0;
+}
+int ew_copy_rows(eegldm_ctx* ctx, void* dst, long ldd, const void* src, long lds, long rows, int C, int dtype) {
+  DISPATCH_T(dtype, hipLaunchKernelGGL((copy_rows_kernel<T>), dim3(grid1d(rows * C, ctx)), dim3(NT), 0, ctx->stream, (T*)dst, ldd, (const T*)src, lds, rows, C));
+  LAUNCH_CHECK(); return 0;
+}
+
+// ================================================================== C ABI
+extern "C" int eegldm_ncl_to_nlc(eegldm_ctx* ctx, const float* src, void* dst, long ld, int B, int C, int L, int dtype) {
+  EEG_CHECK(B > 0 && C > 0 && L > 0 && ld >= C, "bad shape");
+  dim3 grid((L + 63) / 64, (C + 63) / 64, B);
+  DISPATCH_T(dtype, hipLaunchKernelGGL((ncl_to_nlc_kernel<T>), grid, dim3(NT), 0, ctx->stream, src, (T*)dst, ld, C, L));
+  LAUNCH_CHECK(); return 0;
+}
+extern "C" int eegldm_nlc_to_ncl(eegldm_ctx* ctx, const void* src, long ld, float* dst, int B, int C, int L, int dtype) {
+  EEG_CHECK(B > 0 && C > 0 && L > 0 && ld >= C, "bad shape");
+  dim3 grid((L + 63) / 64, (C + 63) / 64, B);
+  DISPATCH_T(dtype, hipLaunchKernelGGL((nlc_to_ncl_kernel<T>), grid, dim3(NT), 0, ctx->stream, (const T*)src, ld, dst, C, L));
+  LAUNCH_CHECK(); return 0;
+}
+extern "C" int eegldm_pack_conv_weight(eegldm_ctx* ctx, const float* w, float* p, int Cout, int Cin, int K) {
+  hipLaunchKernelGGL(pack_w_kernel, dim3(grid1d((long)Cout * Cin * K, ctx)), dim3(NT), 0, ctx->stream, w, p, Cout, Cin, K, 0);
+  LAUNCH_CHECK(); return 0;
+}
+extern "C" int eegldm_unpack_conv_weight(eegldm_ctx* ctx, const float* p, float* w, int Cout, int Cin, int K) {
+  hipLaunchKernelGGL(pack_w_kernel, dim3(grid1d((long)Cout * Cin * K, ctx)), dim3(NT), 0, ctx->stream, p, w, Cout, Cin, K, 1);
+  LAUNCH_CHECK(); return 0;
+}
+extern "C" int eegldm_cast(eegldm_ctx* ctx, const float* s, void* d, long n, int dtype) {
+  if (n <= 0) return 0;
+  DISPATCH_T(dtype, hipLaunchKernelGGL((cast_kernel<T>), dim3(grid1d(n, ctx)), dim3(NT), 0, ctx->stream, s, (T*)d, n));
+  LAUNCH_CHECK(); return 0;
+}
+extern "C" int eegldm_fill(eegldm_ctx* ctx, float* p, long n, float v) {
+  if (n <= 0) return 0;
+  if (v == 0.0f) { HIP_TRY(hipMemsetAsync(p, 0, n * sizeof(float), ctx->stream)); return 0; }
+  hipLaunchKernelGGL(fill_kernel, dim3(grid1d(n, ctx)), dim3(NT), 0, ctx->stream, p, n, v);
+  LAUNCH_CHECK(); return 0;
+}
+extern "C" int eegldm_add_noise(eegldm_ctx* ctx, const float* x, const float* nz, const int64_t* t, const float* acp, float* out, int B, long per) {
+  hipLaunchKernelGGL(add_noise_kernel, dim3(grid1d((long)B * per, ctx)), dim3(NT), 0, ctx->stream, x, nz, t, acp, out, (long)B * per, per, 0);
+  LAUNCH_CHECK(); return 0;
+}
+extern "C" int eegldm_get_velocity(eegldm_ctx* ctx, const float* x, const float* nz, const int64_t* t, const float* acp, float* out, int B, long per) {
+  hipLaunchKernelGGL(add_noise_kernel, dim3(grid1d((long)B * per, ctx)), dim3(NT), 0, ctx->stream, x, nz, t, acp, out, (long)B * per, per, 1);
+  LAUNCH_CHECK(); return 0;
+}
+extern "C" int eegldm_ddim_step(eegldm_ctx* ctx, const float* mo, const float* x, float a_t, float a_prev, int pred, int clip,
+                                float* prev, float* x0, long n) {
+  EEG_CHECK(pred >= 0 && pred <= 2, "prediction type %d", pred);
+  hipLaunchKernelGGL(ddim_step_kernel, dim3(grid1d(n, ctx)), dim3(NT), 0, ctx->stream, mo, x, a_t, a_prev, pred, clip, prev, x0, n);
+  LAUNCH_CHECK(); return 0;
+}
+extern "C" int eegldm_mse_loss(eegldm_ctx* ctx, const float* p, const float* t, float* loss, float* dp, long n, float gscale) {
+  HIP_TRY(hipMemsetAsync(loss, 0, sizeof(float), ctx->stream));
+  hipLaunchKernelGGL(mse_kernel, dim3(grid1d(n, ctx, 4)), dim3(NT), 0, ctx->stream, p, t, loss, dp, n, 1.0f / (float)n, gscale);
+  LAUNCH_CHECK(); return 0;
+}
+extern "C" int eegldm_adam_step(eegldm_ctx* ctx, float* p, const float* g, float* m, float* v, long n, float lr, float b1, float b2,
+                                float eps, int step, float ginv) {
+  EEG_CHECK(step >= 1, "step starts at 1");
+  const float bc1 = 1.0f - powf(b1, (float)step), bc2s = sqrtf(1.0f - powf(b2, (float)step));
+  hipLaunchKernelGGL(adam_kernel, dim3(grid1d(n, ctx, 2)), dim3(NT), 0, ctx->stream, p, g, m, v, n, lr, b1, b2, eps, bc1, bc2s, ginv);
+  LAUNCH_CHECK(); return 0;
+}
+extern "C" int eegldm_randn(eegldm_ctx* ctx, float* out, long n, uint64_t seed, uint64_t offset) {
+  hipLaunchKernelGGL(randn_kernel, dim3(grid1d((n + 3) / 4, ctx)), dim3(NT), 0, ctx->stream, out, n, seed, offset);
+  LAUNCH_CHECK(); return 0;
+}
+extern "C" int eegldm_randint(eegldm_ctx* ctx, int64_t* out, long n, int64_t high, uint64_t seed, uint64_t offset) {
+  EEG_CHECK(high > 0, "high must be positive");
+  hipLaunchKernelGGL(randint_kernel, dim3(grid1d(n, ctx)), dim3(NT), 0, ctx->stream, out, n, high, seed, offset);
+  LAUNCH_CHECK(); return 0;
+}

@@ -1,0 +1,40 @@
+// Internal (non-ABI) launchers shared between translation units.
+#pragma once
+#include "common.h"
+
+// elementwise.hip
+int ew_temb(eegldm_ctx*, const int64_t* t, void* out, int B, int dim, int dtype);
+int ew_silu(eegldm_ctx*, const float* x, void* y, long n, int dtype);
+int ew_silu_bwd(eegldm_ctx*, const float* dy, const float* x, void* dx, long n, int dtype);
+int ew_colsum(eegldm_ctx*, const void* x, long ldx, void* out_ps, long ldo, float* total, int B, int L, int C, int dtype);
+int ew_softmax(eegldm_ctx*, const float* S, void* P, long rows, int n, int dtype);
+int ew_softmax_bwd(eegldm_ctx*, const float* dP, const void* P, void* dS, long rows, int n, float alpha, int dtype);
+int ew_add_rows(eegldm_ctx*, void* dst, long ldd, const void* src, long lds, long rows, int C, int dtype);
+int ew_copy_rows(eegldm_ctx*, void* dst, long ldd, const void* src, long lds, long rows, int C, int dtype);
+
+// direct_conv.hip
+bool conv_is_thin(int Cin, int Cout, int dtype);
+int dconv_run(eegldm_ctx*, int dtype, bool dgrad, const void* in, long ldin, const void* w, const float* bias,
+              const void* resid, long ldr, void* out, long ldout, int B, int Lin, int Lout, int Cin, int Cout, int K,
+              int stride, int pad_l);
+int dconv_wgrad(eegldm_ctx*, int dtype, const void* x, long ldx, const void* dy, long lddy, float* dw, int B, int Lin,
+                int Lout, int Cin, int Cout, int K, int stride, int pad_l);
+
+// ops.hip
+int op_conv_fwd(eegldm_ctx*, int dtype, const void* x, long ldx, const void* w, const float* bias, void* y, long ldy,
+                int B, int Lin, int Cin, int Cout, int K, int stride, int pad_l, int pad_r,
+                const float* rowvec, long ld_rowvec, const void* resid, long ldr);
+int op_conv_dgrad(eegldm_ctx*, int dtype, const void* dy, long lddy, const void* w, void* dx, long lddx,
+                  int B, int Lin, int Cin, int Cout, int K, int stride, int pad_l, int pad_r, const void* resid, long ldr);
+int op_conv_wgrad(eegldm_ctx*, int dtype, const void* x, long ldx, const void* dy, long lddy, float* dw, float* dbias,
+                  int B, int Lin, int Cin, int Cout, int K, int stride, int pad_l, int pad_r);
+int op_linear(eegldm_ctx*, int dtype, const void* x, long ldx, const void* w, long ldw, const float* bias, void* y, long ldy,
+              int M, int N, int K, int out_f32);
+int op_linear_dgrad(eegldm_ctx*, int dtype, const void* dy, long lddy, const void* w, long ldw, void* dx, long lddx,
+                    int M, int N, int K, int out_f32);
+int op_linear_wgrad(eegldm_ctx*, int dtype, const void* x, long ldx, const void* dy, long lddy, float* dw, long lddw,
+                    int M, int N, int K);
+int op_attention_fwd(eegldm_ctx*, int dtype, const void* qkv, long ldq, void* out, long ldo, void* probs, float* logits,
+                     int B, int T, int C);
+int op_attention_bwd(eegldm_ctx*, int dtype, const void* qkv, long ldq, const void* probs, const void* dout, long lddo,
+                     void* dqkv, long lddq, float* dprobs, void* dlogits, int B, int T, int C);

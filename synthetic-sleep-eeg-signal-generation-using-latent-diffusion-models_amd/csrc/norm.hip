@@ -1,0 +1,343 @@
+// GroupNorm (+SiLU, + fused AvgPool2 / nearest-x2 resampling) forward and backward on the
+// NLC layout.  Reference: nn.GroupNorm(32, C, eps=1e-6) at /root/reference/src/models/unet.py:71-74
+// used by ResBlock (:260-262, :286-288) and AttentionBlock (:157); MONAI AutoencoderKL uses
+// G = norm_num_groups = 1 (config_aekl_eeg.yaml:25).  Up/down ResBlocks resample AFTER the
+// activation, on both h and the raw x (unet.py:308-313).
+//
+// HBM-bound.  Statistics are reduced per (sample, group) with fp32 thread partials (a few
+// dozen elements each), LDS float atomics per block, then fp64 global atomics -- biased
+// variance from fp64 sums, so E[x^2]-mean^2 cancellation stays below fp32 rounding.
+#include "common.h"
+
+namespace {
+
+constexpr int NT = 256;
+constexpr int MAXG_LDS = 1024;   // LDS accumulators per block (groups / channels)
+
+template <typename T, int V> struct Vec;
+template <> struct Vec<float, 4> { typedef float4 type; };
+template <> struct Vec<bf16_t, 4> { typedef uint2 type; };
+
+template <typename T> __device__ __forceinline__ void load4(const T* p, float v[4]);
+template <> __device__ __forceinline__ void load4<float>(const float* p, float v[4]) {
+  float4 t = *(const float4*)p; v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
+}
+template <> __device__ __forceinline__ void load4<bf16_t>(const bf16_t* p, float v[4]) {
+  uint2 t = *(const uint2*)p;
+  v[0] = __uint_as_float(t.x << 16); v[1] = __uint_as_float(t.x & 0xffff0000u);
+  v[2] = __uint_as_float(t.y << 16); v[3] = __uint_as_float(t.y & 0xffff0000u);
+}
+template <typename T> __device__ __forceinline__ void store4(T* p, const float v[4]);
+template <> __device__ __forceinline__ void store4<float>(float* p, const float v[4]) {
+  *(float4*)p = make_float4(v[0], v[1], v[2], v[3]);
+}
+template <> __device__ __forceinline__ void store4<bf16_t>(bf16_t* p, const float v[4]) {
+  uint2 t;
+  t.x = (unsigned)f32_to_bf16(v[0]) | ((unsigned)f32_to_bf16(v[1]) << 16);
+  t.y = (unsigned)f32_to_bf16(v[2]) | ((unsigned)f32_to_bf16(v[3]) << 16);
+  *(uint2*)p = t;
+}
+template <typename T, int V> __device__ __forceinline__ void loadv(const T* p, float v[V]) {
+  if constexpr (V == 4) load4<T>(p, v); else v[0] = ld_f32(p);
+}
+template <typename T, int V> __device__ __forceinline__ void storev(T* p, const float v[V]) {
+  if constexpr (V == 4) store4<T>(p, v); else st_f32(p, v[0]);
+}
+
+// thread -> (column-vector, row-lane) decomposition of a block
+struct ColMap { int TX, TY, ncols; };
+__device__ __forceinline__ ColMap colmap(int C, int V) {
+  ColMap m; m.ncols = C / V;
+  if (m.ncols >= NT) { m.TX = NT; m.TY = 1; } else { m.TX = m.ncols; m.TY = NT / m.ncols; }
+  return m;
+}
+
+// ------------------------------------------------------------------ forward statistics
+// grid (LSPLIT, B); sums: double [B][G][2] (pre-zeroed)
+template <typename T, int V>
+__global__ __launch_bounds__(NT) void gn_stats_kernel(const T* __restrict__ x, long ldx, double* __restrict__ sums,
+                                                      int L, int C, int G, int rows_per_block) {
+  __shared__ float acc[2 * MAXG_LDS];
+  const int b = blockIdx.y, tid = threadIdx.x;
+  const int cpg = C / G;
+  for (int i = tid; i < 2 * G; i += NT) acc[i] = 0.f;
+  __syncthreads();
+  const ColMap cm = colmap(C, V);
+  const int l0 = blockIdx.x * rows_per_block, l1 = min(L, l0 + rows_per_block);
+  if (tid < cm.TX * cm.TY) {
+    const int tx = tid % cm.TX, ty = tid / cm.TX;
+    for (int col = tx; col < cm.ncols; col += cm.TX) {
+      const int c = col * V;
+      float s1 = 0.f, s2 = 0.f;
+      for (int l = l0 + ty; l < l1; l += cm.TY) {
+        float v[V];
+        loadv<T, V>(x + ((long)b * L + l) * ldx + c, v);
+#pragma unroll
+        for (int k = 0; k < V; k++) { s1 += v[k]; s2 += v[k] * v[k]; }
+      }
+      const int g = c / cpg;
+      atomicAdd(&acc[2 * g], s1);
+      atomicAdd(&acc[2 * g + 1], s2);
+    }
+  }
+  __syncthreads();
+  for (int i = tid; i < 2 * G; i += NT) atomicAdd(&sums[(long)b * G * 2 + i], (double)acc[i]);
+}
+
+__global__ void gn_finalize_kernel(const double* __restrict__ sums, float* __restrict__ stats, int BG, double n, float eps) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= BG) return;
+  const double mean = sums[2 * i] / n;
+  double var = sums[2 * i + 1] / n - mean * mean;
+  if (var < 0) var = 0;
+  stats[2 * i] = (float)mean;
+  stats[2 * i + 1] = (float)(1.0 / sqrt(var + (double)eps));
+}
+
+// ------------------------------------------------------------------ forward apply
+// iterates over INPUT rows; resample: 0 none, 1 avgpool2 (pairs of input rows -> one
+// output row), 2 nearest x2 (one input row -> two output rows)
+template <typename T, int V>
+__global__ __launch_bounds__(NT) void gn_apply_kernel(const T* __restrict__ x, long ldx, const float* __restrict__ gamma,
+                                                      const float* __restrict__ beta, const float* __restrict__ stats,
+                                                      T* __restrict__ y, long ldy, T* __restrict__ xr, long ldxr,
+                                                      int B, int L, int C, int G, int silu, int resample) {
+  const int ncols = C / V, cpg = C / G;
+  const long rows = (resample == 1) ? (long)B * (L / 2) : (long)B * L;   // work rows
+  const long total = rows * ncols;
+  for (long idx = (long)blockIdx.x * NT + threadIdx.x; idx < total; idx += (long)gridDim.x * NT) {
+    const long wr = idx / ncols; const int c = (int)(idx - wr * ncols) * V;
+    const int Lw = (resample == 1) ? L / 2 : L;
+    const int b = (int)(wr / Lw), lw = (int)(wr - (long)b * Lw);
+    const int g = c / cpg;
+    const float mean = stats[((long)b * G + g) * 2], rstd = stats[((long)b * G + g) * 2 + 1];
+    float ga[V], be[V];
+#pragma unroll
+    for (int k = 0; k < V; k++) { ga[k] = gamma[c + k] * rstd; be[k] = beta[c + k] - mean * ga[k]; }
+    if (resample == 1) {
+      float v0[V], v1[V], o[V], r[V];
+      loadv<T, V>(x + ((long)b * L + 2 * lw) * ldx + c, v0);
+      loadv<T, V>(x + ((long)b * L + 2 * lw + 1) * ldx + c, v1);
+#pragma unroll
+      for (int k = 0; k < V; k++) {
+        float z0 = v0[k] * ga[k] + be[k], z1 = v1[k] * ga[k] + be[k];
+        if (silu) { z0 = silu_f(z0); z1 = silu_f(z1); }
+        o[k] = 0.5f * (z0 + z1); r[k] = 0.5f * (v0[k] + v1[k]);
+      }
+      storev<T, V>(y + wr * ldy + c, o);
+      if (xr) storev<T, V>(xr + wr * ldxr + c, r);
+    } else {
+      float v[V], o[V];
+      loadv<T, V>(x + wr * ldx + c, v);
+#pragma unroll
+      for (int k = 0; k < V; k++) { float z = v[k] * ga[k] + be[k]; o[k] = silu ? silu_f(z) : z; }
+      if (resample == 0) {
+        storev<T, V>(y + wr * ldy + c, o);
+      } else {
+        const long orow = ((long)b * 2 * L + 2 * lw);
+        storev<T, V>(y + orow * ldy + c, o); storev<T, V>(y + (orow + 1) * ldy + c, o);
+        if (xr) { storev<T, V>(xr + orow * ldxr + c, v); storev<T, V>(xr + (orow + 1) * ldxr + c, v); }
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------ backward
+// effective upstream gradient at input row (b,l), channels c..c+V-1
+template <typename T, int V>
+__device__ __forceinline__ void load_dy_eff(const T* dy, long lddy, int b, int l, int L, int c, int resample, float d[V]) {
+  if (resample == 0) {
+    loadv<T, V>(dy + ((long)b * L + l) * lddy + c, d);
+  } else if (resample == 1) {
+    loadv<T, V>(dy + ((long)b * (L / 2) + (l >> 1)) * lddy + c, d);
+#pragma unroll
+    for (int k = 0; k < V; k++) d[k] *= 0.5f;
+  } else {
+    float e[V];
+    loadv<T, V>(dy + ((long)b * 2 * L + 2 * l) * lddy + c, d);
+    loadv<T, V>(dy + ((long)b * 2 * L + 2 * l + 1) * lddy + c, e);
+#pragma unroll
+    for (int k = 0; k < V; k++) d[k] += e[k];
+  }
+}
+
+// grid (LSPLIT, B): group sums S1 = sum dz*gamma, S2 = sum dz*gamma*xhat -> gsums double [B][G][2];
+// dgamma[c] += sum dz*xhat, dbeta[c] += sum dz (fp32 atomics)
+template <typename T, int V>
+__global__ __launch_bounds__(NT) void gn_bwd_reduce_kernel(const T* __restrict__ x, long ldx, const float* __restrict__ gamma,
+                                                           const float* __restrict__ beta, const float* __restrict__ stats,
+                                                           const T* __restrict__ dy, long lddy, double* __restrict__ gsums,
+                                                           float* __restrict__ dgamma, float* __restrict__ dbeta,
+                                                           int L, int C, int G, int silu, int resample, int rows_per_block) {
+  __shared__ float accg[2 * MAXG_LDS];
+  __shared__ float accc[2 * MAXG_LDS];
+  const int b = blockIdx.y, tid = threadIdx.x;
+  const int cpg = C / G;
+  for (int i = tid; i < 2 * G; i += NT) accg[i] = 0.f;
+  for (int i = tid; i < 2 * C; i += NT) accc[i] = 0.f;
+  __syncthreads();
+  const ColMap cm = colmap(C, V);
+  const int l0 = blockIdx.x * rows_per_block, l1 = min(L, l0 + rows_per_block);
+  if (tid < cm.TX * cm.TY) {
+    const int tx = tid % cm.TX, ty = tid / cm.TX;
+    for (int col = tx; col < cm.ncols; col += cm.TX) {
+      const int c = col * V, g = c / cpg;
+      const float mean = stats[((long)b * G + g) * 2], rstd = stats[((long)b * G + g) * 2 + 1];
+      float ga[V], be[V], dg[V], db[V];
+#pragma unroll
+      for (int k = 0; k < V; k++) { ga[k] = gamma[c + k]; be[k] = beta[c + k]; dg[k] = 0.f; db[k] = 0.f; }
+      float s1 = 0.f, s2 = 0.f;
+      for (int l = l0 + ty; l < l1; l += cm.TY) {
+        float v[V], d[V];
+        loadv<T, V>(x + ((long)b * L + l) * ldx + c, v);
+        load_dy_eff<T, V>(dy, lddy, b, l, L, c, resample, d);
+#pragma unroll
+        for (int k = 0; k < V; k++) {
+          const float xh = (v[k] - mean) * rstd;
+          float dz = d[k];
+          if (silu) dz *= silu_grad_f(ga[k] * xh + be[k]);
+          dg[k] += dz * xh; db[k] += dz;
+          s1 += dz * ga[k]; s2 += dz * ga[k] * xh;
+        }
+      }
+      atomicAdd(&accg[2 * g], s1); atomicAdd(&accg[2 * g + 1], s2);
+#pragma unroll
+      for (int k = 0; k < V; k++) { atomicAdd(&accc[c + k], dg[k]); atomicAdd(&accc[C + c + k], db[k]); }
+    }
+  }
+  __syncthreads();
+  for (int i = tid; i < 2 * G; i += NT) atomicAdd(&gsums[(long)b * G * 2 + i], (double)accg[i]);
+  if (dgamma) for (int i = tid; i < C; i += NT) { atomicAdd(&dgamma[i], accc[i]); atomicAdd(&dbeta[i], accc[C + i]); }
+}
+
+// dx = rstd * (dz*gamma - S1/n - xhat*S2/n) [+ resample^T(dxr)]
+template <typename T, int V>
+__global__ __launch_bounds__(NT) void gn_bwd_apply_kernel(const T* __restrict__ x, long ldx, const float* __restrict__ gamma,
+                                                          const float* __restrict__ beta, const float* __restrict__ stats,
+                                                          const T* __restrict__ dy, long lddy, const double* __restrict__ gsums,
+                                                          T* __restrict__ dx, long lddx, const T* __restrict__ dxr, long lddxr,
+                                                          int B, int L, int C, int G, int silu, int resample) {
+  const int ncols = C / V, cpg = C / G;
+  const float inv_n = 1.0f / ((float)cpg * (float)L);
+  const long total = (long)B * L * ncols;
+  for (long idx = (long)blockIdx.x * NT + threadIdx.x; idx < total; idx += (long)gridDim.x * NT) {
+    const long row = idx / ncols; const int c = (int)(idx - row * ncols) * V;
+    const int b = (int)(row / L), l = (int)(row - (long)b * L);
+    const int g = c / cpg;
+    const float mean = stats[((long)b * G + g) * 2], rstd = stats[((long)b * G + g) * 2 + 1];
+    const float m1 = (float)gsums[((long)b * G + g) * 2] * inv_n, m2 = (float)gsums[((long)b * G + g) * 2 + 1] * inv_n;
+    float v[V], d[V], o[V];
+    loadv<T, V>(x + row * ldx + c, v);
+    load_dy_eff<T, V>(dy, lddy, b, l, L, c, resample, d);
+#pragma unroll
+    for (int k = 0; k < V; k++) {
+      const float ga = gamma[c + k], xh = (v[k] - mean) * rstd;
+      float dz = d[k];
+      if (silu) dz *= silu_grad_f(ga * xh + beta[c + k]);
+      o[k] = rstd * (dz * ga - m1 - xh * m2);
+    }
+    if (dxr) {
+      float e[V];
+      load_dy_eff<T, V>(dxr, lddxr, b, l, L, c, resample, e);
+#pragma unroll
+      for (int k = 0; k < V; k++) o[k] += e[k];
+    }
+    storev<T, V>(dx + row * lddx + c, o);
+  }
+}
+
+int grid_for(long total_threads, eegldm_ctx* ctx) {
+  long blocks = (total_threads + NT - 1) / NT;
+  long cap = (long)ctx->num_cu * 16;
+  return (int)(blocks < cap ? (blocks < 1 ? 1 : blocks) : cap);
+}
+
+int pick_lsplit(int B, int L, int C, eegldm_ctx* ctx, int* rows_per_block) {
+  // enough blocks to fill the chip, at least 16 rows per block
+  int want = (ctx->num_cu * 8 + B - 1) / B;
+  int maxsplit = (L + 15) / 16;
+  int ls = want < 1 ? 1 : (want > maxsplit ? maxsplit : want);
+  int rpb = (L + ls - 1) / ls;
+  *rows_per_block = rpb;
+  return (L + rpb - 1) / rpb;
+}
+
+template <typename T, int V>
+int gn_fwd_t(eegldm_ctx* ctx, const void* x, long ldx, const float* gamma, const float* beta, void* y, long ldy,
+             float* stats, int B, int L, int C, int G, float eps, int silu, int resample, void* xr, long ldxr) {
+  double* sums = (double*)ctx->scratch;
+  HIP_TRY(hipMemsetAsync(sums, 0, sizeof(double) * 2 * B * G, ctx->stream));
+  int rpb; int ls = pick_lsplit(B, L, C, ctx, &rpb);
+  hipLaunchKernelGGL((gn_stats_kernel<T, V>), dim3(ls, B), dim3(NT), 0, ctx->stream, (const T*)x, ldx, sums, L, C, G, rpb);
+  LAUNCH_CHECK();
+  hipLaunchKernelGGL(gn_finalize_kernel, dim3((B * G + 255) / 256), dim3(256), 0, ctx->stream, sums, stats, B * G,
+                     (double)(C / G) * (double)L, eps);
+  LAUNCH_CHECK();
+  long total = (long)B * (resample == 1 ? L / 2 : L) * (C / V);
+  hipLaunchKernelGGL((gn_apply_kernel<T, V>), dim3(grid_for(total, ctx)), dim3(NT), 0, ctx->stream, (const T*)x, ldx, gamma,
+                     beta, stats, (T*)y, ldy, (T*)xr, ldxr, B, L, C, G, silu, resample);
+  LAUNCH_CHECK();
+  return 0;
+}
+
+template <typename T, int V>
+int gn_bwd_t(eegldm_ctx* ctx, const void* x, long ldx, const float* gamma, const float* beta, const float* stats,
+             const void* dy, long lddy, void* dx, long lddx, float* dgamma, float* dbeta, int B, int L, int C, int G,
+             int silu, int resample, const void* dxr, long lddxr) {
+  double* gsums = (double*)ctx->scratch;
+  HIP_TRY(hipMemsetAsync(gsums, 0, sizeof(double) * 2 * B * G, ctx->stream));
+  int rpb; int ls = pick_lsplit(B, L, C, ctx, &rpb);
+  hipLaunchKernelGGL((gn_bwd_reduce_kernel<T, V>), dim3(ls, B), dim3(NT), 0, ctx->stream, (const T*)x, ldx, gamma, beta, stats,
+                     (const T*)dy, lddy, gsums, dgamma, dbeta, L, C, G, silu, resample, rpb);
+  LAUNCH_CHECK();
+  long total = (long)B * L * (C / V);
+  hipLaunchKernelGGL((gn_bwd_apply_kernel<T, V>), dim3(grid_for(total, ctx)), dim3(NT), 0, ctx->stream, (const T*)x, ldx, gamma,
+                     beta, stats, (const T*)dy, lddy, gsums, (T*)dx, lddx, (const T*)dxr, lddxr, B, L, C, G, silu, resample);
+  LAUNCH_CHECK();
+  return 0;
+}
+
+int gn_check(eegldm_ctx* ctx, int B, int L, int C, int G, int resample, long ldx) {
+  EEG_CHECK(B > 0 && L > 0 && C > 0 && G > 0 && C % G == 0, "bad shape B=%d L=%d C=%d G=%d", B, L, C, G);
+  EEG_CHECK(G <= MAXG_LDS && C <= MAXG_LDS, "C, G must be <= %d", MAXG_LDS);
+  EEG_CHECK(resample >= 0 && resample <= 2, "resample must be 0/1/2");
+  EEG_CHECK(resample != 1 || L % 2 == 0, "avgpool needs even L");
+  EEG_CHECK((size_t)B * G * 2 * sizeof(double) <= ctx->scratch_bytes, "scratch too small for B*G=%d", B * G);
+  return 0;
+}
+bool vec4_ok(int C, int G, long a, long b, long c, long d) {
+  return (C % 4 == 0) && ((C / G) % 4 == 0) && a % 4 == 0 && b % 4 == 0 && c % 4 == 0 && d % 4 == 0;
+}
+
+}  // namespace
+
+extern "C" int eegldm_groupnorm_fwd(eegldm_ctx* ctx, const void* x, long ldx, const float* gamma, const float* beta,
+                                    void* y, long ldy, float* stats, int B, int L, int C, int G, float eps,
+                                    int fuse_silu, int resample, void* xr, long ldxr, int dtype) {
+  EEG_TRY(gn_check(ctx, B, L, C, G, resample, ldx));
+  const bool v4 = vec4_ok(C, G, ldx, ldy, xr ? ldxr : 0, 0);
+  if (dtype == EEGLDM_F32) {
+    return v4 ? gn_fwd_t<float, 4>(ctx, x, ldx, gamma, beta, y, ldy, stats, B, L, C, G, eps, fuse_silu, resample, xr, ldxr)
+              : gn_fwd_t<float, 1>(ctx, x, ldx, gamma, beta, y, ldy, stats, B, L, C, G, eps, fuse_silu, resample, xr, ldxr);
+  } else if (dtype == EEGLDM_BF16) {
+    return v4 ? gn_fwd_t<bf16_t, 4>(ctx, x, ldx, gamma, beta, y, ldy, stats, B, L, C, G, eps, fuse_silu, resample, xr, ldxr)
+              : gn_fwd_t<bf16_t, 1>(ctx, x, ldx, gamma, beta, y, ldy, stats, B, L, C, G, eps, fuse_silu, resample, xr, ldxr);
+  }
+  EEG_FAIL(EEGLDM_ERR_UNSUPPORTED, "dtype %d", dtype);
+}
+
+extern "C" int eegldm_groupnorm_bwd(eegldm_ctx* ctx, const void* x, long ldx, const float* gamma, const float* beta,
+                                    const float* stats, const void* dy, long lddy, void* dx, long lddx,
+                                    float* dgamma, float* dbeta, int B, int L, int C, int G, int fuse_silu,
+                                    int resample, const void* dxr, long lddxr, int dtype) {
+  EEG_TRY(gn_check(ctx, B, L, C, G, resample, ldx));
+  const bool v4 = vec4_ok(C, G, ldx, lddy, lddx, dxr ? lddxr : 0);
+  if (dtype == EEGLDM_F32) {
+    return v4 ? gn_bwd_t<float, 4>(ctx, x, ldx, gamma, beta, stats, dy, lddy, dx, lddx, dgamma, dbeta, B, L, C, G, fuse_silu, resample, dxr, lddxr)
+              : gn_bwd_t<float, 1>(ctx, x, ldx, gamma, beta, stats, dy, lddy, dx, lddx, dgamma, dbeta, B, L, C, G, fuse_silu, resample, dxr, lddxr);
+  } else if (dtype == EEGLDM_BF16) {
+    return v4 ? gn_bwd_t<bf16_t, 4>(ctx, x, ldx, gamma, beta, stats, dy, lddy, dx, lddx, dgamma, dbeta, B, L, C, G, fuse_silu, resample, dxr, lddxr)
+              : gn_bwd_t<bf16_t, 1>(ctx, x, ldx, gamma, beta, stats, dy, lddy, dx, lddx, dgamma, dbeta, B, L, C, G, fuse_silu, resample, dxr, lddxr);
+  }
+  EEG_FAIL(EEGLDM_ERR_UNSUPPORTED, "dtype %d", dtype);
+}

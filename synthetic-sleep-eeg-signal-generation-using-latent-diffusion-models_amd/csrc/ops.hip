@@ -1,0 +1,183 @@
+// Operator layer: maps nn.Conv1d / nn.Linear / QKV attention (forward + both backward
+// passes) onto the MFMA GEMM family (gemm.hip) or the thin-channel direct kernels
+// (direct_conv.hip).  Everything is NLC; see include/eegldm.h for the contracts.
+#include <math.h>
+
+#include "common.h"
+#include "internal.h"
+
+static inline int conv_lout(int Lin, int K, int stride, int pad_l, int pad_r) { return (Lin + pad_l + pad_r - K) / stride + 1; }
+
+int op_conv_fwd(eegldm_ctx* ctx, int dtype, const void* x, long ldx, const void* w, const float* bias, void* y, long ldy,
+                int B, int Lin, int Cin, int Cout, int K, int stride, int pad_l, int pad_r,
+                const float* rowvec, long ld_rowvec, const void* resid, long ldr) {
+  EEG_CHECK(B > 0 && Lin > 0 && Cin > 0 && Cout > 0 && (K == 1 || K == 3) && (stride == 1 || stride == 2),
+            "unsupported conv B=%d Lin=%d Cin=%d Cout=%d K=%d stride=%d", B, Lin, Cin, Cout, K, stride);
+  const int Lout = conv_lout(Lin, K, stride, pad_l, pad_r);
+  EEG_CHECK(Lout > 0, "empty output");
+  if (conv_is_thin(Cin, Cout, dtype)) {
+    EEG_CHECK(rowvec == nullptr, "rowvec add is not available on the thin-channel path");
+    return dconv_run(ctx, dtype, false, x, ldx, w, bias, resid, ldr, y, ldy, B, Lin, Lout, Cin, Cout, K, stride, pad_l);
+  }
+  GemmArgs a = {};
+  a.dtype = dtype; a.A = x; a.lda = ldx; a.B = w; a.ldb = Cin; a.sBt = (long)Cout * Cin; a.C = y; a.ldc = ldy;
+  a.M = B * Lout; a.N = Cout; a.K = Cin; a.batch = 1; a.taps = K; a.alpha = 1.0f; a.bias = bias;
+  a.rowvec = rowvec; a.ld_rowvec = ld_rowvec; a.rows_per_vec = Lout; a.resid = resid; a.ldr = ldr;
+  a.bmode = GB_NT;
+  if (K == 1) {
+    EEG_CHECK(stride == 1 && pad_l == 0 && pad_r == 0, "1x1 conv must be stride 1, no padding");
+    a.amode = GA_PLAIN;
+  } else {
+    EEG_CHECK(Lin == Lout * stride, "k3 conv geometry Lin=%d Lout=%d stride=%d not supported by the implicit GEMM", Lin, Lout, stride);
+    a.amode = GA_CONV; a.Lout = Lout; a.Lin = Lin; a.stride = stride; a.pad_l = pad_l;
+  }
+  return gemm_launch(ctx, a);
+}
+
+int op_conv_dgrad(eegldm_ctx* ctx, int dtype, const void* dy, long lddy, const void* w, void* dx, long lddx,
+                  int B, int Lin, int Cin, int Cout, int K, int stride, int pad_l, int pad_r, const void* resid, long ldr) {
+  const int Lout = conv_lout(Lin, K, stride, pad_l, pad_r);
+  if (conv_is_thin(Cin, Cout, dtype))
+    return dconv_run(ctx, dtype, true, dy, lddy, w, nullptr, resid, ldr, dx, lddx, B, Lin, Lout, Cin, Cout, K, stride, pad_l);
+  GemmArgs a = {};
+  a.dtype = dtype; a.A = dy; a.lda = lddy; a.B = w; a.ldb = Cin; a.sBt = (long)Cout * Cin; a.C = dx; a.ldc = lddx;
+  a.M = B * Lin; a.N = Cin; a.K = Cout; a.batch = 1; a.taps = K; a.alpha = 1.0f; a.resid = resid; a.ldr = ldr;
+  a.bmode = GB_TR;
+  if (K == 1) {
+    a.amode = GA_PLAIN;
+  } else {
+    EEG_CHECK(Lin == Lout * stride, "k3 dgrad geometry not supported");
+    // transposed conv as a stride-1 conv over the (virtually zero-upsampled) gradient, taps flipped
+    a.amode = GA_CONV; a.tap_flip = 1; a.Lout = Lin; a.Lin = Lin; a.stride = 1; a.pad_l = K - 1 - pad_l;
+    a.ups = stride; a.Lsrc = Lout;
+  }
+  return gemm_launch(ctx, a);
+}
+
+int op_conv_wgrad(eegldm_ctx* ctx, int dtype, const void* x, long ldx, const void* dy, long lddy, float* dw, float* dbias,
+                  int B, int Lin, int Cin, int Cout, int K, int stride, int pad_l, int pad_r) {
+  const int Lout = conv_lout(Lin, K, stride, pad_l, pad_r);
+  if (dbias) EEG_TRY(ew_colsum(ctx, dy, lddy, nullptr, 0, dbias, B, Lout, Cout, dtype));
+  if (conv_is_thin(Cin, Cout, dtype))
+    return dconv_wgrad(ctx, dtype, x, ldx, dy, lddy, dw, B, Lin, Lout, Cin, Cout, K, stride, pad_l);
+  GemmArgs a = {};
+  a.dtype = dtype; a.amode = GA_TR; a.bmode = GB_TR;
+  a.A = dy; a.lda = lddy; a.B = x; a.ldb = ldx; a.C = dw; a.ldc = Cin; a.sCt = (long)Cout * Cin;
+  a.M = Cout; a.N = Cin; a.K = B * Lout; a.batch = 1; a.taps = 1; a.ztaps = K; a.alpha = 1.0f;
+  a.conv_map = 1; a.Lout = Lout; a.Lin = Lin; a.stride = stride; a.pad_l = pad_l;
+  a.out_f32 = 1; a.atomic_out = 1;
+  const int bn = Cin > 64 ? 128 : (Cin > 32 ? 64 : 32);
+  const long tiles = (long)((Cout + 127) / 128) * ((Cin + bn - 1) / bn) * K;
+  const int kstage = 2 * (dtype == EEGLDM_F32 ? 16 : 32);
+  long want = ((long)ctx->num_cu * 3 + tiles - 1) / tiles;
+  long maxs = ((long)a.K + 4 * kstage - 1) / (4 * kstage);     // at least 4 stages per split
+  if (want > maxs) want = maxs;
+  a.splitk = (int)(want < 1 ? 1 : want);
+  return gemm_launch(ctx, a);
+}
+
+int op_linear(eegldm_ctx* ctx, int dtype, const void* x, long ldx, const void* w, long ldw, const float* bias, void* y, long ldy,
+              int M, int N, int K, int out_f32) {
+  GemmArgs a = {};
+  a.dtype = dtype; a.amode = GA_PLAIN; a.bmode = GB_NT; a.A = x; a.lda = ldx; a.B = w; a.ldb = ldw; a.C = y; a.ldc = ldy;
+  a.M = M; a.N = N; a.K = K; a.batch = 1; a.taps = 1; a.alpha = 1.0f; a.bias = bias; a.out_f32 = out_f32;
+  return gemm_launch(ctx, a);
+}
+// dx[M][K] = dy[M][N] w[N][K]
+int op_linear_dgrad(eegldm_ctx* ctx, int dtype, const void* dy, long lddy, const void* w, long ldw, void* dx, long lddx,
+                    int M, int N, int K, int out_f32) {
+  GemmArgs a = {};
+  a.dtype = dtype; a.amode = GA_PLAIN; a.bmode = GB_TR; a.A = dy; a.lda = lddy; a.B = w; a.ldb = ldw; a.C = dx; a.ldc = lddx;
+  a.M = M; a.N = K; a.K = N; a.batch = 1; a.taps = 1; a.alpha = 1.0f; a.out_f32 = out_f32;
+  return gemm_launch(ctx, a);
+}
+// dw[N][K] += dy[M][N]^T x[M][K]
+int op_linear_wgrad(eegldm_ctx* ctx, int dtype, const void* x, long ldx, const void* dy, long lddy, float* dw, long lddw,
+                    int M, int N, int K) {
+  GemmArgs a = {};
+  a.dtype = dtype; a.amode = GA_TR; a.bmode = GB_TR; a.A = dy; a.lda = lddy; a.B = x; a.ldb = ldx; a.C = dw; a.ldc = lddw;
+  a.M = N; a.N = K; a.K = M; a.batch = 1; a.taps = 1; a.alpha = 1.0f; a.out_f32 = 1; a.atomic_out = 1;
+  return gemm_launch(ctx, a);
+}
+
+// ------------------------------------------------------------------ attention (unet.py:107-125)
+int op_attention_fwd(eegldm_ctx* ctx, int dtype, const void* qkv, long ldq, void* out, long ldo, void* probs, float* logits,
+                     int B, int T, int C) {
+  const size_t es = dtype_size(dtype);
+  const char* q = (const char*)qkv; const char* k = q + (size_t)C * es; const char* v = q + (size_t)2 * C * es;
+  GemmArgs a = {};
+  a.dtype = dtype; a.amode = GA_PLAIN; a.bmode = GB_NT; a.A = q; a.lda = ldq; a.sAb = (long)T * ldq; a.B = k; a.ldb = ldq;
+  a.sBb = (long)T * ldq; a.C = logits; a.ldc = T; a.sCb = (long)T * T; a.M = T; a.N = T; a.K = C; a.batch = B; a.taps = 1;
+  a.alpha = 1.0f / sqrtf((float)C);   // (q*s)(k*s), s = C^-1/4
+  a.out_f32 = 1;
+  EEG_TRY(gemm_launch(ctx, a));
+  EEG_TRY(ew_softmax(ctx, logits, probs, (long)B * T, T, dtype));
+  GemmArgs b = {};
+  b.dtype = dtype; b.amode = GA_PLAIN; b.bmode = GB_TR; b.A = probs; b.lda = T; b.sAb = (long)T * T; b.B = v; b.ldb = ldq;
+  b.sBb = (long)T * ldq; b.C = out; b.ldc = ldo; b.sCb = (long)T * ldo; b.M = T; b.N = C; b.K = T; b.batch = B; b.taps = 1;
+  b.alpha = 1.0f;
+  return gemm_launch(ctx, b);
+}
+
+int op_attention_bwd(eegldm_ctx* ctx, int dtype, const void* qkv, long ldq, const void* probs, const void* dout, long lddo,
+                     void* dqkv, long lddq, float* dprobs, void* dlogits, int B, int T, int C) {
+  const size_t es = dtype_size(dtype);
+  const char* q = (const char*)qkv; const char* k = q + (size_t)C * es; const char* v = q + (size_t)2 * C * es;
+  char* dq = (char*)dqkv; char* dk = dq + (size_t)C * es; char* dv = dq + (size_t)2 * C * es;
+  const float alpha = 1.0f / sqrtf((float)C);
+  GemmArgs g = {};
+  // dV[s][c] = sum_t P[t][s] dO[t][c]
+  g.dtype = dtype; g.amode = GA_TR; g.bmode = GB_TR; g.A = probs; g.lda = T; g.sAb = (long)T * T; g.B = dout; g.ldb = lddo;
+  g.sBb = (long)T * lddo; g.C = dv; g.ldc = lddq; g.sCb = (long)T * lddq; g.M = T; g.N = C; g.K = T; g.batch = B; g.taps = 1; g.alpha = 1.f;
+  EEG_TRY(gemm_launch(ctx, g));
+  // dP[t][s] = sum_c dO[t][c] V[s][c]
+  g = GemmArgs{};
+  g.dtype = dtype; g.amode = GA_PLAIN; g.bmode = GB_NT; g.A = dout; g.lda = lddo; g.sAb = (long)T * lddo; g.B = v; g.ldb = ldq;
+  g.sBb = (long)T * ldq; g.C = dprobs; g.ldc = T; g.sCb = (long)T * T; g.M = T; g.N = T; g.K = C; g.batch = B; g.taps = 1; g.alpha = 1.f;
+  g.out_f32 = 1;
+  EEG_TRY(gemm_launch(ctx, g));
+  EEG_TRY(ew_softmax_bwd(ctx, dprobs, probs, dlogits, (long)B * T, T, alpha, dtype));
+  // dQ[t][c] = sum_s dS[t][s] K[s][c]
+  g = GemmArgs{};
+  g.dtype = dtype; g.amode = GA_PLAIN; g.bmode = GB_TR; g.A = dlogits; g.lda = T; g.sAb = (long)T * T; g.B = k; g.ldb = ldq;
+  g.sBb = (long)T * ldq; g.C = dq; g.ldc = lddq; g.sCb = (long)T * lddq; g.M = T; g.N = C; g.K = T; g.batch = B; g.taps = 1; g.alpha = 1.f;
+  EEG_TRY(gemm_launch(ctx, g));
+  // dK[s][c] = sum_t dS[t][s] Q[t][c]
+  g = GemmArgs{};
+  g.dtype = dtype; g.amode = GA_TR; g.bmode = GB_TR; g.A = dlogits; g.lda = T; g.sAb = (long)T * T; g.B = q; g.ldb = ldq;
+  g.sBb = (long)T * ldq; g.C = dk; g.ldc = lddq; g.sCb = (long)T * lddq; g.M = T; g.N = C; g.K = T; g.batch = B; g.taps = 1; g.alpha = 1.f;
+  return gemm_launch(ctx, g);
+}
+
+// ================================================================== C ABI
+extern "C" int eegldm_conv1d_fwd(eegldm_ctx* ctx, const void* x, long ldx, const void* w, const float* bias, void* y, long ldy,
+                                 int B, int Lin, int Cin, int Cout, int K, int stride, int pad_l, int pad_r,
+                                 const float* rowvec, long ld_rowvec, const void* resid, long ld_resid, int dtype) {
+  EEG_CHECK(ctx && x && w && y, "null pointer");
+  return op_conv_fwd(ctx, dtype, x, ldx, w, bias, y, ldy, B, Lin, Cin, Cout, K, stride, pad_l, pad_r, rowvec, ld_rowvec, resid, ld_resid);
+}
+extern "C" int eegldm_conv1d_bwd_data(eegldm_ctx* ctx, const void* dy, long lddy, const void* w, void* dx, long lddx, int B, int Lin,
+                                      int Cin, int Cout, int K, int stride, int pad_l, int pad_r, const void* resid, long ld_resid, int dtype) {
+  EEG_CHECK(ctx && dy && w && dx, "null pointer");
+  return op_conv_dgrad(ctx, dtype, dy, lddy, w, dx, lddx, B, Lin, Cin, Cout, K, stride, pad_l, pad_r, resid, ld_resid);
+}
+extern "C" int eegldm_conv1d_bwd_weight(eegldm_ctx* ctx, const void* x, long ldx, const void* dy, long lddy, float* dw, float* dbias,
+                                        int B, int Lin, int Cin, int Cout, int K, int stride, int pad_l, int pad_r, int dtype) {
+  EEG_CHECK(ctx && x && dy && dw, "null pointer");
+  return op_conv_wgrad(ctx, dtype, x, ldx, dy, lddy, dw, dbias, B, Lin, Cin, Cout, K, stride, pad_l, pad_r);
+}
+extern "C" int eegldm_linear_fwd(eegldm_ctx* ctx, const void* x, long ldx, const void* w, const float* bias, void* y, long ldy,
+                                 int M, int N, int K, int dtype, int out_f32) {
+  EEG_CHECK(ctx && x && w && y, "null pointer");
+  return op_linear(ctx, dtype, x, ldx, w, K, bias, y, ldy, M, N, K, out_f32);
+}
+extern "C" int eegldm_attention_fwd(eegldm_ctx* ctx, const void* qkv, long ldqkv, void* out, long ldo, void* probs, float* scratch_logits,
+                                    int B, int T, int C, int dtype) {
+  EEG_CHECK(ctx && qkv && out && probs && scratch_logits, "null pointer");
+  return op_attention_fwd(ctx, dtype, qkv, ldqkv, out, ldo, probs, scratch_logits, B, T, C);
+}
+extern "C" int eegldm_attention_bwd(eegldm_ctx* ctx, const void* qkv, long ldqkv, const void* probs, const void* dout, long lddo,
+                                    void* dqkv, long lddqkv, float* scratch_dprobs, void* scratch_dlogits, int B, int T, int C, int dtype) {
+  EEG_CHECK(ctx && qkv && probs && dout && dqkv && scratch_dprobs && scratch_dlogits, "null pointer");
+  return op_attention_bwd(ctx, dtype, qkv, ldqkv, probs, dout, lddo, dqkv, lddqkv, scratch_dprobs, scratch_dlogits, B, T, C);
+}

@@ -1,0 +1,561 @@
+// UNet denoiser executor: forward, hand-written backward and the LDM train-step body.
+// Mirrors UNetModel of /root/reference/src/models/unet.py:330-563 (constructor loops
+// :382-499, forward :512-563) with resblock_updown=True, use_scale_shift_norm=False,
+// dropout=0, num_heads=1 -- the configuration of config/config_ldm.yaml:30-43.
+//
+// Host side only: this file sequences kernels from gemm.hip / norm.hip / elementwise.hip
+// / direct_conv.hip on the context's stream.  All activations are NLC in the model dtype;
+// channel concatenations of the up path (`th.cat([h, h_pop], 1)`, unet.py:553) are never
+// materialised: the producer of each half writes straight into its column range of a
+// pre-sized buffer (every kernel takes a leading dimension).
+//
+// Parameters live in ONE flat fp32 buffer owned by the caller (so Adam is one launch and
+// DDP is one all-reduce over a contiguous gradient buffer); conv weights are stored packed
+// [K][Cout][Cin]; the 21 timestep-embedding Linear layers of the ResBlocks are stored
+// contiguously so `emb_layers` of every block is ONE GEMM per step.
+#include <string.h>
+
+#include <string>
+#include <vector>
+
+#include "common.h"
+#include "internal.h"
+
+namespace {
+
+constexpr int GN_G = 32;
+constexpr float GN_EPS = 1e-6f;
+
+struct Arena {
+  struct Block { char* p; size_t cap; };
+  std::vector<Block> blocks;
+  size_t cur_block = 0, cur_off = 0;
+  size_t min_block = (size_t)512 << 20;
+  ~Arena() { for (auto& b : blocks) hipFree(b.p); }
+  void reset() { cur_block = 0; cur_off = 0; }
+  struct Mark { size_t b, o; };
+  Mark mark() const { return {cur_block, cur_off}; }
+  void release(Mark m) { cur_block = m.b; cur_off = m.o; }
+  void* alloc(size_t bytes) {
+    bytes = (bytes + 255) & ~(size_t)255;
+    while (true) {
+      if (cur_block < blocks.size()) {
+        if (cur_off + bytes <= blocks[cur_block].cap) { void* r = blocks[cur_block].p + cur_off; cur_off += bytes; return r; }
+        cur_block++; cur_off = 0;
+        continue;
+      }
+      size_t cap = bytes > min_block ? bytes : min_block;
+      char* p = nullptr;
+      if (hipMalloc(&p, cap) != hipSuccess) return nullptr;
+      blocks.push_back({p, cap});
+    }
+  }
+};
+
+struct View { void* p = nullptr; long ld = 0; int C = 0; };
+static inline View col_view(const View& v, int col, int C, int dtype) {
+  View r; r.p = (char*)v.p + (size_t)col * dtype_size(dtype); r.ld = v.ld; r.C = C; return r;
+}
+
+struct Entry { std::string name; long offset, numel; int ndim; int shape[3]; };
+
+struct ResDesc {
+  int cin, cout, updown;   // updown: 0 none, 1 down, 2 up
+  long gn1_w, gn1_b, c1_w, c1_b, gn2_w, gn2_b, c2_w, c2_b, sk_w, sk_b;
+  int emb_col;
+};
+struct AttnDesc { int c; long n_w, n_b, qkv_w, qkv_b, pr_w, pr_b; };
+struct Layer { int kind; ResDesc r; AttnDesc a; };   // kind 0 = res, 1 = attn
+struct Block { std::vector<Layer> layers; int cin, cout, lshift_in, lshift_out; };
+
+struct ResTape { View x, a1, xr, h1, a2; float *st1, *st2; int B, Lin, Lout; };
+struct AttnTape { View x, xn, qkv, o; void* probs; float* st; int B, T; };
+
+}  // namespace
+
+struct eegldm_unet {
+  eegldm_ctx* ctx;
+  eegldm_unet_cfg cfg;
+  int dtype, mc, te, etot;
+  std::vector<Entry> entries;
+  long nparams = 0;
+  long off_emb_w = 0, off_emb_b = 0, off_te0_w, off_te0_b, off_te2_w, off_te2_b, off_cin_w, off_cin_b, off_out_gw, off_out_gb, off_out_w, off_out_b;
+  std::vector<Block> in_blocks, out_blocks; Block mid;
+  std::vector<int> skip_c1;      // per output block: channels of h entering the concat
+  float* params = nullptr; float* grads = nullptr;
+  void* wT = nullptr;            // compute-dtype copy of params (bf16) or == params (fp32)
+  bool owns_wT = false;
+  Arena arena;
+  // ---- forward tape
+  int B = 0, L = 0; bool have_tape = false;
+  View x0, h_last, a_out; float* st_out = nullptr;
+  void *e0 = nullptr, *a1e = nullptr, *semb = nullptr; float *h1e = nullptr, *emb = nullptr, *emb_all = nullptr;
+  std::vector<ResTape> rt; std::vector<AttnTape> at;
+  std::vector<View> in_out;      // outputs of the input blocks (views into concat buffers)
+  std::vector<View> cat;         // concat buffers per output block
+
+  const void* W(long off) const { return (const char*)wT + (size_t)off * dtype_size(dtype); }
+  const float* P(long off) const { return params + off; }
+  float* G(long off) const { return grads + off; }
+  void* alloc_act(long rows, long cols) { return arena.alloc((size_t)rows * cols * dtype_size(dtype)); }
+};
+
+namespace {
+
+void add_entry(eegldm_unet* u, const std::string& name, long off, int ndim, int s0, int s1 = 0, int s2 = 0) {
+  Entry e; e.name = name; e.offset = off; e.ndim = ndim; e.shape[0] = s0; e.shape[1] = s1; e.shape[2] = s2;
+  e.numel = (long)s0 * (ndim > 1 ? s1 : 1) * (ndim > 2 ? s2 : 1);
+  u->entries.push_back(e);
+}
+
+// Builds the block plan exactly like the reference constructor and lays out the flat buffer.
+int build_plan(eegldm_unet* u) {
+  const eegldm_unet_cfg& c = u->cfg;
+  const int mc = c.model_channels, te = 4 * mc;
+  u->mc = mc; u->te = te;
+  auto has_attn = [&](int ds) { for (int i = 0; i < c.n_attn; i++) if (c.attention_resolutions[i] == ds) return true; return false; };
+
+  // ---- pass 1: structure
+  struct Tmp { int kind, cin, cout, updown; };
+  std::vector<std::vector<Tmp>> inp, outp; std::vector<Tmp> mid;
+  std::vector<int> chans{mc};
+  inp.push_back({});   // block 0 = conv_in (handled separately)
+  int ch = mc, ds = 1;
+  for (int level = 0; level < c.n_mult; level++) {
+    const int mult = c.channel_mult[level];
+    for (int r = 0; r < c.num_res_blocks; r++) {
+      std::vector<Tmp> l{{0, ch, mult * mc, 0}};
+      ch = mult * mc;
+      if (has_attn(ds)) l.push_back({1, ch, ch, 0});
+      inp.push_back(l); chans.push_back(ch);
+    }
+    if (level != c.n_mult - 1) { inp.push_back({{0, ch, ch, 1}}); chans.push_back(ch); ds *= 2; }
+  }
+  mid = {{0, ch, ch, 0}, {1, ch, ch, 0}, {0, ch, ch, 0}};
+  std::vector<int> chans_pop = chans;
+  for (int level = c.n_mult - 1; level >= 0; level--) {
+    const int mult = c.channel_mult[level];
+    for (int i = 0; i <= c.num_res_blocks; i++) {
+      const int ich = chans_pop.back(); chans_pop.pop_back();
+      u->skip_c1.push_back(ch);
+      std::vector<Tmp> l{{0, ch + ich, mc * mult, 0}};
+      ch = mc * mult;
+      if (has_attn(ds)) l.push_back({1, ch, ch, 0});
+      if (level && i == c.num_res_blocks) { l.push_back({0, ch, ch, 2}); ds /= 2; }
+      outp.push_back(l);
+    }
+  }
+  EEG_CHECK(ch == mc, "plan error: final channels %d != model_channels %d", ch, mc);
+
+  // ---- pass 2: flat layout.  Region A: all ResBlock emb Linear weights [etot][te] then biases [etot].
+  int etot = 0;
+  auto count_emb = [&](const std::vector<Tmp>& l) { for (auto& t : l) if (t.kind == 0) etot += t.cout; };
+  for (auto& l : inp) count_emb(l);
+  count_emb(mid);
+  for (auto& l : outp) count_emb(l);
+  u->etot = etot;
+  long off = 0;
+  u->off_emb_w = off; off += (long)etot * te;
+  u->off_emb_b = off; off += etot;
+  auto take = [&](long n) { long o = off; off += (n + 7) / 8 * 8; return o; };   // keep every tensor 32-byte aligned
+
+  u->off_te0_w = take((long)te * mc); u->off_te0_b = take(te);
+  u->off_te2_w = take((long)te * te); u->off_te2_b = take(te);
+  add_entry(u, "time_embed.0.weight", u->off_te0_w, 2, te, mc); add_entry(u, "time_embed.0.bias", u->off_te0_b, 1, te);
+  add_entry(u, "time_embed.2.weight", u->off_te2_w, 2, te, te); add_entry(u, "time_embed.2.bias", u->off_te2_b, 1, te);
+  u->off_cin_w = take((long)mc * c.in_channels * 3); u->off_cin_b = take(mc);
+  add_entry(u, "input_blocks.0.0.weight", u->off_cin_w, 3, mc, c.in_channels, 3); add_entry(u, "input_blocks.0.0.bias", u->off_cin_b, 1, mc);
+
+  int emb_col = 0;
+  auto lay = [&](const std::string& prefix, const std::vector<Tmp>& l, Block& blk) {
+    for (size_t j = 0; j < l.size(); j++) {
+      const std::string p = prefix + std::to_string(j) + ".";
+      Layer L; L.kind = l[j].kind;
+      if (l[j].kind == 0) {
+        ResDesc& r = L.r; r.cin = l[j].cin; r.cout = l[j].cout; r.updown = l[j].updown;
+        r.gn1_w = take(r.cin); r.gn1_b = take(r.cin);
+        add_entry(u, p + "in_layers.0.weight", r.gn1_w, 1, r.cin); add_entry(u, p + "in_layers.0.bias", r.gn1_b, 1, r.cin);
+        r.c1_w = take((long)r.cout * r.cin * 3); r.c1_b = take(r.cout);
+        add_entry(u, p + "in_layers.2.weight", r.c1_w, 3, r.cout, r.cin, 3); add_entry(u, p + "in_layers.2.bias", r.c1_b, 1, r.cout);
+        r.emb_col = emb_col; emb_col += r.cout;
+        add_entry(u, p + "emb_layers.1.weight", u->off_emb_w + (long)r.emb_col * te, 2, r.cout, te);
+        add_entry(u, p + "emb_layers.1.bias", u->off_emb_b + r.emb_col, 1, r.cout);
+        r.gn2_w = take(r.cout); r.gn2_b = take(r.cout);
+        add_entry(u, p + "out_layers.0.weight", r.gn2_w, 1, r.cout); add_entry(u, p + "out_layers.0.bias", r.gn2_b, 1, r.cout);
+        r.c2_w = take((long)r.cout * r.cout * 3); r.c2_b = take(r.cout);
+        add_entry(u, p + "out_layers.3.weight", r.c2_w, 3, r.cout, r.cout, 3); add_entry(u, p + "out_layers.3.bias", r.c2_b, 1, r.cout);
+        r.sk_w = r.sk_b = -1;
+        if (r.cin != r.cout) {
+          r.sk_w = take((long)r.cout * r.cin); r.sk_b = take(r.cout);
+          add_entry(u, p + "skip_connection.weight", r.sk_w, 3, r.cout, r.cin, 1); add_entry(u, p + "skip_connection.bias", r.sk_b, 1, r.cout);
+        }
+      } else {
+        AttnDesc& a = L.a; a.c = l[j].cin;
+        a.n_w = take(a.c); a.n_b = take(a.c);
+        add_entry(u, p + "norm.weight", a.n_w, 1, a.c); add_entry(u, p + "norm.bias", a.n_b, 1, a.c);
+        a.qkv_w = take((long)3 * a.c * a.c); a.qkv_b = take(3 * a.c);
+        add_entry(u, p + "qkv.weight", a.qkv_w, 3, 3 * a.c, a.c, 1); add_entry(u, p + "qkv.bias", a.qkv_b, 1, 3 * a.c);
+        a.pr_w = take((long)a.c * a.c); a.pr_b = take(a.c);
+        add_entry(u, p + "proj_out.weight", a.pr_w, 3, a.c, a.c, 1); add_entry(u, p + "proj_out.bias", a.pr_b, 1, a.c);
+      }
+      blk.layers.push_back(L);
+    }
+    blk.cin = l.front().cin; blk.cout = l.back().cout;
+  };
+  u->in_blocks.resize(inp.size());
+  for (size_t i = 1; i < inp.size(); i++) lay("input_blocks." + std::to_string(i) + ".", inp[i], u->in_blocks[i]);
+  lay("middle_block.", mid, u->mid);
+  u->out_blocks.resize(outp.size());
+  for (size_t i = 0; i < outp.size(); i++) lay("output_blocks." + std::to_string(i) + ".", outp[i], u->out_blocks[i]);
+  u->off_out_gw = take(mc); u->off_out_gb = take(mc);
+  add_entry(u, "out.0.weight", u->off_out_gw, 1, mc); add_entry(u, "out.0.bias", u->off_out_gb, 1, mc);
+  u->off_out_w = take((long)c.out_channels * mc * 3); u->off_out_b = take(c.out_channels);
+  add_entry(u, "out.2.weight", u->off_out_w, 3, c.out_channels, mc, 3); add_entry(u, "out.2.bias", u->off_out_b, 1, c.out_channels);
+  u->nparams = off;
+  return 0;
+}
+
+#define ALLOC_OR_FAIL(var, expr)                                                     \
+  do { (var) = (expr); if (!(var)) EEG_FAIL(EEGLDM_ERR_NOMEM, "workspace allocation failed"); } while (0)
+
+// ------------------------------------------------------------------ ResBlock (unet.py:307-327)
+int res_forward(eegldm_unet* u, const ResDesc& r, const View& x, int B, int Lin, const View& out) {
+  eegldm_ctx* ctx = u->ctx; const int dt = u->dtype;
+  const int Lout = r.updown == 1 ? Lin / 2 : (r.updown == 2 ? Lin * 2 : Lin);
+  ResTape t; t.x = x; t.B = B; t.Lin = Lin; t.Lout = Lout;
+  ALLOC_OR_FAIL(t.st1, (float*)u->arena.alloc(sizeof(float) * 2 * B * GN_G));
+  ALLOC_OR_FAIL(t.st2, (float*)u->arena.alloc(sizeof(float) * 2 * B * GN_G));
+  ALLOC_OR_FAIL(t.a1.p, u->alloc_act((long)B * Lout, r.cin)); t.a1.ld = r.cin; t.a1.C = r.cin;
+  if (r.updown) { ALLOC_OR_FAIL(t.xr.p, u->alloc_act((long)B * Lout, r.cin)); t.xr.ld = r.cin; t.xr.C = r.cin; } else t.xr = x;
+  EEG_TRY(eegldm_groupnorm_fwd(ctx, x.p, x.ld, u->P(r.gn1_w), u->P(r.gn1_b), t.a1.p, t.a1.ld, t.st1, B, Lin, r.cin, GN_G, GN_EPS, 1,
+                               r.updown, r.updown ? t.xr.p : nullptr, t.xr.ld, dt));
+  ALLOC_OR_FAIL(t.h1.p, u->alloc_act((long)B * Lout, r.cout)); t.h1.ld = r.cout; t.h1.C = r.cout;
+  EEG_TRY(op_conv_fwd(ctx, dt, t.a1.p, t.a1.ld, u->W(r.c1_w), u->P(r.c1_b), t.h1.p, t.h1.ld, B, Lout, r.cin, r.cout, 3, 1, 1, 1,
+                      u->emb_all + r.emb_col, u->etot, nullptr, 0));
+  ALLOC_OR_FAIL(t.a2.p, u->alloc_act((long)B * Lout, r.cout)); t.a2.ld = r.cout; t.a2.C = r.cout;
+  EEG_TRY(eegldm_groupnorm_fwd(ctx, t.h1.p, t.h1.ld, u->P(r.gn2_w), u->P(r.gn2_b), t.a2.p, t.a2.ld, t.st2, B, Lout, r.cout, GN_G, GN_EPS, 1,
+                               0, nullptr, 0, dt));
+  if (r.sk_w >= 0) {
+    EEG_TRY(op_conv_fwd(ctx, dt, t.xr.p, t.xr.ld, u->W(r.sk_w), u->P(r.sk_b), out.p, out.ld, B, Lout, r.cin, r.cout, 1, 1, 0, 0, nullptr, 0, nullptr, 0));
+    EEG_TRY(op_conv_fwd(ctx, dt, t.a2.p, t.a2.ld, u->W(r.c2_w), u->P(r.c2_b), out.p, out.ld, B, Lout, r.cout, r.cout, 3, 1, 1, 1, nullptr, 0, out.p, out.ld));
+  } else {
+    EEG_TRY(op_conv_fwd(ctx, dt, t.a2.p, t.a2.ld, u->W(r.c2_w), u->P(r.c2_b), out.p, out.ld, B, Lout, r.cout, r.cout, 3, 1, 1, 1, nullptr, 0, t.xr.p, t.xr.ld));
+  }
+  u->rt.push_back(t);
+  return 0;
+}
+
+// dout: [B*Lout][cout]; writes dx: [B*Lin][cin]; accumulates parameter grads; demb_all gets per-sample sums
+int res_backward(eegldm_unet* u, const ResDesc& r, const ResTape& t, const View& dout, const View& dx, void* demb_all) {
+  eegldm_ctx* ctx = u->ctx; const int dt = u->dtype; const int B = t.B, Lin = t.Lin, Lout = t.Lout;
+  Arena::Mark mk = u->arena.mark();
+  View dxr = dout;
+  if (r.sk_w >= 0) {
+    EEG_TRY(op_conv_wgrad(ctx, dt, t.xr.p, t.xr.ld, dout.p, dout.ld, u->G(r.sk_w), u->G(r.sk_b), B, Lout, r.cin, r.cout, 1, 1, 0, 0));
+    ALLOC_OR_FAIL(dxr.p, u->alloc_act((long)B * Lout, r.cin)); dxr.ld = r.cin; dxr.C = r.cin;
+    EEG_TRY(op_conv_dgrad(ctx, dt, dout.p, dout.ld, u->W(r.sk_w), dxr.p, dxr.ld, B, Lout, r.cin, r.cout, 1, 1, 0, 0, nullptr, 0));
+  }
+  EEG_TRY(op_conv_wgrad(ctx, dt, t.a2.p, t.a2.ld, dout.p, dout.ld, u->G(r.c2_w), u->G(r.c2_b), B, Lout, r.cout, r.cout, 3, 1, 1, 1));
+  View da2; ALLOC_OR_FAIL(da2.p, u->alloc_act((long)B * Lout, r.cout)); da2.ld = r.cout;
+  EEG_TRY(op_conv_dgrad(ctx, dt, dout.p, dout.ld, u->W(r.c2_w), da2.p, da2.ld, B, Lout, r.cout, r.cout, 3, 1, 1, 1, nullptr, 0));
+  View dh1; ALLOC_OR_FAIL(dh1.p, u->alloc_act((long)B * Lout, r.cout)); dh1.ld = r.cout;
+  EEG_TRY(eegldm_groupnorm_bwd(ctx, t.h1.p, t.h1.ld, u->P(r.gn2_w), u->P(r.gn2_b), t.st2, da2.p, da2.ld, dh1.p, dh1.ld, u->G(r.gn2_w), u->G(r.gn2_b),
+                               B, Lout, r.cout, GN_G, 1, 0, nullptr, 0, dt));
+  // h1 = conv(a1) + b1 + emb_out[b]: per-sample column sums feed the embedding MLP, their total is db1
+  EEG_TRY(ew_colsum(ctx, dh1.p, dh1.ld, (char*)demb_all + (size_t)r.emb_col * dtype_size(dt), u->etot, u->G(r.c1_b), B, Lout, r.cout, dt));
+  EEG_TRY(op_conv_wgrad(ctx, dt, t.a1.p, t.a1.ld, dh1.p, dh1.ld, u->G(r.c1_w), nullptr, B, Lout, r.cin, r.cout, 3, 1, 1, 1));
+  View da1; ALLOC_OR_FAIL(da1.p, u->alloc_act((long)B * Lout, r.cin)); da1.ld = r.cin;
+  EEG_TRY(op_conv_dgrad(ctx, dt, dh1.p, dh1.ld, u->W(r.c1_w), da1.p, da1.ld, B, Lout, r.cin, r.cout, 3, 1, 1, 1, nullptr, 0));
+  EEG_TRY(eegldm_groupnorm_bwd(ctx, t.x.p, t.x.ld, u->P(r.gn1_w), u->P(r.gn1_b), t.st1, da1.p, da1.ld, dx.p, dx.ld, u->G(r.gn1_w), u->G(r.gn1_b),
+                               B, Lin, r.cin, GN_G, 1, r.updown, dxr.p, dxr.ld, dt));
+  u->arena.release(mk);
+  return 0;
+}
+
+// ------------------------------------------------------------------ AttentionBlock (unet.py:168-174)
+int attn_forward(eegldm_unet* u, const AttnDesc& a, const View& x, int B, int T, const View& out) {
+  eegldm_ctx* ctx = u->ctx; const int dt = u->dtype; const int C = a.c;
+  AttnTape t; t.x = x; t.B = B; t.T = T;
+  ALLOC_OR_FAIL(t.st, (float*)u->arena.alloc(sizeof(float) * 2 * B * GN_G));
+  ALLOC_OR_FAIL(t.xn.p, u->alloc_act((long)B * T, C)); t.xn.ld = C;
+  EEG_TRY(eegldm_groupnorm_fwd(ctx, x.p, x.ld, u->P(a.n_w), u->P(a.n_b), t.xn.p, C, t.st, B, T, C, GN_G, GN_EPS, 0, 0, nullptr, 0, dt));
+  ALLOC_OR_FAIL(t.qkv.p, u->alloc_act((long)B * T, 3 * C)); t.qkv.ld = 3 * C;
+  EEG_TRY(op_conv_fwd(ctx, dt, t.xn.p, C, u->W(a.qkv_w), u->P(a.qkv_b), t.qkv.p, 3 * C, B, T, C, 3 * C, 1, 1, 0, 0, nullptr, 0, nullptr, 0));
+  ALLOC_OR_FAIL(t.probs, u->alloc_act((long)B * T, T));
+  ALLOC_OR_FAIL(t.o.p, u->alloc_act((long)B * T, C)); t.o.ld = C;
+  Arena::Mark mk = u->arena.mark();
+  float* logits; ALLOC_OR_FAIL(logits, (float*)u->arena.alloc(sizeof(float) * (size_t)B * T * T));
+  EEG_TRY(op_attention_fwd(ctx, dt, t.qkv.p, 3 * C, t.o.p, C, t.probs, logits, B, T, C));
+  u->arena.release(mk);
+  EEG_TRY(op_conv_fwd(ctx, dt, t.o.p, C, u->W(a.pr_w), u->P(a.pr_b), out.p, out.ld, B, T, C, C, 1, 1, 0, 0, nullptr, 0, x.p, x.ld));
+  u->at.push_back(t);
+  return 0;
+}
+
+int attn_backward(eegldm_unet* u, const AttnDesc& a, const AttnTape& t, const View& dout, const View& dx) {
+  eegldm_ctx* ctx = u->ctx; const int dt = u->dtype; const int C = a.c, B = t.B, T = t.T;
+  Arena::Mark mk = u->arena.mark();
+  EEG_TRY(op_conv_wgrad(ctx, dt, t.o.p, C, dout.p, dout.ld, u->G(a.pr_w), u->G(a.pr_b), B, T, C, C, 1, 1, 0, 0));
+  void* d_o; ALLOC_OR_FAIL(d_o, u->alloc_act((long)B * T, C));
+  EEG_TRY(op_conv_dgrad(ctx, dt, dout.p, dout.ld, u->W(a.pr_w), d_o, C, B, T, C, C, 1, 1, 0, 0, nullptr, 0));
+  void* dqkv; ALLOC_OR_FAIL(dqkv, u->alloc_act((long)B * T, 3 * C));
+  float* dprobs; ALLOC_OR_FAIL(dprobs, (float*)u->arena.alloc(sizeof(float) * (size_t)B * T * T));
+  void* dlogits; ALLOC_OR_FAIL(dlogits, u->alloc_act((long)B * T, T));
+  EEG_TRY(op_attention_bwd(ctx, dt, t.qkv.p, 3 * C, t.probs, d_o, C, dqkv, 3 * C, dprobs, dlogits, B, T, C));
+  EEG_TRY(op_conv_wgrad(ctx, dt, t.xn.p, C, dqkv, 3 * C, u->G(a.qkv_w), u->G(a.qkv_b), B, T, C, 3 * C, 1, 1, 0, 0));
+  void* dxn; ALLOC_OR_FAIL(dxn, u->alloc_act((long)B * T, C));
+  EEG_TRY(op_conv_dgrad(ctx, dt, dqkv, 3 * C, u->W(a.qkv_w), dxn, C, B, T, C, 3 * C, 1, 1, 0, 0, nullptr, 0));
+  EEG_TRY(eegldm_groupnorm_bwd(ctx, t.x.p, t.x.ld, u->P(a.n_w), u->P(a.n_b), t.st, dxn, C, dx.p, dx.ld, u->G(a.n_w), u->G(a.n_b),
+                               B, T, C, GN_G, 0, 0, dout.p, dout.ld, dt));
+  u->arena.release(mk);
+  return 0;
+}
+
+int block_out_len(const Block& b, int Lin) {
+  int L = Lin;
+  for (auto& l : b.layers) if (l.kind == 0) { if (l.r.updown == 1) L /= 2; else if (l.r.updown == 2) L *= 2; }
+  return L;
+}
+
+// runs the layers of one block; the LAST layer writes into `out`
+int block_forward(eegldm_unet* u, const Block& b, View x, int B, int& L, const View& out) {
+  for (size_t j = 0; j < b.layers.size(); j++) {
+    const Layer& l = b.layers[j];
+    const bool last = j + 1 == b.layers.size();
+    const int cout = l.kind == 0 ? l.r.cout : l.a.c;
+    const int Lo = l.kind == 0 ? (l.r.updown == 1 ? L / 2 : (l.r.updown == 2 ? L * 2 : L)) : L;
+    View y = out;
+    if (!last) { ALLOC_OR_FAIL(y.p, u->alloc_act((long)B * Lo, cout)); y.ld = cout; y.C = cout; }
+    if (l.kind == 0) EEG_TRY(res_forward(u, l.r, x, B, L, y)); else EEG_TRY(attn_forward(u, l.a, x, B, L, y));
+    x = y; L = Lo;
+  }
+  return 0;
+}
+
+// backward through a block: dout = gradient of the block output; dx_dest = where the gradient of
+// the block input goes.  Tapes are consumed from the back of u->rt / u->at.
+int block_backward(eegldm_unet* u, const Block& b, View dout, const View& dx_dest, int B, size_t& ri, size_t& ai, void* demb_all) {
+  for (int j = (int)b.layers.size() - 1; j >= 0; j--) {
+    const Layer& l = b.layers[j];
+    View dx = dx_dest;
+    if (j > 0) {
+      const int cin = l.kind == 0 ? l.r.cin : l.a.c;
+      const long rows = l.kind == 0 ? (long)u->rt[ri - 1].B * u->rt[ri - 1].Lin : (long)u->at[ai - 1].B * u->at[ai - 1].T;
+      ALLOC_OR_FAIL(dx.p, u->alloc_act(rows, cin)); dx.ld = cin; dx.C = cin;
+    }
+    if (l.kind == 0) { EEG_TRY(res_backward(u, l.r, u->rt[--ri], dout, dx, demb_all)); }
+    else { EEG_TRY(attn_backward(u, l.a, u->at[--ai], dout, dx)); }
+    dout = dx;
+  }
+  return 0;
+}
+
+}  // namespace
+
+// ================================================================== C ABI
+extern "C" int eegldm_unet_create(eegldm_ctx* ctx, const eegldm_unet_cfg* cfg, eegldm_unet** out) {
+  EEG_CHECK(ctx && cfg && out, "null argument");
+  EEG_CHECK(cfg->num_heads == 1, "only num_heads=1 is implemented (every reference config)");
+  EEG_CHECK(cfg->model_channels % 32 == 0, "model_channels must be a multiple of 32 (GroupNorm(32))");
+  EEG_CHECK(cfg->n_mult >= 1 && cfg->n_mult <= 8 && cfg->n_attn >= 0 && cfg->n_attn <= 8, "bad channel_mult / attention_resolutions");
+  EEG_CHECK(cfg->dtype == EEGLDM_F32 || cfg->dtype == EEGLDM_BF16, "bad dtype");
+  eegldm_unet* u = new eegldm_unet();
+  u->ctx = ctx; u->cfg = *cfg; u->dtype = cfg->dtype;
+  int rc = build_plan(u);
+  if (rc) { delete u; return rc; }
+  *out = u;
+  return 0;
+}
+extern "C" int eegldm_unet_destroy(eegldm_unet* u) {
+  if (!u) return 0;
+  if (u->owns_wT && u->wT) hipFree(u->wT);
+  delete u;
+  return 0;
+}
+extern "C" int eegldm_unet_num_entries(const eegldm_unet* u) { return (int)u->entries.size(); }
+extern "C" long eegldm_unet_num_params(const eegldm_unet* u) { return u->nparams; }
+extern "C" int eegldm_unet_entry(const eegldm_unet* u, int i, char* name, int cap, long* offset, long* numel, int* ndim, int shape[3]) {
+  EEG_CHECK(u && i >= 0 && i < (int)u->entries.size(), "entry index %d out of range", i);
+  const Entry& e = u->entries[i];
+  if (name && cap > 0) { strncpy(name, e.name.c_str(), cap - 1); name[cap - 1] = 0; }
+  if (offset) *offset = e.offset;
+  if (numel) *numel = e.numel;
+  if (ndim) *ndim = e.ndim;
+  if (shape) { shape[0] = e.shape[0]; shape[1] = e.shape[1]; shape[2] = e.shape[2]; }
+  return 0;
+}
+extern "C" int eegldm_unet_bind(eegldm_unet* u, float* params, float* grads) {
+  EEG_CHECK(u && params, "null argument");
+  u->params = params; u->grads = grads;
+  if (u->dtype == EEGLDM_F32) { u->wT = params; u->owns_wT = false; }
+  else if (!u->wT) { HIP_TRY(hipMalloc(&u->wT, (size_t)u->nparams * 2)); u->owns_wT = true; }
+  return eegldm_unet_sync_weights(u);
+}
+extern "C" int eegldm_unet_sync_weights(eegldm_unet* u) {
+  EEG_CHECK(u && u->params, "bind parameters first");
+  if (u->dtype == EEGLDM_F32) return 0;
+  return eegldm_cast(u->ctx, u->params, u->wT, u->nparams, u->dtype);
+}
+
+extern "C" int eegldm_unet_forward(eegldm_unet* u, const float* x, const int64_t* tsteps, float* y, int B, int L, int training) {
+  EEG_CHECK(u && x && tsteps && y, "null argument");
+  EEG_CHECK(u->params, "bind parameters first");
+  EEG_CHECK(B > 0 && L > 0 && (L % (1 << (u->cfg.n_mult - 1))) == 0, "L=%d must be divisible by 2^(levels-1)", L);
+  (void)training;
+  eegldm_ctx* ctx = u->ctx; const int dt = u->dtype; const int mc = u->mc, te = u->te;
+  u->arena.reset(); u->rt.clear(); u->at.clear(); u->in_out.clear(); u->cat.clear();
+  u->B = B; u->L = L; u->have_tape = false;
+
+  // ---- timestep embedding MLP + all ResBlock embedding projections (unet.py:526-529, 316)
+  ALLOC_OR_FAIL(u->e0, u->alloc_act(B, mc));
+  EEG_TRY(ew_temb(ctx, tsteps, u->e0, B, mc, dt));
+  ALLOC_OR_FAIL(u->h1e, (float*)u->arena.alloc(sizeof(float) * B * te));
+  EEG_TRY(op_linear(ctx, dt, u->e0, mc, u->W(u->off_te0_w), mc, u->P(u->off_te0_b), u->h1e, te, B, te, mc, 1));
+  ALLOC_OR_FAIL(u->a1e, u->alloc_act(B, te));
+  EEG_TRY(ew_silu(ctx, u->h1e, u->a1e, (long)B * te, dt));
+  ALLOC_OR_FAIL(u->emb, (float*)u->arena.alloc(sizeof(float) * B * te));
+  EEG_TRY(op_linear(ctx, dt, u->a1e, te, u->W(u->off_te2_w), te, u->P(u->off_te2_b), u->emb, te, B, te, te, 1));
+  ALLOC_OR_FAIL(u->semb, u->alloc_act(B, te));
+  EEG_TRY(ew_silu(ctx, u->emb, u->semb, (long)B * te, dt));
+  ALLOC_OR_FAIL(u->emb_all, (float*)u->arena.alloc(sizeof(float) * (size_t)B * u->etot));
+  EEG_TRY(op_linear(ctx, dt, u->semb, te, u->W(u->off_emb_w), te, u->P(u->off_emb_b), u->emb_all, u->etot, B, u->etot, te, 1));
+
+  // ---- concat buffers: output block j consumes [h (c1) | skip (ich)] where skip = input block n_in-1-j
+  const int n_in = (int)u->in_blocks.size(), n_out = (int)u->out_blocks.size();
+  std::vector<int> in_len(n_in), in_ch(n_in);
+  { int Lc = L; in_len[0] = L; in_ch[0] = mc;
+    for (int i = 1; i < n_in; i++) { Lc = block_out_len(u->in_blocks[i], Lc); in_len[i] = Lc; in_ch[i] = u->in_blocks[i].cout; } }
+  u->cat.resize(n_out);
+  for (int j = 0; j < n_out; j++) {
+    const int i = n_in - 1 - j, c1 = u->skip_c1[j], C = c1 + in_ch[i];
+    ALLOC_OR_FAIL(u->cat[j].p, u->alloc_act((long)B * in_len[i], C)); u->cat[j].ld = C; u->cat[j].C = C;
+  }
+  u->in_out.resize(n_in);
+  for (int i = 0; i < n_in; i++) { const int j = n_in - 1 - i; u->in_out[i] = col_view(u->cat[j], u->skip_c1[j], in_ch[i], dt); }
+
+  // ---- input path
+  ALLOC_OR_FAIL(u->x0.p, u->alloc_act((long)B * L, u->cfg.in_channels)); u->x0.ld = u->cfg.in_channels; u->x0.C = u->cfg.in_channels;
+  EEG_TRY(eegldm_ncl_to_nlc(ctx, x, u->x0.p, u->x0.ld, B, u->cfg.in_channels, L, dt));
+  EEG_TRY(op_conv_fwd(ctx, dt, u->x0.p, u->x0.ld, u->W(u->off_cin_w), u->P(u->off_cin_b), u->in_out[0].p, u->in_out[0].ld, B, L,
+                      u->cfg.in_channels, mc, 3, 1, 1, 1, nullptr, 0, nullptr, 0));
+  View h = u->in_out[0]; int Lc = L;
+  for (int i = 1; i < n_in; i++) { EEG_TRY(block_forward(u, u->in_blocks[i], h, B, Lc, u->in_out[i])); h = u->in_out[i]; }
+  // ---- middle: writes into columns [0, c1) of concat buffer 0
+  { View dst = col_view(u->cat[0], 0, u->skip_c1[0], dt); EEG_TRY(block_forward(u, u->mid, h, B, Lc, dst)); }
+  // ---- output path
+  for (int j = 0; j < n_out; j++) {
+    View dst;
+    if (j + 1 < n_out) dst = col_view(u->cat[j + 1], 0, u->skip_c1[j + 1], dt);
+    else { ALLOC_OR_FAIL(dst.p, u->alloc_act((long)B * L, mc)); dst.ld = mc; dst.C = mc; }
+    int Lj = in_len[n_in - 1 - j];
+    EEG_TRY(block_forward(u, u->out_blocks[j], u->cat[j], B, Lj, dst));
+    h = dst;
+  }
+  // ---- out: GN + SiLU + conv3 (unet.py:501-505)
+  u->h_last = h;
+  ALLOC_OR_FAIL(u->st_out, (float*)u->arena.alloc(sizeof(float) * 2 * B * GN_G));
+  ALLOC_OR_FAIL(u->a_out.p, u->alloc_act((long)B * L, mc)); u->a_out.ld = mc; u->a_out.C = mc;
+  EEG_TRY(eegldm_groupnorm_fwd(ctx, h.p, h.ld, u->P(u->off_out_gw), u->P(u->off_out_gb), u->a_out.p, mc, u->st_out, B, L, mc, GN_G, GN_EPS, 1, 0, nullptr, 0, dt));
+  Arena::Mark mk = u->arena.mark();
+  void* yo; ALLOC_OR_FAIL(yo, u->alloc_act((long)B * L, u->cfg.out_channels));
+  EEG_TRY(op_conv_fwd(ctx, dt, u->a_out.p, mc, u->W(u->off_out_w), u->P(u->off_out_b), yo, u->cfg.out_channels, B, L, mc, u->cfg.out_channels,
+                      3, 1, 1, 1, nullptr, 0, nullptr, 0));
+  EEG_TRY(eegldm_nlc_to_ncl(ctx, yo, u->cfg.out_channels, y, B, u->cfg.out_channels, L, dt));
+  u->arena.release(mk);
+  u->have_tape = true;
+  return 0;
+}
+
+extern "C" int eegldm_unet_backward(eegldm_unet* u, const float* dy, float* dx_out) {
+  EEG_CHECK(u && dy, "null argument");
+  EEG_CHECK(u->have_tape, "call eegldm_unet_forward first");
+  EEG_CHECK(u->grads, "no gradient buffer bound");
+  eegldm_ctx* ctx = u->ctx; const int dt = u->dtype; const int mc = u->mc, te = u->te, B = u->B, L = u->L;
+  const int cin = u->cfg.in_channels, cout = u->cfg.out_channels;
+  const int n_in = (int)u->in_blocks.size(), n_out = (int)u->out_blocks.size();
+  u->have_tape = false;   // the tape is consumed
+
+  void* demb_all; ALLOC_OR_FAIL(demb_all, u->alloc_act(B, u->etot));
+  // ---- out conv + GN
+  View dyv; ALLOC_OR_FAIL(dyv.p, u->alloc_act((long)B * L, cout)); dyv.ld = cout;
+  EEG_TRY(eegldm_ncl_to_nlc(ctx, dy, dyv.p, cout, B, cout, L, dt));
+  EEG_TRY(op_conv_wgrad(ctx, dt, u->a_out.p, mc, dyv.p, cout, u->G(u->off_out_w), u->G(u->off_out_b), B, L, mc, cout, 3, 1, 1, 1));
+  View da; ALLOC_OR_FAIL(da.p, u->alloc_act((long)B * L, mc)); da.ld = mc;
+  EEG_TRY(op_conv_dgrad(ctx, dt, dyv.p, cout, u->W(u->off_out_w), da.p, mc, B, L, mc, cout, 3, 1, 1, 1, nullptr, 0));
+  View dh; ALLOC_OR_FAIL(dh.p, u->alloc_act((long)B * L, mc)); dh.ld = mc; dh.C = mc;
+  EEG_TRY(eegldm_groupnorm_bwd(ctx, u->h_last.p, u->h_last.ld, u->P(u->off_out_gw), u->P(u->off_out_gb), u->st_out, da.p, mc, dh.p, mc,
+                               u->G(u->off_out_gw), u->G(u->off_out_gb), B, L, mc, GN_G, 1, 0, nullptr, 0, dt));
+  // ---- output blocks, reversed.  Each yields d(cat_j); its skip half is kept for the input path.
+  size_t ri = u->rt.size(), ai = u->at.size();
+  std::vector<View> dskip(n_in);
+  std::vector<int> in_len(n_in), in_ch(n_in);
+  { int Lc = L; in_len[0] = L; in_ch[0] = mc;
+    for (int i = 1; i < n_in; i++) { Lc = block_out_len(u->in_blocks[i], Lc); in_len[i] = Lc; in_ch[i] = u->in_blocks[i].cout; } }
+  View dout = dh;
+  for (int j = n_out - 1; j >= 0; j--) {
+    const int i = n_in - 1 - j, C = u->cat[j].C;
+    View dcat; ALLOC_OR_FAIL(dcat.p, u->alloc_act((long)B * in_len[i], C)); dcat.ld = C; dcat.C = C;
+    EEG_TRY(block_backward(u, u->out_blocks[j], dout, dcat, B, ri, ai, demb_all));
+    dout = col_view(dcat, 0, u->skip_c1[j], dt);
+    dskip[i] = col_view(dcat, u->skip_c1[j], in_ch[i], dt);
+  }
+  // ---- middle
+  { View g; ALLOC_OR_FAIL(g.p, u->alloc_act((long)B * in_len[n_in - 1], in_ch[n_in - 1])); g.ld = in_ch[n_in - 1]; g.C = g.ld;
+    EEG_TRY(block_backward(u, u->mid, dout, g, B, ri, ai, demb_all));
+    dout = g; }
+  // ---- input blocks, reversed: gradient of block i's output = consumer's dx + skip gradient
+  for (int i = n_in - 1; i >= 1; i--) {
+    EEG_TRY(ew_add_rows(ctx, dout.p, dout.ld, dskip[i].p, dskip[i].ld, (long)B * in_len[i], in_ch[i], dt));
+    View g; ALLOC_OR_FAIL(g.p, u->alloc_act((long)B * in_len[i - 1], in_ch[i - 1])); g.ld = in_ch[i - 1]; g.C = g.ld;
+    EEG_TRY(block_backward(u, u->in_blocks[i], dout, g, B, ri, ai, demb_all));
+    dout = g;
+  }
+  EEG_TRY(ew_add_rows(ctx, dout.p, dout.ld, dskip[0].p, dskip[0].ld, (long)B * L, mc, dt));
+  // ---- conv_in
+  EEG_TRY(op_conv_wgrad(ctx, dt, u->x0.p, u->x0.ld, dout.p, dout.ld, u->G(u->off_cin_w), u->G(u->off_cin_b), B, L, cin, mc, 3, 1, 1, 1));
+  if (dx_out) {
+    void* dx0; ALLOC_OR_FAIL(dx0, u->alloc_act((long)B * L, cin));
+    EEG_TRY(op_conv_dgrad(ctx, dt, dout.p, dout.ld, u->W(u->off_cin_w), dx0, cin, B, L, cin, mc, 3, 1, 1, 1, nullptr, 0));
+    EEG_TRY(eegldm_nlc_to_ncl(ctx, dx0, cin, dx_out, B, cin, L, dt));
+  }
+  // ---- embedding MLP backward
+  const int E = u->etot;
+  EEG_TRY(ew_colsum(ctx, demb_all, E, nullptr, 0, u->G(u->off_emb_b), 1, B, E, dt));
+  EEG_TRY(op_linear_wgrad(ctx, dt, u->semb, te, demb_all, E, u->G(u->off_emb_w), te, B, E, te));
+  float* dsemb; ALLOC_OR_FAIL(dsemb, (float*)u->arena.alloc(sizeof(float) * B * te));
+  EEG_TRY(op_linear_dgrad(ctx, dt, demb_all, E, u->W(u->off_emb_w), te, dsemb, te, B, E, te, 1));
+  void* demb; ALLOC_OR_FAIL(demb, u->alloc_act(B, te));
+  EEG_TRY(ew_silu_bwd(ctx, dsemb, u->emb, demb, (long)B * te, dt));
+  EEG_TRY(ew_colsum(ctx, demb, te, nullptr, 0, u->G(u->off_te2_b), 1, B, te, dt));
+  EEG_TRY(op_linear_wgrad(ctx, dt, u->a1e, te, demb, te, u->G(u->off_te2_w), te, B, te, te));
+  float* da1; ALLOC_OR_FAIL(da1, (float*)u->arena.alloc(sizeof(float) * B * te));
+  EEG_TRY(op_linear_dgrad(ctx, dt, demb, te, u->W(u->off_te2_w), te, da1, te, B, te, te, 1));
+  void* dh1; ALLOC_OR_FAIL(dh1, u->alloc_act(B, te));
+  EEG_TRY(ew_silu_bwd(ctx, da1, u->h1e, dh1, (long)B * te, dt));
+  EEG_TRY(ew_colsum(ctx, dh1, te, nullptr, 0, u->G(u->off_te0_b), 1, B, te, dt));
+  EEG_TRY(op_linear_wgrad(ctx, dt, u->e0, mc, dh1, te, u->G(u->off_te0_w), mc, B, te, mc));
+  return 0;
+}
+
+extern "C" int eegldm_ldm_train_step(eegldm_unet* u, const float* latents, const float* noise, const int64_t* t, const float* acp,
+                                     int pred_type, int B, int L, float grad_scale, float* loss) {
+  EEG_CHECK(u && latents && noise && t && acp && loss, "null argument");
+  EEG_CHECK(pred_type == EEGLDM_PRED_EPSILON || pred_type == EEGLDM_PRED_V, "prediction type must be epsilon or v_prediction");
+  eegldm_ctx* ctx = u->ctx;
+  const int C = u->cfg.in_channels;
+  EEG_CHECK(u->cfg.out_channels == C, "LDM training needs in_channels == out_channels");
+  const long n = (long)B * C * L;
+  // small fp32 NCL staging buffers; they must outlive the arena reset inside forward, so they live in a side arena block
+  static thread_local float* stage = nullptr; static thread_local size_t stage_cap = 0;
+  if (stage_cap < (size_t)n * 4) {
+    if (stage) hipFree(stage);
+    HIP_TRY(hipMalloc(&stage, sizeof(float) * n * 4)); stage_cap = (size_t)n * 4;
+  }
+  float *noisy = stage, *pred = stage + n, *target = stage + 2 * n, *dpred = stage + 3 * n;
+  EEG_TRY(eegldm_add_noise(ctx, latents, noise, t, acp, noisy, B, (long)C * L));
+  EEG_TRY(eegldm_unet_forward(u, noisy, t, pred, B, L, 1));
+  const float* tgt = noise;
+  if (pred_type == EEGLDM_PRED_V) { EEG_TRY(eegldm_get_velocity(ctx, latents, noise, t, acp, target, B, (long)C * L)); tgt = target; }
+  EEG_TRY(eegldm_mse_loss(ctx, pred, tgt, loss, dpred, n, grad_scale));
+  return eegldm_unet_backward(u, dpred, nullptr);
+}
