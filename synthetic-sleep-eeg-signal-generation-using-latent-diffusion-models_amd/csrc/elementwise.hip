@@ -266,15 +266,15 @@ int ew_silu_bwd(eegldm_ctx* ctx, const float* dy, const float* x, void* dx, long
   DISPATCH_T(dtype, hipLaunchKernelGGL((silu_bwd_kernel<T>), dim3(grid1d(n, ctx)), dim3(NT), 0, ctx->stream, dy, x, (T*)dx, n));
   LAUNCH_CHECK(); return 0;
 }
-// out_ps: per-sample sums [B][ldo] in dtype (written; single L split) or NULL; total: fp32 [C] accumulated (+=) or NULL
-int ew_colsum(eegldm_ctx* ctx, const void* x, long ldx, void* out_ps, long ldo, float* total, int B, int L, int C, int dtype) {
+// out_ps: per-sample sums [B][ldo] fp32 (written; single L split) or NULL; total: fp32 [C] accumulated (+=) or NULL
+int ew_colsum(eegldm_ctx* ctx, const void* x, long ldx, float* out_ps, long ldo, float* total, int B, int L, int C, int dtype) {
   int lsplit = 1, rpb = L;
   if (!out_ps) {  // free to split L when only the fp32 atomic total is wanted
     int want = (ctx->num_cu * 4) / (B * ((C + 63) / 64)) ; if (want < 1) want = 1;
     int maxs = (L + 31) / 32; lsplit = want > maxs ? maxs : want; rpb = (L + lsplit - 1) / lsplit; lsplit = (L + rpb - 1) / rpb;
   }
   dim3 grid((C + 63) / 64, lsplit, B);
-  DISPATCH_T(dtype, hipLaunchKernelGGL((colsum_kernel<T, T>), grid, dim3(NT), 0, ctx->stream, (const T*)x, ldx, (T*)out_ps, ldo, total, L, C, rpb));
+  DISPATCH_T(dtype, hipLaunchKernelGGL((colsum_kernel<T, float>), grid, dim3(NT), 0, ctx->stream, (const T*)x, ldx, out_ps, ldo, total, L, C, rpb));
   LAUNCH_CHECK(); return 0;
 }
 int ew_softmax(eegldm_ctx* ctx, const float* S, void* P, long rows, int n, int dtype) {

@@ -6,7 +6,7 @@
 int ew_temb(eegldm_ctx*, const int64_t* t, void* out, int B, int dim, int dtype);
 int ew_silu(eegldm_ctx*, const float* x, void* y, long n, int dtype);
 int ew_silu_bwd(eegldm_ctx*, const float* dy, const float* x, void* dx, long n, int dtype);
-int ew_colsum(eegldm_ctx*, const void* x, long ldx, void* out_ps, long ldo, float* total, int B, int L, int C, int dtype);
+int ew_colsum(eegldm_ctx*, const void* x, long ldx, float* out_ps, long ldo, float* total, int B, int L, int C, int dtype);
 int ew_softmax(eegldm_ctx*, const float* S, void* P, long rows, int n, int dtype);
 int ew_softmax_bwd(eegldm_ctx*, const float* dP, const void* P, void* dS, long rows, int n, float alpha, int dtype);
 int ew_add_rows(eegldm_ctx*, void* dst, long ldd, const void* src, long lds, long rows, int C, int dtype);

@@ -89,7 +89,7 @@ struct eegldm_unet {
   // ---- forward tape
   int B = 0, L = 0; bool have_tape = false;
   View x0, h_last, a_out; float* st_out = nullptr;
-  void *e0 = nullptr, *a1e = nullptr, *semb = nullptr; float *h1e = nullptr, *emb = nullptr, *emb_all = nullptr;
+  float *e0 = nullptr, *a1e = nullptr, *semb = nullptr, *h1e = nullptr, *emb = nullptr, *emb_all = nullptr;   // embedding MLP runs in fp32
   std::vector<ResTape> rt; std::vector<AttnTape> at;
   std::vector<View> in_out;      // outputs of the input blocks (views into concat buffers)
   std::vector<View> cat;         // concat buffers per output block
@@ -246,7 +246,7 @@ int res_forward(eegldm_unet* u, const ResDesc& r, const View& x, int B, int Lin,
 }
 
 // dout: [B*Lout][cout]; writes dx: [B*Lin][cin]; accumulates parameter grads; demb_all gets per-sample sums
-int res_backward(eegldm_unet* u, const ResDesc& r, const ResTape& t, const View& dout, const View& dx, void* demb_all) {
+int res_backward(eegldm_unet* u, const ResDesc& r, const ResTape& t, const View& dout, const View& dx, float* demb_all) {
   eegldm_ctx* ctx = u->ctx; const int dt = u->dtype; const int B = t.B, Lin = t.Lin, Lout = t.Lout;
   Arena::Mark mk = u->arena.mark();
   View dxr = dout;
@@ -262,7 +262,7 @@ int res_backward(eegldm_unet* u, const ResDesc& r, const ResTape& t, const View&
   EEG_TRY(eegldm_groupnorm_bwd(ctx, t.h1.p, t.h1.ld, u->P(r.gn2_w), u->P(r.gn2_b), t.st2, da2.p, da2.ld, dh1.p, dh1.ld, u->G(r.gn2_w), u->G(r.gn2_b),
                                B, Lout, r.cout, GN_G, 1, 0, nullptr, 0, dt));
   // h1 = conv(a1) + b1 + emb_out[b]: per-sample column sums feed the embedding MLP, their total is db1
-  EEG_TRY(ew_colsum(ctx, dh1.p, dh1.ld, (char*)demb_all + (size_t)r.emb_col * dtype_size(dt), u->etot, u->G(r.c1_b), B, Lout, r.cout, dt));
+  EEG_TRY(ew_colsum(ctx, dh1.p, dh1.ld, demb_all + r.emb_col, u->etot, u->G(r.c1_b), B, Lout, r.cout, dt));
   EEG_TRY(op_conv_wgrad(ctx, dt, t.a1.p, t.a1.ld, dh1.p, dh1.ld, u->G(r.c1_w), nullptr, B, Lout, r.cin, r.cout, 3, 1, 1, 1));
   View da1; ALLOC_OR_FAIL(da1.p, u->alloc_act((long)B * Lout, r.cin)); da1.ld = r.cin;
   EEG_TRY(op_conv_dgrad(ctx, dt, dh1.p, dh1.ld, u->W(r.c1_w), da1.p, da1.ld, B, Lout, r.cin, r.cout, 3, 1, 1, 1, nullptr, 0));
@@ -334,7 +334,7 @@ int block_forward(eegldm_unet* u, const Block& b, View x, int B, int& L, const V
 
 // backward through a block: dout = gradient of the block output; dx_dest = where the gradient of
 // the block input goes.  Tapes are consumed from the back of u->rt / u->at.
-int block_backward(eegldm_unet* u, const Block& b, View dout, const View& dx_dest, int B, size_t& ri, size_t& ai, void* demb_all) {
+int block_backward(eegldm_unet* u, const Block& b, View dout, const View& dx_dest, int B, size_t& ri, size_t& ai, float* demb_all) {
   for (int j = (int)b.layers.size() - 1; j >= 0; j--) {
     const Layer& l = b.layers[j];
     View dx = dx_dest;
@@ -406,19 +406,22 @@ extern "C" int eegldm_unet_forward(eegldm_unet* u, const float* x, const int64_t
   u->arena.reset(); u->rt.clear(); u->at.clear(); u->in_out.clear(); u->cat.clear();
   u->B = B; u->L = L; u->have_tape = false;
 
-  // ---- timestep embedding MLP + all ResBlock embedding projections (unet.py:526-529, 316)
-  ALLOC_OR_FAIL(u->e0, u->alloc_act(B, mc));
-  EEG_TRY(ew_temb(ctx, tsteps, u->e0, B, mc, dt));
-  ALLOC_OR_FAIL(u->h1e, (float*)u->arena.alloc(sizeof(float) * B * te));
-  EEG_TRY(op_linear(ctx, dt, u->e0, mc, u->W(u->off_te0_w), mc, u->P(u->off_te0_b), u->h1e, te, B, te, mc, 1));
-  ALLOC_OR_FAIL(u->a1e, u->alloc_act(B, te));
-  EEG_TRY(ew_silu(ctx, u->h1e, u->a1e, (long)B * te, dt));
-  ALLOC_OR_FAIL(u->emb, (float*)u->arena.alloc(sizeof(float) * B * te));
-  EEG_TRY(op_linear(ctx, dt, u->a1e, te, u->W(u->off_te2_w), te, u->P(u->off_te2_b), u->emb, te, B, te, te, 1));
-  ALLOC_OR_FAIL(u->semb, u->alloc_act(B, te));
-  EEG_TRY(ew_silu(ctx, u->emb, u->semb, (long)B * te, dt));
-  ALLOC_OR_FAIL(u->emb_all, (float*)u->arena.alloc(sizeof(float) * (size_t)B * u->etot));
-  EEG_TRY(op_linear(ctx, dt, u->semb, te, u->W(u->off_emb_w), te, u->P(u->off_emb_b), u->emb_all, u->etot, B, u->etot, te, 1));
+  // ---- timestep embedding MLP + all ResBlock embedding projections (unet.py:526-529, 316).
+  // Tiny (B x 4mc): always fp32 on the fp32 master weights, whatever the activation dtype.
+  const int F = EEGLDM_F32;
+  auto fbuf = [&](long n) { return (float*)u->arena.alloc(sizeof(float) * (size_t)n); };
+  ALLOC_OR_FAIL(u->e0, fbuf((long)B * mc));
+  EEG_TRY(ew_temb(ctx, tsteps, u->e0, B, mc, F));
+  ALLOC_OR_FAIL(u->h1e, fbuf((long)B * te));
+  EEG_TRY(op_linear(ctx, F, u->e0, mc, u->P(u->off_te0_w), mc, u->P(u->off_te0_b), u->h1e, te, B, te, mc, 1));
+  ALLOC_OR_FAIL(u->a1e, fbuf((long)B * te));
+  EEG_TRY(ew_silu(ctx, u->h1e, u->a1e, (long)B * te, F));
+  ALLOC_OR_FAIL(u->emb, fbuf((long)B * te));
+  EEG_TRY(op_linear(ctx, F, u->a1e, te, u->P(u->off_te2_w), te, u->P(u->off_te2_b), u->emb, te, B, te, te, 1));
+  ALLOC_OR_FAIL(u->semb, fbuf((long)B * te));
+  EEG_TRY(ew_silu(ctx, u->emb, u->semb, (long)B * te, F));
+  ALLOC_OR_FAIL(u->emb_all, fbuf((long)B * u->etot));
+  EEG_TRY(op_linear(ctx, F, u->semb, te, u->P(u->off_emb_w), te, u->P(u->off_emb_b), u->emb_all, u->etot, B, u->etot, te, 1));
 
   // ---- concat buffers: output block j consumes [h (c1) | skip (ich)] where skip = input block n_in-1-j
   const int n_in = (int)u->in_blocks.size(), n_out = (int)u->out_blocks.size();
@@ -475,7 +478,7 @@ extern "C" int eegldm_unet_backward(eegldm_unet* u, const float* dy, float* dx_o
   const int n_in = (int)u->in_blocks.size(), n_out = (int)u->out_blocks.size();
   u->have_tape = false;   // the tape is consumed
 
-  void* demb_all; ALLOC_OR_FAIL(demb_all, u->alloc_act(B, u->etot));
+  float* demb_all; ALLOC_OR_FAIL(demb_all, (float*)u->arena.alloc(sizeof(float) * (size_t)B * u->etot));
   // ---- out conv + GN
   View dyv; ALLOC_OR_FAIL(dyv.p, u->alloc_act((long)B * L, cout)); dyv.ld = cout;
   EEG_TRY(eegldm_ncl_to_nlc(ctx, dy, dyv.p, cout, B, cout, L, dt));
@@ -518,22 +521,23 @@ extern "C" int eegldm_unet_backward(eegldm_unet* u, const float* dy, float* dx_o
     EEG_TRY(op_conv_dgrad(ctx, dt, dout.p, dout.ld, u->W(u->off_cin_w), dx0, cin, B, L, cin, mc, 3, 1, 1, 1, nullptr, 0));
     EEG_TRY(eegldm_nlc_to_ncl(ctx, dx0, cin, dx_out, B, cin, L, dt));
   }
-  // ---- embedding MLP backward
-  const int E = u->etot;
-  EEG_TRY(ew_colsum(ctx, demb_all, E, nullptr, 0, u->G(u->off_emb_b), 1, B, E, dt));
-  EEG_TRY(op_linear_wgrad(ctx, dt, u->semb, te, demb_all, E, u->G(u->off_emb_w), te, B, E, te));
-  float* dsemb; ALLOC_OR_FAIL(dsemb, (float*)u->arena.alloc(sizeof(float) * B * te));
-  EEG_TRY(op_linear_dgrad(ctx, dt, demb_all, E, u->W(u->off_emb_w), te, dsemb, te, B, E, te, 1));
-  void* demb; ALLOC_OR_FAIL(demb, u->alloc_act(B, te));
-  EEG_TRY(ew_silu_bwd(ctx, dsemb, u->emb, demb, (long)B * te, dt));
-  EEG_TRY(ew_colsum(ctx, demb, te, nullptr, 0, u->G(u->off_te2_b), 1, B, te, dt));
-  EEG_TRY(op_linear_wgrad(ctx, dt, u->a1e, te, demb, te, u->G(u->off_te2_w), te, B, te, te));
-  float* da1; ALLOC_OR_FAIL(da1, (float*)u->arena.alloc(sizeof(float) * B * te));
-  EEG_TRY(op_linear_dgrad(ctx, dt, demb, te, u->W(u->off_te2_w), te, da1, te, B, te, te, 1));
-  void* dh1; ALLOC_OR_FAIL(dh1, u->alloc_act(B, te));
-  EEG_TRY(ew_silu_bwd(ctx, da1, u->h1e, dh1, (long)B * te, dt));
-  EEG_TRY(ew_colsum(ctx, dh1, te, nullptr, 0, u->G(u->off_te0_b), 1, B, te, dt));
-  EEG_TRY(op_linear_wgrad(ctx, dt, u->e0, mc, dh1, te, u->G(u->off_te0_w), mc, B, te, mc));
+  // ---- embedding MLP backward (fp32)
+  const int E = u->etot, F = EEGLDM_F32;
+  auto fbuf = [&](long n) { return (float*)u->arena.alloc(sizeof(float) * (size_t)n); };
+  EEG_TRY(ew_colsum(ctx, demb_all, E, nullptr, 0, u->G(u->off_emb_b), 1, B, E, F));
+  EEG_TRY(op_linear_wgrad(ctx, F, u->semb, te, demb_all, E, u->G(u->off_emb_w), te, B, E, te));
+  float* dsemb; ALLOC_OR_FAIL(dsemb, fbuf((long)B * te));
+  EEG_TRY(op_linear_dgrad(ctx, F, demb_all, E, u->P(u->off_emb_w), te, dsemb, te, B, E, te, 1));
+  float* demb; ALLOC_OR_FAIL(demb, fbuf((long)B * te));
+  EEG_TRY(ew_silu_bwd(ctx, dsemb, u->emb, demb, (long)B * te, F));
+  EEG_TRY(ew_colsum(ctx, demb, te, nullptr, 0, u->G(u->off_te2_b), 1, B, te, F));
+  EEG_TRY(op_linear_wgrad(ctx, F, u->a1e, te, demb, te, u->G(u->off_te2_w), te, B, te, te));
+  float* da1; ALLOC_OR_FAIL(da1, fbuf((long)B * te));
+  EEG_TRY(op_linear_dgrad(ctx, F, demb, te, u->P(u->off_te2_w), te, da1, te, B, te, te, 1));
+  float* dh1; ALLOC_OR_FAIL(dh1, fbuf((long)B * te));
+  EEG_TRY(ew_silu_bwd(ctx, da1, u->h1e, dh1, (long)B * te, F));
+  EEG_TRY(ew_colsum(ctx, dh1, te, nullptr, 0, u->G(u->off_te0_b), 1, B, te, F));
+  EEG_TRY(op_linear_wgrad(ctx, F, u->e0, mc, dh1, te, u->G(u->off_te0_w), mc, B, te, mc));
   return 0;
 }
 

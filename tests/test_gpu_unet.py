@@ -27,24 +27,34 @@ def test_unet_vs_reference_golden(golden_dir, name, dtype):
     x = torch.from_numpy(normal((B, cfg["in_channels"], L), seed=sx))
     y = net(x, timesteps=torch.from_numpy(g["t"]))
     f32 = dtype == "float32"
-    # fp32 engine: reference tolerance of SURVEY 8c (fwd rtol 1e-4 / atol 1e-5 scaled by output magnitude, grads rtol 1e-3)
-    tol = dict(rtol=1e-4, atol=2e-5) if f32 else dict(rtol=5e-2, atol=5e-2)
-    G.assert_close(y, g["y"], **tol, name="y")
+    # fp32 engine (exact-fp32 MFMA, fp32/fp64 statistics): SURVEY 8c tolerance -- fwd rtol 1e-4 / atol 1e-5, grads rtol 1e-3.
+    # bf16 engine: storage rounding compounds over ~50 layers, so it is judged on relative L2 error.
+    def rel_l2(a, b):
+        a = a.detach().double().cpu().reshape(-1); b = torch.as_tensor(b).double().reshape(-1)
+        return float((a - b).norm() / (b.norm() + 1e-12))
+    if f32:
+        G.assert_close(y, g["y"], rtol=1e-4, atol=2e-5, name="y")
+    assert rel_l2(y, g["y"]) < (1e-5 if f32 else 4e-2), f"y rel L2 {rel_l2(y, g['y']):.3e}"
     net.zero_grad()
     dx = net.backward(torch.from_numpy(normal(tuple(y.shape), seed=sdy)), need_dx=True)
-    gt = dict(rtol=1e-3, atol=2e-4) if f32 else dict(rtol=8e-2, atol=8e-2)
-    G.assert_close(dx, g["dx"], **gt, name="dx")
+    if f32:
+        G.assert_close(dx, g["dx"], rtol=1e-3, atol=2e-5, name="dx")
+    assert rel_l2(dx, g["dx"]) < (2e-5 if f32 else 8e-2), f"dx rel L2 {rel_l2(dx, g['dx']):.3e}"
     grads = net.grad_dict()
+    # gradients that are mathematically ~0 (a bias in front of a 1-channel-per-group GroupNorm) are pure rounding noise:
+    # errors are measured against the tensor's own norm plus 1e-3 (fp32) / 3e-2 (bf16) of the model-wide gradient scale
+    gscale = max(float(g["g_l2:" + k]) for k in net.entries)
     worst = 0.0
     for k in net.entries:
         gr = grads[k].double().reshape(-1).cpu()
-        l2 = float(g["g_l2:" + k])
-        rel = abs(float(gr.norm()) - l2) / (l2 + 1e-6)
-        head_err = float(np.abs(gr[:32].float().numpy() - g["g_head:" + k]).max()) / (float(np.abs(g["g_head:" + k]).max()) + 1e-3)
+        l2 = float(g["g_l2:" + k]); n = gr.numel()
+        floor = (1e-3 if f32 else 3e-2) * gscale
+        rel = abs(float(gr.norm()) - l2) / (l2 + floor)
+        head = g["g_head:" + k].astype(np.float64)
+        head_err = float(np.linalg.norm(gr[:32].numpy() - head)) / (float(np.linalg.norm(head)) + floor)
         worst = max(worst, rel, head_err)
-        lim = 2e-3 if f32 else 6e-2
-        assert rel < lim and head_err < (5e-3 if f32 else 0.15), f"{k}: |g| rel err {rel:.2e}, head err {head_err:.2e}"
-    print(f"{name} {dtype}: worst param-grad error {worst:.2e}")
+        assert rel < (1e-3 if f32 else 6e-2) and head_err < (1e-3 if f32 else 0.12), f"{k}: |g| rel err {rel:.2e}, head err {head_err:.2e}"
+    print(f"{name} {dtype}: y relL2 {rel_l2(y, g['y']):.2e} dx relL2 {rel_l2(dx, g['dx']):.2e} worst param-grad error {worst:.2e}")
 
 
 def test_unet_full_size_shapes_and_state_dict(golden_dir):
