@@ -1,0 +1,163 @@
+"""Headline benchmark: 30-s EEG windows/sec on the hot path (BASELINE.json metric).
+
+    python bench.py --gpus N --steps K --warmup W            (N=1)
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...   (N>1)
+
+A "step" is one LDM train step of the reference loop (/root/reference/src/training/training.py:419-443)
+on one synthetic batch per GPU: draw timesteps + noise on device, [frozen AutoencoderKL encode when the
+AEKL executor is present], add_noise, UNet(config_ldm.yaml) forward, MSE, hand-written backward,
+gradient all-reduce (N>1, RCCL), fused Adam, bf16 weight refresh.  Inputs are resident in HBM when the
+timed region starts.  Prints ONE JSON line on rank 0; `roofline` is measured live with HIP events
+around every launch of the dominant kernel class on the library's stream; `cpu_baseline` times the
+oracle (torch CPU fp32, same math) on this host's cores on a bounded sample (rank 0, N=1 only).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for p in (ROOT, os.path.join(ROOT, "tests", "golden")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+UNET_CFG = dict(image_size=768, in_channels=1, out_channels=1, model_channels=128, num_res_blocks=2,
+                attention_resolutions=[8, 4], channel_mult=[1, 2, 4], resblock_updown=True)   # config_ldm.yaml:30-43, latent_channels=1
+MFMA_PEAK_TFLOPS = {"bf16": 2500.0, "f32": 157.3}     # dense, /opt/skills/guides/MI355X_MICROARCH.md
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=256, help="windows per GPU per step (C4: 2048 / 8 GPUs)")
+    ap.add_argument("--length", type=int, default=768, help="latent length (3072 / 4)")
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true")
+    return ap.parse_args()
+
+
+def cpu_baseline(batch=8, length=768, steps=2):
+    """Oracle LDM train step (fp32, torch CPU ops + autograd + torch.optim-style Adam) on a bounded sample."""
+    import torch
+    from oracle import losses as Ls
+    from oracle import steps as S
+    from oracle import unet as U
+    from param_gen import gen_param, normal, timesteps
+    cores = max(1, (os.cpu_count() or 2) // 2)
+    torch.set_num_threads(cores)
+    cfg = dict(UNET_CFG)
+    sd = {k: torch.from_numpy(gen_param(42, k, s)) for k, s in U.unet_param_shapes(cfg).items()}
+    acp = Ls.alphas_cumprod("scaled_linear_beta", 1000, 0.0015, 0.0195)
+    lat, nz = torch.from_numpy(normal((batch, 1, length), seed=1)), torch.from_numpy(normal((batch, 1, length), seed=2))
+    t = torch.from_numpy(timesteps(batch, seed=3))
+    state = {}
+    times = []
+    for i in range(steps + 1):
+        t0 = time.time()
+        _loss, grads, _ = S.ldm_train_step(sd, cfg, acp, lat, nz, t)
+        sd = S.adam_update(sd, grads, state, 1e-4, i + 1)
+        times.append(time.time() - t0)
+    dt = sorted(times[1:])[len(times[1:]) // 2]
+    return {"value": batch / dt, "unit": "windows/s", "cores": cores, "kind": "port",
+            "sample": f"oracle LDM train step (UNet config_ldm fwd+bwd+Adam, fp32), batch {batch} x (1,{length}), median of {steps} steps after 1 warm-up"}
+
+
+def main():
+    args = parse()
+    import torch
+    import eegldm
+    from eegldm import distributed as D
+    from eegldm.models import UNetModel
+    from eegldm.schedulers import DDPMScheduler
+    from eegldm.training import Adam, ldm_train_step, randint, randn
+
+    rank, local, world = D.init_from_env()
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world} (launch with torch.distributed.run)"
+    torch.cuda.set_device(local)
+    ctx = eegldm.default_context(local)
+    dev = torch.device("cuda", local)
+    B, L = args.batch, args.length
+    dtype = {"bf16": "bfloat16", "f32": "float32"}[args.dtype]
+
+    unet = UNetModel(**UNET_CFG, dtype=dtype, device=local)
+    g = torch.Generator().manual_seed(42)
+    sd = unet.state_dict()
+    # random-init weights of the named architecture; zero-initialised layers get N(0, 0.02) so no work is trivially zero
+    unet.load_state_dict({k: (torch.randn(v.shape, generator=g) * 0.02 if float(v.abs().sum()) == 0.0 else v) for k, v in sd.items()})
+    D.broadcast_flat(unet.flat); unet.sync_weights()
+    sched = DDPMScheduler(num_train_timesteps=1000, schedule="scaled_linear_beta", beta_start=0.0015, beta_end=0.0195, device=local)
+    opt = Adam(unet, lr=1e-4)
+    loss = torch.zeros(1, device=dev)
+    # synthetic latents of the AEKL output shape, resident in HBM (per-rank RNG stream)
+    latents = randn(ctx, (B, 1, L), seed=1234 + rank)
+
+    def step(i):
+        t = randint(ctx, B, 1000, seed=1235 + rank, offset=i * B)
+        noise = randn(ctx, (B, 1, L), seed=1236 + rank, offset=i * B * L)
+        unet.zero_grad()
+        ldm_train_step(unet, sched, latents, noise, t, loss_out=loss)
+        D.allreduce_mean_flat(unet.flat_grad)
+        opt.step()
+
+    for i in range(args.warmup):
+        step(i)
+    if world > 1:
+        torch.distributed.barrier()
+    torch.cuda.synchronize()
+    t0 = time.time()
+    for i in range(args.steps):
+        step(args.warmup + i)
+    if world > 1:
+        torch.distributed.barrier()
+    torch.cuda.synchronize()
+    dt = torch.tensor([time.time() - t0], device=dev)
+    if world > 1:
+        torch.distributed.all_reduce(dt, op=torch.distributed.ReduceOp.MAX)
+    elapsed = float(dt)
+    final_loss = float(loss)
+
+    roofline = None
+    if rank == 0 and not args.no_roofline:
+        ctx.prof_enable(True)
+        for i in range(2):
+            step(args.warmup + args.steps + i)
+        torch.cuda.synchronize()
+        summ = ctx.prof_summary()
+        ctx.prof_enable(False)
+        dom = max(summ.items(), key=lambda kv: kv[1]["ms"])
+        k, v = dom
+        ach = v["flops"] / (v["ms"] * 1e-3) / 1e12 if v["ms"] > 0 else 0.0
+        peak = MFMA_PEAK_TFLOPS[args.dtype]
+        roofline = {"bound": "mfma", "kernel": k, "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4),
+                    "traffic": None, "launches_per_step": v["launches"] // 2, "avg_launch_us": round(1e3 * v["ms"] / max(1, v["launches"]), 2),
+                    "gflop_per_launch": round(v["flops"] / max(1, v["launches"]) / 1e9, 3),
+                    "all_gemm_classes": {kk: {"tflops": round(vv["flops"] / (vv["ms"] * 1e-3) / 1e12, 1) if vv["ms"] > 0 else 0.0,
+                                              "ms_per_step": round(vv["ms"] / 2, 3), "launches_per_step": vv["launches"] // 2}
+                                         for kk, vv in summ.items() if vv["launches"]}}
+
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        cpu = cpu_baseline()
+
+    if rank == 0:
+        out = {
+            "metric": "EEG windows/sec (LDM train step)", "value": round(world * B * args.steps / elapsed, 2), "unit": "windows/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed / args.steps, 3),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
+            "config": {"workload": "LDM train step: config_ldm.yaml UNet (30.5M params, latent_channels=1) over (B,1,768) latents, "
+                                   "epsilon-prediction MSE, Adam lr 1e-4 [BASELINE configs[2]/[3]]",
+                       "per_gpu_batch": B, "global_batch": world * B, "latent_len": L, "parallelism": f"dp{world}",
+                       "final_loss": round(final_loss, 5), "gflop_per_window": 41.7},
+            "roofline": roofline, "cpu_baseline": cpu,
+        }
+        print(json.dumps(out))
+    if world > 1:
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

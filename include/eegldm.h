@@ -64,6 +64,13 @@ int eegldm_ctx_sync(eegldm_ctx* ctx);
  * torch.cuda.Event only sees torch's current stream). */
 int eegldm_timer_start(eegldm_ctx* ctx);
 int eegldm_timer_stop_ms(eegldm_ctx* ctx, float* ms_host);
+/* Per-launch profiling of the MFMA GEMM / implicit-conv family: while enabled, every launch
+ * is bracketed by HIP events on the context's stream.  eegldm_prof_summary returns, for one
+ * kernel class (0 conv fwd, 1 conv dgrad, 2 conv wgrad, 3 gemm NT, 4 gemm NN, 5 gemm TN),
+ * the summed algorithmic FLOPs (2*M*N*K*taps), summed kernel time and launch count since
+ * eegldm_prof_enable(ctx, 1).  Host outputs. */
+int eegldm_prof_enable(eegldm_ctx* ctx, int on);
+int eegldm_prof_summary(eegldm_ctx* ctx, int kernel_class, double* flops_host, double* ms_host, int* launches_host);
 
 /* ------------------------------------------------------------------ layout / packing */
 int eegldm_ncl_to_nlc(eegldm_ctx*, const float* src_ncl, void* dst_nlc, long ld_dst, int B, int C, int L, int dst_dtype);

@@ -38,6 +38,8 @@ SIGNATURES = {
     "eegldm_ctx_sync": [_vp],
     "eegldm_timer_start": [_vp],
     "eegldm_timer_stop_ms": [_vp, C.POINTER(_f)],
+    "eegldm_prof_enable": [_vp, _i],
+    "eegldm_prof_summary": [_vp, _i, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(_i)],
     "eegldm_ncl_to_nlc": [_vp, _vp, _vp, _l, _i, _i, _i, _i],
     "eegldm_nlc_to_ncl": [_vp, _vp, _l, _vp, _i, _i, _i, _i],
     "eegldm_pack_conv_weight": [_vp, _vp, _vp, _i, _i, _i],
@@ -123,6 +125,19 @@ class Context:
         ms = C.c_float()
         check(lib.eegldm_timer_stop_ms(self.h, C.byref(ms)))
         return ms.value
+
+    PROF_CLASSES = ["conv3_fwd_implicit_gemm", "conv3_dgrad_implicit_gemm", "conv_wgrad_splitk_gemm", "gemm_nt", "gemm_nn", "gemm_tn"]
+
+    def prof_enable(self, on=True):
+        check(lib.eegldm_prof_enable(self.h, 1 if on else 0))
+
+    def prof_summary(self):
+        out = {}
+        for i, name in enumerate(self.PROF_CLASSES):
+            f, ms, n = C.c_double(), C.c_double(), C.c_int()
+            check(lib.eegldm_prof_summary(self.h, i, C.byref(f), C.byref(ms), C.byref(n)))
+            out[name] = dict(flops=f.value, ms=ms.value, launches=n.value)
+        return out
 
     def __del__(self):
         try:

@@ -53,3 +53,25 @@ extern "C" int eegldm_timer_stop_ms(eegldm_ctx* c, float* ms) {
   HIP_TRY(hipEventElapsedTime(ms, g_timer.a, g_timer.b));
   return 0;
 }
+
+// ------------------------------------------------------------------ per-launch GEMM profiling (HIP events on the ctx stream)
+extern "C" int eegldm_prof_enable(eegldm_ctx* c, int on) {
+  EEG_CHECK(c, "null ctx");
+  for (auto& r : c->prof) { hipEventDestroy(r.a); hipEventDestroy(r.b); }
+  c->prof.clear();
+  c->prof_on = on != 0;
+  return 0;
+}
+extern "C" int eegldm_prof_summary(eegldm_ctx* c, int cls, double* flops, double* ms, int* launches) {
+  EEG_CHECK(c && flops && ms && launches, "null argument");
+  EEG_CHECK(cls >= 0 && cls < PROF_NCLASS, "class %d out of range", cls);
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  double f = 0, t = 0; int n = 0;
+  for (auto& r : c->prof) {
+    if (r.cls != cls) continue;
+    float e = 0; HIP_TRY(hipEventElapsedTime(&e, r.a, r.b));
+    f += r.flops; t += e; n++;
+  }
+  *flops = f; *ms = t; *launches = n;
+  return 0;
+}

@@ -4,6 +4,7 @@
 #include <stdint.h>
 #include <stdio.h>
 #include <string>
+#include <vector>
 
 #include "../../include/eegldm.h"
 
@@ -32,6 +33,9 @@ void eegldm_set_error(const std::string& msg);
 #define LAUNCH_CHECK() HIP_TRY(hipGetLastError())
 
 // ---------------------------------------------------------------- context
+struct ProfRec { int cls; double flops; hipEvent_t a, b; };
+enum { PROF_CONV_FWD = 0, PROF_CONV_DGRAD = 1, PROF_CONV_WGRAD = 2, PROF_GEMM_NT = 3, PROF_GEMM_NN = 4, PROF_GEMM_TN = 5, PROF_NCLASS = 6 };
+
 struct eegldm_ctx {
   int device;
   hipStream_t stream;
@@ -40,6 +44,9 @@ struct eegldm_ctx {
   void* scratch;
   size_t scratch_bytes;
   int num_cu;
+  // optional per-launch HIP-event profiling of the GEMM family (bench.py roofline leg)
+  bool prof_on = false;
+  std::vector<ProfRec> prof;
 };
 
 static inline size_t dtype_size(int dt) { return dt == EEGLDM_F32 ? 4 : 2; }

@@ -377,7 +377,19 @@ int gemm_launch(eegldm_ctx* ctx, const GemmArgs& a_in) {
   else EEG_CHECK(a.K % epc == 0 && a.ldb % epc == 0, "B: K, ldb must be multiples of %d", epc);
   EEG_CHECK(!(a.atomic_out || a.splitk > 1) || a.out_f32, "atomic / split-K output must be f32");
   if (a.splitk > 1) a.atomic_out = 1;
-  if (a.dtype == EEGLDM_F32) return launch_modes<float>(ctx, a);
-  if (a.dtype == EEGLDM_BF16) return launch_modes<bf16_t>(ctx, a);
-  EEG_FAIL(EEGLDM_ERR_UNSUPPORTED, "dtype %d", a.dtype);
+  ProfRec rec; bool prof = ctx->prof_on;
+  if (prof) {
+    rec.cls = a.amode == GA_CONV ? (a.bmode == GB_NT ? PROF_CONV_FWD : PROF_CONV_DGRAD)
+              : (a.amode == GA_TR ? (a.conv_map ? PROF_CONV_WGRAD : PROF_GEMM_TN) : (a.bmode == GB_NT ? PROF_GEMM_NT : PROF_GEMM_NN));
+    // algorithmic work: the transposed (strided) dgrad multiplies a half-zero virtual signal; only the real taps count
+    rec.flops = 2.0 * a.M * a.N * (double)a.K * a.taps * a.ztaps * a.batch / (a.ups > 1 ? a.ups : 1);
+    HIP_TRY(hipEventCreate(&rec.a)); HIP_TRY(hipEventCreate(&rec.b));
+    HIP_TRY(hipEventRecord(rec.a, ctx->stream));
+  }
+  int rc;
+  if (a.dtype == EEGLDM_F32) rc = launch_modes<float>(ctx, a);
+  else if (a.dtype == EEGLDM_BF16) rc = launch_modes<bf16_t>(ctx, a);
+  else EEG_FAIL(EEGLDM_ERR_UNSUPPORTED, "dtype %d", a.dtype);
+  if (prof) { HIP_TRY(hipEventRecord(rec.b, ctx->stream)); ctx->prof.push_back(rec); }
+  return rc;
 }

@@ -1,0 +1,119 @@
+"""DDPMScheduler / DDIMScheduler / DiffusionInferer with the monai-generative interface the
+reference scripts use (/root/reference/src/train_ldm.py:199-200, src/training/training.py:420-436,
+src/sample_trials.py:136-163, src/train_pure_ldm.py:124,134, src/sample_trials_ddpm.py:83-102).
+Schedule tables are tiny host-side constants; the per-element arithmetic runs in
+libeegldm (eegldm_add_noise / eegldm_get_velocity / eegldm_ddim_step)."""
+import numpy as np
+import torch
+
+from ._lib import lib, check, ptr, default_context, PRED
+
+_SCHEDULE_ALIASES = {"linear": "linear_beta", "linear_beta": "linear_beta", "scaled_linear": "scaled_linear_beta",
+                     "scaled_linear_beta": "scaled_linear_beta"}
+
+
+def _betas(schedule, n, beta_start, beta_end):
+    schedule = _SCHEDULE_ALIASES[schedule]
+    if schedule == "linear_beta":
+        return torch.linspace(beta_start, beta_end, n, dtype=torch.float32)
+    return torch.linspace(beta_start ** 0.5, beta_end ** 0.5, n, dtype=torch.float32) ** 2
+
+
+class _Scheduler:
+    def __init__(self, num_train_timesteps=1000, schedule="linear_beta", beta_start=1e-4, beta_end=2e-2,
+                 prediction_type="epsilon", clip_sample=True, beta_schedule=None, device=0, ctx=None):
+        if beta_schedule is not None:       # old monai-generative kwarg, still used by train_ldm.py:199
+            schedule = beta_schedule
+        if prediction_type not in PRED:
+            raise ValueError(f"prediction_type must be one of {list(PRED)}")
+        self.num_train_timesteps = num_train_timesteps
+        self.prediction_type = prediction_type
+        self.clip_sample = clip_sample
+        self.betas = _betas(schedule, num_train_timesteps, beta_start, beta_end)
+        self.alphas = 1.0 - self.betas
+        self.alphas_cumprod = torch.cumprod(self.alphas, dim=0)
+        self.one = torch.tensor(1.0)
+        self.ctx = ctx or default_context(device)
+        self.device = torch.device("cuda", self.ctx.device)
+        self._acp_dev = self.alphas_cumprod.to(self.device)
+        self.timesteps = torch.from_numpy(np.arange(0, num_train_timesteps)[::-1].copy().astype(np.int64))
+        self.num_inference_steps = num_train_timesteps
+
+    def to(self, *a, **k):
+        return self
+
+    def add_noise(self, original_samples, noise, timesteps):
+        x = original_samples.to(self.device, torch.float32).contiguous()
+        nz = noise.to(self.device, torch.float32).contiguous()
+        t = timesteps.to(self.device, torch.int64).contiguous()
+        out = torch.empty_like(x)
+        check(lib.eegldm_add_noise(self.ctx.h, ptr(x), ptr(nz), ptr(t), ptr(self._acp_dev), ptr(out), x.shape[0], x[0].numel()))
+        return out
+
+    def get_velocity(self, sample, noise, timesteps):
+        x = sample.to(self.device, torch.float32).contiguous()
+        nz = noise.to(self.device, torch.float32).contiguous()
+        t = timesteps.to(self.device, torch.int64).contiguous()
+        out = torch.empty_like(x)
+        check(lib.eegldm_get_velocity(self.ctx.h, ptr(x), ptr(nz), ptr(t), ptr(self._acp_dev), ptr(out), x.shape[0], x[0].numel()))
+        return out
+
+
+class DDPMScheduler(_Scheduler):
+    """Training-side scheduler (add_noise / get_velocity).  The ancestral `step` of the
+    reference's logging sampler (util.py:241-243) is outside the hot path and not provided."""
+
+    def set_timesteps(self, num_inference_steps):
+        self.num_inference_steps = num_inference_steps
+        ratio = self.num_train_timesteps // num_inference_steps
+        self.timesteps = torch.from_numpy((np.arange(0, num_inference_steps) * ratio).round()[::-1].copy().astype(np.int64))
+
+
+class DDIMScheduler(_Scheduler):
+    def __init__(self, *a, set_alpha_to_one=True, steps_offset=0, **k):
+        super().__init__(*a, **k)
+        self.final_alpha_cumprod = 1.0 if set_alpha_to_one else float(self.alphas_cumprod[0])
+        self.steps_offset = steps_offset
+
+    def set_timesteps(self, num_inference_steps):
+        if num_inference_steps > self.num_train_timesteps:
+            raise ValueError("num_inference_steps cannot exceed num_train_timesteps")
+        self.num_inference_steps = num_inference_steps
+        ratio = self.num_train_timesteps // num_inference_steps
+        self.timesteps = torch.from_numpy((np.arange(0, num_inference_steps) * ratio).round()[::-1].copy().astype(np.int64)) + self.steps_offset
+
+    def step(self, model_output, timestep, sample, eta=0.0, generator=None):
+        if eta != 0.0:
+            raise NotImplementedError("the reference samples with eta = 0 (sample_trials.py:163)")
+        t = int(timestep)
+        prev_t = t - self.num_train_timesteps // self.num_inference_steps
+        a_t = float(self.alphas_cumprod[t])
+        a_prev = float(self.alphas_cumprod[prev_t]) if prev_t >= 0 else self.final_alpha_cumprod
+        mo = model_output.to(self.device, torch.float32).contiguous()
+        x = sample.to(self.device, torch.float32).contiguous()
+        prev, x0 = torch.empty_like(x), torch.empty_like(x)
+        check(lib.eegldm_ddim_step(self.ctx.h, ptr(mo), ptr(x), a_t, a_prev, PRED[self.prediction_type], int(self.clip_sample),
+                                   ptr(prev), ptr(x0), x.numel()))
+        return prev, x0
+
+
+class DiffusionInferer:
+    """training_diffusion.py:146 / sample_trials_ddpm.py:99-102."""
+
+    def __init__(self, scheduler):
+        self.scheduler = scheduler
+
+    def __call__(self, inputs, diffusion_model, noise, timesteps, condition=None):
+        noisy = self.scheduler.add_noise(original_samples=inputs, noise=noise, timesteps=timesteps)
+        return diffusion_model(x=noisy, timesteps=timesteps)
+
+    @torch.no_grad()
+    def sample(self, input_noise, diffusion_model, scheduler=None, save_intermediates=False, intermediate_steps=100,
+               conditioning=None, verbose=False):
+        scheduler = scheduler or self.scheduler
+        image = input_noise
+        for t in scheduler.timesteps:
+            tt = torch.full((image.shape[0],), int(t), dtype=torch.int64)
+            out = diffusion_model(image, timesteps=tt)
+            image, _ = scheduler.step(out, int(t), image)
+        return image

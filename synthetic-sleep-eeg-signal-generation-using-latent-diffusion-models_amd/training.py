@@ -1,0 +1,60 @@
+"""Train-step bodies of the reference loops, each one native call per phase:
+  ldm_train_step  <-> /root/reference/src/training/training.py:419-443
+  Adam            <-> torch.optim.Adam as used at /root/reference/src/train_ldm.py:208
+Gradients live in each model's flat fp32 buffer, so data-parallel training is ONE
+all-reduce over a contiguous tensor (see eegldm.distributed)."""
+import torch
+
+from ._lib import lib, check, ptr, PRED
+
+
+class Adam:
+    """torch.optim.Adam defaults (betas 0.9/0.999, eps 1e-8, no weight decay) as one fused HIP
+    kernel over the model's flat parameter buffer."""
+
+    def __init__(self, model, lr=1e-3, betas=(0.9, 0.999), eps=1e-8):
+        self.model, self.lr, self.betas, self.eps = model, lr, betas, eps
+        self.m = torch.zeros_like(model.flat)
+        self.v = torch.zeros_like(model.flat)
+        self.step_count = 0
+        self.param_groups = [{"lr": lr}]
+
+    def zero_grad(self, set_to_none=True):
+        self.model.zero_grad()
+
+    def step(self, grad_inv_scale=1.0):
+        self.step_count += 1
+        md = self.model
+        check(lib.eegldm_adam_step(md.ctx.h, ptr(md.flat), ptr(md.flat_grad), ptr(self.m), ptr(self.v), md.flat.numel(),
+                                   self.param_groups[0]["lr"], self.betas[0], self.betas[1], self.eps, self.step_count, grad_inv_scale))
+        md.sync_weights()
+
+    def state_dict(self):
+        return {"step": self.step_count, "exp_avg": self.m.clone(), "exp_avg_sq": self.v.clone(), "lr": self.param_groups[0]["lr"]}
+
+    def load_state_dict(self, sd):
+        self.step_count = int(sd["step"]); self.m.copy_(sd["exp_avg"]); self.v.copy_(sd["exp_avg_sq"])
+        self.param_groups[0]["lr"] = sd.get("lr", self.lr)
+
+
+def ldm_train_step(unet, scheduler, latents, noise, timesteps, loss_out=None, grad_scale=1.0):
+    """add_noise -> UNet forward -> MSE against noise (epsilon) or velocity (v_prediction) -> backward.
+    Accumulates into unet.flat_grad; returns the device scalar loss tensor."""
+    if loss_out is None:
+        loss_out = torch.zeros(1, device=unet.device)
+    B, _C, L = latents.shape
+    check(lib.eegldm_ldm_train_step(unet.h, ptr(latents), ptr(noise), ptr(timesteps), ptr(scheduler._acp_dev),
+                                    PRED[scheduler.prediction_type], B, L, grad_scale, ptr(loss_out)))
+    return loss_out
+
+
+def randn(ctx, shape, seed, offset=0, device=None):
+    out = torch.empty(shape, device=device or torch.device("cuda", ctx.device), dtype=torch.float32)
+    check(lib.eegldm_randn(ctx.h, ptr(out), out.numel(), seed, offset))
+    return out
+
+
+def randint(ctx, n, high, seed, offset=0, device=None):
+    out = torch.empty(n, device=device or torch.device("cuda", ctx.device), dtype=torch.int64)
+    check(lib.eegldm_randint(ctx.h, ptr(out), n, high, seed, offset))
+    return out
