@@ -180,6 +180,82 @@ int eegldm_fill(eegldm_ctx*, float* p, long n, float value);
 int eegldm_ldm_train_step(eegldm_unet*, const float* latents, const float* noise, const int64_t* t,
                           const float* acp, int pred_type, int B, int L, float grad_scale, float* loss);
 
+/* ------------------------------------------------------------------ losses of the AEKL step (fp32 NCL tensors)
+ * L1Loss (train_autoencoderkl.py:155,206): *loss = mean|a-b|; da_accum (nullable) += grad_weight * d/da.
+ * PatchAdversarialLoss("least_squares") (:156,214,226,228): LeakyReLU(0.05) on the logits, MSE against 1 / 0;
+ *   dlogits (nullable) = grad_weight * d/dlogits.
+ * JukeboxLoss(spatial_dims=1, reduction="sum") (:158,208): sum over windows and bins of (|FFT_ortho(recon)| -
+ *   |FFT_ortho(target)|)^2; d_recon_accum (nullable) += grad_weight * d/d recon.  C must be 1; L in {3072, 768, 256, 96}. */
+int eegldm_l1_loss(eegldm_ctx*, const float* a, const float* b, float* loss, float* da_accum, long n, float grad_weight);
+int eegldm_lsgan_loss(eegldm_ctx*, const float* logits, int target_is_real, float* loss, float* dlogits, long n, float grad_weight);
+int eegldm_spectral_loss(eegldm_ctx*, const float* recon, const float* target, float* loss, float* d_recon_accum,
+                         int B, int C, int L, float grad_weight);
+int eegldm_axpy(eegldm_ctx*, float* y, const float* x, float a, long n);
+
+/* ------------------------------------------------------------------ AutoencoderKL
+ * AutoencoderKL(spatial_dims=1, in_channels, out_channels, num_channels, latent_channels, num_res_blocks,
+ * norm_num_groups, attention_levels=all False, with_*_nonlocal_attn=False) -- monai-generative, as configured by
+ * config/config_aekl_eeg.yaml:19-28 and train_autoencoderkl.py:129-133.  Parameter table / bind / sync as for the UNet;
+ * keys follow monai-generative's state_dict naming (encoder.blocks.N..., quant_conv_mu.conv..., ...). */
+typedef struct {
+  int in_channels, out_channels;
+  int n_levels; int num_channels[8];
+  int latent_channels, num_res_blocks, norm_num_groups;
+  int dtype;
+} eegldm_aekl_cfg;
+int eegldm_aekl_create(eegldm_ctx*, const eegldm_aekl_cfg* cfg, eegldm_aekl** out);
+int eegldm_aekl_destroy(eegldm_aekl*);
+int eegldm_aekl_num_entries(const eegldm_aekl*);
+long eegldm_aekl_num_params(const eegldm_aekl*);
+int eegldm_aekl_entry(const eegldm_aekl*, int i, char* name, int name_cap, long* offset, long* numel, int* ndim, int shape[3]);
+int eegldm_aekl_bind(eegldm_aekl*, float* params, float* grads);
+int eegldm_aekl_sync_weights(eegldm_aekl*);
+/* encode + sampling (encode_stage_2_inputs, train_ldm.py:148; Stage1Wrapper, training.py:15-26):
+ * x (B,in,L) -> z = mu + eps*sigma (B,lat,L/2^(levels-1)); eps NULL -> z = mu.  z / z_mu / z_sigma nullable. */
+int eegldm_aekl_encode(eegldm_aekl*, const float* x, const float* eps, float* z, float* z_mu, float* z_sigma, int B, int L);
+/* decode_stage_2_outputs (sample_trials.py:166): z (B,lat,Ll) -> (B,out,Ll*2^(levels-1)) */
+int eegldm_aekl_decode(eegldm_aekl*, const float* z, float* recon, int B, int Ll);
+/* forward(x) -> (reconstruction, z_mu, z_sigma) with the reparameterisation noise eps supplied by the caller;
+ * kl (nullable device scalar) receives 0.5*sum(mu^2+sigma^2-log sigma^2-1)/B.  Keeps the tape for backward. */
+int eegldm_aekl_forward(eegldm_aekl*, const float* x, const float* eps, float* recon, float* z_mu, float* z_sigma,
+                        float* kl, int B, int L);
+/* grads += d/dparams [ <d_recon, recon> + kl_weight * KL ]; dx nullable */
+int eegldm_aekl_backward(eegldm_aekl*, const float* d_recon, float kl_weight, float* dx);
+
+/* ------------------------------------------------------------------ PatchDiscriminator
+ * PatchDiscriminator(spatial_dims=1, num_layers_d, num_channels, in_channels, out_channels, kernel_size=3,
+ * norm="BATCH", bias, padding=1) -- monai-generative, config/config_aekl_eeg.yaml:30-40.  forward returns the
+ * last feature map (the reference indexes [-1], train_autoencoderkl.py:213).  BatchNorm running statistics live
+ * in a separate caller-owned flat fp32 `buffers` array (num_batches_tracked stored as a float count). */
+typedef struct {
+  int in_channels, out_channels, num_channels, num_layers_d, kernel_size, padding, bias;
+  int dtype;
+} eegldm_disc_cfg;
+int eegldm_disc_create(eegldm_ctx*, const eegldm_disc_cfg* cfg, eegldm_disc** out);
+int eegldm_disc_destroy(eegldm_disc*);
+int eegldm_disc_num_entries(const eegldm_disc*);
+long eegldm_disc_num_params(const eegldm_disc*);
+int eegldm_disc_entry(const eegldm_disc*, int i, char* name, int name_cap, long* offset, long* numel, int* ndim, int shape[3]);
+int eegldm_disc_num_buffer_entries(const eegldm_disc*);
+long eegldm_disc_num_buffers(const eegldm_disc*);
+int eegldm_disc_buffer_entry(const eegldm_disc*, int i, char* name, int name_cap, long* offset, long* numel, int* ndim, int shape[3]);
+int eegldm_disc_bind(eegldm_disc*, float* params, float* grads, float* buffers);
+int eegldm_disc_sync_weights(eegldm_disc*);
+/* training != 0: batch statistics + running-stat update (momentum 0.1); else running statistics */
+int eegldm_disc_forward(eegldm_disc*, const float* x, float* logits, int B, int L, int training);
+/* param_grads != 0: grads += d/dparams; dx (nullable) = d/dx */
+int eegldm_disc_backward(eegldm_disc*, const float* dlogits, float* dx, int param_grads);
+
+/* The AEKL/GAN step body (train_autoencoderkl.py:203-234) for one batch: generator forward, L1 + KL + adversarial
+ * (+ spectral when use_spectral) backward into the autoencoder's gradient buffer, then the two discriminator
+ * passes (fake -> 0, real -> 1, 0.5*adv_weight each) into the discriminator's gradient buffer; BatchNorm running
+ * statistics are updated three times, as in the reference.  Both gradient buffers must be zeroed by the caller
+ * (optimizer.zero_grad) and both Adam steps run after the call; the result equals the reference order because the
+ * discriminator passes only consume `reconstruction.detach()`.
+ * losses: device float[6] = recons L1, spectral, KL, generator adversarial, D fake, D real.  recon_out nullable. */
+int eegldm_aekl_train_step(eegldm_aekl*, eegldm_disc*, const float* x, const float* eps, float adv_weight, float kl_weight,
+                           float spectral_weight, int use_spectral, float* losses, float* recon_out, int B, int L);
+
 #ifdef __cplusplus
 }
 #endif

@@ -20,7 +20,9 @@ from . import unet as U
 
 
 def _leafify(sd):
-    return {k: (v.detach().clone().requires_grad_(True) if v.is_floating_point() else v.clone()) for k, v in sd.items()}
+    """Trainable leaves for parameters; BatchNorm running statistics stay plain buffers."""
+    return {k: (v.detach().clone().requires_grad_(True) if (v.is_floating_point() and "running" not in k) else v.detach().clone())
+            for k, v in sd.items()}
 
 
 def ldm_train_step(unet_sd, unet_cfg, acp, latents, noise, t, prediction_type="epsilon"):
@@ -70,7 +72,7 @@ def aekl_train_step(ae_sd, ae_cfg, d_sd, d_cfg, x, eps, adv_weight, kl_weight, s
     g_grads = {k: v.grad for k, v in g.items() if v.grad is not None}
     new_g = adam_update({k: v.detach() for k, v in g.items()}, g_grads, opt_state_g, lr_g, step)
 
-    d2 = _leafify({k: v.detach() if torch.is_tensor(v) else v for k, v in d.items()})
+    d2 = _leafify({k: v.detach() for k, v in d.items()})
     running = {}
     lf = A.disc_forward(d2, d_cfg, recon.detach().contiguous(), True, running)[-1]
     for k, v in running.items():      # update #2
@@ -81,9 +83,8 @@ def aekl_train_step(ae_sd, ae_cfg, d_sd, d_cfg, x, eps, adv_weight, kl_weight, s
     loss_d_real = Ls.patch_adv_loss(lr_, True, True)
     disc_loss = (loss_d_fake + loss_d_real) * 0.5
     (adv_weight * disc_loss).backward()
-    d_grads = {k: v.grad for k, v in d2.items() if v.is_floating_point() and v.grad is not None}
-    new_d = adam_update({k: (v.detach() if v.is_floating_point() else v) for k, v in d2.items()}, d_grads,
-                        opt_state_d, lr_d, step)
+    d_grads = {k: v.grad for k, v in d2.items() if v.grad is not None}
+    new_d = adam_update({k: v.detach() for k, v in d2.items()}, d_grads, opt_state_d, lr_d, step)
     for k, v in running.items():      # update #3
         new_d[k] = v
     losses = dict(recons=rec_loss.detach(), spectral=spec.detach(), kl=kl.detach(), gen=gen_loss.detach(),

@@ -71,7 +71,48 @@ SIGNATURES = {
     "eegldm_unet_forward": [_vp, _vp, _vp, _vp, _i, _i, _i],
     "eegldm_unet_backward": [_vp, _vp, _vp],
     "eegldm_ldm_train_step": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _f, _vp],
+    "eegldm_l1_loss": [_vp, _vp, _vp, _vp, _vp, _l, _f],
+    "eegldm_lsgan_loss": [_vp, _vp, _i, _vp, _vp, _l, _f],
+    "eegldm_spectral_loss": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _f],
+    "eegldm_axpy": [_vp, _vp, _vp, _f, _l],
+    "eegldm_aekl_create": [_vp, _vp, C.POINTER(_vp)],
+    "eegldm_aekl_destroy": [_vp],
+    "eegldm_aekl_num_entries": [_vp],
+    "eegldm_aekl_num_params": [_vp],
+    "eegldm_aekl_entry": [_vp, _i, C.c_char_p, _i, C.POINTER(_l), C.POINTER(_l), C.POINTER(_i), C.POINTER(_i)],
+    "eegldm_aekl_bind": [_vp, _vp, _vp],
+    "eegldm_aekl_sync_weights": [_vp],
+    "eegldm_aekl_encode": [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i],
+    "eegldm_aekl_decode": [_vp, _vp, _vp, _i, _i],
+    "eegldm_aekl_forward": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i],
+    "eegldm_aekl_backward": [_vp, _vp, _f, _vp],
+    "eegldm_disc_create": [_vp, _vp, C.POINTER(_vp)],
+    "eegldm_disc_destroy": [_vp],
+    "eegldm_disc_num_entries": [_vp],
+    "eegldm_disc_num_params": [_vp],
+    "eegldm_disc_entry": [_vp, _i, C.c_char_p, _i, C.POINTER(_l), C.POINTER(_l), C.POINTER(_i), C.POINTER(_i)],
+    "eegldm_disc_num_buffer_entries": [_vp],
+    "eegldm_disc_num_buffers": [_vp],
+    "eegldm_disc_buffer_entry": [_vp, _i, C.c_char_p, _i, C.POINTER(_l), C.POINTER(_l), C.POINTER(_i), C.POINTER(_i)],
+    "eegldm_disc_bind": [_vp, _vp, _vp, _vp],
+    "eegldm_disc_sync_weights": [_vp],
+    "eegldm_disc_forward": [_vp, _vp, _vp, _i, _i, _i],
+    "eegldm_disc_backward": [_vp, _vp, _vp, _i],
+    "eegldm_aekl_train_step": [_vp, _vp, _vp, _vp, _f, _f, _f, _i, _vp, _vp, _i, _i],
 }
+for _n in ("eegldm_aekl_num_params", "eegldm_disc_num_params", "eegldm_disc_num_buffers"):
+    if hasattr(lib, _n):
+        getattr(lib, _n).restype = C.c_long
+
+
+class AeklCfg(C.Structure):
+    _fields_ = [("in_channels", _i), ("out_channels", _i), ("n_levels", _i), ("num_channels", _i * 8),
+                ("latent_channels", _i), ("num_res_blocks", _i), ("norm_num_groups", _i), ("dtype", _i)]
+
+
+class DiscCfg(C.Structure):
+    _fields_ = [("in_channels", _i), ("out_channels", _i), ("num_channels", _i), ("num_layers_d", _i),
+                ("kernel_size", _i), ("padding", _i), ("bias", _i), ("dtype", _i)]
 
 
 class UNetCfg(C.Structure):

@@ -1,0 +1,455 @@
+// AutoencoderKL and PatchDiscriminator executors + the fused AEKL/GAN train-step body.
+// Host code: sequences kernels of gemm.hip / direct_conv.hip / norm.hip / losses.hip / spectral.hip.
+//
+// Mirrors (structure per SURVEY.md Appendix B; MONAI-Generative source is absent, PARITY UNPINNED):
+//   AutoencoderKL(spatial_dims=1, in/out_channels, num_channels, latent_channels, num_res_blocks,
+//                 norm_num_groups, attention_levels all False)      config/config_aekl_eeg.yaml:19-28
+//       encode / sampling / decode / forward                        twin /root/reference/src/models/ae_kl.py:259-291
+//   PatchDiscriminator(spatial_dims=1, num_layers_d, num_channels, in/out_channels, kernel_size=3,
+//                 norm="BATCH", bias=False, padding=1)              config/config_aekl_eeg.yaml:30-40
+//   train step body                                                 /root/reference/src/train_autoencoderkl.py:200-234
+#include <string>
+#include <vector>
+
+#include "net.h"
+
+int ls_bn_lrelu_fwd(eegldm_ctx*, const void* x, long ldx, const float* gamma, const float* beta, float* stats, float* rmean, float* rvar,
+                    float* nbt, void* y, long ldy, long rows, int C, float slope, int training, int dtype);
+int ls_bn_lrelu_bwd(eegldm_ctx*, const void* x, long ldx, const float* gamma, const float* beta, const float* stats, const void* dy, long lddy,
+                    void* dx, long lddx, float* dgamma, float* dbeta, long rows, int C, float slope, int dtype);
+int ls_upsample2(eegldm_ctx*, const void* x, long ldx, void* y, long ldy, long rows_in, int C, int dtype);
+int ls_upsample2_bwd(eegldm_ctx*, const void* dy, long lddy, void* dx, long lddx, long rows_in, int C, int dtype);
+int ls_reparam(eegldm_ctx*, const void* mu, const void* lv, const float* eps, void* z, float* sigma, float* kl, long n, int B, int dtype);
+int ls_reparam_bwd(eegldm_ctx*, const void* mu, const void* lv, const float* eps, const float* sigma, const void* dz, void* dmu, void* dlv, long n,
+                   float klw_over_B, int dtype);
+
+namespace {
+
+enum { OP_CONV = 0, OP_RES = 1, OP_UPS = 2, OP_GN = 3, OP_ACT = 4 };
+struct Op {
+  int kind = 0;
+  int cin = 0, cout = 0, k = 3, stride = 1, pl = 1, pr = 1; long w = -1, b = -1;       // conv
+  ResDesc r;                                                                           // res
+  int groups = 1; long gw = -1, gb = -1;                                               // gn (no activation)
+  long bn_w = -1, bn_b = -1, rm = -1, rv = -1, nbt = -1; float slope = 0.2f;           // act: bn_w < 0 -> plain LeakyReLU
+};
+struct OpTape { View x; float* st = nullptr; int Lin = 0, Lout = 0; };
+
+struct SeqNet : NetBase {
+  float* buffers = nullptr;     // BatchNorm running statistics (discriminator)
+  int forward_seq(const std::vector<Op>& ops, View x, int B, int& L, View* out, std::vector<OpTape>& tape, int training);
+  int backward_seq(const std::vector<Op>& ops, std::vector<OpTape>& tape, int B, View dy, View* dx, bool need_dx);
+};
+
+int SeqNet::forward_seq(const std::vector<Op>& ops, View x, int B, int& L, View* out, std::vector<OpTape>& tape, int training) {
+  const int dt = dtype;
+  for (size_t i = 0; i < ops.size(); i++) {
+    const Op& o = ops[i];
+    OpTape t; t.x = x; t.Lin = L;
+    View y;
+    if (o.kind == OP_CONV) {
+      const int Lo = (L + o.pl + o.pr - o.k) / o.stride + 1;
+      ALLOC_OR_FAIL(y.p, alloc_act((long)B * Lo, o.cout)); y.ld = o.cout; y.C = o.cout;
+      EEG_TRY(op_conv_fwd(ctx, dt, x.p, x.ld, W(o.w), o.b >= 0 ? P(o.b) : nullptr, y.p, y.ld, B, L, o.cin, o.cout, o.k, o.stride, o.pl, o.pr,
+                          nullptr, 0, nullptr, 0));
+      L = Lo;
+    } else if (o.kind == OP_RES) {
+      ALLOC_OR_FAIL(y.p, alloc_act((long)B * L, o.r.cout)); y.ld = o.r.cout; y.C = o.r.cout;
+      EEG_TRY(res_forward(this, o.r, x, B, L, y));
+    } else if (o.kind == OP_UPS) {
+      ALLOC_OR_FAIL(y.p, alloc_act((long)B * 2 * L, x.C)); y.ld = x.C; y.C = x.C;
+      EEG_TRY(ls_upsample2(ctx, x.p, x.ld, y.p, y.ld, (long)B * L, x.C, dt));
+      L *= 2;
+    } else if (o.kind == OP_GN) {
+      ALLOC_OR_FAIL(y.p, alloc_act((long)B * L, x.C)); y.ld = x.C; y.C = x.C;
+      ALLOC_OR_FAIL(t.st, arena.alloc(sizeof(float) * 2 * B * o.groups));
+      EEG_TRY(eegldm_groupnorm_fwd(ctx, x.p, x.ld, P(o.gw), P(o.gb), y.p, y.ld, t.st, B, L, x.C, o.groups, GN_EPS, 0, 0, nullptr, 0, dt));
+    } else {  // OP_ACT
+      ALLOC_OR_FAIL(y.p, alloc_act((long)B * L, x.C)); y.ld = x.C; y.C = x.C;
+      if (o.bn_w >= 0) {
+        ALLOC_OR_FAIL(t.st, arena.alloc(sizeof(float) * 2 * x.C));
+        EEG_TRY(ls_bn_lrelu_fwd(ctx, x.p, x.ld, P(o.bn_w), P(o.bn_b), t.st, buffers ? buffers + o.rm : nullptr, buffers ? buffers + o.rv : nullptr,
+                                buffers ? buffers + o.nbt : nullptr, y.p, y.ld, (long)B * L, x.C, o.slope, training, dt));
+      } else {
+        EEG_TRY(ls_bn_lrelu_fwd(ctx, x.p, x.ld, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, y.p, y.ld, (long)B * L, x.C, o.slope, training, dt));
+      }
+    }
+    t.Lout = L;
+    tape.push_back(t);
+    x = y;
+  }
+  *out = x;
+  return 0;
+}
+
+int SeqNet::backward_seq(const std::vector<Op>& ops, std::vector<OpTape>& tape, int B, View dy, View* dx_out, bool need_dx) {
+  const int dt = dtype;
+  for (int i = (int)ops.size() - 1; i >= 0; i--) {
+    const Op& o = ops[i];
+    const OpTape t = tape.back(); tape.pop_back();
+    const bool want_dx = need_dx || i > 0;
+    View dx; dx.ld = t.x.C; dx.C = t.x.C;
+    if (want_dx) ALLOC_OR_FAIL(dx.p, alloc_act((long)B * t.Lin, t.x.C));
+    if (o.kind == OP_CONV) {
+      if (param_grads)
+        EEG_TRY(op_conv_wgrad(ctx, dt, t.x.p, t.x.ld, dy.p, dy.ld, G(o.w), o.b >= 0 ? G(o.b) : nullptr, B, t.Lin, o.cin, o.cout, o.k, o.stride, o.pl, o.pr));
+      if (want_dx) EEG_TRY(op_conv_dgrad(ctx, dt, dy.p, dy.ld, W(o.w), dx.p, dx.ld, B, t.Lin, o.cin, o.cout, o.k, o.stride, o.pl, o.pr, nullptr, 0));
+    } else if (o.kind == OP_RES) {
+      // res_backward always produces dx (cheap relative to the block); allocate if the caller did not want it
+      if (!want_dx) ALLOC_OR_FAIL(dx.p, alloc_act((long)B * t.Lin, t.x.C));
+      const ResTape rtp = rt.back(); rt.pop_back();
+      EEG_TRY(res_backward(this, o.r, rtp, dy, dx, nullptr));
+    } else if (o.kind == OP_UPS) {
+      if (want_dx) EEG_TRY(ls_upsample2_bwd(ctx, dy.p, dy.ld, dx.p, dx.ld, (long)B * t.Lin, t.x.C, dt));
+    } else if (o.kind == OP_GN) {
+      if (!want_dx) ALLOC_OR_FAIL(dx.p, alloc_act((long)B * t.Lin, t.x.C));
+      EEG_TRY(eegldm_groupnorm_bwd(ctx, t.x.p, t.x.ld, P(o.gw), P(o.gb), t.st, dy.p, dy.ld, dx.p, dx.ld, param_grads ? G(o.gw) : nullptr,
+                                   param_grads ? G(o.gb) : nullptr, B, t.Lin, t.x.C, o.groups, 0, 0, nullptr, 0, dt));
+    } else {
+      if (!want_dx) ALLOC_OR_FAIL(dx.p, alloc_act((long)B * t.Lin, t.x.C));
+      if (o.bn_w >= 0)
+        EEG_TRY(ls_bn_lrelu_bwd(ctx, t.x.p, t.x.ld, P(o.bn_w), P(o.bn_b), t.st, dy.p, dy.ld, dx.p, dx.ld, param_grads ? G(o.bn_w) : nullptr,
+                                param_grads ? G(o.bn_b) : nullptr, (long)B * t.Lin, t.x.C, o.slope, dt));
+      else
+        EEG_TRY(ls_bn_lrelu_bwd(ctx, t.x.p, t.x.ld, nullptr, nullptr, nullptr, dy.p, dy.ld, dx.p, dx.ld, nullptr, nullptr, (long)B * t.Lin, t.x.C, o.slope, dt));
+    }
+    dy = dx;
+  }
+  if (dx_out) *dx_out = dy;
+  return 0;
+}
+
+struct Layout {
+  long off = 0;
+  long take(long n) { long o = off; off += (n + 7) / 8 * 8; return o; }
+};
+
+Op make_conv(NetBase* n, Layout& lay, const std::string& p, int cin, int cout, int k, int stride, int pl, int pr, bool bias) {
+  Op o; o.kind = OP_CONV; o.cin = cin; o.cout = cout; o.k = k; o.stride = stride; o.pl = pl; o.pr = pr;
+  o.w = lay.take((long)cout * cin * k); n->add_entry(p + ".weight", o.w, 3, cout, cin, k);
+  if (bias) { o.b = lay.take(cout); n->add_entry(p + ".bias", o.b, 1, cout); }
+  return o;
+}
+Op make_res(NetBase* n, Layout& lay, const std::string& p, int cin, int cout, int groups) {
+  Op o; o.kind = OP_RES; ResDesc& r = o.r;
+  r.cin = cin; r.cout = cout; r.updown = 0; r.groups = groups; r.emb_col = -1;
+  r.gn1_w = lay.take(cin); r.gn1_b = lay.take(cin);
+  n->add_entry(p + ".norm1.weight", r.gn1_w, 1, cin); n->add_entry(p + ".norm1.bias", r.gn1_b, 1, cin);
+  r.c1_w = lay.take((long)cout * cin * 3); r.c1_b = lay.take(cout);
+  n->add_entry(p + ".conv1.conv.weight", r.c1_w, 3, cout, cin, 3); n->add_entry(p + ".conv1.conv.bias", r.c1_b, 1, cout);
+  r.gn2_w = lay.take(cout); r.gn2_b = lay.take(cout);
+  n->add_entry(p + ".norm2.weight", r.gn2_w, 1, cout); n->add_entry(p + ".norm2.bias", r.gn2_b, 1, cout);
+  r.c2_w = lay.take((long)cout * cout * 3); r.c2_b = lay.take(cout);
+  n->add_entry(p + ".conv2.conv.weight", r.c2_w, 3, cout, cout, 3); n->add_entry(p + ".conv2.conv.bias", r.c2_b, 1, cout);
+  r.sk_w = r.sk_b = -1;
+  if (cin != cout) {
+    r.sk_w = lay.take((long)cout * cin); r.sk_b = lay.take(cout);
+    n->add_entry(p + ".nin_shortcut.conv.weight", r.sk_w, 3, cout, cin, 1); n->add_entry(p + ".nin_shortcut.conv.bias", r.sk_b, 1, cout);
+  }
+  return o;
+}
+Op make_gn(NetBase* n, Layout& lay, const std::string& p, int c, int groups) {
+  Op o; o.kind = OP_GN; o.groups = groups; o.cin = o.cout = c;
+  o.gw = lay.take(c); o.gb = lay.take(c);
+  n->add_entry(p + ".weight", o.gw, 1, c); n->add_entry(p + ".bias", o.gb, 1, c);
+  return o;
+}
+}  // namespace
+
+// ================================================================== AutoencoderKL
+struct eegldm_aekl : SeqNet {
+  eegldm_aekl_cfg cfg;
+  std::vector<Op> enc, dec; Op q_mu, q_lv;
+  std::vector<OpTape> tape_enc, tape_dec;
+  Arena stage;                      // fp32 NCL staging that must survive arena resets (train step)
+  // tape of the latent head
+  int B = 0, L = 0, Ll = 0; bool have_tape = false;
+  View h_enc, mu, lv; float *eps_nlc = nullptr, *sigma = nullptr;
+};
+
+extern "C" int eegldm_aekl_create(eegldm_ctx* ctx, const eegldm_aekl_cfg* cfg, eegldm_aekl** out) {
+  EEG_CHECK(ctx && cfg && out, "null argument");
+  EEG_CHECK(cfg->n_levels >= 1 && cfg->n_levels <= 8 && cfg->num_res_blocks >= 1, "bad num_channels / num_res_blocks");
+  EEG_CHECK(cfg->dtype == EEGLDM_F32 || cfg->dtype == EEGLDM_BF16, "bad dtype");
+  for (int i = 0; i < cfg->n_levels; i++)
+    EEG_CHECK(cfg->num_channels[i] % cfg->norm_num_groups == 0, "num_channels[%d]=%d not divisible by norm_num_groups=%d", i, cfg->num_channels[i], cfg->norm_num_groups);
+  eegldm_aekl* a = new eegldm_aekl();
+  a->ctx = ctx; a->cfg = *cfg; a->dtype = cfg->dtype;
+  a->arena.min_block = (size_t)256 << 20; a->stage.min_block = (size_t)32 << 20;
+  const int nl = cfg->n_levels, G = cfg->norm_num_groups, lat = cfg->latent_channels;
+  const int* nc = cfg->num_channels;
+  Layout lay;
+  // encoder (MONAI Encoder: conv, [res x nrb, downsample] per level, norm, conv)
+  int bi = 0;
+  auto ename = [&](const char* s) { return std::string("encoder.blocks.") + std::to_string(bi) + s; };
+  a->enc.push_back(make_conv(a, lay, ename(".conv"), cfg->in_channels, nc[0], 3, 1, 1, 1, true)); bi++;
+  int oc = nc[0];
+  for (int i = 0; i < nl; i++) {
+    int ic = oc; oc = nc[i];
+    for (int r = 0; r < cfg->num_res_blocks; r++) { a->enc.push_back(make_res(a, lay, ename(""), ic, oc, G)); bi++; ic = oc; }
+    if (i != nl - 1) { a->enc.push_back(make_conv(a, lay, ename(".conv.conv"), ic, ic, 3, 2, 0, 1, true)); bi++; }   // pad (0,1), stride 2
+  }
+  a->enc.push_back(make_gn(a, lay, ename(""), oc, G)); bi++;
+  a->enc.push_back(make_conv(a, lay, ename(".conv"), oc, lat, 3, 1, 1, 1, true)); bi++;
+  // decoder (conv, [res x nrb, upsample] per level reversed, norm, conv); post_quant_conv is prepended at run time
+  bi = 0;
+  auto dname = [&](const char* s) { return std::string("decoder.blocks.") + std::to_string(bi) + s; };
+  std::vector<Op> dec;
+  dec.push_back(make_conv(a, lay, dname(".conv"), lat, nc[nl - 1], 3, 1, 1, 1, true)); bi++;
+  oc = nc[nl - 1];
+  for (int i = nl - 1; i >= 0; i--) {
+    int ic = oc; oc = nc[i];
+    for (int r = 0; r < cfg->num_res_blocks; r++) { dec.push_back(make_res(a, lay, dname(""), ic, oc, G)); bi++; ic = oc; }
+    if (i != 0) {
+      Op u; u.kind = OP_UPS; dec.push_back(u);
+      dec.push_back(make_conv(a, lay, dname(".conv.conv"), ic, ic, 3, 1, 1, 1, true)); bi++;
+    }
+  }
+  dec.push_back(make_gn(a, lay, dname(""), oc, G)); bi++;
+  dec.push_back(make_conv(a, lay, dname(".conv"), oc, cfg->out_channels, 3, 1, 1, 1, true)); bi++;
+  a->q_mu = make_conv(a, lay, "quant_conv_mu.conv", lat, lat, 1, 1, 0, 0, true);
+  a->q_lv = make_conv(a, lay, "quant_conv_log_sigma.conv", lat, lat, 1, 1, 0, 0, true);
+  a->dec.push_back(make_conv(a, lay, "post_quant_conv.conv", lat, lat, 1, 1, 0, 0, true));
+  for (auto& o : dec) a->dec.push_back(o);
+  a->nparams = lay.off;
+  *out = a;
+  return 0;
+}
+extern "C" int eegldm_aekl_destroy(eegldm_aekl* a) { delete a; return 0; }
+extern "C" int eegldm_aekl_num_entries(const eegldm_aekl* a) { return (int)a->entries.size(); }
+extern "C" long eegldm_aekl_num_params(const eegldm_aekl* a) { return a->nparams; }
+extern "C" int eegldm_aekl_entry(const eegldm_aekl* a, int i, char* name, int cap, long* offset, long* numel, int* ndim, int shape[3]) {
+  return entry_query(a, i, name, cap, offset, numel, ndim, shape);
+}
+extern "C" int eegldm_aekl_bind(eegldm_aekl* a, float* params, float* grads) { EEG_CHECK(a && params, "null argument"); return a->bind(params, grads); }
+extern "C" int eegldm_aekl_sync_weights(eegldm_aekl* a) { EEG_CHECK(a, "null argument"); return a->sync_weights(); }
+
+namespace {
+int lat_len(const eegldm_aekl* a, int L) { return L >> (a->cfg.n_levels - 1); }
+
+// encoder + heads + sampling.  Leaves mu / lv / sigma / z in the arena; returns z view.
+int aekl_encode_impl(eegldm_aekl* a, const float* x, const float* eps, int B, int L, View* z_out, float* kl) {
+  EEG_CHECK((L % (1 << (a->cfg.n_levels - 1))) == 0, "L=%d must be divisible by 2^(levels-1)", L);
+  eegldm_ctx* ctx = a->ctx; const int dt = a->dtype, lat = a->cfg.latent_channels, cin = a->cfg.in_channels;
+  a->arena.reset(); a->rt.clear(); a->tape_enc.clear(); a->tape_dec.clear();
+  a->B = B; a->L = L; a->have_tape = false;
+  View x0; ALLOC_OR_FAIL(x0.p, a->alloc_act((long)B * L, cin)); x0.ld = cin; x0.C = cin;
+  EEG_TRY(eegldm_ncl_to_nlc(ctx, x, x0.p, cin, B, cin, L, dt));
+  int Lc = L;
+  EEG_TRY(a->forward_seq(a->enc, x0, B, Lc, &a->h_enc, a->tape_enc, 1));
+  a->Ll = Lc;
+  const long n = (long)B * Lc * lat;
+  ALLOC_OR_FAIL(a->mu.p, a->alloc_act((long)B * Lc, lat)); a->mu.ld = lat; a->mu.C = lat;
+  ALLOC_OR_FAIL(a->lv.p, a->alloc_act((long)B * Lc, lat)); a->lv.ld = lat; a->lv.C = lat;
+  EEG_TRY(op_conv_fwd(ctx, dt, a->h_enc.p, a->h_enc.ld, a->W(a->q_mu.w), a->P(a->q_mu.b), a->mu.p, lat, B, Lc, lat, lat, 1, 1, 0, 0, nullptr, 0, nullptr, 0));
+  EEG_TRY(op_conv_fwd(ctx, dt, a->h_enc.p, a->h_enc.ld, a->W(a->q_lv.w), a->P(a->q_lv.b), a->lv.p, lat, B, Lc, lat, lat, 1, 1, 0, 0, nullptr, 0, nullptr, 0));
+  a->eps_nlc = nullptr;
+  if (eps) {
+    ALLOC_OR_FAIL(a->eps_nlc, a->arena.alloc(sizeof(float) * n));
+    EEG_TRY(eegldm_ncl_to_nlc(ctx, eps, a->eps_nlc, lat, B, lat, Lc, EEGLDM_F32));
+  }
+  ALLOC_OR_FAIL(a->sigma, a->arena.alloc(sizeof(float) * n));
+  View z; ALLOC_OR_FAIL(z.p, a->alloc_act((long)B * Lc, lat)); z.ld = lat; z.C = lat;
+  if (kl) HIP_TRY(hipMemsetAsync(kl, 0, sizeof(float), ctx->stream));
+  EEG_TRY(ls_reparam(ctx, a->mu.p, a->lv.p, a->eps_nlc, z.p, a->sigma, kl, n, B, dt));
+  *z_out = z;
+  return 0;
+}
+int aekl_export_latents(eegldm_aekl* a, const View& z, float* z_ncl, float* mu_ncl, float* sigma_ncl) {
+  const int lat = a->cfg.latent_channels;
+  if (z_ncl) EEG_TRY(eegldm_nlc_to_ncl(a->ctx, z.p, lat, z_ncl, a->B, lat, a->Ll, a->dtype));
+  if (mu_ncl) EEG_TRY(eegldm_nlc_to_ncl(a->ctx, a->mu.p, lat, mu_ncl, a->B, lat, a->Ll, a->dtype));
+  if (sigma_ncl) EEG_TRY(eegldm_nlc_to_ncl(a->ctx, a->sigma, lat, sigma_ncl, a->B, lat, a->Ll, EEGLDM_F32));
+  return 0;
+}
+int aekl_decode_impl(eegldm_aekl* a, const View& z, int B, int Ll, float* recon) {
+  int Lc = Ll; View y;
+  EEG_TRY(a->forward_seq(a->dec, z, B, Lc, &y, a->tape_dec, 1));
+  return eegldm_nlc_to_ncl(a->ctx, y.p, y.ld, recon, B, a->cfg.out_channels, Lc, a->dtype);
+}
+}  // namespace
+
+// encode_stage_2_inputs / Stage1Wrapper (training.py:15-26): z = mu + eps*sigma (eps NULL -> z = mu)
+extern "C" int eegldm_aekl_encode(eegldm_aekl* a, const float* x, const float* eps, float* z, float* z_mu, float* z_sigma, int B, int L) {
+  EEG_CHECK(a && x && a->params, "null argument / unbound parameters");
+  View zv;
+  EEG_TRY(aekl_encode_impl(a, x, eps, B, L, &zv, nullptr));
+  return aekl_export_latents(a, zv, z, z_mu, z_sigma);
+}
+// decode_stage_2_outputs (sample_trials.py:166): z (B, lat, Ll) -> (B, out, Ll * 2^(levels-1))
+extern "C" int eegldm_aekl_decode(eegldm_aekl* a, const float* z, float* recon, int B, int Ll) {
+  EEG_CHECK(a && z && recon && a->params, "null argument / unbound parameters");
+  const int lat = a->cfg.latent_channels;
+  a->arena.reset(); a->rt.clear(); a->tape_enc.clear(); a->tape_dec.clear(); a->have_tape = false;
+  View zv; ALLOC_OR_FAIL(zv.p, a->alloc_act((long)B * Ll, lat)); zv.ld = lat; zv.C = lat;
+  EEG_TRY(eegldm_ncl_to_nlc(a->ctx, z, zv.p, lat, B, lat, Ll, a->dtype));
+  return aekl_decode_impl(a, zv, B, Ll, recon);
+}
+// forward(x) -> (reconstruction, z_mu, z_sigma) with eps supplied; kl (nullable device scalar) = KL term
+extern "C" int eegldm_aekl_forward(eegldm_aekl* a, const float* x, const float* eps, float* recon, float* z_mu, float* z_sigma, float* kl, int B, int L) {
+  EEG_CHECK(a && x && recon && a->params, "null argument / unbound parameters");
+  View zv;
+  EEG_TRY(aekl_encode_impl(a, x, eps, B, L, &zv, kl));
+  EEG_TRY(aekl_export_latents(a, zv, nullptr, z_mu, z_sigma));
+  EEG_TRY(aekl_decode_impl(a, zv, B, a->Ll, recon));
+  a->have_tape = true;
+  return 0;
+}
+// grads += d/dparams [ <d_recon, recon> + kl_weight * KL ]; dx nullable
+extern "C" int eegldm_aekl_backward(eegldm_aekl* a, const float* d_recon, float kl_weight, float* dx) {
+  EEG_CHECK(a && d_recon, "null argument");
+  EEG_CHECK(a->have_tape, "call eegldm_aekl_forward first");
+  EEG_CHECK(a->grads, "no gradient buffer bound");
+  a->have_tape = false;
+  eegldm_ctx* ctx = a->ctx; const int dt = a->dtype, lat = a->cfg.latent_channels, B = a->B, L = a->L, Ll = a->Ll, co = a->cfg.out_channels;
+  View dy; ALLOC_OR_FAIL(dy.p, a->alloc_act((long)B * L, co)); dy.ld = co; dy.C = co;
+  EEG_TRY(eegldm_ncl_to_nlc(ctx, d_recon, dy.p, co, B, co, L, dt));
+  View dz;
+  EEG_TRY(a->backward_seq(a->dec, a->tape_dec, B, dy, &dz, true));
+  const long n = (long)B * Ll * lat;
+  View dmu, dlv; ALLOC_OR_FAIL(dmu.p, a->alloc_act((long)B * Ll, lat)); ALLOC_OR_FAIL(dlv.p, a->alloc_act((long)B * Ll, lat));
+  dmu.ld = dlv.ld = lat;
+  EEG_TRY(ls_reparam_bwd(ctx, a->mu.p, a->lv.p, a->eps_nlc, a->sigma, dz.p, dmu.p, dlv.p, n, kl_weight / (float)B, dt));
+  const int ce = a->h_enc.C;
+  EEG_TRY(op_conv_wgrad(ctx, dt, a->h_enc.p, a->h_enc.ld, dmu.p, lat, a->G(a->q_mu.w), a->G(a->q_mu.b), B, Ll, lat, lat, 1, 1, 0, 0));
+  EEG_TRY(op_conv_wgrad(ctx, dt, a->h_enc.p, a->h_enc.ld, dlv.p, lat, a->G(a->q_lv.w), a->G(a->q_lv.b), B, Ll, lat, lat, 1, 1, 0, 0));
+  View dh; ALLOC_OR_FAIL(dh.p, a->alloc_act((long)B * Ll, ce)); dh.ld = ce; dh.C = ce;
+  EEG_TRY(op_conv_dgrad(ctx, dt, dmu.p, lat, a->W(a->q_mu.w), dh.p, ce, B, Ll, lat, lat, 1, 1, 0, 0, nullptr, 0));
+  EEG_TRY(op_conv_dgrad(ctx, dt, dlv.p, lat, a->W(a->q_lv.w), dh.p, ce, B, Ll, lat, lat, 1, 1, 0, 0, dh.p, ce));
+  View dx0;
+  EEG_TRY(a->backward_seq(a->enc, a->tape_enc, B, dh, &dx0, dx != nullptr));
+  if (dx) EEG_TRY(eegldm_nlc_to_ncl(ctx, dx0.p, dx0.ld, dx, B, a->cfg.in_channels, L, dt));
+  return 0;
+}
+
+// ================================================================== PatchDiscriminator
+struct eegldm_disc : SeqNet {
+  eegldm_disc_cfg cfg;
+  std::vector<Op> ops;
+  std::vector<OpTape> tape;
+  std::vector<Entry> buf_entries; long nbuffers = 0;
+  int B = 0, L = 0, Lo = 0; bool have_tape = false;
+};
+
+extern "C" int eegldm_disc_create(eegldm_ctx* ctx, const eegldm_disc_cfg* cfg, eegldm_disc** out) {
+  EEG_CHECK(ctx && cfg && out, "null argument");
+  EEG_CHECK(cfg->kernel_size == 3 && cfg->padding == 1, "only kernel_size=3, padding=1 (config_aekl_eeg.yaml:36-40) is implemented");
+  EEG_CHECK(cfg->num_layers_d >= 1 && cfg->num_layers_d <= 6, "bad num_layers_d");
+  eegldm_disc* d = new eegldm_disc();
+  d->ctx = ctx; d->cfg = *cfg; d->dtype = cfg->dtype; d->arena.min_block = (size_t)256 << 20;
+  Layout lay, blay;
+  d->ops.push_back(make_conv(d, lay, "initial_conv.conv", cfg->in_channels, cfg->num_channels, 3, 2, 1, 1, true));
+  { Op a; a.kind = OP_ACT; a.slope = 0.2f; d->ops.push_back(a); }
+  int ic = cfg->num_channels, oc = ic * 2;
+  for (int l = 0; l < cfg->num_layers_d; l++) {
+    const int stride = (l == cfg->num_layers_d - 1) ? 1 : 2;
+    const std::string p = std::to_string(l);
+    d->ops.push_back(make_conv(d, lay, p + ".conv", ic, oc, 3, stride, 1, 1, cfg->bias != 0));
+    Op a; a.kind = OP_ACT; a.slope = 0.2f;
+    a.bn_w = lay.take(oc); a.bn_b = lay.take(oc);
+    d->add_entry(p + ".adn.N.weight", a.bn_w, 1, oc); d->add_entry(p + ".adn.N.bias", a.bn_b, 1, oc);
+    a.rm = blay.take(oc); a.rv = blay.take(oc); a.nbt = blay.take(1);
+    Entry e; e.ndim = 1; e.shape[0] = oc; e.shape[1] = e.shape[2] = 0; e.numel = oc;
+    e.name = p + ".adn.N.running_mean"; e.offset = a.rm; d->buf_entries.push_back(e);
+    e.name = p + ".adn.N.running_var"; e.offset = a.rv; d->buf_entries.push_back(e);
+    e.name = p + ".adn.N.num_batches_tracked"; e.offset = a.nbt; e.ndim = 0; e.numel = 1; e.shape[0] = 0; d->buf_entries.push_back(e);
+    d->ops.push_back(a);
+    ic = oc; oc *= 2;
+  }
+  d->ops.push_back(make_conv(d, lay, "final_conv.conv", ic, cfg->out_channels, 3, 1, 1, 1, true));
+  d->nparams = lay.off; d->nbuffers = blay.off;
+  *out = d;
+  return 0;
+}
+extern "C" int eegldm_disc_destroy(eegldm_disc* d) { delete d; return 0; }
+extern "C" int eegldm_disc_num_entries(const eegldm_disc* d) { return (int)d->entries.size(); }
+extern "C" long eegldm_disc_num_params(const eegldm_disc* d) { return d->nparams; }
+extern "C" int eegldm_disc_entry(const eegldm_disc* d, int i, char* name, int cap, long* offset, long* numel, int* ndim, int shape[3]) {
+  return entry_query(d, i, name, cap, offset, numel, ndim, shape);
+}
+extern "C" int eegldm_disc_num_buffer_entries(const eegldm_disc* d) { return (int)d->buf_entries.size(); }
+extern "C" long eegldm_disc_num_buffers(const eegldm_disc* d) { return d->nbuffers; }
+extern "C" int eegldm_disc_buffer_entry(const eegldm_disc* d, int i, char* name, int cap, long* offset, long* numel, int* ndim, int shape[3]) {
+  EEG_CHECK(d && i >= 0 && i < (int)d->buf_entries.size(), "buffer entry %d out of range", i);
+  NetBase tmp; tmp.entries.push_back(d->buf_entries[i]);
+  return entry_query(&tmp, 0, name, cap, offset, numel, ndim, shape);
+}
+// buffers: flat fp32 [num_buffers] holding running_mean / running_var / num_batches_tracked (as a float count)
+extern "C" int eegldm_disc_bind(eegldm_disc* d, float* params, float* grads, float* buffers) {
+  EEG_CHECK(d && params && buffers, "null argument");
+  d->buffers = buffers;
+  return d->bind(params, grads);
+}
+extern "C" int eegldm_disc_sync_weights(eegldm_disc* d) { EEG_CHECK(d, "null argument"); return d->sync_weights(); }
+
+// forward(x)[-1]: x (B, in, L) -> logits (B, out, L/2^(num_layers_d)); training: batch statistics + running-stat update
+extern "C" int eegldm_disc_forward(eegldm_disc* d, const float* x, float* logits, int B, int L, int training) {
+  EEG_CHECK(d && x && logits && d->params, "null argument / unbound parameters");
+  const int cin = d->cfg.in_channels;
+  d->arena.reset(); d->tape.clear(); d->rt.clear();
+  View x0; ALLOC_OR_FAIL(x0.p, d->alloc_act((long)B * L, cin)); x0.ld = cin; x0.C = cin;
+  EEG_TRY(eegldm_ncl_to_nlc(d->ctx, x, x0.p, cin, B, cin, L, d->dtype));
+  int Lc = L; View y;
+  EEG_TRY(d->forward_seq(d->ops, x0, B, Lc, &y, d->tape, training));
+  d->B = B; d->L = L; d->Lo = Lc; d->have_tape = true;
+  return eegldm_nlc_to_ncl(d->ctx, y.p, y.ld, logits, B, d->cfg.out_channels, Lc, d->dtype);
+}
+// param_grads != 0: grads += d/dparams; dx (nullable) = d/dx
+extern "C" int eegldm_disc_backward(eegldm_disc* d, const float* dlogits, float* dx, int param_grads) {
+  EEG_CHECK(d && dlogits, "null argument");
+  EEG_CHECK(d->have_tape, "call eegldm_disc_forward first");
+  EEG_CHECK(!param_grads || d->grads, "no gradient buffer bound");
+  d->have_tape = false;
+  const int co = d->cfg.out_channels, B = d->B;
+  View dy; ALLOC_OR_FAIL(dy.p, d->alloc_act((long)B * d->Lo, co)); dy.ld = co; dy.C = co;
+  EEG_TRY(eegldm_ncl_to_nlc(d->ctx, dlogits, dy.p, co, B, co, d->Lo, d->dtype));
+  d->param_grads = param_grads != 0;
+  View dx0;
+  int rc = d->backward_seq(d->ops, d->tape, B, dy, &dx0, dx != nullptr);
+  d->param_grads = true;
+  EEG_TRY(rc);
+  if (dx) EEG_TRY(eegldm_nlc_to_ncl(d->ctx, dx0.p, dx0.ld, dx, B, d->cfg.in_channels, d->L, d->dtype));
+  return 0;
+}
+
+// ================================================================== fused train step (train_autoencoderkl.py:200-234)
+extern "C" int eegldm_l1_loss(eegldm_ctx*, const float*, const float*, float*, float*, long, float);
+extern "C" int eegldm_lsgan_loss(eegldm_ctx*, const float*, int, float*, float*, long, float);
+extern "C" int eegldm_axpy(eegldm_ctx*, float*, const float*, float, long);
+
+extern "C" int eegldm_aekl_train_step(eegldm_aekl* a, eegldm_disc* d, const float* x, const float* eps, float adv_weight, float kl_weight,
+                                      float spectral_weight, int use_spectral, float* losses, float* recon_out, int B, int L) {
+  EEG_CHECK(a && d && x && eps && losses, "null argument");
+  EEG_CHECK(a->cfg.in_channels == a->cfg.out_channels && d->cfg.in_channels == a->cfg.out_channels, "channel mismatch between autoencoder and discriminator");
+  eegldm_ctx* ctx = a->ctx;
+  const int C = a->cfg.in_channels;
+  const long n = (long)B * C * L;
+  int Ld = L; for (int i = 0; i < d->cfg.num_layers_d; i++) Ld = (Ld + 2 - 3) / 2 + 1;   // initial + (num_layers_d-1) stride-2 convs
+  const long nl = (long)B * d->cfg.out_channels * Ld;
+  a->stage.reset();
+  float* recon; ALLOC_OR_FAIL(recon, a->stage.alloc(sizeof(float) * n));
+  float* drecon; ALLOC_OR_FAIL(drecon, a->stage.alloc(sizeof(float) * n));
+  float* dxd; ALLOC_OR_FAIL(dxd, a->stage.alloc(sizeof(float) * n));
+  float* logits; ALLOC_OR_FAIL(logits, a->stage.alloc(sizeof(float) * nl));
+  float* dlogits; ALLOC_OR_FAIL(dlogits, a->stage.alloc(sizeof(float) * nl));
+  // losses[0..5] = recons (L1), spectral, kl, generator adv, D fake, D real
+  // ---- generator
+  EEG_TRY(eegldm_aekl_forward(a, x, eps, recon, nullptr, nullptr, losses + 2, B, L));
+  HIP_TRY(hipMemsetAsync(drecon, 0, sizeof(float) * n, ctx->stream));
+  EEG_TRY(eegldm_l1_loss(ctx, recon, x, losses + 0, drecon, n, 1.0f));
+  EEG_TRY(eegldm_spectral_loss(ctx, recon, x, losses + 1, use_spectral ? drecon : nullptr, B, C, L, spectral_weight));
+  EEG_TRY(eegldm_disc_forward(d, recon, logits, B, L, 1));
+  EEG_TRY(eegldm_lsgan_loss(ctx, logits, 1, losses + 3, dlogits, nl, adv_weight));
+  EEG_TRY(eegldm_disc_backward(d, dlogits, dxd, 0));
+  EEG_TRY(eegldm_axpy(ctx, drecon, dxd, 1.0f, n));
+  EEG_TRY(eegldm_aekl_backward(a, drecon, kl_weight, nullptr));
+  // ---- discriminator: 0.5 * adv_weight * (fake->0 + real->1)
+  EEG_TRY(eegldm_disc_forward(d, recon, logits, B, L, 1));
+  EEG_TRY(eegldm_lsgan_loss(ctx, logits, 0, losses + 4, dlogits, nl, 0.5f * adv_weight));
+  EEG_TRY(eegldm_disc_backward(d, dlogits, nullptr, 1));
+  EEG_TRY(eegldm_disc_forward(d, x, logits, B, L, 1));
+  EEG_TRY(eegldm_lsgan_loss(ctx, logits, 1, losses + 5, dlogits, nl, 0.5f * adv_weight));
+  EEG_TRY(eegldm_disc_backward(d, dlogits, nullptr, 1));
+  if (recon_out) HIP_TRY(hipMemcpyAsync(recon_out, recon, sizeof(float) * n, hipMemcpyDeviceToDevice, ctx->stream));
+  return 0;
+}

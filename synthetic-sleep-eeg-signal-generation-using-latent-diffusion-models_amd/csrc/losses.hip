@@ -1,0 +1,285 @@
+// HBM-bound kernels of the AutoencoderKL / PatchDiscriminator train step that are not
+// shared with the UNet: BatchNorm1d(train)+LeakyReLU, LeakyReLU, nearest x2 up-sampling,
+// KL reparameterisation, L1 and least-squares adversarial losses.
+// Reference call sites: /root/reference/src/train_autoencoderkl.py:204-234; MONAI
+// PatchDiscriminator / PatchAdversarialLoss / AutoencoderKL.sampling.
+#include "common.h"
+#include "internal.h"
+
+namespace {
+constexpr int NT = 256;
+#define GRID_STRIDE(i, n) for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < (n); i += (long)gridDim.x * blockDim.x)
+inline int grid1d(long n, eegldm_ctx* ctx) {
+  long blocks = (n + NT - 1) / NT, cap = (long)ctx->num_cu * 16;
+  if (blocks < 1) blocks = 1;
+  return (int)(blocks < cap ? blocks : cap);
+}
+
+// ------------------------------------------------------------------ BatchNorm statistics
+// sums[c][0..1] += sum x, sum x^2 over a chunk of rows (double atomics); grid (ceil(C/64), RSPLIT)
+template <typename T>
+__global__ __launch_bounds__(NT) void bn_stats_kernel(const T* __restrict__ x, long ldx, double* __restrict__ sums, long rows, int C, long rows_per_block) {
+  __shared__ float r1[4][64], r2[4][64];
+  const int c = blockIdx.x * 64 + (threadIdx.x & 63), ry = threadIdx.x >> 6;
+  const long l0 = (long)blockIdx.y * rows_per_block, l1 = min(rows, l0 + rows_per_block);
+  float s1 = 0.f, s2 = 0.f;
+  if (c < C) for (long l = l0 + ry; l < l1; l += 4) { const float v = ld_f32(x + l * ldx + c); s1 += v; s2 += v * v; }
+  r1[ry][threadIdx.x & 63] = s1; r2[ry][threadIdx.x & 63] = s2;
+  __syncthreads();
+  if (ry == 0 && c < C) {
+    const int i = threadIdx.x;
+    atomicAdd(&sums[2 * c], (double)(r1[0][i] + r1[1][i] + r1[2][i] + r1[3][i]));
+    atomicAdd(&sums[2 * c + 1], (double)(r2[0][i] + r2[1][i] + r2[2][i] + r2[3][i]));
+  }
+}
+// stats[c] = (mean, rstd); running stats: momentum 0.1, unbiased variance (torch BatchNorm1d defaults)
+__global__ void bn_finalize_kernel(const double* __restrict__ sums, float* __restrict__ stats, float* __restrict__ rmean,
+                                   float* __restrict__ rvar, float* __restrict__ nbt, int C, double n, float eps, float momentum) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  const double mean = sums[2 * c] / n;
+  double var = sums[2 * c + 1] / n - mean * mean;
+  if (var < 0) var = 0;
+  stats[2 * c] = (float)mean; stats[2 * c + 1] = (float)(1.0 / sqrt(var + (double)eps));
+  if (rmean) {
+    rmean[c] = (1.0f - momentum) * rmean[c] + momentum * (float)mean;
+    rvar[c] = (1.0f - momentum) * rvar[c] + momentum * (float)(var * n / (n > 1 ? n - 1 : 1));
+    if (c == 0 && nbt) nbt[0] += 1.0f;
+  }
+}
+__global__ void bn_eval_stats_kernel(const float* __restrict__ rmean, const float* __restrict__ rvar, float* __restrict__ stats, int C, float eps) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c < C) { stats[2 * c] = rmean[c]; stats[2 * c + 1] = rsqrtf(rvar[c] + eps); }
+}
+// y = lrelu(gamma * (x - mean) * rstd + beta, slope); gamma == null -> plain lrelu(x)
+template <typename T>
+__global__ void bn_lrelu_apply_kernel(const T* __restrict__ x, long ldx, const float* __restrict__ gamma, const float* __restrict__ beta,
+                                      const float* __restrict__ stats, T* __restrict__ y, long ldy, long rows, int C, float slope) {
+  GRID_STRIDE(i, rows * C) {
+    const long r = i / C; const int c = (int)(i - r * C);
+    float z = ld_f32(x + r * ldx + c);
+    if (gamma) z = (z - stats[2 * c]) * stats[2 * c + 1] * gamma[c] + beta[c];
+    st_f32(y + r * ldy + c, z > 0.f ? z : slope * z);
+  }
+}
+// per-channel sums of dz and dz*xhat (double atomics) -> sums[c][0..1]
+template <typename T>
+__global__ __launch_bounds__(NT) void bn_bwd_reduce_kernel(const T* __restrict__ x, long ldx, const float* __restrict__ gamma,
+                                                           const float* __restrict__ beta, const float* __restrict__ stats,
+                                                           const T* __restrict__ dy, long lddy, double* __restrict__ sums, long rows, int C,
+                                                           long rows_per_block, float slope) {
+  __shared__ float r1[4][64], r2[4][64];
+  const int c = blockIdx.x * 64 + (threadIdx.x & 63), ry = threadIdx.x >> 6;
+  const long l0 = (long)blockIdx.y * rows_per_block, l1 = min(rows, l0 + rows_per_block);
+  float s1 = 0.f, s2 = 0.f;
+  if (c < C) {
+    const float mean = stats[2 * c], rstd = stats[2 * c + 1], ga = gamma[c], be = beta[c];
+    for (long l = l0 + ry; l < l1; l += 4) {
+      const float xh = (ld_f32(x + l * ldx + c) - mean) * rstd;
+      float dz = ld_f32(dy + l * lddy + c);
+      if (ga * xh + be <= 0.f) dz *= slope;
+      s1 += dz; s2 += dz * xh;
+    }
+  }
+  r1[ry][threadIdx.x & 63] = s1; r2[ry][threadIdx.x & 63] = s2;
+  __syncthreads();
+  if (ry == 0 && c < C) {
+    const int i = threadIdx.x;
+    atomicAdd(&sums[2 * c], (double)(r1[0][i] + r1[1][i] + r1[2][i] + r1[3][i]));
+    atomicAdd(&sums[2 * c + 1], (double)(r2[0][i] + r2[1][i] + r2[2][i] + r2[3][i]));
+  }
+}
+// dx = gamma*rstd*(dz - S1/n - xhat*S2/n); plain lrelu when gamma == null; dgamma/dbeta accumulated by one block
+template <typename T>
+__global__ void bn_bwd_apply_kernel(const T* __restrict__ x, long ldx, const float* __restrict__ gamma, const float* __restrict__ beta,
+                                    const float* __restrict__ stats, const T* __restrict__ dy, long lddy, const double* __restrict__ sums,
+                                    T* __restrict__ dx, long lddx, float* __restrict__ dgamma, float* __restrict__ dbeta, long rows, int C, float slope) {
+  const float inv_n = 1.0f / (float)rows;
+  if (gamma && dgamma && blockIdx.x == 0)
+    for (int c = threadIdx.x; c < C; c += blockDim.x) { atomicAdd(&dbeta[c], (float)sums[2 * c]); atomicAdd(&dgamma[c], (float)sums[2 * c + 1]); }
+  GRID_STRIDE(i, rows * C) {
+    const long r = i / C; const int c = (int)(i - r * C);
+    const float xv = ld_f32(x + r * ldx + c);
+    float dz = ld_f32(dy + r * lddy + c);
+    if (!gamma) { st_f32(dx + r * lddx + c, xv > 0.f ? dz : slope * dz); continue; }
+    const float rstd = stats[2 * c + 1], ga = gamma[c], xh = (xv - stats[2 * c]) * rstd;
+    if (ga * xh + beta[c] <= 0.f) dz *= slope;
+    st_f32(dx + r * lddx + c, ga * rstd * (dz - (float)sums[2 * c] * inv_n - xh * (float)sums[2 * c + 1] * inv_n));
+  }
+}
+
+// ------------------------------------------------------------------ nearest x2 (MONAI Upsample; twin ae_kl.py:27-30)
+template <typename T>
+__global__ void upsample2_kernel(const T* __restrict__ x, long ldx, T* __restrict__ y, long ldy, long rows_in, int C) {
+  GRID_STRIDE(i, rows_in * C) {
+    const long r = i / C; const int c = (int)(i - r * C);
+    const T v = x[r * ldx + c];
+    y[(2 * r) * ldy + c] = v; y[(2 * r + 1) * ldy + c] = v;
+  }
+}
+template <typename T>
+__global__ void upsample2_bwd_kernel(const T* __restrict__ dy, long lddy, T* __restrict__ dx, long lddx, long rows_in, int C) {
+  GRID_STRIDE(i, rows_in * C) {
+    const long r = i / C; const int c = (int)(i - r * C);
+    st_f32(dx + r * lddx + c, ld_f32(dy + (2 * r) * lddy + c) + ld_f32(dy + (2 * r + 1) * lddy + c));
+  }
+}
+
+// ------------------------------------------------------------------ reparameterisation + KL (train_autoencoderkl.py:210-211)
+// mu, lv: conv outputs (T, [rows][C]); eps fp32 [rows][C] or null (z = mu).  Writes z (T), sigma (fp32 rows x C),
+// accumulates KL = 0.5 * sum(mu^2 + sigma^2 - log sigma^2 - 1) / B into *kl.
+template <typename T>
+__global__ __launch_bounds__(NT) void reparam_kernel(const T* __restrict__ mu, const T* __restrict__ lv, const float* __restrict__ eps,
+                                                     T* __restrict__ z, float* __restrict__ sigma, float* __restrict__ kl, long n, float inv_B) {
+  float s = 0.f;
+  GRID_STRIDE(i, n) {
+    const float m = ld_f32(mu + i);
+    const float l = fminf(20.0f, fmaxf(-30.0f, ld_f32(lv + i)));
+    const float sg = expf(0.5f * l);
+    sigma[i] = sg;
+    st_f32(z + i, eps ? m + eps[i] * sg : m);
+    s += 0.5f * (m * m + sg * sg - logf(sg * sg) - 1.0f);
+  }
+  if (kl) {
+    s = wave_sum(s);
+    __shared__ float red[4];
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) atomicAdd(kl, (red[0] + red[1] + red[2] + red[3]) * inv_B);
+  }
+}
+// dmu = dz + klw*mu/B ; dlv = [ -30 < lv < 20 ] * (dz*eps + klw*(sigma - 1/sigma)/B) * sigma/2
+template <typename T>
+__global__ void reparam_bwd_kernel(const T* __restrict__ mu, const T* __restrict__ lv, const float* __restrict__ eps, const float* __restrict__ sigma,
+                                   const T* __restrict__ dz, T* __restrict__ dmu, T* __restrict__ dlv, long n, float klw_over_B) {
+  GRID_STRIDE(i, n) {
+    const float d = dz ? ld_f32(dz + i) : 0.f, m = ld_f32(mu + i), l = ld_f32(lv + i), sg = sigma[i];
+    st_f32(dmu + i, d + klw_over_B * m);
+    const float dsg = d * (eps ? eps[i] : 0.f) + klw_over_B * (sg - 1.0f / sg);
+    st_f32(dlv + i, (l > -30.0f && l < 20.0f) ? dsg * sg * 0.5f : 0.f);
+  }
+}
+
+// ------------------------------------------------------------------ losses on fp32 NCL tensors
+// L1: loss += w_loss * mean|a-b| ; da += w_grad * sign(a-b)/n
+__global__ __launch_bounds__(NT) void l1_kernel(const float* __restrict__ a, const float* __restrict__ b, float* __restrict__ loss,
+                                                float* __restrict__ da, long n, float inv_n, float wgrad) {
+  float s = 0.f;
+  GRID_STRIDE(i, n) {
+    const float d = a[i] - b[i];
+    s += fabsf(d);
+    if (da) da[i] += wgrad * inv_n * (d > 0.f ? 1.0f : (d < 0.f ? -1.0f : 0.f));
+  }
+  s = wave_sum(s);
+  __shared__ float red[4];
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) atomicAdd(loss, (red[0] + red[1] + red[2] + red[3]) * inv_n);
+}
+// least-squares GAN: a = lrelu(logit, 0.05); loss = mean((a - target)^2); dlogit = w * 2(a-target)/n * lrelu'
+__global__ __launch_bounds__(NT) void lsgan_kernel(const float* __restrict__ lg, float target, float* __restrict__ loss, float* __restrict__ dlg,
+                                                   long n, float inv_n, float wgrad) {
+  float s = 0.f;
+  GRID_STRIDE(i, n) {
+    const float x = lg[i], a = x > 0.f ? x : 0.05f * x, d = a - target;
+    s += d * d;
+    if (dlg) dlg[i] = wgrad * 2.0f * d * inv_n * (x > 0.f ? 1.0f : 0.05f);
+  }
+  s = wave_sum(s);
+  __shared__ float red[4];
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) atomicAdd(loss, (red[0] + red[1] + red[2] + red[3]) * inv_n);
+}
+__global__ void axpy_kernel(float* __restrict__ y, const float* __restrict__ x, float a, long n) { GRID_STRIDE(i, n) y[i] += a * x[i]; }
+
+inline void pick_rsplit(long rows, int C, eegldm_ctx* ctx, int* rsplit, long* rpb) {
+  long want = ((long)ctx->num_cu * 8) / ((C + 63) / 64); if (want < 1) want = 1;
+  long maxs = (rows + 63) / 64; if (want > maxs) want = maxs;
+  *rpb = (rows + want - 1) / want; *rsplit = (int)((rows + *rpb - 1) / *rpb);
+}
+}  // namespace
+
+#define DISPATCH_T(dtype, ...)                                            \
+  do {                                                                    \
+    if ((dtype) == EEGLDM_F32) { typedef float T; __VA_ARGS__; }          \
+    else if ((dtype) == EEGLDM_BF16) { typedef bf16_t T; __VA_ARGS__; }   \
+    else EEG_FAIL(EEGLDM_ERR_UNSUPPORTED, "dtype %d", (int)(dtype));      \
+  } while (0)
+
+// BatchNorm1d + LeakyReLU forward.  training: batch statistics (and running-stat update when rmean != null);
+// eval: running statistics.  stats: [C][2] fp32 out.  gamma == null: plain LeakyReLU (stats unused).
+int ls_bn_lrelu_fwd(eegldm_ctx* ctx, const void* x, long ldx, const float* gamma, const float* beta, float* stats, float* rmean, float* rvar,
+                    float* nbt, void* y, long ldy, long rows, int C, float slope, int training, int dtype) {
+  if (gamma) {
+    if (training) {
+      double* sums = (double*)ctx->scratch;
+      EEG_CHECK((size_t)C * 2 * sizeof(double) <= ctx->scratch_bytes, "scratch too small");
+      HIP_TRY(hipMemsetAsync(sums, 0, sizeof(double) * 2 * C, ctx->stream));
+      int rs; long rpb; pick_rsplit(rows, C, ctx, &rs, &rpb);
+      DISPATCH_T(dtype, hipLaunchKernelGGL((bn_stats_kernel<T>), dim3((C + 63) / 64, rs), dim3(NT), 0, ctx->stream, (const T*)x, ldx, sums, rows, C, rpb));
+      LAUNCH_CHECK();
+      hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 255) / 256), dim3(256), 0, ctx->stream, sums, stats, rmean, rvar, nbt, C, (double)rows, 1e-5f, 0.1f);
+      LAUNCH_CHECK();
+    } else {
+      EEG_CHECK(rmean && rvar, "eval-mode BatchNorm needs running statistics");
+      hipLaunchKernelGGL(bn_eval_stats_kernel, dim3((C + 255) / 256), dim3(256), 0, ctx->stream, rmean, rvar, stats, C, 1e-5f);
+      LAUNCH_CHECK();
+    }
+  }
+  DISPATCH_T(dtype, hipLaunchKernelGGL((bn_lrelu_apply_kernel<T>), dim3(grid1d(rows * C, ctx)), dim3(NT), 0, ctx->stream, (const T*)x, ldx, gamma, beta, stats, (T*)y, ldy, rows, C, slope));
+  LAUNCH_CHECK();
+  return 0;
+}
+int ls_bn_lrelu_bwd(eegldm_ctx* ctx, const void* x, long ldx, const float* gamma, const float* beta, const float* stats, const void* dy, long lddy,
+                    void* dx, long lddx, float* dgamma, float* dbeta, long rows, int C, float slope, int dtype) {
+  double* sums = (double*)ctx->scratch;
+  if (gamma) {
+    HIP_TRY(hipMemsetAsync(sums, 0, sizeof(double) * 2 * C, ctx->stream));
+    int rs; long rpb; pick_rsplit(rows, C, ctx, &rs, &rpb);
+    DISPATCH_T(dtype, hipLaunchKernelGGL((bn_bwd_reduce_kernel<T>), dim3((C + 63) / 64, rs), dim3(NT), 0, ctx->stream, (const T*)x, ldx, gamma, beta, stats,
+                                         (const T*)dy, lddy, sums, rows, C, rpb, slope));
+    LAUNCH_CHECK();
+  }
+  DISPATCH_T(dtype, hipLaunchKernelGGL((bn_bwd_apply_kernel<T>), dim3(grid1d(rows * C, ctx)), dim3(NT), 0, ctx->stream, (const T*)x, ldx, gamma, beta, stats,
+                                       (const T*)dy, lddy, sums, (T*)dx, lddx, dgamma, dbeta, rows, C, slope));
+  LAUNCH_CHECK();
+  return 0;
+}
+int ls_upsample2(eegldm_ctx* ctx, const void* x, long ldx, void* y, long ldy, long rows_in, int C, int dtype) {
+  DISPATCH_T(dtype, hipLaunchKernelGGL((upsample2_kernel<T>), dim3(grid1d(rows_in * C, ctx)), dim3(NT), 0, ctx->stream, (const T*)x, ldx, (T*)y, ldy, rows_in, C));
+  LAUNCH_CHECK(); return 0;
+}
+int ls_upsample2_bwd(eegldm_ctx* ctx, const void* dy, long lddy, void* dx, long lddx, long rows_in, int C, int dtype) {
+  DISPATCH_T(dtype, hipLaunchKernelGGL((upsample2_bwd_kernel<T>), dim3(grid1d(rows_in * C, ctx)), dim3(NT), 0, ctx->stream, (const T*)dy, lddy, (T*)dx, lddx, rows_in, C));
+  LAUNCH_CHECK(); return 0;
+}
+int ls_reparam(eegldm_ctx* ctx, const void* mu, const void* lv, const float* eps, void* z, float* sigma, float* kl, long n, int B, int dtype) {
+  DISPATCH_T(dtype, hipLaunchKernelGGL((reparam_kernel<T>), dim3(grid1d(n, ctx)), dim3(NT), 0, ctx->stream, (const T*)mu, (const T*)lv, eps, (T*)z, sigma, kl, n, 1.0f / (float)B));
+  LAUNCH_CHECK(); return 0;
+}
+int ls_reparam_bwd(eegldm_ctx* ctx, const void* mu, const void* lv, const float* eps, const float* sigma, const void* dz, void* dmu, void* dlv, long n,
+                   float klw_over_B, int dtype) {
+  DISPATCH_T(dtype, hipLaunchKernelGGL((reparam_bwd_kernel<T>), dim3(grid1d(n, ctx)), dim3(NT), 0, ctx->stream, (const T*)mu, (const T*)lv, eps, sigma, (const T*)dz,
+                                       (T*)dmu, (T*)dlv, n, klw_over_B));
+  LAUNCH_CHECK(); return 0;
+}
+
+// ================================================================== C ABI (losses)
+extern "C" int eegldm_l1_loss(eegldm_ctx* ctx, const float* a, const float* b, float* loss, float* da_accum, long n, float grad_weight) {
+  EEG_CHECK(ctx && a && b && loss && n > 0, "bad argument");
+  HIP_TRY(hipMemsetAsync(loss, 0, sizeof(float), ctx->stream));
+  hipLaunchKernelGGL(l1_kernel, dim3(grid1d(n / 4 + 1, ctx)), dim3(NT), 0, ctx->stream, a, b, loss, da_accum, n, 1.0f / (float)n, grad_weight);
+  LAUNCH_CHECK(); return 0;
+}
+extern "C" int eegldm_lsgan_loss(eegldm_ctx* ctx, const float* logits, int target_is_real, float* loss, float* dlogits, long n, float grad_weight) {
+  EEG_CHECK(ctx && logits && loss && n > 0, "bad argument");
+  HIP_TRY(hipMemsetAsync(loss, 0, sizeof(float), ctx->stream));
+  hipLaunchKernelGGL(lsgan_kernel, dim3(grid1d(n, ctx)), dim3(NT), 0, ctx->stream, logits, target_is_real ? 1.0f : 0.0f, loss, dlogits, n, 1.0f / (float)n, grad_weight);
+  LAUNCH_CHECK(); return 0;
+}
+extern "C" int eegldm_axpy(eegldm_ctx* ctx, float* y, const float* x, float a, long n) {
+  EEG_CHECK(ctx && y && x, "null argument");
+  hipLaunchKernelGGL(axpy_kernel, dim3(grid1d(n, ctx)), dim3(NT), 0, ctx->stream, y, x, a, n);
+  LAUNCH_CHECK(); return 0;
+}

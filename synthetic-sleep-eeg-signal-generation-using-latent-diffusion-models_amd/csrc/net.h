@@ -1,0 +1,90 @@
+// Shared host-side pieces of the model executors (UNet, AutoencoderKL, PatchDiscriminator):
+// bump arena for activations, NLC views, the flat-parameter base struct, and the
+// ResBlock / AttentionBlock forward+backward sequences both model families use.
+#pragma once
+#include <string>
+#include <vector>
+
+#include "common.h"
+#include "internal.h"
+
+struct Arena {
+  struct Block { char* p; size_t cap; };
+  std::vector<Block> blocks;
+  size_t cur_block = 0, cur_off = 0;
+  size_t min_block = (size_t)512 << 20;
+  ~Arena() { for (auto& b : blocks) (void)hipFree(b.p); }
+  void reset() { cur_block = 0; cur_off = 0; }
+  struct Mark { size_t b, o; };
+  Mark mark() const { return {cur_block, cur_off}; }
+  void release(Mark m) { cur_block = m.b; cur_off = m.o; }
+  void* alloc(size_t bytes) {
+    bytes = (bytes + 255) & ~(size_t)255;
+    while (true) {
+      if (cur_block < blocks.size()) {
+        if (cur_off + bytes <= blocks[cur_block].cap) { void* r = blocks[cur_block].p + cur_off; cur_off += bytes; return r; }
+        cur_block++; cur_off = 0;
+        continue;
+      }
+      size_t cap = bytes > min_block ? bytes : min_block;
+      char* p = nullptr;
+      if (hipMalloc(&p, cap) != hipSuccess) return nullptr;
+      blocks.push_back({p, cap});
+    }
+  }
+};
+
+struct View { void* p = nullptr; long ld = 0; int C = 0; };
+static inline View col_view(const View& v, int col, int C, int dtype) {
+  View r; r.p = (char*)v.p + (size_t)col * dtype_size(dtype); r.ld = v.ld; r.C = C; return r;
+}
+
+struct Entry { std::string name; long offset, numel; int ndim; int shape[3]; };
+
+struct ResDesc {
+  int cin, cout, updown;   // updown: 0 none, 1 down (AvgPool2), 2 up (nearest x2) -- UNet only
+  int groups;              // GroupNorm groups (32 in the UNet, norm_num_groups in the AutoencoderKL)
+  long gn1_w, gn1_b, c1_w, c1_b, gn2_w, gn2_b, c2_w, c2_b, sk_w, sk_b;
+  int emb_col;             // column in the batched embedding projection, or -1 (no timestep embedding)
+};
+struct AttnDesc { int c; long n_w, n_b, qkv_w, qkv_b, pr_w, pr_b; };
+struct ResTape { View x, a1, xr, h1, a2; float *st1, *st2; int B, Lin, Lout; };
+struct AttnTape { View x, xn, qkv, o; void* probs; float* st; int B, T; };
+
+struct NetBase {
+  eegldm_ctx* ctx = nullptr;
+  int dtype = EEGLDM_F32;
+  std::vector<Entry> entries;
+  long nparams = 0;
+  float* params = nullptr; float* grads = nullptr;
+  void* wT = nullptr;            // compute-dtype copy of params (bf16) or == params (fp32)
+  bool owns_wT = false;
+  bool param_grads = true;       // false: backward propagates to the input only (G step through D)
+  Arena arena;
+  float* emb_all = nullptr; int etot = 0;   // batched timestep-embedding projections (UNet)
+  std::vector<ResTape> rt; std::vector<AttnTape> at;
+
+  const void* W(long off) const { return (const char*)wT + (size_t)off * dtype_size(dtype); }
+  const float* P(long off) const { return params + off; }
+  float* G(long off) const { return grads + off; }
+  void* alloc_act(long rows, long cols) { return arena.alloc((size_t)rows * cols * dtype_size(dtype)); }
+  void add_entry(const std::string& name, long off, int ndim, int s0, int s1 = 0, int s2 = 0) {
+    Entry e; e.name = name; e.offset = off; e.ndim = ndim; e.shape[0] = s0; e.shape[1] = s1; e.shape[2] = s2;
+    e.numel = (long)s0 * (ndim > 1 ? s1 : 1) * (ndim > 2 ? s2 : 1);
+    entries.push_back(e);
+  }
+  int bind(float* p, float* g);
+  int sync_weights();
+  ~NetBase() { if (owns_wT && wT) (void)hipFree(wT); }
+};
+
+#define ALLOC_OR_FAIL(var, expr)                                                     \
+  do { (var) = (decltype(var))(expr); if (!(var)) EEG_FAIL(EEGLDM_ERR_NOMEM, "workspace allocation failed"); } while (0)
+
+constexpr float GN_EPS = 1e-6f;
+
+int res_forward(NetBase* u, const ResDesc& r, const View& x, int B, int Lin, const View& out);
+int res_backward(NetBase* u, const ResDesc& r, const ResTape& t, const View& dout, const View& dx, float* demb_all);
+int attn_forward(NetBase* u, const AttnDesc& a, const View& x, int B, int T, const View& out);
+int attn_backward(NetBase* u, const AttnDesc& a, const AttnTape& t, const View& dout, const View& dx);
+int entry_query(const NetBase* u, int i, char* name, int cap, long* offset, long* numel, int* ndim, int shape[3]);

@@ -1,0 +1,127 @@
+// ResBlock / AttentionBlock kernel sequences shared by the model executors, plus the
+// flat-parameter plumbing of NetBase.  Host code only.
+//   ResBlock:       /root/reference/src/models/unet.py:307-327 (with timestep embedding) and the
+//                   MONAI AutoencoderKL ResBlock (no embedding; twin /root/reference/src/models/ae_kl.py:67-80)
+//   AttentionBlock: /root/reference/src/models/unet.py:168-174
+#include <string.h>
+
+#include "net.h"
+
+int NetBase::bind(float* p, float* g) {
+  EEG_CHECK(p, "null parameter buffer");
+  params = p; grads = g;
+  if (dtype == EEGLDM_F32) { wT = p; owns_wT = false; }
+  else if (!wT) { HIP_TRY(hipMalloc(&wT, (size_t)nparams * 2)); owns_wT = true; }
+  return sync_weights();
+}
+int NetBase::sync_weights() {
+  EEG_CHECK(params, "bind parameters first");
+  if (dtype == EEGLDM_F32) return 0;
+  return eegldm_cast(ctx, params, wT, nparams, dtype);
+}
+int entry_query(const NetBase* u, int i, char* name, int cap, long* offset, long* numel, int* ndim, int shape[3]) {
+  EEG_CHECK(u && i >= 0 && i < (int)u->entries.size(), "entry index %d out of range", i);
+  const Entry& e = u->entries[i];
+  if (name && cap > 0) { strncpy(name, e.name.c_str(), cap - 1); name[cap - 1] = 0; }
+  if (offset) *offset = e.offset;
+  if (numel) *numel = e.numel;
+  if (ndim) *ndim = e.ndim;
+  if (shape) { shape[0] = e.shape[0]; shape[1] = e.shape[1]; shape[2] = e.shape[2]; }
+  return 0;
+}
+
+// ------------------------------------------------------------------ ResBlock (unet.py:307-327)
+int res_forward(NetBase* u, const ResDesc& r, const View& x, int B, int Lin, const View& out) {
+  eegldm_ctx* ctx = u->ctx; const int dt = u->dtype;
+  const int Lout = r.updown == 1 ? Lin / 2 : (r.updown == 2 ? Lin * 2 : Lin);
+  ResTape t; t.x = x; t.B = B; t.Lin = Lin; t.Lout = Lout;
+  ALLOC_OR_FAIL(t.st1, (float*)u->arena.alloc(sizeof(float) * 2 * B * r.groups));
+  ALLOC_OR_FAIL(t.st2, (float*)u->arena.alloc(sizeof(float) * 2 * B * r.groups));
+  ALLOC_OR_FAIL(t.a1.p, u->alloc_act((long)B * Lout, r.cin)); t.a1.ld = r.cin; t.a1.C = r.cin;
+  if (r.updown) { ALLOC_OR_FAIL(t.xr.p, u->alloc_act((long)B * Lout, r.cin)); t.xr.ld = r.cin; t.xr.C = r.cin; } else t.xr = x;
+  EEG_TRY(eegldm_groupnorm_fwd(ctx, x.p, x.ld, u->P(r.gn1_w), u->P(r.gn1_b), t.a1.p, t.a1.ld, t.st1, B, Lin, r.cin, r.groups, GN_EPS, 1,
+                               r.updown, r.updown ? t.xr.p : nullptr, t.xr.ld, dt));
+  ALLOC_OR_FAIL(t.h1.p, u->alloc_act((long)B * Lout, r.cout)); t.h1.ld = r.cout; t.h1.C = r.cout;
+  EEG_TRY(op_conv_fwd(ctx, dt, t.a1.p, t.a1.ld, u->W(r.c1_w), u->P(r.c1_b), t.h1.p, t.h1.ld, B, Lout, r.cin, r.cout, 3, 1, 1, 1,
+                      r.emb_col >= 0 ? u->emb_all + r.emb_col : nullptr, u->etot, nullptr, 0));
+  ALLOC_OR_FAIL(t.a2.p, u->alloc_act((long)B * Lout, r.cout)); t.a2.ld = r.cout; t.a2.C = r.cout;
+  EEG_TRY(eegldm_groupnorm_fwd(ctx, t.h1.p, t.h1.ld, u->P(r.gn2_w), u->P(r.gn2_b), t.a2.p, t.a2.ld, t.st2, B, Lout, r.cout, r.groups, GN_EPS, 1,
+                               0, nullptr, 0, dt));
+  if (r.sk_w >= 0) {
+    EEG_TRY(op_conv_fwd(ctx, dt, t.xr.p, t.xr.ld, u->W(r.sk_w), u->P(r.sk_b), out.p, out.ld, B, Lout, r.cin, r.cout, 1, 1, 0, 0, nullptr, 0, nullptr, 0));
+    EEG_TRY(op_conv_fwd(ctx, dt, t.a2.p, t.a2.ld, u->W(r.c2_w), u->P(r.c2_b), out.p, out.ld, B, Lout, r.cout, r.cout, 3, 1, 1, 1, nullptr, 0, out.p, out.ld));
+  } else {
+    EEG_TRY(op_conv_fwd(ctx, dt, t.a2.p, t.a2.ld, u->W(r.c2_w), u->P(r.c2_b), out.p, out.ld, B, Lout, r.cout, r.cout, 3, 1, 1, 1, nullptr, 0, t.xr.p, t.xr.ld));
+  }
+  u->rt.push_back(t);
+  return 0;
+}
+
+// dout: [B*Lout][cout]; writes dx: [B*Lin][cin]; accumulates parameter grads; demb_all gets per-sample sums
+int res_backward(NetBase* u, const ResDesc& r, const ResTape& t, const View& dout, const View& dx, float* demb_all) {
+  eegldm_ctx* ctx = u->ctx; const int dt = u->dtype; const int B = t.B, Lin = t.Lin, Lout = t.Lout;
+  Arena::Mark mk = u->arena.mark();
+  View dxr = dout;
+  if (r.sk_w >= 0) {
+    if (u->param_grads) EEG_TRY(op_conv_wgrad(ctx, dt, t.xr.p, t.xr.ld, dout.p, dout.ld, u->G(r.sk_w), u->G(r.sk_b), B, Lout, r.cin, r.cout, 1, 1, 0, 0));
+    ALLOC_OR_FAIL(dxr.p, u->alloc_act((long)B * Lout, r.cin)); dxr.ld = r.cin; dxr.C = r.cin;
+    EEG_TRY(op_conv_dgrad(ctx, dt, dout.p, dout.ld, u->W(r.sk_w), dxr.p, dxr.ld, B, Lout, r.cin, r.cout, 1, 1, 0, 0, nullptr, 0));
+  }
+  if (u->param_grads) EEG_TRY(op_conv_wgrad(ctx, dt, t.a2.p, t.a2.ld, dout.p, dout.ld, u->G(r.c2_w), u->G(r.c2_b), B, Lout, r.cout, r.cout, 3, 1, 1, 1));
+  View da2; ALLOC_OR_FAIL(da2.p, u->alloc_act((long)B * Lout, r.cout)); da2.ld = r.cout;
+  EEG_TRY(op_conv_dgrad(ctx, dt, dout.p, dout.ld, u->W(r.c2_w), da2.p, da2.ld, B, Lout, r.cout, r.cout, 3, 1, 1, 1, nullptr, 0));
+  View dh1; ALLOC_OR_FAIL(dh1.p, u->alloc_act((long)B * Lout, r.cout)); dh1.ld = r.cout;
+  EEG_TRY(eegldm_groupnorm_bwd(ctx, t.h1.p, t.h1.ld, u->P(r.gn2_w), u->P(r.gn2_b), t.st2, da2.p, da2.ld, dh1.p, dh1.ld, u->param_grads ? u->G(r.gn2_w) : nullptr, u->param_grads ? u->G(r.gn2_b) : nullptr,
+                               B, Lout, r.cout, r.groups, 1, 0, nullptr, 0, dt));
+  // h1 = conv(a1) + b1 + emb_out[b]: per-sample column sums feed the embedding MLP, their total is db1
+  const bool pg = u->param_grads;
+  if (r.emb_col >= 0) EEG_TRY(ew_colsum(ctx, dh1.p, dh1.ld, demb_all + r.emb_col, u->etot, pg ? u->G(r.c1_b) : nullptr, B, Lout, r.cout, dt));
+  else if (pg) EEG_TRY(ew_colsum(ctx, dh1.p, dh1.ld, nullptr, 0, u->G(r.c1_b), B, Lout, r.cout, dt));
+  if (pg) EEG_TRY(op_conv_wgrad(ctx, dt, t.a1.p, t.a1.ld, dh1.p, dh1.ld, u->G(r.c1_w), nullptr, B, Lout, r.cin, r.cout, 3, 1, 1, 1));
+  View da1; ALLOC_OR_FAIL(da1.p, u->alloc_act((long)B * Lout, r.cin)); da1.ld = r.cin;
+  EEG_TRY(op_conv_dgrad(ctx, dt, dh1.p, dh1.ld, u->W(r.c1_w), da1.p, da1.ld, B, Lout, r.cin, r.cout, 3, 1, 1, 1, nullptr, 0));
+  EEG_TRY(eegldm_groupnorm_bwd(ctx, t.x.p, t.x.ld, u->P(r.gn1_w), u->P(r.gn1_b), t.st1, da1.p, da1.ld, dx.p, dx.ld, u->param_grads ? u->G(r.gn1_w) : nullptr, u->param_grads ? u->G(r.gn1_b) : nullptr,
+                               B, Lin, r.cin, r.groups, 1, r.updown, dxr.p, dxr.ld, dt));
+  u->arena.release(mk);
+  return 0;
+}
+
+// ------------------------------------------------------------------ AttentionBlock (unet.py:168-174)
+int attn_forward(NetBase* u, const AttnDesc& a, const View& x, int B, int T, const View& out) {
+  eegldm_ctx* ctx = u->ctx; const int dt = u->dtype; const int C = a.c; constexpr int AG = 32;
+  AttnTape t; t.x = x; t.B = B; t.T = T;
+  ALLOC_OR_FAIL(t.st, (float*)u->arena.alloc(sizeof(float) * 2 * B * AG));
+  ALLOC_OR_FAIL(t.xn.p, u->alloc_act((long)B * T, C)); t.xn.ld = C;
+  EEG_TRY(eegldm_groupnorm_fwd(ctx, x.p, x.ld, u->P(a.n_w), u->P(a.n_b), t.xn.p, C, t.st, B, T, C, AG, GN_EPS, 0, 0, nullptr, 0, dt));
+  ALLOC_OR_FAIL(t.qkv.p, u->alloc_act((long)B * T, 3 * C)); t.qkv.ld = 3 * C;
+  EEG_TRY(op_conv_fwd(ctx, dt, t.xn.p, C, u->W(a.qkv_w), u->P(a.qkv_b), t.qkv.p, 3 * C, B, T, C, 3 * C, 1, 1, 0, 0, nullptr, 0, nullptr, 0));
+  ALLOC_OR_FAIL(t.probs, u->alloc_act((long)B * T, T));
+  ALLOC_OR_FAIL(t.o.p, u->alloc_act((long)B * T, C)); t.o.ld = C;
+  Arena::Mark mk = u->arena.mark();
+  float* logits; ALLOC_OR_FAIL(logits, (float*)u->arena.alloc(sizeof(float) * (size_t)B * T * T));
+  EEG_TRY(op_attention_fwd(ctx, dt, t.qkv.p, 3 * C, t.o.p, C, t.probs, logits, B, T, C));
+  u->arena.release(mk);
+  EEG_TRY(op_conv_fwd(ctx, dt, t.o.p, C, u->W(a.pr_w), u->P(a.pr_b), out.p, out.ld, B, T, C, C, 1, 1, 0, 0, nullptr, 0, x.p, x.ld));
+  u->at.push_back(t);
+  return 0;
+}
+
+int attn_backward(NetBase* u, const AttnDesc& a, const AttnTape& t, const View& dout, const View& dx) {
+  eegldm_ctx* ctx = u->ctx; const int dt = u->dtype; const int C = a.c, B = t.B, T = t.T; constexpr int AG = 32;
+  Arena::Mark mk = u->arena.mark();
+  EEG_TRY(op_conv_wgrad(ctx, dt, t.o.p, C, dout.p, dout.ld, u->G(a.pr_w), u->G(a.pr_b), B, T, C, C, 1, 1, 0, 0));
+  void* d_o; ALLOC_OR_FAIL(d_o, u->alloc_act((long)B * T, C));
+  EEG_TRY(op_conv_dgrad(ctx, dt, dout.p, dout.ld, u->W(a.pr_w), d_o, C, B, T, C, C, 1, 1, 0, 0, nullptr, 0));
+  void* dqkv; ALLOC_OR_FAIL(dqkv, u->alloc_act((long)B * T, 3 * C));
+  float* dprobs; ALLOC_OR_FAIL(dprobs, (float*)u->arena.alloc(sizeof(float) * (size_t)B * T * T));
+  void* dlogits; ALLOC_OR_FAIL(dlogits, u->alloc_act((long)B * T, T));
+  EEG_TRY(op_attention_bwd(ctx, dt, t.qkv.p, 3 * C, t.probs, d_o, C, dqkv, 3 * C, dprobs, dlogits, B, T, C));
+  EEG_TRY(op_conv_wgrad(ctx, dt, t.xn.p, C, dqkv, 3 * C, u->G(a.qkv_w), u->G(a.qkv_b), B, T, C, 3 * C, 1, 1, 0, 0));
+  void* dxn; ALLOC_OR_FAIL(dxn, u->alloc_act((long)B * T, C));
+  EEG_TRY(op_conv_dgrad(ctx, dt, dqkv, 3 * C, u->W(a.qkv_w), dxn, C, B, T, C, 3 * C, 1, 1, 0, 0, nullptr, 0));
+  EEG_TRY(eegldm_groupnorm_bwd(ctx, t.x.p, t.x.ld, u->P(a.n_w), u->P(a.n_b), t.st, dxn, C, dx.p, dx.ld, u->G(a.n_w), u->G(a.n_b),
+                               B, T, C, AG, 0, 0, dout.p, dout.ld, dt));
+  u->arena.release(mk);
+  return 0;
+}
+

@@ -18,95 +18,29 @@
 #include <string>
 #include <vector>
 
-#include "common.h"
-#include "internal.h"
+#include "net.h"
 
 namespace {
-
 constexpr int GN_G = 32;
-constexpr float GN_EPS = 1e-6f;
-
-struct Arena {
-  struct Block { char* p; size_t cap; };
-  std::vector<Block> blocks;
-  size_t cur_block = 0, cur_off = 0;
-  size_t min_block = (size_t)512 << 20;
-  ~Arena() { for (auto& b : blocks) hipFree(b.p); }
-  void reset() { cur_block = 0; cur_off = 0; }
-  struct Mark { size_t b, o; };
-  Mark mark() const { return {cur_block, cur_off}; }
-  void release(Mark m) { cur_block = m.b; cur_off = m.o; }
-  void* alloc(size_t bytes) {
-    bytes = (bytes + 255) & ~(size_t)255;
-    while (true) {
-      if (cur_block < blocks.size()) {
-        if (cur_off + bytes <= blocks[cur_block].cap) { void* r = blocks[cur_block].p + cur_off; cur_off += bytes; return r; }
-        cur_block++; cur_off = 0;
-        continue;
-      }
-      size_t cap = bytes > min_block ? bytes : min_block;
-      char* p = nullptr;
-      if (hipMalloc(&p, cap) != hipSuccess) return nullptr;
-      blocks.push_back({p, cap});
-    }
-  }
-};
-
-struct View { void* p = nullptr; long ld = 0; int C = 0; };
-static inline View col_view(const View& v, int col, int C, int dtype) {
-  View r; r.p = (char*)v.p + (size_t)col * dtype_size(dtype); r.ld = v.ld; r.C = C; return r;
-}
-
-struct Entry { std::string name; long offset, numel; int ndim; int shape[3]; };
-
-struct ResDesc {
-  int cin, cout, updown;   // updown: 0 none, 1 down, 2 up
-  long gn1_w, gn1_b, c1_w, c1_b, gn2_w, gn2_b, c2_w, c2_b, sk_w, sk_b;
-  int emb_col;
-};
-struct AttnDesc { int c; long n_w, n_b, qkv_w, qkv_b, pr_w, pr_b; };
 struct Layer { int kind; ResDesc r; AttnDesc a; };   // kind 0 = res, 1 = attn
-struct Block { std::vector<Layer> layers; int cin, cout, lshift_in, lshift_out; };
-
-struct ResTape { View x, a1, xr, h1, a2; float *st1, *st2; int B, Lin, Lout; };
-struct AttnTape { View x, xn, qkv, o; void* probs; float* st; int B, T; };
-
+struct Block { std::vector<Layer> layers; int cin, cout; };
 }  // namespace
 
-struct eegldm_unet {
-  eegldm_ctx* ctx;
+struct eegldm_unet : NetBase {
   eegldm_unet_cfg cfg;
-  int dtype, mc, te, etot;
-  std::vector<Entry> entries;
-  long nparams = 0;
+  int mc, te;
   long off_emb_w = 0, off_emb_b = 0, off_te0_w, off_te0_b, off_te2_w, off_te2_b, off_cin_w, off_cin_b, off_out_gw, off_out_gb, off_out_w, off_out_b;
   std::vector<Block> in_blocks, out_blocks; Block mid;
   std::vector<int> skip_c1;      // per output block: channels of h entering the concat
-  float* params = nullptr; float* grads = nullptr;
-  void* wT = nullptr;            // compute-dtype copy of params (bf16) or == params (fp32)
-  bool owns_wT = false;
-  Arena arena;
   // ---- forward tape
   int B = 0, L = 0; bool have_tape = false;
   View x0, h_last, a_out; float* st_out = nullptr;
-  float *e0 = nullptr, *a1e = nullptr, *semb = nullptr, *h1e = nullptr, *emb = nullptr, *emb_all = nullptr;   // embedding MLP runs in fp32
-  std::vector<ResTape> rt; std::vector<AttnTape> at;
+  float *e0 = nullptr, *a1e = nullptr, *semb = nullptr, *h1e = nullptr, *emb = nullptr;   // embedding MLP runs in fp32
   std::vector<View> in_out;      // outputs of the input blocks (views into concat buffers)
   std::vector<View> cat;         // concat buffers per output block
-
-  const void* W(long off) const { return (const char*)wT + (size_t)off * dtype_size(dtype); }
-  const float* P(long off) const { return params + off; }
-  float* G(long off) const { return grads + off; }
-  void* alloc_act(long rows, long cols) { return arena.alloc((size_t)rows * cols * dtype_size(dtype)); }
 };
 
 namespace {
-
-void add_entry(eegldm_unet* u, const std::string& name, long off, int ndim, int s0, int s1 = 0, int s2 = 0) {
-  Entry e; e.name = name; e.offset = off; e.ndim = ndim; e.shape[0] = s0; e.shape[1] = s1; e.shape[2] = s2;
-  e.numel = (long)s0 * (ndim > 1 ? s1 : 1) * (ndim > 2 ? s2 : 1);
-  u->entries.push_back(e);
-}
 
 // Builds the block plan exactly like the reference constructor and lays out the flat buffer.
 int build_plan(eegldm_unet* u) {
@@ -161,10 +95,10 @@ int build_plan(eegldm_unet* u) {
 
   u->off_te0_w = take((long)te * mc); u->off_te0_b = take(te);
   u->off_te2_w = take((long)te * te); u->off_te2_b = take(te);
-  add_entry(u, "time_embed.0.weight", u->off_te0_w, 2, te, mc); add_entry(u, "time_embed.0.bias", u->off_te0_b, 1, te);
-  add_entry(u, "time_embed.2.weight", u->off_te2_w, 2, te, te); add_entry(u, "time_embed.2.bias", u->off_te2_b, 1, te);
+  u->add_entry("time_embed.0.weight", u->off_te0_w, 2, te, mc); u->add_entry("time_embed.0.bias", u->off_te0_b, 1, te);
+  u->add_entry("time_embed.2.weight", u->off_te2_w, 2, te, te); u->add_entry("time_embed.2.bias", u->off_te2_b, 1, te);
   u->off_cin_w = take((long)mc * c.in_channels * 3); u->off_cin_b = take(mc);
-  add_entry(u, "input_blocks.0.0.weight", u->off_cin_w, 3, mc, c.in_channels, 3); add_entry(u, "input_blocks.0.0.bias", u->off_cin_b, 1, mc);
+  u->add_entry("input_blocks.0.0.weight", u->off_cin_w, 3, mc, c.in_channels, 3); u->add_entry("input_blocks.0.0.bias", u->off_cin_b, 1, mc);
 
   int emb_col = 0;
   auto lay = [&](const std::string& prefix, const std::vector<Tmp>& l, Block& blk) {
@@ -172,31 +106,31 @@ int build_plan(eegldm_unet* u) {
       const std::string p = prefix + std::to_string(j) + ".";
       Layer L; L.kind = l[j].kind;
       if (l[j].kind == 0) {
-        ResDesc& r = L.r; r.cin = l[j].cin; r.cout = l[j].cout; r.updown = l[j].updown;
+        ResDesc& r = L.r; r.cin = l[j].cin; r.cout = l[j].cout; r.updown = l[j].updown; r.groups = GN_G;
         r.gn1_w = take(r.cin); r.gn1_b = take(r.cin);
-        add_entry(u, p + "in_layers.0.weight", r.gn1_w, 1, r.cin); add_entry(u, p + "in_layers.0.bias", r.gn1_b, 1, r.cin);
+        u->add_entry(p + "in_layers.0.weight", r.gn1_w, 1, r.cin); u->add_entry(p + "in_layers.0.bias", r.gn1_b, 1, r.cin);
         r.c1_w = take((long)r.cout * r.cin * 3); r.c1_b = take(r.cout);
-        add_entry(u, p + "in_layers.2.weight", r.c1_w, 3, r.cout, r.cin, 3); add_entry(u, p + "in_layers.2.bias", r.c1_b, 1, r.cout);
+        u->add_entry(p + "in_layers.2.weight", r.c1_w, 3, r.cout, r.cin, 3); u->add_entry(p + "in_layers.2.bias", r.c1_b, 1, r.cout);
         r.emb_col = emb_col; emb_col += r.cout;
-        add_entry(u, p + "emb_layers.1.weight", u->off_emb_w + (long)r.emb_col * te, 2, r.cout, te);
-        add_entry(u, p + "emb_layers.1.bias", u->off_emb_b + r.emb_col, 1, r.cout);
+        u->add_entry(p + "emb_layers.1.weight", u->off_emb_w + (long)r.emb_col * te, 2, r.cout, te);
+        u->add_entry(p + "emb_layers.1.bias", u->off_emb_b + r.emb_col, 1, r.cout);
         r.gn2_w = take(r.cout); r.gn2_b = take(r.cout);
-        add_entry(u, p + "out_layers.0.weight", r.gn2_w, 1, r.cout); add_entry(u, p + "out_layers.0.bias", r.gn2_b, 1, r.cout);
+        u->add_entry(p + "out_layers.0.weight", r.gn2_w, 1, r.cout); u->add_entry(p + "out_layers.0.bias", r.gn2_b, 1, r.cout);
         r.c2_w = take((long)r.cout * r.cout * 3); r.c2_b = take(r.cout);
-        add_entry(u, p + "out_layers.3.weight", r.c2_w, 3, r.cout, r.cout, 3); add_entry(u, p + "out_layers.3.bias", r.c2_b, 1, r.cout);
+        u->add_entry(p + "out_layers.3.weight", r.c2_w, 3, r.cout, r.cout, 3); u->add_entry(p + "out_layers.3.bias", r.c2_b, 1, r.cout);
         r.sk_w = r.sk_b = -1;
         if (r.cin != r.cout) {
           r.sk_w = take((long)r.cout * r.cin); r.sk_b = take(r.cout);
-          add_entry(u, p + "skip_connection.weight", r.sk_w, 3, r.cout, r.cin, 1); add_entry(u, p + "skip_connection.bias", r.sk_b, 1, r.cout);
+          u->add_entry(p + "skip_connection.weight", r.sk_w, 3, r.cout, r.cin, 1); u->add_entry(p + "skip_connection.bias", r.sk_b, 1, r.cout);
         }
       } else {
         AttnDesc& a = L.a; a.c = l[j].cin;
         a.n_w = take(a.c); a.n_b = take(a.c);
-        add_entry(u, p + "norm.weight", a.n_w, 1, a.c); add_entry(u, p + "norm.bias", a.n_b, 1, a.c);
+        u->add_entry(p + "norm.weight", a.n_w, 1, a.c); u->add_entry(p + "norm.bias", a.n_b, 1, a.c);
         a.qkv_w = take((long)3 * a.c * a.c); a.qkv_b = take(3 * a.c);
-        add_entry(u, p + "qkv.weight", a.qkv_w, 3, 3 * a.c, a.c, 1); add_entry(u, p + "qkv.bias", a.qkv_b, 1, 3 * a.c);
+        u->add_entry(p + "qkv.weight", a.qkv_w, 3, 3 * a.c, a.c, 1); u->add_entry(p + "qkv.bias", a.qkv_b, 1, 3 * a.c);
         a.pr_w = take((long)a.c * a.c); a.pr_b = take(a.c);
-        add_entry(u, p + "proj_out.weight", a.pr_w, 3, a.c, a.c, 1); add_entry(u, p + "proj_out.bias", a.pr_b, 1, a.c);
+        u->add_entry(p + "proj_out.weight", a.pr_w, 3, a.c, a.c, 1); u->add_entry(p + "proj_out.bias", a.pr_b, 1, a.c);
       }
       blk.layers.push_back(L);
     }
@@ -208,106 +142,10 @@ int build_plan(eegldm_unet* u) {
   u->out_blocks.resize(outp.size());
   for (size_t i = 0; i < outp.size(); i++) lay("output_blocks." + std::to_string(i) + ".", outp[i], u->out_blocks[i]);
   u->off_out_gw = take(mc); u->off_out_gb = take(mc);
-  add_entry(u, "out.0.weight", u->off_out_gw, 1, mc); add_entry(u, "out.0.bias", u->off_out_gb, 1, mc);
+  u->add_entry("out.0.weight", u->off_out_gw, 1, mc); u->add_entry("out.0.bias", u->off_out_gb, 1, mc);
   u->off_out_w = take((long)c.out_channels * mc * 3); u->off_out_b = take(c.out_channels);
-  add_entry(u, "out.2.weight", u->off_out_w, 3, c.out_channels, mc, 3); add_entry(u, "out.2.bias", u->off_out_b, 1, c.out_channels);
+  u->add_entry("out.2.weight", u->off_out_w, 3, c.out_channels, mc, 3); u->add_entry("out.2.bias", u->off_out_b, 1, c.out_channels);
   u->nparams = off;
-  return 0;
-}
-
-#define ALLOC_OR_FAIL(var, expr)                                                     \
-  do { (var) = (expr); if (!(var)) EEG_FAIL(EEGLDM_ERR_NOMEM, "workspace allocation failed"); } while (0)
-
-// ------------------------------------------------------------------ ResBlock (unet.py:307-327)
-int res_forward(eegldm_unet* u, const ResDesc& r, const View& x, int B, int Lin, const View& out) {
-  eegldm_ctx* ctx = u->ctx; const int dt = u->dtype;
-  const int Lout = r.updown == 1 ? Lin / 2 : (r.updown == 2 ? Lin * 2 : Lin);
-  ResTape t; t.x = x; t.B = B; t.Lin = Lin; t.Lout = Lout;
-  ALLOC_OR_FAIL(t.st1, (float*)u->arena.alloc(sizeof(float) * 2 * B * GN_G));
-  ALLOC_OR_FAIL(t.st2, (float*)u->arena.alloc(sizeof(float) * 2 * B * GN_G));
-  ALLOC_OR_FAIL(t.a1.p, u->alloc_act((long)B * Lout, r.cin)); t.a1.ld = r.cin; t.a1.C = r.cin;
-  if (r.updown) { ALLOC_OR_FAIL(t.xr.p, u->alloc_act((long)B * Lout, r.cin)); t.xr.ld = r.cin; t.xr.C = r.cin; } else t.xr = x;
-  EEG_TRY(eegldm_groupnorm_fwd(ctx, x.p, x.ld, u->P(r.gn1_w), u->P(r.gn1_b), t.a1.p, t.a1.ld, t.st1, B, Lin, r.cin, GN_G, GN_EPS, 1,
-                               r.updown, r.updown ? t.xr.p : nullptr, t.xr.ld, dt));
-  ALLOC_OR_FAIL(t.h1.p, u->alloc_act((long)B * Lout, r.cout)); t.h1.ld = r.cout; t.h1.C = r.cout;
-  EEG_TRY(op_conv_fwd(ctx, dt, t.a1.p, t.a1.ld, u->W(r.c1_w), u->P(r.c1_b), t.h1.p, t.h1.ld, B, Lout, r.cin, r.cout, 3, 1, 1, 1,
-                      u->emb_all + r.emb_col, u->etot, nullptr, 0));
-  ALLOC_OR_FAIL(t.a2.p, u->alloc_act((long)B * Lout, r.cout)); t.a2.ld = r.cout; t.a2.C = r.cout;
-  EEG_TRY(eegldm_groupnorm_fwd(ctx, t.h1.p, t.h1.ld, u->P(r.gn2_w), u->P(r.gn2_b), t.a2.p, t.a2.ld, t.st2, B, Lout, r.cout, GN_G, GN_EPS, 1,
-                               0, nullptr, 0, dt));
-  if (r.sk_w >= 0) {
-    EEG_TRY(op_conv_fwd(ctx, dt, t.xr.p, t.xr.ld, u->W(r.sk_w), u->P(r.sk_b), out.p, out.ld, B, Lout, r.cin, r.cout, 1, 1, 0, 0, nullptr, 0, nullptr, 0));
-    EEG_TRY(op_conv_fwd(ctx, dt, t.a2.p, t.a2.ld, u->W(r.c2_w), u->P(r.c2_b), out.p, out.ld, B, Lout, r.cout, r.cout, 3, 1, 1, 1, nullptr, 0, out.p, out.ld));
-  } else {
-    EEG_TRY(op_conv_fwd(ctx, dt, t.a2.p, t.a2.ld, u->W(r.c2_w), u->P(r.c2_b), out.p, out.ld, B, Lout, r.cout, r.cout, 3, 1, 1, 1, nullptr, 0, t.xr.p, t.xr.ld));
-  }
-  u->rt.push_back(t);
-  return 0;
-}
-
-// dout: [B*Lout][cout]; writes dx: [B*Lin][cin]; accumulates parameter grads; demb_all gets per-sample sums
-int res_backward(eegldm_unet* u, const ResDesc& r, const ResTape& t, const View& dout, const View& dx, float* demb_all) {
-  eegldm_ctx* ctx = u->ctx; const int dt = u->dtype; const int B = t.B, Lin = t.Lin, Lout = t.Lout;
-  Arena::Mark mk = u->arena.mark();
-  View dxr = dout;
-  if (r.sk_w >= 0) {
-    EEG_TRY(op_conv_wgrad(ctx, dt, t.xr.p, t.xr.ld, dout.p, dout.ld, u->G(r.sk_w), u->G(r.sk_b), B, Lout, r.cin, r.cout, 1, 1, 0, 0));
-    ALLOC_OR_FAIL(dxr.p, u->alloc_act((long)B * Lout, r.cin)); dxr.ld = r.cin; dxr.C = r.cin;
-    EEG_TRY(op_conv_dgrad(ctx, dt, dout.p, dout.ld, u->W(r.sk_w), dxr.p, dxr.ld, B, Lout, r.cin, r.cout, 1, 1, 0, 0, nullptr, 0));
-  }
-  EEG_TRY(op_conv_wgrad(ctx, dt, t.a2.p, t.a2.ld, dout.p, dout.ld, u->G(r.c2_w), u->G(r.c2_b), B, Lout, r.cout, r.cout, 3, 1, 1, 1));
-  View da2; ALLOC_OR_FAIL(da2.p, u->alloc_act((long)B * Lout, r.cout)); da2.ld = r.cout;
-  EEG_TRY(op_conv_dgrad(ctx, dt, dout.p, dout.ld, u->W(r.c2_w), da2.p, da2.ld, B, Lout, r.cout, r.cout, 3, 1, 1, 1, nullptr, 0));
-  View dh1; ALLOC_OR_FAIL(dh1.p, u->alloc_act((long)B * Lout, r.cout)); dh1.ld = r.cout;
-  EEG_TRY(eegldm_groupnorm_bwd(ctx, t.h1.p, t.h1.ld, u->P(r.gn2_w), u->P(r.gn2_b), t.st2, da2.p, da2.ld, dh1.p, dh1.ld, u->G(r.gn2_w), u->G(r.gn2_b),
-                               B, Lout, r.cout, GN_G, 1, 0, nullptr, 0, dt));
-  // h1 = conv(a1) + b1 + emb_out[b]: per-sample column sums feed the embedding MLP, their total is db1
-  EEG_TRY(ew_colsum(ctx, dh1.p, dh1.ld, demb_all + r.emb_col, u->etot, u->G(r.c1_b), B, Lout, r.cout, dt));
-  EEG_TRY(op_conv_wgrad(ctx, dt, t.a1.p, t.a1.ld, dh1.p, dh1.ld, u->G(r.c1_w), nullptr, B, Lout, r.cin, r.cout, 3, 1, 1, 1));
-  View da1; ALLOC_OR_FAIL(da1.p, u->alloc_act((long)B * Lout, r.cin)); da1.ld = r.cin;
-  EEG_TRY(op_conv_dgrad(ctx, dt, dh1.p, dh1.ld, u->W(r.c1_w), da1.p, da1.ld, B, Lout, r.cin, r.cout, 3, 1, 1, 1, nullptr, 0));
-  EEG_TRY(eegldm_groupnorm_bwd(ctx, t.x.p, t.x.ld, u->P(r.gn1_w), u->P(r.gn1_b), t.st1, da1.p, da1.ld, dx.p, dx.ld, u->G(r.gn1_w), u->G(r.gn1_b),
-                               B, Lin, r.cin, GN_G, 1, r.updown, dxr.p, dxr.ld, dt));
-  u->arena.release(mk);
-  return 0;
-}
-
-// ------------------------------------------------------------------ AttentionBlock (unet.py:168-174)
-int attn_forward(eegldm_unet* u, const AttnDesc& a, const View& x, int B, int T, const View& out) {
-  eegldm_ctx* ctx = u->ctx; const int dt = u->dtype; const int C = a.c;
-  AttnTape t; t.x = x; t.B = B; t.T = T;
-  ALLOC_OR_FAIL(t.st, (float*)u->arena.alloc(sizeof(float) * 2 * B * GN_G));
-  ALLOC_OR_FAIL(t.xn.p, u->alloc_act((long)B * T, C)); t.xn.ld = C;
-  EEG_TRY(eegldm_groupnorm_fwd(ctx, x.p, x.ld, u->P(a.n_w), u->P(a.n_b), t.xn.p, C, t.st, B, T, C, GN_G, GN_EPS, 0, 0, nullptr, 0, dt));
-  ALLOC_OR_FAIL(t.qkv.p, u->alloc_act((long)B * T, 3 * C)); t.qkv.ld = 3 * C;
-  EEG_TRY(op_conv_fwd(ctx, dt, t.xn.p, C, u->W(a.qkv_w), u->P(a.qkv_b), t.qkv.p, 3 * C, B, T, C, 3 * C, 1, 1, 0, 0, nullptr, 0, nullptr, 0));
-  ALLOC_OR_FAIL(t.probs, u->alloc_act((long)B * T, T));
-  ALLOC_OR_FAIL(t.o.p, u->alloc_act((long)B * T, C)); t.o.ld = C;
-  Arena::Mark mk = u->arena.mark();
-  float* logits; ALLOC_OR_FAIL(logits, (float*)u->arena.alloc(sizeof(float) * (size_t)B * T * T));
-  EEG_TRY(op_attention_fwd(ctx, dt, t.qkv.p, 3 * C, t.o.p, C, t.probs, logits, B, T, C));
-  u->arena.release(mk);
-  EEG_TRY(op_conv_fwd(ctx, dt, t.o.p, C, u->W(a.pr_w), u->P(a.pr_b), out.p, out.ld, B, T, C, C, 1, 1, 0, 0, nullptr, 0, x.p, x.ld));
-  u->at.push_back(t);
-  return 0;
-}
-
-int attn_backward(eegldm_unet* u, const AttnDesc& a, const AttnTape& t, const View& dout, const View& dx) {
-  eegldm_ctx* ctx = u->ctx; const int dt = u->dtype; const int C = a.c, B = t.B, T = t.T;
-  Arena::Mark mk = u->arena.mark();
-  EEG_TRY(op_conv_wgrad(ctx, dt, t.o.p, C, dout.p, dout.ld, u->G(a.pr_w), u->G(a.pr_b), B, T, C, C, 1, 1, 0, 0));
-  void* d_o; ALLOC_OR_FAIL(d_o, u->alloc_act((long)B * T, C));
-  EEG_TRY(op_conv_dgrad(ctx, dt, dout.p, dout.ld, u->W(a.pr_w), d_o, C, B, T, C, C, 1, 1, 0, 0, nullptr, 0));
-  void* dqkv; ALLOC_OR_FAIL(dqkv, u->alloc_act((long)B * T, 3 * C));
-  float* dprobs; ALLOC_OR_FAIL(dprobs, (float*)u->arena.alloc(sizeof(float) * (size_t)B * T * T));
-  void* dlogits; ALLOC_OR_FAIL(dlogits, u->alloc_act((long)B * T, T));
-  EEG_TRY(op_attention_bwd(ctx, dt, t.qkv.p, 3 * C, t.probs, d_o, C, dqkv, 3 * C, dprobs, dlogits, B, T, C));
-  EEG_TRY(op_conv_wgrad(ctx, dt, t.xn.p, C, dqkv, 3 * C, u->G(a.qkv_w), u->G(a.qkv_b), B, T, C, 3 * C, 1, 1, 0, 0));
-  void* dxn; ALLOC_OR_FAIL(dxn, u->alloc_act((long)B * T, C));
-  EEG_TRY(op_conv_dgrad(ctx, dt, dqkv, 3 * C, u->W(a.qkv_w), dxn, C, B, T, C, 3 * C, 1, 1, 0, 0, nullptr, 0));
-  EEG_TRY(eegldm_groupnorm_bwd(ctx, t.x.p, t.x.ld, u->P(a.n_w), u->P(a.n_b), t.st, dxn, C, dx.p, dx.ld, u->G(a.n_w), u->G(a.n_b),
-                               B, T, C, GN_G, 0, 0, dout.p, dout.ld, dt));
-  u->arena.release(mk);
   return 0;
 }
 
@@ -368,33 +206,21 @@ extern "C" int eegldm_unet_create(eegldm_ctx* ctx, const eegldm_unet_cfg* cfg, e
 }
 extern "C" int eegldm_unet_destroy(eegldm_unet* u) {
   if (!u) return 0;
-  if (u->owns_wT && u->wT) hipFree(u->wT);
   delete u;
   return 0;
 }
 extern "C" int eegldm_unet_num_entries(const eegldm_unet* u) { return (int)u->entries.size(); }
 extern "C" long eegldm_unet_num_params(const eegldm_unet* u) { return u->nparams; }
 extern "C" int eegldm_unet_entry(const eegldm_unet* u, int i, char* name, int cap, long* offset, long* numel, int* ndim, int shape[3]) {
-  EEG_CHECK(u && i >= 0 && i < (int)u->entries.size(), "entry index %d out of range", i);
-  const Entry& e = u->entries[i];
-  if (name && cap > 0) { strncpy(name, e.name.c_str(), cap - 1); name[cap - 1] = 0; }
-  if (offset) *offset = e.offset;
-  if (numel) *numel = e.numel;
-  if (ndim) *ndim = e.ndim;
-  if (shape) { shape[0] = e.shape[0]; shape[1] = e.shape[1]; shape[2] = e.shape[2]; }
-  return 0;
+  return entry_query(u, i, name, cap, offset, numel, ndim, shape);
 }
 extern "C" int eegldm_unet_bind(eegldm_unet* u, float* params, float* grads) {
   EEG_CHECK(u && params, "null argument");
-  u->params = params; u->grads = grads;
-  if (u->dtype == EEGLDM_F32) { u->wT = params; u->owns_wT = false; }
-  else if (!u->wT) { HIP_TRY(hipMalloc(&u->wT, (size_t)u->nparams * 2)); u->owns_wT = true; }
-  return eegldm_unet_sync_weights(u);
+  return u->bind(params, grads);
 }
 extern "C" int eegldm_unet_sync_weights(eegldm_unet* u) {
-  EEG_CHECK(u && u->params, "bind parameters first");
-  if (u->dtype == EEGLDM_F32) return 0;
-  return eegldm_cast(u->ctx, u->params, u->wT, u->nparams, u->dtype);
+  EEG_CHECK(u, "null argument");
+  return u->sync_weights();
 }
 
 extern "C" int eegldm_unet_forward(eegldm_unet* u, const float* x, const int64_t* tsteps, float* y, int B, int L, int training) {

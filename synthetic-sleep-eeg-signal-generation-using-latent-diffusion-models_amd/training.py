@@ -58,3 +58,17 @@ def randint(ctx, n, high, seed, offset=0, device=None):
     out = torch.empty(n, device=device or torch.device("cuda", ctx.device), dtype=torch.int64)
     check(lib.eegldm_randint(ctx.h, ptr(out), n, high, seed, offset))
     return out
+
+
+def aekl_train_step(autoencoder, discriminator, x, eps, adv_weight, kl_weight, spectral_weight, use_spectral,
+                    losses_out=None, recon_out=None):
+    """The step body of /root/reference/src/train_autoencoderkl.py:203-234 as ONE native call: fills
+    autoencoder.flat_grad and discriminator.flat_grad (both must be zeroed first) and returns the device
+    tensor [recons L1, spectral, KL, generator adversarial, D fake, D real]."""
+    dev = autoencoder.device
+    if losses_out is None:
+        losses_out = torch.zeros(6, device=dev)
+    B, _c, L = x.shape
+    check(lib.eegldm_aekl_train_step(autoencoder.h, discriminator.h, ptr(x), ptr(eps), float(adv_weight), float(kl_weight),
+                                     float(spectral_weight), 1 if use_spectral else 0, ptr(losses_out), ptr(recon_out), B, L))
+    return losses_out

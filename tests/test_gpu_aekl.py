@@ -1,0 +1,204 @@
+"""-m gpu: AutoencoderKL / PatchDiscriminator / losses / fused GAN train step on the HIP engine
+against the CPU oracle (oracle/aekl.py, oracle/losses.py, oracle/steps.py) on identical seeded inputs.
+The oracle itself is "parity unpinned" at the MONAI boundary (see oracle/aekl.py)."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+from param_gen import gen_param, normal, eeg_windows  # noqa: E402
+
+AE_CASES = {
+    "c32_32_64_lat1": dict(num_channels=[32, 32, 64], latent_channels=1),
+    "c32_32_64_lat3": dict(num_channels=[32, 32, 64], latent_channels=3),
+    "c2_2_4_lat1": dict(num_channels=[2, 2, 4], latent_channels=1),
+    "c16_32_lat2": dict(num_channels=[16, 32], latent_channels=2),
+}
+D_CFG = dict(spatial_dims=1, num_layers_d=3, num_channels=64, in_channels=1, out_channels=1, kernel_size=3, norm="BATCH", bias=False, padding=1)
+
+
+def rel_l2(a, b):
+    a = torch.as_tensor(a).detach().double().cpu().reshape(-1); b = torch.as_tensor(b).detach().double().cpu().reshape(-1)
+    return float((a - b).norm() / (b.norm() + 1e-12))
+
+
+def check_grads(got, want, tol, floor_frac, label):
+    gscale = max(float(v.norm()) for v in want.values())
+    worst = ("", 0.0)
+    for k, w in want.items():
+        e = float((got[k].cpu().double() - w.double()).norm()) / (float(w.norm()) + floor_frac * gscale)
+        if e > worst[1]:
+            worst = (k, e)
+        assert e < tol, f"{label} grad {k}: rel err {e:.3e}"
+    return worst
+
+
+@pytest.mark.parametrize("dtype", ["float32", "bfloat16"])
+@pytest.mark.parametrize("name", list(AE_CASES))
+def test_autoencoderkl_fwd_bwd(name, dtype):
+    from eegldm.models import AutoencoderKL
+    from oracle import aekl as A, losses as Ls
+    cfg = dict(AE_CASES[name], in_channels=1, out_channels=1, num_res_blocks=2, norm_num_groups=1)
+    B, L = 2, 256
+    shapes = A.aekl_param_shapes(cfg)
+    sd = {k: torch.from_numpy(gen_param(11, k, s)).requires_grad_(True) for k, s in shapes.items()}
+    x = torch.from_numpy(eeg_windows(B, seed=5, length=L, pad=8)).requires_grad_(True)
+    Ll = L >> (len(cfg["num_channels"]) - 1)
+    eps = torch.from_numpy(normal((B, cfg["latent_channels"], Ll), seed=6))
+    recon, mu, sg = A.forward(sd, cfg, x, eps)
+    kl = Ls.kl_loss(mu, sg)
+    dy = torch.from_numpy(normal(tuple(recon.shape), seed=7))
+    klw = 0.3
+    ((recon * dy).sum() + klw * kl).backward()
+
+    net = AutoencoderKL(spatial_dims=1, attention_levels=[False] * len(cfg["num_channels"]), dtype=dtype, **cfg)
+    assert list(net.entries.keys()) == list(shapes.keys())
+    assert sum(int(np.prod(s)) for s in shapes.values()) == sum(n for (_o, n, _s) in net.entries.values())
+    net.load_state_dict({k: v.detach() for k, v in sd.items()})
+    klo = torch.zeros(1, device=net.device)
+    r_d, mu_d, sg_d = net(x.detach(), eps=eps, kl_out=klo)
+    f32 = dtype == "float32"
+    t = 2e-5 if f32 else 5e-2
+    assert rel_l2(r_d, recon) < t and rel_l2(mu_d, mu) < t and rel_l2(sg_d, sg) < t, (rel_l2(r_d, recon), rel_l2(mu_d, mu), rel_l2(sg_d, sg))
+    assert abs(float(klo) - float(kl)) < (1e-4 if f32 else 5e-2) * abs(float(kl)) + 1e-5
+    net.zero_grad()
+    dx = net.backward(dy, kl_weight=klw, need_dx=True)
+    assert rel_l2(dx, x.grad) < (1e-4 if f32 else 0.12), rel_l2(dx, x.grad)
+    worst = check_grads(net.grad_dict(), {k: v.grad for k, v in sd.items()}, 2e-3 if f32 else 0.15, 1e-3 if f32 else 3e-2, name)
+    # encode / decode entry points agree with forward
+    z = net.encode_stage_2_inputs(x.detach(), eps=eps)
+    assert rel_l2(z, (mu + eps * sg)) < t
+    assert rel_l2(net.decode(z), recon) < (t if f32 else 8e-2)
+    print(f"{name} {dtype}: recon {rel_l2(r_d, recon):.2e} dx {rel_l2(dx, x.grad):.2e} worst grad {worst[0]} {worst[1]:.2e}")
+
+
+def test_autoencoderkl_param_counts():
+    """SURVEY.md Appendix B structural recount: 174 184 ([32,32,64], lat 1), 174 984 (lat 3), 934 ([2,2,4])."""
+    from eegldm.models import AutoencoderKL
+    for nc, lat, want in [([32, 32, 64], 1, 174184), ([32, 32, 64], 3, 174984), ([2, 2, 4], 1, 934)]:
+        net = AutoencoderKL(spatial_dims=1, in_channels=1, out_channels=1, num_channels=nc, latent_channels=lat, num_res_blocks=2,
+                            norm_num_groups=1, attention_levels=[False, False, False])
+        assert sum(n for (_o, n, _s) in net.entries.values()) == want
+        r, mu, sg = net(torch.zeros(2, 1, 3072) + 0.5)
+        assert r.shape == (2, 1, 3072) and mu.shape == (2, lat, 768) and sg.shape == (2, lat, 768)
+
+
+@pytest.mark.parametrize("dtype", ["float32", "bfloat16"])
+def test_patch_discriminator_fwd_bwd(dtype):
+    from eegldm.models import PatchDiscriminator
+    from oracle import aekl as A
+    B, L = 3, 256
+    shapes = A.disc_param_shapes(D_CFG)
+    sd = {}
+    for k, s in shapes.items():
+        v = torch.from_numpy(gen_param(21, k, s))
+        if k.endswith("conv.weight"):
+            v = v * 2.0
+        sd[k] = v.requires_grad_(True) if v.is_floating_point() and "running" not in k else v
+    x = torch.from_numpy(normal((B, 1, L), seed=8)).requires_grad_(True)
+    running = {}
+    logits = A.disc_forward(sd, D_CFG, x, True, running)[-1]
+    dy = torch.from_numpy(normal(tuple(logits.shape), seed=9))
+    (logits * dy).sum().backward()
+    net = PatchDiscriminator(**D_CFG, dtype=dtype)
+    assert sum(n for (_o, n, _s) in net.entries.values()) == 519681
+    net.load_state_dict({k: v.detach() for k, v in sd.items()})
+    f32 = dtype == "float32"
+    out = net(x.detach())[-1]
+    assert out.shape == logits.shape
+    assert rel_l2(out, logits) < (2e-5 if f32 else 5e-2), rel_l2(out, logits)
+    net.zero_grad()
+    dx = net.backward(dy, need_dx=True, in_shape=tuple(x.shape))
+    assert rel_l2(dx, x.grad) < (2e-4 if f32 else 0.15), rel_l2(dx, x.grad)
+    want = {k: v.grad for k, v in sd.items() if torch.is_tensor(v) and v.is_floating_point() and v.grad is not None}
+    got = net.grad_dict()
+    worst = check_grads({k: got[k] for k in want}, want, 2e-3 if f32 else 0.15, 1e-3 if f32 else 3e-2, "disc")
+    new = net.state_dict()
+    for k, v in running.items():
+        assert rel_l2(new[k], v) < (1e-5 if f32 else 2e-2), k
+    assert int(new["0.adn.N.num_batches_tracked"]) == 1
+    # eval mode uses the running statistics
+    net.eval()
+    sd_eval = {k: (new[k].cpu() if k in new else v) for k, v in sd.items()}
+    ref_eval = A.disc_forward({k: v.detach() if torch.is_tensor(v) else v for k, v in sd_eval.items()}, D_CFG, x.detach(), False)[-1]
+    assert rel_l2(net(x.detach())[-1], ref_eval) < (2e-5 if f32 else 5e-2)
+    print(f"disc {dtype}: logits {rel_l2(out, logits):.2e} dx {rel_l2(dx, x.grad):.2e} worst grad {worst[0]} {worst[1]:.2e}")
+
+
+@pytest.mark.parametrize("L", [3072, 768, 256, 96])
+def test_spectral_l1_lsgan_losses(L):
+    import gpu_util as G
+    from oracle import losses as Ls
+    c = G.ctx(); B = 3
+    a = torch.from_numpy(eeg_windows(B, seed=1, length=L, pad=4)) + 0.05 * torch.from_numpy(normal((B, 1, L), seed=2))
+    b = torch.from_numpy(eeg_windows(B, seed=3, length=L, pad=4))
+    ar = a.clone().requires_grad_(True)
+    spec = Ls.jukebox_loss(ar, b, "sum"); spec.backward()
+    ad, bd = a.to(G.DEV), b.to(G.DEV)
+    loss = torch.zeros(1, device=G.DEV); d = torch.zeros(B, 1, L, device=G.DEV)
+    G.check(G.lib.eegldm_spectral_loss(c.h, G.ptr(ad), G.ptr(bd), G.ptr(loss), G.ptr(d), B, 1, L, 2.5))
+    assert abs(float(loss) - float(spec)) < 2e-5 * abs(float(spec)) + 1e-6, (float(loss), float(spec))
+    assert rel_l2(d, 2.5 * ar.grad) < 5e-5, rel_l2(d, 2.5 * ar.grad)
+    # closed forms: loss(x, x) == 0 ; Parseval
+    G.check(G.lib.eegldm_spectral_loss(c.h, G.ptr(ad), G.ptr(ad), G.ptr(loss), None, B, 1, L, 0.0))
+    assert float(loss) < 1e-8
+    z = torch.zeros_like(ad)
+    G.check(G.lib.eegldm_spectral_loss(c.h, G.ptr(ad), G.ptr(z), G.ptr(loss), None, B, 1, L, 0.0))
+    assert abs(float(loss) - float((a ** 2).sum())) < 1e-4 * float((a ** 2).sum())
+    # L1
+    ar = a.clone().requires_grad_(True); l1 = F.l1_loss(ar, b); l1.backward()
+    d.zero_()
+    G.check(G.lib.eegldm_l1_loss(c.h, G.ptr(ad), G.ptr(bd), G.ptr(loss), G.ptr(d), B * L, 1.0))
+    assert abs(float(loss) - float(l1)) < 1e-5 * float(l1) and rel_l2(d, ar.grad) < 1e-6
+    # LSGAN
+    lg = torch.from_numpy(normal((B, 1, L), seed=4))
+    for real, for_d in [(True, False), (False, True), (True, True)]:
+        lr = lg.clone().requires_grad_(True); ref = Ls.patch_adv_loss(lr, real, for_d); ref.backward()
+        lgd = lg.to(G.DEV); dl = torch.empty(B, 1, L, device=G.DEV)
+        G.check(G.lib.eegldm_lsgan_loss(c.h, G.ptr(lgd), int(real), G.ptr(loss), G.ptr(dl), B * L, 1.0))
+        assert abs(float(loss) - float(ref)) < 1e-5 * float(ref) and rel_l2(dl, lr.grad) < 1e-6
+
+
+@pytest.mark.parametrize("use_spectral", [False, True])
+def test_fused_aekl_gan_train_step_matches_oracle(use_spectral):
+    """Two full G+D steps (forward, all losses, backward, Adam x2, BatchNorm running stats) vs oracle/steps.py."""
+    from eegldm.models import AutoencoderKL, PatchDiscriminator
+    from eegldm.training import Adam, aekl_train_step
+    from oracle import aekl as A, steps as S
+    cfg = dict(num_channels=[32, 32, 64], latent_channels=1, in_channels=1, out_channels=1, num_res_blocks=2, norm_num_groups=1)
+    B, L = 4, 256
+    ae_sd = {k: torch.from_numpy(gen_param(31, k, s)) for k, s in A.aekl_param_shapes(cfg).items()}
+    d_sd = {k: torch.from_numpy(gen_param(32, k, s)) for k, s in A.disc_param_shapes(D_CFG).items()}
+    adv_w, kl_w, spec_w = 0.01, 1e-3, 1e-2
+    ae = AutoencoderKL(spatial_dims=1, attention_levels=[False] * 3, **cfg); ae.load_state_dict(ae_sd)
+    disc = PatchDiscriminator(**D_CFG); disc.load_state_dict(d_sd)
+    og, od = Adam(ae, lr=5e-3), Adam(disc, lr=5e-4)
+    sg, sdd = {}, {}
+    for step in (1, 2):
+        x = torch.from_numpy(eeg_windows(B, seed=40 + step, length=L, pad=8))
+        eps = torch.from_numpy(normal((B, 1, L // 4), seed=50 + step))
+        losses, ae_sd, d_sd, recon, _gg, _dg = S.aekl_train_step(ae_sd, cfg, d_sd, D_CFG, x, eps, adv_w, kl_w, spec_w, use_spectral,
+                                                                 5e-3, 5e-4, step, sg, sdd)
+        ae.zero_grad(); disc.zero_grad()
+        rec_d = torch.empty(B, 1, L, device=ae.device)
+        out = aekl_train_step(ae, disc, x.to(ae.device), eps.to(ae.device), adv_w, kl_w, spec_w, use_spectral, recon_out=rec_d)
+        og.step(); od.step()
+        o = out.cpu()
+        want = [losses["recons"], losses["spectral"], losses["kl"], losses["gen"]]
+        for i, w in enumerate(want):
+            assert abs(float(o[i]) - float(w)) < 2e-4 * abs(float(w)) + 1e-6, (step, i, float(o[i]), float(w))
+        assert abs(0.5 * float(o[4] + o[5]) - float(losses["disc"])) < 2e-4 * float(losses["disc"]) + 1e-6
+        assert rel_l2(rec_d, recon) < 2e-5
+    # Adam moves every weight by ~lr per step, so updated parameters are compared in absolute units of lr
+    got = ae.state_dict()
+    for k, v in ae_sd.items():
+        assert float((got[k].cpu() - v).abs().max()) < 0.15 * 5e-3, f"ae {k}: {float((got[k].cpu() - v).abs().max()):.3e}"
+    gotd = disc.state_dict()
+    for k, v in d_sd.items():
+        if "num_batches" in k:
+            assert int(gotd[k]) == 6
+        else:
+            lim = 0.15 * 5e-4 if "running" not in k else 1e-4
+            assert float((gotd[k].cpu().float() - v.float()).abs().max()) < lim + 1e-5 * float(v.abs().max()), f"disc {k}"
