@@ -109,13 +109,16 @@ class AutoencoderKL(_Flat):
         eps = torch.randn_like(z_sigma) if eps is None else eps.to(z_sigma.device)
         return z_mu + eps * z_sigma        # elementwise glue on caller tensors; the fused path is encode_stage_2_inputs
 
-    def encode_stage_2_inputs(self, x, eps=None):
+    def encode_stage_2_inputs(self, x, eps=None, scale_factor=None):
+        """z = mu + eps * sigma (Stage1Wrapper, training.py:15-26), optionally times scale_factor (training.py:426)."""
         x = self._x(x); B, _c, L = x.shape
         z = torch.empty(B, self.latent_channels, L // self.down, device=self.device)
         if eps is None:
             eps = torch.randn(z.shape, device=self.device)
         eps = self._x(eps)
         check(lib.eegldm_aekl_encode(self.h, ptr(x), ptr(eps), ptr(z), None, None, B, L))
+        if scale_factor is not None and float(scale_factor) != 1.0:
+            check(lib.eegldm_axpy(self.ctx.h, ptr(z), ptr(z), float(scale_factor) - 1.0, z.numel()))
         return z
 
     def decode(self, z):
