@@ -4,9 +4,11 @@
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...   (N>1)
 
 A "step" is one LDM train step of the reference loop (/root/reference/src/training/training.py:419-443)
-on one synthetic batch per GPU: draw timesteps + noise on device, [frozen AutoencoderKL encode when the
-AEKL executor is present], add_noise, UNet(config_ldm.yaml) forward, MSE, hand-written backward,
-gradient all-reduce (N>1, RCCL), fused Adam, bf16 weight refresh.  Inputs are resident in HBM when the
+on one synthetic batch of raw (B,1,3072) windows per GPU: draw timesteps + noise + eps on device, frozen
+AutoencoderKL [32,32,64] encode + sampling x scale_factor, add_noise, UNet(config_ldm.yaml) forward, MSE,
+hand-written backward, gradient all-reduce (N>1, RCCL), fused Adam, bf16 weight refresh.
+Secondary measurements (same JSON line, `parts`): the AEKL/GAN train step of BASELINE configs[1]
+(config_aekl_eeg_2_2_4_spec.yaml, spectral loss on, batch 256) and DDIM-50 sampling + decode.  Inputs are resident in HBM when the
 timed region starts.  Prints ONE JSON line on rank 0; `roofline` is measured live with HIP events
 around every launch of the dominant kernel class on the library's stream; `cpu_baseline` times the
 oracle (torch CPU fp32, same math) on this host's cores on a bounded sample (rank 0, N=1 only).
@@ -37,6 +39,7 @@ def parse():
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--no-parts", action="store_true", help="skip the secondary AEKL-GAN / DDIM-50 measurements")
     return ap.parse_args()
 
 
@@ -71,9 +74,11 @@ def main():
     import torch
     import eegldm
     from eegldm import distributed as D
-    from eegldm.models import UNetModel
+    from eegldm.models import UNetModel, AutoencoderKL, PatchDiscriminator
     from eegldm.schedulers import DDPMScheduler
-    from eegldm.training import Adam, ldm_train_step, randint, randn
+    from eegldm.training import Adam, ldm_train_step, aekl_train_step, randint, randn
+    from eegldm.sampling import ddim_sample, make_sampling_scheduler
+    from param_gen import eeg_windows
 
     rank, local, world = D.init_from_env()
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world} (launch with torch.distributed.run)"
@@ -92,12 +97,19 @@ def main():
     sched = DDPMScheduler(num_train_timesteps=1000, schedule="scaled_linear_beta", beta_start=0.0015, beta_end=0.0195, device=local)
     opt = Adam(unet, lr=1e-4)
     loss = torch.zeros(1, device=dev)
-    # synthetic latents of the AEKL output shape, resident in HBM (per-rank RNG stream)
-    latents = randn(ctx, (B, 1, L), seed=1234 + rank)
+    # frozen stage-1 autoencoder (production channels [32,32,64], latent 1: clusters/run_aekl_shhs_1.sh:8-10)
+    ae = AutoencoderKL(spatial_dims=1, in_channels=1, out_channels=1, num_channels=[32, 32, 64], latent_channels=1, num_res_blocks=2,
+                       norm_num_groups=1, attention_levels=[False, False, False], dtype=dtype, device=local)
+    D.broadcast_flat(ae.flat); ae.sync_weights()
+    # synthetic 30-s windows (SURVEY 8d recipe), resident in HBM before the timed region; per-rank stream
+    windows = torch.from_numpy(eeg_windows(B, seed=1234 + rank, length=4 * L)).to(dev)
+    scale_factor = 1.0 / float(ae.encode_stage_2_inputs(windows, eps=randn(ctx, (B, 1, L), seed=99)).std())   # train_ldm.py:203-204
 
     def step(i):
         t = randint(ctx, B, 1000, seed=1235 + rank, offset=i * B)
         noise = randn(ctx, (B, 1, L), seed=1236 + rank, offset=i * B * L)
+        eps = randn(ctx, (B, 1, L), seed=1237 + rank, offset=i * B * L)
+        latents = ae.encode_stage_2_inputs(windows, eps=eps, scale_factor=scale_factor)
         unet.zero_grad()
         ldm_train_step(unet, sched, latents, noise, t, loss_out=loss)
         D.allreduce_mean_flat(unet.flat_grad)
@@ -139,6 +151,47 @@ def main():
                                               "ms_per_step": round(vv["ms"] / 2, 3), "launches_per_step": vv["launches"] // 2}
                                          for kk, vv in summ.items() if vv["launches"]}}
 
+    # ---- secondary workloads (rank 0 only; not part of `value`)
+    parts = None
+    if rank == 0 and not args.no_parts:
+        parts = {}
+        Ba = args.batch
+        ae2 = AutoencoderKL(spatial_dims=1, in_channels=1, out_channels=1, num_channels=[2, 2, 4], latent_channels=1, num_res_blocks=2,
+                            norm_num_groups=1, attention_levels=[False, False, False], dtype=dtype, device=local)
+        disc = PatchDiscriminator(spatial_dims=1, num_layers_d=3, num_channels=64, in_channels=1, out_channels=1, kernel_size=3,
+                                  norm="BATCH", bias=False, padding=1, dtype=dtype, device=local)
+        og, od = Adam(ae2, lr=5e-3), Adam(disc, lr=5e-4)
+        xw = torch.from_numpy(eeg_windows(Ba, seed=77, length=4 * L)).to(dev)
+        lo = torch.zeros(6, device=dev)
+
+        def gan_step(i):
+            eps = randn(ctx, (Ba, 1, L), seed=555, offset=i * Ba * L)
+            ae2.zero_grad(); disc.zero_grad()
+            aekl_train_step(ae2, disc, xw, eps, 0.01, 1e-9, 1e4, True, losses_out=lo)   # config_aekl_eeg.yaml:13-17 weights
+            og.step(); od.step()
+
+        for i in range(2):
+            gan_step(i)
+        torch.cuda.synchronize(); t1 = time.time()
+        n_gan = max(3, args.steps // 2)
+        for i in range(n_gan):
+            gan_step(2 + i)
+        torch.cuda.synchronize(); dtg = (time.time() - t1) / n_gan
+        parts["aekl_gan_train_step"] = {"windows_per_s": round(Ba / dtg, 1), "ms_per_step": round(1e3 * dtg, 3), "batch": Ba,
+                                        "config": "config_aekl_eeg_2_2_4_spec.yaml: AutoencoderKL [2,2,4] + PatchDiscriminator(64, 3 layers) + "
+                                                  "L1 + KL + LSGAN + spectral(1e4), Adam 5e-3 / 5e-4",
+                                        "losses": [round(float(v), 5) for v in lo.cpu()]}
+        Bs = min(args.batch, 256)
+        sch = make_sampling_scheduler(50, device=local)
+        nz = randn(ctx, (Bs, 1, L), seed=4242)
+        ddim_sample(unet, ae, sch, nz[:8], scale_factor=scale_factor)      # warm-up
+        torch.cuda.synchronize(); t1 = time.time()
+        out, _ = ddim_sample(unet, ae, sch, nz, scale_factor=scale_factor)
+        torch.cuda.synchronize(); dts = time.time() - t1
+        parts["ddim50_sample_decode"] = {"windows_per_s": round(Bs / dts, 1), "seconds": round(dts, 3), "batch": Bs, "steps": 50,
+                                         "config": "config_ldm.yaml UNet, DDIM-50 (scaled-linear 0.0015-0.0205, eta 0), decode [32,32,64], crop to 3000",
+                                         "out_shape": list(out.shape), "gflop_per_window": 695.3}
+
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         cpu = cpu_baseline()
@@ -148,11 +201,12 @@ def main():
             "metric": "EEG windows/sec (LDM train step)", "value": round(world * B * args.steps / elapsed, 2), "unit": "windows/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed / args.steps, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
-            "config": {"workload": "LDM train step: config_ldm.yaml UNet (30.5M params, latent_channels=1) over (B,1,768) latents, "
-                                   "epsilon-prediction MSE, Adam lr 1e-4 [BASELINE configs[2]/[3]]",
+            "config": {"workload": "LDM train step on raw (B,1,3072) windows: frozen AutoencoderKL[32,32,64] encode+sample x scale, add_noise, "
+                                   "config_ldm.yaml UNet (30.5M params, latent_channels=1) fwd+bwd, epsilon MSE, Adam lr 1e-4 "
+                                   "[BASELINE configs[2]/[3]: per-GPU batch 256 = global 2048 / 8]",
                        "per_gpu_batch": B, "global_batch": world * B, "latent_len": L, "parallelism": f"dp{world}",
-                       "final_loss": round(final_loss, 5), "gflop_per_window": 41.7},
-            "roofline": roofline, "cpu_baseline": cpu,
+                       "final_loss": round(final_loss, 5), "gflop_per_window": 41.9},
+            "roofline": roofline, "cpu_baseline": cpu, "parts": parts,
         }
         print(json.dumps(out))
     if world > 1:

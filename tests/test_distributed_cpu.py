@@ -1,0 +1,51 @@
+"""CPU, world_size 2, gloo: the data-parallel glue (flat-gradient all-reduce mean, parameter broadcast,
+seed sharding) gives the same result as one rank on the concatenated batch."""
+import os
+import sys
+
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    from eegldm import distributed as D
+    r, _l, w = D.init_from_env(backend="gloo")
+    assert (r, w) == (rank, world)
+    torch.manual_seed(0)
+    flat = torch.randn(1000) if rank == 0 else torch.zeros(1000)
+    D.broadcast_flat(flat)                              # parameters: rank 0 -> all
+    grads = torch.arange(3000, dtype=torch.float32) * (rank + 1)
+    D.allreduce_mean_flat(grads, bucket_elems=700)      # several uneven buckets
+    lo, hi = D.shard_range(11, rank, world)
+    q.put((rank, flat.sum().item(), grads.tolist(), (lo, hi)))     # plain python: no fd passing after the child exits
+    dist.destroy_process_group()
+
+
+def test_gloo_world2_allreduce_and_sharding():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29500 + os.getpid() % 400
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=120) for _ in procs], key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert res[0][1] == res[1][1]                                    # broadcast made parameters identical
+    want = torch.arange(3000, dtype=torch.float32) * 1.5             # mean of 1x and 2x
+    assert torch.allclose(torch.tensor(res[0][2]), want) and torch.allclose(torch.tensor(res[1][2]), want)
+    assert res[0][3] == (0, 6) and res[1][3] == (6, 11)             # 11 seeds over 2 ranks, contiguous, complete
+
+
+def test_single_process_is_noop():
+    sys.path.insert(0, ROOT)
+    from eegldm import distributed as D
+    t = torch.ones(10)
+    D.allreduce_mean_flat(t); D.broadcast_flat(t)
+    assert torch.equal(t, torch.ones(10)) and D.shard_range(5, 0, 1) == (0, 5)
