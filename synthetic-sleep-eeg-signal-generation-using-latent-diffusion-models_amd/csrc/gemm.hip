@@ -20,7 +20,13 @@
 // overlaps the MFMA phase), because the conv halo, sample-boundary zero fill, tap flip
 // and row maps need per-lane source addressing that LDS-DMA cannot express.
 // K-contiguous operands are read with ds_read_b128; K-strided operands ("TR") with
-// ds_read_b64_tr_b16 (bf16) or ds_read_b32 (fp32).
+// ds_read_b64_tr_b16 (bf16) or ds_read_b32 (fp32).  LDS images are XOR-swizzled (no padding) so
+// that the b128 fragment reads, the transpose reads and the b128 staging writes are all
+// bank-conflict-free for the 128-wide tiles (model + search: tools/lds_conflicts.py).
+// The MFMA is issued with A and B swapped (D' = B.A^T), so every lane ends up holding FOUR
+// CONSECUTIVE output channels of one row; the epilogue passes the tile through LDS once and
+// writes full 16-byte (fp32) / 8-byte (bf16) vectors -- whole 256-byte rows per 32 lanes --
+// with bias, timestep-embedding and residual adds done on those vectors.
 #include "common.h"
 
 namespace {
@@ -45,10 +51,25 @@ template <> __device__ __forceinline__ void mma<bf16_t>(const uint4& a, const ui
 
 typedef s16x4 __attribute__((address_space(3))) * lds_s16x4_ptr;
 
-// K-strided fragment read from a [k rows][x cols] tile (row pitch in bytes).
-template <typename T>
-__device__ __forceinline__ uint4 read_tr(const char* tile, int pitch, int ks, int x0, int lm, int q);
-template <> __device__ __forceinline__ uint4 read_tr<float>(const char* tile, int pitch, int ks, int x0, int lm, int q) {
+// ---- LDS swizzles -------------------------------------------------------------------
+// NT tile: rows of KSUB*64 bytes, 16-byte slots; slot ^= f(row).
+template <int KSUB> __device__ __forceinline__ int nt_swz(int row, int slot) {
+  if constexpr (KSUB == 1) return slot ^ (((row >> 2) & 1) * 3);
+  else return slot ^ (2 * ((row >> 1) & 3));
+}
+// TR bf16 tile: rows of BX*2 bytes; byte offset within the row ^= 32 * g(row) (mod row size)
+template <int BX> __device__ __forceinline__ int tr_swz(int row, int colbyte) {
+  return colbyte ^ ((((row & 3) | (((row >> 3) & 1) << 2)) * 32) & (BX * 2 - 1));
+}
+
+// K-strided fragment read from a [k rows][x cols] tile.
+template <typename T, int BX> struct TrPitch;
+template <int BX> struct TrPitch<float, BX> { static constexpr int v = BX * 4 + 16; };
+template <int BX> struct TrPitch<bf16_t, BX> { static constexpr int v = BX * 2; };
+
+template <int BX>
+__device__ __forceinline__ uint4 read_tr_f32(const char* tile, int ks, int x0, int lm, int q) {
+  constexpr int pitch = TrPitch<float, BX>::v;
   const char* p = tile + (ks * 16 + 4 * q) * pitch + (x0 + lm) * 4;
   uint4 r;
   r.x = *(const unsigned*)(p);
@@ -57,18 +78,33 @@ template <> __device__ __forceinline__ uint4 read_tr<float>(const char* tile, in
   r.w = *(const unsigned*)(p + 3 * pitch);
   return r;
 }
-template <> __device__ __forceinline__ uint4 read_tr<bf16_t>(const char* tile, int pitch, int ks, int x0, int lm, int q) {
+template <int BX>
+__device__ __forceinline__ uint4 read_tr_bf16(const char* tile, int ks, int x0, int lm, int q) {
   // lane p of a 16-lane group supplies row (base + p/4), 4 columns at 4*(p%4); it receives
   // column p of the 4x16 block, rows base..base+3 (verified: tools/probes/layout_probe.hip).
-  const char* p0 = tile + (ks * 32 + 8 * q + (lm >> 2)) * pitch + (x0 + 4 * (lm & 3)) * 2;
+  constexpr int pitch = TrPitch<bf16_t, BX>::v;
+  const int row0 = ks * 32 + 8 * q + (lm >> 2), colb = (x0 + 4 * (lm & 3)) * 2;
+  const char* p0 = tile + row0 * pitch + tr_swz<BX>(row0, colb);
+  const char* p1 = tile + (row0 + 4) * pitch + tr_swz<BX>(row0 + 4, colb);
   s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(p0));
-  s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(p0 + 4 * pitch));
+  s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(p1));
   uint4 r;
   r.x = (unsigned)(unsigned short)lo[0] | ((unsigned)(unsigned short)lo[1] << 16);
   r.y = (unsigned)(unsigned short)lo[2] | ((unsigned)(unsigned short)lo[3] << 16);
   r.z = (unsigned)(unsigned short)hi[0] | ((unsigned)(unsigned short)hi[1] << 16);
   r.w = (unsigned)(unsigned short)hi[2] | ((unsigned)(unsigned short)hi[3] << 16);
   return r;
+}
+template <typename T, int BX>
+__device__ __forceinline__ uint4 read_tr_t(const char* tile, int ks, int x0, int lm, int q) {
+  if constexpr (sizeof(T) == 4) return read_tr_f32<BX>(tile, ks, x0, lm, q);
+  else return read_tr_bf16<BX>(tile, ks, x0, lm, q);
+}
+// byte offset of 16-byte chunk (krow, seg) of a TR tile
+template <typename T, int BX>
+__device__ __forceinline__ int tr_store_off(int krow, int seg) {
+  if constexpr (sizeof(T) == 4) return krow * TrPitch<float, BX>::v + seg * 16;
+  else return krow * TrPitch<bf16_t, BX>::v + tr_swz<BX>(krow, seg * 16);
 }
 
 template <typename T, int AMODE, int BMODE, int TAPS, int KSUB, int BN, int STRIDE>
@@ -77,10 +113,10 @@ struct Cfg {
   static constexpr int EPC = Tr<T>::EPC;
   static constexpr int KSTAGE = KSUB * KC;                       // K elements per stage
   static constexpr int SEGS = 4 * KSUB;                          // 16B chunks per NT row
-  static constexpr int PITCH_NT = KSUB * 64 + 16;                // bytes
+  static constexpr int PITCH_NT = KSUB * 64;                     // bytes (XOR-swizzled, unpadded)
   static constexpr int A_ROWS_NT = (AMODE == GA_CONV) ? (BM * STRIDE + TAPS - 1) : BM;
-  static constexpr int PITCH_A_TR = BM * (int)sizeof(T) + 16;
-  static constexpr int PITCH_B_TR = BN * (int)sizeof(T) + 16;
+  static constexpr int PITCH_A_TR = TrPitch<T, BM>::v;
+  static constexpr int PITCH_B_TR = TrPitch<T, BN>::v;
   static constexpr int A_BYTES = (AMODE == GA_TR) ? KSTAGE * PITCH_A_TR : A_ROWS_NT * PITCH_NT;
   static constexpr int B_TILE_BYTES = (BMODE == GB_TR) ? KSTAGE * PITCH_B_TR : BN * PITCH_NT;
   static constexpr int B_BYTES = TAPS * B_TILE_BYTES;
@@ -89,7 +125,9 @@ struct Cfg {
   static constexpr int CA = (A_CHUNKS + NTHREADS - 1) / NTHREADS;
   static constexpr int CB = (B_CHUNKS + NTHREADS - 1) / NTHREADS;
   static constexpr int FN = BN / 32;                              // 16-wide fragments per wave along N
-  static constexpr int LDS_BYTES = A_BYTES + B_BYTES;
+  static constexpr int EPI_PITCH = BN * 4 + 16;                   // fp32 epilogue tile [32][BN]
+  static constexpr int EPI_BYTES = 32 * EPI_PITCH;
+  static constexpr int LDS_BYTES = (A_BYTES + B_BYTES) > EPI_BYTES ? (A_BYTES + B_BYTES) : EPI_BYTES;
 };
 
 template <typename T, int AMODE, int BMODE, int TAPS, int KSUB, int BN, int STRIDE>
@@ -200,9 +238,10 @@ __global__ __launch_bounds__(NTHREADS) void gemm_kernel(const GemmArgs p) {
       if (c < C::A_CHUNKS) {
         if constexpr (AMODE == GA_TR) {
           constexpr int RC = BM / C::EPC;
-          *(uint4*)(smA + (c / RC) * C::PITCH_A_TR + (c % RC) * 16) = ra[i];
+          *(uint4*)(smA + tr_store_off<T, BM>(c / RC, c % RC)) = ra[i];
         } else {
-          *(uint4*)(smA + (c / C::SEGS) * C::PITCH_NT + (c % C::SEGS) * 16) = ra[i];
+          const int row = c / C::SEGS;
+          *(uint4*)(smA + row * C::PITCH_NT + nt_swz<KSUB>(row, c % C::SEGS) * 16) = ra[i];
         }
       }
     }
@@ -213,10 +252,11 @@ __global__ __launch_bounds__(NTHREADS) void gemm_kernel(const GemmArgs p) {
         if constexpr (BMODE == GB_TR) {
           constexpr int RC = BN / C::EPC;
           const int tap = c / (C::KSTAGE * RC), r = c % (C::KSTAGE * RC);
-          *(uint4*)(smB + tap * C::B_TILE_BYTES + (r / RC) * C::PITCH_B_TR + (r % RC) * 16) = rb[i];
+          *(uint4*)(smB + tap * C::B_TILE_BYTES + tr_store_off<T, BN>(r / RC, r % RC)) = rb[i];
         } else {
           const int tap = c / (BN * C::SEGS), r = c % (BN * C::SEGS);
-          *(uint4*)(smB + tap * C::B_TILE_BYTES + (r / C::SEGS) * C::PITCH_NT + (r % C::SEGS) * 16) = rb[i];
+          const int row = r / C::SEGS;
+          *(uint4*)(smB + tap * C::B_TILE_BYTES + row * C::PITCH_NT + nt_swz<KSUB>(row, r % C::SEGS) * 16) = rb[i];
         }
       }
     }
@@ -257,11 +297,11 @@ __global__ __launch_bounds__(NTHREADS) void gemm_kernel(const GemmArgs p) {
 #pragma unroll
         for (int i = 0; i < 4; i++) {
           if constexpr (AMODE == GA_TR) {
-            af[i] = read_tr<T>(smA, C::PITCH_A_TR, ks, wm * 64 + i * 16, lm, q);
+            af[i] = read_tr_t<T, BM>(smA, ks, wm * 64 + i * 16, lm, q);
           } else {
             int row = wm * 64 + i * 16 + lm;
             if constexpr (AMODE == GA_CONV) row = row * STRIDE + t;
-            af[i] = *(const uint4*)(smA + row * C::PITCH_NT + ks * 64 + q * 16);
+            af[i] = *(const uint4*)(smA + row * C::PITCH_NT + nt_swz<KSUB>(row, ks * 4 + q) * 16);
             if constexpr (AMODE == GA_CONV) {
               if (zmask & (1u << (i * TAPS + t))) af[i] = zero4;
             }
@@ -270,49 +310,106 @@ __global__ __launch_bounds__(NTHREADS) void gemm_kernel(const GemmArgs p) {
 #pragma unroll
         for (int j = 0; j < FN; j++) {
           if constexpr (BMODE == GB_TR) {
-            bf[j] = read_tr<T>(smB + t * C::B_TILE_BYTES, C::PITCH_B_TR, ks, wn * (BN / 2) + j * 16, lm, q);
+            bf[j] = read_tr_t<T, BN>(smB + t * C::B_TILE_BYTES, ks, wn * (BN / 2) + j * 16, lm, q);
           } else {
             const int row = wn * (BN / 2) + j * 16 + lm;
-            bf[j] = *(const uint4*)(smB + t * C::B_TILE_BYTES + row * C::PITCH_NT + ks * 64 + q * 16);
+            bf[j] = *(const uint4*)(smB + t * C::B_TILE_BYTES + row * C::PITCH_NT + nt_swz<KSUB>(row, ks * 4 + q) * 16);
           }
         }
 #pragma unroll
         for (int i = 0; i < 4; i++)
 #pragma unroll
-          for (int j = 0; j < FN; j++) mma<T>(af[i], bf[j], acc[i][j]);
+          for (int j = 0; j < FN; j++) {
+            if constexpr (AMODE == GA_TR) mma<T>(af[i], bf[j], acc[i][j]);      // TN products keep the natural fragment (atomic epilogue)
+            else mma<T>(bf[j], af[i], acc[i][j]);                                // swapped: acc = (B.A^T) fragment
+          }
       }
     }
     __syncthreads();
   }
 
   // ---- epilogue ---------------------------------------------------------------------
+  // acc[i][j][r] = C[m = wm*64 + i*16 + lm][n = wn*(BN/2) + j*16 + q*4 + r] (operands were swapped).
+  // Four passes of 32 rows through an fp32 LDS tile, then 4-wide vector read-modify-store.
   char* Cb = (char*)p.C;
   const long cbase = (long)bz * p.sCb + (long)tz * p.sCt;
+  constexpr int CH = BN / 4;                      // 4-element chunks per row
+  constexpr int NCH = 32 * CH;                    // chunks per pass
+  if constexpr (AMODE == GA_TR) {
+    if (p.atomic_out) {
+      // split-K weight gradients: natural fragment layout (rows q*4+r, col lm), fp32 atomics straight from registers
+#pragma unroll
+      for (int i = 0; i < 4; i++)
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+          const int m = m0 + wm * 64 + i * 16 + q * 4 + r;
+          if (m >= p.M) continue;
+#pragma unroll
+          for (int j = 0; j < FN; j++) {
+            const int n = n0 + wn * (BN / 2) + j * 16 + lm;
+            if (n < p.N) atomicAdd((float*)Cb + cbase + (long)m * p.ldc + n, acc[i][j][r] * p.alpha);
+          }
+        }
+      return;
+    }
+  }
 #pragma unroll
   for (int i = 0; i < 4; i++) {
 #pragma unroll
-    for (int r = 0; r < 4; r++) {
-      const int m = m0 + wm * 64 + i * 16 + q * 4 + r;
-      if (m >= p.M) continue;
-      const float* rv = p.rowvec ? p.rowvec + (long)(m / p.rows_per_vec) * p.ld_rowvec : nullptr;
+    for (int j = 0; j < FN; j++) {
+      if constexpr (AMODE == GA_TR) {
 #pragma unroll
-      for (int j = 0; j < FN; j++) {
-        const int n = n0 + wn * (BN / 2) + j * 16 + lm;
-        if (n >= p.N) continue;
-        float v = acc[i][j][r] * p.alpha;
-        if (p.bias) v += p.bias[n];
-        if (rv) v += rv[n];
-        if (p.resid) v += ld_f32((const T*)p.resid + (long)m * p.ldr + n);
-        const long off = cbase + (long)m * p.ldc + n;
-        if (p.atomic_out) {
-          atomicAdd((float*)Cb + off, v);
-        } else if (p.out_f32) {
-          ((float*)Cb)[off] = v;
-        } else {
-          st_f32((T*)Cb + off, v);
+        for (int r = 0; r < 4; r++)
+          *(float*)(smem + (wm * 16 + q * 4 + r) * C::EPI_PITCH + (wn * (BN / 2) + j * 16 + lm) * 4) = acc[i][j][r] * p.alpha;
+      } else {
+        float4 v = make_float4(acc[i][j][0] * p.alpha, acc[i][j][1] * p.alpha, acc[i][j][2] * p.alpha, acc[i][j][3] * p.alpha);
+        *(float4*)(smem + (wm * 16 + lm) * C::EPI_PITCH + (wn * (BN / 2) + j * 16 + q * 4) * 4) = v;
+      }
+    }
+    __syncthreads();
+    if (p.atomic_out) {
+      // split-K / accumulate: one float per lane so each wave-instruction hits 256 contiguous bytes
+      for (int c = tid; c < 32 * BN; c += NTHREADS) {
+        const int row = c / BN, col = c % BN;
+        const int m = m0 + (row >> 4) * 64 + i * 16 + (row & 15), n = n0 + col;
+        if (m < p.M && n < p.N) atomicAdd((float*)Cb + cbase + (long)m * p.ldc + n, *(const float*)(smem + row * C::EPI_PITCH + col * 4));
+      }
+    } else
+#pragma unroll
+    for (int cc = 0; cc < (NCH + NTHREADS - 1) / NTHREADS; cc++) {
+      const int c = tid + cc * NTHREADS;
+      if (c < NCH) {
+        const int row = c / CH, cs = c % CH;
+        const int m = m0 + (row >> 4) * 64 + i * 16 + (row & 15), n = n0 + cs * 4;
+        if (m < p.M && n < p.N) {
+          float4 v = *(const float4*)(smem + row * C::EPI_PITCH + cs * 16);
+          if (p.bias) { const float4 b = *(const float4*)(p.bias + n); v.x += b.x; v.y += b.y; v.z += b.z; v.w += b.w; }
+          if (p.rowvec) {
+            const float4 b = *(const float4*)(p.rowvec + (long)(m / p.rows_per_vec) * p.ld_rowvec + n);
+            v.x += b.x; v.y += b.y; v.z += b.z; v.w += b.w;
+          }
+          const long off = cbase + (long)m * p.ldc + n;
+          if (p.resid) {
+            const T* rp = (const T*)p.resid + (long)m * p.ldr + n;
+            if constexpr (sizeof(T) == 4) { const float4 b = *(const float4*)rp; v.x += b.x; v.y += b.y; v.z += b.z; v.w += b.w; }
+            else {
+              const uint2 b = *(const uint2*)rp;
+              v.x += __uint_as_float(b.x << 16); v.y += __uint_as_float(b.x & 0xffff0000u);
+              v.z += __uint_as_float(b.y << 16); v.w += __uint_as_float(b.y & 0xffff0000u);
+            }
+          }
+          if (p.out_f32 || sizeof(T) == 4) {
+            *(float4*)((float*)Cb + off) = v;
+          } else {
+            uint2 o;
+            o.x = (unsigned)f32_to_bf16(v.x) | ((unsigned)f32_to_bf16(v.y) << 16);
+            o.y = (unsigned)f32_to_bf16(v.z) | ((unsigned)f32_to_bf16(v.w) << 16);
+            *(uint2*)((bf16_t*)Cb + off) = o;
+          }
         }
       }
     }
+    __syncthreads();
   }
 }
 
@@ -321,7 +418,7 @@ int launch_t(eegldm_ctx* ctx, const GemmArgs& a) {
   using C = Cfg<T, AMODE, BMODE, TAPS, KSUB, BN, STRIDE>;
   auto kern = gemm_kernel<T, AMODE, BMODE, TAPS, KSUB, BN, STRIDE>;
   static bool attr_set = false;
-  if (!attr_set && C::LDS_BYTES > 64 * 1024) {
+  if (!attr_set && C::LDS_BYTES > 48 * 1024) {
     HIP_TRY(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES));
     attr_set = true;
   }
@@ -376,6 +473,9 @@ int gemm_launch(eegldm_ctx* ctx, const GemmArgs& a_in) {
   if (a.bmode == GB_TR) EEG_CHECK(a.N % epc == 0 && a.ldb % epc == 0, "B(TR): N, ldb must be multiples of %d", epc);
   else EEG_CHECK(a.K % epc == 0 && a.ldb % epc == 0, "B: K, ldb must be multiples of %d", epc);
   EEG_CHECK(!(a.atomic_out || a.splitk > 1) || a.out_f32, "atomic / split-K output must be f32");
+  EEG_CHECK(a.N % 4 == 0 && a.ldc % 4 == 0, "N and ldc must be multiples of 4 (vector epilogue): N=%d ldc=%ld", a.N, a.ldc);
+  EEG_CHECK(!a.resid || a.ldr % 4 == 0, "ldr must be a multiple of 4");
+  EEG_CHECK(!a.rowvec || a.ld_rowvec % 4 == 0, "ld_rowvec must be a multiple of 4");
   if (a.splitk > 1) a.atomic_out = 1;
   ProfRec rec; bool prof = ctx->prof_on;
   if (prof) {

@@ -69,8 +69,8 @@ int op_conv_wgrad(eegldm_ctx* ctx, int dtype, const void* x, long ldx, const voi
   const int bn = Cin > 64 ? 128 : (Cin > 32 ? 64 : 32);
   const long tiles = (long)((Cout + 127) / 128) * ((Cin + bn - 1) / bn) * K;
   const int kstage = 2 * (dtype == EEGLDM_F32 ? 16 : 32);
-  long want = ((long)ctx->num_cu * 3 + tiles - 1) / tiles;
-  long maxs = ((long)a.K + 4 * kstage - 1) / (4 * kstage);     // at least 4 stages per split
+  long want = ((long)ctx->num_cu * 3 + tiles - 1) / tiles;     // fill the 3 resident blocks per CU
+  long maxs = ((long)a.K + 8 * kstage - 1) / (8 * kstage);     // at least 8 stages per split
   if (want > maxs) want = maxs;
   a.splitk = (int)(want < 1 ? 1 : want);
   return gemm_launch(ctx, a);
