@@ -24,6 +24,8 @@ extern "C" int eegldm_ctx_create(int device, void* stream, int own_stream, eegld
   else { c->stream = (hipStream_t)stream; c->owns_stream = false; }
   c->scratch_bytes = 8u << 20;
   HIP_TRY(hipMalloc(&c->scratch, c->scratch_bytes));
+  HIP_TRY(hipMalloc(&c->zero_page, 4096));
+  HIP_TRY(hipMemset(c->zero_page, 0, 4096));
   *out = c;
   return 0;
 }
@@ -31,6 +33,7 @@ extern "C" int eegldm_ctx_destroy(eegldm_ctx* c) {
   if (!c) return 0;
   hipSetDevice(c->device);
   if (c->scratch) hipFree(c->scratch);
+  if (c->zero_page) hipFree(c->zero_page);
   if (c->owns_stream) hipStreamDestroy(c->stream);
   delete c;
   return 0;

@@ -44,6 +44,7 @@ struct eegldm_ctx {
   void* scratch;
   size_t scratch_bytes;
   int num_cu;
+  void* zero_page = nullptr;   // 4 KiB of zeros: source of out-of-range LDS-DMA chunks
   // optional per-launch HIP-event profiling of the GEMM family (bench.py roofline leg)
   bool prof_on = false;
   std::vector<ProfRec> prof;
@@ -109,5 +110,6 @@ struct GemmArgs {
   const void* resid; long ldr;                            // residual add (dtype)
   int out_f32;           // C is float regardless of dtype
   int atomic_out;        // C += result via float atomics (requires out_f32)
+  const void* zero_page; // >= 16 zero bytes in device memory (set by gemm_launch)
 };
 int gemm_launch(eegldm_ctx* ctx, const GemmArgs& a);

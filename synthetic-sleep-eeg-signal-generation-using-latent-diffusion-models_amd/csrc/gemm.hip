@@ -27,12 +27,12 @@
 // CONSECUTIVE output channels of one row; the epilogue passes the tile through LDS once and
 // writes full 16-byte (fp32) / 8-byte (bf16) vectors -- whole 256-byte rows per 32 lanes --
 // with bias, timestep-embedding and residual adds done on those vectors.
+#include <stdlib.h>
+
 #include "common.h"
 
 namespace {
 
-constexpr int BM = 128;
-constexpr int NTHREADS = 256;
 
 template <typename T> struct Tr;
 template <> struct Tr<float> { static constexpr int KC = 16; static constexpr int EPC = 4; };
@@ -107,8 +107,11 @@ __device__ __forceinline__ int tr_store_off(int krow, int seg) {
   else return krow * TrPitch<bf16_t, BX>::v + tr_swz<BX>(krow, seg * 16);
 }
 
-template <typename T, int AMODE, int BMODE, int TAPS, int KSUB, int BN, int STRIDE>
+template <typename T, int AMODE, int BMODE, int TAPS, int KSUB, int BN, int STRIDE, int WMT>
 struct Cfg {
+  static constexpr int BM = 64 * WMT;                             // block rows: WMT waves along M, 2 along N
+  static constexpr int NW = 2 * WMT;                              // waves per block
+  static constexpr int NTHREADS = 64 * NW;
   static constexpr int KC = Tr<T>::KC;
   static constexpr int EPC = Tr<T>::EPC;
   static constexpr int KSTAGE = KSUB * KC;                       // K elements per stage
@@ -120,23 +123,33 @@ struct Cfg {
   static constexpr int A_BYTES = (AMODE == GA_TR) ? KSTAGE * PITCH_A_TR : A_ROWS_NT * PITCH_NT;
   static constexpr int B_TILE_BYTES = (BMODE == GB_TR) ? KSTAGE * PITCH_B_TR : BN * PITCH_NT;
   static constexpr int B_BYTES = TAPS * B_TILE_BYTES;
-  static constexpr int A_CHUNKS = (AMODE == GA_TR) ? KSTAGE * (BM / EPC) : A_ROWS_NT * SEGS;
-  static constexpr int B_CHUNKS = TAPS * ((BMODE == GB_TR) ? KSTAGE * (BN / EPC) : BN * SEGS);
-  static constexpr int CA = (A_CHUNKS + NTHREADS - 1) / NTHREADS;
-  static constexpr int CB = (B_CHUNKS + NTHREADS - 1) / NTHREADS;
+  // LDS-DMA staging: every tile is a linear run of 16-byte chunks; one wave-instruction fills 64 of them (1 KiB)
+  static constexpr int A_CHUNKS = A_BYTES / 16;
+  static constexpr int B_CHUNKS = B_BYTES / 16;
+  static constexpr int A_INSTR = (A_CHUNKS + 63) / 64;
+  static constexpr int B_INSTR = (B_CHUNKS + 63) / 64;
+  static constexpr int IA = (A_INSTR + NW - 1) / NW;              // DMA instructions per wave per stage (uniform over waves:
+  static constexpr int IB = (B_INSTR + NW - 1) / NW;              //  the tail instructions fill padding from the zero page)
+  static constexpr int A_ALLOC = IA * NW * 1024;
+  static constexpr int B_ALLOC = IB * NW * 1024;
+  static constexpr int STAGE_BYTES = A_ALLOC + B_ALLOC;
+  static constexpr int NSTG = (WMT == 4 && 3 * STAGE_BYTES <= 160 * 1024) ? 3 : 2;   // LDS ring depth (prefetch distance NSTG-1)
   static constexpr int FN = BN / 32;                              // 16-wide fragments per wave along N
   static constexpr int EPI_PITCH = BN * 4 + 16;                   // fp32 epilogue tile [32][BN]
-  static constexpr int EPI_BYTES = 32 * EPI_PITCH;
-  static constexpr int LDS_BYTES = (A_BYTES + B_BYTES) > EPI_BYTES ? (A_BYTES + B_BYTES) : EPI_BYTES;
+  static constexpr int EPI_ROWS = 16 * WMT;
+  static constexpr int EPI_BYTES = EPI_ROWS * EPI_PITCH;
+  static constexpr int LDS_BYTES = (NSTG * STAGE_BYTES) > EPI_BYTES ? (NSTG * STAGE_BYTES) : EPI_BYTES;
 };
 
-template <typename T, int AMODE, int BMODE, int TAPS, int KSUB, int BN, int STRIDE>
-__global__ __launch_bounds__(NTHREADS) void gemm_kernel(const GemmArgs p) {
-  using C = Cfg<T, AMODE, BMODE, TAPS, KSUB, BN, STRIDE>;
+typedef __attribute__((address_space(3))) void* lds_void_ptr;
+typedef const __attribute__((address_space(1))) void* glb_void_ptr;
+
+template <typename T, int AMODE, int BMODE, int TAPS, int KSUB, int BN, int STRIDE, int WMT>
+__global__ __launch_bounds__(128 * WMT) void gemm_kernel(const GemmArgs p) {
+  using C = Cfg<T, AMODE, BMODE, TAPS, KSUB, BN, STRIDE, WMT>;
   constexpr int FN = C::FN;
+  constexpr int BM = C::BM, NTHREADS = C::NTHREADS, NW = C::NW;
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  char* smA = smem;
-  char* smB = smem + C::A_BYTES;
 
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
@@ -163,102 +176,73 @@ __global__ __launch_bounds__(NTHREADS) void gemm_kernel(const GemmArgs p) {
   }
   const int nstages = (kend - kbeg + C::KSTAGE - 1) / C::KSTAGE;
 
-  uint4 ra[C::CA], rb[C::CB];
   const uint4 zero4 = make_uint4(0, 0, 0, 0);
+  const T* __restrict__ zeros = (const T*)p.zero_page;
 
-  // ---- staging: global -> registers ------------------------------------------------
-  auto load_stage = [&](int s) {
-    const int k0 = kbeg + s * C::KSTAGE;
-#pragma unroll
-    for (int i = 0; i < C::CA; i++) {
-      const int c = tid + i * NTHREADS;
-      uint4 v = zero4;
-      if (c < C::A_CHUNKS) {
-        if constexpr (AMODE == GA_PLAIN) {
-          const int row = c / C::SEGS, seg = c % C::SEGS;
-          const int m = m0 + row, k = k0 + seg * C::EPC;
-          if (m < p.M && k < kend) v = *(const uint4*)(Ag + (long)m * p.lda + k);
-        } else if constexpr (AMODE == GA_CONV) {
-          const int row = c / C::SEGS, seg = c % C::SEGS;
-          const long fr = (long)m0 * STRIDE - p.pad_l + row;   // flattened virtual input row
-          const int k = k0 + seg * C::EPC;
-          if (fr >= 0 && fr < (long)p.M * STRIDE && k < kend) {
-            if (p.ups == 1) {
-              v = *(const uint4*)(Ag + fr * p.lda + k);
-            } else {
-              const long b = fr / p.Lin; const int vv = (int)(fr - b * p.Lin);
-              if ((vv % p.ups) == 0 && (vv / p.ups) < p.Lsrc)
-                v = *(const uint4*)(Ag + (b * p.Lsrc + vv / p.ups) * p.lda + k);
-            }
-          }
-        } else {  // GA_TR: source [K][M], M contiguous
-          constexpr int RC = BM / C::EPC;
-          const int krow = c / RC, seg = c % RC;
-          const int k = k0 + krow, m = m0 + seg * C::EPC;
-          if (k < kend && m < p.M) v = *(const uint4*)(Ag + (long)k * p.lda + m);
-        }
-      }
-      ra[i] = v;
-    }
-#pragma unroll
-    for (int i = 0; i < C::CB; i++) {
-      const int c = tid + i * NTHREADS;
-      uint4 v = zero4;
-      if (c < C::B_CHUNKS) {
-        if constexpr (BMODE == GB_NT) {
-          const int tap = c / (BN * C::SEGS), r = c % (BN * C::SEGS);
-          const int n = n0 + r / C::SEGS, k = k0 + (r % C::SEGS) * C::EPC;
-          const int tw = p.tap_flip ? (TAPS - 1 - tap) : tap;
-          if (n < p.N && k < kend) v = *(const uint4*)(Bg + (long)tw * p.sBt + (long)n * p.ldb + k);
-        } else {  // GB_TR: source [K][N], N contiguous
-          constexpr int RC = BN / C::EPC;
-          const int tap = c / (C::KSTAGE * RC), r = c % (C::KSTAGE * RC);
-          const int krow = r / RC, seg = r % RC;
-          const int k = k0 + krow, n = n0 + seg * C::EPC;
-          const int tw = p.tap_flip ? (TAPS - 1 - tap) : tap;
-          if (k < kend && n < p.N) {
-            if (p.conv_map) {   // wgrad: K index = output row -> input row of tap tz
-              const int bs = k / p.Lout, lo = k - bs * p.Lout;
-              const int vv = lo * p.stride + tz - p.pad_l;
-              if (vv >= 0 && vv < p.Lin) v = *(const uint4*)(Bg + ((long)bs * p.Lin + vv) * p.ldb + n);
-            } else {
-              v = *(const uint4*)(Bg + (long)tw * p.sBt + (long)k * p.ldb + n);
-            }
-          }
-        }
-      }
-      rb[i] = v;
+  // ---- staging: global -> LDS by DMA (global_load_lds_dwordx4).  LDS chunk c of a tile receives the
+  // 16 source bytes its swizzled position stands for; out-of-range chunks read the zero page.
+  auto a_src = [&](int c, int k0) -> const T* {
+    if (c >= C::A_CHUNKS) return zeros;
+    if constexpr (AMODE == GA_PLAIN) {
+      const int row = c / C::SEGS, seg = nt_swz<KSUB>(row, c % C::SEGS);
+      const int m = m0 + row, k = k0 + seg * C::EPC;
+      return (m < p.M && k < kend) ? Ag + (long)m * p.lda + k : zeros;
+    } else if constexpr (AMODE == GA_CONV) {
+      const int row = c / C::SEGS, seg = nt_swz<KSUB>(row, c % C::SEGS);
+      const long fr = (long)m0 * STRIDE - p.pad_l + row;   // flattened virtual input row
+      const int k = k0 + seg * C::EPC;
+      if (fr < 0 || fr >= (long)p.M * STRIDE || k >= kend) return zeros;
+      if (p.ups == 1) return Ag + fr * p.lda + k;
+      const long b = fr / p.Lin; const int vv = (int)(fr - b * p.Lin);
+      return ((vv % p.ups) == 0 && (vv / p.ups) < p.Lsrc) ? Ag + (b * p.Lsrc + vv / p.ups) * p.lda + k : zeros;
+    } else {  // GA_TR: source [K][M], M contiguous
+      constexpr int RCP = C::PITCH_A_TR / 16;
+      const int krow = c / RCP, cs = c % RCP;
+      int seg;
+      if constexpr (sizeof(T) == 4) { if (cs >= BM / 4) return zeros; seg = cs; }
+      else seg = tr_swz<BM>(krow, cs * 16) >> 4;
+      const int k = k0 + krow, m = m0 + seg * C::EPC;
+      return (k < kend && m < p.M) ? Ag + (long)k * p.lda + m : zeros;
     }
   };
-  // ---- staging: registers -> LDS ---------------------------------------------------
-  auto store_stage = [&]() {
-#pragma unroll
-    for (int i = 0; i < C::CA; i++) {
-      const int c = tid + i * NTHREADS;
-      if (c < C::A_CHUNKS) {
-        if constexpr (AMODE == GA_TR) {
-          constexpr int RC = BM / C::EPC;
-          *(uint4*)(smA + tr_store_off<T, BM>(c / RC, c % RC)) = ra[i];
-        } else {
-          const int row = c / C::SEGS;
-          *(uint4*)(smA + row * C::PITCH_NT + nt_swz<KSUB>(row, c % C::SEGS) * 16) = ra[i];
-        }
+  auto b_src = [&](int c, int k0) -> const T* {
+    if (c >= C::B_CHUNKS) return zeros;
+    if constexpr (BMODE == GB_NT) {
+      const int tap = c / (BN * C::SEGS), r = c % (BN * C::SEGS);
+      const int row = r / C::SEGS, seg = nt_swz<KSUB>(row, r % C::SEGS);
+      const int n = n0 + row, k = k0 + seg * C::EPC;
+      const int tw = p.tap_flip ? (TAPS - 1 - tap) : tap;
+      return (n < p.N && k < kend) ? Bg + (long)tw * p.sBt + (long)n * p.ldb + k : zeros;
+    } else {  // GB_TR: source [K][N], N contiguous
+      constexpr int RCP = C::PITCH_B_TR / 16;
+      const int tap = c / (C::KSTAGE * RCP), r = c % (C::KSTAGE * RCP);
+      const int krow = r / RCP, cs = r % RCP;
+      int seg;
+      if constexpr (sizeof(T) == 4) { if (cs >= BN / 4) return zeros; seg = cs; }
+      else seg = tr_swz<BN>(krow, cs * 16) >> 4;
+      const int k = k0 + krow, n = n0 + seg * C::EPC;
+      if (k >= kend || n >= p.N) return zeros;
+      if (p.conv_map) {   // wgrad: K index = output row -> input row of tap tz
+        const int bs = k / p.Lout, lo = k - bs * p.Lout;
+        const int vv = lo * p.stride + tz - p.pad_l;
+        return (vv >= 0 && vv < p.Lin) ? Bg + ((long)bs * p.Lin + vv) * p.ldb + n : zeros;
       }
+      const int tw = p.tap_flip ? (TAPS - 1 - tap) : tap;
+      return Bg + (long)tw * p.sBt + (long)k * p.ldb + n;
+    }
+  };
+  auto issue_stage = [&](int s, int buf) {
+    const int k0 = kbeg + s * C::KSTAGE;
+    char* base = smem + buf * C::STAGE_BYTES;
+#pragma unroll
+    for (int i = 0; i < C::IA; i++) {
+      const int ins = wave + NW * i;
+      __builtin_amdgcn_global_load_lds((glb_void_ptr)a_src(ins * 64 + lane, k0), (lds_void_ptr)(base + ins * 1024), 16, 0, 0);
     }
 #pragma unroll
-    for (int i = 0; i < C::CB; i++) {
-      const int c = tid + i * NTHREADS;
-      if (c < C::B_CHUNKS) {
-        if constexpr (BMODE == GB_TR) {
-          constexpr int RC = BN / C::EPC;
-          const int tap = c / (C::KSTAGE * RC), r = c % (C::KSTAGE * RC);
-          *(uint4*)(smB + tap * C::B_TILE_BYTES + tr_store_off<T, BN>(r / RC, r % RC)) = rb[i];
-        } else {
-          const int tap = c / (BN * C::SEGS), r = c % (BN * C::SEGS);
-          const int row = r / C::SEGS;
-          *(uint4*)(smB + tap * C::B_TILE_BYTES + row * C::PITCH_NT + nt_swz<KSUB>(row, r % C::SEGS) * 16) = rb[i];
-        }
-      }
+    for (int i = 0; i < C::IB; i++) {
+      const int ins = wave + NW * i;
+      __builtin_amdgcn_global_load_lds((glb_void_ptr)b_src(ins * 64 + lane, k0), (lds_void_ptr)(base + C::A_ALLOC + ins * 1024), 16, 0, 0);
     }
   };
 
@@ -284,11 +268,25 @@ __global__ __launch_bounds__(NTHREADS) void gemm_kernel(const GemmArgs p) {
 #pragma unroll
     for (int j = 0; j < FN; j++) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  load_stage(0);
+  // ring of NSTG stage buffers, loads run NSTG-1 stages ahead; each wave issues exactly IA+IB DMA instructions per
+  // stage, so "stage s has landed" == at most (NSTG-2)*(IA+IB) of this wave's DMAs still outstanding.
+  constexpr int PER = C::IA + C::IB;
+  issue_stage(0, 0);
+  if constexpr (C::NSTG == 3) { if (nstages > 1) issue_stage(1, 1); }
   for (int s = 0; s < nstages; s++) {
-    store_stage();
-    __syncthreads();
-    if (s + 1 < nstages) load_stage(s + 1);
+    if constexpr (C::NSTG == 3) {
+      if (s + 1 < nstages) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PER) : "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      asm volatile("" ::: "memory");
+      if (s + 2 < nstages) issue_stage(s + 2, (s + 2) % 3);
+    } else {
+      // vmcnt(0) + barrier: stage s has landed in buffer s&1, and every wave is done reading buffer (s+1)&1
+      __syncthreads();
+      if (s + 1 < nstages) issue_stage(s + 1, (s + 1) & 1);
+    }
+    const char* smA = smem + (s % C::NSTG) * C::STAGE_BYTES;
+    const char* smB = smA + C::A_ALLOC;
 #pragma unroll
     for (int t = 0; t < TAPS; t++) {
 #pragma unroll
@@ -325,16 +323,16 @@ __global__ __launch_bounds__(NTHREADS) void gemm_kernel(const GemmArgs p) {
           }
       }
     }
-    __syncthreads();
   }
+  __syncthreads();   // all waves done with the staging buffers before the epilogue tile reuses them
 
   // ---- epilogue ---------------------------------------------------------------------
   // acc[i][j][r] = C[m = wm*64 + i*16 + lm][n = wn*(BN/2) + j*16 + q*4 + r] (operands were swapped).
-  // Four passes of 32 rows through an fp32 LDS tile, then 4-wide vector read-modify-store.
+  // Four passes of 16*WMT rows through an fp32 LDS tile, then 4-wide vector read-modify-store.
   char* Cb = (char*)p.C;
   const long cbase = (long)bz * p.sCb + (long)tz * p.sCt;
   constexpr int CH = BN / 4;                      // 4-element chunks per row
-  constexpr int NCH = 32 * CH;                    // chunks per pass
+  constexpr int NCH = C::EPI_ROWS * CH;           // chunks per pass
   if constexpr (AMODE == GA_TR) {
     if (p.atomic_out) {
       // split-K weight gradients: natural fragment layout (rows q*4+r, col lm), fp32 atomics straight from registers
@@ -369,7 +367,7 @@ __global__ __launch_bounds__(NTHREADS) void gemm_kernel(const GemmArgs p) {
     __syncthreads();
     if (p.atomic_out) {
       // split-K / accumulate: one float per lane so each wave-instruction hits 256 contiguous bytes
-      for (int c = tid; c < 32 * BN; c += NTHREADS) {
+      for (int c = tid; c < C::EPI_ROWS * BN; c += NTHREADS) {
         const int row = c / BN, col = c % BN;
         const int m = m0 + (row >> 4) * 64 + i * 16 + (row & 15), n = n0 + col;
         if (m < p.M && n < p.N) atomicAdd((float*)Cb + cbase + (long)m * p.ldc + n, *(const float*)(smem + row * C::EPI_PITCH + col * 4));
@@ -413,26 +411,32 @@ __global__ __launch_bounds__(NTHREADS) void gemm_kernel(const GemmArgs p) {
   }
 }
 
-template <typename T, int AMODE, int BMODE, int TAPS, int KSUB, int BN, int STRIDE>
+template <typename T, int AMODE, int BMODE, int TAPS, int KSUB, int BN, int STRIDE, int WMT>
 int launch_t(eegldm_ctx* ctx, const GemmArgs& a) {
-  using C = Cfg<T, AMODE, BMODE, TAPS, KSUB, BN, STRIDE>;
-  auto kern = gemm_kernel<T, AMODE, BMODE, TAPS, KSUB, BN, STRIDE>;
+  using C = Cfg<T, AMODE, BMODE, TAPS, KSUB, BN, STRIDE, WMT>;
+  auto kern = gemm_kernel<T, AMODE, BMODE, TAPS, KSUB, BN, STRIDE, WMT>;
   static bool attr_set = false;
+  static_assert(C::LDS_BYTES <= 160 * 1024, "tile does not fit the 160 KiB LDS");
   if (!attr_set && C::LDS_BYTES > 48 * 1024) {
     HIP_TRY(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES));
     attr_set = true;
   }
-  dim3 grid((a.N + BN - 1) / BN, (a.M + BM - 1) / BM, a.batch * a.ztaps * a.splitk);
-  hipLaunchKernelGGL(kern, grid, dim3(NTHREADS), C::LDS_BYTES, ctx->stream, a);
+  dim3 grid((a.N + BN - 1) / BN, (a.M + C::BM - 1) / C::BM, a.batch * a.ztaps * a.splitk);
+  hipLaunchKernelGGL(kern, grid, dim3(C::NTHREADS), C::LDS_BYTES, ctx->stream, a);
   LAUNCH_CHECK();
   return 0;
 }
 
+// tile selection.  The 256-row / 8-wave / 3-deep-ring variant (WMT = 4) is kept compiled but measured no faster
+// than 128-row blocks at 2 blocks per CU on the UNet's shapes (profiles/r01_gemm_tile_sweep.txt), so it is opt-in
+// (EEGLDM_GEMM_BIG_TILES=1) until the LDS-read / MFMA interleave is hand-scheduled.
 template <typename T, int AMODE, int BMODE, int TAPS, int KSUB, int STRIDE>
 int launch_bn(eegldm_ctx* ctx, const GemmArgs& a) {
-  if (a.N > 64) return launch_t<T, AMODE, BMODE, TAPS, KSUB, 128, STRIDE>(ctx, a);
-  if (a.N > 32) return launch_t<T, AMODE, BMODE, TAPS, KSUB, 64, STRIDE>(ctx, a);
-  return launch_t<T, AMODE, BMODE, TAPS, KSUB, 32, STRIDE>(ctx, a);
+  static const bool big_ok = getenv("EEGLDM_GEMM_BIG_TILES") != nullptr;
+  const bool big = big_ok && a.M >= 256 && !(AMODE == GA_CONV && STRIDE == 2);
+  if (a.N > 64) return big ? launch_t<T, AMODE, BMODE, TAPS, KSUB, 128, STRIDE, 4>(ctx, a) : launch_t<T, AMODE, BMODE, TAPS, KSUB, 128, STRIDE, 2>(ctx, a);
+  if (a.N > 32) return launch_t<T, AMODE, BMODE, TAPS, KSUB, 64, STRIDE, 2>(ctx, a);
+  return launch_t<T, AMODE, BMODE, TAPS, KSUB, 32, STRIDE, 2>(ctx, a);
 }
 
 template <typename T>
@@ -477,6 +481,7 @@ int gemm_launch(eegldm_ctx* ctx, const GemmArgs& a_in) {
   EEG_CHECK(!a.resid || a.ldr % 4 == 0, "ldr must be a multiple of 4");
   EEG_CHECK(!a.rowvec || a.ld_rowvec % 4 == 0, "ld_rowvec must be a multiple of 4");
   if (a.splitk > 1) a.atomic_out = 1;
+  a.zero_page = ctx->zero_page;
   ProfRec rec; bool prof = ctx->prof_on;
   if (prof) {
     rec.cls = a.amode == GA_CONV ? (a.bmode == GB_NT ? PROF_CONV_FWD : PROF_CONV_DGRAD)

@@ -67,9 +67,10 @@ int op_conv_wgrad(eegldm_ctx* ctx, int dtype, const void* x, long ldx, const voi
   a.conv_map = 1; a.Lout = Lout; a.Lin = Lin; a.stride = stride; a.pad_l = pad_l;
   a.out_f32 = 1; a.atomic_out = 1;
   const int bn = Cin > 64 ? 128 : (Cin > 32 ? 64 : 32);
-  const long tiles = (long)((Cout + 127) / 128) * ((Cin + bn - 1) / bn) * K;
+  const int bm = 128;
+  const long tiles = (long)((Cout + bm - 1) / bm) * ((Cin + bn - 1) / bn) * K;
   const int kstage = 2 * (dtype == EEGLDM_F32 ? 16 : 32);
-  long want = ((long)ctx->num_cu * 3 + tiles - 1) / tiles;     // fill the 3 resident blocks per CU
+  long want = ((long)ctx->num_cu * 2 + tiles - 1) / tiles;     // fill the 2 resident blocks per CU
   long maxs = ((long)a.K + 8 * kstage - 1) / (8 * kstage);     // at least 8 stages per split
   if (want > maxs) want = maxs;
   a.splitk = (int)(want < 1 ? 1 : want);
