@@ -71,6 +71,8 @@ int eegldm_timer_stop_ms(eegldm_ctx* ctx, float* ms_host);
  * eegldm_prof_enable(ctx, 1).  Host outputs. */
 int eegldm_prof_enable(eegldm_ctx* ctx, int on);
 int eegldm_prof_summary(eegldm_ctx* ctx, int kernel_class, double* flops_host, double* ms_host, int* launches_host);
+/* developer aid: CSV of every profiled launch (class,M,N,K,taps,splitk,ms,gflop) */
+int eegldm_prof_dump(eegldm_ctx* ctx, const char* path_host);
 
 /* ------------------------------------------------------------------ layout / packing */
 int eegldm_ncl_to_nlc(eegldm_ctx*, const float* src_ncl, void* dst_nlc, long ld_dst, int B, int C, int L, int dst_dtype);

@@ -40,6 +40,7 @@ SIGNATURES = {
     "eegldm_timer_stop_ms": [_vp, C.POINTER(_f)],
     "eegldm_prof_enable": [_vp, _i],
     "eegldm_prof_summary": [_vp, _i, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(_i)],
+    "eegldm_prof_dump": [_vp, C.c_char_p],
     "eegldm_ncl_to_nlc": [_vp, _vp, _vp, _l, _i, _i, _i, _i],
     "eegldm_nlc_to_ncl": [_vp, _vp, _l, _vp, _i, _i, _i, _i],
     "eegldm_pack_conv_weight": [_vp, _vp, _vp, _i, _i, _i],

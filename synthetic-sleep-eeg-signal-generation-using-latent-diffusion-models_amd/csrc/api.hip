@@ -78,3 +78,18 @@ extern "C" int eegldm_prof_summary(eegldm_ctx* c, int cls, double* flops, double
   *flops = f; *ms = t; *launches = n;
   return 0;
 }
+
+// developer aid: one CSV line per profiled launch (class,M,N,K,taps,splitk,ms,gflop)
+extern "C" int eegldm_prof_dump(eegldm_ctx* c, const char* path_host) {
+  EEG_CHECK(c && path_host, "null argument");
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  FILE* f = fopen(path_host, "w");
+  EEG_CHECK(f != nullptr, "cannot open %s", path_host);
+  fprintf(f, "class,M,N,K,taps,splitk,ms,gflop\n");
+  for (auto& r : c->prof) {
+    float e = 0; hipEventElapsedTime(&e, r.a, r.b);
+    fprintf(f, "%d,%d,%d,%d,%d,%d,%.5f,%.3f\n", r.cls, r.M, r.N, r.K, r.taps, r.splitk, e, r.flops / 1e9);
+  }
+  fclose(f);
+  return 0;
+}

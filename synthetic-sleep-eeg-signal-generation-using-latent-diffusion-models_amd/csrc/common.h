@@ -33,7 +33,7 @@ void eegldm_set_error(const std::string& msg);
 #define LAUNCH_CHECK() HIP_TRY(hipGetLastError())
 
 // ---------------------------------------------------------------- context
-struct ProfRec { int cls; double flops; hipEvent_t a, b; };
+struct ProfRec { int cls; double flops; hipEvent_t a, b; int M, N, K, taps, splitk; };
 enum { PROF_CONV_FWD = 0, PROF_CONV_DGRAD = 1, PROF_CONV_WGRAD = 2, PROF_GEMM_NT = 3, PROF_GEMM_NN = 4, PROF_GEMM_TN = 5, PROF_NCLASS = 6 };
 
 struct eegldm_ctx {

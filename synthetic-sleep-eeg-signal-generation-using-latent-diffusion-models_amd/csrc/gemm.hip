@@ -133,7 +133,13 @@ struct Cfg {
   static constexpr int A_ALLOC = IA * NW * 1024;
   static constexpr int B_ALLOC = IB * NW * 1024;
   static constexpr int STAGE_BYTES = A_ALLOC + B_ALLOC;
-  static constexpr int NSTG = (WMT == 4 && 3 * STAGE_BYTES <= 160 * 1024) ? 3 : 2;   // LDS ring depth (prefetch distance NSTG-1)
+  // Staging engine, chosen by measurement (profiles/r01_gemm_tile_sweep.txt): the 3-tap conv kernels are fastest with
+  // LDS-DMA into a double-buffered ring (one barrier per stage); the 1-tap kernels (1x1 / Linear / attention / wgrad)
+  // are fastest with register staging (global -> VGPR prefetch under the MFMA phase -> ds_write), single buffer.
+  static constexpr bool USE_DMA = (TAPS == 3);
+  static constexpr int NSTG = !USE_DMA ? 1 : ((WMT == 4 && 3 * STAGE_BYTES <= 160 * 1024) ? 3 : 2);   // LDS ring depth
+  static constexpr int CA = (A_CHUNKS + NTHREADS - 1) / NTHREADS;  // register-staged 16-byte chunks per thread
+  static constexpr int CB = (B_CHUNKS + NTHREADS - 1) / NTHREADS;
   static constexpr int FN = BN / 32;                              // 16-wide fragments per wave along N
   static constexpr int EPI_PITCH = BN * 4 + 16;                   // fp32 epilogue tile [32][BN]
   static constexpr int EPI_ROWS = 16 * WMT;
@@ -181,57 +187,72 @@ __global__ __launch_bounds__(128 * WMT) void gemm_kernel(const GemmArgs p) {
 
   // ---- staging: global -> LDS by DMA (global_load_lds_dwordx4).  LDS chunk c of a tile receives the
   // 16 source bytes its swizzled position stands for; out-of-range chunks read the zero page.
-  auto a_src = [&](int c, int k0) -> const T* {
-    if (c >= C::A_CHUNKS) return zeros;
+  // (branch-free on purpose: a per-chunk branch makes hipcc wait for each register-staged load separately)
+  auto a_dec = [&](int c, int k0, long& off) __attribute__((always_inline)) -> bool {
+    bool ok = c < C::A_CHUNKS;
+    off = 0;
     if constexpr (AMODE == GA_PLAIN) {
       const int row = c / C::SEGS, seg = nt_swz<KSUB>(row, c % C::SEGS);
       const int m = m0 + row, k = k0 + seg * C::EPC;
-      return (m < p.M && k < kend) ? Ag + (long)m * p.lda + k : zeros;
+      ok = ok && m < p.M && k < kend;
+      off = (long)m * p.lda + k;
     } else if constexpr (AMODE == GA_CONV) {
       const int row = c / C::SEGS, seg = nt_swz<KSUB>(row, c % C::SEGS);
-      const long fr = (long)m0 * STRIDE - p.pad_l + row;   // flattened virtual input row
+      long fr = (long)m0 * STRIDE - p.pad_l + row;   // flattened virtual input row
       const int k = k0 + seg * C::EPC;
-      if (fr < 0 || fr >= (long)p.M * STRIDE || k >= kend) return zeros;
-      if (p.ups == 1) return Ag + fr * p.lda + k;
-      const long b = fr / p.Lin; const int vv = (int)(fr - b * p.Lin);
-      return ((vv % p.ups) == 0 && (vv / p.ups) < p.Lsrc) ? Ag + (b * p.Lsrc + vv / p.ups) * p.lda + k : zeros;
+      ok = ok && fr >= 0 && fr < (long)p.M * STRIDE && k < kend;
+      if (p.ups != 1) {                                // wave-uniform
+        const long b = fr / p.Lin; const int vv = (int)(fr - b * p.Lin);
+        ok = ok && (vv % p.ups) == 0 && (vv / p.ups) < p.Lsrc;
+        fr = b * p.Lsrc + vv / p.ups;
+      }
+      off = fr * p.lda + k;
     } else {  // GA_TR: source [K][M], M contiguous
       constexpr int RCP = C::PITCH_A_TR / 16;
       const int krow = c / RCP, cs = c % RCP;
-      int seg;
-      if constexpr (sizeof(T) == 4) { if (cs >= BM / 4) return zeros; seg = cs; }
+      int seg = cs;
+      if constexpr (sizeof(T) == 4) ok = ok && cs < BM / 4;
       else seg = tr_swz<BM>(krow, cs * 16) >> 4;
       const int k = k0 + krow, m = m0 + seg * C::EPC;
-      return (k < kend && m < p.M) ? Ag + (long)k * p.lda + m : zeros;
+      ok = ok && k < kend && m < p.M;
+      off = (long)k * p.lda + m;
     }
+    return ok;
   };
-  auto b_src = [&](int c, int k0) -> const T* {
-    if (c >= C::B_CHUNKS) return zeros;
+  auto b_dec = [&](int c, int k0, long& off) __attribute__((always_inline)) -> bool {
+    bool ok = c < C::B_CHUNKS;
+    off = 0;
     if constexpr (BMODE == GB_NT) {
       const int tap = c / (BN * C::SEGS), r = c % (BN * C::SEGS);
       const int row = r / C::SEGS, seg = nt_swz<KSUB>(row, r % C::SEGS);
       const int n = n0 + row, k = k0 + seg * C::EPC;
       const int tw = p.tap_flip ? (TAPS - 1 - tap) : tap;
-      return (n < p.N && k < kend) ? Bg + (long)tw * p.sBt + (long)n * p.ldb + k : zeros;
+      ok = ok && n < p.N && k < kend;
+      off = (long)tw * p.sBt + (long)n * p.ldb + k;
     } else {  // GB_TR: source [K][N], N contiguous
       constexpr int RCP = C::PITCH_B_TR / 16;
       const int tap = c / (C::KSTAGE * RCP), r = c % (C::KSTAGE * RCP);
       const int krow = r / RCP, cs = r % RCP;
-      int seg;
-      if constexpr (sizeof(T) == 4) { if (cs >= BN / 4) return zeros; seg = cs; }
+      int seg = cs;
+      if constexpr (sizeof(T) == 4) ok = ok && cs < BN / 4;
       else seg = tr_swz<BN>(krow, cs * 16) >> 4;
       const int k = k0 + krow, n = n0 + seg * C::EPC;
-      if (k >= kend || n >= p.N) return zeros;
-      if (p.conv_map) {   // wgrad: K index = output row -> input row of tap tz
+      ok = ok && k < kend && n < p.N;
+      if (p.conv_map) {   // wgrad (wave-uniform): K index = output row -> input row of tap tz
         const int bs = k / p.Lout, lo = k - bs * p.Lout;
         const int vv = lo * p.stride + tz - p.pad_l;
-        return (vv >= 0 && vv < p.Lin) ? Bg + ((long)bs * p.Lin + vv) * p.ldb + n : zeros;
+        ok = ok && vv >= 0 && vv < p.Lin;
+        off = ((long)bs * p.Lin + vv) * p.ldb + n;
+      } else {
+        const int tw = p.tap_flip ? (TAPS - 1 - tap) : tap;
+        off = (long)tw * p.sBt + (long)k * p.ldb + n;
       }
-      const int tw = p.tap_flip ? (TAPS - 1 - tap) : tap;
-      return Bg + (long)tw * p.sBt + (long)k * p.ldb + n;
     }
+    return ok;
   };
-  auto issue_stage = [&](int s, int buf) {
+  auto a_src = [&](int c, int k0) __attribute__((always_inline)) -> const T* { long off; const bool ok = a_dec(c, k0, off); return ok ? Ag + off : zeros; };
+  auto b_src = [&](int c, int k0) __attribute__((always_inline)) -> const T* { long off; const bool ok = b_dec(c, k0, off); return ok ? Bg + off : zeros; };
+  auto issue_stage = [&](int s, int buf) __attribute__((always_inline)) {
     const int k0 = kbeg + s * C::KSTAGE;
     char* base = smem + buf * C::STAGE_BYTES;
 #pragma unroll
@@ -244,6 +265,30 @@ __global__ __launch_bounds__(128 * WMT) void gemm_kernel(const GemmArgs p) {
       const int ins = wave + NW * i;
       __builtin_amdgcn_global_load_lds((glb_void_ptr)b_src(ins * 64 + lane, k0), (lds_void_ptr)(base + C::A_ALLOC + ins * 1024), 16, 0, 0);
     }
+  };
+
+  // ---- register staging (1-tap kernels): chunk c of the linear LDS image <- 16 bytes (predicated load, zeros otherwise)
+  uint4 ra[C::USE_DMA ? 1 : C::CA], rb[C::USE_DMA ? 1 : C::CB];
+  auto load_stage = [&](int s) __attribute__((always_inline)) {
+    const int k0 = kbeg + s * C::KSTAGE;
+#pragma unroll
+    for (int i = 0; i < C::CA; i++) {
+      long off; uint4 v = zero4;
+      if (a_dec(tid + i * NTHREADS, k0, off)) v = *(const uint4*)(Ag + off);
+      ra[i] = v;
+    }
+#pragma unroll
+    for (int i = 0; i < C::CB; i++) {
+      long off; uint4 v = zero4;
+      if (b_dec(tid + i * NTHREADS, k0, off)) v = *(const uint4*)(Bg + off);
+      rb[i] = v;
+    }
+  };
+  auto store_stage = [&]() __attribute__((always_inline)) {
+#pragma unroll
+    for (int i = 0; i < C::CA; i++) { const int c = tid + i * NTHREADS; if (c < C::A_CHUNKS) *(uint4*)(smem + c * 16) = ra[i]; }
+#pragma unroll
+    for (int i = 0; i < C::CB; i++) { const int c = tid + i * NTHREADS; if (c < C::B_CHUNKS) *(uint4*)(smem + C::A_ALLOC + c * 16) = rb[i]; }
   };
 
   // ---- per-lane conv validity masks -------------------------------------------------
@@ -271,10 +316,18 @@ __global__ __launch_bounds__(128 * WMT) void gemm_kernel(const GemmArgs p) {
   // ring of NSTG stage buffers, loads run NSTG-1 stages ahead; each wave issues exactly IA+IB DMA instructions per
   // stage, so "stage s has landed" == at most (NSTG-2)*(IA+IB) of this wave's DMAs still outstanding.
   constexpr int PER = C::IA + C::IB;
-  issue_stage(0, 0);
-  if constexpr (C::NSTG == 3) { if (nstages > 1) issue_stage(1, 1); }
+  if constexpr (C::USE_DMA) {
+    issue_stage(0, 0);
+    if constexpr (C::NSTG == 3) { if (nstages > 1) issue_stage(1, 1); }
+  } else {
+    load_stage(0);
+  }
   for (int s = 0; s < nstages; s++) {
-    if constexpr (C::NSTG == 3) {
+    if constexpr (!C::USE_DMA) {
+      store_stage();
+      __syncthreads();
+      if (s + 1 < nstages) load_stage(s + 1);
+    } else if constexpr (C::NSTG == 3) {
       if (s + 1 < nstages) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PER) : "memory");
       else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __builtin_amdgcn_s_barrier();
@@ -323,8 +376,9 @@ __global__ __launch_bounds__(128 * WMT) void gemm_kernel(const GemmArgs p) {
           }
       }
     }
+    if constexpr (!C::USE_DMA) __syncthreads();   // single buffer: reads of stage s done before stage s+1 is written
   }
-  __syncthreads();   // all waves done with the staging buffers before the epilogue tile reuses them
+  if constexpr (C::USE_DMA) __syncthreads();       // all waves done with the staging buffers before the epilogue tile reuses them
 
   // ---- epilogue ---------------------------------------------------------------------
   // acc[i][j][r] = C[m = wm*64 + i*16 + lm][n = wn*(BN/2) + j*16 + q*4 + r] (operands were swapped).
@@ -488,6 +542,7 @@ int gemm_launch(eegldm_ctx* ctx, const GemmArgs& a_in) {
               : (a.amode == GA_TR ? (a.conv_map ? PROF_CONV_WGRAD : PROF_GEMM_TN) : (a.bmode == GB_NT ? PROF_GEMM_NT : PROF_GEMM_NN));
     // algorithmic work: the transposed (strided) dgrad multiplies a half-zero virtual signal; only the real taps count
     rec.flops = 2.0 * a.M * a.N * (double)a.K * a.taps * a.ztaps * a.batch / (a.ups > 1 ? a.ups : 1);
+    rec.M = a.M; rec.N = a.N; rec.K = a.K; rec.taps = a.taps * a.ztaps; rec.splitk = a.splitk;
     HIP_TRY(hipEventCreate(&rec.a)); HIP_TRY(hipEventCreate(&rec.b));
     HIP_TRY(hipEventRecord(rec.a, ctx->stream));
   }

@@ -69,6 +69,7 @@ __global__ __launch_bounds__(NT) void gn_stats_kernel(const T* __restrict__ x, l
     for (int col = tx; col < cm.ncols; col += cm.TX) {
       const int c = col * V;
       float s1 = 0.f, s2 = 0.f;
+#pragma unroll 4
       for (int l = l0 + ty; l < l1; l += cm.TY) {
         float v[V];
         loadv<T, V>(x + ((long)b * L + l) * ldx + c, v);
@@ -95,48 +96,62 @@ __global__ void gn_finalize_kernel(const double* __restrict__ sums, float* __res
 }
 
 // ------------------------------------------------------------------ forward apply
-// iterates over INPUT rows; resample: 0 none, 1 avgpool2 (pairs of input rows -> one
-// output row), 2 nearest x2 (one input row -> two output rows)
+// grid (row chunks, B): block = one sample, a run of WORK rows (work row = output row for avgpool, input row
+// otherwise).  Threads tile (column vector, row lane) like the statistics kernel, so the element loop has no
+// integer division; per-thread scale/shift are hoisted out of the row loop.
+// resample: 0 none, 1 avgpool2 (pairs of input rows -> one output row), 2 nearest x2 (one input row -> two output rows)
 template <typename T, int V>
 __global__ __launch_bounds__(NT) void gn_apply_kernel(const T* __restrict__ x, long ldx, const float* __restrict__ gamma,
                                                       const float* __restrict__ beta, const float* __restrict__ stats,
                                                       T* __restrict__ y, long ldy, T* __restrict__ xr, long ldxr,
-                                                      int B, int L, int C, int G, int silu, int resample) {
-  const int ncols = C / V, cpg = C / G;
-  const long rows = (resample == 1) ? (long)B * (L / 2) : (long)B * L;   // work rows
-  const long total = rows * ncols;
-  for (long idx = (long)blockIdx.x * NT + threadIdx.x; idx < total; idx += (long)gridDim.x * NT) {
-    const long wr = idx / ncols; const int c = (int)(idx - wr * ncols) * V;
-    const int Lw = (resample == 1) ? L / 2 : L;
-    const int b = (int)(wr / Lw), lw = (int)(wr - (long)b * Lw);
-    const int g = c / cpg;
+                                                      int L, int C, int G, int silu, int resample, int rows_per_block) {
+  const int b = blockIdx.y, tid = threadIdx.x, cpg = C / G;
+  const ColMap cm = colmap(C, V);
+  if (tid >= cm.TX * cm.TY) return;
+  const int tx = tid % cm.TX, ty = tid / cm.TX;
+  const int Lw = (resample == 1) ? L / 2 : L;
+  const int l0 = blockIdx.x * rows_per_block, l1 = min(Lw, l0 + rows_per_block);
+  const T* xb = x + (long)b * L * ldx;
+  for (int col = tx; col < cm.ncols; col += cm.TX) {
+    const int c = col * V, g = c / cpg;
     const float mean = stats[((long)b * G + g) * 2], rstd = stats[((long)b * G + g) * 2 + 1];
     float ga[V], be[V];
 #pragma unroll
     for (int k = 0; k < V; k++) { ga[k] = gamma[c + k] * rstd; be[k] = beta[c + k] - mean * ga[k]; }
     if (resample == 1) {
-      float v0[V], v1[V], o[V], r[V];
-      loadv<T, V>(x + ((long)b * L + 2 * lw) * ldx + c, v0);
-      loadv<T, V>(x + ((long)b * L + 2 * lw + 1) * ldx + c, v1);
+      T* yb = y + (long)b * Lw * ldy; T* xrb = xr ? xr + (long)b * Lw * ldxr : nullptr;
+      for (int lw = l0 + ty; lw < l1; lw += cm.TY) {
+        float v0[V], v1[V], o[V], r[V];
+        loadv<T, V>(xb + (long)(2 * lw) * ldx + c, v0);
+        loadv<T, V>(xb + (long)(2 * lw + 1) * ldx + c, v1);
 #pragma unroll
-      for (int k = 0; k < V; k++) {
-        float z0 = v0[k] * ga[k] + be[k], z1 = v1[k] * ga[k] + be[k];
-        if (silu) { z0 = silu_f(z0); z1 = silu_f(z1); }
-        o[k] = 0.5f * (z0 + z1); r[k] = 0.5f * (v0[k] + v1[k]);
+        for (int k = 0; k < V; k++) {
+          float z0 = v0[k] * ga[k] + be[k], z1 = v1[k] * ga[k] + be[k];
+          if (silu) { z0 = silu_f(z0); z1 = silu_f(z1); }
+          o[k] = 0.5f * (z0 + z1); r[k] = 0.5f * (v0[k] + v1[k]);
+        }
+        storev<T, V>(yb + (long)lw * ldy + c, o);
+        if (xrb) storev<T, V>(xrb + (long)lw * ldxr + c, r);
       }
-      storev<T, V>(y + wr * ldy + c, o);
-      if (xr) storev<T, V>(xr + wr * ldxr + c, r);
-    } else {
-      float v[V], o[V];
-      loadv<T, V>(x + wr * ldx + c, v);
+    } else if (resample == 0) {
+      T* yb = y + (long)b * L * ldy;
+#pragma unroll 4
+      for (int lw = l0 + ty; lw < l1; lw += cm.TY) {
+        float v[V], o[V];
+        loadv<T, V>(xb + (long)lw * ldx + c, v);
 #pragma unroll
-      for (int k = 0; k < V; k++) { float z = v[k] * ga[k] + be[k]; o[k] = silu ? silu_f(z) : z; }
-      if (resample == 0) {
-        storev<T, V>(y + wr * ldy + c, o);
-      } else {
-        const long orow = ((long)b * 2 * L + 2 * lw);
-        storev<T, V>(y + orow * ldy + c, o); storev<T, V>(y + (orow + 1) * ldy + c, o);
-        if (xr) { storev<T, V>(xr + orow * ldxr + c, v); storev<T, V>(xr + (orow + 1) * ldxr + c, v); }
+        for (int k = 0; k < V; k++) { float z = v[k] * ga[k] + be[k]; o[k] = silu ? silu_f(z) : z; }
+        storev<T, V>(yb + (long)lw * ldy + c, o);
+      }
+    } else {
+      T* yb = y + (long)b * 2 * L * ldy; T* xrb = xr ? xr + (long)b * 2 * L * ldxr : nullptr;
+      for (int lw = l0 + ty; lw < l1; lw += cm.TY) {
+        float v[V], o[V];
+        loadv<T, V>(xb + (long)lw * ldx + c, v);
+#pragma unroll
+        for (int k = 0; k < V; k++) { float z = v[k] * ga[k] + be[k]; o[k] = silu ? silu_f(z) : z; }
+        storev<T, V>(yb + (long)(2 * lw) * ldy + c, o); storev<T, V>(yb + (long)(2 * lw + 1) * ldy + c, o);
+        if (xrb) { storev<T, V>(xrb + (long)(2 * lw) * ldxr + c, v); storev<T, V>(xrb + (long)(2 * lw + 1) * ldxr + c, v); }
       }
     }
   }
@@ -187,6 +202,7 @@ __global__ __launch_bounds__(NT) void gn_bwd_reduce_kernel(const T* __restrict__
 #pragma unroll
       for (int k = 0; k < V; k++) { ga[k] = gamma[c + k]; be[k] = beta[c + k]; dg[k] = 0.f; db[k] = 0.f; }
       float s1 = 0.f, s2 = 0.f;
+#pragma unroll 4
       for (int l = l0 + ty; l < l1; l += cm.TY) {
         float v[V], d[V];
         loadv<T, V>(x + ((long)b * L + l) * ldx + c, v);
@@ -210,39 +226,47 @@ __global__ __launch_bounds__(NT) void gn_bwd_reduce_kernel(const T* __restrict__
   if (dgamma) for (int i = tid; i < C; i += NT) { atomicAdd(&dgamma[i], accc[i]); atomicAdd(&dbeta[i], accc[C + i]); }
 }
 
-// dx = rstd * (dz*gamma - S1/n - xhat*S2/n) [+ resample^T(dxr)]
+// dx = rstd * (dz*gamma - S1/n - xhat*S2/n) [+ resample^T(dxr)];  grid (row chunks, B), same tiling as the forward
 template <typename T, int V>
 __global__ __launch_bounds__(NT) void gn_bwd_apply_kernel(const T* __restrict__ x, long ldx, const float* __restrict__ gamma,
                                                           const float* __restrict__ beta, const float* __restrict__ stats,
                                                           const T* __restrict__ dy, long lddy, const double* __restrict__ gsums,
                                                           T* __restrict__ dx, long lddx, const T* __restrict__ dxr, long lddxr,
-                                                          int B, int L, int C, int G, int silu, int resample) {
-  const int ncols = C / V, cpg = C / G;
+                                                          int L, int C, int G, int silu, int resample, int rows_per_block) {
+  const int b = blockIdx.y, tid = threadIdx.x, cpg = C / G;
+  const ColMap cm = colmap(C, V);
+  if (tid >= cm.TX * cm.TY) return;
+  const int tx = tid % cm.TX, ty = tid / cm.TX;
   const float inv_n = 1.0f / ((float)cpg * (float)L);
-  const long total = (long)B * L * ncols;
-  for (long idx = (long)blockIdx.x * NT + threadIdx.x; idx < total; idx += (long)gridDim.x * NT) {
-    const long row = idx / ncols; const int c = (int)(idx - row * ncols) * V;
-    const int b = (int)(row / L), l = (int)(row - (long)b * L);
-    const int g = c / cpg;
+  const int l0 = blockIdx.x * rows_per_block, l1 = min(L, l0 + rows_per_block);
+  for (int col = tx; col < cm.ncols; col += cm.TX) {
+    const int c = col * V, g = c / cpg;
     const float mean = stats[((long)b * G + g) * 2], rstd = stats[((long)b * G + g) * 2 + 1];
     const float m1 = (float)gsums[((long)b * G + g) * 2] * inv_n, m2 = (float)gsums[((long)b * G + g) * 2 + 1] * inv_n;
-    float v[V], d[V], o[V];
-    loadv<T, V>(x + row * ldx + c, v);
-    load_dy_eff<T, V>(dy, lddy, b, l, L, c, resample, d);
+    float ga[V], be[V];
 #pragma unroll
-    for (int k = 0; k < V; k++) {
-      const float ga = gamma[c + k], xh = (v[k] - mean) * rstd;
-      float dz = d[k];
-      if (silu) dz *= silu_grad_f(ga * xh + beta[c + k]);
-      o[k] = rstd * (dz * ga - m1 - xh * m2);
-    }
-    if (dxr) {
-      float e[V];
-      load_dy_eff<T, V>(dxr, lddxr, b, l, L, c, resample, e);
+    for (int k = 0; k < V; k++) { ga[k] = gamma[c + k]; be[k] = beta[c + k]; }
+#pragma unroll 2
+    for (int l = l0 + ty; l < l1; l += cm.TY) {
+      const long row = (long)b * L + l;
+      float v[V], d[V], o[V];
+      loadv<T, V>(x + row * ldx + c, v);
+      load_dy_eff<T, V>(dy, lddy, b, l, L, c, resample, d);
 #pragma unroll
-      for (int k = 0; k < V; k++) o[k] += e[k];
+      for (int k = 0; k < V; k++) {
+        const float xh = (v[k] - mean) * rstd;
+        float dz = d[k];
+        if (silu) dz *= silu_grad_f(ga[k] * xh + be[k]);
+        o[k] = rstd * (dz * ga[k] - m1 - xh * m2);
+      }
+      if (dxr) {
+        float e[V];
+        load_dy_eff<T, V>(dxr, lddxr, b, l, L, c, resample, e);
+#pragma unroll
+        for (int k = 0; k < V; k++) o[k] += e[k];
+      }
+      storev<T, V>(dx + row * lddx + c, o);
     }
-    storev<T, V>(dx + row * lddx + c, o);
   }
 }
 
@@ -252,10 +276,11 @@ int grid_for(long total_threads, eegldm_ctx* ctx) {
   return (int)(blocks < cap ? (blocks < 1 ? 1 : blocks) : cap);
 }
 
-int pick_lsplit(int B, int L, int C, eegldm_ctx* ctx, int* rows_per_block) {
-  // enough blocks to fill the chip, at least 16 rows per block
-  int want = (ctx->num_cu * 8 + B - 1) / B;
-  int maxsplit = (L + 15) / 16;
+// row-chunk split of one sample: `per_cu` blocks per CU in total, at least `min_rows` rows per block.
+// Reductions want few long chunks (fewer atomics), streaming apply kernels want many short ones.
+int pick_lsplit(int B, int L, int C, eegldm_ctx* ctx, int* rows_per_block, int per_cu = 8, int min_rows = 16) {
+  int want = (ctx->num_cu * per_cu + B - 1) / B;
+  int maxsplit = (L + min_rows - 1) / min_rows;
   int ls = want < 1 ? 1 : (want > maxsplit ? maxsplit : want);
   int rpb = (L + ls - 1) / ls;
   *rows_per_block = rpb;
@@ -273,9 +298,9 @@ int gn_fwd_t(eegldm_ctx* ctx, const void* x, long ldx, const float* gamma, const
   hipLaunchKernelGGL(gn_finalize_kernel, dim3((B * G + 255) / 256), dim3(256), 0, ctx->stream, sums, stats, B * G,
                      (double)(C / G) * (double)L, eps);
   LAUNCH_CHECK();
-  long total = (long)B * (resample == 1 ? L / 2 : L) * (C / V);
-  hipLaunchKernelGGL((gn_apply_kernel<T, V>), dim3(grid_for(total, ctx)), dim3(NT), 0, ctx->stream, (const T*)x, ldx, gamma,
-                     beta, stats, (T*)y, ldy, (T*)xr, ldxr, B, L, C, G, silu, resample);
+  int rpb2; int ls2 = pick_lsplit(B, resample == 1 ? L / 2 : L, C, ctx, &rpb2, 16, 8);
+  hipLaunchKernelGGL((gn_apply_kernel<T, V>), dim3(ls2, B), dim3(NT), 0, ctx->stream, (const T*)x, ldx, gamma,
+                     beta, stats, (T*)y, ldy, (T*)xr, ldxr, L, C, G, silu, resample, rpb2);
   LAUNCH_CHECK();
   return 0;
 }
@@ -290,9 +315,9 @@ int gn_bwd_t(eegldm_ctx* ctx, const void* x, long ldx, const float* gamma, const
   hipLaunchKernelGGL((gn_bwd_reduce_kernel<T, V>), dim3(ls, B), dim3(NT), 0, ctx->stream, (const T*)x, ldx, gamma, beta, stats,
                      (const T*)dy, lddy, gsums, dgamma, dbeta, L, C, G, silu, resample, rpb);
   LAUNCH_CHECK();
-  long total = (long)B * L * (C / V);
-  hipLaunchKernelGGL((gn_bwd_apply_kernel<T, V>), dim3(grid_for(total, ctx)), dim3(NT), 0, ctx->stream, (const T*)x, ldx, gamma,
-                     beta, stats, (const T*)dy, lddy, gsums, (T*)dx, lddx, (const T*)dxr, lddxr, B, L, C, G, silu, resample);
+  int rpb2; int ls2 = pick_lsplit(B, L, C, ctx, &rpb2, 16, 8);
+  hipLaunchKernelGGL((gn_bwd_apply_kernel<T, V>), dim3(ls2, B), dim3(NT), 0, ctx->stream, (const T*)x, ldx, gamma,
+                     beta, stats, (const T*)dy, lddy, gsums, (T*)dx, lddx, (const T*)dxr, lddxr, L, C, G, silu, resample, rpb2);
   LAUNCH_CHECK();
   return 0;
 }

@@ -90,6 +90,15 @@ int op_linear_dgrad(eegldm_ctx* ctx, int dtype, const void* dy, long lddy, const
   GemmArgs a = {};
   a.dtype = dtype; a.amode = GA_PLAIN; a.bmode = GB_TR; a.A = dy; a.lda = lddy; a.B = w; a.ldb = ldw; a.C = dx; a.ldc = lddx;
   a.M = M; a.N = K; a.K = N; a.batch = 1; a.taps = 1; a.alpha = 1.0f; a.out_f32 = out_f32;
+  // few output tiles but a long reduction (the batched embedding projection, K = 6656): split K over the chip
+  const long tiles = (long)((M + 127) / 128) * ((K + 127) / 128);
+  if (out_f32 && tiles * 8 < ctx->num_cu && N >= 1024) {
+    long sk = ctx->num_cu / tiles; const long maxs = N / 256; if (sk > maxs) sk = maxs;
+    if (sk > 1) {
+      HIP_TRY(hipMemset2DAsync(dx, (size_t)lddx * 4, 0, (size_t)K * 4, M, ctx->stream));
+      a.splitk = (int)sk;
+    }
+  }
   return gemm_launch(ctx, a);
 }
 // dw[N][K] += dy[M][N]^T x[M][K]

@@ -191,14 +191,19 @@ def test_fused_aekl_gan_train_step_matches_oracle(use_spectral):
             assert abs(float(o[i]) - float(w)) < 2e-4 * abs(float(w)) + 1e-6, (step, i, float(o[i]), float(w))
         assert abs(0.5 * float(o[4] + o[5]) - float(losses["disc"])) < 2e-4 * float(losses["disc"]) + 1e-6
         assert rel_l2(rec_d, recon) < 2e-5
-    # Adam moves every weight by ~lr per step, so updated parameters are compared in absolute units of lr
+    # Adam normalises every gradient to ~+-lr, so an element whose true gradient is at rounding-noise level can move by
+    # up to 2*lr in either direction; parameters are therefore compared in units of lr: every element within two Adam
+    # steps' worth, and the mean deviation a small fraction of one step.
     got = ae.state_dict()
     for k, v in ae_sd.items():
-        assert float((got[k].cpu() - v).abs().max()) < 0.15 * 5e-3, f"ae {k}: {float((got[k].cpu() - v).abs().max()):.3e}"
+        d = (got[k].cpu() - v).abs()
+        assert float(d.max()) < 2.5 * 5e-3 and float(d.mean()) < 0.05 * 5e-3, f"ae {k}: max {float(d.max()):.3e} mean {float(d.mean()):.3e}"
     gotd = disc.state_dict()
     for k, v in d_sd.items():
         if "num_batches" in k:
             assert int(gotd[k]) == 6
+        elif "running" in k:
+            assert float((gotd[k].cpu().float() - v.float()).abs().max()) < 1e-4 + 1e-5 * float(v.abs().max()), f"disc {k}"
         else:
-            lim = 0.15 * 5e-4 if "running" not in k else 1e-4
-            assert float((gotd[k].cpu().float() - v.float()).abs().max()) < lim + 1e-5 * float(v.abs().max()), f"disc {k}"
+            d = (gotd[k].cpu().float() - v.float()).abs()
+            assert float(d.max()) < 2.5 * 5e-4 and float(d.mean()) < 0.05 * 5e-4, f"disc {k}: max {float(d.max()):.3e} mean {float(d.mean()):.3e}"
