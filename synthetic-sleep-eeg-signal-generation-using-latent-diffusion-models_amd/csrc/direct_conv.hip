@@ -89,29 +89,79 @@ __global__ __launch_bounds__(NT) void dconv_rowdot_kernel(const DArgs a) {
   }
 }
 
-// dW[t][co][ci] += sum_r dy[r][co] * x[in_row(r,t)][ci]; thread per weight element, block per row chunk
+// dW[t][co][ci] += sum_r dy[r][co] * x[in_row(r,t)][ci].
+// "wide" variant (one side up to 512 channels): thread per weight element, each block grid-strides over row chunks
+// and issues ONE atomic per element at the end (atomics = blocks x E, not threads x chunks).
 template <typename T>
 __global__ __launch_bounds__(NT) void dconv_wgrad_kernel(const T* __restrict__ x, long ldx, const T* __restrict__ dy, long lddy,
                                                          float* __restrict__ dw, int B, int Lo, int Li, int Cout, int Cin, int K,
-                                                         int stride, int pad_l, int rows_per_block) {
+                                                         int stride, int pad_l, int rows_per_chunk) {
   const int E = K * Cout * Cin;
   const long rows = (long)B * Lo;
-  const long r0 = (long)blockIdx.x * rows_per_block, r1 = min(rows, r0 + rows_per_block);
-  // when E is small, several row-lanes share one element
-  int RS = 1; if (E < NT) RS = NT / E;
-  const int e0 = threadIdx.x % (E < NT ? E : NT), rs = threadIdx.x / (E < NT ? E : NT);
-  if (rs >= RS) return;
-  for (int e = e0; e < E; e += NT) {
+  for (int e = threadIdx.x; e < E; e += NT) {
     const int ci = e % Cin, co = (e / Cin) % Cout, t = e / (Cin * Cout);
     float acc = 0.f;
-    for (long r = r0 + rs; r < r1; r += RS) {
-      const int b = (int)(r / Lo), lo = (int)(r - (long)b * Lo);
-      const int v = lo * stride + t - pad_l;
-      if (v < 0 || v >= Li) continue;
-      acc += ld_f32(dy + r * lddy + co) * ld_f32(x + ((long)b * Li + v) * ldx + ci);
+    for (long r0 = (long)blockIdx.x * rows_per_chunk; r0 < rows; r0 += (long)gridDim.x * rows_per_chunk) {
+      const long r1 = min(rows, r0 + rows_per_chunk);
+      for (long r = r0; r < r1; r++) {
+        const int b = (int)(r / Lo), lo = (int)(r - (long)b * Lo);
+        const int v = lo * stride + t - pad_l;
+        if (v >= 0 && v < Li) acc += ld_f32(dy + r * lddy + co) * ld_f32(x + ((long)b * Li + v) * ldx + ci);
+      }
     }
     atomicAdd(dw + e, acc);
-    if (E < NT) break;
+  }
+}
+
+// "tiny" variant (Cin, Cout <= 4; every layer of the [2,2,4] autoencoder): thread per output row with all K*Cout*Cin
+// partial sums in registers, wave-shuffle + LDS reduction, one atomic per element per block.
+template <typename T>
+__global__ __launch_bounds__(NT) void dconv_wgrad_tiny_kernel(const T* __restrict__ x, long ldx, const T* __restrict__ dy, long lddy,
+                                                              float* __restrict__ dw, int B, int Lo, int Li, int Cout, int Cin, int K,
+                                                              int stride, int pad_l) {
+  float acc[3][4][4];
+#pragma unroll
+  for (int t = 0; t < 3; t++)
+#pragma unroll
+    for (int o = 0; o < 4; o++)
+#pragma unroll
+      for (int i = 0; i < 4; i++) acc[t][o][i] = 0.f;
+  const long rows = (long)B * Lo;
+  for (long r = (long)blockIdx.x * NT + threadIdx.x; r < rows; r += (long)gridDim.x * NT) {
+    const int b = (int)(r / Lo), lo = (int)(r - (long)b * Lo);
+    float d[4];
+#pragma unroll
+    for (int o = 0; o < 4; o++) d[o] = o < Cout ? ld_f32(dy + r * lddy + o) : 0.f;
+#pragma unroll
+    for (int t = 0; t < 3; t++) {
+      const int v = lo * stride + t - pad_l;
+      if (t < K && v >= 0 && v < Li) {
+        const T* xr = x + ((long)b * Li + v) * ldx;
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+          const float xv = i < Cin ? ld_f32(xr + i) : 0.f;
+#pragma unroll
+          for (int o = 0; o < 4; o++) acc[t][o][i] += d[o] * xv;
+        }
+      }
+    }
+  }
+  __shared__ float red[4][48];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+  for (int t = 0; t < 3; t++)
+#pragma unroll
+    for (int o = 0; o < 4; o++)
+#pragma unroll
+      for (int i = 0; i < 4; i++) {
+        const float s = wave_sum(acc[t][o][i]);
+        if (lane == 0) red[wave][(t * 4 + o) * 4 + i] = s;
+      }
+  __syncthreads();
+  const int e = threadIdx.x;
+  if (e < 48) {
+    const int t = e / 16, o = (e / 4) % 4, i = e % 4;
+    if (t < K && o < Cout && i < Cin) atomicAdd(dw + ((long)t * Cout + o) * Cin + i, red[0][e] + red[1][e] + red[2][e] + red[3][e]);
   }
 }
 
@@ -153,14 +203,27 @@ int dconv_run(eegldm_ctx* ctx, int dtype, bool dgrad, const void* in, long ldin,
 int dconv_wgrad(eegldm_ctx* ctx, int dtype, const void* x, long ldx, const void* dy, long lddy, float* dw, int B, int Lin,
                 int Lout, int Cin, int Cout, int K, int stride, int pad_l) {
   const long rows = (long)B * Lout;
-  int rpb = 256;
-  long blocks = (rows + rpb - 1) / rpb;
+  if (Cin <= 4 && Cout <= 4 && K <= 3) {
+    const int blocks = grid_cap((rows + NT - 1) / NT, ctx) / 4 + 1;
+    if (dtype == EEGLDM_F32)
+      hipLaunchKernelGGL((dconv_wgrad_tiny_kernel<float>), dim3(blocks), dim3(NT), 0, ctx->stream, (const float*)x, ldx, (const float*)dy, lddy,
+                         dw, B, Lout, Lin, Cout, Cin, K, stride, pad_l);
+    else
+      hipLaunchKernelGGL((dconv_wgrad_tiny_kernel<bf16_t>), dim3(blocks), dim3(NT), 0, ctx->stream, (const bf16_t*)x, ldx, (const bf16_t*)dy, lddy,
+                         dw, B, Lout, Lin, Cout, Cin, K, stride, pad_l);
+    LAUNCH_CHECK();
+    return 0;
+  }
+  const int rpc = 64;
+  long blocks = (rows + rpc - 1) / rpc;
+  const long cap = (long)ctx->num_cu * 4;
+  if (blocks > cap) blocks = cap;
   if (dtype == EEGLDM_F32)
     hipLaunchKernelGGL((dconv_wgrad_kernel<float>), dim3((unsigned)blocks), dim3(NT), 0, ctx->stream, (const float*)x, ldx,
-                       (const float*)dy, lddy, dw, B, Lout, Lin, Cout, Cin, K, stride, pad_l, rpb);
+                       (const float*)dy, lddy, dw, B, Lout, Lin, Cout, Cin, K, stride, pad_l, rpc);
   else
     hipLaunchKernelGGL((dconv_wgrad_kernel<bf16_t>), dim3((unsigned)blocks), dim3(NT), 0, ctx->stream, (const bf16_t*)x, ldx,
-                       (const bf16_t*)dy, lddy, dw, B, Lout, Lin, Cout, Cin, K, stride, pad_l, rpb);
+                       (const bf16_t*)dy, lddy, dw, B, Lout, Lin, Cout, Cin, K, stride, pad_l, rpc);
   LAUNCH_CHECK();
   return 0;
 }

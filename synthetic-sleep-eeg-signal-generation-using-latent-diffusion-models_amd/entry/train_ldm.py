@@ -1,0 +1,96 @@
+"""Latent-diffusion UNet training over frozen AutoencoderKL latents -- counterpart of
+/root/reference/src/train_ldm.py + src/training/training.py::train_ldm (flags, yaml schema, checkpoint keys
+training.py:381-397).  One process per GPU under torch.distributed.run for data parallelism."""
+import argparse
+import os
+import time
+
+import torch
+
+from .. import distributed as D
+from ..models import AutoencoderKL, UNetModel
+from ..schedulers import DDPMScheduler
+from ..training import Adam, ldm_train_step, randint, randn
+from .common import ParseListAction, WindowLoader, load_config, setup_run_dir
+
+
+def parse_args(argv=None):
+    p = argparse.ArgumentParser()
+    p.add_argument("--config_file", required=True)
+    p.add_argument("--path_train_ids", default=None); p.add_argument("--path_valid_ids", default=None)
+    p.add_argument("--path_cached_data", default=None); p.add_argument("--path_pre_processed", default=None)
+    p.add_argument("--num_channels", action=ParseListAction, default=None)
+    p.add_argument("--autoencoderkl_config_file_path", required=True); p.add_argument("--best_model_path", default=None)
+    p.add_argument("--spe", default="no-spectral"); p.add_argument("--latent_channels", type=int, default=1)
+    p.add_argument("--type_dataset", default="edfx"); p.add_argument("--dataset", default="edfx")
+    p.add_argument("--synthetic_windows", type=int, default=0); p.add_argument("--dtype", default="float32")
+    p.add_argument("--max_steps", type=int, default=0); p.add_argument("--output_dir", default=None)
+    p.add_argument("--prediction_type", default="epsilon")
+    return p.parse_args(argv)
+
+
+def main(args):
+    rank, local, world = D.init_from_env()
+    torch.cuda.set_device(local)
+    config = load_config(args.config_file)
+    torch.manual_seed(config.train.seed)
+    run_dir, _resume = setup_run_dir(config, args)
+    ae_cfg = dict(load_config(args.autoencoderkl_config_file_path).autoencoderkl.params)
+    if args.num_channels is not None:
+        ae_cfg["num_channels"] = args.num_channels
+    ae_cfg["latent_channels"] = args.latent_channels
+    stage1 = AutoencoderKL(**ae_cfg, dtype=args.dtype, device=local)
+    if args.best_model_path:
+        stage1.load_state_dict(torch.load(os.path.join(args.best_model_path, "best_model.pth"), map_location="cpu"))
+    stage1.eval()
+    up = dict(config.model.params.unet_config.params)
+    up["in_channels"] = up["out_channels"] = args.latent_channels            # train_ldm.py:184-187
+    unet = UNetModel(**up, dtype=args.dtype, device=local)
+    D.broadcast_flat(unet.flat); unet.sync_weights(); D.broadcast_flat(stage1.flat); stage1.sync_weights()
+    sched = DDPMScheduler(num_train_timesteps=1000, schedule="scaled_linear_beta", beta_start=0.0015, beta_end=0.0195,
+                          prediction_type=args.prediction_type, device=local)   # train_ldm.py:199-200 ("linear" there == scaled-linear)
+    opt = Adam(unet, lr=config.train.get("base_lr", 1e-4))
+    bs = max(1, config.train.batch_size // world)
+    train = WindowLoader(args.path_pre_processed, bs, args.synthetic_windows, seed=config.train.seed + rank, drop_last=config.train.drop_last)
+    dev, ctx = unet.device, unet.ctx
+    first = next(iter(train))["eeg"].to(dev)
+    z = stage1.encode_stage_2_inputs(first)
+    scale_factor = 1.0 / float(z.std())                                       # train_ldm.py:203-204 (unbiased std of one batch)
+    if rank == 0:
+        print(f"Scaling factor set to {scale_factor}")
+    loss = torch.zeros(1, device=dev)
+    steps, t0, seen, best = 0, time.time(), 0, float("inf")
+    for epoch in range(config.train.n_epochs):
+        unet.train()
+        for batch in train:
+            x = batch["eeg"].to(dev)
+            B = x.shape[0]
+            t = randint(ctx, B, sched.num_train_timesteps, seed=config.train.seed + 11 + rank, offset=steps * B)
+            eps = randn(ctx, (B, args.latent_channels, x.shape[2] // stage1.down), seed=config.train.seed + 12 + rank, offset=steps * z[0].numel() * B)
+            noise = randn(ctx, eps.shape, seed=config.train.seed + 13 + rank, offset=steps * z[0].numel() * B)
+            e = stage1.encode_stage_2_inputs(x, eps=eps, scale_factor=scale_factor)
+            opt.zero_grad()
+            ldm_train_step(unet, sched, e, noise, t, loss_out=loss)
+            D.allreduce_mean_flat(unet.flat_grad)
+            opt.step()
+            steps += 1; seen += B * world
+            if args.max_steps and steps >= args.max_steps:
+                break
+        if rank == 0:
+            print(f"epoch {epoch}: loss {float(loss):.5f} | {seen/(time.time()-t0):.1f} windows/s", flush=True)
+            if (epoch + 1) % config.train.get("eval_freq", 1) == 0 or (args.max_steps and steps >= args.max_steps):
+                cur = float(loss)
+                if cur <= best:
+                    best = cur
+                    torch.save({k: v.cpu() for k, v in unet.state_dict().items()}, os.path.join(run_dir, "best_model.pth"))
+                torch.save({"epoch": epoch + 1, "diffusion": {k: v.cpu() for k, v in unet.state_dict().items()}, "optimizer": opt.state_dict(),
+                            "best_loss": best, "scale_factor": torch.tensor(scale_factor)}, os.path.join(run_dir, "checkpoint.pth"))
+        if args.max_steps and steps >= args.max_steps:
+            break
+    if rank == 0:
+        torch.save({k: v.cpu() for k, v in unet.state_dict().items()}, os.path.join(run_dir, "final_model.pth"))
+    return run_dir
+
+
+if __name__ == "__main__":
+    main(parse_args())
