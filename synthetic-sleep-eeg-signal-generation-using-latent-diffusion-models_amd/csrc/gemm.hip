@@ -68,9 +68,9 @@ template <int BX> struct TrPitch<float, BX> { static constexpr int v = BX * 4 + 
 template <int BX> struct TrPitch<bf16_t, BX> { static constexpr int v = BX * 2; };
 
 template <int BX>
-__device__ __forceinline__ uint4 read_tr_f32(const char* tile, int ks, int x0, int lm, int q) {
+__device__ __forceinline__ uint4 read_tr_f32(const char* tile, int ks, int x0, int lm, int q, int rowoff) {
   constexpr int pitch = TrPitch<float, BX>::v;
-  const char* p = tile + (ks * 16 + 4 * q) * pitch + (x0 + lm) * 4;
+  const char* p = tile + (ks * 16 + 4 * q + rowoff) * pitch + (x0 + lm) * 4;
   uint4 r;
   r.x = *(const unsigned*)(p);
   r.y = *(const unsigned*)(p + pitch);
@@ -79,11 +79,11 @@ __device__ __forceinline__ uint4 read_tr_f32(const char* tile, int ks, int x0, i
   return r;
 }
 template <int BX>
-__device__ __forceinline__ uint4 read_tr_bf16(const char* tile, int ks, int x0, int lm, int q) {
+__device__ __forceinline__ uint4 read_tr_bf16(const char* tile, int ks, int x0, int lm, int q, int rowoff) {
   // lane p of a 16-lane group supplies row (base + p/4), 4 columns at 4*(p%4); it receives
   // column p of the 4x16 block, rows base..base+3 (verified: tools/probes/layout_probe.hip).
   constexpr int pitch = TrPitch<bf16_t, BX>::v;
-  const int row0 = ks * 32 + 8 * q + (lm >> 2), colb = (x0 + 4 * (lm & 3)) * 2;
+  const int row0 = ks * 32 + 8 * q + (lm >> 2) + rowoff, colb = (x0 + 4 * (lm & 3)) * 2;
   const char* p0 = tile + row0 * pitch + tr_swz<BX>(row0, colb);
   const char* p1 = tile + (row0 + 4) * pitch + tr_swz<BX>(row0 + 4, colb);
   s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(p0));
@@ -96,9 +96,9 @@ __device__ __forceinline__ uint4 read_tr_bf16(const char* tile, int ks, int x0, 
   return r;
 }
 template <typename T, int BX>
-__device__ __forceinline__ uint4 read_tr_t(const char* tile, int ks, int x0, int lm, int q) {
-  if constexpr (sizeof(T) == 4) return read_tr_f32<BX>(tile, ks, x0, lm, q);
-  else return read_tr_bf16<BX>(tile, ks, x0, lm, q);
+__device__ __forceinline__ uint4 read_tr_t(const char* tile, int ks, int x0, int lm, int q, int rowoff = 0) {
+  if constexpr (sizeof(T) == 4) return read_tr_f32<BX>(tile, ks, x0, lm, q, rowoff);
+  else return read_tr_bf16<BX>(tile, ks, x0, lm, q, rowoff);
 }
 // byte offset of 16-byte chunk (krow, seg) of a TR tile
 template <typename T, int BX>
@@ -121,8 +121,13 @@ struct Cfg {
   static constexpr int PITCH_A_TR = TrPitch<T, BM>::v;
   static constexpr int PITCH_B_TR = TrPitch<T, BN>::v;
   static constexpr int A_BYTES = (AMODE == GA_TR) ? KSTAGE * PITCH_A_TR : A_ROWS_NT * PITCH_NT;
-  static constexpr int B_TILE_BYTES = (BMODE == GB_TR) ? KSTAGE * PITCH_B_TR : BN * PITCH_NT;
-  static constexpr int B_BYTES = TAPS * B_TILE_BYTES;
+  // WG3: fused 3-tap weight gradient -- dY tile staged once, X tile staged once with a 1-row halo each side,
+  // the three taps are row-shifted transpose reads of the same X tile (3x less staging per MFMA than one tap per block)
+  static constexpr bool WG3 = (AMODE == GA_TR && BMODE == GB_TR && TAPS == 3);
+  static constexpr int B_ROWS_TR = WG3 ? KSTAGE + 2 : KSTAGE;
+  static constexpr int B_TILE_BYTES = (BMODE == GB_TR) ? B_ROWS_TR * PITCH_B_TR : BN * PITCH_NT;
+  static constexpr int B_BYTES = (WG3 ? 1 : TAPS) * B_TILE_BYTES;
+  static constexpr int NACC = WG3 ? 3 : 1;
   // LDS-DMA staging: every tile is a linear run of 16-byte chunks; one wave-instruction fills 64 of them (1 KiB)
   static constexpr int A_CHUNKS = A_BYTES / 16;
   static constexpr int B_CHUNKS = B_BYTES / 16;
@@ -136,7 +141,7 @@ struct Cfg {
   // Staging engine, chosen by measurement (profiles/r01_gemm_tile_sweep.txt): the 3-tap conv kernels are fastest with
   // LDS-DMA into a double-buffered ring (one barrier per stage); the 1-tap kernels (1x1 / Linear / attention / wgrad)
   // are fastest with register staging (global -> VGPR prefetch under the MFMA phase -> ds_write), single buffer.
-  static constexpr bool USE_DMA = (TAPS == 3);
+  static constexpr bool USE_DMA = (TAPS == 3 && AMODE == GA_CONV);
   static constexpr int NSTG = !USE_DMA ? 1 : ((WMT == 4 && 3 * STAGE_BYTES <= 160 * 1024) ? 3 : 2);   // LDS ring depth
   static constexpr int CA = (A_CHUNKS + NTHREADS - 1) / NTHREADS;  // register-staged 16-byte chunks per thread
   static constexpr int CB = (B_CHUNKS + NTHREADS - 1) / NTHREADS;
@@ -151,7 +156,7 @@ typedef __attribute__((address_space(3))) void* lds_void_ptr;
 typedef const __attribute__((address_space(1))) void* glb_void_ptr;
 
 template <typename T, int AMODE, int BMODE, int TAPS, int KSUB, int BN, int STRIDE, int WMT>
-__global__ __launch_bounds__(128 * WMT) void gemm_kernel(const GemmArgs p) {
+__global__ __launch_bounds__(128 * WMT, 2) void gemm_kernel(const GemmArgs p) {   // >= 2 waves per SIMD: <= 256 VGPR+AGPR
   using C = Cfg<T, AMODE, BMODE, TAPS, KSUB, BN, STRIDE, WMT>;
   constexpr int FN = C::FN;
   constexpr int BM = C::BM, NTHREADS = C::NTHREADS, NW = C::NW;
@@ -231,12 +236,21 @@ __global__ __launch_bounds__(128 * WMT) void gemm_kernel(const GemmArgs p) {
       off = (long)tw * p.sBt + (long)n * p.ldb + k;
     } else {  // GB_TR: source [K][N], N contiguous
       constexpr int RCP = C::PITCH_B_TR / 16;
-      const int tap = c / (C::KSTAGE * RCP), r = c % (C::KSTAGE * RCP);
+      const int tap = c / (C::B_ROWS_TR * RCP), r = c % (C::B_ROWS_TR * RCP);
       const int krow = r / RCP, cs = r % RCP;
       int seg = cs;
       if constexpr (sizeof(T) == 4) ok = ok && cs < BN / 4;
       else seg = tr_swz<BN>(krow, cs * 16) >> 4;
-      const int k = k0 + krow, n = n0 + seg * C::EPC;
+      const int n = n0 + seg * C::EPC;
+      if constexpr (C::WG3) {
+        // tile row krow <-> input row k0 + krow - 1 (k=3, stride 1, pad 1); rows of another sample read as zero, which is
+        // exactly the conv's zero padding because a K chunk never straddles a sample (Lout % KSTAGE == 0, checked on the host)
+        const int xr = k0 + krow - 1;
+        ok = ok && xr >= 0 && xr < p.K && (xr / p.Lout) == (k0 / p.Lout) && n < p.N;
+        off = (long)xr * p.ldb + n;
+        return ok;
+      }
+      const int k = k0 + krow;
       ok = ok && k < kend && n < p.N;
       if (p.conv_map) {   // wgrad (wave-uniform): K index = output row -> input row of tap tz
         const int bs = k / p.Lout, lo = k - bs * p.Lout;
@@ -307,11 +321,13 @@ __global__ __launch_bounds__(128 * WMT) void gemm_kernel(const GemmArgs p) {
     }
   }
 
-  f32x4 acc[4][FN];
+  f32x4 acc[C::NACC][4][FN];
 #pragma unroll
-  for (int i = 0; i < 4; i++)
+  for (int a = 0; a < C::NACC; a++)
 #pragma unroll
-    for (int j = 0; j < FN; j++) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int i = 0; i < 4; i++)
+#pragma unroll
+      for (int j = 0; j < FN; j++) acc[a][i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
   // ring of NSTG stage buffers, loads run NSTG-1 stages ahead; each wave issues exactly IA+IB DMA instructions per
   // stage, so "stage s has landed" == at most (NSTG-2)*(IA+IB) of this wave's DMAs still outstanding.
@@ -361,7 +377,7 @@ __global__ __launch_bounds__(128 * WMT) void gemm_kernel(const GemmArgs p) {
 #pragma unroll
         for (int j = 0; j < FN; j++) {
           if constexpr (BMODE == GB_TR) {
-            bf[j] = read_tr_t<T, BN>(smB + t * C::B_TILE_BYTES, ks, wn * (BN / 2) + j * 16, lm, q);
+            bf[j] = read_tr_t<T, BN>(smB + (C::WG3 ? 0 : t) * C::B_TILE_BYTES, ks, wn * (BN / 2) + j * 16, lm, q, C::WG3 ? t : 0);
           } else {
             const int row = wn * (BN / 2) + j * 16 + lm;
             bf[j] = *(const uint4*)(smB + t * C::B_TILE_BYTES + row * C::PITCH_NT + nt_swz<KSUB>(row, ks * 4 + q) * 16);
@@ -371,8 +387,8 @@ __global__ __launch_bounds__(128 * WMT) void gemm_kernel(const GemmArgs p) {
         for (int i = 0; i < 4; i++)
 #pragma unroll
           for (int j = 0; j < FN; j++) {
-            if constexpr (AMODE == GA_TR) mma<T>(af[i], bf[j], acc[i][j]);      // TN products keep the natural fragment (atomic epilogue)
-            else mma<T>(bf[j], af[i], acc[i][j]);                                // swapped: acc = (B.A^T) fragment
+            if constexpr (AMODE == GA_TR) mma<T>(af[i], bf[j], acc[C::WG3 ? t : 0][i][j]);   // TN products keep the natural fragment (atomic epilogue)
+            else mma<T>(bf[j], af[i], acc[0][i][j]);                               // swapped: acc = (B.A^T) fragment
           }
       }
     }
@@ -391,17 +407,19 @@ __global__ __launch_bounds__(128 * WMT) void gemm_kernel(const GemmArgs p) {
     if (p.atomic_out) {
       // split-K weight gradients: natural fragment layout (rows q*4+r, col lm), fp32 atomics straight from registers
 #pragma unroll
-      for (int i = 0; i < 4; i++)
+      for (int a = 0; a < C::NACC; a++)
 #pragma unroll
-        for (int r = 0; r < 4; r++) {
-          const int m = m0 + wm * 64 + i * 16 + q * 4 + r;
-          if (m >= p.M) continue;
+        for (int i = 0; i < 4; i++)
 #pragma unroll
-          for (int j = 0; j < FN; j++) {
-            const int n = n0 + wn * (BN / 2) + j * 16 + lm;
-            if (n < p.N) atomicAdd((float*)Cb + cbase + (long)m * p.ldc + n, acc[i][j][r] * p.alpha);
+          for (int r = 0; r < 4; r++) {
+            const int m = m0 + wm * 64 + i * 16 + q * 4 + r;
+            if (m >= p.M) continue;
+#pragma unroll
+            for (int j = 0; j < FN; j++) {
+              const int n = n0 + wn * (BN / 2) + j * 16 + lm;
+              if (n < p.N) atomicAdd((float*)Cb + cbase + (long)a * p.sCt + (long)m * p.ldc + n, acc[a][i][j][r] * p.alpha);
+            }
           }
-        }
       return;
     }
   }
@@ -412,9 +430,9 @@ __global__ __launch_bounds__(128 * WMT) void gemm_kernel(const GemmArgs p) {
       if constexpr (AMODE == GA_TR) {
 #pragma unroll
         for (int r = 0; r < 4; r++)
-          *(float*)(smem + (wm * 16 + q * 4 + r) * C::EPI_PITCH + (wn * (BN / 2) + j * 16 + lm) * 4) = acc[i][j][r] * p.alpha;
+          *(float*)(smem + (wm * 16 + q * 4 + r) * C::EPI_PITCH + (wn * (BN / 2) + j * 16 + lm) * 4) = acc[0][i][j][r] * p.alpha;
       } else {
-        float4 v = make_float4(acc[i][j][0] * p.alpha, acc[i][j][1] * p.alpha, acc[i][j][2] * p.alpha, acc[i][j][3] * p.alpha);
+        float4 v = make_float4(acc[0][i][j][0] * p.alpha, acc[0][i][j][1] * p.alpha, acc[0][i][j][2] * p.alpha, acc[0][i][j][3] * p.alpha);
         *(float4*)(smem + (wm * 16 + lm) * C::EPI_PITCH + (wn * (BN / 2) + j * 16 + q * 4) * 4) = v;
       }
     }
@@ -507,6 +525,10 @@ int launch_modes(eegldm_ctx* ctx, const GemmArgs& a) {
     }
     EEG_FAIL(EEGLDM_ERR_UNSUPPORTED, "conv gemm: taps=%d stride=%d bmode=%d", a.taps, a.stride, a.bmode);
   }
+  if (a.amode == GA_TR && a.bmode == GB_TR && a.taps == 3) {   // fused 3-tap wgrad (see Cfg::WG3); BN <= 64 keeps 3 accumulator sets in registers
+    if (a.N > 32) return launch_t<T, GA_TR, GB_TR, 3, 2, 64, 1, 2>(ctx, a);
+    return launch_t<T, GA_TR, GB_TR, 3, 2, 32, 1, 2>(ctx, a);
+  }
   EEG_CHECK(a.taps == 1, "taps>1 needs conv A mode");
   if (a.amode == GA_PLAIN && a.bmode == GB_NT) return launch_bn<T, GA_PLAIN, GB_NT, 1, 2, 1>(ctx, a);
   if (a.amode == GA_PLAIN && a.bmode == GB_TR) return launch_bn<T, GA_PLAIN, GB_TR, 1, 2, 1>(ctx, a);
@@ -539,7 +561,7 @@ int gemm_launch(eegldm_ctx* ctx, const GemmArgs& a_in) {
   ProfRec rec; bool prof = ctx->prof_on;
   if (prof) {
     rec.cls = a.amode == GA_CONV ? (a.bmode == GB_NT ? PROF_CONV_FWD : PROF_CONV_DGRAD)
-              : (a.amode == GA_TR ? (a.conv_map ? PROF_CONV_WGRAD : PROF_GEMM_TN) : (a.bmode == GB_NT ? PROF_GEMM_NT : PROF_GEMM_NN));
+              : (a.amode == GA_TR ? ((a.conv_map || a.taps == 3) ? PROF_CONV_WGRAD : PROF_GEMM_TN) : (a.bmode == GB_NT ? PROF_GEMM_NT : PROF_GEMM_NN));
     // algorithmic work: the transposed (strided) dgrad multiplies a half-zero virtual signal; only the real taps count
     rec.flops = 2.0 * a.M * a.N * (double)a.K * a.taps * a.ztaps * a.batch / (a.ups > 1 ? a.ups : 1);
     rec.M = a.M; rec.N = a.N; rec.K = a.K; rec.taps = a.taps * a.ztaps; rec.splitk = a.splitk;

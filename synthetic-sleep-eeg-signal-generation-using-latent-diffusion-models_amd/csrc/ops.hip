@@ -66,10 +66,17 @@ int op_conv_wgrad(eegldm_ctx* ctx, int dtype, const void* x, long ldx, const voi
   a.M = Cout; a.N = Cin; a.K = B * Lout; a.batch = 1; a.taps = 1; a.ztaps = K; a.alpha = 1.0f;
   a.conv_map = 1; a.Lout = Lout; a.Lin = Lin; a.stride = stride; a.pad_l = pad_l;
   a.out_f32 = 1; a.atomic_out = 1;
-  const int bn = Cin > 64 ? 128 : (Cin > 32 ? 64 : 32);
-  const int bm = 128;
-  const long tiles = (long)((Cout + bm - 1) / bm) * ((Cin + bn - 1) / bn) * K;
   const int kstage = 2 * (dtype == EEGLDM_F32 ? 16 : 32);
+  const bool fused3 = (K == 3 && stride == 1 && pad_l == 1 && pad_r == 1 && Lout % kstage == 0);
+  int bn = Cin > 64 ? 128 : (Cin > 32 ? 64 : 32);
+  long tiles;
+  if (fused3) {   // one block = all three taps of a 128 x 64 weight tile: dY and X staged once per K chunk
+    a.taps = 3; a.ztaps = 1; a.conv_map = 0;
+    bn = Cin > 32 ? 64 : 32;
+    tiles = (long)((Cout + 127) / 128) * ((Cin + bn - 1) / bn);
+  } else {
+    tiles = (long)((Cout + 127) / 128) * ((Cin + bn - 1) / bn) * K;
+  }
   long want = ((long)ctx->num_cu * 2 + tiles - 1) / tiles;     // fill the 2 resident blocks per CU
   long maxs = ((long)a.K + 8 * kstage - 1) / (8 * kstage);     // at least 8 stages per split
   if (want > maxs) want = maxs;
