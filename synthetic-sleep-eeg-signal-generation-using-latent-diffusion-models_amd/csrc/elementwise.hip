@@ -86,21 +86,49 @@ template <typename T> __global__ void silu_bwd_kernel(const float* __restrict__ 
 }
 
 // ------------------------------------------------------------------ column sums
-// per-sample: out[b][c] (=|+=) sum_l X[b][l][c]; grid (ceil(C/64), LSPLIT, B)
-template <typename T, typename TO>
-__global__ __launch_bounds__(NT) void colsum_kernel(const T* __restrict__ x, long ldx, TO* __restrict__ out, long ldo,
-                                                    float* __restrict__ total, int L, int C, int rows_per_block) {
-  __shared__ float red[4][64];
-  const int c = blockIdx.x * 64 + (threadIdx.x & 63), ry = threadIdx.x >> 6;
-  const int b = blockIdx.z, l0 = blockIdx.y * rows_per_block, l1 = min(L, l0 + rows_per_block);
-  float s = 0.f;
-  if (c < C) for (int l = l0 + ry; l < l1; l += 4) s += ld_f32(x + ((long)b * L + l) * ldx + c);
-  red[ry][threadIdx.x & 63] = s;
+// out[b][c] = sum_l X[b][l][c] (per sample, written) and/or total[c] += sum over everything (fp32 atomics).
+// grid (LSPLIT, B); 4-channel vectors per thread, (column vector, row lane) tiling, LDS reduction over row lanes.
+template <typename T, int V>
+__global__ __launch_bounds__(NT) void colsum_kernel(const T* __restrict__ x, long ldx, float* __restrict__ out, long ldo,
+                                                    float* __restrict__ total, int L, int Cfull, int rows_per_block) {
+  __shared__ float acc[1024];
+  const int b = blockIdx.y, tid = threadIdx.x;
+  // grid.z tiles the channels in chunks of 1024 (qkv biases have 1536, the batched embedding bias ~7k)
+  const int c0 = blockIdx.z * 1024, C = min(1024, Cfull - c0);
+  x += c0; if (out) out += c0; if (total) total += c0;
+  for (int i = tid; i < C; i += NT) acc[i] = 0.f;
   __syncthreads();
-  if (ry == 0 && c < C) {
-    s = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
-    if (out) st_f32(out + (long)b * ldo + c, s);   // written, not accumulated: single L split only
-    if (total) atomicAdd(total + c, s);
+  const int ncols = C / V;
+  const int TX = ncols >= NT ? NT : ncols, TY = ncols >= NT ? 1 : NT / ncols;
+  const int l0 = blockIdx.x * rows_per_block, l1 = min(L, l0 + rows_per_block);
+  if (tid < TX * TY) {
+    const int tx = tid % TX, ty = tid / TX;
+    for (int col = tx; col < ncols; col += TX) {
+      const int c = col * V;
+      float s[V];
+#pragma unroll
+      for (int k = 0; k < V; k++) s[k] = 0.f;
+#pragma unroll 4
+      for (int l = l0 + ty; l < l1; l += TY) {
+        const T* p = x + ((long)b * L + l) * ldx + c;
+        if constexpr (V == 4 && sizeof(T) == 2) {
+          const uint2 t = *(const uint2*)p;
+          s[0] += __uint_as_float(t.x << 16); s[1] += __uint_as_float(t.x & 0xffff0000u);
+          s[2] += __uint_as_float(t.y << 16); s[3] += __uint_as_float(t.y & 0xffff0000u);
+        } else if constexpr (V == 4) {
+          const float4 t = *(const float4*)p; s[0] += t.x; s[1] += t.y; s[2] += t.z; s[3] += t.w;
+        } else {
+          s[0] += ld_f32(p);
+        }
+      }
+#pragma unroll
+      for (int k = 0; k < V; k++) atomicAdd(&acc[c + k], s[k]);
+    }
+  }
+  __syncthreads();
+  for (int i = tid; i < C; i += NT) {
+    if (out) out[(long)b * ldo + i] = acc[i];     // written, not accumulated: single L split only
+    if (total) atomicAdd(total + i, acc[i]);
   }
 }
 
@@ -270,11 +298,13 @@ int ew_silu_bwd(eegldm_ctx* ctx, const float* dy, const float* x, void* dx, long
 int ew_colsum(eegldm_ctx* ctx, const void* x, long ldx, float* out_ps, long ldo, float* total, int B, int L, int C, int dtype) {
   int lsplit = 1, rpb = L;
   if (!out_ps) {  // free to split L when only the fp32 atomic total is wanted
-    int want = (ctx->num_cu * 4) / (B * ((C + 63) / 64)) ; if (want < 1) want = 1;
+    int want = (ctx->num_cu * 4 + B - 1) / B; if (want < 1) want = 1;
     int maxs = (L + 31) / 32; lsplit = want > maxs ? maxs : want; rpb = (L + lsplit - 1) / lsplit; lsplit = (L + rpb - 1) / rpb;
   }
-  dim3 grid((C + 63) / 64, lsplit, B);
-  DISPATCH_T(dtype, hipLaunchKernelGGL((colsum_kernel<T, float>), grid, dim3(NT), 0, ctx->stream, (const T*)x, ldx, out_ps, ldo, total, L, C, rpb));
+  dim3 grid(lsplit, B, (C + 1023) / 1024);
+  const bool v4 = (C % 4 == 0) && (ldx % 4 == 0);
+  if (v4) { DISPATCH_T(dtype, hipLaunchKernelGGL((colsum_kernel<T, 4>), grid, dim3(NT), 0, ctx->stream, (const T*)x, ldx, out_ps, ldo, total, L, C, rpb)); }
+  else { DISPATCH_T(dtype, hipLaunchKernelGGL((colsum_kernel<T, 1>), grid, dim3(NT), 0, ctx->stream, (const T*)x, ldx, out_ps, ldo, total, L, C, rpb)); }
   LAUNCH_CHECK(); return 0;
 }
 int ew_softmax(eegldm_ctx* ctx, const float* S, void* P, long rows, int n, int dtype) {

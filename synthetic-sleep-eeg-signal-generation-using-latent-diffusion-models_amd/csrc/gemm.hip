@@ -266,18 +266,34 @@ __global__ __launch_bounds__(128 * WMT, 2) void gemm_kernel(const GemmArgs p) { 
   };
   auto a_src = [&](int c, int k0) __attribute__((always_inline)) -> const T* { long off; const bool ok = a_dec(c, k0, off); return ok ? Ag + off : zeros; };
   auto b_src = [&](int c, int k0) __attribute__((always_inline)) -> const T* { long off; const bool ok = b_dec(c, k0, off); return ok ? Bg + off : zeros; };
+  // Fast path (every UNet shape): when K is a whole number of stages the source of each DMA chunk moves by a constant
+  // per stage, so the decode above runs ONCE per block and the K loop only adds a stride to a saved pointer
+  // (the full decode per stage cost ~7 VALU instructions per MFMA -- PMC: profiles/r01_gemm_pmc.txt).
+  const bool kwhole = ((kend - kbeg) % C::KSTAGE) == 0;
+  const T* apre[C::USE_DMA ? C::IA : 1]; const T* bpre[C::USE_DMA ? C::IB : 1];
+  long astep = 0, bstep = 0;     // elements per stage
+  if constexpr (C::USE_DMA) {
+    astep = C::KSTAGE;                                       // A is K-contiguous in the conv modes
+    bstep = (BMODE == GB_NT) ? (long)C::KSTAGE : (long)C::KSTAGE * p.ldb;
+#pragma unroll
+    for (int i = 0; i < C::IA; i++) { long off; const bool ok = a_dec((wave + NW * i) * 64 + lane, kbeg, off); apre[i] = ok ? Ag + off : nullptr; }
+#pragma unroll
+    for (int i = 0; i < C::IB; i++) { long off; const bool ok = b_dec((wave + NW * i) * 64 + lane, kbeg, off); bpre[i] = ok ? Bg + off : nullptr; }
+  }
   auto issue_stage = [&](int s, int buf) __attribute__((always_inline)) {
     const int k0 = kbeg + s * C::KSTAGE;
     char* base = smem + buf * C::STAGE_BYTES;
 #pragma unroll
     for (int i = 0; i < C::IA; i++) {
       const int ins = wave + NW * i;
-      __builtin_amdgcn_global_load_lds((glb_void_ptr)a_src(ins * 64 + lane, k0), (lds_void_ptr)(base + ins * 1024), 16, 0, 0);
+      const T* src = kwhole ? (apre[i] ? apre[i] + s * astep : zeros) : a_src(ins * 64 + lane, k0);
+      __builtin_amdgcn_global_load_lds((glb_void_ptr)src, (lds_void_ptr)(base + ins * 1024), 16, 0, 0);
     }
 #pragma unroll
     for (int i = 0; i < C::IB; i++) {
       const int ins = wave + NW * i;
-      __builtin_amdgcn_global_load_lds((glb_void_ptr)b_src(ins * 64 + lane, k0), (lds_void_ptr)(base + C::A_ALLOC + ins * 1024), 16, 0, 0);
+      const T* src = kwhole ? (bpre[i] ? bpre[i] + s * bstep : zeros) : b_src(ins * 64 + lane, k0);
+      __builtin_amdgcn_global_load_lds((glb_void_ptr)src, (lds_void_ptr)(base + C::A_ALLOC + ins * 1024), 16, 0, 0);
     }
   };
 
@@ -505,6 +521,8 @@ int launch_t(eegldm_ctx* ctx, const GemmArgs& a) {
 template <typename T, int AMODE, int BMODE, int TAPS, int KSUB, int STRIDE>
 int launch_bn(eegldm_ctx* ctx, const GemmArgs& a) {
   static const bool big_ok = getenv("EEGLDM_GEMM_BIG_TILES") != nullptr;
+  static const int bn64_maxk = getenv("EEGLDM_GEMM_BN64_MAXK") ? atoi(getenv("EEGLDM_GEMM_BN64_MAXK")) : 0;
+  if (a.N > 64 && a.K <= bn64_maxk) return launch_t<T, AMODE, BMODE, TAPS, KSUB, 64, STRIDE, 2>(ctx, a);
   const bool big = big_ok && a.M >= 256 && !(AMODE == GA_CONV && STRIDE == 2);
   if (a.N > 64) return big ? launch_t<T, AMODE, BMODE, TAPS, KSUB, 128, STRIDE, 4>(ctx, a) : launch_t<T, AMODE, BMODE, TAPS, KSUB, 128, STRIDE, 2>(ctx, a);
   if (a.N > 32) return launch_t<T, AMODE, BMODE, TAPS, KSUB, 64, STRIDE, 2>(ctx, a);
@@ -516,6 +534,12 @@ int launch_modes(eegldm_ctx* ctx, const GemmArgs& a) {
   if (a.amode == GA_CONV) {
     EEG_CHECK(a.batch == 1, "conv mode expects flattened rows (batch=1)");
     EEG_CHECK(a.Lin == a.Lout * a.stride, "conv mode needs Lin == Lout*stride (got %d, %d, %d)", a.Lin, a.Lout, a.stride);
+    static const int conv_variant = getenv("EEGLDM_CONV_VARIANT") ? atoi(getenv("EEGLDM_CONV_VARIANT")) : 0;
+    if (conv_variant == 1 && a.taps == 3 && a.stride == 1 && a.N > 32 && a.M >= 256) {
+      // experiment: 256 x 64 tiles, 8 waves, K stage of 64 channels = 128-byte rows (full-line L2 requests)
+      if (a.bmode == GB_NT) return launch_t<T, GA_CONV, GB_NT, 3, 2, 64, 1, 4>(ctx, a);
+      return launch_t<T, GA_CONV, GB_TR, 3, 2, 64, 1, 4>(ctx, a);
+    }
     if (a.bmode == GB_NT) {
       if (a.taps == 3 && a.stride == 1) return launch_bn<T, GA_CONV, GB_NT, 3, 1, 1>(ctx, a);
       if (a.taps == 3 && a.stride == 2) return launch_bn<T, GA_CONV, GB_NT, 3, 1, 2>(ctx, a);

@@ -63,11 +63,23 @@ int res_backward(NetBase* u, const ResDesc& r, const ResTape& t, const View& dou
   Arena::Mark mk = u->arena.mark();
   View dxr = dout;
   if (r.sk_w >= 0) {
-    if (u->param_grads) EEG_TRY(op_conv_wgrad(ctx, dt, t.xr.p, t.xr.ld, dout.p, dout.ld, u->G(r.sk_w), u->G(r.sk_b), B, Lout, r.cin, r.cout, 1, 1, 0, 0));
+    // the skip conv's bias gradient equals conv2's (both are column sums of dout): computed once below and copied
+    if (u->param_grads) EEG_TRY(op_conv_wgrad(ctx, dt, t.xr.p, t.xr.ld, dout.p, dout.ld, u->G(r.sk_w), nullptr, B, Lout, r.cin, r.cout, 1, 1, 0, 0));
     ALLOC_OR_FAIL(dxr.p, u->alloc_act((long)B * Lout, r.cin)); dxr.ld = r.cin; dxr.C = r.cin;
     EEG_TRY(op_conv_dgrad(ctx, dt, dout.p, dout.ld, u->W(r.sk_w), dxr.p, dxr.ld, B, Lout, r.cin, r.cout, 1, 1, 0, 0, nullptr, 0));
   }
-  if (u->param_grads) EEG_TRY(op_conv_wgrad(ctx, dt, t.a2.p, t.a2.ld, dout.p, dout.ld, u->G(r.c2_w), u->G(r.c2_b), B, Lout, r.cout, r.cout, 3, 1, 1, 1));
+  if (u->param_grads) {
+    if (r.sk_w >= 0) {
+      float* tmp = (float*)((char*)ctx->scratch + (3u << 20));        // [cout] staging in the context scratch
+      HIP_TRY(hipMemsetAsync(tmp, 0, sizeof(float) * r.cout, ctx->stream));
+      EEG_TRY(ew_colsum(ctx, dout.p, dout.ld, nullptr, 0, tmp, B, Lout, r.cout, dt));
+      EEG_TRY(eegldm_axpy(ctx, u->G(r.c2_b), tmp, 1.0f, r.cout));
+      EEG_TRY(eegldm_axpy(ctx, u->G(r.sk_b), tmp, 1.0f, r.cout));
+      EEG_TRY(op_conv_wgrad(ctx, dt, t.a2.p, t.a2.ld, dout.p, dout.ld, u->G(r.c2_w), nullptr, B, Lout, r.cout, r.cout, 3, 1, 1, 1));
+    } else {
+      EEG_TRY(op_conv_wgrad(ctx, dt, t.a2.p, t.a2.ld, dout.p, dout.ld, u->G(r.c2_w), u->G(r.c2_b), B, Lout, r.cout, r.cout, 3, 1, 1, 1));
+    }
+  }
   View da2; ALLOC_OR_FAIL(da2.p, u->alloc_act((long)B * Lout, r.cout)); da2.ld = r.cout;
   EEG_TRY(op_conv_dgrad(ctx, dt, dout.p, dout.ld, u->W(r.c2_w), da2.p, da2.ld, B, Lout, r.cout, r.cout, 3, 1, 1, 1, nullptr, 0));
   View dh1; ALLOC_OR_FAIL(dh1.p, u->alloc_act((long)B * Lout, r.cout)); dh1.ld = r.cout;

@@ -13,6 +13,8 @@ namespace {
 
 constexpr int NT = 256;
 constexpr int MAXG_LDS = 1024;   // LDS accumulators per block (groups / channels)
+constexpr int GN_NSLOT = 64;     // partial dgamma/dbeta buffers
+constexpr size_t GN_SLOT_OFFSET = 1u << 20;   // byte offset of the slot area inside ctx->scratch
 
 template <typename T, int V> struct Vec;
 template <> struct Vec<float, 4> { typedef float4 type; };
@@ -182,7 +184,7 @@ template <typename T, int V>
 __global__ __launch_bounds__(NT) void gn_bwd_reduce_kernel(const T* __restrict__ x, long ldx, const float* __restrict__ gamma,
                                                            const float* __restrict__ beta, const float* __restrict__ stats,
                                                            const T* __restrict__ dy, long lddy, double* __restrict__ gsums,
-                                                           float* __restrict__ dgamma, float* __restrict__ dbeta,
+                                                           float* __restrict__ slots,
                                                            int L, int C, int G, int silu, int resample, int rows_per_block) {
   __shared__ float accg[2 * MAXG_LDS];
   __shared__ float accc[2 * MAXG_LDS];
@@ -223,7 +225,19 @@ __global__ __launch_bounds__(NT) void gn_bwd_reduce_kernel(const T* __restrict__
   }
   __syncthreads();
   for (int i = tid; i < 2 * G; i += NT) atomicAdd(&gsums[(long)b * G * 2 + i], (double)accg[i]);
-  if (dgamma) for (int i = tid; i < C; i += NT) { atomicAdd(&dgamma[i], accc[i]); atomicAdd(&dbeta[i], accc[C + i]); }
+  // per-channel sums go to one of NSLOT partial buffers (thousands of blocks hammering 2C addresses serialise in L2)
+  if (slots) {
+    float* sl = slots + (size_t)((blockIdx.y * gridDim.x + blockIdx.x) % GN_NSLOT) * 2 * C;
+    for (int i = tid; i < 2 * C; i += NT) atomicAdd(&sl[i], accc[i]);
+  }
+}
+
+__global__ void gn_slot_reduce_kernel(const float* __restrict__ slots, float* __restrict__ dgamma, float* __restrict__ dbeta, int C) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= 2 * C) return;
+  float s = 0.f;
+  for (int k = 0; k < GN_NSLOT; k++) s += slots[(size_t)k * 2 * C + i];
+  if (i < C) dgamma[i] += s; else dbeta[i - C] += s;
 }
 
 // dx = rstd * (dz*gamma - S1/n - xhat*S2/n) [+ resample^T(dxr)];  grid (row chunks, B), same tiling as the forward
@@ -312,9 +326,15 @@ int gn_bwd_t(eegldm_ctx* ctx, const void* x, long ldx, const float* gamma, const
   double* gsums = (double*)ctx->scratch;
   HIP_TRY(hipMemsetAsync(gsums, 0, sizeof(double) * 2 * B * G, ctx->stream));
   int rpb; int ls = pick_lsplit(B, L, C, ctx, &rpb);
+  float* slots = dgamma ? (float*)((char*)ctx->scratch + GN_SLOT_OFFSET) : nullptr;
+  if (slots) HIP_TRY(hipMemsetAsync(slots, 0, sizeof(float) * GN_NSLOT * 2 * C, ctx->stream));
   hipLaunchKernelGGL((gn_bwd_reduce_kernel<T, V>), dim3(ls, B), dim3(NT), 0, ctx->stream, (const T*)x, ldx, gamma, beta, stats,
-                     (const T*)dy, lddy, gsums, dgamma, dbeta, L, C, G, silu, resample, rpb);
+                     (const T*)dy, lddy, gsums, slots, L, C, G, silu, resample, rpb);
   LAUNCH_CHECK();
+  if (slots) {
+    hipLaunchKernelGGL(gn_slot_reduce_kernel, dim3((2 * C + 255) / 256), dim3(256), 0, ctx->stream, slots, dgamma, dbeta, C);
+    LAUNCH_CHECK();
+  }
   int rpb2; int ls2 = pick_lsplit(B, L, C, ctx, &rpb2, 16, 8);
   hipLaunchKernelGGL((gn_bwd_apply_kernel<T, V>), dim3(ls2, B), dim3(NT), 0, ctx->stream, (const T*)x, ldx, gamma,
                      beta, stats, (const T*)dy, lddy, gsums, (T*)dx, lddx, (const T*)dxr, lddxr, L, C, G, silu, resample, rpb2);
@@ -327,7 +347,7 @@ int gn_check(eegldm_ctx* ctx, int B, int L, int C, int G, int resample, long ldx
   EEG_CHECK(G <= MAXG_LDS && C <= MAXG_LDS, "C, G must be <= %d", MAXG_LDS);
   EEG_CHECK(resample >= 0 && resample <= 2, "resample must be 0/1/2");
   EEG_CHECK(resample != 1 || L % 2 == 0, "avgpool needs even L");
-  EEG_CHECK((size_t)B * G * 2 * sizeof(double) <= ctx->scratch_bytes, "scratch too small for B*G=%d", B * G);
+  EEG_CHECK((size_t)B * G * 2 * sizeof(double) <= GN_SLOT_OFFSET, "scratch too small for B*G=%d", B * G);
   return 0;
 }
 bool vec4_ok(int C, int G, long a, long b, long c, long d) {
