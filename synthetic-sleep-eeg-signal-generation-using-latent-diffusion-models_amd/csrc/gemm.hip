@@ -107,7 +107,7 @@ __device__ __forceinline__ int tr_store_off(int krow, int seg) {
   else return krow * TrPitch<bf16_t, BX>::v + tr_swz<BX>(krow, seg * 16);
 }
 
-template <typename T, int AMODE, int BMODE, int TAPS, int KSUB, int BN, int STRIDE, int WMT>
+template <typename T, int AMODE, int BMODE, int TAPS, int KSUB, int BN, int STRIDE, int WMT, bool DMA>
 struct Cfg {
   static constexpr int BM = 64 * WMT;                             // block rows: WMT waves along M, 2 along N
   static constexpr int NW = 2 * WMT;                              // waves per block
@@ -141,13 +141,19 @@ struct Cfg {
   // Staging engine, chosen by measurement (profiles/r01_gemm_tile_sweep.txt): the 3-tap conv kernels are fastest with
   // LDS-DMA into a double-buffered ring (one barrier per stage); the 1-tap kernels (1x1 / Linear / attention / wgrad)
   // are fastest with register staging (global -> VGPR prefetch under the MFMA phase -> ds_write), single buffer.
-  static constexpr bool USE_DMA = (TAPS == 3 && AMODE == GA_CONV);
+  static constexpr bool USE_DMA = DMA;   // host picks DMA for the 3-tap conv kernels when K is a whole number of stages
   static constexpr int NSTG = !USE_DMA ? 1 : ((WMT == 4 && 3 * STAGE_BYTES <= 160 * 1024) ? 3 : 2);   // LDS ring depth
   static constexpr int CA = (A_CHUNKS + NTHREADS - 1) / NTHREADS;  // register-staged 16-byte chunks per thread
   static constexpr int CB = (B_CHUNKS + NTHREADS - 1) / NTHREADS;
+  static constexpr int NSTG_BYTES_HINT = NSTG * STAGE_BYTES;
   static constexpr int FN = BN / 32;                              // 16-wide fragments per wave along N
   static constexpr int EPI_PITCH = BN * 4 + 16;                   // fp32 epilogue tile [32][BN]
-  static constexpr int EPI_ROWS = 16 * WMT;
+  // epilogue passes: EPI_I of the four 16-row fragment groups go through LDS per pass.  One pass of all four when the
+  // staging ring already owns that much LDS (conv kernels), two otherwise -- fewer barriers and, more importantly,
+  // all of a pass's bias / residual loads are independent and in flight together (the 4-pass version serialised
+  // ~1 us of load latency per pass: 8-10 us per block, profiles/r01_gemm_fixed_cost.txt).
+  static constexpr int EPI_I = (4 * 16 * WMT * EPI_PITCH <= NSTG_BYTES_HINT) ? 4 : 2;
+  static constexpr int EPI_ROWS = EPI_I * 16 * WMT;
   static constexpr int EPI_BYTES = EPI_ROWS * EPI_PITCH;
   static constexpr int LDS_BYTES = (NSTG * STAGE_BYTES) > EPI_BYTES ? (NSTG * STAGE_BYTES) : EPI_BYTES;
 };
@@ -155,9 +161,9 @@ struct Cfg {
 typedef __attribute__((address_space(3))) void* lds_void_ptr;
 typedef const __attribute__((address_space(1))) void* glb_void_ptr;
 
-template <typename T, int AMODE, int BMODE, int TAPS, int KSUB, int BN, int STRIDE, int WMT>
+template <typename T, int AMODE, int BMODE, int TAPS, int KSUB, int BN, int STRIDE, int WMT, bool DMA>
 __global__ __launch_bounds__(128 * WMT, 2) void gemm_kernel(const GemmArgs p) {   // >= 2 waves per SIMD: <= 256 VGPR+AGPR
-  using C = Cfg<T, AMODE, BMODE, TAPS, KSUB, BN, STRIDE, WMT>;
+  using C = Cfg<T, AMODE, BMODE, TAPS, KSUB, BN, STRIDE, WMT, DMA>;
   constexpr int FN = C::FN;
   constexpr int BM = C::BM, NTHREADS = C::NTHREADS, NW = C::NW;
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -264,12 +270,9 @@ __global__ __launch_bounds__(128 * WMT, 2) void gemm_kernel(const GemmArgs p) { 
     }
     return ok;
   };
-  auto a_src = [&](int c, int k0) __attribute__((always_inline)) -> const T* { long off; const bool ok = a_dec(c, k0, off); return ok ? Ag + off : zeros; };
-  auto b_src = [&](int c, int k0) __attribute__((always_inline)) -> const T* { long off; const bool ok = b_dec(c, k0, off); return ok ? Bg + off : zeros; };
-  // Fast path (every UNet shape): when K is a whole number of stages the source of each DMA chunk moves by a constant
+  // DMA kernels are only launched when K is a whole number of stages: the source of each chunk then moves by a constant
   // per stage, so the decode above runs ONCE per block and the K loop only adds a stride to a saved pointer
-  // (the full decode per stage cost ~7 VALU instructions per MFMA -- PMC: profiles/r01_gemm_pmc.txt).
-  const bool kwhole = ((kend - kbeg) % C::KSTAGE) == 0;
+  // (decoding per stage cost ~7 VALU instructions per MFMA and a very branchy loop body).
   const T* apre[C::USE_DMA ? C::IA : 1]; const T* bpre[C::USE_DMA ? C::IB : 1];
   long astep = 0, bstep = 0;     // elements per stage
   if constexpr (C::USE_DMA) {
@@ -281,19 +284,16 @@ __global__ __launch_bounds__(128 * WMT, 2) void gemm_kernel(const GemmArgs p) { 
     for (int i = 0; i < C::IB; i++) { long off; const bool ok = b_dec((wave + NW * i) * 64 + lane, kbeg, off); bpre[i] = ok ? Bg + off : nullptr; }
   }
   auto issue_stage = [&](int s, int buf) __attribute__((always_inline)) {
-    const int k0 = kbeg + s * C::KSTAGE;
     char* base = smem + buf * C::STAGE_BYTES;
 #pragma unroll
     for (int i = 0; i < C::IA; i++) {
-      const int ins = wave + NW * i;
-      const T* src = kwhole ? (apre[i] ? apre[i] + s * astep : zeros) : a_src(ins * 64 + lane, k0);
-      __builtin_amdgcn_global_load_lds((glb_void_ptr)src, (lds_void_ptr)(base + ins * 1024), 16, 0, 0);
+      const T* src = apre[i] ? apre[i] + s * astep : zeros;
+      __builtin_amdgcn_global_load_lds((glb_void_ptr)src, (lds_void_ptr)(base + (wave + NW * i) * 1024), 16, 0, 0);
     }
 #pragma unroll
     for (int i = 0; i < C::IB; i++) {
-      const int ins = wave + NW * i;
-      const T* src = kwhole ? (bpre[i] ? bpre[i] + s * bstep : zeros) : b_src(ins * 64 + lane, k0);
-      __builtin_amdgcn_global_load_lds((glb_void_ptr)src, (lds_void_ptr)(base + C::A_ALLOC + ins * 1024), 16, 0, 0);
+      const T* src = bpre[i] ? bpre[i] + s * bstep : zeros;
+      __builtin_amdgcn_global_load_lds((glb_void_ptr)src, (lds_void_ptr)(base + C::A_ALLOC + (wave + NW * i) * 1024), 16, 0, 0);
     }
   };
 
@@ -414,7 +414,7 @@ __global__ __launch_bounds__(128 * WMT, 2) void gemm_kernel(const GemmArgs p) { 
 
   // ---- epilogue ---------------------------------------------------------------------
   // acc[i][j][r] = C[m = wm*64 + i*16 + lm][n = wn*(BN/2) + j*16 + q*4 + r] (operands were swapped).
-  // Four passes of 16*WMT rows through an fp32 LDS tile, then 4-wide vector read-modify-store.
+  // 4/EPI_I passes through an fp32 LDS tile, then 4-wide vector read-modify-store.
   char* Cb = (char*)p.C;
   const long cbase = (long)bz * p.sCb + (long)tz * p.sCt;
   constexpr int CH = BN / 4;                      // 4-element chunks per row
@@ -439,17 +439,23 @@ __global__ __launch_bounds__(128 * WMT, 2) void gemm_kernel(const GemmArgs p) { 
       return;
     }
   }
+  // tile row of (wm, i, r16) inside a pass: ((i % EPI_I) * WMT + wm) * 16 + r16
 #pragma unroll
-  for (int i = 0; i < 4; i++) {
+  for (int pass = 0; pass < 4 / C::EPI_I; pass++) {
 #pragma unroll
-    for (int j = 0; j < FN; j++) {
-      if constexpr (AMODE == GA_TR) {
+    for (int ii = 0; ii < C::EPI_I; ii++) {
+      const int i = pass * C::EPI_I + ii;
+      const int trow = (ii * WMT + wm) * 16;
 #pragma unroll
-        for (int r = 0; r < 4; r++)
-          *(float*)(smem + (wm * 16 + q * 4 + r) * C::EPI_PITCH + (wn * (BN / 2) + j * 16 + lm) * 4) = acc[0][i][j][r] * p.alpha;
-      } else {
-        float4 v = make_float4(acc[0][i][j][0] * p.alpha, acc[0][i][j][1] * p.alpha, acc[0][i][j][2] * p.alpha, acc[0][i][j][3] * p.alpha);
-        *(float4*)(smem + (wm * 16 + lm) * C::EPI_PITCH + (wn * (BN / 2) + j * 16 + q * 4) * 4) = v;
+      for (int j = 0; j < FN; j++) {
+        if constexpr (AMODE == GA_TR) {
+#pragma unroll
+          for (int r = 0; r < 4; r++)
+            *(float*)(smem + (trow + q * 4 + r) * C::EPI_PITCH + (wn * (BN / 2) + j * 16 + lm) * 4) = acc[0][i][j][r] * p.alpha;
+        } else {
+          float4 v = make_float4(acc[0][i][j][0] * p.alpha, acc[0][i][j][1] * p.alpha, acc[0][i][j][2] * p.alpha, acc[0][i][j][3] * p.alpha);
+          *(float4*)(smem + (trow + lm) * C::EPI_PITCH + (wn * (BN / 2) + j * 16 + q * 4) * 4) = v;
+        }
       }
     }
     __syncthreads();
@@ -457,52 +463,66 @@ __global__ __launch_bounds__(128 * WMT, 2) void gemm_kernel(const GemmArgs p) { 
       // split-K / accumulate: one float per lane so each wave-instruction hits 256 contiguous bytes
       for (int c = tid; c < C::EPI_ROWS * BN; c += NTHREADS) {
         const int row = c / BN, col = c % BN;
-        const int m = m0 + (row >> 4) * 64 + i * 16 + (row & 15), n = n0 + col;
+        const int g = row >> 4, ii = g / WMT, wmr = g % WMT;
+        const int m = m0 + wmr * 64 + (pass * C::EPI_I + ii) * 16 + (row & 15), n = n0 + col;
         if (m < p.M && n < p.N) atomicAdd((float*)Cb + cbase + (long)m * p.ldc + n, *(const float*)(smem + row * C::EPI_PITCH + col * 4));
       }
-    } else
+    } else {
+      constexpr int NIT = (NCH + NTHREADS - 1) / NTHREADS;
+      // phase 1: issue every global read of the pass (residual, embedding row) -- independent, all in flight together
+      float4 add[NIT];
+      int mm[NIT];
 #pragma unroll
-    for (int cc = 0; cc < (NCH + NTHREADS - 1) / NTHREADS; cc++) {
-      const int c = tid + cc * NTHREADS;
-      if (c < NCH) {
+      for (int cc = 0; cc < NIT; cc++) {
+        const int c = tid + cc * NTHREADS;
         const int row = c / CH, cs = c % CH;
-        const int m = m0 + (row >> 4) * 64 + i * 16 + (row & 15), n = n0 + cs * 4;
-        if (m < p.M && n < p.N) {
-          float4 v = *(const float4*)(smem + row * C::EPI_PITCH + cs * 16);
-          if (p.bias) { const float4 b = *(const float4*)(p.bias + n); v.x += b.x; v.y += b.y; v.z += b.z; v.w += b.w; }
-          if (p.rowvec) {
-            const float4 b = *(const float4*)(p.rowvec + (long)(m / p.rows_per_vec) * p.ld_rowvec + n);
-            v.x += b.x; v.y += b.y; v.z += b.z; v.w += b.w;
-          }
-          const long off = cbase + (long)m * p.ldc + n;
+        const int g = row >> 4, ii = g / WMT, wmr = g % WMT;
+        const int m = m0 + wmr * 64 + (pass * C::EPI_I + ii) * 16 + (row & 15), n = n0 + cs * 4;
+        const bool ok = c < NCH && m < p.M && n < p.N;
+        mm[cc] = ok ? m : -1;
+        float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (ok) {
+          if (p.bias) a = *(const float4*)(p.bias + n);
+          if (p.rowvec) { const float4 b = *(const float4*)(p.rowvec + (long)(m / p.rows_per_vec) * p.ld_rowvec + n); a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w; }
           if (p.resid) {
             const T* rp = (const T*)p.resid + (long)m * p.ldr + n;
-            if constexpr (sizeof(T) == 4) { const float4 b = *(const float4*)rp; v.x += b.x; v.y += b.y; v.z += b.z; v.w += b.w; }
+            if constexpr (sizeof(T) == 4) { const float4 b = *(const float4*)rp; a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w; }
             else {
               const uint2 b = *(const uint2*)rp;
-              v.x += __uint_as_float(b.x << 16); v.y += __uint_as_float(b.x & 0xffff0000u);
-              v.z += __uint_as_float(b.y << 16); v.w += __uint_as_float(b.y & 0xffff0000u);
+              a.x += __uint_as_float(b.x << 16); a.y += __uint_as_float(b.x & 0xffff0000u);
+              a.z += __uint_as_float(b.y << 16); a.w += __uint_as_float(b.y & 0xffff0000u);
             }
           }
-          if (p.out_f32 || sizeof(T) == 4) {
-            *(float4*)((float*)Cb + off) = v;
-          } else {
-            uint2 o;
-            o.x = (unsigned)f32_to_bf16(v.x) | ((unsigned)f32_to_bf16(v.y) << 16);
-            o.y = (unsigned)f32_to_bf16(v.z) | ((unsigned)f32_to_bf16(v.w) << 16);
-            *(uint2*)((bf16_t*)Cb + off) = o;
-          }
+        }
+        add[cc] = a;
+      }
+      // phase 2: LDS tile + addend -> vector store
+#pragma unroll
+      for (int cc = 0; cc < NIT; cc++) {
+        if (mm[cc] < 0) continue;
+        const int c = tid + cc * NTHREADS;
+        const int row = c / CH, cs = c % CH;
+        float4 v = *(const float4*)(smem + row * C::EPI_PITCH + cs * 16);
+        v.x += add[cc].x; v.y += add[cc].y; v.z += add[cc].z; v.w += add[cc].w;
+        const long off = cbase + (long)mm[cc] * p.ldc + n0 + cs * 4;
+        if (p.out_f32 || sizeof(T) == 4) {
+          *(float4*)((float*)Cb + off) = v;
+        } else {
+          uint2 o;
+          o.x = (unsigned)f32_to_bf16(v.x) | ((unsigned)f32_to_bf16(v.y) << 16);
+          o.y = (unsigned)f32_to_bf16(v.z) | ((unsigned)f32_to_bf16(v.w) << 16);
+          *(uint2*)((bf16_t*)Cb + off) = o;
         }
       }
     }
-    __syncthreads();
+    if (pass + 1 < 4 / C::EPI_I) __syncthreads();
   }
 }
 
-template <typename T, int AMODE, int BMODE, int TAPS, int KSUB, int BN, int STRIDE, int WMT>
-int launch_t(eegldm_ctx* ctx, const GemmArgs& a) {
-  using C = Cfg<T, AMODE, BMODE, TAPS, KSUB, BN, STRIDE, WMT>;
-  auto kern = gemm_kernel<T, AMODE, BMODE, TAPS, KSUB, BN, STRIDE, WMT>;
+template <typename T, int AMODE, int BMODE, int TAPS, int KSUB, int BN, int STRIDE, int WMT, bool DMA>
+int launch_k(eegldm_ctx* ctx, const GemmArgs& a) {
+  using C = Cfg<T, AMODE, BMODE, TAPS, KSUB, BN, STRIDE, WMT, DMA>;
+  auto kern = gemm_kernel<T, AMODE, BMODE, TAPS, KSUB, BN, STRIDE, WMT, DMA>;
   static bool attr_set = false;
   static_assert(C::LDS_BYTES <= 160 * 1024, "tile does not fit the 160 KiB LDS");
   if (!attr_set && C::LDS_BYTES > 48 * 1024) {
@@ -514,15 +534,22 @@ int launch_t(eegldm_ctx* ctx, const GemmArgs& a) {
   LAUNCH_CHECK();
   return 0;
 }
+// staging engine: LDS-DMA ring for the 3-tap implicit-conv kernels when every block's K range is a whole number of
+// stages (all production shapes), register staging otherwise (K tails, 1-tap kernels, fused wgrad)
+template <typename T, int AMODE, int BMODE, int TAPS, int KSUB, int BN, int STRIDE, int WMT>
+int launch_t(eegldm_ctx* ctx, const GemmArgs& a) {
+  if constexpr (AMODE == GA_CONV && TAPS == 3) {
+    constexpr int KSTAGE = KSUB * Tr<T>::KC;
+    if (a.K % KSTAGE == 0 && a.splitk == 1) return launch_k<T, AMODE, BMODE, TAPS, KSUB, BN, STRIDE, WMT, true>(ctx, a);
+  }
+  return launch_k<T, AMODE, BMODE, TAPS, KSUB, BN, STRIDE, WMT, false>(ctx, a);
+}
 
-// tile selection.  The 256-row / 8-wave / 3-deep-ring variant (WMT = 4) is kept compiled but measured no faster
-// than 128-row blocks at 2 blocks per CU on the UNet's shapes (profiles/r01_gemm_tile_sweep.txt), so it is opt-in
-// (EEGLDM_GEMM_BIG_TILES=1) until the LDS-read / MFMA interleave is hand-scheduled.
+// tile selection.  The 256-row / 8-wave variant (WMT = 4) is kept compiled but measured no faster than 128-row blocks
+// at 2 blocks per CU on the UNet's shapes (profiles/r01_gemm_tile_sweep.txt), so it is opt-in (EEGLDM_GEMM_BIG_TILES=1).
 template <typename T, int AMODE, int BMODE, int TAPS, int KSUB, int STRIDE>
 int launch_bn(eegldm_ctx* ctx, const GemmArgs& a) {
   static const bool big_ok = getenv("EEGLDM_GEMM_BIG_TILES") != nullptr;
-  static const int bn64_maxk = getenv("EEGLDM_GEMM_BN64_MAXK") ? atoi(getenv("EEGLDM_GEMM_BN64_MAXK")) : 0;
-  if (a.N > 64 && a.K <= bn64_maxk) return launch_t<T, AMODE, BMODE, TAPS, KSUB, 64, STRIDE, 2>(ctx, a);
   const bool big = big_ok && a.M >= 256 && !(AMODE == GA_CONV && STRIDE == 2);
   if (a.N > 64) return big ? launch_t<T, AMODE, BMODE, TAPS, KSUB, 128, STRIDE, 4>(ctx, a) : launch_t<T, AMODE, BMODE, TAPS, KSUB, 128, STRIDE, 2>(ctx, a);
   if (a.N > 32) return launch_t<T, AMODE, BMODE, TAPS, KSUB, 64, STRIDE, 2>(ctx, a);
@@ -534,12 +561,6 @@ int launch_modes(eegldm_ctx* ctx, const GemmArgs& a) {
   if (a.amode == GA_CONV) {
     EEG_CHECK(a.batch == 1, "conv mode expects flattened rows (batch=1)");
     EEG_CHECK(a.Lin == a.Lout * a.stride, "conv mode needs Lin == Lout*stride (got %d, %d, %d)", a.Lin, a.Lout, a.stride);
-    static const int conv_variant = getenv("EEGLDM_CONV_VARIANT") ? atoi(getenv("EEGLDM_CONV_VARIANT")) : 0;
-    if (conv_variant == 1 && a.taps == 3 && a.stride == 1 && a.N > 32 && a.M >= 256) {
-      // experiment: 256 x 64 tiles, 8 waves, K stage of 64 channels = 128-byte rows (full-line L2 requests)
-      if (a.bmode == GB_NT) return launch_t<T, GA_CONV, GB_NT, 3, 2, 64, 1, 4>(ctx, a);
-      return launch_t<T, GA_CONV, GB_TR, 3, 2, 64, 1, 4>(ctx, a);
-    }
     if (a.bmode == GB_NT) {
       if (a.taps == 3 && a.stride == 1) return launch_bn<T, GA_CONV, GB_NT, 3, 1, 1>(ctx, a);
       if (a.taps == 3 && a.stride == 2) return launch_bn<T, GA_CONV, GB_NT, 3, 1, 2>(ctx, a);
