@@ -24,6 +24,7 @@ extern "C" int eegldm_ctx_create(int device, void* stream, int own_stream, eegld
   else { c->stream = (hipStream_t)stream; c->owns_stream = false; }
   c->scratch_bytes = 8u << 20;
   HIP_TRY(hipMalloc(&c->scratch, c->scratch_bytes));
+  HIP_TRY(hipMemset(c->scratch, 0, c->scratch_bytes));   // reduction scratch is self-cleaning: kernels re-zero what they consume
   HIP_TRY(hipMalloc(&c->zero_page, 4096));
   HIP_TRY(hipMemset(c->zero_page, 0, 4096));
   *out = c;

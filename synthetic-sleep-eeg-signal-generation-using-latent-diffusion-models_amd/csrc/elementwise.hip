@@ -166,13 +166,27 @@ __global__ __launch_bounds__(NT) void softmax_bwd_kernel(const float* __restrict
   }
 }
 
-// dst[r][c] += src[r][c] (both T, own leading dims)
+// dst[r][c] += src[r][c] (both T, own leading dims); 4-channel vectors, 2-D grid (no per-element division)
 template <typename T>
 __global__ void add_rows_kernel(T* __restrict__ dst, long ldd, const T* __restrict__ src, long lds, long rows, int C) {
-  GRID_STRIDE(i, rows * C) {
-    const long r = i / C; const int c = (int)(i - r * C);
-    T* d = dst + r * ldd + c;
-    st_f32(d, ld_f32(d) + ld_f32(src + r * lds + c));
+  const int nc = C / 4;
+  for (long r = blockIdx.x; r < rows; r += gridDim.x) {
+    for (int cv = threadIdx.x; cv < nc; cv += blockDim.x) {
+      T* d = dst + r * ldd + cv * 4; const T* sp = src + r * lds + cv * 4;
+      if constexpr (sizeof(T) == 2) {
+        const uint2 a = *(const uint2*)d, b = *(const uint2*)sp;
+        uint2 o;
+        o.x = (unsigned)f32_to_bf16(__uint_as_float(a.x << 16) + __uint_as_float(b.x << 16)) |
+              ((unsigned)f32_to_bf16(__uint_as_float(a.x & 0xffff0000u) + __uint_as_float(b.x & 0xffff0000u)) << 16);
+        o.y = (unsigned)f32_to_bf16(__uint_as_float(a.y << 16) + __uint_as_float(b.y << 16)) |
+              ((unsigned)f32_to_bf16(__uint_as_float(a.y & 0xffff0000u) + __uint_as_float(b.y & 0xffff0000u)) << 16);
+        *(uint2*)d = o;
+      } else {
+        float4 a = *(const float4*)d; const float4 b = *(const float4*)sp;
+        a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w; *(float4*)d = a;
+      }
+    }
+    for (int c = nc * 4 + threadIdx.x; c < C; c += blockDim.x) { T* d = dst + r * ldd + c; st_f32(d, ld_f32(d) + ld_f32(src + r * lds + c)); }
   }
 }
 template <typename T>
@@ -316,7 +330,9 @@ int ew_softmax_bwd(eegldm_ctx* ctx, const float* dP, const void* P, void* dS, lo
   LAUNCH_CHECK(); return 0;
 }
 int ew_add_rows(eegldm_ctx* ctx, void* dst, long ldd, const void* src, long lds, long rows, int C, int dtype) {
-  DISPATCH_T(dtype, hipLaunchKernelGGL((add_rows_kernel<T>), dim3(grid1d(rows * C, ctx)), dim3(NT), 0, ctx->stream, (T*)dst, ldd, (const T*)src, lds, rows, C));
+  EEG_CHECK(ldd % 4 == 0 && lds % 4 == 0, "add_rows: leading dimensions must be multiples of 4");
+  const long cap = (long)ctx->num_cu * 32;
+  DISPATCH_T(dtype, hipLaunchKernelGGL((add_rows_kernel<T>), dim3((unsigned)(rows < cap ? rows : cap)), dim3(C >= 512 ? 128 : 64), 0, ctx->stream, (T*)dst, ldd, (const T*)src, lds, rows, C));
   LAUNCH_CHECK(); return 0;
 }
 int ew_copy_rows(eegldm_ctx* ctx, void* dst, long ldd, const void* src, long lds, long rows, int C, int dtype) {

@@ -213,8 +213,8 @@ int ls_bn_lrelu_fwd(eegldm_ctx* ctx, const void* x, long ldx, const float* gamma
                     float* nbt, void* y, long ldy, long rows, int C, float slope, int training, int dtype) {
   if (gamma) {
     if (training) {
-      double* sums = (double*)ctx->scratch;
-      EEG_CHECK((size_t)C * 2 * sizeof(double) <= ctx->scratch_bytes, "scratch too small");
+      double* sums = (double*)((char*)ctx->scratch + (2u << 20));   // BatchNorm region of the context scratch (GroupNorm owns [0, 1 MiB) self-cleaning)
+      EEG_CHECK((size_t)C * 2 * sizeof(double) <= (1u << 20), "scratch too small");
       HIP_TRY(hipMemsetAsync(sums, 0, sizeof(double) * 2 * C, ctx->stream));
       int rs; long rpb; pick_rsplit(rows, C, ctx, &rs, &rpb);
       DISPATCH_T(dtype, hipLaunchKernelGGL((bn_stats_kernel<T>), dim3((C + 63) / 64, rs), dim3(NT), 0, ctx->stream, (const T*)x, ldx, sums, rows, C, rpb));
@@ -233,7 +233,7 @@ int ls_bn_lrelu_fwd(eegldm_ctx* ctx, const void* x, long ldx, const float* gamma
 }
 int ls_bn_lrelu_bwd(eegldm_ctx* ctx, const void* x, long ldx, const float* gamma, const float* beta, const float* stats, const void* dy, long lddy,
                     void* dx, long lddx, float* dgamma, float* dbeta, long rows, int C, float slope, int dtype) {
-  double* sums = (double*)ctx->scratch;
+  double* sums = (double*)((char*)ctx->scratch + (2u << 20));
   if (gamma) {
     HIP_TRY(hipMemsetAsync(sums, 0, sizeof(double) * 2 * C, ctx->stream));
     int rs; long rpb; pick_rsplit(rows, C, ctx, &rs, &rpb);

@@ -87,11 +87,13 @@ __global__ __launch_bounds__(NT) void gn_stats_kernel(const T* __restrict__ x, l
   for (int i = tid; i < 2 * G; i += NT) atomicAdd(&sums[(long)b * G * 2 + i], (double)acc[i]);
 }
 
-__global__ void gn_finalize_kernel(const double* __restrict__ sums, float* __restrict__ stats, int BG, double n, float eps) {
+// (self-cleaning: the accumulators are zeroed again for the next GroupNorm, so no memset launches are needed)
+__global__ void gn_finalize_kernel(double* __restrict__ sums, float* __restrict__ stats, int BG, double n, float eps) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= BG) return;
   const double mean = sums[2 * i] / n;
   double var = sums[2 * i + 1] / n - mean * mean;
+  sums[2 * i] = 0.0; sums[2 * i + 1] = 0.0;
   if (var < 0) var = 0;
   stats[2 * i] = (float)mean;
   stats[2 * i + 1] = (float)(1.0 / sqrt(var + (double)eps));
@@ -232,11 +234,14 @@ __global__ __launch_bounds__(NT) void gn_bwd_reduce_kernel(const T* __restrict__
   }
 }
 
-__global__ void gn_slot_reduce_kernel(const float* __restrict__ slots, float* __restrict__ dgamma, float* __restrict__ dbeta, int C) {
+// runs AFTER the backward apply kernel: folds the slots into dgamma/dbeta and re-zeroes slots and group sums
+__global__ void gn_slot_reduce_kernel(float* __restrict__ slots, float* __restrict__ dgamma, float* __restrict__ dbeta, int C,
+                                      double* __restrict__ gsums, int n_gsums) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= 2 * C) return;
+  for (int k = i; k < n_gsums; k += gridDim.x * blockDim.x) gsums[k] = 0.0;
+  if (i >= 2 * C || !slots) return;
   float s = 0.f;
-  for (int k = 0; k < GN_NSLOT; k++) s += slots[(size_t)k * 2 * C + i];
+  for (int k = 0; k < GN_NSLOT; k++) { s += slots[(size_t)k * 2 * C + i]; slots[(size_t)k * 2 * C + i] = 0.f; }
   if (i < C) dgamma[i] += s; else dbeta[i - C] += s;
 }
 
@@ -304,8 +309,7 @@ int pick_lsplit(int B, int L, int C, eegldm_ctx* ctx, int* rows_per_block, int p
 template <typename T, int V>
 int gn_fwd_t(eegldm_ctx* ctx, const void* x, long ldx, const float* gamma, const float* beta, void* y, long ldy,
              float* stats, int B, int L, int C, int G, float eps, int silu, int resample, void* xr, long ldxr) {
-  double* sums = (double*)ctx->scratch;
-  HIP_TRY(hipMemsetAsync(sums, 0, sizeof(double) * 2 * B * G, ctx->stream));
+  double* sums = (double*)ctx->scratch;      // zero on entry (context creation / previous finalize)
   int rpb; int ls = pick_lsplit(B, L, C, ctx, &rpb);
   hipLaunchKernelGGL((gn_stats_kernel<T, V>), dim3(ls, B), dim3(NT), 0, ctx->stream, (const T*)x, ldx, sums, L, C, G, rpb);
   LAUNCH_CHECK();
@@ -323,21 +327,18 @@ template <typename T, int V>
 int gn_bwd_t(eegldm_ctx* ctx, const void* x, long ldx, const float* gamma, const float* beta, const float* stats,
              const void* dy, long lddy, void* dx, long lddx, float* dgamma, float* dbeta, int B, int L, int C, int G,
              int silu, int resample, const void* dxr, long lddxr) {
-  double* gsums = (double*)ctx->scratch;
-  HIP_TRY(hipMemsetAsync(gsums, 0, sizeof(double) * 2 * B * G, ctx->stream));
+  double* gsums = (double*)ctx->scratch;     // zero on entry; shared with the forward sums (stream-ordered)
   int rpb; int ls = pick_lsplit(B, L, C, ctx, &rpb);
   float* slots = dgamma ? (float*)((char*)ctx->scratch + GN_SLOT_OFFSET) : nullptr;
-  if (slots) HIP_TRY(hipMemsetAsync(slots, 0, sizeof(float) * GN_NSLOT * 2 * C, ctx->stream));
   hipLaunchKernelGGL((gn_bwd_reduce_kernel<T, V>), dim3(ls, B), dim3(NT), 0, ctx->stream, (const T*)x, ldx, gamma, beta, stats,
                      (const T*)dy, lddy, gsums, slots, L, C, G, silu, resample, rpb);
   LAUNCH_CHECK();
-  if (slots) {
-    hipLaunchKernelGGL(gn_slot_reduce_kernel, dim3((2 * C + 255) / 256), dim3(256), 0, ctx->stream, slots, dgamma, dbeta, C);
-    LAUNCH_CHECK();
-  }
   int rpb2; int ls2 = pick_lsplit(B, L, C, ctx, &rpb2, 16, 8);
   hipLaunchKernelGGL((gn_bwd_apply_kernel<T, V>), dim3(ls2, B), dim3(NT), 0, ctx->stream, (const T*)x, ldx, gamma,
                      beta, stats, (const T*)dy, lddy, gsums, (T*)dx, lddx, (const T*)dxr, lddxr, L, C, G, silu, resample, rpb2);
+  LAUNCH_CHECK();
+  const int n_gs = 2 * B * G;
+  hipLaunchKernelGGL(gn_slot_reduce_kernel, dim3(((2 * C > n_gs ? 2 * C : n_gs) + 255) / 256), dim3(256), 0, ctx->stream, slots, dgamma, dbeta, C, gsums, n_gs);
   LAUNCH_CHECK();
   return 0;
 }
