@@ -16,6 +16,12 @@ $(CSRC)/build/%.o: $(CSRC)/%.hip $(wildcard $(CSRC)/*.h) include/eegldm.h
 $(LIB): $(OBJS)
 	$(HIPCC) --offload-arch=gfx950 -shared -fPIC $(OBJS) -o $@
 
+# developer build with per-stage cycle stamps in the GEMM kernels (tools/debug/stage_timing.py)
+dbg:
+	@mkdir -p $(CSRC)/build_dbg
+	for f in $(SRCS); do $(HIPCC) $(FLAGS) -DEEG_STAGE_TIMING -c $$f -o $(CSRC)/build_dbg/$$(basename $$f .hip).o || exit 1; done
+	$(HIPCC) --offload-arch=gfx950 -shared -fPIC $(CSRC)/build_dbg/*.o -o tools/debug/libeegldm_dbg.so
+
 clean:
-	rm -rf $(CSRC)/build $(LIB)
-.PHONY: all clean
+	rm -rf $(CSRC)/build $(CSRC)/build_dbg $(LIB)
+.PHONY: all clean dbg

@@ -25,8 +25,13 @@ extern "C" int eegldm_ctx_create(int device, void* stream, int own_stream, eegld
   c->scratch_bytes = 8u << 20;
   HIP_TRY(hipMalloc(&c->scratch, c->scratch_bytes));
   HIP_TRY(hipMemset(c->scratch, 0, c->scratch_bytes));   // reduction scratch is self-cleaning: kernels re-zero what they consume
-  HIP_TRY(hipMalloc(&c->zero_page, 4096));
-  HIP_TRY(hipMemset(c->zero_page, 0, 4096));
+#ifdef EEG_STAGE_TIMING
+  const size_t zp_bytes = 64u << 20;     // debug build: the area behind the zero page receives per-block stage timestamps
+#else
+  const size_t zp_bytes = 4096;
+#endif
+  HIP_TRY(hipMalloc(&c->zero_page, zp_bytes));
+  HIP_TRY(hipMemset(c->zero_page, 0, zp_bytes));
   *out = c;
   return 0;
 }
@@ -94,3 +99,12 @@ extern "C" int eegldm_prof_dump(eegldm_ctx* c, const char* path_host) {
   fclose(f);
   return 0;
 }
+
+#ifdef EEG_STAGE_TIMING
+extern "C" int eegldm_debug_read_tlog(eegldm_ctx* c, unsigned long long* dst_host, long n_words) {
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  HIP_TRY(hipMemcpy(dst_host, (char*)c->zero_page + 4096, n_words * 8, hipMemcpyDeviceToHost));
+  HIP_TRY(hipMemset((char*)c->zero_page + 4096, 0, n_words * 8));
+  return 0;
+}
+#endif

@@ -54,12 +54,14 @@ static inline size_t dtype_size(int dt) { return dt == EEGLDM_F32 ? 4 : 2; }
 
 // ---------------------------------------------------------------- device helpers
 __device__ __forceinline__ float bf16_to_f32(bf16_t v) { return __uint_as_float(((unsigned)v) << 16); }
-__device__ __forceinline__ bf16_t f32_to_bf16(float f) {  // round-to-nearest-even, NaN preserved
-  unsigned u = __float_as_uint(f);
-  if ((u & 0x7fffffffu) > 0x7f800000u) return (bf16_t)((u >> 16) | 0x40);
-  u += 0x7fffu + ((u >> 16) & 1u);
-  return (bf16_t)(u >> 16);
+// gfx950 has a hardware fp32 -> packed bf16 conversion (round-to-nearest-even, NaN stays NaN): one VALU op for two values
+// instead of the ~10-instruction exec-masked software sequence.
+__device__ __forceinline__ unsigned pack_bf16x2(float lo, float hi) {
+  unsigned r;
+  asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(lo), "v"(hi));
+  return r;
 }
+__device__ __forceinline__ bf16_t f32_to_bf16(float f) { return (bf16_t)(pack_bf16x2(f, f) & 0xffffu); }
 template <typename T> __device__ __forceinline__ float ld_f32(const T* p);
 template <> __device__ __forceinline__ float ld_f32<float>(const float* p) { return *p; }
 template <> __device__ __forceinline__ float ld_f32<bf16_t>(const bf16_t* p) { return bf16_to_f32(*p); }

@@ -176,10 +176,8 @@ __global__ void add_rows_kernel(T* __restrict__ dst, long ldd, const T* __restri
       if constexpr (sizeof(T) == 2) {
         const uint2 a = *(const uint2*)d, b = *(const uint2*)sp;
         uint2 o;
-        o.x = (unsigned)f32_to_bf16(__uint_as_float(a.x << 16) + __uint_as_float(b.x << 16)) |
-              ((unsigned)f32_to_bf16(__uint_as_float(a.x & 0xffff0000u) + __uint_as_float(b.x & 0xffff0000u)) << 16);
-        o.y = (unsigned)f32_to_bf16(__uint_as_float(a.y << 16) + __uint_as_float(b.y << 16)) |
-              ((unsigned)f32_to_bf16(__uint_as_float(a.y & 0xffff0000u) + __uint_as_float(b.y & 0xffff0000u)) << 16);
+        o.x = pack_bf16x2(__uint_as_float(a.x << 16) + __uint_as_float(b.x << 16), __uint_as_float(a.x & 0xffff0000u) + __uint_as_float(b.x & 0xffff0000u));
+        o.y = pack_bf16x2(__uint_as_float(a.y << 16) + __uint_as_float(b.y << 16), __uint_as_float(a.y & 0xffff0000u) + __uint_as_float(b.y & 0xffff0000u));
         *(uint2*)d = o;
       } else {
         float4 a = *(const float4*)d; const float4 b = *(const float4*)sp;

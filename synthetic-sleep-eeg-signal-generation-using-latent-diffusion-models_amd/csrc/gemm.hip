@@ -354,6 +354,14 @@ __global__ __launch_bounds__(128 * WMT, 2) void gemm_kernel(const GemmArgs p) { 
   } else {
     load_stage(0);
   }
+#ifdef EEG_STAGE_TIMING
+  unsigned long long* tlog = (unsigned long long*)p.zero_page + 512 + (blockIdx.y * gridDim.x + blockIdx.x) * 64;   // debug only
+  int tl = 0;
+#define TSTAMP() do { if (tid == 0 && tl < 64) tlog[tl++] = __builtin_readcyclecounter(); } while (0)
+#else
+#define TSTAMP() do {} while (0)
+#endif
+  TSTAMP();
   for (int s = 0; s < nstages; s++) {
     if constexpr (!C::USE_DMA) {
       store_stage();
@@ -370,6 +378,7 @@ __global__ __launch_bounds__(128 * WMT, 2) void gemm_kernel(const GemmArgs p) { 
       __syncthreads();
       if (s + 1 < nstages) issue_stage(s + 1, (s + 1) & 1);
     }
+    TSTAMP();   // after wait+barrier(+issue of the next stage)
     const char* smA = smem + (s % C::NSTG) * C::STAGE_BYTES;
     const char* smB = smA + C::A_ALLOC;
 #pragma unroll
@@ -408,10 +417,12 @@ __global__ __launch_bounds__(128 * WMT, 2) void gemm_kernel(const GemmArgs p) { 
           }
       }
     }
+    TSTAMP();   // after the MFMA phase of stage s
     if constexpr (!C::USE_DMA) __syncthreads();   // single buffer: reads of stage s done before stage s+1 is written
   }
   if constexpr (C::USE_DMA) __syncthreads();       // all waves done with the staging buffers before the epilogue tile reuses them
 
+  TSTAMP();   // start of epilogue
   // ---- epilogue ---------------------------------------------------------------------
   // acc[i][j][r] = C[m = wm*64 + i*16 + lm][n = wn*(BN/2) + j*16 + q*4 + r] (operands were swapped).
   // 4/EPI_I passes through an fp32 LDS tile, then 4-wide vector read-modify-store.
@@ -458,7 +469,9 @@ __global__ __launch_bounds__(128 * WMT, 2) void gemm_kernel(const GemmArgs p) { 
         }
       }
     }
+    TSTAMP();   // E1: LDS tile written
     __syncthreads();
+    TSTAMP();   // E2: barrier
     if (p.atomic_out) {
       // split-K / accumulate: one float per lane so each wave-instruction hits 256 contiguous bytes
       for (int c = tid; c < C::EPI_ROWS * BN; c += NTHREADS) {
@@ -468,55 +481,92 @@ __global__ __launch_bounds__(128 * WMT, 2) void gemm_kernel(const GemmArgs p) { 
         if (m < p.M && n < p.N) atomicAdd((float*)Cb + cbase + (long)m * p.ldc + n, *(const float*)(smem + row * C::EPI_PITCH + col * 4));
       }
     } else {
-      constexpr int NIT = (NCH + NTHREADS - 1) / NTHREADS;
-      // phase 1: issue every global read of the pass (residual, embedding row) -- independent, all in flight together
-      float4 add[NIT];
+      // Every thread owns one 4-column chunk (cs) of rows r0, r0+RSTEP, ...  All global reads of the pass are issued
+      // back to back from clamped (always legal) addresses, then all LDS reads, then the stores: no per-row waits.
+      static_assert(NTHREADS % CH == 0, "column chunk must be loop invariant");
+      constexpr int RSTEP = NTHREADS / CH;
+      constexpr int NIT = (C::EPI_ROWS + RSTEP - 1) / RSTEP;
+      const int cs = tid % CH, r0 = tid / CH;
+      const int n = n0 + cs * 4;
+      const bool nok = n < p.N;
+      const int nc = nok ? n : 0;
       int mm[NIT];
+      float4 add[NIT];
+      float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (p.bias) bv = *(const float4*)(p.bias + nc);
 #pragma unroll
       for (int cc = 0; cc < NIT; cc++) {
-        const int c = tid + cc * NTHREADS;
-        const int row = c / CH, cs = c % CH;
+        const int row = r0 + cc * RSTEP;
         const int g = row >> 4, ii = g / WMT, wmr = g % WMT;
-        const int m = m0 + wmr * 64 + (pass * C::EPI_I + ii) * 16 + (row & 15), n = n0 + cs * 4;
-        const bool ok = c < NCH && m < p.M && n < p.N;
-        mm[cc] = ok ? m : -1;
-        float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (ok) {
-          if (p.bias) a = *(const float4*)(p.bias + n);
-          if (p.rowvec) { const float4 b = *(const float4*)(p.rowvec + (long)(m / p.rows_per_vec) * p.ld_rowvec + n); a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w; }
-          if (p.resid) {
-            const T* rp = (const T*)p.resid + (long)m * p.ldr + n;
-            if constexpr (sizeof(T) == 4) { const float4 b = *(const float4*)rp; a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w; }
-            else {
-              const uint2 b = *(const uint2*)rp;
-              a.x += __uint_as_float(b.x << 16); a.y += __uint_as_float(b.x & 0xffff0000u);
-              a.z += __uint_as_float(b.y << 16); a.w += __uint_as_float(b.y & 0xffff0000u);
-            }
+        const int m = m0 + wmr * 64 + (pass * C::EPI_I + ii) * 16 + (row & 15);
+        mm[cc] = (row < C::EPI_ROWS && nok && m < p.M) ? m : -1;
+        add[cc] = bv;
+      }
+      if (p.rowvec) {
+        // sample index of a row: the tile spans < 2 samples when rows_per_vec >= tile rows (one compare), else divide
+        const int s0 = m0 / p.rows_per_vec;
+        const int bnd = (s0 + 1) * p.rows_per_vec;
+        const bool fast = p.rows_per_vec >= BM;
+#pragma unroll
+        for (int cc = 0; cc < NIT; cc++) {
+          const int mc = mm[cc] < 0 ? m0 : mm[cc];
+          const int sidx = fast ? s0 + (mc >= bnd ? 1 : 0) : mc / p.rows_per_vec;
+          const float4 b = *(const float4*)(p.rowvec + (long)sidx * p.ld_rowvec + nc);
+          add[cc].x += b.x; add[cc].y += b.y; add[cc].z += b.z; add[cc].w += b.w;
+        }
+      }
+      if (p.resid) {
+        if constexpr (sizeof(T) == 4) {
+          float4 rv[NIT];
+#pragma unroll
+          for (int cc = 0; cc < NIT; cc++) rv[cc] = *(const float4*)((const T*)p.resid + (long)(mm[cc] < 0 ? m0 : mm[cc]) * p.ldr + nc);
+#pragma unroll
+          for (int cc = 0; cc < NIT; cc++) { add[cc].x += rv[cc].x; add[cc].y += rv[cc].y; add[cc].z += rv[cc].z; add[cc].w += rv[cc].w; }
+        } else {
+          uint2 rv[NIT];
+#pragma unroll
+          for (int cc = 0; cc < NIT; cc++) rv[cc] = *(const uint2*)((const T*)p.resid + (long)(mm[cc] < 0 ? m0 : mm[cc]) * p.ldr + nc);
+#pragma unroll
+          for (int cc = 0; cc < NIT; cc++) {
+            add[cc].x += __uint_as_float(rv[cc].x << 16); add[cc].y += __uint_as_float(rv[cc].x & 0xffff0000u);
+            add[cc].z += __uint_as_float(rv[cc].y << 16); add[cc].w += __uint_as_float(rv[cc].y & 0xffff0000u);
           }
         }
-        add[cc] = a;
       }
-      // phase 2: LDS tile + addend -> vector store
+      TSTAMP();   // E3: global reads issued
+#ifdef EEG_STAGE_TIMING
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      TSTAMP();   // E4: global reads landed
+#endif
+      float4 v[NIT];
 #pragma unroll
       for (int cc = 0; cc < NIT; cc++) {
-        if (mm[cc] < 0) continue;
-        const int c = tid + cc * NTHREADS;
-        const int row = c / CH, cs = c % CH;
-        float4 v = *(const float4*)(smem + row * C::EPI_PITCH + cs * 16);
-        v.x += add[cc].x; v.y += add[cc].y; v.z += add[cc].z; v.w += add[cc].w;
-        const long off = cbase + (long)mm[cc] * p.ldc + n0 + cs * 4;
-        if (p.out_f32 || sizeof(T) == 4) {
-          *(float4*)((float*)Cb + off) = v;
-        } else {
-          uint2 o;
-          o.x = (unsigned)f32_to_bf16(v.x) | ((unsigned)f32_to_bf16(v.y) << 16);
-          o.y = (unsigned)f32_to_bf16(v.z) | ((unsigned)f32_to_bf16(v.w) << 16);
-          *(uint2*)((bf16_t*)Cb + off) = o;
-        }
+        const int row = r0 + cc * RSTEP;
+        v[cc] = *(const float4*)(smem + (row < C::EPI_ROWS ? row : 0) * C::EPI_PITCH + cs * 16);
+        v[cc].x += add[cc].x; v[cc].y += add[cc].y; v[cc].z += add[cc].z; v[cc].w += add[cc].w;
+      }
+      if (p.out_f32 || sizeof(T) == 4) {
+#pragma unroll
+        for (int cc = 0; cc < NIT; cc++)
+          if (mm[cc] >= 0) *(float4*)((float*)Cb + cbase + (long)mm[cc] * p.ldc + n) = v[cc];
+      } else {
+#pragma unroll
+        for (int cc = 0; cc < NIT; cc++)
+          if (mm[cc] >= 0) {
+            uint2 o;
+            o.x = pack_bf16x2(v[cc].x, v[cc].y);
+            o.y = pack_bf16x2(v[cc].z, v[cc].w);
+            *(uint2*)((bf16_t*)Cb + cbase + (long)mm[cc] * p.ldc + n) = o;
+          }
       }
     }
     if (pass + 1 < 4 / C::EPI_I) __syncthreads();
   }
+  TSTAMP();   // E5: stores issued
+#ifdef EEG_STAGE_TIMING
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  TSTAMP();   // E6: stores retired
+#endif
 }
 
 template <typename T, int AMODE, int BMODE, int TAPS, int KSUB, int BN, int STRIDE, int WMT, bool DMA>

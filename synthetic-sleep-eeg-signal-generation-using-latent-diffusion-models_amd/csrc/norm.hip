@@ -35,8 +35,8 @@ template <> __device__ __forceinline__ void store4<float>(float* p, const float 
 }
 template <> __device__ __forceinline__ void store4<bf16_t>(bf16_t* p, const float v[4]) {
   uint2 t;
-  t.x = (unsigned)f32_to_bf16(v[0]) | ((unsigned)f32_to_bf16(v[1]) << 16);
-  t.y = (unsigned)f32_to_bf16(v[2]) | ((unsigned)f32_to_bf16(v[3]) << 16);
+  t.x = pack_bf16x2(v[0], v[1]);
+  t.y = pack_bf16x2(v[2], v[3]);
   *(uint2*)p = t;
 }
 template <typename T, int V> __device__ __forceinline__ void loadv(const T* p, float v[V]) {

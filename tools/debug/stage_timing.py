@@ -1,0 +1,35 @@
+"""Developer tool: per-stage timeline of the conv kernel from an instrumented build (-DEEG_STAGE_TIMING)."""
+import ctypes as C, os, sys, numpy as np, torch
+HERE = os.path.dirname(os.path.abspath(__file__))
+os.environ["EEGLDM_LIB"] = os.path.join(HERE, "libeegldm_dbg.so")
+sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
+import eegldm
+from eegldm._lib import lib, ptr, check
+ctx = eegldm.default_context(0)
+B, L = 256, 192
+for (ci, co, k) in [(512, 512, 3), (128, 128, 3), (512, 512, 1)]:
+    if ci == 128: L = 768
+    else: L = 192
+    R = B * L
+    x = torch.randn(R, ci, device="cuda").bfloat16(); w = (torch.randn(k, co, ci, device="cuda") * 0.05).bfloat16(); b = torch.zeros(co, device="cuda")
+    y = torch.empty(R, co, device="cuda", dtype=torch.bfloat16)
+    nblk = (R // 128) * (co // 128)
+    buf = np.zeros(nblk * 64, dtype=np.uint64)
+    pad = 1 if k == 3 else 0
+    for _ in range(3):
+        check(lib.eegldm_conv1d_fwd(ctx.h, ptr(x), ci, ptr(w), ptr(b), ptr(y), co, B, L, ci, co, k, 1, pad, pad, None, 0, None, 0, 1))
+        lib.eegldm_debug_read_tlog(ctx.h, buf.ctypes.data_as(C.c_void_p), C.c_long(buf.size))
+    t = buf.reshape(nblk, 64).astype(np.int64)
+    nst = ci // (32 if k == 3 else 64)
+    # stamps: [0]=before loop, then per stage: after barrier/issue, after mfma ; then epilogue start, end
+    d = np.diff(t[:, :2 * nst + 8], axis=1)
+    wait = d[:, 0:2 * nst:2]      # before-loop/prev-mfma -> after barrier+issue
+    mfma = d[:, 1:2 * nst:2]
+    pro = d[:, 0]
+    e = d[:, 2 * nst:]            # [sync->epi start, E1 lds written, E2 barrier, E3 reads issued, E4 reads landed, E5 stores issued, E6 stores retired]
+    med = lambda a: float(np.median(a))
+    print(f"conv k{k} {ci}->{co} L={L}: blocks {nblk}, stages {nst}; values in shader cycles")
+    print(f"  first wait {med(pro):.0f}; per-stage wait {med(wait[:,1:]):.0f} (p90 {np.percentile(wait[:,1:],90):.0f}); per-stage MFMA phase {med(mfma):.0f} (p90 {np.percentile(mfma,90):.0f})")
+    names = ["final sync", "LDS tile written", "barrier", "global reads issued", "global reads landed", "LDS read + stores issued", "stores retired"]
+    for n, c in zip(names, e.T): print(f"  epilogue {n:26s} {med(c):8.0f}  (p90 {np.percentile(c,90):.0f})")
+    print(f"  block total {med(t[:,2*nst+8]-t[:,0]):.0f}")
