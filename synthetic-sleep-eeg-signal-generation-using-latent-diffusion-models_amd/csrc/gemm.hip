@@ -275,16 +275,40 @@ __global__ __launch_bounds__(128 * WMT, 2) void gemm_kernel(const GemmArgs p) { 
   // (decoding per stage cost ~7 VALU instructions per MFMA and a very branchy loop body).
   const T* apre[C::USE_DMA ? C::IA : 1]; const T* bpre[C::USE_DMA ? C::IB : 1];
   long astep = 0, bstep = 0;     // elements per stage
+  unsigned btop = 0, bbot = 0;   // WG3: bit i set -> this lane's chunk of B instruction i lies in the top / bottom halo row
   if constexpr (C::USE_DMA) {
-    astep = C::KSTAGE;                                       // A is K-contiguous in the conv modes
+    astep = (AMODE == GA_TR) ? (long)C::KSTAGE * p.lda : (long)C::KSTAGE;   // conv / plain A is K-contiguous, TR A is K-strided
     bstep = (BMODE == GB_NT) ? (long)C::KSTAGE : (long)C::KSTAGE * p.ldb;
 #pragma unroll
     for (int i = 0; i < C::IA; i++) { long off; const bool ok = a_dec((wave + NW * i) * 64 + lane, kbeg, off); apre[i] = ok ? Ag + off : nullptr; }
 #pragma unroll
-    for (int i = 0; i < C::IB; i++) { long off; const bool ok = b_dec((wave + NW * i) * 64 + lane, kbeg, off); bpre[i] = ok ? Bg + off : nullptr; }
+    for (int i = 0; i < C::IB; i++) {
+      const int c = (wave + NW * i) * 64 + lane;
+      if constexpr (C::WG3) {
+        // halo rows are valid or zero depending on the stage (sample boundary), so only the static part is decoded here
+        constexpr int RCP = C::PITCH_B_TR / 16;
+        const int krow = c / RCP, cs = c % RCP;
+        int seg = cs; bool ok = c < C::B_CHUNKS;
+        if constexpr (sizeof(T) == 4) ok = ok && cs < BN / 4;
+        else seg = tr_swz<BN>(krow, cs * 16) >> 4;
+        const int n = n0 + seg * C::EPC;
+        ok = ok && n < p.N;
+        if (krow == 0) btop |= 1u << i;
+        if (krow == C::KSTAGE + 1) bbot |= 1u << i;
+        bpre[i] = ok ? Bg + ((long)(kbeg + krow - 1) * p.ldb + n) : nullptr;
+      } else {
+        long off; const bool ok = b_dec(c, kbeg, off); bpre[i] = ok ? Bg + off : nullptr;
+      }
+    }
   }
   auto issue_stage = [&](int s, int buf) __attribute__((always_inline)) {
     char* base = smem + buf * C::STAGE_BYTES;
+    unsigned bdead = 0;
+    if constexpr (C::WG3) {   // k=3, pad 1: the row above the first / below the last row of a sample is the conv's zero padding
+      const int k0 = kbeg + s * C::KSTAGE;
+      if (k0 % p.Lout == 0) bdead |= btop;
+      if ((k0 + C::KSTAGE) % p.Lout == 0) bdead |= bbot;
+    }
 #pragma unroll
     for (int i = 0; i < C::IA; i++) {
       const T* src = apre[i] ? apre[i] + s * astep : zeros;
@@ -292,7 +316,7 @@ __global__ __launch_bounds__(128 * WMT, 2) void gemm_kernel(const GemmArgs p) { 
     }
 #pragma unroll
     for (int i = 0; i < C::IB; i++) {
-      const T* src = bpre[i] ? bpre[i] + s * bstep : zeros;
+      const T* src = (bpre[i] && !((bdead >> i) & 1)) ? bpre[i] + s * bstep : zeros;
       __builtin_amdgcn_global_load_lds((glb_void_ptr)src, (lds_void_ptr)(base + C::A_ALLOC + (wave + NW * i) * 1024), 16, 0, 0);
     }
   };
@@ -345,6 +369,10 @@ __global__ __launch_bounds__(128 * WMT, 2) void gemm_kernel(const GemmArgs p) { 
 #pragma unroll
       for (int j = 0; j < FN; j++) acc[a][i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
+  // bias chunk of this thread's epilogue columns: fetched now so its latency hides behind the whole K loop
+  float4 bias4 = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (p.bias) { const int nb = n0 + (tid % (BN / 4)) * 4; bias4 = *(const float4*)(p.bias + (nb < p.N ? nb : 0)); }
+
   // ring of NSTG stage buffers, loads run NSTG-1 stages ahead; each wave issues exactly IA+IB DMA instructions per
   // stage, so "stage s has landed" == at most (NSTG-2)*(IA+IB) of this wave's DMAs still outstanding.
   constexpr int PER = C::IA + C::IB;
@@ -355,7 +383,7 @@ __global__ __launch_bounds__(128 * WMT, 2) void gemm_kernel(const GemmArgs p) { 
     load_stage(0);
   }
 #ifdef EEG_STAGE_TIMING
-  unsigned long long* tlog = (unsigned long long*)p.zero_page + 512 + (blockIdx.y * gridDim.x + blockIdx.x) * 64;   // debug only
+  unsigned long long* tlog = (unsigned long long*)p.zero_page + 512 + ((blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * 64;   // debug only
   int tl = 0;
 #define TSTAMP() do { if (tid == 0 && tl < 64) tlog[tl++] = __builtin_readcyclecounter(); } while (0)
 #else
@@ -432,11 +460,16 @@ __global__ __launch_bounds__(128 * WMT, 2) void gemm_kernel(const GemmArgs p) { 
   constexpr int NCH = C::EPI_ROWS * CH;           // chunks per pass
   if constexpr (AMODE == GA_TR) {
     if (p.atomic_out) {
-      // split-K weight gradients: natural fragment layout (rows q*4+r, col lm), fp32 atomics straight from registers
+      // split-K weight gradients: natural fragment layout (rows q*4+r, col lm), fp32 atomics straight from registers.
+      // All splits of a tile add into the same lines; each split starts a quarter of the way further round the tile so
+      // that concurrently finishing blocks are spread over different lines / L2 channels instead of queueing on one.
+      auto emit = [&](auto ROT) {
+        constexpr int NAI = C::NACC * 4;
 #pragma unroll
-      for (int a = 0; a < C::NACC; a++)
-#pragma unroll
-        for (int i = 0; i < 4; i++)
+        for (int ai0 = 0; ai0 < NAI; ai0++) {
+          constexpr int R = decltype(ROT)::value;
+          const int ai = (ai0 + R * C::NACC) % NAI;
+          const int a = ai / 4, i = ai % 4;
 #pragma unroll
           for (int r = 0; r < 4; r++) {
             const int m = m0 + wm * 64 + i * 16 + q * 4 + r;
@@ -447,6 +480,19 @@ __global__ __launch_bounds__(128 * WMT, 2) void gemm_kernel(const GemmArgs p) { 
               if (n < p.N) atomicAdd((float*)Cb + cbase + (long)a * p.sCt + (long)m * p.ldc + n, acc[a][i][j][r] * p.alpha);
             }
           }
+        }
+      };
+      switch (ksplit & 3) {
+        case 0: emit(std::integral_constant<int, 0>{}); break;
+        case 1: emit(std::integral_constant<int, 1>{}); break;
+        case 2: emit(std::integral_constant<int, 2>{}); break;
+        default: emit(std::integral_constant<int, 3>{}); break;
+      }
+      TSTAMP();   // atomics issued
+#ifdef EEG_STAGE_TIMING
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      TSTAMP();   // atomics retired
+#endif
       return;
     }
   }
@@ -492,15 +538,13 @@ __global__ __launch_bounds__(128 * WMT, 2) void gemm_kernel(const GemmArgs p) { 
       const int nc = nok ? n : 0;
       int mm[NIT];
       float4 add[NIT];
-      float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (p.bias) bv = *(const float4*)(p.bias + nc);
 #pragma unroll
       for (int cc = 0; cc < NIT; cc++) {
         const int row = r0 + cc * RSTEP;
         const int g = row >> 4, ii = g / WMT, wmr = g % WMT;
         const int m = m0 + wmr * 64 + (pass * C::EPI_I + ii) * 16 + (row & 15);
         mm[cc] = (row < C::EPI_ROWS && nok && m < p.M) ? m : -1;
-        add[cc] = bv;
+        add[cc] = bias4;
       }
       if (p.rowvec) {
         // sample index of a row: the tile spans < 2 samples when rows_per_vec >= tile rows (one compare), else divide
@@ -588,9 +632,15 @@ int launch_k(eegldm_ctx* ctx, const GemmArgs& a) {
 // stages (all production shapes), register staging otherwise (K tails, 1-tap kernels, fused wgrad)
 template <typename T, int AMODE, int BMODE, int TAPS, int KSUB, int BN, int STRIDE, int WMT>
 int launch_t(eegldm_ctx* ctx, const GemmArgs& a) {
+  constexpr int KSTAGE = KSUB * Tr<T>::KC;
   if constexpr (AMODE == GA_CONV && TAPS == 3) {
-    constexpr int KSTAGE = KSUB * Tr<T>::KC;
     if (a.K % KSTAGE == 0 && a.splitk == 1) return launch_k<T, AMODE, BMODE, TAPS, KSUB, BN, STRIDE, WMT, true>(ctx, a);
+  }
+  if constexpr (AMODE == GA_TR && BMODE == GB_TR && WMT == 2) {
+    // weight gradients (fused 3-tap and 1-tap / Linear): every split is a whole number of stages when K is, and the source
+    // of a chunk moves by a constant per stage unless the K index is remapped per tap (conv_map: unfused strided wgrad)
+    static const bool no_dma = getenv("EEGLDM_WGRAD_NO_DMA") != nullptr;
+    if (!no_dma && a.K % KSTAGE == 0 && !a.conv_map) return launch_k<T, AMODE, BMODE, TAPS, KSUB, BN, STRIDE, WMT, true>(ctx, a);
   }
   return launch_k<T, AMODE, BMODE, TAPS, KSUB, BN, STRIDE, WMT, false>(ctx, a);
 }

@@ -33,3 +33,26 @@ for (ci, co, k) in [(512, 512, 3), (128, 128, 3), (512, 512, 1)]:
     names = ["final sync", "LDS tile written", "barrier", "global reads issued", "global reads landed", "LDS read + stores issued", "stores retired"]
     for n, c in zip(names, e.T): print(f"  epilogue {n:26s} {med(c):8.0f}  (p90 {np.percentile(c,90):.0f})")
     print(f"  block total {med(t[:,2*nst+8]-t[:,0]):.0f}")
+
+# weight-gradient kernels (fused 3-tap TN, split-K, direct register atomics)
+for (ci, co, L) in [(128, 128, 768), (256, 256, 384), (512, 512, 192)]:
+    R = B * L
+    x = torch.randn(R, ci, device="cuda").bfloat16(); dy = torch.randn(R, co, device="cuda").bfloat16()
+    dw = torch.zeros(3, co, ci, device="cuda")
+    tiles = ((co + 127) // 128) * ((ci + 63) // 64)
+    splitk = min((512 + tiles - 1) // tiles, (R + 511) // 512)
+    nblk = tiles * splitk
+    buf = np.zeros(nblk * 64, dtype=np.uint64)
+    for _ in range(3):
+        check(lib.eegldm_conv1d_bwd_weight(ctx.h, ptr(x), ci, ptr(dy), co, ptr(dw), None, B, L, ci, co, 3, 1, 1, 1, 1))
+        lib.eegldm_debug_read_tlog(ctx.h, buf.ctypes.data_as(C.c_void_p), C.c_long(buf.size))
+    t = buf.reshape(nblk, 64).astype(np.int64)
+    cnt = (t != 0).sum(axis=1)
+    n = int(np.median(cnt))
+    t = t[cnt == n]
+    d = np.diff(t[:, :n], axis=1)
+    nst = (n - 4) // 2
+    med = lambda a: float(np.median(a))
+    print(f"wgrad k3 {ci}->{co} L={L}: blocks {nblk} (tiles {tiles} x splitk {splitk}), stamps {n}, stages {nst}")
+    print(f"  first wait {med(d[:,0]):.0f}; per-stage wait {med(d[:,2:2*nst:2]):.0f}; per-stage MFMA {med(d[:,1:2*nst:2]):.0f}")
+    print(f"  tail: {[int(med(c)) for c in d[:, 2*nst:].T]}  (final sync, atomics issued, atomics retired); total {med(t[:,n-1]-t[:,0]):.0f}")
