@@ -624,6 +624,15 @@ int launch_k(eegldm_ctx* ctx, const GemmArgs& a) {
     attr_set = true;
   }
   dim3 grid((a.N + BN - 1) / BN, (a.M + C::BM - 1) / C::BM, a.batch * a.ztaps * a.splitk);
+#ifdef EEG_STAGE_TIMING
+  static const int lds_pad = getenv("EEGLDM_GEMM_LDS_PAD") ? atoi(getenv("EEGLDM_GEMM_LDS_PAD")) : 0;   // occupancy experiments
+  if (lds_pad) {
+    HIP_TRY(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES + lds_pad));
+    hipLaunchKernelGGL(kern, grid, dim3(C::NTHREADS), C::LDS_BYTES + lds_pad, ctx->stream, a);
+    LAUNCH_CHECK();
+    return 0;
+  }
+#endif
   hipLaunchKernelGGL(kern, grid, dim3(C::NTHREADS), C::LDS_BYTES, ctx->stream, a);
   LAUNCH_CHECK();
   return 0;

@@ -38,3 +38,7 @@ int op_attention_fwd(eegldm_ctx*, int dtype, const void* qkv, long ldq, void* ou
                      int B, int T, int C);
 int op_attention_bwd(eegldm_ctx*, int dtype, const void* qkv, long ldq, const void* probs, const void* dout, long lddo,
                      void* dqkv, long lddq, float* dprobs, void* dlogits, int B, int T, int C);
+// GroupNorm backward with an optional fused per-sample column sum of dx (norm.hip); *colsum_done = 1 when produced
+int op_groupnorm_bwd(eegldm_ctx*, const void* x, long ldx, const float* gamma, const float* beta, const float* stats,
+                     const void* dy, long lddy, void* dx, long lddx, float* dgamma, float* dbeta, int B, int L, int C, int G,
+                     int fuse_silu, int resample, const void* dxr, long lddxr, int dtype, float* colsum_ps, long ldps, int* colsum_done);

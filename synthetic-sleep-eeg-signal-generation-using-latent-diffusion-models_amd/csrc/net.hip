@@ -83,12 +83,21 @@ int res_backward(NetBase* u, const ResDesc& r, const ResTape& t, const View& dou
   View da2; ALLOC_OR_FAIL(da2.p, u->alloc_act((long)B * Lout, r.cout)); da2.ld = r.cout;
   EEG_TRY(op_conv_dgrad(ctx, dt, dout.p, dout.ld, u->W(r.c2_w), da2.p, da2.ld, B, Lout, r.cout, r.cout, 3, 1, 1, 1, nullptr, 0));
   View dh1; ALLOC_OR_FAIL(dh1.p, u->alloc_act((long)B * Lout, r.cout)); dh1.ld = r.cout;
-  EEG_TRY(eegldm_groupnorm_bwd(ctx, t.h1.p, t.h1.ld, u->P(r.gn2_w), u->P(r.gn2_b), t.st2, da2.p, da2.ld, dh1.p, dh1.ld, u->param_grads ? u->G(r.gn2_w) : nullptr, u->param_grads ? u->G(r.gn2_b) : nullptr,
-                               B, Lout, r.cout, r.groups, 1, 0, nullptr, 0, dt));
-  // h1 = conv(a1) + b1 + emb_out[b]: per-sample column sums feed the embedding MLP, their total is db1
+  // h1 = conv(a1) + b1 + emb_out[b]: the per-sample column sums of dh1 feed the embedding MLP, their total is db1.
+  // The one-pass GroupNorm backward produces them while dh1 is still in registers; otherwise a separate column sum.
   const bool pg = u->param_grads;
-  if (r.emb_col >= 0) EEG_TRY(ew_colsum(ctx, dh1.p, dh1.ld, demb_all + r.emb_col, u->etot, pg ? u->G(r.c1_b) : nullptr, B, Lout, r.cout, dt));
-  else if (pg) EEG_TRY(ew_colsum(ctx, dh1.p, dh1.ld, nullptr, 0, u->G(r.c1_b), B, Lout, r.cout, dt));
+  float* ps = nullptr; long ldps = 0;
+  if (r.emb_col >= 0) { ps = demb_all + r.emb_col; ldps = u->etot; }
+  else if (pg) { ALLOC_OR_FAIL(ps, (float*)u->arena.alloc(sizeof(float) * (size_t)B * r.cout)); ldps = r.cout; }
+  int cs_done = 0;
+  EEG_TRY(op_groupnorm_bwd(ctx, t.h1.p, t.h1.ld, u->P(r.gn2_w), u->P(r.gn2_b), t.st2, da2.p, da2.ld, dh1.p, dh1.ld, pg ? u->G(r.gn2_w) : nullptr, pg ? u->G(r.gn2_b) : nullptr,
+                           B, Lout, r.cout, r.groups, 1, 0, nullptr, 0, dt, ps, ldps, &cs_done));
+  if (cs_done) {
+    if (pg) EEG_TRY(ew_colsum(ctx, ps, ldps, nullptr, 0, u->G(r.c1_b), 1, B, r.cout, EEGLDM_F32));
+  } else {
+    if (r.emb_col >= 0) EEG_TRY(ew_colsum(ctx, dh1.p, dh1.ld, ps, ldps, pg ? u->G(r.c1_b) : nullptr, B, Lout, r.cout, dt));
+    else if (pg) EEG_TRY(ew_colsum(ctx, dh1.p, dh1.ld, nullptr, 0, u->G(r.c1_b), B, Lout, r.cout, dt));
+  }
   if (pg) EEG_TRY(op_conv_wgrad(ctx, dt, t.a1.p, t.a1.ld, dh1.p, dh1.ld, u->G(r.c1_w), nullptr, B, Lout, r.cin, r.cout, 3, 1, 1, 1));
   View da1; ALLOC_OR_FAIL(da1.p, u->alloc_act((long)B * Lout, r.cin)); da1.ld = r.cin;
   EEG_TRY(op_conv_dgrad(ctx, dt, dh1.p, dh1.ld, u->W(r.c1_w), da1.p, da1.ld, B, Lout, r.cin, r.cout, 3, 1, 1, 1, nullptr, 0));

@@ -8,6 +8,8 @@
 // dozen elements each), LDS float atomics per block, then fp64 global atomics -- biased
 // variance from fp64 sums, so E[x^2]-mean^2 cancellation stays below fp32 rounding.
 #include "common.h"
+#include "internal.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -26,6 +28,12 @@ template <> __device__ __forceinline__ void load4<float>(const float* p, float v
 }
 template <> __device__ __forceinline__ void load4<bf16_t>(const bf16_t* p, float v[4]) {
   uint2 t = *(const uint2*)p;
+  v[0] = __uint_as_float(t.x << 16); v[1] = __uint_as_float(t.x & 0xffff0000u);
+  v[2] = __uint_as_float(t.y << 16); v[3] = __uint_as_float(t.y & 0xffff0000u);
+}
+template <typename T> __device__ __forceinline__ void unpack4(const typename Vec<T, 4>::type& t, float v[4]);
+template <> __device__ __forceinline__ void unpack4<float>(const float4& t, float v[4]) { v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w; }
+template <> __device__ __forceinline__ void unpack4<bf16_t>(const uint2& t, float v[4]) {
   v[0] = __uint_as_float(t.x << 16); v[1] = __uint_as_float(t.x & 0xffff0000u);
   v[2] = __uint_as_float(t.y << 16); v[3] = __uint_as_float(t.y & 0xffff0000u);
 }
@@ -289,6 +297,242 @@ __global__ __launch_bounds__(NT) void gn_bwd_apply_kernel(const T* __restrict__ 
   }
 }
 
+// ------------------------------------------------------------------ register-resident one-pass GroupNorm
+// A 1024-thread block owns ONE sample x a chunk of CC channels (whole groups) over the full length L and keeps its
+// rows in registers: x (and dy) are read from HBM exactly once, statistics / group sums are reduced inside the
+// block (no global atomics, no finalize launch), and the normalised output / input gradient is produced from the
+// registers.  HBM traffic: forward 1R+1W (was 2R+1W), backward 2R+1W (was 4R+1W).
+// Thread (tx, ty): tx = 4-channel vector column of the chunk, ty = row lane; row k of a thread is k*TY + ty, or in
+// pair mode (avgpool) rows 2*((k/2)*TY + ty) + k%2 so that both rows of a pooling pair live in one thread.
+constexpr int NTB = 1024;
+constexpr int RES_MAXG = 64;     // local groups per chunk
+constexpr int RES_MAXC = 256;    // channels per chunk
+
+struct ResMap { int TX, TY, tx, ty, c, gl; bool act; };
+__device__ __forceinline__ ResMap resmap(int CC, int C, int cpg) {
+  ResMap m; m.TX = CC / 4; m.TY = NTB / m.TX;
+  const int tid = threadIdx.x;
+  m.tx = tid % m.TX; m.ty = tid / m.TX;
+  m.c = blockIdx.x * CC + m.tx * 4; m.gl = (m.tx * 4) / cpg;
+  m.act = tid < m.TX * m.TY && m.c < C;
+  return m;
+}
+__device__ __forceinline__ int res_row(int k, int ty, int TY, bool pair) {
+  return pair ? 2 * ((k >> 1) * TY + ty) + (k & 1) : k * TY + ty;
+}
+
+template <typename T, int RPT>
+__global__ __launch_bounds__(NTB) void gn_fwd_resident_kernel(const T* __restrict__ x, long ldx, const float* __restrict__ gamma,
+                                                              const float* __restrict__ beta, T* __restrict__ y, long ldy,
+                                                              T* __restrict__ xr, long ldxr, float* __restrict__ stats,
+                                                              int L, int C, int G, float eps, int silu, int resample, int CC) {
+  __shared__ float red[2 * RES_MAXG];
+  const int b = blockIdx.y, cpg = C / G;
+  const ResMap m = resmap(CC, C, cpg);
+  const bool pair = resample == 1;
+  if (threadIdx.x < 2 * RES_MAXG) red[threadIdx.x] = 0.f;
+  typename Vec<T, 4>::type raw[RPT];
+  const T* xb = x + (long)b * L * ldx + m.c;
+  if (m.act) {
+#pragma unroll
+    for (int k = 0; k < RPT; k++) {
+      const int l = res_row(k, m.ty, m.TY, pair);
+      if (l < L) raw[k] = *(const typename Vec<T, 4>::type*)(xb + (long)l * ldx);
+    }
+  }
+  __syncthreads();
+  const float inv_n = 1.0f / ((float)cpg * (float)L);
+  float s = 0.f;
+  if (m.act) {
+#pragma unroll
+    for (int k = 0; k < RPT; k++) {
+      if (res_row(k, m.ty, m.TY, pair) < L) { float v[4]; unpack4<T>(raw[k], v); s += (v[0] + v[1]) + (v[2] + v[3]); }
+    }
+    atomicAdd(&red[m.gl], s);
+  }
+  __syncthreads();
+  float mean = 0.f, rstd = 0.f;
+  if (m.act) {
+    mean = red[m.gl] * inv_n;
+    float q = 0.f;
+#pragma unroll
+    for (int k = 0; k < RPT; k++) {
+      if (res_row(k, m.ty, m.TY, pair) < L) {
+        float v[4]; unpack4<T>(raw[k], v);
+#pragma unroll
+        for (int j = 0; j < 4; j++) { const float d = v[j] - mean; q += d * d; }
+      }
+    }
+    atomicAdd(&red[RES_MAXG + m.gl], q);
+  }
+  __syncthreads();
+  if (!m.act) return;
+  rstd = rsqrtf(red[RES_MAXG + m.gl] * inv_n + eps);
+  if (m.ty == 0 && (m.tx * 4) % cpg == 0) { float* st = stats + ((long)b * G + m.c / cpg) * 2; st[0] = mean; st[1] = rstd; }
+  float ga[4], be[4];
+#pragma unroll
+  for (int j = 0; j < 4; j++) { ga[j] = gamma[m.c + j] * rstd; be[j] = beta[m.c + j] - mean * ga[j]; }
+  if (resample == 1) {
+    T* yb = y + (long)b * (L / 2) * ldy + m.c; T* xrb = xr ? xr + (long)b * (L / 2) * ldxr + m.c : nullptr;
+#pragma unroll
+    for (int k = 0; k + 1 < RPT; k += 2) {
+      const int l = res_row(k, m.ty, m.TY, true);
+      if (l + 1 < L) {
+        float v0[4], v1[4], o[4], r[4];
+        unpack4<T>(raw[k], v0); unpack4<T>(raw[k + 1], v1);
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+          float z0 = v0[j] * ga[j] + be[j], z1 = v1[j] * ga[j] + be[j];
+          if (silu) { z0 = silu_f(z0); z1 = silu_f(z1); }
+          o[j] = 0.5f * (z0 + z1); r[j] = 0.5f * (v0[j] + v1[j]);
+        }
+        store4<T>(yb + (long)(l >> 1) * ldy, o);
+        if (xrb) store4<T>(xrb + (long)(l >> 1) * ldxr, r);
+      }
+    }
+  } else {
+    const int up = resample == 2 ? 2 : 1;
+    T* yb = y + (long)b * up * L * ldy + m.c; T* xrb = (xr && up == 2) ? xr + (long)b * 2 * L * ldxr + m.c : nullptr;
+#pragma unroll
+    for (int k = 0; k < RPT; k++) {
+      const int l = res_row(k, m.ty, m.TY, false);
+      if (l < L) {
+        float v[4], o[4];
+        unpack4<T>(raw[k], v);
+#pragma unroll
+        for (int j = 0; j < 4; j++) { const float z = v[j] * ga[j] + be[j]; o[j] = silu ? silu_f(z) : z; }
+        if (up == 1) store4<T>(yb + (long)l * ldy, o);
+        else {
+          store4<T>(yb + (long)(2 * l) * ldy, o); store4<T>(yb + (long)(2 * l + 1) * ldy, o);
+          if (xrb) { store4<T>(xrb + (long)(2 * l) * ldxr, v); store4<T>(xrb + (long)(2 * l + 1) * ldxr, v); }
+        }
+      }
+    }
+  }
+}
+
+// backward: dgamma/dbeta partials go to the slot buffers (folded by gn_slot_reduce_kernel); colsum_ps (optional) receives
+// the per-sample column sums of the written dx -- the block owns (sample, channels) over all of L, so no atomics.
+template <typename T, int RPT>
+__global__ __launch_bounds__(NTB) void gn_bwd_resident_kernel(const T* __restrict__ x, long ldx, const float* __restrict__ gamma,
+                                                              const float* __restrict__ beta, const float* __restrict__ stats,
+                                                              const T* __restrict__ dy, long lddy, T* __restrict__ dx, long lddx,
+                                                              const T* __restrict__ dxr, long lddxr, float* __restrict__ slots,
+                                                              float* __restrict__ colsum_ps, long ldps,
+                                                              int L, int C, int G, int silu, int resample, int CC) {
+  __shared__ float redg[2 * RES_MAXG];
+  __shared__ float redc[3 * RES_MAXC];
+  const int b = blockIdx.y, cpg = C / G;
+  const ResMap m = resmap(CC, C, cpg);
+  for (int i = threadIdx.x; i < 2 * RES_MAXG + 3 * RES_MAXC; i += NTB) { if (i < 2 * RES_MAXG) redg[i] = 0.f; else redc[i - 2 * RES_MAXG] = 0.f; }
+  typename Vec<T, 4>::type raw[RPT];
+  float d[RPT][4];
+  if (m.act) {
+    const T* xb = x + (long)b * L * ldx + m.c;
+#pragma unroll
+    for (int k = 0; k < RPT; k++) {
+      const int l = k * m.TY + m.ty;
+      if (l < L) raw[k] = *(const typename Vec<T, 4>::type*)(xb + (long)l * ldx);
+    }
+#pragma unroll
+    for (int k = 0; k < RPT; k++) {
+      const int l = k * m.TY + m.ty;
+      if (l < L) load_dy_eff<T, 4>(dy, lddy, b, l, L, m.c, resample, d[k]);
+    }
+  }
+  __syncthreads();
+  float mean = 0.f, rstd = 0.f, ga[4], be[4];
+  if (m.act) {
+    const float* st = stats + ((long)b * G + m.c / cpg) * 2;
+    mean = st[0]; rstd = st[1];
+    float dg[4] = {0.f, 0.f, 0.f, 0.f}, db[4] = {0.f, 0.f, 0.f, 0.f}, s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int j = 0; j < 4; j++) { ga[j] = gamma[m.c + j]; be[j] = beta[m.c + j]; }
+#pragma unroll
+    for (int k = 0; k < RPT; k++) {
+      if (k * m.TY + m.ty < L) {
+        float v[4]; unpack4<T>(raw[k], v);
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+          const float xh = (v[j] - mean) * rstd;
+          float dz = d[k][j];
+          if (silu) dz *= silu_grad_f(ga[j] * xh + be[j]);
+          d[k][j] = dz;
+          dg[j] += dz * xh; db[j] += dz;
+          s1 += dz * ga[j]; s2 += dz * ga[j] * xh;
+        }
+      }
+    }
+    atomicAdd(&redg[2 * m.gl], s1); atomicAdd(&redg[2 * m.gl + 1], s2);
+    if (slots) {
+#pragma unroll
+      for (int j = 0; j < 4; j++) { atomicAdd(&redc[m.tx * 4 + j], dg[j]); atomicAdd(&redc[RES_MAXC + m.tx * 4 + j], db[j]); }
+    }
+  }
+  __syncthreads();
+  if (m.act) {
+    const float inv_n = 1.0f / ((float)cpg * (float)L);
+    const float m1 = redg[2 * m.gl] * inv_n, m2 = redg[2 * m.gl + 1] * inv_n;
+    if (slots && m.ty == 0) {
+      float* sl = slots + (size_t)(b % GN_NSLOT) * 2 * C;
+#pragma unroll
+      for (int j = 0; j < 4; j++) { atomicAdd(&sl[m.c + j], redc[m.tx * 4 + j]); atomicAdd(&sl[C + m.c + j], redc[RES_MAXC + m.tx * 4 + j]); }
+    }
+    float cs[4] = {0.f, 0.f, 0.f, 0.f};
+    T* dxb = dx + (long)b * L * lddx + m.c;
+#pragma unroll
+    for (int k = 0; k < RPT; k++) {
+      const int l = k * m.TY + m.ty;
+      if (l < L) {
+        float v[4], o[4]; unpack4<T>(raw[k], v);
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+          const float xh = (v[j] - mean) * rstd;
+          o[j] = rstd * (d[k][j] * ga[j] - m1 - xh * m2);
+        }
+        if (dxr) {
+          float e[4];
+          load_dy_eff<T, 4>(dxr, lddxr, b, l, L, m.c, resample, e);
+#pragma unroll
+          for (int j = 0; j < 4; j++) o[j] += e[j];
+        }
+#pragma unroll
+        for (int j = 0; j < 4; j++) cs[j] += o[j];
+        store4<T>(dxb + (long)l * lddx, o);
+      }
+    }
+    if (colsum_ps) {
+#pragma unroll
+      for (int j = 0; j < 4; j++) atomicAdd(&redc[2 * RES_MAXC + m.tx * 4 + j], cs[j]);
+    }
+  }
+  if (colsum_ps) {
+    __syncthreads();
+    if (m.act && m.ty == 0) {
+#pragma unroll
+      for (int j = 0; j < 4; j++) colsum_ps[(long)b * ldps + m.c + j] = redc[2 * RES_MAXC + m.tx * 4 + j];
+    }
+  }
+}
+
+// chunk width for the resident kernels: the widest whole-group chunk (<= 256 channels, dividing C) whose rows fit the
+// per-thread register budget; 0 = not eligible (fall back to the split kernels)
+int resident_chunk(int L, int C, int G, int resample_pair, int rpt_max, int* rpt_out) {
+  const int cpg = C / G;
+  if (C % 4 != 0 || cpg % 4 != 0) return 0;
+  int best = 0, best_rpt = 0;
+  for (int mlt = 1; mlt * cpg <= RES_MAXC && mlt <= RES_MAXG; mlt++) {
+    const int cc = mlt * cpg;
+    if (C % cc != 0) continue;
+    const int tx = cc / 4, ty = NTB / tx;
+    int rpt = resample_pair ? 2 * ((L / 2 + ty - 1) / ty) : (L + ty - 1) / ty;
+    if (rpt > rpt_max) break;
+    best = cc; best_rpt = rpt;
+  }
+  *rpt_out = best_rpt;
+  return best;
+}
+
 int grid_for(long total_threads, eegldm_ctx* ctx) {
   long blocks = (total_threads + NT - 1) / NT;
   long cap = (long)ctx->num_cu * 16;
@@ -309,6 +553,19 @@ int pick_lsplit(int B, int L, int C, eegldm_ctx* ctx, int* rows_per_block, int p
 template <typename T, int V>
 int gn_fwd_t(eegldm_ctx* ctx, const void* x, long ldx, const float* gamma, const float* beta, void* y, long ldy,
              float* stats, int B, int L, int C, int G, float eps, int silu, int resample, void* xr, long ldxr) {
+  if constexpr (V == 4) {
+    static const bool off = getenv("EEGLDM_GN_NO_RESIDENT") != nullptr;
+    int rpt = 0; const int cc = off ? 0 : resident_chunk(L, C, G, resample == 1, sizeof(T) == 2 ? 24 : 12, &rpt);
+    if (cc) {
+      const dim3 grid(C / cc, B);
+#define GN_FWD_RES(R) hipLaunchKernelGGL((gn_fwd_resident_kernel<T, R>), grid, dim3(NTB), 0, ctx->stream, (const T*)x, ldx, gamma, beta, \
+                                         (T*)y, ldy, (T*)xr, ldxr, stats, L, C, G, eps, silu, resample, cc)
+      if (rpt <= 6) GN_FWD_RES(6); else if (rpt <= 12) GN_FWD_RES(12); else { if constexpr (sizeof(T) == 2) GN_FWD_RES(24); }
+#undef GN_FWD_RES
+      LAUNCH_CHECK();
+      return 0;
+    }
+  }
   double* sums = (double*)ctx->scratch;      // zero on entry (context creation / previous finalize)
   int rpb; int ls = pick_lsplit(B, L, C, ctx, &rpb);
   hipLaunchKernelGGL((gn_stats_kernel<T, V>), dim3(ls, B), dim3(NT), 0, ctx->stream, (const T*)x, ldx, sums, L, C, G, rpb);
@@ -326,7 +583,28 @@ int gn_fwd_t(eegldm_ctx* ctx, const void* x, long ldx, const float* gamma, const
 template <typename T, int V>
 int gn_bwd_t(eegldm_ctx* ctx, const void* x, long ldx, const float* gamma, const float* beta, const float* stats,
              const void* dy, long lddy, void* dx, long lddx, float* dgamma, float* dbeta, int B, int L, int C, int G,
-             int silu, int resample, const void* dxr, long lddxr) {
+             int silu, int resample, const void* dxr, long lddxr, float* colsum_ps, long ldps, int* colsum_done) {
+  if (colsum_done) *colsum_done = 0;
+  if constexpr (V == 4) {
+    static const bool off = getenv("EEGLDM_GN_NO_RESIDENT") != nullptr;
+    int rpt = 0; const int cc = off ? 0 : resident_chunk(L, C, G, 0, sizeof(T) == 2 ? 12 : 8, &rpt);
+    if (cc) {
+      const dim3 grid(C / cc, B);
+      float* slots = dgamma ? (float*)((char*)ctx->scratch + GN_SLOT_OFFSET) : nullptr;
+#define GN_BWD_RES(R) hipLaunchKernelGGL((gn_bwd_resident_kernel<T, R>), grid, dim3(NTB), 0, ctx->stream, (const T*)x, ldx, gamma, beta, stats, \
+                                         (const T*)dy, lddy, (T*)dx, lddx, (const T*)dxr, lddxr, slots, colsum_ps, ldps, L, C, G, silu, resample, cc)
+      constexpr int RLO = sizeof(T) == 2 ? 6 : 4, RHI = sizeof(T) == 2 ? 12 : 8;
+      if (rpt <= RLO) GN_BWD_RES(RLO); else GN_BWD_RES(RHI);
+#undef GN_BWD_RES
+      LAUNCH_CHECK();
+      if (slots) {
+        hipLaunchKernelGGL(gn_slot_reduce_kernel, dim3((2 * C + 255) / 256), dim3(256), 0, ctx->stream, slots, dgamma, dbeta, C, (double*)ctx->scratch, 0);
+        LAUNCH_CHECK();
+      }
+      if (colsum_done && colsum_ps) *colsum_done = 1;
+      return 0;
+    }
+  }
   double* gsums = (double*)ctx->scratch;     // zero on entry; shared with the forward sums (stream-ordered)
   int rpb; int ls = pick_lsplit(B, L, C, ctx, &rpb);
   float* slots = dgamma ? (float*)((char*)ctx->scratch + GN_SLOT_OFFSET) : nullptr;
@@ -372,18 +650,25 @@ extern "C" int eegldm_groupnorm_fwd(eegldm_ctx* ctx, const void* x, long ldx, co
   EEG_FAIL(EEGLDM_ERR_UNSUPPORTED, "dtype %d", dtype);
 }
 
+// colsum_ps (optional): per-sample column sums of dx [B][ldps] fp32; *colsum_done tells the caller whether the
+// one-pass kernel produced them (otherwise it runs ew_colsum itself)
+int op_groupnorm_bwd(eegldm_ctx* ctx, const void* x, long ldx, const float* gamma, const float* beta,
+                     const float* stats, const void* dy, long lddy, void* dx, long lddx,
+                     float* dgamma, float* dbeta, int B, int L, int C, int G, int fuse_silu,
+                     int resample, const void* dxr, long lddxr, int dtype, float* colsum_ps, long ldps, int* colsum_done) {
+  EEG_TRY(gn_check(ctx, B, L, C, G, resample, ldx));
+  const bool v4 = vec4_ok(C, G, ldx, lddy, lddx, dxr ? lddxr : 0);
+#define GN_BWD_ARGS ctx, x, ldx, gamma, beta, stats, dy, lddy, dx, lddx, dgamma, dbeta, B, L, C, G, fuse_silu, resample, dxr, lddxr, colsum_ps, ldps, colsum_done
+  if (dtype == EEGLDM_F32) return v4 ? gn_bwd_t<float, 4>(GN_BWD_ARGS) : gn_bwd_t<float, 1>(GN_BWD_ARGS);
+  if (dtype == EEGLDM_BF16) return v4 ? gn_bwd_t<bf16_t, 4>(GN_BWD_ARGS) : gn_bwd_t<bf16_t, 1>(GN_BWD_ARGS);
+#undef GN_BWD_ARGS
+  EEG_FAIL(EEGLDM_ERR_UNSUPPORTED, "dtype %d", dtype);
+}
+
 extern "C" int eegldm_groupnorm_bwd(eegldm_ctx* ctx, const void* x, long ldx, const float* gamma, const float* beta,
                                     const float* stats, const void* dy, long lddy, void* dx, long lddx,
                                     float* dgamma, float* dbeta, int B, int L, int C, int G, int fuse_silu,
                                     int resample, const void* dxr, long lddxr, int dtype) {
-  EEG_TRY(gn_check(ctx, B, L, C, G, resample, ldx));
-  const bool v4 = vec4_ok(C, G, ldx, lddy, lddx, dxr ? lddxr : 0);
-  if (dtype == EEGLDM_F32) {
-    return v4 ? gn_bwd_t<float, 4>(ctx, x, ldx, gamma, beta, stats, dy, lddy, dx, lddx, dgamma, dbeta, B, L, C, G, fuse_silu, resample, dxr, lddxr)
-              : gn_bwd_t<float, 1>(ctx, x, ldx, gamma, beta, stats, dy, lddy, dx, lddx, dgamma, dbeta, B, L, C, G, fuse_silu, resample, dxr, lddxr);
-  } else if (dtype == EEGLDM_BF16) {
-    return v4 ? gn_bwd_t<bf16_t, 4>(ctx, x, ldx, gamma, beta, stats, dy, lddy, dx, lddx, dgamma, dbeta, B, L, C, G, fuse_silu, resample, dxr, lddxr)
-              : gn_bwd_t<bf16_t, 1>(ctx, x, ldx, gamma, beta, stats, dy, lddy, dx, lddx, dgamma, dbeta, B, L, C, G, fuse_silu, resample, dxr, lddxr);
-  }
-  EEG_FAIL(EEGLDM_ERR_UNSUPPORTED, "dtype %d", dtype);
+  return op_groupnorm_bwd(ctx, x, ldx, gamma, beta, stats, dy, lddy, dx, lddx, dgamma, dbeta, B, L, C, G, fuse_silu, resample,
+                          dxr, lddxr, dtype, nullptr, 0, nullptr);
 }

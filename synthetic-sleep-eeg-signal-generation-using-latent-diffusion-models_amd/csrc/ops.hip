@@ -64,7 +64,8 @@ int op_conv_wgrad(eegldm_ctx* ctx, int dtype, const void* x, long ldx, const voi
   a.dtype = dtype; a.amode = GA_TR; a.bmode = GB_TR;
   a.A = dy; a.lda = lddy; a.B = x; a.ldb = ldx; a.C = dw; a.ldc = Cin; a.sCt = (long)Cout * Cin;
   a.M = Cout; a.N = Cin; a.K = B * Lout; a.batch = 1; a.taps = 1; a.ztaps = K; a.alpha = 1.0f;
-  a.conv_map = 1; a.Lout = Lout; a.Lin = Lin; a.stride = stride; a.pad_l = pad_l;
+  a.conv_map = !(K == 1 && stride == 1 && pad_l == 0);   // a 1x1 conv's K index is the input row itself (plain TN GEMM: LDS-DMA staging)
+  a.Lout = Lout; a.Lin = Lin; a.stride = stride; a.pad_l = pad_l;
   a.out_f32 = 1; a.atomic_out = 1;
   const int kstage = 2 * (dtype == EEGLDM_F32 ? 16 : 32);
   const bool fused3 = (K == 3 && stride == 1 && pad_l == 1 && pad_r == 1 && Lout % kstage == 0);
