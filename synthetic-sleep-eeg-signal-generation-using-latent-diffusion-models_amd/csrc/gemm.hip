@@ -161,6 +161,16 @@ struct Cfg {
 typedef __attribute__((address_space(3))) void* lds_void_ptr;
 typedef const __attribute__((address_space(1))) void* glb_void_ptr;
 
+// One LDS-DMA wave-instruction: lane l's 16 source bytes -> LDS[lds_off + 16*l].  Issued as inline assembly on purpose:
+// through the builtin, hipcc treats the instruction as an LDS store and puts s_waitcnt vmcnt(0) in front of EVERY later
+// ds_read -- the "prefetch" of stage s+1 was waited for before the MFMAs of stage s could read their own (different)
+// buffer, i.e. no DMA/MFMA overlap at all (tools/debug/stage_timing.py: 42 cycles per MFMA).  The kernel orders DMA
+// against LDS reads itself: dma_wait_all() + barrier before a buffer is consumed or refilled.
+__device__ __forceinline__ void dma16(const void* g, unsigned lds_off) {
+  asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off" ::"s"(lds_off), "v"(g) : "memory", "m0");
+}
+__device__ __forceinline__ void dma_wait_all() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+
 template <typename T, int AMODE, int BMODE, int TAPS, int KSUB, int BN, int STRIDE, int WMT, bool DMA>
 __global__ __launch_bounds__(128 * WMT, 2) void gemm_kernel(const GemmArgs p) {   // >= 2 waves per SIMD: <= 256 VGPR+AGPR
   using C = Cfg<T, AMODE, BMODE, TAPS, KSUB, BN, STRIDE, WMT, DMA>;
@@ -194,6 +204,7 @@ __global__ __launch_bounds__(128 * WMT, 2) void gemm_kernel(const GemmArgs p) { 
   const int nstages = (kend - kbeg + C::KSTAGE - 1) / C::KSTAGE;
 
   const uint4 zero4 = make_uint4(0, 0, 0, 0);
+  if (tid < 4) *(uint4*)(smem + C::LDS_BYTES + tid * 16) = zero4;   // zero chunk behind the tiles (conv rows of other samples); visible after the first barrier
   const T* __restrict__ zeros = (const T*)p.zero_page;
 
   // ---- staging: global -> LDS by DMA (global_load_lds_dwordx4).  LDS chunk c of a tile receives the
@@ -301,8 +312,9 @@ __global__ __launch_bounds__(128 * WMT, 2) void gemm_kernel(const GemmArgs p) { 
       }
     }
   }
+  const unsigned lds0 = (unsigned)(size_t)(lds_void_ptr)smem;           // LDS byte address of the tile area
+  const unsigned wave_u = __builtin_amdgcn_readfirstlane(wave);   // scalar copy (M0 must come from an SGPR)
   auto issue_stage = [&](int s, int buf) __attribute__((always_inline)) {
-    char* base = smem + buf * C::STAGE_BYTES;
     unsigned bdead = 0;
     if constexpr (C::WG3) {   // k=3, pad 1: the row above the first / below the last row of a sample is the conv's zero padding
       const int k0 = kbeg + s * C::KSTAGE;
@@ -312,12 +324,12 @@ __global__ __launch_bounds__(128 * WMT, 2) void gemm_kernel(const GemmArgs p) { 
 #pragma unroll
     for (int i = 0; i < C::IA; i++) {
       const T* src = apre[i] ? apre[i] + s * astep : zeros;
-      __builtin_amdgcn_global_load_lds((glb_void_ptr)src, (lds_void_ptr)(base + (wave + NW * i) * 1024), 16, 0, 0);
+      dma16(src, lds0 + buf * C::STAGE_BYTES + (wave_u + NW * i) * 1024);
     }
 #pragma unroll
     for (int i = 0; i < C::IB; i++) {
       const T* src = (bpre[i] && !((bdead >> i) & 1)) ? bpre[i] + s * bstep : zeros;
-      __builtin_amdgcn_global_load_lds((glb_void_ptr)src, (lds_void_ptr)(base + C::A_ALLOC + (wave + NW * i) * 1024), 16, 0, 0);
+      dma16(src, lds0 + buf * C::STAGE_BYTES + C::A_ALLOC + (wave_u + NW * i) * 1024);
     }
   };
 
@@ -397,53 +409,63 @@ __global__ __launch_bounds__(128 * WMT, 2) void gemm_kernel(const GemmArgs p) { 
       if (s + 1 < nstages) load_stage(s + 1);
     } else if constexpr (C::NSTG == 3) {
       if (s + 1 < nstages) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PER) : "memory");
-      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      else dma_wait_all();
       __builtin_amdgcn_s_barrier();
       asm volatile("" ::: "memory");
       if (s + 2 < nstages) issue_stage(s + 2, (s + 2) % 3);
     } else {
       // vmcnt(0) + barrier: stage s has landed in buffer s&1, and every wave is done reading buffer (s+1)&1
+      dma_wait_all();
       __syncthreads();
       if (s + 1 < nstages) issue_stage(s + 1, (s + 1) & 1);
     }
     TSTAMP();   // after wait+barrier(+issue of the next stage)
     const char* smA = smem + (s % C::NSTG) * C::STAGE_BYTES;
     const char* smB = smA + C::A_ALLOC;
+    // Fragment loads run one (tap, k-sub) step ahead of the MFMAs that consume them: with one or two waves per SIMD the
+    // ~200-cycle ds_read latency was fully exposed three times per stage (MFMA phase 2200 cycles for 770 cycles of MFMA work,
+    // tools/debug/stage_timing.py).  Rows of another sample are read from a 16-byte zero chunk in LDS (address select)
+    // instead of being cleared after the load.
+    constexpr int NSTEP = TAPS * KSUB;
+    auto load_frags = [&](int st, uint4 (&af)[4], uint4 (&bf)[FN]) __attribute__((always_inline)) {
+      const int t = st / KSUB, ks = st % KSUB;
 #pragma unroll
-    for (int t = 0; t < TAPS; t++) {
-#pragma unroll
-      for (int ks = 0; ks < KSUB; ks++) {
-        uint4 af[4], bf[FN];
-#pragma unroll
-        for (int i = 0; i < 4; i++) {
-          if constexpr (AMODE == GA_TR) {
-            af[i] = read_tr_t<T, BM>(smA, ks, wm * 64 + i * 16, lm, q);
-          } else {
-            int row = wm * 64 + i * 16 + lm;
-            if constexpr (AMODE == GA_CONV) row = row * STRIDE + t;
-            af[i] = *(const uint4*)(smA + row * C::PITCH_NT + nt_swz<KSUB>(row, ks * 4 + q) * 16);
-            if constexpr (AMODE == GA_CONV) {
-              if (zmask & (1u << (i * TAPS + t))) af[i] = zero4;
-            }
-          }
+      for (int i = 0; i < 4; i++) {
+        if constexpr (AMODE == GA_TR) {
+          af[i] = read_tr_t<T, BM>(smA, ks, wm * 64 + i * 16, lm, q);
+        } else {
+          int row = wm * 64 + i * 16 + lm;
+          if constexpr (AMODE == GA_CONV) row = row * STRIDE + t;
+          const char* ap = smA + row * C::PITCH_NT + nt_swz<KSUB>(row, ks * 4 + q) * 16;
+          if constexpr (AMODE == GA_CONV) { if (zmask & (1u << (i * TAPS + t))) ap = smem + C::LDS_BYTES; }
+          af[i] = *(const uint4*)ap;
         }
+      }
+#pragma unroll
+      for (int j = 0; j < FN; j++) {
+        if constexpr (BMODE == GB_TR) {
+          bf[j] = read_tr_t<T, BN>(smB + (C::WG3 ? 0 : t) * C::B_TILE_BYTES, ks, wn * (BN / 2) + j * 16, lm, q, C::WG3 ? t : 0);
+        } else {
+          const int row = wn * (BN / 2) + j * 16 + lm;
+          bf[j] = *(const uint4*)(smB + t * C::B_TILE_BYTES + row * C::PITCH_NT + nt_swz<KSUB>(row, ks * 4 + q) * 16);
+        }
+      }
+    };
+    uint4 af[2][4], bf[2][FN];
+    load_frags(0, af[0], bf[0]);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int st = 0; st < NSTEP; st++) {
+      if (st + 1 < NSTEP) load_frags(st + 1, af[(st + 1) & 1], bf[(st + 1) & 1]);
+      __builtin_amdgcn_sched_barrier(0);   // keep the prefetch above this step's MFMAs (hipcc otherwise sinks each read to just before its use)
+      const int t = st / KSUB;
+#pragma unroll
+      for (int i = 0; i < 4; i++)
 #pragma unroll
         for (int j = 0; j < FN; j++) {
-          if constexpr (BMODE == GB_TR) {
-            bf[j] = read_tr_t<T, BN>(smB + (C::WG3 ? 0 : t) * C::B_TILE_BYTES, ks, wn * (BN / 2) + j * 16, lm, q, C::WG3 ? t : 0);
-          } else {
-            const int row = wn * (BN / 2) + j * 16 + lm;
-            bf[j] = *(const uint4*)(smB + t * C::B_TILE_BYTES + row * C::PITCH_NT + nt_swz<KSUB>(row, ks * 4 + q) * 16);
-          }
+          if constexpr (AMODE == GA_TR) mma<T>(af[st & 1][i], bf[st & 1][j], acc[C::WG3 ? t : 0][i][j]);   // TN products keep the natural fragment (atomic epilogue)
+          else mma<T>(bf[st & 1][j], af[st & 1][i], acc[0][i][j]);                                        // swapped: acc = (B.A^T) fragment
         }
-#pragma unroll
-        for (int i = 0; i < 4; i++)
-#pragma unroll
-          for (int j = 0; j < FN; j++) {
-            if constexpr (AMODE == GA_TR) mma<T>(af[i], bf[j], acc[C::WG3 ? t : 0][i][j]);   // TN products keep the natural fragment (atomic epilogue)
-            else mma<T>(bf[j], af[i], acc[0][i][j]);                               // swapped: acc = (B.A^T) fragment
-          }
-      }
     }
     TSTAMP();   // after the MFMA phase of stage s
     if constexpr (!C::USE_DMA) __syncthreads();   // single buffer: reads of stage s done before stage s+1 is written
@@ -618,22 +640,22 @@ int launch_k(eegldm_ctx* ctx, const GemmArgs& a) {
   using C = Cfg<T, AMODE, BMODE, TAPS, KSUB, BN, STRIDE, WMT, DMA>;
   auto kern = gemm_kernel<T, AMODE, BMODE, TAPS, KSUB, BN, STRIDE, WMT, DMA>;
   static bool attr_set = false;
-  static_assert(C::LDS_BYTES <= 160 * 1024, "tile does not fit the 160 KiB LDS");
-  if (!attr_set && C::LDS_BYTES > 48 * 1024) {
-    HIP_TRY(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES));
+  static_assert(C::LDS_BYTES + 64 <= 160 * 1024, "tile does not fit the 160 KiB LDS");
+  if (!attr_set && C::LDS_BYTES + 64 > 48 * 1024) {
+    HIP_TRY(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES + 64));
     attr_set = true;
   }
   dim3 grid((a.N + BN - 1) / BN, (a.M + C::BM - 1) / C::BM, a.batch * a.ztaps * a.splitk);
 #ifdef EEG_STAGE_TIMING
   static const int lds_pad = getenv("EEGLDM_GEMM_LDS_PAD") ? atoi(getenv("EEGLDM_GEMM_LDS_PAD")) : 0;   // occupancy experiments
   if (lds_pad) {
-    HIP_TRY(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES + lds_pad));
-    hipLaunchKernelGGL(kern, grid, dim3(C::NTHREADS), C::LDS_BYTES + lds_pad, ctx->stream, a);
+    HIP_TRY(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES + 64 + lds_pad));
+    hipLaunchKernelGGL(kern, grid, dim3(C::NTHREADS), C::LDS_BYTES + 64 + lds_pad, ctx->stream, a);
     LAUNCH_CHECK();
     return 0;
   }
 #endif
-  hipLaunchKernelGGL(kern, grid, dim3(C::NTHREADS), C::LDS_BYTES, ctx->stream, a);
+  hipLaunchKernelGGL(kern, grid, dim3(C::NTHREADS), C::LDS_BYTES + 64, ctx->stream, a);
   LAUNCH_CHECK();
   return 0;
 }
