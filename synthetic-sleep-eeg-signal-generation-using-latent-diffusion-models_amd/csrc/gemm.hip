@@ -667,6 +667,11 @@ int launch_t(eegldm_ctx* ctx, const GemmArgs& a) {
   if constexpr (AMODE == GA_CONV && TAPS == 3) {
     if (a.K % KSTAGE == 0 && a.splitk == 1) return launch_k<T, AMODE, BMODE, TAPS, KSUB, BN, STRIDE, WMT, true>(ctx, a);
   }
+  if constexpr (AMODE == GA_PLAIN && WMT == 2) {
+    // 1x1 conv / Linear / attention products: same double-buffered DMA ring (K % KSTAGE == 0 on all production shapes)
+    static const bool no_dma1 = getenv("EEGLDM_GEMM1_NO_DMA") != nullptr;
+    if (!no_dma1 && a.K % KSTAGE == 0 && a.splitk == 1) return launch_k<T, AMODE, BMODE, TAPS, KSUB, BN, STRIDE, WMT, true>(ctx, a);
+  }
   if constexpr (AMODE == GA_TR && BMODE == GB_TR && WMT == 2) {
     // weight gradients (fused 3-tap and 1-tap / Linear): every split is a whole number of stages when K is, and the source
     // of a chunk moves by a constant per stage unless the K index is remapped per tap (conv_map: unfused strided wgrad)
