@@ -114,6 +114,7 @@ struct GemmArgs {
   const void* resid; long ldr;                            // residual add (dtype)
   int out_f32;           // C is float regardless of dtype
   int atomic_out;        // C += result via float atomics (requires out_f32)
+  int xcd_swizzle;       // set by the launcher: XCD-aware tile order (see gemm_kernel)
   const void* zero_page; // >= 16 zero bytes in device memory (set by gemm_launch)
 };
 int gemm_launch(eegldm_ctx* ctx, const GemmArgs& a);

@@ -142,7 +142,10 @@ struct Cfg {
   // LDS-DMA into a double-buffered ring (one barrier per stage); the 1-tap kernels (1x1 / Linear / attention / wgrad)
   // are fastest with register staging (global -> VGPR prefetch under the MFMA phase -> ds_write), single buffer.
   static constexpr bool USE_DMA = DMA;   // host picks DMA for the 3-tap conv kernels when K is a whole number of stages
-  static constexpr int NSTG = !USE_DMA ? 1 : ((WMT == 4 && 3 * STAGE_BYTES <= 160 * 1024) ? 3 : 2);   // LDS ring depth
+  // LDS ring depth: 2 for the 3-tap conv tiles (33 KB stages, 2 blocks per CU), 3 for the 256-row variant, and 4 for the
+  // short-stage (KSUB == 1) 1-tap tiles -- a 16 KB stage holds only 16 MFMAs per wave (~260 cycles), far less than the
+  // ~2500-cycle DMA latency, so three stages are kept in flight
+  static constexpr int NSTG = !USE_DMA ? 1 : ((WMT == 4 && 3 * STAGE_BYTES <= 160 * 1024) ? 3 : ((TAPS == 1 && KSUB == 1 && AMODE != GA_CONV) ? 4 : 2));
   static constexpr int CA = (A_CHUNKS + NTHREADS - 1) / NTHREADS;  // register-staged 16-byte chunks per thread
   static constexpr int CB = (B_CHUNKS + NTHREADS - 1) / NTHREADS;
   static constexpr int NSTG_BYTES_HINT = NSTG * STAGE_BYTES;
@@ -182,8 +185,18 @@ __global__ __launch_bounds__(128 * WMT, 2) void gemm_kernel(const GemmArgs p) { 
   const int lane = tid & 63, wave = tid >> 6;
   const int lm = lane & 15, q = lane >> 4;
   const int wm = wave >> 1, wn = wave & 1;
-  const int n0 = blockIdx.x * BN;
-  const int m0 = blockIdx.y * BM;
+  // XCD-aware tile order.  Workgroups are dealt round-robin to the 8 XCDs (linear id % 8), each with its own L2.  With the
+  // plain (x = N tile, y = M tile) order the N tiles of one M tile -- which all read the same A rows -- land on different
+  // XCDs and every L2 fetches those rows again.  When the M tile count is a multiple of 8, XCD x instead walks M tiles
+  // x, x+8, ... and runs all N tiles of an M tile back to back, so A rows are fetched into one L2 once.
+  int tile_n = blockIdx.x, tile_m = blockIdx.y;
+  if (p.xcd_swizzle) {
+    const int w = blockIdx.y * gridDim.x + blockIdx.x, xcd = w & 7, slot = w >> 3;
+    tile_n = slot % (int)gridDim.x;
+    tile_m = (slot / (int)gridDim.x) * 8 + xcd;
+  }
+  const int n0 = tile_n * BN;
+  const int m0 = tile_m * BM;
   int z = blockIdx.z;
   const int ksplit = z % p.splitk; z /= p.splitk;
   const int tz = z % p.ztaps;      z /= p.ztaps;
@@ -390,7 +403,8 @@ __global__ __launch_bounds__(128 * WMT, 2) void gemm_kernel(const GemmArgs p) { 
   constexpr int PER = C::IA + C::IB;
   if constexpr (C::USE_DMA) {
     issue_stage(0, 0);
-    if constexpr (C::NSTG == 3) { if (nstages > 1) issue_stage(1, 1); }
+#pragma unroll
+    for (int k = 1; k < C::NSTG - 1; k++) if (k < nstages) issue_stage(k, k);
   } else {
     load_stage(0);
   }
@@ -407,12 +421,15 @@ __global__ __launch_bounds__(128 * WMT, 2) void gemm_kernel(const GemmArgs p) { 
       store_stage();
       __syncthreads();
       if (s + 1 < nstages) load_stage(s + 1);
-    } else if constexpr (C::NSTG == 3) {
-      if (s + 1 < nstages) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PER) : "memory");
+    } else if constexpr (C::NSTG > 2) {
+      // stage s has landed once at most min(NSTG-2, stages issued after s) * PER of this wave's DMAs are outstanding
+      const int ahead = min(nstages - 1 - s, C::NSTG - 2);
+      if (ahead >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * PER) : "memory");
+      else if (ahead == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PER) : "memory");
       else dma_wait_all();
       __builtin_amdgcn_s_barrier();
       asm volatile("" ::: "memory");
-      if (s + 2 < nstages) issue_stage(s + 2, (s + 2) % 3);
+      if (s + C::NSTG - 1 < nstages) issue_stage(s + C::NSTG - 1, (s + C::NSTG - 1) % C::NSTG);
     } else {
       // vmcnt(0) + barrier: stage s has landed in buffer s&1, and every wave is done reading buffer (s+1)&1
       dma_wait_all();
@@ -636,7 +653,7 @@ __global__ __launch_bounds__(128 * WMT, 2) void gemm_kernel(const GemmArgs p) { 
 }
 
 template <typename T, int AMODE, int BMODE, int TAPS, int KSUB, int BN, int STRIDE, int WMT, bool DMA>
-int launch_k(eegldm_ctx* ctx, const GemmArgs& a) {
+int launch_k(eegldm_ctx* ctx, const GemmArgs& a_in) {
   using C = Cfg<T, AMODE, BMODE, TAPS, KSUB, BN, STRIDE, WMT, DMA>;
   auto kern = gemm_kernel<T, AMODE, BMODE, TAPS, KSUB, BN, STRIDE, WMT, DMA>;
   static bool attr_set = false;
@@ -645,7 +662,9 @@ int launch_k(eegldm_ctx* ctx, const GemmArgs& a) {
     HIP_TRY(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES + 64));
     attr_set = true;
   }
+  GemmArgs a = a_in;
   dim3 grid((a.N + BN - 1) / BN, (a.M + C::BM - 1) / C::BM, a.batch * a.ztaps * a.splitk);
+  a.xcd_swizzle = (a_in.xcd_swizzle && grid.x > 1 && grid.y % 8 == 0) ? 1 : 0;
 #ifdef EEG_STAGE_TIMING
   static const int lds_pad = getenv("EEGLDM_GEMM_LDS_PAD") ? atoi(getenv("EEGLDM_GEMM_LDS_PAD")) : 0;   // occupancy experiments
   if (lds_pad) {
@@ -711,6 +730,11 @@ int launch_modes(eegldm_ctx* ctx, const GemmArgs& a) {
     return launch_t<T, GA_TR, GB_TR, 3, 2, 32, 1, 2>(ctx, a);
   }
   EEG_CHECK(a.taps == 1, "taps>1 needs conv A mode");
+  static const bool deep1 = getenv("EEGLDM_GEMM1_DEEP") != nullptr;   // short stages, 4-deep DMA ring (see Cfg::NSTG)
+  if (deep1 && a.amode == GA_PLAIN && a.splitk == 1 && a.K % Tr<T>::KC == 0) {
+    if (a.bmode == GB_NT) return launch_bn<T, GA_PLAIN, GB_NT, 1, 1, 1>(ctx, a);
+    return launch_bn<T, GA_PLAIN, GB_TR, 1, 1, 1>(ctx, a);
+  }
   if (a.amode == GA_PLAIN && a.bmode == GB_NT) return launch_bn<T, GA_PLAIN, GB_NT, 1, 2, 1>(ctx, a);
   if (a.amode == GA_PLAIN && a.bmode == GB_TR) return launch_bn<T, GA_PLAIN, GB_TR, 1, 2, 1>(ctx, a);
   if (a.amode == GA_TR && a.bmode == GB_TR) return launch_bn<T, GA_TR, GB_TR, 1, 2, 1>(ctx, a);
@@ -739,6 +763,7 @@ int gemm_launch(eegldm_ctx* ctx, const GemmArgs& a_in) {
   EEG_CHECK(!a.rowvec || a.ld_rowvec % 4 == 0, "ld_rowvec must be a multiple of 4");
   if (a.splitk > 1) a.atomic_out = 1;
   a.zero_page = ctx->zero_page;
+  { static const bool no_swz = getenv("EEGLDM_GEMM_NO_XCD_SWIZZLE") != nullptr; a.xcd_swizzle = no_swz ? 0 : 1; }
   ProfRec rec; bool prof = ctx->prof_on;
   if (prof) {
     rec.cls = a.amode == GA_CONV ? (a.bmode == GB_NT ? PROF_CONV_FWD : PROF_CONV_DGRAD)
