@@ -190,14 +190,21 @@ __global__ __launch_bounds__(128 * WMT, 2) void gemm_kernel(const GemmArgs p) { 
   // XCDs and every L2 fetches those rows again.  When the M tile count is a multiple of 8, XCD x instead walks M tiles
   // x, x+8, ... and runs all N tiles of an M tile back to back, so A rows are fetched into one L2 once.
   int tile_n = blockIdx.x, tile_m = blockIdx.y;
-  if (p.xcd_swizzle) {
+  int z = blockIdx.z;
+  if (p.xcd_swizzle == 1) {
     const int w = blockIdx.y * gridDim.x + blockIdx.x, xcd = w & 7, slot = w >> 3;
     tile_n = slot % (int)gridDim.x;
     tile_m = (slot / (int)gridDim.x) * 8 + xcd;
+  } else if (p.xcd_swizzle == 2) {
+    // split-K weight gradients: the tiles of one K split all read the same dY / X rows -> one split per XCD at a time
+    const int tiles = gridDim.x * gridDim.y;
+    const int w = (blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x, xcd = w & 7, slot = w >> 3;
+    const int tile = slot % tiles;
+    z = (slot / tiles) * 8 + xcd;
+    tile_n = tile % (int)gridDim.x; tile_m = tile / (int)gridDim.x;
   }
   const int n0 = tile_n * BN;
   const int m0 = tile_m * BM;
-  int z = blockIdx.z;
   const int ksplit = z % p.splitk; z /= p.splitk;
   const int tz = z % p.ztaps;      z /= p.ztaps;
   const int bz = z;
@@ -664,7 +671,11 @@ int launch_k(eegldm_ctx* ctx, const GemmArgs& a_in) {
   }
   GemmArgs a = a_in;
   dim3 grid((a.N + BN - 1) / BN, (a.M + C::BM - 1) / C::BM, a.batch * a.ztaps * a.splitk);
-  a.xcd_swizzle = (a_in.xcd_swizzle && grid.x > 1 && grid.y % 8 == 0) ? 1 : 0;
+  a.xcd_swizzle = 0;
+  if (a_in.xcd_swizzle) {
+    if (AMODE == GA_TR && a.splitk > 1) { if (a.batch * a.ztaps == 1 && a.splitk % 8 == 0 && grid.x * grid.y > 1) a.xcd_swizzle = 2; }
+    else if (grid.x > 1 && grid.y % 8 == 0) a.xcd_swizzle = 1;
+  }
 #ifdef EEG_STAGE_TIMING
   static const int lds_pad = getenv("EEGLDM_GEMM_LDS_PAD") ? atoi(getenv("EEGLDM_GEMM_LDS_PAD")) : 0;   // occupancy experiments
   if (lds_pad) {
