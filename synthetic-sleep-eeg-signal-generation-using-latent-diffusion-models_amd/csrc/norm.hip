@@ -171,6 +171,24 @@ __global__ __launch_bounds__(NT) void gn_apply_kernel(const T* __restrict__ x, l
 
 // ------------------------------------------------------------------ backward
 // effective upstream gradient at input row (b,l), channels c..c+V-1
+// (resample mode as a compile-time constant inside streaming loops: a run-time branch around the load makes hipcc wait
+//  for every load separately instead of keeping an unrolled batch in flight)
+template <typename T, int V, int RS>
+__device__ __forceinline__ void load_dy_eff_c(const T* dy, long lddy, int b, int l, int L, int c, float d[V]) {
+  if constexpr (RS == 0) {
+    loadv<T, V>(dy + ((long)b * L + l) * lddy + c, d);
+  } else if constexpr (RS == 1) {
+    loadv<T, V>(dy + ((long)b * (L / 2) + (l >> 1)) * lddy + c, d);
+#pragma unroll
+    for (int k = 0; k < V; k++) d[k] *= 0.5f;
+  } else {
+    float e[V];
+    loadv<T, V>(dy + ((long)b * 2 * L + 2 * l) * lddy + c, d);
+    loadv<T, V>(dy + ((long)b * 2 * L + 2 * l + 1) * lddy + c, e);
+#pragma unroll
+    for (int k = 0; k < V; k++) d[k] += e[k];
+  }
+}
 template <typename T, int V>
 __device__ __forceinline__ void load_dy_eff(const T* dy, long lddy, int b, int l, int L, int c, int resample, float d[V]) {
   if (resample == 0) {
@@ -190,12 +208,12 @@ __device__ __forceinline__ void load_dy_eff(const T* dy, long lddy, int b, int l
 
 // grid (LSPLIT, B): group sums S1 = sum dz*gamma, S2 = sum dz*gamma*xhat -> gsums double [B][G][2];
 // dgamma[c] += sum dz*xhat, dbeta[c] += sum dz (fp32 atomics)
-template <typename T, int V>
+template <typename T, int V, int RS>
 __global__ __launch_bounds__(NT) void gn_bwd_reduce_kernel(const T* __restrict__ x, long ldx, const float* __restrict__ gamma,
                                                            const float* __restrict__ beta, const float* __restrict__ stats,
                                                            const T* __restrict__ dy, long lddy, double* __restrict__ gsums,
                                                            float* __restrict__ slots,
-                                                           int L, int C, int G, int silu, int resample, int rows_per_block) {
+                                                           int L, int C, int G, int silu, int rows_per_block) {
   __shared__ float accg[2 * MAXG_LDS];
   __shared__ float accc[2 * MAXG_LDS];
   const int b = blockIdx.y, tid = threadIdx.x;
@@ -218,7 +236,7 @@ __global__ __launch_bounds__(NT) void gn_bwd_reduce_kernel(const T* __restrict__
       for (int l = l0 + ty; l < l1; l += cm.TY) {
         float v[V], d[V];
         loadv<T, V>(x + ((long)b * L + l) * ldx + c, v);
-        load_dy_eff<T, V>(dy, lddy, b, l, L, c, resample, d);
+        load_dy_eff_c<T, V, RS>(dy, lddy, b, l, L, c, d);
 #pragma unroll
         for (int k = 0; k < V; k++) {
           const float xh = (v[k] - mean) * rstd;
@@ -254,12 +272,12 @@ __global__ void gn_slot_reduce_kernel(float* __restrict__ slots, float* __restri
 }
 
 // dx = rstd * (dz*gamma - S1/n - xhat*S2/n) [+ resample^T(dxr)];  grid (row chunks, B), same tiling as the forward
-template <typename T, int V>
+template <typename T, int V, int RS>
 __global__ __launch_bounds__(NT) void gn_bwd_apply_kernel(const T* __restrict__ x, long ldx, const float* __restrict__ gamma,
                                                           const float* __restrict__ beta, const float* __restrict__ stats,
                                                           const T* __restrict__ dy, long lddy, const double* __restrict__ gsums,
                                                           T* __restrict__ dx, long lddx, const T* __restrict__ dxr, long lddxr,
-                                                          int L, int C, int G, int silu, int resample, int rows_per_block) {
+                                                          int L, int C, int G, int silu, int rows_per_block) {
   const int b = blockIdx.y, tid = threadIdx.x, cpg = C / G;
   const ColMap cm = colmap(C, V);
   if (tid >= cm.TX * cm.TY) return;
@@ -278,7 +296,7 @@ __global__ __launch_bounds__(NT) void gn_bwd_apply_kernel(const T* __restrict__ 
       const long row = (long)b * L + l;
       float v[V], d[V], o[V];
       loadv<T, V>(x + row * ldx + c, v);
-      load_dy_eff<T, V>(dy, lddy, b, l, L, c, resample, d);
+      load_dy_eff_c<T, V, RS>(dy, lddy, b, l, L, c, d);
 #pragma unroll
       for (int k = 0; k < V; k++) {
         const float xh = (v[k] - mean) * rstd;
@@ -288,7 +306,7 @@ __global__ __launch_bounds__(NT) void gn_bwd_apply_kernel(const T* __restrict__ 
       }
       if (dxr) {
         float e[V];
-        load_dy_eff<T, V>(dxr, lddxr, b, l, L, c, resample, e);
+        load_dy_eff_c<T, V, RS>(dxr, lddxr, b, l, L, c, e);
 #pragma unroll
         for (int k = 0; k < V; k++) o[k] += e[k];
       }
@@ -555,7 +573,9 @@ int gn_fwd_t(eegldm_ctx* ctx, const void* x, long ldx, const float* gamma, const
              float* stats, int B, int L, int C, int G, float eps, int silu, int resample, void* xr, long ldxr) {
   if constexpr (V == 4) {
     static const bool off = getenv("EEGLDM_GN_NO_RESIDENT") != nullptr;
-    int rpt = 0; const int cc = off ? 0 : resident_chunk(L, C, G, resample == 1, sizeof(T) == 2 ? 24 : 12, &rpt);
+    int rpt = 0; int cc = off ? 0 : resident_chunk(L, C, G, resample == 1, sizeof(T) == 2 ? 24 : 12, &rpt);
+    // measured (tools/debug/gn_bench.py): wins while the rows are at least a 128-byte line and the blocks fit two rounds
+    if (cc && (cc * (int)sizeof(T) < 128 || (long)(C / cc) * B > 2L * ctx->num_cu)) cc = 0;
     if (cc) {
       const dim3 grid(C / cc, B);
 #define GN_FWD_RES(R) hipLaunchKernelGGL((gn_fwd_resident_kernel<T, R>), grid, dim3(NTB), 0, ctx->stream, (const T*)x, ldx, gamma, beta, \
@@ -587,7 +607,9 @@ int gn_bwd_t(eegldm_ctx* ctx, const void* x, long ldx, const float* gamma, const
   if (colsum_done) *colsum_done = 0;
   if constexpr (V == 4) {
     static const bool off = getenv("EEGLDM_GN_NO_RESIDENT") != nullptr;
-    int rpt = 0; const int cc = off ? 0 : resident_chunk(L, C, G, 0, sizeof(T) == 2 ? 12 : 8, &rpt);
+    int rpt = 0; int cc = off ? 0 : resident_chunk(L, C, G, 0, sizeof(T) == 2 ? 12 : 8, &rpt);
+    // measured (tools/debug/gn_bench.py): the one-pass kernel wins while its blocks fit two rounds of one block per CU
+    if (cc && (cc * (int)sizeof(T) < 128 || (long)(C / cc) * B > 2L * ctx->num_cu)) cc = 0;
     if (cc) {
       const dim3 grid(C / cc, B);
       float* slots = dgamma ? (float*)((char*)ctx->scratch + GN_SLOT_OFFSET) : nullptr;
@@ -608,12 +630,14 @@ int gn_bwd_t(eegldm_ctx* ctx, const void* x, long ldx, const float* gamma, const
   double* gsums = (double*)ctx->scratch;     // zero on entry; shared with the forward sums (stream-ordered)
   int rpb; int ls = pick_lsplit(B, L, C, ctx, &rpb);
   float* slots = dgamma ? (float*)((char*)ctx->scratch + GN_SLOT_OFFSET) : nullptr;
-  hipLaunchKernelGGL((gn_bwd_reduce_kernel<T, V>), dim3(ls, B), dim3(NT), 0, ctx->stream, (const T*)x, ldx, gamma, beta, stats,
-                     (const T*)dy, lddy, gsums, slots, L, C, G, silu, resample, rpb);
-  LAUNCH_CHECK();
+#define GN_BWD_SPLIT(RS) do { \
+    hipLaunchKernelGGL((gn_bwd_reduce_kernel<T, V, RS>), dim3(ls, B), dim3(NT), 0, ctx->stream, (const T*)x, ldx, gamma, beta, stats, \
+                       (const T*)dy, lddy, gsums, slots, L, C, G, silu, rpb); \
+    hipLaunchKernelGGL((gn_bwd_apply_kernel<T, V, RS>), dim3(ls2, B), dim3(NT), 0, ctx->stream, (const T*)x, ldx, gamma, \
+                       beta, stats, (const T*)dy, lddy, gsums, (T*)dx, lddx, (const T*)dxr, lddxr, L, C, G, silu, rpb2); } while (0)
   int rpb2; int ls2 = pick_lsplit(B, L, C, ctx, &rpb2, 16, 8);
-  hipLaunchKernelGGL((gn_bwd_apply_kernel<T, V>), dim3(ls2, B), dim3(NT), 0, ctx->stream, (const T*)x, ldx, gamma,
-                     beta, stats, (const T*)dy, lddy, gsums, (T*)dx, lddx, (const T*)dxr, lddxr, L, C, G, silu, resample, rpb2);
+  if (resample == 0) GN_BWD_SPLIT(0); else if (resample == 1) GN_BWD_SPLIT(1); else GN_BWD_SPLIT(2);
+#undef GN_BWD_SPLIT
   LAUNCH_CHECK();
   const int n_gs = 2 * B * G;
   hipLaunchKernelGGL(gn_slot_reduce_kernel, dim3(((2 * C > n_gs ? 2 * C : n_gs) + 255) / 256), dim3(256), 0, ctx->stream, slots, dgamma, dbeta, C, gsums, n_gs);
