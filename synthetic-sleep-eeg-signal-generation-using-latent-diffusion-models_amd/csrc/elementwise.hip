@@ -90,7 +90,7 @@ template <typename T> __global__ void silu_bwd_kernel(const float* __restrict__ 
 // grid (LSPLIT, B); 4-channel vectors per thread, (column vector, row lane) tiling, LDS reduction over row lanes.
 template <typename T, int V>
 __global__ __launch_bounds__(NT) void colsum_kernel(const T* __restrict__ x, long ldx, float* __restrict__ out, long ldo,
-                                                    float* __restrict__ total, int L, int Cfull, int rows_per_block) {
+                                                    float* __restrict__ total, float* __restrict__ parts, int L, int Cfull, int rows_per_block) {
   __shared__ float acc[1024];
   const int b = blockIdx.y, tid = threadIdx.x;
   // grid.z tiles the channels in chunks of 1024 (qkv biases have 1536, the batched embedding bias ~7k)
@@ -108,7 +108,7 @@ __global__ __launch_bounds__(NT) void colsum_kernel(const T* __restrict__ x, lon
       float s[V];
 #pragma unroll
       for (int k = 0; k < V; k++) s[k] = 0.f;
-#pragma unroll 4
+#pragma unroll 8
       for (int l = l0 + ty; l < l1; l += TY) {
         const T* p = x + ((long)b * L + l) * ldx + c;
         if constexpr (V == 4 && sizeof(T) == 2) {
@@ -128,8 +128,21 @@ __global__ __launch_bounds__(NT) void colsum_kernel(const T* __restrict__ x, lon
   __syncthreads();
   for (int i = tid; i < C; i += NT) {
     if (out) out[(long)b * ldo + i] = acc[i];     // written, not accumulated: single L split only
-    if (total) atomicAdd(total + i, acc[i]);
+    if (parts) parts[((long)b * gridDim.x + blockIdx.x) * Cfull + c0 + i] = acc[i];
+    else if (total) atomicAdd(total + i, acc[i]);
   }
+}
+// second stage of the two-stage total: total[c] += sum over the nparts written partial rows (one thread per channel;
+// thousands of blocks adding atomically into the same C addresses serialised in L2 and cost more than the streaming pass)
+__global__ void colsum_finish_kernel(const float* __restrict__ parts, int nparts, int C, float* __restrict__ total) {
+  __shared__ float red[NT];
+  const int c = blockIdx.x * 64 + (threadIdx.x & 63), seg = threadIdx.x >> 6;      // 64 channels x 4 row lanes per block; grid.y row ranges
+  const int per = (nparts + gridDim.y - 1) / gridDim.y, r0 = blockIdx.y * per, r1 = min(nparts, r0 + per);
+  float s = 0.f;
+  if (c < C) for (int r = r0 + seg; r < r1; r += NT / 64) s += parts[(long)r * C + c];
+  red[threadIdx.x] = s;
+  __syncthreads();
+  if (seg == 0 && c < C) atomicAdd(total + c, red[threadIdx.x] + red[threadIdx.x + 64] + red[threadIdx.x + 128] + red[threadIdx.x + 192]);
 }
 
 // ------------------------------------------------------------------ softmax over rows (unet.py:123)
@@ -310,14 +323,20 @@ int ew_silu_bwd(eegldm_ctx* ctx, const float* dy, const float* x, void* dx, long
 int ew_colsum(eegldm_ctx* ctx, const void* x, long ldx, float* out_ps, long ldo, float* total, int B, int L, int C, int dtype) {
   int lsplit = 1, rpb = L;
   if (!out_ps) {  // free to split L when only the fp32 atomic total is wanted
-    int want = (ctx->num_cu * 4 + B - 1) / B; if (want < 1) want = 1;
+    int want = (ctx->num_cu * 8 + B - 1) / B; if (want < 1) want = 1;   // 8 blocks (2048 threads) per CU: enough loads in flight to stream
     int maxs = (L + 31) / 32; lsplit = want > maxs ? maxs : want; rpb = (L + lsplit - 1) / lsplit; lsplit = (L + rpb - 1) / rpb;
   }
   dim3 grid(lsplit, B, (C + 1023) / 1024);
   const bool v4 = (C % 4 == 0) && (ldx % 4 == 0);
-  if (v4) { DISPATCH_T(dtype, hipLaunchKernelGGL((colsum_kernel<T, 4>), grid, dim3(NT), 0, ctx->stream, (const T*)x, ldx, out_ps, ldo, total, L, C, rpb)); }
-  else { DISPATCH_T(dtype, hipLaunchKernelGGL((colsum_kernel<T, 1>), grid, dim3(NT), 0, ctx->stream, (const T*)x, ldx, out_ps, ldo, total, L, C, rpb)); }
-  LAUNCH_CHECK(); return 0;
+  // totals over many blocks: written partials + a finishing pass instead of same-address atomics
+  float* parts = nullptr;
+  const long nparts = (long)lsplit * B;
+  if (total && nparts >= 64 && (size_t)nparts * C * sizeof(float) <= (16u << 20)) parts = (float*)((char*)ctx->scratch + (8u << 20));
+  if (v4) { DISPATCH_T(dtype, hipLaunchKernelGGL((colsum_kernel<T, 4>), grid, dim3(NT), 0, ctx->stream, (const T*)x, ldx, out_ps, ldo, total, parts, L, C, rpb)); }
+  else { DISPATCH_T(dtype, hipLaunchKernelGGL((colsum_kernel<T, 1>), grid, dim3(NT), 0, ctx->stream, (const T*)x, ldx, out_ps, ldo, total, parts, L, C, rpb)); }
+  LAUNCH_CHECK();
+  if (parts) { hipLaunchKernelGGL(colsum_finish_kernel, dim3((C + 63) / 64, 32), dim3(NT), 0, ctx->stream, parts, (int)nparts, C, total); LAUNCH_CHECK(); }
+  return 0;
 }
 int ew_softmax(eegldm_ctx* ctx, const float* S, void* P, long rows, int n, int dtype) {
   DISPATCH_T(dtype, hipLaunchKernelGGL((softmax_kernel<T>), dim3((unsigned)((rows + 3) / 4)), dim3(NT), 0, ctx->stream, S, (T*)P, rows, n));
