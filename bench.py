@@ -144,8 +144,18 @@ def main():
         k, v = dom
         ach = v["flops"] / (v["ms"] * 1e-3) / 1e12 if v["ms"] > 0 else 0.0
         peak = MFMA_PEAK_TFLOPS[args.dtype]
+        # HBM bytes per launch of this kernel class from the committed PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in
+        # separate runs of the same step, tools/pmc_traffic.py; FETCH_SIZE doubled per the gfx950 note in the guide)
+        traffic, traffic_src = None, None
+        try:
+            pj = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_pmc_hbm_traffic.json")
+            if args.dtype == "bf16" and args.batch == 256:
+                traffic = round(json.load(open(pj))["classes"][k]["hbm_bytes_per_launch"])
+                traffic_src = "profiles/r01_pmc_hbm_traffic.json (bytes per launch, B=256 bf16)"
+        except Exception:
+            pass
         roofline = {"bound": "mfma", "kernel": k, "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4),
-                    "traffic": None, "launches_per_step": v["launches"] // 2, "avg_launch_us": round(1e3 * v["ms"] / max(1, v["launches"]), 2),
+                    "traffic": traffic, "traffic_source": traffic_src, "launches_per_step": v["launches"] // 2, "avg_launch_us": round(1e3 * v["ms"] / max(1, v["launches"]), 2),
                     "gflop_per_launch": round(v["flops"] / max(1, v["launches"]) / 1e9, 3),
                     "all_gemm_classes": {kk: {"tflops": round(vv["flops"] / (vv["ms"] * 1e-3) / 1e12, 1) if vv["ms"] > 0 else 0.0,
                                               "ms_per_step": round(vv["ms"] / 2, 3), "launches_per_step": vv["launches"] // 2}
