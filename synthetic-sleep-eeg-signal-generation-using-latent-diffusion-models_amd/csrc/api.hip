@@ -1,5 +1,6 @@
 // Library plumbing: thread-local error string, context, HIP-event timer.
 #include "common.h"
+#include <stdlib.h>
 
 static thread_local std::string g_err;
 void eegldm_set_error(const std::string& msg) { g_err = msg; }
@@ -30,9 +31,27 @@ extern "C" int eegldm_ctx_create(int device, void* stream, int own_stream, eegld
 #else
   const size_t zp_bytes = 4096;
 #endif
+  if (!getenv("EEGLDM_NO_SIDE_STREAM")) {
+    HIP_TRY(hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking));
+    HIP_TRY(hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
+    HIP_TRY(hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming));
+    c->side_on = true;
+  }
   HIP_TRY(hipMalloc(&c->zero_page, zp_bytes));
   HIP_TRY(hipMemset(c->zero_page, 0, zp_bytes));
   *out = c;
+  return 0;
+}
+int ctx_fork(eegldm_ctx* c) {
+  if (!c->side_on) return 0;
+  HIP_TRY(hipEventRecord(c->ev_fork, c->stream));
+  HIP_TRY(hipStreamWaitEvent(c->side, c->ev_fork, 0));
+  return 0;
+}
+int ctx_join(eegldm_ctx* c) {
+  if (!c->side_on) return 0;
+  HIP_TRY(hipEventRecord(c->ev_join, c->side));
+  HIP_TRY(hipStreamWaitEvent(c->stream, c->ev_join, 0));
   return 0;
 }
 extern "C" int eegldm_ctx_destroy(eegldm_ctx* c) {
@@ -41,6 +60,7 @@ extern "C" int eegldm_ctx_destroy(eegldm_ctx* c) {
   if (c->scratch) hipFree(c->scratch);
   if (c->zero_page) hipFree(c->zero_page);
   if (c->owns_stream) hipStreamDestroy(c->stream);
+  if (c->side) { hipStreamDestroy(c->side); hipEventDestroy(c->ev_fork); hipEventDestroy(c->ev_join); }
   delete c;
   return 0;
 }

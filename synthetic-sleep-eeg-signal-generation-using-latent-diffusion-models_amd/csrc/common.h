@@ -45,12 +45,26 @@ struct eegldm_ctx {
   size_t scratch_bytes;
   int num_cu;
   void* zero_page = nullptr;   // 4 KiB of zeros: source of out-of-range LDS-DMA chunks
+  // second stream for the weight-gradient GEMMs of the backward pass (nothing downstream of a layer needs its dW before
+  // the optimizer): they overlap the dgrad -> GroupNorm-backward chain instead of serialising with it
+  hipStream_t side = nullptr;
+  hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+  bool side_on = false;
   // optional per-launch HIP-event profiling of the GEMM family (bench.py roofline leg)
   bool prof_on = false;
   std::vector<ProfRec> prof;
 };
 
 static inline size_t dtype_size(int dt) { return dt == EEGLDM_F32 ? 4 : 2; }
+// side waits for everything enqueued on the main stream so far / main waits for everything enqueued on the side stream
+int ctx_fork(eegldm_ctx* c);
+int ctx_join(eegldm_ctx* c);
+// RAII: launches inside the scope go to the side stream (pure GEMM work only: the context scratch belongs to the main stream)
+struct SideScope {
+  eegldm_ctx* c; hipStream_t saved;
+  explicit SideScope(eegldm_ctx* ctx) : c(ctx), saved(ctx->stream) { if (c->side_on) c->stream = c->side; }
+  ~SideScope() { c->stream = saved; }
+};
 
 // ---------------------------------------------------------------- device helpers
 __device__ __forceinline__ float bf16_to_f32(bf16_t v) { return __uint_as_float(((unsigned)v) << 16); }

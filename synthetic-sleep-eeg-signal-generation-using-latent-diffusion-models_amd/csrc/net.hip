@@ -61,48 +61,58 @@ int res_forward(NetBase* u, const ResDesc& r, const View& x, int B, int Lin, con
 int res_backward(NetBase* u, const ResDesc& r, const ResTape& t, const View& dout, const View& dx, float* demb_all) {
   eegldm_ctx* ctx = u->ctx; const int dt = u->dtype; const int B = t.B, Lin = t.Lin, Lout = t.Lout;
   Arena::Mark mk = u->arena.mark();
+  const bool pg = u->param_grads;
   View dxr = dout;
+  // weight gradients run on the side stream (pure GEMMs, no context scratch); bias sums stay on the main stream
+  if (pg) {
+    EEG_TRY(ctx_fork(ctx));                       // dout (and everything before) is ready for the side stream
+    SideScope side(ctx);
+    if (r.sk_w >= 0) EEG_TRY(op_conv_wgrad(ctx, dt, t.xr.p, t.xr.ld, dout.p, dout.ld, u->G(r.sk_w), nullptr, B, Lout, r.cin, r.cout, 1, 1, 0, 0));
+    EEG_TRY(op_conv_wgrad(ctx, dt, t.a2.p, t.a2.ld, dout.p, dout.ld, u->G(r.c2_w), nullptr, B, Lout, r.cout, r.cout, 3, 1, 1, 1));
+  }
   if (r.sk_w >= 0) {
-    // the skip conv's bias gradient equals conv2's (both are column sums of dout): computed once below and copied
-    if (u->param_grads) EEG_TRY(op_conv_wgrad(ctx, dt, t.xr.p, t.xr.ld, dout.p, dout.ld, u->G(r.sk_w), nullptr, B, Lout, r.cin, r.cout, 1, 1, 0, 0));
     ALLOC_OR_FAIL(dxr.p, u->alloc_act((long)B * Lout, r.cin)); dxr.ld = r.cin; dxr.C = r.cin;
     EEG_TRY(op_conv_dgrad(ctx, dt, dout.p, dout.ld, u->W(r.sk_w), dxr.p, dxr.ld, B, Lout, r.cin, r.cout, 1, 1, 0, 0, nullptr, 0));
   }
-  if (u->param_grads) {
+  View da2; ALLOC_OR_FAIL(da2.p, u->alloc_act((long)B * Lout, r.cout)); da2.ld = r.cout;
+  EEG_TRY(op_conv_dgrad(ctx, dt, dout.p, dout.ld, u->W(r.c2_w), da2.p, da2.ld, B, Lout, r.cout, r.cout, 3, 1, 1, 1, nullptr, 0));
+  if (pg) {
+    // conv2's bias gradient = column sums of dout; the skip conv's bias gradient is the same vector
     if (r.sk_w >= 0) {
       float* tmp = (float*)((char*)ctx->scratch + (3u << 20));        // [cout] staging in the context scratch
       HIP_TRY(hipMemsetAsync(tmp, 0, sizeof(float) * r.cout, ctx->stream));
       EEG_TRY(ew_colsum(ctx, dout.p, dout.ld, nullptr, 0, tmp, B, Lout, r.cout, dt));
       EEG_TRY(eegldm_axpy(ctx, u->G(r.c2_b), tmp, 1.0f, r.cout));
       EEG_TRY(eegldm_axpy(ctx, u->G(r.sk_b), tmp, 1.0f, r.cout));
-      EEG_TRY(op_conv_wgrad(ctx, dt, t.a2.p, t.a2.ld, dout.p, dout.ld, u->G(r.c2_w), nullptr, B, Lout, r.cout, r.cout, 3, 1, 1, 1));
     } else {
-      EEG_TRY(op_conv_wgrad(ctx, dt, t.a2.p, t.a2.ld, dout.p, dout.ld, u->G(r.c2_w), u->G(r.c2_b), B, Lout, r.cout, r.cout, 3, 1, 1, 1));
+      EEG_TRY(ew_colsum(ctx, dout.p, dout.ld, nullptr, 0, u->G(r.c2_b), B, Lout, r.cout, dt));
     }
   }
-  View da2; ALLOC_OR_FAIL(da2.p, u->alloc_act((long)B * Lout, r.cout)); da2.ld = r.cout;
-  EEG_TRY(op_conv_dgrad(ctx, dt, dout.p, dout.ld, u->W(r.c2_w), da2.p, da2.ld, B, Lout, r.cout, r.cout, 3, 1, 1, 1, nullptr, 0));
   View dh1; ALLOC_OR_FAIL(dh1.p, u->alloc_act((long)B * Lout, r.cout)); dh1.ld = r.cout;
   // h1 = conv(a1) + b1 + emb_out[b]: the per-sample column sums of dh1 feed the embedding MLP, their total is db1.
   // The one-pass GroupNorm backward produces them while dh1 is still in registers; otherwise a separate column sum.
-  const bool pg = u->param_grads;
   float* ps = nullptr; long ldps = 0;
   if (r.emb_col >= 0) { ps = demb_all + r.emb_col; ldps = u->etot; }
   else if (pg) { ALLOC_OR_FAIL(ps, (float*)u->arena.alloc(sizeof(float) * (size_t)B * r.cout)); ldps = r.cout; }
   int cs_done = 0;
   EEG_TRY(op_groupnorm_bwd(ctx, t.h1.p, t.h1.ld, u->P(r.gn2_w), u->P(r.gn2_b), t.st2, da2.p, da2.ld, dh1.p, dh1.ld, pg ? u->G(r.gn2_w) : nullptr, pg ? u->G(r.gn2_b) : nullptr,
                            B, Lout, r.cout, r.groups, 1, 0, nullptr, 0, dt, ps, ldps, &cs_done));
+  if (pg) {
+    EEG_TRY(ctx_fork(ctx));                       // dh1 is ready
+    SideScope side(ctx);
+    EEG_TRY(op_conv_wgrad(ctx, dt, t.a1.p, t.a1.ld, dh1.p, dh1.ld, u->G(r.c1_w), nullptr, B, Lout, r.cin, r.cout, 3, 1, 1, 1));
+  }
   if (cs_done) {
     if (pg) EEG_TRY(ew_colsum(ctx, ps, ldps, nullptr, 0, u->G(r.c1_b), 1, B, r.cout, EEGLDM_F32));
   } else {
     if (r.emb_col >= 0) EEG_TRY(ew_colsum(ctx, dh1.p, dh1.ld, ps, ldps, pg ? u->G(r.c1_b) : nullptr, B, Lout, r.cout, dt));
     else if (pg) EEG_TRY(ew_colsum(ctx, dh1.p, dh1.ld, nullptr, 0, u->G(r.c1_b), B, Lout, r.cout, dt));
   }
-  if (pg) EEG_TRY(op_conv_wgrad(ctx, dt, t.a1.p, t.a1.ld, dh1.p, dh1.ld, u->G(r.c1_w), nullptr, B, Lout, r.cin, r.cout, 3, 1, 1, 1));
   View da1; ALLOC_OR_FAIL(da1.p, u->alloc_act((long)B * Lout, r.cin)); da1.ld = r.cin;
   EEG_TRY(op_conv_dgrad(ctx, dt, dh1.p, dh1.ld, u->W(r.c1_w), da1.p, da1.ld, B, Lout, r.cin, r.cout, 3, 1, 1, 1, nullptr, 0));
   EEG_TRY(eegldm_groupnorm_bwd(ctx, t.x.p, t.x.ld, u->P(r.gn1_w), u->P(r.gn1_b), t.st1, da1.p, da1.ld, dx.p, dx.ld, u->param_grads ? u->G(r.gn1_w) : nullptr, u->param_grads ? u->G(r.gn1_b) : nullptr,
                                B, Lin, r.cin, r.groups, 1, r.updown, dxr.p, dxr.ld, dt));
+  if (pg) EEG_TRY(ctx_join(ctx));                 // the side stream's reads of dout / dh1 / tape are done before the arena is reused
   u->arena.release(mk);
   return 0;
 }
