@@ -158,7 +158,9 @@ struct Cfg {
   static constexpr int EPI_I = (4 * 16 * WMT * EPI_PITCH <= NSTG_BYTES_HINT) ? 4 : 2;
   static constexpr int EPI_ROWS = EPI_I * 16 * WMT;
   static constexpr int EPI_BYTES = EPI_ROWS * EPI_PITCH;
-  static constexpr int LDS_BYTES = (NSTG * STAGE_BYTES) > EPI_BYTES ? (NSTG * STAGE_BYTES) : EPI_BYTES;
+  static constexpr int EPI16_BYTES = (sizeof(T) == 2 && AMODE != GA_TR) ? BM * (BN * 2 + 16) : 0;   // packed bf16 output tile (one pass)
+  static constexpr int LDS_BYTES0 = (NSTG * STAGE_BYTES) > EPI_BYTES ? (NSTG * STAGE_BYTES) : EPI_BYTES;
+  static constexpr int LDS_BYTES = LDS_BYTES0 > EPI16_BYTES ? LDS_BYTES0 : EPI16_BYTES;
 };
 
 typedef __attribute__((address_space(3))) void* lds_void_ptr;
@@ -403,7 +405,37 @@ __global__ __launch_bounds__(128 * WMT, 2) void gemm_kernel(const GemmArgs p) { 
 
   // bias chunk of this thread's epilogue columns: fetched now so its latency hides behind the whole K loop
   float4 bias4 = make_float4(0.f, 0.f, 0.f, 0.f);
-  if (p.bias) { const int nb = n0 + (tid % (BN / 4)) * 4; bias4 = *(const float4*)(p.bias + (nb < p.N ? nb : 0)); }
+  constexpr bool EPI16 = sizeof(T) == 2 && AMODE != GA_TR;      // packed-bf16 epilogue available (see the epilogue)
+  const bool use16 = EPI16 && !p.out_f32 && !p.atomic_out && p.N % 8 == 0 && p.ldc % 8 == 0 && (!p.rowvec || p.rows_per_vec >= BM);
+  if (p.bias && !use16) { const int nb = n0 + (tid % (BN / 4)) * 4; bias4 = *(const float4*)(p.bias + (nb < p.N ? nb : 0)); }
+  // addends of the packed-bf16 epilogue in the fragment layout: bias now, residual / embedding rows during the LAST K stage
+  // (their ~1-2 us latency hides behind that stage's MFMAs instead of opening the epilogue)
+  float4 pf_bias[EPI16 ? FN : 1];
+  uint2 pf_res[EPI16 ? 4 : 1][EPI16 ? FN : 1];
+  if constexpr (EPI16) {
+    if (use16) {
+#pragma unroll
+      for (int j = 0; j < FN; j++) {
+        const int nj = n0 + wn * (BN / 2) + j * 16 + q * 4;
+        pf_bias[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (p.bias) pf_bias[j] = *(const float4*)(p.bias + (nj < p.N ? nj : 0));
+      }
+    }
+  }
+  auto prefetch_epi = [&]() __attribute__((always_inline)) {
+    if constexpr (EPI16) {
+      if (!use16) return;
+      if (p.resid) {
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+          const int mr = m0 + wm * 64 + i * 16 + lm;
+          const T* rp = (const T*)p.resid + (long)(mr < p.M ? mr : m0) * p.ldr;
+#pragma unroll
+          for (int j = 0; j < FN; j++) { const int nj = n0 + wn * (BN / 2) + j * 16 + q * 4; pf_res[i][j] = *(const uint2*)(rp + (nj < p.N ? nj : 0)); }
+        }
+      }
+    }
+  };
 
   // ring of NSTG stage buffers, loads run NSTG-1 stages ahead; each wave issues exactly IA+IB DMA instructions per
   // stage, so "stage s has landed" == at most (NSTG-2)*(IA+IB) of this wave's DMAs still outstanding.
@@ -423,7 +455,9 @@ __global__ __launch_bounds__(128 * WMT, 2) void gemm_kernel(const GemmArgs p) { 
 #define TSTAMP() do {} while (0)
 #endif
   TSTAMP();
-  for (int s = 0; s < nstages; s++) {
+  // one K stage; the last one is a separate copy of the body (peeled) so that the epilogue prefetch registers are not
+  // live -- and not spilled -- across the whole loop
+  auto run_stage = [&](const int s, const bool last) __attribute__((always_inline)) {
     if constexpr (!C::USE_DMA) {
       store_stage();
       __syncthreads();
@@ -444,6 +478,7 @@ __global__ __launch_bounds__(128 * WMT, 2) void gemm_kernel(const GemmArgs p) { 
       if (s + 1 < nstages) issue_stage(s + 1, (s + 1) & 1);
     }
     TSTAMP();   // after wait+barrier(+issue of the next stage)
+    if (last) prefetch_epi();
     const char* smA = smem + (s % C::NSTG) * C::STAGE_BYTES;
     const char* smB = smA + C::A_ALLOC;
     // Fragment loads run one (tap, k-sub) step ahead of the MFMAs that consume them: with one or two waves per SIMD the
@@ -493,7 +528,9 @@ __global__ __launch_bounds__(128 * WMT, 2) void gemm_kernel(const GemmArgs p) { 
     }
     TSTAMP();   // after the MFMA phase of stage s
     if constexpr (!C::USE_DMA) __syncthreads();   // single buffer: reads of stage s done before stage s+1 is written
-  }
+  };
+  for (int s = 0; s + 1 < nstages; s++) run_stage(s, false);
+  run_stage(nstages - 1, true);
   if constexpr (C::USE_DMA) __syncthreads();       // all waves done with the staging buffers before the epilogue tile reuses them
 
   TSTAMP();   // start of epilogue
@@ -538,6 +575,75 @@ __global__ __launch_bounds__(128 * WMT, 2) void gemm_kernel(const GemmArgs p) { 
 #ifdef EEG_STAGE_TIMING
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       TSTAMP();   // atomics retired
+#endif
+      return;
+    }
+  }
+  if constexpr (EPI16) {
+    if (use16) {
+      // bf16 output: bias / embedding / residual are added in the fragment layout (every lane owns 4 consecutive columns of
+      // one row: acc[0][i][j][r] = C[wm*64 + i*16 + lm][wn*(BN/2) + j*16 + q*4 + r]), the result is packed to bf16 FIRST and
+      // only then transposed through LDS: half the LDS bytes of the fp32 tile, one pass, and 16-byte global stores.
+      constexpr int PITCH16 = BN * 2 + 16;
+      static_assert(BM * PITCH16 <= C::LDS_BYTES, "bf16 epilogue tile must fit the staging area");
+      float4 pf_rv[2][FN];
+      int pf_bnd = 0;
+      if (p.rowvec) {
+        // a tile of BM rows touches at most two samples (rows_per_vec >= BM is part of use16)
+        const int s0 = m0 / p.rows_per_vec;
+        pf_bnd = (s0 + 1) * p.rows_per_vec;
+        const int s1 = min(s0 + 1, (p.M - 1) / p.rows_per_vec);
+#pragma unroll
+        for (int j = 0; j < FN; j++) {
+          const int nj = n0 + wn * (BN / 2) + j * 16 + q * 4, nc = nj < p.N ? nj : 0;
+          pf_rv[0][j] = *(const float4*)(p.rowvec + (long)s0 * p.ld_rowvec + nc);
+          pf_rv[1][j] = *(const float4*)(p.rowvec + (long)s1 * p.ld_rowvec + nc);
+        }
+      }
+#pragma unroll
+      for (int i = 0; i < 4; i++) {
+        const bool hi = p.rowvec && (m0 + wm * 64 + i * 16 + lm) >= pf_bnd;
+#pragma unroll
+        for (int j = 0; j < FN; j++) {
+          float4 a = pf_bias[j];
+          if (p.rowvec) {
+            a.x += hi ? pf_rv[1][j].x : pf_rv[0][j].x; a.y += hi ? pf_rv[1][j].y : pf_rv[0][j].y;
+            a.z += hi ? pf_rv[1][j].z : pf_rv[0][j].z; a.w += hi ? pf_rv[1][j].w : pf_rv[0][j].w;
+          }
+          if (p.resid) {
+            a.x += __uint_as_float(pf_res[i][j].x << 16); a.y += __uint_as_float(pf_res[i][j].x & 0xffff0000u);
+            a.z += __uint_as_float(pf_res[i][j].y << 16); a.w += __uint_as_float(pf_res[i][j].y & 0xffff0000u);
+          }
+          uint2 o;
+          o.x = pack_bf16x2(acc[0][i][j][0] * p.alpha + a.x, acc[0][i][j][1] * p.alpha + a.y);
+          o.y = pack_bf16x2(acc[0][i][j][2] * p.alpha + a.z, acc[0][i][j][3] * p.alpha + a.w);
+          *(uint2*)(smem + (wm * 64 + i * 16 + lm) * PITCH16 + (wn * (BN / 2) + j * 16 + q * 4) * 2) = o;
+        }
+      }
+      TSTAMP();   // E1: LDS tile written
+      __syncthreads();
+      TSTAMP();   // E2
+      constexpr int CH8 = BN / 8;                       // 16-byte chunks per row
+      static_assert(NTHREADS % CH8 == 0, "");
+      constexpr int RSTEP8 = NTHREADS / CH8;
+      constexpr int NIT8 = (BM + RSTEP8 - 1) / RSTEP8;
+      const int cs8 = tid % CH8, r08 = tid / CH8;
+      const int n8 = n0 + cs8 * 8;
+      uint4 v8[NIT8];
+#pragma unroll
+      for (int cc = 0; cc < NIT8; cc++) {
+        const int row = r08 + cc * RSTEP8;
+        v8[cc] = *(const uint4*)(smem + (row < BM ? row : 0) * PITCH16 + cs8 * 16);
+      }
+#pragma unroll
+      for (int cc = 0; cc < NIT8; cc++) {
+        const int row = r08 + cc * RSTEP8, mg = m0 + row;
+        if (row < BM && mg < p.M && n8 < p.N) *(uint4*)((bf16_t*)Cb + cbase + (long)mg * p.ldc + n8) = v8[cc];
+      }
+      TSTAMP(); TSTAMP(); TSTAMP();   // keep the stamp count of the fp32 path
+#ifdef EEG_STAGE_TIMING
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      TSTAMP();
 #endif
       return;
     }
