@@ -43,13 +43,13 @@ extern "C" int eegldm_ctx_create(int device, void* stream, int own_stream, eegld
   return 0;
 }
 int ctx_fork(eegldm_ctx* c) {
-  if (!c->side_on) return 0;
+  if (!c->side_on || c->prof_on) return 0;
   HIP_TRY(hipEventRecord(c->ev_fork, c->stream));
   HIP_TRY(hipStreamWaitEvent(c->side, c->ev_fork, 0));
   return 0;
 }
 int ctx_join(eegldm_ctx* c) {
-  if (!c->side_on) return 0;
+  if (!c->side_on || c->prof_on) return 0;
   HIP_TRY(hipEventRecord(c->ev_join, c->side));
   HIP_TRY(hipStreamWaitEvent(c->stream, c->ev_join, 0));
   return 0;

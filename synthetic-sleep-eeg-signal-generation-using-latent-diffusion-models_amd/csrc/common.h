@@ -62,7 +62,7 @@ int ctx_join(eegldm_ctx* c);
 // RAII: launches inside the scope go to the side stream (pure GEMM work only: the context scratch belongs to the main stream)
 struct SideScope {
   eegldm_ctx* c; hipStream_t saved;
-  explicit SideScope(eegldm_ctx* ctx) : c(ctx), saved(ctx->stream) { if (c->side_on) c->stream = c->side; }
+  explicit SideScope(eegldm_ctx* ctx) : c(ctx), saved(ctx->stream) { if (c->side_on && !c->prof_on) c->stream = c->side; }   // serial while kernels are being timed
   ~SideScope() { c->stream = saved; }
 };
 
