@@ -56,6 +56,242 @@ __global__ __launch_bounds__(NT) void dconv_point_kernel(const DArgs a) {
   }
 }
 
+// thread per output ROW when both sides are thin (<= 8 channels, padded up to CI / CO in {1,2,4,8}): weights and bias
+// sit in LDS (broadcast reads), the input taps are read once per row as one vector when the layout allows, all outputs of
+// the row leave as one vector.  The per-(row, channel) kernel above paid two integer divisions and up to 24 scalar
+// 2-byte loads per OUTPUT ELEMENT (25 us for a 3 MB tensor).
+template <typename T, int N> struct RowVec { T v[N]; };
+template <typename T, int CI, int CO>
+__global__ __launch_bounds__(NT) void dconv_row_kernel(const DArgs a) {
+  __shared__ float wl[3 * 8 * 8];
+  __shared__ float bl[8];
+  const int nw = a.K * a.Co * a.Ci;
+  for (int i = threadIdx.x; i < a.K * CO * CI; i += NT) {
+    const int t = i / (CO * CI), o = (i / CI) % CO, ci = i % CI;
+    wl[i] = (o < a.Co && ci < a.Ci) ? wsel<T>(a, t, o, ci) : 0.f;
+  }
+  (void)nw;
+  if (threadIdx.x < CO) bl[threadIdx.x] = (a.bias && threadIdx.x < a.Co) ? a.bias[threadIdx.x] : 0.f;
+  __syncthreads();
+  const long rows = (long)a.B * a.Lo;
+  const bool vin = (a.Ci == CI) && (a.ldin % CI == 0), vout = (a.Co == CO) && (a.ldout % CO == 0) && (!a.resid || a.ldr % CO == 0);
+  for (long r = (long)blockIdx.x * NT + threadIdx.x; r < rows; r += (long)gridDim.x * NT) {
+    const int b = (int)(r / a.Lo), l = (int)(r - (long)b * a.Lo);
+    float acc[CO];
+#pragma unroll
+    for (int o = 0; o < CO; o++) acc[o] = bl[o];
+    for (int t = 0; t < a.K; t++) {
+      const int v = in_pos(a, l, t);
+      if (v < 0) continue;
+      const T* xin = (const T*)a.in + ((long)b * a.Li + v) * a.ldin;
+      float xv[CI];
+      if (vin) {
+        const RowVec<T, CI> rv = *(const RowVec<T, CI>*)xin;
+#pragma unroll
+        for (int i = 0; i < CI; i++) xv[i] = ld_f32(&rv.v[i]);
+      } else {
+#pragma unroll
+        for (int i = 0; i < CI; i++) xv[i] = i < a.Ci ? ld_f32(xin + i) : 0.f;
+      }
+      const float* wt = wl + t * CO * CI;
+#pragma unroll
+      for (int o = 0; o < CO; o++)
+#pragma unroll
+        for (int i = 0; i < CI; i++) acc[o] += xv[i] * wt[o * CI + i];
+    }
+    T* op = (T*)a.out + r * a.ldout;
+    if (vout) {
+      if (a.resid) {
+        const RowVec<T, CO> rr = *(const RowVec<T, CO>*)((const T*)a.resid + r * a.ldr);
+#pragma unroll
+        for (int o = 0; o < CO; o++) acc[o] += ld_f32(&rr.v[o]);
+      }
+      RowVec<T, CO> ov;
+#pragma unroll
+      for (int o = 0; o < CO; o++) st_f32(&ov.v[o], acc[o]);
+      *(RowVec<T, CO>*)op = ov;
+    } else {
+#pragma unroll
+      for (int o = 0; o < CO; o++) {
+        if (o < a.Co) {
+          float s = acc[o];
+          if (a.resid) s += ld_f32((const T*)a.resid + r * a.ldr + o);
+          st_f32(op + o, s);
+        }
+      }
+    }
+  }
+}
+
+// ---- wide side handled as 16-byte channel groups (G = 8 bf16 / 4 fp32 channels per thread) ----------------------------
+// thin input (Ci <= 8), wide output (Co % G == 0): thread per (row, channel group); weights for the group in registers
+template <typename T>
+__global__ __launch_bounds__(NT) void dconv_thin_in_kernel(const DArgs a) {
+  constexpr int G = 16 / sizeof(T);
+  extern __shared__ float wl[];                                  // [K][Ci][Co] (output channel fastest) followed by bias [Co]
+  for (int i = threadIdx.x; i < a.K * a.Ci * a.Co; i += NT) {
+    const int o = i % a.Co, ci = (i / a.Co) % a.Ci, t = i / (a.Co * a.Ci);
+    wl[i] = wsel<T>(a, t, o, ci);
+  }
+  float* bl = wl + a.K * a.Ci * a.Co;
+  for (int i = threadIdx.x; i < a.Co; i += NT) bl[i] = a.bias ? a.bias[i] : 0.f;
+  __syncthreads();
+  const int gpr = a.Co / G;                                    // channel groups per row
+  const long total = (long)a.B * a.Lo * gpr;
+  for (long idx = (long)blockIdx.x * NT + threadIdx.x; idx < total; idx += (long)gridDim.x * NT) {
+    const long r = idx / gpr;
+    const int o0 = (int)(idx - r * gpr) * G;
+    const int b = (int)(r / a.Lo), l = (int)(r - (long)b * a.Lo);
+    float acc[G];
+#pragma unroll
+    for (int k = 0; k < G; k++) acc[k] = bl[o0 + k];
+    for (int t = 0; t < a.K; t++) {
+      const int v = in_pos(a, l, t);
+      if (v < 0) continue;
+      const T* xin = (const T*)a.in + ((long)b * a.Li + v) * a.ldin;
+      for (int i = 0; i < a.Ci; i++) {
+        const float xv = ld_f32(xin + i);
+        const float* wp = wl + ((long)t * a.Ci + i) * a.Co + o0;
+#pragma unroll
+        for (int k = 0; k < G; k++) acc[k] += xv * wp[k];
+      }
+    }
+    if (a.resid) {
+      const RowVec<T, G> rr = *(const RowVec<T, G>*)((const T*)a.resid + r * a.ldr + o0);
+#pragma unroll
+      for (int k = 0; k < G; k++) acc[k] += ld_f32(&rr.v[k]);
+    }
+    RowVec<T, G> ov;
+#pragma unroll
+    for (int k = 0; k < G; k++) st_f32(&ov.v[k], acc[k]);
+    *(RowVec<T, G>*)((T*)a.out + r * a.ldout + o0) = ov;
+  }
+}
+// wide input (Ci % G == 0, Ci/G a power of two <= 64), thin output (Co <= 8): Ci/G lanes per row, shuffle reduction
+template <typename T>
+__global__ __launch_bounds__(NT) void dconv_thin_out_kernel(const DArgs a) {
+  constexpr int G = 16 / sizeof(T);
+  extern __shared__ float wl[];                                  // [K][Co][Ci]
+  for (int i = threadIdx.x; i < a.K * a.Co * a.Ci; i += NT) {
+    const int t = i / (a.Co * a.Ci), o = (i / a.Ci) % a.Co, ci = i % a.Ci;
+    wl[i] = wsel<T>(a, t, o, ci);
+  }
+  __syncthreads();
+  const int lpr = a.Ci / G, lane = threadIdx.x % lpr, rpb = NT / lpr;
+  const long rows = (long)a.B * a.Lo;
+  for (long r = (long)blockIdx.x * rpb + threadIdx.x / lpr; r < rows + rpb; r += (long)gridDim.x * rpb) {   // uniform trip count for the shuffles
+    const bool ok = r < rows;
+    const long rc = ok ? r : rows - 1;
+    const int b = (int)(rc / a.Lo), l = (int)(rc - (long)b * a.Lo);
+    float acc[8];
+#pragma unroll
+    for (int o = 0; o < 8; o++) acc[o] = 0.f;
+    for (int t = 0; t < a.K; t++) {
+      const int v = in_pos(a, l, t);
+      if (v < 0) continue;
+      const RowVec<T, G> rv = *(const RowVec<T, G>*)((const T*)a.in + ((long)b * a.Li + v) * a.ldin + lane * G);
+      float xv[G];
+#pragma unroll
+      for (int k = 0; k < G; k++) xv[k] = ld_f32(&rv.v[k]);
+#pragma unroll
+      for (int o = 0; o < 8; o++) {
+        if (o < a.Co) {
+          const float* wp = wl + ((long)t * a.Co + o) * a.Ci + lane * G;
+#pragma unroll
+          for (int k = 0; k < G; k++) acc[o] += xv[k] * wp[k];
+        }
+      }
+    }
+#pragma unroll
+    for (int o = 0; o < 8; o++) {
+      if (o >= a.Co) break;
+      float s = acc[o];
+      for (int d = lpr >> 1; d > 0; d >>= 1) s += __shfl_xor(s, d, 64);
+      if (lane == 0 && ok) {
+        if (a.bias) s += a.bias[o];
+        if (a.resid) s += ld_f32((const T*)a.resid + r * a.ldr + o);
+        st_f32((T*)a.out + r * a.ldout + o, s);
+      }
+    }
+  }
+}
+// weight gradient of a (thin <= 2) x (wide % G == 0) conv: dW[t][co][ci] += sum_r dy[r][co] * x[in_row(r,t)][ci].
+// WIDE_OUT: the wide side is Cout (dy rows are wide, x is thin) else Cin (x rows wide, dy thin).
+template <typename T, bool WIDE_OUT>
+__global__ __launch_bounds__(NT) void dconv_wgrad_wt_kernel(const T* __restrict__ x, long ldx, const T* __restrict__ dy, long lddy,
+                                                            float* __restrict__ dw, int B, int Lo, int Li, int Cout, int Cin, int K,
+                                                            int stride, int pad_l) {
+  constexpr int G = 16 / sizeof(T);
+  __shared__ float red[NT];
+  const int wide = WIDE_OUT ? Cout : Cin, thin = WIDE_OUT ? Cin : Cout;
+  const int lpr = wide / G, lane = threadIdx.x % lpr, rpb = NT / lpr, rl = threadIdx.x / lpr;
+  float acc[3][2][G];
+#pragma unroll
+  for (int t = 0; t < 3; t++)
+#pragma unroll
+    for (int j = 0; j < 2; j++)
+#pragma unroll
+      for (int k = 0; k < G; k++) acc[t][j][k] = 0.f;
+  const long rows = (long)B * Lo;
+#pragma unroll 4
+  for (long r = (long)blockIdx.x * rpb + rl; r < rows; r += (long)gridDim.x * rpb) {
+    const int b = (int)(r / Lo), lo = (int)(r - (long)b * Lo);
+    if (WIDE_OUT) {
+      const RowVec<T, G> dv = *(const RowVec<T, G>*)(dy + r * lddy + lane * G);
+      float d[G];
+#pragma unroll
+      for (int k = 0; k < G; k++) d[k] = ld_f32(&dv.v[k]);
+#pragma unroll
+      for (int t = 0; t < 3; t++) {
+        const int v = lo * stride + t - pad_l;
+        if (t < K && v >= 0 && v < Li) {
+          const T* xr = x + ((long)b * Li + v) * ldx;
+#pragma unroll
+          for (int j = 0; j < 2; j++) {
+            if (j < thin) { const float xv = ld_f32(xr + j);
+#pragma unroll
+              for (int k = 0; k < G; k++) acc[t][j][k] += d[k] * xv; }
+          }
+        }
+      }
+    } else {
+      float d[2];
+#pragma unroll
+      for (int j = 0; j < 2; j++) d[j] = j < thin ? ld_f32(dy + r * lddy + j) : 0.f;
+#pragma unroll
+      for (int t = 0; t < 3; t++) {
+        const int v = lo * stride + t - pad_l;
+        if (t < K && v >= 0 && v < Li) {
+          const RowVec<T, G> xvv = *(const RowVec<T, G>*)(x + ((long)b * Li + v) * ldx + lane * G);
+#pragma unroll
+          for (int k = 0; k < G; k++) { const float xv = ld_f32(&xvv.v[k]);
+#pragma unroll
+            for (int j = 0; j < 2; j++) acc[t][j][k] += d[j] * xv; }
+        }
+      }
+    }
+  }
+  // reduce over the rpb row lanes of the block: one (t, j, k) plane at a time through LDS, then one atomic per element
+#pragma unroll
+  for (int t = 0; t < 3; t++)
+#pragma unroll
+    for (int j = 0; j < 2; j++)
+#pragma unroll
+      for (int k = 0; k < G; k++) {
+        if (t >= K || j >= thin) continue;
+        __syncthreads();
+        red[threadIdx.x] = acc[t][j][k];
+        __syncthreads();
+        if (rl == 0) {
+          float s = 0.f;
+          for (int q = 0; q < rpb; q++) s += red[q * lpr + lane];
+          const int wch = lane * G + k;
+          const int co = WIDE_OUT ? wch : j, ci = WIDE_OUT ? j : wch;
+          atomicAdd(dw + ((long)t * Cout + co) * Cin + ci, s);
+        }
+      }
+}
+
 // wave per row, lanes over the (wide) input channels, <= 8 output channels
 template <typename T>
 __global__ __launch_bounds__(NT) void dconv_rowdot_kernel(const DArgs a) {
@@ -189,6 +425,42 @@ int dconv_run(eegldm_ctx* ctx, int dtype, bool dgrad, const void* in, long ldin,
   const bool rowdot = a.Ci > 8 && a.Co <= 8;
   EEG_CHECK(a.Ci <= 8 || a.Co <= 8, "direct conv expects a thin side (Cin=%d Cout=%d)", Cin, Cout);
   const long rows = (long)B * a.Lo;
+  if (a.Ci <= 8 && a.Co <= 8 && K <= 3) {
+    const int ci = a.Ci <= 1 ? 1 : (a.Ci <= 2 ? 2 : (a.Ci <= 4 ? 4 : 8)), co = a.Co <= 1 ? 1 : (a.Co <= 2 ? 2 : (a.Co <= 4 ? 4 : 8));
+    const dim3 g(grid_cap((rows + NT - 1) / NT, ctx));
+#define DROW(T_, CI_, CO_) hipLaunchKernelGGL((dconv_row_kernel<T_, CI_, CO_>), g, dim3(NT), 0, ctx->stream, a)
+#define DROW_CO(T_, CI_) do { if (co == 1) DROW(T_, CI_, 1); else if (co == 2) DROW(T_, CI_, 2); else if (co == 4) DROW(T_, CI_, 4); else DROW(T_, CI_, 8); } while (0)
+#define DROW_T(T_) do { if (ci == 1) DROW_CO(T_, 1); else if (ci == 2) DROW_CO(T_, 2); else if (ci == 4) DROW_CO(T_, 4); else DROW_CO(T_, 8); } while (0)
+    if (dtype == EEGLDM_F32) DROW_T(float); else DROW_T(bf16_t);
+#undef DROW_T
+#undef DROW_CO
+#undef DROW
+    LAUNCH_CHECK();
+    return 0;
+  }
+  {
+    const int G = dtype == EEGLDM_F32 ? 4 : 8;
+    const bool al = (ldin % G == 0) && (ldout % G == 0) && (!resid || ldr % G == 0);
+    if (a.Ci <= 8 && a.Co % G == 0 && a.Co >= 16 && K <= 3 && ldout % G == 0 && (!resid || ldr % G == 0) && ((size_t)K * a.Ci * a.Co + a.Co) * 4 <= 48 * 1024) {
+      const long total = rows * (a.Co / G);
+      const dim3 g(grid_cap((total + NT - 1) / NT, ctx));
+      const size_t sh = ((size_t)K * a.Ci * a.Co + a.Co) * sizeof(float);
+      if (dtype == EEGLDM_F32) hipLaunchKernelGGL((dconv_thin_in_kernel<float>), g, dim3(NT), sh, ctx->stream, a);
+      else hipLaunchKernelGGL((dconv_thin_in_kernel<bf16_t>), g, dim3(NT), sh, ctx->stream, a);
+      LAUNCH_CHECK();
+      return 0;
+    }
+    const int lpr = a.Ci / G;
+    if (a.Co <= 8 && a.Ci % G == 0 && lpr >= 1 && lpr <= 64 && (lpr & (lpr - 1)) == 0 && ldin % G == 0 && (size_t)K * a.Co * a.Ci * 4 <= 48 * 1024 && al == al) {
+      const int rpb = NT / lpr;
+      const dim3 g(grid_cap((rows + rpb - 1) / rpb, ctx));
+      const size_t sh = (size_t)K * a.Co * a.Ci * sizeof(float);
+      if (dtype == EEGLDM_F32) hipLaunchKernelGGL((dconv_thin_out_kernel<float>), g, dim3(NT), sh, ctx->stream, a);
+      else hipLaunchKernelGGL((dconv_thin_out_kernel<bf16_t>), g, dim3(NT), sh, ctx->stream, a);
+      LAUNCH_CHECK();
+      return 0;
+    }
+  }
   if (dtype == EEGLDM_F32) {
     if (rowdot) hipLaunchKernelGGL((dconv_rowdot_kernel<float>), dim3(grid_cap((rows + 3) / 4, ctx)), dim3(NT), 0, ctx->stream, a);
     else hipLaunchKernelGGL((dconv_point_kernel<float>), dim3(grid_cap((rows * a.Co + NT - 1) / NT, ctx)), dim3(NT), 0, ctx->stream, a);
@@ -213,6 +485,24 @@ int dconv_wgrad(eegldm_ctx* ctx, int dtype, const void* x, long ldx, const void*
                          dw, B, Lout, Lin, Cout, Cin, K, stride, pad_l);
     LAUNCH_CHECK();
     return 0;
+  }
+  {
+    const int G = dtype == EEGLDM_F32 ? 4 : 8;
+    const bool wide_out = Cin <= 2 && Cout % G == 0 && Cout >= 16 && lddy % G == 0;
+    const bool wide_in = Cout <= 2 && Cin % G == 0 && Cin >= 16 && ldx % G == 0;
+    const int wide = wide_out ? Cout : Cin, lpr = wide / G;
+    if ((wide_out || wide_in) && K <= 3 && lpr <= NT && NT % lpr == 0) {
+      const int rpb = NT / lpr;
+      // few blocks: every block ends with one atomic per weight element on the SAME addresses (2048 blocks cost 460 us in atomics)
+      long nb = (rows + rpb - 1) / rpb; const long capb = (long)ctx->num_cu * 2; if (nb > capb) nb = capb;
+#define DWT(T_, WO_) hipLaunchKernelGGL((dconv_wgrad_wt_kernel<T_, WO_>), dim3((unsigned)nb), dim3(NT), 0, ctx->stream, (const T_*)x, ldx, (const T_*)dy, lddy, \
+                                        dw, B, Lout, Lin, Cout, Cin, K, stride, pad_l)
+      if (dtype == EEGLDM_F32) { if (wide_out) DWT(float, true); else DWT(float, false); }
+      else { if (wide_out) DWT(bf16_t, true); else DWT(bf16_t, false); }
+#undef DWT
+      LAUNCH_CHECK();
+      return 0;
+    }
   }
   const int rpc = 64;
   long blocks = (rows + rpc - 1) / rpc;

@@ -108,6 +108,131 @@ __global__ void bn_bwd_apply_kernel(const T* __restrict__ x, long ldx, const flo
   }
 }
 
+// ------------------------------------------------------------------ 4-channel-vector BatchNorm kernels (C % 4 == 0, ld % 4 == 0)
+// Thread (tx, ty): tx = 4-channel column (fixed for the thread: scale/shift hoisted, no integer division per element),
+// ty = row lane; a block walks `rows_per_block` rows.  The scalar kernels above remain for odd shapes.
+template <typename T> __device__ __forceinline__ void ldv4(const T* p, float v[4]);
+template <> __device__ __forceinline__ void ldv4<float>(const float* p, float v[4]) { const float4 t = *(const float4*)p; v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w; }
+template <> __device__ __forceinline__ void ldv4<bf16_t>(const bf16_t* p, float v[4]) {
+  const uint2 t = *(const uint2*)p;
+  v[0] = __uint_as_float(t.x << 16); v[1] = __uint_as_float(t.x & 0xffff0000u); v[2] = __uint_as_float(t.y << 16); v[3] = __uint_as_float(t.y & 0xffff0000u);
+}
+template <typename T> __device__ __forceinline__ void stv4(T* p, const float v[4]);
+template <> __device__ __forceinline__ void stv4<float>(float* p, const float v[4]) { *(float4*)p = make_float4(v[0], v[1], v[2], v[3]); }
+template <> __device__ __forceinline__ void stv4<bf16_t>(bf16_t* p, const float v[4]) { uint2 t; t.x = pack_bf16x2(v[0], v[1]); t.y = pack_bf16x2(v[2], v[3]); *(uint2*)p = t; }
+
+struct BnMap { int TX, TY, tx, ty; bool act; };
+__device__ __forceinline__ BnMap bnmap(int C) {
+  BnMap m; const int ncols = C / 4;
+  m.TX = ncols < NT ? ncols : NT; m.TY = NT / m.TX;
+  m.tx = threadIdx.x % m.TX; m.ty = threadIdx.x / m.TX; m.act = threadIdx.x < m.TX * m.TY;
+  return m;
+}
+// MODE 0: sums x, x^2;  MODE 1: sums dz, dz*xhat (backward)
+template <typename T, int MODE>
+__global__ __launch_bounds__(NT) void bn_reduce4_kernel(const T* __restrict__ x, long ldx, const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                        const float* __restrict__ stats, const T* __restrict__ dy, long lddy,
+                                                        void* __restrict__ parts, long rows, int C, long rows_per_block, float slope) {
+  __shared__ float red[2 * 1024];
+  const BnMap m = bnmap(C);
+  for (int i = threadIdx.x; i < 2 * C; i += NT) red[i] = 0.f;
+  __syncthreads();
+  const long l0 = (long)blockIdx.x * rows_per_block, l1 = min(rows, l0 + rows_per_block);
+  if (m.act) {
+    for (int col = m.tx; col < C / 4; col += m.TX) {
+      const int c = col * 4;
+      float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
+      float mean[4], rstd[4], ga[4], be[4];
+      if (MODE == 1) {
+#pragma unroll
+        for (int j = 0; j < 4; j++) { mean[j] = stats[2 * (c + j)]; rstd[j] = stats[2 * (c + j) + 1]; ga[j] = gamma[c + j]; be[j] = beta[c + j]; }
+      }
+#pragma unroll 4
+      for (long l = l0 + m.ty; l < l1; l += m.TY) {
+        float v[4]; ldv4<T>(x + l * ldx + c, v);
+        if (MODE == 0) {
+#pragma unroll
+          for (int j = 0; j < 4; j++) { s1[j] += v[j]; s2[j] += v[j] * v[j]; }
+        } else {
+          float d[4]; ldv4<T>(dy + l * lddy + c, d);
+#pragma unroll
+          for (int j = 0; j < 4; j++) {
+            const float xh = (v[j] - mean[j]) * rstd[j];
+            const float dz = (ga[j] * xh + be[j] <= 0.f) ? d[j] * slope : d[j];
+            s1[j] += dz; s2[j] += dz * xh;
+          }
+        }
+      }
+#pragma unroll
+      for (int j = 0; j < 4; j++) { atomicAdd(&red[2 * (c + j)], s1[j]); atomicAdd(&red[2 * (c + j) + 1], s2[j]); }
+    }
+  }
+  __syncthreads();
+  // written partials + a folding pass: a thousand blocks adding atomically into the same 2C addresses serialise in L2
+  float* part = (float*)parts + (size_t)blockIdx.x * 2 * C;
+  for (int i = threadIdx.x; i < 2 * C; i += NT) part[i] = red[i];
+}
+__global__ void bn_fold_kernel(const float* __restrict__ parts, int nparts, int n2c, double* __restrict__ sums) {
+  __shared__ double red[NT];
+  const int i = blockIdx.x * 64 + (threadIdx.x & 63), seg = threadIdx.x >> 6;
+  const int per = (nparts + gridDim.y - 1) / gridDim.y, r0 = blockIdx.y * per, r1 = min(nparts, r0 + per);    // sums pre-zeroed
+  double s = 0.0;
+  if (i < n2c) for (int r = r0 + seg; r < r1; r += NT / 64) s += (double)parts[(size_t)r * n2c + i];
+  red[threadIdx.x] = s;
+  __syncthreads();
+  if (seg == 0 && i < n2c) atomicAdd(&sums[i], red[threadIdx.x] + red[threadIdx.x + 64] + red[threadIdx.x + 128] + red[threadIdx.x + 192]);
+}
+// MODE 0: y = lrelu(bn(x));  MODE 1: dx of the same (sums = per-channel S1, S2)
+template <typename T, int MODE>
+__global__ __launch_bounds__(NT) void bn_apply4_kernel(const T* __restrict__ x, long ldx, const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                       const float* __restrict__ stats, const T* __restrict__ dy, long lddy, const double* __restrict__ sums,
+                                                       T* __restrict__ out, long ldo, float* __restrict__ dgamma, float* __restrict__ dbeta,
+                                                       long rows, int C, long rows_per_block, float slope) {
+  const BnMap m = bnmap(C);
+  if (MODE == 1 && gamma && dgamma && blockIdx.x == 0)
+    for (int c = threadIdx.x; c < C; c += NT) { atomicAdd(&dbeta[c], (float)sums[2 * c]); atomicAdd(&dgamma[c], (float)sums[2 * c + 1]); }
+  if (!m.act) return;
+  const float inv_n = 1.0f / (float)rows;
+  const long l0 = (long)blockIdx.x * rows_per_block, l1 = min(rows, l0 + rows_per_block);
+  for (int col = m.tx; col < C / 4; col += m.TX) {
+    const int c = col * 4;
+    float sc[4], sh[4], mean[4], rstd[4], k1[4], k2[4];
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+      if (gamma) {
+        mean[j] = stats[2 * (c + j)]; rstd[j] = stats[2 * (c + j) + 1];
+        sc[j] = gamma[c + j] * rstd[j]; sh[j] = beta[c + j] - mean[j] * sc[j];
+        if (MODE == 1) { k1[j] = (float)sums[2 * (c + j)] * inv_n; k2[j] = (float)sums[2 * (c + j) + 1] * inv_n; }
+      } else { sc[j] = 1.f; sh[j] = 0.f; mean[j] = 0.f; rstd[j] = 1.f; k1[j] = 0.f; k2[j] = 0.f; }
+    }
+#pragma unroll 4
+    for (long l = l0 + m.ty; l < l1; l += m.TY) {
+      float v[4], o[4]; ldv4<T>(x + l * ldx + c, v);
+      if (MODE == 0) {
+#pragma unroll
+        for (int j = 0; j < 4; j++) { const float z = v[j] * sc[j] + sh[j]; o[j] = z > 0.f ? z : slope * z; }
+      } else {
+        float d[4]; ldv4<T>(dy + l * lddy + c, d);
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+          const float z = v[j] * sc[j] + sh[j];
+          const float dz = z > 0.f ? d[j] : slope * d[j];
+          if (gamma) { const float xh = (v[j] - mean[j]) * rstd[j]; o[j] = sc[j] * (dz - k1[j] - xh * k2[j]); }
+          else o[j] = dz;
+        }
+      }
+      stv4<T>(out + l * ldo + c, o);
+    }
+  }
+}
+inline void bn_split(long rows, eegldm_ctx* ctx, int per_cu, int* blocks, long* rpb) {
+  long want = (long)ctx->num_cu * per_cu, maxb = (rows + 15) / 16;
+  if (want > maxb) want = maxb;
+  if (want < 1) want = 1;
+  *rpb = (rows + want - 1) / want;
+  *blocks = (int)((rows + *rpb - 1) / *rpb);
+}
+
 // ------------------------------------------------------------------ nearest x2 (MONAI Upsample; twin ae_kl.py:27-30)
 template <typename T>
 __global__ void upsample2_kernel(const T* __restrict__ x, long ldx, T* __restrict__ y, long ldy, long rows_in, int C) {
@@ -216,8 +341,16 @@ int ls_bn_lrelu_fwd(eegldm_ctx* ctx, const void* x, long ldx, const float* gamma
       double* sums = (double*)((char*)ctx->scratch + (2u << 20));   // BatchNorm region of the context scratch (GroupNorm owns [0, 1 MiB) self-cleaning)
       EEG_CHECK((size_t)C * 2 * sizeof(double) <= (1u << 20), "scratch too small");
       HIP_TRY(hipMemsetAsync(sums, 0, sizeof(double) * 2 * C, ctx->stream));
-      int rs; long rpb; pick_rsplit(rows, C, ctx, &rs, &rpb);
-      DISPATCH_T(dtype, hipLaunchKernelGGL((bn_stats_kernel<T>), dim3((C + 63) / 64, rs), dim3(NT), 0, ctx->stream, (const T*)x, ldx, sums, rows, C, rpb));
+      if (C % 4 == 0 && ldx % 4 == 0 && C <= 1024) {
+        int nb; long rpb4; bn_split(rows, ctx, 8, &nb, &rpb4);
+        void* parts = (char*)ctx->scratch + (8u << 20);
+        DISPATCH_T(dtype, hipLaunchKernelGGL((bn_reduce4_kernel<T, 0>), dim3(nb), dim3(NT), 0, ctx->stream, (const T*)x, ldx, nullptr, nullptr, nullptr,
+                                             (const T*)nullptr, 0, parts, rows, C, rpb4, 0.f));
+        hipLaunchKernelGGL(bn_fold_kernel, dim3((2 * C + 63) / 64, 32), dim3(NT), 0, ctx->stream, (const float*)parts, nb, 2 * C, sums);
+      } else {
+        int rs; long rpb; pick_rsplit(rows, C, ctx, &rs, &rpb);
+        DISPATCH_T(dtype, hipLaunchKernelGGL((bn_stats_kernel<T>), dim3((C + 63) / 64, rs), dim3(NT), 0, ctx->stream, (const T*)x, ldx, sums, rows, C, rpb));
+      }
       LAUNCH_CHECK();
       hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 255) / 256), dim3(256), 0, ctx->stream, sums, stats, rmean, rvar, nbt, C, (double)rows, 1e-5f, 0.1f);
       LAUNCH_CHECK();
@@ -227,7 +360,13 @@ int ls_bn_lrelu_fwd(eegldm_ctx* ctx, const void* x, long ldx, const float* gamma
       LAUNCH_CHECK();
     }
   }
-  DISPATCH_T(dtype, hipLaunchKernelGGL((bn_lrelu_apply_kernel<T>), dim3(grid1d(rows * C, ctx)), dim3(NT), 0, ctx->stream, (const T*)x, ldx, gamma, beta, stats, (T*)y, ldy, rows, C, slope));
+  if (C % 4 == 0 && ldx % 4 == 0 && ldy % 4 == 0) {
+    int nb; long rpb4; bn_split(rows, ctx, 16, &nb, &rpb4);
+    DISPATCH_T(dtype, hipLaunchKernelGGL((bn_apply4_kernel<T, 0>), dim3(nb), dim3(NT), 0, ctx->stream, (const T*)x, ldx, gamma, beta, stats, (const T*)nullptr, 0,
+                                         nullptr, (T*)y, ldy, nullptr, nullptr, rows, C, rpb4, slope));
+  } else {
+    DISPATCH_T(dtype, hipLaunchKernelGGL((bn_lrelu_apply_kernel<T>), dim3(grid1d(rows * C, ctx)), dim3(NT), 0, ctx->stream, (const T*)x, ldx, gamma, beta, stats, (T*)y, ldy, rows, C, slope));
+  }
   LAUNCH_CHECK();
   return 0;
 }
@@ -236,13 +375,27 @@ int ls_bn_lrelu_bwd(eegldm_ctx* ctx, const void* x, long ldx, const float* gamma
   double* sums = (double*)((char*)ctx->scratch + (2u << 20));
   if (gamma) {
     HIP_TRY(hipMemsetAsync(sums, 0, sizeof(double) * 2 * C, ctx->stream));
-    int rs; long rpb; pick_rsplit(rows, C, ctx, &rs, &rpb);
-    DISPATCH_T(dtype, hipLaunchKernelGGL((bn_bwd_reduce_kernel<T>), dim3((C + 63) / 64, rs), dim3(NT), 0, ctx->stream, (const T*)x, ldx, gamma, beta, stats,
-                                         (const T*)dy, lddy, sums, rows, C, rpb, slope));
+    if (C % 4 == 0 && ldx % 4 == 0 && lddy % 4 == 0 && C <= 1024) {
+      int nb; long rpb4; bn_split(rows, ctx, 8, &nb, &rpb4);
+      void* parts = (char*)ctx->scratch + (8u << 20);
+      DISPATCH_T(dtype, hipLaunchKernelGGL((bn_reduce4_kernel<T, 1>), dim3(nb), dim3(NT), 0, ctx->stream, (const T*)x, ldx, gamma, beta, stats,
+                                           (const T*)dy, lddy, parts, rows, C, rpb4, slope));
+      hipLaunchKernelGGL(bn_fold_kernel, dim3((2 * C + 63) / 64, 32), dim3(NT), 0, ctx->stream, (const float*)parts, nb, 2 * C, sums);
+    } else {
+      int rs; long rpb; pick_rsplit(rows, C, ctx, &rs, &rpb);
+      DISPATCH_T(dtype, hipLaunchKernelGGL((bn_bwd_reduce_kernel<T>), dim3((C + 63) / 64, rs), dim3(NT), 0, ctx->stream, (const T*)x, ldx, gamma, beta, stats,
+                                           (const T*)dy, lddy, sums, rows, C, rpb, slope));
+    }
     LAUNCH_CHECK();
   }
-  DISPATCH_T(dtype, hipLaunchKernelGGL((bn_bwd_apply_kernel<T>), dim3(grid1d(rows * C, ctx)), dim3(NT), 0, ctx->stream, (const T*)x, ldx, gamma, beta, stats,
-                                       (const T*)dy, lddy, sums, (T*)dx, lddx, dgamma, dbeta, rows, C, slope));
+  if (C % 4 == 0 && ldx % 4 == 0 && lddy % 4 == 0 && lddx % 4 == 0) {
+    int nb; long rpb4; bn_split(rows, ctx, 16, &nb, &rpb4);
+    DISPATCH_T(dtype, hipLaunchKernelGGL((bn_apply4_kernel<T, 1>), dim3(nb), dim3(NT), 0, ctx->stream, (const T*)x, ldx, gamma, beta, stats, (const T*)dy, lddy,
+                                         sums, (T*)dx, lddx, dgamma, dbeta, rows, C, rpb4, slope));
+  } else {
+    DISPATCH_T(dtype, hipLaunchKernelGGL((bn_bwd_apply_kernel<T>), dim3(grid1d(rows * C, ctx)), dim3(NT), 0, ctx->stream, (const T*)x, ldx, gamma, beta, stats,
+                                         (const T*)dy, lddy, sums, (T*)dx, lddx, dgamma, dbeta, rows, C, slope));
+  }
   LAUNCH_CHECK();
   return 0;
 }
