@@ -105,14 +105,19 @@ def main():
     windows = torch.from_numpy(eeg_windows(B, seed=1234 + rank, length=4 * L)).to(dev)
     scale_factor = 1.0 / float(ae.encode_stage_2_inputs(windows, eps=randn(ctx, (B, 1, L), seed=99)).std())   # train_ldm.py:203-204
 
+    gsync = D.OverlappedGradSync(unet.flat_grad) if world > 1 else None
+
     def step(i):
         t = randint(ctx, B, 1000, seed=1235 + rank, offset=i * B)
         noise = randn(ctx, (B, 1, L), seed=1236 + rank, offset=i * B * L)
         eps = randn(ctx, (B, 1, L), seed=1237 + rank, offset=i * B * L)
         latents = ae.encode_stage_2_inputs(windows, eps=eps, scale_factor=scale_factor)
         unet.zero_grad()
-        ldm_train_step(unet, sched, latents, noise, t, loss_out=loss)
-        D.allreduce_mean_flat(unet.flat_grad)
+        # N > 1: the all-reduce of out / output_blocks / middle_block gradients starts inside the native backward (grad hook)
+        # and overlaps the input blocks' backward; the rest follows the call
+        ldm_train_step(unet, sched, latents, noise, t, loss_out=loss, grad_sync=gsync)
+        if gsync is not None:
+            gsync.wait()
         opt.step()
 
     for i in range(args.warmup):

@@ -167,6 +167,12 @@ int eegldm_unet_entry(const eegldm_unet*, int i, char* name, int name_cap, long*
                       int* ndim, int shape[3]);
 /* Bind caller-owned flat fp32 buffers (grads may be NULL for inference). */
 int eegldm_unet_bind(eegldm_unet*, float* params, float* grads);
+/* Optional host callback fired from eegldm_unet_backward / eegldm_ldm_train_step once the gradients in
+ * [offset, offset + numel) of the flat gradient buffer (out, output_blocks, middle_block -- the tail of the layout) are
+ * complete in stream order, while the input blocks' backward is still to be enqueued.  Data-parallel hosts start the
+ * all-reduce of that slice there (replaces torch.nn.DataParallel's gather, train_ldm.py:190-192).  NULL disables. */
+typedef void (*eegldm_grad_hook)(void* user, long offset, long numel);
+int eegldm_unet_set_grad_hook(eegldm_unet*, eegldm_grad_hook fn, void* user);
 /* Refresh the compute-dtype weight copies after `params` changed (no-op for fp32). */
 int eegldm_unet_sync_weights(eegldm_unet*);
 /* forward(x, timesteps): x, y are NCL fp32 (B, C, L); t int64 (B).  training != 0 keeps

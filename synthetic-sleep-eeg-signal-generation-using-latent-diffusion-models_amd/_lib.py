@@ -69,6 +69,7 @@ SIGNATURES = {
     "eegldm_unet_entry": [_vp, _i, C.c_char_p, _i, C.POINTER(_l), C.POINTER(_l), C.POINTER(_i), C.POINTER(_i)],
     "eegldm_unet_bind": [_vp, _vp, _vp],
     "eegldm_unet_sync_weights": [_vp],
+    "eegldm_unet_set_grad_hook": [_vp, _vp, _vp],
     "eegldm_unet_forward": [_vp, _vp, _vp, _vp, _i, _i, _i],
     "eegldm_unet_backward": [_vp, _vp, _vp],
     "eegldm_ldm_train_step": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _f, _vp],

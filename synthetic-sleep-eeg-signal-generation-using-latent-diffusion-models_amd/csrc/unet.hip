@@ -31,6 +31,8 @@ struct eegldm_unet : NetBase {
   int mc, te;
   long off_emb_w = 0, off_emb_b = 0, off_te0_w, off_te0_b, off_te2_w, off_te2_b, off_cin_w, off_cin_b, off_out_gw, off_out_gb, off_out_w, off_out_b;
   std::vector<Block> in_blocks, out_blocks; Block mid;
+  long off_mid_begin = 0;        // flat offset of the first middle-block parameter: [off_mid_begin, nparams) is final once the middle block's backward is enqueued
+  eegldm_grad_hook grad_hook = nullptr; void* grad_hook_user = nullptr;
   std::vector<int> skip_c1;      // per output block: channels of h entering the concat
   // ---- forward tape
   int B = 0, L = 0; bool have_tape = false;
@@ -138,6 +140,7 @@ int build_plan(eegldm_unet* u) {
   };
   u->in_blocks.resize(inp.size());
   for (size_t i = 1; i < inp.size(); i++) lay("input_blocks." + std::to_string(i) + ".", inp[i], u->in_blocks[i]);
+  u->off_mid_begin = off;
   lay("middle_block.", mid, u->mid);
   u->out_blocks.resize(outp.size());
   for (size_t i = 0; i < outp.size(); i++) lay("output_blocks." + std::to_string(i) + ".", outp[i], u->out_blocks[i]);
@@ -211,6 +214,11 @@ extern "C" int eegldm_unet_destroy(eegldm_unet* u) {
 }
 extern "C" int eegldm_unet_num_entries(const eegldm_unet* u) { return (int)u->entries.size(); }
 extern "C" long eegldm_unet_num_params(const eegldm_unet* u) { return u->nparams; }
+extern "C" int eegldm_unet_set_grad_hook(eegldm_unet* u, eegldm_grad_hook fn, void* user) {
+  EEG_CHECK(u, "null unet");
+  u->grad_hook = fn; u->grad_hook_user = user;
+  return 0;
+}
 extern "C" int eegldm_unet_entry(const eegldm_unet* u, int i, char* name, int cap, long* offset, long* numel, int* ndim, int shape[3]) {
   return entry_query(u, i, name, cap, offset, numel, ndim, shape);
 }
@@ -332,6 +340,9 @@ extern "C" int eegldm_unet_backward(eegldm_unet* u, const float* dy, float* dx_o
   { View g; ALLOC_OR_FAIL(g.p, u->alloc_act((long)B * in_len[n_in - 1], in_ch[n_in - 1])); g.ld = in_ch[n_in - 1]; g.C = g.ld;
     EEG_TRY(block_backward(u, u->mid, dout, g, B, ri, ai, demb_all));
     dout = g; }
+  // gradients of out / output_blocks / middle_block are complete (in stream order): the host may start reducing them
+  // across ranks while the input blocks' backward runs
+  if (u->grad_hook) u->grad_hook(u->grad_hook_user, u->off_mid_begin, u->nparams - u->off_mid_begin);
   // ---- input blocks, reversed: gradient of block i's output = consumer's dx + skip gradient
   for (int i = n_in - 1; i >= 1; i--) {
     EEG_TRY(ew_add_rows(ctx, dout.p, dout.ld, dskip[i].p, dskip[i].ld, (long)B * in_len[i], in_ch[i], dt));

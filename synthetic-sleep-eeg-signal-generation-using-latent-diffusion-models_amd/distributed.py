@@ -45,6 +45,58 @@ def allreduce_mean_flat(t, bucket_elems=BUCKET_ELEMS):
     t.mul_(1.0 / world)
 
 
+class OverlappedGradSync:
+    """Data-parallel gradient mean with the communication started before backward has finished.
+
+    `on_ready(offset, numel)` (called from the native backward through eegldm.training.set_grad_hook) launches the
+    bucketed async all-reduce of a finished slice of the flat gradient buffer; `finish()` reduces whatever has not been
+    covered yet; `wait()` blocks the current stream on all of it and applies the 1/world scaling.  With one process it
+    does nothing.  Slices must not overlap (the native hook reports one tail range)."""
+
+    def __init__(self, flat_grad, bucket_elems=BUCKET_ELEMS):
+        self.g = flat_grad
+        self.bucket = int(bucket_elems)
+        self.works = []
+        self.done = []          # (start, end) ranges already launched
+
+    @property
+    def active(self):
+        return dist.is_initialized() and dist.get_world_size() > 1
+
+    def begin(self):
+        self.works, self.done = [], []
+
+    def _launch(self, a, b):
+        for s in range(a, b, self.bucket):
+            e = min(b, s + self.bucket)
+            self.works.append(dist.all_reduce(self.g[s:e], op=dist.ReduceOp.SUM, async_op=True))
+
+    def on_ready(self, offset, numel):
+        if not self.active or numel <= 0:
+            return
+        self._launch(offset, offset + numel)
+        self.done.append((offset, offset + numel))
+
+    def finish(self):
+        if not self.active:
+            return
+        pos = 0
+        for a, b in sorted(self.done):
+            if a > pos:
+                self._launch(pos, a)
+            pos = max(pos, b)
+        if pos < self.g.numel():
+            self._launch(pos, self.g.numel())
+
+    def wait(self):
+        if not self.active:
+            return
+        for w in self.works:
+            w.wait()
+        self.works = []
+        self.g.mul_(1.0 / dist.get_world_size())
+
+
 def shard_range(n, rank, world):
     """Contiguous split of n independent items (sampling seeds) over ranks."""
     per, rem = divmod(n, world)

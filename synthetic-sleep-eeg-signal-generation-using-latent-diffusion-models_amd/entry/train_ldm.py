@@ -59,6 +59,7 @@ def main(args):
     if rank == 0:
         print(f"Scaling factor set to {scale_factor}")
     loss = torch.zeros(1, device=dev)
+    gsync = D.OverlappedGradSync(unet.flat_grad)          # no-op with one process
     steps, t0, seen, best = 0, time.time(), 0, float("inf")
     for epoch in range(config.train.n_epochs):
         unet.train()
@@ -70,8 +71,8 @@ def main(args):
             noise = randn(ctx, eps.shape, seed=config.train.seed + 13 + rank, offset=steps * z[0].numel() * B)
             e = stage1.encode_stage_2_inputs(x, eps=eps, scale_factor=scale_factor)
             opt.zero_grad()
-            ldm_train_step(unet, sched, e, noise, t, loss_out=loss)
-            D.allreduce_mean_flat(unet.flat_grad)
+            ldm_train_step(unet, sched, e, noise, t, loss_out=loss, grad_sync=gsync)
+            gsync.wait()
             opt.step()
             steps += 1; seen += B * world
             if args.max_steps and steps >= args.max_steps:

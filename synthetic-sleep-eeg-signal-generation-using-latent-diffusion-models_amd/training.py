@@ -3,6 +3,8 @@
   Adam            <-> torch.optim.Adam as used at /root/reference/src/train_ldm.py:208
 Gradients live in each model's flat fp32 buffer, so data-parallel training is ONE
 all-reduce over a contiguous tensor (see eegldm.distributed)."""
+import ctypes as C
+
 import torch
 
 from ._lib import lib, check, ptr, PRED
@@ -37,14 +39,41 @@ class Adam:
         self.param_groups[0]["lr"] = sd.get("lr", self.lr)
 
 
-def ldm_train_step(unet, scheduler, latents, noise, timesteps, loss_out=None, grad_scale=1.0):
+GRAD_HOOK = C.CFUNCTYPE(None, C.c_void_p, C.c_long, C.c_long)
+
+
+def set_grad_hook(unet, fn):
+    """fn(offset, numel) is called from inside the native backward as soon as unet.flat_grad[offset:offset+numel]
+    (out / output_blocks / middle_block) is final in stream order; None removes the hook.  The ctypes thunk is kept
+    alive on the model."""
+    if fn is None:
+        unet._grad_hook_thunk = None
+        check(lib.eegldm_unet_set_grad_hook(unet.h, None, None))
+        return
+    thunk = GRAD_HOOK(lambda _user, off, n: fn(int(off), int(n)))
+    unet._grad_hook_thunk = thunk
+    check(lib.eegldm_unet_set_grad_hook(unet.h, C.cast(thunk, C.c_void_p), None))
+
+
+def ldm_train_step(unet, scheduler, latents, noise, timesteps, loss_out=None, grad_scale=1.0, grad_sync=None):
     """add_noise -> UNet forward -> MSE against noise (epsilon) or velocity (v_prediction) -> backward.
-    Accumulates into unet.flat_grad; returns the device scalar loss tensor."""
+    Accumulates into unet.flat_grad; returns the device scalar loss tensor.  grad_sync: an
+    eegldm.distributed.OverlappedGradSync -- the tail of the gradient buffer is all-reduced while the input blocks'
+    backward still runs, the rest right after the call; the caller then only has to `grad_sync.wait()`."""
     if loss_out is None:
         loss_out = torch.zeros(1, device=unet.device)
     B, _C, L = latents.shape
-    check(lib.eegldm_ldm_train_step(unet.h, ptr(latents), ptr(noise), ptr(timesteps), ptr(scheduler._acp_dev),
-                                    PRED[scheduler.prediction_type], B, L, grad_scale, ptr(loss_out)))
+    if grad_sync is not None:
+        grad_sync.begin()
+        set_grad_hook(unet, grad_sync.on_ready)
+    try:
+        check(lib.eegldm_ldm_train_step(unet.h, ptr(latents), ptr(noise), ptr(timesteps), ptr(scheduler._acp_dev),
+                                        PRED[scheduler.prediction_type], B, L, grad_scale, ptr(loss_out)))
+    finally:
+        if grad_sync is not None:
+            set_grad_hook(unet, None)
+    if grad_sync is not None:
+        grad_sync.finish()
     return loss_out
 
 

@@ -22,6 +22,11 @@ def _worker(rank, world, port, q):
     grads = torch.arange(3000, dtype=torch.float32) * (rank + 1)
     D.allreduce_mean_flat(grads, bucket_elems=700)      # several uneven buckets
     lo, hi = D.shard_range(11, rank, world)
+    # overlapped gradient sync: the "native backward" reports a finished tail slice first, the head follows
+    g2 = torch.arange(3000, dtype=torch.float32) * (rank + 1)
+    gs = D.OverlappedGradSync(g2, bucket_elems=700)
+    gs.begin(); gs.on_ready(1800, 1200); gs.finish(); gs.wait()
+    assert torch.allclose(g2, grads), "overlapped sync must equal the plain bucketed mean"
     q.put((rank, flat.sum().item(), grads.tolist(), (lo, hi)))     # plain python: no fd passing after the child exits
     dist.destroy_process_group()
 
@@ -49,3 +54,6 @@ def test_single_process_is_noop():
     t = torch.ones(10)
     D.allreduce_mean_flat(t); D.broadcast_flat(t)
     assert torch.equal(t, torch.ones(10)) and D.shard_range(5, 0, 1) == (0, 5)
+    gs = D.OverlappedGradSync(t)
+    gs.begin(); gs.on_ready(4, 6); gs.finish(); gs.wait()
+    assert torch.equal(t, torch.ones(10))

@@ -74,3 +74,38 @@ def test_unet_full_size_shapes_and_state_dict(golden_dir):
         assert torch.equal(back[k].cpu(), sd2[k].cpu()), k
     y = net(torch.randn(2, 1, 768), timesteps=torch.tensor([5, 900]))
     assert y.shape == (2, 1, 768) and torch.isfinite(y).all()
+
+
+@pytest.mark.gpu
+def test_grad_hook_reports_final_tail_slice():
+    """The native backward reports [offset, offset+numel) = middle_block + output_blocks + out gradients once they are final;
+    those values must equal the gradients of a run without the hook (the input blocks' backward does not touch them)."""
+    import eegldm
+    from eegldm.models import UNetModel
+    from eegldm.schedulers import DDPMScheduler
+    from eegldm.training import ldm_train_step, set_grad_hook
+    torch.manual_seed(0)
+    net = UNetModel(image_size=64, in_channels=1, out_channels=1, model_channels=32, num_res_blocks=1, attention_resolutions=[2],
+                    channel_mult=[1, 2], resblock_updown=True, dtype="float32")
+    sd = net.state_dict()
+    net.load_state_dict({k: torch.randn(v.shape) * 0.05 for k, v in sd.items()})
+    sched = DDPMScheduler(num_train_timesteps=1000, beta_schedule="scaled_linear", beta_start=0.0015, beta_end=0.0195)
+    dev = net.device
+    lat = torch.randn(4, 1, 64, device=dev); noise = torch.randn(4, 1, 64, device=dev); t = torch.randint(0, 1000, (4,), device=dev)
+    net.zero_grad(); ldm_train_step(net, sched, lat, noise, t); ref = net.flat_grad.clone()
+    calls = []
+    snap = {}
+
+    def hook(off, n):
+        calls.append((off, n))
+        snap["tail"] = net.flat_grad[off:off + n].clone()       # stream-ordered copy at the moment the hook fires
+
+    net.zero_grad(); set_grad_hook(net, hook); ldm_train_step(net, sched, lat, noise, t); set_grad_hook(net, None)
+    torch.cuda.synchronize()
+    assert len(calls) == 1
+    off, n = calls[0]
+    keys = {k: i for i, k in enumerate(sd.keys())}
+    assert 0 < off and off + n == net.n_flat
+    scale = ref.abs().max()
+    assert (snap["tail"] - ref[off:off + n]).abs().max() <= 1e-4 * scale
+    assert (net.flat_grad - ref).abs().max() <= 1e-4 * scale
