@@ -109,8 +109,13 @@ __device__ __forceinline__ int tr_store_off(int krow, int seg) {
 
 template <typename T, int AMODE, int BMODE, int TAPS, int KSUB, int BN, int STRIDE, int WMT, bool DMA>
 struct Cfg {
-  static constexpr int BM = 64 * WMT;                             // block rows: WMT waves along M, 2 along N
-  static constexpr int NW = 2 * WMT;                              // waves per block
+  // WMT encodes the M geometry: 2 / 4 = that many waves along M with four 16-row fragments each (128 / 256 rows);
+  // 3 = two waves along M with SIX fragments each (192 rows): 25 % fewer L2->LDS bytes per MFMA than the 128-row tile at
+  // the same 2 blocks per CU (the K loop is bound by L2->LDS queueing), and every UNet length (192/384/768) divides
+  static constexpr int WM = (WMT == 3) ? 2 : WMT;                 // waves along M (2 along N)
+  static constexpr int FM = (WMT == 3) ? 6 : 4;                   // 16-row fragments per wave along M
+  static constexpr int BM = WM * FM * 16;                         // block rows
+  static constexpr int NW = 2 * WM;                               // waves per block
   static constexpr int NTHREADS = 64 * NW;
   static constexpr int KC = Tr<T>::KC;
   static constexpr int EPC = Tr<T>::EPC;
@@ -155,12 +160,17 @@ struct Cfg {
   // staging ring already owns that much LDS (conv kernels), two otherwise -- fewer barriers and, more importantly,
   // all of a pass's bias / residual loads are independent and in flight together (the 4-pass version serialised
   // ~1 us of load latency per pass: 8-10 us per block, profiles/r01_gemm_fixed_cost.txt).
-  static constexpr int EPI_I = (4 * 16 * WMT * EPI_PITCH <= NSTG_BYTES_HINT) ? 4 : 2;
-  static constexpr int EPI_ROWS = EPI_I * 16 * WMT;
+  static constexpr int EPI_I = (FM * 16 * WM * EPI_PITCH <= NSTG_BYTES_HINT) ? FM : 2;
+  static constexpr int EPI_ROWS = EPI_I * 16 * WM;
   static constexpr int EPI_BYTES = EPI_ROWS * EPI_PITCH;
   static constexpr int EPI16_BYTES = (sizeof(T) == 2 && AMODE != GA_TR) ? BM * (BN * 2 + 16) : 0;   // packed bf16 output tile (one pass)
   static constexpr int LDS_BYTES0 = (NSTG * STAGE_BYTES) > EPI_BYTES ? (NSTG * STAGE_BYTES) : EPI_BYTES;
   static constexpr int LDS_BYTES = LDS_BYTES0 > EPI16_BYTES ? LDS_BYTES0 : EPI16_BYTES;
+  // 16 zero bytes for conv rows of a neighbouring sample: the first padding chunk behind the A tile of buffer 0 when the
+  // DMA pads that tile (it is then refilled from the zero page every stage), else a slot behind the tiles
+  static constexpr bool ZPAD = DMA && AMODE == GA_CONV && (A_BYTES + 16 <= A_ALLOC);
+  static constexpr int ZOFF = ZPAD ? A_BYTES : LDS_BYTES;
+  static constexpr int LDS_TOTAL = LDS_BYTES + (ZPAD ? 0 : 64);
 };
 
 typedef __attribute__((address_space(3))) void* lds_void_ptr;
@@ -177,7 +187,7 @@ __device__ __forceinline__ void dma16(const void* g, unsigned lds_off) {
 __device__ __forceinline__ void dma_wait_all() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 
 template <typename T, int AMODE, int BMODE, int TAPS, int KSUB, int BN, int STRIDE, int WMT, bool DMA>
-__global__ __launch_bounds__(128 * WMT, 2) void gemm_kernel(const GemmArgs p) {   // >= 2 waves per SIMD: <= 256 VGPR+AGPR
+__global__ __launch_bounds__((WMT == 3 ? 256 : 128 * WMT), 2) void gemm_kernel(const GemmArgs p) {   // >= 2 waves per SIMD: <= 256 VGPR+AGPR
   using C = Cfg<T, AMODE, BMODE, TAPS, KSUB, BN, STRIDE, WMT, DMA>;
   constexpr int FN = C::FN;
   constexpr int BM = C::BM, NTHREADS = C::NTHREADS, NW = C::NW;
@@ -226,7 +236,7 @@ __global__ __launch_bounds__(128 * WMT, 2) void gemm_kernel(const GemmArgs p) { 
   const int nstages = (kend - kbeg + C::KSTAGE - 1) / C::KSTAGE;
 
   const uint4 zero4 = make_uint4(0, 0, 0, 0);
-  if (tid < 4) *(uint4*)(smem + C::LDS_BYTES + tid * 16) = zero4;   // zero chunk behind the tiles (conv rows of other samples); visible after the first barrier
+  if constexpr (!C::ZPAD) { if (tid < 4) *(uint4*)(smem + C::LDS_BYTES + tid * 16) = zero4; }   // zero chunk behind the tiles (conv rows of other samples); visible after the first barrier
   const T* __restrict__ zeros = (const T*)p.zero_page;
 
   // ---- staging: global -> LDS by DMA (global_load_lds_dwordx4).  LDS chunk c of a tile receives the
@@ -384,8 +394,8 @@ __global__ __launch_bounds__(128 * WMT, 2) void gemm_kernel(const GemmArgs p) { 
   unsigned zmask = 0;
   if constexpr (AMODE == GA_CONV) {
 #pragma unroll
-    for (int i = 0; i < 4; i++) {
-      const int m = m0 + wm * 64 + i * 16 + lm;
+    for (int i = 0; i < C::FM; i++) {
+      const int m = m0 + wm * (C::FM * 16) + i * 16 + lm;
       const int lo = m % p.Lout;
 #pragma unroll
       for (int t = 0; t < TAPS; t++) {
@@ -395,11 +405,11 @@ __global__ __launch_bounds__(128 * WMT, 2) void gemm_kernel(const GemmArgs p) { 
     }
   }
 
-  f32x4 acc[C::NACC][4][FN];
+  f32x4 acc[C::NACC][C::FM][FN];
 #pragma unroll
   for (int a = 0; a < C::NACC; a++)
 #pragma unroll
-    for (int i = 0; i < 4; i++)
+    for (int i = 0; i < C::FM; i++)
 #pragma unroll
       for (int j = 0; j < FN; j++) acc[a][i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
@@ -411,7 +421,7 @@ __global__ __launch_bounds__(128 * WMT, 2) void gemm_kernel(const GemmArgs p) { 
   // addends of the packed-bf16 epilogue in the fragment layout: bias now, residual / embedding rows during the LAST K stage
   // (their ~1-2 us latency hides behind that stage's MFMAs instead of opening the epilogue)
   float4 pf_bias[EPI16 ? FN : 1];
-  uint2 pf_res[EPI16 ? 4 : 1][EPI16 ? FN : 1];
+  uint2 pf_res[EPI16 ? C::FM : 1][EPI16 ? FN : 1];
   if constexpr (EPI16) {
     if (use16) {
 #pragma unroll
@@ -422,13 +432,13 @@ __global__ __launch_bounds__(128 * WMT, 2) void gemm_kernel(const GemmArgs p) { 
       }
     }
   }
-  auto prefetch_epi = [&]() __attribute__((always_inline)) {
+  auto prefetch_epi = [&](const bool in_epilogue) __attribute__((always_inline)) {
     if constexpr (EPI16) {
       if (!use16) return;
-      if (p.resid) {
+      if (p.resid && (C::FM == 4 || in_epilogue)) {   // six-fragment tiles have no registers to spare during the K loop
 #pragma unroll
-        for (int i = 0; i < 4; i++) {
-          const int mr = m0 + wm * 64 + i * 16 + lm;
+        for (int i = 0; i < C::FM; i++) {
+          const int mr = m0 + wm * (C::FM * 16) + i * 16 + lm;
           const T* rp = (const T*)p.resid + (long)(mr < p.M ? mr : m0) * p.ldr;
 #pragma unroll
           for (int j = 0; j < FN; j++) { const int nj = n0 + wn * (BN / 2) + j * 16 + q * 4; pf_res[i][j] = *(const uint2*)(rp + (nj < p.N ? nj : 0)); }
@@ -478,7 +488,7 @@ __global__ __launch_bounds__(128 * WMT, 2) void gemm_kernel(const GemmArgs p) { 
       if (s + 1 < nstages) issue_stage(s + 1, (s + 1) & 1);
     }
     TSTAMP();   // after wait+barrier(+issue of the next stage)
-    if (last) prefetch_epi();
+    if (last) prefetch_epi(false);
     const char* smA = smem + (s % C::NSTG) * C::STAGE_BYTES;
     const char* smB = smA + C::A_ALLOC;
     // Fragment loads run one (tap, k-sub) step ahead of the MFMAs that consume them: with one or two waves per SIMD the
@@ -486,17 +496,17 @@ __global__ __launch_bounds__(128 * WMT, 2) void gemm_kernel(const GemmArgs p) { 
     // tools/debug/stage_timing.py).  Rows of another sample are read from a 16-byte zero chunk in LDS (address select)
     // instead of being cleared after the load.
     constexpr int NSTEP = TAPS * KSUB;
-    auto load_frags = [&](int st, uint4 (&af)[4], uint4 (&bf)[FN]) __attribute__((always_inline)) {
+    auto load_frags = [&](int st, uint4 (&af)[C::FM], uint4 (&bf)[FN]) __attribute__((always_inline)) {
       const int t = st / KSUB, ks = st % KSUB;
 #pragma unroll
-      for (int i = 0; i < 4; i++) {
+      for (int i = 0; i < C::FM; i++) {
         if constexpr (AMODE == GA_TR) {
-          af[i] = read_tr_t<T, BM>(smA, ks, wm * 64 + i * 16, lm, q);
+          af[i] = read_tr_t<T, BM>(smA, ks, wm * (C::FM * 16) + i * 16, lm, q);
         } else {
-          int row = wm * 64 + i * 16 + lm;
+          int row = wm * (C::FM * 16) + i * 16 + lm;
           if constexpr (AMODE == GA_CONV) row = row * STRIDE + t;
           const char* ap = smA + row * C::PITCH_NT + nt_swz<KSUB>(row, ks * 4 + q) * 16;
-          if constexpr (AMODE == GA_CONV) { if (zmask & (1u << (i * TAPS + t))) ap = smem + C::LDS_BYTES; }
+          if constexpr (AMODE == GA_CONV) { if (zmask & (1u << (i * TAPS + t))) ap = smem + C::ZOFF; }
           af[i] = *(const uint4*)ap;
         }
       }
@@ -510,7 +520,7 @@ __global__ __launch_bounds__(128 * WMT, 2) void gemm_kernel(const GemmArgs p) { 
         }
       }
     };
-    uint4 af[2][4], bf[2][FN];
+    uint4 af[2][C::FM], bf[2][FN];
     load_frags(0, af[0], bf[0]);
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -519,7 +529,7 @@ __global__ __launch_bounds__(128 * WMT, 2) void gemm_kernel(const GemmArgs p) { 
       __builtin_amdgcn_sched_barrier(0);   // keep the prefetch above this step's MFMAs (hipcc otherwise sinks each read to just before its use)
       const int t = st / KSUB;
 #pragma unroll
-      for (int i = 0; i < 4; i++)
+      for (int i = 0; i < C::FM; i++)
 #pragma unroll
         for (int j = 0; j < FN; j++) {
           if constexpr (AMODE == GA_TR) mma<T>(af[st & 1][i], bf[st & 1][j], acc[C::WG3 ? t : 0][i][j]);   // TN products keep the natural fragment (atomic epilogue)
@@ -547,15 +557,15 @@ __global__ __launch_bounds__(128 * WMT, 2) void gemm_kernel(const GemmArgs p) { 
       // All splits of a tile add into the same lines; each split starts a quarter of the way further round the tile so
       // that concurrently finishing blocks are spread over different lines / L2 channels instead of queueing on one.
       auto emit = [&](auto ROT) {
-        constexpr int NAI = C::NACC * 4;
+        constexpr int NAI = C::NACC * C::FM;
 #pragma unroll
         for (int ai0 = 0; ai0 < NAI; ai0++) {
           constexpr int R = decltype(ROT)::value;
           const int ai = (ai0 + R * C::NACC) % NAI;
-          const int a = ai / 4, i = ai % 4;
+          const int a = ai / C::FM, i = ai % C::FM;
 #pragma unroll
           for (int r = 0; r < 4; r++) {
-            const int m = m0 + wm * 64 + i * 16 + q * 4 + r;
+            const int m = m0 + wm * (C::FM * 16) + i * 16 + q * 4 + r;
             if (m >= p.M) continue;
 #pragma unroll
             for (int j = 0; j < FN; j++) {
@@ -586,6 +596,7 @@ __global__ __launch_bounds__(128 * WMT, 2) void gemm_kernel(const GemmArgs p) { 
       // only then transposed through LDS: half the LDS bytes of the fp32 tile, one pass, and 16-byte global stores.
       constexpr int PITCH16 = BN * 2 + 16;
       static_assert(BM * PITCH16 <= C::LDS_BYTES, "bf16 epilogue tile must fit the staging area");
+      if constexpr (C::FM != 4) prefetch_epi(true);
       float4 pf_rv[2][FN];
       int pf_bnd = 0;
       if (p.rowvec) {
@@ -601,8 +612,8 @@ __global__ __launch_bounds__(128 * WMT, 2) void gemm_kernel(const GemmArgs p) { 
         }
       }
 #pragma unroll
-      for (int i = 0; i < 4; i++) {
-        const bool hi = p.rowvec && (m0 + wm * 64 + i * 16 + lm) >= pf_bnd;
+      for (int i = 0; i < C::FM; i++) {
+        const bool hi = p.rowvec && (m0 + wm * (C::FM * 16) + i * 16 + lm) >= pf_bnd;
 #pragma unroll
         for (int j = 0; j < FN; j++) {
           float4 a = pf_bias[j];
@@ -617,7 +628,7 @@ __global__ __launch_bounds__(128 * WMT, 2) void gemm_kernel(const GemmArgs p) { 
           uint2 o;
           o.x = pack_bf16x2(acc[0][i][j][0] * p.alpha + a.x, acc[0][i][j][1] * p.alpha + a.y);
           o.y = pack_bf16x2(acc[0][i][j][2] * p.alpha + a.z, acc[0][i][j][3] * p.alpha + a.w);
-          *(uint2*)(smem + (wm * 64 + i * 16 + lm) * PITCH16 + (wn * (BN / 2) + j * 16 + q * 4) * 2) = o;
+          *(uint2*)(smem + (wm * (C::FM * 16) + i * 16 + lm) * PITCH16 + (wn * (BN / 2) + j * 16 + q * 4) * 2) = o;
         }
       }
       TSTAMP();   // E1: LDS tile written
@@ -648,13 +659,13 @@ __global__ __launch_bounds__(128 * WMT, 2) void gemm_kernel(const GemmArgs p) { 
       return;
     }
   }
-  // tile row of (wm, i, r16) inside a pass: ((i % EPI_I) * WMT + wm) * 16 + r16
+  // tile row of (wm, i, r16) inside a pass: ((i % EPI_I) * WM + wm) * 16 + r16
 #pragma unroll
-  for (int pass = 0; pass < 4 / C::EPI_I; pass++) {
+  for (int pass = 0; pass < C::FM / C::EPI_I; pass++) {
 #pragma unroll
     for (int ii = 0; ii < C::EPI_I; ii++) {
       const int i = pass * C::EPI_I + ii;
-      const int trow = (ii * WMT + wm) * 16;
+      const int trow = (ii * C::WM + wm) * 16;
 #pragma unroll
       for (int j = 0; j < FN; j++) {
         if constexpr (AMODE == GA_TR) {
@@ -674,8 +685,8 @@ __global__ __launch_bounds__(128 * WMT, 2) void gemm_kernel(const GemmArgs p) { 
       // split-K / accumulate: one float per lane so each wave-instruction hits 256 contiguous bytes
       for (int c = tid; c < C::EPI_ROWS * BN; c += NTHREADS) {
         const int row = c / BN, col = c % BN;
-        const int g = row >> 4, ii = g / WMT, wmr = g % WMT;
-        const int m = m0 + wmr * 64 + (pass * C::EPI_I + ii) * 16 + (row & 15), n = n0 + col;
+        const int g = row >> 4, ii = g / C::WM, wmr = g % C::WM;
+        const int m = m0 + wmr * (C::FM * 16) + (pass * C::EPI_I + ii) * 16 + (row & 15), n = n0 + col;
         if (m < p.M && n < p.N) atomicAdd((float*)Cb + cbase + (long)m * p.ldc + n, *(const float*)(smem + row * C::EPI_PITCH + col * 4));
       }
     } else {
@@ -693,8 +704,8 @@ __global__ __launch_bounds__(128 * WMT, 2) void gemm_kernel(const GemmArgs p) { 
 #pragma unroll
       for (int cc = 0; cc < NIT; cc++) {
         const int row = r0 + cc * RSTEP;
-        const int g = row >> 4, ii = g / WMT, wmr = g % WMT;
-        const int m = m0 + wmr * 64 + (pass * C::EPI_I + ii) * 16 + (row & 15);
+        const int g = row >> 4, ii = g / C::WM, wmr = g % C::WM;
+        const int m = m0 + wmr * (C::FM * 16) + (pass * C::EPI_I + ii) * 16 + (row & 15);
         mm[cc] = (row < C::EPI_ROWS && nok && m < p.M) ? m : -1;
         add[cc] = bias4;
       }
@@ -756,7 +767,7 @@ __global__ __launch_bounds__(128 * WMT, 2) void gemm_kernel(const GemmArgs p) { 
           }
       }
     }
-    if (pass + 1 < 4 / C::EPI_I) __syncthreads();
+    if (pass + 1 < C::FM / C::EPI_I) __syncthreads();
   }
   TSTAMP();   // E5: stores issued
 #ifdef EEG_STAGE_TIMING
@@ -770,9 +781,9 @@ int launch_k(eegldm_ctx* ctx, const GemmArgs& a_in) {
   using C = Cfg<T, AMODE, BMODE, TAPS, KSUB, BN, STRIDE, WMT, DMA>;
   auto kern = gemm_kernel<T, AMODE, BMODE, TAPS, KSUB, BN, STRIDE, WMT, DMA>;
   static bool attr_set = false;
-  static_assert(C::LDS_BYTES + 64 <= 160 * 1024, "tile does not fit the 160 KiB LDS");
-  if (!attr_set && C::LDS_BYTES + 64 > 48 * 1024) {
-    HIP_TRY(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES + 64));
+  static_assert(C::LDS_TOTAL <= 160 * 1024, "tile does not fit the 160 KiB LDS");
+  if (!attr_set && C::LDS_TOTAL > 48 * 1024) {
+    HIP_TRY(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_TOTAL));
     attr_set = true;
   }
   GemmArgs a = a_in;
@@ -785,13 +796,13 @@ int launch_k(eegldm_ctx* ctx, const GemmArgs& a_in) {
 #ifdef EEG_STAGE_TIMING
   static const int lds_pad = getenv("EEGLDM_GEMM_LDS_PAD") ? atoi(getenv("EEGLDM_GEMM_LDS_PAD")) : 0;   // occupancy experiments
   if (lds_pad) {
-    HIP_TRY(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES + 64 + lds_pad));
-    hipLaunchKernelGGL(kern, grid, dim3(C::NTHREADS), C::LDS_BYTES + 64 + lds_pad, ctx->stream, a);
+    HIP_TRY(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_TOTAL + lds_pad));
+    hipLaunchKernelGGL(kern, grid, dim3(C::NTHREADS), C::LDS_TOTAL + lds_pad, ctx->stream, a);
     LAUNCH_CHECK();
     return 0;
   }
 #endif
-  hipLaunchKernelGGL(kern, grid, dim3(C::NTHREADS), C::LDS_BYTES + 64, ctx->stream, a);
+  hipLaunchKernelGGL(kern, grid, dim3(C::NTHREADS), C::LDS_TOTAL, ctx->stream, a);
   LAUNCH_CHECK();
   return 0;
 }
@@ -823,6 +834,13 @@ template <typename T, int AMODE, int BMODE, int TAPS, int KSUB, int STRIDE>
 int launch_bn(eegldm_ctx* ctx, const GemmArgs& a) {
   static const bool big_ok = getenv("EEGLDM_GEMM_BIG_TILES") != nullptr;
   const bool big = big_ok && a.M >= 256 && !(AMODE == GA_CONV && STRIDE == 2);
+  if constexpr (AMODE == GA_CONV && TAPS == 3 && STRIDE == 1 && sizeof(T) == 2) {
+    // 192-row tiles (two waves x six fragments along M) for the bf16 3-tap kernels
+    static const int t192 = getenv("EEGLDM_GEMM_TILE192") ? atoi(getenv("EEGLDM_GEMM_TILE192")) : 0;   // opt-in: no gain at step level
+    // measured (tools/debug/gemm_bench.py): wins for the forward (NT) kernels from K = 512 up (+5..8 %), loses on short K loops
+    // (the 192-row epilogue / prologue weigh more) and on the transposed-weight dgrad (register spills)
+    if (t192 && BMODE == GB_NT && a.N > 64 && a.M >= 192 && a.K >= 512 * t192 && a.K % 32 == 0 && a.splitk == 1) return launch_t<T, AMODE, BMODE, TAPS, KSUB, 128, STRIDE, 3>(ctx, a);
+  }
   if (a.N > 64) return big ? launch_t<T, AMODE, BMODE, TAPS, KSUB, 128, STRIDE, 4>(ctx, a) : launch_t<T, AMODE, BMODE, TAPS, KSUB, 128, STRIDE, 2>(ctx, a);
   if (a.N > 32) return launch_t<T, AMODE, BMODE, TAPS, KSUB, 64, STRIDE, 2>(ctx, a);
   return launch_t<T, AMODE, BMODE, TAPS, KSUB, 32, STRIDE, 2>(ctx, a);
