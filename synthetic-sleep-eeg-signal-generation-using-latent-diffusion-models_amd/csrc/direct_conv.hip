@@ -349,6 +349,58 @@ __global__ __launch_bounds__(NT) void dconv_wgrad_kernel(const T* __restrict__ x
   }
 }
 
+// vector-load version of the tiny weight gradient: exact channel counts as template constants, one load per row and tap
+template <typename T, int CI, int CO>
+__global__ __launch_bounds__(NT) void dconv_wgrad_tinyv_kernel(const T* __restrict__ x, long ldx, const T* __restrict__ dy, long lddy,
+                                                               float* __restrict__ dw, int B, int Lo, int Li, int K, int stride, int pad_l) {
+  float acc[3][CO][CI];
+#pragma unroll
+  for (int t = 0; t < 3; t++)
+#pragma unroll
+    for (int o = 0; o < CO; o++)
+#pragma unroll
+      for (int i = 0; i < CI; i++) acc[t][o][i] = 0.f;
+  const long rows = (long)B * Lo;
+#pragma unroll 2
+  for (long r = (long)blockIdx.x * NT + threadIdx.x; r < rows; r += (long)gridDim.x * NT) {
+    const int b = (int)(r / Lo), lo = (int)(r - (long)b * Lo);
+    const RowVec<T, CO> dv = *(const RowVec<T, CO>*)(dy + r * lddy);
+    float d[CO];
+#pragma unroll
+    for (int o = 0; o < CO; o++) d[o] = ld_f32(&dv.v[o]);
+#pragma unroll
+    for (int t = 0; t < 3; t++) {
+      const int v = lo * stride + t - pad_l;
+      if (t < K && v >= 0 && v < Li) {
+        const RowVec<T, CI> xv = *(const RowVec<T, CI>*)(x + ((long)b * Li + v) * ldx);
+#pragma unroll
+        for (int i = 0; i < CI; i++) {
+          const float xf = ld_f32(&xv.v[i]);
+#pragma unroll
+          for (int o = 0; o < CO; o++) acc[t][o][i] += d[o] * xf;
+        }
+      }
+    }
+  }
+  __shared__ float red[4][3 * CO * CI];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+  for (int t = 0; t < 3; t++)
+#pragma unroll
+    for (int o = 0; o < CO; o++)
+#pragma unroll
+      for (int i = 0; i < CI; i++) {
+        const float s = wave_sum(acc[t][o][i]);
+        if (lane == 0) red[wave][(t * CO + o) * CI + i] = s;
+      }
+  __syncthreads();
+  const int e = threadIdx.x;
+  if (e < 3 * CO * CI) {
+    const int t = e / (CO * CI);
+    if (t < K) atomicAdd(dw + e, red[0][e] + red[1][e] + red[2][e] + red[3][e]);      // dw is [K][CO][CI]: e is the flat index
+  }
+}
+
 // "tiny" variant (Cin, Cout <= 4; every layer of the [2,2,4] autoencoder): thread per output row with all K*Cout*Cin
 // partial sums in registers, wave-shuffle + LDS reduction, one atomic per element per block.
 template <typename T>
@@ -476,7 +528,21 @@ int dconv_wgrad(eegldm_ctx* ctx, int dtype, const void* x, long ldx, const void*
                 int Lout, int Cin, int Cout, int K, int stride, int pad_l) {
   const long rows = (long)B * Lout;
   if (Cin <= 4 && Cout <= 4 && K <= 3) {
-    const int blocks = grid_cap((rows + NT - 1) / NT, ctx) / 4 + 1;
+    long nb = (rows + NT - 1) / NT; if (nb > 2L * ctx->num_cu) nb = 2L * ctx->num_cu;
+    const int blocks = (int)(nb < 1 ? 1 : nb);
+    const bool pow2 = (Cin == 1 || Cin == 2 || Cin == 4) && (Cout == 1 || Cout == 2 || Cout == 4);
+    if (pow2 && ldx % Cin == 0 && lddy % Cout == 0) {
+#define DWV(T_, CI_, CO_) hipLaunchKernelGGL((dconv_wgrad_tinyv_kernel<T_, CI_, CO_>), dim3(blocks), dim3(NT), 0, ctx->stream, (const T_*)x, ldx, (const T_*)dy, lddy, \
+                                             dw, B, Lout, Lin, K, stride, pad_l)
+#define DWV_CO(T_, CI_) do { if (Cout == 1) DWV(T_, CI_, 1); else if (Cout == 2) DWV(T_, CI_, 2); else DWV(T_, CI_, 4); } while (0)
+#define DWV_T(T_) do { if (Cin == 1) DWV_CO(T_, 1); else if (Cin == 2) DWV_CO(T_, 2); else DWV_CO(T_, 4); } while (0)
+      if (dtype == EEGLDM_F32) DWV_T(float); else DWV_T(bf16_t);
+#undef DWV_T
+#undef DWV_CO
+#undef DWV
+      LAUNCH_CHECK();
+      return 0;
+    }
     if (dtype == EEGLDM_F32)
       hipLaunchKernelGGL((dconv_wgrad_tiny_kernel<float>), dim3(blocks), dim3(NT), 0, ctx->stream, (const float*)x, ldx, (const float*)dy, lddy,
                          dw, B, Lout, Lin, Cout, Cin, K, stride, pad_l);
