@@ -33,6 +33,9 @@ CONV_CASES = [
     (2, 64, 4, 4, 3, 2, 0, 1),
     (2, 64, 1, 64, 3, 2, 1, 1),          # discriminator first conv
     (2, 48, 512, 1, 3, 1, 1, 1),         # discriminator last conv
+    (8, 128, 64, 256, 3, 1, 1, 1),       # 8 M tiles x 2 N tiles: XCD-aware tile order (all N tiles of an M tile on one XCD)
+    (8, 128, 64, 256, 1, 1, 0, 0),       # same for the 1-tap kernels
+    (32, 512, 128, 256, 3, 1, 1, 1),     # split-K weight gradient with splitk % 8 == 0: one K split per XCD
 ]
 
 
@@ -72,18 +75,23 @@ def test_conv1d_fwd_bwd(case, dtype):
     G.assert_close(dbd, b.grad, rtol=G.GTOL[dtype]["rtol"], atol=G.GTOL[dtype]["atol"] * max(1.0, float(b.grad.abs().max())), name="db")
 
 
-def test_conv1d_epilogue_rowvec_resid():
+@pytest.mark.parametrize("dtype", [0, 1])
+def test_conv1d_epilogue_rowvec_resid(dtype):
+    """bias + per-sample embedding row + residual in the GEMM epilogue; L = 192 puts a sample boundary inside a 128-row tile
+    (fp32: LDS fp32 tile path; bf16: fragment-layout addends, packed-bf16 LDS transpose, prefetch under the last K stage)."""
     G = _imports()
-    B, L, Cin, Cout = 3, 64, 64, 128
+    B, L, Cin, Cout = 3, 192, 64, 128
     x = torch.from_numpy(normal((B, Cin, L), seed=1)); w = torch.from_numpy(normal((Cout, Cin, 3), seed=2)) / 14.0
     b = torch.from_numpy(normal((Cout,), seed=3)); e = torch.from_numpy(normal((B, Cout), seed=4)); r = torch.from_numpy(normal((B, Cout, L), seed=5))
+    if dtype == G.BF16:
+        x, w, r = x.bfloat16().float(), w.bfloat16().float(), r.bfloat16().float()
     y_ref = F.conv1d(x, w, b, padding=1) + e[:, :, None] + r
     c = G.ctx()
-    xd, wd, rd = G.nlc(x), G.pack_w(w), G.nlc(r)
-    yd = torch.empty(B * L, Cout, device=G.DEV); bd, ed = b.to(G.DEV), e.to(G.DEV)
+    xd, wd, rd = G.nlc(x, dtype), G.pack_w(w, dtype), G.nlc(r, dtype)
+    yd = torch.empty(B * L, Cout, device=G.DEV, dtype=G.TDT[dtype]); bd, ed = b.to(G.DEV), e.to(G.DEV)
     G.check(G.lib.eegldm_conv1d_fwd(c.h, G.ptr(xd), Cin, G.ptr(wd), G.ptr(bd), G.ptr(yd), Cout, B, L, Cin, Cout, 3, 1, 1, 1,
-                                    G.ptr(ed), Cout, G.ptr(rd), Cout, 0))
-    G.assert_close(G.ncl(yd, B, L), y_ref, **G.TOL[0], name="y")
+                                    G.ptr(ed), Cout, G.ptr(rd), Cout, dtype))
+    G.assert_close(G.ncl(yd, B, L), y_ref, **G.TOL[dtype], name="y")
 
 
 GN_CASES = [  # B, L, C, G, silu, resample
