@@ -107,7 +107,7 @@ def main():
 
     gsync = D.OverlappedGradSync(unet.flat_grad) if world > 1 else None
 
-    def step(i):
+    def step(i, sync=True):
         t = randint(ctx, B, 1000, seed=1235 + rank, offset=i * B)
         noise = randn(ctx, (B, 1, L), seed=1236 + rank, offset=i * B * L)
         eps = randn(ctx, (B, 1, L), seed=1237 + rank, offset=i * B * L)
@@ -115,9 +115,10 @@ def main():
         unet.zero_grad()
         # N > 1: the all-reduce of out / output_blocks / middle_block gradients starts inside the native backward (grad hook)
         # and overlaps the input blocks' backward; the rest follows the call
-        ldm_train_step(unet, sched, latents, noise, t, loss_out=loss, grad_sync=gsync)
-        if gsync is not None:
-            gsync.wait()
+        gs = gsync if sync else None          # the rank-0-only profiling leg below must not enter a collective
+        ldm_train_step(unet, sched, latents, noise, t, loss_out=loss, grad_sync=gs)
+        if gs is not None:
+            gs.wait()
         opt.step()
 
     for i in range(args.warmup):
@@ -141,7 +142,7 @@ def main():
     if rank == 0 and not args.no_roofline:
         ctx.prof_enable(True)
         for i in range(2):
-            step(args.warmup + args.steps + i)
+            step(args.warmup + args.steps + i, sync=False)
         torch.cuda.synchronize()
         summ = ctx.prof_summary()
         ctx.prof_enable(False)
@@ -168,7 +169,7 @@ def main():
 
     # ---- secondary workloads (rank 0 only; not part of `value`)
     parts = None
-    if rank == 0 and not args.no_parts:
+    if rank == 0 and world == 1 and not args.no_parts:      # secondary workloads only on the single-GPU run
         parts = {}
         Ba = args.batch
         ae2 = AutoencoderKL(spatial_dims=1, in_channels=1, out_channels=1, num_channels=[2, 2, 4], latent_channels=1, num_res_blocks=2,

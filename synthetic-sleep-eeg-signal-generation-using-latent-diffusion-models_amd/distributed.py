@@ -17,6 +17,11 @@ def init_from_env(backend=None):
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    # test hooks: run several ranks on ONE GPU over gloo (EEGLDM_DIST_BACKEND=gloo EEGLDM_LOCAL_DEVICE=0) to exercise the
+    # multi-process control flow where only a single-GPU box is available
+    if "EEGLDM_LOCAL_DEVICE" in os.environ:
+        local = int(os.environ["EEGLDM_LOCAL_DEVICE"])
+    backend = backend or os.environ.get("EEGLDM_DIST_BACKEND")
     if world > 1 and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29511")
