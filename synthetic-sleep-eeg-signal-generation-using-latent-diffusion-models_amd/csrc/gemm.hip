@@ -170,7 +170,7 @@ struct Cfg {
   // DMA pads that tile (it is then refilled from the zero page every stage), else a slot behind the tiles
   static constexpr bool ZPAD = DMA && AMODE == GA_CONV && (A_BYTES + 16 <= A_ALLOC);
   static constexpr int ZOFF = ZPAD ? A_BYTES : LDS_BYTES;
-  static constexpr int LDS_TOTAL = LDS_BYTES + (ZPAD ? 0 : 64);
+  static constexpr int LDS_TOTAL = LDS_BYTES + ((AMODE == GA_CONV && !ZPAD) ? 64 : 0);   // only conv kernels read the zero chunk
 };
 
 typedef __attribute__((address_space(3))) void* lds_void_ptr;
@@ -236,7 +236,7 @@ __global__ __launch_bounds__((WMT == 3 ? 256 : 128 * WMT), 2) void gemm_kernel(c
   const int nstages = (kend - kbeg + C::KSTAGE - 1) / C::KSTAGE;
 
   const uint4 zero4 = make_uint4(0, 0, 0, 0);
-  if constexpr (!C::ZPAD) { if (tid < 4) *(uint4*)(smem + C::LDS_BYTES + tid * 16) = zero4; }   // zero chunk behind the tiles (conv rows of other samples); visible after the first barrier
+  if constexpr (AMODE == GA_CONV && !C::ZPAD) { if (tid < 4) *(uint4*)(smem + C::LDS_BYTES + tid * 16) = zero4; }   // zero chunk behind the tiles (conv rows of other samples); visible after the first barrier
   const T* __restrict__ zeros = (const T*)p.zero_page;
 
   // ---- staging: global -> LDS by DMA (global_load_lds_dwordx4).  LDS chunk c of a tile receives the
@@ -814,7 +814,7 @@ int launch_t(eegldm_ctx* ctx, const GemmArgs& a) {
   if constexpr (AMODE == GA_CONV && TAPS == 3) {
     if (a.K % KSTAGE == 0 && a.splitk == 1) return launch_k<T, AMODE, BMODE, TAPS, KSUB, BN, STRIDE, WMT, true>(ctx, a);
   }
-  if constexpr (AMODE == GA_PLAIN && WMT == 2) {
+  if constexpr (AMODE == GA_PLAIN && (WMT == 2 || WMT == 3)) {
     // 1x1 conv / Linear / attention products: same double-buffered DMA ring (K % KSTAGE == 0 on all production shapes)
     static const bool no_dma1 = getenv("EEGLDM_GEMM1_NO_DMA") != nullptr;
     if (!no_dma1 && a.K % KSTAGE == 0 && a.splitk == 1) return launch_k<T, AMODE, BMODE, TAPS, KSUB, BN, STRIDE, WMT, true>(ctx, a);
@@ -865,6 +865,15 @@ int launch_modes(eegldm_ctx* ctx, const GemmArgs& a) {
     return launch_t<T, GA_TR, GB_TR, 3, 2, 32, 1, 2>(ctx, a);
   }
   EEG_CHECK(a.taps == 1, "taps>1 needs conv A mode");
+  // attention products at T = 192 (one sample = 1.5 tiles of 128 rows): 192-row tiles (two waves x six fragments) and, for
+  // the 192-wide QK^T output, 64-wide N tiles -- no half-empty tiles (25..44 % of the MFMA work of those launches)
+  if constexpr (sizeof(T) == 2) {
+    static const bool no192 = getenv("EEGLDM_GEMM_NO_ATTN192") != nullptr;
+    if (!no192 && a.amode == GA_PLAIN && a.batch > 1 && a.M % 192 == 0 && a.M % 128 != 0 && a.splitk == 1 && a.K % 64 == 0) {
+      if (a.bmode == GB_NT) return (a.N % 128 == 0) ? launch_t<T, GA_PLAIN, GB_NT, 1, 2, 128, 1, 3>(ctx, a) : launch_t<T, GA_PLAIN, GB_NT, 1, 2, 64, 1, 3>(ctx, a);
+      return (a.N % 128 == 0) ? launch_t<T, GA_PLAIN, GB_TR, 1, 2, 128, 1, 3>(ctx, a) : launch_t<T, GA_PLAIN, GB_TR, 1, 2, 64, 1, 3>(ctx, a);
+    }
+  }
   static const bool deep1 = getenv("EEGLDM_GEMM1_DEEP") != nullptr;   // short stages, 4-deep DMA ring (see Cfg::NSTG)
   if (deep1 && a.amode == GA_PLAIN && a.splitk == 1 && a.K % Tr<T>::KC == 0) {
     if (a.bmode == GB_NT) return launch_bn<T, GA_PLAIN, GB_NT, 1, 1, 1>(ctx, a);
