@@ -315,6 +315,26 @@ __global__ __launch_bounds__(NT) void gn_bwd_apply_kernel(const T* __restrict__ 
   }
 }
 
+// effective upstream gradient from a wave-uniform per-sample base and 32-bit byte offsets (the one-pass kernels: per-lane
+// 64-bit pointer arithmetic was ~30 % of their VALU instructions, and they are VALU-bound)
+template <typename T>
+__device__ __forceinline__ void load_dy_eff32(const char* base, unsigned ldb, unsigned cb, int l, int resample, float d[4]) {
+  if (resample == 0) {
+    load4<T>((const T*)(base + ((unsigned)l * ldb + cb)), d);
+  } else if (resample == 1) {
+    load4<T>((const T*)(base + ((unsigned)(l >> 1) * ldb + cb)), d);
+#pragma unroll
+    for (int k = 0; k < 4; k++) d[k] *= 0.5f;
+  } else {
+    float e[4];
+    load4<T>((const T*)(base + ((unsigned)(2 * l) * ldb + cb)), d);
+    load4<T>((const T*)(base + ((unsigned)(2 * l + 1) * ldb + cb)), e);
+#pragma unroll
+    for (int k = 0; k < 4; k++) d[k] += e[k];
+  }
+}
+__device__ __forceinline__ long dy_rows(int L, int resample) { return resample == 1 ? L / 2 : (resample == 2 ? 2L * L : L); }
+
 // ------------------------------------------------------------------ register-resident one-pass GroupNorm
 // A 1024-thread block owns ONE sample x a chunk of CC channels (whole groups) over the full length L and keeps its
 // rows in registers: x (and dy) are read from HBM exactly once, statistics / group sums are reduced inside the
@@ -431,6 +451,12 @@ __global__ __launch_bounds__(NTB) void gn_fwd_resident_kernel(const T* __restric
 
 // backward: dgamma/dbeta partials go to the slot buffers (folded by gn_slot_reduce_kernel); colsum_ps (optional) receives
 // the per-sample column sums of the written dx -- the block owns (sample, channels) over all of L, so no atomics.
+#ifdef EEG_STAGE_TIMING
+__device__ unsigned long long gn_tlog[4096 * 8];
+#define GN_TSTAMP(k) do { if (threadIdx.x == 0) { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); gn_tlog[((size_t)blockIdx.y * gridDim.x + blockIdx.x) % 4096 * 8 + (k)] = __builtin_readcyclecounter(); } } while (0)
+#else
+#define GN_TSTAMP(k) do {} while (0)
+#endif
 template <typename T, int RPT>
 __global__ __launch_bounds__(NTB) void gn_bwd_resident_kernel(const T* __restrict__ x, long ldx, const float* __restrict__ gamma,
                                                               const float* __restrict__ beta, const float* __restrict__ stats,
@@ -440,25 +466,32 @@ __global__ __launch_bounds__(NTB) void gn_bwd_resident_kernel(const T* __restric
                                                               int L, int C, int G, int silu, int resample, int CC) {
   __shared__ float redg[2 * RES_MAXG];
   __shared__ float redc[3 * RES_MAXC];
+  GN_TSTAMP(0);
   const int b = blockIdx.y, cpg = C / G;
   const ResMap m = resmap(CC, C, cpg);
   for (int i = threadIdx.x; i < 2 * RES_MAXG + 3 * RES_MAXC; i += NTB) { if (i < 2 * RES_MAXG) redg[i] = 0.f; else redc[i - 2 * RES_MAXG] = 0.f; }
   typename Vec<T, 4>::type raw[RPT];
   float d[RPT][4];
+  // wave-uniform per-sample bases + 32-bit byte offsets (scalar-base addressing: one VALU add per access)
+  const char* xs = (const char*)(x + (long)b * L * ldx);
+  const char* dys = (const char*)(dy + (long)b * dy_rows(L, resample) * lddy);
+  const unsigned cb = (unsigned)m.c * (unsigned)sizeof(T);
+  const unsigned ldxb = (unsigned)ldx * (unsigned)sizeof(T), lddyb = (unsigned)lddy * (unsigned)sizeof(T);
   if (m.act) {
-    const T* xb = x + (long)b * L * ldx + m.c;
 #pragma unroll
     for (int k = 0; k < RPT; k++) {
       const int l = k * m.TY + m.ty;
-      if (l < L) raw[k] = *(const typename Vec<T, 4>::type*)(xb + (long)l * ldx);
+      if (l < L) raw[k] = *(const typename Vec<T, 4>::type*)(xs + ((unsigned)l * ldxb + cb));
     }
 #pragma unroll
     for (int k = 0; k < RPT; k++) {
       const int l = k * m.TY + m.ty;
-      if (l < L) load_dy_eff<T, 4>(dy, lddy, b, l, L, m.c, resample, d[k]);
+      if (l < L) load_dy_eff32<T>(dys, lddyb, cb, l, resample, d[k]);
     }
   }
+  GN_TSTAMP(1);
   __syncthreads();
+  GN_TSTAMP(2);
   float mean = 0.f, rstd = 0.f, ga[4], be[4];
   if (m.act) {
     const float* st = stats + ((long)b * G + m.c / cpg) * 2;
@@ -487,7 +520,9 @@ __global__ __launch_bounds__(NTB) void gn_bwd_resident_kernel(const T* __restric
       for (int j = 0; j < 4; j++) { atomicAdd(&redc[m.tx * 4 + j], dg[j]); atomicAdd(&redc[RES_MAXC + m.tx * 4 + j], db[j]); }
     }
   }
+  GN_TSTAMP(3);
   __syncthreads();
+  GN_TSTAMP(4);
   if (m.act) {
     const float inv_n = 1.0f / ((float)cpg * (float)L);
     const float m1 = redg[2 * m.gl] * inv_n, m2 = redg[2 * m.gl + 1] * inv_n;
@@ -497,7 +532,9 @@ __global__ __launch_bounds__(NTB) void gn_bwd_resident_kernel(const T* __restric
       for (int j = 0; j < 4; j++) { atomicAdd(&sl[m.c + j], redc[m.tx * 4 + j]); atomicAdd(&sl[C + m.c + j], redc[RES_MAXC + m.tx * 4 + j]); }
     }
     float cs[4] = {0.f, 0.f, 0.f, 0.f};
-    T* dxb = dx + (long)b * L * lddx + m.c;
+    char* dxs = (char*)(dx + (long)b * L * lddx);
+    const char* dxrs = dxr ? (const char*)(dxr + (long)b * dy_rows(L, resample) * lddxr) : nullptr;
+    const unsigned lddxb = (unsigned)lddx * (unsigned)sizeof(T), lddxrb = (unsigned)lddxr * (unsigned)sizeof(T);
 #pragma unroll
     for (int k = 0; k < RPT; k++) {
       const int l = k * m.TY + m.ty;
@@ -510,13 +547,13 @@ __global__ __launch_bounds__(NTB) void gn_bwd_resident_kernel(const T* __restric
         }
         if (dxr) {
           float e[4];
-          load_dy_eff<T, 4>(dxr, lddxr, b, l, L, m.c, resample, e);
+          load_dy_eff32<T>(dxrs, lddxrb, cb, l, resample, e);
 #pragma unroll
           for (int j = 0; j < 4; j++) o[j] += e[j];
         }
 #pragma unroll
         for (int j = 0; j < 4; j++) cs[j] += o[j];
-        store4<T>(dxb + (long)l * lddx, o);
+        store4<T>((T*)(dxs + ((unsigned)l * lddxb + cb)), o);
       }
     }
     if (colsum_ps) {
@@ -524,6 +561,7 @@ __global__ __launch_bounds__(NTB) void gn_bwd_resident_kernel(const T* __restric
       for (int j = 0; j < 4; j++) atomicAdd(&redc[2 * RES_MAXC + m.tx * 4 + j], cs[j]);
     }
   }
+  GN_TSTAMP(5);
   if (colsum_ps) {
     __syncthreads();
     if (m.act && m.ty == 0) {
@@ -696,3 +734,11 @@ extern "C" int eegldm_groupnorm_bwd(eegldm_ctx* ctx, const void* x, long ldx, co
   return op_groupnorm_bwd(ctx, x, ldx, gamma, beta, stats, dy, lddy, dx, lddx, dgamma, dbeta, B, L, C, G, fuse_silu, resample,
                           dxr, lddxr, dtype, nullptr, 0, nullptr);
 }
+
+#ifdef EEG_STAGE_TIMING
+extern "C" int eegldm_debug_read_gn_tlog(unsigned long long* dst_host, long n_words) {
+  HIP_TRY(hipDeviceSynchronize());
+  HIP_TRY(hipMemcpyFromSymbol(dst_host, HIP_SYMBOL(gn_tlog), n_words * 8));
+  return 0;
+}
+#endif
