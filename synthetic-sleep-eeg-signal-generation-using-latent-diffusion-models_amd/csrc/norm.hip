@@ -496,29 +496,36 @@ __global__ __launch_bounds__(NTB) void gn_bwd_resident_kernel(const T* __restric
   if (m.act) {
     const float* st = stats + ((long)b * G + m.c / cpg) * 2;
     mean = st[0]; rstd = st[1];
-    float dg[4] = {0.f, 0.f, 0.f, 0.f}, db[4] = {0.f, 0.f, 0.f, 0.f}, s1 = 0.f, s2 = 0.f;
+    float dg[4] = {0.f, 0.f, 0.f, 0.f}, db[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int j = 0; j < 4; j++) { ga[j] = gamma[m.c + j]; be[j] = beta[m.c + j]; }
+    // pass 1 is VALU issue-bound (profiles/r01_gemm_stage_timing.txt): xhat as one FMA, SiLU' evaluated unconditionally and
+    // selected (no per-element branch), and the group sums S1 = sum dz*gamma, S2 = sum dz*gamma*xhat are NOT accumulated per
+    // element -- they follow from the per-channel sums after the block reduction (S1 = sum_c gamma_c db_c, S2 = sum_c gamma_c dg_c)
+    const float nmr = -mean * rstd;
 #pragma unroll
     for (int k = 0; k < RPT; k++) {
       if (k * m.TY + m.ty < L) {
         float v[4]; unpack4<T>(raw[k], v);
 #pragma unroll
         for (int j = 0; j < 4; j++) {
-          const float xh = (v[j] - mean) * rstd;
-          float dz = d[k][j];
-          if (silu) dz *= silu_grad_f(ga[j] * xh + be[j]);
+          const float xh = fmaf(v[j], rstd, nmr);
+          const float sg = silu_grad_f(fmaf(ga[j], xh, be[j]));
+          const float dz = d[k][j] * (silu ? sg : 1.0f);
           d[k][j] = dz;
-          dg[j] += dz * xh; db[j] += dz;
-          s1 += dz * ga[j]; s2 += dz * ga[j] * xh;
+          dg[j] = fmaf(dz, xh, dg[j]); db[j] += dz;
         }
       }
     }
-    atomicAdd(&redg[2 * m.gl], s1); atomicAdd(&redg[2 * m.gl + 1], s2);
-    if (slots) {
 #pragma unroll
-      for (int j = 0; j < 4; j++) { atomicAdd(&redc[m.tx * 4 + j], dg[j]); atomicAdd(&redc[RES_MAXC + m.tx * 4 + j], db[j]); }
-    }
+    for (int j = 0; j < 4; j++) { atomicAdd(&redc[m.tx * 4 + j], dg[j]); atomicAdd(&redc[RES_MAXC + m.tx * 4 + j], db[j]); }
+  }
+  __syncthreads();
+  if (m.act && m.ty == 0) {
+    float p1 = 0.f, p2 = 0.f;
+#pragma unroll
+    for (int j = 0; j < 4; j++) { p1 = fmaf(ga[j], redc[RES_MAXC + m.tx * 4 + j], p1); p2 = fmaf(ga[j], redc[m.tx * 4 + j], p2); }
+    atomicAdd(&redg[2 * m.gl], p1); atomicAdd(&redg[2 * m.gl + 1], p2);
   }
   GN_TSTAMP(3);
   __syncthreads();
@@ -531,6 +538,11 @@ __global__ __launch_bounds__(NTB) void gn_bwd_resident_kernel(const T* __restric
 #pragma unroll
       for (int j = 0; j < 4; j++) { atomicAdd(&sl[m.c + j], redc[m.tx * 4 + j]); atomicAdd(&sl[C + m.c + j], redc[RES_MAXC + m.tx * 4 + j]); }
     }
+    // dx = rstd * (dz*gamma - m1 - xhat*m2) with the per-thread constants folded
+    const float rm1 = rstd * m1, rm2 = rstd * m2;
+    float gr[4];
+#pragma unroll
+    for (int j = 0; j < 4; j++) gr[j] = ga[j] * rstd;
     float cs[4] = {0.f, 0.f, 0.f, 0.f};
     char* dxs = (char*)(dx + (long)b * L * lddx);
     const char* dxrs = dxr ? (const char*)(dxr + (long)b * dy_rows(L, resample) * lddxr) : nullptr;
@@ -542,8 +554,8 @@ __global__ __launch_bounds__(NTB) void gn_bwd_resident_kernel(const T* __restric
         float v[4], o[4]; unpack4<T>(raw[k], v);
 #pragma unroll
         for (int j = 0; j < 4; j++) {
-          const float xh = (v[j] - mean) * rstd;
-          o[j] = rstd * (d[k][j] * ga[j] - m1 - xh * m2);
+          const float xh = fmaf(v[j], rstd, -mean * rstd);
+          o[j] = fmaf(d[k][j], gr[j], fmaf(xh, -rm2, -rm1));
         }
         if (dxr) {
           float e[4];
