@@ -457,7 +457,9 @@ __device__ unsigned long long gn_tlog[4096 * 8];
 #else
 #define GN_TSTAMP(k) do {} while (0)
 #endif
-template <typename T, int RPT>
+// RAW0: resample == 0 specialisation that fetches the gradient rows packed, in the same predicated block as the x rows (the
+// conversion in place makes hipcc wait for every load separately: 12 serialised HBM latencies, 19 k of the block's 57 k cycles)
+template <typename T, int RPT, bool RAW0>
 __global__ __launch_bounds__(NTB) void gn_bwd_resident_kernel(const T* __restrict__ x, long ldx, const float* __restrict__ gamma,
                                                               const float* __restrict__ beta, const float* __restrict__ stats,
                                                               const T* __restrict__ dy, long lddy, T* __restrict__ dx, long lddx,
@@ -477,16 +479,22 @@ __global__ __launch_bounds__(NTB) void gn_bwd_resident_kernel(const T* __restric
   const char* dys = (const char*)(dy + (long)b * dy_rows(L, resample) * lddy);
   const unsigned cb = (unsigned)m.c * (unsigned)sizeof(T);
   const unsigned ldxb = (unsigned)ldx * (unsigned)sizeof(T), lddyb = (unsigned)lddy * (unsigned)sizeof(T);
+  typename Vec<T, 4>::type dr[RAW0 ? RPT : 1];
   if (m.act) {
 #pragma unroll
     for (int k = 0; k < RPT; k++) {
       const int l = k * m.TY + m.ty;
-      if (l < L) raw[k] = *(const typename Vec<T, 4>::type*)(xs + ((unsigned)l * ldxb + cb));
+      if (l < L) {
+        raw[k] = *(const typename Vec<T, 4>::type*)(xs + ((unsigned)l * ldxb + cb));
+        if constexpr (RAW0) dr[k] = *(const typename Vec<T, 4>::type*)(dys + ((unsigned)l * lddyb + cb));
+      }
     }
+    if constexpr (!RAW0) {
 #pragma unroll
-    for (int k = 0; k < RPT; k++) {
-      const int l = k * m.TY + m.ty;
-      if (l < L) load_dy_eff32<T>(dys, lddyb, cb, l, resample, d[k]);
+      for (int k = 0; k < RPT; k++) {
+        const int l = k * m.TY + m.ty;
+        if (l < L) load_dy_eff32<T>(dys, lddyb, cb, l, resample, d[k]);
+      }
     }
   }
   GN_TSTAMP(1);
@@ -507,6 +515,7 @@ __global__ __launch_bounds__(NTB) void gn_bwd_resident_kernel(const T* __restric
     for (int k = 0; k < RPT; k++) {
       if (k * m.TY + m.ty < L) {
         float v[4]; unpack4<T>(raw[k], v);
+        if constexpr (RAW0) unpack4<T>(dr[k], d[k]);
 #pragma unroll
         for (int j = 0; j < 4; j++) {
           const float xh = fmaf(v[j], rstd, nmr);
@@ -663,11 +672,14 @@ int gn_bwd_t(eegldm_ctx* ctx, const void* x, long ldx, const float* gamma, const
     if (cc) {
       const dim3 grid(C / cc, B);
       float* slots = dgamma ? (float*)((char*)ctx->scratch + GN_SLOT_OFFSET) : nullptr;
-#define GN_BWD_RES(R) hipLaunchKernelGGL((gn_bwd_resident_kernel<T, R>), grid, dim3(NTB), 0, ctx->stream, (const T*)x, ldx, gamma, beta, stats, \
+#define GN_BWD_RES1(R, RAW) hipLaunchKernelGGL((gn_bwd_resident_kernel<T, R, RAW>), grid, dim3(NTB), 0, ctx->stream, (const T*)x, ldx, gamma, beta, stats, \
                                          (const T*)dy, lddy, (T*)dx, lddx, (const T*)dxr, lddxr, slots, colsum_ps, ldps, L, C, G, silu, resample, cc)
+      static const bool raw0 = getenv("EEGLDM_GN_NO_RAW0") == nullptr;
+#define GN_BWD_RES(R) do { if (resample == 0 && raw0) GN_BWD_RES1(R, true); else GN_BWD_RES1(R, false); } while (0)
       constexpr int RLO = sizeof(T) == 2 ? 6 : 4, RHI = sizeof(T) == 2 ? 12 : 8;
       if (rpt <= RLO) GN_BWD_RES(RLO); else GN_BWD_RES(RHI);
 #undef GN_BWD_RES
+#undef GN_BWD_RES1
       LAUNCH_CHECK();
       if (slots) {
         hipLaunchKernelGGL(gn_slot_reduce_kernel, dim3((2 * C + 255) / 256), dim3(256), 0, ctx->stream, slots, dgamma, dbeta, C, (double*)ctx->scratch, 0);
