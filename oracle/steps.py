@@ -5,6 +5,7 @@ training / sampling loops compose them, in fp32 on the CPU with torch autograd
 and torch.optim.Adam (what the reference itself calls):
 
 * ldm_train_step   /root/reference/src/training/training.py:419-443
+* dm_train_step    /root/reference/src/training/training_diffusion.py:133-158 (pixel-space DM, optional spectral term)
 * aekl_train_step  /root/reference/src/train_autoencoderkl.py:200-234
 * ddim_sample      /root/reference/src/sample_trials.py:149-170
 
@@ -33,6 +34,20 @@ def ldm_train_step(unet_sd, unet_cfg, acp, latents, noise, t, prediction_type="e
     pred = U.unet_forward(sd, unet_cfg, noisy, t)
     target = noise if prediction_type == "epsilon" else Ls.get_velocity(acp, latents, noise, t)
     loss = F.mse_loss(pred.float(), target.float())
+    loss.backward()
+    grads = {k: v.grad for k, v in sd.items() if v.is_floating_point() and v.grad is not None}
+    return loss.detach(), grads, pred.detach()
+
+
+def dm_train_step(unet_sd, unet_cfg, acp, images, noise, t, spectral_weight=0.0, spectral_loss=False):
+    """Pixel-space diffusion step (training_diffusion.py:141-151): epsilon prediction on the raw windows,
+    loss = mse(noise_pred, noise) [+ spectral_weight * JukeboxLoss(sum)(noise_pred, noise)]."""
+    sd = _leafify(unet_sd)
+    noisy = Ls.add_noise(acp, images, noise, t)
+    pred = U.unet_forward(sd, unet_cfg, noisy, t)
+    loss = F.mse_loss(pred.float(), noise.float())
+    if spectral_loss:
+        loss = loss + spectral_weight * Ls.jukebox_loss(pred.float(), noise.float(), reduction="sum")
     loss.backward()
     grads = {k: v.grad for k, v in sd.items() if v.is_floating_point() and v.grad is not None}
     return loss.detach(), grads, pred.detach()

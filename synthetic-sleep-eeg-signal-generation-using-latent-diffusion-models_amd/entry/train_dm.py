@@ -1,0 +1,79 @@
+"""Pixel-space diffusion training directly on the (B,1,3072) windows -- counterpart of
+/root/reference/src/train_pure_ldm.py + src/training/training_diffusion.py::train_epoch_diffusion (config_dm.yaml; BASELINE C5):
+UNet with in/out channels forced to 1 (train_pure_ldm.py:113-115), DDPMScheduler("linear_beta", 0.0015, 0.0195) (:123-124),
+Adam 1e-4 (:136), loss = mse(noise_pred, noise) [+ 1e-6 * JukeboxLoss(sum) with --spe spectral (:128-132, :157-158)].
+One process per GPU under torch.distributed.run for data parallelism."""
+import argparse
+import os
+import time
+
+import torch
+
+from .. import distributed as D
+from ..models import UNetModel
+from ..schedulers import DDPMScheduler
+from ..training import Adam, dm_train_step, randint, randn
+from .common import WindowLoader, load_config, setup_run_dir
+
+
+def parse_args(argv=None):
+    p = argparse.ArgumentParser()
+    p.add_argument("--config_file", required=True)
+    p.add_argument("--path_train_ids", default=None); p.add_argument("--path_valid_ids", default=None)
+    p.add_argument("--path_cached_data", default=None); p.add_argument("--path_pre_processed", default=None)
+    p.add_argument("--spe", default="no-spectral"); p.add_argument("--type_dataset", default="edfx"); p.add_argument("--dataset", default="edfx")
+    p.add_argument("--synthetic_windows", type=int, default=0); p.add_argument("--dtype", default="float32")
+    p.add_argument("--max_steps", type=int, default=0); p.add_argument("--output_dir", default=None)
+    return p.parse_args(argv)
+
+
+def main(args):
+    rank, local, world = D.init_from_env()
+    torch.cuda.set_device(local)
+    config = load_config(args.config_file)
+    torch.manual_seed(config.train.seed)
+    run_dir, _resume = setup_run_dir(config, args)
+    up = dict(config.model.params.unet_config.params)
+    up["in_channels"] = up["out_channels"] = 1                                  # train_pure_ldm.py:113-115
+    unet = UNetModel(**up, dtype=args.dtype, device=local)
+    D.broadcast_flat(unet.flat); unet.sync_weights()
+    sched = DDPMScheduler(num_train_timesteps=1000, schedule="linear_beta", beta_start=0.0015, beta_end=0.0195, device=local)
+    opt = Adam(unet, lr=1e-4)
+    spectral = args.spe == "spectral"
+    bs = max(1, config.train.batch_size // world)
+    train = WindowLoader(args.path_pre_processed, bs, args.synthetic_windows, seed=config.train.seed + rank, drop_last=config.train.drop_last)
+    dev, ctx = unet.device, unet.ctx
+    loss = torch.zeros(1, device=dev)
+    gsync = D.OverlappedGradSync(unet.flat_grad)          # no-op with one process
+    steps, t0, seen, best = 0, time.time(), 0, float("inf")
+    for epoch in range(config.train.n_epochs):
+        unet.train()
+        for batch in train:
+            x = batch["eeg"].to(dev)
+            B = x.shape[0]
+            t = randint(ctx, B, sched.num_train_timesteps, seed=config.train.seed + 11 + rank, offset=steps * B)
+            noise = randn(ctx, tuple(x.shape), seed=config.train.seed + 13 + rank, offset=steps * x.numel())
+            opt.zero_grad()
+            dm_train_step(unet, sched, x, noise, t, spectral_weight=1e-6, spectral_loss=spectral, loss_out=loss, grad_sync=gsync)
+            gsync.wait()
+            opt.step()
+            steps += 1; seen += B * world
+            if args.max_steps and steps >= args.max_steps:
+                break
+        if rank == 0:
+            print(f"epoch {epoch}: loss {float(loss):.5f} | {seen/(time.time()-t0):.1f} windows/s", flush=True)
+            cur = float(loss)
+            if cur <= best:
+                best = cur
+                torch.save({k: v.cpu() for k, v in unet.state_dict().items()}, os.path.join(run_dir, "best_model.pth"))
+            torch.save({"epoch": epoch + 1, "diffusion": {k: v.cpu() for k, v in unet.state_dict().items()}, "optimizer": opt.state_dict(),
+                        "best_loss": best}, os.path.join(run_dir, "checkpoint.pth"))
+        if args.max_steps and steps >= args.max_steps:
+            break
+    if rank == 0:
+        torch.save({k: v.cpu() for k, v in unet.state_dict().items()}, os.path.join(run_dir, "final_model.pth"))
+    return run_dir
+
+
+if __name__ == "__main__":
+    main(parse_args())

@@ -77,6 +77,38 @@ def ldm_train_step(unet, scheduler, latents, noise, timesteps, loss_out=None, gr
     return loss_out
 
 
+def dm_train_step(unet, scheduler, images, noise, timesteps, spectral_weight=0.0, spectral_loss=False, loss_out=None, grad_sync=None):
+    """Pixel-space diffusion step of /root/reference/src/training/training_diffusion.py:141-151 (config_dm.yaml, BASELINE C5):
+    epsilon prediction directly on the (B,1,3072) windows, loss = mse(noise_pred, noise) [+ spectral_weight *
+    JukeboxLoss(sum)(noise_pred, noise)].  Composed from the same native calls as the latent step: add_noise, UNet forward,
+    MSE (writes d pred), spectral loss (accumulates its gradient into d pred), hand-written backward.  Returns the loss tensor."""
+    dev = unet.device
+    if loss_out is None:
+        loss_out = torch.zeros(1, device=dev)
+    unet.train()
+    x = images.to(dev, torch.float32).contiguous(); nz = noise.to(dev, torch.float32).contiguous()
+    B, Cc, L = x.shape
+    noisy = scheduler.add_noise(original_samples=x, noise=nz, timesteps=timesteps)
+    pred = unet(noisy, timesteps=timesteps)
+    dpred = torch.empty_like(pred)
+    check(lib.eegldm_mse_loss(unet.ctx.h, ptr(pred), ptr(nz), ptr(loss_out), ptr(dpred), pred.numel(), 1.0))
+    if spectral_loss:
+        spec = torch.zeros(1, device=dev)
+        check(lib.eegldm_spectral_loss(unet.ctx.h, ptr(pred), ptr(nz), ptr(spec), ptr(dpred), B, Cc, L, float(spectral_weight)))
+        loss_out.add_(spec, alpha=float(spectral_weight))
+    if grad_sync is not None:
+        grad_sync.begin()
+        set_grad_hook(unet, grad_sync.on_ready)
+    try:
+        unet.backward(dpred)
+    finally:
+        if grad_sync is not None:
+            set_grad_hook(unet, None)
+    if grad_sync is not None:
+        grad_sync.finish()
+    return loss_out
+
+
 def randn(ctx, shape, seed, offset=0, device=None):
     out = torch.empty(shape, device=device or torch.device("cuda", ctx.device), dtype=torch.float32)
     check(lib.eegldm_randn(ctx.h, ptr(out), out.numel(), seed, offset))

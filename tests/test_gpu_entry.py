@@ -53,3 +53,16 @@ def test_train_aekl_train_ldm_sample(tmp_path):
         s = np.load(os.path.join(sdir, f"sample_{i}.npy"))
         assert s.shape == (1, 1, 3000) and np.isfinite(s).all()
     assert not os.path.exists(os.path.join(sdir, "sample_6.npy"))
+
+
+def test_train_pixel_dm(tmp_path):
+    """train_pure_ldm.py counterpart: UNet directly on (B,1,3072) windows, in/out channels forced to 1, optional spectral term."""
+    from eegldm.entry import train_dm as TD
+    out = str(tmp_path)
+    d_yaml = os.path.join(out, "dm.yaml")
+    d = dict(LDM_YAML); d["train"] = dict(d["train"], output_dir=out, run_dir="dm_eeg", batch_size=4)
+    yaml.safe_dump(d, open(d_yaml, "w"))
+    run_d = TD.main(TD.parse_args(["--config_file", d_yaml, "--spe", "spectral", "--synthetic_windows", "8", "--max_steps", "2"]))
+    ck = torch.load(os.path.join(run_d, "checkpoint.pth"))
+    assert set(ck) >= {"epoch", "diffusion", "optimizer", "best_loss"} and np.isfinite(ck["best_loss"])
+    assert ck["diffusion"]["input_blocks.0.0.weight"].shape == (32, 1, 3)          # in_channels forced to 1 (train_pure_ldm.py:113-115)

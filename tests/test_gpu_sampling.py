@@ -64,3 +64,29 @@ def test_ldm_step_with_frozen_encoder_matches_oracle():
     num = sum(float((g[k].cpu() - grads_ref[k]).double().pow(2).sum()) for k in grads_ref)
     den = sum(float(grads_ref[k].double().pow(2).sum()) for k in grads_ref)
     assert (num / den) ** 0.5 < 1e-4
+
+
+@pytest.mark.parametrize("spectral", [False, True])
+def test_pixel_dm_step_matches_oracle(spectral):
+    """Pixel-space diffusion step (training_diffusion.py:141-151, config_dm.yaml): mse(noise_pred, noise) [+ w * JukeboxLoss(sum)]
+    on raw windows; L = 256 is one of the FFT lengths the spectral kernel implements."""
+    from eegldm.models import UNetModel
+    from eegldm.schedulers import DDPMScheduler
+    from eegldm.training import dm_train_step
+    from oracle import losses as Ls, steps as S, unet as U
+    ucfg, _B, _L = UNET_CASES["tiny_l64"]
+    usd = {k: torch.from_numpy(gen_param(81, k, s)) for k, s in U.unet_param_shapes(ucfg).items()}
+    B, L, w = 3, 256, 0.05
+    x = torch.from_numpy(eeg_windows(B, seed=83, length=L, pad=8))
+    noise = torch.from_numpy(normal((B, 1, L), seed=85)); t = torch.from_numpy(timesteps(B, seed=86))
+    acp = Ls.alphas_cumprod("scaled_linear_beta", 1000, 0.0015, 0.0195)
+    loss_ref, grads_ref, _ = S.dm_train_step(usd, ucfg, acp, x, noise, t, spectral_weight=w, spectral_loss=spectral)
+    unet = UNetModel(**ucfg); unet.load_state_dict(usd)
+    sched = DDPMScheduler(1000, schedule="scaled_linear_beta", beta_start=0.0015, beta_end=0.0195)
+    unet.zero_grad()
+    loss = dm_train_step(unet, sched, x, noise, t.to(unet.device), spectral_weight=w, spectral_loss=spectral)
+    assert abs(float(loss) - float(loss_ref)) < 2e-4 * abs(float(loss_ref)), (float(loss), float(loss_ref))
+    g = unet.grad_dict()
+    num = sum(float((g[k].cpu() - grads_ref[k]).double().pow(2).sum()) for k in grads_ref)
+    den = sum(float(grads_ref[k].double().pow(2).sum()) for k in grads_ref)
+    assert (num / den) ** 0.5 < 2e-4
