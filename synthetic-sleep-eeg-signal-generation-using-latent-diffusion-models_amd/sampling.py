@@ -20,6 +20,8 @@ def ddim_sample(unet, autoencoder, scheduler, noise, scale_factor=1.0, crop=36):
         tt.fill_(int(t))
         out = unet(x, timesteps=tt)
         x, _ = scheduler.step(out, int(t), x)
+    if autoencoder is None:      # pixel-space model (sample_trials_ddpm.py:99-104): the UNet output IS the window
+        return (x[:, :, crop:-crop] if crop else x), x
     z = x
     if float(scale_factor) != 1.0:
         z = x.clone()
@@ -38,7 +40,8 @@ def make_sampling_scheduler(num_inference_steps=50, prediction_type="epsilon", b
 
 
 def sample_seeds(unet, autoencoder, scheduler, seeds, latent_len=768, scale_factor=1.0, crop=36):
-    """One window per seed (sample_trials.py:149-151 draws a fresh N(0,1) latent per seed), batched."""
+    """One window per seed (sample_trials.py:149-151 draws a fresh N(0,1) latent per seed), batched.
+    autoencoder=None samples a pixel-space model: latent_len is then the window length (3072)."""
     lat = unet.in_channels
     noise = torch.empty(len(seeds), lat, latent_len, device=unet.device)
     for i, sd in enumerate(seeds):

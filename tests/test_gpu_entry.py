@@ -66,3 +66,9 @@ def test_train_pixel_dm(tmp_path):
     ck = torch.load(os.path.join(run_d, "checkpoint.pth"))
     assert set(ck) >= {"epoch", "diffusion", "optimizer", "best_loss"} and np.isfinite(ck["best_loss"])
     assert ck["diffusion"]["input_blocks.0.0.weight"].shape == (32, 1, 3)          # in_channels forced to 1 (train_pure_ldm.py:113-115)
+    from eegldm.entry import sample_trials_dm as SD
+    sdir = SD.main(SD.parse_args(["--output_dir", out, "--config_file", d_yaml, "--diffusion_path", run_d, "--start_seed", "1", "--stop_seed", "3",
+                                  "--num_inference_steps", "4"]))
+    for i in (1, 2):
+        s = np.load(os.path.join(sdir, f"sample_{i}.npy"))
+        assert s.shape == (1, 1, 3000) and np.isfinite(s).all()                    # sample_trials_ddpm.py:104-105
