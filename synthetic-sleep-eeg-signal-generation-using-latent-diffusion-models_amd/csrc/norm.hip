@@ -359,12 +359,19 @@ __device__ __forceinline__ int res_row(int k, int ty, int TY, bool pair) {
   return pair ? 2 * ((k >> 1) * TY + ty) + (k & 1) : k * TY + ty;
 }
 
+#ifdef EEG_STAGE_TIMING
+__device__ unsigned long long gn_tlog[4096 * 8];
+#define GN_TSTAMP(k) do { if (threadIdx.x == 0) { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); gn_tlog[((size_t)blockIdx.y * gridDim.x + blockIdx.x) % 4096 * 8 + (k)] = __builtin_readcyclecounter(); } } while (0)
+#else
+#define GN_TSTAMP(k) do {} while (0)
+#endif
 template <typename T, int RPT>
 __global__ __launch_bounds__(NTB) void gn_fwd_resident_kernel(const T* __restrict__ x, long ldx, const float* __restrict__ gamma,
                                                               const float* __restrict__ beta, T* __restrict__ y, long ldy,
                                                               T* __restrict__ xr, long ldxr, float* __restrict__ stats,
                                                               int L, int C, int G, float eps, int silu, int resample, int CC) {
   __shared__ float red[2 * RES_MAXG];
+  GN_TSTAMP(0);
   const int b = blockIdx.y, cpg = C / G;
   const ResMap m = resmap(CC, C, cpg);
   const bool pair = resample == 1;
@@ -378,7 +385,9 @@ __global__ __launch_bounds__(NTB) void gn_fwd_resident_kernel(const T* __restric
       if (l < L) raw[k] = *(const typename Vec<T, 4>::type*)(xb + (long)l * ldx);
     }
   }
+  GN_TSTAMP(1);
   __syncthreads();
+  GN_TSTAMP(2);
   const float inv_n = 1.0f / ((float)cpg * (float)L);
   float s = 0.f;
   if (m.act) {
@@ -389,6 +398,7 @@ __global__ __launch_bounds__(NTB) void gn_fwd_resident_kernel(const T* __restric
     atomicAdd(&red[m.gl], s);
   }
   __syncthreads();
+  GN_TSTAMP(3);
   float mean = 0.f, rstd = 0.f;
   if (m.act) {
     mean = red[m.gl] * inv_n;
@@ -404,6 +414,7 @@ __global__ __launch_bounds__(NTB) void gn_fwd_resident_kernel(const T* __restric
     atomicAdd(&red[RES_MAXG + m.gl], q);
   }
   __syncthreads();
+  GN_TSTAMP(4);
   if (!m.act) return;
   rstd = rsqrtf(red[RES_MAXG + m.gl] * inv_n + eps);
   if (m.ty == 0 && (m.tx * 4) % cpg == 0) { float* st = stats + ((long)b * G + m.c / cpg) * 2; st[0] = mean; st[1] = rstd; }
@@ -447,16 +458,11 @@ __global__ __launch_bounds__(NTB) void gn_fwd_resident_kernel(const T* __restric
       }
     }
   }
+  GN_TSTAMP(5);
 }
 
 // backward: dgamma/dbeta partials go to the slot buffers (folded by gn_slot_reduce_kernel); colsum_ps (optional) receives
 // the per-sample column sums of the written dx -- the block owns (sample, channels) over all of L, so no atomics.
-#ifdef EEG_STAGE_TIMING
-__device__ unsigned long long gn_tlog[4096 * 8];
-#define GN_TSTAMP(k) do { if (threadIdx.x == 0) { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); gn_tlog[((size_t)blockIdx.y * gridDim.x + blockIdx.x) % 4096 * 8 + (k)] = __builtin_readcyclecounter(); } } while (0)
-#else
-#define GN_TSTAMP(k) do {} while (0)
-#endif
 // RAW0: resample == 0 specialisation that fetches the gradient rows packed, in the same predicated block as the x rows (the
 // conversion in place makes hipcc wait for every load separately: 12 serialised HBM latencies, 19 k of the block's 57 k cycles)
 template <typename T, int RPT, bool RAW0>
@@ -632,7 +638,9 @@ int gn_fwd_t(eegldm_ctx* ctx, const void* x, long ldx, const float* gamma, const
              float* stats, int B, int L, int C, int G, float eps, int silu, int resample, void* xr, long ldxr) {
   if constexpr (V == 4) {
     static const bool off = getenv("EEGLDM_GN_NO_RESIDENT") != nullptr;
-    int rpt = 0; int cc = off ? 0 : resident_chunk(L, C, G, resample == 1, sizeof(T) == 2 ? 24 : 12, &rpt);
+    // 12 rows per thread (56 VGPRs: two 1024-thread blocks per CU) measured faster than 24 (one block per CU): 24 vs 35 us
+    static const int fwd_rpt_max = getenv("EEGLDM_GN_FWD_RPT") ? atoi(getenv("EEGLDM_GN_FWD_RPT")) : 12;
+    int rpt = 0; int cc = off ? 0 : resident_chunk(L, C, G, resample == 1, fwd_rpt_max, &rpt);
     // measured (tools/debug/gn_bench.py): wins while the rows are at least a 128-byte line and the blocks fit two rounds
     if (cc && (cc * (int)sizeof(T) < 128 || (long)(C / cc) * B > 2L * ctx->num_cu)) cc = 0;
     if (cc) {
