@@ -5,6 +5,7 @@
 // keep global accesses coalesced along the wide channel side and broadcast the thin side.
 // Layout NLC; weights packed [K][Cout][Cin] in the activation dtype; bias/grad fp32.
 #include "common.h"
+#include "internal.h"
 
 namespace {
 constexpr int NT = 256;
@@ -219,7 +220,7 @@ __global__ __launch_bounds__(NT) void dconv_thin_out_kernel(const DArgs a) {
 // WIDE_OUT: the wide side is Cout (dy rows are wide, x is thin) else Cin (x rows wide, dy thin).
 template <typename T, bool WIDE_OUT>
 __global__ __launch_bounds__(NT) void dconv_wgrad_wt_kernel(const T* __restrict__ x, long ldx, const T* __restrict__ dy, long lddy,
-                                                            float* __restrict__ dw, int B, int Lo, int Li, int Cout, int Cin, int K,
+                                                            float* __restrict__ dw, float* __restrict__ parts, int B, int Lo, int Li, int Cout, int Cin, int K,
                                                             int stride, int pad_l) {
   constexpr int G = 16 / sizeof(T);
   __shared__ float red[NT];
@@ -287,7 +288,10 @@ __global__ __launch_bounds__(NT) void dconv_wgrad_wt_kernel(const T* __restrict_
           for (int q = 0; q < rpb; q++) s += red[q * lpr + lane];
           const int wch = lane * G + k;
           const int co = WIDE_OUT ? wch : j, ci = WIDE_OUT ? j : wch;
-          atomicAdd(dw + ((long)t * Cout + co) * Cin + ci, s);
+          // written partial per block + a folding pass (hundreds of blocks adding atomically into the same few hundred
+          // addresses serialise in L2); plain atomics only when no workspace was given
+          const long e = ((long)t * Cout + co) * Cin + ci;
+          if (parts) parts[(long)blockIdx.x * ((long)K * Cout * Cin) + e] = s; else atomicAdd(dw + e, s);
         }
       }
 }
@@ -560,13 +564,17 @@ int dconv_wgrad(eegldm_ctx* ctx, int dtype, const void* x, long ldx, const void*
     if ((wide_out || wide_in) && K <= 3 && lpr <= NT && NT % lpr == 0) {
       const int rpb = NT / lpr;
       // few blocks: every block ends with one atomic per weight element on the SAME addresses (2048 blocks cost 460 us in atomics)
-      long nb = (rows + rpb - 1) / rpb; const long capb = (long)ctx->num_cu * 2; if (nb > capb) nb = capb;
+      const long E = (long)K * Cout * Cin;
+      long nb = (rows + rpb - 1) / rpb; const long capb = (long)ctx->num_cu * 8; if (nb > capb) nb = capb;
+      float* parts = ((size_t)nb * E * sizeof(float) <= (16u << 20)) ? (float*)((char*)ctx->scratch + (8u << 20)) : nullptr;
+      if (!parts) { const long cap2 = (long)ctx->num_cu * 2; if (nb > cap2) nb = cap2; }
 #define DWT(T_, WO_) hipLaunchKernelGGL((dconv_wgrad_wt_kernel<T_, WO_>), dim3((unsigned)nb), dim3(NT), 0, ctx->stream, (const T_*)x, ldx, (const T_*)dy, lddy, \
-                                        dw, B, Lout, Lin, Cout, Cin, K, stride, pad_l)
+                                        dw, parts, B, Lout, Lin, Cout, Cin, K, stride, pad_l)
       if (dtype == EEGLDM_F32) { if (wide_out) DWT(float, true); else DWT(float, false); }
       else { if (wide_out) DWT(bf16_t, true); else DWT(bf16_t, false); }
 #undef DWT
       LAUNCH_CHECK();
+      if (parts) EEG_TRY(ew_fold_partials(ctx, parts, (int)nb, (int)E, dw));
       return 0;
     }
   }

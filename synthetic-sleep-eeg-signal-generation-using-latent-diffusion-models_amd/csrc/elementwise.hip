@@ -338,6 +338,11 @@ int ew_colsum(eegldm_ctx* ctx, const void* x, long ldx, float* out_ps, long ldo,
   if (parts) { hipLaunchKernelGGL(colsum_finish_kernel, dim3((C + 63) / 64, 32), dim3(NT), 0, ctx->stream, parts, (int)nparts, C, total); LAUNCH_CHECK(); }
   return 0;
 }
+// total[i] += sum over nparts rows of parts[r][i] (i < n): the finishing pass of the written-partials reductions
+int ew_fold_partials(eegldm_ctx* ctx, const float* parts, int nparts, int n, float* total) {
+  hipLaunchKernelGGL(colsum_finish_kernel, dim3((n + 63) / 64, 32), dim3(NT), 0, ctx->stream, parts, nparts, n, total);
+  LAUNCH_CHECK(); return 0;
+}
 int ew_softmax(eegldm_ctx* ctx, const float* S, void* P, long rows, int n, int dtype) {
   DISPATCH_T(dtype, hipLaunchKernelGGL((softmax_kernel<T>), dim3((unsigned)((rows + 3) / 4)), dim3(NT), 0, ctx->stream, S, (T*)P, rows, n));
   LAUNCH_CHECK(); return 0;

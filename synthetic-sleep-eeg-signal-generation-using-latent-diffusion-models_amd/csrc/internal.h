@@ -42,3 +42,4 @@ int op_attention_bwd(eegldm_ctx*, int dtype, const void* qkv, long ldq, const vo
 int op_groupnorm_bwd(eegldm_ctx*, const void* x, long ldx, const float* gamma, const float* beta, const float* stats,
                      const void* dy, long lddy, void* dx, long lddx, float* dgamma, float* dbeta, int B, int L, int C, int G,
                      int fuse_silu, int resample, const void* dxr, long lddxr, int dtype, float* colsum_ps, long ldps, int* colsum_done);
+int ew_fold_partials(eegldm_ctx*, const float* parts, int nparts, int n, float* total);
