@@ -865,11 +865,16 @@ int launch_modes(eegldm_ctx* ctx, const GemmArgs& a) {
     return launch_t<T, GA_TR, GB_TR, 3, 2, 32, 1, 2>(ctx, a);
   }
   EEG_CHECK(a.taps == 1, "taps>1 needs conv A mode");
-  // attention products at T = 192 (one sample = 1.5 tiles of 128 rows): 192-row tiles (two waves x six fragments) and, for
-  // the 192-wide QK^T output, 64-wide N tiles -- no half-empty tiles (25..44 % of the MFMA work of those launches)
+  // 192-row tiles (two waves x six fragments) for the 1-tap kernels: a 16 KB stage of a 128-row tile carries only 32 MFMAs per
+  // wave against the ~2500-cycle DMA round trip; 192 rows carry 48 at the same 2 blocks per CU (80 KB LDS each).  The attention
+  // products at T = 192 additionally stop computing half-empty tiles (one sample = 1.5 tiles of 128 rows; 64-wide N tiles for
+  // the 192-wide QK^T output)
   if constexpr (sizeof(T) == 2) {
     static const bool no192 = getenv("EEGLDM_GEMM_NO_ATTN192") != nullptr;
-    if (!no192 && a.amode == GA_PLAIN && a.batch > 1 && a.M % 192 == 0 && a.M % 128 != 0 && a.splitk == 1 && a.K % 64 == 0) {
+    static const int all192 = getenv("EEGLDM_GEMM1_TILE192") ? atoi(getenv("EEGLDM_GEMM1_TILE192")) : 1;   // 1-tap kernels: +2..8 % on every UNet shape
+    const bool attn192 = a.batch > 1 && a.M % 192 == 0 && a.M % 128 != 0;
+    const bool conv192 = all192 && a.batch == 1 && a.M % 192 == 0 && a.K >= 64 * all192;
+    if (!no192 && a.amode == GA_PLAIN && (attn192 || conv192) && a.splitk == 1 && a.K % 64 == 0) {
       if (a.bmode == GB_NT) return (a.N % 128 == 0) ? launch_t<T, GA_PLAIN, GB_NT, 1, 2, 128, 1, 3>(ctx, a) : launch_t<T, GA_PLAIN, GB_NT, 1, 2, 64, 1, 3>(ctx, a);
       return (a.N % 128 == 0) ? launch_t<T, GA_PLAIN, GB_TR, 1, 2, 128, 1, 3>(ctx, a) : launch_t<T, GA_PLAIN, GB_TR, 1, 2, 64, 1, 3>(ctx, a);
     }
