@@ -47,6 +47,7 @@ struct eegldm_ctx {
   void* zero_page = nullptr;   // 4 KiB of zeros: source of out-of-range LDS-DMA chunks
   // second stream for the weight-gradient GEMMs of the backward pass (nothing downstream of a layer needs its dW before
   // the optimizer): they overlap the dgrad -> GroupNorm-backward chain instead of serialising with it
+  void* splitk_ws = nullptr; size_t splitk_ws_bytes = 0;   // partial tiles of split-K weight gradients (grown on demand)
   hipStream_t side = nullptr;
   hipEvent_t ev_fork = nullptr, ev_join = nullptr;
   bool side_on = false;
@@ -111,6 +112,7 @@ struct GemmArgs {
   const void* A; long lda; long sAb;            // batch stride (elements)
   const void* B; long ldb; long sBb; long sBt;  // batch / tap strides (elements)
   void* C; long ldc; long sCb; long sCt;        // sCt: per-tap output stride (wgrad-by-tap)
+  long sCk;                                     // per-K-split output stride (split-K partials written to a workspace), else 0
   int M, N, K;           // per batch (and per tap); K = reduction length
   int batch;
   int taps;              // taps folded in the K loop (conv fwd/dgrad): 1 or 3

@@ -548,7 +548,7 @@ __global__ __launch_bounds__((WMT == 3 ? 256 : 128 * WMT), 2) void gemm_kernel(c
   // acc[i][j][r] = C[m = wm*64 + i*16 + lm][n = wn*(BN/2) + j*16 + q*4 + r] (operands were swapped).
   // 4/EPI_I passes through an fp32 LDS tile, then 4-wide vector read-modify-store.
   char* Cb = (char*)p.C;
-  const long cbase = (long)bz * p.sCb + (long)tz * p.sCt;
+  const long cbase = (long)bz * p.sCb + (long)tz * p.sCt + (long)ksplit * p.sCk;
   constexpr int CH = BN / 4;                      // 4-element chunks per row
   constexpr int NCH = C::EPI_ROWS * CH;           // chunks per pass
   if constexpr (AMODE == GA_TR) {
@@ -892,6 +892,18 @@ int launch_modes(eegldm_ctx* ctx, const GemmArgs& a) {
 
 }  // namespace
 
+// dst[i] += sum_r ws[r][i]: one thread per 4 outputs, streaming over the split-K partial tiles
+__global__ void splitk_fold_kernel(const float* __restrict__ ws, int nsplit, long n, float* __restrict__ dst) {
+  const long i = ((long)blockIdx.x * blockDim.x + threadIdx.x) * 4;
+  if (i >= n) return;
+  float4 s = *(const float4*)(dst + i);
+  for (int r = 0; r < nsplit; r++) {
+    const float4 v = *(const float4*)(ws + (long)r * n + i);
+    s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+  }
+  *(float4*)(dst + i) = s;
+}
+
 int gemm_launch(eegldm_ctx* ctx, const GemmArgs& a_in) {
   GemmArgs a = a_in;
   if (a.splitk < 1) a.splitk = 1;
@@ -910,7 +922,27 @@ int gemm_launch(eegldm_ctx* ctx, const GemmArgs& a_in) {
   EEG_CHECK(a.N % 4 == 0 && a.ldc % 4 == 0, "N and ldc must be multiples of 4 (vector epilogue): N=%d ldc=%ld", a.N, a.ldc);
   EEG_CHECK(!a.resid || a.ldr % 4 == 0, "ldr must be a multiple of 4");
   EEG_CHECK(!a.rowvec || a.ld_rowvec % 4 == 0, "ld_rowvec must be a multiple of 4");
-  if (a.splitk > 1) a.atomic_out = 1;
+  // Split-K weight gradients of 1-tap TN products: partial tiles are WRITTEN to a workspace (coalesced stores through the
+  // LDS epilogue) and folded into dW afterwards, instead of draining millions of fp32 atomics at ~370 G/s
+  // (profiles/r01_gemm_stage_timing.txt); the fused 3-tap kernel keeps its register atomics (three accumulator sets).
+  float* fold_dst = nullptr; long fold_n = 0;
+  if (a.splitk > 1 && a.amode == GA_TR && a.bmode == GB_TR && a.taps == 1 && a.ztaps == 1 && a.batch == 1 && a.atomic_out && a.ldc == a.N &&
+      !getenv("EEGLDM_GEMM_NO_SPLITK_WS")) {
+    const size_t need = (size_t)a.splitk * a.M * a.N * sizeof(float);
+    if (need <= (size_t)512 << 20) {
+      if (ctx->splitk_ws_bytes < need) {
+        if (ctx->splitk_ws) { HIP_TRY(hipStreamSynchronize(ctx->stream)); HIP_TRY(hipFree(ctx->splitk_ws)); ctx->splitk_ws = nullptr; ctx->splitk_ws_bytes = 0; }
+        HIP_TRY(hipMalloc(&ctx->splitk_ws, need)); ctx->splitk_ws_bytes = need;
+      }
+      // every split writes its whole tile (empty trailing splits are avoided by the even K partition below)
+      const int KST = 2 * (a.dtype == EEGLDM_F32 ? 16 : 32);
+      int per = (a.K + a.splitk - 1) / a.splitk; per = (per + KST - 1) / KST * KST;
+      a.splitk = (a.K + per - 1) / per;
+      fold_dst = (float*)a.C; fold_n = (long)a.M * a.N;
+      a.C = ctx->splitk_ws; a.sCk = fold_n; a.atomic_out = 0;
+    }
+  }
+  if (a.splitk > 1 && !fold_dst) a.atomic_out = 1;
   a.zero_page = ctx->zero_page;
   { static const bool no_swz = getenv("EEGLDM_GEMM_NO_XCD_SWIZZLE") != nullptr; a.xcd_swizzle = no_swz ? 0 : 1; }
   ProfRec rec; bool prof = ctx->prof_on;
@@ -927,6 +959,10 @@ int gemm_launch(eegldm_ctx* ctx, const GemmArgs& a_in) {
   if (a.dtype == EEGLDM_F32) rc = launch_modes<float>(ctx, a);
   else if (a.dtype == EEGLDM_BF16) rc = launch_modes<bf16_t>(ctx, a);
   else EEG_FAIL(EEGLDM_ERR_UNSUPPORTED, "dtype %d", a.dtype);
+  if (rc == 0 && fold_dst) {
+    hipLaunchKernelGGL(splitk_fold_kernel, dim3((unsigned)((fold_n / 4 + 255) / 256)), dim3(256), 0, ctx->stream, (const float*)ctx->splitk_ws, a.splitk, fold_n, fold_dst);
+    LAUNCH_CHECK();
+  }
   if (prof) { HIP_TRY(hipEventRecord(rec.b, ctx->stream)); ctx->prof.push_back(rec); }
   return rc;
 }
