@@ -660,6 +660,10 @@ __global__ __launch_bounds__((WMT == 3 ? 256 : 128 * WMT), 2) void gemm_kernel(c
     }
   }
   // tile row of (wm, i, r16) inside a pass: ((i % EPI_I) * WM + wm) * 16 + r16
+  // (the fused 3-tap weight gradient has three accumulator sets: one tile per tap, sCt apart)
+#pragma unroll
+  for (int aset = 0; aset < C::NACC; aset++) {
+  const long cbase_a = cbase + (long)aset * (C::NACC > 1 ? p.sCt : 0);
 #pragma unroll
   for (int pass = 0; pass < C::FM / C::EPI_I; pass++) {
 #pragma unroll
@@ -671,7 +675,7 @@ __global__ __launch_bounds__((WMT == 3 ? 256 : 128 * WMT), 2) void gemm_kernel(c
         if constexpr (AMODE == GA_TR) {
 #pragma unroll
           for (int r = 0; r < 4; r++)
-            *(float*)(smem + (trow + q * 4 + r) * C::EPI_PITCH + (wn * (BN / 2) + j * 16 + lm) * 4) = acc[0][i][j][r] * p.alpha;
+            *(float*)(smem + (trow + q * 4 + r) * C::EPI_PITCH + (wn * (BN / 2) + j * 16 + lm) * 4) = acc[aset][i][j][r] * p.alpha;
         } else {
           float4 v = make_float4(acc[0][i][j][0] * p.alpha, acc[0][i][j][1] * p.alpha, acc[0][i][j][2] * p.alpha, acc[0][i][j][3] * p.alpha);
           *(float4*)(smem + (trow + lm) * C::EPI_PITCH + (wn * (BN / 2) + j * 16 + q * 4) * 4) = v;
@@ -687,7 +691,7 @@ __global__ __launch_bounds__((WMT == 3 ? 256 : 128 * WMT), 2) void gemm_kernel(c
         const int row = c / BN, col = c % BN;
         const int g = row >> 4, ii = g / C::WM, wmr = g % C::WM;
         const int m = m0 + wmr * (C::FM * 16) + (pass * C::EPI_I + ii) * 16 + (row & 15), n = n0 + col;
-        if (m < p.M && n < p.N) atomicAdd((float*)Cb + cbase + (long)m * p.ldc + n, *(const float*)(smem + row * C::EPI_PITCH + col * 4));
+        if (m < p.M && n < p.N) atomicAdd((float*)Cb + cbase_a + (long)m * p.ldc + n, *(const float*)(smem + row * C::EPI_PITCH + col * 4));
       }
     } else {
       // Every thread owns one 4-column chunk (cs) of rows r0, r0+RSTEP, ...  All global reads of the pass are issued
@@ -755,7 +759,7 @@ __global__ __launch_bounds__((WMT == 3 ? 256 : 128 * WMT), 2) void gemm_kernel(c
       if (p.out_f32 || sizeof(T) == 4) {
 #pragma unroll
         for (int cc = 0; cc < NIT; cc++)
-          if (mm[cc] >= 0) *(float4*)((float*)Cb + cbase + (long)mm[cc] * p.ldc + n) = v[cc];
+          if (mm[cc] >= 0) *(float4*)((float*)Cb + cbase_a + (long)mm[cc] * p.ldc + n) = v[cc];
       } else {
 #pragma unroll
         for (int cc = 0; cc < NIT; cc++)
@@ -763,11 +767,12 @@ __global__ __launch_bounds__((WMT == 3 ? 256 : 128 * WMT), 2) void gemm_kernel(c
             uint2 o;
             o.x = pack_bf16x2(v[cc].x, v[cc].y);
             o.y = pack_bf16x2(v[cc].z, v[cc].w);
-            *(uint2*)((bf16_t*)Cb + cbase + (long)mm[cc] * p.ldc + n) = o;
+            *(uint2*)((bf16_t*)Cb + cbase_a + (long)mm[cc] * p.ldc + n) = o;
           }
       }
     }
-    if (pass + 1 < C::FM / C::EPI_I) __syncthreads();
+    if (pass + 1 < C::FM / C::EPI_I || aset + 1 < C::NACC) __syncthreads();
+  }
   }
   TSTAMP();   // E5: stores issued
 #ifdef EEG_STAGE_TIMING
@@ -926,9 +931,10 @@ int gemm_launch(eegldm_ctx* ctx, const GemmArgs& a_in) {
   // LDS epilogue) and folded into dW afterwards, instead of draining millions of fp32 atomics at ~370 G/s
   // (profiles/r01_gemm_stage_timing.txt); the fused 3-tap kernel keeps its register atomics (three accumulator sets).
   float* fold_dst = nullptr; long fold_n = 0;
-  if (a.splitk > 1 && a.amode == GA_TR && a.bmode == GB_TR && a.taps == 1 && a.ztaps == 1 && a.batch == 1 && a.atomic_out && a.ldc == a.N &&
+  static const bool fused_ws = getenv("EEGLDM_GEMM_FUSED3_WS") != nullptr;   // experiment: workspace reduction for the fused 3-tap kernel too
+  if (a.splitk > 1 && a.amode == GA_TR && a.bmode == GB_TR && (a.taps == 1 || (a.taps == 3 && a.sCt == (long)a.M * a.N && fused_ws)) && a.ztaps == 1 && a.batch == 1 && a.atomic_out && a.ldc == a.N &&
       !getenv("EEGLDM_GEMM_NO_SPLITK_WS")) {
-    const size_t need = (size_t)a.splitk * a.M * a.N * sizeof(float);
+    const size_t need = (size_t)a.splitk * a.taps * a.M * a.N * sizeof(float);
     if (need <= (size_t)512 << 20) {
       if (ctx->splitk_ws_bytes < need) {
         if (ctx->splitk_ws) { HIP_TRY(hipStreamSynchronize(ctx->stream)); HIP_TRY(hipFree(ctx->splitk_ws)); ctx->splitk_ws = nullptr; ctx->splitk_ws_bytes = 0; }
@@ -938,7 +944,7 @@ int gemm_launch(eegldm_ctx* ctx, const GemmArgs& a_in) {
       const int KST = 2 * (a.dtype == EEGLDM_F32 ? 16 : 32);
       int per = (a.K + a.splitk - 1) / a.splitk; per = (per + KST - 1) / KST * KST;
       a.splitk = (a.K + per - 1) / per;
-      fold_dst = (float*)a.C; fold_n = (long)a.M * a.N;
+      fold_dst = (float*)a.C; fold_n = (long)a.taps * a.M * a.N;
       a.C = ctx->splitk_ws; a.sCk = fold_n; a.atomic_out = 0;
     }
   }
