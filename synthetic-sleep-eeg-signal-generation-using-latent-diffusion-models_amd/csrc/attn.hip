@@ -1,0 +1,295 @@
+// Fused single-head attention "chain" kernel for short sequences (T <= 256, the UNet's T = 192; unet.py:107-125):
+//   forward :  S = alpha * Q K^T  ->  P = softmax_rows(S) (fp32, rounded to bf16)  ->  O = P V
+//   backward:  dP = dO V^T        ->  dS = alpha * P o (dP - rowsum(dP o P))        ->  dQ = dS K
+// One block = one sample x 64 query rows.  Both products run on MFMA with LDS-DMA staged operands; the T-wide score tile
+// never leaves the CU: it lives in registers between the two products and is written once as bf16 (P for the backward pass,
+// dS for the dK / dV products, which stay ordinary batched TN GEMMs).  Replaces QK^T (fp32 logits) + softmax + PV, i.e.
+// three launches and ~95 MB of logits/probs traffic per attention block at B = 256.  bf16 only (the fp32 parity path keeps
+// the unfused composition in ops.hip).
+#include "common.h"
+#include "internal.h"
+
+namespace {
+
+typedef __attribute__((address_space(3))) void* lds_ptr_t;
+typedef s16x4 __attribute__((address_space(3))) * lds_s16x4_p;
+
+__device__ __forceinline__ int swz1(int row, int slot) { return slot ^ (((row >> 2) & 1) * 3); }     // 64-byte rows (gemm.hip nt_swz<1>)
+__device__ __forceinline__ int trswz256(int row, int colbyte) { return colbyte ^ ((((row & 3) | (((row >> 3) & 1) << 2)) * 32) & 511); }
+__device__ __forceinline__ void dma16a(const void* g, unsigned lds_off) {
+  asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off" ::"s"(lds_off), "v"(g) : "memory", "m0");
+}
+__device__ __forceinline__ void mma16(const uint4& a, const uint4& b, f32x4& acc) {
+  acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), acc, 0, 0, 0);
+}
+// K-strided 16-column fragment of a [32 k rows][256 cols] bf16 tile (see gemm.hip read_tr_bf16)
+__device__ __forceinline__ uint4 read_tr256(const char* tile, int x0, int lm, int q) {
+  const int row0 = 8 * q + (lm >> 2), colb = (x0 + 4 * (lm & 3)) * 2;
+  const char* p0 = tile + row0 * 512 + trswz256(row0, colb);
+  const char* p1 = tile + (row0 + 4) * 512 + trswz256(row0 + 4, colb);
+  s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_p)(p0));
+  s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_p)(p1));
+  uint4 r;
+  r.x = (unsigned)(unsigned short)lo[0] | ((unsigned)(unsigned short)lo[1] << 16);
+  r.y = (unsigned)(unsigned short)lo[2] | ((unsigned)(unsigned short)lo[3] << 16);
+  r.z = (unsigned)(unsigned short)hi[0] | ((unsigned)(unsigned short)hi[1] << 16);
+  r.w = (unsigned)(unsigned short)hi[2] | ((unsigned)(unsigned short)hi[3] << 16);
+  return r;
+}
+
+struct ChainArgs {
+  const bf16_t* A1; long lda1, sA1;    // Q (fwd) / dO (bwd): [B][T][lda1], reduction (C) contiguous
+  const bf16_t* B1; long ldb1, sB1;    // K (fwd) / V (bwd)
+  const bf16_t* B2; long ldb2, sB2;    // V (fwd) / K (bwd): [T][C], used through transpose reads
+  bf16_t* P; long sP;                  // probabilities [B][T][T]: written by fwd, read by bwd
+  bf16_t* dS; long sdS;                // bwd: scaled score gradient [B][T][T]
+  bf16_t* O; long ldo, sO;             // out (fwd) / dQ (bwd)
+  int T, C; float alpha;
+};
+
+constexpr int NTA = 256;
+
+template <int NJ, int MODE>
+__global__ __launch_bounds__(NTA, 2) void attn_chain_kernel(const ChainArgs p) {
+  constexpr int T = 64 * NJ;                      // keys; every wave owns NJ 16-column fragments
+  constexpr int A_BYTES = 64 * 64, B_BYTES = T * 64, STG = A_BYTES + B_BYTES;
+  constexpr int STAGE_AREA = (2 * STG > 32768) ? 2 * STG : 32768;
+  constexpr int PP = T * 2 + 16;                  // padded row pitch of the bf16 score tile (conflict-free b128 fragment reads)
+  extern __shared__ __attribute__((aligned(16))) char sm[];
+  char* pt = sm + STAGE_AREA;                     // [64][PP]
+  float* red = (float*)(pt + 64 * PP);            // [64 rows][4 waves]
+  const int tid = threadIdx.x, lane = tid & 63, lm = lane & 15, q = lane >> 4;
+  const unsigned w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int b = blockIdx.y, m0 = blockIdx.x * 64;
+  const unsigned lds0 = (unsigned)(size_t)(lds_ptr_t)sm;
+  const bf16_t* A1 = p.A1 + (long)b * p.sA1 + (long)m0 * p.lda1;
+  const bf16_t* B1 = p.B1 + (long)b * p.sB1;
+  const bf16_t* B2 = p.B2 + (long)b * p.sB2;
+
+  // backward: this lane's probabilities (rows i*16+lm, columns (w*NJ+j)*16 + q*4 .. +3), fetched before anything else
+  uint2 pr[4][NJ];
+  if (MODE == 1) {
+#pragma unroll
+    for (int i = 0; i < 4; i++)
+#pragma unroll
+      for (int j = 0; j < NJ; j++)
+        pr[i][j] = *(const uint2*)(p.P + (long)b * p.sP + (long)(m0 + i * 16 + lm) * T + (w * NJ + j) * 16 + q * 4);
+  }
+
+  // ---------------- product 1: S^T fragments, reduction over C in 32-wide stages ----------------
+  f32x4 acc[4][NJ];
+#pragma unroll
+  for (int i = 0; i < 4; i++)
+#pragma unroll
+    for (int j = 0; j < NJ; j++) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const int nst = p.C / 32;
+  // per-lane source pointers of this wave's DMA chunks (chunk c of a tile <-> row c/4, swizzled 16-byte slot)
+  const bf16_t* asrc; const bf16_t* bsrc[NJ];
+  { const int c = w * 64 + lane, row = c >> 2, slot = swz1(row, c & 3); asrc = A1 + (long)row * p.lda1 + slot * 8; }
+#pragma unroll
+  for (int i = 0; i < NJ; i++) { const int c = (w + 4 * i) * 64 + lane, row = c >> 2, slot = swz1(row, c & 3); bsrc[i] = B1 + (long)row * p.ldb1 + slot * 8; }
+  auto issue1 = [&](int s, int buf) __attribute__((always_inline)) {
+    const unsigned base = lds0 + buf * STG;
+    dma16a(asrc + s * 32, base + w * 1024);
+#pragma unroll
+    for (int i = 0; i < NJ; i++) dma16a(bsrc[i] + s * 32, base + A_BYTES + (w + 4 * i) * 1024);
+  };
+  issue1(0, 0);
+  for (int s = 0; s < nst; s++) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (s + 1 < nst) issue1(s + 1, (s + 1) & 1);
+    const char* sa = sm + (s & 1) * STG; const char* sb = sa + A_BYTES;
+    uint4 af[4], bfr[NJ];
+#pragma unroll
+    for (int i = 0; i < 4; i++) { const int row = i * 16 + lm; af[i] = *(const uint4*)(sa + row * 64 + swz1(row, q) * 16); }
+#pragma unroll
+    for (int j = 0; j < NJ; j++) { const int row = (w * NJ + j) * 16 + lm; bfr[j] = *(const uint4*)(sb + row * 64 + swz1(row, q) * 16); }
+#pragma unroll
+    for (int i = 0; i < 4; i++)
+#pragma unroll
+      for (int j = 0; j < NJ; j++) mma16(bfr[j], af[i], acc[i][j]);     // swapped: acc[i][j][r] = S[i*16+lm][(w*NJ+j)*16 + q*4 + r]
+  }
+  __syncthreads();                                 // staging area free
+
+  // ---------------- product 2 staging (V / K tile [32 rows][256 cols], transpose-read layout) ----------------
+  const int nks = T / 32, nnc = p.C / 256, nu = nks * nnc;
+  auto issue2 = [&](int u, int buf) __attribute__((always_inline)) {
+    const int nc = u / nks, ks = u - nc * nks;
+    const unsigned base = lds0 + buf * 16384;
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+      const int c = (w * 4 + i) * 64 + lane, krow = c >> 5, cs = c & 31;
+      const int seg = trswz256(krow, cs * 16) >> 4;
+      dma16a(B2 + (long)(ks * 32 + krow) * p.ldb2 + nc * 256 + seg * 8, base + (w * 4 + i) * 1024);
+    }
+  };
+  issue2(0, 0);                                    // lands while the row operation runs
+
+  // ---------------- row operation on the score tile ----------------
+  auto row_reduce = [&](float v[4], const bool is_max) __attribute__((always_inline)) {
+    // v[i]: this lane's partial for row i*16+lm -> full row value over the 4 lane groups and the 4 waves
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+      float o1 = __shfl_xor(v[i], 16, 64); v[i] = is_max ? fmaxf(v[i], o1) : v[i] + o1;
+      float o2 = __shfl_xor(v[i], 32, 64); v[i] = is_max ? fmaxf(v[i], o2) : v[i] + o2;
+    }
+    __syncthreads();                               // previous use of `red` is over
+    if (q == 0) {
+#pragma unroll
+      for (int i = 0; i < 4; i++) red[(i * 16 + lm) * 4 + w] = v[i];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+      const float4 t = *(const float4*)(red + (i * 16 + lm) * 4);
+      v[i] = is_max ? fmaxf(fmaxf(t.x, t.y), fmaxf(t.z, t.w)) : (t.x + t.y) + (t.z + t.w);
+    }
+  };
+  if (MODE == 0) {
+    float mx[4];
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+      float m = -3.0e38f;
+#pragma unroll
+      for (int j = 0; j < NJ; j++)
+#pragma unroll
+        for (int r = 0; r < 4; r++) { acc[i][j][r] *= p.alpha; m = fmaxf(m, acc[i][j][r]); }
+      mx[i] = m;
+    }
+    row_reduce(mx, true);
+    float sum[4];
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+      float s = 0.f;
+#pragma unroll
+      for (int j = 0; j < NJ; j++)
+#pragma unroll
+        for (int r = 0; r < 4; r++) { const float e = __expf(acc[i][j][r] - mx[i]); acc[i][j][r] = e; s += e; }
+      sum[i] = s;
+    }
+    row_reduce(sum, false);
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+      const float inv = 1.0f / sum[i];
+#pragma unroll
+      for (int j = 0; j < NJ; j++) {
+        uint2 o; o.x = pack_bf16x2(acc[i][j][0] * inv, acc[i][j][1] * inv); o.y = pack_bf16x2(acc[i][j][2] * inv, acc[i][j][3] * inv);
+        const int col = (w * NJ + j) * 16 + q * 4;
+        *(uint2*)(pt + (i * 16 + lm) * PP + col * 2) = o;
+        *(uint2*)(p.P + (long)b * p.sP + (long)(m0 + i * 16 + lm) * T + col) = o;
+      }
+    }
+  } else {
+    float dl[4];
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+      float s = 0.f;
+#pragma unroll
+      for (int j = 0; j < NJ; j++) {
+        const float p0 = __uint_as_float(pr[i][j].x << 16), p1 = __uint_as_float(pr[i][j].x & 0xffff0000u);
+        const float p2 = __uint_as_float(pr[i][j].y << 16), p3 = __uint_as_float(pr[i][j].y & 0xffff0000u);
+        s += acc[i][j][0] * p0 + acc[i][j][1] * p1 + acc[i][j][2] * p2 + acc[i][j][3] * p3;
+      }
+      dl[i] = s;
+    }
+    row_reduce(dl, false);
+#pragma unroll
+    for (int i = 0; i < 4; i++)
+#pragma unroll
+      for (int j = 0; j < NJ; j++) {
+        const float p0 = __uint_as_float(pr[i][j].x << 16), p1 = __uint_as_float(pr[i][j].x & 0xffff0000u);
+        const float p2 = __uint_as_float(pr[i][j].y << 16), p3 = __uint_as_float(pr[i][j].y & 0xffff0000u);
+        uint2 o;
+        o.x = pack_bf16x2(p.alpha * p0 * (acc[i][j][0] - dl[i]), p.alpha * p1 * (acc[i][j][1] - dl[i]));
+        o.y = pack_bf16x2(p.alpha * p2 * (acc[i][j][2] - dl[i]), p.alpha * p3 * (acc[i][j][3] - dl[i]));
+        const int col = (w * NJ + j) * 16 + q * 4;
+        *(uint2*)(pt + (i * 16 + lm) * PP + col * 2) = o;
+        *(uint2*)(p.dS + (long)b * p.sdS + (long)(m0 + i * 16 + lm) * T + col) = o;
+      }
+  }
+
+  // ---------------- product 2: out[64][C] = tile[64][T] . B2[T][C], 256 output columns per pass ----------------
+  f32x4 acc2[4][4];
+  for (int u = 0; u < nu; u++) {
+    const int nc = u / nks, ks = u - nc * nks;
+    if (ks == 0) {
+#pragma unroll
+      for (int i = 0; i < 4; i++)
+#pragma unroll
+        for (int j = 0; j < 4; j++) acc2[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();                               // tile u landed (and, for u = 0, the score tile is complete in LDS)
+    if (u + 1 < nu) issue2(u + 1, (u + 1) & 1);
+    const char* sv = sm + (u & 1) * 16384;
+    uint4 af[4], bfr[4];
+#pragma unroll
+    for (int i = 0; i < 4; i++) af[i] = *(const uint4*)(pt + (i * 16 + lm) * PP + (ks * 32 + q * 8) * 2);
+#pragma unroll
+    for (int j = 0; j < 4; j++) bfr[j] = read_tr256(sv, w * 64 + j * 16, lm, q);
+#pragma unroll
+    for (int i = 0; i < 4; i++)
+#pragma unroll
+      for (int j = 0; j < 4; j++) mma16(bfr[j], af[i], acc2[i][j]);
+    if (ks == nks - 1) {
+#pragma unroll
+      for (int i = 0; i < 4; i++)
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+          uint2 o; o.x = pack_bf16x2(acc2[i][j][0], acc2[i][j][1]); o.y = pack_bf16x2(acc2[i][j][2], acc2[i][j][3]);
+          *(uint2*)(p.O + (long)b * p.sO + (long)(m0 + i * 16 + lm) * p.ldo + nc * 256 + w * 64 + j * 16 + q * 4) = o;
+        }
+    }
+  }
+}
+
+template <int NJ, int MODE>
+int launch_chain(eegldm_ctx* ctx, const ChainArgs& a, int B) {
+  constexpr int T = 64 * NJ;
+  constexpr int STG = 64 * 64 + T * 64;
+  constexpr int STAGE_AREA = (2 * STG > 32768) ? 2 * STG : 32768;
+  constexpr int LDS = STAGE_AREA + 64 * (T * 2 + 16) + 64 * 4 * 4;
+  auto kern = attn_chain_kernel<NJ, MODE>;
+  static bool attr = false;
+  if (!attr && LDS > 48 * 1024) { HIP_TRY(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS)); attr = true; }
+  hipLaunchKernelGGL(kern, dim3(T / 64, B), dim3(NTA), LDS, ctx->stream, a);
+  LAUNCH_CHECK();
+  return 0;
+}
+
+}  // namespace
+
+bool attn_chain_ok(int dtype, int T, int C, long ldq, long ldo) {
+  static const bool off = getenv("EEGLDM_NO_FUSED_ATTENTION") != nullptr;
+  return !off && dtype == EEGLDM_BF16 && (T == 64 || T == 128 || T == 192 || T == 256) && C % 256 == 0 && ldq % 8 == 0 && ldo % 8 == 0;
+}
+
+// forward: probs written, out = softmax(alpha q k^T) v
+int attn_chain_fwd(eegldm_ctx* ctx, const void* qkv, long ldq, void* out, long ldo, void* probs, int B, int T, int C) {
+  ChainArgs a = {};
+  const bf16_t* q = (const bf16_t*)qkv;
+  a.A1 = q; a.lda1 = ldq; a.sA1 = (long)T * ldq; a.B1 = q + C; a.ldb1 = ldq; a.sB1 = (long)T * ldq; a.B2 = q + 2 * C; a.ldb2 = ldq; a.sB2 = (long)T * ldq;
+  a.P = (bf16_t*)probs; a.sP = (long)T * T; a.O = (bf16_t*)out; a.ldo = ldo; a.sO = (long)T * ldo; a.T = T; a.C = C; a.alpha = 1.0f / sqrtf((float)C);
+  switch (T / 64) {
+    case 1: return launch_chain<1, 0>(ctx, a, B);
+    case 2: return launch_chain<2, 0>(ctx, a, B);
+    case 3: return launch_chain<3, 0>(ctx, a, B);
+    default: return launch_chain<4, 0>(ctx, a, B);
+  }
+}
+// backward part: dS (scaled) written, dq = dS k
+int attn_chain_bwd(eegldm_ctx* ctx, const void* qkv, long ldq, const void* probs, const void* dout, long lddo, void* dq, long lddq,
+                   void* dS, int B, int T, int C) {
+  ChainArgs a = {};
+  const bf16_t* q = (const bf16_t*)qkv;
+  a.A1 = (const bf16_t*)dout; a.lda1 = lddo; a.sA1 = (long)T * lddo; a.B1 = q + 2 * C; a.ldb1 = ldq; a.sB1 = (long)T * ldq;
+  a.B2 = q + C; a.ldb2 = ldq; a.sB2 = (long)T * ldq; a.P = (bf16_t*)probs; a.sP = (long)T * T; a.dS = (bf16_t*)dS; a.sdS = (long)T * T;
+  a.O = (bf16_t*)dq; a.ldo = lddq; a.sO = (long)T * lddq; a.T = T; a.C = C; a.alpha = 1.0f / sqrtf((float)C);
+  switch (T / 64) {
+    case 1: return launch_chain<1, 1>(ctx, a, B);
+    case 2: return launch_chain<2, 1>(ctx, a, B);
+    case 3: return launch_chain<3, 1>(ctx, a, B);
+    default: return launch_chain<4, 1>(ctx, a, B);
+  }
+}

@@ -43,3 +43,8 @@ int op_groupnorm_bwd(eegldm_ctx*, const void* x, long ldx, const float* gamma, c
                      const void* dy, long lddy, void* dx, long lddx, float* dgamma, float* dbeta, int B, int L, int C, int G,
                      int fuse_silu, int resample, const void* dxr, long lddxr, int dtype, float* colsum_ps, long ldps, int* colsum_done);
 int ew_fold_partials(eegldm_ctx*, const float* parts, int nparts, int n, float* total);
+// fused short-sequence attention (attn.hip)
+bool attn_chain_ok(int dtype, int T, int C, long ldq, long ldo);
+int attn_chain_fwd(eegldm_ctx*, const void* qkv, long ldq, void* out, long ldo, void* probs, int B, int T, int C);
+int attn_chain_bwd(eegldm_ctx*, const void* qkv, long ldq, const void* probs, const void* dout, long lddo, void* dq, long lddq,
+                   void* dS, int B, int T, int C);

@@ -121,6 +121,7 @@ int op_linear_wgrad(eegldm_ctx* ctx, int dtype, const void* x, long ldx, const v
 // ------------------------------------------------------------------ attention (unet.py:107-125)
 int op_attention_fwd(eegldm_ctx* ctx, int dtype, const void* qkv, long ldq, void* out, long ldo, void* probs, float* logits,
                      int B, int T, int C) {
+  if (attn_chain_ok(dtype, T, C, ldq, ldo)) return attn_chain_fwd(ctx, qkv, ldq, out, ldo, probs, B, T, C);
   const size_t es = dtype_size(dtype);
   const char* q = (const char*)qkv; const char* k = q + (size_t)C * es; const char* v = q + (size_t)2 * C * es;
   GemmArgs a = {};
@@ -148,6 +149,11 @@ int op_attention_bwd(eegldm_ctx* ctx, int dtype, const void* qkv, long ldq, cons
   g.dtype = dtype; g.amode = GA_TR; g.bmode = GB_TR; g.A = probs; g.lda = T; g.sAb = (long)T * T; g.B = dout; g.ldb = lddo;
   g.sBb = (long)T * lddo; g.C = dv; g.ldc = lddq; g.sCb = (long)T * lddq; g.M = T; g.N = C; g.K = T; g.batch = B; g.taps = 1; g.alpha = 1.f;
   EEG_TRY(gemm_launch(ctx, g));
+  const bool fused = attn_chain_ok(dtype, T, C, ldq, lddo) && lddq % 8 == 0;
+  if (fused) {
+    // dP = dO V^T, dS = alpha P o (dP - rowsum(dP o P)), dQ = dS K in one launch; dK below from the written dS
+    EEG_TRY(attn_chain_bwd(ctx, qkv, ldq, probs, dout, lddo, dq, lddq, dlogits, B, T, C));
+  } else {
   // dP[t][s] = sum_c dO[t][c] V[s][c]
   g = GemmArgs{};
   g.dtype = dtype; g.amode = GA_PLAIN; g.bmode = GB_NT; g.A = dout; g.lda = lddo; g.sAb = (long)T * lddo; g.B = v; g.ldb = ldq;
@@ -160,6 +166,7 @@ int op_attention_bwd(eegldm_ctx* ctx, int dtype, const void* qkv, long ldq, cons
   g.dtype = dtype; g.amode = GA_PLAIN; g.bmode = GB_TR; g.A = dlogits; g.lda = T; g.sAb = (long)T * T; g.B = k; g.ldb = ldq;
   g.sBb = (long)T * ldq; g.C = dq; g.ldc = lddq; g.sCb = (long)T * lddq; g.M = T; g.N = C; g.K = T; g.batch = B; g.taps = 1; g.alpha = 1.f;
   EEG_TRY(gemm_launch(ctx, g));
+  }
   // dK[s][c] = sum_t dS[t][s] Q[t][c]
   g = GemmArgs{};
   g.dtype = dtype; g.amode = GA_TR; g.bmode = GB_TR; g.A = dlogits; g.lda = T; g.sAb = (long)T * T; g.B = q; g.ldb = ldq;
