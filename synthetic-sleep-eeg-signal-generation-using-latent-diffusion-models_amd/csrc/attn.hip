@@ -53,7 +53,9 @@ template <int NJ, int MODE>
 __global__ __launch_bounds__(NTA, 2) void attn_chain_kernel(const ChainArgs p) {
   constexpr int T = 64 * NJ;                      // keys; every wave owns NJ 16-column fragments
   constexpr int A_BYTES = 64 * 64, B_BYTES = T * 64, STG = A_BYTES + B_BYTES;
-  constexpr int STAGE_AREA = (2 * STG > 32768) ? 2 * STG : 32768;
+  // 3-deep DMA rings: a stage carries only 12-16 MFMAs per wave against a ~2500-cycle DMA round trip, so two stages are kept
+  // in flight (with a 2-deep ring the kernel ran at one DMA latency per stage: 76 us per launch)
+  constexpr int STAGE_AREA = (3 * STG > 49152) ? 3 * STG : 49152;
   constexpr int PP = T * 2 + 16;                  // padded row pitch of the bf16 score tile (conflict-free b128 fragment reads)
   extern __shared__ __attribute__((aligned(16))) char sm[];
   char* pt = sm + STAGE_AREA;                     // [64][PP]
@@ -94,12 +96,15 @@ __global__ __launch_bounds__(NTA, 2) void attn_chain_kernel(const ChainArgs p) {
 #pragma unroll
     for (int i = 0; i < NJ; i++) dma16a(bsrc[i] + s * 32, base + A_BYTES + (w + 4 * i) * 1024);
   };
+  constexpr int PER1 = 1 + NJ;                    // DMA instructions per wave per stage
   issue1(0, 0);
+  if (nst > 1) issue1(1, 1);
   for (int s = 0; s < nst; s++) {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (s + 1 < nst) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PER1) : "memory");     // stage s landed, stage s+1 may be in flight
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    if (s + 1 < nst) issue1(s + 1, (s + 1) & 1);
-    const char* sa = sm + (s & 1) * STG; const char* sb = sa + A_BYTES;
+    if (s + 2 < nst) issue1(s + 2, (s + 2) % 3);
+    const char* sa = sm + (s % 3) * STG; const char* sb = sa + A_BYTES;
     uint4 af[4], bfr[NJ];
 #pragma unroll
     for (int i = 0; i < 4; i++) { const int row = i * 16 + lm; af[i] = *(const uint4*)(sa + row * 64 + swz1(row, q) * 16); }
@@ -124,7 +129,8 @@ __global__ __launch_bounds__(NTA, 2) void attn_chain_kernel(const ChainArgs p) {
       dma16a(B2 + (long)(ks * 32 + krow) * p.ldb2 + nc * 256 + seg * 8, base + (w * 4 + i) * 1024);
     }
   };
-  issue2(0, 0);                                    // lands while the row operation runs
+  issue2(0, 0);                                    // land while the row operation runs
+  if (nu > 1) issue2(1, 1);
 
   // ---------------- row operation on the score tile ----------------
   auto row_reduce = [&](float v[4], const bool is_max) __attribute__((always_inline)) {
@@ -211,6 +217,7 @@ __global__ __launch_bounds__(NTA, 2) void attn_chain_kernel(const ChainArgs p) {
 
   // ---------------- product 2: out[64][C] = tile[64][T] . B2[T][C], 256 output columns per pass ----------------
   f32x4 acc2[4][4];
+  bool stores_pending = true;                      // the P / dS stores of the row operation
   for (int u = 0; u < nu; u++) {
     const int nc = u / nks, ks = u - nc * nks;
     if (ks == 0) {
@@ -219,10 +226,13 @@ __global__ __launch_bounds__(NTA, 2) void attn_chain_kernel(const ChainArgs p) {
 #pragma unroll
         for (int j = 0; j < 4; j++) acc2[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
     }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();                               // tile u landed (and, for u = 0, the score tile is complete in LDS)
-    if (u + 1 < nu) issue2(u + 1, (u + 1) & 1);
-    const char* sv = sm + (u & 1) * 16384;
+    // tile u landed; one newer tile (4 DMAs) may stay in flight unless stores were issued since (they share the counter)
+    if (u + 1 < nu && !stores_pending) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    stores_pending = false;
+    __syncthreads();                               // (for u = 0 also: the score tile is complete in LDS)
+    if (u + 2 < nu) issue2(u + 2, (u + 2) % 3);
+    const char* sv = sm + (u % 3) * 16384;
     uint4 af[4], bfr[4];
 #pragma unroll
     for (int i = 0; i < 4; i++) af[i] = *(const uint4*)(pt + (i * 16 + lm) * PP + (ks * 32 + q * 8) * 2);
@@ -240,6 +250,7 @@ __global__ __launch_bounds__(NTA, 2) void attn_chain_kernel(const ChainArgs p) {
           uint2 o; o.x = pack_bf16x2(acc2[i][j][0], acc2[i][j][1]); o.y = pack_bf16x2(acc2[i][j][2], acc2[i][j][3]);
           *(uint2*)(p.O + (long)b * p.sO + (long)(m0 + i * 16 + lm) * p.ldo + nc * 256 + w * 64 + j * 16 + q * 4) = o;
         }
+      stores_pending = true;
     }
   }
 }
@@ -248,7 +259,7 @@ template <int NJ, int MODE>
 int launch_chain(eegldm_ctx* ctx, const ChainArgs& a, int B) {
   constexpr int T = 64 * NJ;
   constexpr int STG = 64 * 64 + T * 64;
-  constexpr int STAGE_AREA = (2 * STG > 32768) ? 2 * STG : 32768;
+  constexpr int STAGE_AREA = (3 * STG > 49152) ? 3 * STG : 49152;
   constexpr int LDS = STAGE_AREA + 64 * (T * 2 + 16) + 64 * 4 * 4;
   auto kern = attn_chain_kernel<NJ, MODE>;
   static bool attr = false;
