@@ -49,20 +49,26 @@ struct ChainArgs {
 
 constexpr int NTA = 256;
 
-template <int NJ, int MODE>
-__global__ __launch_bounds__(NTA, 2) void attn_chain_kernel(const ChainArgs p) {
+// NQ = 64-row query tiles per block: 1 (grid = T/64 x B) or NJ (one block = one whole sample: K / V tiles are staged once
+// for all query rows and, at B = 256, the grid is exactly one block per CU -- no 1.5-round tail).
+template <int NJ, int MODE, int NQ>
+__global__ __launch_bounds__(256 * NQ) void attn_chain_kernel(const ChainArgs p) {
   constexpr int T = 64 * NJ;                      // keys; every wave owns NJ 16-column fragments
-  constexpr int A_BYTES = 64 * 64, B_BYTES = T * 64, STG = A_BYTES + B_BYTES;
+  constexpr int QR = 64 * NQ;                     // query rows per block
+  constexpr int NWV = 4 * NQ;                     // waves per block
+  constexpr int A_BYTES = QR * 64, B_BYTES = T * 64, STG = A_BYTES + B_BYTES;
   // 3-deep DMA rings: a stage carries only 12-16 MFMAs per wave against a ~2500-cycle DMA round trip, so two stages are kept
   // in flight (with a 2-deep ring the kernel ran at one DMA latency per stage: 76 us per launch)
   constexpr int STAGE_AREA = (3 * STG > 49152) ? 3 * STG : 49152;
   constexpr int PP = T * 2 + 16;                  // padded row pitch of the bf16 score tile (conflict-free b128 fragment reads)
   extern __shared__ __attribute__((aligned(16))) char sm[];
-  char* pt = sm + STAGE_AREA;                     // [64][PP]
-  float* red = (float*)(pt + 64 * PP);            // [64 rows][4 waves]
+  char* pt = sm + STAGE_AREA;                     // [QR][PP]
+  float* red = (float*)(pt + QR * PP);            // [QR rows][4 column waves]
   const int tid = threadIdx.x, lane = tid & 63, lm = lane & 15, q = lane >> 4;
-  const unsigned w = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int b = blockIdx.y, m0 = blockIdx.x * 64;
+  const unsigned wv = __builtin_amdgcn_readfirstlane(tid >> 6);    // wave in block
+  const unsigned w = wv & 3, wq = wv >> 2;                       // column wave (owns NJ key fragments) / query tile of this wave
+  const int b = blockIdx.y, m0 = blockIdx.x * QR;                // first query row of the block
+  const int mq = wq * 64;                                        // this wave's query rows inside the block tile
   const unsigned lds0 = (unsigned)(size_t)(lds_ptr_t)sm;
   const bf16_t* A1 = p.A1 + (long)b * p.sA1 + (long)m0 * p.lda1;
   const bf16_t* B1 = p.B1 + (long)b * p.sB1;
@@ -75,7 +81,7 @@ __global__ __launch_bounds__(NTA, 2) void attn_chain_kernel(const ChainArgs p) {
     for (int i = 0; i < 4; i++)
 #pragma unroll
       for (int j = 0; j < NJ; j++)
-        pr[i][j] = *(const uint2*)(p.P + (long)b * p.sP + (long)(m0 + i * 16 + lm) * T + (w * NJ + j) * 16 + q * 4);
+        pr[i][j] = *(const uint2*)(p.P + (long)b * p.sP + (long)(m0 + mq + i * 16 + lm) * T + (w * NJ + j) * 16 + q * 4);
   }
 
   // ---------------- product 1: S^T fragments, reduction over C in 32-wide stages ----------------
@@ -86,17 +92,20 @@ __global__ __launch_bounds__(NTA, 2) void attn_chain_kernel(const ChainArgs p) {
     for (int j = 0; j < NJ; j++) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
   const int nst = p.C / 32;
   // per-lane source pointers of this wave's DMA chunks (chunk c of a tile <-> row c/4, swizzled 16-byte slot)
-  const bf16_t* asrc; const bf16_t* bsrc[NJ];
-  { const int c = w * 64 + lane, row = c >> 2, slot = swz1(row, c & 3); asrc = A1 + (long)row * p.lda1 + slot * 8; }
+  // A tile: QR*4 chunks = 4*NQ wave-instructions (one per wave); B tile: T*4 chunks = 4*NJ instructions, NB1 per wave
+  constexpr int NB1 = (4 * NJ + NWV - 1) / NWV;
+  static_assert((4 * NJ) % NWV == 0, "B-tile DMA instructions must divide evenly over the waves (uniform vmcnt)");
+  const bf16_t* asrc; const bf16_t* bsrc[NB1];
+  { const int c = wv * 64 + lane, row = c >> 2, slot = swz1(row, c & 3); asrc = A1 + (long)row * p.lda1 + slot * 8; }
 #pragma unroll
-  for (int i = 0; i < NJ; i++) { const int c = (w + 4 * i) * 64 + lane, row = c >> 2, slot = swz1(row, c & 3); bsrc[i] = B1 + (long)row * p.ldb1 + slot * 8; }
+  for (int i = 0; i < NB1; i++) { const int c = (wv + NWV * i) * 64 + lane, row = c >> 2, slot = swz1(row, c & 3); bsrc[i] = B1 + (long)row * p.ldb1 + slot * 8; }
   auto issue1 = [&](int s, int buf) __attribute__((always_inline)) {
     const unsigned base = lds0 + buf * STG;
-    dma16a(asrc + s * 32, base + w * 1024);
+    dma16a(asrc + s * 32, base + wv * 1024);
 #pragma unroll
-    for (int i = 0; i < NJ; i++) dma16a(bsrc[i] + s * 32, base + A_BYTES + (w + 4 * i) * 1024);
+    for (int i = 0; i < NB1; i++) dma16a(bsrc[i] + s * 32, base + A_BYTES + (wv + NWV * i) * 1024);
   };
-  constexpr int PER1 = 1 + NJ;                    // DMA instructions per wave per stage
+  constexpr int PER1 = 1 + NB1;                   // DMA instructions per wave per stage
   issue1(0, 0);
   if (nst > 1) issue1(1, 1);
   for (int s = 0; s < nst; s++) {
@@ -107,7 +116,7 @@ __global__ __launch_bounds__(NTA, 2) void attn_chain_kernel(const ChainArgs p) {
     const char* sa = sm + (s % 3) * STG; const char* sb = sa + A_BYTES;
     uint4 af[4], bfr[NJ];
 #pragma unroll
-    for (int i = 0; i < 4; i++) { const int row = i * 16 + lm; af[i] = *(const uint4*)(sa + row * 64 + swz1(row, q) * 16); }
+    for (int i = 0; i < 4; i++) { const int row = mq + i * 16 + lm; af[i] = *(const uint4*)(sa + row * 64 + swz1(row, q) * 16); }
 #pragma unroll
     for (int j = 0; j < NJ; j++) { const int row = (w * NJ + j) * 16 + lm; bfr[j] = *(const uint4*)(sb + row * 64 + swz1(row, q) * 16); }
 #pragma unroll
@@ -122,13 +131,18 @@ __global__ __launch_bounds__(NTA, 2) void attn_chain_kernel(const ChainArgs p) {
   auto issue2 = [&](int u, int buf) __attribute__((always_inline)) {
     const int nc = u / nks, ks = u - nc * nks;
     const unsigned base = lds0 + buf * 16384;
+    // 16 wave-instructions per tile: instruction ii goes to wave ii % NWV (waves < 16 % NWV issue one more than the others)
 #pragma unroll
-    for (int i = 0; i < 4; i++) {
-      const int c = (w * 4 + i) * 64 + lane, krow = c >> 5, cs = c & 31;
-      const int seg = trswz256(krow, cs * 16) >> 4;
-      dma16a(B2 + (long)(ks * 32 + krow) * p.ldb2 + nc * 256 + seg * 8, base + (w * 4 + i) * 1024);
+    for (int i = 0; i < (16 + NWV - 1) / NWV; i++) {
+      const int ii = wv + NWV * i;
+      if (ii < 16) {
+        const int c = ii * 64 + lane, krow = c >> 5, cs = c & 31;
+        const int seg = trswz256(krow, cs * 16) >> 4;
+        dma16a(B2 + (long)(ks * 32 + krow) * p.ldb2 + nc * 256 + seg * 8, base + ii * 1024);
+      }
     }
   };
+  const int per2 = (int)((16 - (int)wv + NWV - 1) / NWV);       // this wave's DMA instructions per tile (wave-uniform)
   issue2(0, 0);                                    // land while the row operation runs
   if (nu > 1) issue2(1, 1);
 
@@ -143,12 +157,12 @@ __global__ __launch_bounds__(NTA, 2) void attn_chain_kernel(const ChainArgs p) {
     __syncthreads();                               // previous use of `red` is over
     if (q == 0) {
 #pragma unroll
-      for (int i = 0; i < 4; i++) red[(i * 16 + lm) * 4 + w] = v[i];
+      for (int i = 0; i < 4; i++) red[(mq + i * 16 + lm) * 4 + w] = v[i];
     }
     __syncthreads();
 #pragma unroll
     for (int i = 0; i < 4; i++) {
-      const float4 t = *(const float4*)(red + (i * 16 + lm) * 4);
+      const float4 t = *(const float4*)(red + (mq + i * 16 + lm) * 4);
       v[i] = is_max ? fmaxf(fmaxf(t.x, t.y), fmaxf(t.z, t.w)) : (t.x + t.y) + (t.z + t.w);
     }
   };
@@ -182,8 +196,8 @@ __global__ __launch_bounds__(NTA, 2) void attn_chain_kernel(const ChainArgs p) {
       for (int j = 0; j < NJ; j++) {
         uint2 o; o.x = pack_bf16x2(acc[i][j][0] * inv, acc[i][j][1] * inv); o.y = pack_bf16x2(acc[i][j][2] * inv, acc[i][j][3] * inv);
         const int col = (w * NJ + j) * 16 + q * 4;
-        *(uint2*)(pt + (i * 16 + lm) * PP + col * 2) = o;
-        *(uint2*)(p.P + (long)b * p.sP + (long)(m0 + i * 16 + lm) * T + col) = o;
+        *(uint2*)(pt + (mq + i * 16 + lm) * PP + col * 2) = o;
+        *(uint2*)(p.P + (long)b * p.sP + (long)(m0 + mq + i * 16 + lm) * T + col) = o;
       }
     }
   } else {
@@ -210,8 +224,8 @@ __global__ __launch_bounds__(NTA, 2) void attn_chain_kernel(const ChainArgs p) {
         o.x = pack_bf16x2(p.alpha * p0 * (acc[i][j][0] - dl[i]), p.alpha * p1 * (acc[i][j][1] - dl[i]));
         o.y = pack_bf16x2(p.alpha * p2 * (acc[i][j][2] - dl[i]), p.alpha * p3 * (acc[i][j][3] - dl[i]));
         const int col = (w * NJ + j) * 16 + q * 4;
-        *(uint2*)(pt + (i * 16 + lm) * PP + col * 2) = o;
-        *(uint2*)(p.dS + (long)b * p.sdS + (long)(m0 + i * 16 + lm) * T + col) = o;
+        *(uint2*)(pt + (mq + i * 16 + lm) * PP + col * 2) = o;
+        *(uint2*)(p.dS + (long)b * p.sdS + (long)(m0 + mq + i * 16 + lm) * T + col) = o;
       }
   }
 
@@ -227,15 +241,18 @@ __global__ __launch_bounds__(NTA, 2) void attn_chain_kernel(const ChainArgs p) {
         for (int j = 0; j < 4; j++) acc2[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
     }
     // tile u landed; one newer tile (4 DMAs) may stay in flight unless stores were issued since (they share the counter)
-    if (u + 1 < nu && !stores_pending) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (u + 1 < nu && !stores_pending) {
+      if (per2 >= 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+      else if (per2 == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
+    } else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     stores_pending = false;
     __syncthreads();                               // (for u = 0 also: the score tile is complete in LDS)
     if (u + 2 < nu) issue2(u + 2, (u + 2) % 3);
     const char* sv = sm + (u % 3) * 16384;
     uint4 af[4], bfr[4];
 #pragma unroll
-    for (int i = 0; i < 4; i++) af[i] = *(const uint4*)(pt + (i * 16 + lm) * PP + (ks * 32 + q * 8) * 2);
+    for (int i = 0; i < 4; i++) af[i] = *(const uint4*)(pt + (mq + i * 16 + lm) * PP + (ks * 32 + q * 8) * 2);
 #pragma unroll
     for (int j = 0; j < 4; j++) bfr[j] = read_tr256(sv, w * 64 + j * 16, lm, q);
 #pragma unroll
@@ -248,25 +265,33 @@ __global__ __launch_bounds__(NTA, 2) void attn_chain_kernel(const ChainArgs p) {
 #pragma unroll
         for (int j = 0; j < 4; j++) {
           uint2 o; o.x = pack_bf16x2(acc2[i][j][0], acc2[i][j][1]); o.y = pack_bf16x2(acc2[i][j][2], acc2[i][j][3]);
-          *(uint2*)(p.O + (long)b * p.sO + (long)(m0 + i * 16 + lm) * p.ldo + nc * 256 + w * 64 + j * 16 + q * 4) = o;
+          *(uint2*)(p.O + (long)b * p.sO + (long)(m0 + mq + i * 16 + lm) * p.ldo + nc * 256 + w * 64 + j * 16 + q * 4) = o;
         }
       stores_pending = true;
     }
   }
 }
 
-template <int NJ, int MODE>
-int launch_chain(eegldm_ctx* ctx, const ChainArgs& a, int B) {
-  constexpr int T = 64 * NJ;
-  constexpr int STG = 64 * 64 + T * 64;
+template <int NJ, int MODE, int NQ>
+int launch_chain_q(eegldm_ctx* ctx, const ChainArgs& a, int B) {
+  constexpr int T = 64 * NJ, QR = 64 * NQ;
+  constexpr int STG = QR * 64 + T * 64;
   constexpr int STAGE_AREA = (3 * STG > 49152) ? 3 * STG : 49152;
-  constexpr int LDS = STAGE_AREA + 64 * (T * 2 + 16) + 64 * 4 * 4;
-  auto kern = attn_chain_kernel<NJ, MODE>;
+  constexpr int LDS = STAGE_AREA + QR * (T * 2 + 16) + QR * 4 * 4;
+  static_assert(LDS <= 160 * 1024, "attention tile does not fit the LDS");
+  auto kern = attn_chain_kernel<NJ, MODE, NQ>;
   static bool attr = false;
   if (!attr && LDS > 48 * 1024) { HIP_TRY(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS)); attr = true; }
-  hipLaunchKernelGGL(kern, dim3(T / 64, B), dim3(NTA), LDS, ctx->stream, a);
+  hipLaunchKernelGGL(kern, dim3(T / QR, B), dim3(256 * NQ), LDS, ctx->stream, a);
   LAUNCH_CHECK();
   return 0;
+}
+template <int NJ, int MODE>
+int launch_chain(eegldm_ctx* ctx, const ChainArgs& a, int B) {
+  // whole-sample blocks (12 waves at T = 192) when the batch alone fills the chip; 64-row blocks otherwise (more blocks)
+  static const bool no_whole = getenv("EEGLDM_ATTN_NO_WHOLE") != nullptr;
+  if constexpr (NJ == 3) { if (!no_whole && B >= ctx->num_cu / 2) return launch_chain_q<NJ, MODE, NJ>(ctx, a, B); }
+  return launch_chain_q<NJ, MODE, 1>(ctx, a, B);
 }
 
 }  // namespace
