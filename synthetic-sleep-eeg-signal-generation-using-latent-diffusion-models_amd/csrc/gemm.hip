@@ -129,6 +129,7 @@ struct Cfg {
   // WG3: fused 3-tap weight gradient -- dY tile staged once, X tile staged once with a 1-row halo each side,
   // the three taps are row-shifted transpose reads of the same X tile (3x less staging per MFMA than one tap per block)
   static constexpr bool WG3 = (AMODE == GA_TR && BMODE == GB_TR && TAPS == 3);
+  static constexpr bool COLSUM = (AMODE == GA_TR && sizeof(T) == 2);   // fused column sums of A (GemmArgs::colsum)
   static constexpr int B_ROWS_TR = WG3 ? KSTAGE + 2 : KSTAGE;
   static constexpr int B_TILE_BYTES = (BMODE == GB_TR) ? B_ROWS_TR * PITCH_B_TR : BN * PITCH_NT;
   static constexpr int B_BYTES = (WG3 ? 1 : TAPS) * B_TILE_BYTES;
@@ -412,6 +413,14 @@ __global__ __launch_bounds__((WMT == 3 ? 256 : 128 * WMT), 2) void gemm_kernel(c
     for (int i = 0; i < C::FM; i++)
 #pragma unroll
       for (int j = 0; j < FN; j++) acc[a][i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  // fused bias gradient (GemmArgs::colsum): the first N tile's wn == 0 waves (tap slice 0) also multiply their A fragments by ones
+  f32x4 cs[C::COLSUM ? C::FM : 1];
+  bool do_cs = false;
+  if constexpr (C::COLSUM) {
+    do_cs = p.colsum != nullptr && tile_n == 0 && wn == 0 && tz == 0 && bz == 0;
+#pragma unroll
+    for (int i = 0; i < C::FM; i++) cs[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+  }
 
   // bias chunk of this thread's epilogue columns: fetched now so its latency hides behind the whole K loop
   float4 bias4 = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -535,6 +544,14 @@ __global__ __launch_bounds__((WMT == 3 ? 256 : 128 * WMT), 2) void gemm_kernel(c
           if constexpr (AMODE == GA_TR) mma<T>(af[st & 1][i], bf[st & 1][j], acc[C::WG3 ? t : 0][i][j]);   // TN products keep the natural fragment (atomic epilogue)
           else mma<T>(bf[st & 1][j], af[st & 1][i], acc[0][i][j]);                                        // swapped: acc = (B.A^T) fragment
         }
+      if constexpr (C::COLSUM) {
+        // bias gradient for free: A (dY, transposed) times an all-ones B fragment = the row sums of this K step in every column
+        if (do_cs && t == 0) {
+          const uint4 ones = make_uint4(0x3F803F80u, 0x3F803F80u, 0x3F803F80u, 0x3F803F80u);
+#pragma unroll
+          for (int i = 0; i < C::FM; i++) mma<T>(af[st & 1][i], ones, cs[i]);
+        }
+      }
     }
     TSTAMP();   // after the MFMA phase of stage s
     if constexpr (!C::USE_DMA) __syncthreads();   // single buffer: reads of stage s done before stage s+1 is written
@@ -551,6 +568,17 @@ __global__ __launch_bounds__((WMT == 3 ? 256 : 128 * WMT), 2) void gemm_kernel(c
   const long cbase = (long)bz * p.sCb + (long)tz * p.sCt + (long)ksplit * p.sCk;
   constexpr int CH = BN / 4;                      // 4-element chunks per row
   constexpr int NCH = C::EPI_ROWS * CH;           // chunks per pass
+  if constexpr (C::COLSUM) {
+    if (do_cs && lm == 0) {   // every column of cs holds the row sums: column 0's lanes add them (one atomic per row and K split)
+#pragma unroll
+      for (int i = 0; i < C::FM; i++)
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+          const int m = m0 + wm * (C::FM * 16) + i * 16 + q * 4 + r;
+          if (m < p.M) atomicAdd(p.colsum + m, cs[i][r]);
+        }
+    }
+  }
   if constexpr (AMODE == GA_TR) {
     if (p.atomic_out) {
       // split-K weight gradients: natural fragment layout (rows q*4+r, col lm), fp32 atomics straight from registers.
@@ -927,6 +955,7 @@ int gemm_launch(eegldm_ctx* ctx, const GemmArgs& a_in) {
   EEG_CHECK(a.N % 4 == 0 && a.ldc % 4 == 0, "N and ldc must be multiples of 4 (vector epilogue): N=%d ldc=%ld", a.N, a.ldc);
   EEG_CHECK(!a.resid || a.ldr % 4 == 0, "ldr must be a multiple of 4");
   EEG_CHECK(!a.rowvec || a.ld_rowvec % 4 == 0, "ld_rowvec must be a multiple of 4");
+  EEG_CHECK(!a.colsum || (a.amode == GA_TR && a.dtype != EEGLDM_F32 && a.batch == 1), "fused column sums need a 16-bit transposed A operand and batch 1");
   // Split-K weight gradients of 1-tap TN products: partial tiles are WRITTEN to a workspace (coalesced stores through the
   // LDS epilogue) and folded into dW afterwards, instead of draining millions of fp32 atomics at ~370 G/s
   // (profiles/r01_gemm_stage_timing.txt); the fused 3-tap kernel keeps its register atomics (three accumulator sets).

@@ -26,6 +26,7 @@ int op_conv_fwd(eegldm_ctx*, int dtype, const void* x, long ldx, const void* w, 
                 const float* rowvec, long ld_rowvec, const void* resid, long ldr);
 int op_conv_dgrad(eegldm_ctx*, int dtype, const void* dy, long lddy, const void* w, void* dx, long lddx,
                   int B, int Lin, int Cin, int Cout, int K, int stride, int pad_l, int pad_r, const void* resid, long ldr);
+bool op_wgrad_fuses_bias(int dtype, int Cin, int Cout);
 int op_conv_wgrad(eegldm_ctx*, int dtype, const void* x, long ldx, const void* dy, long lddy, float* dw, float* dbias,
                   int B, int Lin, int Cin, int Cout, int K, int stride, int pad_l, int pad_r);
 int op_linear(eegldm_ctx*, int dtype, const void* x, long ldx, const void* w, long ldw, const float* bias, void* y, long ldy,

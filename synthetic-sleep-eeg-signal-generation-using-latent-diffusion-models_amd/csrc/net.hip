@@ -63,12 +63,15 @@ int res_backward(NetBase* u, const ResDesc& r, const ResTape& t, const View& dou
   Arena::Mark mk = u->arena.mark();
   const bool pg = u->param_grads;
   View dxr = dout;
-  // weight gradients run on the side stream (pure GEMMs, no context scratch); bias sums stay on the main stream
+  // weight gradients run on the side stream (pure GEMMs, no context scratch).  With 16-bit operands the GEMM also produces the
+  // bias gradient (column sums of its dY operand); otherwise the bias sums are separate kernels on the main stream.
+  const bool fb2 = pg && op_wgrad_fuses_bias(dt, r.cout, r.cout), fbs = pg && r.sk_w >= 0 && op_wgrad_fuses_bias(dt, r.cin, r.cout);
+  const bool fb1 = pg && op_wgrad_fuses_bias(dt, r.cin, r.cout);
   if (pg) {
     EEG_TRY(ctx_fork(ctx));                       // dout (and everything before) is ready for the side stream
     SideScope side(ctx);
-    if (r.sk_w >= 0) EEG_TRY(op_conv_wgrad(ctx, dt, t.xr.p, t.xr.ld, dout.p, dout.ld, u->G(r.sk_w), nullptr, B, Lout, r.cin, r.cout, 1, 1, 0, 0));
-    EEG_TRY(op_conv_wgrad(ctx, dt, t.a2.p, t.a2.ld, dout.p, dout.ld, u->G(r.c2_w), nullptr, B, Lout, r.cout, r.cout, 3, 1, 1, 1));
+    if (r.sk_w >= 0) EEG_TRY(op_conv_wgrad(ctx, dt, t.xr.p, t.xr.ld, dout.p, dout.ld, u->G(r.sk_w), fbs ? u->G(r.sk_b) : nullptr, B, Lout, r.cin, r.cout, 1, 1, 0, 0));
+    EEG_TRY(op_conv_wgrad(ctx, dt, t.a2.p, t.a2.ld, dout.p, dout.ld, u->G(r.c2_w), fb2 ? u->G(r.c2_b) : nullptr, B, Lout, r.cout, r.cout, 3, 1, 1, 1));
   }
   if (r.sk_w >= 0) {
     ALLOC_OR_FAIL(dxr.p, u->alloc_act((long)B * Lout, r.cin)); dxr.ld = r.cin; dxr.C = r.cin;
@@ -78,7 +81,9 @@ int res_backward(NetBase* u, const ResDesc& r, const ResTape& t, const View& dou
   EEG_TRY(op_conv_dgrad(ctx, dt, dout.p, dout.ld, u->W(r.c2_w), da2.p, da2.ld, B, Lout, r.cout, r.cout, 3, 1, 1, 1, nullptr, 0));
   if (pg) {
     // conv2's bias gradient = column sums of dout; the skip conv's bias gradient is the same vector
-    if (r.sk_w >= 0) {
+    if (fb2 && (r.sk_w < 0 || fbs)) {
+      // done inside the weight-gradient GEMMs
+    } else if (r.sk_w >= 0) {
       float* tmp = (float*)((char*)ctx->scratch + (3u << 20));        // [cout] staging in the context scratch
       HIP_TRY(hipMemsetAsync(tmp, 0, sizeof(float) * r.cout, ctx->stream));
       EEG_TRY(ew_colsum(ctx, dout.p, dout.ld, nullptr, 0, tmp, B, Lout, r.cout, dt));
@@ -93,20 +98,20 @@ int res_backward(NetBase* u, const ResDesc& r, const ResTape& t, const View& dou
   // The one-pass GroupNorm backward produces them while dh1 is still in registers; otherwise a separate column sum.
   float* ps = nullptr; long ldps = 0;
   if (r.emb_col >= 0) { ps = demb_all + r.emb_col; ldps = u->etot; }
-  else if (pg) { ALLOC_OR_FAIL(ps, (float*)u->arena.alloc(sizeof(float) * (size_t)B * r.cout)); ldps = r.cout; }
+  else if (pg && !fb1) { ALLOC_OR_FAIL(ps, (float*)u->arena.alloc(sizeof(float) * (size_t)B * r.cout)); ldps = r.cout; }
   int cs_done = 0;
   EEG_TRY(op_groupnorm_bwd(ctx, t.h1.p, t.h1.ld, u->P(r.gn2_w), u->P(r.gn2_b), t.st2, da2.p, da2.ld, dh1.p, dh1.ld, pg ? u->G(r.gn2_w) : nullptr, pg ? u->G(r.gn2_b) : nullptr,
                            B, Lout, r.cout, r.groups, 1, 0, nullptr, 0, dt, ps, ldps, &cs_done));
   if (pg) {
     EEG_TRY(ctx_fork(ctx));                       // dh1 is ready
     SideScope side(ctx);
-    EEG_TRY(op_conv_wgrad(ctx, dt, t.a1.p, t.a1.ld, dh1.p, dh1.ld, u->G(r.c1_w), nullptr, B, Lout, r.cin, r.cout, 3, 1, 1, 1));
+    EEG_TRY(op_conv_wgrad(ctx, dt, t.a1.p, t.a1.ld, dh1.p, dh1.ld, u->G(r.c1_w), fb1 ? u->G(r.c1_b) : nullptr, B, Lout, r.cin, r.cout, 3, 1, 1, 1));
   }
   if (cs_done) {
-    if (pg) EEG_TRY(ew_colsum(ctx, ps, ldps, nullptr, 0, u->G(r.c1_b), 1, B, r.cout, EEGLDM_F32));
+    if (pg && !fb1) EEG_TRY(ew_colsum(ctx, ps, ldps, nullptr, 0, u->G(r.c1_b), 1, B, r.cout, EEGLDM_F32));
   } else {
-    if (r.emb_col >= 0) EEG_TRY(ew_colsum(ctx, dh1.p, dh1.ld, ps, ldps, pg ? u->G(r.c1_b) : nullptr, B, Lout, r.cout, dt));
-    else if (pg) EEG_TRY(ew_colsum(ctx, dh1.p, dh1.ld, nullptr, 0, u->G(r.c1_b), B, Lout, r.cout, dt));
+    if (r.emb_col >= 0) EEG_TRY(ew_colsum(ctx, dh1.p, dh1.ld, ps, ldps, pg && !fb1 ? u->G(r.c1_b) : nullptr, B, Lout, r.cout, dt));
+    else if (pg && !fb1) EEG_TRY(ew_colsum(ctx, dh1.p, dh1.ld, nullptr, 0, u->G(r.c1_b), B, Lout, r.cout, dt));
   }
   View da1; ALLOC_OR_FAIL(da1.p, u->alloc_act((long)B * Lout, r.cin)); da1.ld = r.cin;
   EEG_TRY(op_conv_dgrad(ctx, dt, dh1.p, dh1.ld, u->W(r.c1_w), da1.p, da1.ld, B, Lout, r.cin, r.cout, 3, 1, 1, 1, nullptr, 0));

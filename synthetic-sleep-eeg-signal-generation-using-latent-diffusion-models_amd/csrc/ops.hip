@@ -54,13 +54,24 @@ int op_conv_dgrad(eegldm_ctx* ctx, int dtype, const void* dy, long lddy, const v
   return gemm_launch(ctx, a);
 }
 
+// true when op_conv_wgrad produces the bias gradient inside its GEMM (no context scratch: safe on the side stream)
+bool op_wgrad_fuses_bias(int dtype, int Cin, int Cout) {
+  static const bool fuse_bias = getenv("EEGLDM_NO_FUSED_BIAS_GRAD") == nullptr;
+  return fuse_bias && dtype != EEGLDM_F32 && !conv_is_thin(Cin, Cout, dtype);
+}
+
 int op_conv_wgrad(eegldm_ctx* ctx, int dtype, const void* x, long ldx, const void* dy, long lddy, float* dw, float* dbias,
                   int B, int Lin, int Cin, int Cout, int K, int stride, int pad_l, int pad_r) {
   const int Lout = conv_lout(Lin, K, stride, pad_l, pad_r);
-  if (dbias) EEG_TRY(ew_colsum(ctx, dy, lddy, nullptr, 0, dbias, B, Lout, Cout, dtype));
-  if (conv_is_thin(Cin, Cout, dtype))
+  // bias gradient = column sums of dY: the split-K GEMM produces them from the A fragments it already holds (16-bit operands);
+  // fp32 parity mode and the thin direct convs keep the separate column-sum kernel.
+  const bool thin = conv_is_thin(Cin, Cout, dtype);
+  const bool bias_in_gemm = dbias && op_wgrad_fuses_bias(dtype, Cin, Cout);
+  if (dbias && !bias_in_gemm) EEG_TRY(ew_colsum(ctx, dy, lddy, nullptr, 0, dbias, B, Lout, Cout, dtype));
+  if (thin)
     return dconv_wgrad(ctx, dtype, x, ldx, dy, lddy, dw, B, Lin, Lout, Cin, Cout, K, stride, pad_l);
   GemmArgs a = {};
+  a.colsum = bias_in_gemm ? dbias : nullptr;
   a.dtype = dtype; a.amode = GA_TR; a.bmode = GB_TR;
   a.A = dy; a.lda = lddy; a.B = x; a.ldb = ldx; a.C = dw; a.ldc = Cin; a.sCt = (long)Cout * Cin;
   a.M = Cout; a.N = Cin; a.K = B * Lout; a.batch = 1; a.taps = 1; a.ztaps = K; a.alpha = 1.0f;

@@ -5,7 +5,8 @@ from eegldm._lib import lib, ptr, check
 from eegldm.models import UNetModel
 from eegldm.schedulers import DDPMScheduler
 from eegldm.training import ldm_train_step
-B, L = 256, 768
+B = int(sys.argv[1]) if len(sys.argv) > 1 else 256
+L = int(sys.argv[2]) if len(sys.argv) > 2 else 768
 net = UNetModel(image_size=L, in_channels=1, out_channels=1, model_channels=128, num_res_blocks=2, attention_resolutions=[8, 4], channel_mult=[1, 2, 4], resblock_updown=True, dtype="bfloat16")
 sd = net.state_dict(); g = torch.Generator().manual_seed(0)
 net.load_state_dict({k: (torch.randn(v.shape, generator=g) * 0.02 if v.abs().sum() == 0 else v) for k, v in sd.items()})
