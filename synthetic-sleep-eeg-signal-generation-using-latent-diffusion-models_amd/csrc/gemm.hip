@@ -925,16 +925,36 @@ int launch_modes(eegldm_ctx* ctx, const GemmArgs& a) {
 
 }  // namespace
 
-// dst[i] += sum_r ws[r][i]: one thread per 4 outputs, streaming over the split-K partial tiles
-__global__ void splitk_fold_kernel(const float* __restrict__ ws, int nsplit, long n, float* __restrict__ dst) {
-  const long i = ((long)blockIdx.x * blockDim.x + threadIdx.x) * 4;
-  if (i >= n) return;
-  float4 s = *(const float4*)(dst + i);
-  for (int r = 0; r < nsplit; r++) {
-    const float4 v = *(const float4*)(ws + (long)r * n + i);
-    s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+// dst[i] += sum_r ws[r][i].  A block owns 64 float4 outputs; its four waves each stream a quarter of the split-K partial tiles
+// (independent 16-byte loads, 1 KB per wave instruction), the partial sums meet in LDS and wave 0 updates dst.
+__global__ __launch_bounds__(256) void splitk_fold_kernel(const float* __restrict__ ws, int nsplit, long n, float* __restrict__ dst) {
+  __shared__ float4 red[3][64];
+  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+  const long i = ((long)blockIdx.x * 64 + tx) * 4;
+  const bool ok = i < n;
+  float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (ok) {
+    int r = ty;
+    for (; r + 12 < nsplit; r += 16) {
+      const float4 v0 = *(const float4*)(ws + (long)r * n + i), v1 = *(const float4*)(ws + (long)(r + 4) * n + i);
+      const float4 v2 = *(const float4*)(ws + (long)(r + 8) * n + i), v3 = *(const float4*)(ws + (long)(r + 12) * n + i);
+      s.x += (v0.x + v1.x) + (v2.x + v3.x); s.y += (v0.y + v1.y) + (v2.y + v3.y);
+      s.z += (v0.z + v1.z) + (v2.z + v3.z); s.w += (v0.w + v1.w) + (v2.w + v3.w);
+    }
+    for (; r < nsplit; r += 4) {
+      const float4 v = *(const float4*)(ws + (long)r * n + i);
+      s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+    }
   }
-  *(float4*)(dst + i) = s;
+  if (ty > 0) red[ty - 1][tx] = s;
+  __syncthreads();
+  if (ty == 0 && ok) {
+    float4 d = *(const float4*)(dst + i);
+#pragma unroll
+    for (int k = 0; k < 3; k++) { const float4 v = red[k][tx]; s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w; }
+    d.x += s.x; d.y += s.y; d.z += s.z; d.w += s.w;
+    *(float4*)(dst + i) = d;
+  }
 }
 
 int gemm_launch(eegldm_ctx* ctx, const GemmArgs& a_in) {
@@ -995,7 +1015,7 @@ int gemm_launch(eegldm_ctx* ctx, const GemmArgs& a_in) {
   else if (a.dtype == EEGLDM_BF16) rc = launch_modes<bf16_t>(ctx, a);
   else EEG_FAIL(EEGLDM_ERR_UNSUPPORTED, "dtype %d", a.dtype);
   if (rc == 0 && fold_dst) {
-    hipLaunchKernelGGL(splitk_fold_kernel, dim3((unsigned)((fold_n / 4 + 255) / 256)), dim3(256), 0, ctx->stream, (const float*)ctx->splitk_ws, a.splitk, fold_n, fold_dst);
+    hipLaunchKernelGGL(splitk_fold_kernel, dim3((unsigned)((fold_n / 4 + 63) / 64)), dim3(256), 0, ctx->stream, (const float*)ctx->splitk_ws, a.splitk, fold_n, fold_dst);
     LAUNCH_CHECK();
   }
   if (prof) { HIP_TRY(hipEventRecord(rec.b, ctx->stream)); ctx->prof.push_back(rec); }

@@ -102,16 +102,19 @@ int res_backward(NetBase* u, const ResDesc& r, const ResTape& t, const View& dou
   int cs_done = 0;
   EEG_TRY(op_groupnorm_bwd(ctx, t.h1.p, t.h1.ld, u->P(r.gn2_w), u->P(r.gn2_b), t.st2, da2.p, da2.ld, dh1.p, dh1.ld, pg ? u->G(r.gn2_w) : nullptr, pg ? u->G(r.gn2_b) : nullptr,
                            B, Lout, r.cout, r.groups, 1, 0, nullptr, 0, dt, ps, ldps, &cs_done));
+  // few output channels = hundreds of K splits adding into the same bias entries (+17 us at 128 channels): when the one-pass
+  // GroupNorm backward already produced per-sample sums, their total is cheaper
+  const bool fb1e = fb1 && !(cs_done && ps && r.cout < 256);
   if (pg) {
     EEG_TRY(ctx_fork(ctx));                       // dh1 is ready
     SideScope side(ctx);
-    EEG_TRY(op_conv_wgrad(ctx, dt, t.a1.p, t.a1.ld, dh1.p, dh1.ld, u->G(r.c1_w), fb1 ? u->G(r.c1_b) : nullptr, B, Lout, r.cin, r.cout, 3, 1, 1, 1));
+    EEG_TRY(op_conv_wgrad(ctx, dt, t.a1.p, t.a1.ld, dh1.p, dh1.ld, u->G(r.c1_w), fb1e ? u->G(r.c1_b) : nullptr, B, Lout, r.cin, r.cout, 3, 1, 1, 1));
   }
   if (cs_done) {
-    if (pg && !fb1) EEG_TRY(ew_colsum(ctx, ps, ldps, nullptr, 0, u->G(r.c1_b), 1, B, r.cout, EEGLDM_F32));
+    if (pg && !fb1e) EEG_TRY(ew_colsum(ctx, ps, ldps, nullptr, 0, u->G(r.c1_b), 1, B, r.cout, EEGLDM_F32));
   } else {
-    if (r.emb_col >= 0) EEG_TRY(ew_colsum(ctx, dh1.p, dh1.ld, ps, ldps, pg && !fb1 ? u->G(r.c1_b) : nullptr, B, Lout, r.cout, dt));
-    else if (pg && !fb1) EEG_TRY(ew_colsum(ctx, dh1.p, dh1.ld, nullptr, 0, u->G(r.c1_b), B, Lout, r.cout, dt));
+    if (r.emb_col >= 0) EEG_TRY(ew_colsum(ctx, dh1.p, dh1.ld, ps, ldps, pg && !fb1e ? u->G(r.c1_b) : nullptr, B, Lout, r.cout, dt));
+    else if (pg && !fb1e) EEG_TRY(ew_colsum(ctx, dh1.p, dh1.ld, nullptr, 0, u->G(r.c1_b), B, Lout, r.cout, dt));
   }
   View da1; ALLOC_OR_FAIL(da1.p, u->alloc_act((long)B * Lout, r.cin)); da1.ld = r.cin;
   EEG_TRY(op_conv_dgrad(ctx, dt, dh1.p, dh1.ld, u->W(r.c1_w), da1.p, da1.ld, B, Lout, r.cin, r.cout, 3, 1, 1, 1, nullptr, 0));

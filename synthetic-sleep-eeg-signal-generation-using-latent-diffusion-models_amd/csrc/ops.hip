@@ -89,7 +89,10 @@ int op_conv_wgrad(eegldm_ctx* ctx, int dtype, const void* x, long ldx, const voi
   } else {
     tiles = (long)((Cout + 127) / 128) * ((Cin + bn - 1) / bn) * K;
   }
-  long want = ((long)ctx->num_cu * 2 + tiles - 1) / tiles;     // fill the 2 resident blocks per CU
+  // fill the 2 resident blocks per CU in ONE round: rounding the split count up (11 x 48 tiles = 528 blocks on 512 slots) leaves a
+  // second round of 16 blocks that costs as much as the first
+  static const bool split_ceil = getenv("EEGLDM_WGRAD_SPLIT_CEIL") != nullptr;
+  long want = split_ceil ? ((long)ctx->num_cu * 2 + tiles - 1) / tiles : ((long)ctx->num_cu * 2) / tiles;
   long maxs = ((long)a.K + 8 * kstage - 1) / (8 * kstage);     // at least 8 stages per split
   if (want > maxs) want = maxs;
   a.splitk = (int)(want < 1 ? 1 : want);
