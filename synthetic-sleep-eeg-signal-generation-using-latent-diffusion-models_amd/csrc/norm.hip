@@ -715,6 +715,221 @@ int gn_bwd_t(eegldm_ctx* ctx, const void* x, long ldx, const float* gamma, const
   return 0;
 }
 
+// ------------------------------------------------------------------ thin AutoencoderKL layers: G = 1, C in {1, 2, 4, 8}, contiguous samples
+// (config_aekl_eeg_2_2_4_spec.yaml: num_channels [2, 2, 4], norm_num_groups 1).  A sample is one flat run of L*C <= 24576 elements:
+// one 256-thread block keeps it in registers as 16-byte chunks of 8 elements (element j of every chunk is channel j % C), so the
+// statistics, the normalisation and the whole backward are ONE launch each instead of stats + finalize + apply /
+// reduce + apply (2048 blocks of one row per thread and 256-way LDS atomics on these shapes: 40 us for a 1.5 MB tensor).
+constexpr int FLAT_NT = 256;
+template <typename T> struct Chunk8;
+template <> struct Chunk8<bf16_t> {
+  typedef uint4 raw_t;
+  static __device__ __forceinline__ raw_t load(const bf16_t* p) { return *(const uint4*)p; }
+  static __device__ __forceinline__ void unpack(const raw_t& r, float v[8]) {
+    v[0] = __uint_as_float(r.x << 16); v[1] = __uint_as_float(r.x & 0xffff0000u); v[2] = __uint_as_float(r.y << 16); v[3] = __uint_as_float(r.y & 0xffff0000u);
+    v[4] = __uint_as_float(r.z << 16); v[5] = __uint_as_float(r.z & 0xffff0000u); v[6] = __uint_as_float(r.w << 16); v[7] = __uint_as_float(r.w & 0xffff0000u);
+  }
+  static __device__ __forceinline__ void store(bf16_t* p, const float v[8]) {
+    uint4 t; t.x = pack_bf16x2(v[0], v[1]); t.y = pack_bf16x2(v[2], v[3]); t.z = pack_bf16x2(v[4], v[5]); t.w = pack_bf16x2(v[6], v[7]);
+    *(uint4*)p = t;
+  }
+};
+template <> struct Chunk8<float> {
+  struct raw_t { float4 a, b; };
+  static __device__ __forceinline__ raw_t load(const float* p) { raw_t r; r.a = *(const float4*)p; r.b = *(const float4*)(p + 4); return r; }
+  static __device__ __forceinline__ void unpack(const raw_t& r, float v[8]) {
+    v[0] = r.a.x; v[1] = r.a.y; v[2] = r.a.z; v[3] = r.a.w; v[4] = r.b.x; v[5] = r.b.y; v[6] = r.b.z; v[7] = r.b.w;
+  }
+  static __device__ __forceinline__ void store(float* p, const float v[8]) {
+    *(float4*)p = make_float4(v[0], v[1], v[2], v[3]); *(float4*)(p + 4) = make_float4(v[4], v[5], v[6], v[7]);
+  }
+};
+// sum of K per-thread values over the block (4 waves): result in every thread
+template <int K> __device__ __forceinline__ void flat_block_sum(float (&v)[K], float* sm) {
+#pragma unroll
+  for (int k = 0; k < K; k++)
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) v[k] += __shfl_xor(v[k], off);
+  const int wave = threadIdx.x >> 6;
+  if ((threadIdx.x & 63) == 0) {
+#pragma unroll
+    for (int k = 0; k < K; k++) sm[wave * K + k] = v[k];
+  }
+  __syncthreads();
+#pragma unroll
+  for (int k = 0; k < K; k++) v[k] = (sm[k] + sm[K + k]) + (sm[2 * K + k] + sm[3 * K + k]);
+  __syncthreads();
+}
+
+template <typename T, int C, int MAXCH>
+__global__ __launch_bounds__(FLAT_NT) void gn_flat_fwd_kernel(const T* __restrict__ x, const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                              T* __restrict__ y, float* __restrict__ stats, int n, float eps, int silu) {
+  __shared__ float sm[4];
+  const int b = blockIdx.x, tid = threadIdx.x, nch = n >> 3;
+  const T* xs = x + (long)b * n; T* ys = y + (long)b * n;
+  typename Chunk8<T>::raw_t raw[MAXCH];
+#pragma unroll
+  for (int k = 0; k < MAXCH; k++) { const int ci = k * FLAT_NT + tid; if (ci < nch) raw[k] = Chunk8<T>::load(xs + (long)ci * 8); }
+  float s[1] = {0.f};
+#pragma unroll
+  for (int k = 0; k < MAXCH; k++) {
+    if (k * FLAT_NT + tid < nch) {
+      float v[8]; Chunk8<T>::unpack(raw[k], v);
+      s[0] += ((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7]));
+    }
+  }
+  flat_block_sum<1>(s, sm);
+  const float inv_n = 1.0f / (float)n, mean = s[0] * inv_n;
+  float q[1] = {0.f};
+#pragma unroll
+  for (int k = 0; k < MAXCH; k++) {
+    if (k * FLAT_NT + tid < nch) {
+      float v[8]; Chunk8<T>::unpack(raw[k], v);
+#pragma unroll
+      for (int j = 0; j < 8; j++) { const float d = v[j] - mean; q[0] = fmaf(d, d, q[0]); }
+    }
+  }
+  flat_block_sum<1>(q, sm);
+  const float rstd = rsqrtf(q[0] * inv_n + eps);
+  if (tid == 0) { stats[2 * b] = mean; stats[2 * b + 1] = rstd; }
+  float ga[8], be[8];
+#pragma unroll
+  for (int j = 0; j < 8; j++) { ga[j] = gamma[j % C]; be[j] = beta[j % C]; }
+  const float nmr = -mean * rstd;
+#pragma unroll
+  for (int k = 0; k < MAXCH; k++) {
+    const int ci = k * FLAT_NT + tid;
+    if (ci < nch) {
+      float v[8], o[8]; Chunk8<T>::unpack(raw[k], v);
+#pragma unroll
+      for (int j = 0; j < 8; j++) { const float z = fmaf(fmaf(v[j], rstd, nmr), ga[j], be[j]); o[j] = silu ? silu_f(z) : z; }
+      Chunk8<T>::store(ys + (long)ci * 8, o);
+    }
+  }
+}
+
+template <typename T, int C, int MAXCH>
+__global__ __launch_bounds__(FLAT_NT) void gn_flat_bwd_kernel(const T* __restrict__ x, const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                              const float* __restrict__ stats, const T* __restrict__ dy, T* __restrict__ dx,
+                                                              const T* __restrict__ dxr, float* __restrict__ slots, int n, int silu) {
+  __shared__ float sm[4 * 2 * C];
+  const int b = blockIdx.x, tid = threadIdx.x, nch = n >> 3;
+  const T* xs = x + (long)b * n; const T* dys = dy + (long)b * n; T* dxs = dx + (long)b * n;
+  typename Chunk8<T>::raw_t raw[MAXCH], rd[MAXCH];
+#pragma unroll
+  for (int k = 0; k < MAXCH; k++) {
+    const int ci = k * FLAT_NT + tid;
+    if (ci < nch) { raw[k] = Chunk8<T>::load(xs + (long)ci * 8); rd[k] = Chunk8<T>::load(dys + (long)ci * 8); }
+  }
+  const float mean = stats[2 * b], rstd = stats[2 * b + 1], nmr = -mean * rstd;
+  float ga[8], be[8];
+#pragma unroll
+  for (int j = 0; j < 8; j++) { ga[j] = gamma[j % C]; be[j] = beta[j % C]; }
+  float dz[MAXCH][8];
+  float dg[8], db[8];
+#pragma unroll
+  for (int j = 0; j < 8; j++) { dg[j] = 0.f; db[j] = 0.f; }
+#pragma unroll
+  for (int k = 0; k < MAXCH; k++) {
+    if (k * FLAT_NT + tid < nch) {
+      float v[8], e[8]; Chunk8<T>::unpack(raw[k], v); Chunk8<T>::unpack(rd[k], e);
+#pragma unroll
+      for (int j = 0; j < 8; j++) {
+        const float xh = fmaf(v[j], rstd, nmr);
+        const float z = silu ? e[j] * silu_grad_f(fmaf(ga[j], xh, be[j])) : e[j];
+        dz[k][j] = z; dg[j] = fmaf(z, xh, dg[j]); db[j] += z;
+      }
+    }
+  }
+  float r[2 * C];
+#pragma unroll
+  for (int c = 0; c < C; c++) {
+    float a = 0.f, bb = 0.f;
+#pragma unroll
+    for (int j = c; j < 8; j += C) { a += dg[j]; bb += db[j]; }
+    r[c] = a; r[C + c] = bb;
+  }
+  flat_block_sum<2 * C>(r, sm);
+  float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+  for (int c = 0; c < C; c++) { s1 = fmaf(ga[c], r[C + c], s1); s2 = fmaf(ga[c], r[c], s2); }
+  if (slots && tid == 0) {
+    float* sl = slots + (size_t)(b % GN_NSLOT) * 2 * C;
+#pragma unroll
+    for (int c = 0; c < 2 * C; c++) atomicAdd(&sl[c], r[c]);
+  }
+  const float inv_n = 1.0f / (float)n;
+  const float rm1 = rstd * s1 * inv_n, rm2 = rstd * s2 * inv_n;
+  float gr[8];
+#pragma unroll
+  for (int j = 0; j < 8; j++) gr[j] = ga[j] * rstd;
+  const T* dxrs = dxr ? dxr + (long)b * n : nullptr;
+#pragma unroll
+  for (int k = 0; k < MAXCH; k++) {
+    const int ci = k * FLAT_NT + tid;
+    if (ci < nch) {
+      float v[8], o[8]; Chunk8<T>::unpack(raw[k], v);
+#pragma unroll
+      for (int j = 0; j < 8; j++) o[j] = fmaf(dz[k][j], gr[j], fmaf(fmaf(v[j], rstd, nmr), -rm2, -rm1));
+      if (dxrs) {
+        float e[8]; const typename Chunk8<T>::raw_t t = Chunk8<T>::load(dxrs + (long)ci * 8); Chunk8<T>::unpack(t, e);
+#pragma unroll
+        for (int j = 0; j < 8; j++) o[j] += e[j];
+      }
+      Chunk8<T>::store(dxs + (long)ci * 8, o);
+    }
+  }
+}
+
+bool gn_flat_ok(int L, int C, int G, int resample, long l0, long l1, long l2, long l3) {
+  static const bool off = getenv("EEGLDM_GN_NO_FLAT") != nullptr;
+  const long n = (long)L * C;
+  return !off && G == 1 && resample == 0 && (C == 1 || C == 2 || C == 4 || C == 8) && n % 8 == 0 && n <= (long)FLAT_NT * 8 * 12 &&
+         l0 == C && l1 == C && (l2 == 0 || l2 == C) && (l3 == 0 || l3 == C);
+}
+template <typename T, int C>
+int gn_flat_fwd_c(eegldm_ctx* ctx, const void* x, const float* gamma, const float* beta, void* y, float* stats, int B, int n, float eps, int silu) {
+  if (n <= FLAT_NT * 8 * 3) hipLaunchKernelGGL((gn_flat_fwd_kernel<T, C, 3>), dim3(B), dim3(FLAT_NT), 0, ctx->stream, (const T*)x, gamma, beta, (T*)y, stats, n, eps, silu);
+  else hipLaunchKernelGGL((gn_flat_fwd_kernel<T, C, 12>), dim3(B), dim3(FLAT_NT), 0, ctx->stream, (const T*)x, gamma, beta, (T*)y, stats, n, eps, silu);
+  LAUNCH_CHECK();
+  return 0;
+}
+template <typename T>
+int gn_flat_fwd(eegldm_ctx* ctx, const void* x, const float* gamma, const float* beta, void* y, float* stats, int B, int L, int C, float eps, int silu) {
+  switch (C) {
+    case 1: return gn_flat_fwd_c<T, 1>(ctx, x, gamma, beta, y, stats, B, L * C, eps, silu);
+    case 2: return gn_flat_fwd_c<T, 2>(ctx, x, gamma, beta, y, stats, B, L * C, eps, silu);
+    case 4: return gn_flat_fwd_c<T, 4>(ctx, x, gamma, beta, y, stats, B, L * C, eps, silu);
+    default: return gn_flat_fwd_c<T, 8>(ctx, x, gamma, beta, y, stats, B, L * C, eps, silu);
+  }
+}
+template <typename T, int C>
+int gn_flat_bwd_c(eegldm_ctx* ctx, const void* x, const float* gamma, const float* beta, const float* stats, const void* dy, void* dx, const void* dxr,
+                  float* slots, int B, int n, int silu) {
+  if (n <= FLAT_NT * 8 * 3) hipLaunchKernelGGL((gn_flat_bwd_kernel<T, C, 3>), dim3(B), dim3(FLAT_NT), 0, ctx->stream, (const T*)x, gamma, beta, stats, (const T*)dy, (T*)dx, (const T*)dxr, slots, n, silu);
+  else hipLaunchKernelGGL((gn_flat_bwd_kernel<T, C, 12>), dim3(B), dim3(FLAT_NT), 0, ctx->stream, (const T*)x, gamma, beta, stats, (const T*)dy, (T*)dx, (const T*)dxr, slots, n, silu);
+  LAUNCH_CHECK();
+  return 0;
+}
+template <typename T>
+int gn_flat_bwd(eegldm_ctx* ctx, const void* x, const float* gamma, const float* beta, const float* stats, const void* dy, void* dx, const void* dxr,
+                float* dgamma, float* dbeta, int B, int L, int C, int silu) {
+  float* slots = dgamma ? (float*)((char*)ctx->scratch + GN_SLOT_OFFSET) : nullptr;
+  int rc;
+  switch (C) {
+    case 1: rc = gn_flat_bwd_c<T, 1>(ctx, x, gamma, beta, stats, dy, dx, dxr, slots, B, L * C, silu); break;
+    case 2: rc = gn_flat_bwd_c<T, 2>(ctx, x, gamma, beta, stats, dy, dx, dxr, slots, B, L * C, silu); break;
+    case 4: rc = gn_flat_bwd_c<T, 4>(ctx, x, gamma, beta, stats, dy, dx, dxr, slots, B, L * C, silu); break;
+    default: rc = gn_flat_bwd_c<T, 8>(ctx, x, gamma, beta, stats, dy, dx, dxr, slots, B, L * C, silu); break;
+  }
+  if (rc) return rc;
+  if (slots) {
+    hipLaunchKernelGGL(gn_slot_reduce_kernel, dim3(1), dim3(256), 0, ctx->stream, slots, dgamma, dbeta, C, (double*)ctx->scratch, 0);
+    LAUNCH_CHECK();
+  }
+  return 0;
+}
+
 int gn_check(eegldm_ctx* ctx, int B, int L, int C, int G, int resample, long ldx) {
   EEG_CHECK(B > 0 && L > 0 && C > 0 && G > 0 && C % G == 0, "bad shape B=%d L=%d C=%d G=%d", B, L, C, G);
   EEG_CHECK(G <= MAXG_LDS && C <= MAXG_LDS, "C, G must be <= %d", MAXG_LDS);
@@ -733,6 +948,10 @@ extern "C" int eegldm_groupnorm_fwd(eegldm_ctx* ctx, const void* x, long ldx, co
                                     void* y, long ldy, float* stats, int B, int L, int C, int G, float eps,
                                     int fuse_silu, int resample, void* xr, long ldxr, int dtype) {
   EEG_TRY(gn_check(ctx, B, L, C, G, resample, ldx));
+  if (gn_flat_ok(L, C, G, resample, ldx, ldy, 0, 0)) {
+    if (dtype == EEGLDM_F32) return gn_flat_fwd<float>(ctx, x, gamma, beta, y, stats, B, L, C, eps, fuse_silu);
+    if (dtype == EEGLDM_BF16) return gn_flat_fwd<bf16_t>(ctx, x, gamma, beta, y, stats, B, L, C, eps, fuse_silu);
+  }
   const bool v4 = vec4_ok(C, G, ldx, ldy, xr ? ldxr : 0, 0);
   if (dtype == EEGLDM_F32) {
     return v4 ? gn_fwd_t<float, 4>(ctx, x, ldx, gamma, beta, y, ldy, stats, B, L, C, G, eps, fuse_silu, resample, xr, ldxr)
@@ -751,6 +970,11 @@ int op_groupnorm_bwd(eegldm_ctx* ctx, const void* x, long ldx, const float* gamm
                      float* dgamma, float* dbeta, int B, int L, int C, int G, int fuse_silu,
                      int resample, const void* dxr, long lddxr, int dtype, float* colsum_ps, long ldps, int* colsum_done) {
   EEG_TRY(gn_check(ctx, B, L, C, G, resample, ldx));
+  if (gn_flat_ok(L, C, G, resample, ldx, lddy, lddx, dxr ? lddxr : 0)) {
+    if (colsum_done) *colsum_done = 0;
+    if (dtype == EEGLDM_F32) return gn_flat_bwd<float>(ctx, x, gamma, beta, stats, dy, dx, dxr, dgamma, dbeta, B, L, C, fuse_silu);
+    if (dtype == EEGLDM_BF16) return gn_flat_bwd<bf16_t>(ctx, x, gamma, beta, stats, dy, dx, dxr, dgamma, dbeta, B, L, C, fuse_silu);
+  }
   const bool v4 = vec4_ok(C, G, ldx, lddy, lddx, dxr ? lddxr : 0);
 #define GN_BWD_ARGS ctx, x, ldx, gamma, beta, stats, dy, lddy, dx, lddx, dgamma, dbeta, B, L, C, G, fuse_silu, resample, dxr, lddxr, colsum_ps, ldps, colsum_done
   if (dtype == EEGLDM_F32) return v4 ? gn_bwd_t<float, 4>(GN_BWD_ARGS) : gn_bwd_t<float, 1>(GN_BWD_ARGS);
