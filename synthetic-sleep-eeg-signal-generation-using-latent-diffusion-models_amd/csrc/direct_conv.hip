@@ -356,8 +356,11 @@ __global__ __launch_bounds__(NT) void dconv_wgrad_kernel(const T* __restrict__ x
 // vector-load version of the tiny weight gradient: exact channel counts as template constants, one load per row and tap
 template <typename T, int CI, int CO>
 __global__ __launch_bounds__(NT) void dconv_wgrad_tinyv_kernel(const T* __restrict__ x, long ldx, const T* __restrict__ dy, long lddy,
-                                                               float* __restrict__ dw, int B, int Lo, int Li, int K, int stride, int pad_l) {
+                                                               float* __restrict__ parts, int B, int Lo, int Li, int K, int stride, int pad_l) {
   float acc[3][CO][CI];
+  float dbs[CO];
+#pragma unroll
+  for (int o = 0; o < CO; o++) dbs[o] = 0.f;
 #pragma unroll
   for (int t = 0; t < 3; t++)
 #pragma unroll
@@ -371,7 +374,7 @@ __global__ __launch_bounds__(NT) void dconv_wgrad_tinyv_kernel(const T* __restri
     const RowVec<T, CO> dv = *(const RowVec<T, CO>*)(dy + r * lddy);
     float d[CO];
 #pragma unroll
-    for (int o = 0; o < CO; o++) d[o] = ld_f32(&dv.v[o]);
+    for (int o = 0; o < CO; o++) { d[o] = ld_f32(&dv.v[o]); dbs[o] += d[o]; }
 #pragma unroll
     for (int t = 0; t < 3; t++) {
       const int v = lo * stride + t - pad_l;
@@ -386,7 +389,11 @@ __global__ __launch_bounds__(NT) void dconv_wgrad_tinyv_kernel(const T* __restri
       }
     }
   }
-  __shared__ float red[4][3 * CO * CI];
+  // one row of 3*CO*CI weight-gradient sums (dw is [K][CO][CI]: the flat index) + CO bias-gradient sums per block, WRITTEN to the
+  // partial buffer and folded by dconv_tiny_fold_kernel: 512 blocks adding atomically into the same <= 52 addresses serialised
+  // in L2 for 15-35 us per launch, and the bias gradient was a separate column-sum pass over dy
+  constexpr int EW = 3 * CO * CI, EP = EW + CO;
+  __shared__ float red[4][EP];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 #pragma unroll
   for (int t = 0; t < 3; t++)
@@ -397,12 +404,26 @@ __global__ __launch_bounds__(NT) void dconv_wgrad_tinyv_kernel(const T* __restri
         const float s = wave_sum(acc[t][o][i]);
         if (lane == 0) red[wave][(t * CO + o) * CI + i] = s;
       }
+#pragma unroll
+  for (int o = 0; o < CO; o++) {
+    const float s = wave_sum(dbs[o]);
+    if (lane == 0) red[wave][EW + o] = s;
+  }
   __syncthreads();
   const int e = threadIdx.x;
-  if (e < 3 * CO * CI) {
-    const int t = e / (CO * CI);
-    if (t < K) atomicAdd(dw + e, red[0][e] + red[1][e] + red[2][e] + red[3][e]);      // dw is [K][CO][CI]: e is the flat index
-  }
+  if (e < EP) parts[(long)blockIdx.x * EP + e] = (red[0][e] + red[1][e]) + (red[2][e] + red[3][e]);
+}
+
+// dw[e] += sum_p parts[p][e] (e < ew), dbias[o] += sum_p parts[p][bias_off + o]: lanes = elements, (block, wave) = part subsets
+__global__ __launch_bounds__(NT) void dconv_tiny_fold_kernel(const float* __restrict__ parts, int nparts, int stride, int ew, int bias_off, int co,
+                                                             float* __restrict__ dw, float* __restrict__ dbias) {
+  const int e = threadIdx.x & 63, w = blockIdx.x * (NT / 64) + (threadIdx.x >> 6), nw = gridDim.x * (NT / 64);
+  const bool is_w = e < ew, is_b = dbias && e >= bias_off && e < bias_off + co;
+  if (!is_w && !is_b) return;
+  float s = 0.f;
+#pragma unroll 4
+  for (int p = w; p < nparts; p += nw) s += parts[(long)p * stride + e];
+  atomicAdd(is_w ? dw + e : dbias + (e - bias_off), s);
 }
 
 // "tiny" variant (Cin, Cout <= 4; every layer of the [2,2,4] autoencoder): thread per output row with all K*Cout*Cin
@@ -528,16 +549,24 @@ int dconv_run(eegldm_ctx* ctx, int dtype, bool dgrad, const void* in, long ldin,
   return 0;
 }
 
+bool dconv_wgrad_tinyv_ok(int Cin, int Cout, int K) {
+  return K <= 3 && (Cin == 1 || Cin == 2 || Cin == 4) && (Cout == 1 || Cout == 2 || Cout == 4);
+}
+
+// *bias_done (optional) is set when the kernel also produced dbias (the tiny vector kernel); otherwise the caller sums dy itself
 int dconv_wgrad(eegldm_ctx* ctx, int dtype, const void* x, long ldx, const void* dy, long lddy, float* dw, int B, int Lin,
-                int Lout, int Cin, int Cout, int K, int stride, int pad_l) {
+                int Lout, int Cin, int Cout, int K, int stride, int pad_l, float* dbias, int* bias_done) {
   const long rows = (long)B * Lout;
+  if (bias_done) *bias_done = 0;
   if (Cin <= 4 && Cout <= 4 && K <= 3) {
     long nb = (rows + NT - 1) / NT; if (nb > 2L * ctx->num_cu) nb = 2L * ctx->num_cu;
     const int blocks = (int)(nb < 1 ? 1 : nb);
-    const bool pow2 = (Cin == 1 || Cin == 2 || Cin == 4) && (Cout == 1 || Cout == 2 || Cout == 4);
-    if (pow2 && ldx % Cin == 0 && lddy % Cout == 0) {
+    if (dconv_wgrad_tinyv_ok(Cin, Cout, K) && ldx % Cin == 0 && lddy % Cout == 0) {
+      // partial sums live in their own slice of the context scratch ([4, 5) MiB): this path also runs on the side stream
+      float* parts = (float*)((char*)ctx->scratch + (4u << 20));
+      const int EW = 3 * Cout * Cin, EP = EW + Cout;
 #define DWV(T_, CI_, CO_) hipLaunchKernelGGL((dconv_wgrad_tinyv_kernel<T_, CI_, CO_>), dim3(blocks), dim3(NT), 0, ctx->stream, (const T_*)x, ldx, (const T_*)dy, lddy, \
-                                             dw, B, Lout, Lin, K, stride, pad_l)
+                                             parts, B, Lout, Lin, K, stride, pad_l)
 #define DWV_CO(T_, CI_) do { if (Cout == 1) DWV(T_, CI_, 1); else if (Cout == 2) DWV(T_, CI_, 2); else DWV(T_, CI_, 4); } while (0)
 #define DWV_T(T_) do { if (Cin == 1) DWV_CO(T_, 1); else if (Cin == 2) DWV_CO(T_, 2); else DWV_CO(T_, 4); } while (0)
       if (dtype == EEGLDM_F32) DWV_T(float); else DWV_T(bf16_t);
@@ -545,6 +574,9 @@ int dconv_wgrad(eegldm_ctx* ctx, int dtype, const void* x, long ldx, const void*
 #undef DWV_CO
 #undef DWV
       LAUNCH_CHECK();
+      hipLaunchKernelGGL(dconv_tiny_fold_kernel, dim3(blocks >= 64 ? 8 : 1), dim3(NT), 0, ctx->stream, parts, blocks, EP, K * Cout * Cin, EW, Cout, dw, dbias);
+      LAUNCH_CHECK();
+      if (bias_done && dbias) *bias_done = 1;
       return 0;
     }
     if (dtype == EEGLDM_F32)

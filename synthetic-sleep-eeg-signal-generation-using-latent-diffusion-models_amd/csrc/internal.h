@@ -18,7 +18,8 @@ int dconv_run(eegldm_ctx*, int dtype, bool dgrad, const void* in, long ldin, con
               const void* resid, long ldr, void* out, long ldout, int B, int Lin, int Lout, int Cin, int Cout, int K,
               int stride, int pad_l);
 int dconv_wgrad(eegldm_ctx*, int dtype, const void* x, long ldx, const void* dy, long lddy, float* dw, int B, int Lin,
-                int Lout, int Cin, int Cout, int K, int stride, int pad_l);
+                int Lout, int Cin, int Cout, int K, int stride, int pad_l, float* dbias, int* bias_done);
+bool dconv_wgrad_tinyv_ok(int Cin, int Cout, int K);
 
 // ops.hip
 int op_conv_fwd(eegldm_ctx*, int dtype, const void* x, long ldx, const void* w, const float* bias, void* y, long ldy,

@@ -54,22 +54,30 @@ int op_conv_dgrad(eegldm_ctx* ctx, int dtype, const void* dy, long lddy, const v
   return gemm_launch(ctx, a);
 }
 
-// true when op_conv_wgrad produces the bias gradient inside its GEMM (no context scratch: safe on the side stream)
+// true when op_conv_wgrad produces the bias gradient inside its weight-gradient kernel (no shared context scratch: safe on the
+// side stream): the split-K GEMM with 16-bit operands, or the tiny direct kernel of the [2,2,4] autoencoder layers
 bool op_wgrad_fuses_bias(int dtype, int Cin, int Cout) {
   static const bool fuse_bias = getenv("EEGLDM_NO_FUSED_BIAS_GRAD") == nullptr;
-  return fuse_bias && dtype != EEGLDM_F32 && !conv_is_thin(Cin, Cout, dtype);
+  if (!fuse_bias) return false;
+  if (conv_is_thin(Cin, Cout, dtype)) return dconv_wgrad_tinyv_ok(Cin, Cout, 3);
+  return dtype != EEGLDM_F32;
 }
 
 int op_conv_wgrad(eegldm_ctx* ctx, int dtype, const void* x, long ldx, const void* dy, long lddy, float* dw, float* dbias,
                   int B, int Lin, int Cin, int Cout, int K, int stride, int pad_l, int pad_r) {
   const int Lout = conv_lout(Lin, K, stride, pad_l, pad_r);
-  // bias gradient = column sums of dY: the split-K GEMM produces them from the A fragments it already holds (16-bit operands);
-  // fp32 parity mode and the thin direct convs keep the separate column-sum kernel.
+  // bias gradient = column sums of dY: the split-K GEMM produces them from the A fragments it already holds (16-bit operands),
+  // the tiny direct kernel from the dy rows it reads; fp32 parity mode and the other thin shapes keep the separate column-sum kernel.
   const bool thin = conv_is_thin(Cin, Cout, dtype);
+  if (thin) {
+    static const bool fuse_bias = getenv("EEGLDM_NO_FUSED_BIAS_GRAD") == nullptr;
+    int done = 0;
+    EEG_TRY(dconv_wgrad(ctx, dtype, x, ldx, dy, lddy, dw, B, Lin, Lout, Cin, Cout, K, stride, pad_l, fuse_bias ? dbias : nullptr, &done));
+    if (dbias && !done) EEG_TRY(ew_colsum(ctx, dy, lddy, nullptr, 0, dbias, B, Lout, Cout, dtype));
+    return 0;
+  }
   const bool bias_in_gemm = dbias && op_wgrad_fuses_bias(dtype, Cin, Cout);
   if (dbias && !bias_in_gemm) EEG_TRY(ew_colsum(ctx, dy, lddy, nullptr, 0, dbias, B, Lout, Cout, dtype));
-  if (thin)
-    return dconv_wgrad(ctx, dtype, x, ldx, dy, lddy, dw, B, Lin, Lout, Cin, Cout, K, stride, pad_l);
   GemmArgs a = {};
   a.colsum = bias_in_gemm ? dbias : nullptr;
   a.dtype = dtype; a.amode = GA_TR; a.bmode = GB_TR;
