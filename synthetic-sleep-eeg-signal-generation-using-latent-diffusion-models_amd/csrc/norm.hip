@@ -642,7 +642,9 @@ int gn_fwd_t(eegldm_ctx* ctx, const void* x, long ldx, const float* gamma, const
     static const int fwd_rpt_max = getenv("EEGLDM_GN_FWD_RPT") ? atoi(getenv("EEGLDM_GN_FWD_RPT")) : 12;
     int rpt = 0; int cc = off ? 0 : resident_chunk(L, C, G, resample == 1, fwd_rpt_max, &rpt);
     // measured (tools/debug/gn_bench.py): wins while the rows are at least a 128-byte line and the blocks fit two rounds
-    if (cc && (cc * (int)sizeof(T) < 128 || (long)(C / cc) * B > 2L * ctx->num_cu)) cc = 0;
+    // (1024 blocks = the 100 MB concat tensors of the up path: 47-48 us one-pass vs 51 us split)
+    static const long fwd_bpc = getenv("EEGLDM_GN_FWD_BLOCKS_PER_CU") ? atol(getenv("EEGLDM_GN_FWD_BLOCKS_PER_CU")) : 4;
+    if (cc && (cc * (int)sizeof(T) < 128 || (long)(C / cc) * B > fwd_bpc * ctx->num_cu)) cc = 0;
     if (cc) {
       const dim3 grid(C / cc, B);
 #define GN_FWD_RES(R) hipLaunchKernelGGL((gn_fwd_resident_kernel<T, R>), grid, dim3(NTB), 0, ctx->stream, (const T*)x, ldx, gamma, beta, \
@@ -676,7 +678,9 @@ int gn_bwd_t(eegldm_ctx* ctx, const void* x, long ldx, const float* gamma, const
     static const bool off = getenv("EEGLDM_GN_NO_RESIDENT") != nullptr;
     int rpt = 0; int cc = off ? 0 : resident_chunk(L, C, G, 0, sizeof(T) == 2 ? 12 : 8, &rpt);
     // measured (tools/debug/gn_bench.py): the one-pass kernel wins while its blocks fit two rounds of one block per CU
-    if (cc && (cc * (int)sizeof(T) < 128 || (long)(C / cc) * B > 2L * ctx->num_cu)) cc = 0;
+    // (1024 blocks: 112 us one-pass vs 117-120 us split on the 100 MB tensors; 2048 blocks of 96-channel chunks lose)
+    static const long bwd_bpc = getenv("EEGLDM_GN_BWD_BLOCKS_PER_CU") ? atol(getenv("EEGLDM_GN_BWD_BLOCKS_PER_CU")) : 4;
+    if (cc && (cc * (int)sizeof(T) < 128 || (long)(C / cc) * B > bwd_bpc * ctx->num_cu)) cc = 0;
     if (cc) {
       const dim3 grid(C / cc, B);
       float* slots = dgamma ? (float*)((char*)ctx->scratch + GN_SLOT_OFFSET) : nullptr;

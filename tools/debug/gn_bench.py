@@ -4,7 +4,7 @@ import eegldm
 from eegldm._lib import lib, ptr, check
 ctx = eegldm.default_context(0)
 B = 256
-for (L, C) in [(768, 128), (384, 256), (192, 512), (768, 384), (192, 1024)]:
+for (L, C) in [(768, 128), (384, 256), (192, 512), (768, 256), (768, 384), (384, 512), (384, 768), (192, 1024), (192, 1536)]:
     R = B * L
     x = torch.randn(R, C, device="cuda").bfloat16(); y = torch.empty_like(x); dy = torch.randn(R, C, device="cuda").bfloat16(); dx = torch.empty_like(x)
     ga = torch.ones(C, device="cuda"); be = torch.zeros(C, device="cuda"); st = torch.empty(B * 32 * 2, device="cuda"); dg = torch.zeros(C, device="cuda"); db = torch.zeros(C, device="cuda")
