@@ -544,13 +544,20 @@ __global__ __launch_bounds__((WMT == 3 ? 256 : 128 * WMT), 2) void gemm_kernel(c
           if constexpr (AMODE == GA_TR) mma<T>(af[st & 1][i], bf[st & 1][j], acc[C::WG3 ? t : 0][i][j]);   // TN products keep the natural fragment (atomic epilogue)
           else mma<T>(bf[st & 1][j], af[st & 1][i], acc[0][i][j]);                                        // swapped: acc = (B.A^T) fragment
         }
-      if constexpr (C::COLSUM) {
-        // bias gradient for free: A (dY, transposed) times an all-ones B fragment = the row sums of this K step in every column
-        if (do_cs && t == 0) {
-          const uint4 ones = make_uint4(0x3F803F80u, 0x3F803F80u, 0x3F803F80u, 0x3F803F80u);
+    }
+    if constexpr (C::COLSUM) {
+      // bias gradient for free: A (dY, transposed) times an all-ones B fragment = the row sums of this stage in every column.
+      // A separate pass over the stage's A tile (one wave in 16 takes it) -- a branch inside the unrolled MFMA steps cost every
+      // wave 8 % (512 x 512 x 49152: 1.03 -> 1.11 ms).
+      if (do_cs) {
+        const uint4 ones = make_uint4(0x3F803F80u, 0x3F803F80u, 0x3F803F80u, 0x3F803F80u);
 #pragma unroll
-          for (int i = 0; i < C::FM; i++) mma<T>(af[st & 1][i], ones, cs[i]);
-        }
+        for (int ks = 0; ks < KSUB; ks++)
+#pragma unroll
+          for (int i = 0; i < C::FM; i++) {
+            const uint4 a = read_tr_t<T, BM>(smA, ks, wm * (C::FM * 16) + i * 16, lm, q);
+            mma<T>(a, ones, cs[i]);
+          }
       }
     }
     TSTAMP();   // after the MFMA phase of stage s
