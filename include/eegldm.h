@@ -141,6 +141,9 @@ int eegldm_ddim_step(eegldm_ctx*, const float* model_out, const float* sample, f
 int eegldm_mse_loss(eegldm_ctx*, const float* pred, const float* target, float* loss, float* dpred, long n, float grad_scale);
 int eegldm_adam_step(eegldm_ctx*, float* p, const float* g, float* m, float* v, long n, float lr, float beta1,
                      float beta2, float eps, int step, float grad_inv_scale);
+/* found_inf[0] (device float) = 1 if any of g[0..n) is inf/nan, else 0 -- the check behind GradScaler.unscale_/step
+ * (torch.cuda.amp.GradScaler at /root/reference/src/training/training.py:334,441-443). g must be 16-byte aligned. */
+int eegldm_grad_check_finite(eegldm_ctx*, const float* g, long n, float* found_inf);
 int eegldm_randn(eegldm_ctx*, float* out, long n, uint64_t seed, uint64_t offset);
 int eegldm_randint(eegldm_ctx*, int64_t* out, long n, int64_t high, uint64_t seed, uint64_t offset);
 

@@ -53,6 +53,18 @@ def dm_train_step(unet_sd, unet_cfg, acp, images, noise, t, spectral_weight=0.0,
     return loss.detach(), grads, pred.detach()
 
 
+def grad_scaler_update(scale, growth_tracker, found_inf, growth_factor=2.0, backoff_factor=0.5, growth_interval=2000):
+    """torch.cuda.amp.GradScaler.update (used at /root/reference/src/training/training.py:334,443): a step with inf/nan gradients
+    multiplies the scale by backoff_factor and resets the streak; growth_interval consecutive clean steps multiply it by
+    growth_factor.  Returns (new_scale, new_growth_tracker).  Pinned against torch.amp.GradScaler in tests/test_oracle_closed_form.py."""
+    if found_inf:
+        return scale * backoff_factor, 0
+    t = growth_tracker + 1
+    if t == growth_interval:
+        return scale * growth_factor, 0
+    return scale, t
+
+
 def adam_update(params, grads, state, lr, step, b1=0.9, b2=0.999, eps=1e-8):
     """torch.optim.Adam semantics (no weight decay, no amsgrad), in place."""
     for k, g in grads.items():

@@ -59,6 +59,7 @@ SIGNATURES = {
     "eegldm_ddim_step": [_vp, _vp, _vp, _f, _f, _i, _i, _vp, _vp, _l],
     "eegldm_mse_loss": [_vp, _vp, _vp, _vp, _vp, _l, _f],
     "eegldm_adam_step": [_vp, _vp, _vp, _vp, _vp, _l, _f, _f, _f, _f, _i, _f],
+    "eegldm_grad_check_finite": [_vp, _vp, _l, _vp],
     "eegldm_randn": [_vp, _vp, _l, C.c_uint64, C.c_uint64],
     "eegldm_randint": [_vp, _vp, _l, C.c_int64, C.c_uint64, C.c_uint64],
     "eegldm_fill": [_vp, _vp, _l, _f],

@@ -420,6 +420,26 @@ extern "C" int eegldm_adam_step(eegldm_ctx* ctx, float* p, const float* g, float
   hipLaunchKernelGGL(adam_kernel, dim3(grid1d(n, ctx, 2)), dim3(NT), 0, ctx->stream, p, g, m, v, n, lr, b1, b2, eps, bc1, bc2s, ginv);
   LAUNCH_CHECK(); return 0;
 }
+// GradScaler.unscale_/step support (training.py:334,441-443 use torch.cuda.amp.GradScaler): found_inf[0] = 1 if any gradient is
+// inf / nan, else 0.  One pass over the flat gradient buffer, 16-byte loads; the flag stays on the device until the host reads it.
+__global__ void finite_check_kernel(const float* __restrict__ g, long n, float* __restrict__ found_inf) {
+  bool bad = false;
+  const long n4 = n >> 2;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
+    const float4 v = ((const float4*)g)[i];
+    // (x - x) is 0 for finite x and nan for inf / nan
+    bad |= ((v.x - v.x) + (v.y - v.y) + (v.z - v.z) + (v.w - v.w)) != 0.0f;
+  }
+  for (long i = (n4 << 2) + (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) bad |= (g[i] - g[i]) != 0.0f;
+  if (__any(bad) && (threadIdx.x & 63) == 0) found_inf[0] = 1.0f;
+}
+extern "C" int eegldm_grad_check_finite(eegldm_ctx* ctx, const float* g, long n, float* found_inf) {
+  EEG_CHECK(g && found_inf && n >= 0, "grad_check_finite: null argument");
+  EEG_CHECK(((uintptr_t)g & 15) == 0, "grad_check_finite: gradient buffer must be 16-byte aligned");
+  HIP_TRY(hipMemsetAsync(found_inf, 0, sizeof(float), ctx->stream));
+  if (n > 0) { hipLaunchKernelGGL(finite_check_kernel, dim3(grid1d((n + 3) / 4, ctx, 4)), dim3(NT), 0, ctx->stream, g, n, found_inf); LAUNCH_CHECK(); }
+  return 0;
+}
 extern "C" int eegldm_randn(eegldm_ctx* ctx, float* out, long n, uint64_t seed, uint64_t offset) {
   hipLaunchKernelGGL(randn_kernel, dim3(grid1d((n + 3) / 4, ctx)), dim3(NT), 0, ctx->stream, out, n, seed, offset);
   LAUNCH_CHECK(); return 0;

@@ -10,7 +10,7 @@ import torch
 from .. import distributed as D
 from ..models import AutoencoderKL, UNetModel
 from ..schedulers import DDPMScheduler
-from ..training import Adam, ldm_train_step, randint, randn
+from ..training import Adam, GradScaler, ldm_train_step, randint, randn
 from .common import ParseListAction, WindowLoader, load_config, setup_run_dir
 
 
@@ -26,6 +26,7 @@ def parse_args(argv=None):
     p.add_argument("--synthetic_windows", type=int, default=0); p.add_argument("--dtype", default="float32")
     p.add_argument("--max_steps", type=int, default=0); p.add_argument("--output_dir", default=None)
     p.add_argument("--prediction_type", default="epsilon")
+    p.add_argument("--grad_scaler", action="store_true", help="dynamic loss scaling as in the reference loop (training.py:334,441-443); bf16/fp32 do not need it")
     return p.parse_args(argv)
 
 
@@ -50,6 +51,7 @@ def main(args):
     sched = DDPMScheduler(num_train_timesteps=1000, schedule="scaled_linear_beta", beta_start=0.0015, beta_end=0.0195,
                           prediction_type=args.prediction_type, device=local)   # train_ldm.py:199-200 ("linear" there == scaled-linear)
     opt = Adam(unet, lr=config.train.get("base_lr", 1e-4))
+    scaler = GradScaler(enabled=args.grad_scaler)
     bs = max(1, config.train.batch_size // world)
     train = WindowLoader(args.path_pre_processed, bs, args.synthetic_windows, seed=config.train.seed + rank, drop_last=config.train.drop_last)
     dev, ctx = unet.device, unet.ctx
@@ -71,9 +73,9 @@ def main(args):
             noise = randn(ctx, eps.shape, seed=config.train.seed + 13 + rank, offset=steps * z[0].numel() * B)
             e = stage1.encode_stage_2_inputs(x, eps=eps, scale_factor=scale_factor)
             opt.zero_grad()
-            ldm_train_step(unet, sched, e, noise, t, loss_out=loss, grad_sync=gsync)
+            ldm_train_step(unet, sched, e, noise, t, loss_out=loss, grad_scale=scaler.get_scale(), grad_sync=gsync)
             gsync.wait()
-            opt.step()
+            scaler.step(opt); scaler.update()
             steps += 1; seen += B * world
             if args.max_steps and steps >= args.max_steps:
                 break

@@ -39,6 +39,77 @@ class Adam:
         self.param_groups[0]["lr"] = sd.get("lr", self.lr)
 
 
+class GradScaler:
+    """Dynamic loss scaling with torch.cuda.amp.GradScaler's interface and update rule (the reference's LDM / DM loops:
+    /root/reference/src/training/training.py:334,441-443 -- ``scaler.scale(loss).backward(); scaler.step(opt); scaler.update()``).
+
+    The native train steps take the scale as their ``grad_scale`` argument (``get_scale()``), ``step`` checks the flat
+    gradient buffer for inf/nan on the device (one host read of the flag, as torch's scaler does), skips the optimizer
+    step when one is found and otherwise un-scales inside the Adam kernel; ``update`` backs off / grows the scale.
+    bf16 and fp32 share fp32's exponent range, so the entry scripts leave it disabled unless asked (--grad-scaler)."""
+
+    def __init__(self, init_scale=65536.0, growth_factor=2.0, backoff_factor=0.5, growth_interval=2000, enabled=True):
+        self._scale, self._growth_factor, self._backoff_factor = float(init_scale), float(growth_factor), float(backoff_factor)
+        self._growth_interval, self._enabled = int(growth_interval), bool(enabled)
+        self._growth_tracker, self._found_inf, self._flag = 0, None, None
+
+    def is_enabled(self):
+        return self._enabled
+
+    def get_scale(self):
+        return self._scale if self._enabled else 1.0
+
+    def scale(self, outputs):
+        return outputs * self.get_scale() if self._enabled else outputs
+
+    def unscale_(self, optimizer):
+        """Records whether optimizer.model's gradients hold an inf/nan (the division itself happens inside the Adam kernel)."""
+        if not self._enabled:
+            return
+        md = optimizer.model
+        if self._flag is None or self._flag.device != md.flat_grad.device:
+            self._flag = torch.zeros(1, device=md.flat_grad.device)
+        check(lib.eegldm_grad_check_finite(md.ctx.h, ptr(md.flat_grad), md.flat_grad.numel(), ptr(self._flag)))
+        md.ctx.sync()
+        self._found_inf = bool(float(self._flag) != 0.0)
+
+    def step(self, optimizer):
+        if not self._enabled:
+            return optimizer.step()
+        if self._found_inf is None:
+            self.unscale_(optimizer)
+        if self._found_inf:
+            return None                     # skipped: parameters, moments and the optimizer's step count stay as they are
+        return optimizer.step(grad_inv_scale=1.0 / self._scale)
+
+    def update(self, new_scale=None):
+        if not self._enabled:
+            return
+        if new_scale is not None:
+            self._scale, self._found_inf = float(new_scale), None
+            return
+        found = bool(self._found_inf)
+        if found:
+            self._scale *= self._backoff_factor
+            self._growth_tracker = 0
+        else:
+            self._growth_tracker += 1
+            if self._growth_tracker == self._growth_interval:
+                self._scale *= self._growth_factor
+                self._growth_tracker = 0
+        self._found_inf = None
+
+    def state_dict(self):
+        return {"scale": self._scale, "growth_factor": self._growth_factor, "backoff_factor": self._backoff_factor,
+                "growth_interval": self._growth_interval, "_growth_tracker": self._growth_tracker} if self._enabled else {}
+
+    def load_state_dict(self, sd):
+        if not self._enabled or not sd:
+            return
+        self._scale, self._growth_factor, self._backoff_factor = float(sd["scale"]), float(sd["growth_factor"]), float(sd["backoff_factor"])
+        self._growth_interval, self._growth_tracker = int(sd["growth_interval"]), int(sd["_growth_tracker"])
+
+
 GRAD_HOOK = C.CFUNCTYPE(None, C.c_void_p, C.c_long, C.c_long)
 
 

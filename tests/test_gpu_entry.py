@@ -43,7 +43,7 @@ def test_train_aekl_train_ldm_sample(tmp_path):
     # resume path
     TA.main(TA.parse_args(["--config_file", a_yaml, "--spe", "spectral", "--synthetic_windows", "16", "--latent_channels", "1"]))
     run_l = TL.main(TL.parse_args(["--config_file", l_yaml, "--autoencoderkl_config_file_path", a_yaml, "--best_model_path", run_a,
-                                   "--synthetic_windows", "16", "--latent_channels", "1", "--max_steps", "2"]))
+                                   "--synthetic_windows", "16", "--latent_channels", "1", "--max_steps", "2", "--grad_scaler"]))   # scaler path as in training.py:441-443
     ck = torch.load(os.path.join(run_l, "checkpoint.pth"))
     assert set(ck) >= {"epoch", "diffusion", "optimizer", "best_loss", "scale_factor"} and float(ck["scale_factor"]) > 0   # training.py:381-387
     sdir = ST.main(ST.parse_args(["--output_dir", out, "--best_model_path", run_a, "--diffusion_path", run_l,

@@ -90,3 +90,35 @@ def test_pixel_dm_step_matches_oracle(spectral):
     num = sum(float((g[k].cpu() - grads_ref[k]).double().pow(2).sum()) for k in grads_ref)
     den = sum(float(grads_ref[k].double().pow(2).sum()) for k in grads_ref)
     assert (num / den) ** 0.5 < 2e-4
+
+
+@pytest.mark.gpu
+def test_grad_scaler_skips_overflow_and_unscales():
+    """GradScaler (training.py:334,441-443): a step whose gradients hold an inf is skipped and halves the scale; a clean step
+    equals a plain Adam step on the un-scaled gradients; the scale grows after growth_interval clean steps."""
+    import eegldm
+    from eegldm.models import UNetModel
+    from eegldm.training import Adam, GradScaler
+    from oracle import steps as S
+    net = UNetModel(image_size=64, in_channels=1, out_channels=1, model_channels=32, num_res_blocks=1, attention_resolutions=[4],
+                    channel_mult=[1, 2], resblock_updown=True, dtype="float32", device=0)
+    opt = Adam(net, lr=1e-3)
+    sc = GradScaler(init_scale=256.0, growth_interval=2)
+    g = torch.Generator().manual_seed(3)
+    grad = torch.randn(net.flat.numel(), generator=g).to(net.flat.device)
+    p0 = net.flat.clone()
+    # overflow: skipped
+    net.flat_grad.copy_(grad * sc.get_scale()); net.flat_grad[12345 % net.flat.numel()] = float("inf")
+    sc.step(opt); sc.update()
+    assert torch.equal(net.flat, p0) and opt.step_count == 0 and sc.get_scale() == 128.0
+    net.flat_grad.copy_(grad * sc.get_scale()); net.flat_grad[-1] = float("nan")
+    sc.step(opt); sc.update()
+    assert torch.equal(net.flat, p0) and sc.get_scale() == 64.0
+    # clean steps: Adam on grad (oracle), scale doubles after two of them
+    ref = {"p": p0.cpu().clone()}; st = {}
+    for i in range(2):
+        net.flat_grad.copy_(grad * sc.get_scale())
+        sc.step(opt); sc.update()
+        ref = S.adam_update(ref, {"p": grad.cpu()}, st, 1e-3, i + 1)
+    assert opt.step_count == 2 and sc.get_scale() == 128.0
+    torch.testing.assert_close(net.flat.cpu(), ref["p"], rtol=1e-5, atol=1e-7)

@@ -96,3 +96,28 @@ def test_aekl_blocks_match_reference_local_twin():
     up = R.Upsample(32)
     got = F.conv1d(F.interpolate(x, scale_factor=2.0, mode="nearest"), up.conv.weight, up.conv.bias, padding=1)
     np.testing.assert_allclose(got.detach().numpy(), up(x).detach().numpy(), rtol=1e-5, atol=1e-6)
+
+
+def test_grad_scaler_update_rule_matches_torch():
+    """The oracle's GradScaler.update restatement and the product's host-side class against torch.amp.GradScaler itself
+    (CPU device): same scale after every step of a finite / inf gradient sequence, and skipped steps leave the parameter alone."""
+    from oracle import steps as S
+    import eegldm
+    from eegldm.training import GradScaler
+    seq = [False, False, True, False, False, False, True, True, False, False, False, False]
+    ref = torch.amp.GradScaler("cpu", init_scale=1024.0, growth_factor=2.0, backoff_factor=0.5, growth_interval=3)
+    p = torch.nn.Parameter(torch.ones(4)); opt = torch.optim.SGD([p], lr=0.1)
+    mine = GradScaler(init_scale=1024.0, growth_factor=2.0, backoff_factor=0.5, growth_interval=3)
+    scale, tracker = 1024.0, 0
+    for bad in seq:
+        opt.zero_grad()
+        loss = (p * (float("inf") if bad else 1.0)).sum()
+        before = p.detach().clone()
+        ref.scale(loss).backward(); ref.step(opt); ref.update()
+        assert torch.equal(before, p.detach()) == bad                # skipped exactly when the gradients overflowed
+        scale, tracker = S.grad_scaler_update(scale, tracker, bad, 2.0, 0.5, 3)
+        mine._found_inf = bad; mine.update()
+        assert float(ref.get_scale()) == scale == mine.get_scale()
+    assert mine.state_dict()["_growth_tracker"] == tracker
+    off = GradScaler(enabled=False)
+    assert off.get_scale() == 1.0 and off.state_dict() == {}
