@@ -67,10 +67,10 @@ __device__ __forceinline__ ColMap colmap(int C, int V) {
 template <typename T, int V>
 __global__ __launch_bounds__(NT) void gn_stats_kernel(const T* __restrict__ x, long ldx, double* __restrict__ sums,
                                                       int L, int C, int G, int rows_per_block) {
-  __shared__ float acc[2 * MAXG_LDS];
+  __shared__ double acc[2 * MAXG_LDS];   // fp64 like the global sums: the arrival order of the threads must not show in the statistics (reproducible forward)
   const int b = blockIdx.y, tid = threadIdx.x;
   const int cpg = C / G;
-  for (int i = tid; i < 2 * G; i += NT) acc[i] = 0.f;
+  for (int i = tid; i < 2 * G; i += NT) acc[i] = 0.0;
   __syncthreads();
   const ColMap cm = colmap(C, V);
   const int l0 = blockIdx.x * rows_per_block, l1 = min(L, l0 + rows_per_block);
@@ -87,12 +87,12 @@ __global__ __launch_bounds__(NT) void gn_stats_kernel(const T* __restrict__ x, l
         for (int k = 0; k < V; k++) { s1 += v[k]; s2 += v[k] * v[k]; }
       }
       const int g = c / cpg;
-      atomicAdd(&acc[2 * g], s1);
-      atomicAdd(&acc[2 * g + 1], s2);
+      atomicAdd(&acc[2 * g], (double)s1);
+      atomicAdd(&acc[2 * g + 1], (double)s2);
     }
   }
   __syncthreads();
-  for (int i = tid; i < 2 * G; i += NT) atomicAdd(&sums[(long)b * G * 2 + i], (double)acc[i]);
+  for (int i = tid; i < 2 * G; i += NT) atomicAdd(&sums[(long)b * G * 2 + i], acc[i]);
 }
 
 // (self-cleaning: the accumulators are zeroed again for the next GroupNorm, so no memset launches are needed)
@@ -214,11 +214,11 @@ __global__ __launch_bounds__(NT) void gn_bwd_reduce_kernel(const T* __restrict__
                                                            const T* __restrict__ dy, long lddy, double* __restrict__ gsums,
                                                            float* __restrict__ slots,
                                                            int L, int C, int G, int silu, int rows_per_block) {
-  __shared__ float accg[2 * MAXG_LDS];
+  __shared__ double accg[2 * MAXG_LDS];  // group sums feed dx: fp64 so that the thread arrival order does not show (see gn_stats_kernel)
   __shared__ float accc[2 * MAXG_LDS];
   const int b = blockIdx.y, tid = threadIdx.x;
   const int cpg = C / G;
-  for (int i = tid; i < 2 * G; i += NT) accg[i] = 0.f;
+  for (int i = tid; i < 2 * G; i += NT) accg[i] = 0.0;
   for (int i = tid; i < 2 * C; i += NT) accc[i] = 0.f;
   __syncthreads();
   const ColMap cm = colmap(C, V);
@@ -246,13 +246,13 @@ __global__ __launch_bounds__(NT) void gn_bwd_reduce_kernel(const T* __restrict__
           s1 += dz * ga[k]; s2 += dz * ga[k] * xh;
         }
       }
-      atomicAdd(&accg[2 * g], s1); atomicAdd(&accg[2 * g + 1], s2);
+      atomicAdd(&accg[2 * g], (double)s1); atomicAdd(&accg[2 * g + 1], (double)s2);
 #pragma unroll
       for (int k = 0; k < V; k++) { atomicAdd(&accc[c + k], dg[k]); atomicAdd(&accc[C + c + k], db[k]); }
     }
   }
   __syncthreads();
-  for (int i = tid; i < 2 * G; i += NT) atomicAdd(&gsums[(long)b * G * 2 + i], (double)accg[i]);
+  for (int i = tid; i < 2 * G; i += NT) atomicAdd(&gsums[(long)b * G * 2 + i], accg[i]);
   // per-channel sums go to one of NSLOT partial buffers (thousands of blocks hammering 2C addresses serialise in L2)
   if (slots) {
     float* sl = slots + (size_t)((blockIdx.y * gridDim.x + blockIdx.x) % GN_NSLOT) * 2 * C;
@@ -370,12 +370,14 @@ __global__ __launch_bounds__(NTB) void gn_fwd_resident_kernel(const T* __restric
                                                               const float* __restrict__ beta, T* __restrict__ y, long ldy,
                                                               T* __restrict__ xr, long ldxr, float* __restrict__ stats,
                                                               int L, int C, int G, float eps, int silu, int resample, int CC) {
-  __shared__ float red[2 * RES_MAXG];
+  // fp64 LDS accumulators: the order in which the waves arrive no longer shows in the fp32 mean / rstd, so the forward (and with it
+  // seeded sampling) is reproducible run to run -- fp32 atomics differed in the last bit and bf16 roundings downstream flipped
+  __shared__ double red[2 * RES_MAXG];
   GN_TSTAMP(0);
   const int b = blockIdx.y, cpg = C / G;
   const ResMap m = resmap(CC, C, cpg);
   const bool pair = resample == 1;
-  if (threadIdx.x < 2 * RES_MAXG) red[threadIdx.x] = 0.f;
+  if (threadIdx.x < 2 * RES_MAXG) red[threadIdx.x] = 0.0;
   typename Vec<T, 4>::type raw[RPT];
   const T* xb = x + (long)b * L * ldx + m.c;
   if (m.act) {
@@ -395,13 +397,13 @@ __global__ __launch_bounds__(NTB) void gn_fwd_resident_kernel(const T* __restric
     for (int k = 0; k < RPT; k++) {
       if (res_row(k, m.ty, m.TY, pair) < L) { float v[4]; unpack4<T>(raw[k], v); s += (v[0] + v[1]) + (v[2] + v[3]); }
     }
-    atomicAdd(&red[m.gl], s);
+    atomicAdd(&red[m.gl], (double)s);
   }
   __syncthreads();
   GN_TSTAMP(3);
   float mean = 0.f, rstd = 0.f;
   if (m.act) {
-    mean = red[m.gl] * inv_n;
+    mean = (float)(red[m.gl] * (double)inv_n);
     float q = 0.f;
 #pragma unroll
     for (int k = 0; k < RPT; k++) {
@@ -411,12 +413,12 @@ __global__ __launch_bounds__(NTB) void gn_fwd_resident_kernel(const T* __restric
         for (int j = 0; j < 4; j++) { const float d = v[j] - mean; q += d * d; }
       }
     }
-    atomicAdd(&red[RES_MAXG + m.gl], q);
+    atomicAdd(&red[RES_MAXG + m.gl], (double)q);
   }
   __syncthreads();
   GN_TSTAMP(4);
   if (!m.act) return;
-  rstd = rsqrtf(red[RES_MAXG + m.gl] * inv_n + eps);
+  rstd = rsqrtf((float)(red[RES_MAXG + m.gl] * (double)inv_n) + eps);
   if (m.ty == 0 && (m.tx * 4) % cpg == 0) { float* st = stats + ((long)b * G + m.c / cpg) * 2; st[0] = mean; st[1] = rstd; }
   float ga[4], be[4];
 #pragma unroll
@@ -472,12 +474,14 @@ __global__ __launch_bounds__(NTB) void gn_bwd_resident_kernel(const T* __restric
                                                               const T* __restrict__ dxr, long lddxr, float* __restrict__ slots,
                                                               float* __restrict__ colsum_ps, long ldps,
                                                               int L, int C, int G, int silu, int resample, int CC) {
-  __shared__ float redg[2 * RES_MAXG];
-  __shared__ float redc[3 * RES_MAXC];
+  // fp64 LDS accumulators (as in the forward): dx must not depend on the order in which the waves arrive -- an fp32 one-ulp
+  // difference in the group sums flips bf16 roundings of dx and the flips compound through the remaining layers
+  __shared__ double redg[2 * RES_MAXG];
+  __shared__ double redc[3 * RES_MAXC];
   GN_TSTAMP(0);
   const int b = blockIdx.y, cpg = C / G;
   const ResMap m = resmap(CC, C, cpg);
-  for (int i = threadIdx.x; i < 2 * RES_MAXG + 3 * RES_MAXC; i += NTB) { if (i < 2 * RES_MAXG) redg[i] = 0.f; else redc[i - 2 * RES_MAXG] = 0.f; }
+  for (int i = threadIdx.x; i < 2 * RES_MAXG + 3 * RES_MAXC; i += NTB) { if (i < 2 * RES_MAXG) redg[i] = 0.0; else redc[i - 2 * RES_MAXG] = 0.0; }
   typename Vec<T, 4>::type raw[RPT];
   float d[RPT][4];
   // wave-uniform per-sample bases + 32-bit byte offsets (scalar-base addressing: one VALU add per access)
@@ -533,13 +537,13 @@ __global__ __launch_bounds__(NTB) void gn_bwd_resident_kernel(const T* __restric
       }
     }
 #pragma unroll
-    for (int j = 0; j < 4; j++) { atomicAdd(&redc[m.tx * 4 + j], dg[j]); atomicAdd(&redc[RES_MAXC + m.tx * 4 + j], db[j]); }
+    for (int j = 0; j < 4; j++) { atomicAdd(&redc[m.tx * 4 + j], (double)dg[j]); atomicAdd(&redc[RES_MAXC + m.tx * 4 + j], (double)db[j]); }
   }
   __syncthreads();
   if (m.act && m.ty == 0) {
-    float p1 = 0.f, p2 = 0.f;
+    double p1 = 0.0, p2 = 0.0;
 #pragma unroll
-    for (int j = 0; j < 4; j++) { p1 = fmaf(ga[j], redc[RES_MAXC + m.tx * 4 + j], p1); p2 = fmaf(ga[j], redc[m.tx * 4 + j], p2); }
+    for (int j = 0; j < 4; j++) { p1 += (double)ga[j] * redc[RES_MAXC + m.tx * 4 + j]; p2 += (double)ga[j] * redc[m.tx * 4 + j]; }
     atomicAdd(&redg[2 * m.gl], p1); atomicAdd(&redg[2 * m.gl + 1], p2);
   }
   GN_TSTAMP(3);
@@ -547,11 +551,11 @@ __global__ __launch_bounds__(NTB) void gn_bwd_resident_kernel(const T* __restric
   GN_TSTAMP(4);
   if (m.act) {
     const float inv_n = 1.0f / ((float)cpg * (float)L);
-    const float m1 = redg[2 * m.gl] * inv_n, m2 = redg[2 * m.gl + 1] * inv_n;
+    const float m1 = (float)(redg[2 * m.gl] * (double)inv_n), m2 = (float)(redg[2 * m.gl + 1] * (double)inv_n);
     if (slots && m.ty == 0) {
       float* sl = slots + (size_t)(b % GN_NSLOT) * 2 * C;
 #pragma unroll
-      for (int j = 0; j < 4; j++) { atomicAdd(&sl[m.c + j], redc[m.tx * 4 + j]); atomicAdd(&sl[C + m.c + j], redc[RES_MAXC + m.tx * 4 + j]); }
+      for (int j = 0; j < 4; j++) { atomicAdd(&sl[m.c + j], (float)redc[m.tx * 4 + j]); atomicAdd(&sl[C + m.c + j], (float)redc[RES_MAXC + m.tx * 4 + j]); }
     }
     // dx = rstd * (dz*gamma - m1 - xhat*m2) with the per-thread constants folded
     const float rm1 = rstd * m1, rm2 = rstd * m2;
@@ -585,7 +589,7 @@ __global__ __launch_bounds__(NTB) void gn_bwd_resident_kernel(const T* __restric
     }
     if (colsum_ps) {
 #pragma unroll
-      for (int j = 0; j < 4; j++) atomicAdd(&redc[2 * RES_MAXC + m.tx * 4 + j], cs[j]);
+      for (int j = 0; j < 4; j++) atomicAdd(&redc[2 * RES_MAXC + m.tx * 4 + j], (double)cs[j]);
     }
   }
   GN_TSTAMP(5);
@@ -593,7 +597,7 @@ __global__ __launch_bounds__(NTB) void gn_bwd_resident_kernel(const T* __restric
     __syncthreads();
     if (m.act && m.ty == 0) {
 #pragma unroll
-      for (int j = 0; j < 4; j++) colsum_ps[(long)b * ldps + m.c + j] = redc[2 * RES_MAXC + m.tx * 4 + j];
+      for (int j = 0; j < 4; j++) colsum_ps[(long)b * ldps + m.c + j] = (float)redc[2 * RES_MAXC + m.tx * 4 + j];
     }
   }
 }
