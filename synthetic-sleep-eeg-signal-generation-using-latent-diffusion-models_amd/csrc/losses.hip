@@ -133,9 +133,9 @@ template <typename T, int MODE>
 __global__ __launch_bounds__(NT) void bn_reduce4_kernel(const T* __restrict__ x, long ldx, const float* __restrict__ gamma, const float* __restrict__ beta,
                                                         const float* __restrict__ stats, const T* __restrict__ dy, long lddy,
                                                         void* __restrict__ parts, long rows, int C, long rows_per_block, float slope) {
-  __shared__ float red[2 * 1024];
+  __shared__ double red[2 * 1024];   // fp64 LDS atomics: order-independent sums, and faster than contended fp32 LDS atomics (see norm.hip)
   const BnMap m = bnmap(C);
-  for (int i = threadIdx.x; i < 2 * C; i += NT) red[i] = 0.f;
+  for (int i = threadIdx.x; i < 2 * C; i += NT) red[i] = 0.0;
   __syncthreads();
   const long l0 = (long)blockIdx.x * rows_per_block, l1 = min(rows, l0 + rows_per_block);
   if (m.act) {
@@ -164,13 +164,13 @@ __global__ __launch_bounds__(NT) void bn_reduce4_kernel(const T* __restrict__ x,
         }
       }
 #pragma unroll
-      for (int j = 0; j < 4; j++) { atomicAdd(&red[2 * (c + j)], s1[j]); atomicAdd(&red[2 * (c + j) + 1], s2[j]); }
+      for (int j = 0; j < 4; j++) { atomicAdd(&red[2 * (c + j)], (double)s1[j]); atomicAdd(&red[2 * (c + j) + 1], (double)s2[j]); }
     }
   }
   __syncthreads();
   // written partials + a folding pass: a thousand blocks adding atomically into the same 2C addresses serialise in L2
   float* part = (float*)parts + (size_t)blockIdx.x * 2 * C;
-  for (int i = threadIdx.x; i < 2 * C; i += NT) part[i] = red[i];
+  for (int i = threadIdx.x; i < 2 * C; i += NT) part[i] = (float)red[i];
 }
 __global__ void bn_fold_kernel(const float* __restrict__ parts, int nparts, int n2c, double* __restrict__ sums) {
   __shared__ double red[NT];

@@ -215,11 +215,11 @@ __global__ __launch_bounds__(NT) void gn_bwd_reduce_kernel(const T* __restrict__
                                                            float* __restrict__ slots,
                                                            int L, int C, int G, int silu, int rows_per_block) {
   __shared__ double accg[2 * MAXG_LDS];  // group sums feed dx: fp64 so that the thread arrival order does not show (see gn_stats_kernel)
-  __shared__ float accc[2 * MAXG_LDS];
+  __shared__ double accc[2 * MAXG_LDS];
   const int b = blockIdx.y, tid = threadIdx.x;
   const int cpg = C / G;
   for (int i = tid; i < 2 * G; i += NT) accg[i] = 0.0;
-  for (int i = tid; i < 2 * C; i += NT) accc[i] = 0.f;
+  for (int i = tid; i < 2 * C; i += NT) accc[i] = 0.0;
   __syncthreads();
   const ColMap cm = colmap(C, V);
   const int l0 = blockIdx.x * rows_per_block, l1 = min(L, l0 + rows_per_block);
@@ -248,7 +248,7 @@ __global__ __launch_bounds__(NT) void gn_bwd_reduce_kernel(const T* __restrict__
       }
       atomicAdd(&accg[2 * g], (double)s1); atomicAdd(&accg[2 * g + 1], (double)s2);
 #pragma unroll
-      for (int k = 0; k < V; k++) { atomicAdd(&accc[c + k], dg[k]); atomicAdd(&accc[C + c + k], db[k]); }
+      for (int k = 0; k < V; k++) { atomicAdd(&accc[c + k], (double)dg[k]); atomicAdd(&accc[C + c + k], (double)db[k]); }
     }
   }
   __syncthreads();
@@ -256,7 +256,7 @@ __global__ __launch_bounds__(NT) void gn_bwd_reduce_kernel(const T* __restrict__
   // per-channel sums go to one of NSLOT partial buffers (thousands of blocks hammering 2C addresses serialise in L2)
   if (slots) {
     float* sl = slots + (size_t)((blockIdx.y * gridDim.x + blockIdx.x) % GN_NSLOT) * 2 * C;
-    for (int i = tid; i < 2 * C; i += NT) atomicAdd(&sl[i], accc[i]);
+    for (int i = tid; i < 2 * C; i += NT) atomicAdd(&sl[i], (float)accc[i]);
   }
 }
 
