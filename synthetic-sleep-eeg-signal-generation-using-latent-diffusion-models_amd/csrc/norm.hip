@@ -683,8 +683,9 @@ int gn_bwd_t(eegldm_ctx* ctx, const void* x, long ldx, const float* gamma, const
     int rpt = 0; int cc = off ? 0 : resident_chunk(L, C, G, 0, sizeof(T) == 2 ? 12 : 8, &rpt);
     // measured (tools/debug/gn_bench.py): the one-pass kernel wins while its blocks fit two rounds of one block per CU
     // (1024 blocks: 112 us one-pass vs 117-120 us split on the 100 MB tensors; 2048 blocks of 96-channel chunks lose)
-    static const long bwd_bpc = getenv("EEGLDM_GN_BWD_BLOCKS_PER_CU") ? atol(getenv("EEGLDM_GN_BWD_BLOCKS_PER_CU")) : 4;
-    if (cc && (cc * (int)sizeof(T) < 128 || (long)(C / cc) * B > bwd_bpc * ctx->num_cu)) cc = 0;
+    static const long bwd_bpc = getenv("EEGLDM_GN_BWD_BLOCKS_PER_CU") ? atol(getenv("EEGLDM_GN_BWD_BLOCKS_PER_CU")) : 8;
+    static const int bwd_minrow = getenv("EEGLDM_GN_BWD_MIN_ROW_BYTES") ? atoi(getenv("EEGLDM_GN_BWD_MIN_ROW_BYTES")) : 128;
+    if (cc && (cc * (int)sizeof(T) < bwd_minrow || (long)(C / cc) * B > bwd_bpc * ctx->num_cu)) cc = 0;
     if (cc) {
       const dim3 grid(C / cc, B);
       float* slots = dgamma ? (float*)((char*)ctx->scratch + GN_SLOT_OFFSET) : nullptr;
