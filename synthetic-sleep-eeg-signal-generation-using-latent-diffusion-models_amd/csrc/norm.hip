@@ -738,6 +738,8 @@ template <> struct Chunk8<bf16_t> {
     v[0] = __uint_as_float(r.x << 16); v[1] = __uint_as_float(r.x & 0xffff0000u); v[2] = __uint_as_float(r.y << 16); v[3] = __uint_as_float(r.y & 0xffff0000u);
     v[4] = __uint_as_float(r.z << 16); v[5] = __uint_as_float(r.z & 0xffff0000u); v[6] = __uint_as_float(r.w << 16); v[7] = __uint_as_float(r.w & 0xffff0000u);
   }
+  // opaque to the optimiser: keeps the packed chunk (not its eight unpacked floats) live between two passes
+  static __device__ __forceinline__ void touch(raw_t& r) { asm volatile("" : "+v"(r.x), "+v"(r.y), "+v"(r.z), "+v"(r.w)); }
   static __device__ __forceinline__ void store(bf16_t* p, const float v[8]) {
     uint4 t; t.x = pack_bf16x2(v[0], v[1]); t.y = pack_bf16x2(v[2], v[3]); t.z = pack_bf16x2(v[4], v[5]); t.w = pack_bf16x2(v[6], v[7]);
     *(uint4*)p = t;
@@ -749,12 +751,13 @@ template <> struct Chunk8<float> {
   static __device__ __forceinline__ void unpack(const raw_t& r, float v[8]) {
     v[0] = r.a.x; v[1] = r.a.y; v[2] = r.a.z; v[3] = r.a.w; v[4] = r.b.x; v[5] = r.b.y; v[6] = r.b.z; v[7] = r.b.w;
   }
+  static __device__ __forceinline__ void touch(raw_t&) {}
   static __device__ __forceinline__ void store(float* p, const float v[8]) {
     *(float4*)p = make_float4(v[0], v[1], v[2], v[3]); *(float4*)(p + 4) = make_float4(v[4], v[5], v[6], v[7]);
   }
 };
 // sum of K per-thread values over the block (4 waves): result in every thread
-template <int K> __device__ __forceinline__ void flat_block_sum(float (&v)[K], float* sm) {
+template <int K, int NW = 4> __device__ __forceinline__ void flat_block_sum(float (&v)[K], float* sm) {
 #pragma unroll
   for (int k = 0; k < K; k++)
 #pragma unroll
@@ -766,7 +769,12 @@ template <int K> __device__ __forceinline__ void flat_block_sum(float (&v)[K], f
   }
   __syncthreads();
 #pragma unroll
-  for (int k = 0; k < K; k++) v[k] = (sm[k] + sm[K + k]) + (sm[2 * K + k] + sm[3 * K + k]);
+  for (int k = 0; k < K; k++) {
+    float t = 0.f;
+#pragma unroll
+    for (int w = 0; w < NW; w += 4) t += (sm[w * K + k] + sm[(w + 1) * K + k]) + (sm[(w + 2) * K + k] + sm[(w + 3) * K + k]);
+    v[k] = t;
+  }
   __syncthreads();
 }
 
@@ -890,6 +898,77 @@ __global__ __launch_bounds__(FLAT_NT) void gn_flat_bwd_kernel(const T* __restric
   }
 }
 
+// Same idea for the [32,32,64] AutoencoderKL (frozen encoder in front of every LDM step, decoder after sampling): G = 1, C a
+// multiple of 8 that divides 8192, a sample of up to 98 304 contiguous elements resident in 1024 threads x 12 chunks.  With
+// 1024 * 8 a multiple of C every thread always sees the same 8 channels.  1R + 1W instead of the split kernels' 2R + 1W.
+constexpr int WIDE_NT = 1024;
+template <typename T, int MAXCH>
+__global__ __launch_bounds__(WIDE_NT) void gn_flat_fwd_wide_kernel(const T* __restrict__ x, const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                                   T* __restrict__ y, float* __restrict__ stats, int n, int C, float eps, int silu) {
+  __shared__ float sm[WIDE_NT / 64];
+  const int b = blockIdx.x, tid = threadIdx.x, nch = n >> 3;
+  const T* xs = x + (long)b * n; T* ys = y + (long)b * n;
+  typename Chunk8<T>::raw_t raw[MAXCH];
+#pragma unroll
+  for (int k = 0; k < MAXCH; k++) { const int ci = k * WIDE_NT + tid; if (ci < nch) raw[k] = Chunk8<T>::load(xs + (long)ci * 8); }
+  float s[1] = {0.f};
+#pragma unroll
+  for (int k = 0; k < MAXCH; k++) {
+    if (k * WIDE_NT + tid < nch) {
+      float v[8]; Chunk8<T>::unpack(raw[k], v);
+      s[0] += ((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7]));
+    }
+  }
+  flat_block_sum<1, WIDE_NT / 64>(s, sm);
+#pragma unroll
+  for (int k = 0; k < MAXCH; k++) Chunk8<T>::touch(raw[k]);
+  const float inv_n = 1.0f / (float)n, mean = s[0] * inv_n;
+  float q[1] = {0.f};
+#pragma unroll
+  for (int k = 0; k < MAXCH; k++) {
+    if (k * WIDE_NT + tid < nch) {
+      float v[8]; Chunk8<T>::unpack(raw[k], v);
+#pragma unroll
+      for (int j = 0; j < 8; j++) { const float d = v[j] - mean; q[0] = fmaf(d, d, q[0]); }
+    }
+  }
+  flat_block_sum<1, WIDE_NT / 64>(q, sm);
+#pragma unroll
+  for (int k = 0; k < MAXCH; k++) Chunk8<T>::touch(raw[k]);
+  const float rstd = rsqrtf(q[0] * inv_n + eps);
+  if (tid == 0) { stats[2 * b] = mean; stats[2 * b + 1] = rstd; }
+  const int c0 = (tid * 8) % C;
+  float ga[8], be[8];
+  { const float4 g0 = *(const float4*)(gamma + c0), g1 = *(const float4*)(gamma + c0 + 4), b0 = *(const float4*)(beta + c0), b1 = *(const float4*)(beta + c0 + 4);
+    ga[0] = g0.x; ga[1] = g0.y; ga[2] = g0.z; ga[3] = g0.w; ga[4] = g1.x; ga[5] = g1.y; ga[6] = g1.z; ga[7] = g1.w;
+    be[0] = b0.x; be[1] = b0.y; be[2] = b0.z; be[3] = b0.w; be[4] = b1.x; be[5] = b1.y; be[6] = b1.z; be[7] = b1.w; }
+  const float nmr = -mean * rstd;
+#pragma unroll
+  for (int k = 0; k < MAXCH; k++) {
+    const int ci = k * WIDE_NT + tid;
+    if (ci < nch) {
+      float v[8], o[8]; Chunk8<T>::unpack(raw[k], v);
+#pragma unroll
+      for (int j = 0; j < 8; j++) { const float z = fmaf(fmaf(v[j], rstd, nmr), ga[j], be[j]); o[j] = silu ? silu_f(z) : z; }
+      Chunk8<T>::store(ys + (long)ci * 8, o);
+    }
+  }
+}
+bool gn_flat_wide_ok(int L, int C, int G, int resample, long l0, long l1) {
+  static const bool off = getenv("EEGLDM_GN_NO_FLAT") != nullptr;
+  const long n = (long)L * C;
+  return !off && G == 1 && resample == 0 && C >= 16 && C % 8 == 0 && (WIDE_NT * 8) % C == 0 && n % 8 == 0 &&
+         n <= (long)WIDE_NT * 8 * 12 && l0 == C && l1 == C;
+}
+template <typename T>
+int gn_flat_fwd_wide(eegldm_ctx* ctx, const void* x, const float* gamma, const float* beta, void* y, float* stats, int B, int L, int C, float eps, int silu) {
+  const int n = L * C;
+  if (n <= WIDE_NT * 8 * 6) hipLaunchKernelGGL((gn_flat_fwd_wide_kernel<T, 6>), dim3(B), dim3(WIDE_NT), 0, ctx->stream, (const T*)x, gamma, beta, (T*)y, stats, n, C, eps, silu);
+  else hipLaunchKernelGGL((gn_flat_fwd_wide_kernel<T, 12>), dim3(B), dim3(WIDE_NT), 0, ctx->stream, (const T*)x, gamma, beta, (T*)y, stats, n, C, eps, silu);
+  LAUNCH_CHECK();
+  return 0;
+}
+
 bool gn_flat_ok(int L, int C, int G, int resample, long l0, long l1, long l2, long l3) {
   static const bool off = getenv("EEGLDM_GN_NO_FLAT") != nullptr;
   const long n = (long)L * C;
@@ -960,6 +1039,10 @@ extern "C" int eegldm_groupnorm_fwd(eegldm_ctx* ctx, const void* x, long ldx, co
   if (gn_flat_ok(L, C, G, resample, ldx, ldy, 0, 0)) {
     if (dtype == EEGLDM_F32) return gn_flat_fwd<float>(ctx, x, gamma, beta, y, stats, B, L, C, eps, fuse_silu);
     if (dtype == EEGLDM_BF16) return gn_flat_fwd<bf16_t>(ctx, x, gamma, beta, y, stats, B, L, C, eps, fuse_silu);
+  }
+  if (gn_flat_wide_ok(L, C, G, resample, ldx, ldy) && (dtype != EEGLDM_F32 || (long)L * C <= (long)WIDE_NT * 8 * 6)) {   // fp32: 12 chunks of 8 floats would spill
+    if (dtype == EEGLDM_F32) return gn_flat_fwd_wide<float>(ctx, x, gamma, beta, y, stats, B, L, C, eps, fuse_silu);
+    if (dtype == EEGLDM_BF16) return gn_flat_fwd_wide<bf16_t>(ctx, x, gamma, beta, y, stats, B, L, C, eps, fuse_silu);
   }
   const bool v4 = vec4_ok(C, G, ldx, ldy, xr ? ldxr : 0, 0);
   if (dtype == EEGLDM_F32) {

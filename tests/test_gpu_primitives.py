@@ -99,6 +99,7 @@ GN_CASES = [  # B, L, C, G, silu, resample
     (2, 64, 32, 32, 1, 1), (2, 32, 64, 32, 1, 2), (2, 128, 32, 1, 1, 0), (2, 128, 2, 1, 1, 0), (2, 64, 4, 1, 0, 0),
     (2, 3072, 32, 1, 1, 0),
     # thin AutoencoderKL layers (G = 1, C <= 8): one-launch flat kernels, small (3 chunks/thread) and large (12) variants
+    (2, 1536, 32, 1, 1, 0), (3, 768, 64, 1, 0, 0), (2, 100, 16, 1, 1, 0),      # [32,32,64] AutoencoderKL: wide flat forward (1024 threads)
     (4, 3072, 2, 1, 1, 0), (3, 768, 4, 1, 1, 0), (2, 96, 8, 1, 1, 0), (2, 40, 1, 1, 1, 0), (2, 3072, 8, 1, 0, 0), (2, 1000, 4, 1, 1, 0),
 ]
 
