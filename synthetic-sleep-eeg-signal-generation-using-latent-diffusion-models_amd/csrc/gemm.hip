@@ -228,10 +228,21 @@ __global__ __launch_bounds__((WMT == 3 ? 256 : 128 * WMT), 2) void gemm_kernel(c
   // K range of this block
   int kbeg = 0, kend = p.K;
   if (p.splitk > 1) {
-    int per = (p.K + p.splitk - 1) / p.splitk;
-    per = (per + C::KSTAGE - 1) / C::KSTAGE * C::KSTAGE;
-    kbeg = ksplit * per;
-    kend = min(p.K, kbeg + per);
+    if (p.k_skew > 0.f) {
+      // Skewed split: with equal chunks every block of the single round finishes at the same moment and the chip then waits for
+      // all their fp32 atomics to drain (24.6 k per block, ~370 G/s chip-wide: 34 of 105 us for 512x512x49152).  Chunk lengths
+      // that grow linearly with the split index spread the finish times, so early blocks' atomics drain under the others' K loops.
+      const int S = (p.K + C::KSTAGE - 1) / C::KSTAGE;
+      const float sk = p.k_skew, inv = 1.0f / (float)p.splitk;
+      auto bnd = [&](int i) { const float f = (float)i * inv; return i >= p.splitk ? S : (int)((float)S * ((1.0f - sk) * f + sk * f * f) + 0.5f); };
+      kbeg = bnd(ksplit) * C::KSTAGE;
+      kend = min(p.K, bnd(ksplit + 1) * C::KSTAGE);
+    } else {
+      int per = (p.K + p.splitk - 1) / p.splitk;
+      per = (per + C::KSTAGE - 1) / C::KSTAGE * C::KSTAGE;
+      kbeg = ksplit * per;
+      kend = min(p.K, kbeg + per);
+    }
     if (kbeg >= kend) return;
   }
   const int nstages = (kend - kbeg + C::KSTAGE - 1) / C::KSTAGE;
@@ -1016,6 +1027,19 @@ int gemm_launch(eegldm_ctx* ctx, const GemmArgs& a_in) {
     rec.M = a.M; rec.N = a.N; rec.K = a.K; rec.taps = a.taps * a.ztaps; rec.splitk = a.splitk;
     HIP_TRY(hipEventCreate(&rec.a)); HIP_TRY(hipEventCreate(&rec.b));
     HIP_TRY(hipEventRecord(rec.a, ctx->stream));
+  }
+  // skewed K chunks for the atomic split-K epilogue (see gemm_kernel); the workspace path writes plain stores and keeps equal chunks.
+  // The atomics per block are constant (3 x 128 x 64), so the skew that pays shrinks with the stages per block (measured, B=256:
+  // 12 or 24 stages per block -11 % at 0.5; 48 stages -3 % at 0.25; 73+ stages: any skew loses) -> (66 - stages) / 84, clamped.
+  static const float wgrad_skew = getenv("EEGLDM_WGRAD_SKEW") ? (float)atof(getenv("EEGLDM_WGRAD_SKEW")) : -1.0f;
+  a.k_skew = 0.f;
+  if (a.splitk > 1 && a.amode == GA_TR && a.atomic_out && !fold_dst && wgrad_skew != 0.f) {
+    const int kst = (a.dtype == EEGLDM_F32 ? 16 : 32) * 2;
+    const long S = ((long)a.K + kst - 1) / kst;
+    const float spb = (float)S / (float)a.splitk;
+    float sk = wgrad_skew > 0.f ? wgrad_skew : (66.0f - spb) / 84.0f;
+    sk = sk < 0.f ? 0.f : (sk > 0.5f ? 0.5f : sk);
+    if (sk > 0.f && spb * (1.0f - sk) >= 2.0f) a.k_skew = sk;      // every chunk keeps at least two stages
   }
   int rc;
   if (a.dtype == EEGLDM_F32) rc = launch_modes<float>(ctx, a);
