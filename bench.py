@@ -208,6 +208,40 @@ def main():
                                          "config": "config_ldm.yaml UNet, DDIM-50 (scaled-linear 0.0015-0.0205, eta 0), decode [32,32,64], crop to 3000",
                                          "out_shape": list(out.shape), "gflop_per_window": 695.3}
 
+        # configs[4]: config_dm.yaml pixel-space model on raw (B,1,3072) windows (global 512 over 8 GPUs = 64 per GPU): long-sequence
+        # convs and T = 768 attention (training_diffusion.py:133-158, spectral term on as in train_pure_ldm --spe spectral)
+        from eegldm.training import dm_train_step
+        from eegldm.schedulers import DDPMScheduler
+        Bd, Ld = 64, 4 * L
+        unet_dm = UNetModel(image_size=Ld, in_channels=1, out_channels=1, model_channels=128, num_res_blocks=2, attention_resolutions=[8, 4],
+                            channel_mult=[1, 2, 4], resblock_updown=True, dtype=dtype, device=local)
+        gz = torch.Generator().manual_seed(9)
+        sdm = unet_dm.state_dict()
+        unet_dm.load_state_dict({k: (torch.randn(v.shape, generator=gz) * 0.02 if float(v.abs().sum()) == 0 else v.cpu()) for k, v in sdm.items()})
+        sch_dm = DDPMScheduler(num_train_timesteps=1000, schedule="linear_beta", beta_start=0.0015, beta_end=0.0195, device=local)
+        opt_dm = Adam(unet_dm, lr=1e-4)
+        xdm = xw[:Bd].contiguous()
+        ldm = torch.zeros(1, device=dev)
+
+        def dm_step(i):
+            tdm = randint(ctx, Bd, 1000, seed=31, offset=i * Bd)
+            ndm = randn(ctx, (Bd, 1, Ld), seed=32, offset=i * Bd * Ld)
+            opt_dm.zero_grad()
+            dm_train_step(unet_dm, sch_dm, xdm, ndm, tdm, spectral_weight=1e-6, spectral_loss=True, loss_out=ldm)
+            opt_dm.step()
+
+        for i in range(2):
+            dm_step(i)
+        torch.cuda.synchronize(); t1 = time.time()
+        n_dm = max(3, args.steps // 2)
+        for i in range(n_dm):
+            dm_step(2 + i)
+        torch.cuda.synchronize(); dtd = (time.time() - t1) / n_dm
+        parts["pixel_dm_train_step"] = {"windows_per_s": round(Bd / dtd, 1), "ms_per_step": round(1e3 * dtd, 3), "batch": Bd,
+                                        "config": "config_dm.yaml UNet on raw (B,1,3072) windows (T=768 attention), epsilon MSE + 1e-6 x spectral, "
+                                                  "Adam 1e-4; per-GPU batch 64 = global 512 / 8 [BASELINE configs[4]]",
+                                        "final_loss": round(float(ldm), 5), "gflop_per_window": 183.0}
+
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         cpu = cpu_baseline()
