@@ -43,7 +43,8 @@ int op_attention_bwd(eegldm_ctx*, int dtype, const void* qkv, long ldq, const vo
 // GroupNorm backward with an optional fused per-sample column sum of dx (norm.hip); *colsum_done = 1 when produced
 int op_groupnorm_bwd(eegldm_ctx*, const void* x, long ldx, const float* gamma, const float* beta, const float* stats,
                      const void* dy, long lddy, void* dx, long lddx, float* dgamma, float* dbeta, int B, int L, int C, int G,
-                     int fuse_silu, int resample, const void* dxr, long lddxr, int dtype, float* colsum_ps, long ldps, int* colsum_done);
+                     int fuse_silu, int resample, const void* dxr, long lddxr, int dtype, float* colsum_ps, long ldps, int* colsum_done,
+                     const void* dxr2 = nullptr, long lddxr2 = 0, int* dxr2_done = nullptr);   // dxr2: second, un-resampled addend [B*L][C] (skip gradient); *dxr2_done = 1 when the kernel added it
 int ew_fold_partials(eegldm_ctx*, const float* parts, int nparts, int n, float* total);
 // fused short-sequence attention (attn.hip)
 bool attn_chain_ok(int dtype, int T, int C, long ldq, long ldo);

@@ -84,7 +84,9 @@ struct NetBase {
 constexpr float GN_EPS = 1e-6f;
 
 int res_forward(NetBase* u, const ResDesc& r, const View& x, int B, int Lin, const View& out);
-int res_backward(NetBase* u, const ResDesc& r, const ResTape& t, const View& dout, const View& dx, float* demb_all);
+// extra (optional): a tensor of dx's shape to be added into dx (the UNet skip gradient); *extra_done = 1 when the last GroupNorm kernel took it
+int res_backward(NetBase* u, const ResDesc& r, const ResTape& t, const View& dout, const View& dx, float* demb_all,
+                 const View* extra = nullptr, int* extra_done = nullptr);
 int attn_forward(NetBase* u, const AttnDesc& a, const View& x, int B, int T, const View& out);
 int attn_backward(NetBase* u, const AttnDesc& a, const AttnTape& t, const View& dout, const View& dx);
 int entry_query(const NetBase* u, int i, char* name, int cap, long* offset, long* numel, int* ndim, int shape[3]);

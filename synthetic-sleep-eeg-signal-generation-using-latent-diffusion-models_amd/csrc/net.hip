@@ -58,7 +58,8 @@ int res_forward(NetBase* u, const ResDesc& r, const View& x, int B, int Lin, con
 }
 
 // dout: [B*Lout][cout]; writes dx: [B*Lin][cin]; accumulates parameter grads; demb_all gets per-sample sums
-int res_backward(NetBase* u, const ResDesc& r, const ResTape& t, const View& dout, const View& dx, float* demb_all) {
+int res_backward(NetBase* u, const ResDesc& r, const ResTape& t, const View& dout, const View& dx, float* demb_all,
+                 const View* extra, int* extra_done) {
   eegldm_ctx* ctx = u->ctx; const int dt = u->dtype; const int B = t.B, Lin = t.Lin, Lout = t.Lout;
   Arena::Mark mk = u->arena.mark();
   const bool pg = u->param_grads;
@@ -118,8 +119,10 @@ int res_backward(NetBase* u, const ResDesc& r, const ResTape& t, const View& dou
   }
   View da1; ALLOC_OR_FAIL(da1.p, u->alloc_act((long)B * Lout, r.cin)); da1.ld = r.cin;
   EEG_TRY(op_conv_dgrad(ctx, dt, dh1.p, dh1.ld, u->W(r.c1_w), da1.p, da1.ld, B, Lout, r.cin, r.cout, 3, 1, 1, 1, nullptr, 0));
-  EEG_TRY(eegldm_groupnorm_bwd(ctx, t.x.p, t.x.ld, u->P(r.gn1_w), u->P(r.gn1_b), t.st1, da1.p, da1.ld, dx.p, dx.ld, u->param_grads ? u->G(r.gn1_w) : nullptr, u->param_grads ? u->G(r.gn1_b) : nullptr,
-                               B, Lin, r.cin, r.groups, 1, r.updown, dxr.p, dxr.ld, dt));
+  if (extra_done) *extra_done = 0;
+  EEG_TRY(op_groupnorm_bwd(ctx, t.x.p, t.x.ld, u->P(r.gn1_w), u->P(r.gn1_b), t.st1, da1.p, da1.ld, dx.p, dx.ld, u->param_grads ? u->G(r.gn1_w) : nullptr, u->param_grads ? u->G(r.gn1_b) : nullptr,
+                           B, Lin, r.cin, r.groups, 1, r.updown, dxr.p, dxr.ld, dt, nullptr, 0, nullptr,
+                           extra ? extra->p : nullptr, extra ? extra->ld : 0, extra_done));
   if (pg) EEG_TRY(ctx_join(ctx));                 // the side stream's reads of dout / dh1 / tape are done before the arena is reused
   u->arena.release(mk);
   return 0;

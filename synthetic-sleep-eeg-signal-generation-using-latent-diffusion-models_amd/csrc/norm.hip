@@ -473,7 +473,8 @@ __global__ __launch_bounds__(NTB) void gn_bwd_resident_kernel(const T* __restric
                                                               const T* __restrict__ dy, long lddy, T* __restrict__ dx, long lddx,
                                                               const T* __restrict__ dxr, long lddxr, float* __restrict__ slots,
                                                               float* __restrict__ colsum_ps, long ldps,
-                                                              int L, int C, int G, int silu, int resample, int CC) {
+                                                              int L, int C, int G, int silu, int resample, int CC,
+                                                              const T* __restrict__ dxr2, long lddxr2) {
   // fp64 LDS accumulators (as in the forward): dx must not depend on the order in which the waves arrive -- an fp32 one-ulp
   // difference in the group sums flips bf16 roundings of dx and the flips compound through the remaining layers
   __shared__ double redg[2 * RES_MAXG];
@@ -566,6 +567,8 @@ __global__ __launch_bounds__(NTB) void gn_bwd_resident_kernel(const T* __restric
     char* dxs = (char*)(dx + (long)b * L * lddx);
     const char* dxrs = dxr ? (const char*)(dxr + (long)b * dy_rows(L, resample) * lddxr) : nullptr;
     const unsigned lddxb = (unsigned)lddx * (unsigned)sizeof(T), lddxrb = (unsigned)lddxr * (unsigned)sizeof(T);
+    const char* dxr2s = dxr2 ? (const char*)(dxr2 + (long)b * L * lddxr2) : nullptr;
+    const unsigned lddxr2b = (unsigned)lddxr2 * (unsigned)sizeof(T);
 #pragma unroll
     for (int k = 0; k < RPT; k++) {
       const int l = k * m.TY + m.ty;
@@ -579,6 +582,12 @@ __global__ __launch_bounds__(NTB) void gn_bwd_resident_kernel(const T* __restric
         if (dxr) {
           float e[4];
           load_dy_eff32<T>(dxrs, lddxrb, cb, l, resample, e);
+#pragma unroll
+          for (int j = 0; j < 4; j++) o[j] += e[j];
+        }
+        if (dxr2) {      // second addend at dx's own resolution (UNet skip gradient): saves a separate read-modify-write pass over dx
+          float e[4];
+          load4<T>((const T*)(dxr2s + ((unsigned)l * lddxr2b + cb)), e);
 #pragma unroll
           for (int j = 0; j < 4; j++) o[j] += e[j];
         }
@@ -676,8 +685,12 @@ int gn_fwd_t(eegldm_ctx* ctx, const void* x, long ldx, const float* gamma, const
 template <typename T, int V>
 int gn_bwd_t(eegldm_ctx* ctx, const void* x, long ldx, const float* gamma, const float* beta, const float* stats,
              const void* dy, long lddy, void* dx, long lddx, float* dgamma, float* dbeta, int B, int L, int C, int G,
-             int silu, int resample, const void* dxr, long lddxr, float* colsum_ps, long ldps, int* colsum_done) {
+             int silu, int resample, const void* dxr, long lddxr, float* colsum_ps, long ldps, int* colsum_done,
+             const void* dxr2, long lddxr2, int* dxr2_done) {
   if (colsum_done) *colsum_done = 0;
+  if (dxr2_done) *dxr2_done = 0;
+  static const bool no_dxr2 = getenv("EEGLDM_GN_NO_DXR2") != nullptr;
+  if (!dxr2_done || lddxr2 % 4 != 0 || no_dxr2) dxr2 = nullptr;      // only a caller that can fall back may hand over a second addend
   if constexpr (V == 4) {
     static const bool off = getenv("EEGLDM_GN_NO_RESIDENT") != nullptr;
     int rpt = 0; int cc = off ? 0 : resident_chunk(L, C, G, 0, sizeof(T) == 2 ? 12 : 8, &rpt);
@@ -690,7 +703,7 @@ int gn_bwd_t(eegldm_ctx* ctx, const void* x, long ldx, const float* gamma, const
       const dim3 grid(C / cc, B);
       float* slots = dgamma ? (float*)((char*)ctx->scratch + GN_SLOT_OFFSET) : nullptr;
 #define GN_BWD_RES1(R, RAW) hipLaunchKernelGGL((gn_bwd_resident_kernel<T, R, RAW>), grid, dim3(NTB), 0, ctx->stream, (const T*)x, ldx, gamma, beta, stats, \
-                                         (const T*)dy, lddy, (T*)dx, lddx, (const T*)dxr, lddxr, slots, colsum_ps, ldps, L, C, G, silu, resample, cc)
+                                         (const T*)dy, lddy, (T*)dx, lddx, (const T*)dxr, lddxr, slots, colsum_ps, ldps, L, C, G, silu, resample, cc, (const T*)dxr2, lddxr2)
       static const bool raw0 = getenv("EEGLDM_GN_NO_RAW0") == nullptr;
 #define GN_BWD_RES(R) do { if (resample == 0 && raw0) GN_BWD_RES1(R, true); else GN_BWD_RES1(R, false); } while (0)
       constexpr int RLO = sizeof(T) == 2 ? 6 : 4, RHI = sizeof(T) == 2 ? 12 : 8;
@@ -703,6 +716,7 @@ int gn_bwd_t(eegldm_ctx* ctx, const void* x, long ldx, const float* gamma, const
         LAUNCH_CHECK();
       }
       if (colsum_done && colsum_ps) *colsum_done = 1;
+      if (dxr2) *dxr2_done = 1;
       return 0;
     }
   }
@@ -1060,7 +1074,9 @@ extern "C" int eegldm_groupnorm_fwd(eegldm_ctx* ctx, const void* x, long ldx, co
 int op_groupnorm_bwd(eegldm_ctx* ctx, const void* x, long ldx, const float* gamma, const float* beta,
                      const float* stats, const void* dy, long lddy, void* dx, long lddx,
                      float* dgamma, float* dbeta, int B, int L, int C, int G, int fuse_silu,
-                     int resample, const void* dxr, long lddxr, int dtype, float* colsum_ps, long ldps, int* colsum_done) {
+                     int resample, const void* dxr, long lddxr, int dtype, float* colsum_ps, long ldps, int* colsum_done,
+                     const void* dxr2, long lddxr2, int* dxr2_done) {
+  if (dxr2_done) *dxr2_done = 0;
   EEG_TRY(gn_check(ctx, B, L, C, G, resample, ldx));
   if (gn_flat_ok(L, C, G, resample, ldx, lddy, lddx, dxr ? lddxr : 0)) {
     if (colsum_done) *colsum_done = 0;
@@ -1068,7 +1084,7 @@ int op_groupnorm_bwd(eegldm_ctx* ctx, const void* x, long ldx, const float* gamm
     if (dtype == EEGLDM_BF16) return gn_flat_bwd<bf16_t>(ctx, x, gamma, beta, stats, dy, dx, dxr, dgamma, dbeta, B, L, C, fuse_silu);
   }
   const bool v4 = vec4_ok(C, G, ldx, lddy, lddx, dxr ? lddxr : 0);
-#define GN_BWD_ARGS ctx, x, ldx, gamma, beta, stats, dy, lddy, dx, lddx, dgamma, dbeta, B, L, C, G, fuse_silu, resample, dxr, lddxr, colsum_ps, ldps, colsum_done
+#define GN_BWD_ARGS ctx, x, ldx, gamma, beta, stats, dy, lddy, dx, lddx, dgamma, dbeta, B, L, C, G, fuse_silu, resample, dxr, lddxr, colsum_ps, ldps, colsum_done, dxr2, lddxr2, dxr2_done
   if (dtype == EEGLDM_F32) return v4 ? gn_bwd_t<float, 4>(GN_BWD_ARGS) : gn_bwd_t<float, 1>(GN_BWD_ARGS);
   if (dtype == EEGLDM_BF16) return v4 ? gn_bwd_t<bf16_t, 4>(GN_BWD_ARGS) : gn_bwd_t<bf16_t, 1>(GN_BWD_ARGS);
 #undef GN_BWD_ARGS

@@ -175,7 +175,9 @@ int block_forward(eegldm_unet* u, const Block& b, View x, int B, int& L, const V
 
 // backward through a block: dout = gradient of the block output; dx_dest = where the gradient of
 // the block input goes.  Tapes are consumed from the back of u->rt / u->at.
-int block_backward(eegldm_unet* u, const Block& b, View dout, const View& dx_dest, int B, size_t& ri, size_t& ai, float* demb_all) {
+// extra (optional): added into dx_dest (skip gradient of the input path); fused into the block's last GroupNorm kernel when it can, else add_rows
+int block_backward(eegldm_unet* u, const Block& b, View dout, const View& dx_dest, int B, size_t& ri, size_t& ai, float* demb_all,
+                   const View* extra = nullptr, long extra_rows = 0) {
   for (int j = (int)b.layers.size() - 1; j >= 0; j--) {
     const Layer& l = b.layers[j];
     View dx = dx_dest;
@@ -184,8 +186,10 @@ int block_backward(eegldm_unet* u, const Block& b, View dout, const View& dx_des
       const long rows = l.kind == 0 ? (long)u->rt[ri - 1].B * u->rt[ri - 1].Lin : (long)u->at[ai - 1].B * u->at[ai - 1].T;
       ALLOC_OR_FAIL(dx.p, u->alloc_act(rows, cin)); dx.ld = cin; dx.C = cin;
     }
-    if (l.kind == 0) { EEG_TRY(res_backward(u, l.r, u->rt[--ri], dout, dx, demb_all)); }
+    int fused = 0;
+    if (l.kind == 0) { EEG_TRY(res_backward(u, l.r, u->rt[--ri], dout, dx, demb_all, j == 0 ? extra : nullptr, &fused)); }
     else { EEG_TRY(attn_backward(u, l.a, u->at[--ai], dout, dx)); }
+    if (j == 0 && extra && !fused) EEG_TRY(ew_add_rows(u->ctx, dx.p, dx.ld, extra->p, extra->ld, extra_rows, extra->C, u->dtype));
     dout = dx;
   }
   return 0;
@@ -338,19 +342,19 @@ extern "C" int eegldm_unet_backward(eegldm_unet* u, const float* dy, float* dx_o
   }
   // ---- middle
   { View g; ALLOC_OR_FAIL(g.p, u->alloc_act((long)B * in_len[n_in - 1], in_ch[n_in - 1])); g.ld = in_ch[n_in - 1]; g.C = g.ld;
-    EEG_TRY(block_backward(u, u->mid, dout, g, B, ri, ai, demb_all));
+    // (the skip gradient of the deepest input block joins here; each input block's backward then adds the next one)
+    EEG_TRY(block_backward(u, u->mid, dout, g, B, ri, ai, demb_all, n_in > 1 ? &dskip[n_in - 1] : nullptr, (long)B * in_len[n_in - 1]));
     dout = g; }
   // gradients of out / output_blocks / middle_block are complete (in stream order): the host may start reducing them
   // across ranks while the input blocks' backward runs
   if (u->grad_hook) u->grad_hook(u->grad_hook_user, u->off_mid_begin, u->nparams - u->off_mid_begin);
   // ---- input blocks, reversed: gradient of block i's output = consumer's dx + skip gradient
   for (int i = n_in - 1; i >= 1; i--) {
-    EEG_TRY(ew_add_rows(ctx, dout.p, dout.ld, dskip[i].p, dskip[i].ld, (long)B * in_len[i], in_ch[i], dt));
     View g; ALLOC_OR_FAIL(g.p, u->alloc_act((long)B * in_len[i - 1], in_ch[i - 1])); g.ld = in_ch[i - 1]; g.C = g.ld;
-    EEG_TRY(block_backward(u, u->in_blocks[i], dout, g, B, ri, ai, demb_all));
+    EEG_TRY(block_backward(u, u->in_blocks[i], dout, g, B, ri, ai, demb_all, &dskip[i - 1], (long)B * in_len[i - 1]));
     dout = g;
   }
-  EEG_TRY(ew_add_rows(ctx, dout.p, dout.ld, dskip[0].p, dskip[0].ld, (long)B * L, mc, dt));
+  if (n_in == 1) EEG_TRY(ew_add_rows(ctx, dout.p, dout.ld, dskip[0].p, dskip[0].ld, (long)B * L, mc, dt));
   // ---- conv_in
   EEG_TRY(op_conv_wgrad(ctx, dt, u->x0.p, u->x0.ld, dout.p, dout.ld, u->G(u->off_cin_w), u->G(u->off_cin_b), B, L, cin, mc, 3, 1, 1, 1));
   if (dx_out) {
