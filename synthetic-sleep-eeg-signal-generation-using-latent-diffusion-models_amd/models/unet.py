@@ -134,12 +134,28 @@ class UNetModel:
 
     # ------------------------------------------------------------------ compute
     def forward(self, x, timesteps=None, context=None, y=None, **kwargs):
-        assert timesteps is not None, "need to implement no-timestep usage"
+        assert timesteps is not None, "need to implement no-timestep usage"      # unet.py:520-521 (same assertion text)
         x = x.to(self.device, torch.float32).contiguous()
         t = timesteps.to(self.device, torch.int64).contiguous()
+        if x.dim() != 3:
+            raise ValueError(f"UNetModel expects x of shape (B, {self.in_channels}, L), got {tuple(x.shape)}")
         B, Cc, L = x.shape
-        assert Cc == self.in_channels and t.shape == (B,)
+        if Cc != self.in_channels:
+            raise ValueError(f"UNetModel was built with in_channels={self.in_channels}, got x with {Cc} channels")
+        if tuple(t.shape) != (B,):
+            raise ValueError(f"timesteps must have shape ({B},) to match the batch, got {tuple(t.shape)}")
         out = torch.empty(B, self.out_channels, L, device=self.device, dtype=torch.float32)
+        if B == 0:
+            return out                                   # empty batch in, empty batch out (as the reference modules do)
+        levels = len(self.channel_mult)
+        if L % (1 << (levels - 1)) != 0:
+            raise ValueError(f"L={L} must be divisible by {1 << (levels - 1)} (one halving per resolution level; the reference's "
+                             "length-mismatch crop at unet.py:544-551 is not implemented)")
+        vec = 4 if self.dtype == F32 else 8              # contiguous-dimension granularity of the MFMA operand loads
+        for lvl in range(levels):
+            if (1 << lvl) in self.attention_resolutions and (L >> lvl) % vec != 0:
+                raise ValueError(f"attention at downsample rate {1 << lvl} sees T={L >> lvl} positions; this engine needs T to be a "
+                                 f"multiple of {vec} ({'fp32' if vec == 4 else 'bf16'}): use L divisible by {vec << lvl}")
         check(lib.eegldm_unet_forward(self.h, ptr(x), ptr(t), ptr(out), B, L, 1 if self.training else 0))
         return out
 

@@ -109,3 +109,25 @@ def test_grad_hook_reports_final_tail_slice():
     scale = ref.abs().max()
     assert (snap["tail"] - ref[off:off + n]).abs().max() <= 1e-4 * scale
     assert (net.flat_grad - ref).abs().max() <= 1e-4 * scale
+
+
+def test_unet_edge_inputs():
+    """Ragged / degenerate inputs: single window and empty batch work, shapes the engine cannot tile fail before any launch
+    with a message that names the constraint (the reference would run any L through its crop hack, unet.py:544-551)."""
+    from eegldm.models import UNetModel
+    net = UNetModel(image_size=64, in_channels=1, out_channels=1, model_channels=32, num_res_blocks=1, attention_resolutions=[2],
+                    channel_mult=[1, 2], resblock_updown=True, dtype="bfloat16")
+    y1 = net(torch.randn(1, 1, 64), timesteps=torch.tensor([7]))
+    assert y1.shape == (1, 1, 64) and torch.isfinite(y1).all()
+    y0 = net(torch.randn(0, 1, 64), timesteps=torch.zeros(0, dtype=torch.int64))
+    assert y0.shape == (0, 1, 64)
+    y96 = net(torch.randn(2, 1, 96), timesteps=torch.tensor([1, 999]))      # any L with T = L/2 a multiple of 8
+    assert y96.shape == (2, 1, 96) and torch.isfinite(y96).all()
+    with pytest.raises(ValueError, match="divisible by 2"):
+        net(torch.randn(2, 1, 63), timesteps=torch.tensor([1, 2]))
+    with pytest.raises(ValueError, match="multiple of 8"):
+        net(torch.randn(2, 1, 72), timesteps=torch.tensor([1, 2]))
+    with pytest.raises(ValueError, match="timesteps must have shape"):
+        net(torch.randn(2, 1, 64), timesteps=torch.tensor([5]))
+    with pytest.raises(ValueError, match="in_channels=1"):
+        net(torch.randn(2, 2, 64), timesteps=torch.tensor([5, 6]))
