@@ -99,9 +99,21 @@ class AutoencoderKL(_Flat):
     def _x(self, x):
         return x.to(self.device, torch.float32).contiguous()
 
+    def _win(self, x, channels, latent=False):
+        """Validated (B, channels, L) input on the device; L must survive the strided convolutions (a multiple of `down`)."""
+        x = self._x(x)
+        if x.dim() != 3 or x.shape[1] != channels:
+            raise ValueError(f"AutoencoderKL expects a (B, {channels}, L) tensor here, got {tuple(x.shape)}")
+        if not latent and x.shape[2] % self.down != 0:
+            raise ValueError(f"L={x.shape[2]} must be a multiple of {self.down} (one stride-2 downsample per level but the last; "
+                             "the loader pads 3000-sample windows to 3072, dataset.py:12-19)")
+        return x
+
     def encode(self, x):
-        x = self._x(x); B, _c, L = x.shape
+        x = self._win(x, self.in_channels); B, _c, L = x.shape
         mu = torch.empty(B, self.latent_channels, L // self.down, device=self.device); sg = torch.empty_like(mu)
+        if B == 0:
+            return mu, sg
         check(lib.eegldm_aekl_encode(self.h, ptr(x), None, None, ptr(mu), ptr(sg), B, L))
         return mu, sg
 
@@ -111,8 +123,10 @@ class AutoencoderKL(_Flat):
 
     def encode_stage_2_inputs(self, x, eps=None, scale_factor=None):
         """z = mu + eps * sigma (Stage1Wrapper, training.py:15-26), optionally times scale_factor (training.py:426)."""
-        x = self._x(x); B, _c, L = x.shape
+        x = self._win(x, self.in_channels); B, _c, L = x.shape
         z = torch.empty(B, self.latent_channels, L // self.down, device=self.device)
+        if B == 0:
+            return z
         if eps is None:
             eps = torch.randn(z.shape, device=self.device)
         eps = self._x(eps)
@@ -122,8 +136,10 @@ class AutoencoderKL(_Flat):
         return z
 
     def decode(self, z):
-        z = self._x(z); B, _c, Ll = z.shape
+        z = self._win(z, self.latent_channels, latent=True); B, _c, Ll = z.shape
         out = torch.empty(B, self.out_channels, Ll * self.down, device=self.device)
+        if B == 0:
+            return out
         check(lib.eegldm_aekl_decode(self.h, ptr(z), ptr(out), B, Ll))
         return out
 
@@ -134,7 +150,10 @@ class AutoencoderKL(_Flat):
         return self.decode(mu)
 
     def forward(self, x, eps=None, kl_out=None):
-        x = self._x(x); B, _c, L = x.shape
+        x = self._win(x, self.in_channels); B, _c, L = x.shape
+        if B == 0:
+            e = torch.empty(0, self.latent_channels, L // self.down, device=self.device)
+            return torch.empty(0, self.out_channels, L, device=self.device), e, e.clone()
         if eps is None:
             eps = torch.randn(B, self.latent_channels, L // self.down, device=self.device)
         eps = self._x(eps)

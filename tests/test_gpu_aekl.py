@@ -207,3 +207,20 @@ def test_fused_aekl_gan_train_step_matches_oracle(use_spectral):
         else:
             d = (gotd[k].cpu().float() - v.float()).abs()
             assert float(d.max()) < 2.5 * 5e-4 and float(d.mean()) < 0.05 * 5e-4, f"disc {k}: max {float(d.max()):.3e} mean {float(d.mean()):.3e}"
+
+
+def test_autoencoderkl_edge_inputs():
+    """Single window, empty batch, and inputs the strided encoder cannot take (loud ValueError, no launch)."""
+    from eegldm.models import AutoencoderKL
+    ae = AutoencoderKL(spatial_dims=1, in_channels=1, out_channels=1, num_channels=[32, 32, 64], latent_channels=1, num_res_blocks=2,
+                       norm_num_groups=1, attention_levels=[False, False, False], dtype="bfloat16", device=0)
+    r, mu, sg = ae(torch.randn(1, 1, 3072))
+    assert r.shape == (1, 1, 3072) and mu.shape == sg.shape == (1, 1, 768) and torch.isfinite(r).all()
+    r0, mu0, _ = ae(torch.randn(0, 1, 3072))
+    assert r0.shape == (0, 1, 3072) and mu0.shape == (0, 1, 768)
+    assert ae.decode(torch.randn(0, 1, 768)).shape == (0, 1, 3072)
+    assert ae.decode(torch.randn(2, 1, 50)).shape == (2, 1, 200)          # any latent length decodes
+    with pytest.raises(ValueError, match="multiple of 4"):
+        ae.encode(torch.randn(2, 1, 3001))
+    with pytest.raises(ValueError, match=r"\(B, 1, L\)"):
+        ae.encode(torch.randn(2, 3, 3072))
