@@ -377,6 +377,27 @@ __global__ __launch_bounds__((WMT == 3 ? 256 : 128 * WMT), 2) void gemm_kernel(c
     }
   };
 
+  // one DMA instruction of a stage (piece k < IA: A, else B): the double-buffered kernels issue the next stage's pieces BETWEEN the
+  // MFMAs of the current stage instead of as a burst after the barrier.  An LDS-DMA instruction costs the issuing wave 100-185
+  // cycles when nothing else is in flight and ~60 among MFMAs (MI355X_MICROARCH.md): the burst of 9 pieces was most of the
+  // ~1200-cycle "wait" half of every stage (stage stamps: wait 1212 + MFMA phase 1212 per stage), with the MFMA pipe idle.
+  auto issue_piece = [&](int s, int buf, int k) __attribute__((always_inline)) {      // k is a constant after unrolling
+    if (k < C::IA) {
+      const T* src = apre[k] ? apre[k] + s * astep : zeros;
+      dma16(src, lds0 + buf * C::STAGE_BYTES + (wave_u + NW * k) * 1024);
+    } else {
+      const int i = k - C::IA;
+      bool dead = false;
+      if constexpr (C::WG3) {
+        const int k0 = kbeg + s * C::KSTAGE;
+        dead = ((btop >> i) & 1) && (k0 % p.Lout == 0);
+        dead = dead || (((bbot >> i) & 1) && ((k0 + C::KSTAGE) % p.Lout == 0));
+      }
+      const T* src = (bpre[i] && !dead) ? bpre[i] + s * bstep : zeros;
+      dma16(src, lds0 + buf * C::STAGE_BYTES + C::A_ALLOC + (wave_u + NW * i) * 1024);
+    }
+  };
+
   // ---- register staging (1-tap kernels): chunk c of the linear LDS image <- 16 bytes (predicated load, zeros otherwise)
   uint4 ra[C::USE_DMA ? 1 : C::CA], rb[C::USE_DMA ? 1 : C::CB];
   auto load_stage = [&](int s) __attribute__((always_inline)) {
@@ -470,6 +491,15 @@ __global__ __launch_bounds__((WMT == 3 ? 256 : 128 * WMT), 2) void gemm_kernel(c
   // ring of NSTG stage buffers, loads run NSTG-1 stages ahead; each wave issues exactly IA+IB DMA instructions per
   // stage, so "stage s has landed" == at most (NSTG-2)*(IA+IB) of this wave's DMAs still outstanding.
   constexpr int PER = C::IA + C::IB;
+#ifdef EEG_DMA_BURST
+  constexpr bool INTERLEAVE = false;
+#else
+  constexpr bool INTERLEAVE = C::USE_DMA && (C::NSTG == 2 || C::NSTG == 3);
+#endif
+  constexpr int NMFMA_STAGE = TAPS * KSUB * C::FM * C::FN;                                  // MFMAs per wave and stage
+  constexpr int DMA_FIRST = 1;
+  constexpr int DMA_EVERY = (2 * NMFMA_STAGE / 3) / PER > 1 ? (2 * NMFMA_STAGE / 3) / PER : 1;
+  static_assert(!INTERLEAVE || DMA_FIRST + (PER - 1) * DMA_EVERY < NMFMA_STAGE, "every DMA piece needs an MFMA slot");
   if constexpr (C::USE_DMA) {
     issue_stage(0, 0);
 #pragma unroll
@@ -480,7 +510,8 @@ __global__ __launch_bounds__((WMT == 3 ? 256 : 128 * WMT), 2) void gemm_kernel(c
 #ifdef EEG_STAGE_TIMING
   unsigned long long* tlog = (unsigned long long*)p.zero_page + 512 + ((blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * 64;   // debug only
   int tl = 0;
-#define TSTAMP() do { if (tid == 0 && tl < 64) tlog[tl++] = __builtin_readcyclecounter(); } while (0)
+// slots 0..61: shader-cycle stamps (per-XCD counters); slot 62 / 63: first / latest 100 MHz wall clock (comparable across the chip)
+#define TSTAMP() do { if (tid == 0 && tl < 62) { tlog[tl++] = __builtin_readcyclecounter(); const unsigned long long wc_ = wall_clock64(); if (tl == 1) tlog[62] = wc_; tlog[63] = wc_; } } while (0)
 #else
 #define TSTAMP() do {} while (0)
 #endif
@@ -500,12 +531,12 @@ __global__ __launch_bounds__((WMT == 3 ? 256 : 128 * WMT), 2) void gemm_kernel(c
       else dma_wait_all();
       __builtin_amdgcn_s_barrier();
       asm volatile("" ::: "memory");
-      if (s + C::NSTG - 1 < nstages) issue_stage(s + C::NSTG - 1, (s + C::NSTG - 1) % C::NSTG);
+      if constexpr (!INTERLEAVE) { if (s + C::NSTG - 1 < nstages) issue_stage(s + C::NSTG - 1, (s + C::NSTG - 1) % C::NSTG); }
     } else {
       // vmcnt(0) + barrier: stage s has landed in buffer s&1, and every wave is done reading buffer (s+1)&1
       dma_wait_all();
       __syncthreads();
-      if (s + 1 < nstages) issue_stage(s + 1, (s + 1) & 1);
+      if constexpr (!INTERLEAVE) { if (s + 1 < nstages) issue_stage(s + 1, (s + 1) & 1); }
     }
     TSTAMP();   // after wait+barrier(+issue of the next stage)
     if (last) prefetch_epi(false);
@@ -554,6 +585,18 @@ __global__ __launch_bounds__((WMT == 3 ? 256 : 128 * WMT), 2) void gemm_kernel(c
         for (int j = 0; j < FN; j++) {
           if constexpr (AMODE == GA_TR) mma<T>(af[st & 1][i], bf[st & 1][j], acc[C::WG3 ? t : 0][i][j]);   // TN products keep the natural fragment (atomic epilogue)
           else mma<T>(bf[st & 1][j], af[st & 1][i], acc[0][i][j]);                                        // swapped: acc = (B.A^T) fragment
+          if constexpr (INTERLEAVE) {
+            // piece number (m - DMA_FIRST) / DMA_EVERY goes out after MFMA m of the stage: all pieces are issued in the first part
+            // of the MFMA sequence so that they have the rest of it (and the other block's phase) to land
+            constexpr int MPS = C::FM * FN;                    // MFMAs per step
+            const int m = st * MPS + i * FN + j;               // compile-time after unrolling
+            if (!last && m >= DMA_FIRST && (m - DMA_FIRST) % DMA_EVERY == 0 && (m - DMA_FIRST) / DMA_EVERY < PER) {
+              __builtin_amdgcn_sched_barrier(0);
+              if (C::NSTG == 2 || s + C::NSTG - 1 < nstages)      // deeper rings: the last NSTG-2 non-final stages have nothing left to fetch (wave-uniform)
+                issue_piece(s + C::NSTG - 1, (s + C::NSTG - 1) % C::NSTG, (m - DMA_FIRST) / DMA_EVERY);
+              __builtin_amdgcn_sched_barrier(0);
+            }
+          }
         }
     }
     if constexpr (C::COLSUM) {

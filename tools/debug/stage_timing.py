@@ -33,7 +33,12 @@ for (ci, co, k) in [(512, 512, 3), (128, 128, 3), (512, 512, 1)]:
     print(f"  first wait {med(pro):.0f}; per-stage wait {med(wait[:,1:]):.0f} (p90 {np.percentile(wait[:,1:],90):.0f}); per-stage MFMA phase {med(mfma):.0f} (p90 {np.percentile(mfma,90):.0f})")
     names = ["final sync", "LDS tile written", "barrier", "global reads issued", "global reads landed", "LDS read + stores issued", "stores retired"]
     for n, c in zip(names, e.T): print(f"  epilogue {n:26s} {med(c):8.0f}  (p90 {np.percentile(c,90):.0f})")
-    print(f"  block total {med(t[:,2*nst+8]-t[:,0]):.0f}")
+    last = np.array([row[:62][row[:62] != 0][-1] for row in t]); first = t[:, 0]
+    w0 = t[:, 62]; w1 = t[:, 63]                      # 100 MHz wall clock of the first / last stamp of each block
+    span_us = (w1.max() - w0.min()) / 100.0
+    rel = np.sort(w0 - w0.min()) / 100.0
+    endrel = np.sort(w1 - w0.min()) / 100.0
+    print(f"  block duration median {med(last - first):.0f} cycles = {med(w1 - w0)/100.0:.1f} us; kernel span {span_us:.1f} us; block starts p10/p50/p90/max {rel[len(rel)//10]:.1f}/{rel[len(rel)//2]:.1f}/{rel[9*len(rel)//10]:.1f}/{rel[-1]:.1f} us; first block end {endrel[0]:.1f} us")
 
 # weight-gradient kernels (fused 3-tap TN, split-K, direct register atomics)
 for (ci, co, L) in [(128, 128, 768), (256, 256, 384), (512, 512, 192)]:
@@ -48,7 +53,7 @@ for (ci, co, L) in [(128, 128, 768), (256, 256, 384), (512, 512, 192)]:
         check(lib.eegldm_conv1d_bwd_weight(ctx.h, ptr(x), ci, ptr(dy), co, ptr(dw), None, B, L, ci, co, 3, 1, 1, 1, 1))
         lib.eegldm_debug_read_tlog(ctx.h, buf.ctypes.data_as(C.c_void_p), C.c_long(buf.size))
     t = buf.reshape(nblk, 64).astype(np.int64)
-    cnt = (t != 0).sum(axis=1)
+    cnt = (t[:, :62] != 0).sum(axis=1)
     n = int(np.median(cnt))
     t = t[cnt == n]
     d = np.diff(t[:, :n], axis=1)
