@@ -498,7 +498,11 @@ __global__ __launch_bounds__((WMT == 3 ? 256 : 128 * WMT), 2) void gemm_kernel(c
 #endif
   constexpr int NMFMA_STAGE = TAPS * KSUB * C::FM * C::FN;                                  // MFMAs per wave and stage
   constexpr int DMA_FIRST = 1;
-  constexpr int DMA_EVERY = (2 * NMFMA_STAGE / 3) / PER > 1 ? (2 * NMFMA_STAGE / 3) / PER : 1;
+#ifndef EEG_DMA_SPAN_NUM
+#define EEG_DMA_SPAN_NUM 2
+#define EEG_DMA_SPAN_DEN 3
+#endif
+  constexpr int DMA_EVERY = (EEG_DMA_SPAN_NUM * NMFMA_STAGE / EEG_DMA_SPAN_DEN) / PER > 1 ? (EEG_DMA_SPAN_NUM * NMFMA_STAGE / EEG_DMA_SPAN_DEN) / PER : 1;
   static_assert(!INTERLEAVE || DMA_FIRST + (PER - 1) * DMA_EVERY < NMFMA_STAGE, "every DMA piece needs an MFMA slot");
   if constexpr (C::USE_DMA) {
     issue_stage(0, 0);
