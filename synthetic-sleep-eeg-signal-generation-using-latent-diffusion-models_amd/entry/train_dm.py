@@ -32,7 +32,7 @@ def main(args):
     torch.cuda.set_device(local)
     config = load_config(args.config_file)
     torch.manual_seed(config.train.seed)
-    run_dir, _resume = setup_run_dir(config, args)
+    run_dir, resume = setup_run_dir(config, args)
     up = dict(config.model.params.unet_config.params)
     up["in_channels"] = up["out_channels"] = 1                                  # train_pure_ldm.py:113-115
     unet = UNetModel(**up, dtype=args.dtype, device=local)
@@ -45,19 +45,25 @@ def main(args):
     dev, ctx = unet.device, unet.ctx
     loss = torch.zeros(1, device=dev)
     gsync = D.OverlappedGradSync(unet.flat_grad)          # no-op with one process
-    steps, t0, seen, best = 0, time.time(), 0, float("inf")
-    for epoch in range(config.train.n_epochs):
+    steps, t0, seen, best, start_epoch, gstep = 0, time.time(), 0, float("inf"), 0, 0      # gstep: steps over all invocations (RNG offsets)
+    if resume:      # continue from {run_dir}/checkpoint.pth
+        ck = torch.load(os.path.join(run_dir, "checkpoint.pth"), map_location="cpu")
+        unet.load_state_dict(ck["diffusion"]); opt.load_state_dict(ck["optimizer"])
+        start_epoch, best, gstep = int(ck["epoch"]), float(ck["best_loss"]), int(ck.get("steps", 0))
+        if rank == 0:
+            print(f"Resuming from epoch {start_epoch} (best loss {best:.5f})")
+    for epoch in range(start_epoch, config.train.n_epochs):
         unet.train()
         for batch in train:
             x = batch["eeg"].to(dev)
             B = x.shape[0]
-            t = randint(ctx, B, sched.num_train_timesteps, seed=config.train.seed + 11 + rank, offset=steps * B)
-            noise = randn(ctx, tuple(x.shape), seed=config.train.seed + 13 + rank, offset=steps * x.numel())
+            t = randint(ctx, B, sched.num_train_timesteps, seed=config.train.seed + 11 + rank, offset=gstep * B)
+            noise = randn(ctx, tuple(x.shape), seed=config.train.seed + 13 + rank, offset=gstep * x.numel())
             opt.zero_grad()
             dm_train_step(unet, sched, x, noise, t, spectral_weight=1e-6, spectral_loss=spectral, loss_out=loss, grad_sync=gsync)
             gsync.wait()
             opt.step()
-            steps += 1; seen += B * world
+            steps += 1; gstep += 1; seen += B * world
             if args.max_steps and steps >= args.max_steps:
                 break
         if rank == 0:
@@ -67,7 +73,7 @@ def main(args):
                 best = cur
                 torch.save({k: v.cpu() for k, v in unet.state_dict().items()}, os.path.join(run_dir, "best_model.pth"))
             torch.save({"epoch": epoch + 1, "diffusion": {k: v.cpu() for k, v in unet.state_dict().items()}, "optimizer": opt.state_dict(),
-                        "best_loss": best}, os.path.join(run_dir, "checkpoint.pth"))
+                        "best_loss": best, "steps": gstep}, os.path.join(run_dir, "checkpoint.pth"))
         if args.max_steps and steps >= args.max_steps:
             break
     if rank == 0:

@@ -35,7 +35,7 @@ def main(args):
     torch.cuda.set_device(local)
     config = load_config(args.config_file)
     torch.manual_seed(config.train.seed)
-    run_dir, _resume = setup_run_dir(config, args)
+    run_dir, resume = setup_run_dir(config, args)
     ae_cfg = dict(load_config(args.autoencoderkl_config_file_path).autoencoderkl.params)
     if args.num_channels is not None:
         ae_cfg["num_channels"] = args.num_channels
@@ -62,21 +62,32 @@ def main(args):
         print(f"Scaling factor set to {scale_factor}")
     loss = torch.zeros(1, device=dev)
     gsync = D.OverlappedGradSync(unet.flat_grad)          # no-op with one process
-    steps, t0, seen, best = 0, time.time(), 0, float("inf")
-    for epoch in range(config.train.n_epochs):
+    steps, t0, seen, best, start_epoch, gstep = 0, time.time(), 0, float("inf"), 0, 0      # gstep: steps over all invocations (RNG offsets)
+    if resume:
+        # continue from {run_dir}/checkpoint.pth (keys as written below = training.py:381-387).  The reference computes `resume`
+        # but always restarts at epoch 0 (train_ldm.py:113,210-211); here the run really continues, with the saved scale_factor
+        ck = torch.load(os.path.join(run_dir, "checkpoint.pth"), map_location="cpu")
+        unet.load_state_dict(ck["diffusion"]); opt.load_state_dict(ck["optimizer"])
+        if "scaler" in ck:
+            scaler.load_state_dict(ck["scaler"])
+        start_epoch, best, scale_factor = int(ck["epoch"]), float(ck["best_loss"]), float(ck["scale_factor"])
+        gstep = int(ck.get("steps", 0))
+        if rank == 0:
+            print(f"Resuming from epoch {start_epoch} (best loss {best:.5f}, scale factor {scale_factor})")
+    for epoch in range(start_epoch, config.train.n_epochs):
         unet.train()
         for batch in train:
             x = batch["eeg"].to(dev)
             B = x.shape[0]
-            t = randint(ctx, B, sched.num_train_timesteps, seed=config.train.seed + 11 + rank, offset=steps * B)
-            eps = randn(ctx, (B, args.latent_channels, x.shape[2] // stage1.down), seed=config.train.seed + 12 + rank, offset=steps * z[0].numel() * B)
-            noise = randn(ctx, eps.shape, seed=config.train.seed + 13 + rank, offset=steps * z[0].numel() * B)
+            t = randint(ctx, B, sched.num_train_timesteps, seed=config.train.seed + 11 + rank, offset=gstep * B)
+            eps = randn(ctx, (B, args.latent_channels, x.shape[2] // stage1.down), seed=config.train.seed + 12 + rank, offset=gstep * z[0].numel() * B)
+            noise = randn(ctx, eps.shape, seed=config.train.seed + 13 + rank, offset=gstep * z[0].numel() * B)
             e = stage1.encode_stage_2_inputs(x, eps=eps, scale_factor=scale_factor)
             opt.zero_grad()
             ldm_train_step(unet, sched, e, noise, t, loss_out=loss, grad_scale=scaler.get_scale(), grad_sync=gsync)
             gsync.wait()
             scaler.step(opt); scaler.update()
-            steps += 1; seen += B * world
+            steps += 1; gstep += 1; seen += B * world
             if args.max_steps and steps >= args.max_steps:
                 break
         if rank == 0:
@@ -87,7 +98,8 @@ def main(args):
                     best = cur
                     torch.save({k: v.cpu() for k, v in unet.state_dict().items()}, os.path.join(run_dir, "best_model.pth"))
                 torch.save({"epoch": epoch + 1, "diffusion": {k: v.cpu() for k, v in unet.state_dict().items()}, "optimizer": opt.state_dict(),
-                            "best_loss": best, "scale_factor": torch.tensor(scale_factor)}, os.path.join(run_dir, "checkpoint.pth"))
+                            "best_loss": best, "scale_factor": torch.tensor(scale_factor), "scaler": scaler.state_dict(), "steps": gstep},
+                           os.path.join(run_dir, "checkpoint.pth"))
         if args.max_steps and steps >= args.max_steps:
             break
     if rank == 0:

@@ -46,6 +46,12 @@ def test_train_aekl_train_ldm_sample(tmp_path):
                                    "--synthetic_windows", "16", "--latent_channels", "1", "--max_steps", "2", "--grad_scaler"]))   # scaler path as in training.py:441-443
     ck = torch.load(os.path.join(run_l, "checkpoint.pth"))
     assert set(ck) >= {"epoch", "diffusion", "optimizer", "best_loss", "scale_factor"} and float(ck["scale_factor"]) > 0   # training.py:381-387
+    # a second invocation finds checkpoint.pth and continues from it (epoch budget already used: nothing left to train, same scale factor)
+    run_l2 = TL.main(TL.parse_args(["--config_file", l_yaml, "--autoencoderkl_config_file_path", a_yaml, "--best_model_path", run_a,
+                                    "--synthetic_windows", "16", "--latent_channels", "1", "--max_steps", "2", "--grad_scaler"]))
+    ck2 = torch.load(os.path.join(run_l2, "checkpoint.pth"))
+    assert run_l2 == run_l and ck2["epoch"] == ck["epoch"] and int(ck2["steps"]) == int(ck["steps"]) == 2
+    assert float(ck2["scale_factor"]) == float(ck["scale_factor"])
     sdir = ST.main(ST.parse_args(["--output_dir", out, "--best_model_path", run_a, "--diffusion_path", run_l,
                                   "--autoencoderkl_config_file_path", a_yaml, "--ldm_config_file_path", l_yaml,
                                   "--start_seed", "3", "--stop_seed", "6", "--num_inference_steps", "5", "--latent_channels", "1"]))
