@@ -59,7 +59,10 @@ template <int KSUB> __device__ __forceinline__ int nt_swz(int row, int slot) {
 }
 // TR bf16 tile: rows of BX*2 bytes; byte offset within the row ^= 32 * g(row) (mod row size)
 template <int BX> __device__ __forceinline__ int tr_swz(int row, int colbyte) {
-  return colbyte ^ ((((row & 3) | (((row >> 3) & 1) << 2)) * 32) & (BX * 2 - 1));
+  // the XOR must stay inside the row: the whole row when its size is a power of two, else 128-byte windows (192-row tiles: 384 B)
+  constexpr int WIN = ((BX * 2) & (BX * 2 - 1)) == 0 ? BX * 2 - 1 : 127;
+  static_assert((BX * 2) % (WIN + 1) == 0, "TR rows must be whole swizzle windows");
+  return colbyte ^ ((((row & 3) | (((row >> 3) & 1) << 2)) * 32) & WIN);
 }
 
 // K-strided fragment read from a [k rows][x cols] tile.
@@ -917,7 +920,7 @@ int launch_t(eegldm_ctx* ctx, const GemmArgs& a) {
     static const bool no_dma1 = getenv("EEGLDM_GEMM1_NO_DMA") != nullptr;
     if (!no_dma1 && a.K % KSTAGE == 0 && a.splitk == 1) return launch_k<T, AMODE, BMODE, TAPS, KSUB, BN, STRIDE, WMT, true>(ctx, a);
   }
-  if constexpr (AMODE == GA_TR && BMODE == GB_TR && WMT == 2) {
+  if constexpr (AMODE == GA_TR && BMODE == GB_TR && (WMT == 2 || WMT == 3)) {
     // weight gradients (fused 3-tap and 1-tap / Linear): every split is a whole number of stages when K is, and the source
     // of a chunk moves by a constant per stage unless the K index is remapped per tap (conv_map: unfused strided wgrad)
     static const bool no_dma = getenv("EEGLDM_WGRAD_NO_DMA") != nullptr;
@@ -976,6 +979,14 @@ int launch_modes(eegldm_ctx* ctx, const GemmArgs& a) {
       if (a.bmode == GB_NT) return (a.N % 128 == 0) ? launch_t<T, GA_PLAIN, GB_NT, 1, 2, 128, 1, 3>(ctx, a) : launch_t<T, GA_PLAIN, GB_NT, 1, 2, 64, 1, 3>(ctx, a);
       return (a.N % 128 == 0) ? launch_t<T, GA_PLAIN, GB_TR, 1, 2, 128, 1, 3>(ctx, a) : launch_t<T, GA_PLAIN, GB_TR, 1, 2, 64, 1, 3>(ctx, a);
     }
+  }
+  if constexpr (sizeof(T) == 2) {
+    // transposed-operand (TN) products whose M is a multiple of 192 but not of 128: the attention dK / dV gradients (192-row
+    // samples, batched) stop computing a half-empty second 128-row tile; 1-tap weight gradients with 192 k output channels
+    static const bool no_tn192 = getenv("EEGLDM_GEMM_NO_TN192") != nullptr;
+    static const bool tn192_all = getenv("EEGLDM_GEMM_TN192_ALL") != nullptr;   // experiment: also when 128 divides M
+    if (!no_tn192 && a.amode == GA_TR && a.bmode == GB_TR && a.taps == 1 && !a.conv_map && a.M % 192 == 0 && (a.M % 128 != 0 || tn192_all) && a.K % 64 == 0 && a.N % 64 == 0)
+      return (a.N % 128 == 0) ? launch_t<T, GA_TR, GB_TR, 1, 2, 128, 1, 3>(ctx, a) : launch_t<T, GA_TR, GB_TR, 1, 2, 64, 1, 3>(ctx, a);
   }
   static const bool deep1 = getenv("EEGLDM_GEMM1_DEEP") != nullptr;   // short stages, 4-deep DMA ring (see Cfg::NSTG)
   if (deep1 && a.amode == GA_PLAIN && a.splitk == 1 && a.K % Tr<T>::KC == 0) {
