@@ -100,15 +100,16 @@ int res_backward(NetBase* u, const ResDesc& r, const ResTape& t, const View& dou
   float* ps = nullptr; long ldps = 0;
   if (r.emb_col >= 0) { ps = demb_all + r.emb_col; ldps = u->etot; }
   else if (pg && !fb1) { ALLOC_OR_FAIL(ps, (float*)u->arena.alloc(sizeof(float) * (size_t)B * r.cout)); ldps = r.cout; }
-  int cs_done = 0;
+  int cs_done = 0, gn2_deferred = 0;
   EEG_TRY(op_groupnorm_bwd(ctx, t.h1.p, t.h1.ld, u->P(r.gn2_w), u->P(r.gn2_b), t.st2, da2.p, da2.ld, dh1.p, dh1.ld, pg ? u->G(r.gn2_w) : nullptr, pg ? u->G(r.gn2_b) : nullptr,
-                           B, Lout, r.cout, r.groups, 1, 0, nullptr, 0, dt, ps, ldps, &cs_done));
+                           B, Lout, r.cout, r.groups, 1, 0, nullptr, 0, dt, ps, ldps, &cs_done, nullptr, 0, nullptr, pg ? &gn2_deferred : nullptr));
   // few output channels = hundreds of K splits adding into the same bias entries (+17 us at 128 channels): when the one-pass
   // GroupNorm backward already produced per-sample sums, their total is cheaper
   const bool fb1e = fb1 && !(cs_done && ps && r.cout < 256);
   if (pg) {
     EEG_TRY(ctx_fork(ctx));                       // dh1 is ready
     SideScope side(ctx);
+    if (gn2_deferred) EEG_TRY(op_gn_slot_reduce_deferred(ctx, u->G(r.gn2_w), u->G(r.gn2_b), r.cout));   // dgamma / dbeta fold of GN2, off the main chain
     EEG_TRY(op_conv_wgrad(ctx, dt, t.a1.p, t.a1.ld, dh1.p, dh1.ld, u->G(r.c1_w), fb1e ? u->G(r.c1_b) : nullptr, B, Lout, r.cin, r.cout, 3, 1, 1, 1));
   }
   if (cs_done) {

@@ -16,7 +16,8 @@ namespace {
 constexpr int NT = 256;
 constexpr int MAXG_LDS = 1024;   // LDS accumulators per block (groups / channels)
 constexpr int GN_NSLOT = 64;     // partial dgamma/dbeta buffers
-constexpr size_t GN_SLOT_OFFSET = 1u << 20;   // byte offset of the slot area inside ctx->scratch
+constexpr size_t GN_SLOT_OFFSET = 1u << 20;   // byte offset of the slot area inside ctx->scratch (64 slots x 2C floats <= 512 KiB)
+constexpr size_t GN_SLOT_OFFSET_B = (1u << 20) + (512u << 10);   // second slot area: partials whose fold the caller runs later (side stream)
 
 template <typename T, int V> struct Vec;
 template <> struct Vec<float, 4> { typedef float4 type; };
@@ -686,9 +687,10 @@ template <typename T, int V>
 int gn_bwd_t(eegldm_ctx* ctx, const void* x, long ldx, const float* gamma, const float* beta, const float* stats,
              const void* dy, long lddy, void* dx, long lddx, float* dgamma, float* dbeta, int B, int L, int C, int G,
              int silu, int resample, const void* dxr, long lddxr, float* colsum_ps, long ldps, int* colsum_done,
-             const void* dxr2, long lddxr2, int* dxr2_done) {
+             const void* dxr2, long lddxr2, int* dxr2_done, int* slots_deferred) {
   if (colsum_done) *colsum_done = 0;
   if (dxr2_done) *dxr2_done = 0;
+  if (slots_deferred) *slots_deferred = 0;
   static const bool no_dxr2 = getenv("EEGLDM_GN_NO_DXR2") != nullptr;
   if (!dxr2_done || lddxr2 % 4 != 0 || no_dxr2) dxr2 = nullptr;      // only a caller that can fall back may hand over a second addend
   if constexpr (V == 4) {
@@ -701,7 +703,11 @@ int gn_bwd_t(eegldm_ctx* ctx, const void* x, long ldx, const float* gamma, const
     if (cc && (cc * (int)sizeof(T) < bwd_minrow || (long)(C / cc) * B > bwd_bpc * ctx->num_cu)) cc = 0;
     if (cc) {
       const dim3 grid(C / cc, B);
-      float* slots = dgamma ? (float*)((char*)ctx->scratch + GN_SLOT_OFFSET) : nullptr;
+      // a caller that can run the 7-us fold of the dgamma / dbeta partial slots elsewhere (side stream) gets them in the second slot
+      // region and calls op_gn_slot_reduce_deferred itself
+      static const bool no_defer = getenv("EEGLDM_GN_NO_DEFER") != nullptr;
+      const bool defer = slots_deferred && dgamma && !no_defer;
+      float* slots = dgamma ? (float*)((char*)ctx->scratch + (defer ? GN_SLOT_OFFSET_B : GN_SLOT_OFFSET)) : nullptr;
 #define GN_BWD_RES1(R, RAW) hipLaunchKernelGGL((gn_bwd_resident_kernel<T, R, RAW>), grid, dim3(NTB), 0, ctx->stream, (const T*)x, ldx, gamma, beta, stats, \
                                          (const T*)dy, lddy, (T*)dx, lddx, (const T*)dxr, lddxr, slots, colsum_ps, ldps, L, C, G, silu, resample, cc, (const T*)dxr2, lddxr2)
       static const bool raw0 = getenv("EEGLDM_GN_NO_RAW0") == nullptr;
@@ -711,10 +717,11 @@ int gn_bwd_t(eegldm_ctx* ctx, const void* x, long ldx, const float* gamma, const
 #undef GN_BWD_RES
 #undef GN_BWD_RES1
       LAUNCH_CHECK();
-      if (slots) {
+      if (slots && !defer) {
         hipLaunchKernelGGL(gn_slot_reduce_kernel, dim3((2 * C + 255) / 256), dim3(256), 0, ctx->stream, slots, dgamma, dbeta, C, (double*)ctx->scratch, 0);
         LAUNCH_CHECK();
       }
+      if (defer) *slots_deferred = 1;
       if (colsum_done && colsum_ps) *colsum_done = 1;
       if (dxr2) *dxr2_done = 1;
       return 0;
@@ -1075,8 +1082,9 @@ int op_groupnorm_bwd(eegldm_ctx* ctx, const void* x, long ldx, const float* gamm
                      const float* stats, const void* dy, long lddy, void* dx, long lddx,
                      float* dgamma, float* dbeta, int B, int L, int C, int G, int fuse_silu,
                      int resample, const void* dxr, long lddxr, int dtype, float* colsum_ps, long ldps, int* colsum_done,
-                     const void* dxr2, long lddxr2, int* dxr2_done) {
+                     const void* dxr2, long lddxr2, int* dxr2_done, int* slots_deferred) {
   if (dxr2_done) *dxr2_done = 0;
+  if (slots_deferred) *slots_deferred = 0;
   EEG_TRY(gn_check(ctx, B, L, C, G, resample, ldx));
   if (gn_flat_ok(L, C, G, resample, ldx, lddy, lddx, dxr ? lddxr : 0)) {
     if (colsum_done) *colsum_done = 0;
@@ -1084,11 +1092,19 @@ int op_groupnorm_bwd(eegldm_ctx* ctx, const void* x, long ldx, const float* gamm
     if (dtype == EEGLDM_BF16) return gn_flat_bwd<bf16_t>(ctx, x, gamma, beta, stats, dy, dx, dxr, dgamma, dbeta, B, L, C, fuse_silu);
   }
   const bool v4 = vec4_ok(C, G, ldx, lddy, lddx, dxr ? lddxr : 0);
-#define GN_BWD_ARGS ctx, x, ldx, gamma, beta, stats, dy, lddy, dx, lddx, dgamma, dbeta, B, L, C, G, fuse_silu, resample, dxr, lddxr, colsum_ps, ldps, colsum_done, dxr2, lddxr2, dxr2_done
+#define GN_BWD_ARGS ctx, x, ldx, gamma, beta, stats, dy, lddy, dx, lddx, dgamma, dbeta, B, L, C, G, fuse_silu, resample, dxr, lddxr, colsum_ps, ldps, colsum_done, dxr2, lddxr2, dxr2_done, slots_deferred
   if (dtype == EEGLDM_F32) return v4 ? gn_bwd_t<float, 4>(GN_BWD_ARGS) : gn_bwd_t<float, 1>(GN_BWD_ARGS);
   if (dtype == EEGLDM_BF16) return v4 ? gn_bwd_t<bf16_t, 4>(GN_BWD_ARGS) : gn_bwd_t<bf16_t, 1>(GN_BWD_ARGS);
 #undef GN_BWD_ARGS
   EEG_FAIL(EEGLDM_ERR_UNSUPPORTED, "dtype %d", dtype);
+}
+
+// folds the second slot area into dgamma / dbeta (and re-zeroes it): the deferred half of op_groupnorm_bwd(..., slots_deferred)
+int op_gn_slot_reduce_deferred(eegldm_ctx* ctx, float* dgamma, float* dbeta, int C) {
+  float* slots = (float*)((char*)ctx->scratch + GN_SLOT_OFFSET_B);
+  hipLaunchKernelGGL(gn_slot_reduce_kernel, dim3((2 * C + 255) / 256), dim3(256), 0, ctx->stream, slots, dgamma, dbeta, C, (double*)ctx->scratch, 0);
+  LAUNCH_CHECK();
+  return 0;
 }
 
 extern "C" int eegldm_groupnorm_bwd(eegldm_ctx* ctx, const void* x, long ldx, const float* gamma, const float* beta,
