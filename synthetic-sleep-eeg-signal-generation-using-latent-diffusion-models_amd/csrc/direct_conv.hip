@@ -168,6 +168,54 @@ __global__ __launch_bounds__(NT) void dconv_thin_in_kernel(const DArgs a) {
     *(RowVec<T, G>*)((T*)a.out + r * a.ldout + o0) = ov;
   }
 }
+// Same shape class with the weights of the thread's channel group in REGISTERS and (channel group, row lane) threads: the kernel
+// above re-reads 8 weights from LDS per tap and input channel for every output vector and pays two 64-bit divisions per vector
+// (57 us for the discriminator's 1 -> 64 stride-2 conv = 0.9 TB/s on a 50 MB output).  CI <= 4, K <= 3, Co/G divides the block.
+template <typename T, int CI>
+__global__ __launch_bounds__(NT) void dconv_thin_in_reg_kernel(const DArgs a) {
+  constexpr int G = 16 / sizeof(T);
+  const int gpr = a.Co / G, tx = threadIdx.x % gpr, ty = threadIdx.x / gpr, rpb = NT / gpr, o0 = tx * G;
+  float w[3][CI][G], bias[G];
+#pragma unroll
+  for (int t = 0; t < 3; t++)
+#pragma unroll
+    for (int i = 0; i < CI; i++)
+#pragma unroll
+      for (int k = 0; k < G; k++) w[t][i][k] = (t < a.K && i < a.Ci) ? wsel<T>(a, t, o0 + k, i) : 0.f;
+#pragma unroll
+  for (int k = 0; k < G; k++) bias[k] = a.bias ? a.bias[o0 + k] : 0.f;
+  const int rows = a.B * a.Lo;
+  for (int r = blockIdx.x * rpb + ty; r < rows; r += gridDim.x * rpb) {
+    const int b = r / a.Lo, l = r - b * a.Lo;
+    float acc[G];
+#pragma unroll
+    for (int k = 0; k < G; k++) acc[k] = bias[k];
+#pragma unroll
+    for (int t = 0; t < 3; t++) {
+      const int v = t < a.K ? in_pos(a, l, t) : -1;
+      if (v >= 0) {
+        const T* xin = (const T*)a.in + ((long)b * a.Li + v) * a.ldin;
+#pragma unroll
+        for (int i = 0; i < CI; i++) {
+          if (i < a.Ci) {
+            const float xv = ld_f32(xin + i);
+#pragma unroll
+            for (int k = 0; k < G; k++) acc[k] = fmaf(xv, w[t][i][k], acc[k]);
+          }
+        }
+      }
+    }
+    if (a.resid) {
+      const RowVec<T, G> rr = *(const RowVec<T, G>*)((const T*)a.resid + (long)r * a.ldr + o0);
+#pragma unroll
+      for (int k = 0; k < G; k++) acc[k] += ld_f32(&rr.v[k]);
+    }
+    RowVec<T, G> ov;
+#pragma unroll
+    for (int k = 0; k < G; k++) st_f32(&ov.v[k], acc[k]);
+    *(RowVec<T, G>*)((T*)a.out + (long)r * a.ldout + o0) = ov;
+  }
+}
 // wide input (Ci % G == 0, Ci/G a power of two <= 64), thin output (Co <= 8): Ci/G lanes per row, shuffle reduction
 template <typename T>
 __global__ __launch_bounds__(NT) void dconv_thin_out_kernel(const DArgs a) {
@@ -521,6 +569,17 @@ int dconv_run(eegldm_ctx* ctx, int dtype, bool dgrad, const void* in, long ldin,
     if (a.Ci <= 8 && a.Co % G == 0 && a.Co >= 16 && K <= 3 && ldout % G == 0 && (!resid || ldr % G == 0) && ((size_t)K * a.Ci * a.Co + a.Co) * 4 <= 48 * 1024) {
       const long total = rows * (a.Co / G);
       const dim3 g(grid_cap((total + NT - 1) / NT, ctx));
+      static const bool reg_ok = getenv("EEGLDM_DCONV_NO_REG") == nullptr;
+      const int gpr = a.Co / G;
+      if (reg_ok && a.Ci <= 4 && gpr <= NT && NT % gpr == 0 && rows < (1L << 30)) {
+#define DTI(T_, CI_) hipLaunchKernelGGL((dconv_thin_in_reg_kernel<T_, CI_>), g, dim3(NT), 0, ctx->stream, a)
+#define DTI_T(T_) do { if (a.Ci == 1) DTI(T_, 1); else if (a.Ci == 2) DTI(T_, 2); else DTI(T_, 4); } while (0)
+        if (dtype == EEGLDM_F32) DTI_T(float); else DTI_T(bf16_t);
+#undef DTI_T
+#undef DTI
+        LAUNCH_CHECK();
+        return 0;
+      }
       const size_t sh = ((size_t)K * a.Ci * a.Co + a.Co) * sizeof(float);
       if (dtype == EEGLDM_F32) hipLaunchKernelGGL((dconv_thin_in_kernel<float>), g, dim3(NT), sh, ctx->stream, a);
       else hipLaunchKernelGGL((dconv_thin_in_kernel<bf16_t>), g, dim3(NT), sh, ctx->stream, a);
