@@ -973,7 +973,8 @@ int launch_modes(eegldm_ctx* ctx, const GemmArgs& a) {
   if constexpr (sizeof(T) == 2) {
     static const bool no192 = getenv("EEGLDM_GEMM_NO_ATTN192") != nullptr;
     static const int all192 = getenv("EEGLDM_GEMM1_TILE192") ? atoi(getenv("EEGLDM_GEMM1_TILE192")) : 1;   // 1-tap kernels: +2..8 % on every UNet shape
-    const bool attn192 = a.batch > 1 && a.M % 192 == 0 && a.M % 128 != 0;
+    static const bool attn192_all = getenv("EEGLDM_GEMM_NO_ATTN192_ALL") == nullptr;   // also when 128 divides M (T = 384 / 768, pixel-space model): +0.7 % of that step
+    const bool attn192 = a.batch > 1 && a.M % 192 == 0 && (a.M % 128 != 0 || attn192_all);
     const bool conv192 = all192 && a.batch == 1 && a.M % 192 == 0 && a.K >= 64 * all192;
     if (!no192 && a.amode == GA_PLAIN && (attn192 || conv192) && a.splitk == 1 && a.K % 64 == 0) {
       if (a.bmode == GB_NT) return (a.N % 128 == 0) ? launch_t<T, GA_PLAIN, GB_NT, 1, 2, 128, 1, 3>(ctx, a) : launch_t<T, GA_PLAIN, GB_NT, 1, 2, 64, 1, 3>(ctx, a);
