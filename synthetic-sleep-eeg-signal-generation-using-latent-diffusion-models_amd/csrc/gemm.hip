@@ -986,7 +986,8 @@ int launch_modes(eegldm_ctx* ctx, const GemmArgs& a) {
     // samples, batched) stop computing a half-empty second 128-row tile; 1-tap weight gradients with 192 k output channels
     static const bool no_tn192 = getenv("EEGLDM_GEMM_NO_TN192") != nullptr;
     static const bool tn192_all = getenv("EEGLDM_GEMM_TN192_ALL") != nullptr;   // experiment: also when 128 divides M
-    if (!no_tn192 && a.amode == GA_TR && a.bmode == GB_TR && a.taps == 1 && !a.conv_map && a.M % 192 == 0 && (a.M % 128 != 0 || tn192_all) && a.K % 64 == 0 && a.N % 64 == 0)
+    static const bool tn192_batched = getenv("EEGLDM_GEMM_TN192_BATCHED") != nullptr;   // experiment: batched products (dK / dV at T = 768)
+    if (!no_tn192 && a.amode == GA_TR && a.bmode == GB_TR && a.taps == 1 && !a.conv_map && a.M % 192 == 0 && (a.M % 128 != 0 || tn192_all || (a.batch > 1 && tn192_batched)) && a.K % 64 == 0 && a.N % 64 == 0)
       return (a.N % 128 == 0) ? launch_t<T, GA_TR, GB_TR, 1, 2, 128, 1, 3>(ctx, a) : launch_t<T, GA_TR, GB_TR, 1, 2, 64, 1, 3>(ctx, a);
   }
   static const bool deep1 = getenv("EEGLDM_GEMM1_DEEP") != nullptr;   // short stages, 4-deep DMA ring (see Cfg::NSTG)
