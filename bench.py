@@ -160,8 +160,16 @@ def main():
                 traffic_src = "profiles/r01_pmc_hbm_traffic.json (bytes per launch, B=256 bf16)"
         except Exception:
             pass
+        # MFMA-busy share of the same class from the committed SQ counter pass (profiles/r01_pmc_mfma_busy.json)
+        mfma_util = None
+        try:
+            pm = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_pmc_mfma_busy.json")
+            if args.dtype == "bf16" and args.batch == 256:
+                mfma_util = json.load(open(pm))["classes"][k]["MfmaUtil_pct"]
+        except Exception:
+            pass
         roofline = {"bound": "mfma", "kernel": k, "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4),
-                    "traffic": traffic, "traffic_source": traffic_src, "launches_per_step": v["launches"] // 2, "avg_launch_us": round(1e3 * v["ms"] / max(1, v["launches"]), 2),
+                    "traffic": traffic, "traffic_source": traffic_src, "mfma_busy_pct_pmc": mfma_util, "launches_per_step": v["launches"] // 2, "avg_launch_us": round(1e3 * v["ms"] / max(1, v["launches"]), 2),
                     "gflop_per_launch": round(v["flops"] / max(1, v["launches"]) / 1e9, 3),
                     "all_gemm_classes": {kk: {"tflops": round(vv["flops"] / (vv["ms"] * 1e-3) / 1e12, 1) if vv["ms"] > 0 else 0.0,
                                               "ms_per_step": round(vv["ms"] / 2, 3), "launches_per_step": vv["launches"] // 2}
