@@ -581,6 +581,9 @@ __global__ __launch_bounds__((WMT == 3 ? 256 : 128 * WMT), 2) void gemm_kernel(c
     uint4 af[2][C::FM], bf[2][FN];
     load_frags(0, af[0], bf[0]);
     __builtin_amdgcn_sched_barrier(0);
+#ifdef EEG_SETPRIO
+    __builtin_amdgcn_s_setprio(EEG_SETPRIO);      // experiment: the wave in its MFMA phase wins issue arbitration against the co-resident block's wave
+#endif
 #pragma unroll
     for (int st = 0; st < NSTEP; st++) {
       if (st + 1 < NSTEP) load_frags(st + 1, af[(st + 1) & 1], bf[(st + 1) & 1]);
@@ -621,6 +624,9 @@ __global__ __launch_bounds__((WMT == 3 ? 256 : 128 * WMT), 2) void gemm_kernel(c
           }
       }
     }
+#ifdef EEG_SETPRIO
+    __builtin_amdgcn_s_setprio(0);
+#endif
     TSTAMP();   // after the MFMA phase of stage s
     if constexpr (!C::USE_DMA) __syncthreads();   // single buffer: reads of stage s done before stage s+1 is written
   };
