@@ -169,7 +169,8 @@ def main():
         except Exception:
             pass
         roofline = {"bound": "mfma", "kernel": k, "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4),
-                    "traffic": traffic, "traffic_source": traffic_src, "mfma_busy_pct_pmc": mfma_util, "launches_per_step": v["launches"] // 2, "avg_launch_us": round(1e3 * v["ms"] / max(1, v["launches"]), 2),
+                    "traffic": traffic, "traffic_source": traffic_src, "mfma_busy_pct_pmc": mfma_util,
+                    "event_bracket_overhead_us_subtracted": round(ctx.prof_bracket_overhead_us(), 2), "launches_per_step": v["launches"] // 2, "avg_launch_us": round(1e3 * v["ms"] / max(1, v["launches"]), 2),
                     "gflop_per_launch": round(v["flops"] / max(1, v["launches"]) / 1e9, 3),
                     "all_gemm_classes": {kk: {"tflops": round(vv["flops"] / (vv["ms"] * 1e-3) / 1e12, 1) if vv["ms"] > 0 else 0.0,
                                               "ms_per_step": round(vv["ms"] / 2, 3), "launches_per_step": vv["launches"] // 2}

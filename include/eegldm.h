@@ -68,9 +68,13 @@ int eegldm_timer_stop_ms(eegldm_ctx* ctx, float* ms_host);
  * is bracketed by HIP events on the context's stream.  eegldm_prof_summary returns, for one
  * kernel class (0 conv fwd, 1 conv dgrad, 2 conv wgrad, 3 gemm NT, 4 gemm NN, 5 gemm TN),
  * the summed algorithmic FLOPs (2*M*N*K*taps), summed kernel time and launch count since
- * eegldm_prof_enable(ctx, 1).  Host outputs. */
+ * eegldm_prof_enable(ctx, 1).  Host outputs.  Enabling also measures the elapsed time of an EMPTY
+ * event pair on the stream (median of 33); the summary subtracts it once per launch so that the
+ * durations are the kernels' own (they then agree with a rocprofv3 kernel trace of the same run);
+ * eegldm_prof_bracket_overhead_ms reports that calibration value. */
 int eegldm_prof_enable(eegldm_ctx* ctx, int on);
 int eegldm_prof_summary(eegldm_ctx* ctx, int kernel_class, double* flops_host, double* ms_host, int* launches_host);
+int eegldm_prof_bracket_overhead_ms(eegldm_ctx* ctx, double* ms_host);
 /* developer aid: CSV of every profiled launch (class,M,N,K,taps,splitk,ms,gflop) */
 int eegldm_prof_dump(eegldm_ctx* ctx, const char* path_host);
 

@@ -40,6 +40,7 @@ SIGNATURES = {
     "eegldm_timer_stop_ms": [_vp, C.POINTER(_f)],
     "eegldm_prof_enable": [_vp, _i],
     "eegldm_prof_summary": [_vp, _i, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(_i)],
+    "eegldm_prof_bracket_overhead_ms": [_vp, C.POINTER(C.c_double)],
     "eegldm_prof_dump": [_vp, C.c_char_p],
     "eegldm_ncl_to_nlc": [_vp, _vp, _vp, _l, _i, _i, _i, _i],
     "eegldm_nlc_to_ncl": [_vp, _vp, _l, _vp, _i, _i, _i, _i],
@@ -182,6 +183,11 @@ class Context:
             check(lib.eegldm_prof_summary(self.h, i, C.byref(f), C.byref(ms), C.byref(n)))
             out[name] = dict(flops=f.value, ms=ms.value, launches=n.value)
         return out
+
+    def prof_bracket_overhead_us(self):
+        ms = C.c_double()
+        check(lib.eegldm_prof_bracket_overhead_ms(self.h, C.byref(ms)))
+        return 1e3 * ms.value
 
     def __del__(self):
         try:

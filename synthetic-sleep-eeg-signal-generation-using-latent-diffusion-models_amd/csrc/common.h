@@ -54,6 +54,7 @@ struct eegldm_ctx {
   // optional per-launch HIP-event profiling of the GEMM family (bench.py roofline leg)
   bool prof_on = false;
   std::vector<ProfRec> prof;
+  double prof_bracket_ms = 0.0;   // elapsed time of an EMPTY event pair on this stream (calibrated by eegldm_prof_enable): subtracted per launch
 };
 
 static inline size_t dtype_size(int dt) { return dt == EEGLDM_F32 ? 4 : 2; }
