@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define EEGLDM_ABI_VERSION 1
+#define EEGLDM_ABI_VERSION 2
 
 enum { EEGLDM_F32 = 0, EEGLDM_BF16 = 1 };
 enum {
@@ -141,6 +141,12 @@ int eegldm_get_velocity(eegldm_ctx*, const float* x, const float* noise, const i
                         float* out, int B, long n_per_sample);
 int eegldm_ddim_step(eegldm_ctx*, const float* model_out, const float* sample, float a_t, float a_prev,
                      int pred_type, int clip_sample, float* prev_sample, float* pred_x0, long n);
+/* DDPMScheduler.step (variance_type "fixed_small"; the ancestral sampler of util.py:241-243,261-285 and sample_trials_ddpm.py:99-102;
+ * arithmetic pinned against DDPM.p_sample, /root/reference/src/models/ldm.py:311-357): x0 from the prediction type, optional clamp
+ * to [-1,1], prev = c0*x0 + ct*sample + sqrt(max(var,1e-20))*noise with the posterior coefficients of (a_t, a_prev, beta_t);
+ * a_prev == 1 (t == 0) adds no noise and `noise` may be NULL there.  pred_x0 nullable. */
+int eegldm_ddpm_step(eegldm_ctx*, const float* model_out, const float* sample, const float* noise, float a_t, float a_prev,
+                     float beta_t, int pred_type, int clip_sample, float* prev_sample, float* pred_x0, long n);
 /* loss = mean((pred-target)^2); dpred = 2 (pred-target) / n * grad_scale (nullable) */
 int eegldm_mse_loss(eegldm_ctx*, const float* pred, const float* target, float* loss, float* dpred, long n, float grad_scale);
 int eegldm_adam_step(eegldm_ctx*, float* p, const float* g, float* m, float* v, long n, float lr, float beta1,
@@ -236,6 +242,19 @@ int eegldm_aekl_forward(eegldm_aekl*, const float* x, const float* eps, float* r
                         float* kl, int B, int L);
 /* grads += d/dparams [ <d_recon, recon> + kl_weight * KL ]; dx nullable */
 int eegldm_aekl_backward(eegldm_aekl*, const float* d_recon, float kl_weight, float* dx);
+
+/* ------------------------------------------------------------------ sampler
+ * The whole sampling loop of sample_trials.py:149-170 (DDIM, eta 0) or util.py:261-285 / sample_trials_ddpm.py:99-104 (ancestral
+ * DDPM, `ancestral` != 0) as one call: x <- noise (B,C,L); for i < n_steps: out = UNet(x, timesteps_host[i]);
+ * x = step(out, x; a_t_host[i], a_prev_host[i] [, beta_t_host[i]]); then latents_out (nullable) <- x and windows_out (nullable) <-
+ * decode(x * inv_scale_factor) when `ae` is given, else x itself (pixel-space model).  The three schedule arrays are HOST arrays
+ * of n_steps entries (a_prev = 1 for the final step).  Ancestral noise is drawn on-device (Philox, noise_seed).
+ * use_graph != 0: the UNet forward is captured once per (B, L) into a hipGraph and replayed (launch-bound at small B -- the
+ * reference samples one window per call); *graph_used_host (nullable) reports whether the replay path ran. */
+int eegldm_sample(eegldm_unet*, eegldm_aekl* ae, const float* noise, const int64_t* timesteps_host, const float* a_t_host,
+                  const float* a_prev_host, const float* beta_t_host, int n_steps, int ancestral, int pred_type, int clip_sample,
+                  float inv_scale_factor, uint64_t noise_seed, float* latents_out, float* windows_out, int B, int L, int use_graph,
+                  int* graph_used_host);
 
 /* ------------------------------------------------------------------ PatchDiscriminator
  * PatchDiscriminator(spatial_dims=1, num_layers_d, num_channels, in_channels, out_channels, kernel_size=3,

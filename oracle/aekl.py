@@ -19,11 +19,13 @@ State-dict keys follow monai-generative's naming (recollection, unverified).
 import torch
 import torch.nn.functional as F
 
+from .quant import q as sq, qw as wq
+
 NORM_EPS = 1e-6
 
 
 def _conv(sd, p, x, stride=1, padding=1):
-    return F.conv1d(x, sd[p + ".conv.weight"], sd.get(p + ".conv.bias"), stride=stride, padding=padding)
+    return sq(F.conv1d(x, wq(sd[p + ".conv.weight"]), sd.get(p + ".conv.bias"), stride=stride, padding=padding))
 
 
 def _gn(sd, p, x, groups):
@@ -31,13 +33,13 @@ def _gn(sd, p, x, groups):
 
 
 def _resblock(sd, p, x, groups):
-    h = F.silu(_gn(sd, p + ".norm1", x, groups))
+    h = sq(F.silu(_gn(sd, p + ".norm1", x, groups)))
     h = _conv(sd, p + ".conv1", h)
-    h = F.silu(_gn(sd, p + ".norm2", h, groups))
+    h = sq(F.silu(_gn(sd, p + ".norm2", h, groups)))
     h = _conv(sd, p + ".conv2", h)
     if (p + ".nin_shortcut.conv.weight") in sd:
         x = _conv(sd, p + ".nin_shortcut", x, padding=0)
-    return x + h
+    return sq(x + h)
 
 
 def aekl_plan(num_channels, num_res_blocks=2):
@@ -77,7 +79,7 @@ def _run(sd, prefix, plan, x, groups):
         elif kind == "up":                # nearest x2 then conv3
             x = _conv(sd, p + ".conv", F.interpolate(x, scale_factor=2.0, mode="nearest"))
         elif kind == "gn":                # NO nonlinearity after the final norm
-            x = _gn(sd, p, x, groups)
+            x = sq(_gn(sd, p, x, groups))
     return x
 
 
@@ -164,20 +166,20 @@ def disc_forward(sd, cfg, x, training=True, running=None):
     unbiased var feeds running_var, momentum 0.1)."""
     pad, nl = cfg.get("padding", 1), cfg["num_layers_d"]
     outs = []
-    h = F.conv1d(x, sd["initial_conv.conv.weight"], sd["initial_conv.conv.bias"], stride=2, padding=pad)
-    h = F.leaky_relu(h, 0.2)
+    h = F.conv1d(sq(x), wq(sd["initial_conv.conv.weight"]), sd["initial_conv.conv.bias"], stride=2, padding=pad)
+    h = sq(F.leaky_relu(h, 0.2))
     outs.append(h)
     for l_ in range(nl):
         stride = 1 if l_ == nl - 1 else 2
-        h = F.conv1d(h, sd[f"{l_}.conv.weight"], sd.get(f"{l_}.conv.bias"), stride=stride, padding=pad)
+        h = sq(F.conv1d(h, wq(sd[f"{l_}.conv.weight"]), sd.get(f"{l_}.conv.bias"), stride=stride, padding=pad))
         rm = sd[f"{l_}.adn.N.running_mean"].clone(); rv = sd[f"{l_}.adn.N.running_var"].clone()
         h = F.batch_norm(h, rm, rv, sd[f"{l_}.adn.N.weight"], sd[f"{l_}.adn.N.bias"], training=training,
                          momentum=BN_MOMENTUM, eps=BN_EPS)
         if running is not None:
             running[f"{l_}.adn.N.running_mean"] = rm; running[f"{l_}.adn.N.running_var"] = rv
-        h = F.leaky_relu(h, 0.2)
+        h = sq(F.leaky_relu(h, 0.2))
         outs.append(h)
     k = sd["final_conv.conv.weight"].shape[-1]
-    h = F.conv1d(h, sd["final_conv.conv.weight"], sd["final_conv.conv.bias"], stride=1, padding=(k - 1) // 2)
+    h = F.conv1d(h, wq(sd["final_conv.conv.weight"]), sd["final_conv.conv.bias"], stride=1, padding=(k - 1) // 2)
     outs.append(h)
     return outs

@@ -58,6 +58,7 @@ SIGNATURES = {
     "eegldm_add_noise": [_vp, _vp, _vp, _vp, _vp, _vp, _i, _l],
     "eegldm_get_velocity": [_vp, _vp, _vp, _vp, _vp, _vp, _i, _l],
     "eegldm_ddim_step": [_vp, _vp, _vp, _f, _f, _i, _i, _vp, _vp, _l],
+    "eegldm_ddpm_step": [_vp, _vp, _vp, _vp, _f, _f, _f, _i, _i, _vp, _vp, _l],
     "eegldm_mse_loss": [_vp, _vp, _vp, _vp, _vp, _l, _f],
     "eegldm_adam_step": [_vp, _vp, _vp, _vp, _vp, _l, _f, _f, _f, _f, _i, _f],
     "eegldm_grad_check_finite": [_vp, _vp, _l, _vp],
@@ -90,6 +91,8 @@ SIGNATURES = {
     "eegldm_aekl_decode": [_vp, _vp, _vp, _i, _i],
     "eegldm_aekl_forward": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i],
     "eegldm_aekl_backward": [_vp, _vp, _f, _vp],
+    "eegldm_sample": [_vp, _vp, _vp, C.POINTER(C.c_int64), C.POINTER(_f), C.POINTER(_f), C.POINTER(_f), _i, _i, _i, _i, _f, C.c_uint64, _vp, _vp,
+                      _i, _i, _i, C.POINTER(_i)],
     "eegldm_disc_create": [_vp, _vp, C.POINTER(_vp)],
     "eegldm_disc_destroy": [_vp],
     "eegldm_disc_num_entries": [_vp],

@@ -215,6 +215,7 @@ extern "C" int eegldm_aekl_create(eegldm_ctx* ctx, const eegldm_aekl_cfg* cfg, e
   *out = a;
   return 0;
 }
+eegldm_ctx* aekl_ctx(const eegldm_aekl* a) { return a->ctx; }
 extern "C" int eegldm_aekl_destroy(eegldm_aekl* a) { delete a; return 0; }
 extern "C" int eegldm_aekl_num_entries(const eegldm_aekl* a) { return (int)a->entries.size(); }
 extern "C" long eegldm_aekl_num_params(const eegldm_aekl* a) { return a->nparams; }

@@ -232,6 +232,25 @@ __global__ void ddim_step_kernel(const float* __restrict__ mo, const float* __re
   }
 }
 
+// DDPM ancestral step (DDPMScheduler.step, variance_type fixed_small: the 1000-step logging sampler of util.py:241-243,261-285 and
+// sample_trials_ddpm.py:99-102; same arithmetic as DDPM.p_sample, /root/reference/src/models/ldm.py:311-357):
+//   x0 from the prediction type, optional clamp, mean = c0 * x0 + ct * x_t, plus sigma * noise when t > 0 (sigma = 0 at t = 0)
+__global__ void ddpm_step_kernel(const float* __restrict__ mo, const float* __restrict__ x, const float* __restrict__ nz, float sa, float sb,
+                                 float c0, float ct, float sigma, int pred, int clip, float* __restrict__ prev, float* __restrict__ x0o, long n) {
+  GRID_STRIDE(i, n) {
+    const float o = mo[i], s = x[i];
+    float x0;
+    if (pred == EEGLDM_PRED_EPSILON) x0 = (s - sb * o) / sa;
+    else if (pred == EEGLDM_PRED_V) x0 = sa * s - sb * o;
+    else x0 = o;
+    if (clip) x0 = fminf(1.0f, fmaxf(-1.0f, x0));
+    float m = c0 * x0 + ct * s;
+    if (sigma != 0.0f) m += sigma * nz[i];
+    prev[i] = m;
+    if (x0o) x0o[i] = x0;
+  }
+}
+
 // ------------------------------------------------------------------ MSE (training.py:437)
 __global__ __launch_bounds__(NT) void mse_kernel(const float* __restrict__ p, const float* __restrict__ t, float* __restrict__ loss,
                                                  float* __restrict__ dp, long n, float inv_n, float gscale) {
@@ -406,6 +425,23 @@ extern "C" int eegldm_ddim_step(eegldm_ctx* ctx, const float* mo, const float* x
                                 float* prev, float* x0, long n) {
   EEG_CHECK(pred >= 0 && pred <= 2, "prediction type %d", pred);
   hipLaunchKernelGGL(ddim_step_kernel, dim3(grid1d(n, ctx)), dim3(NT), 0, ctx->stream, mo, x, a_t, a_prev, pred, clip, prev, x0, n);
+  LAUNCH_CHECK(); return 0;
+}
+extern "C" int eegldm_ddpm_step(eegldm_ctx* ctx, const float* mo, const float* x, const float* noise, float a_t, float a_prev, float beta_t,
+                                int pred, int clip, float* prev, float* x0, long n) {
+  EEG_CHECK(ctx && mo && x && prev, "null argument");
+  EEG_CHECK(pred >= 0 && pred <= 2, "prediction type %d", pred);
+  EEG_CHECK(a_t > 0.0f && a_t < 1.0f && a_prev > 0.0f && a_prev <= 1.0f && beta_t > 0.0f && beta_t < 1.0f, "bad schedule values");
+  // posterior q(x_{t-1} | x_t, x_0): coefficients in double on the host, as the schedulers build their tables
+  const double bt = 1.0 - (double)a_t, bp = 1.0 - (double)a_prev;
+  const double c0 = sqrt((double)a_prev) * (double)beta_t / bt, ct = sqrt(1.0 - (double)beta_t) * bp / bt;
+  double var = bp / bt * (double)beta_t;
+  const bool last = a_prev >= 1.0f;                  // t == 0: no noise
+  if (var < 1e-20) var = 1e-20;
+  const float sigma = last ? 0.0f : (float)sqrt(var);
+  EEG_CHECK(last || noise, "noise is required for t > 0");
+  hipLaunchKernelGGL(ddpm_step_kernel, dim3(grid1d(n, ctx)), dim3(NT), 0, ctx->stream, mo, x, noise, (float)sqrt((double)a_t), (float)sqrt(bt),
+                     (float)c0, (float)ct, sigma, pred, clip, prev, x0, n);
   LAUNCH_CHECK(); return 0;
 }
 extern "C" int eegldm_mse_loss(eegldm_ctx* ctx, const float* p, const float* t, float* loss, float* dp, long n, float gscale) {

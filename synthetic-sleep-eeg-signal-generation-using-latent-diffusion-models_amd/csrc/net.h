@@ -89,4 +89,10 @@ int res_backward(NetBase* u, const ResDesc& r, const ResTape& t, const View& dou
                  const View* extra = nullptr, int* extra_done = nullptr);
 int attn_forward(NetBase* u, const AttnDesc& a, const View& x, int B, int T, const View& out);
 int attn_backward(NetBase* u, const AttnDesc& a, const AttnTape& t, const View& dout, const View& dx);
+// accessors for the sampler (sampler.hip); the struct itself is private to unet.hip
+eegldm_ctx* unet_ctx(const eegldm_unet* u);
+int unet_in_channels(const eegldm_unet* u);
+int unet_out_channels(const eegldm_unet* u);
+void sampler_release(const eegldm_unet* u);
+eegldm_ctx* aekl_ctx(const eegldm_aekl* a);
 int entry_query(const NetBase* u, int i, char* name, int cap, long* offset, long* numel, int* ndim, int shape[3]);

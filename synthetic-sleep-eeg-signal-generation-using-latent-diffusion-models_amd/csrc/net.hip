@@ -88,8 +88,9 @@ int res_backward(NetBase* u, const ResDesc& r, const ResTape& t, const View& dou
       float* tmp = (float*)((char*)ctx->scratch + (3u << 20));        // [cout] staging in the context scratch
       HIP_TRY(hipMemsetAsync(tmp, 0, sizeof(float) * r.cout, ctx->stream));
       EEG_TRY(ew_colsum(ctx, dout.p, dout.ld, nullptr, 0, tmp, B, Lout, r.cout, dt));
-      EEG_TRY(eegldm_axpy(ctx, u->G(r.c2_b), tmp, 1.0f, r.cout));
-      EEG_TRY(eegldm_axpy(ctx, u->G(r.sk_b), tmp, 1.0f, r.cout));
+      // each bias takes the sum from exactly ONE producer: the side-stream weight-gradient GEMM when it fuses it, tmp otherwise
+      if (!fb2) EEG_TRY(eegldm_axpy(ctx, u->G(r.c2_b), tmp, 1.0f, r.cout));
+      if (!fbs) EEG_TRY(eegldm_axpy(ctx, u->G(r.sk_b), tmp, 1.0f, r.cout));
     } else {
       EEG_TRY(ew_colsum(ctx, dout.p, dout.ld, nullptr, 0, u->G(r.c2_b), B, Lout, r.cout, dt));
     }

@@ -1,0 +1,124 @@
+// DDIM / DDPM sampling as ONE native call: the loop of /root/reference/src/sample_trials.py:149-170
+// (noise -> [UNet, scheduler.step] x N -> decode(z / scale_factor)) and of sample_trials_ddpm.py:99-104 /
+// util.py:261-285 (pixel-space model, 1000-step ancestral sampler).  Host code only.
+//
+// The reference samples ONE window per call (sample_trials.py:149-163): at batch 1 a UNet forward is ~350 launches of
+// microsecond kernels and the host's launch rate, not the GPU, sets the latency.  The forward pass is therefore captured
+// once per (B, L) into a hipGraph (activation arena, timestep buffer and latent buffer have fixed addresses) and the loop
+// replays it: per step one fill of the timestep buffer, one graph launch and one scheduler-step kernel.
+#include <map>
+#include <tuple>
+#include <utility>
+#include <vector>
+
+#include "net.h"
+
+namespace {
+struct GraphKey { const eegldm_unet* u; int B, L; bool operator<(const GraphKey& o) const { return std::tie(u, B, L) < std::tie(o.u, o.B, o.L); } };
+struct SamplerState {
+  hipGraphExec_t exec = nullptr; hipGraph_t graph = nullptr;
+  float *x = nullptr, *out = nullptr, *nz = nullptr; int64_t* tt = nullptr;
+  hipStream_t stream = nullptr; hipEvent_t ev_in = nullptr, ev_out = nullptr;
+  bool capture_failed = false;
+};
+std::map<GraphKey, SamplerState>& states() { static std::map<GraphKey, SamplerState> m; return m; }
+
+__global__ void fill_i64_kernel(int64_t* p, int n, int64_t v) { const int i = blockIdx.x * blockDim.x + threadIdx.x; if (i < n) p[i] = v; }
+}  // namespace
+
+void sampler_release(const eegldm_unet* u) {
+  auto& m = states();
+  for (auto it = m.begin(); it != m.end();) {
+    if (it->first.u != u) { ++it; continue; }
+    SamplerState& s = it->second;
+    if (s.exec) (void)hipGraphExecDestroy(s.exec);
+    if (s.graph) (void)hipGraphDestroy(s.graph);
+    if (s.x) (void)hipFree(s.x);
+    if (s.out) (void)hipFree(s.out);
+    if (s.nz) (void)hipFree(s.nz);
+    if (s.tt) (void)hipFree(s.tt);
+    if (s.ev_in) (void)hipEventDestroy(s.ev_in);
+    if (s.ev_out) (void)hipEventDestroy(s.ev_out);
+    if (s.stream) (void)hipStreamDestroy(s.stream);
+    it = m.erase(it);
+  }
+}
+
+extern "C" int eegldm_sample(eegldm_unet* u, eegldm_aekl* ae, const float* noise, const int64_t* timesteps_host, const float* a_t_host,
+                             const float* a_prev_host, const float* beta_t_host, int n_steps, int ancestral, int pred_type, int clip_sample,
+                             float inv_scale_factor, uint64_t noise_seed, float* latents_out, float* windows_out, int B, int L, int use_graph,
+                             int* graph_used_host) {
+  EEG_CHECK(u && noise && timesteps_host && a_t_host && a_prev_host, "null argument");
+  EEG_CHECK(!ancestral || beta_t_host, "the ancestral (DDPM) step needs beta_t");
+  EEG_CHECK(n_steps >= 1 && B >= 1 && L >= 1, "bad sizes");
+  EEG_CHECK(latents_out || windows_out, "nothing to return: pass latents_out and/or windows_out");
+  eegldm_ctx* ctx = unet_ctx(u);
+  const int C = unet_in_channels(u);
+  EEG_CHECK(unet_out_channels(u) == C, "sampling needs in_channels == out_channels");
+  EEG_CHECK(!ae || aekl_ctx(ae) == ctx, "the autoencoder and the UNet must share one context");
+  const long n = (long)B * C * L;
+  SamplerState& s = states()[GraphKey{u, B, L}];
+  if (!s.x) {
+    HIP_TRY(hipMalloc(&s.x, sizeof(float) * n)); HIP_TRY(hipMalloc(&s.out, sizeof(float) * n)); HIP_TRY(hipMalloc(&s.nz, sizeof(float) * n));
+    HIP_TRY(hipMalloc(&s.tt, sizeof(int64_t) * B));
+    HIP_TRY(hipStreamCreateWithFlags(&s.stream, hipStreamNonBlocking));
+    HIP_TRY(hipEventCreateWithFlags(&s.ev_in, hipEventDisableTiming)); HIP_TRY(hipEventCreateWithFlags(&s.ev_out, hipEventDisableTiming));
+  }
+  // the whole loop runs on the sampler's own stream (a capture cannot start on the NULL stream the caller may have given the context):
+  // it waits for the caller's stream first and the caller's stream waits for it at the end
+  hipStream_t caller = ctx->stream;
+  struct Restore { eegldm_ctx* c; hipStream_t s; ~Restore() { c->stream = s; } } restore{ctx, caller};
+  HIP_TRY(hipEventRecord(s.ev_in, caller));
+  HIP_TRY(hipStreamWaitEvent(s.stream, s.ev_in, 0));
+  ctx->stream = s.stream;
+  HIP_TRY(hipMemcpyAsync(s.x, noise, sizeof(float) * n, hipMemcpyDeviceToDevice, s.stream));
+
+  auto set_t = [&](int64_t t) { hipLaunchKernelGGL(fill_i64_kernel, dim3((B + 255) / 256), dim3(256), 0, s.stream, s.tt, B, t); };
+  bool graph_ok = false;
+  if (use_graph && !ctx->prof_on && !s.capture_failed) {
+    if (!s.exec) {
+      // eager warm-up: grows the arena / workspaces (hipMalloc is not capturable), then capture the identical launch sequence
+      set_t(timesteps_host[0]);
+      EEG_TRY(eegldm_unet_forward(u, s.x, s.tt, s.out, B, L, 0));
+      HIP_TRY(hipStreamSynchronize(s.stream));
+      int rc = 0;
+      if (hipStreamBeginCapture(s.stream, hipStreamCaptureModeThreadLocal) == hipSuccess) {
+        rc = eegldm_unet_forward(u, s.x, s.tt, s.out, B, L, 0);
+        hipError_t e = hipStreamEndCapture(s.stream, &s.graph);
+        if (rc == 0 && e == hipSuccess && s.graph && hipGraphInstantiate(&s.exec, s.graph, nullptr, nullptr, 0) == hipSuccess) graph_ok = true;
+      }
+      if (!graph_ok) {
+        (void)hipGetLastError();
+        if (s.graph) { (void)hipGraphDestroy(s.graph); s.graph = nullptr; }
+        s.exec = nullptr; s.capture_failed = true;
+        if (rc) return rc;
+      }
+    } else graph_ok = true;
+  }
+  if (graph_used_host) *graph_used_host = graph_ok ? 1 : 0;
+
+  for (int i = 0; i < n_steps; i++) {
+    set_t(timesteps_host[i]);
+    if (graph_ok) HIP_TRY(hipGraphLaunch(s.exec, s.stream));
+    else EEG_TRY(eegldm_unet_forward(u, s.x, s.tt, s.out, B, L, 0));
+    if (ancestral) {
+      const bool last = a_prev_host[i] >= 1.0f;
+      if (!last) EEG_TRY(eegldm_randn(ctx, s.nz, n, noise_seed, (uint64_t)i * (uint64_t)((n + 3) / 4)));
+      EEG_TRY(eegldm_ddpm_step(ctx, s.out, s.x, last ? nullptr : s.nz, a_t_host[i], a_prev_host[i], beta_t_host[i], pred_type, clip_sample, s.x, nullptr, n));
+    } else {
+      EEG_TRY(eegldm_ddim_step(ctx, s.out, s.x, a_t_host[i], a_prev_host[i], pred_type, clip_sample, s.x, nullptr, n));
+    }
+  }
+  if (latents_out) HIP_TRY(hipMemcpyAsync(latents_out, s.x, sizeof(float) * n, hipMemcpyDeviceToDevice, s.stream));
+  if (windows_out) {
+    if (ae) {
+      if (inv_scale_factor != 1.0f) EEG_TRY(eegldm_axpy(ctx, s.x, s.x, inv_scale_factor - 1.0f, n));     // z / scale_factor (sample_trials.py:166)
+      EEG_TRY(eegldm_aekl_decode(ae, s.x, windows_out, B, L));
+    } else {
+      HIP_TRY(hipMemcpyAsync(windows_out, s.x, sizeof(float) * n, hipMemcpyDeviceToDevice, s.stream));    // pixel-space model: x IS the window
+    }
+  }
+  HIP_TRY(hipEventRecord(s.ev_out, s.stream));
+  HIP_TRY(hipStreamWaitEvent(caller, s.ev_out, 0));
+  return 0;
+}

@@ -211,8 +211,12 @@ extern "C" int eegldm_unet_create(eegldm_ctx* ctx, const eegldm_unet_cfg* cfg, e
   *out = u;
   return 0;
 }
+eegldm_ctx* unet_ctx(const eegldm_unet* u) { return u->ctx; }
+int unet_in_channels(const eegldm_unet* u) { return u->cfg.in_channels; }
+int unet_out_channels(const eegldm_unet* u) { return u->cfg.out_channels; }
 extern "C" int eegldm_unet_destroy(eegldm_unet* u) {
   if (!u) return 0;
+  sampler_release(u);
   delete u;
   return 0;
 }

@@ -60,13 +60,47 @@ class _Scheduler:
 
 
 class DDPMScheduler(_Scheduler):
-    """Training-side scheduler (add_noise / get_velocity).  The ancestral `step` of the
-    reference's logging sampler (util.py:241-243) is outside the hot path and not provided."""
+    """Training-side scheduler (add_noise / get_velocity) and the ancestral `step` of the reference's 1000-step samplers
+    (util.py:241-243,261-285; sample_trials_ddpm.py:99-102), variance_type "fixed_small".  The step arithmetic is pinned against
+    the reference's own DDPM.p_sample (/root/reference/src/models/ldm.py:311-357; tests/golden/ddpm_steps.npz)."""
+
+    def __init__(self, *a, variance_type="fixed_small", **k):
+        if variance_type != "fixed_small":
+            raise NotImplementedError("the reference uses DDPMScheduler's default variance_type='fixed_small'")
+        k.setdefault("clip_sample", True)
+        super().__init__(*a, **k)
+        self.variance_type = variance_type
+        self._step_calls = 0
 
     def set_timesteps(self, num_inference_steps):
+        if num_inference_steps > self.num_train_timesteps:
+            raise ValueError("num_inference_steps cannot exceed num_train_timesteps")
         self.num_inference_steps = num_inference_steps
         ratio = self.num_train_timesteps // num_inference_steps
         self.timesteps = torch.from_numpy((np.arange(0, num_inference_steps) * ratio).round()[::-1].copy().astype(np.int64))
+
+    def step(self, model_output, timestep, sample, generator=None, noise=None):
+        """-> (pred_prev_sample, pred_original_sample).  `noise` (optional, the parity tests pass it) replaces the N(0,1) draw;
+        otherwise the draw comes from `generator` (a torch CPU/GPU generator) or the device Philox stream."""
+        t = int(timestep)
+        a_t = float(self.alphas_cumprod[t])
+        a_prev = float(self.alphas_cumprod[t - 1]) if t > 0 else 1.0
+        mo = model_output.to(self.device, torch.float32).contiguous()
+        x = sample.to(self.device, torch.float32).contiguous()
+        nz = None
+        if t > 0:
+            if noise is not None:
+                nz = noise.to(self.device, torch.float32).contiguous()
+            elif generator is not None:
+                nz = torch.randn(x.shape, generator=generator, device=generator.device).to(self.device)
+            else:
+                nz = torch.empty_like(x)
+                check(lib.eegldm_randn(self.ctx.h, ptr(nz), nz.numel(), 0x5EED + t, self._step_calls * ((nz.numel() + 3) // 4)))
+                self._step_calls += 1
+        prev, x0 = torch.empty_like(x), torch.empty_like(x)
+        check(lib.eegldm_ddpm_step(self.ctx.h, ptr(mo), ptr(x), ptr(nz), a_t, a_prev, float(self.betas[t]), PRED[self.prediction_type],
+                                   int(self.clip_sample), ptr(prev), ptr(x0), x.numel()))
+        return prev, x0
 
 
 class DDIMScheduler(_Scheduler):
@@ -110,10 +144,15 @@ class DiffusionInferer:
     @torch.no_grad()
     def sample(self, input_noise, diffusion_model, scheduler=None, save_intermediates=False, intermediate_steps=100,
                conditioning=None, verbose=False):
+        """The loop of DiffusionInferer.sample (sample_trials_ddpm.py:99-102, util.py:261-285): model call + scheduler.step per
+        entry of scheduler.timesteps; with save_intermediates returns (image, [every intermediate_steps-th image]) like MONAI."""
         scheduler = scheduler or self.scheduler
         image = input_noise
+        intermediates = []
         for t in scheduler.timesteps:
             tt = torch.full((image.shape[0],), int(t), dtype=torch.int64)
             out = diffusion_model(image, timesteps=tt)
             image, _ = scheduler.step(out, int(t), image)
-        return image
+            if save_intermediates and int(t) % intermediate_steps == 0:
+                intermediates.append(image)
+        return (image, intermediates) if save_intermediates else image

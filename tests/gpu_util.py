@@ -55,3 +55,31 @@ def assert_close(got, want, rtol, atol, name=""):
 # tolerances: fp32 path (exact-fp32 MFMA, fp32 stats) vs the fp32 CPU oracle; bf16 path = storage rounding
 TOL = {F32: dict(rtol=1e-4, atol=1e-5), BF16: dict(rtol=3e-2, atol=3e-2)}
 GTOL = {F32: dict(rtol=1e-3, atol=1e-4), BF16: dict(rtol=5e-2, atol=5e-2)}
+
+
+def rel_l2(a, b):
+    a = torch.as_tensor(a).detach().double().cpu().reshape(-1); b = torch.as_tensor(b).detach().double().cpu().reshape(-1)
+    return float((a - b).norm() / (b.norm() + 1e-12))
+
+
+# bf16 bounds are DERIVED, not guessed: `gap` = rel-L2 distance between the fp32 oracle and the same oracle with bf16 storage
+# emulated at every activation / activation-gradient / weight-read point (oracle/quant.py).  That is the error the storage
+# format alone causes when the summation order differs; an engine result must lie within BF16_GAP_FACTOR x gap of the fp32
+# oracle (plus a floor of a few bf16 ulps for tensors whose gap happens to be tiny).
+BF16_GAP_FACTOR = 2.0
+BF16_FLOOR = 2.0 ** -7
+
+
+def bf16_gap_bound(gap, floor=BF16_FLOOR):
+    return max(BF16_GAP_FACTOR * gap, floor)
+
+
+def grads_rel_errors(got, want, floor_frac):
+    """per-key relative L2 error of parameter gradients; `floor_frac` of the model-wide gradient scale is added to the
+    denominator so tensors whose true gradient is rounding noise do not dominate"""
+    gscale = max(float(torch.as_tensor(v).double().norm()) for v in want.values())
+    out = {}
+    for k, w in want.items():
+        w = torch.as_tensor(w).double().cpu()
+        out[k] = float((got[k].double().cpu() - w).norm()) / (float(w.norm()) + floor_frac * gscale)
+    return out

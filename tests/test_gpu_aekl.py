@@ -15,6 +15,11 @@ AE_CASES = {
     "c32_32_64_lat3": dict(num_channels=[32, 32, 64], latent_channels=3),
     "c2_2_4_lat1": dict(num_channels=[2, 2, 4], latent_channels=1),
     "c16_32_lat2": dict(num_channels=[16, 32], latent_channels=2),
+    # reference configs config_aekl_eeg_4_16_32 / _4_4_16 / _8_8_16: ResBlocks with a 1x1 shortcut whose bias gradient shares its
+    # column sum with conv2's (round-1 advisor finding: double-counted when only one of the two weight-gradient GEMMs fuses it)
+    "c4_16_32_lat1": dict(num_channels=[4, 16, 32], latent_channels=1),
+    "c4_4_16_lat1": dict(num_channels=[4, 4, 16], latent_channels=1),
+    "c8_8_16_lat1": dict(num_channels=[8, 8, 16], latent_channels=1),
 }
 D_CFG = dict(spatial_dims=1, num_layers_d=3, num_channels=64, in_channels=1, out_channels=1, kernel_size=3, norm="BATCH", bias=False, padding=1)
 
@@ -224,3 +229,24 @@ def test_autoencoderkl_edge_inputs():
         ae.encode(torch.randn(2, 1, 3001))
     with pytest.raises(ValueError, match=r"\(B, 1, L\)"):
         ae.encode(torch.randn(2, 3, 3072))
+
+
+def test_spectral_loss_zero_amplitude_gradient_is_zero_not_nan():
+    """Documented deviation: where |FFT(recon)| is exactly 0 the derivative of sqrt(re^2 + im^2) is 0/0; torch /
+    MONAI's JukeboxLoss propagates NaN from there (the instability the reference README.md:17 mentions), the engine defines the
+    sub-gradient as 0.  An all-zero reconstruction makes every bin's amplitude exactly 0: the loss value still matches the oracle,
+    the oracle's gradient is NaN, the engine's is exactly 0 for that window and matches the oracle for the other windows."""
+    import gpu_util as G
+    from oracle import losses as Ls
+    c = G.ctx(); B, L = 3, 3072
+    a = torch.from_numpy(eeg_windows(B, seed=1, length=L)); a[1] = 0.0
+    b = torch.from_numpy(eeg_windows(B, seed=3, length=L))
+    ar = a.clone().requires_grad_(True)
+    spec = Ls.jukebox_loss(ar, b, "sum"); spec.backward()
+    assert torch.isnan(ar.grad[1]).any() and torch.isfinite(ar.grad[0]).all() and torch.isfinite(ar.grad[2]).all()
+    ad, bd = a.to(G.DEV), b.to(G.DEV)
+    loss = torch.zeros(1, device=G.DEV); d = torch.zeros(B, 1, L, device=G.DEV)
+    G.check(G.lib.eegldm_spectral_loss(c.h, G.ptr(ad), G.ptr(bd), G.ptr(loss), G.ptr(d), B, 1, L, 1.0))
+    assert abs(float(loss) - float(spec)) < 2e-5 * float(spec)
+    assert torch.isfinite(d).all() and float(d[1].abs().max()) == 0.0
+    assert rel_l2(d[0], ar.grad[0]) < 5e-5 and rel_l2(d[2], ar.grad[2]) < 5e-5

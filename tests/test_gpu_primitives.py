@@ -36,6 +36,14 @@ CONV_CASES = [
     (8, 128, 64, 256, 3, 1, 1, 1),       # 8 M tiles x 2 N tiles: XCD-aware tile order (all N tiles of an M tile on one XCD)
     (8, 128, 64, 256, 1, 1, 0, 0),       # same for the 1-tap kernels
     (32, 512, 128, 256, 3, 1, 1, 1),     # split-K weight gradient with splitk % 8 == 0: one K split per XCD
+    # production reduction lengths of the config_ldm UNet's deepest level (T = 192): K up to 3 x 1024 per output, split-K with
+    # skewed chunks, 192-row tiles, fused bias gradient (colsum) at Cin in {512, 768, 1024}
+    (32, 192, 512, 512, 3, 1, 1, 1),
+    (32, 192, 768, 512, 3, 1, 1, 1),
+    (32, 192, 1024, 512, 3, 1, 1, 1),
+    (32, 192, 1024, 512, 1, 1, 0, 0),    # skip_connection of the first output block
+    (32, 192, 512, 1536, 1, 1, 0, 0),    # qkv
+    (16, 384, 768, 256, 3, 1, 1, 1),     # output_blocks.3: 512 + 256 -> 256 at T = 384
 ]
 
 

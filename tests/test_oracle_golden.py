@@ -113,3 +113,74 @@ def test_scaled_linear_schedule(golden_dir, name, b0, b1):
     # SURVEY §8c known answers
     ref = {"train_0.0015_0.0195": (0.99850, 0.115844, 1.42304e-4), "sample_0.0015_0.0205": (0.99850, 0.108576, 9.69109e-5)}[name]
     np.testing.assert_allclose(acp[[0, 499, 999]], ref, rtol=2e-4)
+
+
+# ------------------------------------------------------------------ round 2: DDPM.q_sample / p_sample and the full-size UNet
+def test_add_noise_vs_reference_q_sample(golden_dir):
+    """oracle add_noise == DDPM.q_sample (/root/reference/src/models/ldm.py:392-408) on the reference's own sqrt tables."""
+    g = _load(golden_dir, "ddpm_steps.npz")
+    sx, sn = [int(v) for v in g["q_sample:seeds"]]
+    x0, nz = torch.from_numpy(normal((3, 1, 64), seed=sx)), torch.from_numpy(normal((3, 1, 64), seed=sn))
+    acp = Ls.alphas_cumprod("scaled_linear_beta", 1000, 0.0015, 0.0195)      # local "linear" == sqrt-space schedule
+    np.testing.assert_allclose(acp.numpy(), g["alphas_cumprod"], rtol=2e-5)
+    out = Ls.add_noise(acp, x0, nz, torch.from_numpy(g["q_sample:t"]))
+    np.testing.assert_allclose(out.numpy(), g["q_sample:out"], rtol=2e-5, atol=2e-6)
+
+
+@pytest.mark.parametrize("par,pred", [("eps", "epsilon"), ("x0", "sample")])
+@pytest.mark.parametrize("tval", [0, 1, 500, 999])
+@pytest.mark.parametrize("clip", [False, True])
+def test_ddpm_step_vs_reference_p_sample(golden_dir, par, pred, tval, clip):
+    """oracle ddpm_step (the MONAI DDPMScheduler.step formula, fixed_small variance) == DDPM.p_sample
+    (/root/reference/src/models/ldm.py:311-357): posterior mean coefficients, clipped log-variance, no noise at t = 0."""
+    g = _load(golden_dir, "ddpm_steps.npz")
+    so, sx, sz = [int(v) for v in g[f"p_sample:{par}:seeds"]]
+    mo = torch.from_numpy(normal((3, 1, 64), seed=so)) * (1.0 if par == "eps" else 0.6)
+    xt, zn = torch.from_numpy(normal((3, 1, 64), seed=sx)), torch.from_numpy(normal((3, 1, 64), seed=sz))
+    betas = Ls.make_betas("scaled_linear_beta", 1000, 0.0015, 0.0195)
+    np.testing.assert_allclose(betas.numpy(), g["betas"], rtol=2e-5)
+    acp = torch.cumprod(1 - betas, 0)
+    prev, x0 = Ls.ddpm_step(acp, betas, mo, tval, xt, zn, pred, clip)
+    # 1/sqrt(acp[999]) ~ 84 amplifies fp32 rounding of the schedule tables in the unclipped x0
+    tol = dict(rtol=2e-4, atol=2e-4 if tval < 999 else 5e-3)
+    np.testing.assert_allclose(x0.numpy(), g[f"p_sample:{par}:t{tval}:clip{int(clip)}:x0"], **tol)
+    np.testing.assert_allclose(prev.numpy(), g[f"p_sample:{par}:t{tval}:clip{int(clip)}:prev"], **tol)
+
+
+def test_ddpm_step_with_unet_vs_reference(golden_dir):
+    """One step of the 1000-step ancestral sampler with the real (tiny) reference UNet inside p_sample."""
+    g = _load(golden_dir, "ddpm_steps.npz")
+    cfg, _B, _L = UNET_CASES["tiny_l64"]
+    sd = {k: torch.from_numpy(gen_param(42, k, s)) for k, s in U.unet_param_shapes(cfg).items()}
+    _so, sx, sz = [int(v) for v in g["p_sample:eps:seeds"]]
+    xt, zn = torch.from_numpy(normal((3, 1, 64), seed=sx)), torch.from_numpy(normal((3, 1, 64), seed=sz))
+    t = int(g["p_sample_unet:t"])
+    betas = Ls.make_betas("scaled_linear_beta", 1000, 0.0015, 0.0195); acp = torch.cumprod(1 - betas, 0)
+    with torch.no_grad():
+        out = U.unet_forward(sd, cfg, xt, torch.full((3,), t, dtype=torch.int64))
+    prev, x0 = Ls.ddpm_step(acp, betas, out, t, xt, zn, "epsilon", False)
+    np.testing.assert_allclose(x0.numpy(), g["p_sample_unet:x0"], rtol=1e-3, atol=1e-3)
+    np.testing.assert_allclose(prev.numpy(), g["p_sample_unet:prev"], rtol=1e-3, atol=1e-3)
+
+
+def test_unet_full_size_vs_reference(golden_dir):
+    """The BASELINE UNet itself (config_ldm.yaml: model_channels 128, 30 533 121 parameters, Cin up to 1024), B=2, L=768:
+    oracle forward, input gradient and every parameter gradient against the imported reference."""
+    from make_golden_cases import UNET_FULL
+    g = _load(golden_dir, "unet_full_l768.npz")
+    cfg, B, L = UNET_FULL
+    sw, sx, _st, sdy = [int(v) for v in g["seeds"]]
+    shapes = U.unet_param_shapes(cfg)
+    assert list(shapes.keys()) == [str(k) for k in g["keys"]] and int(g["n_params"]) == 30533121
+    torch.set_num_threads(max(1, min(16, os.cpu_count() or 1)))
+    sd = {k: torch.from_numpy(gen_param(sw, k, s)).requires_grad_(True) for k, s in shapes.items()}
+    x = torch.from_numpy(normal((B, 1, L), seed=sx)).requires_grad_(True)
+    y = U.unet_forward(sd, cfg, x, torch.from_numpy(g["t"]))
+    y.backward(torch.from_numpy(normal(tuple(y.shape), seed=sdy)))
+    np.testing.assert_allclose(y.detach().numpy(), g["y"], rtol=2e-4, atol=2e-5)
+    np.testing.assert_allclose(x.grad.numpy(), g["dx"], rtol=2e-3, atol=2e-5)
+    for k in shapes:
+        gr = sd[k].grad.double().reshape(-1)
+        l2 = float(g["g_l2:" + k])
+        np.testing.assert_allclose(gr[:16].float().numpy(), g["g_head:" + k], rtol=2e-3, atol=2e-4 * max(1.0, l2 / np.sqrt(gr.numel())))
+        assert abs(float(gr.norm()) - l2) <= 1e-3 * l2 + 1e-5, k
