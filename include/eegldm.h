@@ -243,6 +243,19 @@ int eegldm_aekl_forward(eegldm_aekl*, const float* x, const float* eps, float* r
 /* grads += d/dparams [ <d_recon, recon> + kl_weight * KL ]; dx nullable */
 int eegldm_aekl_backward(eegldm_aekl*, const float* d_recon, float kl_weight, float* dx);
 
+/* ------------------------------------------------------------------ quality metrics (fp32 NCL tensors, results on the device)
+ * 1-D multi-scale SSIM -- the reference's local adaptation of MONAI's MultiScaleSSIMMetric (compute_mmds.py:214-408; used with
+ * spatial_dims=1, data_range=1.0, kernel_size=7 at :487): per scale a `ksize`-tap (gaussian) valid convolution gives the local
+ * moments, cs / ssim maps are averaged over channels and positions, avg_pool1d(2) between scales, out[b] = prod_s relu(.)^w_s
+ * with the last scale using ssim.  kernel_host [ksize], weights_host [n_scales] are HOST arrays.  L <= 4096. */
+int eegldm_ms_ssim_1d(eegldm_ctx*, const float* a, const float* b, float* out, int B, int C, int L, const float* kernel_host,
+                      int ksize, const float* weights_host, int n_scales, float data_range, float k1, float k2);
+/* Multitaper PSD of single-channel windows x (B, L), one-sided bins 0..n_bins-1 (bin k = k*sfreq/L Hz) -- what
+ * mne's Epochs.compute_psd(fmax=18) computes per epoch at sample_trials.py:172-181 (method "multitaper", normalization "length"):
+ * tapers (device, [n_tapers][L]) and weights_host ([n_tapers], sqrt of the DPSS concentrations) come from the host. */
+int eegldm_psd_multitaper(eegldm_ctx*, const float* x, const float* tapers, const float* weights_host, int n_tapers, float sfreq,
+                          int n_bins, float* psd, int B, int L);
+
 /* ------------------------------------------------------------------ sampler
  * The whole sampling loop of sample_trials.py:149-170 (DDIM, eta 0) or util.py:261-285 / sample_trials_ddpm.py:99-104 (ancestral
  * DDPM, `ancestral` != 0) as one call: x <- noise (B,C,L); for i < n_steps: out = UNet(x, timesteps_host[i]);

@@ -91,6 +91,8 @@ SIGNATURES = {
     "eegldm_aekl_decode": [_vp, _vp, _vp, _i, _i],
     "eegldm_aekl_forward": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i],
     "eegldm_aekl_backward": [_vp, _vp, _f, _vp],
+    "eegldm_ms_ssim_1d": [_vp, _vp, _vp, _vp, _i, _i, _i, C.POINTER(_f), _i, C.POINTER(_f), _i, _f, _f, _f],
+    "eegldm_psd_multitaper": [_vp, _vp, _vp, C.POINTER(_f), _i, _f, _i, _vp, _i, _i],
     "eegldm_sample": [_vp, _vp, _vp, C.POINTER(C.c_int64), C.POINTER(_f), C.POINTER(_f), C.POINTER(_f), _i, _i, _i, _i, _f, C.c_uint64, _vp, _vp,
                       _i, _i, _i, C.POINTER(_i)],
     "eegldm_disc_create": [_vp, _vp, C.POINTER(_vp)],
@@ -162,6 +164,7 @@ class Context:
         h = C.c_void_p()
         check(lib.eegldm_ctx_create(device, C.c_void_p(stream), 0 if use_torch_stream else 1, C.byref(h)))
         self.h = h
+        self.stream_handle = stream
 
     def sync(self):
         check(lib.eegldm_ctx_sync(self.h))

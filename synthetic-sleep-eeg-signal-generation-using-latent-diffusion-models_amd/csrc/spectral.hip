@@ -10,7 +10,9 @@
 //     64-point DFTs along the rows) with a sin/cos table of the N-th roots in LDS -- ~112 complex
 //     MACs per output, negligible next to the autoencoder, exact to fp32 rounding, no bit reversal.
 //   * gradient: dL/d recon[n] = Re FFT_ortho(G)[n], G[k] = 2(A_k - B_k) conj(R_k)/A_k
-//     (G_k := 0 where A_k == 0; torch would produce NaN there -- README.md:17 notes that instability).
+//     (G_k := 0 where A_k is zero to rounding, A_k^2 <= 1e-10 (A_k^2 + B_k^2): the two spectra are separated from ONE packed FFT, so
+//      an exactly-zero A_k comes out as ~1e-7 |Z_k| of rounding noise whose phase is meaningless; torch produces NaN there --
+//      README.md:17 notes that instability.  Deviation stated in INTEGRATION.md, tested in tests/test_gpu_aekl.py).
 // HBM traffic = the two windows in, one gradient window out: HBM-bound, ~36 KB per window.
 #include "common.h"
 
@@ -85,7 +87,7 @@ __global__ __launch_bounds__(NT) void spectral_kernel(const float* __restrict__ 
     const float A = sqrtf(rr * rr + ri * ri), Bm = sqrtf(tr * tr + ti * ti);
     const float d = A - Bm;
     part += d * d;
-    const float g = A > 0.f ? 2.0f * d / A : 0.f;
+    const float g = (A * A > 1e-10f * (A * A + Bm * Bm)) ? 2.0f * d / A : 0.f;
     bufA[k] = make_float2(g * rr, -g * ri);      // G_k = 2(A-B) conj(R_k)/A
   }
   part = wave_sum(part);

@@ -58,8 +58,9 @@ class OverlappedGradSync:
     covered yet; `wait()` blocks the current stream on all of it and applies the 1/world scaling.  With one process it
     does nothing.  Slices must not overlap (the native hook reports one tail range)."""
 
-    def __init__(self, flat_grad, bucket_elems=BUCKET_ELEMS):
+    def __init__(self, flat_grad, bucket_elems=BUCKET_ELEMS, ctx=None):
         self.g = flat_grad
+        self.ctx = ctx          # eegldm.Context whose stream the native backward enqueues on (checked in on_ready)
         self.bucket = int(bucket_elems)
         self.works = []
         self.done = []          # (start, end) ranges already launched
@@ -79,6 +80,11 @@ class OverlappedGradSync:
     def on_ready(self, offset, numel):
         if not self.active or numel <= 0:
             return
+        # dist.all_reduce orders itself after torch's CURRENT stream; the backward that produced this slice was enqueued on the
+        # context's stream (torch's current stream when the Context was created).  They must be the same stream.
+        if self.ctx is not None and self.g.is_cuda and torch.cuda.current_stream(self.g.device).cuda_stream != self.ctx.stream_handle:
+            raise RuntimeError("OverlappedGradSync: torch's current stream differs from the stream the eegldm Context enqueues on; "
+                               "the all-reduce would not be ordered after the backward (create the Context under the stream you train on)")
         self._launch(offset, offset + numel)
         self.done.append((offset, offset + numel))
 

@@ -52,25 +52,72 @@ def synthetic_windows(n, seed, length=3072, pad=36):
     return x
 
 
-class WindowLoader:
-    """Iterable of {'eeg': float32 (B,1,3072)} batches.  Source: a directory of pre-processed per-recording .npy files
-    (one channel x samples, as written by the reference's preprocessing) or, when absent / --synthetic_windows is given,
-    synthetic windows.  Each item = min-max normalise the recording, random 3000-sample crop, 36-sample zero pad
-    (dataset.py:12-19); recordings are cached in memory after the first read."""
+WINDOW = 3000      # 30 s at 100 Hz (dataset.py:7-8)
+BORDER = 36        # BorderPadD(spatial_border=[36]) (dataset.py:18)
 
-    def __init__(self, path_pre_processed, batch_size, n_synthetic=0, seed=0, drop_last=False, shuffle=True):
+
+def normalise_recording(a):
+    """The deterministic head of get_trans (dataset.py:12-16): ScaleIntensityD(factor=1e6) = x * (1 + 1e6), then
+    ScaleIntensityD(minv=0, maxv=1) = min-max over the WHOLE recording (a constant recording maps to zeros, as
+    monai.transforms.utils.rescale_array does).  float32 in, float32 out, flattened to one channel."""
+    a = np.asarray(a, dtype=np.float32).reshape(-1) * np.float32(1.0 + 1e6)
+    lo, hi = a.min(), a.max()
+    if hi == lo:
+        return np.zeros_like(a)
+    return (a - lo) / (hi - lo)
+
+
+def crop_and_pad(rec, start):
+    """RandSpatialCropD(roi_size=[3000], random_size=False) at offset `start`, then 36 zeros on each side -> (1, 3072)."""
+    w = np.zeros((1, WINDOW + 2 * BORDER), np.float32)
+    w[0, BORDER:BORDER + WINDOW] = rec[start:start + WINDOW]
+    return w
+
+
+def read_ids(path_ids, path_pre_processed, dataset="edfx"):
+    """File list from an id CSV (column FILE_NAME_EEG), as get_datalist builds it (dataset.py:33-60): '.npy' suffix for edfx."""
+    import csv
+    with open(path_ids, newline="") as f:
+        rows = list(csv.DictReader(f))
+    if rows and "FILE_NAME_EEG" not in rows[0]:
+        raise ValueError(f"{path_ids}: no FILE_NAME_EEG column (dataset.py:49)")
+    final = ".npy" if dataset == "edfx" else ""
+    return [os.path.join(path_pre_processed or "", r["FILE_NAME_EEG"] + final) for r in rows]
+
+
+class WindowLoader:
+    """Iterable of {'eeg': float32 (B,1,3072)} batches -- the loader output contract of dataset.py:10-30,62-69.
+
+    Source: the recordings named by an id CSV (`path_ids`, column FILE_NAME_EEG: the reference's train / valid / test split), or
+    every *.npy under `path_pre_processed` when no CSV is given, or synthetic windows (`n_synthetic`).  Each item = normalise the
+    whole recording (x * (1 + 1e6), min-max), random 3000-sample crop, 36-sample zero pad.  The reference re-reads and re-normalises
+    a whole night (~23 MB) for every 12 KB window (PersistentDataset(cache_dir=None)); here a recording is read and normalised ONCE
+    and kept in memory, and `windows_per_recording` crops are drawn from it per epoch (1 = the reference's epoch definition).
+    `shard=(rank, world)` gives every data-parallel rank its own slice of the file list (an epoch is the data once, not world
+    times).  Crop offsets come from a numpy Generator seeded per loader (`crop_starts` can be injected for parity tests)."""
+
+    def __init__(self, path_pre_processed, batch_size, n_synthetic=0, seed=0, drop_last=False, shuffle=True, path_ids=None,
+                 dataset="edfx", shard=(0, 1), windows_per_recording=1, crop_starts=None):
         self.batch_size, self.drop_last, self.shuffle = batch_size, drop_last, shuffle
         self.rng = np.random.default_rng(seed)
-        files = sorted(glob.glob(os.path.join(path_pre_processed or "", "**", "*.npy"), recursive=True)) if path_pre_processed else []
-        if files and not n_synthetic:
-            self.recordings = []
-            for f in files:
-                a = np.load(f).astype(np.float32).reshape(-1)
-                a = a * (1 + 1e6)
-                lo, hi = float(a.min()), float(a.max())
-                self.recordings.append((a - lo) / (hi - lo + 1e-12))
-            self.windows = None
-            self.n = len(self.recordings)
+        self.wpr = max(1, int(windows_per_recording))
+        self.crop_starts = crop_starts
+        self.recordings, self.windows, self.files = None, None, []
+        if n_synthetic:
+            files = []
+        elif path_ids:
+            files = read_ids(path_ids, path_pre_processed, dataset)
+            missing = [f for f in files if not os.path.exists(f)]
+            if missing:
+                raise FileNotFoundError(f"{len(missing)} recordings listed in {path_ids} are missing, e.g. {missing[0]}")
+        else:
+            files = sorted(glob.glob(os.path.join(path_pre_processed or "", "**", "*.npy"), recursive=True)) if path_pre_processed else []
+        rank, world = shard
+        files = files[rank::world] if world > 1 else files
+        if files:
+            self.files = files
+            self.recordings = [None] * len(files)          # read + normalised on first use, then cached
+            self.n = len(files) * self.wpr
         else:
             self.windows = synthetic_windows(n_synthetic or 4 * batch_size, seed)
             self.n = len(self.windows)
@@ -78,17 +125,33 @@ class WindowLoader:
     def __len__(self):
         return self.n // self.batch_size if self.drop_last else -(-self.n // self.batch_size)
 
+    def _recording(self, r):
+        if self.recordings[r] is None:
+            rec = normalise_recording(np.load(self.files[r]))
+            if rec.shape[0] < WINDOW:
+                raise ValueError(f"{self.files[r]}: {rec.shape[0]} samples, need at least {WINDOW}")
+            self.recordings[r] = rec
+        return self.recordings[r]
+
     def _item(self, i):
         if self.windows is not None:
             return self.windows[i]
-        a = self.recordings[i]
-        s = int(self.rng.integers(0, max(1, a.shape[0] - 3000)))
-        w = np.zeros((1, 3072), np.float32)
-        w[0, 36:3036] = a[s:s + 3000]
-        return w
+        rec = self._recording(i // self.wpr)
+        if self.crop_starts is not None:
+            s = int(self.crop_starts[i])
+        else:
+            s = int(self.rng.integers(0, rec.shape[0] - WINDOW + 1))       # RandSpatialCrop: every valid start, last one included
+        return crop_and_pad(rec, s)
 
     def __iter__(self):
         order = self.rng.permutation(self.n) if self.shuffle else np.arange(self.n)
         for k in range(len(self)):
             idx = order[k * self.batch_size:(k + 1) * self.batch_size]
             yield {"eeg": torch.from_numpy(np.stack([self._item(int(i)) for i in idx]))}
+
+
+def rng_seed(base_seed, role, rank=0, world=1):
+    """Distinct Philox key per (role, rank): base * 2^20 + role * 4096 + rank.  Roles: 1 timesteps, 2 posterior eps, 3 diffusion
+    noise, 4 autoencoder eps.  (seed + role + rank collides across ranks: rank r's noise stream == rank r+1's eps stream.)"""
+    assert 0 <= rank < 4096 and 0 <= role < 256
+    return (int(base_seed) << 20) + (int(role) << 12) + int(rank)

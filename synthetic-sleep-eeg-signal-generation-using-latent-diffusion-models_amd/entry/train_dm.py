@@ -13,7 +13,7 @@ from .. import distributed as D
 from ..models import UNetModel
 from ..schedulers import DDPMScheduler
 from ..training import Adam, dm_train_step, randint, randn
-from .common import WindowLoader, load_config, setup_run_dir
+from .common import WindowLoader, load_config, rng_seed, setup_run_dir
 
 
 def parse_args(argv=None):
@@ -41,10 +41,12 @@ def main(args):
     opt = Adam(unet, lr=1e-4)
     spectral = args.spe == "spectral"
     bs = max(1, config.train.batch_size // world)
-    train = WindowLoader(args.path_pre_processed, bs, args.synthetic_windows, seed=config.train.seed + rank, drop_last=config.train.drop_last)
+    train = WindowLoader(args.path_pre_processed, bs, args.synthetic_windows, seed=config.train.seed + rank, drop_last=config.train.drop_last,
+                         path_ids=args.path_train_ids, dataset=args.type_dataset, shard=(rank, world))
+    s_t, s_noise = rng_seed(config.train.seed, 1, rank, world), rng_seed(config.train.seed, 3, rank, world)
     dev, ctx = unet.device, unet.ctx
     loss = torch.zeros(1, device=dev)
-    gsync = D.OverlappedGradSync(unet.flat_grad)          # no-op with one process
+    gsync = D.OverlappedGradSync(unet.flat_grad, ctx=unet.ctx)          # no-op with one process
     steps, t0, seen, best, start_epoch, gstep = 0, time.time(), 0, float("inf"), 0, 0      # gstep: steps over all invocations (RNG offsets)
     if resume:      # continue from {run_dir}/checkpoint.pth
         ck = torch.load(os.path.join(run_dir, "checkpoint.pth"), map_location="cpu")
@@ -57,8 +59,8 @@ def main(args):
         for batch in train:
             x = batch["eeg"].to(dev)
             B = x.shape[0]
-            t = randint(ctx, B, sched.num_train_timesteps, seed=config.train.seed + 11 + rank, offset=gstep * B)
-            noise = randn(ctx, tuple(x.shape), seed=config.train.seed + 13 + rank, offset=gstep * x.numel())
+            t = randint(ctx, B, sched.num_train_timesteps, seed=s_t, offset=gstep * B)
+            noise = randn(ctx, tuple(x.shape), seed=s_noise, offset=gstep * x.numel())
             opt.zero_grad()
             dm_train_step(unet, sched, x, noise, t, spectral_weight=1e-6, spectral_loss=spectral, loss_out=loss, grad_sync=gsync)
             gsync.wait()

@@ -11,7 +11,7 @@ from .. import distributed as D
 from ..models import AutoencoderKL, UNetModel
 from ..schedulers import DDPMScheduler
 from ..training import Adam, GradScaler, ldm_train_step, randint, randn
-from .common import ParseListAction, WindowLoader, load_config, setup_run_dir
+from .common import ParseListAction, WindowLoader, load_config, rng_seed, setup_run_dir
 
 
 def parse_args(argv=None):
@@ -26,8 +26,31 @@ def parse_args(argv=None):
     p.add_argument("--synthetic_windows", type=int, default=0); p.add_argument("--dtype", default="float32")
     p.add_argument("--max_steps", type=int, default=0); p.add_argument("--output_dir", default=None)
     p.add_argument("--prediction_type", default="epsilon")
+    p.add_argument("--schedule", default="linear_beta", choices=["linear_beta", "scaled_linear_beta"],
+                   help="training noise schedule; the reference builds DDPMScheduler(beta_schedule='linear') = plain linspace (train_ldm.py:199-200)")
     p.add_argument("--grad_scaler", action="store_true", help="dynamic loss scaling as in the reference loop (training.py:334,441-443); bf16/fp32 do not need it")
     return p.parse_args(argv)
+
+
+@torch.no_grad()
+def validate(unet, stage1, sched, loader, scale_factor, seed, latent_channels):
+    """eval_ldm (training.py:455-497): mean epsilon-MSE over the validation windows, fixed noise stream."""
+    from .._lib import lib, check, ptr
+    unet.eval()
+    tot, n, dev, ctx = 0.0, 0, unet.device, unet.ctx
+    out = torch.zeros(1, device=dev)
+    for k, batch in enumerate(loader):
+        x = batch["eeg"].to(dev); B = x.shape[0]
+        Ll = x.shape[2] // stage1.down
+        t = randint(ctx, B, sched.num_train_timesteps, seed=seed, offset=k * B)
+        eps = randn(ctx, (B, latent_channels, Ll), seed=seed + 1, offset=k * B * Ll)
+        noise = randn(ctx, eps.shape, seed=seed + 2, offset=k * B * Ll)
+        e = stage1.encode_stage_2_inputs(x, eps=eps, scale_factor=scale_factor)
+        pred = unet(sched.add_noise(original_samples=e, noise=noise, timesteps=t), timesteps=t)
+        check(lib.eegldm_mse_loss(ctx.h, ptr(pred), ptr(noise), ptr(out), None, pred.numel(), 1.0))
+        tot += float(out) * B; n += B
+    unet.train()
+    return tot / max(1, n)
 
 
 def main(args):
@@ -48,12 +71,19 @@ def main(args):
     up["in_channels"] = up["out_channels"] = args.latent_channels            # train_ldm.py:184-187
     unet = UNetModel(**up, dtype=args.dtype, device=local)
     D.broadcast_flat(unet.flat); unet.sync_weights(); D.broadcast_flat(stage1.flat); stage1.sync_weights()
-    sched = DDPMScheduler(num_train_timesteps=1000, schedule="scaled_linear_beta", beta_start=0.0015, beta_end=0.0195,
-                          prediction_type=args.prediction_type, device=local)   # train_ldm.py:199-200 ("linear" there == scaled-linear)
+    # train_ldm.py:199-200: monai-generative DDPMScheduler(beta_schedule="linear", 0.0015, 0.0195) = plain linspace of the betas
+    # (alpha_bar[999] = 2.57e-5).  The sqrt-space "linear" of the reference's local models/ldm.py is a different table and is not
+    # what train_ldm uses; --schedule scaled_linear_beta selects it deliberately.
+    sched = DDPMScheduler(num_train_timesteps=1000, schedule=args.schedule, beta_start=0.0015, beta_end=0.0195,
+                          prediction_type=args.prediction_type, device=local)
     opt = Adam(unet, lr=config.train.get("base_lr", 1e-4))
     scaler = GradScaler(enabled=args.grad_scaler)
     bs = max(1, config.train.batch_size // world)
-    train = WindowLoader(args.path_pre_processed, bs, args.synthetic_windows, seed=config.train.seed + rank, drop_last=config.train.drop_last)
+    train = WindowLoader(args.path_pre_processed, bs, args.synthetic_windows, seed=config.train.seed + rank, drop_last=config.train.drop_last,
+                         path_ids=args.path_train_ids, dataset=args.type_dataset, shard=(rank, world))
+    valid = WindowLoader(args.path_pre_processed, bs, 0, seed=config.train.seed + 7919, shuffle=False, path_ids=args.path_valid_ids,
+                         dataset=args.type_dataset, shard=(rank, world)) if args.path_valid_ids else None
+    s_t, s_eps, s_noise = (rng_seed(config.train.seed, role, rank, world) for role in (1, 2, 3))
     dev, ctx = unet.device, unet.ctx
     first = next(iter(train))["eeg"].to(dev)
     z = stage1.encode_stage_2_inputs(first)
@@ -61,7 +91,7 @@ def main(args):
     if rank == 0:
         print(f"Scaling factor set to {scale_factor}")
     loss = torch.zeros(1, device=dev)
-    gsync = D.OverlappedGradSync(unet.flat_grad)          # no-op with one process
+    gsync = D.OverlappedGradSync(unet.flat_grad, ctx=unet.ctx)          # no-op with one process
     steps, t0, seen, best, start_epoch, gstep = 0, time.time(), 0, float("inf"), 0, 0      # gstep: steps over all invocations (RNG offsets)
     if resume:
         # continue from {run_dir}/checkpoint.pth (keys as written below = training.py:381-387).  The reference computes `resume`
@@ -79,9 +109,9 @@ def main(args):
         for batch in train:
             x = batch["eeg"].to(dev)
             B = x.shape[0]
-            t = randint(ctx, B, sched.num_train_timesteps, seed=config.train.seed + 11 + rank, offset=gstep * B)
-            eps = randn(ctx, (B, args.latent_channels, x.shape[2] // stage1.down), seed=config.train.seed + 12 + rank, offset=gstep * z[0].numel() * B)
-            noise = randn(ctx, eps.shape, seed=config.train.seed + 13 + rank, offset=gstep * z[0].numel() * B)
+            t = randint(ctx, B, sched.num_train_timesteps, seed=s_t, offset=gstep * B)
+            eps = randn(ctx, (B, args.latent_channels, x.shape[2] // stage1.down), seed=s_eps, offset=gstep * z[0].numel() * B)
+            noise = randn(ctx, eps.shape, seed=s_noise, offset=gstep * z[0].numel() * B)
             e = stage1.encode_stage_2_inputs(x, eps=eps, scale_factor=scale_factor)
             opt.zero_grad()
             ldm_train_step(unet, sched, e, noise, t, loss_out=loss, grad_scale=scaler.get_scale(), grad_sync=gsync)
@@ -94,6 +124,8 @@ def main(args):
             print(f"epoch {epoch}: loss {float(loss):.5f} | {seen/(time.time()-t0):.1f} windows/s", flush=True)
             if (epoch + 1) % config.train.get("eval_freq", 1) == 0 or (args.max_steps and steps >= args.max_steps):
                 cur = float(loss)
+                if valid is not None:      # model selection on the validation split (training.py:356-380), epsilon MSE over its windows
+                    cur = validate(unet, stage1, sched, valid, scale_factor, rng_seed(config.train.seed, 5, rank, world), args.latent_channels)
                 if cur <= best:
                     best = cur
                     torch.save({k: v.cpu() for k, v in unet.state_dict().items()}, os.path.join(run_dir, "best_model.pth"))

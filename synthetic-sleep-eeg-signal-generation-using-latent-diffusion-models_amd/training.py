@@ -31,12 +31,73 @@ class Adam:
                                    self.param_groups[0]["lr"], self.betas[0], self.betas[1], self.eps, self.step_count, grad_inv_scale))
         md.sync_weights()
 
+    # ---- checkpoint wire format: torch.optim.Adam's own state_dict layout, so that the optimizer entry of a reference
+    # checkpoint.pth (train_autoencoderkl.py:320-329, training/training.py:381-388 store `optimizer.state_dict()`) resumes here
+    # and a checkpoint written here resumes under torch.optim.Adam.  Parameter index i = the i-th entry of the model's
+    # parameter table (= the order of nn.Module.parameters() in the reference; BatchNorm buffers are not parameters).
     def state_dict(self):
-        return {"step": self.step_count, "exp_avg": self.m.clone(), "exp_avg_sq": self.v.clone(), "lr": self.param_groups[0]["lr"]}
+        return flat_to_torch_adam_state(self.model.entries, self.m, self.v, self.step_count, self.param_groups[0]["lr"], self.betas, self.eps)
 
     def load_state_dict(self, sd):
-        self.step_count = int(sd["step"]); self.m.copy_(sd["exp_avg"]); self.v.copy_(sd["exp_avg_sq"])
-        self.param_groups[0]["lr"] = sd.get("lr", self.lr)
+        if "state" not in sd:             # round-1 private format {step, exp_avg, exp_avg_sq, lr} (flat tensors)
+            self.step_count = int(sd["step"]); self.m.copy_(sd["exp_avg"]); self.v.copy_(sd["exp_avg_sq"])
+            self.param_groups[0]["lr"] = sd.get("lr", self.lr)
+            return
+        step, hyper = torch_adam_state_to_flat(self.model.entries, sd, self.m, self.v)
+        self.step_count = step
+        self.param_groups[0]["lr"] = hyper.get("lr", self.lr)
+        self.betas = tuple(hyper.get("betas", self.betas)); self.eps = hyper.get("eps", self.eps)
+
+
+def _ref_layout(t, shape):
+    """flat packed slice -> tensor in the reference shape (conv weights are stored [K][Cout][Cin])"""
+    if len(shape) == 3:
+        t = t.reshape(shape[2], shape[0], shape[1]).permute(1, 2, 0)
+    return t.reshape(shape).contiguous()
+
+
+def flat_to_torch_adam_state(entries, m, v, step, lr, betas=(0.9, 0.999), eps=1e-8):
+    """{'state': {i: {'step', 'exp_avg', 'exp_avg_sq'}}, 'param_groups': [...]} exactly as torch.optim.Adam.state_dict() lays it out."""
+    state = {}
+    if step > 0:                       # torch creates per-parameter state lazily at the first step
+        for i, (_k, (o, n, shape)) in enumerate(entries.items()):
+            state[i] = {"step": torch.tensor(float(step)), "exp_avg": _ref_layout(m[o:o + n], shape).cpu().clone(),
+                        "exp_avg_sq": _ref_layout(v[o:o + n], shape).cpu().clone()}
+    group = {"lr": lr, "betas": tuple(betas), "eps": eps, "weight_decay": 0, "amsgrad": False, "maximize": False, "foreach": None,
+             "capturable": False, "differentiable": False, "fused": None, "decoupled_weight_decay": False,
+             "params": list(range(len(entries)))}
+    return {"state": state, "param_groups": [group]}
+
+
+def torch_adam_state_to_flat(entries, sd, m_out, v_out):
+    """Inverse of flat_to_torch_adam_state for a state_dict written by torch.optim.Adam (any torch version: `step` may be an int
+    or a tensor) or by this class.  Fills the flat moment buffers; returns (step, hyper-parameters of the single param group)."""
+    groups = sd["param_groups"]
+    if len(groups) != 1:
+        raise ValueError("the reference optimizers have a single param group")
+    g = groups[0]
+    if g.get("amsgrad") or g.get("weight_decay", 0) not in (0, 0.0) or g.get("maximize"):
+        raise NotImplementedError("Adam with amsgrad / weight_decay / maximize is not used by the reference (train_ldm.py:208)")
+    if len(g["params"]) != len(entries):
+        raise ValueError(f"optimizer state covers {len(g['params'])} parameters, the model has {len(entries)}")
+    state = sd["state"]
+    m_out.zero_(); v_out.zero_()
+    steps = set()
+    for pos, (k, (o, n, shape)) in enumerate(entries.items()):
+        st = state.get(g["params"][pos], state.get(str(g["params"][pos])))
+        if st is None:
+            continue                   # parameter that never received a gradient
+        for name, dst in (("exp_avg", m_out), ("exp_avg_sq", v_out)):
+            t = torch.as_tensor(st[name]).detach().to(torch.float32)
+            if tuple(t.shape) != tuple(shape):
+                raise ValueError(f"{k}: optimizer state shape {tuple(t.shape)} != parameter shape {tuple(shape)}")
+            if len(shape) == 3:
+                t = t.permute(2, 0, 1)
+            dst[o:o + n].copy_(t.reshape(-1).to(dst.device))
+        steps.add(int(float(st["step"])))
+    if len(steps) > 1:
+        raise ValueError(f"per-parameter step counts differ ({sorted(steps)}); the fused Adam keeps one step count")
+    return (steps.pop() if steps else 0), {k2: g[k2] for k2 in ("lr", "betas", "eps") if k2 in g}
 
 
 class GradScaler:

@@ -65,13 +65,15 @@ def rel_l2(a, b):
 # bf16 bounds are DERIVED, not guessed: `gap` = rel-L2 distance between the fp32 oracle and the same oracle with bf16 storage
 # emulated at every activation / activation-gradient / weight-read point (oracle/quant.py).  That is the error the storage
 # format alone causes when the summation order differs; an engine result must lie within BF16_GAP_FACTOR x gap of the fp32
-# oracle (plus a floor of a few bf16 ulps for tensors whose gap happens to be tiny).
+# oracle (plus a floor of a few bf16 ulps for tensors whose gap happens to be tiny).  Measured on MI355X (round 2): the
+# config_ldm UNet sits at 1.0-1.2 x gap on every one of its 278 gradients, the AutoencoderKL / discriminator at 1.0-1.8 x.
 BF16_GAP_FACTOR = 2.0
 BF16_FLOOR = 2.0 ** -7
+SMALL = 64          # tensors with fewer elements are judged pooled (see assert_bf16_grads)
 
 
-def bf16_gap_bound(gap, floor=BF16_FLOOR):
-    return max(BF16_GAP_FACTOR * gap, floor)
+def bf16_gap_bound(gap, floor=BF16_FLOOR, factor=BF16_GAP_FACTOR):
+    return max(factor * gap, floor)
 
 
 def grads_rel_errors(got, want, floor_frac):
@@ -83,3 +85,27 @@ def grads_rel_errors(got, want, floor_frac):
         w = torch.as_tensor(w).double().cpu()
         out[k] = float((got[k].double().cpu() - w).norm()) / (float(w.norm()) + floor_frac * gscale)
     return out
+
+
+def assert_bf16_grads(got, want32, wantq, label, floor_frac=2e-2, factor=BF16_GAP_FACTOR):
+    """Engine bf16 parameter gradients `got` against the fp32 oracle `want32`, bounded by the storage gap measured with the
+    bf16-storage oracle `wantq`.  Tensors of >= SMALL elements are bounded one by one.  For a tensor of a handful of elements
+    (a 2-channel GroupNorm scale) the gap is ONE draw of a very noisy quantity (the ratio of two such draws exceeds 3 in 10 % of
+    cases at 2 elements), so the small tensors are bounded POOLED (root-mean-square over all of them, ~100 elements in total)
+    and each of them only by a gross-error cap (a wrong tap or a double-counted bias is a 100 % error).  Returns a summary string."""
+    gap = grads_rel_errors(wantq, want32, floor_frac); err = grads_rel_errors(got, want32, floor_frac)
+    big = [k for k in err if want32[k].numel() >= SMALL]; small = [k for k in err if want32[k].numel() < SMALL]
+    worst = ("", 0.0, 0.0)
+    for k in big:
+        b = bf16_gap_bound(gap[k], factor=factor)
+        if err[k] / b > worst[1]:
+            worst = (k, err[k] / b, gap[k])
+        assert err[k] < b, f"{label} {k}: engine {err[k]:.3e} vs storage gap {gap[k]:.3e} (bound {b:.3e})"
+    msg = f"{label}: worst {worst[0]} at {worst[1]:.2f} of its bound (gap {worst[2]:.2e})"
+    if small:
+        pe = (sum(err[k] ** 2 for k in small) / len(small)) ** 0.5; pg = (sum(gap[k] ** 2 for k in small) / len(small)) ** 0.5
+        assert pe < bf16_gap_bound(pg, factor=factor), f"{label}: pooled small-tensor error {pe:.3e} vs pooled gap {pg:.3e}"
+        for k in small:
+            assert err[k] < max(8.0 * gap[k], 0.15), f"{label} {k}: engine {err[k]:.3e} vs storage gap {gap[k]:.3e} (gross-error cap)"
+        msg += f"; {len(small)} small tensors pooled {pe:.2e} (gap {pg:.2e})"
+    return msg

@@ -142,7 +142,8 @@ def test_native_sampler_matches_hostloop_and_oracle(B, pred):
     assert torch.equal(z2, z) and torch.equal(got2, got)
     got3, z3 = ddim_sample(unet, ae, sched, noise, scale_factor=0.7, crop=8, use_graph=False)
     got4, z4 = ddim_sample_hostloop(unet, ae, sched, noise, scale_factor=0.7, crop=8)
-    assert torch.equal(z3, z) and torch.equal(z4, z) and torch.equal(got3, got) and torch.equal(got4, got)
+    # (the host loop forms 1/scale_factor - 1 in double, the native call in float: the decoded windows agree to rounding, the latents exactly)
+    assert torch.equal(z3, z) and torch.equal(z4, z) and torch.equal(got3, got) and G.rel_l2(got4, got) < 1e-6
     # new weights must be picked up by the cached graph (it holds pointers, not values)
     unet.load_state_dict({k: v * 1.01 for k, v in usd.items()})
     z5 = ddim_sample(unet, ae, sched, noise, scale_factor=0.7, crop=8, use_graph=True)[1]

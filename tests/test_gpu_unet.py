@@ -32,28 +32,46 @@ def test_unet_vs_reference_golden(golden_dir, name, dtype):
     def rel_l2(a, b):
         a = a.detach().double().cpu().reshape(-1); b = torch.as_tensor(b).double().reshape(-1)
         return float((a - b).norm() / (b.norm() + 1e-12))
-    if f32:
-        G.assert_close(y, g["y"], rtol=1e-4, atol=2e-5, name="y")
-    assert rel_l2(y, g["y"]) < (1e-5 if f32 else 4e-2), f"y rel L2 {rel_l2(y, g['y']):.3e}"
+    dy = torch.from_numpy(normal(tuple(y.shape), seed=sdy))
     net.zero_grad()
-    dx = net.backward(torch.from_numpy(normal(tuple(y.shape), seed=sdy)), need_dx=True)
-    if f32:
-        G.assert_close(dx, g["dx"], rtol=1e-3, atol=2e-5, name="dx")
-    assert rel_l2(dx, g["dx"]) < (2e-5 if f32 else 8e-2), f"dx rel L2 {rel_l2(dx, g['dx']):.3e}"
+    dx = net.backward(dy, need_dx=True)
     grads = net.grad_dict()
+    if not f32:
+        # bf16 engine: bounds derived from the bf16-storage oracle (gpu_util.assert_bf16_grads), the fp32 oracle being pinned to the
+        # reference golden first -- replaces the round-1 constants (4e-2 / 8e-2 / 6e-2 / 0.12)
+        from oracle import quant as Q, unet as U
+        sd = {k: torch.from_numpy(gen_param(sw, k, shape)) for k, (_o, _n, shape) in net.entries.items()}
+        def run(emul):
+            p = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+            xr = x.clone().requires_grad_(True)
+            with Q.bf16_storage(emul):
+                yo = U.unet_forward(p, cfg, xr, torch.from_numpy(g["t"]))
+                yo.backward(dy)
+            return yo.detach(), xr.grad, {k: v.grad for k, v in p.items()}
+        y32, dx32, g32 = run(False); yq, dxq, gq = run(True)
+        np.testing.assert_allclose(y32.numpy(), g["y"], rtol=1e-4, atol=2e-5)
+        assert rel_l2(y, y32) < G.bf16_gap_bound(rel_l2(yq, y32)) and rel_l2(dx, dx32) < G.bf16_gap_bound(rel_l2(dxq, dx32)), \
+            (rel_l2(y, y32), rel_l2(yq, y32), rel_l2(dx, dx32), rel_l2(dxq, dx32))
+        print(f"{name} bf16: y {rel_l2(y, y32):.2e} (gap {rel_l2(yq, y32):.2e}) dx {rel_l2(dx, dx32):.2e} (gap {rel_l2(dxq, dx32):.2e});",
+              G.assert_bf16_grads(grads, g32, gq, name))
+        return
+    G.assert_close(y, g["y"], rtol=1e-4, atol=2e-5, name="y")
+    assert rel_l2(y, g["y"]) < 1e-5, f"y rel L2 {rel_l2(y, g['y']):.3e}"
+    G.assert_close(dx, g["dx"], rtol=1e-3, atol=2e-5, name="dx")
+    assert rel_l2(dx, g["dx"]) < 2e-5, f"dx rel L2 {rel_l2(dx, g['dx']):.3e}"
     # gradients that are mathematically ~0 (a bias in front of a 1-channel-per-group GroupNorm) are pure rounding noise:
-    # errors are measured against the tensor's own norm plus 1e-3 (fp32) / 3e-2 (bf16) of the model-wide gradient scale
+    # errors are measured against the tensor's own norm plus 1e-3 of the model-wide gradient scale
     gscale = max(float(g["g_l2:" + k]) for k in net.entries)
     worst = 0.0
     for k in net.entries:
         gr = grads[k].double().reshape(-1).cpu()
-        l2 = float(g["g_l2:" + k]); n = gr.numel()
-        floor = (1e-3 if f32 else 3e-2) * gscale
+        l2 = float(g["g_l2:" + k])
+        floor = 1e-3 * gscale
         rel = abs(float(gr.norm()) - l2) / (l2 + floor)
         head = g["g_head:" + k].astype(np.float64)
         head_err = float(np.linalg.norm(gr[:32].numpy() - head)) / (float(np.linalg.norm(head)) + floor)
         worst = max(worst, rel, head_err)
-        assert rel < (1e-3 if f32 else 6e-2) and head_err < (1e-3 if f32 else 0.12), f"{k}: |g| rel err {rel:.2e}, head err {head_err:.2e}"
+        assert rel < 1e-3 and head_err < 1e-3, f"{k}: |g| rel err {rel:.2e}, head err {head_err:.2e}"
     print(f"{name} {dtype}: y relL2 {rel_l2(y, g['y']):.2e} dx relL2 {rel_l2(dx, g['dx']):.2e} worst param-grad error {worst:.2e}")
 
 
