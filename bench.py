@@ -1,7 +1,9 @@
 """Headline benchmark: 30-s EEG windows/sec on the hot path (BASELINE.json metric).
 
-    python bench.py --gpus N --steps K --warmup W            (N=1)
-    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...   (N>1)
+    python bench.py --gpus N --steps K --warmup W
+        N = 1 runs in this process; N > 1 without a torch.distributed.run environment re-executes itself as
+        `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py ...`
+        (one rank per GPU over RCCL); launched under torch.distributed.run directly it reads RANK / LOCAL_RANK / WORLD_SIZE.
 
 A "step" is one LDM train step of the reference loop (/root/reference/src/training/training.py:419-443)
 on one synthetic batch of raw (B,1,3072) windows per GPU: draw timesteps + noise + eps on device, frozen
@@ -14,8 +16,11 @@ around every launch of the dominant kernel class on the library's stream; `cpu_b
 oracle (torch CPU fp32, same math) on this host's cores on a bounded sample (rank 0, N=1 only).
 """
 import argparse
+import hashlib
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -27,12 +32,67 @@ for p in (ROOT, os.path.join(ROOT, "tests", "golden")):
 UNET_CFG = dict(image_size=768, in_channels=1, out_channels=1, model_channels=128, num_res_blocks=2,
                 attention_resolutions=[8, 4], channel_mult=[1, 2, 4], resblock_updown=True)   # config_ldm.yaml:30-43, latent_channels=1
 MFMA_PEAK_TFLOPS = {"bf16": 2500.0, "f32": 157.3}     # dense, /opt/skills/guides/MI355X_MICROARCH.md
+HBM_PEAK_GBS = 8000.0                                  # HBM3E spec peak (same guide; ~6.3 TB/s is what a streaming kernel reaches)
+PKG = os.path.join(ROOT, "synthetic-sleep-eeg-signal-generation-using-latent-diffusion-models_amd")
+
+
+def kernel_source_hash():
+    """sha256 over csrc/*.hip|*.h: the PMC summaries under profiles/ carry the hash of the build they were collected on, so a
+    stale counter file is flagged instead of silently reported."""
+    h = hashlib.sha256()
+    d = os.path.join(PKG, "csrc")
+    for f in sorted(os.listdir(d)):
+        if f.endswith((".hip", ".h")):
+            h.update(f.encode()); h.update(open(os.path.join(d, f), "rb").read())
+    return h.hexdigest()[:16]
+
+
+def load_pmc(name):
+    """profiles/<name> -> (dict, stale flag) or (None, None)."""
+    try:
+        j = json.load(open(os.path.join(ROOT, "profiles", name)))
+        return j, (j.get("kernel_source_sha16") != kernel_source_hash())
+    except Exception:
+        return None, None
+
+
+# ---------------------------------------------------------------- algorithmic byte model (SURVEY.md 8d; DESIGN.md 6)
+def aekl_gan_step_bytes(num_channels, L, s, n_res=2, d_ch=64, d_layers=3):
+    """Algorithmic HBM bytes of ONE window through the AEKL/GAN train step, by the survey's layer-granular formula
+    bytes_fwd = sum_conv (|in| + |out|) s + sum_norm/act 2 |in| s (+ parameters, negligible per window);
+    bytes_step = 3 x bytes_fwd of everything that runs forward AND backward: the autoencoder once, the discriminator three
+    times (generator pass, fake, real).  s = storage bytes per activation element."""
+    def res(c_in, c_out, l):
+        e = 2 * c_in * l + (c_in + c_out) * l + 2 * c_out * l + 2 * c_out * l      # norm1, conv1, norm2, conv2
+        return e + ((c_in + c_out) * l if c_in != c_out else 0)
+    nc = list(num_channels)
+    e, l, c = (1 + nc[0]) * L, L, nc[0]                                              # encoder conv_in
+    for i, co in enumerate(nc):
+        for _ in range(n_res):
+            e += res(c, co, l); c = co
+        if i != len(nc) - 1:
+            e += c * l + c * l // 2; l //= 2
+    e += 2 * c * l + (c + 1) * l + 2 * 2 * l                                         # norm, conv -> latent, mu / log-sigma heads
+    e += 2 * l + (1 + c) * l                                                         # decoder: post_quant, conv_in
+    for i, co in enumerate(reversed(nc)):
+        for _ in range(n_res):
+            e += res(c, co, l); c = co
+        if i != len(nc) - 1:
+            e += c * l + c * 2 * l + 2 * c * 2 * l; l *= 2                           # nearest x2 + conv
+    e += 2 * c * l + (c + 1) * l
+    ae = e
+    d, l, c = L + d_ch * L // 2 + 2 * d_ch * L // 2, L // 2, d_ch                   # conv s2 + LeakyReLU
+    for j in range(d_layers):
+        st = 1 if j == d_layers - 1 else 2
+        d += c * l + 2 * c * (l // st) + 2 * 2 * c * (l // st); l //= st; c *= 2     # conv + BatchNorm/LeakyReLU
+    d += (c + 1) * l
+    return 3 * s * (ae + 3 * d)
 
 
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=256, help="windows per GPU per step (C4: 2048 / 8 GPUs)")
     ap.add_argument("--length", type=int, default=768, help="latent length (3072 / 4)")
@@ -43,34 +103,115 @@ def parse():
     return ap.parse_args()
 
 
-def cpu_baseline(batch=8, length=768, steps=2):
-    """Oracle LDM train step (fp32, torch CPU ops + autograd + torch.optim-style Adam) on a bounded sample."""
+def _cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def _physical_cores():
+    try:
+        import psutil
+        return psutil.cpu_count(logical=False) or (os.cpu_count() or 2) // 2
+    except Exception:
+        return max(1, (os.cpu_count() or 2) // 2)
+
+
+def cpu_baseline(budget_s=100.0):
+    """The oracle (torch CPU fp32: same math as the engine, pinned to the reference goldens) on this host's cores, protocol of
+    BASELINE.md 3 / SURVEY 8d: 3 warm-up + 10 timed steps, median; thread count chosen by a short sweep over
+    {8, 16, 32, 64, physical cores} (2 steps each) because oversubscribing torch's intra-op pool made round 1's number 3.5x too
+    slow.  Headline leg = the LDM train step (B = 8); the other BASELINE workloads ride along as `legs` while budget_s lasts."""
     import torch
+    from oracle import aekl as A
     from oracle import losses as Ls
     from oracle import steps as S
     from oracle import unet as U
-    from param_gen import gen_param, normal, timesteps
-    cores = max(1, (os.cpu_count() or 2) // 2)
-    torch.set_num_threads(cores)
+    from param_gen import eeg_windows, gen_param, normal, timesteps
+    t_start = time.time()
+    phys = _physical_cores()
     cfg = dict(UNET_CFG)
     sd = {k: torch.from_numpy(gen_param(42, k, s)) for k, s in U.unet_param_shapes(cfg).items()}
-    acp = Ls.alphas_cumprod("scaled_linear_beta", 1000, 0.0015, 0.0195)
-    lat, nz = torch.from_numpy(normal((batch, 1, length), seed=1)), torch.from_numpy(normal((batch, 1, length), seed=2))
-    t = torch.from_numpy(timesteps(batch, seed=3))
-    state = {}
-    times = []
-    for i in range(steps + 1):
-        t0 = time.time()
-        _loss, grads, _ = S.ldm_train_step(sd, cfg, acp, lat, nz, t)
-        sd = S.adam_update(sd, grads, state, 1e-4, i + 1)
-        times.append(time.time() - t0)
-    dt = sorted(times[1:])[len(times[1:]) // 2]
-    return {"value": batch / dt, "unit": "windows/s", "cores": cores, "kind": "port",
-            "sample": f"oracle LDM train step (UNet config_ldm fwd+bwd+Adam, fp32), batch {batch} x (1,{length}), median of {steps} steps after 1 warm-up"}
+    acp = Ls.alphas_cumprod("linear_beta", 1000, 0.0015, 0.0195)
+
+    def ldm_step_fn(batch, length):
+        lat, nz = torch.from_numpy(normal((batch, 1, length), seed=1)), torch.from_numpy(normal((batch, 1, length), seed=2))
+        t = torch.from_numpy(timesteps(batch, seed=3))
+        c = dict(cfg, image_size=length)
+        st = {"sd": dict(sd), "opt": {}, "i": 0}
+        def f():
+            _l, grads, _ = S.ldm_train_step(st["sd"], c, acp, lat, nz, t)
+            st["i"] += 1
+            st["sd"] = S.adam_update(st["sd"], grads, st["opt"], 1e-4, st["i"])
+        return f
+
+    def timed(f, warm, n):
+        for _ in range(warm):
+            f()
+        ts = []
+        for _ in range(n):
+            t0 = time.time(); f(); ts.append(time.time() - t0)
+        return sorted(ts)[len(ts) // 2], ts
+
+    f8 = ldm_step_fn(8, 768)
+    sweep = {}
+    for nt in sorted({n for n in (8, 16, 32, 64, phys) if n <= max(phys, 8)}):
+        torch.set_num_threads(nt)
+        sweep[nt] = round(8 / timed(f8, 1, 2)[0], 2)
+    best = max(sweep, key=sweep.get)
+    torch.set_num_threads(best)
+    med, _ = timed(f8, 3, 10)
+    out = {"value": round(8 / med, 3), "unit": "windows/s", "cores": best, "kind": "port", "cpu_model": _cpu_model(), "physical_cores": phys,
+           "thread_sweep_windows_per_s": sweep,
+           "sample": "oracle LDM train step (config_ldm UNet fwd+bwd+Adam, fp32), batch 8 x (1,768), 3 warm-up + 10 timed steps, median",
+           "legs": {}}
+    legs = out["legs"]
+
+    def leg(name, fn, batch, warm, n, note):
+        if time.time() - t_start > budget_s:
+            legs[name] = {"skipped": "cpu budget"}
+            return
+        m, ts = timed(fn, warm, n)
+        legs[name] = {"windows_per_s": round(batch / m, 3), "batch": batch, "steps_timed": len(ts), "sample": note}
+
+    # C1: AEKL GAN step, channels [32,32,64], B = 32 (config_aekl_eeg.yaml)
+    acfg = dict(num_channels=[32, 32, 64], latent_channels=1, in_channels=1, out_channels=1, num_res_blocks=2, norm_num_groups=1)
+    dcfg = dict(spatial_dims=1, num_layers_d=3, num_channels=64, in_channels=1, out_channels=1, kernel_size=3, norm="BATCH", bias=False, padding=1)
+    st = {"ae": {k: torch.from_numpy(gen_param(42, k, s)) for k, s in A.aekl_param_shapes(acfg).items()},
+          "d": {k: torch.from_numpy(gen_param(43, k, s)) for k, s in A.disc_param_shapes(dcfg).items()}, "og": {}, "od": {}, "i": 0}
+    xw = torch.from_numpy(eeg_windows(32, seed=1234)); ew = torch.from_numpy(normal((32, 1, 768), seed=1236))
+    def aekl_fn():
+        st["i"] += 1
+        _l, st["ae"], st["d"], _r, _g, _d = S.aekl_train_step(st["ae"], acfg, st["d"], dcfg, xw, ew, 0.01, 1e-6, 1e4, True, 5e-3, 5e-4, st["i"], st["og"], st["od"])
+    leg("aekl_gan_train_step_c1", aekl_fn, 32, 2, 5, "oracle AEKL [32,32,64] + PatchDiscriminator GAN step incl. spectral loss and both Adam updates, B = 32")
+    # C5: pixel-space DM step, B = 2, L = 3072
+    leg("pixel_dm_train_step", ldm_step_fn(2, 3072), 2, 2, 5, "oracle UNet train step on (2,1,3072), epsilon MSE + Adam")
+    # C3: DDIM-50 + decode, B = 8
+    def ddim_fn():
+        S.ddim_sample(sd, cfg, st["ae"], acfg, torch.from_numpy(normal((8, 1, 768), seed=5)), 50, Ls.alphas_cumprod("scaled_linear_beta", 1000, 0.0015, 0.0205))
+    leg("ddim50_sample_decode", ddim_fn, 8, 0, 1, "oracle DDIM-50 (50 UNet forwards) + decode [32,32,64], B = 8, one run")
+    out["seconds_spent"] = round(time.time() - t_start, 1)
+    return out
+
+
+def respawn_under_torchrun(args):
+    """`python bench.py --gpus N` with N > 1 and no rendezvous environment: start N ranks through torch.distributed.run."""
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0)); port = so.getsockname()[1]
+    env = dict(os.environ); env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd, env=env)
 
 
 def main():
     args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(respawn_under_torchrun(args))
     import torch
     import eegldm
     from eegldm import distributed as D
@@ -81,7 +222,7 @@ def main():
     from param_gen import eeg_windows
 
     rank, local, world = D.init_from_env()
-    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world} (launch with torch.distributed.run)"
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
     torch.cuda.set_device(local)
     ctx = eegldm.default_context(local)
     dev = torch.device("cuda", local)
@@ -94,7 +235,7 @@ def main():
     # random-init weights of the named architecture; zero-initialised layers get N(0, 0.02) so no work is trivially zero
     unet.load_state_dict({k: (torch.randn(v.shape, generator=g) * 0.02 if float(v.abs().sum()) == 0.0 else v) for k, v in sd.items()})
     D.broadcast_flat(unet.flat); unet.sync_weights()
-    sched = DDPMScheduler(num_train_timesteps=1000, schedule="scaled_linear_beta", beta_start=0.0015, beta_end=0.0195, device=local)
+    sched = DDPMScheduler(num_train_timesteps=1000, schedule="linear_beta", beta_start=0.0015, beta_end=0.0195, device=local)   # train_ldm.py:199-200
     opt = Adam(unet, lr=1e-4)
     loss = torch.zeros(1, device=dev)
     # frozen stage-1 autoencoder (production channels [32,32,64], latent 1: clusters/run_aekl_shhs_1.sh:8-10)
@@ -105,7 +246,7 @@ def main():
     windows = torch.from_numpy(eeg_windows(B, seed=1234 + rank, length=4 * L)).to(dev)
     scale_factor = 1.0 / float(ae.encode_stage_2_inputs(windows, eps=randn(ctx, (B, 1, L), seed=99)).std())   # train_ldm.py:203-204
 
-    gsync = D.OverlappedGradSync(unet.flat_grad) if world > 1 else None
+    gsync = D.OverlappedGradSync(unet.flat_grad, ctx=ctx) if world > 1 else None
 
     def step(i, sync=True):
         t = randint(ctx, B, 1000, seed=1235 + rank, offset=i * B)
@@ -150,26 +291,25 @@ def main():
         k, v = dom
         ach = v["flops"] / (v["ms"] * 1e-3) / 1e12 if v["ms"] > 0 else 0.0
         peak = MFMA_PEAK_TFLOPS[args.dtype]
-        # HBM bytes per launch of this kernel class from the committed PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in
-        # separate runs of the same step, tools/pmc_traffic.py; FETCH_SIZE doubled per the gfx950 note in the guide)
-        traffic, traffic_src = None, None
-        try:
-            pj = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_pmc_hbm_traffic.json")
-            if args.dtype == "bf16" and args.batch == 256:
-                traffic = round(json.load(open(pj))["classes"][k]["hbm_bytes_per_launch"])
-                traffic_src = "profiles/r01_pmc_hbm_traffic.json (bytes per launch, B=256 bf16)"
-        except Exception:
-            pass
-        # MFMA-busy share of the same class from the committed SQ counter pass (profiles/r01_pmc_mfma_busy.json)
-        mfma_util = None
-        try:
-            pm = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_pmc_mfma_busy.json")
-            if args.dtype == "bf16" and args.batch == 256:
-                mfma_util = json.load(open(pm))["classes"][k]["MfmaUtil_pct"]
-        except Exception:
-            pass
+        # HBM bytes per launch of this kernel class and its MFMA-busy share come from separate rocprofv3 --pmc passes over this same
+        # step (tools/pmc_traffic.py / tools/pmc_collect.sh -> profiles/r02_pmc_*.json; FETCH_SIZE doubled per the gfx950 note in the
+        # guide).  Counters cannot be read from inside the timed process, so the files carry the hash of the kernel sources they
+        # were collected on and `traffic_stale` says whether that is still the build being timed.
+        traffic, traffic_src, traffic_stale, mfma_util = None, None, None, None
+        if args.dtype == "bf16" and args.batch == 256:
+            for fname in ("r02_pmc_hbm_traffic.json", "r01_pmc_hbm_traffic.json"):
+                pj, stale = load_pmc(fname)
+                if pj and k in pj.get("classes", {}):
+                    traffic = round(pj["classes"][k]["hbm_bytes_per_launch"]); traffic_stale = bool(stale)
+                    traffic_src = f"profiles/{fname} (bytes per launch, B=256 bf16)"
+                    break
+            for fname in ("r02_pmc_mfma_busy.json", "r01_pmc_mfma_busy.json"):
+                pm, _st = load_pmc(fname)
+                if pm and k in pm.get("classes", {}):
+                    mfma_util = pm["classes"][k]["MfmaUtil_pct"]
+                    break
         roofline = {"bound": "mfma", "kernel": k, "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4),
-                    "traffic": traffic, "traffic_source": traffic_src, "mfma_busy_pct_pmc": mfma_util,
+                    "traffic": traffic, "traffic_source": traffic_src, "traffic_stale": traffic_stale, "mfma_busy_pct_pmc": mfma_util,
                     "event_bracket_overhead_us_subtracted": round(ctx.prof_bracket_overhead_us(), 2), "launches_per_step": v["launches"] // 2, "avg_launch_us": round(1e3 * v["ms"] / max(1, v["launches"]), 2),
                     "gflop_per_launch": round(v["flops"] / max(1, v["launches"]) / 1e9, 3),
                     "all_gemm_classes": {kk: {"tflops": round(vv["flops"] / (vv["ms"] * 1e-3) / 1e12, 1) if vv["ms"] > 0 else 0.0,
@@ -202,18 +342,45 @@ def main():
         for i in range(n_gan):
             gan_step(2 + i)
         torch.cuda.synchronize(); dtg = (time.time() - t1) / n_gan
+        esz = 2 if args.dtype == "bf16" else 4
+        abytes = aekl_gan_step_bytes([2, 2, 4], 4 * L, esz) * Ba + 16 * (int(ae2.flat.numel()) + int(disc.flat.numel()))
+        hbm_ach = abytes / dtg / 1e9
+        pj, stale = load_pmc("r02_pmc_aekl_step.json")
         parts["aekl_gan_train_step"] = {"windows_per_s": round(Ba / dtg, 1), "ms_per_step": round(1e3 * dtg, 3), "batch": Ba,
+                                        "roofline": {"bound": "hbm", "achieved": round(hbm_ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                                     "frac": round(hbm_ach / HBM_PEAK_GBS, 4),
+                                                     "algorithmic_bytes_per_step": int(abytes), "algorithmic_MB_per_window": round(abytes / Ba / 1e6, 2),
+                                                     "traffic": (round(pj["hbm_bytes_per_step"]) if pj else None),
+                                                     "traffic_source": ("profiles/r02_pmc_aekl_step.json (FETCH_SIZE x2 + WRITE_SIZE summed over the step's kernels)" if pj else None),
+                                                     "traffic_stale": (bool(stale) if pj else None),
+                                                     "flops_view": {"gflop_per_window": 3.76, "achieved_tflops": round(3.76e9 * Ba / dtg / 1e12, 1),
+                                                                    "frac_of_mfma_peak": round(3.76e9 * Ba / dtg / 1e12 / MFMA_PEAK_TFLOPS[args.dtype], 4)}},
                                         "config": "config_aekl_eeg_2_2_4_spec.yaml: AutoencoderKL [2,2,4] + PatchDiscriminator(64, 3 layers) + "
                                                   "L1 + KL + LSGAN + spectral(1e4), Adam 5e-3 / 5e-4",
                                         "losses": [round(float(v), 5) for v in lo.cpu()]}
         Bs = min(args.batch, 256)
         sch = make_sampling_scheduler(50, device=local)
         nz = randn(ctx, (Bs, 1, L), seed=4242)
-        ddim_sample(unet, ae, sch, nz[:8], scale_factor=scale_factor)      # warm-up
+        info = {}
+        ddim_sample(unet, ae, sch, nz, scale_factor=scale_factor, info=info)      # warm-up (captures the hipGraph of the UNet forward for this batch)
         torch.cuda.synchronize(); t1 = time.time()
         out, _ = ddim_sample(unet, ae, sch, nz, scale_factor=scale_factor)
         torch.cuda.synchronize(); dts = time.time() - t1
+        # the reference samples ONE window per call (sample_trials.py:149-163): latency of that mode, graph replay vs eager launches
+        lat = {}
+        for mode, ug in (("graph", True), ("eager", False)):
+            ddim_sample(unet, ae, sch, nz[:1], scale_factor=scale_factor, use_graph=ug)
+            torch.cuda.synchronize(); t1 = time.time()
+            for _ in range(3):
+                ddim_sample(unet, ae, sch, nz[:1], scale_factor=scale_factor, use_graph=ug)
+            torch.cuda.synchronize(); lat[mode] = (time.time() - t1) / 3
+        ddim_tf = 695.3e9 * Bs / dts / 1e12
         parts["ddim50_sample_decode"] = {"windows_per_s": round(Bs / dts, 1), "seconds": round(dts, 3), "batch": Bs, "steps": 50,
+                                         "native_sampler": True, "hipgraph": bool(info.get("graph")),
+                                         "roofline": {"bound": "mfma", "achieved": round(ddim_tf, 1), "peak": MFMA_PEAK_TFLOPS[args.dtype], "unit": "TFLOP/s",
+                                                      "frac": round(ddim_tf / MFMA_PEAK_TFLOPS[args.dtype], 4)},
+                                         "batch1_latency_ms": {k2: round(1e3 * v2, 2) for k2, v2 in lat.items()},
+                                         "batch1_windows_per_s": round(1.0 / lat["graph"], 2),
                                          "config": "config_ldm.yaml UNet, DDIM-50 (scaled-linear 0.0015-0.0205, eta 0), decode [32,32,64], crop to 3000",
                                          "out_shape": list(out.shape), "gflop_per_window": 695.3}
 
@@ -246,7 +413,10 @@ def main():
         for i in range(n_dm):
             dm_step(2 + i)
         torch.cuda.synchronize(); dtd = (time.time() - t1) / n_dm
+        dm_tf = 183.0e9 * Bd / dtd / 1e12
         parts["pixel_dm_train_step"] = {"windows_per_s": round(Bd / dtd, 1), "ms_per_step": round(1e3 * dtd, 3), "batch": Bd,
+                                        "roofline": {"bound": "mfma", "achieved": round(dm_tf, 1), "peak": MFMA_PEAK_TFLOPS[args.dtype], "unit": "TFLOP/s",
+                                                     "frac": round(dm_tf / MFMA_PEAK_TFLOPS[args.dtype], 4)},
                                         "config": "config_dm.yaml UNet on raw (B,1,3072) windows (T=768 attention), epsilon MSE + 1e-6 x spectral, "
                                                   "Adam 1e-4; per-GPU batch 64 = global 512 / 8 [BASELINE configs[4]]",
                                         "final_loss": round(float(ldm), 5), "gflop_per_window": 183.0}
@@ -265,7 +435,7 @@ def main():
                                    "[BASELINE configs[2]/[3]: per-GPU batch 256 = global 2048 / 8]",
                        "per_gpu_batch": B, "global_batch": world * B, "latent_len": L, "parallelism": f"dp{world}",
                        "final_loss": round(final_loss, 5), "gflop_per_window": 41.9},
-            "roofline": roofline, "cpu_baseline": cpu, "parts": parts,
+            "roofline": roofline, "cpu_baseline": cpu, "parts": parts, "kernel_source_sha16": kernel_source_hash(),
         }
         print(json.dumps(out))
     if world > 1:

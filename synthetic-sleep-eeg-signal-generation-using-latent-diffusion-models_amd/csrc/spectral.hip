@@ -10,8 +10,9 @@
 //     64-point DFTs along the rows) with a sin/cos table of the N-th roots in LDS -- ~112 complex
 //     MACs per output, negligible next to the autoencoder, exact to fp32 rounding, no bit reversal.
 //   * gradient: dL/d recon[n] = Re FFT_ortho(G)[n], G[k] = 2(A_k - B_k) conj(R_k)/A_k
-//     (G_k := 0 where A_k is zero to rounding, A_k^2 <= 1e-10 (A_k^2 + B_k^2): the two spectra are separated from ONE packed FFT, so
-//      an exactly-zero A_k comes out as ~1e-7 |Z_k| of rounding noise whose phase is meaningless; torch produces NaN there --
+//     (G_k := 0 where A_k is zero to rounding, A_k^2 <= 1e-10 x the window's mean bin power: the two spectra are separated from
+//      ONE packed fp32 FFT, so an exactly-zero A_k comes out as rounding noise of ~1e-7 of the spectrum's rms amplitude with a
+//      meaningless phase; torch produces NaN there --
 //      README.md:17 notes that instability.  Deviation stated in INTEGRATION.md, tested in tests/test_gpu_aekl.py).
 // HBM traffic = the two windows in, one gradient window out: HBM-bound, ~36 KB per window.
 #include "common.h"
@@ -72,12 +73,18 @@ __global__ __launch_bounds__(NT) void spectral_kernel(const float* __restrict__ 
   __shared__ float red[4];
   const long base = (long)blockIdx.x * N;
   const float scale = rsqrtf((float)N);
+  float en = 0.f;
   for (int j = threadIdx.x; j < N; j += NT) {
     float s, c; sincospif(-2.0f * (float)j / (float)N, &s, &c);
     tw[j] = make_float2(c, s);
-    bufA[j] = make_float2(recon[base + j], target[base + j]);
+    const float2 z = make_float2(recon[base + j], target[base + j]);
+    bufA[j] = z; en += z.x * z.x + z.y * z.y;
   }
+  en = wave_sum(en);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = en;
   __syncthreads();
+  // Parseval (ortho norm): sum_k |Z_k|^2 = sum_n |z_n|^2, so this is 1e-10 x the mean power of a bin
+  const float zero_thr = 1e-10f * (red[0] + red[1] + red[2] + red[3]) / (float)N;
   F::run(bufA, bufX, bufY, tw);
   float part = 0.f;
   for (int k = threadIdx.x; k < N; k += NT) {
@@ -87,10 +94,11 @@ __global__ __launch_bounds__(NT) void spectral_kernel(const float* __restrict__ 
     const float A = sqrtf(rr * rr + ri * ri), Bm = sqrtf(tr * tr + ti * ti);
     const float d = A - Bm;
     part += d * d;
-    const float g = (A * A > 1e-10f * (A * A + Bm * Bm)) ? 2.0f * d / A : 0.f;
+    const float g = (A * A > zero_thr) ? 2.0f * d / A : 0.f;
     bufA[k] = make_float2(g * rr, -g * ri);      // G_k = 2(A-B) conj(R_k)/A
   }
   part = wave_sum(part);
+  __syncthreads();                       // red[] was read for zero_thr above
   if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = part;
   __syncthreads();
   if (threadIdx.x == 0) atomicAdd(loss, red[0] + red[1] + red[2] + red[3]);

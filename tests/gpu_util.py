@@ -104,7 +104,8 @@ def assert_bf16_grads(got, want32, wantq, label, floor_frac=2e-2, factor=BF16_GA
     msg = f"{label}: worst {worst[0]} at {worst[1]:.2f} of its bound (gap {worst[2]:.2e})"
     if small:
         pe = (sum(err[k] ** 2 for k in small) / len(small)) ** 0.5; pg = (sum(gap[k] ** 2 for k in small) / len(small)) ** 0.5
-        assert pe < bf16_gap_bound(pg, factor=factor), f"{label}: pooled small-tensor error {pe:.3e} vs pooled gap {pg:.3e}"
+        if sum(want32[k].numel() for k in small) >= SMALL:       # a pool of a few elements is as noisy as its members: gross cap only
+            assert pe < bf16_gap_bound(pg, factor=factor), f"{label}: pooled small-tensor error {pe:.3e} vs pooled gap {pg:.3e}"
         for k in small:
             assert err[k] < max(8.0 * gap[k], 0.15), f"{label} {k}: engine {err[k]:.3e} vs storage gap {gap[k]:.3e} (gross-error cap)"
         msg += f"; {len(small)} small tensors pooled {pe:.2e} (gap {pg:.2e})"
