@@ -158,6 +158,7 @@ def cpu_baseline(budget_s=100.0):
         return sorted(ts)[len(ts) // 2], ts
 
     f8 = ldm_step_fn(8, 768)
+    f8(); f8()                 # first-touch / allocator warm-up outside the sweep
     sweep = {}
     for nt in sorted({n for n in (8, 16, 32, 64, phys) if n <= max(phys, 8)}):
         torch.set_num_threads(nt)

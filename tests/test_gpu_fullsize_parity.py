@@ -185,12 +185,19 @@ def test_fused_aekl_gan_step_config_2_2_4_spec(dtype):
                 for nm, got, want, wq in (("G", ae.grad_dict(), gg32, ggq), ("D", disc.grad_dict(), dg32, dgq)):
                     print("C2 fused step bf16", G.assert_bf16_grads(got, want, wq, nm, floor_frac=3e-2, factor=2.5))
         og.step(); od.step()
-    # after two Adam steps: parameters in units of lr (see test_gpu_aekl.py), BatchNorm counters exact, running statistics close
+    # after two Adam steps: parameters in units of lr (see test_gpu_aekl.py).  Adam normalises every gradient to ~+-lr, so an element
+    # whose true gradient is rounding noise may move by up to 2 lr against the oracle; the mean deviation is therefore taken over the
+    # whole model (934 / 519 681 elements), not per tensor (a [2,2,4] GroupNorm scale has 2 elements).
     got = ae.state_dict()
+    devs = []
     for k, v in ae32.items():
         d = (got[k].cpu() - v).abs()
-        assert float(d.max()) < 2.5 * 5e-3 and float(d.mean()) < (0.05 if f32 else 0.5) * 5e-3, f"ae {k}: max {float(d.max()):.3e} mean {float(d.mean()):.3e}"
+        assert float(d.max()) < (2.5 if f32 else 4.1) * 5e-3, f"ae {k}: max {float(d.max()):.3e}"     # 4 lr = two steps in opposite directions
+        devs.append(d.reshape(-1))
+    mean_dev = float(torch.cat(devs).mean())
+    assert mean_dev < (0.05 if f32 else 0.25) * 5e-3, f"ae mean |dp| {mean_dev:.3e}"
     gotd = disc.state_dict()
+    devs = []
     for k, v in d32.items():
         if "num_batches" in k:
             assert int(gotd[k]) == 6
@@ -198,4 +205,7 @@ def test_fused_aekl_gan_step_config_2_2_4_spec(dtype):
             assert G.rel_l2(gotd[k], v) < (1e-4 if f32 else 3e-2), k
         else:
             d = (gotd[k].cpu().float() - v.float()).abs()
-            assert float(d.max()) < 2.5 * 5e-4 and float(d.mean()) < (0.05 if f32 else 0.5) * 5e-4, f"disc {k}: max {float(d.max()):.3e} mean {float(d.mean()):.3e}"
+            assert float(d.max()) < (2.5 if f32 else 4.1) * 5e-4, f"disc {k}: max {float(d.max()):.3e}"
+            devs.append(d.reshape(-1))
+    mean_dev = float(torch.cat(devs).mean())
+    assert mean_dev < (0.05 if f32 else 0.25) * 5e-4, f"disc mean |dp| {mean_dev:.3e}"
