@@ -133,6 +133,7 @@ struct GemmArgs {
   int atomic_out;        // C += result via float atomics (requires out_f32)
   float k_skew;          // split-K with atomic output: K chunk lengths grow linearly from (1-k_skew) to (1+k_skew) of the mean (0 = equal)
   float* colsum;         // GA_TR, 16-bit operands, batch 1: colsum[m] += sum_k A[k][m] (bias gradient of a conv whose dY is A), or null
+  int wide_n;            // fused 3-tap weight gradient: use the 128-wide N tile (one block per CU)
   int xcd_swizzle;       // set by the launcher: XCD-aware tile order (see gemm_kernel)
   const void* zero_page; // >= 16 zero bytes in device memory (set by gemm_launch)
 };

@@ -118,7 +118,14 @@ struct Cfg {
   static constexpr int WM = (WMT == 3) ? 2 : WMT;                 // waves along M (2 along N)
   static constexpr int FM = (WMT == 3) ? 6 : 4;                   // 16-row fragments per wave along M
   static constexpr int BM = WM * FM * 16;                         // block rows
-  static constexpr int NW = 2 * WM;                               // waves per block
+  // waves along N: 2, except the wide fused 3-tap weight-gradient tile (AMODE = BMODE = TR, TAPS = 3, BN = 128): FOUR, i.e. one 8-wave
+  // block per CU computing 128 x 128 x 3 taps.  It is two of the 128 x 64 blocks that used to share a CU merged into one: the dY
+  // tile is staged once instead of twice (33 KB instead of 49 KB per stage pair through the L2->LDS path that bounds the K loop) at
+  // the same 2 waves per SIMD and 96 accumulator registers per lane.  (One 4-wave block per CU with 192 accumulators was 12 % SLOWER
+  // than the 128 x 64 tile: with a single wave per SIMD nothing covers the 60-180 cycles each LDS-DMA instruction blocks its issuer.)
+  static constexpr int WN = (AMODE == GA_TR && BMODE == GB_TR && TAPS == 3 && BN == 128) ? 4 : 2;
+  static constexpr int BNW = BN / WN;                             // columns per wave
+  static constexpr int NW = WN * WM;                              // waves per block
   static constexpr int NTHREADS = 64 * NW;
   static constexpr int KC = Tr<T>::KC;
   static constexpr int EPC = Tr<T>::EPC;
@@ -154,11 +161,13 @@ struct Cfg {
   // LDS ring depth: 2 for the 3-tap conv tiles (33 KB stages, 2 blocks per CU), 3 for the 256-row variant, and 4 for the
   // short-stage (KSUB == 1) 1-tap tiles -- a 16 KB stage holds only 16 MFMAs per wave (~260 cycles), far less than the
   // ~2500-cycle DMA latency, so three stages are kept in flight
-  static constexpr int NSTG = !USE_DMA ? 1 : ((WMT == 4 && 3 * STAGE_BYTES <= 160 * 1024) ? 3 : ((TAPS == 1 && KSUB == 1 && AMODE != GA_CONV) ? 4 : 2));
+  // (the 128 x 128 fused 3-tap weight-gradient tile is one 8-wave block per CU: 3-deep ring of 36 KB stages)
+  static constexpr bool WG3_WIDE = WG3 && BN == 128;
+  static constexpr int NSTG = !USE_DMA ? 1 : (((WMT == 4 || WG3_WIDE) && 3 * STAGE_BYTES <= 160 * 1024) ? 3 : ((TAPS == 1 && KSUB == 1 && AMODE != GA_CONV) ? 4 : 2));
   static constexpr int CA = (A_CHUNKS + NTHREADS - 1) / NTHREADS;  // register-staged 16-byte chunks per thread
   static constexpr int CB = (B_CHUNKS + NTHREADS - 1) / NTHREADS;
   static constexpr int NSTG_BYTES_HINT = NSTG * STAGE_BYTES;
-  static constexpr int FN = BN / 32;                              // 16-wide fragments per wave along N
+  static constexpr int FN = BNW / 16;                             // 16-wide fragments per wave along N
   static constexpr int EPI_PITCH = BN * 4 + 16;                   // fp32 epilogue tile [32][BN]
   // epilogue passes: EPI_I of the four 16-row fragment groups go through LDS per pass.  One pass of all four when the
   // staging ring already owns that much LDS (conv kernels), two otherwise -- fewer barriers and, more importantly,
@@ -191,7 +200,8 @@ __device__ __forceinline__ void dma16(const void* g, unsigned lds_off) {
 __device__ __forceinline__ void dma_wait_all() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 
 template <typename T, int AMODE, int BMODE, int TAPS, int KSUB, int BN, int STRIDE, int WMT, bool DMA>
-__global__ __launch_bounds__((WMT == 3 ? 256 : 128 * WMT), 2) void gemm_kernel(const GemmArgs p) {   // >= 2 waves per SIMD: <= 256 VGPR+AGPR
+__global__ __launch_bounds__((Cfg<T, AMODE, BMODE, TAPS, KSUB, BN, STRIDE, WMT, DMA>::NTHREADS), 2)
+void gemm_kernel(const GemmArgs p) {   // >= 2 waves per SIMD: <= 256 VGPR+AGPR
   using C = Cfg<T, AMODE, BMODE, TAPS, KSUB, BN, STRIDE, WMT, DMA>;
   constexpr int FN = C::FN;
   constexpr int BM = C::BM, NTHREADS = C::NTHREADS, NW = C::NW;
@@ -200,7 +210,7 @@ __global__ __launch_bounds__((WMT == 3 ? 256 : 128 * WMT), 2) void gemm_kernel(c
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
   const int lm = lane & 15, q = lane >> 4;
-  const int wm = wave >> 1, wn = wave & 1;
+  const int wm = wave / C::WN, wn = wave % C::WN;
   // XCD-aware tile order.  Workgroups are dealt round-robin to the 8 XCDs (linear id % 8), each with its own L2.  With the
   // plain (x = N tile, y = M tile) order the N tiles of one M tile -- which all read the same A rows -- land on different
   // XCDs and every L2 fetches those rows again.  When the M tile count is a multiple of 8, XCD x instead walks M tiles
@@ -470,7 +480,7 @@ __global__ __launch_bounds__((WMT == 3 ? 256 : 128 * WMT), 2) void gemm_kernel(c
     if (use16) {
 #pragma unroll
       for (int j = 0; j < FN; j++) {
-        const int nj = n0 + wn * (BN / 2) + j * 16 + q * 4;
+        const int nj = n0 + wn * C::BNW + j * 16 + q * 4;
         pf_bias[j] = make_float4(0.f, 0.f, 0.f, 0.f);
         if (p.bias) pf_bias[j] = *(const float4*)(p.bias + (nj < p.N ? nj : 0));
       }
@@ -485,7 +495,7 @@ __global__ __launch_bounds__((WMT == 3 ? 256 : 128 * WMT), 2) void gemm_kernel(c
           const int mr = m0 + wm * (C::FM * 16) + i * 16 + lm;
           const T* rp = (const T*)p.resid + (long)(mr < p.M ? mr : m0) * p.ldr;
 #pragma unroll
-          for (int j = 0; j < FN; j++) { const int nj = n0 + wn * (BN / 2) + j * 16 + q * 4; pf_res[i][j] = *(const uint2*)(rp + (nj < p.N ? nj : 0)); }
+          for (int j = 0; j < FN; j++) { const int nj = n0 + wn * C::BNW + j * 16 + q * 4; pf_res[i][j] = *(const uint2*)(rp + (nj < p.N ? nj : 0)); }
         }
       }
     }
@@ -571,9 +581,9 @@ __global__ __launch_bounds__((WMT == 3 ? 256 : 128 * WMT), 2) void gemm_kernel(c
 #pragma unroll
       for (int j = 0; j < FN; j++) {
         if constexpr (BMODE == GB_TR) {
-          bf[j] = read_tr_t<T, BN>(smB + (C::WG3 ? 0 : t) * C::B_TILE_BYTES, ks, wn * (BN / 2) + j * 16, lm, q, C::WG3 ? t : 0);
+          bf[j] = read_tr_t<T, BN>(smB + (C::WG3 ? 0 : t) * C::B_TILE_BYTES, ks, wn * C::BNW + j * 16, lm, q, C::WG3 ? t : 0);
         } else {
-          const int row = wn * (BN / 2) + j * 16 + lm;
+          const int row = wn * C::BNW + j * 16 + lm;
           bf[j] = *(const uint4*)(smB + t * C::B_TILE_BYTES + row * C::PITCH_NT + nt_swz<KSUB>(row, ks * 4 + q) * 16);
         }
       }
@@ -671,7 +681,7 @@ __global__ __launch_bounds__((WMT == 3 ? 256 : 128 * WMT), 2) void gemm_kernel(c
             if (m >= p.M) continue;
 #pragma unroll
             for (int j = 0; j < FN; j++) {
-              const int n = n0 + wn * (BN / 2) + j * 16 + lm;
+              const int n = n0 + wn * C::BNW + j * 16 + lm;
               if (n < p.N) atomicAdd((float*)Cb + cbase + (long)a * p.sCt + (long)m * p.ldc + n, acc[a][i][j][r] * p.alpha);
             }
           }
@@ -689,6 +699,35 @@ __global__ __launch_bounds__((WMT == 3 ? 256 : 128 * WMT), 2) void gemm_kernel(c
       TSTAMP();   // atomics retired
 #endif
       return;
+    }
+    if constexpr (C::WG3) {
+      if (p.sCk != 0) {
+        // split-K partial tile of the fused 3-tap weight gradient -> this split's slot of the workspace, PLAIN stores straight from
+        // the accumulators (natural fragment layout: a wave instruction writes 4 rows x 64 contiguous bytes).  Measured with
+        // tools/probes/atomic_probe.hip on the same access pattern: 512 blocks x 24576 values take 43 us as fp32 atomics
+        // (290 G adds/s, the same at agent or workgroup scope, shared or per-XCD target) and 11.6 us as stores (4.3 TB/s); the fold
+        // kernel then streams the partials once.
+#pragma unroll
+        for (int a = 0; a < C::NACC; a++)
+#pragma unroll
+          for (int i = 0; i < C::FM; i++)
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+              const int m = m0 + wm * (C::FM * 16) + i * 16 + q * 4 + r;
+              if (m >= p.M) continue;
+#pragma unroll
+              for (int j = 0; j < FN; j++) {
+                const int n = n0 + wn * C::BNW + j * 16 + lm;
+                if (n < p.N) *((float*)Cb + cbase + (long)a * p.sCt + (long)m * p.ldc + n) = acc[a][i][j][r] * p.alpha;
+              }
+            }
+        TSTAMP();
+#ifdef EEG_STAGE_TIMING
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        TSTAMP();
+#endif
+        return;
+      }
     }
   }
   if constexpr (EPI16) {
@@ -708,7 +747,7 @@ __global__ __launch_bounds__((WMT == 3 ? 256 : 128 * WMT), 2) void gemm_kernel(c
         const int s1 = min(s0 + 1, (p.M - 1) / p.rows_per_vec);
 #pragma unroll
         for (int j = 0; j < FN; j++) {
-          const int nj = n0 + wn * (BN / 2) + j * 16 + q * 4, nc = nj < p.N ? nj : 0;
+          const int nj = n0 + wn * C::BNW + j * 16 + q * 4, nc = nj < p.N ? nj : 0;
           pf_rv[0][j] = *(const float4*)(p.rowvec + (long)s0 * p.ld_rowvec + nc);
           pf_rv[1][j] = *(const float4*)(p.rowvec + (long)s1 * p.ld_rowvec + nc);
         }
@@ -730,7 +769,7 @@ __global__ __launch_bounds__((WMT == 3 ? 256 : 128 * WMT), 2) void gemm_kernel(c
           uint2 o;
           o.x = pack_bf16x2(acc[0][i][j][0] * p.alpha + a.x, acc[0][i][j][1] * p.alpha + a.y);
           o.y = pack_bf16x2(acc[0][i][j][2] * p.alpha + a.z, acc[0][i][j][3] * p.alpha + a.w);
-          *(uint2*)(smem + (wm * (C::FM * 16) + i * 16 + lm) * PITCH16 + (wn * (BN / 2) + j * 16 + q * 4) * 2) = o;
+          *(uint2*)(smem + (wm * (C::FM * 16) + i * 16 + lm) * PITCH16 + (wn * C::BNW + j * 16 + q * 4) * 2) = o;
         }
       }
       TSTAMP();   // E1: LDS tile written
@@ -777,10 +816,10 @@ __global__ __launch_bounds__((WMT == 3 ? 256 : 128 * WMT), 2) void gemm_kernel(c
         if constexpr (AMODE == GA_TR) {
 #pragma unroll
           for (int r = 0; r < 4; r++)
-            *(float*)(smem + (trow + q * 4 + r) * C::EPI_PITCH + (wn * (BN / 2) + j * 16 + lm) * 4) = acc[aset][i][j][r] * p.alpha;
+            *(float*)(smem + (trow + q * 4 + r) * C::EPI_PITCH + (wn * C::BNW + j * 16 + lm) * 4) = acc[aset][i][j][r] * p.alpha;
         } else {
           float4 v = make_float4(acc[0][i][j][0] * p.alpha, acc[0][i][j][1] * p.alpha, acc[0][i][j][2] * p.alpha, acc[0][i][j][3] * p.alpha);
-          *(float4*)(smem + (trow + lm) * C::EPI_PITCH + (wn * (BN / 2) + j * 16 + q * 4) * 4) = v;
+          *(float4*)(smem + (trow + lm) * C::EPI_PITCH + (wn * C::BNW + j * 16 + q * 4) * 4) = v;
         }
       }
     }
@@ -968,6 +1007,8 @@ int launch_modes(eegldm_ctx* ctx, const GemmArgs& a) {
     EEG_FAIL(EEGLDM_ERR_UNSUPPORTED, "conv gemm: taps=%d stride=%d bmode=%d", a.taps, a.stride, a.bmode);
   }
   if (a.amode == GA_TR && a.bmode == GB_TR && a.taps == 3) {   // fused 3-tap wgrad (see Cfg::WG3); BN <= 64 keeps 3 accumulator sets in registers
+    // 128 x 128 x 3-tap tile, one 8-wave block per CU (see Cfg::WN); chosen by op_conv_wgrad through GemmArgs::wide_n
+    if constexpr (sizeof(T) == 2) { if (a.wide_n && a.N % 128 == 0 && a.M % 128 == 0) return launch_t<T, GA_TR, GB_TR, 3, 2, 128, 1, 2>(ctx, a); }
     if (a.N > 32) return launch_t<T, GA_TR, GB_TR, 3, 2, 64, 1, 2>(ctx, a);
     return launch_t<T, GA_TR, GB_TR, 3, 2, 32, 1, 2>(ctx, a);
   }
@@ -1064,7 +1105,7 @@ int gemm_launch(eegldm_ctx* ctx, const GemmArgs& a_in) {
   // LDS epilogue) and folded into dW afterwards, instead of draining millions of fp32 atomics at ~370 G/s
   // (profiles/r01_gemm_stage_timing.txt); the fused 3-tap kernel keeps its register atomics (three accumulator sets).
   float* fold_dst = nullptr; long fold_n = 0;
-  static const bool fused_ws = getenv("EEGLDM_GEMM_FUSED3_WS") != nullptr;   // experiment: workspace reduction for the fused 3-tap kernel too
+  static const bool fused_ws = getenv("EEGLDM_GEMM_FUSED3_ATOMIC") == nullptr;   // fused 3-tap kernel: workspace partials (plain stores from the accumulators) + fold; =1 restores the register atomics
   if (a.splitk > 1 && a.amode == GA_TR && a.bmode == GB_TR && (a.taps == 1 || (a.taps == 3 && a.sCt == (long)a.M * a.N && fused_ws)) && a.ztaps == 1 && a.batch == 1 && a.atomic_out && a.ldc == a.N &&
       !getenv("EEGLDM_GEMM_NO_SPLITK_WS")) {
     const size_t need = (size_t)a.splitk * a.taps * a.M * a.N * sizeof(float);

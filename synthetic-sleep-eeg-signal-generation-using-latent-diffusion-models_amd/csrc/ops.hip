@@ -90,17 +90,23 @@ int op_conv_wgrad(eegldm_ctx* ctx, int dtype, const void* x, long ldx, const voi
   const bool fused3 = (K == 3 && stride == 1 && pad_l == 1 && pad_r == 1 && Lout % kstage == 0);
   int bn = Cin > 64 ? 128 : (Cin > 32 ? 64 : 32);
   long tiles;
-  if (fused3) {   // one block = all three taps of a 128 x 64 weight tile: dY and X staged once per K chunk
+  int blocks_per_cu = 2;
+  if (fused3) {   // one block = all three taps of a 128 x 64 (or 128 x 128) weight tile: dY and X staged once per K chunk
     a.taps = 3; a.ztaps = 1; a.conv_map = 0;
     bn = Cin > 32 ? 64 : 32;
+    // opt-in experiment (EEGLDM_WGRAD_WIDE_MIN=128): the 128 x 128 x 3 tile as ONE 8-wave block per CU.  Measured (round 2, B=256):
+    // 5-8 % SLOWER than two independent 128 x 64 blocks per CU although it stages a third fewer bytes -- with one barrier domain per
+    // CU every wave waits at every stage, two independent blocks overlap each other's waits
+    static const int wide_min = getenv("EEGLDM_WGRAD_WIDE_MIN") ? atoi(getenv("EEGLDM_WGRAD_WIDE_MIN")) : 0;
+    if (dtype != EEGLDM_F32 && wide_min > 0 && Cin % 128 == 0 && Cout % 128 == 0 && Cin >= wide_min) { a.wide_n = 1; bn = 128; blocks_per_cu = 1; }
     tiles = (long)((Cout + 127) / 128) * ((Cin + bn - 1) / bn);
   } else {
     tiles = (long)((Cout + 127) / 128) * ((Cin + bn - 1) / bn) * K;
   }
-  // fill the 2 resident blocks per CU in ONE round: rounding the split count up (11 x 48 tiles = 528 blocks on 512 slots) leaves a
+  // fill the resident blocks of every CU in ONE round: rounding the split count up (11 x 48 tiles = 528 blocks on 512 slots) leaves a
   // second round of 16 blocks that costs as much as the first
   static const bool split_ceil = getenv("EEGLDM_WGRAD_SPLIT_CEIL") != nullptr;
-  long want = split_ceil ? ((long)ctx->num_cu * 2 + tiles - 1) / tiles : ((long)ctx->num_cu * 2) / tiles;
+  long want = split_ceil ? ((long)ctx->num_cu * blocks_per_cu + tiles - 1) / tiles : ((long)ctx->num_cu * blocks_per_cu) / tiles;
   long maxs = ((long)a.K + 8 * kstage - 1) / (8 * kstage);     // at least 8 stages per split
   if (want > maxs) want = maxs;
   a.splitk = (int)(want < 1 ? 1 : want);
