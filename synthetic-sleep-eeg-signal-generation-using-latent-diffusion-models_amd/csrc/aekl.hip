@@ -8,6 +8,8 @@
 //   PatchDiscriminator(spatial_dims=1, num_layers_d, num_channels, in/out_channels, kernel_size=3,
 //                 norm="BATCH", bias=False, padding=1)              config/config_aekl_eeg.yaml:30-40
 //   train step body                                                 /root/reference/src/train_autoencoderkl.py:200-234
+#include <stdlib.h>
+
 #include <string>
 #include <vector>
 
@@ -17,6 +19,7 @@ int ls_bn_lrelu_fwd(eegldm_ctx*, const void* x, long ldx, const float* gamma, co
                     float* nbt, void* y, long ldy, long rows, int C, float slope, int training, int dtype);
 int ls_bn_lrelu_bwd(eegldm_ctx*, const void* x, long ldx, const float* gamma, const float* beta, const float* stats, const void* dy, long lddy,
                     void* dx, long lddx, float* dgamma, float* dbeta, long rows, int C, float slope, int dtype);
+int ls_bn_repeat_running(eegldm_ctx*, const float* stats, float* rmean, float* rvar, float* nbt, long rows, int C);
 int ls_upsample2(eegldm_ctx*, const void* x, long ldx, void* y, long ldy, long rows_in, int C, int dtype);
 int ls_upsample2_bwd(eegldm_ctx*, const void* dy, long lddy, void* dx, long lddx, long rows_in, int C, int dtype);
 int ls_reparam(eegldm_ctx*, const void* mu, const void* lv, const float* eps, void* z, float* sigma, float* kl, long n, int B, int dtype);
@@ -38,7 +41,8 @@ struct OpTape { View x; float* st = nullptr; int Lin = 0, Lout = 0; };
 struct SeqNet : NetBase {
   float* buffers = nullptr;     // BatchNorm running statistics (discriminator)
   int forward_seq(const std::vector<Op>& ops, View x, int B, int& L, View* out, std::vector<OpTape>& tape, int training);
-  int backward_seq(const std::vector<Op>& ops, std::vector<OpTape>& tape, int B, View dy, View* dx, bool need_dx);
+  // keep_tape: the tape (and the activations it points to) stays valid for another backward over the same forward
+  int backward_seq(const std::vector<Op>& ops, std::vector<OpTape>& tape, int B, View dy, View* dx, bool need_dx, bool keep_tape = false);
 };
 
 int SeqNet::forward_seq(const std::vector<Op>& ops, View x, int B, int& L, View* out, std::vector<OpTape>& tape, int training) {
@@ -82,11 +86,12 @@ int SeqNet::forward_seq(const std::vector<Op>& ops, View x, int B, int& L, View*
   return 0;
 }
 
-int SeqNet::backward_seq(const std::vector<Op>& ops, std::vector<OpTape>& tape, int B, View dy, View* dx_out, bool need_dx) {
+int SeqNet::backward_seq(const std::vector<Op>& ops, std::vector<OpTape>& tape, int B, View dy, View* dx_out, bool need_dx, bool keep_tape) {
   const int dt = dtype;
   for (int i = (int)ops.size() - 1; i >= 0; i--) {
     const Op& o = ops[i];
-    const OpTape t = tape.back(); tape.pop_back();
+    const OpTape t = keep_tape ? tape[tape.size() - (ops.size() - i)] : tape.back();
+    if (!keep_tape) tape.pop_back();
     const bool want_dx = need_dx || i > 0;
     View dx; dx.ld = t.x.C; dx.C = t.x.C;
     if (want_dx) ALLOC_OR_FAIL(dx.p, alloc_act((long)B * t.Lin, t.x.C));
@@ -396,20 +401,35 @@ extern "C" int eegldm_disc_forward(eegldm_disc* d, const float* x, float* logits
   return eegldm_nlc_to_ncl(d->ctx, y.p, y.ld, logits, B, d->cfg.out_channels, Lc, d->dtype);
 }
 // param_grads != 0: grads += d/dparams; dx (nullable) = d/dx
-extern "C" int eegldm_disc_backward(eegldm_disc* d, const float* dlogits, float* dx, int param_grads) {
+static int disc_backward_impl(eegldm_disc* d, const float* dlogits, float* dx, int param_grads, bool keep_tape);
+extern "C" int eegldm_disc_backward(eegldm_disc* d, const float* dlogits, float* dx, int param_grads) { return disc_backward_impl(d, dlogits, dx, param_grads, false); }
+static int disc_backward_impl(eegldm_disc* d, const float* dlogits, float* dx, int param_grads, bool keep_tape) {
   EEG_CHECK(d && dlogits, "null argument");
   EEG_CHECK(d->have_tape, "call eegldm_disc_forward first");
   EEG_CHECK(!param_grads || d->grads, "no gradient buffer bound");
-  d->have_tape = false;
+  d->have_tape = keep_tape;
   const int co = d->cfg.out_channels, B = d->B;
   View dy; ALLOC_OR_FAIL(dy.p, d->alloc_act((long)B * d->Lo, co)); dy.ld = co; dy.C = co;
   EEG_TRY(eegldm_ncl_to_nlc(d->ctx, dlogits, dy.p, co, B, co, d->Lo, d->dtype));
   d->param_grads = param_grads != 0;
   View dx0;
-  int rc = d->backward_seq(d->ops, d->tape, B, dy, &dx0, dx != nullptr);
+  EEG_CHECK(!keep_tape || d->rt.empty(), "tape reuse is for ResBlock-free stacks");
+  int rc = d->backward_seq(d->ops, d->tape, B, dy, &dx0, dx != nullptr, keep_tape);
   d->param_grads = true;
   EEG_TRY(rc);
   if (dx) EEG_TRY(eegldm_nlc_to_ncl(d->ctx, dx0.p, dx0.ld, dx, B, d->cfg.in_channels, d->L, d->dtype));
+  return 0;
+}
+
+// second running-statistics update of every BatchNorm layer with the batch statistics of the forward whose tape is still held
+static int disc_repeat_running(eegldm_disc* d) {
+  EEG_CHECK(d->have_tape && d->tape.size() == d->ops.size() && d->buffers, "no forward tape to repeat the BatchNorm update from");
+  for (size_t i = 0; i < d->ops.size(); i++) {
+    const Op& o = d->ops[i];
+    if (o.kind != OP_ACT || o.bn_w < 0) continue;
+    const OpTape& t = d->tape[i];
+    EEG_TRY(ls_bn_repeat_running(d->ctx, t.st, d->buffers + o.rm, d->buffers + o.rv, d->buffers + o.nbt, (long)d->B * t.Lin, t.x.C));
+  }
   return 0;
 }
 
@@ -441,11 +461,17 @@ extern "C" int eegldm_aekl_train_step(eegldm_aekl* a, eegldm_disc* d, const floa
   EEG_TRY(eegldm_spectral_loss(ctx, recon, x, losses + 1, use_spectral ? drecon : nullptr, B, C, L, spectral_weight));
   EEG_TRY(eegldm_disc_forward(d, recon, logits, B, L, 1));
   EEG_TRY(eegldm_lsgan_loss(ctx, logits, 1, losses + 3, dlogits, nl, adv_weight));
-  EEG_TRY(eegldm_disc_backward(d, dlogits, dxd, 0));
+  // The reference forwards the discriminator on the reconstruction twice: for the generator loss (:213) and, detached, for the
+  // fake-sample loss (:225).  Between the two only the GENERATOR's parameters change, so activations and logits are identical:
+  // the second forward is replaced by a second backward over the kept tape (other dlogits, this time into D's gradients) plus the
+  // repeat of the BatchNorm running-statistics update that a second forward would have made (same batch statistics).
+  static const bool refwd = getenv("EEGLDM_AEKL_REFORWARD_D") != nullptr;       // developer switch: the literal three-forward sequence
+  EEG_TRY(disc_backward_impl(d, dlogits, dxd, 0, !refwd));
   EEG_TRY(eegldm_axpy(ctx, drecon, dxd, 1.0f, n));
   EEG_TRY(eegldm_aekl_backward(a, drecon, kl_weight, nullptr));
   // ---- discriminator: 0.5 * adv_weight * (fake->0 + real->1)
-  EEG_TRY(eegldm_disc_forward(d, recon, logits, B, L, 1));
+  if (refwd) EEG_TRY(eegldm_disc_forward(d, recon, logits, B, L, 1));
+  else EEG_TRY(disc_repeat_running(d));
   EEG_TRY(eegldm_lsgan_loss(ctx, logits, 0, losses + 4, dlogits, nl, 0.5f * adv_weight));
   EEG_TRY(eegldm_disc_backward(d, dlogits, nullptr, 1));
   EEG_TRY(eegldm_disc_forward(d, x, logits, B, L, 1));

@@ -47,6 +47,20 @@ __global__ void bn_finalize_kernel(const double* __restrict__ sums, float* __res
     if (c == 0 && nbt) nbt[0] += 1.0f;
   }
 }
+// A second running-statistics update with the SAME batch statistics (the fused AEKL/GAN step reuses the discriminator's forward on the
+// reconstruction for the generator loss and for the fake-sample loss; the reference runs that forward twice,
+// train_autoencoderkl.py:213,225, which only differs in this update).  stats = (mean, rstd): var = 1/rstd^2 - eps.
+__global__ void bn_repeat_running_kernel(const float* __restrict__ stats, float* __restrict__ rmean, float* __restrict__ rvar, float* __restrict__ nbt,
+                                         int C, double n, float eps, float momentum) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  const double rstd = (double)stats[2 * c + 1];
+  double var = 1.0 / (rstd * rstd) - (double)eps;
+  if (var < 0) var = 0;
+  rmean[c] = (1.0f - momentum) * rmean[c] + momentum * stats[2 * c];
+  rvar[c] = (1.0f - momentum) * rvar[c] + momentum * (float)(var * n / (n > 1 ? n - 1 : 1));
+  if (c == 0 && nbt) nbt[0] += 1.0f;
+}
 __global__ void bn_eval_stats_kernel(const float* __restrict__ rmean, const float* __restrict__ rvar, float* __restrict__ stats, int C, float eps) {
   const int c = blockIdx.x * blockDim.x + threadIdx.x;
   if (c < C) { stats[2 * c] = rmean[c]; stats[2 * c + 1] = rsqrtf(rvar[c] + eps); }
@@ -332,6 +346,11 @@ inline void pick_rsplit(long rows, int C, eegldm_ctx* ctx, int* rsplit, long* rp
     else EEG_FAIL(EEGLDM_ERR_UNSUPPORTED, "dtype %d", (int)(dtype));      \
   } while (0)
 
+int ls_bn_repeat_running(eegldm_ctx* ctx, const float* stats, float* rmean, float* rvar, float* nbt, long rows, int C) {
+  hipLaunchKernelGGL(bn_repeat_running_kernel, dim3((C + 255) / 256), dim3(256), 0, ctx->stream, stats, rmean, rvar, nbt, C, (double)rows, 1e-5f, 0.1f);
+  LAUNCH_CHECK();
+  return 0;
+}
 // BatchNorm1d + LeakyReLU forward.  training: batch statistics (and running-stat update when rmean != null);
 // eval: running statistics.  stats: [C][2] fp32 out.  gamma == null: plain LeakyReLU (stats unused).
 int ls_bn_lrelu_fwd(eegldm_ctx* ctx, const void* x, long ldx, const float* gamma, const float* beta, float* stats, float* rmean, float* rvar,
