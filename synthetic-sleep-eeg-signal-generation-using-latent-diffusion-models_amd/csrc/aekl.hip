@@ -13,6 +13,7 @@
 #include <string>
 #include <vector>
 
+#include "aekl_thin.h"
 #include "net.h"
 
 int ls_bn_lrelu_fwd(eegldm_ctx*, const void* x, long ldx, const float* gamma, const float* beta, float* stats, float* rmean, float* rvar,
@@ -162,6 +163,7 @@ Op make_gn(NetBase* n, Layout& lay, const std::string& p, int c, int groups) {
 }  // namespace
 
 // ================================================================== AutoencoderKL
+struct eegldm_aekl;
 struct eegldm_aekl : SeqNet {
   eegldm_aekl_cfg cfg;
   std::vector<Op> enc, dec; Op q_mu, q_lv;
@@ -170,7 +172,167 @@ struct eegldm_aekl : SeqNet {
   // tape of the latent head
   int B = 0, L = 0, Ll = 0; bool have_tape = false;
   View h_enc, mu, lv; float *eps_nlc = nullptr, *sigma = nullptr;
+  // whole-network path for thin configurations (aekl_thin.hip): program compiled per window length
+  ThinProgram thin; int thin_L = -1; bool thin_tape = false; float* thin_eps = nullptr;
+  ~eegldm_aekl() { thin_free(&thin); }
 };
+
+namespace {
+// ---- thin whole-network path: compile enc / heads / dec into micro-ops over four LDS tensors (aekl_thin.h)
+bool thin_eligible(const eegldm_aekl* a, int L) {
+  static const bool off = getenv("EEGLDM_AEKL_NO_THIN") != nullptr;
+  const eegldm_aekl_cfg& c = a->cfg;
+  if (off || c.norm_num_groups != 1 || c.in_channels > THIN_MAXC || c.out_channels > THIN_MAXC || c.latent_channels > THIN_MAXC) return false;
+  int mx = 0;
+  for (int i = 0; i < c.n_levels; i++) { if (c.num_channels[i] > THIN_MAXC) return false; const int v = c.num_channels[i] * (L >> i); mx = v > mx ? v : mx; }
+  return (long)mx <= THIN_MAX_FLOATS && (long)c.in_channels * L <= THIN_MAX_FLOATS && (L % (1 << (c.n_levels - 1))) == 0;
+}
+
+struct ThinBuilder {
+  ThinProgram& p; int nslot = 0;
+  struct Seg { int kind; Op op; int L, Lout, slot, slot2, stat1, stat2, ups_slot, C; };   // kind: 0 conv, 1 res, 2 gn, 3 heads, 4 conv-after-upsample
+  std::vector<Seg> segs;
+  explicit ThinBuilder(ThinProgram& pp) : p(pp) {}
+  static int pick(int a, int b = -1, int c = -1) { for (int i = 0; i < THIN_NBUF; i++) if (i != a && i != b && i != c) return i; return -1; }
+  void track(int n) { if (n > p.maxt) p.maxt = n; }
+  int new_slot(int n) { p.tape_off.push_back(p.tape_stride); p.tape_stride += (n + 3) & ~3; return nslot++; }
+  ThinOp blank(int kind) { ThinOp o = {}; o.kind = kind; o.src = o.dst = o.add = o.act = -1; o.b = o.b2 = -1; o.save = -1; o.k = 1; o.stride = 1; return o; }
+  void f_save(int buf, int C, int L, int slot) { ThinOp o = blank(TF_SAVE); o.src = buf; o.cin = C; o.Lin = L; o.save = slot; p.fwd.push_back(o); }
+  ThinOp conv_op(int kind, const Op& c, int Lin, int Lout) {
+    ThinOp o = blank(kind); o.cin = c.cin; o.cout = c.cout; o.Lin = Lin; o.Lout = Lout; o.k = c.k; o.stride = c.stride; o.pad_l = c.pl; o.w = (int)c.w; o.b = (int)c.b; o.need_dx = 1;
+    track(c.cin * Lin); track(c.cout * Lout);
+    return o;
+  }
+  ThinOp gn_op(int kind, long gw, long gb, int C, int L, int silu, int stat) {
+    ThinOp o = blank(kind); o.cin = o.cout = C; o.Lin = o.Lout = L; o.gw = (int)gw; o.gb = (int)gb; o.silu = silu; o.stat = stat; track(C * L);
+    return o;
+  }
+  // one conv described by (w, b, cin, cout, k) of a ResDesc
+  static Op res_conv(const ResDesc& r, int which) {
+    Op c; c.kind = OP_CONV; c.stride = 1;
+    if (which == 0) { c.cin = r.cin; c.cout = r.cout; c.k = 3; c.pl = c.pr = 1; c.w = r.c1_w; c.b = r.c1_b; }
+    else if (which == 1) { c.cin = r.cout; c.cout = r.cout; c.k = 3; c.pl = c.pr = 1; c.w = r.c2_w; c.b = r.c2_b; }
+    else { c.cin = r.cin; c.cout = r.cout; c.k = 1; c.pl = c.pr = 0; c.w = r.sk_w; c.b = r.sk_b; }
+    return c;
+  }
+  // forward over an op list; cur = buffer holding the current tensor (C x L)
+  void forward_ops(const std::vector<Op>& ops, int& cur, int& C, int& L) {
+    bool after_ups = false; int ups_slot = -1;
+    for (const Op& o : ops) {
+      if (o.kind == OP_CONV) {
+        const int Lo = (L + o.pl + o.pr - o.k) / o.stride + 1;
+        Seg sg = {}; sg.kind = after_ups ? 4 : 0; sg.op = o; sg.L = L; sg.Lout = Lo; sg.ups_slot = ups_slot;
+        if (!after_ups) { sg.slot = new_slot(C * L); f_save(cur, C, L, sg.slot); }
+        ThinOp t = conv_op(TF_CONV, o, L, Lo); t.src = cur; t.dst = pick(cur); p.fwd.push_back(t);
+        cur = t.dst; C = o.cout; L = Lo; after_ups = false; segs.push_back(sg);
+      } else if (o.kind == OP_RES) {
+        const ResDesc& r = o.r;
+        Seg sg = {}; sg.kind = 1; sg.op = o; sg.L = L; sg.slot = new_slot(r.cin * L); sg.slot2 = new_slot(r.cout * L); sg.stat1 = p.nstat++; sg.stat2 = p.nstat++;
+        f_save(cur, r.cin, L, sg.slot);
+        const int t1 = pick(cur), t2 = pick(cur, t1), t3 = pick(cur, t1, t2);
+        { ThinOp g = gn_op(TF_GN, r.gn1_w, r.gn1_b, r.cin, L, 1, sg.stat1); g.src = cur; g.dst = t1; p.fwd.push_back(g); }
+        { ThinOp c = conv_op(TF_CONV, res_conv(r, 0), L, L); c.src = t1; c.dst = t2; p.fwd.push_back(c); }
+        f_save(t2, r.cout, L, sg.slot2);
+        { ThinOp g = gn_op(TF_GN, r.gn2_w, r.gn2_b, r.cout, L, 1, sg.stat2); g.src = t2; g.dst = t1; p.fwd.push_back(g); }
+        if (r.sk_w >= 0) {
+          { ThinOp c = conv_op(TF_CONV, res_conv(r, 2), L, L); c.src = cur; c.dst = t2; p.fwd.push_back(c); }
+          { ThinOp c = conv_op(TF_CONV, res_conv(r, 1), L, L); c.src = t1; c.dst = t3; c.add = t2; p.fwd.push_back(c); }
+          cur = t3;
+        } else {
+          { ThinOp c = conv_op(TF_CONV, res_conv(r, 1), L, L); c.src = t1; c.dst = t2; c.add = cur; p.fwd.push_back(c); }
+          cur = t2;
+        }
+        C = r.cout; segs.push_back(sg);
+      } else if (o.kind == OP_UPS) {
+        ups_slot = new_slot(C * L); f_save(cur, C, L, ups_slot);
+        ThinOp u = blank(TF_UPS); u.cin = u.cout = C; u.Lin = L; u.Lout = 2 * L; u.src = cur; u.dst = pick(cur); track(C * 2 * L); p.fwd.push_back(u);
+        cur = u.dst; L *= 2; after_ups = true;
+      } else if (o.kind == OP_GN) {
+        Seg sg = {}; sg.kind = 2; sg.op = o; sg.L = L; sg.C = C; sg.slot = new_slot(C * L); sg.stat1 = p.nstat++;
+        f_save(cur, C, L, sg.slot);
+        ThinOp g = gn_op(TF_GN, o.gw, o.gb, C, L, 0, sg.stat1); g.src = cur; g.dst = pick(cur); p.fwd.push_back(g);
+        cur = g.dst; segs.push_back(sg);
+      }
+    }
+  }
+  // backward over the recorded segments (reverse); g = buffer holding the gradient of the segment's output
+  void backward_segs(int& g) {
+    for (int i = (int)segs.size() - 1; i >= 0; i--) {
+      const Seg& sg = segs[i];
+      if (sg.kind == 0) {
+        const int a = pick(g);
+        { ThinOp l = blank(TB_LOADT); l.dst = a; l.cin = sg.op.cin; l.Lin = sg.L; l.save = sg.slot; p.bwd.push_back(l); }
+        { ThinOp c = conv_op(TB_CONV, sg.op, sg.L, sg.Lout); c.src = g; c.act = a; p.bwd.push_back(c); }
+        g = a;
+      } else if (sg.kind == 4) {       // nearest x2 then conv: the saved tensor is the PRE-upsample input
+        const int a = pick(g), t = pick(g, a), Lpre = sg.L / 2, Cc = sg.op.cin;
+        { ThinOp l = blank(TB_LOADT); l.dst = a; l.cin = Cc; l.Lin = Lpre; l.save = sg.ups_slot; p.bwd.push_back(l); }
+        { ThinOp u = blank(TB_UPS); u.cin = u.cout = Cc; u.Lin = Lpre; u.Lout = sg.L; u.src = a; u.dst = t; p.bwd.push_back(u); }
+        { ThinOp c = conv_op(TB_CONV, sg.op, sg.L, sg.Lout); c.src = g; c.act = t; p.bwd.push_back(c); }
+        { ThinOp u = blank(TB_UPSBWD); u.cin = u.cout = Cc; u.Lin = sg.L; u.Lout = Lpre; u.src = t; u.dst = a; p.bwd.push_back(u); }
+        g = a;
+      } else if (sg.kind == 2) {
+        const int a = pick(g);
+        { ThinOp l = blank(TB_LOADT); l.dst = a; l.cin = sg.C; l.Lin = sg.L; l.save = sg.slot; p.bwd.push_back(l); }
+        { ThinOp n = gn_op(TB_GN, sg.op.gw, sg.op.gb, sg.C, sg.L, 0, sg.stat1); n.act = a; n.src = g; n.dst = g; p.bwd.push_back(n); }
+      } else if (sg.kind == 1) {
+        const ResDesc& r = sg.op.r; const int L = sg.L;
+        int s = pick(g), a = pick(g, s), t = pick(g, s, a);
+        if (r.sk_w >= 0) {
+          { ThinOp l = blank(TB_LOADT); l.dst = s; l.cin = r.cin; l.Lin = L; l.save = sg.slot; p.bwd.push_back(l); }
+          { ThinOp c = conv_op(TB_CONV, res_conv(r, 2), L, L); c.src = g; c.act = s; p.bwd.push_back(c); }      // s <- gradient through the shortcut
+        } else {
+          ThinOp c = blank(TB_COPY); c.src = g; c.dst = s; c.cin = r.cout; c.Lin = L; p.bwd.push_back(c);
+        }
+        { ThinOp l = blank(TB_LOADT); l.dst = a; l.cin = r.cout; l.Lin = L; l.save = sg.slot2; p.bwd.push_back(l); }
+        { ThinOp n = gn_op(TB_RECOMP, r.gn2_w, r.gn2_b, r.cout, L, 1, sg.stat2); n.src = a; n.dst = t; p.bwd.push_back(n); }
+        { ThinOp c = conv_op(TB_CONV, res_conv(r, 1), L, L); c.src = g; c.act = t; p.bwd.push_back(c); }
+        { ThinOp n = gn_op(TB_GN, r.gn2_w, r.gn2_b, r.cout, L, 1, sg.stat2); n.act = a; n.src = t; n.dst = g; p.bwd.push_back(n); }
+        { ThinOp l = blank(TB_LOADT); l.dst = a; l.cin = r.cin; l.Lin = L; l.save = sg.slot; p.bwd.push_back(l); }
+        { ThinOp n = gn_op(TB_RECOMP, r.gn1_w, r.gn1_b, r.cin, L, 1, sg.stat1); n.src = a; n.dst = t; p.bwd.push_back(n); }
+        { ThinOp c = conv_op(TB_CONV, res_conv(r, 0), L, L); c.src = g; c.act = t; p.bwd.push_back(c); }
+        { ThinOp n = gn_op(TB_GN, r.gn1_w, r.gn1_b, r.cin, L, 1, sg.stat1); n.act = a; n.src = t; n.dst = g; n.add = s; p.bwd.push_back(n); }
+      } else if (sg.kind == 3) {
+        const int a = pick(g);
+        { ThinOp l = blank(TB_LOADT); l.dst = a; l.cin = sg.C; l.Lin = sg.L; l.save = sg.slot; p.bwd.push_back(l); }
+        ThinOp h = blank(TB_HEADS); h.cin = h.cout = sg.C; h.Lin = h.Lout = sg.L; h.src = g; h.dst = g; h.act = a; h.save = sg.slot2;
+        h.w = (int)sg.op.w; h.b = (int)sg.op.b; h.w2 = sg.stat1; h.b2 = sg.stat2; p.bwd.push_back(h);
+      }
+    }
+  }
+};
+
+int thin_build(eegldm_aekl* a, int L) {
+  ThinProgram& p = a->thin;
+  thin_free(&p);
+  p = ThinProgram();
+  const eegldm_aekl_cfg& c = a->cfg;
+  ThinBuilder bld(p);
+  int cur = 0, C = c.in_channels, Lc = L;
+  { ThinOp l = bld.blank(TF_LOAD); l.dst = 0; l.cin = C; l.Lin = L; bld.track(C * L); p.fwd.push_back(l); }
+  bld.forward_ops(a->enc, cur, C, Lc);
+  // heads: mu / log-variance 1x1 convs, clamp, sigma, z = mu + eps * sigma (+ KL)
+  {
+    ThinBuilder::Seg sg = {}; sg.kind = 3; sg.C = C; sg.L = Lc; sg.slot = bld.new_slot(C * Lc); sg.slot2 = bld.new_slot(C * Lc); bld.new_slot(C * Lc);   // h, mu, lv
+    sg.op.w = a->q_mu.w; sg.op.b = a->q_mu.b; sg.stat1 = (int)a->q_lv.w; sg.stat2 = (int)a->q_lv.b;
+    bld.f_save(cur, C, Lc, sg.slot);
+    ThinOp h = bld.blank(TF_HEADS); h.cin = h.cout = C; h.Lin = h.Lout = Lc; h.src = cur; h.dst = ThinBuilder::pick(cur); h.save = sg.slot2;
+    h.w = (int)a->q_mu.w; h.b = (int)a->q_mu.b; h.w2 = (int)a->q_lv.w; h.b2 = (int)a->q_lv.b; p.fwd.push_back(h);
+    cur = h.dst; bld.segs.push_back(sg);
+    p.lat = C; p.Ll = Lc;
+  }
+  bld.forward_ops(a->dec, cur, C, Lc);
+  { ThinOp s = bld.blank(TF_STORE); s.src = cur; s.cin = C; s.Lin = Lc; p.fwd.push_back(s); }
+  // backward program
+  int g = 0;
+  { ThinOp l = bld.blank(TB_LOADDY); l.dst = 0; l.cin = C; l.Lin = Lc; p.bwd.push_back(l); }
+  bld.backward_segs(g);
+  { ThinOp s = bld.blank(TB_STOREDX); s.src = g; s.cin = c.in_channels; s.Lin = L; p.bwd.push_back(s); }
+  EEG_TRY(thin_upload(&p));
+  a->thin_L = L;
+  return 0;
+}
+}  // namespace
 
 extern "C" int eegldm_aekl_create(eegldm_ctx* ctx, const eegldm_aekl_cfg* cfg, eegldm_aekl** out) {
   EEG_CHECK(ctx && cfg && out, "null argument");
@@ -294,6 +456,25 @@ extern "C" int eegldm_aekl_decode(eegldm_aekl* a, const float* z, float* recon, 
 // forward(x) -> (reconstruction, z_mu, z_sigma) with eps supplied; kl (nullable device scalar) = KL term
 extern "C" int eegldm_aekl_forward(eegldm_aekl* a, const float* x, const float* eps, float* recon, float* z_mu, float* z_sigma, float* kl, int B, int L) {
   EEG_CHECK(a && x && recon && a->params, "null argument / unbound parameters");
+  a->thin_tape = false;
+  if (thin_eligible(a, L)) {
+    // whole-network path (aekl_thin.hip): one workgroup per window, two launches per forward + backward instead of ~300
+    if (a->thin_L != L) EEG_TRY(thin_build(a, L));
+    ThinProgram& p = a->thin;
+    a->arena.reset(); a->rt.clear(); a->tape_enc.clear(); a->tape_dec.clear(); a->have_tape = false;
+    a->B = B; a->L = L; a->Ll = p.Ll;
+    ALLOC_OR_FAIL(p.tape, a->arena.alloc(sizeof(float) * (size_t)B * p.tape_stride));
+    ALLOC_OR_FAIL(p.stats, a->arena.alloc(sizeof(float) * (size_t)B * p.nstat * 2));
+    a->thin_eps = nullptr;
+    if (eps) {      // kept for the backward pass (the caller's buffer may be gone by then)
+      ALLOC_OR_FAIL(a->thin_eps, a->arena.alloc(sizeof(float) * (size_t)B * p.lat * p.Ll));
+      HIP_TRY(hipMemcpyAsync(a->thin_eps, eps, sizeof(float) * (size_t)B * p.lat * p.Ll, hipMemcpyDeviceToDevice, a->ctx->stream));
+    }
+    if (kl) HIP_TRY(hipMemsetAsync(kl, 0, sizeof(float), a->ctx->stream));
+    EEG_TRY(thin_forward(a->ctx, p, a->params, x, a->thin_eps, recon, z_mu, z_sigma, kl, B));
+    a->have_tape = true; a->thin_tape = true;
+    return 0;
+  }
   View zv;
   EEG_TRY(aekl_encode_impl(a, x, eps, B, L, &zv, kl));
   EEG_TRY(aekl_export_latents(a, zv, nullptr, z_mu, z_sigma));
@@ -307,6 +488,10 @@ extern "C" int eegldm_aekl_backward(eegldm_aekl* a, const float* d_recon, float 
   EEG_CHECK(a->have_tape, "call eegldm_aekl_forward first");
   EEG_CHECK(a->grads, "no gradient buffer bound");
   a->have_tape = false;
+  if (a->thin_tape) {
+    a->thin_tape = false;
+    return thin_backward(a->ctx, a->thin, a->params, a->grads, d_recon, a->thin_eps, kl_weight / (float)a->B, dx, a->B);
+  }
   eegldm_ctx* ctx = a->ctx; const int dt = a->dtype, lat = a->cfg.latent_channels, B = a->B, L = a->L, Ll = a->Ll, co = a->cfg.out_channels;
   View dy; ALLOC_OR_FAIL(dy.p, a->alloc_act((long)B * L, co)); dy.ld = co; dy.C = co;
   EEG_TRY(eegldm_ncl_to_nlc(ctx, d_recon, dy.p, co, B, co, L, dt));
