@@ -182,10 +182,12 @@ namespace {
 bool thin_eligible(const eegldm_aekl* a, int L) {
   static const bool off = getenv("EEGLDM_AEKL_NO_THIN") != nullptr;
   const eegldm_aekl_cfg& c = a->cfg;
-  if (off || c.norm_num_groups != 1 || c.in_channels > THIN_MAXC || c.out_channels > THIN_MAXC || c.latent_channels > THIN_MAXC) return false;
+  auto ok_c = [](int v) { return v == 1 || v == 2 || v == 4; };           // the kernels are specialised on channel counts of 1, 2 and 4
+  if (off || c.norm_num_groups != 1 || !ok_c(c.in_channels) || !ok_c(c.out_channels) || !ok_c(c.latent_channels)) return false;
   int mx = 0;
-  for (int i = 0; i < c.n_levels; i++) { if (c.num_channels[i] > THIN_MAXC) return false; const int v = c.num_channels[i] * (L >> i); mx = v > mx ? v : mx; }
-  return (long)mx <= THIN_MAX_FLOATS && (long)c.in_channels * L <= THIN_MAX_FLOATS && (L % (1 << (c.n_levels - 1))) == 0;
+  for (int i = 0; i < c.n_levels; i++) { if (!ok_c(c.num_channels[i])) return false; const int v = c.num_channels[i] * (L >> i); mx = v > mx ? v : mx; }
+  if ((L >> (c.n_levels - 1)) % 4 != 0) return false;                      // float4 rows at every level
+  return (long)mx <= THIN_MAX_FLOATS - 1024 && a->nparams <= 4096 && (long)c.in_channels * L <= THIN_MAX_FLOATS && (L % (1 << (c.n_levels - 1))) == 0;
 }
 
 struct ThinBuilder {
@@ -194,7 +196,7 @@ struct ThinBuilder {
   std::vector<Seg> segs;
   explicit ThinBuilder(ThinProgram& pp) : p(pp) {}
   static int pick(int a, int b = -1, int c = -1) { for (int i = 0; i < THIN_NBUF; i++) if (i != a && i != b && i != c) return i; return -1; }
-  void track(int n) { if (n > p.maxt) p.maxt = n; }
+  void track(int n) { n = (n + 3) & ~3; if (n > p.maxt) p.maxt = n; }
   int new_slot(int n) { p.tape_off.push_back(p.tape_stride); p.tape_stride += (n + 3) & ~3; return nslot++; }
   ThinOp blank(int kind) { ThinOp o = {}; o.kind = kind; o.src = o.dst = o.add = o.act = -1; o.b = o.b2 = -1; o.save = -1; o.k = 1; o.stride = 1; return o; }
   void f_save(int buf, int C, int L, int slot) { ThinOp o = blank(TF_SAVE); o.src = buf; o.cin = C; o.Lin = L; o.save = slot; p.fwd.push_back(o); }
@@ -308,6 +310,7 @@ int thin_build(eegldm_aekl* a, int L) {
   p = ThinProgram();
   const eegldm_aekl_cfg& c = a->cfg;
   ThinBuilder bld(p);
+  p.nparams = (int)a->nparams;
   int cur = 0, C = c.in_channels, Lc = L;
   { ThinOp l = bld.blank(TF_LOAD); l.dst = 0; l.cin = C; l.Lin = L; bld.track(C * L); p.fwd.push_back(l); }
   bld.forward_ops(a->enc, cur, C, Lc);

@@ -43,6 +43,7 @@ struct ThinProgram {
   int nstat = 0;                  // statistics slots per window
   int maxt = 0;                   // largest tensor (floats): LDS buffer size
   int lat = 0, Ll = 0;
+  int nparams = 0;                // flat parameter count (copied to LDS by the kernels)
   ThinOp* d_fwd = nullptr; ThinOp* d_bwd = nullptr; int* d_tape_off = nullptr;   // device copies (owned)
   float* tape = nullptr; float* stats = nullptr;                                 // per-call workspace (arena)
 };

@@ -13,13 +13,16 @@
 // the workgroup and added to the flat gradient buffer with one atomic per parameter and window.
 #include "aekl_thin.h"
 
+#include <stdlib.h>
+
 namespace {
 constexpr int NT = 512, NWAVE = NT / 64;
 constexpr int MC = THIN_MAXC;
 constexpr float GN_EPS_T = 1e-6f;
 constexpr int RED_FLOATS = NWAVE * 56 + 64;
 
-struct Bufs { float* b[THIN_NBUF]; float* red; };
+struct BufSel { float* base; int maxt; __device__ __forceinline__ float* operator[](int i) const { return base + (size_t)i * maxt; } };
+struct Bufs { BufSel b; float* red; };
 
 // sum of NV per-thread values over the workgroup; results in red[NWAVE*NV + i] (valid for every thread after the call)
 template <int NV> __device__ __forceinline__ void block_reduce(float (&v)[NV], float* red) {
@@ -41,79 +44,149 @@ template <int NV> __device__ __forceinline__ void block_reduce(float (&v)[NV], f
   __syncthreads();
 }
 
-__device__ __forceinline__ void load_w(const ThinOp& o, const float* __restrict__ P, int woff, int boff, float (&w)[MC][MC][3], float (&bias)[MC]) {
+// The channel counts are compile-time (1, 2 or 4 each): the kernels are VALU-issue bound -- one 8-wave workgroup per CU, every
+// wave64 VALU instruction occupies its SIMD for 4 cycles -- so a loop predicated on a run-time channel count (the first version:
+// 4 x 4 x 3 predicated FMAs per position for a 2 -> 2 conv) cost 3x the instructions of the specialised one.
+template <int CIN, int COUT>
+__device__ __forceinline__ void load_w(const ThinOp& o, const float* P, int woff, int boff, float (&w)[COUT][CIN][3], float (&bias)[COUT]) {
 #pragma unroll
-  for (int co = 0; co < MC; co++) {
-    bias[co] = (boff >= 0 && co < o.cout) ? P[boff + co] : 0.f;
+  for (int co = 0; co < COUT; co++) {
+    bias[co] = boff >= 0 ? P[boff + co] : 0.f;
 #pragma unroll
-    for (int ci = 0; ci < MC; ci++)
+    for (int ci = 0; ci < CIN; ci++)
 #pragma unroll
-      for (int k = 0; k < 3; k++) w[co][ci][k] = (co < o.cout && ci < o.cin && k < o.k) ? P[woff + (k * o.cout + co) * o.cin + ci] : 0.f;
+      for (int k = 0; k < 3; k++) w[co][ci][k] = k < o.k ? P[woff + (k * COUT + co) * CIN + ci] : 0.f;
   }
 }
 
-__device__ void f_conv(const ThinOp& o, const float* __restrict__ P, const Bufs& B) {
+// window of one channel row around 4 consecutive positions: v[0..5] = X[l0-1 .. l0+4] (zero outside the row)
+__device__ __forceinline__ void row_window(const float* __restrict__ row, int l0, int L, bool halo, float (&v)[6]) {
+  const float4 c = *(const float4*)(row + l0);
+  v[1] = c.x; v[2] = c.y; v[3] = c.z; v[4] = c.w;
+  v[0] = (halo && l0 > 0) ? row[l0 - 1] : 0.f;
+  v[5] = (halo && l0 + 4 < L) ? row[l0 + 4] : 0.f;
+}
+
+// The kernels are LDS-latency / VALU-issue bound (one 8-wave workgroup per CU = 2 waves per SIMD): a scalar loop of the form
+// load, wait ~100 cycles, use ran at ~400 cycles per 64 positions.  Every hot loop therefore handles FOUR consecutive positions
+// per thread (ds_read_b128 + two halo words per channel row; 4 x the FMAs per LDS instruction, independent accumulators).
+template <int CIN, int COUT>
+__device__ void f_conv_t(const ThinOp& o, const float* P, const Bufs& B) {
   const float* X = B.b[o.src]; float* Y = B.b[o.dst]; const float* A = o.add >= 0 ? B.b[o.add] : nullptr;
-  float w[MC][MC][3], bias[MC];
-  load_w(o, P, o.w, o.b, w, bias);
-  for (int lo = threadIdx.x; lo < o.Lout; lo += NT) {
-    float acc[MC];
+  float w[COUT][CIN][3], bias[COUT];
+  load_w<CIN, COUT>(o, P, o.w, o.b, w, bias);
+  const int Lin = o.Lin, Lout = o.Lout, stride = o.stride, nk = o.k, pad = o.pad_l;
+  if (stride == 1 && ((nk == 3 && pad == 1) || (nk == 1 && pad == 0)) && (Lout & 3) == 0) {
+    const bool k3 = nk == 3;
+    for (int q = threadIdx.x; q < (Lout >> 2); q += NT) {
+      const int l0 = q << 2;
+      float acc[COUT][4];
 #pragma unroll
-    for (int co = 0; co < MC; co++) acc[co] = bias[co];
+      for (int co = 0; co < COUT; co++)
+#pragma unroll
+        for (int j = 0; j < 4; j++) acc[co][j] = bias[co];
+#pragma unroll
+      for (int ci = 0; ci < CIN; ci++) {
+        float v[6];
+        row_window(X + ci * Lin, l0, Lin, k3, v);
+#pragma unroll
+        for (int co = 0; co < COUT; co++)
+#pragma unroll
+          for (int j = 0; j < 4; j++) {
+            if (k3) { acc[co][j] = fmaf(w[co][ci][0], v[j], acc[co][j]); acc[co][j] = fmaf(w[co][ci][1], v[j + 1], acc[co][j]); acc[co][j] = fmaf(w[co][ci][2], v[j + 2], acc[co][j]); }
+            else acc[co][j] = fmaf(w[co][ci][0], v[j + 1], acc[co][j]);
+          }
+      }
+#pragma unroll
+      for (int co = 0; co < COUT; co++) {
+        float4 r = make_float4(acc[co][0], acc[co][1], acc[co][2], acc[co][3]);
+        if (A) { const float4 a = *(const float4*)(A + co * Lout + l0); r.x += a.x; r.y += a.y; r.z += a.z; r.w += a.w; }
+        *(float4*)(Y + co * Lout + l0) = r;
+      }
+    }
+    __syncthreads();
+    return;
+  }
+  for (int lo = threadIdx.x; lo < Lout; lo += NT) {
+    float acc[COUT];
+#pragma unroll
+    for (int co = 0; co < COUT; co++) acc[co] = bias[co];
 #pragma unroll
     for (int k = 0; k < 3; k++) {
-      const int li = lo * o.stride + k - o.pad_l;
-      if (k < o.k && li >= 0 && li < o.Lin) {
+      const int li = lo * stride + k - pad;
+      if (k < nk && li >= 0 && li < Lin) {
 #pragma unroll
-        for (int ci = 0; ci < MC; ci++) {
-          if (ci < o.cin) {
-            const float xv = X[ci * o.Lin + li];
+        for (int ci = 0; ci < CIN; ci++) {
+          const float xv = X[ci * Lin + li];
 #pragma unroll
-            for (int co = 0; co < MC; co++) acc[co] = fmaf(w[co][ci][k], xv, acc[co]);
-          }
+          for (int co = 0; co < COUT; co++) acc[co] = fmaf(w[co][ci][k], xv, acc[co]);
         }
       }
     }
 #pragma unroll
-    for (int co = 0; co < MC; co++) if (co < o.cout) Y[co * o.Lout + lo] = acc[co] + (A ? A[co * o.Lout + lo] : 0.f);
+    for (int co = 0; co < COUT; co++) Y[co * Lout + lo] = acc[co] + (A ? A[co * Lout + lo] : 0.f);
   }
   __syncthreads();
 }
+#define THIN_CC(fn, ...)                                                                      \
+  switch (o.cin * 8 + o.cout) {                                                               \
+    case 1 * 8 + 1: fn<1, 1>(__VA_ARGS__); break; case 1 * 8 + 2: fn<1, 2>(__VA_ARGS__); break; case 1 * 8 + 4: fn<1, 4>(__VA_ARGS__); break; \
+    case 2 * 8 + 1: fn<2, 1>(__VA_ARGS__); break; case 2 * 8 + 2: fn<2, 2>(__VA_ARGS__); break; case 2 * 8 + 4: fn<2, 4>(__VA_ARGS__); break; \
+    case 4 * 8 + 1: fn<4, 1>(__VA_ARGS__); break; case 4 * 8 + 2: fn<4, 2>(__VA_ARGS__); break; case 4 * 8 + 4: fn<4, 4>(__VA_ARGS__); break; \
+    default: break;                                                                           \
+  }
+__device__ void f_conv(const ThinOp& o, const float* P, const Bufs& B) { THIN_CC(f_conv_t, o, P, B) }
 
-__device__ void f_gn(const ThinOp& o, const float* __restrict__ P, const Bufs& B, float* __restrict__ stats) {
+// channel parameter of element group q (4 consecutive elements never straddle a channel row: L % 4 == 0)
+template <int C> __device__ __forceinline__ float sel(const float (&a)[C], int c) {
+  float r = a[0];
+#pragma unroll
+  for (int i = 1; i < C; i++) r = c == i ? a[i] : r;
+  return r;
+}
+template <int C>
+__device__ __forceinline__ void gn_apply_t(const ThinOp& o, const float* P, const float* X, float* Y, float mean, float rstd) {
+  float g[C], bb[C];
+#pragma unroll
+  for (int c = 0; c < C; c++) { g[c] = P[o.gw + c] * rstd; bb[c] = P[o.gb + c] - mean * g[c]; }
+  const int L = o.Lin, nq = (C * L) >> 2; const bool silu = o.silu != 0;
+  for (int q = threadIdx.x; q < nq; q += NT) {
+    const int c = (q << 2) / L;
+    const float gc = sel<C>(g, c), bc = sel<C>(bb, c);
+    const float4 x = *(const float4*)(X + (q << 2));
+    float4 z = make_float4(fmaf(x.x, gc, bc), fmaf(x.y, gc, bc), fmaf(x.z, gc, bc), fmaf(x.w, gc, bc));
+    if (silu) { z.x = silu_f(z.x); z.y = silu_f(z.y); z.z = silu_f(z.z); z.w = silu_f(z.w); }
+    *(float4*)(Y + (q << 2)) = z;
+  }
+  __syncthreads();
+}
+template <int C>
+__device__ void f_gn_t(const ThinOp& o, const float* P, const Bufs& B, float* __restrict__ stats) {
   const float* X = B.b[o.src]; float* Y = B.b[o.dst];
-  const int n = o.cin * o.Lin;
-  float s[1] = {0.f};
-  for (int i = threadIdx.x; i < n; i += NT) s[0] += X[i];
-  block_reduce<1>(s, B.red);
-  const float mean = B.red[NWAVE] / (float)n;
-  float q[1] = {0.f};
-  for (int i = threadIdx.x; i < n; i += NT) { const float d = X[i] - mean; q[0] = fmaf(d, d, q[0]); }
-  block_reduce<1>(q, B.red);
-  const float rstd = rsqrtf(B.red[NWAVE] / (float)n + GN_EPS_T);
-  if (threadIdx.x == 0) { stats[2 * o.stat] = mean; stats[2 * o.stat + 1] = rstd; }
-  for (int c = 0; c < o.cin; c++) {
-    const float g = P[o.gw + c] * rstd, bb = P[o.gb + c] - mean * g;
-    for (int l = threadIdx.x; l < o.Lin; l += NT) {
-      const float z = fmaf(X[c * o.Lin + l], g, bb);
-      Y[c * o.Lin + l] = o.silu ? silu_f(z) : z;
-    }
+  const int n = C * o.Lin, nq = n >> 2;
+  // one pass: sums of (x - K) and (x - K)^2 with K = the tensor's first element (removes the cancellation of E[x^2] - mean^2)
+  const float K = X[0];
+  float sq[2] = {0.f, 0.f};
+  for (int q = threadIdx.x; q < nq; q += NT) {
+    const float4 x = *(const float4*)(X + (q << 2));
+    const float a = x.x - K, b = x.y - K, c = x.z - K, d = x.w - K;
+    sq[0] += (a + b) + (c + d);
+    sq[1] = fmaf(a, a, fmaf(b, b, fmaf(c, c, fmaf(d, d, sq[1]))));
   }
-  __syncthreads();
+  block_reduce<2>(sq, B.red);
+  const float m1 = B.red[NWAVE * 2] / (float)n, m2 = B.red[NWAVE * 2 + 1] / (float)n;
+  const float mean = K + m1, rstd = rsqrtf(fmaxf(m2 - m1 * m1, 0.f) + GN_EPS_T);
+  if (threadIdx.x == 0) { stats[2 * o.stat] = mean; stats[2 * o.stat + 1] = rstd; }
+  gn_apply_t<C>(o, P, X, Y, mean, rstd);
 }
-
+__device__ void f_gn(const ThinOp& o, const float* P, const Bufs& B, float* stats) {
+  if (o.cin == 1) f_gn_t<1>(o, P, B, stats); else if (o.cin == 2) f_gn_t<2>(o, P, B, stats); else if (o.cin == 4) f_gn_t<4>(o, P, B, stats);
+}
 // GroupNorm apply with saved statistics (backward: recompute a conv's input)
-__device__ void b_recomp(const ThinOp& o, const float* __restrict__ P, const Bufs& B, const float* __restrict__ stats) {
+__device__ void b_recomp(const ThinOp& o, const float* P, const Bufs& B, const float* __restrict__ stats) {
   const float* X = B.b[o.src]; float* Y = B.b[o.dst];
   const float mean = stats[2 * o.stat], rstd = stats[2 * o.stat + 1];
-  for (int c = 0; c < o.cin; c++) {
-    const float g = P[o.gw + c] * rstd, bb = P[o.gb + c] - mean * g;
-    for (int l = threadIdx.x; l < o.Lin; l += NT) {
-      const float z = fmaf(X[c * o.Lin + l], g, bb);
-      Y[c * o.Lin + l] = o.silu ? silu_f(z) : z;
-    }
-  }
-  __syncthreads();
+  if (o.cin == 1) gn_apply_t<1>(o, P, X, Y, mean, rstd); else if (o.cin == 2) gn_apply_t<2>(o, P, X, Y, mean, rstd); else if (o.cin == 4) gn_apply_t<4>(o, P, X, Y, mean, rstd);
 }
 
 __device__ void d_ups(const ThinOp& o, const Bufs& B) {
@@ -122,218 +195,302 @@ __device__ void d_ups(const ThinOp& o, const Bufs& B) {
   __syncthreads();
 }
 
-__device__ void f_heads(const ThinOp& o, const float* __restrict__ P, const Bufs& B, float* __restrict__ tape, const int* __restrict__ tape_off,
-                        const float* __restrict__ eps, float* __restrict__ z_mu, float* __restrict__ z_sigma, float* __restrict__ kl, float inv_B) {
+template <int LAT>
+__device__ void f_heads_t(const ThinOp& o, const float* P, const Bufs& B, float* __restrict__ tape, const int* __restrict__ tape_off,
+                          const float* __restrict__ eps, float* __restrict__ z_mu, float* __restrict__ z_sigma, float* __restrict__ kl, float inv_B) {
   const float* H = B.b[o.src]; float* Z = B.b[o.dst];
-  const int lat = o.cin, L = o.Lin;
+  const int L = o.Lin;
   float* tmu = tape + tape_off[o.save]; float* tlv = tape + tape_off[o.save + 1];
   float part[1] = {0.f};
   for (int l = threadIdx.x; l < L; l += NT) {
-    float h[MC];
+    float h[LAT];
 #pragma unroll
-    for (int ci = 0; ci < MC; ci++) h[ci] = ci < lat ? H[ci * L + l] : 0.f;
+    for (int ci = 0; ci < LAT; ci++) h[ci] = H[ci * L + l];
 #pragma unroll
-    for (int co = 0; co < MC; co++) {
-      if (co < lat) {
-        float mu = P[o.b + co], lv = P[o.b2 + co];
+    for (int co = 0; co < LAT; co++) {
+      float mu = P[o.b + co], lv = P[o.b2 + co];
 #pragma unroll
-        for (int ci = 0; ci < MC; ci++) if (ci < lat) { mu = fmaf(P[o.w + co * lat + ci], h[ci], mu); lv = fmaf(P[o.w2 + co * lat + ci], h[ci], lv); }
-        const float lvc = fminf(20.f, fmaxf(-30.f, lv));
-        const float sg = __expf(0.5f * lvc);
-        const float e = eps ? eps[co * L + l] : 0.f;
-        Z[co * L + l] = fmaf(e, sg, mu);
-        tmu[co * L + l] = mu; tlv[co * L + l] = lv;
-        if (z_mu) z_mu[co * L + l] = mu;
-        if (z_sigma) z_sigma[co * L + l] = sg;
-        part[0] += 0.5f * (mu * mu + sg * sg - lvc - 1.0f);
-      }
+      for (int ci = 0; ci < LAT; ci++) { mu = fmaf(P[o.w + co * LAT + ci], h[ci], mu); lv = fmaf(P[o.w2 + co * LAT + ci], h[ci], lv); }
+      const float lvc = fminf(20.f, fmaxf(-30.f, lv));
+      const float sg = __expf(0.5f * lvc);
+      const float e = eps ? eps[co * L + l] : 0.f;
+      Z[co * L + l] = fmaf(e, sg, mu);
+      tmu[co * L + l] = mu; tlv[co * L + l] = lv;
+      if (z_mu) z_mu[co * L + l] = mu;
+      if (z_sigma) z_sigma[co * L + l] = sg;
+      part[0] += 0.5f * (mu * mu + sg * sg - lvc - 1.0f);
     }
   }
   block_reduce<1>(part, B.red);
   if (kl && threadIdx.x == 0) atomicAdd(kl, B.red[NWAVE] * inv_B);
 }
+__device__ void f_heads(const ThinOp& o, const float* P, const Bufs& B, float* tape, const int* tape_off, const float* eps, float* z_mu, float* z_sigma,
+                        float* kl, float inv_B) {
+  if (o.cin == 1) f_heads_t<1>(o, P, B, tape, tape_off, eps, z_mu, z_sigma, kl, inv_B);
+  else if (o.cin == 2) f_heads_t<2>(o, P, B, tape, tape_off, eps, z_mu, z_sigma, kl, inv_B);
+  else if (o.cin == 4) f_heads_t<4>(o, P, B, tape, tape_off, eps, z_mu, z_sigma, kl, inv_B);
+}
 
 // ------------------------------------------------------------------ backward pieces
-__device__ void b_conv(const ThinOp& o, const float* __restrict__ P, float* __restrict__ G, const Bufs& B) {
+template <int CIN, int COUT>
+__device__ void b_conv_t(const ThinOp& o, const float* P, float* __restrict__ G, const Bufs& B) {
   const float* dY = B.b[o.src]; float* A = B.b[o.act];
-  float w[MC][MC][3], bias[MC];
-  load_w(o, P, o.w, -1, w, bias);
+  float w[COUT][CIN][3], bias[COUT];
+  load_w<CIN, COUT>(o, P, o.w, -1, w, bias);
+  const int Lin = o.Lin, Lout = o.Lout, stride = o.stride, nk = o.k, pad = o.pad_l;
+  const bool vec = stride == 1 && ((nk == 3 && pad == 1) || (nk == 1 && pad == 0)) && (Lout & 3) == 0;
+  const bool k3 = nk == 3;
   // ---- dW / db
-  float acc[MC * MC * 3 + MC];
+  constexpr int NW_ = COUT * CIN * 3, NV = NW_ + COUT;
+  float acc[NV];
 #pragma unroll
-  for (int i = 0; i < MC * MC * 3 + MC; i++) acc[i] = 0.f;
-  for (int lo = threadIdx.x; lo < o.Lout; lo += NT) {
-    float dy[MC];
+  for (int i = 0; i < NV; i++) acc[i] = 0.f;
+  if (vec) {
+    for (int q = threadIdx.x; q < (Lout >> 2); q += NT) {
+      const int l0 = q << 2;
+      float dy[COUT][4];
 #pragma unroll
-    for (int co = 0; co < MC; co++) { dy[co] = co < o.cout ? dY[co * o.Lout + lo] : 0.f; acc[MC * MC * 3 + co] += dy[co]; }
+      for (int co = 0; co < COUT; co++) {
+        const float4 d = *(const float4*)(dY + co * Lout + l0);
+        dy[co][0] = d.x; dy[co][1] = d.y; dy[co][2] = d.z; dy[co][3] = d.w;
+        acc[NW_ + co] += (d.x + d.y) + (d.z + d.w);
+      }
 #pragma unroll
-    for (int k = 0; k < 3; k++) {
-      const int li = lo * o.stride + k - o.pad_l;
-      if (k < o.k && li >= 0 && li < o.Lin) {
+      for (int ci = 0; ci < CIN; ci++) {
+        float v[6];
+        row_window(A + ci * Lin, l0, Lin, k3, v);
 #pragma unroll
-        for (int ci = 0; ci < MC; ci++) {
-          if (ci < o.cin) {
-            const float xv = A[ci * o.Lin + li];
+        for (int co = 0; co < COUT; co++)
 #pragma unroll
-            for (int co = 0; co < MC; co++) acc[(co * MC + ci) * 3 + k] = fmaf(dy[co], xv, acc[(co * MC + ci) * 3 + k]);
+          for (int j = 0; j < 4; j++) {
+            if (k3) {
+#pragma unroll
+              for (int k = 0; k < 3; k++) acc[(co * CIN + ci) * 3 + k] = fmaf(dy[co][j], v[j + k], acc[(co * CIN + ci) * 3 + k]);
+            } else acc[(co * CIN + ci) * 3] = fmaf(dy[co][j], v[j + 1], acc[(co * CIN + ci) * 3]);
+          }
+      }
+    }
+  } else {
+    for (int lo = threadIdx.x; lo < Lout; lo += NT) {
+      float dy[COUT];
+#pragma unroll
+      for (int co = 0; co < COUT; co++) { dy[co] = dY[co * Lout + lo]; acc[NW_ + co] += dy[co]; }
+#pragma unroll
+      for (int k = 0; k < 3; k++) {
+        const int li = lo * stride + k - pad;
+        if (k < nk && li >= 0 && li < Lin) {
+#pragma unroll
+          for (int ci = 0; ci < CIN; ci++) {
+            const float xv = A[ci * Lin + li];
+#pragma unroll
+            for (int co = 0; co < COUT; co++) acc[(co * CIN + ci) * 3 + k] = fmaf(dy[co], xv, acc[(co * CIN + ci) * 3 + k]);
           }
         }
       }
     }
   }
-  block_reduce<MC * MC * 3 + MC>(acc, B.red);       // ends with a barrier: every read of A above is done
-  const float* R = B.red + NWAVE * (MC * MC * 3 + MC);
-  if (threadIdx.x < MC * MC * 3) {
-    const int co = threadIdx.x / (MC * 3), ci = (threadIdx.x / 3) % MC, k = threadIdx.x % 3;
-    if (co < o.cout && ci < o.cin && k < o.k) atomicAdd(G + o.w + (k * o.cout + co) * o.cin + ci, R[threadIdx.x]);
-  } else if (threadIdx.x < MC * MC * 3 + MC) {
-    const int co = threadIdx.x - MC * MC * 3;
-    if (o.b >= 0 && co < o.cout) atomicAdd(G + o.b + co, R[threadIdx.x]);
+  block_reduce<NV>(acc, B.red);       // ends with a barrier: every read of A above is done
+  const float* R = B.red + NWAVE * NV;
+  if (threadIdx.x < NW_) {
+    const int co = threadIdx.x / (CIN * 3), ci = (threadIdx.x / 3) % CIN, k = threadIdx.x % 3;
+    if (k < nk) atomicAdd(G + o.w + (k * COUT + co) * CIN + ci, R[threadIdx.x]);
+  } else if (threadIdx.x < NV) {
+    if (o.b >= 0) atomicAdd(G + o.b + (threadIdx.x - NW_), R[threadIdx.x]);
   }
   // ---- dX -> overwrites the activation buffer
   if (o.need_dx) {
-    for (int li = threadIdx.x; li < o.Lin; li += NT) {
-      float dx[MC];
+    if (vec) {
+      // dX[ci][l] = sum_co sum_k w[co][ci][k] dY[co][l + 1 - k]  (k = 3, pad 1)  |  sum_co w[co][ci][0] dY[co][l]  (k = 1)
+      for (int q = threadIdx.x; q < (Lin >> 2); q += NT) {
+        const int l0 = q << 2;
+        float dx[CIN][4];
 #pragma unroll
-      for (int ci = 0; ci < MC; ci++) dx[ci] = 0.f;
+        for (int ci = 0; ci < CIN; ci++)
 #pragma unroll
-      for (int k = 0; k < 3; k++) {
-        const int t = li + o.pad_l - k;
-        if (k < o.k && t >= 0 && (o.stride == 1 || (t & 1) == 0)) {
-          const int lo = o.stride == 1 ? t : t >> 1;
-          if (lo < o.Lout) {
+          for (int j = 0; j < 4; j++) dx[ci][j] = 0.f;
 #pragma unroll
-            for (int co = 0; co < MC; co++) {
-              if (co < o.cout) {
-                const float dy = dY[co * o.Lout + lo];
+        for (int co = 0; co < COUT; co++) {
+          float v[6];
+          row_window(dY + co * Lout, l0, Lout, k3, v);
 #pragma unroll
-                for (int ci = 0; ci < MC; ci++) dx[ci] = fmaf(w[co][ci][k], dy, dx[ci]);
+          for (int ci = 0; ci < CIN; ci++)
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+              if (k3) { dx[ci][j] = fmaf(w[co][ci][0], v[j + 2], dx[ci][j]); dx[ci][j] = fmaf(w[co][ci][1], v[j + 1], dx[ci][j]); dx[ci][j] = fmaf(w[co][ci][2], v[j], dx[ci][j]); }
+              else dx[ci][j] = fmaf(w[co][ci][0], v[j + 1], dx[ci][j]);
+            }
+        }
+#pragma unroll
+        for (int ci = 0; ci < CIN; ci++) *(float4*)(A + ci * Lin + l0) = make_float4(dx[ci][0], dx[ci][1], dx[ci][2], dx[ci][3]);
+      }
+    } else {
+      for (int li = threadIdx.x; li < Lin; li += NT) {
+        float dx[CIN];
+#pragma unroll
+        for (int ci = 0; ci < CIN; ci++) dx[ci] = 0.f;
+#pragma unroll
+        for (int k = 0; k < 3; k++) {
+          const int t = li + pad - k;
+          if (k < nk && t >= 0 && (stride == 1 || (t & 1) == 0)) {
+            const int lo = stride == 1 ? t : t >> 1;
+            if (lo < Lout) {
+#pragma unroll
+              for (int co = 0; co < COUT; co++) {
+                const float dy = dY[co * Lout + lo];
+#pragma unroll
+                for (int ci = 0; ci < CIN; ci++) dx[ci] = fmaf(w[co][ci][k], dy, dx[ci]);
               }
             }
           }
         }
-      }
 #pragma unroll
-      for (int ci = 0; ci < MC; ci++) if (ci < o.cin) A[ci * o.Lin + li] = dx[ci];
+        for (int ci = 0; ci < CIN; ci++) A[ci * Lin + li] = dx[ci];
+      }
     }
   }
   __syncthreads();
 }
+__device__ void b_conv(const ThinOp& o, const float* P, float* G, const Bufs& B) { THIN_CC(b_conv_t, o, P, G, B) }
 
-__device__ void b_gn(const ThinOp& o, const float* __restrict__ P, float* __restrict__ G, const Bufs& B, const float* __restrict__ stats) {
+template <int C>
+__device__ void b_gn_t(const ThinOp& o, const float* P, float* __restrict__ G, const Bufs& B, const float* __restrict__ stats) {
   const float* X = B.b[o.act]; const float* dY = B.b[o.src]; float* dX = B.b[o.dst]; const float* ADD = o.add >= 0 ? B.b[o.add] : nullptr;
   const float mean = stats[2 * o.stat], rstd = stats[2 * o.stat + 1];
-  const int L = o.Lin, C = o.cin;
-  float acc[2 * MC];
+  const int L = o.Lin, nq = (C * L) >> 2; const bool silu = o.silu != 0;
+  float acc[2 * C];
 #pragma unroll
-  for (int i = 0; i < 2 * MC; i++) acc[i] = 0.f;
-  float ga[MC], be[MC];
+  for (int i = 0; i < 2 * C; i++) acc[i] = 0.f;
+  float ga[C], be[C];
 #pragma unroll
-  for (int c = 0; c < MC; c++) { ga[c] = c < C ? P[o.gw + c] : 0.f; be[c] = c < C ? P[o.gb + c] : 0.f; }
+  for (int c = 0; c < C; c++) { ga[c] = P[o.gw + c]; be[c] = P[o.gb + c]; }
+  const float nmr = -mean * rstd;
+  for (int q = threadIdx.x; q < nq; q += NT) {
+    const int c = (q << 2) / L;
+    const float gc = sel<C>(ga, c), bc = sel<C>(be, c);
+    const float4 x = *(const float4*)(X + (q << 2)), d = *(const float4*)(dY + (q << 2));
+    const float xs[4] = {x.x, x.y, x.z, x.w}, ds[4] = {d.x, d.y, d.z, d.w};
+    float sg = 0.f, sb = 0.f;
 #pragma unroll
-  for (int c = 0; c < MC; c++) {
-    if (c < C) {
-      for (int l = threadIdx.x; l < L; l += NT) {
-        const float xh = (X[c * L + l] - mean) * rstd;
-        const float dz = dY[c * L + l] * (o.silu ? silu_grad_f(fmaf(xh, ga[c], be[c])) : 1.0f);
-        acc[c] = fmaf(dz, xh, acc[c]); acc[MC + c] += dz;
-      }
+    for (int j = 0; j < 4; j++) {
+      const float xh = fmaf(xs[j], rstd, nmr);
+      const float dz = ds[j] * (silu ? silu_grad_f(fmaf(xh, gc, bc)) : 1.0f);
+      sg = fmaf(dz, xh, sg); sb += dz;
     }
+#pragma unroll
+    for (int i = 0; i < C; i++) { acc[i] += c == i ? sg : 0.f; acc[C + i] += c == i ? sb : 0.f; }
   }
-  block_reduce<2 * MC>(acc, B.red);
-  const float* R = B.red + NWAVE * 2 * MC;
-  if (threadIdx.x < MC) { if (threadIdx.x < C) atomicAdd(G + o.gw + threadIdx.x, R[threadIdx.x]); }
-  else if (threadIdx.x < 2 * MC) { if (threadIdx.x - MC < C) atomicAdd(G + o.gb + threadIdx.x - MC, R[threadIdx.x]); }
+  block_reduce<2 * C>(acc, B.red);
+  const float* R = B.red + NWAVE * 2 * C;
+  if (threadIdx.x < C) atomicAdd(G + o.gw + threadIdx.x, R[threadIdx.x]);
+  else if (threadIdx.x < 2 * C) atomicAdd(G + o.gb + threadIdx.x - C, R[threadIdx.x]);
   float s1 = 0.f, s2 = 0.f;
 #pragma unroll
-  for (int c = 0; c < MC; c++) { s1 = fmaf(ga[c], R[MC + c], s1); s2 = fmaf(ga[c], R[c], s2); }
+  for (int c = 0; c < C; c++) { s1 = fmaf(ga[c], R[C + c], s1); s2 = fmaf(ga[c], R[c], s2); }
   const float inv_n = 1.0f / (float)(C * L);
   const float m1 = s1 * inv_n, m2 = s2 * inv_n;
+  for (int q = threadIdx.x; q < nq; q += NT) {
+    const int c = (q << 2) / L;
+    const float gc = sel<C>(ga, c), bc = sel<C>(be, c);
+    const float4 x = *(const float4*)(X + (q << 2)), d = *(const float4*)(dY + (q << 2));
+    const float xs[4] = {x.x, x.y, x.z, x.w}, ds[4] = {d.x, d.y, d.z, d.w};
+    float r[4];
 #pragma unroll
-  for (int c = 0; c < MC; c++) {
-    if (c < C) {
-      for (int l = threadIdx.x; l < L; l += NT) {
-        const float xh = (X[c * L + l] - mean) * rstd;
-        const float dz = dY[c * L + l] * (o.silu ? silu_grad_f(fmaf(xh, ga[c], be[c])) : 1.0f);
-        dX[c * L + l] = rstd * (dz * ga[c] - m1 - xh * m2) + (ADD ? ADD[c * L + l] : 0.f);
-      }
+    for (int j = 0; j < 4; j++) {
+      const float xh = fmaf(xs[j], rstd, nmr);
+      const float dz = ds[j] * (silu ? silu_grad_f(fmaf(xh, gc, bc)) : 1.0f);
+      r[j] = rstd * (dz * gc - m1 - xh * m2);
     }
+    float4 out = make_float4(r[0], r[1], r[2], r[3]);
+    if (ADD) { const float4 a = *(const float4*)(ADD + (q << 2)); out.x += a.x; out.y += a.y; out.z += a.z; out.w += a.w; }
+    *(float4*)(dX + (q << 2)) = out;
   }
   __syncthreads();
 }
+__device__ void b_gn(const ThinOp& o, const float* P, float* G, const Bufs& B, const float* stats) {
+  if (o.cin == 1) b_gn_t<1>(o, P, G, B, stats); else if (o.cin == 2) b_gn_t<2>(o, P, G, B, stats); else if (o.cin == 4) b_gn_t<4>(o, P, G, B, stats);
+}
 
-__device__ void b_heads(const ThinOp& o, const float* __restrict__ P, float* __restrict__ G, const Bufs& B, const float* __restrict__ tape,
-                        const int* __restrict__ tape_off, const float* __restrict__ eps, float klw_over_B) {
+template <int LAT>
+__device__ void b_heads_t(const ThinOp& o, const float* P, float* __restrict__ G, const Bufs& B, const float* __restrict__ tape,
+                          const int* __restrict__ tape_off, const float* __restrict__ eps, float klw_over_B) {
   float* DZ = B.b[o.src]; float* DH = B.b[o.dst]; const float* H = B.b[o.act];
-  const int lat = o.cin, L = o.Lin;
+  const int L = o.Lin;
   const float* tmu = tape + tape_off[o.save]; const float* tlv = tape + tape_off[o.save + 1];
-  constexpr int NV = 2 * (MC * MC + MC);
+  constexpr int NV = 2 * (LAT * LAT + LAT);
   float acc[NV];            // [dWmu co][ci], [dbmu], [dWlv], [dblv]
 #pragma unroll
   for (int i = 0; i < NV; i++) acc[i] = 0.f;
   for (int l = threadIdx.x; l < L; l += NT) {
-    float h[MC], dmu[MC], dlv[MC], dh[MC];
+    float h[LAT], dmu[LAT], dlv[LAT], dh[LAT];
 #pragma unroll
-    for (int c = 0; c < MC; c++) { h[c] = c < lat ? H[c * L + l] : 0.f; dh[c] = 0.f; dmu[c] = 0.f; dlv[c] = 0.f; }
+    for (int c = 0; c < LAT; c++) { h[c] = H[c * L + l]; dh[c] = 0.f; }
 #pragma unroll
-    for (int co = 0; co < MC; co++) {
-      if (co < lat) {
-        const float dz = DZ[co * L + l], mu = tmu[co * L + l], lv = tlv[co * L + l];
-        const bool inside = lv > -30.f && lv < 20.f;             // clamp passes the gradient strictly inside (torch.clamp)
-        const float lvc = fminf(20.f, fmaxf(-30.f, lv));
-        const float sg = __expf(0.5f * lvc);
-        const float e = eps ? eps[co * L + l] : 0.f;
-        dmu[co] = fmaf(klw_over_B, mu, dz);                       // z = mu + eps sigma ; KL: d/dmu = mu
-        // d/dlv: z -> dz * eps * sigma / 2 ; KL 0.5 (sigma^2 - lv - 1) -> 0.5 (sigma^2 - 1)
-        dlv[co] = inside ? fmaf(dz * e, 0.5f * sg, klw_over_B * 0.5f * (sg * sg - 1.0f)) : 0.f;
+    for (int co = 0; co < LAT; co++) {
+      const float dz = DZ[co * L + l], mu = tmu[co * L + l], lv = tlv[co * L + l];
+      const bool inside = lv > -30.f && lv < 20.f;             // clamp passes the gradient strictly inside (torch.clamp)
+      const float lvc = fminf(20.f, fmaxf(-30.f, lv));
+      const float sg = __expf(0.5f * lvc);
+      const float e = eps ? eps[co * L + l] : 0.f;
+      dmu[co] = fmaf(klw_over_B, mu, dz);                       // z = mu + eps sigma ; KL: d/dmu = mu
+      // d/dlv: z -> dz * eps * sigma / 2 ; KL 0.5 (sigma^2 - lv - 1) -> 0.5 (sigma^2 - 1)
+      dlv[co] = inside ? fmaf(dz * e, 0.5f * sg, klw_over_B * 0.5f * (sg * sg - 1.0f)) : 0.f;
+    }
+#pragma unroll
+    for (int co = 0; co < LAT; co++) {
+      acc[LAT * LAT + co] += dmu[co]; acc[LAT * LAT + LAT + LAT * LAT + co] += dlv[co];
+#pragma unroll
+      for (int ci = 0; ci < LAT; ci++) {
+        acc[co * LAT + ci] = fmaf(dmu[co], h[ci], acc[co * LAT + ci]);
+        acc[LAT * LAT + LAT + co * LAT + ci] = fmaf(dlv[co], h[ci], acc[LAT * LAT + LAT + co * LAT + ci]);
+        dh[ci] = fmaf(P[o.w + co * LAT + ci], dmu[co], dh[ci]);
+        dh[ci] = fmaf(P[o.w2 + co * LAT + ci], dlv[co], dh[ci]);
       }
     }
 #pragma unroll
-    for (int co = 0; co < MC; co++) {
-      if (co < lat) {
-        acc[MC * MC + co] += dmu[co]; acc[MC * MC + MC + MC * MC + co] += dlv[co];
-#pragma unroll
-        for (int ci = 0; ci < MC; ci++) {
-          if (ci < lat) {
-            acc[co * MC + ci] = fmaf(dmu[co], h[ci], acc[co * MC + ci]);
-            acc[MC * MC + MC + co * MC + ci] = fmaf(dlv[co], h[ci], acc[MC * MC + MC + co * MC + ci]);
-            dh[ci] = fmaf(P[o.w + co * lat + ci], dmu[co], dh[ci]);
-            dh[ci] = fmaf(P[o.w2 + co * lat + ci], dlv[co], dh[ci]);
-          }
-        }
-      }
-    }
-#pragma unroll
-    for (int ci = 0; ci < MC; ci++) if (ci < lat) DH[ci * L + l] = dh[ci];
+    for (int ci = 0; ci < LAT; ci++) DH[ci * L + l] = dh[ci];
   }
   block_reduce<NV>(acc, B.red);
   const float* R = B.red + NWAVE * NV;
   const int t = threadIdx.x;
-  if (t < MC * MC) { const int co = t / MC, ci = t % MC; if (co < lat && ci < lat) atomicAdd(G + o.w + co * lat + ci, R[t]); }
-  else if (t < MC * MC + MC) { const int co = t - MC * MC; if (co < lat) atomicAdd(G + o.b + co, R[t]); }
-  else if (t < 2 * MC * MC + MC) { const int u = t - MC * MC - MC, co = u / MC, ci = u % MC; if (co < lat && ci < lat) atomicAdd(G + o.w2 + co * lat + ci, R[t]); }
-  else if (t < NV) { const int co = t - 2 * MC * MC - MC; if (co < lat) atomicAdd(G + o.b2 + co, R[t]); }
+  if (t < LAT * LAT) atomicAdd(G + o.w + t, R[t]);
+  else if (t < LAT * LAT + LAT) atomicAdd(G + o.b + (t - LAT * LAT), R[t]);
+  else if (t < 2 * LAT * LAT + LAT) atomicAdd(G + o.w2 + (t - LAT * LAT - LAT), R[t]);
+  else if (t < NV) atomicAdd(G + o.b2 + (t - 2 * LAT * LAT - LAT), R[t]);
   __syncthreads();
+}
+__device__ void b_heads(const ThinOp& o, const float* P, float* G, const Bufs& B, const float* tape, const int* tape_off, const float* eps, float klw_over_B) {
+  if (o.cin == 1) b_heads_t<1>(o, P, G, B, tape, tape_off, eps, klw_over_B);
+  else if (o.cin == 2) b_heads_t<2>(o, P, G, B, tape, tape_off, eps, klw_over_B);
+  else if (o.cin == 4) b_heads_t<4>(o, P, G, B, tape, tape_off, eps, klw_over_B);
 }
 
 __device__ __forceinline__ Bufs make_bufs(char* smem, int maxt) {
   Bufs B;
-#pragma unroll
-  for (int i = 0; i < THIN_NBUF; i++) B.b[i] = (float*)smem + (size_t)i * maxt;
+  B.b.base = (float*)smem; B.b.maxt = maxt;
   B.red = (float*)smem + (size_t)THIN_NBUF * maxt;
   return B;
 }
 
-__global__ __launch_bounds__(NT) void thin_fwd_kernel(const ThinOp* __restrict__ ops, int nops, const int* __restrict__ tape_off, int tape_stride, int nstat,
-                                                      int maxt, const float* __restrict__ P, const float* __restrict__ x, const float* __restrict__ eps,
+__global__ __launch_bounds__(NT) void thin_fwd_kernel(const ThinOp* ops, int nops, const int* __restrict__ tape_off, int tape_stride, int nstat,
+                                                      int maxt, const float* P, const float* __restrict__ x, const float* __restrict__ eps,
                                                       float* __restrict__ recon, float* __restrict__ z_mu, float* __restrict__ z_sigma, float* __restrict__ kl,
-                                                      float* __restrict__ tape_all, float* __restrict__ stats_all, int lat, int Ll, float inv_B) {
+                                                      float* __restrict__ tape_all, float* __restrict__ stats_all, int lat, int Ll, float inv_B, int nparams, unsigned long long* __restrict__ prof) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const Bufs B = make_bufs(smem, maxt);
+  // the whole parameter set (934 values for [2,2,4]) is copied to LDS once: every micro-op starts by reading its weights, and a
+  // dependent global load there exposed ~2 us of latency per op (90 ops: most of the first version's 310 us)
+  float* PL = B.red + RED_FLOATS;
+  for (int j = threadIdx.x; j < nparams; j += NT) PL[j] = P[j];
+  // ... and so is the micro-op table (each op used to start with a dependent scalar load of its descriptor)
+  int* OL = (int*)(PL + ((nparams + 3) & ~3));
+  for (int j = threadIdx.x; j < nops * (int)(sizeof(ThinOp) / 4); j += NT) OL[j] = ((const int*)ops)[j];
+  __syncthreads();
+  P = PL; ops = (const ThinOp*)OL;
   const int b = blockIdx.x;
   float* tape = tape_all + (size_t)b * tape_stride; float* stats = stats_all + (size_t)b * nstat * 2;
   for (int i = 0; i < nops; i++) {
     const ThinOp o = ops[i];
+    const unsigned long long t0 = prof ? __builtin_readcyclecounter() : 0ull;
     switch (o.kind) {
       case TF_LOAD: {
         const float* src = x + (size_t)b * o.cin * o.Lin; float* D = B.b[o.dst];
@@ -344,8 +501,8 @@ __global__ __launch_bounds__(NT) void thin_fwd_kernel(const ThinOp* __restrict__
       case TF_GN: f_gn(o, P, B, stats); break;
       case TF_UPS: d_ups(o, B); break;
       case TF_SAVE: {
-        const float* S = B.b[o.src]; float* D = tape + tape_off[o.save];
-        for (int j = threadIdx.x; j < o.cin * o.Lin; j += NT) D[j] = S[j];
+        const float4* S = (const float4*)B.b[o.src]; float4* D = (float4*)(tape + tape_off[o.save]);
+        for (int j = threadIdx.x; j < (o.cin * o.Lin) >> 2; j += NT) D[j] = S[j];
         __syncthreads();       // the next op may overwrite the saved buffer
       } break;
       case TF_HEADS:
@@ -357,19 +514,27 @@ __global__ __launch_bounds__(NT) void thin_fwd_kernel(const ThinOp* __restrict__
         for (int j = threadIdx.x; j < o.cin * o.Lin; j += NT) D[j] = S[j];
       } break;
     }
+    if (prof && blockIdx.x == 0 && threadIdx.x == 0) prof[i] = __builtin_readcyclecounter() - t0;
   }
 }
 
-__global__ __launch_bounds__(NT) void thin_bwd_kernel(const ThinOp* __restrict__ ops, int nops, const int* __restrict__ tape_off, int tape_stride, int nstat,
-                                                      int maxt, const float* __restrict__ P, float* __restrict__ G, const float* __restrict__ d_recon,
+__global__ __launch_bounds__(NT) void thin_bwd_kernel(const ThinOp* ops, int nops, const int* __restrict__ tape_off, int tape_stride, int nstat,
+                                                      int maxt, const float* P, float* __restrict__ G, const float* __restrict__ d_recon,
                                                       const float* __restrict__ eps, float* __restrict__ dx_out, const float* __restrict__ tape_all,
-                                                      const float* __restrict__ stats_all, int lat, int Ll, float klw_over_B) {
+                                                      const float* __restrict__ stats_all, int lat, int Ll, float klw_over_B, int nparams, unsigned long long* __restrict__ prof) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const Bufs B = make_bufs(smem, maxt);
+  float* PL = B.red + RED_FLOATS;
+  for (int j = threadIdx.x; j < nparams; j += NT) PL[j] = P[j];
+  int* OL = (int*)(PL + ((nparams + 3) & ~3));
+  for (int j = threadIdx.x; j < nops * (int)(sizeof(ThinOp) / 4); j += NT) OL[j] = ((const int*)ops)[j];
+  __syncthreads();
+  P = PL; ops = (const ThinOp*)OL;
   const int b = blockIdx.x;
   const float* tape = tape_all + (size_t)b * tape_stride; const float* stats = stats_all + (size_t)b * nstat * 2;
   for (int i = 0; i < nops; i++) {
     const ThinOp o = ops[i];
+    const unsigned long long t0 = prof ? __builtin_readcyclecounter() : 0ull;
     switch (o.kind) {
       case TB_LOADDY: {
         const float* src = d_recon + (size_t)b * o.cin * o.Lin; float* D = B.b[o.dst];
@@ -377,8 +542,8 @@ __global__ __launch_bounds__(NT) void thin_bwd_kernel(const ThinOp* __restrict__
         __syncthreads();
       } break;
       case TB_LOADT: {
-        const float* src = tape + tape_off[o.save]; float* D = B.b[o.dst];
-        for (int j = threadIdx.x; j < o.cin * o.Lin; j += NT) D[j] = src[j];
+        const float4* src = (const float4*)(tape + tape_off[o.save]); float4* D = (float4*)B.b[o.dst];
+        for (int j = threadIdx.x; j < (o.cin * o.Lin) >> 2; j += NT) D[j] = src[j];
         __syncthreads();
       } break;
       case TB_RECOMP: b_recomp(o, P, B, stats); break;
@@ -391,8 +556,8 @@ __global__ __launch_bounds__(NT) void thin_bwd_kernel(const ThinOp* __restrict__
         __syncthreads();
       } break;
       case TB_COPY: {
-        const float* S = B.b[o.src]; float* D = B.b[o.dst];
-        for (int j = threadIdx.x; j < o.cin * o.Lin; j += NT) D[j] = S[j];
+        const float4* S = (const float4*)B.b[o.src]; float4* D = (float4*)B.b[o.dst];
+        for (int j = threadIdx.x; j < (o.cin * o.Lin) >> 2; j += NT) D[j] = S[j];
         __syncthreads();
       } break;
       case TB_HEADS: b_heads(o, P, G, B, tape, tape_off, eps ? eps + (size_t)b * lat * Ll : nullptr, klw_over_B); break;
@@ -403,14 +568,37 @@ __global__ __launch_bounds__(NT) void thin_bwd_kernel(const ThinOp* __restrict__
         }
       } break;
     }
+    if (prof && blockIdx.x == 0 && threadIdx.x == 0) prof[i] = __builtin_readcyclecounter() - t0;
   }
 }
 
-size_t lds_bytes(const ThinProgram& p) { return sizeof(float) * ((size_t)THIN_NBUF * p.maxt + RED_FLOATS + 64); }
+size_t lds_bytes(const ThinProgram& p) {
+  const size_t nops = p.fwd.size() > p.bwd.size() ? p.fwd.size() : p.bwd.size();
+  return sizeof(float) * ((size_t)THIN_NBUF * p.maxt + RED_FLOATS + p.nparams + 64) + nops * sizeof(ThinOp);
+}
 }  // namespace
+
+// developer aid (EEGLDM_THIN_PROF=1): per-op shader cycles of workgroup 0, summed per op kind, printed after every launch
+static unsigned long long* prof_buf() {
+  static const bool on = getenv("EEGLDM_THIN_PROF") != nullptr;
+  static unsigned long long* buf = nullptr;
+  if (on && !buf) (void)hipMalloc(&buf, 8 * 1024);
+  return on ? buf : nullptr;
+}
+static void prof_dump(eegldm_ctx* ctx, const std::vector<ThinOp>& ops, unsigned long long* prof, const char* tag) {
+  (void)hipStreamSynchronize(ctx->stream);
+  std::vector<unsigned long long> h(ops.size());
+  (void)hipMemcpy(h.data(), prof, 8 * ops.size(), hipMemcpyDeviceToHost);
+  unsigned long long kind[16] = {0}, tot = 0; int cnt[16] = {0};
+  for (size_t i = 0; i < ops.size(); i++) { kind[ops[i].kind] += h[i]; cnt[ops[i].kind]++; tot += h[i]; }
+  fprintf(stderr, "thin %s: %zu ops, %llu cycles;", tag, ops.size(), tot);
+  for (int k = 0; k < 16; k++) if (cnt[k]) fprintf(stderr, " kind%d x%d: %llu", k, cnt[k], kind[k]);
+  fprintf(stderr, "\n");
+}
 
 int thin_upload(ThinProgram* p) {
   EEG_CHECK(p->maxt > 0 && p->maxt <= THIN_MAX_FLOATS, "thin autoencoder: tensor of %d values does not fit the LDS buffers", p->maxt);
+  EEG_CHECK(p->nparams > 0 && lds_bytes(*p) <= 160 * 1024, "thin autoencoder: %d parameters + tensors exceed the LDS", p->nparams);
   thin_free(p);
   HIP_TRY(hipMalloc(&p->d_fwd, sizeof(ThinOp) * p->fwd.size()));
   HIP_TRY(hipMalloc(&p->d_bwd, sizeof(ThinOp) * p->bwd.size()));
@@ -432,16 +620,20 @@ void thin_free(ThinProgram* p) {
 int thin_forward(eegldm_ctx* ctx, const ThinProgram& p, const float* params, const float* x, const float* eps, float* recon, float* z_mu,
                  float* z_sigma, float* kl, int B) {
   EEG_CHECK(p.d_fwd && p.tape && p.stats, "thin program not prepared");
+  unsigned long long* prof = prof_buf();
   hipLaunchKernelGGL(thin_fwd_kernel, dim3(B), dim3(NT), lds_bytes(p), ctx->stream, p.d_fwd, (int)p.fwd.size(), p.d_tape_off, p.tape_stride, p.nstat, p.maxt,
-                     params, x, eps, recon, z_mu, z_sigma, kl, p.tape, p.stats, p.lat, p.Ll, 1.0f / (float)B);
+                     params, x, eps, recon, z_mu, z_sigma, kl, p.tape, p.stats, p.lat, p.Ll, 1.0f / (float)B, p.nparams, prof);
   LAUNCH_CHECK();
+  if (prof) prof_dump(ctx, p.fwd, prof, "fwd");
   return 0;
 }
 int thin_backward(eegldm_ctx* ctx, const ThinProgram& p, const float* params, float* grads, const float* d_recon, const float* eps, float klw_over_B,
                   float* dx, int B) {
   EEG_CHECK(p.d_bwd && p.tape && p.stats, "thin program not prepared");
+  unsigned long long* prof = prof_buf();
   hipLaunchKernelGGL(thin_bwd_kernel, dim3(B), dim3(NT), lds_bytes(p), ctx->stream, p.d_bwd, (int)p.bwd.size(), p.d_tape_off, p.tape_stride, p.nstat, p.maxt,
-                     params, grads, d_recon, eps, dx, p.tape, p.stats, p.lat, p.Ll, klw_over_B);
+                     params, grads, d_recon, eps, dx, p.tape, p.stats, p.lat, p.Ll, klw_over_B, p.nparams, prof);
   LAUNCH_CHECK();
+  if (prof) prof_dump(ctx, p.bwd, prof, "bwd");
   return 0;
 }
