@@ -55,9 +55,19 @@ int SeqNet::forward_seq(const std::vector<Op>& ops, View x, int B, int& L, View*
     if (o.kind == OP_CONV) {
       const int Lo = (L + o.pl + o.pr - o.k) / o.stride + 1;
       ALLOC_OR_FAIL(y.p, alloc_act((long)B * Lo, o.cout)); y.ld = o.cout; y.C = o.cout;
+      // conv + plain LeakyReLU (the discriminator's first layer): the activation rides on the conv's store.  The tape then holds the
+      // ACTIVATED tensor as the activation op's input: LeakyReLU keeps the sign, so its backward mask (x > 0) is unchanged.
+      const bool fuse_act = i + 1 < ops.size() && ops[i + 1].kind == OP_ACT && ops[i + 1].bn_w < 0 && (long)B * Lo < (1L << 30) &&
+                            op_conv_fuses_act(dt, o.cin, o.cout, o.k, y.ld);
       EEG_TRY(op_conv_fwd(ctx, dt, x.p, x.ld, W(o.w), o.b >= 0 ? P(o.b) : nullptr, y.p, y.ld, B, L, o.cin, o.cout, o.k, o.stride, o.pl, o.pr,
-                          nullptr, 0, nullptr, 0));
+                          nullptr, 0, nullptr, 0, fuse_act ? ops[i + 1].slope : 0.f));
       L = Lo;
+      if (fuse_act) {
+        t.Lout = L; tape.push_back(t);
+        OpTape ta; ta.x = y; ta.Lin = L; ta.Lout = L; tape.push_back(ta);
+        x = y; i++;
+        continue;
+      }
     } else if (o.kind == OP_RES) {
       ALLOC_OR_FAIL(y.p, alloc_act((long)B * L, o.r.cout)); y.ld = o.r.cout; y.C = o.r.cout;
       EEG_TRY(res_forward(this, o.r, x, B, L, y));

@@ -21,6 +21,7 @@ struct DArgs {
   int Cout, Cin;                  // the conv's true Cout/Cin (weight strides)
   int K, stride, pad_l;
   int dgrad;                      // 0: fwd (in row = lo*stride + t - pad_l), 1: dgrad (lo = (li + pad_l - t)/stride)
+  float act_slope;                // > 0: LeakyReLU(act_slope) applied to the output (fused activation; thin-input register kernel only)
 };
 
 // weight element for (tap t, launch-output channel o, launch-input channel i)
@@ -209,6 +210,10 @@ __global__ __launch_bounds__(NT) void dconv_thin_in_reg_kernel(const DArgs a) {
       const RowVec<T, G> rr = *(const RowVec<T, G>*)((const T*)a.resid + (long)r * a.ldr + o0);
 #pragma unroll
       for (int k = 0; k < G; k++) acc[k] += ld_f32(&rr.v[k]);
+    }
+    if (a.act_slope > 0.f) {      // fused LeakyReLU (the discriminator's first layer): saves a 100 MB elementwise pass per forward
+#pragma unroll
+      for (int k = 0; k < G; k++) acc[k] = acc[k] > 0.f ? acc[k] : acc[k] * a.act_slope;
     }
     RowVec<T, G> ov;
 #pragma unroll
@@ -600,10 +605,20 @@ bool conv_is_thin(int Cin, int Cout, int dtype) {
   return Cin < 16 || Cout < 16 || (Cin % epc) != 0 || (Cout % epc) != 0;
 }
 
+// true when dconv_run takes the register-resident thin-input kernel for this forward conv (the one that can fuse a LeakyReLU)
+bool dconv_fuses_act(int dtype, int Cin, int Cout, int K, long ldout) {
+  const int G = dtype == EEGLDM_F32 ? 4 : 8;
+  static const bool reg_ok = getenv("EEGLDM_DCONV_NO_REG") == nullptr, fuse_ok = getenv("EEGLDM_DCONV_NO_FUSED_ACT") == nullptr;
+  const int gpr = Cout / G;
+  return reg_ok && fuse_ok && Cin <= 4 && Cout % G == 0 && Cout >= 16 && K <= 3 && ldout % G == 0 && ((size_t)K * Cin * Cout + Cout) * 4 <= 48 * 1024 &&
+         gpr <= NT && NT % gpr == 0;
+}
 int dconv_run(eegldm_ctx* ctx, int dtype, bool dgrad, const void* in, long ldin, const void* w, const float* bias,
               const void* resid, long ldr, void* out, long ldout, int B, int Lin, int Lout, int Cin, int Cout, int K,
-              int stride, int pad_l) {
+              int stride, int pad_l, float act_slope) {
   DArgs a;
+  a.act_slope = act_slope;
+  EEG_CHECK(act_slope <= 0.f || (!dgrad && dconv_fuses_act(dtype, Cin, Cout, K, ldout) && (long)B * Lout < (1L << 30)), "fused activation is not available for this conv");
   a.in = in; a.ldin = ldin; a.w = w; a.bias = bias; a.resid = resid; a.ldr = ldr; a.out = out; a.ldout = ldout;
   a.B = B; a.Cout = Cout; a.Cin = Cin; a.K = K; a.stride = stride; a.pad_l = pad_l; a.dgrad = dgrad ? 1 : 0;
   if (!dgrad) { a.Lo = Lout; a.Li = Lin; a.Co = Cout; a.Ci = Cin; }

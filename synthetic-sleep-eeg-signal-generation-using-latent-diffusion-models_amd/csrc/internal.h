@@ -16,7 +16,8 @@ int ew_copy_rows(eegldm_ctx*, void* dst, long ldd, const void* src, long lds, lo
 bool conv_is_thin(int Cin, int Cout, int dtype);
 int dconv_run(eegldm_ctx*, int dtype, bool dgrad, const void* in, long ldin, const void* w, const float* bias,
               const void* resid, long ldr, void* out, long ldout, int B, int Lin, int Lout, int Cin, int Cout, int K,
-              int stride, int pad_l);
+              int stride, int pad_l, float act_slope = 0.f);
+bool dconv_fuses_act(int dtype, int Cin, int Cout, int K, long ldout);
 int dconv_wgrad(eegldm_ctx*, int dtype, const void* x, long ldx, const void* dy, long lddy, float* dw, int B, int Lin,
                 int Lout, int Cin, int Cout, int K, int stride, int pad_l, float* dbias, int* bias_done);
 bool dconv_wgrad_tinyv_ok(int Cin, int Cout, int K);
@@ -24,7 +25,8 @@ bool dconv_wgrad_tinyv_ok(int Cin, int Cout, int K);
 // ops.hip
 int op_conv_fwd(eegldm_ctx*, int dtype, const void* x, long ldx, const void* w, const float* bias, void* y, long ldy,
                 int B, int Lin, int Cin, int Cout, int K, int stride, int pad_l, int pad_r,
-                const float* rowvec, long ld_rowvec, const void* resid, long ldr);
+                const float* rowvec, long ld_rowvec, const void* resid, long ldr, float act_slope = 0.f);
+bool op_conv_fuses_act(int dtype, int Cin, int Cout, int K, long ldy);
 int op_conv_dgrad(eegldm_ctx*, int dtype, const void* dy, long lddy, const void* w, void* dx, long lddx,
                   int B, int Lin, int Cin, int Cout, int K, int stride, int pad_l, int pad_r, const void* resid, long ldr);
 bool op_wgrad_fuses_bias(int dtype, int Cin, int Cout);

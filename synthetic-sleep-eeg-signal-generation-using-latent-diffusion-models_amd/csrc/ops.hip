@@ -8,17 +8,19 @@
 
 static inline int conv_lout(int Lin, int K, int stride, int pad_l, int pad_r) { return (Lin + pad_l + pad_r - K) / stride + 1; }
 
+bool op_conv_fuses_act(int dtype, int Cin, int Cout, int K, long ldy) { return conv_is_thin(Cin, Cout, dtype) && dconv_fuses_act(dtype, Cin, Cout, K, ldy); }
 int op_conv_fwd(eegldm_ctx* ctx, int dtype, const void* x, long ldx, const void* w, const float* bias, void* y, long ldy,
                 int B, int Lin, int Cin, int Cout, int K, int stride, int pad_l, int pad_r,
-                const float* rowvec, long ld_rowvec, const void* resid, long ldr) {
+                const float* rowvec, long ld_rowvec, const void* resid, long ldr, float act_slope) {
   EEG_CHECK(B > 0 && Lin > 0 && Cin > 0 && Cout > 0 && (K == 1 || K == 3) && (stride == 1 || stride == 2),
             "unsupported conv B=%d Lin=%d Cin=%d Cout=%d K=%d stride=%d", B, Lin, Cin, Cout, K, stride);
   const int Lout = conv_lout(Lin, K, stride, pad_l, pad_r);
   EEG_CHECK(Lout > 0, "empty output");
   if (conv_is_thin(Cin, Cout, dtype)) {
     EEG_CHECK(rowvec == nullptr, "rowvec add is not available on the thin-channel path");
-    return dconv_run(ctx, dtype, false, x, ldx, w, bias, resid, ldr, y, ldy, B, Lin, Lout, Cin, Cout, K, stride, pad_l);
+    return dconv_run(ctx, dtype, false, x, ldx, w, bias, resid, ldr, y, ldy, B, Lin, Lout, Cin, Cout, K, stride, pad_l, act_slope);
   }
+  EEG_CHECK(act_slope <= 0.f, "fused activation is only available on the thin-input direct conv");
   GemmArgs a = {};
   a.dtype = dtype; a.A = x; a.lda = ldx; a.B = w; a.ldb = Cin; a.sBt = (long)Cout * Cin; a.C = y; a.ldc = ldy;
   a.M = B * Lout; a.N = Cout; a.K = Cin; a.batch = 1; a.taps = K; a.alpha = 1.0f; a.bias = bias;
