@@ -4,17 +4,18 @@ CPU restatement of MONAI-Generative `AutoencoderKL` and `PatchDiscriminator`
 as the reference instantiates them (config/config_aekl_eeg.yaml:19-40;
 /root/reference/src/train_autoencoderkl.py:129-137).
 
-PARITY UNPINNED: `monai-generative` is an un-pinned dependency
-(/root/reference/requirements.txt:12), its source is not under
-/root/reference, and the reference holds no tests or golden vectors for it.
-This restatement follows the published monai-generative 0.2.x algorithm and
-the reference's structurally equivalent local twin
-(/root/reference/src/models/ae_kl.py:20-80,123-300: block order, pad (0,1) +
-stride-2 conv, nearest x2 + conv, clamp(-30, 20), sigma = exp(logvar/2)),
-with GroupNorm(num_groups=norm_num_groups, eps=1e-6) and no attention blocks
-(all three attention flags are false in every config used).  It is checked
-by closed-form / structural tests only (tests/test_oracle_closed_form.py).
-State-dict keys follow monai-generative's naming (recollection, unverified).
+PARITY: `monai-generative` is an un-pinned dependency (/root/reference/requirements.txt:12), its source is not under
+/root/reference, and the reference holds no tests or golden vectors for it, so WHAT MONAI computes is restated from the
+published monai-generative 0.2.x algorithm (unpinned at that library boundary: that AutoencoderKL / PatchDiscriminator have
+this structure, their state-dict key names, norm_num_groups semantics).  The restatement ITSELF is pinned against the
+reference's own code (tests/golden/make_golden_r2.py -> aekl_twin_32_32_64.npz, disc_twin_k3.npz; tests/test_oracle_golden.py):
+  * the local AutoencoderKL (/root/reference/src/models/ae_kl.py:123-291) with its mid-attention blocks removed is exactly this
+    structure (conv, ResBlocks, right-pad stride-2 Downsample, nearest x2 + conv Upsample, final norm + conv, 1x1 heads,
+    clamp(-30, 20), sigma = exp(log_var / 2), post_quant_conv) at [32,32,64] with GroupNorm(32): forward, input gradient and
+    all 126 parameter gradients of recon.dy + 0.3 KL agree to 1e-4;
+  * the local PatchGAN Discriminator (/root/reference/src/models/discriminator.py:15-84) with kernel-3 convs in place of its
+    hard-coded kernel 4 is the configured PatchDiscriminator: logits, gradients, BatchNorm running statistics agree.
+The GroupNorm group count (32 there, norm_num_groups = 1 in the configs) is a parameter of these functions.
 """
 import torch
 import torch.nn.functional as F

@@ -276,3 +276,84 @@ def test_spectral_loss_zero_amplitude_gradient_is_zero_not_nan():
     assert abs(float(loss) - float(spec)) < 2e-5 * float(spec)
     assert torch.isfinite(d).all() and float(d[1].abs().max()) == 0.0
     assert rel_l2(d[0], ar.grad[0]) < 5e-5 and rel_l2(d[2], ar.grad[2]) < 5e-5
+
+
+@pytest.mark.parametrize("dtype", ["float32", "bfloat16"])
+def test_autoencoderkl_vs_reference_local_autoencoder_golden(golden_dir, dtype):
+    """The engine's AutoencoderKL at the production channels [32,32,64] against golden vectors produced by the REFERENCE's own local
+    autoencoder (src/models/ae_kl.py:123-291, mid-attention removed = the MONAI structure, GroupNorm(32)): forward (recon, mu, sigma,
+    KL), input gradient and all 126 parameter gradients of recon.dy + 0.3 KL.  tests/golden/make_golden_r2.py::case_aekl_twin."""
+    import os
+    import gpu_util as G
+    from eegldm.models import AutoencoderKL
+    g = np.load(os.path.join(golden_dir, "aekl_twin_32_32_64.npz"))
+    cfg = dict(num_channels=[32, 32, 64], latent_channels=1, in_channels=1, out_channels=1, num_res_blocks=2, norm_num_groups=32)
+    sw, sx, se, sdy = [int(v) for v in g["seeds"]]
+    net = AutoencoderKL(spatial_dims=1, attention_levels=[False] * 3, dtype=dtype, **cfg)
+    assert list(net.entries.keys()) == [str(k) for k in g["keys"]]
+    net.load_state_dict({k: torch.from_numpy(gen_param(sw, k, shape)) for k, (_o, _n, shape) in net.entries.items()})
+    x = torch.from_numpy(eeg_windows(2, seed=sx, length=256, pad=8)); eps = torch.from_numpy(normal((2, 1, 64), seed=se))
+    dy = torch.from_numpy(normal((2, 1, 256), seed=sdy))
+    klo = torch.zeros(1, device=net.device)
+    recon, mu, sg = net(x, eps=eps, kl_out=klo)
+    net.zero_grad()
+    dx = net.backward(dy, kl_weight=0.3, need_dx=True)
+    grads = net.grad_dict()
+    f32 = dtype == "float32"
+    if f32:
+        G.assert_close(recon, g["recon"], rtol=2e-4, atol=5e-5, name="recon"); G.assert_close(mu, g["z_mu"], rtol=2e-4, atol=5e-5, name="mu")
+        G.assert_close(sg, g["z_sigma"], rtol=2e-4, atol=5e-5, name="sigma"); G.assert_close(dx, g["dx"], rtol=2e-3, atol=5e-4, name="dx")
+        assert abs(float(klo) - float(g["kl"])) < 1e-4 * abs(float(g["kl"]))
+    else:
+        assert rel_l2(recon, g["recon"]) < 4e-2 and rel_l2(mu, g["z_mu"]) < 4e-2 and rel_l2(dx, g["dx"]) < 8e-2
+    gscale = max(float(g["g_l2:" + k]) for k in net.entries)
+    worst = 0.0
+    for k in net.entries:
+        gr = grads[k].double().reshape(-1).cpu(); l2 = float(g["g_l2:" + k]); floor = (1e-3 if f32 else 3e-2) * gscale
+        rel = abs(float(gr.norm()) - l2) / (l2 + floor)
+        head = g["g_head:" + k].astype(np.float64)
+        he = float(np.linalg.norm(gr[:16].numpy() - head)) / (float(np.linalg.norm(head)) + floor)
+        worst = max(worst, rel, he)
+        assert rel < (2e-3 if f32 else 8e-2) and he < (3e-3 if f32 else 0.15), f"{k}: norm {rel:.2e} head {he:.2e}"
+    print(f"aekl twin {dtype}: recon {rel_l2(recon, g['recon']):.2e} dx {rel_l2(dx, g['dx']):.2e} worst grad digest {worst:.2e}")
+
+
+@pytest.mark.parametrize("dtype", ["float32", "bfloat16"])
+def test_patch_discriminator_vs_reference_local_discriminator_golden(golden_dir, dtype):
+    """The engine's PatchDiscriminator against golden vectors of the REFERENCE's own local Discriminator (src/models/discriminator.py:15-84,
+    kernel-4 convs swapped for the kernel-3 ones the config asks for): logits, input gradient, all parameter gradients, BatchNorm
+    running statistics after one training forward.  tests/golden/make_golden_r2.py::case_disc_twin."""
+    import os
+    import gpu_util as G
+    from eegldm.models import PatchDiscriminator
+    g = np.load(os.path.join(golden_dir, "disc_twin_k3.npz"))
+    sw, sx, sdy = [int(v) for v in g["seeds"]]
+    net = PatchDiscriminator(**D_CFG, dtype=dtype)
+    sd = {}
+    for k in [str(k) for k in g["keys"]]:
+        shape = net.entries[k][2] if k in net.entries else net.buf_entries[k][2]
+        v = torch.from_numpy(gen_param(sw, k, shape))
+        sd[k] = v * 2.0 if k.endswith("conv.weight") else v
+    net.load_state_dict(sd)
+    x = torch.from_numpy(normal((3, 1, 256), seed=sx))
+    logits = net(x)[-1]
+    dy = torch.from_numpy(normal(tuple(logits.shape), seed=sdy))
+    net.zero_grad()
+    dx = net.backward(dy, need_dx=True, in_shape=tuple(x.shape))
+    f32 = dtype == "float32"
+    if f32:
+        G.assert_close(logits, g["logits"], rtol=2e-4, atol=5e-5, name="logits"); G.assert_close(dx, g["dx"], rtol=2e-3, atol=5e-4, name="dx")
+    else:
+        assert rel_l2(logits, g["logits"]) < 4e-2 and rel_l2(dx, g["dx"]) < 0.12
+    grads, new = net.grad_dict(), net.state_dict()
+    gscale = max(float(g[f]) for f in g.files if f.startswith("g_l2:"))
+    for k in sd:
+        if "running" in k:
+            assert rel_l2(new[k], g["buf:" + k]) < (1e-5 if f32 else 2e-2), k
+        elif "num_batches" in k:
+            assert int(new[k]) == int(g["buf:" + k]) == 1
+        else:
+            gr = grads[k].double().reshape(-1).cpu(); l2 = float(g["g_l2:" + k]); floor = (1e-3 if f32 else 3e-2) * gscale
+            assert abs(float(gr.norm()) - l2) / (l2 + floor) < (2e-3 if f32 else 8e-2), k
+            head = g["g_head:" + k].astype(np.float64)
+            assert float(np.linalg.norm(gr[:16].numpy() - head)) / (float(np.linalg.norm(head)) + floor) < (3e-3 if f32 else 0.15), k

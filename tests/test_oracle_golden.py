@@ -184,3 +184,70 @@ def test_unet_full_size_vs_reference(golden_dir):
         l2 = float(g["g_l2:" + k])
         np.testing.assert_allclose(gr[:16].float().numpy(), g["g_head:" + k], rtol=2e-3, atol=2e-4 * max(1.0, l2 / np.sqrt(gr.numel())))
         assert abs(float(gr.norm()) - l2) <= 1e-3 * l2 + 1e-5, k
+
+
+def test_aekl_oracle_vs_reference_local_autoencoder(golden_dir):
+    """oracle/aekl.py (encode -> heads -> clamp -> sigma -> reparameterise -> decode, and its autograd backward incl. the KL term)
+    against the reference's OWN local AutoencoderKL (/root/reference/src/models/ae_kl.py:123-291) with its mid-attention blocks
+    removed -- exactly the block structure of the MONAI model the configs instantiate, at num_channels [32,32,64], latent 1,
+    GroupNorm(32) (the configs use norm_num_groups = 1: a parameter here).  Pins block order, right-pad stride-2 downsample,
+    nearest x2 + conv upsample, clamp(-30, 20), sigma = exp(log_var / 2), post_quant_conv placement."""
+    from oracle import aekl as A
+    from param_gen import eeg_windows
+    g = _load(golden_dir, "aekl_twin_32_32_64.npz")
+    cfg = dict(num_channels=[32, 32, 64], latent_channels=1, in_channels=1, out_channels=1, num_res_blocks=2, norm_num_groups=32)
+    sw, sx, se, sdy = [int(v) for v in g["seeds"]]
+    shapes = A.aekl_param_shapes(cfg)
+    assert list(shapes.keys()) == [str(k) for k in g["keys"]]
+    sd = {k: torch.from_numpy(gen_param(sw, k, s)).requires_grad_(True) for k, s in shapes.items()}
+    x = torch.from_numpy(eeg_windows(2, seed=sx, length=256, pad=8)).requires_grad_(True)
+    eps = torch.from_numpy(normal((2, 1, 64), seed=se)); dy = torch.from_numpy(normal((2, 1, 256), seed=sdy))
+    recon, mu, sg = A.forward(sd, cfg, x, eps)
+    kl = Ls.kl_loss(mu, sg)
+    ((recon * dy).sum() + 0.3 * kl).backward()
+    np.testing.assert_allclose(recon.detach().numpy(), g["recon"], rtol=2e-4, atol=2e-5)
+    np.testing.assert_allclose(mu.detach().numpy(), g["z_mu"], rtol=2e-4, atol=2e-5)
+    np.testing.assert_allclose(sg.detach().numpy(), g["z_sigma"], rtol=2e-4, atol=2e-5)
+    assert abs(float(kl) - float(g["kl"])) < 1e-5 * abs(float(g["kl"]))
+    np.testing.assert_allclose(x.grad.numpy(), g["dx"], rtol=2e-3, atol=2e-4)
+    gscale = max(float(g["g_l2:" + k]) for k in shapes)
+    for k in shapes:
+        gr = sd[k].grad.double().reshape(-1); l2 = float(g["g_l2:" + k])
+        assert abs(float(gr.norm()) - l2) <= 1e-3 * l2 + 1e-5 * gscale, k
+        np.testing.assert_allclose(gr[:16].float().numpy(), g["g_head:" + k], rtol=2e-3, atol=2e-4 * max(1.0, gscale / 100))
+
+
+def _disc_twin_inputs(g):
+    from oracle import aekl as A
+    dcfg = dict(spatial_dims=1, num_layers_d=3, num_channels=64, in_channels=1, out_channels=1, kernel_size=3, norm="BATCH", bias=False, padding=1)
+    sw, sx, sdy = [int(v) for v in g["seeds"]]
+    shapes = A.disc_param_shapes(dcfg)
+    assert list(shapes.keys()) == [str(k) for k in g["keys"]]
+    sd = {}
+    for k, s in shapes.items():
+        v = torch.from_numpy(gen_param(sw, k, s))
+        sd[k] = v * 2.0 if k.endswith("conv.weight") else v
+    return dcfg, shapes, sd, torch.from_numpy(normal((3, 1, 256), seed=sx)), sdy
+
+
+def test_discriminator_oracle_vs_reference_local_discriminator(golden_dir):
+    """oracle disc_forward (+ autograd) against the reference's own local PatchGAN Discriminator (/root/reference/src/models/
+    discriminator.py:15-84) with its kernel-4 convs swapped for kernel-3 ones (what config_aekl_eeg.yaml:30-40 asks MONAI for):
+    layer sequence, strides, bias placement, LeakyReLU(0.2), train-mode BatchNorm incl. the running-statistics update."""
+    from oracle import aekl as A
+    g = _load(golden_dir, "disc_twin_k3.npz")
+    dcfg, shapes, sd, x, sdy = _disc_twin_inputs(g)
+    sd = {k: (v.requires_grad_(True) if (v.is_floating_point() and "running" not in k) else v) for k, v in sd.items()}
+    x.requires_grad_(True)
+    running = {}
+    logits = A.disc_forward(sd, dcfg, x, True, running)[-1]
+    (logits * torch.from_numpy(normal(tuple(logits.shape), seed=sdy))).sum().backward()
+    np.testing.assert_allclose(logits.detach().numpy(), g["logits"], rtol=2e-4, atol=2e-5)
+    np.testing.assert_allclose(x.grad.numpy(), g["dx"], rtol=2e-3, atol=2e-4)
+    for k in shapes:
+        if "running" in k:
+            np.testing.assert_allclose(running[k].numpy(), g["buf:" + k], rtol=1e-5, atol=1e-6)
+        elif "num_batches" not in k:
+            gr = sd[k].grad.double().reshape(-1); l2 = float(g["g_l2:" + k])
+            assert abs(float(gr.norm()) - l2) <= 1e-3 * l2 + 1e-5, k
+            np.testing.assert_allclose(gr[:16].float().numpy(), g["g_head:" + k], rtol=2e-3, atol=1e-4 * max(1.0, l2))
