@@ -18,6 +18,10 @@ class LibraryMissing(RuntimeError):
 
 
 def _load():
+    # torch first: it ships its own HIP runtime (torch/lib/libamdhip64.so).  If libeegldm.so is loaded before torch, the loader binds
+    # the system runtime instead and the process ends up with two HIP runtimes -- hipSetDevice then reports "no ROCm-capable device"
+    # (seen when __graft_entry__.build() and smoke() ran in one process).  torch is plumbing here (device memory, streams).
+    import torch  # noqa: F401
     if not os.path.exists(LIB_PATH):
         raise LibraryMissing(f"{LIB_PATH} not found: build it with `make` (python -c 'import __graft_entry__ as g; g.build()')")
     return C.CDLL(LIB_PATH)
