@@ -21,6 +21,12 @@ constexpr int MC = THIN_MAXC;
 constexpr float GN_EPS_T = 1e-6f;
 constexpr int RED_FLOATS = NWAVE * 56 + 64;
 
+// Workgroup barrier that orders LDS traffic only.  __syncthreads() is fence + s_barrier and the fence waits for EVERY outstanding
+// global access (s_waitcnt vmcnt(0)): the tape prefetch of the backward kernel, the tape stores of the forward kernel and the
+// gradient atomics would all be waited for at the next barrier.  Nothing in these kernels reads global memory written earlier in the
+// same launch (tape and statistics are produced by the forward launch and consumed by the backward launch), so LDS ordering suffices.
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
 struct BufSel { float* base; int maxt; __device__ __forceinline__ float* operator[](int i) const { return base + (size_t)i * maxt; } };
 struct Bufs { BufSel b; float* red; };
 
@@ -29,19 +35,19 @@ template <int NV> __device__ __forceinline__ void block_reduce(float (&v)[NV], f
 #pragma unroll
   for (int i = 0; i < NV; i++) v[i] = wave_sum(v[i]);
   const int wave = threadIdx.x >> 6;
-  __syncthreads();
+  lds_barrier();
   if ((threadIdx.x & 63) == 0) {
 #pragma unroll
     for (int i = 0; i < NV; i++) red[wave * NV + i] = v[i];
   }
-  __syncthreads();
+  lds_barrier();
   if (threadIdx.x < NV) {
     float s = 0.f;
 #pragma unroll
     for (int w = 0; w < NWAVE; w++) s += red[w * NV + threadIdx.x];
     red[NWAVE * NV + threadIdx.x] = s;
   }
-  __syncthreads();
+  lds_barrier();
 }
 
 // The channel counts are compile-time (1, 2 or 4 each): the kernels are VALU-issue bound -- one 8-wave workgroup per CU, every
@@ -104,7 +110,7 @@ __device__ void f_conv_t(const ThinOp& o, const float* P, const Bufs& B) {
         *(float4*)(Y + co * Lout + l0) = r;
       }
     }
-    __syncthreads();
+    lds_barrier();
     return;
   }
   for (int lo = threadIdx.x; lo < Lout; lo += NT) {
@@ -126,7 +132,7 @@ __device__ void f_conv_t(const ThinOp& o, const float* P, const Bufs& B) {
 #pragma unroll
     for (int co = 0; co < COUT; co++) Y[co * Lout + lo] = acc[co] + (A ? A[co * Lout + lo] : 0.f);
   }
-  __syncthreads();
+  lds_barrier();
 }
 #define THIN_CC(fn, ...)                                                                      \
   switch (o.cin * 8 + o.cout) {                                                               \
@@ -158,7 +164,7 @@ __device__ __forceinline__ void gn_apply_t(const ThinOp& o, const float* P, cons
     if (silu) { z.x = silu_f(z.x); z.y = silu_f(z.y); z.z = silu_f(z.z); z.w = silu_f(z.w); }
     *(float4*)(Y + (q << 2)) = z;
   }
-  __syncthreads();
+  lds_barrier();
 }
 template <int C>
 __device__ void f_gn_t(const ThinOp& o, const float* P, const Bufs& B, float* __restrict__ stats) {
@@ -192,7 +198,7 @@ __device__ void b_recomp(const ThinOp& o, const float* P, const Bufs& B, const f
 __device__ void d_ups(const ThinOp& o, const Bufs& B) {
   const float* X = B.b[o.src]; float* Y = B.b[o.dst];
   for (int i = threadIdx.x; i < o.cin * o.Lout; i += NT) { const int c = i / o.Lout, l = i - c * o.Lout; Y[i] = X[c * o.Lin + (l >> 1)]; }
-  __syncthreads();
+  lds_barrier();
 }
 
 template <int LAT>
@@ -348,7 +354,7 @@ __device__ void b_conv_t(const ThinOp& o, const float* P, float* __restrict__ G,
       }
     }
   }
-  __syncthreads();
+  lds_barrier();
 }
 __device__ void b_conv(const ThinOp& o, const float* P, float* G, const Bufs& B) { THIN_CC(b_conv_t, o, P, G, B) }
 
@@ -404,7 +410,7 @@ __device__ void b_gn_t(const ThinOp& o, const float* P, float* __restrict__ G, c
     if (ADD) { const float4 a = *(const float4*)(ADD + (q << 2)); out.x += a.x; out.y += a.y; out.z += a.z; out.w += a.w; }
     *(float4*)(dX + (q << 2)) = out;
   }
-  __syncthreads();
+  lds_barrier();
 }
 __device__ void b_gn(const ThinOp& o, const float* P, float* G, const Bufs& B, const float* stats) {
   if (o.cin == 1) b_gn_t<1>(o, P, G, B, stats); else if (o.cin == 2) b_gn_t<2>(o, P, G, B, stats); else if (o.cin == 4) b_gn_t<4>(o, P, G, B, stats);
@@ -456,7 +462,7 @@ __device__ void b_heads_t(const ThinOp& o, const float* P, float* __restrict__ G
   else if (t < LAT * LAT + LAT) atomicAdd(G + o.b + (t - LAT * LAT), R[t]);
   else if (t < 2 * LAT * LAT + LAT) atomicAdd(G + o.w2 + (t - LAT * LAT - LAT), R[t]);
   else if (t < NV) atomicAdd(G + o.b2 + (t - 2 * LAT * LAT - LAT), R[t]);
-  __syncthreads();
+  lds_barrier();
 }
 __device__ void b_heads(const ThinOp& o, const float* P, float* G, const Bufs& B, const float* tape, const int* tape_off, const float* eps, float klw_over_B) {
   if (o.cin == 1) b_heads_t<1>(o, P, G, B, tape, tape_off, eps, klw_over_B);
@@ -484,7 +490,7 @@ __global__ __launch_bounds__(NT) void thin_fwd_kernel(const ThinOp* ops, int nop
   // ... and so is the micro-op table (each op used to start with a dependent scalar load of its descriptor)
   int* OL = (int*)(PL + ((nparams + 3) & ~3));
   for (int j = threadIdx.x; j < nops * (int)(sizeof(ThinOp) / 4); j += NT) OL[j] = ((const int*)ops)[j];
-  __syncthreads();
+  lds_barrier();
   P = PL; ops = (const ThinOp*)OL;
   const int b = blockIdx.x;
   float* tape = tape_all + (size_t)b * tape_stride; float* stats = stats_all + (size_t)b * nstat * 2;
@@ -495,7 +501,7 @@ __global__ __launch_bounds__(NT) void thin_fwd_kernel(const ThinOp* ops, int nop
       case TF_LOAD: {
         const float* src = x + (size_t)b * o.cin * o.Lin; float* D = B.b[o.dst];
         for (int j = threadIdx.x; j < o.cin * o.Lin; j += NT) D[j] = src[j];
-        __syncthreads();
+        lds_barrier();
       } break;
       case TF_CONV: f_conv(o, P, B); break;
       case TF_GN: f_gn(o, P, B, stats); break;
@@ -503,7 +509,7 @@ __global__ __launch_bounds__(NT) void thin_fwd_kernel(const ThinOp* ops, int nop
       case TF_SAVE: {
         const float4* S = (const float4*)B.b[o.src]; float4* D = (float4*)(tape + tape_off[o.save]);
         for (int j = threadIdx.x; j < (o.cin * o.Lin) >> 2; j += NT) D[j] = S[j];
-        __syncthreads();       // the next op may overwrite the saved buffer
+        lds_barrier();       // the next op may overwrite the saved buffer
       } break;
       case TF_HEADS:
         f_heads(o, P, B, tape, tape_off, eps ? eps + (size_t)b * lat * Ll : nullptr, z_mu ? z_mu + (size_t)b * lat * Ll : nullptr,
@@ -528,10 +534,15 @@ __global__ __launch_bounds__(NT) void thin_bwd_kernel(const ThinOp* ops, int nop
   for (int j = threadIdx.x; j < nparams; j += NT) PL[j] = P[j];
   int* OL = (int*)(PL + ((nparams + 3) & ~3));
   for (int j = threadIdx.x; j < nops * (int)(sizeof(ThinOp) / 4); j += NT) OL[j] = ((const int*)ops)[j];
-  __syncthreads();
+  lds_barrier();
   P = PL; ops = (const ThinOp*)OL;
   const int b = blockIdx.x;
   const float* tape = tape_all + (size_t)b * tape_stride; const float* stats = stats_all + (size_t)b * nstat * 2;
+  // tape prefetch: the next TB_LOADT's global loads are issued (into registers) before the op that precedes it starts, so their
+  // ~2.3 us round trip runs under that op instead of in front of the next one (38 loads per window: ~90 us of the first version)
+  constexpr int PFN = 5;                               // float4 per thread: tensors of up to 5 * 4 * 512 = 10240 values
+  float4 pre[PFN];
+  int pf_op = -1;
   for (int i = 0; i < nops; i++) {
     const ThinOp o = ops[i];
     const unsigned long long t0 = prof ? __builtin_readcyclecounter() : 0ull;
@@ -539,12 +550,19 @@ __global__ __launch_bounds__(NT) void thin_bwd_kernel(const ThinOp* ops, int nop
       case TB_LOADDY: {
         const float* src = d_recon + (size_t)b * o.cin * o.Lin; float* D = B.b[o.dst];
         for (int j = threadIdx.x; j < o.cin * o.Lin; j += NT) D[j] = src[j];
-        __syncthreads();
+        lds_barrier();
       } break;
       case TB_LOADT: {
-        const float4* src = (const float4*)(tape + tape_off[o.save]); float4* D = (float4*)B.b[o.dst];
-        for (int j = threadIdx.x; j < (o.cin * o.Lin) >> 2; j += NT) D[j] = src[j];
-        __syncthreads();
+        float4* D = (float4*)B.b[o.dst];
+        const int nq = (o.cin * o.Lin) >> 2;
+        if (pf_op == i) {
+#pragma unroll
+          for (int k = 0; k < PFN; k++) { const int q = threadIdx.x + k * NT; if (q < nq) D[q] = pre[k]; }
+        } else {
+          const float4* src = (const float4*)(tape + tape_off[o.save]);
+          for (int j = threadIdx.x; j < nq; j += NT) D[j] = src[j];
+        }
+        lds_barrier();
       } break;
       case TB_RECOMP: b_recomp(o, P, B, stats); break;
       case TB_UPS: d_ups(o, B); break;
@@ -553,12 +571,12 @@ __global__ __launch_bounds__(NT) void thin_bwd_kernel(const ThinOp* ops, int nop
       case TB_UPSBWD: {
         const float* S = B.b[o.src]; float* D = B.b[o.dst];      // src: cin x Lin (= 2 Lout), dst: cin x Lout
         for (int j = threadIdx.x; j < o.cin * o.Lout; j += NT) { const int c = j / o.Lout, l = j - c * o.Lout; D[j] = S[c * o.Lin + 2 * l] + S[c * o.Lin + 2 * l + 1]; }
-        __syncthreads();
+        lds_barrier();
       } break;
       case TB_COPY: {
         const float4* S = (const float4*)B.b[o.src]; float4* D = (float4*)B.b[o.dst];
         for (int j = threadIdx.x; j < (o.cin * o.Lin) >> 2; j += NT) D[j] = S[j];
-        __syncthreads();
+        lds_barrier();
       } break;
       case TB_HEADS: b_heads(o, P, G, B, tape, tape_off, eps ? eps + (size_t)b * lat * Ll : nullptr, klw_over_B); break;
       case TB_STOREDX: {
@@ -567,6 +585,20 @@ __global__ __launch_bounds__(NT) void thin_bwd_kernel(const ThinOp* ops, int nop
           for (int j = threadIdx.x; j < o.cin * o.Lin; j += NT) D[j] = S[j];
         }
       } break;
+    }
+    if (pf_op <= i) {      // (after op i: the loads fly while ops i+1 .. j-1 run)
+      int j = i + 1;
+      while (j < nops && ops[j].kind != TB_LOADT) j++;
+      if (j < nops && j <= i + 4) {
+        const ThinOp n = ops[j];
+        const int nq = (n.cin * n.Lin) >> 2;
+        if (nq <= PFN * NT) {
+          const float4* src = (const float4*)(tape + tape_off[n.save]);
+#pragma unroll
+          for (int k = 0; k < PFN; k++) { const int q = threadIdx.x + k * NT; if (q < nq) pre[k] = src[q]; }
+          pf_op = j;
+        }
+      }
     }
     if (prof && blockIdx.x == 0 && threadIdx.x == 0) prof[i] = __builtin_readcyclecounter() - t0;
   }
