@@ -4,6 +4,7 @@
 #include <stdint.h>
 #include <stdio.h>
 #include <string>
+#include <unordered_map>
 #include <vector>
 
 #include "../../include/eegldm.h"
@@ -54,6 +55,8 @@ struct eegldm_ctx {
   // optional per-launch HIP-event profiling of the GEMM family (bench.py roofline leg)
   bool prof_on = false;
   std::vector<ProfRec> prof;
+  // K-blocked copies of 3-tap conv weights, keyed by the address of the plain [tap][Cout][Cin] bf16 weight (registered by NetBase)
+  std::unordered_map<const void*, const void*> kblk;
   double prof_bracket_ms = 0.0;   // elapsed time of an EMPTY event pair on this stream (calibrated by eegldm_prof_enable): subtracted per launch
 };
 
@@ -133,6 +136,8 @@ struct GemmArgs {
   int atomic_out;        // C += result via float atomics (requires out_f32)
   float k_skew;          // split-K with atomic output: K chunk lengths grow linearly from (1-k_skew) to (1+k_skew) of the mean (0 = equal)
   float* colsum;         // GA_TR, 16-bit operands, batch 1: colsum[m] += sum_k A[k][m] (bias gradient of a conv whose dY is A), or null
+  int b_kblk;            // GB_NT: B is K-BLOCKED, [tap][K / KC][N][KC] (KC = 32 16-bit elements = 64 bytes): a stage's B tile is one contiguous run
+                         //  (op_conv_fwd with a packed weight copy, see kblk_pack); 0 = plain [tap][N][K]
   int wide_n;            // fused 3-tap weight gradient: use the 128-wide N tile (one block per CU)
   int xcd_swizzle;       // set by the launcher: XCD-aware tile order (see gemm_kernel)
   const void* zero_page; // >= 16 zero bytes in device memory (set by gemm_launch)

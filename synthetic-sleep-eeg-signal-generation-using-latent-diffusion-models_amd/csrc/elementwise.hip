@@ -3,6 +3,7 @@
 // arithmetic, MSE, Adam, Philox RNG.  One pass over the data each, 16-byte accesses where
 // the layout allows.  Reference call sites are cited at each entry point.
 #include "common.h"
+#include "internal.h"
 
 namespace {
 constexpr int NT = 256;
@@ -400,6 +401,26 @@ extern "C" int eegldm_pack_conv_weight(eegldm_ctx* ctx, const float* w, float* p
 }
 extern "C" int eegldm_unpack_conv_weight(eegldm_ctx* ctx, const float* p, float* w, int Cout, int Cin, int K) {
   hipLaunchKernelGGL(pack_w_kernel, dim3(grid1d((long)Cout * Cin * K, ctx)), dim3(NT), 0, ctx->stream, p, w, Cout, Cin, K, 1);
+  LAUNCH_CHECK(); return 0;
+}
+// [3][Cout][Cin] -> [3][Cin / 32][Cout][32] for every table entry; one 16-byte chunk (8 elements) per thread
+__global__ void kblk_pack_kernel(const uint4* __restrict__ src, uint4* __restrict__ dst, const KbDesc* __restrict__ tab, int n, long total) {
+  const long c = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= total) return;
+  int e = 0;
+  while (e + 1 < n && tab[e + 1].chunk0 <= c) e++;
+  const KbDesc d = tab[e];
+  const long r = c - d.chunk0;                 // chunk index inside the weight: (tap, co, ci / 8)
+  const int cpr = d.cin / 8;
+  const int ci8 = (int)(r % cpr); const long tc = r / cpr;
+  const int co = (int)(tc % d.cout), t = (int)(tc / d.cout);
+  const long o = (((long)t * (d.cin / 32) + ci8 / 4) * d.cout + co) * 4 + (ci8 & 3);
+  dst[d.off / 8 + o] = src[d.off / 8 + r];
+}
+int kblk_pack(eegldm_ctx* ctx, const void* w_plain, void* w_packed, const KbDesc* d_table, int n, long total_chunks) {
+  if (n <= 0) return 0;
+  hipLaunchKernelGGL(kblk_pack_kernel, dim3((unsigned)((total_chunks + NT - 1) / NT)), dim3(NT), 0, ctx->stream, (const uint4*)w_plain, (uint4*)w_packed,
+                     d_table, n, total_chunks);
   LAUNCH_CHECK(); return 0;
 }
 extern "C" int eegldm_cast(eegldm_ctx* ctx, const float* s, void* d, long n, int dtype) {

@@ -59,6 +59,11 @@ struct NetBase {
   float* params = nullptr; float* grads = nullptr;
   void* wT = nullptr;            // compute-dtype copy of params (bf16) or == params (fp32)
   bool owns_wT = false;
+  // K-blocked second copy of the 3-tap conv weights that run on the implicit-GEMM path (16-bit dtypes): [tap][Cin / 32][Cout][32].
+  // The forward conv's weight tile of one K stage is then ONE contiguous run instead of 64-byte row segments -- the L2 -> LDS path
+  // moves 64-byte segments at half the rate of >= 128-byte ones (tools/probes/fill_pattern_probe.hip: 29 vs 48-58 B/clk/CU).
+  // Same offsets as wT; refreshed by sync_weights(); registered in ctx->kblk so that op_conv_fwd finds it by the plain weight's address.
+  void* wK = nullptr; void* d_kb = nullptr; int n_kb = 0; long kb_chunks = 0;
   bool param_grads = true;       // false: backward propagates to the input only (G step through D)
   Arena arena;
   float* emb_all = nullptr; int etot = 0;   // batched timestep-embedding projections (UNet)
@@ -75,7 +80,8 @@ struct NetBase {
   }
   int bind(float* p, float* g);
   int sync_weights();
-  ~NetBase() { if (owns_wT && wT) (void)hipFree(wT); }
+  void release_kblk();
+  ~NetBase() { release_kblk(); if (owns_wT && wT) (void)hipFree(wT); }
 };
 
 #define ALLOC_OR_FAIL(var, expr)                                                     \

@@ -3,6 +3,7 @@
 //   ResBlock:       /root/reference/src/models/unet.py:307-327 (with timestep embedding) and the
 //                   MONAI AutoencoderKL ResBlock (no embedding; twin /root/reference/src/models/ae_kl.py:67-80)
 //   AttentionBlock: /root/reference/src/models/unet.py:168-174
+#include <stdlib.h>
 #include <string.h>
 
 #include "net.h"
@@ -12,12 +13,38 @@ int NetBase::bind(float* p, float* g) {
   params = p; grads = g;
   if (dtype == EEGLDM_F32) { wT = p; owns_wT = false; }
   else if (!wT) { HIP_TRY(hipMalloc(&wT, (size_t)nparams * 2)); owns_wT = true; }
+  static const bool no_kblk = getenv("EEGLDM_NO_KBLOCKED_WEIGHTS") != nullptr;
+  if (dtype != EEGLDM_F32 && !wK && !no_kblk) {
+    std::vector<KbDesc> tab; long chunks = 0;
+    for (const Entry& e : entries) {
+      // [Cout][Cin][3] conv weights of the implicit-GEMM path; 16-byte chunks of both layouts must line up (offset % 8, Cin % 32)
+      if (e.ndim != 3 || e.shape[2] != 3 || e.shape[1] % 32 != 0 || e.offset % 8 != 0 || conv_is_thin(e.shape[1], e.shape[0], dtype)) continue;
+      KbDesc d; d.off = e.offset; d.chunk0 = chunks; d.cout = e.shape[0]; d.cin = e.shape[1];
+      chunks += e.numel / 8; tab.push_back(d);
+    }
+    if (!tab.empty()) {
+      HIP_TRY(hipMalloc(&wK, (size_t)nparams * 2));
+      HIP_TRY(hipMalloc(&d_kb, tab.size() * sizeof(KbDesc)));
+      HIP_TRY(hipMemcpy(d_kb, tab.data(), tab.size() * sizeof(KbDesc), hipMemcpyHostToDevice));
+      n_kb = (int)tab.size(); kb_chunks = chunks;
+      for (const KbDesc& d : tab) ctx->kblk[W(d.off)] = (const char*)wK + (size_t)d.off * 2;
+    }
+  }
   return sync_weights();
+}
+void NetBase::release_kblk() {
+  if (!wK) return;
+  for (auto it = ctx->kblk.begin(); it != ctx->kblk.end();) {
+    const char* v = (const char*)it->second;
+    if (v >= (const char*)wK && v < (const char*)wK + (size_t)nparams * 2) it = ctx->kblk.erase(it); else ++it;
+  }
+  (void)hipFree(wK); (void)hipFree(d_kb); wK = nullptr; d_kb = nullptr; n_kb = 0;
 }
 int NetBase::sync_weights() {
   EEG_CHECK(params, "bind parameters first");
   if (dtype == EEGLDM_F32) return 0;
-  return eegldm_cast(ctx, params, wT, nparams, dtype);
+  EEG_TRY(eegldm_cast(ctx, params, wT, nparams, dtype));
+  return kblk_pack(ctx, wT, wK, (const KbDesc*)d_kb, n_kb, kb_chunks);
 }
 int entry_query(const NetBase* u, int i, char* name, int cap, long* offset, long* numel, int* ndim, int shape[3]) {
   EEG_CHECK(u && i >= 0 && i < (int)u->entries.size(), "entry index %d out of range", i);

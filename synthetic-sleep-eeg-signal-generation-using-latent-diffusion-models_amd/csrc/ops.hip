@@ -32,6 +32,10 @@ int op_conv_fwd(eegldm_ctx* ctx, int dtype, const void* x, long ldx, const void*
   } else {
     EEG_CHECK(Lin == Lout * stride, "k3 conv geometry Lin=%d Lout=%d stride=%d not supported by the implicit GEMM", Lin, Lout, stride);
     a.amode = GA_CONV; a.Lout = Lout; a.Lin = Lin; a.stride = stride; a.pad_l = pad_l;
+    if (dtype != EEGLDM_F32 && !ctx->kblk.empty()) {   // a K-blocked copy of this weight (NetBase::bind): contiguous weight tiles per K stage
+      auto it = ctx->kblk.find(w);
+      if (it != ctx->kblk.end()) { a.B = it->second; a.b_kblk = 1; }
+    }
   }
   return gemm_launch(ctx, a);
 }

@@ -1,13 +1,13 @@
 """Developer tool: per-stage timeline of the conv kernel from an instrumented build (-DEEG_STAGE_TIMING)."""
 import ctypes as C, os, sys, numpy as np, torch
 HERE = os.path.dirname(os.path.abspath(__file__))
-os.environ["EEGLDM_LIB"] = os.path.join(HERE, "libeegldm_dbg.so")
+os.environ["EEGLDM_LIB"] = os.environ.get("EEGLDM_DBG_LIB") or os.path.join(HERE, "libeegldm_dbg.so")
 sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
 import eegldm
 from eegldm._lib import lib, ptr, check
 ctx = eegldm.default_context(0)
 B, L = 256, 192
-for (ci, co, k) in [(512, 512, 3), (128, 128, 3), (512, 512, 1)]:
+for (ci, co, k) in ([] if os.environ.get('ST_WGRAD_ONLY') else [(512, 512, 3), (128, 128, 3), (512, 512, 1)]):
     if ci == 128: L = 768
     else: L = 192
     R = B * L
