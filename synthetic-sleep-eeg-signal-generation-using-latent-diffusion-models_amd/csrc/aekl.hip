@@ -131,6 +131,7 @@ int SeqNet::backward_seq(const std::vector<Op>& ops, std::vector<OpTape>& tape, 
     }
     dy = dx;
   }
+  EEG_TRY(flush_gn_folds());   // deferred dgamma / dbeta fold of the last ResBlock (net.hip)
   if (dx_out) *dx_out = dy;
   return 0;
 }

@@ -24,7 +24,7 @@ extern "C" int eegldm_ctx_create(int device, void* stream, int own_stream, eegld
   c->num_cu = prop.multiProcessorCount;
   if (own_stream) { HIP_TRY(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking)); c->owns_stream = true; }
   else { c->stream = (hipStream_t)stream; c->owns_stream = false; }
-  c->scratch_bytes = 24u << 20;    // [0, 8 MiB): reduction accumulators (see norm.hip / losses.hip / net.hip); [8, 24 MiB): column-sum partials
+  c->scratch_bytes = 25u << 20;    // [0, 8 MiB): reduction accumulators (see norm.hip / losses.hip / net.hip); [8, 24 MiB): column-sum partials; [24, 25): GroupNorm slot areas C0 / C1
   HIP_TRY(hipMalloc(&c->scratch, c->scratch_bytes));
   HIP_TRY(hipMemset(c->scratch, 0, c->scratch_bytes));   // reduction scratch is self-cleaning: kernels re-zero what they consume
 #ifdef EEG_STAGE_TIMING

@@ -49,8 +49,8 @@ int op_attention_bwd(eegldm_ctx*, int dtype, const void* qkv, long ldq, const vo
 int op_groupnorm_bwd(eegldm_ctx*, const void* x, long ldx, const float* gamma, const float* beta, const float* stats,
                      const void* dy, long lddy, void* dx, long lddx, float* dgamma, float* dbeta, int B, int L, int C, int G,
                      int fuse_silu, int resample, const void* dxr, long lddxr, int dtype, float* colsum_ps, long ldps, int* colsum_done,
-                     const void* dxr2 = nullptr, long lddxr2 = 0, int* dxr2_done = nullptr, int* slots_deferred = nullptr);
-int op_gn_slot_reduce_deferred(eegldm_ctx*, float* dgamma, float* dbeta, int C);   // when *slots_deferred came back 1 (stream-ordered after the backward)   // dxr2: second, un-resampled addend [B*L][C] (skip gradient); *dxr2_done = 1 when the kernel added it
+                     const void* dxr2 = nullptr, long lddxr2 = 0, int* dxr2_done = nullptr, int* slots_deferred = nullptr, int defer_region = 0);
+int op_gn_slot_reduce_deferred(eegldm_ctx*, float* dgamma, float* dbeta, int C, int region = 0);   // when *slots_deferred came back 1 (stream-ordered after the backward)   // dxr2: second, un-resampled addend [B*L][C] (skip gradient); *dxr2_done = 1 when the kernel added it
 int ew_fold_partials(eegldm_ctx*, const float* parts, int nparts, int n, float* total);
 // fused short-sequence attention (attn.hip)
 bool attn_chain_ok(int dtype, int T, int C, long ldq, long ldo);

@@ -64,6 +64,10 @@ struct NetBase {
   // moves 64-byte segments at half the rate of >= 128-byte ones (tools/probes/fill_pattern_probe.hip: 29 vs 48-58 B/clk/CU).
   // Same offsets as wT; refreshed by sync_weights(); registered in ctx->kblk so that op_conv_fwd finds it by the plain weight's address.
   void* wK = nullptr; void* d_kb = nullptr; int n_kb = 0; long kb_chunks = 0;
+  // dgamma / dbeta folds of a ResBlock's first GroupNorm, launched one block later on the side stream (see res_backward)
+  struct GnFold { float* dgamma; float* dbeta; int C, region; };
+  std::vector<GnFold> gn_pending; int gn_parity = 0;
+  int flush_gn_folds();
   bool param_grads = true;       // false: backward propagates to the input only (G step through D)
   Arena arena;
   float* emb_all = nullptr; int etot = 0;   // batched timestep-embedding projections (UNet)

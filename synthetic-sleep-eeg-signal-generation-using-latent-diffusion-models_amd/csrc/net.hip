@@ -32,6 +32,11 @@ int NetBase::bind(float* p, float* g) {
   }
   return sync_weights();
 }
+int NetBase::flush_gn_folds() {
+  for (const GnFold& f : gn_pending) EEG_TRY(op_gn_slot_reduce_deferred(ctx, f.dgamma, f.dbeta, f.C, f.region));
+  gn_pending.clear();
+  return 0;
+}
 void NetBase::release_kblk() {
   if (!wK) return;
   for (auto it = ctx->kblk.begin(); it != ctx->kblk.end();) {
@@ -98,6 +103,7 @@ int res_backward(NetBase* u, const ResDesc& r, const ResTape& t, const View& dou
   if (pg) {
     EEG_TRY(ctx_fork(ctx));                       // dout (and everything before) is ready for the side stream
     SideScope side(ctx);
+    EEG_TRY(u->flush_gn_folds());                 // the previous block's GN1 dgamma / dbeta fold, off the main chain
     if (r.sk_w >= 0) EEG_TRY(op_conv_wgrad(ctx, dt, t.xr.p, t.xr.ld, dout.p, dout.ld, u->G(r.sk_w), fbs ? u->G(r.sk_b) : nullptr, B, Lout, r.cin, r.cout, 1, 1, 0, 0));
     EEG_TRY(op_conv_wgrad(ctx, dt, t.a2.p, t.a2.ld, dout.p, dout.ld, u->G(r.c2_w), fb2 ? u->G(r.c2_b) : nullptr, B, Lout, r.cout, r.cout, 3, 1, 1, 1));
   }
@@ -149,9 +155,14 @@ int res_backward(NetBase* u, const ResDesc& r, const ResTape& t, const View& dou
   View da1; ALLOC_OR_FAIL(da1.p, u->alloc_act((long)B * Lout, r.cin)); da1.ld = r.cin;
   EEG_TRY(op_conv_dgrad(ctx, dt, dh1.p, dh1.ld, u->W(r.c1_w), da1.p, da1.ld, B, Lout, r.cin, r.cout, 3, 1, 1, 1, nullptr, 0));
   if (extra_done) *extra_done = 0;
+  int gn1_deferred = 0;
   EEG_TRY(op_groupnorm_bwd(ctx, t.x.p, t.x.ld, u->P(r.gn1_w), u->P(r.gn1_b), t.st1, da1.p, da1.ld, dx.p, dx.ld, u->param_grads ? u->G(r.gn1_w) : nullptr, u->param_grads ? u->G(r.gn1_b) : nullptr,
                            B, Lin, r.cin, r.groups, 1, r.updown, dxr.p, dxr.ld, dt, nullptr, 0, nullptr,
-                           extra ? extra->p : nullptr, extra ? extra->ld : 0, extra_done));
+                           extra ? extra->p : nullptr, extra ? extra->ld : 0, extra_done, pg ? &gn1_deferred : nullptr, 1 + u->gn_parity));
+  if (gn1_deferred) {   // folded inside the NEXT block's side-stream section (or by the executor's final flush); areas alternate, so the
+    u->gn_pending.push_back({u->G(r.gn1_w), u->G(r.gn1_b), r.cin, 1 + u->gn_parity});   // block after that may write this one again
+    u->gn_parity ^= 1;
+  }
   if (pg) EEG_TRY(ctx_join(ctx));                 // the side stream's reads of dout / dh1 / tape are done before the arena is reused
   u->arena.release(mk);
   return 0;

@@ -18,6 +18,9 @@ constexpr int MAXG_LDS = 1024;   // LDS accumulators per block (groups / channel
 constexpr int GN_NSLOT = 64;     // partial dgamma/dbeta buffers
 constexpr size_t GN_SLOT_OFFSET = 1u << 20;   // byte offset of the slot area inside ctx->scratch (64 slots x 2C floats <= 512 KiB)
 constexpr size_t GN_SLOT_OFFSET_B = (1u << 20) + (512u << 10);   // second slot area: partials whose fold the caller runs later (side stream)
+// third / fourth slot areas (alternating): folds the caller runs one ResBlock later, inside that block's side-stream section
+constexpr size_t GN_SLOT_OFFSET_C[2] = {24u << 20, (24u << 20) + (512u << 10)};
+static inline size_t gn_slot_region(int region) { return region == 0 ? GN_SLOT_OFFSET_B : GN_SLOT_OFFSET_C[(region - 1) & 1]; }
 
 template <typename T, int V> struct Vec;
 template <> struct Vec<float, 4> { typedef float4 type; };
@@ -468,7 +471,7 @@ __global__ __launch_bounds__(NTB) void gn_fwd_resident_kernel(const T* __restric
 // the per-sample column sums of the written dx -- the block owns (sample, channels) over all of L, so no atomics.
 // RAW0: resample == 0 specialisation that fetches the gradient rows packed, in the same predicated block as the x rows (the
 // conversion in place makes hipcc wait for every load separately: 12 serialised HBM latencies, 19 k of the block's 57 k cycles)
-template <typename T, int RPT, bool RAW0>
+template <typename T, int RPT, bool RAW0, bool SILU>
 __global__ __launch_bounds__(NTB) void gn_bwd_resident_kernel(const T* __restrict__ x, long ldx, const float* __restrict__ gamma,
                                                               const float* __restrict__ beta, const float* __restrict__ stats,
                                                               const T* __restrict__ dy, long lddy, T* __restrict__ dx, long lddx,
@@ -531,8 +534,8 @@ __global__ __launch_bounds__(NTB) void gn_bwd_resident_kernel(const T* __restric
 #pragma unroll
         for (int j = 0; j < 4; j++) {
           const float xh = fmaf(v[j], rstd, nmr);
-          const float sg = silu_grad_f(fmaf(ga[j], xh, be[j]));
-          const float dz = d[k][j] * (silu ? sg : 1.0f);
+          float dz = d[k][j];
+          if constexpr (SILU) dz *= silu_grad_f(fmaf(ga[j], xh, be[j]));   // (compile-time: a run-time select cost one v_cndmask per element)
           d[k][j] = dz;
           dg[j] = fmaf(dz, xh, dg[j]); db[j] += dz;
         }
@@ -687,7 +690,7 @@ template <typename T, int V>
 int gn_bwd_t(eegldm_ctx* ctx, const void* x, long ldx, const float* gamma, const float* beta, const float* stats,
              const void* dy, long lddy, void* dx, long lddx, float* dgamma, float* dbeta, int B, int L, int C, int G,
              int silu, int resample, const void* dxr, long lddxr, float* colsum_ps, long ldps, int* colsum_done,
-             const void* dxr2, long lddxr2, int* dxr2_done, int* slots_deferred) {
+             const void* dxr2, long lddxr2, int* dxr2_done, int* slots_deferred, int defer_region) {
   if (colsum_done) *colsum_done = 0;
   if (dxr2_done) *dxr2_done = 0;
   if (slots_deferred) *slots_deferred = 0;
@@ -707,15 +710,17 @@ int gn_bwd_t(eegldm_ctx* ctx, const void* x, long ldx, const float* gamma, const
       // region and calls op_gn_slot_reduce_deferred itself
       static const bool no_defer = getenv("EEGLDM_GN_NO_DEFER") != nullptr;
       const bool defer = slots_deferred && dgamma && !no_defer;
-      float* slots = dgamma ? (float*)((char*)ctx->scratch + (defer ? GN_SLOT_OFFSET_B : GN_SLOT_OFFSET)) : nullptr;
-#define GN_BWD_RES1(R, RAW) hipLaunchKernelGGL((gn_bwd_resident_kernel<T, R, RAW>), grid, dim3(NTB), 0, ctx->stream, (const T*)x, ldx, gamma, beta, stats, \
+      float* slots = dgamma ? (float*)((char*)ctx->scratch + (defer ? gn_slot_region(defer_region) : GN_SLOT_OFFSET)) : nullptr;
+#define GN_BWD_RES2(R, RAW, SL) hipLaunchKernelGGL((gn_bwd_resident_kernel<T, R, RAW, SL>), grid, dim3(NTB), 0, ctx->stream, (const T*)x, ldx, gamma, beta, stats, \
                                          (const T*)dy, lddy, (T*)dx, lddx, (const T*)dxr, lddxr, slots, colsum_ps, ldps, L, C, G, silu, resample, cc, (const T*)dxr2, lddxr2)
       static const bool raw0 = getenv("EEGLDM_GN_NO_RAW0") == nullptr;
+#define GN_BWD_RES1(R, RAW) do { if (silu) GN_BWD_RES2(R, RAW, true); else GN_BWD_RES2(R, RAW, false); } while (0)
 #define GN_BWD_RES(R) do { if (resample == 0 && raw0) GN_BWD_RES1(R, true); else GN_BWD_RES1(R, false); } while (0)
       constexpr int RLO = sizeof(T) == 2 ? 6 : 4, RHI = sizeof(T) == 2 ? 12 : 8;
       if (rpt <= RLO) GN_BWD_RES(RLO); else GN_BWD_RES(RHI);
 #undef GN_BWD_RES
 #undef GN_BWD_RES1
+#undef GN_BWD_RES2
       LAUNCH_CHECK();
       if (slots && !defer) {
         hipLaunchKernelGGL(gn_slot_reduce_kernel, dim3((2 * C + 255) / 256), dim3(256), 0, ctx->stream, slots, dgamma, dbeta, C, (double*)ctx->scratch, 0);
@@ -1082,7 +1087,7 @@ int op_groupnorm_bwd(eegldm_ctx* ctx, const void* x, long ldx, const float* gamm
                      const float* stats, const void* dy, long lddy, void* dx, long lddx,
                      float* dgamma, float* dbeta, int B, int L, int C, int G, int fuse_silu,
                      int resample, const void* dxr, long lddxr, int dtype, float* colsum_ps, long ldps, int* colsum_done,
-                     const void* dxr2, long lddxr2, int* dxr2_done, int* slots_deferred) {
+                     const void* dxr2, long lddxr2, int* dxr2_done, int* slots_deferred, int defer_region) {
   if (dxr2_done) *dxr2_done = 0;
   if (slots_deferred) *slots_deferred = 0;
   EEG_TRY(gn_check(ctx, B, L, C, G, resample, ldx));
@@ -1092,7 +1097,7 @@ int op_groupnorm_bwd(eegldm_ctx* ctx, const void* x, long ldx, const float* gamm
     if (dtype == EEGLDM_BF16) return gn_flat_bwd<bf16_t>(ctx, x, gamma, beta, stats, dy, dx, dxr, dgamma, dbeta, B, L, C, fuse_silu);
   }
   const bool v4 = vec4_ok(C, G, ldx, lddy, lddx, dxr ? lddxr : 0);
-#define GN_BWD_ARGS ctx, x, ldx, gamma, beta, stats, dy, lddy, dx, lddx, dgamma, dbeta, B, L, C, G, fuse_silu, resample, dxr, lddxr, colsum_ps, ldps, colsum_done, dxr2, lddxr2, dxr2_done, slots_deferred
+#define GN_BWD_ARGS ctx, x, ldx, gamma, beta, stats, dy, lddy, dx, lddx, dgamma, dbeta, B, L, C, G, fuse_silu, resample, dxr, lddxr, colsum_ps, ldps, colsum_done, dxr2, lddxr2, dxr2_done, slots_deferred, defer_region
   if (dtype == EEGLDM_F32) return v4 ? gn_bwd_t<float, 4>(GN_BWD_ARGS) : gn_bwd_t<float, 1>(GN_BWD_ARGS);
   if (dtype == EEGLDM_BF16) return v4 ? gn_bwd_t<bf16_t, 4>(GN_BWD_ARGS) : gn_bwd_t<bf16_t, 1>(GN_BWD_ARGS);
 #undef GN_BWD_ARGS
@@ -1100,8 +1105,8 @@ int op_groupnorm_bwd(eegldm_ctx* ctx, const void* x, long ldx, const float* gamm
 }
 
 // folds the second slot area into dgamma / dbeta (and re-zeroes it): the deferred half of op_groupnorm_bwd(..., slots_deferred)
-int op_gn_slot_reduce_deferred(eegldm_ctx* ctx, float* dgamma, float* dbeta, int C) {
-  float* slots = (float*)((char*)ctx->scratch + GN_SLOT_OFFSET_B);
+int op_gn_slot_reduce_deferred(eegldm_ctx* ctx, float* dgamma, float* dbeta, int C, int region) {
+  float* slots = (float*)((char*)ctx->scratch + gn_slot_region(region));
   hipLaunchKernelGGL(gn_slot_reduce_kernel, dim3((2 * C + 255) / 256), dim3(256), 0, ctx->stream, slots, dgamma, dbeta, C, (double*)ctx->scratch, 0);
   LAUNCH_CHECK();
   return 0;

@@ -351,6 +351,7 @@ extern "C" int eegldm_unet_backward(eegldm_unet* u, const float* dy, float* dx_o
     dout = g; }
   // gradients of out / output_blocks / middle_block are complete (in stream order): the host may start reducing them
   // across ranks while the input blocks' backward runs
+  EEG_TRY(u->flush_gn_folds());   // the last middle ResBlock's deferred dgamma / dbeta fold
   if (u->grad_hook) u->grad_hook(u->grad_hook_user, u->off_mid_begin, u->nparams - u->off_mid_begin);
   // ---- input blocks, reversed: gradient of block i's output = consumer's dx + skip gradient
   for (int i = n_in - 1; i >= 1; i--) {
@@ -359,6 +360,7 @@ extern "C" int eegldm_unet_backward(eegldm_unet* u, const float* dy, float* dx_o
     dout = g;
   }
   if (n_in == 1) EEG_TRY(ew_add_rows(ctx, dout.p, dout.ld, dskip[0].p, dskip[0].ld, (long)B * L, mc, dt));
+  EEG_TRY(u->flush_gn_folds());
   // ---- conv_in
   EEG_TRY(op_conv_wgrad(ctx, dt, u->x0.p, u->x0.ld, dout.p, dout.ld, u->G(u->off_cin_w), u->G(u->off_cin_b), B, L, cin, mc, 3, 1, 1, 1));
   if (dx_out) {
