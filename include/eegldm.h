@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define EEGLDM_ABI_VERSION 2
+#define EEGLDM_ABI_VERSION 3
 
 enum { EEGLDM_F32 = 0, EEGLDM_BF16 = 1 };
 enum {
@@ -86,6 +86,14 @@ int eegldm_pack_conv_weight(eegldm_ctx*, const float* w_ref, float* w_packed, in
 int eegldm_unpack_conv_weight(eegldm_ctx*, const float* w_packed, float* w_ref, int Cout, int Cin, int K);
 /* fp32 -> compute dtype copy (n elements) */
 int eegldm_cast(eegldm_ctx*, const float* src, void* dst, long n, int dst_dtype);
+
+/* K-blocked copy of a 3-tap conv weight, [3][Cin/32][Cout][32] (16-bit dtypes, Cin % 32 == 0): writes it to w_kblocked
+ * (same size as w) and registers it with the context, after which eegldm_conv1d_fwd(.., w, ..) reads its weight tiles from
+ * the copy (one contiguous run per K stage; results are bit-identical).  The model executors do this for their own weights;
+ * a caller of the primitives who updates w must pack again.  eegldm_conv1d_forget_kblocked removes the registration
+ * (before freeing either buffer).  No reference counterpart: layout plumbing behind nn.Conv1d (unet.py:263). */
+int eegldm_conv1d_pack_kblocked(eegldm_ctx*, const void* w, void* w_kblocked, int Cout, int Cin, int dtype);
+int eegldm_conv1d_forget_kblocked(eegldm_ctx*, const void* w);
 
 /* ------------------------------------------------------------------ primitives (NLC)
  * nn.Conv1d as used at unet.py:263,291,302,385,504 and inside MONAI AutoencoderKL /

@@ -49,6 +49,8 @@ SIGNATURES = {
     "eegldm_ncl_to_nlc": [_vp, _vp, _vp, _l, _i, _i, _i, _i],
     "eegldm_nlc_to_ncl": [_vp, _vp, _l, _vp, _i, _i, _i, _i],
     "eegldm_pack_conv_weight": [_vp, _vp, _vp, _i, _i, _i],
+    "eegldm_conv1d_pack_kblocked": [_vp, _vp, _vp, _i, _i, _i],
+    "eegldm_conv1d_forget_kblocked": [_vp, _vp],
     "eegldm_unpack_conv_weight": [_vp, _vp, _vp, _i, _i, _i],
     "eegldm_cast": [_vp, _vp, _vp, _l, _i],
     "eegldm_conv1d_fwd": [_vp, _vp, _l, _vp, _vp, _vp, _l, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _l, _vp, _l, _i],

@@ -417,6 +417,19 @@ __global__ void kblk_pack_kernel(const uint4* __restrict__ src, uint4* __restric
   const long o = (((long)t * (d.cin / 32) + ci8 / 4) * d.cout + co) * 4 + (ci8 & 3);
   dst[d.off / 8 + o] = src[d.off / 8 + r];
 }
+__global__ void kblk_pack1_kernel(const uint4* __restrict__ src, uint4* __restrict__ dst, int cout, int cin, long total) {
+  const long r = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= total) return;
+  const int cpr = cin / 8;
+  const int ci8 = (int)(r % cpr); const long tc = r / cpr;
+  const int co = (int)(tc % cout), t = (int)(tc / cout);
+  dst[(((long)t * (cin / 32) + ci8 / 4) * cout + co) * 4 + (ci8 & 3)] = src[r];
+}
+int kblk_pack_one(eegldm_ctx* ctx, const void* w_plain, void* w_packed, int Cout, int Cin) {
+  const long total = 3l * Cout * Cin / 8;
+  hipLaunchKernelGGL(kblk_pack1_kernel, dim3((unsigned)((total + NT - 1) / NT)), dim3(NT), 0, ctx->stream, (const uint4*)w_plain, (uint4*)w_packed, Cout, Cin, total);
+  LAUNCH_CHECK(); return 0;
+}
 int kblk_pack(eegldm_ctx* ctx, const void* w_plain, void* w_packed, const KbDesc* d_table, int n, long total_chunks) {
   if (n <= 0) return 0;
   hipLaunchKernelGGL(kblk_pack_kernel, dim3((unsigned)((total_chunks + NT - 1) / NT)), dim3(NT), 0, ctx->stream, (const uint4*)w_plain, (uint4*)w_packed,

@@ -215,6 +215,19 @@ extern "C" int eegldm_conv1d_fwd(eegldm_ctx* ctx, const void* x, long ldx, const
   EEG_CHECK(ctx && x && w && y, "null pointer");
   return op_conv_fwd(ctx, dtype, x, ldx, w, bias, y, ldy, B, Lin, Cin, Cout, K, stride, pad_l, pad_r, rowvec, ld_rowvec, resid, ld_resid);
 }
+extern "C" int eegldm_conv1d_pack_kblocked(eegldm_ctx* ctx, const void* w, void* w_kblocked, int Cout, int Cin, int dtype) {
+  EEG_CHECK(ctx && w && w_kblocked && w != w_kblocked, "null or aliased pointer");
+  EEG_CHECK(dtype != EEGLDM_F32 && Cin > 0 && Cout > 0 && Cin % 32 == 0, "K-blocked weights: 16-bit dtype and Cin %% 32 == 0 (got dtype %d, Cin %d)", dtype, Cin);
+  EEG_CHECK(((size_t)w % 16 == 0) && ((size_t)w_kblocked % 16 == 0), "weights must be 16-byte aligned");
+  EEG_TRY(kblk_pack_one(ctx, w, w_kblocked, Cout, Cin));
+  ctx->kblk[w] = w_kblocked;
+  return 0;
+}
+extern "C" int eegldm_conv1d_forget_kblocked(eegldm_ctx* ctx, const void* w) {
+  EEG_CHECK(ctx && w, "null pointer");
+  ctx->kblk.erase(w);
+  return 0;
+}
 extern "C" int eegldm_conv1d_bwd_data(eegldm_ctx* ctx, const void* dy, long lddy, const void* w, void* dx, long lddx, int B, int Lin,
                                       int Cin, int Cout, int K, int stride, int pad_l, int pad_r, const void* resid, long ld_resid, int dtype) {
   EEG_CHECK(ctx && dy && w && dx, "null pointer");

@@ -83,6 +83,55 @@ def test_conv1d_fwd_bwd(case, dtype):
     G.assert_close(dbd, b.grad, rtol=G.GTOL[dtype]["rtol"], atol=G.GTOL[dtype]["atol"] * max(1.0, float(b.grad.abs().max())), name="db")
 
 
+KBLK_CASES = [   # (B, L, Cin, Cout, stride): K-blocked weight copy vs the plain layout, same kernel, results must be bit-identical
+    (8, 192, 512, 512, 1), (4, 192, 1024, 512, 1), (4, 384, 256, 192, 1),   # Cout = 192: a partial 128-column tile
+    (8, 768, 128, 128, 1), (4, 384, 64, 128, 2), (2, 192, 32, 64, 1), (4, 96, 768, 256, 1),
+]
+
+
+@pytest.mark.parametrize("case", KBLK_CASES)
+def test_conv1d_kblocked_weights_bit_identical(case):
+    """eegldm_conv1d_pack_kblocked: [3][Cout][Cin] -> [3][Cin/32][Cout][32]; the forward conv then reads contiguous weight tiles.
+    Only the addressing of the weight operand changes, so the outputs are compared for equality, and against the fp32 reference."""
+    G = _imports()
+    B, L, Cin, Cout, stride = case
+    dtype = G.BF16
+    x = torch.from_numpy(normal((B, Cin, L), seed=11)).bfloat16().float()
+    w = (torch.from_numpy(normal((Cout, Cin, 3), seed=12)) / math.sqrt(3 * Cin)).bfloat16().float()
+    b = torch.from_numpy(normal((Cout,), seed=13))
+    pl, pr = (1, 1) if stride == 1 else (0, 1)
+    y_ref = F.conv1d(F.pad(x, (pl, pr)), w, b, stride=stride)
+    Lout = y_ref.shape[-1]
+    c = G.ctx()
+    xd, wd, bd = G.nlc(x, dtype), G.pack_w(w, dtype), b.to(G.DEV)
+    run = lambda out: G.check(G.lib.eegldm_conv1d_fwd(c.h, G.ptr(xd), Cin, G.ptr(wd), G.ptr(bd), G.ptr(out), Cout, B, L, Cin, Cout, 3, stride, pl, pr,
+                                                      None, 0, None, 0, dtype))
+    y_plain = torch.empty(B * Lout, Cout, device=G.DEV, dtype=G.TDT[dtype]); run(y_plain)
+    wk = torch.full_like(wd, float("nan"))
+    G.check(G.lib.eegldm_conv1d_pack_kblocked(c.h, G.ptr(wd), G.ptr(wk), Cout, Cin, dtype))
+    try:
+        # the copy is a permutation of the weight: [t][ci/32][co][ci%32]
+        exp = wd.view(3, Cout, Cin // 32, 32).permute(0, 2, 1, 3).contiguous().view(-1)
+        assert torch.equal(wk.view(-1).view(torch.int16), exp.view(torch.int16)), "packed layout"
+        y_kb = torch.empty_like(y_plain); run(y_kb)
+    finally:
+        G.check(G.lib.eegldm_conv1d_forget_kblocked(c.h, G.ptr(wd)))
+    assert torch.equal(y_kb.view(torch.int16), y_plain.view(torch.int16)), "K-blocked weights changed the result"
+    G.assert_close(G.ncl(y_kb, B, Lout), y_ref, **G.TOL[dtype], name="y (K-blocked)")
+    y_again = torch.empty_like(y_plain); run(y_again)                  # registration removed: plain path again
+    assert torch.equal(y_again.view(torch.int16), y_plain.view(torch.int16))
+
+
+def test_conv1d_pack_kblocked_rejects_bad_arguments():
+    G = _imports()
+    c = G.ctx()
+    w = torch.zeros(3 * 64 * 48, device=G.DEV, dtype=torch.bfloat16); wk = torch.empty_like(w)
+    assert G.lib.eegldm_conv1d_pack_kblocked(c.h, G.ptr(w), G.ptr(wk), 64, 48, G.BF16) != 0      # Cin % 32 != 0
+    wf = torch.zeros(3 * 64 * 64, device=G.DEV); wkf = torch.empty_like(wf)
+    assert G.lib.eegldm_conv1d_pack_kblocked(c.h, G.ptr(wf), G.ptr(wkf), 64, 64, G.F32) != 0    # fp32 has no K-blocked path
+    assert G.lib.eegldm_conv1d_pack_kblocked(c.h, G.ptr(w), G.ptr(w), 64, 64, G.BF16) != 0        # aliased
+
+
 @pytest.mark.parametrize("dtype", [0, 1])
 def test_conv1d_epilogue_rowvec_resid(dtype):
     """bias + per-sample embedding row + residual in the GEMM epilogue; L = 192 puts a sample boundary inside a 128-row tile
