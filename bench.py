@@ -247,7 +247,7 @@ def main():
     windows = torch.from_numpy(eeg_windows(B, seed=1234 + rank, length=4 * L)).to(dev)
     scale_factor = 1.0 / float(ae.encode_stage_2_inputs(windows, eps=randn(ctx, (B, 1, L), seed=99)).std())   # train_ldm.py:203-204
 
-    gsync = D.OverlappedGradSync(unet.flat_grad, ctx=ctx) if world > 1 else None
+    gsync = D.OverlappedGradSync(unet.flat_grad, ctx=ctx, comm=D.make_comm(ctx)) if world > 1 else None   # EEGLDM_NATIVE_COLLECTIVES=1: eegldm_comm_* (RCCL via the C ABI)
 
     def step(i, sync=True):
         t = randint(ctx, B, 1000, seed=1235 + rank, offset=i * B)

@@ -277,6 +277,25 @@ int eegldm_sample(eegldm_unet*, eegldm_aekl* ae, const float* noise, const int64
                   float inv_scale_factor, uint64_t noise_seed, float* latents_out, float* windows_out, int B, int L, int use_graph,
                   int* graph_used_host);
 
+/* ------------------------------------------------------------------ data-parallel collectives (RCCL over xGMI)
+ * One communicator per process / GPU.  Stands where the reference gathers gradients with single-process nn.DataParallel
+ * (train_ldm.py:190-192, train_autoencoderkl.py:230-233): every rank means the model's flat fp32 gradient buffer across ranks, the
+ * parameters of rank 0 are broadcast once at start (BASELINE configs[3]: 8 ranks, global batch 2048).  Collectives run on the
+ * communicator's own stream, ordered after the work enqueued on the context's stream at the time of the call; eegldm_comm_wait makes
+ * the context's stream wait for them.  RCCL is loaded with dlopen when the first communicator is created (no link-time dependency).
+ * id128: the 128-byte ncclUniqueId made by ONE rank with eegldm_comm_unique_id and handed to the others by the launcher
+ * (eegldm.distributed passes it through the torch.distributed store). */
+typedef struct eegldm_comm eegldm_comm;
+int eegldm_comm_unique_id(char* out128);
+int eegldm_comm_create(eegldm_ctx*, const char* id128, int rank, int world, eegldm_comm** out);
+int eegldm_comm_destroy(eegldm_comm*);
+int eegldm_comm_rank(const eegldm_comm*);
+int eegldm_comm_world(const eegldm_comm*);
+/* buf[0..n) <- mean over ranks, in place, as ceil(n / bucket_elems) collectives in one group (bucket_elems <= 0: one) */
+int eegldm_comm_allreduce_mean_f32(eegldm_comm*, float* buf, long n, long bucket_elems);
+int eegldm_comm_broadcast_f32(eegldm_comm*, float* buf, long n, int root);
+int eegldm_comm_wait(eegldm_comm*);
+
 /* ------------------------------------------------------------------ PatchDiscriminator
  * PatchDiscriminator(spatial_dims=1, num_layers_d, num_channels, in_channels, out_channels, kernel_size=3,
  * norm="BATCH", bias, padding=1) -- monai-generative, config/config_aekl_eeg.yaml:30-40.  forward returns the

@@ -50,6 +50,14 @@ SIGNATURES = {
     "eegldm_nlc_to_ncl": [_vp, _vp, _l, _vp, _i, _i, _i, _i],
     "eegldm_pack_conv_weight": [_vp, _vp, _vp, _i, _i, _i],
     "eegldm_conv1d_pack_kblocked": [_vp, _vp, _vp, _i, _i, _i],
+    "eegldm_comm_unique_id": [_vp],
+    "eegldm_comm_create": [_vp, _vp, _i, _i, _vp],
+    "eegldm_comm_destroy": [_vp],
+    "eegldm_comm_rank": [_vp],
+    "eegldm_comm_world": [_vp],
+    "eegldm_comm_allreduce_mean_f32": [_vp, _vp, _l, _l],
+    "eegldm_comm_broadcast_f32": [_vp, _vp, _l, _i],
+    "eegldm_comm_wait": [_vp],
     "eegldm_conv1d_forget_kblocked": [_vp, _vp],
     "eegldm_unpack_conv_weight": [_vp, _vp, _vp, _i, _i, _i],
     "eegldm_cast": [_vp, _vp, _vp, _l, _i],

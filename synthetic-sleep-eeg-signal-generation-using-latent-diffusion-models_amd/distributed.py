@@ -50,6 +50,78 @@ def allreduce_mean_flat(t, bucket_elems=BUCKET_ELEMS):
     t.mul_(1.0 / world)
 
 
+class NativeComm:
+    """RCCL communicator behind the C ABI (csrc/comm.hip, `eegldm_comm_*`): the gradient mean runs as ncclAvg collectives on the
+    communicator's own stream, ordered after the Context's stream by an event, without going through torch.distributed.
+    Opt-in (`EEGLDM_NATIVE_COLLECTIVES=1`, see `make_comm`): it has only ever run with ONE rank -- no multi-GPU node was available to
+    the builder -- whereas the torch.distributed path is exercised with two processes (gloo) by the tests."""
+
+    def __init__(self, ctx, rank, world, unique_id):
+        import ctypes as C
+        from ._lib import lib, check
+        assert len(unique_id) == 128
+        self.ctx, self.rank, self.world = ctx, int(rank), int(world)
+        h = C.c_void_p()
+        check(lib.eegldm_comm_create(ctx.h, C.c_char_p(bytes(unique_id)), self.rank, self.world, C.byref(h)))
+        self.h = h
+
+    @staticmethod
+    def unique_id():
+        import ctypes as C
+        from ._lib import lib, check
+        buf = C.create_string_buffer(128)
+        check(lib.eegldm_comm_unique_id(buf))
+        return buf.raw
+
+    @classmethod
+    def from_process_group(cls, ctx):
+        """One id made by rank 0 and handed round through the initialised torch.distributed group (any backend)."""
+        rank, world = (dist.get_rank(), dist.get_world_size()) if dist.is_initialized() else (0, 1)
+        box = [cls.unique_id() if rank == 0 else None]
+        if world > 1:
+            dist.broadcast_object_list(box, src=0)
+        return cls(ctx, rank, world, box[0])
+
+    def _chk(self, t):
+        if not (t.is_cuda and t.dtype == torch.float32 and t.is_contiguous()):
+            raise ValueError("NativeComm works on contiguous fp32 device tensors (the flat parameter / gradient buffers)")
+
+    def allreduce_mean(self, t, bucket_elems=BUCKET_ELEMS):
+        from ._lib import lib, check, ptr
+        self._chk(t)
+        check(lib.eegldm_comm_allreduce_mean_f32(self.h, ptr(t), t.numel(), int(bucket_elems)))
+
+    def broadcast(self, t, root=0):
+        from ._lib import lib, check, ptr
+        self._chk(t)
+        check(lib.eegldm_comm_broadcast_f32(self.h, ptr(t), t.numel(), int(root)))
+
+    def wait(self):
+        from ._lib import lib, check
+        check(lib.eegldm_comm_wait(self.h))
+
+    def close(self):
+        from ._lib import lib
+        if self.h:
+            lib.eegldm_comm_destroy(self.h); self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def make_comm(ctx):
+    """The native communicator when asked for (EEGLDM_NATIVE_COLLECTIVES=1) and more than one GPU rank is running, else None
+    (callers then use the torch.distributed collectives)."""
+    if os.environ.get("EEGLDM_NATIVE_COLLECTIVES", "0") != "1" or not dist.is_initialized() or dist.get_world_size() == 1:
+        return None
+    if not torch.cuda.is_available():
+        return None
+    return NativeComm.from_process_group(ctx)
+
+
 class OverlappedGradSync:
     """Data-parallel gradient mean with the communication started before backward has finished.
 
@@ -58,21 +130,27 @@ class OverlappedGradSync:
     covered yet; `wait()` blocks the current stream on all of it and applies the 1/world scaling.  With one process it
     does nothing.  Slices must not overlap (the native hook reports one tail range)."""
 
-    def __init__(self, flat_grad, bucket_elems=BUCKET_ELEMS, ctx=None):
+    def __init__(self, flat_grad, bucket_elems=BUCKET_ELEMS, ctx=None, comm=None):
         self.g = flat_grad
         self.ctx = ctx          # eegldm.Context whose stream the native backward enqueues on (checked in on_ready)
+        self.comm = comm        # NativeComm: collectives through the C ABI instead of torch.distributed
         self.bucket = int(bucket_elems)
         self.works = []
         self.done = []          # (start, end) ranges already launched
 
     @property
     def active(self):
+        if self.comm is not None:
+            return True
         return dist.is_initialized() and dist.get_world_size() > 1
 
     def begin(self):
         self.works, self.done = [], []
 
     def _launch(self, a, b):
+        if self.comm is not None:     # ordered after the Context's stream inside the library; one group of bucketed ncclAvg collectives
+            self.comm.allreduce_mean(self.g[a:b], self.bucket)
+            return
         for s in range(a, b, self.bucket):
             e = min(b, s + self.bucket)
             self.works.append(dist.all_reduce(self.g[s:e], op=dist.ReduceOp.SUM, async_op=True))
@@ -82,7 +160,7 @@ class OverlappedGradSync:
             return
         # dist.all_reduce orders itself after torch's CURRENT stream; the backward that produced this slice was enqueued on the
         # context's stream (torch's current stream when the Context was created).  They must be the same stream.
-        if self.ctx is not None and self.g.is_cuda and torch.cuda.current_stream(self.g.device).cuda_stream != self.ctx.stream_handle:
+        if self.comm is None and self.ctx is not None and self.g.is_cuda and torch.cuda.current_stream(self.g.device).cuda_stream != self.ctx.stream_handle:
             raise RuntimeError("OverlappedGradSync: torch's current stream differs from the stream the eegldm Context enqueues on; "
                                "the all-reduce would not be ordered after the backward (create the Context under the stream you train on)")
         self._launch(offset, offset + numel)
@@ -101,6 +179,9 @@ class OverlappedGradSync:
 
     def wait(self):
         if not self.active:
+            return
+        if self.comm is not None:
+            self.comm.wait()          # the mean is part of the collective (ncclAvg)
             return
         for w in self.works:
             w.wait()

@@ -46,7 +46,7 @@ def main(args):
     s_t, s_noise = rng_seed(config.train.seed, 1, rank, world), rng_seed(config.train.seed, 3, rank, world)
     dev, ctx = unet.device, unet.ctx
     loss = torch.zeros(1, device=dev)
-    gsync = D.OverlappedGradSync(unet.flat_grad, ctx=unet.ctx)          # no-op with one process
+    gsync = D.OverlappedGradSync(unet.flat_grad, ctx=unet.ctx, comm=D.make_comm(unet.ctx))   # no-op with one process; EEGLDM_NATIVE_COLLECTIVES=1: RCCL through the C ABI
     steps, t0, seen, best, start_epoch, gstep = 0, time.time(), 0, float("inf"), 0, 0      # gstep: steps over all invocations (RNG offsets)
     if resume:      # continue from {run_dir}/checkpoint.pth
         ck = torch.load(os.path.join(run_dir, "checkpoint.pth"), map_location="cpu")

@@ -91,7 +91,7 @@ def main(args):
     if rank == 0:
         print(f"Scaling factor set to {scale_factor}")
     loss = torch.zeros(1, device=dev)
-    gsync = D.OverlappedGradSync(unet.flat_grad, ctx=unet.ctx)          # no-op with one process
+    gsync = D.OverlappedGradSync(unet.flat_grad, ctx=unet.ctx, comm=D.make_comm(unet.ctx))   # no-op with one process; EEGLDM_NATIVE_COLLECTIVES=1: RCCL through the C ABI
     steps, t0, seen, best, start_epoch, gstep = 0, time.time(), 0, float("inf"), 0, 0      # gstep: steps over all invocations (RNG offsets)
     if resume:
         # continue from {run_dir}/checkpoint.pth (keys as written below = training.py:381-387).  The reference computes `resume`

@@ -86,3 +86,30 @@ def test_bench_self_spawns_two_ranks():
     j = json.loads(lines[0])
     assert j["n_gpus"] == 2 and j["config"]["global_batch"] == 32 and j["config"]["parallelism"] == "dp2" and j["scaling"] == "weak"
     assert j["value"] > 0 and j["steps"] == 2 and j["unit"] == "windows/s" and j["roofline"]["bound"] == "mfma"
+
+
+def test_native_rccl_communicator_one_rank():
+    """eegldm_comm_* (csrc/comm.hip): RCCL resolved with dlopen, communicator of ONE rank on this GPU.  With one rank the mean / broadcast
+    are identities, so this checks the plumbing only -- id exchange, stream ordering against the Context, bucketing, ncclAvg, wait.
+    (No multi-GPU node: the N > 1 behaviour of this path is untested; the torch.distributed path has the two-process tests above.)"""
+    import torch
+    import eegldm
+    from eegldm import distributed as D
+    ctx = eegldm.default_context(0)
+    comm = D.NativeComm(ctx, 0, 1, D.NativeComm.unique_id())
+    try:
+        from eegldm._lib import lib
+        assert lib.eegldm_comm_rank(comm.h) == 0 and lib.eegldm_comm_world(comm.h) == 1
+        g = torch.randn(1_000_003, device="cuda"); ref = g.clone()
+        comm.allreduce_mean(g, bucket_elems=70_001); comm.wait(); torch.cuda.synchronize()
+        assert torch.equal(g, ref)
+        comm.broadcast(g, 0); comm.wait(); torch.cuda.synchronize()
+        assert torch.equal(g, ref)
+        # the overlapped gradient sync driven as the native backward hook drives it: tail first, the rest at the end
+        gs = D.OverlappedGradSync(g, bucket_elems=70_001, ctx=ctx, comm=comm)
+        gs.begin(); gs.on_ready(600_000, 400_003); g[:10].add_(0.0); gs.finish(); gs.wait(); torch.cuda.synchronize()
+        assert torch.equal(g, ref) and sorted(gs.done) == [(600_000, 1_000_003)]
+        with pytest.raises(ValueError):
+            comm.allreduce_mean(g.double())
+    finally:
+        comm.close()
