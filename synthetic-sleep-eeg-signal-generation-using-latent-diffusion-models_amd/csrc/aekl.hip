@@ -432,7 +432,7 @@ int aekl_encode_impl(eegldm_aekl* a, const float* x, const float* eps, int B, in
   }
   ALLOC_OR_FAIL(a->sigma, a->arena.alloc(sizeof(float) * n));
   View z; ALLOC_OR_FAIL(z.p, a->alloc_act((long)B * Lc, lat)); z.ld = lat; z.C = lat;
-  if (kl) HIP_TRY(hipMemsetAsync(kl, 0, sizeof(float), ctx->stream));
+  if (kl && !ctx->loss_prezeroed) HIP_TRY(hipMemsetAsync(kl, 0, sizeof(float), ctx->stream));
   EEG_TRY(ls_reparam(ctx, a->mu.p, a->lv.p, a->eps_nlc, z.p, a->sigma, kl, n, B, dt));
   *z_out = z;
   return 0;
@@ -484,7 +484,7 @@ extern "C" int eegldm_aekl_forward(eegldm_aekl* a, const float* x, const float* 
       ALLOC_OR_FAIL(a->thin_eps, a->arena.alloc(sizeof(float) * (size_t)B * p.lat * p.Ll));
       HIP_TRY(hipMemcpyAsync(a->thin_eps, eps, sizeof(float) * (size_t)B * p.lat * p.Ll, hipMemcpyDeviceToDevice, a->ctx->stream));
     }
-    if (kl) HIP_TRY(hipMemsetAsync(kl, 0, sizeof(float), a->ctx->stream));
+    if (kl && !a->ctx->loss_prezeroed) HIP_TRY(hipMemsetAsync(kl, 0, sizeof(float), a->ctx->stream));
     EEG_TRY(thin_forward(a->ctx, p, a->params, x, a->thin_eps, recon, z_mu, z_sigma, kl, B));
     a->have_tape = true; a->thin_tape = true;
     return 0;
@@ -654,9 +654,13 @@ extern "C" int eegldm_aekl_train_step(eegldm_aekl* a, eegldm_disc* d, const floa
   float* dlogits; ALLOC_OR_FAIL(dlogits, a->stage.alloc(sizeof(float) * nl));
   // losses[0..5] = recons (L1), spectral, kl, generator adv, D fake, D real
   // ---- generator
+  // one memset for the six loss scalars (the loss entry points skip theirs while loss_prezeroed is set); the L1 term WRITES drecon
+  struct Prezero { eegldm_ctx* c; explicit Prezero(eegldm_ctx* cc) : c(cc) { c->loss_prezeroed = true; } ~Prezero() { c->loss_prezeroed = false; c->l1_overwrite = false; } } prezero(ctx);
+  HIP_TRY(hipMemsetAsync(losses, 0, sizeof(float) * 6, ctx->stream));
   EEG_TRY(eegldm_aekl_forward(a, x, eps, recon, nullptr, nullptr, losses + 2, B, L));
-  HIP_TRY(hipMemsetAsync(drecon, 0, sizeof(float) * n, ctx->stream));
+  ctx->l1_overwrite = true;
   EEG_TRY(eegldm_l1_loss(ctx, recon, x, losses + 0, drecon, n, 1.0f));
+  ctx->l1_overwrite = false;
   EEG_TRY(eegldm_spectral_loss(ctx, recon, x, losses + 1, use_spectral ? drecon : nullptr, B, C, L, spectral_weight));
   EEG_TRY(eegldm_disc_forward(d, recon, logits, B, L, 1));
   EEG_TRY(eegldm_lsgan_loss(ctx, logits, 1, losses + 3, dlogits, nl, adv_weight));

@@ -57,6 +57,11 @@ struct eegldm_ctx {
   std::vector<ProfRec> prof;
   // K-blocked copies of 3-tap conv weights, keyed by the address of the plain [tap][Cout][Cin] bf16 weight (registered by NetBase)
   std::unordered_map<const void*, const void*> kblk;
+  // fused train steps zero ALL their loss scalars with one memset and set this: the loss entry points then skip their own 4-byte memset
+  // (every tiny launch costs ~5 us of dispatch: 22 memsets were 2.5 % of the AutoencoderKL / GAN step)
+  bool loss_prezeroed = false;
+  bool l1_overwrite = false;      // eegldm_l1_loss writes da instead of accumulating (the caller skipped zeroing it)
+  int bn_flip = 0; int bn_dirty[2] = {0, 0};   // BatchNorm sum areas alternate; each call's fold kernel re-zeroes the other one (losses.hip)
   double prof_bracket_ms = 0.0;   // elapsed time of an EMPTY event pair on this stream (calibrated by eegldm_prof_enable): subtracted per launch
 };
 

@@ -186,8 +186,11 @@ __global__ __launch_bounds__(NT) void bn_reduce4_kernel(const T* __restrict__ x,
   float* part = (float*)parts + (size_t)blockIdx.x * 2 * C;
   for (int i = threadIdx.x; i < 2 * C; i += NT) part[i] = (float)red[i];
 }
-__global__ void bn_fold_kernel(const float* __restrict__ parts, int nparts, int n2c, double* __restrict__ sums) {
+__global__ void bn_fold_kernel(const float* __restrict__ parts, int nparts, int n2c, double* __restrict__ sums, double* __restrict__ zero_next, int n_zero) {
   __shared__ double red[NT];
+  // the OTHER sum area (used by the previous BatchNorm call, whose consumers precede this kernel in stream order) is re-zeroed here
+  // for the next call: no memset launch per call
+  if (blockIdx.y == 0 && (threadIdx.x >> 6) == 0) for (int j = blockIdx.x * 64 + (threadIdx.x & 63); j < n_zero; j += gridDim.x * 64) zero_next[j] = 0.0;
   const int i = blockIdx.x * 64 + (threadIdx.x & 63), seg = threadIdx.x >> 6;
   const int per = (nparts + gridDim.y - 1) / gridDim.y, r0 = blockIdx.y * per, r1 = min(nparts, r0 + per);    // sums pre-zeroed
   double s = 0.0;
@@ -302,12 +305,12 @@ __global__ void reparam_bwd_kernel(const T* __restrict__ mu, const T* __restrict
 // ------------------------------------------------------------------ losses on fp32 NCL tensors
 // L1: loss += w_loss * mean|a-b| ; da += w_grad * sign(a-b)/n
 __global__ __launch_bounds__(NT) void l1_kernel(const float* __restrict__ a, const float* __restrict__ b, float* __restrict__ loss,
-                                                float* __restrict__ da, long n, float inv_n, float wgrad) {
+                                                float* __restrict__ da, long n, float inv_n, float wgrad, int overwrite) {
   float s = 0.f;
   GRID_STRIDE(i, n) {
     const float d = a[i] - b[i];
     s += fabsf(d);
-    if (da) da[i] += wgrad * inv_n * (d > 0.f ? 1.0f : (d < 0.f ? -1.0f : 0.f));
+    if (da) { const float g = wgrad * inv_n * (d > 0.f ? 1.0f : (d < 0.f ? -1.0f : 0.f)); da[i] = overwrite ? g : da[i] + g; }
   }
   s = wave_sum(s);
   __shared__ float red[4];
@@ -351,22 +354,34 @@ int ls_bn_repeat_running(eegldm_ctx* ctx, const float* stats, float* rmean, floa
   LAUNCH_CHECK();
   return 0;
 }
+// Sum areas in the context scratch: two alternating ones for the partials + fold path (the fold kernel of a call re-zeroes the area
+// the PREVIOUS call used -- all of that call's consumers precede it in stream order), a third, memset per call, for the atomic path.
+static double* bn_area(eegldm_ctx* ctx, int i) { return (double*)((char*)ctx->scratch + (2u << 20) + (size_t)i * (256u << 10)); }
+static int bn_fold_launch(eegldm_ctx* ctx, const void* parts, int nb, int C, double** sums_out) {
+  const int cur = ctx->bn_flip, oth = cur ^ 1;
+  double* sums = bn_area(ctx, cur);
+  hipLaunchKernelGGL(bn_fold_kernel, dim3((2 * C + 63) / 64, 32), dim3(NT), 0, ctx->stream, (const float*)parts, nb, 2 * C, sums, bn_area(ctx, oth), ctx->bn_dirty[oth]);
+  LAUNCH_CHECK();
+  ctx->bn_dirty[cur] = 2 * C; ctx->bn_dirty[oth] = 0; ctx->bn_flip = oth;
+  *sums_out = sums;
+  return 0;
+}
 // BatchNorm1d + LeakyReLU forward.  training: batch statistics (and running-stat update when rmean != null);
 // eval: running statistics.  stats: [C][2] fp32 out.  gamma == null: plain LeakyReLU (stats unused).
 int ls_bn_lrelu_fwd(eegldm_ctx* ctx, const void* x, long ldx, const float* gamma, const float* beta, float* stats, float* rmean, float* rvar,
                     float* nbt, void* y, long ldy, long rows, int C, float slope, int training, int dtype) {
   if (gamma) {
     if (training) {
-      double* sums = (double*)((char*)ctx->scratch + (2u << 20));   // BatchNorm region of the context scratch (GroupNorm owns [0, 1 MiB) self-cleaning)
-      EEG_CHECK((size_t)C * 2 * sizeof(double) <= (1u << 20), "scratch too small");
-      HIP_TRY(hipMemsetAsync(sums, 0, sizeof(double) * 2 * C, ctx->stream));
+      double* sums = bn_area(ctx, 2);   // BatchNorm region of the context scratch (GroupNorm owns [0, 1 MiB) self-cleaning)
+      EEG_CHECK((size_t)C * 2 * sizeof(double) <= (256u << 10), "scratch too small");
       if (C % 4 == 0 && ldx % 4 == 0 && C <= 1024) {
         int nb; long rpb4; bn_split(rows, ctx, 8, &nb, &rpb4);
         void* parts = (char*)ctx->scratch + (8u << 20);
         DISPATCH_T(dtype, hipLaunchKernelGGL((bn_reduce4_kernel<T, 0>), dim3(nb), dim3(NT), 0, ctx->stream, (const T*)x, ldx, nullptr, nullptr, nullptr,
                                              (const T*)nullptr, 0, parts, rows, C, rpb4, 0.f));
-        hipLaunchKernelGGL(bn_fold_kernel, dim3((2 * C + 63) / 64, 32), dim3(NT), 0, ctx->stream, (const float*)parts, nb, 2 * C, sums);
+        EEG_TRY(bn_fold_launch(ctx, parts, nb, C, &sums));
       } else {
+        HIP_TRY(hipMemsetAsync(sums, 0, sizeof(double) * 2 * C, ctx->stream));
         int rs; long rpb; pick_rsplit(rows, C, ctx, &rs, &rpb);
         DISPATCH_T(dtype, hipLaunchKernelGGL((bn_stats_kernel<T>), dim3((C + 63) / 64, rs), dim3(NT), 0, ctx->stream, (const T*)x, ldx, sums, rows, C, rpb));
       }
@@ -391,16 +406,16 @@ int ls_bn_lrelu_fwd(eegldm_ctx* ctx, const void* x, long ldx, const float* gamma
 }
 int ls_bn_lrelu_bwd(eegldm_ctx* ctx, const void* x, long ldx, const float* gamma, const float* beta, const float* stats, const void* dy, long lddy,
                     void* dx, long lddx, float* dgamma, float* dbeta, long rows, int C, float slope, int dtype) {
-  double* sums = (double*)((char*)ctx->scratch + (2u << 20));
+  double* sums = bn_area(ctx, 2);
   if (gamma) {
-    HIP_TRY(hipMemsetAsync(sums, 0, sizeof(double) * 2 * C, ctx->stream));
     if (C % 4 == 0 && ldx % 4 == 0 && lddy % 4 == 0 && C <= 1024) {
       int nb; long rpb4; bn_split(rows, ctx, 8, &nb, &rpb4);
       void* parts = (char*)ctx->scratch + (8u << 20);
       DISPATCH_T(dtype, hipLaunchKernelGGL((bn_reduce4_kernel<T, 1>), dim3(nb), dim3(NT), 0, ctx->stream, (const T*)x, ldx, gamma, beta, stats,
                                            (const T*)dy, lddy, parts, rows, C, rpb4, slope));
-      hipLaunchKernelGGL(bn_fold_kernel, dim3((2 * C + 63) / 64, 32), dim3(NT), 0, ctx->stream, (const float*)parts, nb, 2 * C, sums);
+      EEG_TRY(bn_fold_launch(ctx, parts, nb, C, &sums));
     } else {
+      HIP_TRY(hipMemsetAsync(sums, 0, sizeof(double) * 2 * C, ctx->stream));
       int rs; long rpb; pick_rsplit(rows, C, ctx, &rs, &rpb);
       DISPATCH_T(dtype, hipLaunchKernelGGL((bn_bwd_reduce_kernel<T>), dim3((C + 63) / 64, rs), dim3(NT), 0, ctx->stream, (const T*)x, ldx, gamma, beta, stats,
                                            (const T*)dy, lddy, sums, rows, C, rpb, slope));
@@ -440,13 +455,13 @@ int ls_reparam_bwd(eegldm_ctx* ctx, const void* mu, const void* lv, const float*
 // ================================================================== C ABI (losses)
 extern "C" int eegldm_l1_loss(eegldm_ctx* ctx, const float* a, const float* b, float* loss, float* da_accum, long n, float grad_weight) {
   EEG_CHECK(ctx && a && b && loss && n > 0, "bad argument");
-  HIP_TRY(hipMemsetAsync(loss, 0, sizeof(float), ctx->stream));
-  hipLaunchKernelGGL(l1_kernel, dim3(grid1d(n / 4 + 1, ctx)), dim3(NT), 0, ctx->stream, a, b, loss, da_accum, n, 1.0f / (float)n, grad_weight);
+  if (!ctx->loss_prezeroed) HIP_TRY(hipMemsetAsync(loss, 0, sizeof(float), ctx->stream));
+  hipLaunchKernelGGL(l1_kernel, dim3(grid1d(n / 4 + 1, ctx)), dim3(NT), 0, ctx->stream, a, b, loss, da_accum, n, 1.0f / (float)n, grad_weight, ctx->l1_overwrite ? 1 : 0);
   LAUNCH_CHECK(); return 0;
 }
 extern "C" int eegldm_lsgan_loss(eegldm_ctx* ctx, const float* logits, int target_is_real, float* loss, float* dlogits, long n, float grad_weight) {
   EEG_CHECK(ctx && logits && loss && n > 0, "bad argument");
-  HIP_TRY(hipMemsetAsync(loss, 0, sizeof(float), ctx->stream));
+  if (!ctx->loss_prezeroed) HIP_TRY(hipMemsetAsync(loss, 0, sizeof(float), ctx->stream));
   hipLaunchKernelGGL(lsgan_kernel, dim3(grid1d(n, ctx)), dim3(NT), 0, ctx->stream, logits, target_is_real ? 1.0f : 0.0f, loss, dlogits, n, 1.0f / (float)n, grad_weight);
   LAUNCH_CHECK(); return 0;
 }

@@ -125,7 +125,7 @@ extern "C" int eegldm_spectral_loss(eegldm_ctx* ctx, const float* recon, const f
                                     int B, int C, int L, float grad_weight) {
   EEG_CHECK(ctx && recon && target && loss && B > 0, "bad argument");
   EEG_CHECK(C == 1, "spectral loss is implemented for single-channel windows (the reference's 1ch x 3072 EEG); got C=%d", C);
-  HIP_TRY(hipMemsetAsync(loss, 0, sizeof(float), ctx->stream));
+  if (!ctx->loss_prezeroed) HIP_TRY(hipMemsetAsync(loss, 0, sizeof(float), ctx->stream));
   if (L == 3072) return launch<48, 64>(ctx, recon, target, loss, d_recon_accum, B, grad_weight);
   if (L == 768) return launch<24, 32>(ctx, recon, target, loss, d_recon_accum, B, grad_weight);
   if (L == 256) return launch<16, 16>(ctx, recon, target, loss, d_recon_accum, B, grad_weight);
