@@ -228,6 +228,18 @@ void gemm_kernel(const GemmArgs p) {   // >= 2 waves per SIMD: <= 256 VGPR+AGPR
     const int tile = slot % tiles;
     z = (slot / tiles) * 8 + xcd;
     tile_n = tile % (int)gridDim.x; tile_m = tile / (int)gridDim.x;
+  } else if (p.xcd_swizzle == 3) {
+    // split-K with ANY split count (equal K chunks): the (split, tile) pairs in split-major order are cut into 8 contiguous runs, one
+    // per XCD (bijective for every block count), so a split's tiles -- which all read the same dY / X rows -- sit on one XCD, two at
+    // most.  Without it (split counts that are not multiples of 8: the qkv weight gradient runs 48 tiles x 10 splits) every XCD
+    // fetched every row panel: the 1-tap TN class read 265 MB per launch where ~95 MB are needed (profiles/r02_pmc_hbm_traffic.json)
+    const int tiles = gridDim.x * gridDim.y, nblk = tiles * (int)gridDim.z;
+    const int w = (blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x, xcd = w & 7, slot = w >> 3;
+    const int q8 = nblk >> 3, r8 = nblk & 7;
+    const int idx = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + slot;
+    z = idx / tiles;
+    const int tile = idx - z * tiles;
+    tile_n = tile % (int)gridDim.x; tile_m = tile / (int)gridDim.x;
   }
   const int n0 = tile_n * BN;
   const int m0 = tile_m * BM;
@@ -949,7 +961,13 @@ int launch_k(eegldm_ctx* ctx, const GemmArgs& a_in) {
   dim3 grid((a.N + BN - 1) / BN, (a.M + C::BM - 1) / C::BM, a.batch * a.ztaps * a.splitk);
   a.xcd_swizzle = 0;
   if (a_in.xcd_swizzle) {
-    if (AMODE == GA_TR && a.splitk > 1) { if (a.batch * a.ztaps == 1 && a.splitk % 8 == 0 && grid.x * grid.y > 1) a.xcd_swizzle = 2; }
+    if (AMODE == GA_TR && a.splitk > 1) {
+      static const bool no_any = getenv("EEGLDM_GEMM_NO_SPLITK_SWIZZLE_ANY") != nullptr;
+      if (a.batch * a.ztaps == 1 && grid.x * grid.y > 1) {
+        if (a.k_skew == 0.f && !no_any) a.xcd_swizzle = 3;          // equal chunks: contiguous runs, any split count
+        else if (a.splitk % 8 == 0) a.xcd_swizzle = 2;             // skewed chunks: interleave the splits over the XCDs (mixes chunk lengths)
+      }
+    }
     else if (grid.x > 1 && grid.y % 8 == 0) a.xcd_swizzle = 1;
   }
 #ifdef EEG_STAGE_TIMING
