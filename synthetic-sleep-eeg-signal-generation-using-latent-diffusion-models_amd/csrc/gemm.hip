@@ -237,8 +237,12 @@ void gemm_kernel(const GemmArgs p) {   // >= 2 waves per SIMD: <= 256 VGPR+AGPR
     const int w = (blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x, xcd = w & 7, slot = w >> 3;
     const int q8 = nblk >> 3, r8 = nblk & 7;
     const int idx = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + slot;
-    z = idx / tiles;
-    const int tile = idx - z * tiles;
+    // idx = (split, tap, tile) with the split slowest: the taps of a wgrad-by-tap launch (stride-2 convs) read the same dY rows and
+    // overlapping X rows as well
+    const int per_split = tiles * p.ztaps;
+    const int sp = idx / per_split, rem = idx - sp * per_split;
+    const int tap = rem / tiles, tile = rem - tap * tiles;
+    z = sp + p.splitk * tap;
     tile_n = tile % (int)gridDim.x; tile_m = tile / (int)gridDim.x;
   }
   const int n0 = tile_n * BN;
@@ -963,7 +967,8 @@ int launch_k(eegldm_ctx* ctx, const GemmArgs& a_in) {
   if (a_in.xcd_swizzle) {
     if (AMODE == GA_TR && a.splitk > 1) {
       static const bool no_any = getenv("EEGLDM_GEMM_NO_SPLITK_SWIZZLE_ANY") != nullptr;
-      if (a.batch * a.ztaps == 1 && grid.x * grid.y > 1) {
+      if (a.batch == 1 && a.k_skew == 0.f && !no_any && (long)grid.x * grid.y * a.ztaps > 1) a.xcd_swizzle = 3;   // (also wgrad-by-tap: ztaps = 3)
+      else if (a.batch * a.ztaps == 1 && grid.x * grid.y > 1) {
         if (a.k_skew == 0.f && !no_any) a.xcd_swizzle = 3;          // equal chunks: contiguous runs, any split count
         else if (a.splitk % 8 == 0) a.xcd_swizzle = 2;             // skewed chunks: interleave the splits over the XCDs (mixes chunk lengths)
       }
