@@ -221,6 +221,58 @@ __global__ __launch_bounds__(NT) void dconv_thin_in_reg_kernel(const DArgs a) {
     *(RowVec<T, G>*)((T*)a.out + (long)r * a.ldout + o0) = ov;
   }
 }
+// Single-channel input (the discriminator's first layer 1 -> 64, stride 2, on 3072-sample windows; stride-1 forward; and the
+// stride-1 dgrad of a conv with ONE output channel, the discriminator's last layer, whose gradient input has one channel):
+// one block = SEG consecutive output rows of ONE sample.  The input samples the segment needs (<= SEG * stride + 2) are staged once in
+// LDS as fp32; the row loop then has no division, no global load and no dependent address arithmetic -- the generic register kernel
+// above spent its time in a per-row chain of (r / Lo, three 2-byte global loads, wait) and reached 1.1 TB/s on the 50 MB output.
+template <typename T, int SEG>
+__global__ __launch_bounds__(NT) void dconv_in1_seg_kernel(const DArgs a) {
+  constexpr int G = 16 / sizeof(T);
+  __shared__ float xs[SEG * 2 + 8];
+  const int gpr = a.Co / G, tx = threadIdx.x % gpr, ty = threadIdx.x / gpr, rpb = NT / gpr, o0 = tx * G;
+  const int b = blockIdx.y, l0 = blockIdx.x * SEG;
+  const int nseg = min(SEG, a.Lo - l0);
+  // input positions v0 .. v0 + nin - 1; tap t of output row l reads xs[l * sm + toff[t]]  (dgrad, stride 1: position l + pad_l - t)
+  const bool dg = a.dgrad != 0;
+  const int v0 = dg ? l0 + a.pad_l - (a.K - 1) : l0 * a.stride - a.pad_l, nin = (nseg - 1) * a.stride + a.K;
+  const int sm = a.stride;
+  int toff[3];
+#pragma unroll
+  for (int t = 0; t < 3; t++) toff[t] = t < a.K ? (dg ? a.K - 1 - t : t) : 0;
+  const T* xin = (const T*)a.in + (long)b * a.Li * a.ldin;
+  for (int i = threadIdx.x; i < SEG * 2 + 8; i += NT) { const int v = v0 + i; xs[i] = (i < nin && v >= 0 && v < a.Li) ? ld_f32(xin + (long)v * a.ldin) : 0.f; }   // (zeros behind the segment: a K < 3 conv multiplies them by zero weights)
+  float w[3][G], bias[G];
+#pragma unroll
+  for (int t = 0; t < 3; t++)
+#pragma unroll
+    for (int k = 0; k < G; k++) w[t][k] = t < a.K ? wsel<T>(a, t, o0 + k, 0) : 0.f;
+#pragma unroll
+  for (int k = 0; k < G; k++) bias[k] = a.bias ? a.bias[o0 + k] : 0.f;
+  __syncthreads();
+  T* out = (T*)a.out + ((long)b * a.Lo + l0) * a.ldout + o0;
+  const T* res = a.resid ? (const T*)a.resid + ((long)b * a.Lo + l0) * a.ldr + o0 : nullptr;
+#pragma unroll 4
+  for (int l = ty; l < nseg; l += rpb) {
+    const float x0 = xs[l * sm + toff[0]], x1 = xs[l * sm + toff[1]], x2 = xs[l * sm + toff[2]];
+    float acc[G];
+#pragma unroll
+    for (int k = 0; k < G; k++) acc[k] = fmaf(x2, w[2][k], fmaf(x1, w[1][k], fmaf(x0, w[0][k], bias[k])));
+    if (res) {
+      const RowVec<T, G> rr = *(const RowVec<T, G>*)(res + (long)l * a.ldr);
+#pragma unroll
+      for (int k = 0; k < G; k++) acc[k] += ld_f32(&rr.v[k]);
+    }
+    if (a.act_slope > 0.f) {
+#pragma unroll
+      for (int k = 0; k < G; k++) acc[k] = acc[k] > 0.f ? acc[k] : acc[k] * a.act_slope;
+    }
+    RowVec<T, G> ov;
+#pragma unroll
+    for (int k = 0; k < G; k++) st_f32(&ov.v[k], acc[k]);
+    *(RowVec<T, G>*)(out + (long)l * a.ldout) = ov;
+  }
+}
 // wide input (Ci % G == 0, Ci/G a power of two <= 64), thin output (Co <= 8): Ci/G lanes per row, shuffle reduction
 template <typename T>
 __global__ __launch_bounds__(NT) void dconv_thin_out_kernel(const DArgs a) {
@@ -647,6 +699,15 @@ int dconv_run(eegldm_ctx* ctx, int dtype, bool dgrad, const void* in, long ldin,
       const dim3 g(grid_cap((total + NT - 1) / NT, ctx));
       static const bool reg_ok = getenv("EEGLDM_DCONV_NO_REG") == nullptr;
       const int gpr = a.Co / G;
+      static const bool seg_ok = getenv("EEGLDM_DCONV_NO_IN1_SEG") == nullptr;
+      if (seg_ok && a.Ci == 1 && K <= 3 && (dgrad ? stride == 1 : stride <= 2) && gpr <= NT && NT % gpr == 0 && a.Lo >= 64 && a.B <= 65535) {
+        constexpr int SEG = 128;
+        const dim3 gs((a.Lo + SEG - 1) / SEG, a.B);
+        if (dtype == EEGLDM_F32) hipLaunchKernelGGL((dconv_in1_seg_kernel<float, SEG>), gs, dim3(NT), 0, ctx->stream, a);
+        else hipLaunchKernelGGL((dconv_in1_seg_kernel<bf16_t, SEG>), gs, dim3(NT), 0, ctx->stream, a);
+        LAUNCH_CHECK();
+        return 0;
+      }
       if (reg_ok && a.Ci <= 4 && gpr <= NT && NT % gpr == 0 && rows < (1L << 30)) {
 #define DTI(T_, CI_) hipLaunchKernelGGL((dconv_thin_in_reg_kernel<T_, CI_>), g, dim3(NT), 0, ctx->stream, a)
 #define DTI_T(T_) do { if (a.Ci == 1) DTI(T_, 1); else if (a.Ci == 2) DTI(T_, 2); else DTI(T_, 4); } while (0)
