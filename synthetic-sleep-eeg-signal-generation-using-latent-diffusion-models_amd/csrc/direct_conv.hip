@@ -340,15 +340,18 @@ __global__ __launch_bounds__(NT) void dconv_thin_out_run_kernel(const DArgs a) {
   for (long g = (long)blockIdx.x * gpb + threadIdx.x / lpr; g < nruns + gpb; g += (long)gridDim.x * gpb) {   // uniform trip count for the shuffles
     const bool ok = g < nruns;
     const long gc = ok ? g : nruns - 1;
-    const int b = (int)(gc / rps), l0 = (int)(gc - (long)b * rps) * R;
+    const int b = (int)((unsigned)gc / (unsigned)rps), l0 = ((int)gc - b * rps) * R;     // (the launcher keeps nruns < 2^31)
     float acc[R];
 #pragma unroll
     for (int i = 0; i < R; i++) acc[i] = 0.f;
+    // all R + 2 row loads are issued unconditionally (clamped row index): predicated loads made hipcc wait for each one separately,
+    // a chain of ten L2 / HBM round trips per run (63 us for the discriminator's 512 -> 1 layer = 0.8 TB/s on a 50 MB input)
     RowVec<T, G> rv[R + 2];
+    const T* xb = (const T*)a.in + (long)b * a.Li * a.ldin + lane * G;
 #pragma unroll
     for (int j = 0; j < R + 2; j++) {
-      const int v = l0 - a.pad_l + j;
-      if (j < R + a.K - 1 && v >= 0 && v < a.Li) rv[j] = *(const RowVec<T, G>*)((const T*)a.in + ((long)b * a.Li + v) * a.ldin + lane * G);
+      const int v = l0 - a.pad_l + j, vc = v < 0 ? 0 : (v >= a.Li ? a.Li - 1 : v);
+      rv[j] = *(const RowVec<T, G>*)(xb + (long)vc * a.ldin);
     }
 #pragma unroll
     for (int j = 0; j < R + 2; j++) {
@@ -368,6 +371,25 @@ __global__ __launch_bounds__(NT) void dconv_thin_out_run_kernel(const DArgs a) {
         }
       }
     }
+    if (R == 8 && lpr == 64) {
+      // eight sums over the 64 lanes of the wave with 10 shuffles instead of 48: each halving step trades half of the values with the
+      // partner lane (bit 5, 4, 3 of the lane select rows 4.., 2.., 1..), then three single-value steps over the remaining 8 lanes
+      float h4[4], h2[2], h1;
+      const bool b5 = lane & 32, b4 = lane & 16, b3 = lane & 8;
+#pragma unroll
+      for (int i = 0; i < 4; i++) { const float keep = b5 ? acc[4 + i] : acc[i], send = b5 ? acc[i] : acc[4 + i]; h4[i] = keep + __shfl_xor(send, 32, 64); }
+#pragma unroll
+      for (int i = 0; i < 2; i++) { const float keep = b4 ? h4[2 + i] : h4[i], send = b4 ? h4[i] : h4[2 + i]; h2[i] = keep + __shfl_xor(send, 16, 64); }
+      { const float keep = b3 ? h2[1] : h2[0], send = b3 ? h2[0] : h2[1]; h1 = keep + __shfl_xor(send, 8, 64); }
+      h1 += __shfl_xor(h1, 4, 64); h1 += __shfl_xor(h1, 2, 64); h1 += __shfl_xor(h1, 1, 64);
+      if ((lane & 7) == 0 && ok) {
+        const int i = (b5 ? 4 : 0) + (b4 ? 2 : 0) + (b3 ? 1 : 0);
+        const long r = (long)b * a.Lo + l0 + i;
+        float sres = h1 + bias;
+        if (a.resid) sres += ld_f32((const T*)a.resid + r * a.ldr);
+        st_f32((T*)a.out + r * a.ldout, sres);
+      }
+    } else {
 #pragma unroll
     for (int i = 0; i < R; i++)
       for (int d = lpr >> 1; d > 0; d >>= 1) acc[i] += __shfl_xor(acc[i], d, 64);
@@ -380,6 +402,51 @@ __global__ __launch_bounds__(NT) void dconv_thin_out_run_kernel(const DArgs a) {
         st_f32((T*)a.out + r * a.ldout, sres);
       }
     }
+    }
+  }
+}
+// Weight gradient of a (wide Cin) -> ONE output channel conv, stride 1 (the discriminator's last layer, 512 -> 1 at 192 rows per sample):
+// a few blocks per sample (segr rows each); the sample's dy (one value per row) sits zero-padded in LDS, every x row is read ONCE and feeds all taps
+// (dW[t][ci] += x[v][ci] * dy[v - t + pad_l]) -- the generic kernel above reads each x row once per tap (3 x 50 MB through the L2).
+template <typename T>
+__global__ __launch_bounds__(NT) void dconv_wgrad_in1out_kernel(const T* __restrict__ x, long ldx, const T* __restrict__ dy, long lddy,
+                                                                float* __restrict__ parts, int Lo, int Cin, int K, int pad_l, int segr) {
+  constexpr int G = 16 / sizeof(T);
+  constexpr int MAXL = 1024;
+  __shared__ float dys[MAXL + 4];
+  __shared__ float red[3 * G][NT];
+  const int lpr = Cin / G, lane = threadIdx.x % lpr, rpb = NT / lpr, rl = threadIdx.x / lpr;
+  const int b = blockIdx.x, v_lo = blockIdx.y * segr, v_hi = min(Lo, v_lo + segr);      // this block's x rows of sample b
+  for (int i = threadIdx.x; i < Lo + 4; i += NT) { const int l = i - 2; dys[i] = (l >= 0 && l < Lo) ? ld_f32(dy + ((long)b * Lo + l) * lddy) : 0.f; }
+  __syncthreads();
+  float acc[3][G];
+#pragma unroll
+  for (int t = 0; t < 3; t++)
+#pragma unroll
+    for (int k = 0; k < G; k++) acc[t][k] = 0.f;
+  const T* xb = x + (long)b * Lo * ldx + lane * G;
+#pragma unroll 8
+  for (int v = v_lo + rl; v < v_hi; v += rpb) {
+    const RowVec<T, G> xv = *(const RowVec<T, G>*)(xb + (long)v * ldx);
+    float d[3];
+#pragma unroll
+    for (int t = 0; t < 3; t++) d[t] = t < K ? dys[v - t + pad_l + 2] : 0.f;
+#pragma unroll
+    for (int k = 0; k < G; k++) { const float xf = ld_f32(&xv.v[k]);
+#pragma unroll
+      for (int t = 0; t < 3; t++) acc[t][k] = fmaf(xf, d[t], acc[t][k]); }
+  }
+#pragma unroll
+  for (int t = 0; t < 3; t++)
+#pragma unroll
+    for (int k = 0; k < G; k++) red[t * G + k][threadIdx.x] = acc[t][k];
+  __syncthreads();
+  for (int o = threadIdx.x; o < 3 * G * lpr; o += NT) {
+    const int pl = o / lpr, ln = o - pl * lpr, t = pl / G, k = pl % G;
+    if (t >= K) continue;
+    float sum = 0.f;
+    for (int q = 0; q < rpb; q++) sum += red[pl][q * lpr + ln];
+    parts[((long)b * gridDim.y + blockIdx.y) * ((long)K * Cin) + (long)t * Cin + ln * G + k] = sum;      // [block][t][co = 0][ci]
   }
 }
 // weight gradient of a (thin <= 2) x (wide % G == 0) conv: dW[t][co][ci] += sum_r dy[r][co] * x[in_row(r,t)][ci].
@@ -389,7 +456,7 @@ __global__ __launch_bounds__(NT) void dconv_wgrad_wt_kernel(const T* __restrict_
                                                             float* __restrict__ dw, float* __restrict__ parts, int B, int Lo, int Li, int Cout, int Cin, int K,
                                                             int stride, int pad_l) {
   constexpr int G = 16 / sizeof(T);
-  __shared__ float red[NT];
+  __shared__ float red[3 * 2 * G][NT];       // every accumulator plane of the block at once: ONE barrier in the epilogue (it was 48)
   const int wide = WIDE_OUT ? Cout : Cin, thin = WIDE_OUT ? Cin : Cout;
   const int lpr = wide / G, lane = threadIdx.x % lpr, rpb = NT / lpr, rl = threadIdx.x / lpr;
   float acc[3][2][G];
@@ -399,67 +466,75 @@ __global__ __launch_bounds__(NT) void dconv_wgrad_wt_kernel(const T* __restrict_
     for (int j = 0; j < 2; j++)
 #pragma unroll
       for (int k = 0; k < G; k++) acc[t][j][k] = 0.f;
-  const long rows = (long)B * Lo;
-#pragma unroll 4
-  for (long r = (long)blockIdx.x * rpb + rl; r < rows; r += (long)gridDim.x * rpb) {
-    const int b = (int)(r / Lo), lo = (int)(r - (long)b * Lo);
+  const int rows = B * Lo;                    // (the launcher keeps B * Lo < 2^31: 32-bit index arithmetic in the row loop)
+  // loads are unconditional (clamped row, zero factor for taps outside the sample): predicated loads are waited for one by one
+#pragma unroll 2
+  for (int r = blockIdx.x * rpb + rl; r < rows; r += gridDim.x * rpb) {
+    const int b = (int)((unsigned)r / (unsigned)Lo), lo = r - b * Lo;
     if (WIDE_OUT) {
-      const RowVec<T, G> dv = *(const RowVec<T, G>*)(dy + r * lddy + lane * G);
+      const RowVec<T, G> dv = *(const RowVec<T, G>*)(dy + (long)r * lddy + lane * G);
+      float xv[3][2];
+#pragma unroll
+      for (int t = 0; t < 3; t++) {
+        const int v = lo * stride + t - pad_l;
+        const bool ok = t < K && v >= 0 && v < Li;
+        const T* xr = x + ((long)b * Li + (ok ? v : 0)) * ldx;
+#pragma unroll
+        for (int j = 0; j < 2; j++) xv[t][j] = (j < thin) ? (ok ? ld_f32(xr + j) : 0.f) : 0.f;
+      }
       float d[G];
 #pragma unroll
       for (int k = 0; k < G; k++) d[k] = ld_f32(&dv.v[k]);
 #pragma unroll
-      for (int t = 0; t < 3; t++) {
-        const int v = lo * stride + t - pad_l;
-        if (t < K && v >= 0 && v < Li) {
-          const T* xr = x + ((long)b * Li + v) * ldx;
+      for (int t = 0; t < 3; t++)
 #pragma unroll
-          for (int j = 0; j < 2; j++) {
-            if (j < thin) { const float xv = ld_f32(xr + j);
+        for (int j = 0; j < 2; j++) {
+          if (j < thin) {
 #pragma unroll
-              for (int k = 0; k < G; k++) acc[t][j][k] += d[k] * xv; }
+            for (int k = 0; k < G; k++) acc[t][j][k] = fmaf(d[k], xv[t][j], acc[t][j][k]);
           }
         }
-      }
     } else {
-      float d[2];
-#pragma unroll
-      for (int j = 0; j < 2; j++) d[j] = j < thin ? ld_f32(dy + r * lddy + j) : 0.f;
+      RowVec<T, G> xvv[3]; float f[3];
 #pragma unroll
       for (int t = 0; t < 3; t++) {
         const int v = lo * stride + t - pad_l;
-        if (t < K && v >= 0 && v < Li) {
-          const RowVec<T, G> xvv = *(const RowVec<T, G>*)(x + ((long)b * Li + v) * ldx + lane * G);
-#pragma unroll
-          for (int k = 0; k < G; k++) { const float xv = ld_f32(&xvv.v[k]);
-#pragma unroll
-            for (int j = 0; j < 2; j++) acc[t][j][k] += d[j] * xv; }
-        }
+        const bool ok = t < K && v >= 0 && v < Li;
+        f[t] = ok ? 1.f : 0.f;
+        xvv[t] = *(const RowVec<T, G>*)(x + ((long)b * Li + (ok ? v : 0)) * ldx + lane * G);
       }
+      float d[2];
+#pragma unroll
+      for (int j = 0; j < 2; j++) d[j] = j < thin ? ld_f32(dy + (long)r * lddy + j) : 0.f;
+#pragma unroll
+      for (int t = 0; t < 3; t++)
+#pragma unroll
+        for (int k = 0; k < G; k++) { const float xv = ld_f32(&xvv[t].v[k]) * f[t];
+#pragma unroll
+          for (int j = 0; j < 2; j++) acc[t][j][k] = fmaf(d[j], xv, acc[t][j][k]); }
     }
   }
-  // reduce over the rpb row lanes of the block: one (t, j, k) plane at a time through LDS, then one atomic per element
+  // reduce over the rpb row lanes of the block: all planes go to LDS, one barrier, then (plane, channel group) threads sum their column
 #pragma unroll
   for (int t = 0; t < 3; t++)
 #pragma unroll
     for (int j = 0; j < 2; j++)
 #pragma unroll
-      for (int k = 0; k < G; k++) {
-        if (t >= K || j >= thin) continue;
-        __syncthreads();
-        red[threadIdx.x] = acc[t][j][k];
-        __syncthreads();
-        if (rl == 0) {
-          float s = 0.f;
-          for (int q = 0; q < rpb; q++) s += red[q * lpr + lane];
-          const int wch = lane * G + k;
-          const int co = WIDE_OUT ? wch : j, ci = WIDE_OUT ? j : wch;
-          // written partial per block + a folding pass (hundreds of blocks adding atomically into the same few hundred
-          // addresses serialise in L2); plain atomics only when no workspace was given
-          const long e = ((long)t * Cout + co) * Cin + ci;
-          if (parts) parts[(long)blockIdx.x * ((long)K * Cout * Cin) + e] = s; else atomicAdd(dw + e, s);
-        }
-      }
+      for (int k = 0; k < G; k++) red[(t * 2 + j) * G + k][threadIdx.x] = acc[t][j][k];
+  __syncthreads();
+  for (int o = threadIdx.x; o < 3 * 2 * G * lpr; o += NT) {
+    const int pl = o / lpr, ln = o - pl * lpr;
+    const int t = pl / (2 * G), j = (pl / G) % 2, k = pl % G;
+    if (t >= K || j >= thin) continue;
+    float sum = 0.f;
+    for (int q = 0; q < rpb; q++) sum += red[pl][q * lpr + ln];
+    const int wch = ln * G + k;
+    const int co = WIDE_OUT ? wch : j, ci = WIDE_OUT ? j : wch;
+    // written partial per block + a folding pass (hundreds of blocks adding atomically into the same few hundred
+    // addresses serialise in L2); plain atomics only when no workspace was given
+    const long e = ((long)t * Cout + co) * Cin + ci;
+    if (parts) parts[(long)blockIdx.x * ((long)K * Cout * Cin) + e] = sum; else atomicAdd(dw + e, sum);
+  }
 }
 
 // wave per row, lanes over the (wide) input channels, <= 8 output channels
@@ -728,7 +803,7 @@ int dconv_run(eegldm_ctx* ctx, int dtype, bool dgrad, const void* in, long ldin,
       const int rpb = NT / lpr;
       static const bool run_ok = getenv("EEGLDM_DCONV_NO_RUN") == nullptr;
       constexpr int RUN = 8;
-      if (run_ok && !dgrad && a.Co == 1 && stride == 1 && K <= 3 && a.Lo % RUN == 0 && a.Li == a.Lo && pad_l <= K - 1) {
+      if (run_ok && !dgrad && a.Co == 1 && stride == 1 && K <= 3 && a.Lo % RUN == 0 && a.Li == a.Lo && pad_l <= K - 1 && rows < (1L << 31)) {
         const long nruns = rows / RUN;
         const dim3 gr(grid_cap((nruns + rpb - 1) / rpb, ctx));
         if (dtype == EEGLDM_F32) hipLaunchKernelGGL((dconv_thin_out_run_kernel<float, RUN>), gr, dim3(NT), 0, ctx->stream, a);
@@ -799,11 +874,22 @@ int dconv_wgrad(eegldm_ctx* ctx, int dtype, const void* x, long ldx, const void*
     const bool wide_out = Cin <= 2 && Cout % G == 0 && Cout >= 16 && lddy % G == 0;
     const bool wide_in = Cout <= 2 && Cin % G == 0 && Cin >= 16 && ldx % G == 0;
     const int wide = wide_out ? Cout : Cin, lpr = wide / G;
-    if ((wide_out || wide_in) && K <= 3 && lpr <= NT && NT % lpr == 0) {
+    if ((wide_out || wide_in) && K <= 3 && lpr <= NT && NT % lpr == 0 && rows < (1L << 31)) {
       const int rpb = NT / lpr;
       // few blocks: every block ends with one atomic per weight element on the SAME addresses (2048 blocks cost 460 us in atomics)
       const long E = (long)K * Cout * Cin;
-      long nb = (rows + rpb - 1) / rpb; const long capb = (long)ctx->num_cu * 8; if (nb > capb) nb = capb;
+      static const bool in1out_ok = getenv("EEGLDM_DCONV_NO_WGRAD_IN1OUT") == nullptr;
+      // blocks per sample: enough blocks to fill the chip four times over (each thread then has <= 8-16 independent row loads in flight)
+      int nsegs = (int)((4L * ctx->num_cu + B - 1) / B); if (nsegs < 1) nsegs = 1;
+      int segr = (Lout + nsegs - 1) / nsegs; segr = (segr + rpb - 1) / rpb * rpb; nsegs = (Lout + segr - 1) / segr;
+      if (in1out_ok && wide_in && Cout == 1 && stride == 1 && Lin == Lout && Lout <= 1024 && pad_l <= 2 && K - 1 - pad_l <= 2 && dtype != EEGLDM_F32 && B <= 65535 &&
+          (size_t)B * nsegs * K * Cin * sizeof(float) <= (16u << 20)) {
+        float* parts1 = (float*)((char*)ctx->scratch + (8u << 20));
+        hipLaunchKernelGGL((dconv_wgrad_in1out_kernel<bf16_t>), dim3(B, nsegs), dim3(NT), 0, ctx->stream, (const bf16_t*)x, ldx, (const bf16_t*)dy, lddy, parts1, Lout, Cin, K, pad_l, segr);
+        LAUNCH_CHECK();
+        return ew_fold_partials(ctx, parts1, B * nsegs, (int)((long)K * Cin), dw);
+      }
+      long nb = (rows + rpb - 1) / rpb; const long capb = (long)ctx->num_cu * 4; if (nb > capb) nb = capb;   // 48 KB of LDS per block: 3 per CU
       float* parts = ((size_t)nb * E * sizeof(float) <= (16u << 20)) ? (float*)((char*)ctx->scratch + (8u << 20)) : nullptr;
       if (!parts) { const long cap2 = (long)ctx->num_cu * 2; if (nb > cap2) nb = cap2; }
 #define DWT(T_, WO_) hipLaunchKernelGGL((dconv_wgrad_wt_kernel<T_, WO_>), dim3((unsigned)nb), dim3(NT), 0, ctx->stream, (const T_*)x, ldx, (const T_*)dy, lddy, \
