@@ -544,6 +544,18 @@ __global__ __launch_bounds__(NTB) void gn_bwd_resident_kernel(const T* __restric
 #pragma unroll
     for (int j = 0; j < 4; j++) { atomicAdd(&redc[m.tx * 4 + j], (double)dg[j]); atomicAdd(&redc[RES_MAXC + m.tx * 4 + j], (double)db[j]); }
   }
+  // the residual-path addend(s) of dx are fetched HERE, packed and unconditionally (clamped row), so their round trip runs under the
+  // two barriers and the group-sum phase: loaded inside pass 2 they were twelve load-wait-use chains per thread (the first GroupNorm of
+  // every ResBlock has such an addend: those launches took ~70 us against 45 us without)
+  typename Vec<T, 4>::type er[RAW0 ? RPT : 1];      // (the rarer second addend stays an in-loop load: both arrays spill at 12 rows per thread)
+  if constexpr (RAW0) {
+    if (m.act && dxr) {
+      const char* q = (const char*)(dxr + (long)b * L * lddxr);
+      const unsigned ldb = (unsigned)lddxr * (unsigned)sizeof(T);
+#pragma unroll
+      for (int k = 0; k < RPT; k++) { const int l = k * m.TY + m.ty, lc = l < L ? l : L - 1; er[k] = *(const typename Vec<T, 4>::type*)(q + ((unsigned)lc * ldb + cb)); }
+    }
+  }
   __syncthreads();
   if (m.act && m.ty == 0) {
     double p1 = 0.0, p2 = 0.0;
@@ -585,7 +597,7 @@ __global__ __launch_bounds__(NTB) void gn_bwd_resident_kernel(const T* __restric
         }
         if (dxr) {
           float e[4];
-          load_dy_eff32<T>(dxrs, lddxrb, cb, l, resample, e);
+          if constexpr (RAW0) unpack4<T>(er[k], e); else load_dy_eff32<T>(dxrs, lddxrb, cb, l, resample, e);
 #pragma unroll
           for (int j = 0; j < 4; j++) o[j] += e[j];
         }
