@@ -283,7 +283,8 @@ def main():
     roofline = None
     if rank == 0 and not args.no_roofline:
         ctx.prof_enable(True)
-        for i in range(2):
+        ROOF_STEPS = 6      # 252 launches of the dominant class: two steps were too few to average out a transient (one run read 650 TF/s where the
+        for i in range(ROOF_STEPS):      # rocprof trace of the same box gave 760)
             step(args.warmup + args.steps + i, sync=False)
         torch.cuda.synchronize()
         summ = ctx.prof_summary()
@@ -311,10 +312,10 @@ def main():
                     break
         roofline = {"bound": "mfma", "kernel": k, "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4),
                     "traffic": traffic, "traffic_source": traffic_src, "traffic_stale": traffic_stale, "mfma_busy_pct_pmc": mfma_util,
-                    "event_bracket_overhead_us_subtracted": round(ctx.prof_bracket_overhead_us(), 2), "launches_per_step": v["launches"] // 2, "avg_launch_us": round(1e3 * v["ms"] / max(1, v["launches"]), 2),
+                    "event_bracket_overhead_us_subtracted": round(ctx.prof_bracket_overhead_us(), 2), "launches_per_step": v["launches"] // ROOF_STEPS, "steps_measured": ROOF_STEPS, "avg_launch_us": round(1e3 * v["ms"] / max(1, v["launches"]), 2),
                     "gflop_per_launch": round(v["flops"] / max(1, v["launches"]) / 1e9, 3),
                     "all_gemm_classes": {kk: {"tflops": round(vv["flops"] / (vv["ms"] * 1e-3) / 1e12, 1) if vv["ms"] > 0 else 0.0,
-                                              "ms_per_step": round(vv["ms"] / 2, 3), "launches_per_step": vv["launches"] // 2}
+                                              "ms_per_step": round(vv["ms"] / ROOF_STEPS, 3), "launches_per_step": vv["launches"] // ROOF_STEPS}
                                          for kk, vv in summ.items() if vv["launches"]}}
 
     # ---- secondary workloads (rank 0 only; not part of `value`)
