@@ -1,4 +1,4 @@
-# Builds libeegldm.so (HIP, gfx950 only) and the oracle's C helpers.
+# Builds libeegldm.so (HIP, gfx950 only).  The oracle is pure Python (torch CPU / numpy): nothing to compile under oracle/.
 PKG   := synthetic-sleep-eeg-signal-generation-using-latent-diffusion-models_amd
 CSRC  := $(PKG)/csrc
 HIPCC ?= /opt/rocm/bin/hipcc

@@ -58,6 +58,8 @@ const char* eegldm_last_error(void);
  * device's default stream, which is what torch uses unless told otherwise).
  * own_stream != 0: ignore hip_stream and create a private non-blocking stream. */
 int eegldm_ctx_create(int hip_device, void* hip_stream, int own_stream, eegldm_ctx** out);
+/* The stream the context enqueues on: `hip_stream` as given, or the library's own non-blocking stream when own_stream != 0. */
+void* eegldm_ctx_stream(const eegldm_ctx*);
 int eegldm_ctx_destroy(eegldm_ctx* ctx);
 int eegldm_ctx_sync(eegldm_ctx* ctx);
 /* HIP-event timing on the context's stream (bench.py measures kernels with these, since
@@ -116,6 +118,10 @@ int eegldm_conv1d_bwd_weight(eegldm_ctx*, const void* x, long ldx, const void* d
 /* nn.Linear (unet.py:373-377, 277-285): y[M][N] = x[M][K] w[N][K]^T + bias; y is fp32 when out_f32 */
 int eegldm_linear_fwd(eegldm_ctx*, const void* x, long ldx, const void* w, const float* bias, void* y, long ldy,
                       int M, int N, int K, int dtype, int out_f32);
+/* its backward (what autograd derives for nn.Linear): dx[M][K] = dy[M][N] w[N][K] (skipped when dx is NULL; fp32 when dx_f32),
+ * dw[N][K] += dy^T x and dbias[N] += column sums of dy (fp32 accumulators; either may be NULL) */
+int eegldm_linear_bwd(eegldm_ctx*, const void* x, long ldx, const void* w, const void* dy, long lddy, void* dx, long lddx,
+                      float* dw, float* dbias, int M, int N, int K, int dtype, int dx_f32);
 
 /* nn.GroupNorm(G, C, eps) [+ SiLU] (unet.py:71-74; MONAI norm_num_groups, eps 1e-6).
  * stats: [B][G][2] fp32 (mean, rstd), written by fwd and consumed by bwd.
@@ -317,6 +323,10 @@ int eegldm_disc_bind(eegldm_disc*, float* params, float* grads, float* buffers);
 int eegldm_disc_sync_weights(eegldm_disc*);
 /* training != 0: batch statistics + running-stat update (momentum 0.1); else running statistics */
 int eegldm_disc_forward(eegldm_disc*, const float* x, float* logits, int B, int L, int training);
+/* MONAI PatchDiscriminator.forward returns the list of per-block feature maps (callers index [-1] = the logits,
+ * train_autoencoderkl.py:213).  Feature `index` (0 = initial conv + LeakyReLU, then one per conv + BatchNorm + LeakyReLU layer)
+ * of the most recent forward, copied out as fp32 (B, C, L); out == NULL only reports *C / *L. */
+int eegldm_disc_feature(eegldm_disc*, int index, float* out, int* C, int* L);
 /* param_grads != 0: grads += d/dparams; dx (nullable) = d/dx */
 int eegldm_disc_backward(eegldm_disc*, const float* dlogits, float* dx, int param_grads);
 

@@ -29,6 +29,8 @@ def _load():
 
 lib = _load()
 lib.eegldm_last_error.restype = C.c_char_p
+if hasattr(lib, "eegldm_ctx_stream"):
+    lib.eegldm_ctx_stream.restype = C.c_void_p
 if hasattr(lib, 'eegldm_unet_num_params'):
     lib.eegldm_unet_num_params.restype = C.c_long
 
@@ -38,6 +40,7 @@ SIGNATURES = {
     "eegldm_abi_version": [],
     "eegldm_last_error": [],
     "eegldm_ctx_create": [_i, _vp, _i, C.POINTER(_vp)],
+    "eegldm_ctx_stream": [_vp],
     "eegldm_ctx_destroy": [_vp],
     "eegldm_ctx_sync": [_vp],
     "eegldm_timer_start": [_vp],
@@ -65,6 +68,7 @@ SIGNATURES = {
     "eegldm_conv1d_bwd_data": [_vp, _vp, _l, _vp, _vp, _l, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _l, _i],
     "eegldm_conv1d_bwd_weight": [_vp, _vp, _l, _vp, _l, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i],
     "eegldm_linear_fwd": [_vp, _vp, _l, _vp, _vp, _vp, _l, _i, _i, _i, _i, _i],
+    "eegldm_linear_bwd": [_vp, _vp, _l, _vp, _vp, _l, _vp, _l, _vp, _vp, _i, _i, _i, _i, _i],
     "eegldm_groupnorm_fwd": [_vp, _vp, _l, _vp, _vp, _vp, _l, _vp, _i, _i, _i, _i, _f, _i, _i, _vp, _l, _i],
     "eegldm_groupnorm_bwd": [_vp, _vp, _l, _vp, _vp, _vp, _vp, _l, _vp, _l, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _l, _i],
     "eegldm_attention_fwd": [_vp, _vp, _l, _vp, _l, _vp, _vp, _i, _i, _i, _i],
@@ -120,6 +124,7 @@ SIGNATURES = {
     "eegldm_disc_bind": [_vp, _vp, _vp, _vp],
     "eegldm_disc_sync_weights": [_vp],
     "eegldm_disc_forward": [_vp, _vp, _vp, _i, _i, _i],
+    "eegldm_disc_feature": [_vp, _i, _vp, _vp, _vp],
     "eegldm_disc_backward": [_vp, _vp, _vp, _i],
     "eegldm_aekl_train_step": [_vp, _vp, _vp, _vp, _f, _f, _f, _i, _vp, _vp, _i, _i],
 }
@@ -178,7 +183,9 @@ class Context:
         h = C.c_void_p()
         check(lib.eegldm_ctx_create(device, C.c_void_p(stream), 0 if use_torch_stream else 1, C.byref(h)))
         self.h = h
-        self.stream_handle = stream
+        # the REAL stream (with use_torch_stream=False the library made its own; 0 would wrongly look like torch's default stream)
+        self.stream_handle = int(lib.eegldm_ctx_stream(h) or 0)
+        self.owns_stream = not use_torch_stream
 
     def sync(self):
         check(lib.eegldm_ctx_sync(self.h))

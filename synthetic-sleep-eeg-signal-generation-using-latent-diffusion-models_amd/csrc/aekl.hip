@@ -185,6 +185,7 @@ struct eegldm_aekl : SeqNet {
   View h_enc, mu, lv; float *eps_nlc = nullptr, *sigma = nullptr;
   // whole-network path for thin configurations (aekl_thin.hip): program compiled per window length
   ThinProgram thin; int thin_L = -1; bool thin_tape = false; float* thin_eps = nullptr;
+  int thin_fail_L = -1;          // length for which the whole-network program did not fit (LDS footprint): use the general path
   ~eegldm_aekl() { thin_free(&thin); }
 };
 
@@ -346,6 +347,16 @@ int thin_build(eegldm_aekl* a, int L) {
   a->thin_L = L;
   return 0;
 }
+// thin_eligible() bounds the tensors and the parameter count but not the real LDS footprint (four tensors + parameters + the op table,
+// aekl_thin.hip::lds_bytes): a configuration can pass it and still not fit.  That is "not eligible", not an error -- remember the
+// length and let the caller take the layer-by-layer path.
+bool thin_ready(eegldm_aekl* a, int L) {
+  if (!thin_eligible(a, L) || a->thin_fail_L == L) return false;
+  if (a->thin_L == L) return true;
+  if (thin_build(a, L) == 0) return true;
+  a->thin_fail_L = L; a->thin_L = -1;
+  return false;
+}
 }  // namespace
 
 extern "C" int eegldm_aekl_create(eegldm_ctx* ctx, const eegldm_aekl_cfg* cfg, eegldm_aekl** out) {
@@ -471,9 +482,8 @@ extern "C" int eegldm_aekl_decode(eegldm_aekl* a, const float* z, float* recon, 
 extern "C" int eegldm_aekl_forward(eegldm_aekl* a, const float* x, const float* eps, float* recon, float* z_mu, float* z_sigma, float* kl, int B, int L) {
   EEG_CHECK(a && x && recon && a->params, "null argument / unbound parameters");
   a->thin_tape = false;
-  if (thin_eligible(a, L)) {
+  if (thin_ready(a, L)) {
     // whole-network path (aekl_thin.hip): one workgroup per window, two launches per forward + backward instead of ~300
-    if (a->thin_L != L) EEG_TRY(thin_build(a, L));
     ThinProgram& p = a->thin;
     a->arena.reset(); a->rt.clear(); a->tape_enc.clear(); a->tape_dec.clear(); a->have_tape = false;
     a->B = B; a->L = L; a->Ll = p.Ll;
@@ -598,6 +608,24 @@ extern "C" int eegldm_disc_forward(eegldm_disc* d, const float* x, float* logits
   EEG_TRY(d->forward_seq(d->ops, x0, B, Lc, &y, d->tape, training));
   d->B = B; d->L = L; d->Lo = Lc; d->have_tape = true;
   return eegldm_nlc_to_ncl(d->ctx, y.p, y.ld, logits, B, d->cfg.out_channels, Lc, d->dtype);
+}
+// The reference's PatchDiscriminator.forward returns the LIST of feature maps, one per block (initial conv + LeakyReLU, every
+// conv + BatchNorm + LeakyReLU layer, final conv); the trainer indexes [-1] (train_autoencoderkl.py:213).  The maps before the last
+// are the activation ops' outputs, which the tape of the most recent forward still holds: feature `index` (0 .. num_layers_d) is
+// copied out as fp32 (B, C, L); out == NULL only reports the shape.  The last entry of the list is the logits eegldm_disc_forward wrote.
+extern "C" int eegldm_disc_feature(eegldm_disc* d, int index, float* out, int* C, int* L) {
+  EEG_CHECK(d && d->have_tape && d->tape.size() == d->ops.size(), "call eegldm_disc_forward first");
+  int seen = -1;
+  for (size_t i = 0; i + 1 < d->ops.size(); i++) {
+    if (d->ops[i].kind != OP_ACT) continue;
+    if (++seen != index) continue;
+    const OpTape& nx = d->tape[i + 1];                    // the next op's input IS this activation's output
+    if (C) *C = nx.x.C;
+    if (L) *L = nx.Lin;
+    if (out) EEG_TRY(eegldm_nlc_to_ncl(d->ctx, nx.x.p, nx.x.ld, out, d->B, nx.x.C, nx.Lin, d->dtype));
+    return 0;
+  }
+  EEG_FAIL(EEGLDM_ERR_INVALID, "feature index out of range");
 }
 // param_grads != 0: grads += d/dparams; dx (nullable) = d/dx
 static int disc_backward_impl(eegldm_disc* d, const float* dlogits, float* dx, int param_grads, bool keep_tape);

@@ -43,6 +43,9 @@ extern "C" int eegldm_ctx_create(int device, void* stream, int own_stream, eegld
   *out = c;
   return 0;
 }
+// the HIP stream every call on this context enqueues on (the caller's, or the library's own when own_stream was set): what a caller
+// that issues its own collectives / copies must order them against
+extern "C" void* eegldm_ctx_stream(const eegldm_ctx* c) { return c ? (void*)c->stream : nullptr; }
 int ctx_fork(eegldm_ctx* c) {
   if (!c->side_on || c->prof_on) return 0;
   HIP_TRY(hipEventRecord(c->ev_fork, c->stream));

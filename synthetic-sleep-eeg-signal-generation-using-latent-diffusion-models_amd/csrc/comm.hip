@@ -52,6 +52,7 @@ extern "C" int eegldm_comm_unique_id(char* out128) {
   return 0;
 }
 
+extern "C" int eegldm_comm_destroy(eegldm_comm* c);
 extern "C" int eegldm_comm_create(eegldm_ctx* ctx, const char* id128, int rank, int world, eegldm_comm** out) {
   EEG_CHECK(ctx && id128 && out && world >= 1 && rank >= 0 && rank < world, "bad argument (rank %d of %d)", rank, world);
   eegldm_comm* c = new eegldm_comm();
@@ -62,12 +63,19 @@ extern "C" int eegldm_comm_create(eegldm_ctx* ctx, const char* id128, int rank, 
   SYM(CommInitRank, "ncclCommInitRank"); SYM(CommDestroy, "ncclCommDestroy"); SYM(AllReduce, "ncclAllReduce"); SYM(Broadcast, "ncclBroadcast");
   SYM(GroupStart, "ncclGroupStart"); SYM(GroupEnd, "ncclGroupEnd"); SYM(GetErrorString, "ncclGetErrorString");
 #undef SYM
-  HIP_TRY(hipSetDevice(ctx->device));
-  ncclUniqueId id; memcpy(id.internal, id128, NCCL_UNIQUE_ID_BYTES);
-  NCCL_TRY(c, c->CommInitRank(&c->comm, world, id, rank));
-  HIP_TRY(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
-  HIP_TRY(hipEventCreateWithFlags(&c->ev_ready, hipEventDisableTiming));
-  HIP_TRY(hipEventCreateWithFlags(&c->ev_done, hipEventDisableTiming));
+  // from here on a failure must not leak the struct (nor a half-made communicator / stream / events): the *_TRY macros return, so the
+  // fallible part runs in a lambda and eegldm_comm_destroy() -- which tolerates every partially initialised state -- cleans up
+  auto init = [&]() -> int {
+    HIP_TRY(hipSetDevice(ctx->device));
+    ncclUniqueId id; memcpy(id.internal, id128, NCCL_UNIQUE_ID_BYTES);
+    NCCL_TRY(c, c->CommInitRank(&c->comm, world, id, rank));
+    HIP_TRY(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+    HIP_TRY(hipEventCreateWithFlags(&c->ev_ready, hipEventDisableTiming));
+    HIP_TRY(hipEventCreateWithFlags(&c->ev_done, hipEventDisableTiming));
+    return 0;
+  };
+  const int rc = init();
+  if (rc != 0) { (void)eegldm_comm_destroy(c); return rc; }
   *out = c;
   return 0;
 }

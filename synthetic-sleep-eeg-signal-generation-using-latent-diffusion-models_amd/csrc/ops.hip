@@ -243,6 +243,16 @@ extern "C" int eegldm_linear_fwd(eegldm_ctx* ctx, const void* x, long ldx, const
   EEG_CHECK(ctx && x && w && y, "null pointer");
   return op_linear(ctx, dtype, x, ldx, w, K, bias, y, ldy, M, N, K, out_f32);
 }
+// nn.Linear backward (autograd of unet.py:373-377,277-285): dx[M][K] = dy w (optional), dw[N][K] += dy^T x, dbias[N] += column sums of dy
+extern "C" int eegldm_linear_bwd(eegldm_ctx* ctx, const void* x, long ldx, const void* w, const void* dy, long lddy, void* dx, long lddx,
+                                 float* dw, float* dbias, int M, int N, int K, int dtype, int dx_f32) {
+  EEG_CHECK(ctx && dy && (dx || dw || dbias), "null pointer");
+  EEG_CHECK(!dx || w, "dx needs the weights"); EEG_CHECK(!dw || x, "dw needs the input");
+  if (dx) EEG_TRY(op_linear_dgrad(ctx, dtype, dy, lddy, w, K, dx, lddx, M, N, K, dx_f32));
+  if (dw) EEG_TRY(op_linear_wgrad(ctx, dtype, x, ldx, dy, lddy, dw, K, M, N, K));
+  if (dbias) EEG_TRY(ew_colsum(ctx, dy, lddy, nullptr, 0, dbias, 1, M, N, dtype));
+  return 0;
+}
 extern "C" int eegldm_attention_fwd(eegldm_ctx* ctx, const void* qkv, long ldqkv, void* out, long ldo, void* probs, float* scratch_logits,
                                     int B, int T, int C, int dtype) {
   EEG_CHECK(ctx && qkv && out && probs && scratch_logits, "null pointer");

@@ -7,6 +7,7 @@
 // once per (B, L) into a hipGraph (activation arena, timestep buffer and latent buffer have fixed addresses) and the loop
 // replays it: per step one fill of the timestep buffer, one graph launch and one scheduler-step kernel.
 #include <map>
+#include <mutex>
 #include <tuple>
 #include <utility>
 #include <vector>
@@ -22,11 +23,16 @@ struct SamplerState {
   bool capture_failed = false;
 };
 std::map<GraphKey, SamplerState>& states() { static std::map<GraphKey, SamplerState> m; return m; }
+// guards the map AND serialises eegldm_sample: a call swaps ctx->stream for its duration, so two concurrent calls on contexts that
+// share a UNet -- or any other call on the same context from a second thread -- are not supported (one context = one thread,
+// include/eegldm.h); the lock at least keeps the graph cache consistent when independent contexts sample from different threads
+std::recursive_mutex& states_mutex() { static std::recursive_mutex m; return m; }
 
 __global__ void fill_i64_kernel(int64_t* p, int n, int64_t v) { const int i = blockIdx.x * blockDim.x + threadIdx.x; if (i < n) p[i] = v; }
 }  // namespace
 
 void sampler_release(const eegldm_unet* u) {
+  std::lock_guard<std::recursive_mutex> lock(states_mutex());
   auto& m = states();
   for (auto it = m.begin(); it != m.end();) {
     if (it->first.u != u) { ++it; continue; }
@@ -57,6 +63,7 @@ extern "C" int eegldm_sample(eegldm_unet* u, eegldm_aekl* ae, const float* noise
   EEG_CHECK(unet_out_channels(u) == C, "sampling needs in_channels == out_channels");
   EEG_CHECK(!ae || aekl_ctx(ae) == ctx, "the autoencoder and the UNet must share one context");
   const long n = (long)B * C * L;
+  std::lock_guard<std::recursive_mutex> lock(states_mutex());
   SamplerState& s = states()[GraphKey{u, B, L}];
   if (!s.x) {
     HIP_TRY(hipMalloc(&s.x, sizeof(float) * n)); HIP_TRY(hipMalloc(&s.out, sizeof(float) * n)); HIP_TRY(hipMalloc(&s.nz, sizeof(float) * n));

@@ -232,6 +232,9 @@ extern "C" int eegldm_unet_entry(const eegldm_unet* u, int i, char* name, int ca
 }
 extern "C" int eegldm_unet_bind(eegldm_unet* u, float* params, float* grads) {
   EEG_CHECK(u && params, "null argument");
+  // a captured sampling graph (sampler.hip) bakes in the addresses of the bound parameter buffer and of the weight copies derived
+  // from it: re-binding must drop those graphs, or the next eegldm_sample would replay against the old (possibly freed) memory
+  sampler_release(u);
   return u->bind(params, grads);
 }
 extern "C" int eegldm_unet_sync_weights(eegldm_unet* u) {

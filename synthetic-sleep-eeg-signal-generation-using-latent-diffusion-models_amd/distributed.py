@@ -37,6 +37,34 @@ def broadcast_flat(t, src=0):
         dist.broadcast(t, src=src)
 
 
+def _comm_device(like=None):
+    """Device a small control tensor must live on for the initialised backend (nccl = RCCL: the rank's GPU; gloo: CPU)."""
+    if dist.get_backend() == "nccl":
+        return like.device if (like is not None and like.is_cuda) else torch.device("cuda", torch.cuda.current_device())
+    return torch.device("cpu")
+
+
+def broadcast_scalar(value, src=0, like=None):
+    """A Python float that is the SAME on every rank afterwards (rank `src`'s value).  Used for quantities the reference computes
+    once in its single process and that data-parallel replicas must agree on -- the latent `scale_factor = 1 / std(z)` of the first
+    batch (/root/reference/src/train_ldm.py:145-148,203-204): computed per rank from a rank-sharded loader it would differ per
+    replica while only rank 0's value reaches checkpoint.pth."""
+    if not dist.is_initialized() or dist.get_world_size() == 1:
+        return float(value)
+    t = torch.tensor([float(value)], dtype=torch.float64, device=_comm_device(like))
+    dist.broadcast(t, src=src)
+    return float(t.item())
+
+
+def allreduce_sum_scalars(values, like=None):
+    """Element-wise sum over ranks of a short list of Python numbers (validation loss sums / counts)."""
+    if not dist.is_initialized() or dist.get_world_size() == 1:
+        return [float(v) for v in values]
+    t = torch.tensor([float(v) for v in values], dtype=torch.float64, device=_comm_device(like))
+    dist.all_reduce(t, op=dist.ReduceOp.SUM)
+    return [float(v) for v in t.tolist()]
+
+
 def allreduce_mean_flat(t, bucket_elems=BUCKET_ELEMS):
     """In-place mean over ranks of a flat tensor, bucketed; async ops are all issued before the first wait."""
     if not dist.is_initialized() or dist.get_world_size() == 1:
@@ -159,7 +187,9 @@ class OverlappedGradSync:
         if not self.active or numel <= 0:
             return
         # dist.all_reduce orders itself after torch's CURRENT stream; the backward that produced this slice was enqueued on the
-        # context's stream (torch's current stream when the Context was created).  They must be the same stream.
+        # context's stream (torch's current stream when the Context was created).  They must be the same stream.  `stream_handle`
+        # is the stream the library REALLY uses (eegldm_ctx_stream): a Context(use_torch_stream=False) owns a private stream that
+        # can never equal torch's, so it is refused here instead of passing as "stream 0 == torch's default stream".
         if self.comm is None and self.ctx is not None and self.g.is_cuda and torch.cuda.current_stream(self.g.device).cuda_stream != self.ctx.stream_handle:
             raise RuntimeError("OverlappedGradSync: torch's current stream differs from the stream the eegldm Context enqueues on; "
                                "the all-reduce would not be ordered after the backward (create the Context under the stream you train on)")

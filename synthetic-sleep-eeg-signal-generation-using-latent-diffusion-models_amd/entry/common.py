@@ -85,6 +85,16 @@ def read_ids(path_ids, path_pre_processed, dataset="edfx"):
     return [os.path.join(path_pre_processed or "", r["FILE_NAME_EEG"] + final) for r in rows]
 
 
+def shard_files(files, rank, world):
+    """Rank `rank`'s slice of the file list, the SAME length on every rank: ceil(N / world) entries, taken round-robin and wrapped
+    around the end of the list (what torch's DistributedSampler does with drop_last=False).  Equal lengths matter: every rank runs
+    one gradient all-reduce per batch, so a rank with one more batch than the others would wait in a collective nobody else enters."""
+    if world <= 1 or not files:
+        return list(files)
+    per = -(-len(files) // world)
+    return [files[(rank + i * world) % len(files)] for i in range(per)]
+
+
 class WindowLoader:
     """Iterable of {'eeg': float32 (B,1,3072)} batches -- the loader output contract of dataset.py:10-30,62-69.
 
@@ -94,7 +104,8 @@ class WindowLoader:
     a whole night (~23 MB) for every 12 KB window (PersistentDataset(cache_dir=None)); here a recording is read and normalised ONCE
     and kept in memory, and `windows_per_recording` crops are drawn from it per epoch (1 = the reference's epoch definition).
     `shard=(rank, world)` gives every data-parallel rank its own slice of the file list (an epoch is the data once, not world
-    times).  Crop offsets come from a numpy Generator seeded per loader (`crop_starts` can be injected for parity tests)."""
+    times; `shard_files`: equal length on every rank, so all ranks run the same number of steps per epoch).  A run that names real
+    data (`path_ids` / `path_pre_processed`) and finds none raises instead of silently training on synthetic windows.  Crop offsets come from a numpy Generator seeded per loader (`crop_starts` can be injected for parity tests)."""
 
     def __init__(self, path_pre_processed, batch_size, n_synthetic=0, seed=0, drop_last=False, shuffle=True, path_ids=None,
                  dataset="edfx", shard=(0, 1), windows_per_recording=1, crop_starts=None):
@@ -113,7 +124,10 @@ class WindowLoader:
         else:
             files = sorted(glob.glob(os.path.join(path_pre_processed or "", "**", "*.npy"), recursive=True)) if path_pre_processed else []
         rank, world = shard
-        files = files[rank::world] if world > 1 else files
+        if (path_ids or path_pre_processed) and not n_synthetic and not files:
+            raise FileNotFoundError(f"no recordings found (path_ids={path_ids!r}, path_pre_processed={path_pre_processed!r}); "
+                                    "refusing to fall back to synthetic windows for a run that named real data")
+        files = shard_files(files, rank, world)
         if files:
             self.files = files
             self.recordings = [None] * len(files)          # read + normalised on first use, then cached

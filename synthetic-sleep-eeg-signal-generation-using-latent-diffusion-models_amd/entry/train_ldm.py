@@ -33,24 +33,32 @@ def parse_args(argv=None):
 
 
 @torch.no_grad()
-def validate(unet, stage1, sched, loader, scale_factor, seed, latent_channels):
-    """eval_ldm (training.py:455-497): mean epsilon-MSE over the validation windows, fixed noise stream."""
+def validate(unet, stage1, sched, loader, scale_factor, seeds, latent_channels):
+    """eval_ldm (training.py:455-497): mean epsilon-MSE over the validation windows, fixed noise stream.  `seeds` = the three Philox
+    keys (timesteps, posterior eps, diffusion noise), each from `rng_seed` with its own role.  Returns (sum of per-window losses,
+    number of windows) so that data-parallel ranks can add their shards up."""
     from .._lib import lib, check, ptr
     unet.eval()
     tot, n, dev, ctx = 0.0, 0, unet.device, unet.ctx
+    s_t, s_eps, s_noise = seeds
     out = torch.zeros(1, device=dev)
-    for k, batch in enumerate(loader):
+    seen = 0
+    for batch in loader:
         x = batch["eeg"].to(dev); B = x.shape[0]
         Ll = x.shape[2] // stage1.down
-        t = randint(ctx, B, sched.num_train_timesteps, seed=seed, offset=k * B)
-        eps = randn(ctx, (B, latent_channels, Ll), seed=seed + 1, offset=k * B * Ll)
-        noise = randn(ctx, eps.shape, seed=seed + 2, offset=k * B * Ll)
+        per = latent_channels * Ll                      # random numbers per window: offsets never overlap, whatever latent_channels is
+        t = randint(ctx, B, sched.num_train_timesteps, seed=s_t, offset=seen)
+        eps = randn(ctx, (B, latent_channels, Ll), seed=s_eps, offset=seen * per)
+        noise = randn(ctx, eps.shape, seed=s_noise, offset=seen * per)
         e = stage1.encode_stage_2_inputs(x, eps=eps, scale_factor=scale_factor)
         pred = unet(sched.add_noise(original_samples=e, noise=noise, timesteps=t), timesteps=t)
         check(lib.eegldm_mse_loss(ctx.h, ptr(pred), ptr(noise), ptr(out), None, pred.numel(), 1.0))
-        tot += float(out) * B; n += B
+        tot += float(out) * B; n += B; seen += B
     unet.train()
-    return tot / max(1, n)
+    return tot, n
+
+
+LAST_RUN = {}      # what the most recent main() ended with (rank-local): read by the multi-rank tests
 
 
 def main(args):
@@ -81,13 +89,18 @@ def main(args):
     bs = max(1, config.train.batch_size // world)
     train = WindowLoader(args.path_pre_processed, bs, args.synthetic_windows, seed=config.train.seed + rank, drop_last=config.train.drop_last,
                          path_ids=args.path_train_ids, dataset=args.type_dataset, shard=(rank, world))
+    # validation: every rank scores its own shard (equal lengths, wrap-around: a recording may be scored twice when N % world != 0)
+    # and the (sum, count) pairs are added over ranks -- model selection sees the WHOLE validation split, as the reference's does
     valid = WindowLoader(args.path_pre_processed, bs, 0, seed=config.train.seed + 7919, shuffle=False, path_ids=args.path_valid_ids,
                          dataset=args.type_dataset, shard=(rank, world)) if args.path_valid_ids else None
+    v_seeds = tuple(rng_seed(config.train.seed, role, rank, world) for role in (5, 6, 7))
     s_t, s_eps, s_noise = (rng_seed(config.train.seed, role, rank, world) for role in (1, 2, 3))
     dev, ctx = unet.device, unet.ctx
     first = next(iter(train))["eeg"].to(dev)
     z = stage1.encode_stage_2_inputs(first)
-    scale_factor = 1.0 / float(z.std())                                       # train_ldm.py:203-204 (unbiased std of one batch)
+    # train_ldm.py:203-204 (unbiased std of one batch).  The reference is ONE process: one value for all replicas.  Here the loader is
+    # rank-sharded, so every rank sees a different first batch -- rank 0's value is broadcast (and is the one checkpointed below)
+    scale_factor = D.broadcast_scalar(1.0 / float(z.std()), src=0, like=z)
     if rank == 0:
         print(f"Scaling factor set to {scale_factor}")
     loss = torch.zeros(1, device=dev)
@@ -120,12 +133,14 @@ def main(args):
             steps += 1; gstep += 1; seen += B * world
             if args.max_steps and steps >= args.max_steps:
                 break
+        do_eval = (epoch + 1) % config.train.get("eval_freq", 1) == 0 or bool(args.max_steps and steps >= args.max_steps)
+        cur = float(loss)
+        if do_eval and valid is not None:      # model selection on the validation split (training.py:356-380), epsilon MSE over its windows
+            v_sum, v_n = D.allreduce_sum_scalars(validate(unet, stage1, sched, valid, scale_factor, v_seeds, args.latent_channels), like=loss)
+            cur = v_sum / max(1.0, v_n)
         if rank == 0:
             print(f"epoch {epoch}: loss {float(loss):.5f} | {seen/(time.time()-t0):.1f} windows/s", flush=True)
-            if (epoch + 1) % config.train.get("eval_freq", 1) == 0 or (args.max_steps and steps >= args.max_steps):
-                cur = float(loss)
-                if valid is not None:      # model selection on the validation split (training.py:356-380), epsilon MSE over its windows
-                    cur = validate(unet, stage1, sched, valid, scale_factor, rng_seed(config.train.seed, 5, rank, world), args.latent_channels)
+            if do_eval:
                 if cur <= best:
                     best = cur
                     torch.save({k: v.cpu() for k, v in unet.state_dict().items()}, os.path.join(run_dir, "best_model.pth"))
@@ -136,6 +151,7 @@ def main(args):
             break
     if rank == 0:
         torch.save({k: v.cpu() for k, v in unet.state_dict().items()}, os.path.join(run_dir, "final_model.pth"))
+    LAST_RUN.clear(); LAST_RUN.update(rank=rank, world=world, scale_factor=scale_factor, steps=steps, param_sum=float(unet.flat.double().sum()))
     return run_dir
 
 

@@ -186,6 +186,7 @@ class PatchDiscriminator(_Flat):
         if last_conv_kernel_size not in (None, kernel_size):
             raise NotImplementedError("last_conv_kernel_size != kernel_size")
         self.in_channels, self.out_channels, self.num_layers_d = in_channels, out_channels, num_layers_d
+        self.kernel_size, self.padding = kernel_size, padding
         self.dtype = DT[dtype]
         self.ctx = ctx or default_context(device if isinstance(device, int) else torch.device(device).index or 0)
         self.device = torch.device("cuda", self.ctx.device)
@@ -225,16 +226,26 @@ class PatchDiscriminator(_Flat):
     def sync_weights(self):
         check(lib.eegldm_disc_sync_weights(self.h))
 
-    def forward(self, x):
-        """Returns a list like the reference; only the last feature map (the logits the trainer uses,
-        train_autoencoderkl.py:213) is materialised -- earlier entries are None."""
+    def forward(self, x, features=True):
+        """The reference's return value: the list of per-block feature maps -- initial conv + LeakyReLU, one per conv + BatchNorm +
+        LeakyReLU layer, then the final conv's logits (the entry the trainer uses, train_autoencoderkl.py:213).  The earlier maps are
+        copied out of the native forward's tape as fp32 (B, C, L) tensors; `features=False` skips those copies and leaves None in
+        their places (the train step itself is one native call and never comes through here)."""
         x = x.to(self.device, torch.float32).contiguous(); B, _c, L = x.shape
         Lo = L
         for _ in range(self.num_layers_d):
-            Lo = (Lo + 2 - 3) // 2 + 1
+            Lo = (Lo + 2 * self.padding - self.kernel_size) // 2 + 1          # initial + (num_layers_d - 1) stride-2 convs; the rest keep L
         logits = torch.empty(B, self.out_channels, Lo, device=self.device)
         check(lib.eegldm_disc_forward(self.h, ptr(x), ptr(logits), B, L, 1 if self.training else 0))
-        return [None] * (self.num_layers_d + 1) + [logits]
+        feats = [None] * (self.num_layers_d + 1)
+        if features:
+            Cc, Lf = C.c_int(), C.c_int()
+            for i in range(self.num_layers_d + 1):
+                check(lib.eegldm_disc_feature(self.h, i, None, C.byref(Cc), C.byref(Lf)))
+                f = torch.empty(B, Cc.value, Lf.value, device=self.device)
+                check(lib.eegldm_disc_feature(self.h, i, ptr(f), None, None))
+                feats[i] = f
+        return feats + [logits]
 
     __call__ = forward
 

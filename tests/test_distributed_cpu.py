@@ -57,3 +57,55 @@ def test_single_process_is_noop():
     gs = D.OverlappedGradSync(t)
     gs.begin(); gs.on_ready(4, 6); gs.finish(); gs.wait()
     assert torch.equal(t, torch.ones(10))
+
+
+def _scalar_worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    from eegldm import distributed as D
+    D.init_from_env(backend="gloo")
+    sf = D.broadcast_scalar(1.0 / (3.0 + rank), src=0)          # per-rank value differs (rank-sharded first batch); rank 0's must win
+    tot = D.allreduce_sum_scalars([1.5 * (rank + 1), 4 + rank])
+    q.put((rank, sf, tot))
+    dist.destroy_process_group()
+
+
+def test_gloo_world2_broadcast_scalar_and_sum():
+    """train_ldm's scale_factor: computed on rank 0, identical everywhere; validation (sum, count) added over ranks."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29100 + os.getpid() % 300
+    procs = [ctx.Process(target=_scalar_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=120) for _ in procs], key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert res[0][1] == res[1][1] == 1.0 / 3.0
+    assert res[0][2] == res[1][2] == [4.5, 9.0]
+
+
+def test_shard_files_equal_length_and_cover():
+    """Every rank gets ceil(N/world) files (ranks with unequal batch counts would hang in the per-step all-reduce); the union covers
+    the list; a run that names real data and finds none raises instead of training on synthetic windows."""
+    sys.path.insert(0, ROOT)
+    import pytest
+    from eegldm.entry.common import WindowLoader, shard_files
+    files = [f"f{i}" for i in range(31)]
+    for world in (1, 2, 3, 4, 8):
+        shards = [shard_files(files, r, world) for r in range(world)]
+        assert len({len(s) for s in shards}) == 1 and len(shards[0]) == -(-31 // world)
+        assert set().union(*map(set, shards)) == set(files)
+    assert shard_files(["a"], 3, 4) == ["a"]                    # fewer files than ranks: wrap around, never an empty shard
+    assert D_single().broadcast_scalar(2.5) == 2.5 and D_single().allreduce_sum_scalars([1, 2]) == [1.0, 2.0]
+    import tempfile
+    with tempfile.TemporaryDirectory() as d:
+        with pytest.raises(FileNotFoundError):
+            WindowLoader(d, 4)                                   # an empty data directory is an error, not a synthetic run
+    assert len(WindowLoader(None, 4, n_synthetic=8)) == 2       # synthetic runs still work when asked for
+
+
+def D_single():
+    from eegldm import distributed as D
+    return D

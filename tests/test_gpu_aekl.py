@@ -118,14 +118,21 @@ def test_patch_discriminator_fwd_bwd(dtype):
         sd[k] = v.requires_grad_(True) if v.is_floating_point() and "running" not in k else v
     x = torch.from_numpy(normal((B, 1, L), seed=8)).requires_grad_(True)
     running = {}
-    logits = A.disc_forward(sd, D_CFG, x, True, running)[-1]
+    feats_ref = A.disc_forward(sd, D_CFG, x, True, running)
+    logits = feats_ref[-1]
     dy = torch.from_numpy(normal(tuple(logits.shape), seed=9))
     (logits * dy).sum().backward()
     net = PatchDiscriminator(**D_CFG, dtype=dtype)
     assert sum(n for (_o, n, _s) in net.entries.values()) == 519681
     net.load_state_dict({k: v.detach() for k, v in sd.items()})
     f32 = dtype == "float32"
-    out = net(x.detach())[-1]
+    feats = net(x.detach())
+    # the reference's return value is the LIST of per-block feature maps (initial, one per layer, logits): all of them, not only [-1]
+    assert len(feats) == len(feats_ref) == D_CFG["num_layers_d"] + 2
+    for i, (got_f, want_f) in enumerate(zip(feats, feats_ref)):
+        assert tuple(got_f.shape) == tuple(want_f.shape), (i, got_f.shape, want_f.shape)
+        assert rel_l2(got_f, want_f.detach()) < (2e-5 if f32 else 5e-2), (i, rel_l2(got_f, want_f.detach()))
+    out = feats[-1]
     assert out.shape == logits.shape
     assert rel_l2(out, logits) < (2e-5 if f32 else 5e-2), rel_l2(out, logits)
     net.zero_grad()

@@ -113,3 +113,108 @@ def test_native_rccl_communicator_one_rank():
             comm.allreduce_mean(g.double())
     finally:
         comm.close()
+
+
+# ---------------------------------------------------------------- AutoencoderKL + PatchDiscriminator GAN step, data-parallel
+def _aekl_worker(rank, world, port, q):
+    """train_autoencoderkl.py:141-144 wraps both networks in nn.DataParallel; here: per-rank fused GAN step (per-rank BatchNorm batch
+    statistics, as DataParallel's replicas have), then the mean of both flat gradient buffers over ranks."""
+    sys.path.insert(0, ROOT)
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                      EEGLDM_DIST_BACKEND="gloo", EEGLDM_LOCAL_DEVICE="0")
+    import torch.distributed as dist
+    from eegldm import distributed as D
+    from eegldm.models import AutoencoderKL, PatchDiscriminator
+    from eegldm.training import aekl_train_step
+    D.init_from_env()
+    torch.manual_seed(10 + rank)                              # different initial weights and BatchNorm buffers per rank: the broadcast must fix that
+    ae = AutoencoderKL(spatial_dims=1, in_channels=1, out_channels=1, num_channels=[8, 8, 16], latent_channels=1, num_res_blocks=2,
+                       norm_num_groups=1, dtype="float32")
+    disc = PatchDiscriminator(spatial_dims=1, num_layers_d=3, num_channels=16, in_channels=1, out_channels=1, kernel_size=3, norm="BATCH",
+                              bias=False, padding=1, dtype="float32")
+    ae.load_state_dict({k: torch.randn(v.shape) * 0.1 + (1.0 if "norm" in k and k.endswith("weight") else 0.0) for k, v in ae.state_dict().items()})
+    disc.buffers.add_(0.25 * rank)
+    D.broadcast_flat(ae.flat); ae.sync_weights()
+    D.broadcast_flat(disc.flat); D.broadcast_flat(disc.buffers); disc.sync_weights()
+    dev = ae.device
+    buf0 = disc.buffers.clone()
+
+    def batch(rk):
+        g = torch.Generator().manual_seed(200 + rk)
+        x = torch.rand(4, 1, 256, generator=g); x[:, :, :8] = 0; x[:, :, -8:] = 0
+        return x.to(dev), torch.randn(4, 1, 64, generator=g).to(dev)
+
+    def step(rk):
+        ae.zero_grad(); disc.zero_grad(); disc.buffers.copy_(buf0)
+        aekl_train_step(ae, disc, *batch(rk), 0.01, 1e-6, 0.1, True)
+        return ae.flat_grad.clone(), disc.flat_grad.clone()
+
+    want_g, want_d = torch.zeros_like(ae.flat_grad), torch.zeros_like(disc.flat_grad)
+    for rk in range(world):                                   # this rank computes every rank's gradients alone and averages them
+        g, d = step(rk); want_g += g / world; want_d += d / world
+    step(rank)
+    D.allreduce_mean_flat(ae.flat_grad); D.allreduce_mean_flat(disc.flat_grad)
+    torch.cuda.synchronize()
+    eg = float((ae.flat_grad - want_g).abs().max() / want_g.abs().max()); ed = float((disc.flat_grad - want_d).abs().max() / want_d.abs().max())
+    q.put((rank, eg, ed, float(ae.flat.double().sum()), float(disc.flat.double().sum()), float(buf0.double().sum()),
+           float(want_g.abs().max()), float(want_d.abs().max())))
+    dist.destroy_process_group()
+
+
+def _spawn2(target, extra=()):
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29700 + os.getpid() % 150
+    procs = [ctx.Process(target=target, args=(r, 2, port, q) + tuple(extra)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=600) for _ in procs], key=lambda v: v[0])
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    return res
+
+
+def test_aekl_gan_step_two_ranks_grad_mean():
+    res = _spawn2(_aekl_worker)
+    assert res[0][3] == res[1][3] and res[0][4] == res[1][4] and res[0][5] == res[1][5]     # params of both nets + BatchNorm buffers identical
+    for rank, eg, ed, _a, _d, _b, mg, md in res:
+        assert mg > 0 and md > 0
+        assert eg < 1e-5 and ed < 1e-5, (rank, eg, ed)      # all-reduced == mean of the per-rank gradients
+
+
+def _entry_worker(rank, world, port, q, out):
+    """The two training entry points under a 2-rank rendezvous: replicas must end with identical parameters, and train_ldm's
+    scale_factor (1/std of the FIRST batch, which differs per rank because the loader is rank-sharded) must be rank 0's everywhere."""
+    sys.path.insert(0, ROOT)
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                      EEGLDM_DIST_BACKEND="gloo", EEGLDM_LOCAL_DEVICE="0")
+    import torch.distributed as dist
+    from eegldm.entry import train_autoencoderkl as TA, train_ldm as TL
+    a_yaml, l_yaml = os.path.join(out, "aekl.yaml"), os.path.join(out, "ldm.yaml")
+    run_a = TA.main(TA.parse_args(["--config_file", a_yaml, "--spe", "spectral", "--synthetic_windows", "16", "--latent_channels", "1", "--max_steps", "3"]))
+    a = dict(TA.LAST_RUN)
+    dist.barrier()                                            # rank 0 has written best_model.pth
+    TL.main(TL.parse_args(["--config_file", l_yaml, "--autoencoderkl_config_file_path", a_yaml, "--best_model_path", run_a,
+                           "--synthetic_windows", "16", "--latent_channels", "1", "--max_steps", "2"]))
+    l = dict(TL.LAST_RUN)
+    # what this rank would have computed on its own first batch (the round-2 behaviour): must differ between ranks for the test to mean anything
+    q.put((rank, a["ae_sum"], a["d_sum"], a["steps"], l["scale_factor"], l["param_sum"], l["steps"]))
+    dist.destroy_process_group()
+
+
+def test_entry_points_two_ranks_identical_replicas(tmp_path):
+    import yaml
+    from test_gpu_entry import AEKL_YAML, LDM_YAML
+    out = str(tmp_path)
+    a = dict(AEKL_YAML); a["train"] = dict(a["train"], output_dir=out)
+    l = dict(LDM_YAML); l["train"] = dict(l["train"], output_dir=out)
+    yaml.safe_dump(a, open(os.path.join(out, "aekl.yaml"), "w")); yaml.safe_dump(l, open(os.path.join(out, "ldm.yaml"), "w"))
+    res = _spawn2(_entry_worker, extra=(out,))
+    r0, r1 = res
+    assert r0[1] == r1[1] and r0[2] == r1[2] and r0[3] == r1[3] == 3           # autoencoder / discriminator replicas identical after 3 steps
+    assert r0[4] == r1[4] and r0[4] > 0                                          # ONE scale factor (rank 0's), bit-identical
+    assert r0[5] == r1[5] and r0[6] == r1[6] == 2                              # UNet replicas identical
+    ck = torch.load(os.path.join(out, "ldm_eeg_no-spectral_edfx", "checkpoint.pth"))
+    assert float(ck["scale_factor"]) == pytest.approx(r0[4], rel=1e-6)

@@ -289,3 +289,36 @@ def test_scheduler_mse_adam_rng():
     ti = torch.empty(1 << 16, device=G.DEV, dtype=torch.int64)
     G.check(G.lib.eegldm_randint(c.h, G.ptr(ti), ti.numel(), 1000, 7, 0))
     assert int(ti.min()) >= 0 and int(ti.max()) <= 999 and abs(float(ti.float().mean()) - 499.5) < 5
+
+
+LINEAR_CASES = [(8, 512, 128), (256, 512, 512), (256, 7168, 512), (5, 96, 40), (3, 7, 33)]     # M, N, K: time_embed.0 / .2, the 21 stacked emb_layers, ragged
+
+
+@pytest.mark.parametrize("dtype", [0, 1])
+@pytest.mark.parametrize("case", LINEAR_CASES)
+def test_linear_fwd_bwd(case, dtype):
+    """nn.Linear (unet.py:373-377, 277-285) forward and its autograd backward through eegldm_linear_fwd / eegldm_linear_bwd."""
+    G = _imports()
+    M, N, K = case
+    x = torch.from_numpy(normal((M, K), seed=11)).requires_grad_(True)
+    w = (torch.from_numpy(normal((N, K), seed=12)) / math.sqrt(K)).requires_grad_(True)
+    b = torch.from_numpy(normal((N,), seed=13)).requires_grad_(True)
+    dy = torch.from_numpy(normal((M, N), seed=14))
+    if dtype == G.BF16:
+        x = x.detach().bfloat16().float().requires_grad_(True); w = w.detach().bfloat16().float().requires_grad_(True); dy = dy.bfloat16().float()
+    y_ref = F.linear(x, w, b)
+    y_ref.backward(dy)
+    c = G.ctx()
+    td = G.TDT[dtype]
+    xd, wd, bd, dyd = x.detach().to(G.DEV).to(td), w.detach().to(G.DEV).to(td), b.detach().to(G.DEV), dy.to(G.DEV).to(td)
+    yd = torch.empty(M, N, device=G.DEV)
+    G.check(G.lib.eegldm_linear_fwd(c.h, G.ptr(xd), K, G.ptr(wd), G.ptr(bd), G.ptr(yd), N, M, N, K, dtype, 1))
+    G.assert_close(yd, y_ref, **G.TOL[dtype], name="y")
+    dxd = torch.empty(M, K, device=G.DEV); dwd = torch.zeros(N, K, device=G.DEV); dbd = torch.zeros(N, device=G.DEV)
+    G.check(G.lib.eegldm_linear_bwd(c.h, G.ptr(xd), K, G.ptr(wd), G.ptr(dyd), N, G.ptr(dxd), K, G.ptr(dwd), G.ptr(dbd), M, N, K, dtype, 1))
+    G.assert_close(dxd, x.grad, **G.GTOL[dtype], name="dx")
+    G.assert_close(dwd, w.grad, **G.GTOL[dtype], name="dw")
+    G.assert_close(dbd, b.grad, **G.GTOL[dtype], name="dbias")
+    # accumulation semantics (+=) and the optional outputs
+    G.check(G.lib.eegldm_linear_bwd(c.h, G.ptr(xd), K, None, G.ptr(dyd), N, None, 0, G.ptr(dwd), None, M, N, K, dtype, 1))
+    G.assert_close(dwd, 2 * w.grad, **G.GTOL[dtype], name="dw accumulated")
