@@ -72,7 +72,14 @@ def test_window_loader_splits_and_shards(nights):
     va = WindowLoader(str(d), 8, path_ids=str(d / "ids_valid.csv"))
     assert set(tr.files).isdisjoint(va.files) and len(tr.files) == 3 and len(va.files) == 2
     shards = [WindowLoader(str(d), 8, path_ids=str(d / "ids_train.csv"), shard=(r, 2)).files for r in range(2)]
-    assert sorted(shards[0] + shards[1]) == sorted(tr.files) and set(shards[0]).isdisjoint(shards[1])
+    # 3 recordings over 2 ranks: equal shard lengths (every rank runs the same number of all-reduces per epoch), the union is the whole
+    # split, and the one repeat is the wrap-around (torch DistributedSampler's drop_last=False convention)
+    assert len(shards[0]) == len(shards[1]) == 2 and set(shards[0]) | set(shards[1]) == set(tr.files)
+    assert shards[0] == [tr.files[0], tr.files[2]] and shards[1] == [tr.files[1], tr.files[0]]
+    loaders = [WindowLoader(str(d), 1, path_ids=str(d / "ids_train.csv"), shard=(r, 2), drop_last=True) for r in range(2)]
+    assert len(loaders[0]) == len(loaders[1])
+    even = [WindowLoader(str(d), 8, path_ids=str(d / "ids_valid.csv"), shard=(r, 2)).files for r in range(2)]
+    assert set(even[0]).isdisjoint(even[1]) and sorted(even[0] + even[1]) == sorted(va.files)       # N % world == 0: a plain partition
     with pytest.raises(FileNotFoundError):
         with open(d / "ids_bad.csv", "w") as f:
             f.write("FILE_NAME_EEG\nnot_there\n")
