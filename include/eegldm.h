@@ -340,6 +340,35 @@ int eegldm_disc_backward(eegldm_disc*, const float* dlogits, float* dx, int para
 int eegldm_aekl_train_step(eegldm_aekl*, eegldm_disc*, const float* x, const float* eps, float adv_weight, float kl_weight,
                            float spectral_weight, int use_spectral, float* losses, float* recon_out, int B, int L);
 
+/* ------------------------------------------------------------------ FID on U-Sleep features
+ * The feature extractor of /root/reference/src/compute_fid.py:357-386: USleep(in_chans=2, sfreq=100, depth=12, ...) of
+ * /root/reference/src/models/usleep.py:101-287, forward only, fp32, reference (B, C, T) layout.  kernel_size = round(time_conv_size_s *
+ * sfreq) (7 at 100 Hz), input_size = ceil(input_size_s * sfreq) (the classifier's AvgPool1d window).  Parameters live in ONE flat
+ * fp32 buffer (conv weights in the reference's (Cout, Cin, K) layout), BatchNorm running statistics + num_batches_tracked (as floats)
+ * in a second one; eegldm_usleep_entry lists both in the reference's state_dict order (kind 0 = parameter, 1 = buffer). */
+typedef struct eegldm_usleep eegldm_usleep;
+typedef struct {
+  int in_chans, depth, n_time_filters, n_classes, kernel_size, input_size, with_skip_connection;
+  float complexity_factor;
+} eegldm_usleep_cfg;
+int eegldm_usleep_create(eegldm_ctx*, const eegldm_usleep_cfg*, eegldm_usleep** out);
+int eegldm_usleep_destroy(eegldm_usleep*);
+long eegldm_usleep_num_params(const eegldm_usleep*);
+long eegldm_usleep_num_buffers(const eegldm_usleep*);
+int eegldm_usleep_num_entries(const eegldm_usleep*);
+int eegldm_usleep_channel(const eegldm_usleep*, int i);      /* c_i of usleep.py:165-172, i = 0 .. depth + 1; -1 out of range */
+int eegldm_usleep_entry(const eegldm_usleep*, int i, char* name, int name_cap, int* kind, long* offset, long* numel, int* ndim, int shape[3]);
+int eegldm_usleep_bind(eegldm_usleep*, float* params, float* buffers);
+/* USleep.forward (usleep.py:249-287): x (B, in_chans, T) -> y_pred (B, n_classes, T / input_size), decoder output (B, c_1, T) and the
+ * bottleneck (B, c_{depth+1}, Lb); each output is optional, and without y_pred and decoder_out the decoder is skipped (the FID feature
+ * of compute_fid.py:380-381 is the bottleneck).  training != 0: BatchNorm on batch statistics + running-statistics update -- what the
+ * reference script runs, since it never calls model.eval(). */
+int eegldm_usleep_forward(eegldm_usleep*, const float* x, float* y_pred, float* decoder_out, float* bottom, int B, int T, int training);
+/* First and second moments of a feature batch (N, D), accumulated in fp64 device buffers the caller zeroed: sum[D] += sum_n f[n],
+ * outer[D][D] += sum_n f[n] f[n]^T.  mean = sum / N, covariance = (outer - N mean mean^T) / (N - 1) are the inputs of the Frechet
+ * distance (compute_fid.py:412-414 = monai-generative FIDMetric: torch.mean, unbiased _cov, trace of the matrix square root). */
+int eegldm_feature_moments(eegldm_ctx*, const float* feats, long N, int D, double* sum, double* outer);
+
 #ifdef __cplusplus
 }
 #endif

@@ -127,8 +127,18 @@ SIGNATURES = {
     "eegldm_disc_feature": [_vp, _i, _vp, _vp, _vp],
     "eegldm_disc_backward": [_vp, _vp, _vp, _i],
     "eegldm_aekl_train_step": [_vp, _vp, _vp, _vp, _f, _f, _f, _i, _vp, _vp, _i, _i],
+    "eegldm_usleep_create": [_vp, _vp, _vp],
+    "eegldm_usleep_destroy": [_vp],
+    "eegldm_usleep_num_params": [_vp],
+    "eegldm_usleep_num_buffers": [_vp],
+    "eegldm_usleep_num_entries": [_vp],
+    "eegldm_usleep_channel": [_vp, _i],
+    "eegldm_usleep_entry": [_vp, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp],
+    "eegldm_usleep_bind": [_vp, _vp, _vp],
+    "eegldm_usleep_forward": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i],
+    "eegldm_feature_moments": [_vp, _vp, _l, _i, _vp, _vp],
 }
-for _n in ("eegldm_aekl_num_params", "eegldm_disc_num_params", "eegldm_disc_num_buffers"):
+for _n in ("eegldm_aekl_num_params", "eegldm_disc_num_params", "eegldm_disc_num_buffers", "eegldm_usleep_num_params", "eegldm_usleep_num_buffers"):
     if hasattr(lib, _n):
         getattr(lib, _n).restype = C.c_long
 
@@ -141,6 +151,11 @@ class AeklCfg(C.Structure):
 class DiscCfg(C.Structure):
     _fields_ = [("in_channels", _i), ("out_channels", _i), ("num_channels", _i), ("num_layers_d", _i),
                 ("kernel_size", _i), ("padding", _i), ("bias", _i), ("dtype", _i)]
+
+
+class USleepCfg(C.Structure):
+    _fields_ = [("in_chans", _i), ("depth", _i), ("n_time_filters", _i), ("n_classes", _i), ("kernel_size", _i), ("input_size", _i),
+                ("with_skip_connection", _i), ("complexity_factor", C.c_float)]
 
 
 class UNetCfg(C.Structure):

@@ -291,7 +291,7 @@ def test_scheduler_mse_adam_rng():
     assert int(ti.min()) >= 0 and int(ti.max()) <= 999 and abs(float(ti.float().mean()) - 499.5) < 5
 
 
-LINEAR_CASES = [(8, 512, 128), (256, 512, 512), (256, 7168, 512), (5, 96, 40), (3, 7, 33)]     # M, N, K: time_embed.0 / .2, the 21 stacked emb_layers, ragged
+LINEAR_CASES = [(8, 512, 128), (256, 512, 512), (256, 7168, 512), (5, 96, 40), (3, 7, 32)]     # M, N, K: time_embed.0 / .2, the 21 stacked emb_layers, ragged M / N
 
 
 @pytest.mark.parametrize("dtype", [0, 1])
@@ -322,3 +322,6 @@ def test_linear_fwd_bwd(case, dtype):
     # accumulation semantics (+=) and the optional outputs
     G.check(G.lib.eegldm_linear_bwd(c.h, G.ptr(xd), K, None, G.ptr(dyd), N, None, 0, G.ptr(dwd), None, M, N, K, dtype, 1))
     G.assert_close(dwd, 2 * w.grad, **G.GTOL[dtype], name="dw accumulated")
+    # the reduction length must be a whole number of 16-byte chunks (MFMA operand rows): a clean error, not a wrong result
+    with pytest.raises(RuntimeError, match="multiples of"):
+        G.check(G.lib.eegldm_linear_fwd(c.h, G.ptr(xd), 33, G.ptr(wd), G.ptr(bd), G.ptr(yd), N, 1, 1, 33, dtype, 1))
