@@ -115,7 +115,8 @@ int eegldm_conv1d_bwd_data(eegldm_ctx*, const void* dy, long lddy, const void* w
 int eegldm_conv1d_bwd_weight(eegldm_ctx*, const void* x, long ldx, const void* dy, long lddy,
                              float* dw, float* dbias, int B, int Lin, int Cin, int Cout, int K,
                              int stride, int pad_l, int pad_r, int dtype);
-/* nn.Linear (unet.py:373-377, 277-285): y[M][N] = x[M][K] w[N][K]^T + bias; y is fp32 when out_f32 */
+/* nn.Linear (unet.py:373-377, 277-285): y[M][N] = x[M][K] w[N][K]^T + bias; y is fp32 when out_f32.  M is free; N must be a
+ * multiple of 4 (vector epilogue) and K a whole number of 16-byte chunks (8 bf16 / 4 fp32 elements): anything else is refused. */
 int eegldm_linear_fwd(eegldm_ctx*, const void* x, long ldx, const void* w, const float* bias, void* y, long ldy,
                       int M, int N, int K, int dtype, int out_f32);
 /* its backward (what autograd derives for nn.Linear): dx[M][K] = dy[M][N] w[N][K] (skipped when dx is NULL; fp32 when dx_f32),

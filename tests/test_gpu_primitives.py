@@ -291,7 +291,7 @@ def test_scheduler_mse_adam_rng():
     assert int(ti.min()) >= 0 and int(ti.max()) <= 999 and abs(float(ti.float().mean()) - 499.5) < 5
 
 
-LINEAR_CASES = [(8, 512, 128), (256, 512, 512), (256, 7168, 512), (5, 96, 40), (3, 7, 32)]     # M, N, K: time_embed.0 / .2, the 21 stacked emb_layers, ragged M / N
+LINEAR_CASES = [(8, 512, 128), (256, 512, 512), (256, 7168, 512), (5, 96, 40), (3, 8, 32)]     # M, N, K: time_embed.0 / .2, the 21 stacked emb_layers, ragged M, one N vector group
 
 
 @pytest.mark.parametrize("dtype", [0, 1])
