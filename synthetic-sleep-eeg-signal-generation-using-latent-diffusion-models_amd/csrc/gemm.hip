@@ -1188,7 +1188,8 @@ int gemm_launch(eegldm_ctx* ctx, const GemmArgs& a_in) {
   if (a.dtype == EEGLDM_F32) rc = launch_modes<float>(ctx, a);
   else if (a.dtype == EEGLDM_BF16) rc = launch_modes<bf16_t>(ctx, a);
   else EEG_FAIL(EEGLDM_ERR_UNSUPPORTED, "dtype %d", a.dtype);
-  if (rc == 0 && fold_dst) {
+  static const bool dbg_skip_fold = getenv("EEGLDM_DBG_SKIP_FOLDS") != nullptr;      // timing experiment only: weight gradients stay in the workspace
+  if (rc == 0 && fold_dst && !dbg_skip_fold) {
     hipLaunchKernelGGL(splitk_fold_kernel, dim3((unsigned)((fold_n / 4 + 63) / 64)), dim3(256), 0, ctx->stream, (const float*)ctx->splitk_ws, a.splitk, fold_n, fold_dst);
     LAUNCH_CHECK();
   }

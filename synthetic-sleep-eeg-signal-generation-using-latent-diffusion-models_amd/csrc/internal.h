@@ -26,6 +26,10 @@ int dconv_wgrad(eegldm_ctx*, int dtype, const void* x, long ldx, const void* dy,
                 int Lout, int Cin, int Cout, int K, int stride, int pad_l, float* dbias, int* bias_done);
 bool dconv_wgrad_tinyv_ok(int Cin, int Cout, int K);
 
+// conv_ws.hip: weight-stationary 3-tap conv for 128 reduction channels (1 = handled, 0 = not this kernel's shape, < 0 = error)
+int conv_ws_try(eegldm_ctx*, int dtype, const void* x, long ldx, const void* w, int Cin, int Cout, int transposed, const float* bias,
+                const float* rowvec, long ld_rowvec, const void* resid, long ldr, void* y, long ldy, int B, int L);
+
 // ops.hip
 int op_conv_fwd(eegldm_ctx*, int dtype, const void* x, long ldx, const void* w, const float* bias, void* y, long ldy,
                 int B, int Lin, int Cin, int Cout, int K, int stride, int pad_l, int pad_r,

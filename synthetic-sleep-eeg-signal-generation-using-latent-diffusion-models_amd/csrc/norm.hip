@@ -350,12 +350,22 @@ constexpr int NTB = 1024;
 constexpr int RES_MAXG = 64;     // local groups per chunk
 constexpr int RES_MAXC = 256;    // channels per chunk
 
-struct ResMap { int TX, TY, tx, ty, c, gl; bool act; };
-__device__ __forceinline__ ResMap resmap(int CC, int C, int cpg) {
-  ResMap m; m.TX = CC / 4; m.TY = NTB / m.TX;
+struct ResMap { int TX, TY, tx, ty, c, gl, b; bool act; };
+// The grid is 1-D: linear id -> (channel chunk, sample).  Plain order = chunk fastest.  XCD-aware order (`xcd` != 0, B % 8 == 0): the
+// hardware deals consecutive workgroup ids round-robin to the 8 XCDs, so ids = x (mod 8) run on XCD x in increasing order; the j-th of
+// them is chunk j % nchunk of sample (j / nchunk) * 8 + x -- all chunks of one sample run back to back on ONE XCD, so a 128-byte line
+// that several narrow chunks share is fetched from HBM once and served to its other readers by that XCD's L2.
+template <int NTH>
+__device__ __forceinline__ ResMap resmap(int CC, int C, int cpg, int xcd) {
+  ResMap m; m.TX = CC / 4; m.TY = NTH / m.TX;
   const int tid = threadIdx.x;
+  const int nchunk = C / CC, lin = blockIdx.x;
+  int chunk, b;
+  if (xcd) { const int x = lin & 7, j = lin >> 3; b = (j / nchunk) * 8 + x; chunk = j % nchunk; }
+  else { chunk = lin % nchunk; b = lin / nchunk; }
+  m.b = b;
   m.tx = tid % m.TX; m.ty = tid / m.TX;
-  m.c = blockIdx.x * CC + m.tx * 4; m.gl = (m.tx * 4) / cpg;
+  m.c = chunk * CC + m.tx * 4; m.gl = (m.tx * 4) / cpg;
   m.act = tid < m.TX * m.TY && m.c < C;
   return m;
 }
@@ -369,19 +379,20 @@ __device__ unsigned long long gn_tlog[4096 * 8];
 #else
 #define GN_TSTAMP(k) do {} while (0)
 #endif
-template <typename T, int RPT>
-__global__ __launch_bounds__(NTB) void gn_fwd_resident_kernel(const T* __restrict__ x, long ldx, const float* __restrict__ gamma,
+template <typename T, int RPT, int NTH>
+__global__ __launch_bounds__(NTH) void gn_fwd_resident_kernel(const T* __restrict__ x, long ldx, const float* __restrict__ gamma,
                                                               const float* __restrict__ beta, T* __restrict__ y, long ldy,
                                                               T* __restrict__ xr, long ldxr, float* __restrict__ stats,
-                                                              int L, int C, int G, float eps, int silu, int resample, int CC) {
+                                                              int L, int C, int G, float eps, int silu, int resample, int CC, int xcd) {
   // fp64 LDS accumulators: the order in which the waves arrive no longer shows in the fp32 mean / rstd, so the forward (and with it
   // seeded sampling) is reproducible run to run -- fp32 atomics differed in the last bit and bf16 roundings downstream flipped
   __shared__ double red[2 * RES_MAXG];
   GN_TSTAMP(0);
-  const int b = blockIdx.y, cpg = C / G;
-  const ResMap m = resmap(CC, C, cpg);
+  const int cpg = C / G;
+  const ResMap m = resmap<NTH>(CC, C, cpg, xcd);
+  const int b = m.b;
   const bool pair = resample == 1;
-  if (threadIdx.x < 2 * RES_MAXG) red[threadIdx.x] = 0.0;
+  for (int i = threadIdx.x; i < 2 * RES_MAXG; i += NTH) red[i] = 0.0;
   typename Vec<T, 4>::type raw[RPT];
   const T* xb = x + (long)b * L * ldx + m.c;
   if (m.act) {
@@ -471,22 +482,23 @@ __global__ __launch_bounds__(NTB) void gn_fwd_resident_kernel(const T* __restric
 // the per-sample column sums of the written dx -- the block owns (sample, channels) over all of L, so no atomics.
 // RAW0: resample == 0 specialisation that fetches the gradient rows packed, in the same predicated block as the x rows (the
 // conversion in place makes hipcc wait for every load separately: 12 serialised HBM latencies, 19 k of the block's 57 k cycles)
-template <typename T, int RPT, bool RAW0, bool SILU>
-__global__ __launch_bounds__(NTB) void gn_bwd_resident_kernel(const T* __restrict__ x, long ldx, const float* __restrict__ gamma,
+template <typename T, int RPT, bool RAW0, bool SILU, int NTH>
+__global__ __launch_bounds__(NTH) void gn_bwd_resident_kernel(const T* __restrict__ x, long ldx, const float* __restrict__ gamma,
                                                               const float* __restrict__ beta, const float* __restrict__ stats,
                                                               const T* __restrict__ dy, long lddy, T* __restrict__ dx, long lddx,
                                                               const T* __restrict__ dxr, long lddxr, float* __restrict__ slots,
                                                               float* __restrict__ colsum_ps, long ldps,
                                                               int L, int C, int G, int silu, int resample, int CC,
-                                                              const T* __restrict__ dxr2, long lddxr2) {
+                                                              const T* __restrict__ dxr2, long lddxr2, int xcd) {
   // fp64 LDS accumulators (as in the forward): dx must not depend on the order in which the waves arrive -- an fp32 one-ulp
   // difference in the group sums flips bf16 roundings of dx and the flips compound through the remaining layers
   __shared__ double redg[2 * RES_MAXG];
   __shared__ double redc[3 * RES_MAXC];
   GN_TSTAMP(0);
-  const int b = blockIdx.y, cpg = C / G;
-  const ResMap m = resmap(CC, C, cpg);
-  for (int i = threadIdx.x; i < 2 * RES_MAXG + 3 * RES_MAXC; i += NTB) { if (i < 2 * RES_MAXG) redg[i] = 0.0; else redc[i - 2 * RES_MAXG] = 0.0; }
+  const int cpg = C / G;
+  const ResMap m = resmap<NTH>(CC, C, cpg, xcd);
+  const int b = m.b;
+  for (int i = threadIdx.x; i < 2 * RES_MAXG + 3 * RES_MAXC; i += NTH) { if (i < 2 * RES_MAXG) redg[i] = 0.0; else redc[i - 2 * RES_MAXG] = 0.0; }
   typename Vec<T, 4>::type raw[RPT];
   float d[RPT][4];
   // wave-uniform per-sample bases + 32-bit byte offsets (scalar-base addressing: one VALU add per access)
@@ -629,14 +641,15 @@ __global__ __launch_bounds__(NTB) void gn_bwd_resident_kernel(const T* __restric
 
 // chunk width for the resident kernels: the widest whole-group chunk (<= 256 channels, dividing C) whose rows fit the
 // per-thread register budget; 0 = not eligible (fall back to the split kernels)
-int resident_chunk(int L, int C, int G, int resample_pair, int rpt_max, int* rpt_out) {
+int resident_chunk(int L, int C, int G, int resample_pair, int rpt_max, int* rpt_out, int nth = NTB) {
   const int cpg = C / G;
   if (C % 4 != 0 || cpg % 4 != 0) return 0;
   int best = 0, best_rpt = 0;
   for (int mlt = 1; mlt * cpg <= RES_MAXC && mlt <= RES_MAXG; mlt++) {
     const int cc = mlt * cpg;
     if (C % cc != 0) continue;
-    const int tx = cc / 4, ty = NTB / tx;
+    const int tx = cc / 4, ty = nth / tx;
+    if (ty < 1) break;
     int rpt = resample_pair ? 2 * ((L / 2 + ty - 1) / ty) : (L + ty - 1) / ty;
     if (rpt > rpt_max) break;
     best = cc; best_rpt = rpt;
@@ -669,17 +682,28 @@ int gn_fwd_t(eegldm_ctx* ctx, const void* x, long ldx, const float* gamma, const
     static const bool off = getenv("EEGLDM_GN_NO_RESIDENT") != nullptr;
     // 12 rows per thread (56 VGPRs: two 1024-thread blocks per CU) measured faster than 24 (one block per CU): 24 vs 35 us
     static const int fwd_rpt_max = getenv("EEGLDM_GN_FWD_RPT") ? atoi(getenv("EEGLDM_GN_FWD_RPT")) : 12;
-    int rpt = 0; int cc = off ? 0 : resident_chunk(L, C, G, resample == 1, fwd_rpt_max, &rpt);
+    // threads per block: 1024 = one (sample, 64-channel) slab per block; 512 / 256 = narrower slabs (32 / 16 channels), 2 / 4x as many
+    // independent blocks per CU whose load / reduce / store phases interleave (EEGLDM_GN_FWD_NTH; narrow slabs use the XCD-aware order)
+    static const int fwd_nth = getenv("EEGLDM_GN_FWD_NTH") ? atoi(getenv("EEGLDM_GN_FWD_NTH")) : 1024;
+    const int nth = (fwd_nth == 512 || fwd_nth == 256) ? fwd_nth : 1024;
+    int rpt = 0; int cc = off ? 0 : resident_chunk(L, C, G, resample == 1, fwd_rpt_max, &rpt, nth);
     // measured (tools/debug/gn_bench.py): wins while the rows are at least a 128-byte line and the blocks fit two rounds
     // (1024 blocks = the 100 MB concat tensors of the up path: 47-48 us one-pass vs 51 us split)
     static const long fwd_bpc = getenv("EEGLDM_GN_FWD_BLOCKS_PER_CU") ? atol(getenv("EEGLDM_GN_FWD_BLOCKS_PER_CU")) : 4;
-    if (cc && (cc * (int)sizeof(T) < 128 || (long)(C / cc) * B > fwd_bpc * ctx->num_cu)) cc = 0;
+    static const bool no_xcd = getenv("EEGLDM_GN_NO_XCD") != nullptr;
+    static const int narrow_min = getenv("EEGLDM_GN_NARROW_MIN_ROW") ? atoi(getenv("EEGLDM_GN_NARROW_MIN_ROW")) : 32;    // 32-byte rows (16-channel slabs) are fine under the XCD-aware order: L = 3072 runs one-pass (pixel-space step 22.84 -> 22.64 ms); 128 = round-2 behaviour
+    const bool can_xcd = !no_xcd && B % 8 == 0;
+    const int min_row = nth == 1024 ? (can_xcd ? narrow_min : 128) : 32;
+    if (cc && (cc * (int)sizeof(T) < min_row || (long)(C / cc) * B > fwd_bpc * ctx->num_cu * (1024 / nth))) cc = 0;
     if (cc) {
-      const dim3 grid(C / cc, B);
-#define GN_FWD_RES(R) hipLaunchKernelGGL((gn_fwd_resident_kernel<T, R>), grid, dim3(NTB), 0, ctx->stream, (const T*)x, ldx, gamma, beta, \
-                                         (T*)y, ldy, (T*)xr, ldxr, stats, L, C, G, eps, silu, resample, cc)
+      const int xcd = ((nth < 1024 || cc * (int)sizeof(T) < 128) && can_xcd) ? 1 : 0;
+      const dim3 grid((unsigned)((long)(C / cc) * B));
+#define GN_FWD_RES1(R, N) hipLaunchKernelGGL((gn_fwd_resident_kernel<T, R, N>), grid, dim3(N), 0, ctx->stream, (const T*)x, ldx, gamma, beta, \
+                                         (T*)y, ldy, (T*)xr, ldxr, stats, L, C, G, eps, silu, resample, cc, xcd)
+#define GN_FWD_RES(R) do { if (nth == 1024) GN_FWD_RES1(R, 1024); else if (nth == 512) GN_FWD_RES1(R, 512); else GN_FWD_RES1(R, 256); } while (0)
       if (rpt <= 6) GN_FWD_RES(6); else if (rpt <= 12) GN_FWD_RES(12); else { if constexpr (sizeof(T) == 2) GN_FWD_RES(24); }
 #undef GN_FWD_RES
+#undef GN_FWD_RES1
       LAUNCH_CHECK();
       return 0;
     }
@@ -710,21 +734,32 @@ int gn_bwd_t(eegldm_ctx* ctx, const void* x, long ldx, const float* gamma, const
   if (!dxr2_done || lddxr2 % 4 != 0 || no_dxr2) dxr2 = nullptr;      // only a caller that can fall back may hand over a second addend
   if constexpr (V == 4) {
     static const bool off = getenv("EEGLDM_GN_NO_RESIDENT") != nullptr;
-    int rpt = 0; int cc = off ? 0 : resident_chunk(L, C, G, 0, sizeof(T) == 2 ? 12 : 8, &rpt);
+    static const int bwd_nth = getenv("EEGLDM_GN_BWD_NTH") ? atoi(getenv("EEGLDM_GN_BWD_NTH")) : 1024;      // see gn_fwd_t
+    // default: 256-thread blocks where they still cover >= 64-byte rows (L <= 384 in bf16): four independent blocks per CU interleave
+    // their load / reduce / store phases, 42-44 vs 47-49 us on the 50 MB tensors (tools/debug/gn_nth.py); at L = 768 the slab would be
+    // 16 channels wide (32-byte rows) and the 1024-thread block stays
+    const int nth = (bwd_nth == 512 || bwd_nth == 256) ? bwd_nth : ((!getenv("EEGLDM_GN_BWD_NTH") && sizeof(T) == 2 && L <= 384 && B % 8 == 0) ? 256 : 1024);
+    int rpt = 0; int cc = off ? 0 : resident_chunk(L, C, G, 0, sizeof(T) == 2 ? 12 : 8, &rpt, nth);
     // measured (tools/debug/gn_bench.py): the one-pass kernel wins while its blocks fit two rounds of one block per CU
     // (1024 blocks: 112 us one-pass vs 117-120 us split on the 100 MB tensors; 2048 blocks of 96-channel chunks lose)
     static const long bwd_bpc = getenv("EEGLDM_GN_BWD_BLOCKS_PER_CU") ? atol(getenv("EEGLDM_GN_BWD_BLOCKS_PER_CU")) : 8;
     static const int bwd_minrow = getenv("EEGLDM_GN_BWD_MIN_ROW_BYTES") ? atoi(getenv("EEGLDM_GN_BWD_MIN_ROW_BYTES")) : 128;
-    if (cc && (cc * (int)sizeof(T) < bwd_minrow || (long)(C / cc) * B > bwd_bpc * ctx->num_cu)) cc = 0;
+    static const bool no_xcd = getenv("EEGLDM_GN_NO_XCD") != nullptr;
+    static const int narrow_min = getenv("EEGLDM_GN_NARROW_MIN_ROW") ? atoi(getenv("EEGLDM_GN_NARROW_MIN_ROW")) : 32;
+    const bool can_xcd = !no_xcd && B % 8 == 0;
+    const int min_row = nth == 1024 ? (can_xcd && narrow_min < bwd_minrow ? narrow_min : bwd_minrow) : 32;
+    if (cc && (cc * (int)sizeof(T) < min_row || (long)(C / cc) * B > bwd_bpc * ctx->num_cu * (1024 / nth))) cc = 0;
     if (cc) {
-      const dim3 grid(C / cc, B);
+      const int xcd = ((nth < 1024 || cc * (int)sizeof(T) < 128) && can_xcd) ? 1 : 0;
+      const dim3 grid((unsigned)((long)(C / cc) * B));
       // a caller that can run the 7-us fold of the dgamma / dbeta partial slots elsewhere (side stream) gets them in the second slot
       // region and calls op_gn_slot_reduce_deferred itself
       static const bool no_defer = getenv("EEGLDM_GN_NO_DEFER") != nullptr;
       const bool defer = slots_deferred && dgamma && !no_defer;
       float* slots = dgamma ? (float*)((char*)ctx->scratch + (defer ? gn_slot_region(defer_region) : GN_SLOT_OFFSET)) : nullptr;
-#define GN_BWD_RES2(R, RAW, SL) hipLaunchKernelGGL((gn_bwd_resident_kernel<T, R, RAW, SL>), grid, dim3(NTB), 0, ctx->stream, (const T*)x, ldx, gamma, beta, stats, \
-                                         (const T*)dy, lddy, (T*)dx, lddx, (const T*)dxr, lddxr, slots, colsum_ps, ldps, L, C, G, silu, resample, cc, (const T*)dxr2, lddxr2)
+#define GN_BWD_RES3(R, RAW, SL, N) hipLaunchKernelGGL((gn_bwd_resident_kernel<T, R, RAW, SL, N>), grid, dim3(N), 0, ctx->stream, (const T*)x, ldx, gamma, beta, stats, \
+                                         (const T*)dy, lddy, (T*)dx, lddx, (const T*)dxr, lddxr, slots, colsum_ps, ldps, L, C, G, silu, resample, cc, (const T*)dxr2, lddxr2, xcd)
+#define GN_BWD_RES2(R, RAW, SL) do { if (nth == 1024) GN_BWD_RES3(R, RAW, SL, 1024); else if (nth == 512) GN_BWD_RES3(R, RAW, SL, 512); else GN_BWD_RES3(R, RAW, SL, 256); } while (0)
       static const bool raw0 = getenv("EEGLDM_GN_NO_RAW0") == nullptr;
 #define GN_BWD_RES1(R, RAW) do { if (silu) GN_BWD_RES2(R, RAW, true); else GN_BWD_RES2(R, RAW, false); } while (0)
 #define GN_BWD_RES(R) do { if (resample == 0 && raw0) GN_BWD_RES1(R, true); else GN_BWD_RES1(R, false); } while (0)
@@ -733,6 +768,7 @@ int gn_bwd_t(eegldm_ctx* ctx, const void* x, long ldx, const float* gamma, const
 #undef GN_BWD_RES
 #undef GN_BWD_RES1
 #undef GN_BWD_RES2
+#undef GN_BWD_RES3
       LAUNCH_CHECK();
       if (slots && !defer) {
         hipLaunchKernelGGL(gn_slot_reduce_kernel, dim3((2 * C + 255) / 256), dim3(256), 0, ctx->stream, slots, dgamma, dbeta, C, (double*)ctx->scratch, 0);
@@ -1118,6 +1154,8 @@ int op_groupnorm_bwd(eegldm_ctx* ctx, const void* x, long ldx, const float* gamm
 
 // folds the second slot area into dgamma / dbeta (and re-zeroes it): the deferred half of op_groupnorm_bwd(..., slots_deferred)
 int op_gn_slot_reduce_deferred(eegldm_ctx* ctx, float* dgamma, float* dbeta, int C, int region) {
+  static const bool dbg_skip = getenv("EEGLDM_DBG_SKIP_FOLDS") != nullptr;      // timing experiment only: leaves dgamma / dbeta unfolded
+  if (dbg_skip) return 0;
   float* slots = (float*)((char*)ctx->scratch + gn_slot_region(region));
   hipLaunchKernelGGL(gn_slot_reduce_kernel, dim3((2 * C + 255) / 256), dim3(256), 0, ctx->stream, slots, dgamma, dbeta, C, (double*)ctx->scratch, 0);
   LAUNCH_CHECK();

@@ -21,6 +21,10 @@ int op_conv_fwd(eegldm_ctx* ctx, int dtype, const void* x, long ldx, const void*
     return dconv_run(ctx, dtype, false, x, ldx, w, bias, resid, ldr, y, ldy, B, Lin, Lout, Cin, Cout, K, stride, pad_l, act_slope);
   }
   EEG_CHECK(act_slope <= 0.f, "fused activation is only available on the thin-input direct conv");
+  if (K == 3 && stride == 1 && pad_l == 1 && pad_r == 1) {      // HBM-bound wide-and-shallow layers: weights stay in registers (conv_ws.hip)
+    const int rc = conv_ws_try(ctx, dtype, x, ldx, w, Cin, Cout, 0, bias, rowvec, ld_rowvec, resid, ldr, y, ldy, B, Lin);
+    if (rc != 0) return rc < 0 ? rc : 0;
+  }
   GemmArgs a = {};
   a.dtype = dtype; a.A = x; a.lda = ldx; a.B = w; a.ldb = Cin; a.sBt = (long)Cout * Cin; a.C = y; a.ldc = ldy;
   a.M = B * Lout; a.N = Cout; a.K = Cin; a.batch = 1; a.taps = K; a.alpha = 1.0f; a.bias = bias;
@@ -45,6 +49,10 @@ int op_conv_dgrad(eegldm_ctx* ctx, int dtype, const void* dy, long lddy, const v
   const int Lout = conv_lout(Lin, K, stride, pad_l, pad_r);
   if (conv_is_thin(Cin, Cout, dtype))
     return dconv_run(ctx, dtype, true, dy, lddy, w, nullptr, resid, ldr, dx, lddx, B, Lin, Lout, Cin, Cout, K, stride, pad_l);
+  if (K == 3 && stride == 1 && pad_l == 1 && pad_r == 1) {
+    const int rc = conv_ws_try(ctx, dtype, dy, lddy, w, Cin, Cout, 1, nullptr, nullptr, 0, resid, ldr, dx, lddx, B, Lin);
+    if (rc != 0) return rc < 0 ? rc : 0;
+  }
   GemmArgs a = {};
   a.dtype = dtype; a.A = dy; a.lda = lddy; a.B = w; a.ldb = Cin; a.sBt = (long)Cout * Cin; a.C = dx; a.ldc = lddx;
   a.M = B * Lin; a.N = Cin; a.K = Cout; a.batch = 1; a.taps = K; a.alpha = 1.0f; a.resid = resid; a.ldr = ldr;
@@ -113,6 +121,8 @@ int op_conv_wgrad(eegldm_ctx* ctx, int dtype, const void* x, long ldx, const voi
   // second round of 16 blocks that costs as much as the first
   static const bool split_ceil = getenv("EEGLDM_WGRAD_SPLIT_CEIL") != nullptr;
   long want = split_ceil ? ((long)ctx->num_cu * blocks_per_cu + tiles - 1) / tiles : ((long)ctx->num_cu * blocks_per_cu) / tiles;
+  static const int split_div = getenv("EEGLDM_WGRAD_SPLIT_DIV") ? atoi(getenv("EEGLDM_WGRAD_SPLIT_DIV")) : 1;   // experiment: fewer, longer splits (smaller launches that co-run with the main stream)
+  if (split_div > 1 && ctx->side_on) want = (want + split_div - 1) / split_div;
   long maxs = ((long)a.K + 8 * kstage - 1) / (8 * kstage);     // at least 8 stages per split
   if (want > maxs) want = maxs;
   a.splitk = (int)(want < 1 ? 1 : want);
