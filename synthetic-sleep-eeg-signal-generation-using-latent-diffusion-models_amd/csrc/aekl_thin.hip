@@ -16,7 +16,10 @@
 #include <stdlib.h>
 
 namespace {
-constexpr int NT = 512, NWAVE = NT / 64;
+#ifndef EEG_THIN_NT
+#define EEG_THIN_NT 512
+#endif
+constexpr int NT = EEG_THIN_NT, NWAVE = NT / 64;      // threads per window (developer builds: -DEEG_THIN_NT=1024)
 constexpr int MC = THIN_MAXC;
 constexpr float GN_EPS_T = 1e-6f;
 constexpr int RED_FLOATS = NWAVE * 56 + 64;

@@ -735,10 +735,12 @@ int gn_bwd_t(eegldm_ctx* ctx, const void* x, long ldx, const float* gamma, const
   if constexpr (V == 4) {
     static const bool off = getenv("EEGLDM_GN_NO_RESIDENT") != nullptr;
     static const int bwd_nth = getenv("EEGLDM_GN_BWD_NTH") ? atoi(getenv("EEGLDM_GN_BWD_NTH")) : 1024;      // see gn_fwd_t
-    // default: 256-thread blocks where they still cover >= 64-byte rows (L <= 384 in bf16): four independent blocks per CU interleave
-    // their load / reduce / store phases, 42-44 vs 47-49 us on the 50 MB tensors (tools/debug/gn_nth.py); at L = 768 the slab would be
-    // 16 channels wide (32-byte rows) and the 1024-thread block stays
-    const int nth = (bwd_nth == 512 || bwd_nth == 256) ? bwd_nth : ((!getenv("EEGLDM_GN_BWD_NTH") && sizeof(T) == 2 && L <= 384 && B % 8 == 0) ? 256 : 1024);
+    // 256-thread blocks (EEGLDM_GN_BWD_NTH=256) measure 42-44 vs 47-49 us on the 50 MB tensors at L <= 384 (tools/debug/gn_nth.py) and
+    // are bit-exact and deterministic in isolation (tools/debug/gn_det2.py .. gn_det4.py) -- but inside the UNet backward, with the
+    // weight-gradient GEMMs of the side stream running beside them, the input gradient came out WRONG (40 % of the elements off by up
+    // to 3 % of the maximum, tools/debug/det_unet.py; correct again with EEGLDM_NO_SIDE_STREAM=1).  The cause was not found in the
+    // time available, so the default stays at 1024 threads and the narrow blocks are a developer switch only.
+    const int nth = (bwd_nth == 512 || bwd_nth == 256) ? bwd_nth : 1024;
     int rpt = 0; int cc = off ? 0 : resident_chunk(L, C, G, 0, sizeof(T) == 2 ? 12 : 8, &rpt, nth);
     // measured (tools/debug/gn_bench.py): the one-pass kernel wins while its blocks fit two rounds of one block per CU
     // (1024 blocks: 112 us one-pass vs 117-120 us split on the 100 MB tensors; 2048 blocks of 96-channel chunks lose)
