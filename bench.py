@@ -57,13 +57,17 @@ def load_pmc(name):
 
 
 # ---------------------------------------------------------------- algorithmic byte model
-def aekl_gan_step_bytes(num_channels, L, s, n_res=2, d_ch=64, d_layers=3):
+def aekl_gan_step_bytes(num_channels, L, s, n_res=2, d_ch=64, d_layers=3, fused=False):
     """Algorithmic HBM bytes of ONE window through the AEKL/GAN train step, by the survey's layer-granular formula
     bytes_fwd = sum_conv (|in| + |out|) s + sum_norm/act 2 |in| s (+ parameters, negligible per window);
     bytes_step = 3 x bytes_fwd of everything that runs forward AND backward: the autoencoder once, the discriminator three
-    times (generator pass, fake, real).  s = storage bytes per activation element."""
+    times (generator pass, fake, real).  s = storage bytes per activation element.
+    fused=True: the FUSED FLOOR -- every normalisation / activation rides on a convolution's operand load or store (GroupNorm / BatchNorm
+    statistics from the producing conv's epilogue, apply + SiLU / LeakyReLU on the consumer's load), so only the convolutions' own
+    |in| + |out| remain.  The layer-granular figure bills every BatchNorm / LeakyReLU pass as necessary and flatters the fraction."""
+    na = 0 if fused else 1          # norm / activation passes counted?
     def res(c_in, c_out, l):
-        e = 2 * c_in * l + (c_in + c_out) * l + 2 * c_out * l + 2 * c_out * l      # norm1, conv1, norm2, conv2
+        e = na * 2 * c_in * l + (c_in + c_out) * l + na * 2 * c_out * l + 2 * c_out * l      # norm1, conv1, norm2, conv2
         return e + ((c_in + c_out) * l if c_in != c_out else 0)
     nc = list(num_channels)
     e, l, c = (1 + nc[0]) * L, L, nc[0]                                              # encoder conv_in
@@ -72,19 +76,19 @@ def aekl_gan_step_bytes(num_channels, L, s, n_res=2, d_ch=64, d_layers=3):
             e += res(c, co, l); c = co
         if i != len(nc) - 1:
             e += c * l + c * l // 2; l //= 2
-    e += 2 * c * l + (c + 1) * l + 2 * 2 * l                                         # norm, conv -> latent, mu / log-sigma heads
+    e += na * 2 * c * l + (c + 1) * l + 2 * 2 * l                                    # norm, conv -> latent, mu / log-sigma heads
     e += 2 * l + (1 + c) * l                                                         # decoder: post_quant, conv_in
     for i, co in enumerate(reversed(nc)):
         for _ in range(n_res):
             e += res(c, co, l); c = co
         if i != len(nc) - 1:
-            e += c * l + c * 2 * l + 2 * c * 2 * l; l *= 2                           # nearest x2 + conv
-    e += 2 * c * l + (c + 1) * l
+            e += na * (c * l + c * 2 * l) + (c * 2 * l + c * 2 * l if fused else 2 * c * 2 * l); l *= 2   # nearest x2 (+ its own pass when unfused) + conv
+    e += na * 2 * c * l + (c + 1) * l
     ae = e
-    d, l, c = L + d_ch * L // 2 + 2 * d_ch * L // 2, L // 2, d_ch                   # conv s2 + LeakyReLU
+    d, l, c = L + d_ch * L // 2 + na * 2 * d_ch * L // 2, L // 2, d_ch              # conv s2 + LeakyReLU
     for j in range(d_layers):
         st = 1 if j == d_layers - 1 else 2
-        d += c * l + 2 * c * (l // st) + 2 * 2 * c * (l // st); l //= st; c *= 2     # conv + BatchNorm/LeakyReLU
+        d += c * l + 2 * c * (l // st) + na * 2 * 2 * c * (l // st); l //= st; c *= 2     # conv + BatchNorm/LeakyReLU
     d += (c + 1) * l
     return 3 * s * (ae + 3 * d)
 
@@ -356,13 +360,13 @@ def main():
         # were collected on and `traffic_stale` says whether that is still the build being timed.
         traffic, traffic_src, traffic_stale, mfma_util = None, None, None, None
         if args.dtype == "bf16" and args.batch == 256:
-            for fname in ("r02_pmc_hbm_traffic.json", "r01_pmc_hbm_traffic.json"):
+            for fname in ("r03_pmc_hbm_traffic.json", "r02_pmc_hbm_traffic.json", "r01_pmc_hbm_traffic.json"):
                 pj, stale = load_pmc(fname)
                 if pj and k in pj.get("classes", {}):
                     traffic = round(pj["classes"][k]["hbm_bytes_per_launch"]); traffic_stale = bool(stale)
                     traffic_src = f"profiles/{fname} (bytes per launch, B=256 bf16)"
                     break
-            for fname in ("r02_pmc_mfma_busy.json", "r01_pmc_mfma_busy.json"):
+            for fname in ("r03_pmc_mfma_busy.json", "r02_pmc_mfma_busy.json", "r01_pmc_mfma_busy.json"):
                 pm, _st = load_pmc(fname)
                 if pm and k in pm.get("classes", {}):
                     mfma_util = pm["classes"][k]["MfmaUtil_pct"]
@@ -404,13 +408,21 @@ def main():
         esz = 2 if args.dtype == "bf16" else 4
         abytes = aekl_gan_step_bytes([2, 2, 4], 4 * L, esz) * Ba + 16 * (int(ae2.flat.numel()) + int(disc.flat.numel()))
         hbm_ach = abytes / dtg / 1e9
-        pj, stale = load_pmc("r02_pmc_aekl_step.json")
+        fbytes = aekl_gan_step_bytes([2, 2, 4], 4 * L, esz, fused=True) * Ba + 16 * (int(ae2.flat.numel()) + int(disc.flat.numel()))
+        fused_ach = fbytes / dtg / 1e9
+        pj, stale = load_pmc("r03_pmc_aekl_step.json")
+        aekl_pmc_name = "r03_pmc_aekl_step.json"
+        if pj is None:
+            pj, stale = load_pmc("r02_pmc_aekl_step.json"); aekl_pmc_name = "r02_pmc_aekl_step.json"
         parts["aekl_gan_train_step"] = {"windows_per_s": round(Ba / dtg, 1), "ms_per_step": round(1e3 * dtg, 3), "batch": Ba,
                                         "roofline": {"bound": "hbm", "achieved": round(hbm_ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                                      "frac": round(hbm_ach / HBM_PEAK_GBS, 4),
                                                      "algorithmic_bytes_per_step": int(abytes), "algorithmic_MB_per_window": round(abytes / Ba / 1e6, 2),
+                                                     "fused_floor": {"algorithmic_bytes_per_step": int(fbytes), "algorithmic_MB_per_window": round(fbytes / Ba / 1e6, 2),
+                                                                     "achieved": round(fused_ach, 1), "frac": round(fused_ach / HBM_PEAK_GBS, 4),
+                                                                     "model": "only the convolutions' |in| + |out| (norm / activation passes fused away), x3 for fwd + bwd, D three times"},
                                                      "traffic": (round(pj["hbm_bytes_per_step"]) if pj else None),
-                                                     "traffic_source": ("profiles/r02_pmc_aekl_step.json (FETCH_SIZE x2 + WRITE_SIZE summed over the step's kernels)" if pj else None),
+                                                     "traffic_source": (f"profiles/{aekl_pmc_name} (FETCH_SIZE x2 + WRITE_SIZE summed over the step's kernels)" if pj else None),
                                                      "traffic_stale": (bool(stale) if pj else None),
                                                      "flops_view": {"gflop_per_window": 3.76, "achieved_tflops": round(3.76e9 * Ba / dtg / 1e12, 1),
                                                                     "frac_of_mfma_peak": round(3.76e9 * Ba / dtg / 1e12 / MFMA_PEAK_TFLOPS[args.dtype], 4)}},
@@ -439,7 +451,7 @@ def main():
                                          "roofline": {"bound": "mfma", "achieved": round(ddim_tf, 1), "peak": MFMA_PEAK_TFLOPS[args.dtype], "unit": "TFLOP/s",
                                                       "frac": round(ddim_tf / MFMA_PEAK_TFLOPS[args.dtype], 4)},
                                          "batch1_latency_ms": {k2: round(1e3 * v2, 2) for k2, v2 in lat.items()},
-                                         "batch1_windows_per_s": round(1.0 / lat["graph"], 2),
+                                         "batch1_windows_per_s": round(1.0 / min(lat.values()), 2), "batch1_default_mode": "eager",
                                          "config": "config_ldm.yaml UNet, DDIM-50 (scaled-linear 0.0015-0.0205, eta 0), decode [32,32,64], crop to 3000",
                                          "out_shape": list(out.shape), "gflop_per_window": 695.3}
 

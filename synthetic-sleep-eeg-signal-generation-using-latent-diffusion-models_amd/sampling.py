@@ -34,9 +34,11 @@ def _step_tables(scheduler):
 @torch.no_grad()
 def ddim_sample(unet, autoencoder, scheduler, noise, scale_factor=1.0, crop=36, use_graph=None, seed=0, info=None):
     """noise (B, lat, Ll) on the device -> (windows (B, out, 3072 - 2*crop), final latents).  ONE native call
-    (eegldm_sample): the scheduler loop, z / scale_factor and the decode run inside the library; the UNet forward is
-    replayed from a hipGraph (use_graph, default on; EEGLDM_NO_GRAPH=1 turns it off) because at the reference's batch
-    of one window per call (sample_trials.py:149-163) the host launch rate, not the GPU, bounds the latency.
+    (eegldm_sample): the scheduler loop, z / scale_factor and the decode run inside the library.  The UNet forward CAN be
+    replayed from a hipGraph (use_graph=True or EEGLDM_SAMPLE_GRAPH=1) but that is no longer the default: measured on
+    MI355X (rounds 2 and 3) the replay is SLOWER than the eager launches at the reference's batch of one window per call
+    (sample_trials.py:149-163: 92.6 vs 87 ms per 50-step window -- ROCm's graph launch does not shorten the ~5 us per
+    dependent kernel) and indistinguishable at batch 256, where launch overhead does not matter.
     `scheduler` may be a DDIMScheduler (eta 0) or a DDPMScheduler (ancestral steps; noise from the device Philox
     stream `seed`).  info (optional dict) receives {"graph": bool}."""
     unet.eval()
@@ -47,7 +49,7 @@ def ddim_sample(unet, autoencoder, scheduler, noise, scale_factor=1.0, crop=36, 
     ts, a_t, a_prev, beta, ancestral = _step_tables(scheduler)
     n = len(ts)
     if use_graph is None:
-        use_graph = os.environ.get("EEGLDM_NO_GRAPH") is None
+        use_graph = os.environ.get("EEGLDM_SAMPLE_GRAPH", "0") == "1" and os.environ.get("EEGLDM_NO_GRAPH") is None
     down = autoencoder.down if autoencoder is not None else 1
     out_c = autoencoder.out_channels if autoencoder is not None else Cc
     lat = torch.empty_like(x)

@@ -1,4 +1,4 @@
-"""Summarise the rocprofv3 passes collected by tools/profile_r02.sh (all --output-format csv) into the files under profiles/:
+"""Summarise the rocprofv3 passes collected by tools/profile_r03.sh (round prefix: EEGLDM_PROFILE_ROUND, default r03; round 2 used tools/profile_r02.sh (all --output-format csv) into the files under profiles/:
 
     python tools/pmc_traffic.py <prof_dir> <tag>
 
@@ -22,6 +22,7 @@ import re
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+RND = os.environ.get("EEGLDM_PROFILE_ROUND", "r03")        # prefix of the files written under profiles/
 GEMM = {("1", "0", "3"): "conv3_fwd_implicit_gemm", ("1", "1", "3"): "conv3_dgrad_implicit_gemm", ("2", "1", "3"): "conv_wgrad_splitk_gemm",
         ("0", "0", "1"): "gemm_nt", ("0", "1", "1"): "gemm_nn", ("2", "1", "1"): "gemm_tn"}
 
@@ -38,6 +39,9 @@ def source_hash():
 def family(name):
     """kernel name -> (GEMM class | kernel family, is_gemm)"""
     name = name.replace("(anonymous namespace)::", "").replace("void ", "")
+    m = re.search(r"conv3_ws_kernel<(\w+)>", name)      # weight-stationary 3-tap conv (conv_ws.hip): forward / data gradient
+    if m:
+        return ("conv3_dgrad_implicit_gemm" if m.group(1) in ("true", "1") else "conv3_fwd_implicit_gemm"), True
     m = re.search(r"gemm_kernel<([^>]*)>", name)
     if m:
         a = [x.strip() for x in m.group(1).split(",")]
@@ -125,8 +129,8 @@ def main(prof, tag):
                    "classes": {k: v for k, v in fam.items() if k in GEMM.values()},
                    "hbm_bound_families": {k: v for k, v in sorted(fam.items(), key=lambda kv: -kv[1]["hbm_bytes_per_launch"] * kv[1]["launches_sampled"])
                                           if k not in GEMM.values() and v["launches_sampled"] >= 2}},
-                  open(os.path.join(P, "r02_pmc_hbm_traffic.json"), "w"), indent=1)
-        print("wrote r02_pmc_hbm_traffic.json")
+                  open(os.path.join(P, f"{RND}_pmc_hbm_traffic.json"), "w"), indent=1)
+        print("wrote", RND + "_pmc_hbm_traffic.json")
     fam, tf, tw = per_family(os.path.join(prof, "pmc_aekl_FETCH_SIZE"), os.path.join(prof, "pmc_aekl_WRITE_SIZE"))
     if fam:
         n_steps = 8        # tools/debug/aekl_bench.py: 3 warm-up + 5 timed steps, all identical
@@ -135,8 +139,8 @@ def main(prof, tag):
                    "corrections": corr, "kernel_source_sha16": sha, "hbm_bytes_per_step": round((tf + tw) / n_steps),
                    "fetch_bytes_per_step": round(tf / n_steps), "write_bytes_per_step": round(tw / n_steps),
                    "families": dict(sorted(fam.items(), key=lambda kv: -kv[1]["hbm_bytes_per_launch"] * kv[1]["launches_sampled"]))},
-                  open(os.path.join(P, "r02_pmc_aekl_step.json"), "w"), indent=1)
-        print("wrote r02_pmc_aekl_step.json")
+                  open(os.path.join(P, f"{RND}_pmc_aekl_step.json"), "w"), indent=1)
+        print("wrote", RND + "_pmc_aekl_step.json")
     mu = read_counter(os.path.join(prof, "pmc_ldm_mfma"), "MfmaUtil")
     if mu:
         agg = {}
@@ -146,21 +150,21 @@ def main(prof, tag):
                 e = agg.setdefault(fam_, [0, 0.0]); e[0] += 1; e[1] += val
         json.dump({"source": "rocprofv3 --pmc MfmaUtil --kernel-trace, tools/debug/quick_bench.py bfloat16 256 768 2, EEGLDM_NO_SIDE_STREAM=1",
                    "kernel_source_sha16": sha, "classes": {k: {"launches_sampled": n, "MfmaUtil_pct": round(v / n, 2)} for k, (n, v) in agg.items()}},
-                  open(os.path.join(P, "r02_pmc_mfma_busy.json"), "w"), indent=1)
-        print("wrote r02_pmc_mfma_busy.json")
-    kernel_table(os.path.join(prof, "trace_ldm"), os.path.join(P, f"r02_ldm_step_bf16_B256_kernel_stats_{tag}.txt"),
+                  open(os.path.join(P, f"{RND}_pmc_mfma_busy.json"), "w"), indent=1)
+        print("wrote", RND + "_pmc_mfma_busy.json")
+    kernel_table(os.path.join(prof, "trace_ldm"), os.path.join(P, f"{RND}_ldm_step_bf16_B256_kernel_stats_{tag}.txt"),
                  "# EEGLDM_NO_SIDE_STREAM=1 rocprofv3 --kernel-trace --stats -- python bench.py --no-parts --no-cpu-baseline --steps 7")
-    kernel_table(os.path.join(prof, "trace_aekl"), os.path.join(P, f"r02_aekl_gan_step_bf16_B256_kernel_stats_{tag}.txt"),
+    kernel_table(os.path.join(prof, "trace_aekl"), os.path.join(P, f"{RND}_aekl_gan_step_bf16_B256_kernel_stats_{tag}.txt"),
                  "# EEGLDM_NO_SIDE_STREAM=1 rocprofv3 --kernel-trace --stats -- python tools/debug/aekl_bench.py 256 bfloat16   (8 steps)")
-    kernel_table(os.path.join(prof, "trace_parts"), os.path.join(P, f"r02_ddim50_and_pixel_dm_kernel_stats_{tag}.txt"),
+    kernel_table(os.path.join(prof, "trace_parts"), os.path.join(P, f"{RND}_ddim50_and_pixel_dm_kernel_stats_{tag}.txt"),
                  "# EEGLDM_NO_SIDE_STREAM=1 rocprofv3 --kernel-trace --stats -- python tools/debug/parts_bench.py   (DDIM-50 B=256 x2, B=1 x2; pixel DM 6 steps)")
-    for src, dst in (("bench_ldm_line.json", f"r02_ldm_step_bf16_B256_rocprofv3.bench_line_{tag}.json.txt"),):
+    for src, dst in (("bench_ldm_line.json", f"{RND}_ldm_step_bf16_B256_rocprofv3.bench_line_{tag}.json.txt"),):
         s = os.path.join(prof, src)
         if os.path.exists(s) and os.path.getsize(s):
             open(os.path.join(P, dst), "w").write(open(s).read())
     st = glob.glob(os.path.join(prof, "trace_ldm", "**", "*kernel_stats.csv"), recursive=True)
     if st:
-        open(os.path.join(P, f"r02_ldm_step_bf16_B256_rocprofv3_kernel_stats_{tag}.csv"), "w").write(open(st[0]).read())
+        open(os.path.join(P, f"{RND}_ldm_step_bf16_B256_rocprofv3_kernel_stats_{tag}.csv"), "w").write(open(st[0]).read())
 
 
 if __name__ == "__main__":
