@@ -64,6 +64,7 @@ extern "C" int eegldm_ctx_destroy(eegldm_ctx* c) {
   if (c->scratch) hipFree(c->scratch);
   if (c->zero_page) hipFree(c->zero_page);
   if (c->splitk_ws) hipFree(c->splitk_ws);
+  if (c->grp_dev) hipFree(c->grp_dev);
   if (c->owns_stream) hipStreamDestroy(c->stream);
   if (c->side) { hipStreamDestroy(c->side); hipEventDestroy(c->ev_fork); hipEventDestroy(c->ev_join); }
   delete c;

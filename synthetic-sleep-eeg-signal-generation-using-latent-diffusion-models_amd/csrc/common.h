@@ -34,6 +34,8 @@ void eegldm_set_error(const std::string& msg);
 #define LAUNCH_CHECK() HIP_TRY(hipGetLastError())
 
 // ---------------------------------------------------------------- context
+struct WgradRec;      // one deferred weight-gradient problem (defined below, after GemmArgs)
+struct GemmGroup;
 struct ProfRec { int cls; double flops; hipEvent_t a, b; int M, N, K, taps, splitk; };
 enum { PROF_CONV_FWD = 0, PROF_CONV_DGRAD = 1, PROF_CONV_WGRAD = 2, PROF_GEMM_NT = 3, PROF_GEMM_NN = 4, PROF_GEMM_TN = 5, PROF_NCLASS = 6 };
 
@@ -63,6 +65,12 @@ struct eegldm_ctx {
   bool l1_overwrite = false;      // eegldm_l1_loss writes da instead of accumulating (the caller skipped zeroing it)
   int bn_flip = 0; int bn_dirty[2] = {0, 0};   // BatchNorm sum areas alternate; each call's fold kernel re-zeroes the other one (losses.hip)
   double prof_bracket_ms = 0.0;   // elapsed time of an EMPTY event pair on this stream (calibrated by eegldm_prof_enable): subtracted per launch
+  // deferred weight gradients (ops.hip: op_conv_wgrad records instead of launching while defer_wgrad is set; op_wgrad_flush groups the
+  // records by shape and launches every group as one grouped GEMM).  Set by the UNet backward only.
+  bool defer_wgrad = false;
+  std::vector<struct WgradRec> wgrad_pending;
+  std::vector<struct GemmGroup> grp_host; struct GemmGroup* grp_dev = nullptr; int grp_cap = 0;   // cached group tables (gemm_launch_grouped)
+  int grp_slot = 0;
 };
 
 static inline size_t dtype_size(int dt) { return dt == EEGLDM_F32 ? 4 : 2; }
@@ -115,6 +123,7 @@ __device__ __forceinline__ float silu_grad_f(float z) {
 enum { GA_PLAIN = 0, GA_CONV = 1, GA_TR = 2 };
 enum { GB_NT = 0, GB_TR = 1 };
 
+constexpr int GEMM_MAX_GROUP = 12;
 struct GemmArgs {
   int dtype;             // EEGLDM_F32 / EEGLDM_BF16 (storage type of A, B, resid, and C unless out_f32)
   int amode, bmode;
@@ -146,5 +155,20 @@ struct GemmArgs {
   int wide_n;            // fused 3-tap weight gradient: use the 128-wide N tile (one block per CU)
   int xcd_swizzle;       // set by the launcher: XCD-aware tile order (see gemm_kernel)
   const void* zero_page; // >= 16 zero bytes in device memory (set by gemm_launch)
+  // GROUPED weight gradients (round 3): `batch` problems of identical shape and leading dimensions but unrelated addresses -- the same
+  // conv shape in different layers of the network -- run as ONE launch.  ngroup > 0: problem b reads A = grpA[b], B = grpB[b] (instead
+  // of A + b * sAb ...), adds its fused column sums into grpCS[b], and its folded result goes to grpDst[b] (gemm_launch_grouped).
+  int ngroup;
+  const struct GemmGroup* grp;       // DEVICE table of the group's pointers (a by-value array indexed by the block's problem number made
+                                     // hipcc spill the whole argument struct to scratch: 672 bytes per lane in 20 instantiations)
 };
+struct GemmGroup {      // per problem: operands, their leading dimensions (dY is often a column view of a wider concat buffer), bias-gradient and dW targets
+  const void* A[GEMM_MAX_GROUP]; const void* B[GEMM_MAX_GROUP]; float* CS[GEMM_MAX_GROUP]; float* Dst[GEMM_MAX_GROUP];
+  long lda[GEMM_MAX_GROUP]; long ldb[GEMM_MAX_GROUP];
+};
+struct WgradRec { GemmArgs a; long tiles; int kstage; float* dst; float* dbias; };
 int gemm_launch(eegldm_ctx* ctx, const GemmArgs& a);
+// grouped split-K weight gradient: a.ngroup problems whose pointers are in the HOST table `g` (a.batch / a.grp are set here), partial
+// tiles to the context workspace, ONE batched fold into the Dst buffers.  `slot` = position of this launch in the step's flush order:
+// the device copy of the table is cached per slot and re-uploaded only when its contents change (addresses repeat step after step).
+int gemm_launch_grouped(eegldm_ctx* ctx, const GemmArgs& a, const GemmGroup& g, int slot);

@@ -28,6 +28,7 @@
 // writes full 16-byte (fp32) / 8-byte (bf16) vectors -- whole 256-byte rows per 32 lanes --
 // with bias, timestep-embedding and residual adds done on those vectors.
 #include <stdlib.h>
+#include <string.h>
 
 #include "common.h"
 
@@ -240,9 +241,10 @@ void gemm_kernel(const GemmArgs p) {   // >= 2 waves per SIMD: <= 256 VGPR+AGPR
     // idx = (split, tap, tile) with the split slowest: the taps of a wgrad-by-tap launch (stride-2 convs) read the same dY rows and
     // overlapping X rows as well
     const int per_split = tiles * p.ztaps;
-    const int sp = idx / per_split, rem = idx - sp * per_split;
-    const int tap = rem / tiles, tile = rem - tap * tiles;
-    z = sp + p.splitk * tap;
+    const int spb = idx / per_split, rem = idx - spb * per_split;         // (problem, split) pair, the problem slowest: grouped launches keep
+    const int tap = rem / tiles, tile = rem - tap * tiles;               // one problem's splits on neighbouring XCD runs
+    const int pb = spb / p.splitk, sp = spb - pb * p.splitk;
+    z = sp + p.splitk * (tap + p.ztaps * pb);
     tile_n = tile % (int)gridDim.x; tile_m = tile / (int)gridDim.x;
   }
   const int n0 = tile_n * BN;
@@ -251,8 +253,10 @@ void gemm_kernel(const GemmArgs p) {   // >= 2 waves per SIMD: <= 256 VGPR+AGPR
   const int tz = z % p.ztaps;      z /= p.ztaps;
   const int bz = z;
 
-  const T* __restrict__ Ag = (const T*)p.A + (long)bz * p.sAb;
-  const T* __restrict__ Bg = (const T*)p.B + (long)bz * p.sBb;
+  const T* __restrict__ Ag = p.ngroup ? (const T*)p.grp->A[bz] : (const T*)p.A + (long)bz * p.sAb;
+  const T* __restrict__ Bg = p.ngroup ? (const T*)p.grp->B[bz] : (const T*)p.B + (long)bz * p.sBb;
+  float* const colsum_g = p.ngroup ? p.grp->CS[bz] : p.colsum;
+  const long lda_g = p.ngroup ? p.grp->lda[bz] : p.lda, ldb_g = p.ngroup ? p.grp->ldb[bz] : p.ldb;
 
   // K range of this block
   int kbeg = 0, kend = p.K;
@@ -290,7 +294,7 @@ void gemm_kernel(const GemmArgs p) {   // >= 2 waves per SIMD: <= 256 VGPR+AGPR
       const int row = c / C::SEGS, seg = nt_swz<KSUB>(row, c % C::SEGS);
       const int m = m0 + row, k = k0 + seg * C::EPC;
       ok = ok && m < p.M && k < kend;
-      off = (long)m * p.lda + k;
+      off = (long)m * lda_g + k;
     } else if constexpr (AMODE == GA_CONV) {
       const int row = c / C::SEGS, seg = nt_swz<KSUB>(row, c % C::SEGS);
       long fr = (long)m0 * STRIDE - p.pad_l + row;   // flattened virtual input row
@@ -301,7 +305,7 @@ void gemm_kernel(const GemmArgs p) {   // >= 2 waves per SIMD: <= 256 VGPR+AGPR
         ok = ok && (vv % p.ups) == 0 && (vv / p.ups) < p.Lsrc;
         fr = b * p.Lsrc + vv / p.ups;
       }
-      off = fr * p.lda + k;
+      off = fr * lda_g + k;
     } else {  // GA_TR: source [K][M], M contiguous
       constexpr int RCP = C::PITCH_A_TR / 16;
       const int krow = c / RCP, cs = c % RCP;
@@ -310,7 +314,7 @@ void gemm_kernel(const GemmArgs p) {   // >= 2 waves per SIMD: <= 256 VGPR+AGPR
       else seg = tr_swz<BM>(krow, cs * 16) >> 4;
       const int k = k0 + krow, m = m0 + seg * C::EPC;
       ok = ok && k < kend && m < p.M;
-      off = (long)k * p.lda + m;
+      off = (long)k * lda_g + m;
     }
     return ok;
   };
@@ -324,7 +328,7 @@ void gemm_kernel(const GemmArgs p) {   // >= 2 waves per SIMD: <= 256 VGPR+AGPR
       const int tw = p.tap_flip ? (TAPS - 1 - tap) : tap;
       ok = ok && n < p.N && k < kend;
       if (p.b_kblk) off = (long)tw * p.sBt + ((long)(k / C::KC) * p.N + n) * C::KC + (k % C::KC);   // [tap][K / KC][N][KC]
-      else off = (long)tw * p.sBt + (long)n * p.ldb + k;
+      else off = (long)tw * p.sBt + (long)n * ldb_g + k;
     } else {  // GB_TR: source [K][N], N contiguous
       constexpr int RCP = C::PITCH_B_TR / 16;
       const int tap = c / (C::B_ROWS_TR * RCP), r = c % (C::B_ROWS_TR * RCP);
@@ -338,7 +342,7 @@ void gemm_kernel(const GemmArgs p) {   // >= 2 waves per SIMD: <= 256 VGPR+AGPR
         // exactly the conv's zero padding because a K chunk never straddles a sample (Lout % KSTAGE == 0, checked on the host)
         const int xr = k0 + krow - 1;
         ok = ok && xr >= 0 && xr < p.K && (xr / p.Lout) == (k0 / p.Lout) && n < p.N;
-        off = (long)xr * p.ldb + n;
+        off = (long)xr * ldb_g + n;
         return ok;
       }
       const int k = k0 + krow;
@@ -347,10 +351,10 @@ void gemm_kernel(const GemmArgs p) {   // >= 2 waves per SIMD: <= 256 VGPR+AGPR
         const int bs = k / p.Lout, lo = k - bs * p.Lout;
         const int vv = lo * p.stride + tz - p.pad_l;
         ok = ok && vv >= 0 && vv < p.Lin;
-        off = ((long)bs * p.Lin + vv) * p.ldb + n;
+        off = ((long)bs * p.Lin + vv) * ldb_g + n;
       } else {
         const int tw = p.tap_flip ? (TAPS - 1 - tap) : tap;
-        off = (long)tw * p.sBt + (long)k * p.ldb + n;
+        off = (long)tw * p.sBt + (long)k * ldb_g + n;
       }
     }
     return ok;
@@ -362,8 +366,8 @@ void gemm_kernel(const GemmArgs p) {   // >= 2 waves per SIMD: <= 256 VGPR+AGPR
   long astep = 0, bstep = 0;     // elements per stage
   unsigned btop = 0, bbot = 0;   // WG3: bit i set -> this lane's chunk of B instruction i lies in the top / bottom halo row
   if constexpr (C::USE_DMA) {
-    astep = (AMODE == GA_TR) ? (long)C::KSTAGE * p.lda : (long)C::KSTAGE;   // conv / plain A is K-contiguous, TR A is K-strided
-    bstep = (BMODE == GB_NT) ? (p.b_kblk ? (long)KSUB * p.N * C::KC : (long)C::KSTAGE) : (long)C::KSTAGE * p.ldb;
+    astep = (AMODE == GA_TR) ? (long)C::KSTAGE * lda_g : (long)C::KSTAGE;   // conv / plain A is K-contiguous, TR A is K-strided
+    bstep = (BMODE == GB_NT) ? (p.b_kblk ? (long)KSUB * p.N * C::KC : (long)C::KSTAGE) : (long)C::KSTAGE * ldb_g;
 #pragma unroll
     for (int i = 0; i < C::IA; i++) { long off; const bool ok = a_dec((wave + NW * i) * 64 + lane, kbeg, off); apre[i] = ok ? Ag + off : nullptr; }
 #pragma unroll
@@ -380,7 +384,7 @@ void gemm_kernel(const GemmArgs p) {   // >= 2 waves per SIMD: <= 256 VGPR+AGPR
         ok = ok && n < p.N;
         if (krow == 0) btop |= 1u << i;
         if (krow == C::KSTAGE + 1) bbot |= 1u << i;
-        bpre[i] = ok ? Bg + ((long)(kbeg + krow - 1) * p.ldb + n) : nullptr;
+        bpre[i] = ok ? Bg + ((long)(kbeg + krow - 1) * ldb_g + n) : nullptr;
       } else {
         long off; const bool ok = b_dec(c, kbeg, off); bpre[i] = ok ? Bg + off : nullptr;
       }
@@ -479,7 +483,7 @@ void gemm_kernel(const GemmArgs p) {   // >= 2 waves per SIMD: <= 256 VGPR+AGPR
   f32x4 cs[C::COLSUM ? C::FM : 1];
   bool do_cs = false;
   if constexpr (C::COLSUM) {
-    do_cs = p.colsum != nullptr && tile_n == 0 && wn == 0 && tz == 0 && bz == 0;
+    do_cs = colsum_g != nullptr && tile_n == 0 && wn == 0 && tz == 0 && (bz == 0 || p.ngroup);
 #pragma unroll
     for (int i = 0; i < C::FM; i++) cs[i] = f32x4{0.f, 0.f, 0.f, 0.f};
   }
@@ -688,7 +692,7 @@ void gemm_kernel(const GemmArgs p) {   // >= 2 waves per SIMD: <= 256 VGPR+AGPR
 #pragma unroll
         for (int r = 0; r < 4; r++) {
           const int m = m0 + wm * (C::FM * 16) + i * 16 + q * 4 + r;
-          if (m < p.M) atomicAdd(p.colsum + m, cs[i][r]);
+          if (m < p.M) atomicAdd(colsum_g + m, cs[i][r]);
         }
     }
   }
@@ -967,7 +971,7 @@ int launch_k(eegldm_ctx* ctx, const GemmArgs& a_in) {
   if (a_in.xcd_swizzle) {
     if (AMODE == GA_TR && a.splitk > 1) {
       static const bool no_any = getenv("EEGLDM_GEMM_NO_SPLITK_SWIZZLE_ANY") != nullptr;
-      if (a.batch == 1 && a.k_skew == 0.f && !no_any && (long)grid.x * grid.y * a.ztaps > 1) a.xcd_swizzle = 3;   // (also wgrad-by-tap: ztaps = 3)
+      if ((a.batch == 1 || a.ngroup) && a.k_skew == 0.f && !no_any && (long)grid.x * grid.y * a.ztaps > 1) a.xcd_swizzle = 3;   // (also wgrad-by-tap: ztaps = 3; grouped problems)
       else if (a.batch * a.ztaps == 1 && grid.x * grid.y > 1) {
         if (a.k_skew == 0.f && !no_any) a.xcd_swizzle = 3;          // equal chunks: contiguous runs, any split count
         else if (a.splitk % 8 == 0) a.xcd_swizzle = 2;             // skewed chunks: interleave the splits over the XCDs (mixes chunk lengths)
@@ -1116,6 +1120,89 @@ __global__ __launch_bounds__(256) void splitk_fold_kernel(const float* __restric
     d.x += s.x; d.y += s.y; d.z += s.z; d.w += s.w;
     *(float4*)(dst + i) = d;
   }
+}
+
+// dst_b[i] += sum_r ws[(b * nsplit + r) * n + i] for every problem b of a grouped launch (blockIdx.y = b)
+__global__ __launch_bounds__(256) void splitk_fold_grouped_kernel(const float* __restrict__ ws, int nsplit, long n, const GemmGroup* __restrict__ grp) {
+  __shared__ float4 red[3][64];
+  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+  const long i = ((long)blockIdx.x * 64 + tx) * 4;
+  const bool ok = i < n;
+  const float* w = ws + (long)blockIdx.y * nsplit * n;
+  float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (ok) {
+    for (int r = ty; r < nsplit; r += 4) {
+      const float4 v = *(const float4*)(w + (long)r * n + i);
+      s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+    }
+  }
+  if (ty > 0) red[ty - 1][tx] = s;
+  __syncthreads();
+  if (ty == 0 && ok) {
+    float* dp = grp->Dst[blockIdx.y] + i;
+    float4 d = *(const float4*)dp;
+#pragma unroll
+    for (int k = 0; k < 3; k++) { const float4 v = red[k][tx]; s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w; }
+    d.x += s.x; d.y += s.y; d.z += s.z; d.w += s.w;
+    *(float4*)dp = d;
+  }
+}
+
+int gemm_launch_grouped(eegldm_ctx* ctx, const GemmArgs& a_in, const GemmGroup& g, int slot) {
+  GemmArgs a = a_in;
+  // device copy of the pointer table, cached per flush slot: the arena hands out the same addresses step after step, so after the first
+  // step nothing is uploaded; a changed table is re-uploaded after draining both streams (an earlier launch may still read the old one)
+  EEG_CHECK(slot >= 0 && slot < 4096, "group slot");
+  if (slot >= ctx->grp_cap) {
+    HIP_TRY(hipStreamSynchronize(ctx->stream)); if (ctx->side_on) HIP_TRY(hipStreamSynchronize(ctx->side));
+    const int cap = slot + 64;
+    GemmGroup* nd = nullptr; HIP_TRY(hipMalloc(&nd, sizeof(GemmGroup) * cap));
+    if (ctx->grp_dev) { HIP_TRY(hipMemcpy(nd, ctx->grp_dev, sizeof(GemmGroup) * ctx->grp_cap, hipMemcpyDeviceToDevice)); HIP_TRY(hipFree(ctx->grp_dev)); }
+    ctx->grp_dev = nd; ctx->grp_cap = cap; ctx->grp_host.resize(cap);
+  }
+  if ((int)ctx->grp_host.size() < ctx->grp_cap) ctx->grp_host.resize(ctx->grp_cap);
+  if (memcmp(&ctx->grp_host[slot], &g, sizeof(GemmGroup)) != 0) {
+    HIP_TRY(hipStreamSynchronize(ctx->stream)); if (ctx->side_on) HIP_TRY(hipStreamSynchronize(ctx->side));
+    HIP_TRY(hipMemcpy(ctx->grp_dev + slot, &g, sizeof(GemmGroup), hipMemcpyHostToDevice));
+    ctx->grp_host[slot] = g;
+  }
+  a.grp = ctx->grp_dev + slot;
+  EEG_CHECK(a.ngroup >= 1 && a.ngroup <= GEMM_MAX_GROUP && a.amode == GA_TR && a.bmode == GB_TR && a.ztaps == 1 && (a.taps == 1 || a.taps == 3), "not a groupable weight gradient");
+  const int epc = a.dtype == EEGLDM_F32 ? 4 : 8;
+  EEG_CHECK(a.M % epc == 0 && a.N % epc == 0 && a.N % 4 == 0, "operand alignment");
+  for (int i = 0; i < a.ngroup; i++) EEG_CHECK(g.lda[i] % epc == 0 && g.ldb[i] % epc == 0 && g.A[i] && g.B[i] && g.Dst[i], "group member %d: leading dimension / null pointer", i);
+  if (a.splitk < 1) a.splitk = 1;
+  a.batch = a.ngroup; a.out_f32 = 1; a.ups = 1; a.rows_per_vec = 1; a.ldc = a.N; a.sCt = (long)a.M * a.N; a.colsum = nullptr;
+  const long fold_n = (long)a.taps * a.M * a.N;
+  const int KST = 2 * (a.dtype == EEGLDM_F32 ? 16 : 32);
+  int per = (a.K + a.splitk - 1) / a.splitk; per = (per + KST - 1) / KST * KST;
+  a.splitk = (a.K + per - 1) / per;                     // every split writes its whole tile: no empty trailing splits
+  const size_t need = (size_t)a.ngroup * a.splitk * fold_n * sizeof(float);
+  if (ctx->splitk_ws_bytes < need) {
+    if (ctx->splitk_ws) { HIP_TRY(hipStreamSynchronize(ctx->stream)); if (ctx->side_on) HIP_TRY(hipStreamSynchronize(ctx->side)); HIP_TRY(hipFree(ctx->splitk_ws)); ctx->splitk_ws = nullptr; ctx->splitk_ws_bytes = 0; }
+    HIP_TRY(hipMalloc(&ctx->splitk_ws, need)); ctx->splitk_ws_bytes = need;
+  }
+  a.C = ctx->splitk_ws; a.sCk = fold_n; a.sCb = (long)a.splitk * fold_n; a.atomic_out = 0; a.k_skew = 0.f;
+  a.zero_page = ctx->zero_page;
+  { static const bool no_swz = getenv("EEGLDM_GEMM_NO_XCD_SWIZZLE") != nullptr; a.xcd_swizzle = no_swz ? 0 : 1; }
+  ProfRec rec; const bool prof = ctx->prof_on;
+  if (prof) {
+    rec.cls = a.taps == 3 ? PROF_CONV_WGRAD : PROF_GEMM_TN;
+    rec.flops = 2.0 * a.M * a.N * (double)a.K * a.taps * a.ngroup;
+    rec.M = a.M; rec.N = a.N; rec.K = a.K; rec.taps = a.taps; rec.splitk = a.splitk;
+    HIP_TRY(hipEventCreate(&rec.a)); HIP_TRY(hipEventCreate(&rec.b));
+    HIP_TRY(hipEventRecord(rec.a, ctx->stream));
+  }
+  int rc;
+  if (a.dtype == EEGLDM_F32) rc = launch_modes<float>(ctx, a);
+  else if (a.dtype == EEGLDM_BF16) rc = launch_modes<bf16_t>(ctx, a);
+  else EEG_FAIL(EEGLDM_ERR_UNSUPPORTED, "dtype %d", a.dtype);
+  if (rc == 0) {
+    hipLaunchKernelGGL(splitk_fold_grouped_kernel, dim3((unsigned)((fold_n / 4 + 63) / 64), a.ngroup), dim3(256), 0, ctx->stream, (const float*)ctx->splitk_ws, a.splitk, fold_n, a.grp);
+    LAUNCH_CHECK();
+  }
+  if (prof) { HIP_TRY(hipEventRecord(rec.b, ctx->stream)); ctx->prof.push_back(rec); }
+  return rc;
 }
 
 int gemm_launch(eegldm_ctx* ctx, const GemmArgs& a_in) {

@@ -93,6 +93,9 @@ int res_forward(NetBase* u, const ResDesc& r, const View& x, int B, int Lin, con
 int res_backward(NetBase* u, const ResDesc& r, const ResTape& t, const View& dout, const View& dx, float* demb_all,
                  const View* extra, int* extra_done) {
   eegldm_ctx* ctx = u->ctx; const int dt = u->dtype; const int B = t.B, Lin = t.Lin, Lout = t.Lout;
+  // deferred weight gradients (ctx->defer_wgrad): conv1's dY operand must outlive this block -> allocate it BELOW the release mark
+  View dh1_keep;
+  if (ctx->defer_wgrad && u->param_grads) { ALLOC_OR_FAIL(dh1_keep.p, u->alloc_act((long)B * t.Lout, r.cout)); dh1_keep.ld = r.cout; }
   Arena::Mark mk = u->arena.mark();
   const bool pg = u->param_grads;
   View dxr = dout;
@@ -128,7 +131,8 @@ int res_backward(NetBase* u, const ResDesc& r, const ResTape& t, const View& dou
       EEG_TRY(ew_colsum(ctx, dout.p, dout.ld, nullptr, 0, u->G(r.c2_b), B, Lout, r.cout, dt));
     }
   }
-  View dh1; ALLOC_OR_FAIL(dh1.p, u->alloc_act((long)B * Lout, r.cout)); dh1.ld = r.cout;
+  View dh1 = dh1_keep;
+  if (!dh1.p) { ALLOC_OR_FAIL(dh1.p, u->alloc_act((long)B * Lout, r.cout)); dh1.ld = r.cout; }
   // h1 = conv(a1) + b1 + emb_out[b]: the per-sample column sums of dh1 feed the embedding MLP, their total is db1.
   // The one-pass GroupNorm backward produces them while dh1 is still in registers; otherwise a separate column sum.
   float* ps = nullptr; long ldps = 0;
@@ -190,11 +194,14 @@ int attn_forward(NetBase* u, const AttnDesc& a, const View& x, int B, int T, con
 
 int attn_backward(NetBase* u, const AttnDesc& a, const AttnTape& t, const View& dout, const View& dx) {
   eegldm_ctx* ctx = u->ctx; const int dt = u->dtype; const int C = a.c, B = t.B, T = t.T; constexpr int AG = 32;
+  void* dqkv_keep = nullptr;      // deferred weight gradients: the qkv conv's dY operand must outlive this block
+  if (ctx->defer_wgrad && u->param_grads) ALLOC_OR_FAIL(dqkv_keep, u->alloc_act((long)B * T, 3 * C));
   Arena::Mark mk = u->arena.mark();
   EEG_TRY(op_conv_wgrad(ctx, dt, t.o.p, C, dout.p, dout.ld, u->G(a.pr_w), u->G(a.pr_b), B, T, C, C, 1, 1, 0, 0));
   void* d_o; ALLOC_OR_FAIL(d_o, u->alloc_act((long)B * T, C));
   EEG_TRY(op_conv_dgrad(ctx, dt, dout.p, dout.ld, u->W(a.pr_w), d_o, C, B, T, C, C, 1, 1, 0, 0, nullptr, 0));
-  void* dqkv; ALLOC_OR_FAIL(dqkv, u->alloc_act((long)B * T, 3 * C));
+  void* dqkv = dqkv_keep;
+  if (!dqkv) ALLOC_OR_FAIL(dqkv, u->alloc_act((long)B * T, 3 * C));
   float* dprobs; ALLOC_OR_FAIL(dprobs, (float*)u->arena.alloc(sizeof(float) * (size_t)B * T * T));
   void* dlogits; ALLOC_OR_FAIL(dlogits, u->alloc_act((long)B * T, T));
   EEG_TRY(op_attention_bwd(ctx, dt, t.qkv.p, 3 * C, t.probs, d_o, C, dqkv, 3 * C, dprobs, dlogits, B, T, C));

@@ -5,6 +5,7 @@
 
 #include "common.h"
 #include "internal.h"
+#include <string.h>
 
 static inline int conv_lout(int Lin, int K, int stride, int pad_l, int pad_r) { return (Lin + pad_l + pad_r - K) / stride + 1; }
 
@@ -126,7 +127,60 @@ int op_conv_wgrad(eegldm_ctx* ctx, int dtype, const void* x, long ldx, const voi
   long maxs = ((long)a.K + 8 * kstage - 1) / (8 * kstage);     // at least 8 stages per split
   if (want > maxs) want = maxs;
   a.splitk = (int)(want < 1 ? 1 : want);
+  // Deferred mode (the UNet backward): record the problem instead of launching it; op_wgrad_flush() later runs all layers of one
+  // shape as ONE grouped launch with far fewer K splits.  Eligible = what gemm_launch would send through the split-K workspace:
+  // the fused 3-tap kernel or a 1x1 conv, K a whole number of stages, contiguous dW.
+  if (ctx->defer_wgrad && (fused3 || (K == 1 && stride == 1 && pad_l == 0 && pad_r == 0)) && a.K % kstage == 0 && !a.wide_n &&
+      a.M % 16 == 0 && a.N % 4 == 0) {
+    WgradRec r; r.a = a; r.tiles = tiles; r.kstage = kstage; r.dst = dw; r.dbias = bias_in_gemm ? dbias : nullptr;
+    r.a.colsum = nullptr; r.a.C = nullptr;
+    ctx->wgrad_pending.push_back(r);
+    return 0;
+  }
+  { static const bool dbg_groups = getenv("EEGLDM_DBG_GROUPS") != nullptr;
+    if (dbg_groups && ctx->defer_wgrad) fprintf(stderr, "wgrad NOT deferred: K %d stride %d pads %d %d Cin %d Cout %d rows %d fused3 %d kstage %d wide %d\n", K, stride, pad_l, pad_r, Cin, Cout, a.K, (int)fused3, kstage, a.wide_n); }
   return gemm_launch(ctx, a);
+}
+
+// Launch the deferred weight gradients (ctx->wgrad_pending): problems with identical (taps, M, N, K, leading dimensions, conv geometry)
+// -- the same conv shape in different layers -- go out as ONE grouped launch of up to GEMM_MAX_GROUP problems.  The split count is
+// chosen per group from a cost model in K-stage units: rounds x (stages per block + fixed prologue / epilogue cost); a single layer
+// fills the chip only by cutting K into 16-256 splits (12-48 stages per block, 50 MB of partial tiles per launch whatever the
+// layer), a group of n layers needs n times fewer.
+int op_wgrad_flush(eegldm_ctx* ctx) {
+  std::vector<WgradRec> recs; recs.swap(ctx->wgrad_pending);
+  if (recs.empty()) return 0;
+  // (ctx->grp_slot counts the grouped launches of the current backward: unet.hip resets it when the backward starts)
+  std::vector<char> done(recs.size(), 0);
+  const long slots = (long)ctx->num_cu * 2;
+  for (size_t i = 0; i < recs.size(); i++) {
+    if (done[i]) continue;
+    const GemmArgs& k = recs[i].a;
+    GemmArgs g = k; g.ngroup = 0;
+    GemmGroup tab; memset(&tab, 0, sizeof(tab));
+    for (size_t j = i; j < recs.size() && g.ngroup < GEMM_MAX_GROUP; j++) {
+      const GemmArgs& o = recs[j].a;
+      if (done[j] || o.dtype != k.dtype || o.taps != k.taps || o.ztaps != k.ztaps || o.M != k.M || o.N != k.N || o.K != k.K ||
+          o.Lout != k.Lout || o.Lin != k.Lin || o.conv_map != k.conv_map || recs[j].tiles != recs[i].tiles) continue;
+      tab.A[g.ngroup] = o.A; tab.B[g.ngroup] = o.B; tab.CS[g.ngroup] = recs[j].dbias; tab.Dst[g.ngroup] = recs[j].dst;
+      tab.lda[g.ngroup] = o.lda; tab.ldb[g.ngroup] = o.ldb;
+      g.ngroup++; done[j] = 1;
+    }
+    // split count: minimise rounds x (K stages per block + ~8 stages of fixed cost), a whisker of preference for fewer partial tiles
+    const long tiles_total = recs[i].tiles * g.ngroup, S = ((long)g.K + recs[i].kstage - 1) / recs[i].kstage;
+    long maxs = S / 8; if (maxs < 1) maxs = 1; if (maxs > 256) maxs = 256;
+    double best = 1e30; int bs = 1;
+    for (long sp = 1; sp <= maxs; sp++) {
+      const long blocks = tiles_total * sp, rounds = (blocks + slots - 1) / slots;
+      const double cost = (double)rounds * ((double)S / (double)sp + 8.0) + 0.004 * (double)blocks;
+      if (cost < best) { best = cost; bs = (int)sp; }
+    }
+    g.splitk = bs; g.batch = g.ngroup;
+    static const bool dbg_groups = getenv("EEGLDM_DBG_GROUPS") != nullptr;
+    if (dbg_groups) fprintf(stderr, "wgrad group: taps %d M %d N %d K %d x%d tiles %ld -> splitk %d\n", g.taps, g.M, g.N, g.K, g.ngroup, recs[i].tiles, bs);
+    EEG_TRY(gemm_launch_grouped(ctx, g, tab, ctx->grp_slot++));
+  }
+  return 0;
 }
 
 int op_linear(eegldm_ctx* ctx, int dtype, const void* x, long ldx, const void* w, long ldw, const float* bias, void* y, long ldy,
