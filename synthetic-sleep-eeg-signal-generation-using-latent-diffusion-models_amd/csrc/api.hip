@@ -47,13 +47,13 @@ extern "C" int eegldm_ctx_create(int device, void* stream, int own_stream, eegld
 // that issues its own collectives / copies must order them against
 extern "C" void* eegldm_ctx_stream(const eegldm_ctx* c) { return c ? (void*)c->stream : nullptr; }
 int ctx_fork(eegldm_ctx* c) {
-  if (!c->side_on || c->prof_on) return 0;
+  if (!c->side_on || c->prof_on || c->defer_wgrad) return 0;      // grouped weight gradients: nothing is left for the side stream
   HIP_TRY(hipEventRecord(c->ev_fork, c->stream));
   HIP_TRY(hipStreamWaitEvent(c->side, c->ev_fork, 0));
   return 0;
 }
 int ctx_join(eegldm_ctx* c) {
-  if (!c->side_on || c->prof_on) return 0;
+  if (!c->side_on || c->prof_on || c->defer_wgrad) return 0;
   HIP_TRY(hipEventRecord(c->ev_join, c->side));
   HIP_TRY(hipStreamWaitEvent(c->stream, c->ev_join, 0));
   return 0;
@@ -65,6 +65,8 @@ extern "C" int eegldm_ctx_destroy(eegldm_ctx* c) {
   if (c->zero_page) hipFree(c->zero_page);
   if (c->splitk_ws) hipFree(c->splitk_ws);
   if (c->grp_dev) hipFree(c->grp_dev);
+  if (c->gn_slot_arena) hipFree(c->gn_slot_arena);
+  if (c->gn_fold_dev) hipFree(c->gn_fold_dev);
   if (c->owns_stream) hipStreamDestroy(c->stream);
   if (c->side) { hipStreamDestroy(c->side); hipEventDestroy(c->ev_fork); hipEventDestroy(c->ev_join); }
   delete c;

@@ -71,6 +71,11 @@ struct eegldm_ctx {
   std::vector<struct WgradRec> wgrad_pending;
   std::vector<struct GemmGroup> grp_host; struct GemmGroup* grp_dev = nullptr; int grp_cap = 0;   // cached group tables (gemm_launch_grouped)
   int grp_slot = 0;
+  // batched dgamma / dbeta folds of the one-pass GroupNorm backward (norm.hip): in the deferred mode every launch gets its own 64-slot
+  // region of gn_slot_arena and ONE kernel folds all of them when the weight gradients are flushed
+  struct GnFoldRec { float* slots; float* dgamma; float* dbeta; int C; };
+  std::vector<GnFoldRec> gn_fold_pending, gn_fold_host;
+  float* gn_slot_arena = nullptr; GnFoldRec* gn_fold_dev = nullptr; int gn_fold_count = 0;
 };
 
 static inline size_t dtype_size(int dt) { return dt == EEGLDM_F32 ? 4 : 2; }
@@ -80,7 +85,7 @@ int ctx_join(eegldm_ctx* c);
 // RAII: launches inside the scope go to the side stream (pure GEMM work only: the context scratch belongs to the main stream)
 struct SideScope {
   eegldm_ctx* c; hipStream_t saved;
-  explicit SideScope(eegldm_ctx* ctx) : c(ctx), saved(ctx->stream) { if (c->side_on && !c->prof_on) c->stream = c->side; }   // serial while kernels are being timed
+  explicit SideScope(eegldm_ctx* ctx) : c(ctx), saved(ctx->stream) { if (c->side_on && !c->prof_on && !c->defer_wgrad) c->stream = c->side; }   // serial while kernels are being timed / in the grouped-weight-gradient mode
   ~SideScope() { c->stream = saved; }
 };
 

@@ -38,6 +38,7 @@ bool op_conv_fuses_act(int dtype, int Cin, int Cout, int K, long ldy);
 int op_conv_dgrad(eegldm_ctx*, int dtype, const void* dy, long lddy, const void* w, void* dx, long lddx,
                   int B, int Lin, int Cin, int Cout, int K, int stride, int pad_l, int pad_r, const void* resid, long ldr);
 bool op_wgrad_fuses_bias(int dtype, int Cin, int Cout);
+int op_gn_fold_flush(eegldm_ctx*);      // batched dgamma / dbeta folds recorded by the one-pass GroupNorm backward in the deferred mode (norm.hip)
 int op_wgrad_flush(eegldm_ctx*);      // launch the weight gradients recorded while ctx->defer_wgrad was set (grouped by shape)
 int op_conv_wgrad(eegldm_ctx*, int dtype, const void* x, long ldx, const void* dy, long lddy, float* dw, float* dbias,
                   int B, int Lin, int Cin, int Cout, int K, int stride, int pad_l, int pad_r);

@@ -147,7 +147,7 @@ int res_backward(NetBase* u, const ResDesc& r, const ResTape& t, const View& dou
   if (pg) {
     EEG_TRY(ctx_fork(ctx));                       // dh1 is ready
     SideScope side(ctx);
-    if (gn2_deferred) EEG_TRY(op_gn_slot_reduce_deferred(ctx, u->G(r.gn2_w), u->G(r.gn2_b), r.cout));   // dgamma / dbeta fold of GN2, off the main chain
+    if (gn2_deferred == 1) EEG_TRY(op_gn_slot_reduce_deferred(ctx, u->G(r.gn2_w), u->G(r.gn2_b), r.cout));   // dgamma / dbeta fold of GN2, off the main chain
     EEG_TRY(op_conv_wgrad(ctx, dt, t.a1.p, t.a1.ld, dh1.p, dh1.ld, u->G(r.c1_w), fb1e ? u->G(r.c1_b) : nullptr, B, Lout, r.cin, r.cout, 3, 1, 1, 1));
   }
   if (cs_done) {
@@ -163,7 +163,7 @@ int res_backward(NetBase* u, const ResDesc& r, const ResTape& t, const View& dou
   EEG_TRY(op_groupnorm_bwd(ctx, t.x.p, t.x.ld, u->P(r.gn1_w), u->P(r.gn1_b), t.st1, da1.p, da1.ld, dx.p, dx.ld, u->param_grads ? u->G(r.gn1_w) : nullptr, u->param_grads ? u->G(r.gn1_b) : nullptr,
                            B, Lin, r.cin, r.groups, 1, r.updown, dxr.p, dxr.ld, dt, nullptr, 0, nullptr,
                            extra ? extra->p : nullptr, extra ? extra->ld : 0, extra_done, pg ? &gn1_deferred : nullptr, 1 + u->gn_parity));
-  if (gn1_deferred) {   // folded inside the NEXT block's side-stream section (or by the executor's final flush); areas alternate, so the
+  if (gn1_deferred == 1) {   // folded inside the NEXT block's side-stream section (or by the executor's final flush); areas alternate, so the
     u->gn_pending.push_back({u->G(r.gn1_w), u->G(r.gn1_b), r.cin, 1 + u->gn_parity});   // block after that may write this one again
     u->gn_parity ^= 1;
   }

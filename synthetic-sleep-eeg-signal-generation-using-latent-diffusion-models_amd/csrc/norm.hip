@@ -16,6 +16,8 @@ namespace {
 constexpr int NT = 256;
 constexpr int MAXG_LDS = 1024;   // LDS accumulators per block (groups / channels)
 constexpr int GN_NSLOT = 64;     // partial dgamma/dbeta buffers
+constexpr int GN_FOLD_MAX = 96;                          // batched folds per flush (the config_ldm UNet has 42 + 7)
+constexpr size_t GN_REGION_FLOATS = (size_t)GN_NSLOT * 2 * 1024;   // one launch's slot region (C <= 1024): 512 KiB
 constexpr size_t GN_SLOT_OFFSET = 1u << 20;   // byte offset of the slot area inside ctx->scratch (64 slots x 2C floats <= 512 KiB)
 constexpr size_t GN_SLOT_OFFSET_B = (1u << 20) + (512u << 10);   // second slot area: partials whose fold the caller runs later (side stream)
 // third / fourth slot areas (alternating): folds the caller runs one ResBlock later, inside that block's side-stream section
@@ -787,6 +789,19 @@ int gn_bwd_t(eegldm_ctx* ctx, const void* x, long ldx, const float* gamma, const
       static const bool no_defer = getenv("EEGLDM_GN_NO_DEFER") != nullptr;
       const bool defer = slots_deferred && dgamma && !no_defer;
       float* slots = dgamma ? (float*)((char*)ctx->scratch + (defer ? gn_slot_region(defer_region) : GN_SLOT_OFFSET)) : nullptr;
+      // batched mode (the UNet backward with grouped weight gradients): this launch gets its OWN slot region and is folded together with
+      // all the others by op_gn_fold_flush -- 49 folds of 7 us become one launch
+      static const bool no_batch = getenv("EEGLDM_GN_NO_BATCHED_FOLD") != nullptr;
+      const bool batched = defer && ctx->defer_wgrad && !no_batch && C <= 1024 && ctx->gn_fold_count < GN_FOLD_MAX;
+      if (batched) {
+        if (!ctx->gn_slot_arena) {
+          HIP_TRY(hipMalloc(&ctx->gn_slot_arena, (size_t)GN_FOLD_MAX * GN_REGION_FLOATS * sizeof(float)));
+          HIP_TRY(hipMemsetAsync(ctx->gn_slot_arena, 0, (size_t)GN_FOLD_MAX * GN_REGION_FLOATS * sizeof(float), ctx->stream));
+        }
+        slots = ctx->gn_slot_arena + (size_t)ctx->gn_fold_count * GN_REGION_FLOATS;
+        ctx->gn_fold_pending.push_back({slots, dgamma, dbeta, C});
+        ctx->gn_fold_count++;
+      }
 #define GN_BWD_RES3(R, RAW, SL, N) hipLaunchKernelGGL((gn_bwd_resident_kernel<T, R, RAW, SL, N>), grid, dim3(N), 0, ctx->stream, (const T*)x, ldx, gamma, beta, stats, \
                                          (const T*)dy, lddy, (T*)dx, lddx, (const T*)dxr, lddxr, slots, colsum_ps, ldps, L, C, G, silu, resample, cc, (const T*)dxr2, lddxr2, xcd)
 #define GN_BWD_RES2(R, RAW, SL) do { if (nth == 1024) GN_BWD_RES3(R, RAW, SL, 1024); else if (nth == 512) GN_BWD_RES3(R, RAW, SL, 512); else GN_BWD_RES3(R, RAW, SL, 256); } while (0)
@@ -804,7 +819,7 @@ int gn_bwd_t(eegldm_ctx* ctx, const void* x, long ldx, const float* gamma, const
         hipLaunchKernelGGL(gn_slot_reduce_kernel, dim3((2 * C + 255) / 256), dim3(256), 0, ctx->stream, slots, dgamma, dbeta, C, (double*)ctx->scratch, 0);
         LAUNCH_CHECK();
       }
-      if (defer) *slots_deferred = 1;
+      if (defer) *slots_deferred = batched ? 2 : 1;       // 2: nothing left for the caller to fold
       if (colsum_done && colsum_ps) *colsum_done = 1;
       if (dxr2) *dxr2_done = 1;
       return 0;
@@ -1183,6 +1198,41 @@ int op_groupnorm_bwd(eegldm_ctx* ctx, const void* x, long ldx, const float* gamm
 }
 
 // folds the second slot area into dgamma / dbeta (and re-zeroes it): the deferred half of op_groupnorm_bwd(..., slots_deferred)
+namespace {
+__global__ void gn_slot_reduce_multi_kernel(const eegldm_ctx::GnFoldRec* __restrict__ tab) {
+  const eegldm_ctx::GnFoldRec r = tab[blockIdx.y];
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= 2 * r.C) return;
+  float s = 0.f;
+  for (int k = 0; k < GN_NSLOT; k++) { s += r.slots[(size_t)k * 2 * r.C + i]; r.slots[(size_t)k * 2 * r.C + i] = 0.f; }
+  if (i < r.C) r.dgamma[i] += s; else r.dbeta[i - r.C] += s;
+}
+}  // namespace
+// folds every slot region recorded since the last flush into its dgamma / dbeta (one launch); the device copy of the table is cached
+// (the same layers write the same regions step after step) and re-uploaded, after a stream drain, only when it changes
+int op_gn_fold_flush(eegldm_ctx* ctx) {
+  std::vector<eegldm_ctx::GnFoldRec>& pend = ctx->gn_fold_pending;
+  if (pend.empty()) return 0;
+  const int first = ctx->gn_fold_count - (int)pend.size();      // table position of this flush's first record
+  if (!ctx->gn_fold_dev) HIP_TRY(hipMalloc(&ctx->gn_fold_dev, sizeof(eegldm_ctx::GnFoldRec) * GN_FOLD_MAX));
+  if ((int)ctx->gn_fold_host.size() < GN_FOLD_MAX) ctx->gn_fold_host.resize(GN_FOLD_MAX, {nullptr, nullptr, nullptr, 0});
+  bool same = true; int maxc = 0;
+  for (size_t i = 0; i < pend.size(); i++) {
+    const eegldm_ctx::GnFoldRec &a = pend[i], &b = ctx->gn_fold_host[first + i];
+    same = same && a.slots == b.slots && a.dgamma == b.dgamma && a.dbeta == b.dbeta && a.C == b.C;
+    maxc = a.C > maxc ? a.C : maxc;
+  }
+  if (!same) {
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    HIP_TRY(hipMemcpy(ctx->gn_fold_dev + first, pend.data(), sizeof(eegldm_ctx::GnFoldRec) * pend.size(), hipMemcpyHostToDevice));
+    for (size_t i = 0; i < pend.size(); i++) ctx->gn_fold_host[first + i] = pend[i];
+  }
+  hipLaunchKernelGGL(gn_slot_reduce_multi_kernel, dim3((2 * maxc + 255) / 256, (unsigned)pend.size()), dim3(256), 0, ctx->stream, ctx->gn_fold_dev + first);
+  LAUNCH_CHECK();
+  pend.clear();
+  return 0;
+}
+
 int op_gn_slot_reduce_deferred(eegldm_ctx* ctx, float* dgamma, float* dbeta, int C, int region) {
   static const bool dbg_skip = getenv("EEGLDM_DBG_SKIP_FOLDS") != nullptr;      // timing experiment only: leaves dgamma / dbeta unfolded
   if (dbg_skip) return 0;

@@ -328,8 +328,8 @@ extern "C" int eegldm_unet_backward(eegldm_unet* u, const float* dy, float* dx_o
   static const bool no_grouped = getenv("EEGLDM_NO_GROUPED_WGRAD") != nullptr;
   struct DeferGuard {
     eegldm_ctx* c; bool on;
-    DeferGuard(eegldm_ctx* ctx_, bool on_) : c(ctx_), on(on_) { if (on) { c->defer_wgrad = true; c->grp_slot = 0; } }
-    ~DeferGuard() { if (on) { c->defer_wgrad = false; c->wgrad_pending.clear(); } }
+    DeferGuard(eegldm_ctx* ctx_, bool on_) : c(ctx_), on(on_) { if (on) { c->defer_wgrad = true; c->grp_slot = 0; c->gn_fold_count = 0; c->gn_fold_pending.clear(); } }
+    ~DeferGuard() { if (on) { c->defer_wgrad = false; c->wgrad_pending.clear(); c->gn_fold_pending.clear(); } }
   } defer_guard(ctx, !no_grouped && u->param_grads);
 
   float* demb_all; ALLOC_OR_FAIL(demb_all, (float*)u->arena.alloc(sizeof(float) * (size_t)B * u->etot));
@@ -364,7 +364,7 @@ extern "C" int eegldm_unet_backward(eegldm_unet* u, const float* dy, float* dx_o
   // gradients of out / output_blocks / middle_block are complete (in stream order): the host may start reducing them
   // across ranks while the input blocks' backward runs
   EEG_TRY(u->flush_gn_folds());   // the last middle ResBlock's deferred dgamma / dbeta fold
-  if (u->grad_hook) EEG_TRY(op_wgrad_flush(ctx));     // the hook promises final gradients for this slice: launch what is pending for it
+  if (u->grad_hook) { EEG_TRY(op_wgrad_flush(ctx)); EEG_TRY(op_gn_fold_flush(ctx)); }     // the hook promises final gradients for this slice: launch what is pending for it
   if (u->grad_hook) u->grad_hook(u->grad_hook_user, u->off_mid_begin, u->nparams - u->off_mid_begin);
   // ---- input blocks, reversed: gradient of block i's output = consumer's dx + skip gradient
   for (int i = n_in - 1; i >= 1; i--) {
@@ -399,6 +399,7 @@ extern "C" int eegldm_unet_backward(eegldm_unet* u, const float* dy, float* dx_o
   EEG_TRY(ew_colsum(ctx, dh1, te, nullptr, 0, u->G(u->off_te0_b), 1, B, te, F));
   EEG_TRY(op_linear_wgrad(ctx, F, u->e0, mc, dh1, te, u->G(u->off_te0_w), mc, B, te, mc));
   EEG_TRY(op_wgrad_flush(ctx));      // the remaining (input-block) weight gradients, grouped by shape
+  EEG_TRY(op_gn_fold_flush(ctx));    // and the remaining GroupNorm dgamma / dbeta folds
   return 0;
 }
 
