@@ -34,7 +34,8 @@
 extern "C" {
 #endif
 
-#define EEGLDM_ABI_VERSION 3
+/* 4: + eegldm_ctx_stream, eegldm_linear_bwd, eegldm_disc_feature, eegldm_usleep_*, eegldm_feature_moments (additive). */
+#define EEGLDM_ABI_VERSION 4
 
 enum { EEGLDM_F32 = 0, EEGLDM_BF16 = 1 };
 enum {
