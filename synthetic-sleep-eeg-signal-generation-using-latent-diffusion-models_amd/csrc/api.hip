@@ -32,7 +32,12 @@ extern "C" int eegldm_ctx_create(int device, void* stream, int own_stream, eegld
 #else
   const size_t zp_bytes = 4096;
 #endif
-  if (!getenv("EEGLDM_NO_SIDE_STREAM")) {
+  // Second stream for the per-layer weight gradients of res_backward / attn_backward (the round-1/2 flow).  OPT-IN since round 3
+  // (EEGLDM_SIDE_STREAM=1; EEGLDM_NO_SIDE_STREAM is still accepted and wins): the UNet backward groups its weight gradients and leaves
+  // nothing for it, and the fused 3-tap weight-gradient kernel running BESIDE a narrow-block GroupNorm backward made that kernel's
+  // group sums come out wrong (reproduced in isolation, tools/debug/gn_conc2.py / gn_conc4.py; cause not found) --
+  // no default path of the library runs two of its own kernels concurrently any more.
+  if (getenv("EEGLDM_SIDE_STREAM") && atoi(getenv("EEGLDM_SIDE_STREAM")) != 0 && !getenv("EEGLDM_NO_SIDE_STREAM")) {
     HIP_TRY(hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking));
     HIP_TRY(hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
     HIP_TRY(hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming));
