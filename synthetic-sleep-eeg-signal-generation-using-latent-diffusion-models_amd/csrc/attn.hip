@@ -6,6 +6,12 @@
 // dS for the dK / dV products, which stay ordinary batched TN GEMMs).  Replaces QK^T (fp32 logits) + softmax + PV, i.e.
 // three launches and ~95 MB of logits/probs traffic per attention block at B = 256.  bf16 only (the fp32 parity path keeps
 // the unfused composition in ops.hip).
+// Long sequences (T = 768, the pixel-space model's attention level, round 3): NCW = 8 column waves, each owning T/128 key fragments
+// (96 score accumulators per lane instead of 192), one 8-wave block per CU: the product-1 ring (3 x 52 KB) takes the whole LDS.  The
+// bf16 score tile (64 x 768 = 97 KB) is NOT kept in LDS for product 2: with it only 48 KB were left for the V / K tiles, two 16 KB
+// tiles in flight against a ~2500-cycle DMA round trip and 8 MFMAs per wave and tile -- the pixel-space step did not move at all
+// (22.16 vs 22.14 ms).  The scores stay in the owning wave's registers as packed bf16 and each 32-key slice (4 KB) is handed to the
+// block through a double-buffered LDS slot just before the tiles that need it; the freed LDS holds an 8-deep ring of V / K tiles.
 #include "common.h"
 #include "internal.h"
 
@@ -45,29 +51,43 @@ struct ChainArgs {
   bf16_t* dS; long sdS;                // bwd: scaled score gradient [B][T][T]
   bf16_t* O; long ldo, sO;             // out (fwd) / dQ (bwd)
   int T, C; float alpha;
+  int xcd;                             // XCD-aware block order (set by the launcher): all query tiles of a sample on one XCD
 };
 
 constexpr int NTA = 256;
 
 // NQ = 64-row query tiles per block: 1 (grid = T/64 x B) or NJ (one block = one whole sample: K / V tiles are staged once
 // for all query rows and, at B = 256, the grid is exactly one block per CU -- no 1.5-round tail).
-template <int NJ, int MODE, int NQ>
-__global__ __launch_bounds__(256 * NQ) void attn_chain_kernel(const ChainArgs p) {
-  constexpr int T = 64 * NJ;                      // keys; every wave owns NJ 16-column fragments
+template <int NJT, int MODE, int NQ, int NCW, int NC2T>
+__global__ __launch_bounds__(64 * NCW * NQ) void attn_chain_kernel(const ChainArgs p) {
+  constexpr int T = 64 * NJT;                     // keys
+  constexpr int NJ = 4 * NJT / NCW;               // 16-column key fragments per column wave
   constexpr int QR = 64 * NQ;                     // query rows per block
-  constexpr int NWV = 4 * NQ;                     // waves per block
+  constexpr int NWV = NCW * NQ;                   // waves per block
   constexpr int A_BYTES = QR * 64, B_BYTES = T * 64, STG = A_BYTES + B_BYTES;
   // 3-deep DMA rings: a stage carries only 12-16 MFMAs per wave against a ~2500-cycle DMA round trip, so two stages are kept
   // in flight (with a 2-deep ring the kernel ran at one DMA latency per stage: 76 us per launch)
   constexpr int STAGE_AREA = (3 * STG > 49152) ? 3 * STG : 49152;
   constexpr int PP = T * 2 + 16;                  // padded row pitch of the bf16 score tile (conflict-free b128 fragment reads)
+  // score tile behind the staging area -- or, when the product-1 ring needs (nearly) the whole LDS (NCW = 8), laid over that ring behind
+  // the 48 KB of product-2 staging: product 1 is complete (block barrier) before the first score is written
+  // NCW = 8 ("long" variant, see the file header): no score tile; an 8-deep ring of 16 KB product-2 tiles, two 4 KB score slices, `red`
+  constexpr int D2 = 8, SL_OFF = D2 * 16384, RED_OFF8 = SL_OFF + 2 * 4096;
   extern __shared__ __attribute__((aligned(16))) char sm[];
-  char* pt = sm + STAGE_AREA;                     // [QR][PP]
-  float* red = (float*)(pt + QR * PP);            // [QR rows][4 column waves]
+  char* pt = sm + STAGE_AREA;                     // [QR][PP]   (NCW = 4 only)
+  float* red = (NCW == 8) ? (float*)(sm + RED_OFF8) : (float*)(pt + QR * PP);            // [QR rows][NCW column waves]
   const int tid = threadIdx.x, lane = tid & 63, lm = lane & 15, q = lane >> 4;
   const unsigned wv = __builtin_amdgcn_readfirstlane(tid >> 6);    // wave in block
-  const unsigned w = wv & 3, wq = wv >> 2;                       // column wave (owns NJ key fragments) / query tile of this wave
-  const int b = blockIdx.y, m0 = blockIdx.x * QR;                // first query row of the block
+  const unsigned w = wv % NCW, wq = wv / NCW;                    // column wave (owns NJ key fragments) / query tile of this wave
+  // Block -> (sample, query tile).  Plain order deals the T / QR tiles of one sample round-robin to the 8 XCDs, so every XCD's L2 sees
+  // the K / V of every sample in flight (T = 768, B = 64: 21 samples x 2.4 MB against 4 MB of L2 -- the kernel ran at the
+  // Infinity-Cache rate, 205 us).  XCD-aware order (B % 8 == 0): ids = x (mod 8) run on XCD x; the j-th of them is tile j % nt of
+  // sample (j / nt) * 8 + x, so a sample's tiles share one L2 and K / V come from HBM once.
+  int b = blockIdx.y, m0 = blockIdx.x * QR;                      // first query row of the block
+  if (p.xcd) {
+    const int nt = gridDim.x, lin = blockIdx.y * nt + blockIdx.x, x = lin & 7, j = lin >> 3;
+    b = (j / nt) * 8 + x; m0 = (j % nt) * QR;
+  }
   const int mq = wq * 64;                                        // this wave's query rows inside the block tile
   const unsigned lds0 = (unsigned)(size_t)(lds_ptr_t)sm;
   const bf16_t* A1 = p.A1 + (long)b * p.sA1 + (long)m0 * p.lda1;
@@ -92,25 +112,28 @@ __global__ __launch_bounds__(256 * NQ) void attn_chain_kernel(const ChainArgs p)
     for (int j = 0; j < NJ; j++) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
   const int nst = p.C / 32;
   // per-lane source pointers of this wave's DMA chunks (chunk c of a tile <-> row c/4, swizzled 16-byte slot)
-  // A tile: QR*4 chunks = 4*NQ wave-instructions (one per wave); B tile: T*4 chunks = 4*NJ instructions, NB1 per wave
-  constexpr int NB1 = (4 * NJ + NWV - 1) / NWV;
-  static_assert((4 * NJ) % NWV == 0, "B-tile DMA instructions must divide evenly over the waves (uniform vmcnt)");
+  // A tile: QR*4 chunks = 4*NQ wave-instructions (waves 0 .. 4*NQ-1 take one each); B tile: T*4 chunks = 4*NJT instructions, NB1 per wave
+  constexpr int NB1 = (4 * NJT + NWV - 1) / NWV;
+  static_assert((4 * NJT) % NWV == 0, "B-tile DMA instructions must divide evenly over the waves (uniform vmcnt)");
+  const bool a_mine = wv < 4 * NQ;                 // wave-uniform (NCW = 8: the upper half of the waves stages no A chunk)
   const bf16_t* asrc; const bf16_t* bsrc[NB1];
-  { const int c = wv * 64 + lane, row = c >> 2, slot = swz1(row, c & 3); asrc = A1 + (long)row * p.lda1 + slot * 8; }
+  { const int c = (a_mine ? wv : 0) * 64 + lane, row = c >> 2, slot = swz1(row, c & 3); asrc = A1 + (long)row * p.lda1 + slot * 8; }
 #pragma unroll
   for (int i = 0; i < NB1; i++) { const int c = (wv + NWV * i) * 64 + lane, row = c >> 2, slot = swz1(row, c & 3); bsrc[i] = B1 + (long)row * p.ldb1 + slot * 8; }
   auto issue1 = [&](int s, int buf) __attribute__((always_inline)) {
     const unsigned base = lds0 + buf * STG;
-    dma16a(asrc + s * 32, base + wv * 1024);
+    if (a_mine) dma16a(asrc + s * 32, base + wv * 1024);
 #pragma unroll
     for (int i = 0; i < NB1; i++) dma16a(bsrc[i] + s * 32, base + A_BYTES + (wv + NWV * i) * 1024);
   };
-  constexpr int PER1 = 1 + NB1;                   // DMA instructions per wave per stage
+  constexpr int PER1 = 1 + NB1;                   // DMA instructions per wave per stage (one less for waves without an A chunk)
   issue1(0, 0);
   if (nst > 1) issue1(1, 1);
   for (int s = 0; s < nst; s++) {
-    if (s + 1 < nst) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PER1) : "memory");     // stage s landed, stage s+1 may be in flight
-    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (s + 1 < nst) {                             // stage s landed, stage s+1 may be in flight
+      if (a_mine) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PER1) : "memory");
+      else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PER1 - 1) : "memory");
+    } else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     if (s + 2 < nst) issue1(s + 2, (s + 2) % 3);
     const char* sa = sm + (s % 3) * STG; const char* sb = sa + A_BYTES;
@@ -143,8 +166,26 @@ __global__ __launch_bounds__(256 * NQ) void attn_chain_kernel(const ChainArgs p)
     }
   };
   const int per2 = (int)((16 - (int)wv + NWV - 1) / NWV);       // this wave's DMA instructions per tile (wave-uniform)
-  issue2(0, 0);                                    // land while the row operation runs
-  if (nu > 1) issue2(1, 1);
+  // long variant: unit u = (32-key slice ks = u / nnc, 256-column pass nc = u % nnc) -- a score slice serves all passes back to back
+  auto issue2l = [&](int u, int buf) __attribute__((always_inline)) {
+    const int ks = u / nnc, nc = u - ks * nnc;
+    const unsigned base = lds0 + buf * 16384;
+#pragma unroll
+    for (int i = 0; i < 2; i++) {                  // 16 wave-instructions per tile over 8 waves
+      const int ii = wv + 8 * i;
+      const int c = ii * 64 + lane, krow = c >> 5, cs = c & 31;
+      const int seg = trswz256(krow, cs * 16) >> 4;
+      dma16a(B2 + (long)(ks * 32 + krow) * p.ldb2 + nc * 256 + seg * 8, base + ii * 1024);
+    }
+  };
+  if constexpr (NCW == 8) {
+#pragma unroll
+    for (int u = 0; u < D2 - 1; u++) if (u < nu) issue2l(u, u);       // land while the row operation runs
+  } else {
+    issue2(0, 0);                                    // land while the row operation runs
+    if (nu > 1) issue2(1, 1);
+  }
+  uint2 pk[NCW == 8 ? 4 : 1][NCW == 8 ? NJ : 1];    // long variant: this wave's scores / score gradients as packed bf16
 
   // ---------------- row operation on the score tile ----------------
   auto row_reduce = [&](float v[4], const bool is_max) __attribute__((always_inline)) {
@@ -157,13 +198,18 @@ __global__ __launch_bounds__(256 * NQ) void attn_chain_kernel(const ChainArgs p)
     __syncthreads();                               // previous use of `red` is over
     if (q == 0) {
 #pragma unroll
-      for (int i = 0; i < 4; i++) red[(mq + i * 16 + lm) * 4 + w] = v[i];
+      for (int i = 0; i < 4; i++) red[(mq + i * 16 + lm) * NCW + w] = v[i];
     }
     __syncthreads();
 #pragma unroll
     for (int i = 0; i < 4; i++) {
-      const float4 t = *(const float4*)(red + (mq + i * 16 + lm) * 4);
+      const float4 t = *(const float4*)(red + (mq + i * 16 + lm) * NCW);
       v[i] = is_max ? fmaxf(fmaxf(t.x, t.y), fmaxf(t.z, t.w)) : (t.x + t.y) + (t.z + t.w);
+      if constexpr (NCW == 8) {
+        const float4 t2 = *(const float4*)(red + (mq + i * 16 + lm) * NCW + 4);
+        const float v2 = is_max ? fmaxf(fmaxf(t2.x, t2.y), fmaxf(t2.z, t2.w)) : (t2.x + t2.y) + (t2.z + t2.w);
+        v[i] = is_max ? fmaxf(v[i], v2) : v[i] + v2;
+      }
     }
   };
   if (MODE == 0) {
@@ -196,7 +242,7 @@ __global__ __launch_bounds__(256 * NQ) void attn_chain_kernel(const ChainArgs p)
       for (int j = 0; j < NJ; j++) {
         uint2 o; o.x = pack_bf16x2(acc[i][j][0] * inv, acc[i][j][1] * inv); o.y = pack_bf16x2(acc[i][j][2] * inv, acc[i][j][3] * inv);
         const int col = (w * NJ + j) * 16 + q * 4;
-        *(uint2*)(pt + (mq + i * 16 + lm) * PP + col * 2) = o;
+        if constexpr (NCW == 8) pk[i][j] = o; else *(uint2*)(pt + (mq + i * 16 + lm) * PP + col * 2) = o;
         *(uint2*)(p.P + (long)b * p.sP + (long)(m0 + mq + i * 16 + lm) * T + col) = o;
       }
     }
@@ -224,19 +270,95 @@ __global__ __launch_bounds__(256 * NQ) void attn_chain_kernel(const ChainArgs p)
         o.x = pack_bf16x2(p.alpha * p0 * (acc[i][j][0] - dl[i]), p.alpha * p1 * (acc[i][j][1] - dl[i]));
         o.y = pack_bf16x2(p.alpha * p2 * (acc[i][j][2] - dl[i]), p.alpha * p3 * (acc[i][j][3] - dl[i]));
         const int col = (w * NJ + j) * 16 + q * 4;
-        *(uint2*)(pt + (mq + i * 16 + lm) * PP + col * 2) = o;
+        if constexpr (NCW == 8) pk[i][j] = o; else *(uint2*)(pt + (mq + i * 16 + lm) * PP + col * 2) = o;
         *(uint2*)(p.dS + (long)b * p.sdS + (long)(m0 + mq + i * 16 + lm) * T + col) = o;
       }
   }
 
+  if constexpr (NCW == 8) {
+    // ---------------- product 2, long variant: out[64][C] = scores[64][T] . B2[T][C], C = 256 * NC2 ----------------
+    // Wave w: rows (w >> 2) * 32 .. + 32, columns (w & 3) * 64 .. + 64 of every 256-column pass.  Slice ks (keys 32 ks .. + 32) is the
+    // fragment pair j = 2 (ks % 3), + 1 of column wave ks / 3, which stores it ([64 rows][32 keys], 64-byte rows: a fragment read is
+    // one linear KB) into slot ks & 1 one slice ahead; the per-unit barrier orders the hand-over.
+    static_assert(NJ == 6 && NQ == 1, "long variant: T = 768, one 64-row query tile per block");
+    constexpr int NC2 = NC2T;
+    const unsigned wc = w & 3; const int mr = (int)(w >> 2) * 32;
+    f32x4 o2[NC2][2][4];
+#pragma unroll
+    for (int c = 0; c < NC2; c++)
+#pragma unroll
+      for (int i = 0; i < 2; i++)
+#pragma unroll
+        for (int j = 0; j < 4; j++) o2[c][i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    auto put_slice = [&](const int jn, const int slot) __attribute__((always_inline)) {     // jn: compile-time after unrolling
+      char* sl = sm + SL_OFF + slot * 4096;
+#pragma unroll
+      for (int i = 0; i < 4; i++)
+#pragma unroll
+        for (int jj = 0; jj < 2; jj++) *(uint2*)(sl + (i * 16 + lm) * 64 + jj * 32 + q * 8) = pk[i][jn + jj];
+    };
+    if (w == 0) put_slice(0, 0);
+    constexpr int NKS = T / 32, NU = NKS * NC2;
+    int u = 0;
+    for (int wo = 0; wo < NCW; wo++) {
+#pragma unroll
+      for (int kk = 0; kk < 3; kk++) {
+        const int ks = wo * 3 + kk;
+#pragma unroll
+        for (int nc = 0; nc < NC2; nc++, u++) {
+          // tile u landed: at most `ahead` newer tiles (2 DMA instructions per wave each) may stay in flight; the very first wait also
+          // retires the P / dS stores of the row operation (stores and loads share the counter but retire independently)
+          const int ahead = min(NU - 1 - u, D2 - 2);
+          if (u == 0 || ahead <= 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+          else if (ahead == 1) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+          else if (ahead == 2) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+          else if (ahead == 3) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+          else if (ahead == 4) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+          else if (ahead == 5) asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
+          else asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+          __syncthreads();
+          if (u + D2 - 1 < NU) issue2l(u + D2 - 1, (u + D2 - 1) % D2);
+          if (nc == 0 && ks + 1 < NKS) {             // next slice, one ahead (slot (ks + 1) & 1 was last read before this unit's barrier)
+            const unsigned owner = (kk == 2) ? wo + 1 : wo;
+            if (w == owner) put_slice(2 * ((kk + 1) % 3), (ks + 1) & 1);
+          }
+          const char* sv = sm + (u % D2) * 16384;
+          const char* sl = sm + SL_OFF + (ks & 1) * 4096;
+          uint4 af[2], bfr[4];
+#pragma unroll
+          for (int i = 0; i < 2; i++) af[i] = *(const uint4*)(sl + (mr + i * 16 + lm) * 64 + q * 16);
+#pragma unroll
+          for (int j = 0; j < 4; j++) bfr[j] = read_tr256(sv, wc * 64 + j * 16, lm, q);
+#pragma unroll
+          for (int i = 0; i < 2; i++)
+#pragma unroll
+            for (int j = 0; j < 4; j++) mma16(bfr[j], af[i], o2[nc][i][j]);
+        }
+      }
+    }
+#pragma unroll
+    for (int c = 0; c < NC2; c++)
+#pragma unroll
+      for (int i = 0; i < 2; i++)
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+          uint2 o; o.x = pack_bf16x2(o2[c][i][j][0], o2[c][i][j][1]); o.y = pack_bf16x2(o2[c][i][j][2], o2[c][i][j][3]);
+          *(uint2*)(p.O + (long)b * p.sO + (long)(m0 + mr + i * 16 + lm) * p.ldo + c * 256 + wc * 64 + j * 16 + q * 4) = o;
+        }
+    return;
+  }
   // ---------------- product 2: out[64][C] = tile[64][T] . B2[T][C], 256 output columns per pass ----------------
-  f32x4 acc2[4][4];
+  // a wave's share of a pass: all 64 rows x 64 columns (4 column waves), or 32 rows x 64 columns (8 column waves: two row halves)
+  constexpr int RF2 = 16 / NCW;                    // 16-row fragments per wave: 4 or 2
+  const unsigned wc2 = w & 3;                      // 64-column quarter of the pass
+  const int mq2 = mq + (int)(w >> 2) * 32;         // first row of this wave's share
+  f32x4 acc2[RF2][4];
   bool stores_pending = true;                      // the P / dS stores of the row operation
   for (int u = 0; u < nu; u++) {
     const int nc = u / nks, ks = u - nc * nks;
     if (ks == 0) {
 #pragma unroll
-      for (int i = 0; i < 4; i++)
+      for (int i = 0; i < RF2; i++)
 #pragma unroll
         for (int j = 0; j < 4; j++) acc2[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
     }
@@ -250,39 +372,44 @@ __global__ __launch_bounds__(256 * NQ) void attn_chain_kernel(const ChainArgs p)
     __syncthreads();                               // (for u = 0 also: the score tile is complete in LDS)
     if (u + 2 < nu) issue2(u + 2, (u + 2) % 3);
     const char* sv = sm + (u % 3) * 16384;
-    uint4 af[4], bfr[4];
+    uint4 af[RF2], bfr[4];
 #pragma unroll
-    for (int i = 0; i < 4; i++) af[i] = *(const uint4*)(pt + (mq + i * 16 + lm) * PP + (ks * 32 + q * 8) * 2);
+    for (int i = 0; i < RF2; i++) af[i] = *(const uint4*)(pt + (mq2 + i * 16 + lm) * PP + (ks * 32 + q * 8) * 2);
 #pragma unroll
-    for (int j = 0; j < 4; j++) bfr[j] = read_tr256(sv, w * 64 + j * 16, lm, q);
+    for (int j = 0; j < 4; j++) bfr[j] = read_tr256(sv, wc2 * 64 + j * 16, lm, q);
 #pragma unroll
-    for (int i = 0; i < 4; i++)
+    for (int i = 0; i < RF2; i++)
 #pragma unroll
       for (int j = 0; j < 4; j++) mma16(bfr[j], af[i], acc2[i][j]);
     if (ks == nks - 1) {
 #pragma unroll
-      for (int i = 0; i < 4; i++)
+      for (int i = 0; i < RF2; i++)
 #pragma unroll
         for (int j = 0; j < 4; j++) {
           uint2 o; o.x = pack_bf16x2(acc2[i][j][0], acc2[i][j][1]); o.y = pack_bf16x2(acc2[i][j][2], acc2[i][j][3]);
-          *(uint2*)(p.O + (long)b * p.sO + (long)(m0 + mq + i * 16 + lm) * p.ldo + nc * 256 + w * 64 + j * 16 + q * 4) = o;
+          *(uint2*)(p.O + (long)b * p.sO + (long)(m0 + mq2 + i * 16 + lm) * p.ldo + nc * 256 + wc2 * 64 + j * 16 + q * 4) = o;
         }
       stores_pending = true;
     }
   }
 }
 
-template <int NJ, int MODE, int NQ>
+template <int NJ, int MODE, int NQ, int NCW = 4, int NC2 = 1>
 int launch_chain_q(eegldm_ctx* ctx, const ChainArgs& a, int B) {
   constexpr int T = 64 * NJ, QR = 64 * NQ;
   constexpr int STG = QR * 64 + T * 64;
   constexpr int STAGE_AREA = (3 * STG > 49152) ? 3 * STG : 49152;
-  constexpr int LDS = STAGE_AREA + QR * (T * 2 + 16) + QR * 4 * 4;
+  constexpr int TILE = QR * (T * 2 + 16) + QR * NCW * 4;          // score tile + row-reduction scratch
+  constexpr int LONG2 = 8 * 16384 + 2 * 4096 + QR * NCW * 4;      // long variant after product 1: tile ring, two score slices, row-reduction scratch
+  constexpr int LDS = (NCW == 8) ? ((STAGE_AREA > LONG2) ? STAGE_AREA : LONG2) : STAGE_AREA + TILE;
   static_assert(LDS <= 160 * 1024, "attention tile does not fit the LDS");
-  auto kern = attn_chain_kernel<NJ, MODE, NQ>;
+  auto kern = attn_chain_kernel<NJ, MODE, NQ, NCW, NC2>;
   static bool attr = false;
   if (!attr && LDS > 48 * 1024) { HIP_TRY(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS)); attr = true; }
-  hipLaunchKernelGGL(kern, dim3(T / QR, B), dim3(256 * NQ), LDS, ctx->stream, a);
+  ChainArgs ax = a;
+  static const bool no_xcd = getenv("EEGLDM_ATTN_NO_XCD") != nullptr;
+  ax.xcd = (!no_xcd && T / QR > 1 && B % 8 == 0) ? 1 : 0;
+  hipLaunchKernelGGL(kern, dim3(T / QR, B), dim3(64 * NCW * NQ), LDS, ctx->stream, ax);
   LAUNCH_CHECK();
   return 0;
 }
@@ -298,7 +425,8 @@ int launch_chain(eegldm_ctx* ctx, const ChainArgs& a, int B) {
 
 bool attn_chain_ok(int dtype, int T, int C, long ldq, long ldo) {
   static const bool off = getenv("EEGLDM_NO_FUSED_ATTENTION") != nullptr;
-  return !off && dtype == EEGLDM_BF16 && (T == 64 || T == 128 || T == 192 || T == 256) && C % 256 == 0 && ldq % 8 == 0 && ldo % 8 == 0;
+  static const bool no_long = getenv("EEGLDM_ATTN_NO_LONG") != nullptr;      // T = 768 back to the GEMM + softmax composition
+  return !off && dtype == EEGLDM_BF16 && (T == 64 || T == 128 || T == 192 || T == 256 || (T == 768 && !no_long && (C == 256 || C == 512))) && C % 256 == 0 && ldq % 8 == 0 && ldo % 8 == 0;
 }
 
 // forward: probs written, out = softmax(alpha q k^T) v
@@ -311,6 +439,7 @@ int attn_chain_fwd(eegldm_ctx* ctx, const void* qkv, long ldq, void* out, long l
     case 1: return launch_chain<1, 0>(ctx, a, B);
     case 2: return launch_chain<2, 0>(ctx, a, B);
     case 3: return launch_chain<3, 0>(ctx, a, B);
+    case 12: return C == 256 ? launch_chain_q<12, 0, 1, 8, 1>(ctx, a, B) : launch_chain_q<12, 0, 1, 8, 2>(ctx, a, B);
     default: return launch_chain<4, 0>(ctx, a, B);
   }
 }
@@ -326,6 +455,7 @@ int attn_chain_bwd(eegldm_ctx* ctx, const void* qkv, long ldq, const void* probs
     case 1: return launch_chain<1, 1>(ctx, a, B);
     case 2: return launch_chain<2, 1>(ctx, a, B);
     case 3: return launch_chain<3, 1>(ctx, a, B);
+    case 12: return C == 256 ? launch_chain_q<12, 1, 1, 8, 1>(ctx, a, B) : launch_chain_q<12, 1, 1, 8, 2>(ctx, a, B);
     default: return launch_chain<4, 1>(ctx, a, B);
   }
 }

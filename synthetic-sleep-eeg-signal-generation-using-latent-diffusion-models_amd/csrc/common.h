@@ -93,10 +93,15 @@ struct SideScope {
 __device__ __forceinline__ float bf16_to_f32(bf16_t v) { return __uint_as_float(((unsigned)v) << 16); }
 // gfx950 has a hardware fp32 -> packed bf16 conversion (round-to-nearest-even, NaN stays NaN): one VALU op for two values
 // instead of the ~10-instruction exec-masked software sequence.
+// Through the compiler's own vector conversion, NOT inline assembly: hipcc's hazard recognizer does not look inside an asm statement,
+// so an asm `v_cvt_pk_bf16_f32` placed right behind the MFMA that produces its operand read the accumulator before the matrix pipe
+// had written it (no s_nop inserted) -- the long attention kernel's C = 256 build stored garbage for exactly that reason (round 3),
+// and every other epilogue was correct only because enough instructions happened to sit in between.
+typedef float eeg_f32x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 eeg_bf16x2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ unsigned pack_bf16x2(float lo, float hi) {
-  unsigned r;
-  asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(lo), "v"(hi));
-  return r;
+  const eeg_f32x2 v = {lo, hi};
+  return __builtin_bit_cast(unsigned, __builtin_convertvector(v, eeg_bf16x2));     // one v_cvt_pk_bf16_f32 on gfx950
 }
 __device__ __forceinline__ bf16_t f32_to_bf16(float f) { return (bf16_t)(pack_bf16x2(f, f) & 0xffffu); }
 template <typename T> __device__ __forceinline__ float ld_f32(const T* p);

@@ -585,9 +585,6 @@ __global__ __launch_bounds__(NTH) void gn_bwd_resident_kernel(const T* __restric
     }
 #pragma unroll
     for (int j = 0; j < 4; j++) { atomicAdd(&redc[m.tx * 4 + j], (double)dg[j]); atomicAdd(&redc[RES_MAXC + m.tx * 4 + j], (double)db[j]); }
-#ifdef EEG_GN_ATOMIC_READBACK   // experiment (tools/debug/gn_conc4.py): a dependent read behind the no-return atomics of this wave
-    { volatile double* vr = redc; const double t = vr[m.tx * 4] + vr[RES_MAXC + m.tx * 4]; if (t == 1.2345e300) dg[0] = 0.f; asm volatile("" :: "v"(dg[0])); }
-#endif
   }
   // the residual-path addend(s) of dx are fetched HERE, packed and unconditionally (clamped row), so their round trip runs under the
   // two barriers and the group-sum phase: loaded inside pass 2 they were twelve load-wait-use chains per thread (the first GroupNorm of

@@ -207,7 +207,9 @@ def test_groupnorm_fwd_bwd(case, dtype):
 
 @pytest.mark.parametrize("dtype", [0, 1])
 @pytest.mark.parametrize("B,T,Cc", [(2, 24, 32), (2, 16, 128), (3, 192, 512), (2, 72, 64), (2, 64, 256), (3, 128, 256), (2, 256, 256),
-                                    (130, 192, 256), (2, 384, 128), (1, 768, 64)])      # the last one: fused chain kernel with whole-sample (12-wave) blocks
+                                    (130, 192, 256), (2, 384, 128), (1, 768, 64), (2, 768, 512), (5, 768, 256)])
+# (130, 192, 256): fused chain kernel with whole-sample (12-wave) blocks; (*, 768, 512 / 256): the 8-column-wave chain kernel of the
+# pixel-space model's attention level (bf16; fp32 and C = 64 take the GEMM + softmax composition)
 def test_attention_fwd_bwd(B, T, Cc, dtype):
     G = _imports()
     from oracle.unet import qkv_attention
