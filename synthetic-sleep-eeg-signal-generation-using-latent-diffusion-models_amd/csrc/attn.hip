@@ -52,7 +52,9 @@ struct ChainArgs {
   bf16_t* O; long ldo, sO;             // out (fwd) / dQ (bwd)
   int T, C; float alpha;
   int xcd;                             // XCD-aware block order (set by the launcher): all query tiles of a sample on one XCD
+  unsigned long long* stamps;          // developer aid (EEGLDM_ATTN_STAMPS=1): shader-clock stamps of block 0's phases, else null
 };
+#define ATTN_STAMP(k) do { if (p.stamps && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) p.stamps[k] = __builtin_readcyclecounter(); } while (0)
 
 constexpr int NTA = 256;
 
@@ -73,6 +75,9 @@ __global__ __launch_bounds__(64 * NCW * NQ) void attn_chain_kernel(const ChainAr
   // the 48 KB of product-2 staging: product 1 is complete (block barrier) before the first score is written
   // NCW = 8 ("long" variant, see the file header): no score tile; an 8-deep ring of 16 KB product-2 tiles, two 4 KB score slices, `red`
   constexpr int D2 = 8, SL_OFF = D2 * 16384, RED_OFF8 = SL_OFF + 2 * 4096;
+  // NCW = 4: product-2 tile ring inside the staging area, 4 deep where that area has 64 KB (whole-sample blocks at T = 192: every block
+  // streams its own sample's V / K from HBM, ~3.5 us per round trip under load -- the unit time was latency / tiles in flight)
+  constexpr int DO2 = (STAGE_AREA >= 65536) ? 4 : 3;
   extern __shared__ __attribute__((aligned(16))) char sm[];
   char* pt = sm + STAGE_AREA;                     // [QR][PP]   (NCW = 4 only)
   float* red = (NCW == 8) ? (float*)(sm + RED_OFF8) : (float*)(pt + QR * PP);            // [QR rows][NCW column waves]
@@ -105,6 +110,7 @@ __global__ __launch_bounds__(64 * NCW * NQ) void attn_chain_kernel(const ChainAr
   }
 
   // ---------------- product 1: S^T fragments, reduction over C in 32-wide stages ----------------
+  ATTN_STAMP(0);
   f32x4 acc[4][NJ];
 #pragma unroll
   for (int i = 0; i < 4; i++)
@@ -135,19 +141,36 @@ __global__ __launch_bounds__(64 * NCW * NQ) void attn_chain_kernel(const ChainAr
       else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PER1 - 1) : "memory");
     } else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    if (s + 2 < nst) issue1(s + 2, (s + 2) % 3);
     const char* sa = sm + (s % 3) * STG; const char* sb = sa + A_BYTES;
     uint4 af[4], bfr[NJ];
 #pragma unroll
     for (int i = 0; i < 4; i++) { const int row = mq + i * 16 + lm; af[i] = *(const uint4*)(sa + row * 64 + swz1(row, q) * 16); }
 #pragma unroll
     for (int j = 0; j < NJ; j++) { const int row = (w * NJ + j) * 16 + lm; bfr[j] = *(const uint4*)(sb + row * 64 + swz1(row, q) * 16); }
+    // The DMA instructions of stage s + 2 go out BETWEEN the MFMAs (one after every EVERY1-th): an LDS-DMA instruction holds its
+    // issuer for 100-185 cycles with nothing else in flight and ~60 among MFMAs; as a burst behind the barrier the 7 of a T = 768 stage
+    // were most of the stage (phase stamps, EEGLDM_ATTN_STAMPS=1: 2 300 cycles per stage for 384 cycles of MFMA work per wave)
+    constexpr int EVERY1 = (4 * NJ) / PER1;
+    static_assert(EVERY1 >= 1, "every DMA piece needs an MFMA slot");
+    const bool more = s + 2 < nst;
+    const unsigned base2 = lds0 + ((s + 2) % 3) * STG;
 #pragma unroll
     for (int i = 0; i < 4; i++)
 #pragma unroll
-      for (int j = 0; j < NJ; j++) mma16(bfr[j], af[i], acc[i][j]);     // swapped: acc[i][j][r] = S[i*16+lm][(w*NJ+j)*16 + q*4 + r]
+      for (int j = 0; j < NJ; j++) {
+        mma16(bfr[j], af[i], acc[i][j]);     // swapped: acc[i][j][r] = S[i*16+lm][(w*NJ+j)*16 + q*4 + r]
+        const int m = i * NJ + j;              // compile-time after unrolling
+        if ((m + 1) % EVERY1 == 0 && (m + 1) / EVERY1 - 1 < PER1) {
+          const int k = (m + 1) / EVERY1 - 1;
+          if (more) {
+            if (k == 0) { if (a_mine) dma16a(asrc + (s + 2) * 32, base2 + wv * 1024); }
+            else dma16a(bsrc[k - 1] + (s + 2) * 32, base2 + A_BYTES + (wv + NWV * (k - 1)) * 1024);
+          }
+        }
+      }
   }
   __syncthreads();                                 // staging area free
+  ATTN_STAMP(1);
 
   // ---------------- product 2 staging (V / K tile [32 rows][256 cols], transpose-read layout) ----------------
   const int nks = T / 32, nnc = p.C / 256, nu = nks * nnc;
@@ -180,10 +203,11 @@ __global__ __launch_bounds__(64 * NCW * NQ) void attn_chain_kernel(const ChainAr
   };
   if constexpr (NCW == 8) {
 #pragma unroll
-    for (int u = 0; u < D2 - 1; u++) if (u < nu) issue2l(u, u);       // land while the row operation runs
+    for (int u = 0; u < D2 - NC2T; u++) if (u < nu) issue2l(u, u);    // D2 / NC2 - 1 key slices: land while the row operation runs
   } else {
     issue2(0, 0);                                    // land while the row operation runs
     if (nu > 1) issue2(1, 1);
+    if (DO2 == 4 && nu > 2) issue2(2, 2);
   }
   uint2 pk[NCW == 8 ? 4 : 1][NCW == 8 ? NJ : 1];    // long variant: this wave's scores / score gradients as packed bf16
 
@@ -275,6 +299,7 @@ __global__ __launch_bounds__(64 * NCW * NQ) void attn_chain_kernel(const ChainAr
       }
   }
 
+  ATTN_STAMP(2);
   if constexpr (NCW == 8) {
     // ---------------- product 2, long variant: out[64][C] = scores[64][T] . B2[T][C], C = 256 * NC2 ----------------
     // Wave w: rows (w >> 2) * 32 .. + 32, columns (w & 3) * 64 .. + 64 of every 256-column pass.  Slice ks (keys 32 ks .. + 32) is the
@@ -298,42 +323,56 @@ __global__ __launch_bounds__(64 * NCW * NQ) void attn_chain_kernel(const ChainAr
         for (int jj = 0; jj < 2; jj++) *(uint2*)(sl + (i * 16 + lm) * 64 + jj * 32 + q * 8) = pk[i][jn + jj];
     };
     if (w == 0) put_slice(0, 0);
-    constexpr int NKS = T / 32, NU = NKS * NC2;
-    int u = 0;
+    // One barrier per key slice: its NC2 tiles are waited for together, the score fragments are read once for all passes, and the
+    // 2 * NC2 DMA instructions that refill the ring (slice ks + DS - 1 into the buffers slice ks - 1 was read from before this barrier)
+    // go out between the MFMAs.  (One barrier per TILE, DMA burst first: 1 330 cycles per 16 KB tile and 8 MFMAs per wave.)
+    constexpr int NKS = T / 32, DS = D2 / NC2;      // slices in the ring: one being read, DS - 1 in flight
     for (int wo = 0; wo < NCW; wo++) {
 #pragma unroll
       for (int kk = 0; kk < 3; kk++) {
         const int ks = wo * 3 + kk;
+        // slice ks landed: at most `ahead` newer slices (2 * NC2 DMA instructions per wave each) stay in flight; the very first wait also
+        // retires the P / dS stores of the row operation (stores and loads share the counter but retire independently)
+        const int ahead = min(NKS - 1 - ks, DS - 2), left = ahead * 2 * NC2;
+        if (ks == 0 || left <= 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        else if (left == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+        else if (left == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        else if (left == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+        else if (left == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        else if (left == 10) asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+        __syncthreads();
+        if (ks + 1 < NKS) {                          // next slice, one ahead (slot (ks + 1) & 1 was last read before this barrier)
+          const unsigned owner = (kk == 2) ? wo + 1 : wo;
+          if (w == owner) put_slice(2 * ((kk + 1) % 3), (ks + 1) & 1);
+        }
+        const char* sl = sm + SL_OFF + (ks & 1) * 4096;
+        uint4 af[2], bfr[NC2][4];
 #pragma unroll
-        for (int nc = 0; nc < NC2; nc++, u++) {
-          // tile u landed: at most `ahead` newer tiles (2 DMA instructions per wave each) may stay in flight; the very first wait also
-          // retires the P / dS stores of the row operation (stores and loads share the counter but retire independently)
-          const int ahead = min(NU - 1 - u, D2 - 2);
-          if (u == 0 || ahead <= 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-          else if (ahead == 1) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
-          else if (ahead == 2) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-          else if (ahead == 3) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-          else if (ahead == 4) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-          else if (ahead == 5) asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
-          else asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
-          __syncthreads();
-          if (u + D2 - 1 < NU) issue2l(u + D2 - 1, (u + D2 - 1) % D2);
-          if (nc == 0 && ks + 1 < NKS) {             // next slice, one ahead (slot (ks + 1) & 1 was last read before this unit's barrier)
-            const unsigned owner = (kk == 2) ? wo + 1 : wo;
-            if (w == owner) put_slice(2 * ((kk + 1) % 3), (ks + 1) & 1);
-          }
-          const char* sv = sm + (u % D2) * 16384;
-          const char* sl = sm + SL_OFF + (ks & 1) * 4096;
-          uint4 af[2], bfr[4];
+        for (int i = 0; i < 2; i++) af[i] = *(const uint4*)(sl + (mr + i * 16 + lm) * 64 + q * 16);
 #pragma unroll
-          for (int i = 0; i < 2; i++) af[i] = *(const uint4*)(sl + (mr + i * 16 + lm) * 64 + q * 16);
+        for (int nc = 0; nc < NC2; nc++) {
+          const char* sv = sm + ((ks * NC2 + nc) % D2) * 16384;
 #pragma unroll
-          for (int j = 0; j < 4; j++) bfr[j] = read_tr256(sv, wc * 64 + j * 16, lm, q);
+          for (int j = 0; j < 4; j++) bfr[nc][j] = read_tr256(sv, wc * 64 + j * 16, lm, q);
+        }
+        const int kn = ks + DS - 1;                  // slice whose tiles are issued now
+        const bool more = kn < NKS;
+#pragma unroll
+        for (int nc = 0; nc < NC2; nc++)
 #pragma unroll
           for (int i = 0; i < 2; i++)
 #pragma unroll
-            for (int j = 0; j < 4; j++) mma16(bfr[j], af[i], o2[nc][i][j]);
-        }
+            for (int j = 0; j < 4; j++) {
+              mma16(bfr[nc][j], af[i], o2[nc][i][j]);
+              const int m = nc * 8 + i * 4 + j;       // compile-time after unrolling: DMA piece m / 4 after every fourth MFMA
+              if (m % 4 == 3 && more) {
+                const int pc = m / 4, nn = pc >> 1, ii = (int)wv + 8 * (pc & 1);
+                const int c = ii * 64 + lane, krow = c >> 5, cs = c & 31;
+                const int seg = trswz256(krow, cs * 16) >> 4;
+                dma16a(B2 + (long)(kn * 32 + krow) * p.ldb2 + nn * 256 + seg * 8, lds0 + ((kn * NC2 + nn) % D2) * 16384 + ii * 1024);
+              }
+            }
       }
     }
 #pragma unroll
@@ -345,6 +384,7 @@ __global__ __launch_bounds__(64 * NCW * NQ) void attn_chain_kernel(const ChainAr
           uint2 o; o.x = pack_bf16x2(o2[c][i][j][0], o2[c][i][j][1]); o.y = pack_bf16x2(o2[c][i][j][2], o2[c][i][j][3]);
           *(uint2*)(p.O + (long)b * p.sO + (long)(m0 + mr + i * 16 + lm) * p.ldo + c * 256 + wc * 64 + j * 16 + q * 4) = o;
         }
+    ATTN_STAMP(3);
     return;
   }
   // ---------------- product 2: out[64][C] = tile[64][T] . B2[T][C], 256 output columns per pass ----------------
@@ -362,16 +402,16 @@ __global__ __launch_bounds__(64 * NCW * NQ) void attn_chain_kernel(const ChainAr
 #pragma unroll
         for (int j = 0; j < 4; j++) acc2[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
     }
-    // tile u landed; one newer tile (4 DMAs) may stay in flight unless stores were issued since (they share the counter)
-    if (u + 1 < nu && !stores_pending) {
-      if (per2 >= 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-      else if (per2 == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
-      else asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
-    } else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    // tile u landed; up to DO2 - 2 newer tiles (per2 DMAs of this wave each) may stay in flight unless stores were issued since (they share the counter)
+    const int left = stores_pending ? 0 : min(nu - 1 - u, DO2 - 2) * per2;
+    if (left >= 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    else if (left >= 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    else if (left >= 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+    else if (left == 1) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     stores_pending = false;
     __syncthreads();                               // (for u = 0 also: the score tile is complete in LDS)
-    if (u + 2 < nu) issue2(u + 2, (u + 2) % 3);
-    const char* sv = sm + (u % 3) * 16384;
+    const char* sv = sm + (u % DO2) * 16384;
     uint4 af[RF2], bfr[4];
 #pragma unroll
     for (int i = 0; i < RF2; i++) af[i] = *(const uint4*)(pt + (mq2 + i * 16 + lm) * PP + (ks * 32 + q * 8) * 2);
@@ -381,6 +421,7 @@ __global__ __launch_bounds__(64 * NCW * NQ) void attn_chain_kernel(const ChainAr
     for (int i = 0; i < RF2; i++)
 #pragma unroll
       for (int j = 0; j < 4; j++) mma16(bfr[j], af[i], acc2[i][j]);
+    if (u + DO2 - 1 < nu) issue2(u + DO2 - 1, (u + DO2 - 1) % DO2);      // behind the MFMAs: the matrix pipe works while the DMA instructions issue
     if (ks == nks - 1) {
 #pragma unroll
       for (int i = 0; i < RF2; i++)
@@ -392,6 +433,7 @@ __global__ __launch_bounds__(64 * NCW * NQ) void attn_chain_kernel(const ChainAr
       stores_pending = true;
     }
   }
+  ATTN_STAMP(3);
 }
 
 template <int NJ, int MODE, int NQ, int NCW = 4, int NC2 = 1>
@@ -409,8 +451,16 @@ int launch_chain_q(eegldm_ctx* ctx, const ChainArgs& a, int B) {
   ChainArgs ax = a;
   static const bool no_xcd = getenv("EEGLDM_ATTN_NO_XCD") != nullptr;
   ax.xcd = (!no_xcd && T / QR > 1 && B % 8 == 0) ? 1 : 0;
+  static const bool stamps = getenv("EEGLDM_ATTN_STAMPS") != nullptr;
+  static unsigned long long* sbuf = nullptr;
+  if (stamps && !sbuf) HIP_TRY(hipMalloc(&sbuf, 64));
+  ax.stamps = stamps ? sbuf : nullptr;
   hipLaunchKernelGGL(kern, dim3(T / QR, B), dim3(64 * NCW * NQ), LDS, ctx->stream, ax);
   LAUNCH_CHECK();
+  if (stamps) {       // (synchronous on purpose: a developer run)
+    unsigned long long h[4]; HIP_TRY(hipStreamSynchronize(ctx->stream)); HIP_TRY(hipMemcpy(h, sbuf, 32, hipMemcpyDeviceToHost));
+    fprintf(stderr, "attn_chain<T=%d, mode %d, NQ %d, NCW %d> block 0: product 1 %llu, row op %llu, product 2 %llu shader cycles\n", T, MODE, NQ, NCW, h[1] - h[0], h[2] - h[1], h[3] - h[2]);
+  }
   return 0;
 }
 template <int NJ, int MODE>
