@@ -421,7 +421,9 @@ namespace {
 int lat_len(const eegldm_aekl* a, int L) { return L >> (a->cfg.n_levels - 1); }
 
 // encoder + heads + sampling.  Leaves mu / lv / sigma / z in the arena; returns z view.
-int aekl_encode_impl(eegldm_aekl* a, const float* x, const float* eps, int B, int L, View* z_out, float* kl) {
+bool enc_fused_eligible(const eegldm_aekl* a, int L);
+int aekl_encode_fused_seq(eegldm_aekl* a, View x, int B, int& L, View* out);
+int aekl_encode_impl(eegldm_aekl* a, const float* x, const float* eps, int B, int L, View* z_out, float* kl, bool frozen = false) {
   EEG_CHECK((L % (1 << (a->cfg.n_levels - 1))) == 0, "L=%d must be divisible by 2^(levels-1)", L);
   eegldm_ctx* ctx = a->ctx; const int dt = a->dtype, lat = a->cfg.latent_channels, cin = a->cfg.in_channels;
   a->arena.reset(); a->rt.clear(); a->tape_enc.clear(); a->tape_dec.clear();
@@ -429,7 +431,8 @@ int aekl_encode_impl(eegldm_aekl* a, const float* x, const float* eps, int B, in
   View x0; ALLOC_OR_FAIL(x0.p, a->alloc_act((long)B * L, cin)); x0.ld = cin; x0.C = cin;
   EEG_TRY(eegldm_ncl_to_nlc(ctx, x, x0.p, cin, B, cin, L, dt));
   int Lc = L;
-  EEG_TRY(a->forward_seq(a->enc, x0, B, Lc, &a->h_enc, a->tape_enc, 1));
+  if (frozen && enc_fused_eligible(a, L)) EEG_TRY(aekl_encode_fused_seq(a, x0, B, Lc, &a->h_enc));      // no tape: the caller never back-propagates
+  else EEG_TRY(a->forward_seq(a->enc, x0, B, Lc, &a->h_enc, a->tape_enc, 1));
   a->Ll = Lc;
   const long n = (long)B * Lc * lat;
   ALLOC_OR_FAIL(a->mu.p, a->alloc_act((long)B * Lc, lat)); a->mu.ld = lat; a->mu.C = lat;
@@ -448,6 +451,65 @@ int aekl_encode_impl(eegldm_aekl* a, const float* x, const float* eps, int B, in
   *z_out = z;
   return 0;
 }
+// ---- frozen encode with fused pre-activation convs (enc_fused.hip).  No tape: only for callers that never back-propagate
+// (eegldm_aekl_encode = Stage1Wrapper / encode_stage_2_inputs under no_grad, train_ldm.py:145-148, training.py:417-421).
+bool enc_fused_eligible(const eegldm_aekl* a, int L) {
+  if (getenv("EEGLDM_AEKL_NO_FUSED_ENC") != nullptr) return false;      // (read per call: tests toggle it inside one process)
+  if (a->dtype != EEGLDM_BF16 || a->cfg.norm_num_groups != 1) return false;
+  int Lc = L; bool any = false;
+  for (const Op& o : a->enc) {
+    if (o.kind == OP_CONV) Lc = (Lc + o.pl + o.pr - o.k) / o.stride + 1;
+    else if (o.kind == OP_RES) { if (!pre_conv3_ok(a->dtype, o.r.cin, o.r.cout, Lc) || !pre_conv3_ok(a->dtype, o.r.cout, o.r.cout, Lc)) return false; any = true; }
+    else if (o.kind != OP_GN) return false;
+  }
+  return any;
+}
+int aekl_encode_fused_seq(eegldm_aekl* a, View x, int B, int& L, View* out) {
+  eegldm_ctx* ctx = a->ctx; const int dt = a->dtype;
+  // one statistics slot (sum, sum of squares per sample) per tensor that a GroupNorm reads: zeroed together, filled by the producers
+  size_t nslots = 0;
+  for (const Op& o : a->enc) nslots += (o.kind == OP_RES) ? 2 : 0;
+  double* slots; ALLOC_OR_FAIL(slots, (double*)a->arena.alloc(sizeof(double) * 2 * B * (nslots + 1)));
+  HIP_TRY(hipMemsetAsync(slots, 0, sizeof(double) * 2 * B * (nslots + 1), ctx->stream));
+  size_t used = 0;
+  auto next_slot = [&]() { return slots + (used++) * 2 * (size_t)B; };
+  double* cur_stats = nullptr;              // statistics of `x` (null: not computed yet)
+  for (size_t i = 0; i < a->enc.size(); i++) {
+    const Op& o = a->enc[i];
+    const bool next_res = i + 1 < a->enc.size() && a->enc[i + 1].kind == OP_RES;
+    if (o.kind == OP_CONV) {
+      const int Lo = (L + o.pl + o.pr - o.k) / o.stride + 1;
+      View y; ALLOC_OR_FAIL(y.p, a->alloc_act((long)B * Lo, o.cout)); y.ld = o.cout; y.C = o.cout;
+      EEG_TRY(op_conv_fwd(ctx, dt, x.p, x.ld, a->W(o.w), o.b >= 0 ? a->P(o.b) : nullptr, y.p, y.ld, B, L, o.cin, o.cout, o.k, o.stride, o.pl, o.pr,
+                          nullptr, 0, nullptr, 0));
+      L = Lo; x = y; cur_stats = nullptr;
+      if (next_res) { cur_stats = next_slot(); EEG_TRY(sample_stats_launch(ctx, x.p, (long)L * x.C, B, cur_stats)); }
+    } else if (o.kind == OP_RES) {
+      const ResDesc& r = o.r;
+      EEG_CHECK(cur_stats, "fused encoder: no statistics for a ResBlock input");
+      View h1; ALLOC_OR_FAIL(h1.p, a->alloc_act((long)B * L, r.cout)); h1.ld = r.cout; h1.C = r.cout;
+      double* st_h1 = next_slot();
+      EEG_TRY(pre_conv3_launch(ctx, x.p, cur_stats, a->P(r.gn1_w), a->P(r.gn1_b), a->W(r.c1_w), a->P(r.c1_b), nullptr, h1.p, st_h1, B, L, r.cin, r.cout, GN_EPS));
+      View res = x;
+      if (r.sk_w >= 0) {
+        ALLOC_OR_FAIL(res.p, a->alloc_act((long)B * L, r.cout)); res.ld = r.cout; res.C = r.cout;
+        EEG_TRY(op_conv_fwd(ctx, dt, x.p, x.ld, a->W(r.sk_w), a->P(r.sk_b), res.p, res.ld, B, L, r.cin, r.cout, 1, 1, 0, 0, nullptr, 0, nullptr, 0));
+      }
+      View y; ALLOC_OR_FAIL(y.p, a->alloc_act((long)B * L, r.cout)); y.ld = r.cout; y.C = r.cout;
+      double* st_y = next_res ? next_slot() : nullptr;          // (a ResBlock followed by a conv / the final norm: nobody reads them)
+      EEG_TRY(pre_conv3_launch(ctx, h1.p, st_h1, a->P(r.gn2_w), a->P(r.gn2_b), a->W(r.c2_w), a->P(r.c2_b), res.p, y.p, st_y, B, L, r.cout, r.cout, GN_EPS));
+      x = y; cur_stats = st_y;
+    } else {  // OP_GN (the final norm, no activation): the flat one-launch kernel
+      View y; ALLOC_OR_FAIL(y.p, a->alloc_act((long)B * L, x.C)); y.ld = x.C; y.C = x.C;
+      float* st; ALLOC_OR_FAIL(st, (float*)a->arena.alloc(sizeof(float) * 2 * B * o.groups));
+      EEG_TRY(eegldm_groupnorm_fwd(ctx, x.p, x.ld, a->P(o.gw), a->P(o.gb), y.p, y.ld, st, B, L, x.C, o.groups, GN_EPS, 0, 0, nullptr, 0, dt));
+      x = y; cur_stats = nullptr;
+    }
+  }
+  *out = x;
+  return 0;
+}
+
 int aekl_export_latents(eegldm_aekl* a, const View& z, float* z_ncl, float* mu_ncl, float* sigma_ncl) {
   const int lat = a->cfg.latent_channels;
   if (z_ncl) EEG_TRY(eegldm_nlc_to_ncl(a->ctx, z.p, lat, z_ncl, a->B, lat, a->Ll, a->dtype));
@@ -466,7 +528,7 @@ int aekl_decode_impl(eegldm_aekl* a, const View& z, int B, int Ll, float* recon)
 extern "C" int eegldm_aekl_encode(eegldm_aekl* a, const float* x, const float* eps, float* z, float* z_mu, float* z_sigma, int B, int L) {
   EEG_CHECK(a && x && a->params, "null argument / unbound parameters");
   View zv;
-  EEG_TRY(aekl_encode_impl(a, x, eps, B, L, &zv, nullptr));
+  EEG_TRY(aekl_encode_impl(a, x, eps, B, L, &zv, nullptr, true));
   return aekl_export_latents(a, zv, z, z_mu, z_sigma);
 }
 // decode_stage_2_outputs (sample_trials.py:166): z (B, lat, Ll) -> (B, out, Ll * 2^(levels-1))

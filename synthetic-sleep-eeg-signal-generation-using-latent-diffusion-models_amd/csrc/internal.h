@@ -59,6 +59,11 @@ int op_groupnorm_bwd(eegldm_ctx*, const void* x, long ldx, const float* gamma, c
                      const void* dxr2 = nullptr, long lddxr2 = 0, int* dxr2_done = nullptr, int* slots_deferred = nullptr, int defer_region = 0);
 int op_gn_slot_reduce_deferred(eegldm_ctx*, float* dgamma, float* dbeta, int C, int region = 0);   // when *slots_deferred came back 1 (stream-ordered after the backward)   // dxr2: second, un-resampled addend [B*L][C] (skip gradient); *dxr2_done = 1 when the kernel added it
 int ew_fold_partials(eegldm_ctx*, const float* parts, int nparts, int n, float* total);
+// frozen-encoder fusion (enc_fused.hip): GroupNorm(G = 1) + SiLU on the operand load of a 3-tap conv, next layer's statistics from its epilogue
+bool pre_conv3_ok(int dtype, int Cin, int Cout, int L);
+int pre_conv3_launch(eegldm_ctx*, const void* x, const double* in_stats, const float* gamma, const float* beta, const void* w,
+                     const float* bias, const void* resid, void* y, double* out_stats, int B, int L, int Cin, int Cout, float eps);
+int sample_stats_launch(eegldm_ctx*, const void* x, long n_per_sample, int B, double* stats);
 // fused short-sequence attention (attn.hip)
 bool attn_chain_ok(int dtype, int T, int C, long ldq, long ldo);
 int attn_chain_fwd(eegldm_ctx*, const void* qkv, long ldq, void* out, long ldo, void* probs, int B, int T, int C);
