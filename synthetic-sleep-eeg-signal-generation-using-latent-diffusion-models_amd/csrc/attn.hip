@@ -23,7 +23,8 @@ typedef s16x4 __attribute__((address_space(3))) * lds_s16x4_p;
 __device__ __forceinline__ int swz1(int row, int slot) { return slot ^ (((row >> 2) & 1) * 3); }     // 64-byte rows (gemm.hip nt_swz<1>)
 __device__ __forceinline__ int trswz256(int row, int colbyte) { return colbyte ^ ((((row & 3) | (((row >> 3) & 1) << 2)) * 32) & 511); }
 __device__ __forceinline__ void dma16a(const void* g, unsigned lds_off) {
-  asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off" ::"s"(lds_off), "v"(g) : "memory", "m0");
+  const unsigned off_s = __builtin_amdgcn_readfirstlane(lds_off);      // wave-uniform by construction; M0 must come from an SGPR
+  asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off" ::"s"(off_s), "v"(g) : "memory", "m0");
 }
 __device__ __forceinline__ void mma16(const uint4& a, const uint4& b, f32x4& acc) {
   acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), acc, 0, 0, 0);
@@ -43,6 +44,20 @@ __device__ __forceinline__ uint4 read_tr256(const char* tile, int x0, int lm, in
   return r;
 }
 
+// The same K-strided fragment from an UNSWIZZLED row-major tile of pitch `pitch` bytes (the score tile): lane (lm, q) gets rows
+// k0 + 8q .. + 7 of column x0 + lm -- the MFMA operand of a product that reduces over the tile's ROWS (dK = dS^T Q, dV = P^T dO)
+__device__ __forceinline__ uint4 read_tr_rows(const char* tile, int pitch, int k0, int x0, int lm, int q) {
+  const int row0 = k0 + 8 * q + (lm >> 2), colb = (x0 + 4 * (lm & 3)) * 2;
+  s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_p)(tile + row0 * pitch + colb));
+  s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_p)(tile + (row0 + 4) * pitch + colb));
+  uint4 r;
+  r.x = (unsigned)(unsigned short)lo[0] | ((unsigned)(unsigned short)lo[1] << 16);
+  r.y = (unsigned)(unsigned short)lo[2] | ((unsigned)(unsigned short)lo[3] << 16);
+  r.z = (unsigned)(unsigned short)hi[0] | ((unsigned)(unsigned short)hi[1] << 16);
+  r.w = (unsigned)(unsigned short)hi[2] | ((unsigned)(unsigned short)hi[3] << 16);
+  return r;
+}
+
 struct ChainArgs {
   const bf16_t* A1; long lda1, sA1;    // Q (fwd) / dO (bwd): [B][T][lda1], reduction (C) contiguous
   const bf16_t* B1; long ldb1, sB1;    // K (fwd) / V (bwd)
@@ -53,6 +68,9 @@ struct ChainArgs {
   int T, C; float alpha;
   int xcd;                             // XCD-aware block order (set by the launcher): all query tiles of a sample on one XCD
   unsigned long long* stamps;          // developer aid (EEGLDM_ATTN_STAMPS=1): shader-clock stamps of block 0's phases, else null
+  // backward, whole-sample blocks only (fuse_kv): dK = dS^T Q as a second pass of product 2 over the score tile, read TRANSPOSED;
+  // Q3 = the query rows of the sample; the result goes to dK (same leading dimension as O)
+  int fuse_kv; const bf16_t* Q3; long ldq3, sQ3; bf16_t* dK;
 };
 #define ATTN_STAMP(k) do { if (p.stamps && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) p.stamps[k] = __builtin_readcyclecounter(); } while (0)
 
@@ -109,6 +127,39 @@ __global__ __launch_bounds__(64 * NCW * NQ) void attn_chain_kernel(const ChainAr
         pr[i][j] = *(const uint2*)(p.P + (long)b * p.sP + (long)(m0 + mq + i * 16 + lm) * T + (w * NJ + j) * 16 + q * 4);
   }
 
+  // ---------------- product 2 staging (V / K tile [32 rows][256 cols], transpose-read layout) ----------------
+  const int nks = T / 32, nnc = p.C / 256, nu = nks * nnc;
+  // unit u of the product-2 sequence: pass pr = u / nu (0: the B2 operand -- V forward, K backward; 1 / 2: the fused dK / dV passes of
+  // the backward, whose tiles are rows of Q / dO), 256-column group nc, 32-row slice ks
+  // (every field is copied to a local first: selecting between members of the by-value argument struct at run time made hipcc keep
+  //  a copy of the struct in scratch -- 320 bytes per lane)
+  const bool fuse_kv = MODE == 1 && p.fuse_kv != 0;
+  const bf16_t* const src1 = fuse_kv ? p.Q3 + (long)b * p.sQ3 : B2;
+  const long ld0 = p.ldb2, ld1 = fuse_kv ? p.ldq3 : p.ldb2;
+  bf16_t* const dst0 = p.O; bf16_t* const dst1 = fuse_kv ? p.dK : p.O;
+  const long sO = p.sO, ldo = p.ldo;
+  // (sources / destinations are switched at pass boundaries through two-way selects only: a three-way `pass == 0 ? a : pass == 1 ? b : c`
+  //  became a lookup table on the stack -- 160 bytes of scratch per lane in every instantiation)
+  auto issue_tile = [&](const bf16_t* src, const long ld, int uu, int buf) __attribute__((always_inline)) {
+    const int nc = uu / nks, ks = uu - nc * nks;
+    const unsigned base = lds0 + buf * 16384;
+    // 16 wave-instructions per tile: instruction ii goes to wave ii % NWV (waves < 16 % NWV issue one more than the others)
+#pragma unroll
+    for (int i = 0; i < (16 + NWV - 1) / NWV; i++) {
+      const int ii = wv + NWV * i;
+      if (ii < 16) {
+        const int c = ii * 64 + lane, krow = c >> 5, cs = c & 31;
+        const int seg = trswz256(krow, cs * 16) >> 4;
+        dma16a(src + (long)(ks * 32 + krow) * ld + nc * 256 + seg * 8, base + ii * 1024);
+      }
+    }
+  };
+  const int per2 = (int)((16 - (int)wv + NWV - 1) / NWV);       // this wave's DMA instructions per tile (wave-uniform)
+  // ---------------- product 2: out[64][C] = tile[64][T] . B2[T][C], 256 output columns per pass ----------------
+  // a wave's share of a pass: all 64 rows x 64 columns (4 column waves), or 32 rows x 64 columns (8 column waves: two row halves)
+  constexpr int RF2 = 16 / NCW;                    // 16-row fragments per wave: 4 or 2
+  const unsigned wc2 = w & 3;                      // 64-column quarter of the pass
+  const int mq2 = mq + (int)(w >> 2) * 32;         // first row of this wave's share
   // ---------------- product 1: S^T fragments, reduction over C in 32-wide stages ----------------
   ATTN_STAMP(0);
   f32x4 acc[4][NJ];
@@ -172,23 +223,6 @@ __global__ __launch_bounds__(64 * NCW * NQ) void attn_chain_kernel(const ChainAr
   __syncthreads();                                 // staging area free
   ATTN_STAMP(1);
 
-  // ---------------- product 2 staging (V / K tile [32 rows][256 cols], transpose-read layout) ----------------
-  const int nks = T / 32, nnc = p.C / 256, nu = nks * nnc;
-  auto issue2 = [&](int u, int buf) __attribute__((always_inline)) {
-    const int nc = u / nks, ks = u - nc * nks;
-    const unsigned base = lds0 + buf * 16384;
-    // 16 wave-instructions per tile: instruction ii goes to wave ii % NWV (waves < 16 % NWV issue one more than the others)
-#pragma unroll
-    for (int i = 0; i < (16 + NWV - 1) / NWV; i++) {
-      const int ii = wv + NWV * i;
-      if (ii < 16) {
-        const int c = ii * 64 + lane, krow = c >> 5, cs = c & 31;
-        const int seg = trswz256(krow, cs * 16) >> 4;
-        dma16a(B2 + (long)(ks * 32 + krow) * p.ldb2 + nc * 256 + seg * 8, base + ii * 1024);
-      }
-    }
-  };
-  const int per2 = (int)((16 - (int)wv + NWV - 1) / NWV);       // this wave's DMA instructions per tile (wave-uniform)
   // long variant: unit u = (32-key slice ks = u / nnc, 256-column pass nc = u % nnc) -- a score slice serves all passes back to back
   auto issue2l = [&](int u, int buf) __attribute__((always_inline)) {
     const int ks = u / nnc, nc = u - ks * nnc;
@@ -205,9 +239,9 @@ __global__ __launch_bounds__(64 * NCW * NQ) void attn_chain_kernel(const ChainAr
 #pragma unroll
     for (int u = 0; u < D2 - NC2T; u++) if (u < nu) issue2l(u, u);    // D2 / NC2 - 1 key slices: land while the row operation runs
   } else {
-    issue2(0, 0);                                    // land while the row operation runs
-    if (nu > 1) issue2(1, 1);
-    if (DO2 == 4 && nu > 2) issue2(2, 2);
+    issue_tile(B2, ld0, 0, 0);                       // land while the row operation runs
+    if (nu > 1) issue_tile(B2, ld0, 1, 1);
+    if (DO2 == 4 && nu > 2) issue_tile(B2, ld0, 2, 2);
   }
   uint2 pk[NCW == 8 ? 4 : 1][NCW == 8 ? NJ : 1];    // long variant: this wave's scores / score gradients as packed bf16
 
@@ -387,15 +421,27 @@ __global__ __launch_bounds__(64 * NCW * NQ) void attn_chain_kernel(const ChainAr
     ATTN_STAMP(3);
     return;
   }
-  // ---------------- product 2: out[64][C] = tile[64][T] . B2[T][C], 256 output columns per pass ----------------
-  // a wave's share of a pass: all 64 rows x 64 columns (4 column waves), or 32 rows x 64 columns (8 column waves: two row halves)
-  constexpr int RF2 = 16 / NCW;                    // 16-row fragments per wave: 4 or 2
-  const unsigned wc2 = w & 3;                      // 64-column quarter of the pass
-  const int mq2 = mq + (int)(w >> 2) * 32;         // first row of this wave's share
-  f32x4 acc2[RF2][4];
+  // ---------------- passes over the score tile as ONE unit sequence (the tile ring prefetches across the pass boundary) ----------------
+  // pass 0: out (forward) / dQ = dS K (backward); pass 1 (backward, whole-sample blocks, fuse_kv): dK = dS^T Q -- the score tile read
+  // TRANSPOSED, tiles = rows of Q.  (dV = P^T dO stays a batched TN GEMM: as a third pass it has to run BEFORE product 1 while P is
+  // still in registers and the tile is free, and the loop around two call sites of this code cost 30 registers -- 700 bytes of spills
+  // at the 168 registers a 12-wave block leaves each lane.)
+  const int pr_count = fuse_kv ? 2 : 1;
   bool stores_pending = true;                      // the P / dS stores of the row operation
-  for (int u = 0; u < nu; u++) {
-    const int nc = u / nks, ks = u - nc * nks;
+  f32x4 acc2[RF2][4];
+  const int nut = pr_count * nu;
+  // issue side (runs DO2 - 1 units ahead) and consume side each carry their own (source | destination, transposed?) state
+  const bf16_t* isrc = B2; long ild = ld0; int iuu = 0;
+  auto issue_next = [&](int buf) __attribute__((always_inline)) {
+    issue_tile(isrc, ild, iuu, buf);
+    if (++iuu == nu) { iuu = 0; isrc = src1; ild = ld1; }        // second pass: dK, tiles = rows of Q
+  };
+  iuu = (DO2 - 1 < nu) ? DO2 - 1 : nu;             // the first tiles were issued before the row operation
+  if (iuu == nu) { iuu = 0; isrc = src1; ild = ld1; }
+  bf16_t* cdst = dst0; bool ctr = false;
+  int uu = 0;
+  for (int u = 0; u < nut; u++) {
+    const int nc = uu / nks, ks = uu - nc * nks;
     if (ks == 0) {
 #pragma unroll
       for (int i = 0; i < RF2; i++)
@@ -403,7 +449,7 @@ __global__ __launch_bounds__(64 * NCW * NQ) void attn_chain_kernel(const ChainAr
         for (int j = 0; j < 4; j++) acc2[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
     }
     // tile u landed; up to DO2 - 2 newer tiles (per2 DMAs of this wave each) may stay in flight unless stores were issued since (they share the counter)
-    const int left = stores_pending ? 0 : min(nu - 1 - u, DO2 - 2) * per2;
+    const int left = stores_pending ? 0 : min(nut - 1 - u, DO2 - 2) * per2;
     if (left >= 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
     else if (left >= 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
     else if (left >= 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
@@ -413,25 +459,32 @@ __global__ __launch_bounds__(64 * NCW * NQ) void attn_chain_kernel(const ChainAr
     __syncthreads();                               // (for u = 0 also: the score tile is complete in LDS)
     const char* sv = sm + (u % DO2) * 16384;
     uint4 af[RF2], bfr[4];
+    if (MODE == 1 && ctr) {
+      // transposed pass: output rows = KEY rows mq2 .. (whole-sample block: as many as query rows), reduction over the query rows of slice ks
 #pragma unroll
-    for (int i = 0; i < RF2; i++) af[i] = *(const uint4*)(pt + (mq2 + i * 16 + lm) * PP + (ks * 32 + q * 8) * 2);
+      for (int i = 0; i < RF2; i++) af[i] = read_tr_rows(pt, PP, ks * 32, mq2 + i * 16, lm, q);
+    } else {
+#pragma unroll
+      for (int i = 0; i < RF2; i++) af[i] = *(const uint4*)(pt + (mq2 + i * 16 + lm) * PP + (ks * 32 + q * 8) * 2);
+    }
 #pragma unroll
     for (int j = 0; j < 4; j++) bfr[j] = read_tr256(sv, wc2 * 64 + j * 16, lm, q);
 #pragma unroll
     for (int i = 0; i < RF2; i++)
 #pragma unroll
       for (int j = 0; j < 4; j++) mma16(bfr[j], af[i], acc2[i][j]);
-    if (u + DO2 - 1 < nu) issue2(u + DO2 - 1, (u + DO2 - 1) % DO2);      // behind the MFMAs: the matrix pipe works while the DMA instructions issue
+    if (u + DO2 - 1 < nut) issue_next((u + DO2 - 1) % DO2);      // behind the MFMAs: the matrix pipe works while the DMA instructions issue
     if (ks == nks - 1) {
 #pragma unroll
       for (int i = 0; i < RF2; i++)
 #pragma unroll
         for (int j = 0; j < 4; j++) {
           uint2 o; o.x = pack_bf16x2(acc2[i][j][0], acc2[i][j][1]); o.y = pack_bf16x2(acc2[i][j][2], acc2[i][j][3]);
-          *(uint2*)(p.O + (long)b * p.sO + (long)(m0 + mq2 + i * 16 + lm) * p.ldo + nc * 256 + wc2 * 64 + j * 16 + q * 4) = o;
+          *(uint2*)(cdst + (long)b * sO + (long)(m0 + mq2 + i * 16 + lm) * ldo + nc * 256 + wc2 * 64 + j * 16 + q * 4) = o;
         }
       stores_pending = true;
     }
+    if (++uu == nu) { uu = 0; cdst = dst1; ctr = true; }      // second pass
   }
   ATTN_STAMP(3);
 }
@@ -494,13 +547,22 @@ int attn_chain_fwd(eegldm_ctx* ctx, const void* qkv, long ldq, void* out, long l
   }
 }
 // backward part: dS (scaled) written, dq = dS k
+// whole-sample blocks (T = 192, batch >= half the CUs): the backward kernel can also produce dK
+bool attn_chain_bwd_fuses_kv(eegldm_ctx* ctx, int B, int T) {
+  static const bool off = getenv("EEGLDM_ATTN_NO_FUSED_KV") != nullptr, no_whole = getenv("EEGLDM_ATTN_NO_WHOLE") != nullptr;
+  return !off && !no_whole && T == 192 && B >= ctx->num_cu / 2;
+}
 int attn_chain_bwd(eegldm_ctx* ctx, const void* qkv, long ldq, const void* probs, const void* dout, long lddo, void* dq, long lddq,
-                   void* dS, int B, int T, int C) {
+                   void* dS, int B, int T, int C, int fuse_kv) {
   ChainArgs a = {};
   const bf16_t* q = (const bf16_t*)qkv;
   a.A1 = (const bf16_t*)dout; a.lda1 = lddo; a.sA1 = (long)T * lddo; a.B1 = q + 2 * C; a.ldb1 = ldq; a.sB1 = (long)T * ldq;
   a.B2 = q + C; a.ldb2 = ldq; a.sB2 = (long)T * ldq; a.P = (bf16_t*)probs; a.sP = (long)T * T; a.dS = (bf16_t*)dS; a.sdS = (long)T * T;
   a.O = (bf16_t*)dq; a.ldo = lddq; a.sO = (long)T * lddq; a.T = T; a.C = C; a.alpha = 1.0f / sqrtf((float)C);
+  if (fuse_kv) {
+    EEG_CHECK(attn_chain_bwd_fuses_kv(ctx, B, T), "fused dK / dV needs whole-sample blocks");
+    a.fuse_kv = 1; a.Q3 = q; a.ldq3 = ldq; a.sQ3 = (long)T * ldq; a.dK = (bf16_t*)dq + C;
+  }
   switch (T / 64) {
     case 1: return launch_chain<1, 1>(ctx, a, B);
     case 2: return launch_chain<2, 1>(ctx, a, B);

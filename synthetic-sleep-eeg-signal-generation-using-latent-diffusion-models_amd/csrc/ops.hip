@@ -243,14 +243,18 @@ int op_attention_bwd(eegldm_ctx* ctx, int dtype, const void* qkv, long ldq, cons
   char* dq = (char*)dqkv; char* dk = dq + (size_t)C * es; char* dv = dq + (size_t)2 * C * es;
   const float alpha = 1.0f / sqrtf((float)C);
   GemmArgs g = {};
+  const bool fused = attn_chain_ok(dtype, T, C, ldq, lddo) && lddq % 8 == 0;
   // dV[s][c] = sum_t P[t][s] dO[t][c]
   g.dtype = dtype; g.amode = GA_TR; g.bmode = GB_TR; g.A = probs; g.lda = T; g.sAb = (long)T * T; g.B = dout; g.ldb = lddo;
   g.sBb = (long)T * lddo; g.C = dv; g.ldc = lddq; g.sCb = (long)T * lddq; g.M = T; g.N = C; g.K = T; g.batch = B; g.taps = 1; g.alpha = 1.f;
   EEG_TRY(gemm_launch(ctx, g));
-  const bool fused = attn_chain_ok(dtype, T, C, ldq, lddo) && lddq % 8 == 0;
   if (fused) {
-    // dP = dO V^T, dS = alpha P o (dP - rowsum(dP o P)), dQ = dS K in one launch; dK below from the written dS
-    EEG_TRY(attn_chain_bwd(ctx, qkv, ldq, probs, dout, lddo, dq, lddq, dlogits, B, T, C));
+    // dP = dO V^T, dS = alpha P o (dP - rowsum(dP o P)), dQ = dS K in one launch; whole-sample blocks also produce dK = dS^T Q (a second
+    // pass over the score tile in LDS, read transposed: no batched TN GEMM with K = T = 192 -- three K stages per tile, 260 TF/s -- and
+    // no re-read of dS); otherwise dK below from the written dS
+    const int fk = attn_chain_bwd_fuses_kv(ctx, B, T) ? 1 : 0;
+    EEG_TRY(attn_chain_bwd(ctx, qkv, ldq, probs, dout, lddo, dq, lddq, dlogits, B, T, C, fk));
+    if (fk) return 0;
   } else {
   // dP[t][s] = sum_c dO[t][c] V[s][c]
   g = GemmArgs{};
