@@ -530,7 +530,8 @@ __global__ __launch_bounds__(NT) void thin_fwd_kernel(const ThinOp* ops, int nop
 __global__ __launch_bounds__(NT) void thin_bwd_kernel(const ThinOp* ops, int nops, const int* __restrict__ tape_off, int tape_stride, int nstat,
                                                       int maxt, const float* P, float* __restrict__ G, const float* __restrict__ d_recon,
                                                       const float* __restrict__ eps, float* __restrict__ dx_out, const float* __restrict__ tape_all,
-                                                      const float* __restrict__ stats_all, int lat, int Ll, float klw_over_B, int nparams, unsigned long long* __restrict__ prof) {
+                                                      const float* __restrict__ stats_all, int lat, int Ll, float klw_over_B, int nparams, unsigned long long* __restrict__ prof,
+                                                      int sp_off, int nspare) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const Bufs B = make_bufs(smem, maxt);
   float* PL = B.red + RED_FLOATS;
@@ -541,11 +542,35 @@ __global__ __launch_bounds__(NT) void thin_bwd_kernel(const ThinOp* ops, int nop
   P = PL; ops = (const ThinOp*)OL;
   const int b = blockIdx.x;
   const float* tape = tape_all + (size_t)b * tape_stride; const float* stats = stats_all + (size_t)b * nstat * 2;
-  // tape prefetch: the next TB_LOADT's global loads are issued (into registers) before the op that precedes it starts, so their
-  // ~2.3 us round trip runs under that op instead of in front of the next one (38 loads per window: ~90 us of the first version)
-  constexpr int PFN = 5;                               // float4 per thread: tensors of up to 5 * 4 * 512 = 10240 values
-  float4 pre[PFN];
-  int pf_op = -1;
+  // Tape prefetch by LDS-DMA into spare LDS tensors (round 3).  A tape load is a pure round trip (~2.3 us: only 256 workgroups of
+  // 512 threads run) and cost 7 200 cycles on average, 38 of them = 21 % of the kernel (EEGLDM_THIN_PROF=1) -- the round-2 prefetch
+  // into REGISTERS did not survive the calls to the op functions (values live across a call are saved to scratch, which first
+  // waits for the load).  global_load_lds needs no registers: the next `nspare` (<= 2) tape tensors stream into spare LDS buffers
+  // while the ops before them run; the TB_LOADT op then waits (vmcnt(0): also the one other prefetch in flight, issued earlier),
+  // and copies LDS -> LDS.
+  const unsigned lds_base = (unsigned)(size_t)(__attribute__((address_space(3))) void*)smem;
+  const int sp_stride = (maxt + 256) * 4;                          // bytes per spare tensor (whole 1 KB DMA instructions)
+  int pf0 = -1, pf1 = -1;                                        // op index whose tape tensor spare slot 0 / 1 holds (or is receiving)
+  auto next_loadt = [&](int j) __attribute__((always_inline)) {
+    while (j < nops && !(ops[j].kind == TB_LOADT && ops[j].cin * ops[j].Lin >= 4 && ops[j].cin * ops[j].Lin <= maxt)) j++;
+    return j;
+  };
+  auto dma_tape = [&](const int slot, const int j) __attribute__((always_inline)) {
+    const int nq = (ops[j].cin * ops[j].Lin) >> 2;                 // 16-byte chunks
+    const float4* src = (const float4*)(tape + tape_off[ops[j].save]);
+    const unsigned dst = lds_base + (unsigned)sp_off + (unsigned)(slot * sp_stride);
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+    for (int ii = wave; ii * 64 < nq; ii += NWAVE) {
+      const int q = ii * 64 + lane;
+      const unsigned off_s = __builtin_amdgcn_readfirstlane(dst + (unsigned)ii * 1024u);
+      const float4* g = src + (q < nq ? q : nq - 1);
+      asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off" ::"s"(off_s), "v"(g) : "memory", "m0");
+    }
+  };
+  if (nspare > 0) {
+    const int j0 = next_loadt(0);
+    if (j0 < nops) { dma_tape(0, j0); pf0 = j0; if (nspare > 1) { const int j1 = next_loadt(j0 + 1); if (j1 < nops) { dma_tape(1, j1); pf1 = j1; } } }
+  }
   for (int i = 0; i < nops; i++) {
     const ThinOp o = ops[i];
     const unsigned long long t0 = prof ? __builtin_readcyclecounter() : 0ull;
@@ -558,9 +583,18 @@ __global__ __launch_bounds__(NT) void thin_bwd_kernel(const ThinOp* ops, int nop
       case TB_LOADT: {
         float4* D = (float4*)B.b[o.dst];
         const int nq = (o.cin * o.Lin) >> 2;
-        if (pf_op == i) {
-#pragma unroll
-          for (int k = 0; k < PFN; k++) { const int q = threadIdx.x + k * NT; if (q < nq) D[q] = pre[k]; }
+        if (pf0 == i || pf1 == i) {
+          const int slot = pf0 == i ? 0 : 1;
+          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // this wave's DMA instructions have landed ...
+          lds_barrier();                                         // ... and so have everybody else's
+          const float4* S = (const float4*)(smem + sp_off + slot * sp_stride);
+          for (int j = threadIdx.x; j < nq; j += NT) D[j] = S[j];
+          lds_barrier();                                         // the spare tensor is free again: refill it with the load after the other slot's
+          const int other = slot == 0 ? pf1 : pf0;
+          const int jn = next_loadt((other > i ? other : i) + 1);
+          const int nv = jn < nops ? jn : -1;
+          if (slot == 0) pf0 = nv; else pf1 = nv;
+          if (jn < nops && (slot == 0 || nspare > 1)) dma_tape(slot, jn);
         } else {
           const float4* src = (const float4*)(tape + tape_off[o.save]);
           for (int j = threadIdx.x; j < nq; j += NT) D[j] = src[j];
@@ -589,20 +623,6 @@ __global__ __launch_bounds__(NT) void thin_bwd_kernel(const ThinOp* ops, int nop
         }
       } break;
     }
-    if (pf_op <= i) {      // (after op i: the loads fly while ops i+1 .. j-1 run)
-      int j = i + 1;
-      while (j < nops && ops[j].kind != TB_LOADT) j++;
-      if (j < nops && j <= i + 4) {
-        const ThinOp n = ops[j];
-        const int nq = (n.cin * n.Lin) >> 2;
-        if (nq <= PFN * NT) {
-          const float4* src = (const float4*)(tape + tape_off[n.save]);
-#pragma unroll
-          for (int k = 0; k < PFN; k++) { const int q = threadIdx.x + k * NT; if (q < nq) pre[k] = src[q]; }
-          pf_op = j;
-        }
-      }
-    }
     if (prof && blockIdx.x == 0 && threadIdx.x == 0) prof[i] = __builtin_readcyclecounter() - t0;
   }
 }
@@ -610,6 +630,15 @@ __global__ __launch_bounds__(NT) void thin_bwd_kernel(const ThinOp* ops, int nop
 size_t lds_bytes(const ThinProgram& p) {
   const size_t nops = p.fwd.size() > p.bwd.size() ? p.fwd.size() : p.bwd.size();
   return sizeof(float) * ((size_t)THIN_NBUF * p.maxt + RED_FLOATS + p.nparams + 64) + nops * sizeof(ThinOp);
+}
+// backward kernel: up to two spare LDS tensors behind everything else for the tape prefetch (as many as the 160 KB allow)
+size_t lds_bytes_bwd(const ThinProgram& p, int* sp_off, int* nspare) {
+  static const bool off = getenv("EEGLDM_THIN_NO_DMA_PREFETCH") != nullptr;
+  const size_t base = (lds_bytes(p) + 15) & ~(size_t)15, one = sizeof(float) * ((size_t)p.maxt + 256);
+  int n = off ? 0 : 2;
+  while (n > 0 && base + n * one > 160 * 1024) n--;
+  *sp_off = (int)base; *nspare = n;
+  return base + n * one;
 }
 }  // namespace
 
@@ -642,7 +671,7 @@ int thin_upload(ThinProgram* p) {
   HIP_TRY(hipMemcpy(p->d_bwd, p->bwd.data(), sizeof(ThinOp) * p->bwd.size(), hipMemcpyHostToDevice));
   HIP_TRY(hipMemcpy(p->d_tape_off, p->tape_off.data(), sizeof(int) * p->tape_off.size(), hipMemcpyHostToDevice));
   HIP_TRY(hipFuncSetAttribute((const void*)thin_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes(*p)));
-  HIP_TRY(hipFuncSetAttribute((const void*)thin_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes(*p)));
+  { int so, ns; HIP_TRY(hipFuncSetAttribute((const void*)thin_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes_bwd(*p, &so, &ns))); }
   return 0;
 }
 void thin_free(ThinProgram* p) {
@@ -666,8 +695,10 @@ int thin_backward(eegldm_ctx* ctx, const ThinProgram& p, const float* params, fl
                   float* dx, int B) {
   EEG_CHECK(p.d_bwd && p.tape && p.stats, "thin program not prepared");
   unsigned long long* prof = prof_buf();
-  hipLaunchKernelGGL(thin_bwd_kernel, dim3(B), dim3(NT), lds_bytes(p), ctx->stream, p.d_bwd, (int)p.bwd.size(), p.d_tape_off, p.tape_stride, p.nstat, p.maxt,
-                     params, grads, d_recon, eps, dx, p.tape, p.stats, p.lat, p.Ll, klw_over_B, p.nparams, prof);
+  int sp_off = 0, nspare = 0;
+  const size_t lds = lds_bytes_bwd(p, &sp_off, &nspare);
+  hipLaunchKernelGGL(thin_bwd_kernel, dim3(B), dim3(NT), lds, ctx->stream, p.d_bwd, (int)p.bwd.size(), p.d_tape_off, p.tape_stride, p.nstat, p.maxt,
+                     params, grads, d_recon, eps, dx, p.tape, p.stats, p.lat, p.Ll, klw_over_B, p.nparams, prof, sp_off, nspare);
   LAUNCH_CHECK();
   if (prof) prof_dump(ctx, p.bwd, prof, "bwd");
   return 0;
