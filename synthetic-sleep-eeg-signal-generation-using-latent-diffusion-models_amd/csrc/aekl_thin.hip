@@ -22,7 +22,8 @@ namespace {
 constexpr int NT = EEG_THIN_NT, NWAVE = NT / 64;      // threads per window (developer builds: -DEEG_THIN_NT=1024)
 constexpr int MC = THIN_MAXC;
 constexpr float GN_EPS_T = 1e-6f;
-constexpr int RED_FLOATS = NWAVE * 56 + 64;
+constexpr int RED_ROWS = NWAVE * 4;                // 16-lane rows per workgroup: one partial per row and value
+constexpr int RED_FLOATS = RED_ROWS * 56 + 64;
 
 // Workgroup barrier that orders LDS traffic only.  __syncthreads() is fence + s_barrier and the fence waits for EVERY outstanding
 // global access (s_waitcnt vmcnt(0)): the tape prefetch of the backward kernel, the tape stores of the forward kernel and the
@@ -33,22 +34,34 @@ __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(
 struct BufSel { float* base; int maxt; __device__ __forceinline__ float* operator[](int i) const { return base + (size_t)i * maxt; } };
 struct Bufs { BufSel b; float* red; };
 
-// sum of NV per-thread values over the workgroup; results in red[NWAVE*NV + i] (valid for every thread after the call)
+// sum of NV per-thread values over the workgroup; results in red[RED_ROWS*NV + i] (valid for every thread after the call).
+// Inside a 16-lane row the sum is four DPP adds (quad swaps, half-row mirror, row mirror: full-rate VALU, no LDS); the 32 row
+// partials per value then meet in LDS.  The first version reduced every value over the whole wave with six `__shfl_xor` = six
+// ds_bpermute round trips each: 312 LDS-pipe instructions for the 52 gradients of a 4 -> 4 conv, ~3.5 k cycles per call, 60 calls
+// per window in the backward kernel.
+__device__ __forceinline__ float row16_sum(float v) {
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, true));     // quad_perm [1,0,3,2]
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xF, 0xF, true));     // quad_perm [2,3,0,1]
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x141, 0xF, 0xF, true));    // row_half_mirror
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x140, 0xF, 0xF, true));    // row_mirror
+  return v;
+}
 template <int NV> __device__ __forceinline__ void block_reduce(float (&v)[NV], float* red) {
+  static_assert(NV <= 56, "row-partial area holds 56 values per row");
 #pragma unroll
-  for (int i = 0; i < NV; i++) v[i] = wave_sum(v[i]);
-  const int wave = threadIdx.x >> 6;
+  for (int i = 0; i < NV; i++) v[i] = row16_sum(v[i]);
+  const int row = threadIdx.x >> 4;
   lds_barrier();
-  if ((threadIdx.x & 63) == 0) {
+  if ((threadIdx.x & 15) == 0) {
 #pragma unroll
-    for (int i = 0; i < NV; i++) red[wave * NV + i] = v[i];
+    for (int i = 0; i < NV; i++) red[row * NV + i] = v[i];
   }
   lds_barrier();
   if (threadIdx.x < NV) {
     float s = 0.f;
 #pragma unroll
-    for (int w = 0; w < NWAVE; w++) s += red[w * NV + threadIdx.x];
-    red[NWAVE * NV + threadIdx.x] = s;
+    for (int w = 0; w < RED_ROWS; w++) s += red[w * NV + threadIdx.x];
+    red[RED_ROWS * NV + threadIdx.x] = s;
   }
   lds_barrier();
 }
@@ -183,7 +196,7 @@ __device__ void f_gn_t(const ThinOp& o, const float* P, const Bufs& B, float* __
     sq[1] = fmaf(a, a, fmaf(b, b, fmaf(c, c, fmaf(d, d, sq[1]))));
   }
   block_reduce<2>(sq, B.red);
-  const float m1 = B.red[NWAVE * 2] / (float)n, m2 = B.red[NWAVE * 2 + 1] / (float)n;
+  const float m1 = B.red[RED_ROWS * 2] / (float)n, m2 = B.red[RED_ROWS * 2 + 1] / (float)n;
   const float mean = K + m1, rstd = rsqrtf(fmaxf(m2 - m1 * m1, 0.f) + GN_EPS_T);
   if (threadIdx.x == 0) { stats[2 * o.stat] = mean; stats[2 * o.stat + 1] = rstd; }
   gn_apply_t<C>(o, P, X, Y, mean, rstd);
@@ -231,7 +244,7 @@ __device__ void f_heads_t(const ThinOp& o, const float* P, const Bufs& B, float*
     }
   }
   block_reduce<1>(part, B.red);
-  if (kl && threadIdx.x == 0) atomicAdd(kl, B.red[NWAVE] * inv_B);
+  if (kl && threadIdx.x == 0) atomicAdd(kl, B.red[RED_ROWS] * inv_B);
 }
 __device__ void f_heads(const ThinOp& o, const float* P, const Bufs& B, float* tape, const int* tape_off, const float* eps, float* z_mu, float* z_sigma,
                         float* kl, float inv_B) {
@@ -299,12 +312,12 @@ __device__ void b_conv_t(const ThinOp& o, const float* P, float* __restrict__ G,
     }
   }
   block_reduce<NV>(acc, B.red);       // ends with a barrier: every read of A above is done
-  const float* R = B.red + NWAVE * NV;
+  const float* R = B.red + RED_ROWS * NV;
   if (threadIdx.x < NW_) {
     const int co = threadIdx.x / (CIN * 3), ci = (threadIdx.x / 3) % CIN, k = threadIdx.x % 3;
-    if (k < nk) atomicAdd(G + o.w + (k * COUT + co) * CIN + ci, R[threadIdx.x]);
+    if (k < nk) G[o.w + (k * COUT + co) * CIN + ci] += R[threadIdx.x];
   } else if (threadIdx.x < NV) {
-    if (o.b >= 0) atomicAdd(G + o.b + (threadIdx.x - NW_), R[threadIdx.x]);
+    if (o.b >= 0) G[o.b + (threadIdx.x - NW_)] += R[threadIdx.x];
   }
   // ---- dX -> overwrites the activation buffer
   if (o.need_dx) {
@@ -389,9 +402,9 @@ __device__ void b_gn_t(const ThinOp& o, const float* P, float* __restrict__ G, c
     for (int i = 0; i < C; i++) { acc[i] += c == i ? sg : 0.f; acc[C + i] += c == i ? sb : 0.f; }
   }
   block_reduce<2 * C>(acc, B.red);
-  const float* R = B.red + NWAVE * 2 * C;
-  if (threadIdx.x < C) atomicAdd(G + o.gw + threadIdx.x, R[threadIdx.x]);
-  else if (threadIdx.x < 2 * C) atomicAdd(G + o.gb + threadIdx.x - C, R[threadIdx.x]);
+  const float* R = B.red + RED_ROWS * 2 * C;
+  if (threadIdx.x < C) G[o.gw + threadIdx.x] += R[threadIdx.x];
+  else if (threadIdx.x < 2 * C) G[o.gb + threadIdx.x - C] += R[threadIdx.x];
   float s1 = 0.f, s2 = 0.f;
 #pragma unroll
   for (int c = 0; c < C; c++) { s1 = fmaf(ga[c], R[C + c], s1); s2 = fmaf(ga[c], R[c], s2); }
@@ -459,12 +472,12 @@ __device__ void b_heads_t(const ThinOp& o, const float* P, float* __restrict__ G
     for (int ci = 0; ci < LAT; ci++) DH[ci * L + l] = dh[ci];
   }
   block_reduce<NV>(acc, B.red);
-  const float* R = B.red + NWAVE * NV;
+  const float* R = B.red + RED_ROWS * NV;
   const int t = threadIdx.x;
-  if (t < LAT * LAT) atomicAdd(G + o.w + t, R[t]);
-  else if (t < LAT * LAT + LAT) atomicAdd(G + o.b + (t - LAT * LAT), R[t]);
-  else if (t < 2 * LAT * LAT + LAT) atomicAdd(G + o.w2 + (t - LAT * LAT - LAT), R[t]);
-  else if (t < NV) atomicAdd(G + o.b2 + (t - 2 * LAT * LAT - LAT), R[t]);
+  if (t < LAT * LAT) G[o.w + t] += R[t];
+  else if (t < LAT * LAT + LAT) G[o.b + (t - LAT * LAT)] += R[t];
+  else if (t < 2 * LAT * LAT + LAT) G[o.w2 + (t - LAT * LAT - LAT)] += R[t];
+  else if (t < NV) G[o.b2 + (t - 2 * LAT * LAT - LAT)] += R[t];
   lds_barrier();
 }
 __device__ void b_heads(const ThinOp& o, const float* P, float* G, const Bufs& B, const float* tape, const int* tape_off, const float* eps, float klw_over_B) {
@@ -536,10 +549,16 @@ __global__ __launch_bounds__(NT) void thin_bwd_kernel(const ThinOp* ops, int nop
   const Bufs B = make_bufs(smem, maxt);
   float* PL = B.red + RED_FLOATS;
   for (int j = threadIdx.x; j < nparams; j += NT) PL[j] = P[j];
-  int* OL = (int*)(PL + ((nparams + 3) & ~3));
+  // The window's parameter gradients accumulate in LDS (every parameter is produced by exactly one thread of one op) and go out as
+  // ONE pass of global atomics at the end: issued per op (round 2) they were in flight -- ~2 us each -- whenever the next tape load
+  // needed `s_waitcnt vmcnt(0)` for its LDS-DMA, and the whole workgroup waited at that op's barrier for wave 0's atomics.
+  float* GL = PL + ((nparams + 3) & ~3);
+  for (int j = threadIdx.x; j < nparams; j += NT) GL[j] = 0.f;
+  int* OL = (int*)(GL + ((nparams + 3) & ~3));
   for (int j = threadIdx.x; j < nops * (int)(sizeof(ThinOp) / 4); j += NT) OL[j] = ((const int*)ops)[j];
   lds_barrier();
   P = PL; ops = (const ThinOp*)OL;
+  float* const Gglobal = G; G = GL;
   const int b = blockIdx.x;
   const float* tape = tape_all + (size_t)b * tape_stride; const float* stats = stats_all + (size_t)b * nstat * 2;
   // Tape prefetch by LDS-DMA into spare LDS tensors (round 3).  A tape load is a pure round trip (~2.3 us: only 256 workgroups of
@@ -625,11 +644,13 @@ __global__ __launch_bounds__(NT) void thin_bwd_kernel(const ThinOp* ops, int nop
     }
     if (prof && blockIdx.x == 0 && threadIdx.x == 0) prof[i] = __builtin_readcyclecounter() - t0;
   }
+  lds_barrier();
+  for (int j = threadIdx.x; j < nparams; j += NT) atomicAdd(Gglobal + j, GL[j]);
 }
 
 size_t lds_bytes(const ThinProgram& p) {
   const size_t nops = p.fwd.size() > p.bwd.size() ? p.fwd.size() : p.bwd.size();
-  return sizeof(float) * ((size_t)THIN_NBUF * p.maxt + RED_FLOATS + p.nparams + 64) + nops * sizeof(ThinOp);
+  return sizeof(float) * ((size_t)THIN_NBUF * p.maxt + RED_FLOATS + 2 * (size_t)p.nparams + 64) + nops * sizeof(ThinOp);   // (2 x: parameters, and the backward kernel's gradient accumulators)
 }
 // backward kernel: up to two spare LDS tensors behind everything else for the tape prefetch (as many as the 160 KB allow)
 size_t lds_bytes_bwd(const ThinProgram& p, int* sp_off, int* nspare) {
