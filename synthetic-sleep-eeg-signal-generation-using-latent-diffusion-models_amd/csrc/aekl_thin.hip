@@ -554,13 +554,17 @@ __global__ __launch_bounds__(NT) void thin_bwd_kernel(const ThinOp* ops, int nop
   // needed `s_waitcnt vmcnt(0)` for its LDS-DMA, and the whole workgroup waited at that op's barrier for wave 0's atomics.
   float* GL = PL + ((nparams + 3) & ~3);
   for (int j = threadIdx.x; j < nparams; j += NT) GL[j] = 0.f;
-  int* OL = (int*)(GL + ((nparams + 3) & ~3));
+  // the window's GroupNorm statistics (written by the forward launch) also come to LDS once: read from global at the top of every
+  // GroupNorm-backward / recompute op they were a dependent ~2 us round trip in front of 50 ops
+  float* SL = GL + ((nparams + 3) & ~3);
+  for (int j = threadIdx.x; j < 2 * nstat; j += NT) SL[j] = stats_all[(size_t)blockIdx.x * nstat * 2 + j];
+  int* OL = (int*)(SL + ((2 * nstat + 3) & ~3));
   for (int j = threadIdx.x; j < nops * (int)(sizeof(ThinOp) / 4); j += NT) OL[j] = ((const int*)ops)[j];
   lds_barrier();
   P = PL; ops = (const ThinOp*)OL;
   float* const Gglobal = G; G = GL;
   const int b = blockIdx.x;
-  const float* tape = tape_all + (size_t)b * tape_stride; const float* stats = stats_all + (size_t)b * nstat * 2;
+  const float* tape = tape_all + (size_t)b * tape_stride; const float* stats = SL;
   // Tape prefetch by LDS-DMA into spare LDS tensors (round 3).  A tape load is a pure round trip (~2.3 us: only 256 workgroups of
   // 512 threads run) and cost 7 200 cycles on average, 38 of them = 21 % of the kernel (EEGLDM_THIN_PROF=1) -- the round-2 prefetch
   // into REGISTERS did not survive the calls to the op functions (values live across a call are saved to scratch, which first
@@ -650,7 +654,7 @@ __global__ __launch_bounds__(NT) void thin_bwd_kernel(const ThinOp* ops, int nop
 
 size_t lds_bytes(const ThinProgram& p) {
   const size_t nops = p.fwd.size() > p.bwd.size() ? p.fwd.size() : p.bwd.size();
-  return sizeof(float) * ((size_t)THIN_NBUF * p.maxt + RED_FLOATS + 2 * (size_t)p.nparams + 64) + nops * sizeof(ThinOp);   // (2 x: parameters, and the backward kernel's gradient accumulators)
+  return sizeof(float) * ((size_t)THIN_NBUF * p.maxt + RED_FLOATS + 2 * (size_t)p.nparams + 2 * (size_t)p.nstat + 72) + nops * sizeof(ThinOp);   // (2 x: parameters, and the backward kernel's gradient accumulators)
 }
 // backward kernel: up to two spare LDS tensors behind everything else for the tape prefetch (as many as the 160 KB allow)
 size_t lds_bytes_bwd(const ThinProgram& p, int* sp_off, int* nspare) {
