@@ -5,6 +5,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspa
 import eegldm
 from eegldm._lib import lib, ptr, check, Context
 victim = sys.argv[1] if len(sys.argv) > 1 else "bwd"
+opts = sys.argv[2:]          # nosilu | nodg | noadd
 ctx = eegldm.default_context(0)
 ctx2 = Context(0, use_torch_stream=False)
 torch.manual_seed(0)
@@ -30,7 +31,8 @@ def run(noise):
         for _ in range(10): noise()
     for _ in range(6):
         if victim == "bwd":
-            check(lib.eegldm_groupnorm_bwd(ctx.h, ptr(x), C, ptr(ga), ptr(be), ptr(st), ptr(dy), C, ptr(out), C, ptr(dg), ptr(db), B, L, C, 32, 1, 0, ptr(ad), C, 1))
+            check(lib.eegldm_groupnorm_bwd(ctx.h, ptr(x), C, ptr(ga), ptr(be), ptr(st), ptr(dy), C, ptr(out), C, None if "nodg" in opts else ptr(dg), None if "nodg" in opts else ptr(db),
+                                           B, L, C, 32, 0 if "nosilu" in opts else 1, 0, None if "noadd" in opts else ptr(ad), C, 1))
         else:
             check(lib.eegldm_groupnorm_fwd(ctx.h, ptr(x), C, ptr(ga), ptr(be), ptr(out), C, ptr(st2), B, L, C, 32, 1e-6, 1, 0, None, 0, 1))
     torch.cuda.synchronize(); ctx2.sync()
@@ -38,4 +40,4 @@ def run(noise):
 quiet = run(None)
 for name, fn in [("wgrad3", noise_wgrad), ("conv3_fwd", noise_fwd), ("conv3_dgrad", noise_dgrad), ("linear_1tap", noise_lin)]:
     nd = [int((quiet != run(fn)).sum()) for _ in range(3)]
-    print(f"victim gn_{victim} (BWD_NTH={os.environ.get('EEGLDM_GN_BWD_NTH', '1024')} FWD_NTH={os.environ.get('EEGLDM_GN_FWD_NTH', '1024')}) beside {name}: differing elements {nd}", flush=True)
+    print(f"[{' '.join(opts)}] victim gn_{victim} (BWD_NTH={os.environ.get('EEGLDM_GN_BWD_NTH', '1024')} FWD_NTH={os.environ.get('EEGLDM_GN_FWD_NTH', '1024')}) beside {name}: differing elements {nd}", flush=True)
