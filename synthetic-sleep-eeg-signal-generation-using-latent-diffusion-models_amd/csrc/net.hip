@@ -208,8 +208,11 @@ int attn_backward(NetBase* u, const AttnDesc& a, const AttnTape& t, const View& 
   EEG_TRY(op_conv_wgrad(ctx, dt, t.xn.p, C, dqkv, 3 * C, u->G(a.qkv_w), u->G(a.qkv_b), B, T, C, 3 * C, 1, 1, 0, 0));
   void* dxn; ALLOC_OR_FAIL(dxn, u->alloc_act((long)B * T, C));
   EEG_TRY(op_conv_dgrad(ctx, dt, dqkv, 3 * C, u->W(a.qkv_w), dxn, C, B, T, C, 3 * C, 1, 1, 0, 0, nullptr, 0));
-  EEG_TRY(eegldm_groupnorm_bwd(ctx, t.x.p, t.x.ld, u->P(a.n_w), u->P(a.n_b), t.st, dxn, C, dx.p, dx.ld, u->G(a.n_w), u->G(a.n_b),
-                               B, T, C, AG, 0, 0, dout.p, dout.ld, dt));
+  // (dgamma / dbeta slot fold: batched with all the others in the grouped mode, else right here)
+  int gn_deferred = 0;
+  EEG_TRY(op_groupnorm_bwd(ctx, t.x.p, t.x.ld, u->P(a.n_w), u->P(a.n_b), t.st, dxn, C, dx.p, dx.ld, u->G(a.n_w), u->G(a.n_b),
+                           B, T, C, AG, 0, 0, dout.p, dout.ld, dt, nullptr, 0, nullptr, nullptr, 0, nullptr, u->param_grads ? &gn_deferred : nullptr));
+  if (gn_deferred == 1) EEG_TRY(op_gn_slot_reduce_deferred(ctx, u->G(a.n_w), u->G(a.n_b), C));
   u->arena.release(mk);
   return 0;
 }

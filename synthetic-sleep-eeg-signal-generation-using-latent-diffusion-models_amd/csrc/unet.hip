@@ -340,8 +340,13 @@ extern "C" int eegldm_unet_backward(eegldm_unet* u, const float* dy, float* dx_o
   View da; ALLOC_OR_FAIL(da.p, u->alloc_act((long)B * L, mc)); da.ld = mc;
   EEG_TRY(op_conv_dgrad(ctx, dt, dyv.p, cout, u->W(u->off_out_w), da.p, mc, B, L, mc, cout, 3, 1, 1, 1, nullptr, 0));
   View dh; ALLOC_OR_FAIL(dh.p, u->alloc_act((long)B * L, mc)); dh.ld = mc; dh.C = mc;
-  EEG_TRY(eegldm_groupnorm_bwd(ctx, u->h_last.p, u->h_last.ld, u->P(u->off_out_gw), u->P(u->off_out_gb), u->st_out, da.p, mc, dh.p, mc,
-                               u->G(u->off_out_gw), u->G(u->off_out_gb), B, L, mc, GN_G, 1, 0, nullptr, 0, dt));
+  {
+    int gn_deferred = 0;       // (slot fold batched with the others in the grouped mode)
+    EEG_TRY(op_groupnorm_bwd(ctx, u->h_last.p, u->h_last.ld, u->P(u->off_out_gw), u->P(u->off_out_gb), u->st_out, da.p, mc, dh.p, mc,
+                             u->G(u->off_out_gw), u->G(u->off_out_gb), B, L, mc, GN_G, 1, 0, nullptr, 0, dt, nullptr, 0, nullptr, nullptr, 0, nullptr,
+                             u->param_grads ? &gn_deferred : nullptr));
+    if (gn_deferred == 1) EEG_TRY(op_gn_slot_reduce_deferred(ctx, u->G(u->off_out_gw), u->G(u->off_out_gb), mc));
+  }
   // ---- output blocks, reversed.  Each yields d(cat_j); its skip half is kept for the input path.
   size_t ri = u->rt.size(), ai = u->at.size();
   std::vector<View> dskip(n_in);
