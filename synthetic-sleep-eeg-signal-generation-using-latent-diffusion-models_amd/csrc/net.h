@@ -71,6 +71,8 @@ struct NetBase {
   bool param_grads = true;       // false: backward propagates to the input only (G step through D)
   Arena arena;
   float* emb_all = nullptr; int etot = 0;   // batched timestep-embedding projections (UNet)
+  long emb_ld = 0;                           // row stride of emb_all: etot, or 0 when all samples share one precomputed row (sampler)
+  const float* emb_shared = nullptr;         // set by the sampler for the duration of an eval forward (unet_set_shared_emb)
   std::vector<ResTape> rt; std::vector<AttnTape> at;
 
   const void* W(long off) const { return (const char*)wT + (size_t)off * dtype_size(dtype); }
@@ -102,6 +104,10 @@ int attn_backward(NetBase* u, const AttnDesc& a, const AttnTape& t, const View& 
 // accessors for the sampler (sampler.hip); the struct itself is private to unet.hip
 eegldm_ctx* unet_ctx(const eegldm_unet* u);
 int unet_in_channels(const eegldm_unet* u);
+int unet_emb_width(const eegldm_unet* u);
+long unet_embed_work_floats(const eegldm_unet* u);
+int unet_embed_table(eegldm_unet* u, const int64_t* tsteps_dev, int n, float* table, float* work);
+void unet_set_shared_emb(eegldm_unet* u, const float* row);
 int unet_out_channels(const eegldm_unet* u);
 void sampler_release(const eegldm_unet* u);
 eegldm_ctx* aekl_ctx(const eegldm_aekl* a);

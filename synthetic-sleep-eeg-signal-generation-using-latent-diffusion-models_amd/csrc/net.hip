@@ -75,7 +75,7 @@ int res_forward(NetBase* u, const ResDesc& r, const View& x, int B, int Lin, con
                                r.updown, r.updown ? t.xr.p : nullptr, t.xr.ld, dt));
   ALLOC_OR_FAIL(t.h1.p, u->alloc_act((long)B * Lout, r.cout)); t.h1.ld = r.cout; t.h1.C = r.cout;
   EEG_TRY(op_conv_fwd(ctx, dt, t.a1.p, t.a1.ld, u->W(r.c1_w), u->P(r.c1_b), t.h1.p, t.h1.ld, B, Lout, r.cin, r.cout, 3, 1, 1, 1,
-                      r.emb_col >= 0 ? u->emb_all + r.emb_col : nullptr, u->etot, nullptr, 0));
+                      r.emb_col >= 0 ? u->emb_all + r.emb_col : nullptr, u->emb_ld, nullptr, 0));
   ALLOC_OR_FAIL(t.a2.p, u->alloc_act((long)B * Lout, r.cout)); t.a2.ld = r.cout; t.a2.C = r.cout;
   EEG_TRY(eegldm_groupnorm_fwd(ctx, t.h1.p, t.h1.ld, u->P(r.gn2_w), u->P(r.gn2_b), t.a2.p, t.a2.ld, t.st2, B, Lout, r.cout, r.groups, GN_EPS, 1,
                                0, nullptr, 0, dt));

@@ -715,8 +715,16 @@ int gn_fwd_t(eegldm_ctx* ctx, const void* x, long ldx, const float* gamma, const
     // threads per block: 1024 = one (sample, 64-channel) slab per block; 512 / 256 = narrower slabs (32 / 16 channels), 2 / 4x as many
     // independent blocks per CU whose load / reduce / store phases interleave (EEGLDM_GN_FWD_NTH; narrow slabs use the XCD-aware order)
     static const int fwd_nth = getenv("EEGLDM_GN_FWD_NTH") ? atoi(getenv("EEGLDM_GN_FWD_NTH")) : 1024;
-    const int nth = (fwd_nth == 512 || fwd_nth == 256) ? fwd_nth : 1024;
+    int nth = (fwd_nth == 512 || fwd_nth == 256) ? fwd_nth : 1024;
     int rpt = 0; int cc = off ? 0 : resident_chunk(L, C, G, resample == 1, fwd_rpt_max, &rpt, nth);
+    // a launch that leaves most of the chip idle (sampling one window per call: 1-8 slabs) is a latency chain, not a bandwidth problem:
+    // 16-channel slabs on 256 threads are 4x as many, shorter blocks (DDIM-50 at B = 1: 71.5 -> 64.5 ms).  The fp64 group sums make
+    // the statistics independent of the slab shape, so the outputs do not change.
+    static const bool no_few = getenv("EEGLDM_GN_NO_FEW_SLAB_NARROW") != nullptr;
+    if (!no_few && cc && nth == 1024 && (long)(C / cc) * B <= ctx->num_cu / 4) {
+      int rpt2 = 0; const int cc2 = resident_chunk(L, C, G, resample == 1, fwd_rpt_max, &rpt2, 256);
+      if (cc2 && cc2 * (int)sizeof(T) >= 32) { nth = 256; cc = cc2; rpt = rpt2; }
+    }
     // measured (tools/debug/gn_bench.py): wins while the rows are at least a 128-byte line and the blocks fit two rounds
     // (1024 blocks = the 100 MB concat tensors of the up path: 47-48 us one-pass vs 51 us split)
     static const long fwd_bpc = getenv("EEGLDM_GN_FWD_BLOCKS_PER_CU") ? atol(getenv("EEGLDM_GN_FWD_BLOCKS_PER_CU")) : 4;

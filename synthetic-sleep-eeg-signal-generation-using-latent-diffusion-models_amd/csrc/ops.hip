@@ -22,6 +22,10 @@ int op_conv_fwd(eegldm_ctx* ctx, int dtype, const void* x, long ldx, const void*
     return dconv_run(ctx, dtype, false, x, ldx, w, bias, resid, ldr, y, ldy, B, Lin, Lout, Cin, Cout, K, stride, pad_l, act_slope);
   }
   EEG_CHECK(act_slope <= 0.f, "fused activation is only available on the thin-input direct conv");
+  if (stride == 1 && ((K == 3 && pad_l == 1 && pad_r == 1) || (K == 1 && pad_l == 0 && pad_r == 0))) {   // a few hundred rows (one window per call): conv_skinny.hip
+    const int rc = conv_skinny_try(ctx, dtype, x, ldx, w, Cin, Cout, K, bias, rowvec, ld_rowvec, resid, ldr, y, ldy, B, Lin);
+    if (rc != 0) return rc < 0 ? rc : 0;
+  }
   if (K == 3 && stride == 1 && pad_l == 1 && pad_r == 1) {      // HBM-bound wide-and-shallow layers: weights stay in registers (conv_ws.hip)
     const int rc = conv_ws_try(ctx, dtype, x, ldx, w, Cin, Cout, 0, bias, rowvec, ld_rowvec, resid, ldr, y, ldy, B, Lin);
     if (rc != 0) return rc < 0 ? rc : 0;

@@ -242,31 +242,52 @@ extern "C" int eegldm_unet_sync_weights(eegldm_unet* u) {
   return u->sync_weights();
 }
 
+// temb -> Linear -> SiLU -> Linear -> SiLU -> every ResBlock's embedding projection in one Linear (unet.py:526-529, 316); n rows
+static int embed_chain(eegldm_unet* u, const int64_t* tsteps, int n, float* e0, float* h1e, float* a1e, float* emb, float* semb, float* emb_all) {
+  eegldm_ctx* ctx = u->ctx; const int mc = u->mc, te = u->te, F = EEGLDM_F32;
+  EEG_TRY(ew_temb(ctx, tsteps, e0, n, mc, F));
+  EEG_TRY(op_linear(ctx, F, e0, mc, u->P(u->off_te0_w), mc, u->P(u->off_te0_b), h1e, te, n, te, mc, 1));
+  EEG_TRY(ew_silu(ctx, h1e, a1e, (long)n * te, F));
+  EEG_TRY(op_linear(ctx, F, a1e, te, u->P(u->off_te2_w), te, u->P(u->off_te2_b), emb, te, n, te, te, 1));
+  EEG_TRY(ew_silu(ctx, emb, semb, (long)n * te, F));
+  return op_linear(ctx, F, semb, te, u->P(u->off_emb_w), te, u->P(u->off_emb_b), emb_all, u->etot, n, u->etot, te, 1);
+}
+// The sampler's timesteps are known before the loop starts and shared by all samples: their embedding rows as ONE batch
+// (table[i] = the etot projections of tsteps[i]; work: n * unet_embed_work_floats() floats), instead of six tiny launches per step.
+int unet_emb_width(const eegldm_unet* u) { return u->etot; }
+long unet_embed_work_floats(const eegldm_unet* u) { return (long)u->mc + 4L * u->te; }
+int unet_embed_table(eegldm_unet* u, const int64_t* tsteps_dev, int n, float* table, float* work) {
+  EEG_CHECK(u && u->params && tsteps_dev && table && work && n > 0, "bad argument");
+  const long te = u->te;
+  float* e0 = work; float* h1e = e0 + (long)n * u->mc; float* a1e = h1e + n * te; float* emb = a1e + n * te; float* semb = emb + n * te;
+  return embed_chain(u, tsteps_dev, n, e0, h1e, a1e, emb, semb, table);
+}
+void unet_set_shared_emb(eegldm_unet* u, const float* row) { u->emb_shared = row; }
+
 extern "C" int eegldm_unet_forward(eegldm_unet* u, const float* x, const int64_t* tsteps, float* y, int B, int L, int training) {
   EEG_CHECK(u && x && tsteps && y, "null argument");
   EEG_CHECK(u->params, "bind parameters first");
   EEG_CHECK(B > 0 && L > 0 && (L % (1 << (u->cfg.n_mult - 1))) == 0, "L=%d must be divisible by 2^(levels-1)", L);
-  (void)training;
   eegldm_ctx* ctx = u->ctx; const int dt = u->dtype; const int mc = u->mc, te = u->te;
   u->arena.reset(); u->rt.clear(); u->at.clear(); u->in_out.clear(); u->cat.clear();
   u->B = B; u->L = L; u->have_tape = false;
 
   // ---- timestep embedding MLP + all ResBlock embedding projections (unet.py:526-529, 316).
   // Tiny (B x 4mc): always fp32 on the fp32 master weights, whatever the activation dtype.
-  const int F = EEGLDM_F32;
-  auto fbuf = [&](long n) { return (float*)u->arena.alloc(sizeof(float) * (size_t)n); };
-  ALLOC_OR_FAIL(u->e0, fbuf((long)B * mc));
-  EEG_TRY(ew_temb(ctx, tsteps, u->e0, B, mc, F));
-  ALLOC_OR_FAIL(u->h1e, fbuf((long)B * te));
-  EEG_TRY(op_linear(ctx, F, u->e0, mc, u->P(u->off_te0_w), mc, u->P(u->off_te0_b), u->h1e, te, B, te, mc, 1));
-  ALLOC_OR_FAIL(u->a1e, fbuf((long)B * te));
-  EEG_TRY(ew_silu(ctx, u->h1e, u->a1e, (long)B * te, F));
-  ALLOC_OR_FAIL(u->emb, fbuf((long)B * te));
-  EEG_TRY(op_linear(ctx, F, u->a1e, te, u->P(u->off_te2_w), te, u->P(u->off_te2_b), u->emb, te, B, te, te, 1));
-  ALLOC_OR_FAIL(u->semb, fbuf((long)B * te));
-  EEG_TRY(ew_silu(ctx, u->emb, u->semb, (long)B * te, F));
-  ALLOC_OR_FAIL(u->emb_all, fbuf((long)B * u->etot));
-  EEG_TRY(op_linear(ctx, F, u->semb, te, u->P(u->off_emb_w), te, u->P(u->off_emb_b), u->emb_all, u->etot, B, u->etot, te, 1));
+  if (u->emb_shared && !training) {
+    // the sampler computed this timestep's row once for the whole run (unet_embed_table): every sample shares it (row stride 0)
+    u->emb_all = const_cast<float*>(u->emb_shared); u->emb_ld = 0;
+  } else {
+    auto fbuf = [&](long n) { return (float*)u->arena.alloc(sizeof(float) * (size_t)n); };
+    ALLOC_OR_FAIL(u->e0, fbuf((long)B * mc));
+    ALLOC_OR_FAIL(u->h1e, fbuf((long)B * te));
+    ALLOC_OR_FAIL(u->a1e, fbuf((long)B * te));
+    ALLOC_OR_FAIL(u->emb, fbuf((long)B * te));
+    ALLOC_OR_FAIL(u->semb, fbuf((long)B * te));
+    ALLOC_OR_FAIL(u->emb_all, fbuf((long)B * u->etot));
+    u->emb_ld = u->etot;
+    EEG_TRY(embed_chain(u, tsteps, B, u->e0, u->h1e, u->a1e, u->emb, u->semb, u->emb_all));
+  }
 
   // ---- concat buffers: output block j consumes [h (c1) | skip (ich)] where skip = input block n_in-1-j
   const int n_in = (int)u->in_blocks.size(), n_out = (int)u->out_blocks.size();

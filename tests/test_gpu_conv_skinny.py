@@ -1,0 +1,83 @@
+"""-m gpu: the few-row forward conv / linear kernel (csrc/conv_skinny.hip) that serves the UNet when ONE window is sampled per call
+(sample_trials.py:149-163).  Every k3 / 1x1 layer shape of the config_ldm UNet at B = 1 (and a ragged B = 2 case whose row count is
+not a multiple of the 16/32-row tiles), bias + time-embedding row + residual, against torch's fp32 conv on the bf16-rounded
+operands; the three register tilings (EEGLDM_CONV_SKINNY_TILE) and the general kernel (EEGLDM_NO_CONV_SKINNY=1) must agree with
+each other to accumulation order (each in a subprocess: the switches are read once per process)."""
+import math
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+SCRIPT = r'''
+import sys, math, numpy as np, torch, torch.nn.functional as F
+sys.path.insert(0, %r); sys.path.insert(0, %r)
+import gpu_util as G
+from param_gen import normal
+CASES = [  # B, L, Cin, Cout, K, rowvec, resid
+    (1, 768, 128, 128, 3, 1, 0), (1, 768, 128, 128, 3, 0, 1), (1, 384, 256, 256, 3, 1, 0), (1, 192, 512, 512, 3, 0, 1),
+    (1, 192, 1024, 512, 3, 1, 0), (1, 192, 768, 512, 3, 1, 0), (1, 384, 768, 256, 3, 1, 0), (1, 384, 512, 256, 3, 1, 0),
+    (1, 768, 384, 128, 3, 1, 0), (1, 768, 256, 128, 3, 1, 0), (1, 384, 128, 256, 3, 1, 0), (1, 192, 256, 512, 3, 1, 0),
+    (1, 192, 512, 1536, 1, 0, 0), (1, 192, 512, 512, 1, 0, 1), (1, 192, 1024, 512, 1, 0, 0), (1, 768, 384, 128, 1, 0, 0),
+    (2, 72, 96, 48, 3, 1, 1), (3, 40, 160, 48, 1, 0, 1), (2, 24, 32, 16, 3, 0, 0), (5, 192, 512, 512, 3, 1, 1),
+]
+c = G.ctx(); dt = G.BF16; out = {}
+for ci, (B, L, Cin, Cout, K, rv, rs) in enumerate(CASES):
+    x = torch.from_numpy(normal((B, Cin, L), seed=10 + ci)).bfloat16().float()
+    w = (torch.from_numpy(normal((Cout, Cin, K), seed=40 + ci)) / math.sqrt(Cin * K)).bfloat16().float()
+    b = torch.from_numpy(normal((Cout,), seed=70 + ci))
+    e = torch.from_numpy(normal((B, Cout), seed=100 + ci)) if rv else None
+    r = torch.from_numpy(normal((B, Cout, L), seed=130 + ci)).bfloat16().float() if rs else None
+    ref = F.conv1d(x, w, b, padding=K // 2)
+    if rv: ref = ref + e[:, :, None]
+    if rs: ref = ref + r
+    xd, wd, bd = G.nlc(x, dt), G.pack_w(w, dt), b.to(G.DEV)
+    ed = e.to(G.DEV) if rv else None; rd = G.nlc(r, dt) if rs else None
+    yd = torch.full((B * L, Cout), float("nan"), device=G.DEV, dtype=torch.bfloat16)
+    G.check(G.lib.eegldm_conv1d_fwd(c.h, G.ptr(xd), Cin, G.ptr(wd), G.ptr(bd), G.ptr(yd), Cout, B, L, Cin, Cout, K, 1, K // 2, K // 2,
+                                    G.ptr(ed) if rv else None, Cout if rv else 0, G.ptr(rd) if rs else None, Cout if rs else 0, dt))
+    y = G.ncl(yd, B, L).float().cpu()
+    assert torch.isfinite(y).all(), CASES[ci]
+    G.assert_close(y, ref, **G.TOL[dt], name="case %%d %%s" %% (ci, CASES[ci]))
+    out["y%%d" %% ci] = y.numpy()
+    if rs:   # in place: the residual IS the output buffer (net.hip: out = conv2(h) + out)
+        yi = rd.clone()
+        G.check(G.lib.eegldm_conv1d_fwd(c.h, G.ptr(xd), Cin, G.ptr(wd), G.ptr(bd), G.ptr(yi), Cout, B, L, Cin, Cout, K, 1, K // 2, K // 2,
+                                        G.ptr(ed) if rv else None, Cout if rv else 0, G.ptr(yi), Cout, dt))
+        assert torch.equal(yi.view(torch.int16), yd.view(torch.int16)), ("in-place residual", CASES[ci])
+np.savez(sys.argv[1], **out)
+print("ok")
+''' % (ROOT, os.path.join(ROOT, "tests"))
+
+
+def _run(tmp_path, name, env_extra):
+    out = tmp_path / (name + ".npz")
+    env = dict(os.environ); env.update(env_extra)
+    env["PYTHONPATH"] = os.path.join(ROOT, "tests", "golden") + os.pathsep + env.get("PYTHONPATH", "")
+    r = subprocess.run([sys.executable, "-c", SCRIPT, str(out)], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, (name, r.stdout[-2000:], r.stderr[-4000:])
+    return np.load(out)
+
+
+def test_skinny_conv_matches_fp32_reference_and_general_kernel(tmp_path):
+    ref = _run(tmp_path, "default", {})
+    for name, env in [("tile11", {"EEGLDM_CONV_SKINNY_TILE": "11"}), ("tile21", {"EEGLDM_CONV_SKINNY_TILE": "21"}),
+                      ("tile22", {"EEGLDM_CONV_SKINNY_TILE": "22"}), ("general_kernel", {"EEGLDM_NO_CONV_SKINNY": "1"})]:
+        v = _run(tmp_path, name, env)          # each run already checked itself against the fp32 reference
+        for k in ref.files:
+            d = float(np.linalg.norm(v[k] - ref[k])) / (float(np.linalg.norm(ref[k])) + 1e-12)
+            assert d < 4e-3, (name, k, d)      # same products, other summation order: bf16 rounding flips only
+
+
+def test_small_shape_primitives_still_pass_on_the_general_kernel():
+    """The small conv cases of test_gpu_primitives.py (tile edges inside samples, K tails, partial column tiles) take the few-row
+    kernel by default; run them once more with it switched off so the general kernel's edge handling stays covered."""
+    env = dict(os.environ); env["EEGLDM_NO_CONV_SKINNY"] = "1"
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(ROOT, "tests", "test_gpu_primitives.py"), "-x", "-q", "-m", "gpu",
+                        "-k", "conv1d or linear", "-p", "no:cacheprovider"], env=env, capture_output=True, text=True, timeout=1500, cwd=ROOT)
+    assert r.returncode == 0, (r.stdout[-3000:], r.stderr[-2000:])
