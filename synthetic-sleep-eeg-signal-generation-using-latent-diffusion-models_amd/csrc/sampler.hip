@@ -2,10 +2,12 @@
 // (noise -> [UNet, scheduler.step] x N -> decode(z / scale_factor)) and of sample_trials_ddpm.py:99-104 /
 // util.py:261-285 (pixel-space model, 1000-step ancestral sampler).  Host code only.
 //
-// The reference samples ONE window per call (sample_trials.py:149-163): at batch 1 a UNet forward is ~350 launches of
-// microsecond kernels and the host's launch rate, not the GPU, sets the latency.  The forward pass is therefore captured
-// once per (B, L) into a hipGraph (activation arena, timestep buffer and latent buffer have fixed addresses) and the loop
-// replays it: per step one fill of the timestep buffer, one graph launch and one scheduler-step kernel.
+// The reference samples ONE window per call (sample_trials.py:149-163).  At batch 1 a UNet forward is ~130 dependent launches whose
+// own latency (not the host's launch rate: the rocprofv3 trace shows them back to back) sets the time per step, so the work went
+// into the kernels of that chain (conv_skinny.hip, few-slab GroupNorm) and into taking launches out of the step: the
+// embedding rows of all timesteps are computed once per run (below).  The forward CAN be replayed from a hipGraph captured once per
+// (B, L) (activation arena, timestep buffer and latent buffer have fixed addresses) -- opt-in, because ROCm's graph launch measured
+// slower than the eager launches at B = 1 and equal at B = 256.
 #include <map>
 #include <mutex>
 #include <tuple>
