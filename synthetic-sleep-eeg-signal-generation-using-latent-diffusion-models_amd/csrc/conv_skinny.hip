@@ -32,11 +32,33 @@ struct SkArgs {
   const bf16_t* resid; long ldr;
   bf16_t* y; long ldy;
   int M, L, N;
+  // GroupNorm statistics out (producer side): every 16-row x 4-channel lane quad of the output leaves (sum, sum of squares) of its bf16-ROUNDED
+  // values -- what a GroupNorm kernel reading the stored tensor would see -- in its own slot part_out[(sample * L/16 + row fragment) * N/4 + quad]:
+  // plain stores, no zeroing, no contention (fp64 atomics on the 64 (sample, group) sums cost the producer +6 us: ~125 ns per same-address atomic)
+  float2* part_out;
+  // GroupNorm (+ SiLU) on the activation operand (consumer side, GN kernels): x is the RAW tensor, gn_part its producer's slots
+  const float2* gn_part; const float* gn_gamma; const float* gn_beta; int gn_cpg; float gn_eps; int gn_silu;
 };
 
-template <int TAPS, int RF, int CF>
+constexpr int SK_GN_MAXC = 1024;            // widest normalised operand (scale / shift table in LDS)
+
+// 8 bf16 activations -> GroupNorm scale / shift (+ SiLU) -> 8 bf16, the rounding the stand-alone GroupNorm kernel applies to its output
+__device__ __forceinline__ uint4 sk_norm8(uint4 a, const float* sc, const float* sh, bool silu) {
+  const unsigned in[4] = {a.x, a.y, a.z, a.w}; unsigned out[4];
+#pragma unroll
+  for (int j = 0; j < 4; j++) {
+    float z0 = __uint_as_float(in[j] << 16) * sc[2 * j] + sh[2 * j], z1 = __uint_as_float(in[j] & 0xffff0000u) * sc[2 * j + 1] + sh[2 * j + 1];
+    if (silu) { z0 = silu_f(z0); z1 = silu_f(z1); }
+    out[j] = pack_bf16x2(z0, z1);
+  }
+  return make_uint4(out[0], out[1], out[2], out[3]);
+}
+
+template <int TAPS, int RF, int CF, bool GN>
 __global__ __launch_bounds__(64 * SK_WAVES) void conv_skinny_kernel(const SkArgs p) {
   __shared__ f32x4 part[SK_WAVES][RF * CF][64];
+  __shared__ float2 gn_ss[GN ? SK_GN_MAXC : 1];            // (scale, shift) per input channel of this block's sample
+  __shared__ float2 gn_mr[GN ? 64 : 1];                    // (mean, rstd) per group
   const int tid = threadIdx.x, lane = tid & 63, lm = lane & 15, q = lane >> 4;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);            // scalar: the chunk walk below is wave-uniform
   const int m0 = blockIdx.x * (16 * RF), n0 = blockIdx.y * (16 * CF);
@@ -106,11 +128,44 @@ __global__ __launch_bounds__(64 * SK_WAVES) void conv_skinny_kernel(const SkArgs
       asm volatile("global_load_dwordx2 %0, %1, off" : "=v"(e_res) : "v"(ps) : "memory");                                           \
     }                                                                                                                                \
     __builtin_amdgcn_sched_barrier(0); /* all loads of the round ahead of its first MFMA */                                          \
+    if (GN && FIRST) { /* the sample's group statistics from the producer's slots, then scale / shift per input channel; all of it    \
+                          under the operand loads' latency */                                                                        \
+      const int G = p.Cin / p.gn_cpg, qpg = p.gn_cpg >> 2, rts = p.L >> 4, S = rts * qpg, nq = p.Cin >> 2;                           \
+      const double cnt = (double)p.gn_cpg * (double)p.L;                                                                             \
+      const float2* pb = p.gn_part + (long)(m0 / p.L) * rts * nq;                                                                    \
+      for (int g = tid >> 4; g < G; g += 4 * SK_WAVES) { /* 16 threads per group */                                                   \
+        double s1 = 0.0, s2 = 0.0;                                                                                                   \
+        for (int i = tid & 15; i < S; i += 16) {                                                                                     \
+          const int rt = i / qpg; const float2 v = pb[(long)rt * nq + g * qpg + (i - rt * qpg)];                                     \
+          s1 += (double)v.x; s2 += (double)v.y;                                                                                      \
+        }                                                                                                                            \
+        _Pragma("unroll") for (int o = 1; o < 16; o <<= 1) { s1 += __shfl_xor(s1, o); s2 += __shfl_xor(s2, o); }                     \
+        if ((tid & 15) == 0) {                                                                                                       \
+          const double mu = s1 / cnt; double var = s2 / cnt - mu * mu; if (var < 0.0) var = 0.0;                                     \
+          gn_mr[g] = make_float2((float)mu, rsqrtf((float)var + p.gn_eps));                                                          \
+        }                                                                                                                            \
+      }                                                                                                                              \
+      __syncthreads();                                                                                                               \
+      for (int ch = tid; ch < p.Cin; ch += 64 * SK_WAVES) {                                                                          \
+        const float2 mr = gn_mr[ch / p.gn_cpg];                                                                                      \
+        const float ga = p.gn_gamma[ch] * mr.y;                                                                                      \
+        gn_ss[ch] = make_float2(ga, p.gn_beta[ch] - mr.x * ga);                                                                      \
+      }                                                                                                                              \
+      __syncthreads();                                                                                                               \
+    }                                                                                                                                \
     _Pragma("unroll") for (int i = 0; i < CH; i++) {                                                                                 \
       if (c0 + i * SK_WAVES < kchunks) { /* wave-uniform */                                                                          \
+        float nsc[8], nsh[8];                                                                                                        \
+        if (GN) {                                                                                                                    \
+          const float4* sp = (const float4*)&gn_ss[(c0 + i * SK_WAVES) * 32 + q * 8];                                                \
+          _Pragma("unroll") for (int j = 0; j < 4; j++) {                                                                            \
+            const float4 v = sp[j]; nsc[2 * j] = v.x; nsh[2 * j] = v.y; nsc[2 * j + 1] = v.z; nsh[2 * j + 1] = v.w;                  \
+          }                                                                                                                          \
+        }                                                                                                                            \
         _Pragma("unroll") for (int t = 0; t < TAPS; t++)                                                                             \
           _Pragma("unroll") for (int rf = 0; rf < RF; rf++) {                                                                        \
             uint4 a = xa[i][t][rf];                                                                                                  \
+            if (GN) a = sk_norm8(a, nsc, nsh, p.gn_silu != 0);                                                                       \
             if (TAPS == 3 && !xok[t][rf]) a = make_uint4(0u, 0u, 0u, 0u);                                                            \
             _Pragma("unroll") for (int cf = 0; cf < CF; cf++)                                                                        \
               acc[rf][cf] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, wb[i][t][cf]),                        \
@@ -142,35 +197,62 @@ __global__ __launch_bounds__(64 * SK_WAVES) void conv_skinny_kernel(const SkArgs
       }
       *(uint2*)(p.y + (long)m_own * p.ldy + n_own) = make_uint2(pack_bf16x2(s[0], s[1]), pack_bf16x2(s[2], s[3]));
     }
+    if (p.part_out) {       // GroupNorm statistics of the tensor just written (rounded values): one slot per 16-row x 4-channel lane quad
+      const unsigned lo = pack_bf16x2(s[0], s[1]), hi = pack_bf16x2(s[2], s[3]);
+      const float r0 = __uint_as_float(lo << 16), r1 = __uint_as_float(lo & 0xffff0000u), r2 = __uint_as_float(hi << 16), r3 = __uint_as_float(hi & 0xffff0000u);
+      float a1 = own_ok ? (r0 + r1) + (r2 + r3) : 0.f, a2 = own_ok ? (r0 * r0 + r1 * r1) + (r2 * r2 + r3 * r3) : 0.f;
+#pragma unroll
+      for (int o = 1; o < 16; o <<= 1) { a1 += __shfl_xor(a1, o); a2 += __shfl_xor(a2, o); }
+      const int r16 = m0 + rf_own * 16;                                   // first row of this fragment: L % 16 == 0, so inside one sample
+      if (lm == 0 && n_own < p.N && r16 < p.M)
+        p.part_out[((long)(r16 / p.L) * (p.L >> 4) + ((r16 % p.L) >> 4)) * (p.N >> 2) + (n_own >> 2)] = make_float2(a1, a2);
+    }
   }
 }
 
-template <int TAPS>
+template <int TAPS, bool GN>
 void sk_launch(eegldm_ctx* ctx, const SkArgs& a, int rf, int cf) {
   const dim3 blk(64 * SK_WAVES);
-  if (rf == 2 && cf == 2) hipLaunchKernelGGL((conv_skinny_kernel<TAPS, 2, 2>), dim3((a.M + 31) / 32, (a.N + 31) / 32), blk, 0, ctx->stream, a);
-  else if (rf == 2) hipLaunchKernelGGL((conv_skinny_kernel<TAPS, 2, 1>), dim3((a.M + 31) / 32, (a.N + 15) / 16), blk, 0, ctx->stream, a);
-  else hipLaunchKernelGGL((conv_skinny_kernel<TAPS, 1, 1>), dim3((a.M + 15) / 16, (a.N + 15) / 16), blk, 0, ctx->stream, a);
+  if (rf == 2 && cf == 2) hipLaunchKernelGGL((conv_skinny_kernel<TAPS, 2, 2, GN>), dim3((a.M + 31) / 32, (a.N + 31) / 32), blk, 0, ctx->stream, a);
+  else if (rf == 2) hipLaunchKernelGGL((conv_skinny_kernel<TAPS, 2, 1, GN>), dim3((a.M + 31) / 32, (a.N + 15) / 16), blk, 0, ctx->stream, a);
+  else hipLaunchKernelGGL((conv_skinny_kernel<TAPS, 1, 1, GN>), dim3((a.M + 15) / 16, (a.N + 15) / 16), blk, 0, ctx->stream, a);
 }
 }  // namespace
 
-// Y[r][n] = sum_t sum_k X[r + t - pad][k] * w[t][n][k] (+ bias[n] + rowvec[sample(r)][n] + resid[r][n]); rows flattened (sample, position).
-// Returns 1 when this kernel took the launch, 0 when the shape is not its (the caller goes on to the general kernels), < 0 on error.
-int conv_skinny_try(eegldm_ctx* ctx, int dtype, const void* x, long ldx, const void* w, int Cin, int Cout, int taps, const float* bias,
-                    const float* rowvec, long ld_rowvec, const void* resid, long ldr, void* y, long ldy, int B, int L) {
+static long sk_max_tiles() {
+  static const long v = getenv("EEGLDM_CONV_SKINNY_MAX_TILES") ? atol(getenv("EEGLDM_CONV_SKINNY_MAX_TILES")) : 32;
+  return v;
+}
+// shape test shared by conv_skinny_try and the callers that want to plan a fused GroupNorm around it (net.hip)
+bool conv_skinny_takes(int dtype, int Cin, int Cout, int taps, int B, int L) {
   static const bool off = getenv("EEGLDM_NO_CONV_SKINNY") != nullptr;
-  static const long max_tiles = getenv("EEGLDM_CONV_SKINNY_MAX_TILES") ? atol(getenv("EEGLDM_CONV_SKINNY_MAX_TILES")) : 32;
   const long M = (long)B * L;
-  if (off || dtype != EEGLDM_BF16 || (taps != 1 && taps != 3) || Cin % 32 != 0 || Cout % 4 != 0 || Cout < 16) return 0;
+  if (off || dtype != EEGLDM_BF16 || (taps != 1 && taps != 3) || Cin % 32 != 0 || Cout % 4 != 0 || Cout < 16) return false;
   // only launches the general kernel cannot spread over the chip: at most `max_tiles` of its 128 x 128 tiles
-  if (((M + 127) / 128) * (((long)Cout + 127) / 128) > max_tiles) return 0;
+  return ((M + 127) / 128) * (((long)Cout + 127) / 128) <= sk_max_tiles();
+}
+
+// Y[r][n] = sum_t sum_k A[r + t - pad][k] * w[t][n][k] (+ bias[n] + rowvec[sample(r)][n] + resid[r][n]); rows flattened (sample, position).
+// A = X, or with `gn`: A = SiLU?(GroupNorm(X)) rounded to bf16, from gn->stats = (sum, sum of squares) per (sample, group) of X.
+// part_out (optional): per-quad statistics of Y for the next GroupNorm ((B * L / 16) * (Cout / 4) float2 slots, all written).
+// Returns 1 when this kernel took the launch, 0 when the shape is not its (the caller goes on to the general kernels), < 0 on error.
+int conv_skinny_ex(eegldm_ctx* ctx, int dtype, const void* x, long ldx, const void* w, int Cin, int Cout, int taps, const float* bias,
+                   const float* rowvec, long ld_rowvec, const void* resid, long ldr, void* y, long ldy, int B, int L,
+                   const SkinnyGn* gn, float2* part_out) {
+  const long M = (long)B * L;
+  if (!conv_skinny_takes(dtype, Cin, Cout, taps, B, L)) return 0;
   if (ldx % 8 != 0 || ldy % 4 != 0 || (resid && ldr % 4 != 0) || (rowvec && ld_rowvec % 4 != 0)) return 0;
   if (((size_t)x | (size_t)w) % 16 != 0 || (size_t)y % 8 != 0 || (resid && (size_t)resid % 8 != 0) || (bias && (size_t)bias % 16 != 0) ||
       (rowvec && (size_t)rowvec % 16 != 0)) return 0;
+  // the fused forms need whole 32-row tiles inside one sample and 4-channel lane quads inside one group
+  if (gn && (taps != 3 || L % 32 != 0 || Cin > SK_GN_MAXC || gn->cpg < 4 || gn->cpg % 4 != 0 || Cin % gn->cpg != 0 || Cin / gn->cpg > 64)) return 0;
+  if (part_out && L % 32 != 0) return 0;
   SkArgs a = {};
   a.x = (const bf16_t*)x; a.ldx = ldx; a.w = (const bf16_t*)w; a.sWt = (long)Cout * Cin; a.Cin = Cin;
   a.bias = bias; a.rowvec = rowvec; a.ld_rowvec = ld_rowvec; a.resid = (const bf16_t*)resid; a.ldr = ldr;
   a.y = (bf16_t*)y; a.ldy = ldy; a.M = (int)M; a.L = L; a.N = Cout;
+  a.part_out = part_out;
+  if (gn) { a.gn_part = gn->part; a.gn_gamma = gn->gamma; a.gn_beta = gn->beta; a.gn_cpg = gn->cpg; a.gn_eps = gn->eps; a.gn_silu = gn->silu; }
   // widest register tile that still gives every CU most of a block (fewer re-reads of the operands through L2)
   static const int force = getenv("EEGLDM_CONV_SKINNY_TILE") ? atoi(getenv("EEGLDM_CONV_SKINNY_TILE")) : 0;   // 11 / 21 / 22
   const long want = ctx->num_cu * 3 / 4;
@@ -185,8 +267,13 @@ int conv_skinny_try(eegldm_ctx* ctx, int dtype, const void* x, long ldx, const v
     HIP_TRY(hipEventCreate(&rec.a)); HIP_TRY(hipEventCreate(&rec.b));
     HIP_TRY(hipEventRecord(rec.a, ctx->stream));
   }
-  if (taps == 3) sk_launch<3>(ctx, a, rf, cf); else sk_launch<1>(ctx, a, rf, cf);
+  if (gn) sk_launch<3, true>(ctx, a, rf, cf); else if (taps == 3) sk_launch<3, false>(ctx, a, rf, cf); else sk_launch<1, false>(ctx, a, rf, cf);
   LAUNCH_CHECK();
   if (prof) { HIP_TRY(hipEventRecord(rec.b, ctx->stream)); ctx->prof.push_back(rec); }
   return 1;
+}
+
+int conv_skinny_try(eegldm_ctx* ctx, int dtype, const void* x, long ldx, const void* w, int Cin, int Cout, int taps, const float* bias,
+                    const float* rowvec, long ld_rowvec, const void* resid, long ldr, void* y, long ldy, int B, int L) {
+  return conv_skinny_ex(ctx, dtype, x, ldx, w, Cin, Cout, taps, bias, rowvec, ld_rowvec, resid, ldr, y, ldy, B, L, nullptr, nullptr);
 }

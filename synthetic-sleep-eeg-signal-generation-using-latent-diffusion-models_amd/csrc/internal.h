@@ -27,6 +27,11 @@ int dconv_wgrad(eegldm_ctx*, int dtype, const void* x, long ldx, const void* dy,
 bool dconv_wgrad_tinyv_ok(int Cin, int Cout, int K);
 
 // conv_ws.hip: weight-stationary 3-tap conv for 128 reduction channels (1 = handled, 0 = not this kernel's shape, < 0 = error)
+struct SkinnyGn { const float2* part; const float* gamma; const float* beta; int cpg; float eps; int silu; };
+bool conv_skinny_takes(int dtype, int Cin, int Cout, int taps, int B, int L);
+int conv_skinny_ex(eegldm_ctx* ctx, int dtype, const void* x, long ldx, const void* w, int Cin, int Cout, int taps, const float* bias,
+                   const float* rowvec, long ld_rowvec, const void* resid, long ldr, void* y, long ldy, int B, int L,
+                   const SkinnyGn* gn, float2* part_out);
 int conv_skinny_try(eegldm_ctx* ctx, int dtype, const void* x, long ldx, const void* w, int Cin, int Cout, int taps, const float* bias,
                     const float* rowvec, long ld_rowvec, const void* resid, long ldr, void* y, long ldy, int B, int L);
 int conv_ws_try(eegldm_ctx*, int dtype, const void* x, long ldx, const void* w, int Cin, int Cout, int transposed, const float* bias,

@@ -73,6 +73,11 @@ struct NetBase {
   float* emb_all = nullptr; int etot = 0;   // batched timestep-embedding projections (UNet)
   long emb_ld = 0;                           // row stride of emb_all: etot, or 0 when all samples share one precomputed row (sampler)
   const float* emb_shared = nullptr;         // set by the sampler for the duration of an eval forward (unet_set_shared_emb)
+  // Eval-mode forward of a few-row launch (sampling one window per call): the second GroupNorm of a ResBlock is not launched -- conv1
+  // (conv_skinny.hip) leaves the (sum, sum of squares) of every 16-row x 4-channel piece of its output in `fuse_stats` and conv2 folds
+  // them per group and normalises its operand on load.  The normalised tensor and the (mean, rstd) pairs are then NOT on the tape: such a forward cannot be back-propagated.
+  bool eval_fuse = false, fused_used = false;
+  float2* fuse_stats = nullptr; size_t fuse_cap = 0, fuse_used = 0;     // float2 slots; every slot of a used area is written by conv1
   std::vector<ResTape> rt; std::vector<AttnTape> at;
 
   const void* W(long off) const { return (const char*)wT + (size_t)off * dtype_size(dtype); }

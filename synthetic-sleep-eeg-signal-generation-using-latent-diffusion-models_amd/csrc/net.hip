@@ -74,8 +74,45 @@ int res_forward(NetBase* u, const ResDesc& r, const View& x, int B, int Lin, con
   EEG_TRY(eegldm_groupnorm_fwd(ctx, x.p, x.ld, u->P(r.gn1_w), u->P(r.gn1_b), t.a1.p, t.a1.ld, t.st1, B, Lin, r.cin, r.groups, GN_EPS, 1,
                                r.updown, r.updown ? t.xr.p : nullptr, t.xr.ld, dt));
   ALLOC_OR_FAIL(t.h1.p, u->alloc_act((long)B * Lout, r.cout)); t.h1.ld = r.cout; t.h1.C = r.cout;
+  const float* emb = r.emb_col >= 0 ? u->emb_all + r.emb_col : nullptr;
+  // ---- eval, few rows: conv1 leaves GroupNorm 2's statistics, conv2 normalises on load (see NetBase::eval_fuse)
+  const int cpg2 = r.cout / r.groups;
+  const size_t need = (size_t)B * (Lout / 16) * (r.cout / 4);       // float2 slots
+  bool fused = false;
+  if (u->eval_fuse && u->fuse_used + need <= u->fuse_cap && Lout % 32 == 0 && cpg2 >= 4 && cpg2 % 4 == 0 && r.cout % r.groups == 0 &&
+      conv_skinny_takes(dt, r.cin, r.cout, 3, B, Lout) && conv_skinny_takes(dt, r.cout, r.cout, 3, B, Lout)) {
+    float2* area = u->fuse_stats + u->fuse_used;
+    const int rc1 = conv_skinny_ex(ctx, dt, t.a1.p, t.a1.ld, u->W(r.c1_w), r.cin, r.cout, 3, u->P(r.c1_b), emb, u->emb_ld, nullptr, 0,
+                                   t.h1.p, t.h1.ld, B, Lout, nullptr, area);
+    if (rc1 < 0) return rc1;
+    if (rc1 == 1) {
+      u->fuse_used += need;
+      const SkinnyGn gn = {area, u->P(r.gn2_w), u->P(r.gn2_b), cpg2, GN_EPS, 1};
+      if (r.sk_w >= 0)
+        EEG_TRY(op_conv_fwd(ctx, dt, t.xr.p, t.xr.ld, u->W(r.sk_w), u->P(r.sk_b), out.p, out.ld, B, Lout, r.cin, r.cout, 1, 1, 0, 0, nullptr, 0, nullptr, 0));
+      const View res = r.sk_w >= 0 ? out : t.xr;
+      const int rc2 = conv_skinny_ex(ctx, dt, t.h1.p, t.h1.ld, u->W(r.c2_w), r.cout, r.cout, 3, u->P(r.c2_b), nullptr, 0, res.p, res.ld,
+                                     out.p, out.ld, B, Lout, &gn, nullptr);
+      if (rc2 < 0) return rc2;
+      if (rc2 == 1) { fused = true; u->fused_used = true; }
+    } else {
+      EEG_TRY(op_conv_fwd(ctx, dt, t.a1.p, t.a1.ld, u->W(r.c1_w), u->P(r.c1_b), t.h1.p, t.h1.ld, B, Lout, r.cin, r.cout, 3, 1, 1, 1, emb, u->emb_ld, nullptr, 0));
+    }
+    if (!fused) {      // conv2 declined (alignment): the stand-alone GroupNorm and the plain conv, as below (the skip conv already ran)
+      ALLOC_OR_FAIL(t.a2.p, u->alloc_act((long)B * Lout, r.cout)); t.a2.ld = r.cout; t.a2.C = r.cout;
+      EEG_TRY(eegldm_groupnorm_fwd(ctx, t.h1.p, t.h1.ld, u->P(r.gn2_w), u->P(r.gn2_b), t.a2.p, t.a2.ld, t.st2, B, Lout, r.cout, r.groups, GN_EPS, 1,
+                                   0, nullptr, 0, dt));
+      const bool skip_done = rc1 == 1 && r.sk_w >= 0;
+      if (r.sk_w >= 0 && !skip_done)
+        EEG_TRY(op_conv_fwd(ctx, dt, t.xr.p, t.xr.ld, u->W(r.sk_w), u->P(r.sk_b), out.p, out.ld, B, Lout, r.cin, r.cout, 1, 1, 0, 0, nullptr, 0, nullptr, 0));
+      const View res = r.sk_w >= 0 ? out : t.xr;
+      EEG_TRY(op_conv_fwd(ctx, dt, t.a2.p, t.a2.ld, u->W(r.c2_w), u->P(r.c2_b), out.p, out.ld, B, Lout, r.cout, r.cout, 3, 1, 1, 1, nullptr, 0, res.p, res.ld));
+    }
+    u->rt.push_back(t);
+    return 0;
+  }
   EEG_TRY(op_conv_fwd(ctx, dt, t.a1.p, t.a1.ld, u->W(r.c1_w), u->P(r.c1_b), t.h1.p, t.h1.ld, B, Lout, r.cin, r.cout, 3, 1, 1, 1,
-                      r.emb_col >= 0 ? u->emb_all + r.emb_col : nullptr, u->emb_ld, nullptr, 0));
+                      emb, u->emb_ld, nullptr, 0));
   ALLOC_OR_FAIL(t.a2.p, u->alloc_act((long)B * Lout, r.cout)); t.a2.ld = r.cout; t.a2.C = r.cout;
   EEG_TRY(eegldm_groupnorm_fwd(ctx, t.h1.p, t.h1.ld, u->P(r.gn2_w), u->P(r.gn2_b), t.a2.p, t.a2.ld, t.st2, B, Lout, r.cout, r.groups, GN_EPS, 1,
                                0, nullptr, 0, dt));

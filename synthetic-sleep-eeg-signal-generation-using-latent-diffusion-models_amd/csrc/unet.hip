@@ -217,6 +217,7 @@ int unet_out_channels(const eegldm_unet* u) { return u->cfg.out_channels; }
 extern "C" int eegldm_unet_destroy(eegldm_unet* u) {
   if (!u) return 0;
   sampler_release(u);
+  if (u->fuse_stats) (void)hipFree(u->fuse_stats);
   delete u;
   return 0;
 }
@@ -271,6 +272,28 @@ extern "C" int eegldm_unet_forward(eegldm_unet* u, const float* x, const int64_t
   eegldm_ctx* ctx = u->ctx; const int dt = u->dtype; const int mc = u->mc, te = u->te;
   u->arena.reset(); u->rt.clear(); u->at.clear(); u->in_out.clear(); u->cat.clear();
   u->B = B; u->L = L; u->have_tape = false;
+
+  // ---- eval-mode GroupNorm fusion for few-row launches (NetBase::eval_fuse): one statistics area per ResBlock
+  {
+    static const bool no_fuse = getenv("EEGLDM_NO_EVAL_GN_FUSE") != nullptr;
+    u->eval_fuse = !training && !no_fuse && dt == EEGLDM_BF16; u->fused_used = false; u->fuse_used = 0;
+    if (u->eval_fuse) {
+      // slots: B * L_out / 16 * cout / 4 per ResBlock; an upper bound from the widest / longest block keeps this simple
+      size_t nres = 0; int cmax = 0;
+      auto count = [&](const Block& b) { for (auto& l : b.layers) if (l.kind == 0) { nres++; if (l.r.cout > cmax) cmax = l.r.cout; } };
+      for (auto& b : u->in_blocks) count(b);
+      count(u->mid);
+      for (auto& b : u->out_blocks) count(b);
+      const size_t need = nres * (size_t)B * (L / 16 + 1) * (cmax / 4);
+      if (need > (size_t)4 << 20) u->eval_fuse = false;               // few-row launches only (32 MB of slots at most)
+      else if (u->fuse_cap < need) {
+        HIP_TRY(hipStreamSynchronize(ctx->stream));
+        if (u->fuse_stats) (void)hipFree(u->fuse_stats);
+        u->fuse_stats = nullptr; u->fuse_cap = 0;
+        HIP_TRY(hipMalloc(&u->fuse_stats, sizeof(float2) * need)); u->fuse_cap = need;
+      }
+    }
+  }
 
   // ---- timestep embedding MLP + all ResBlock embedding projections (unet.py:526-529, 316).
   // Tiny (B x 4mc): always fp32 on the fp32 master weights, whatever the activation dtype.
@@ -331,13 +354,13 @@ extern "C" int eegldm_unet_forward(eegldm_unet* u, const float* x, const int64_t
                       3, 1, 1, 1, nullptr, 0, nullptr, 0));
   EEG_TRY(eegldm_nlc_to_ncl(ctx, yo, u->cfg.out_channels, y, B, u->cfg.out_channels, L, dt));
   u->arena.release(mk);
-  u->have_tape = true;
+  u->have_tape = !u->fused_used;      // a fused eval forward did not keep what the backward needs
   return 0;
 }
 
 extern "C" int eegldm_unet_backward(eegldm_unet* u, const float* dy, float* dx_out) {
   EEG_CHECK(u && dy, "null argument");
-  EEG_CHECK(u->have_tape, "call eegldm_unet_forward first");
+  EEG_CHECK(u->have_tape, "call eegldm_unet_forward first (with training != 0: an eval-mode forward does not keep the activations)");
   EEG_CHECK(u->grads, "no gradient buffer bound");
   eegldm_ctx* ctx = u->ctx; const int dt = u->dtype; const int mc = u->mc, te = u->te, B = u->B, L = u->L;
   const int cin = u->cfg.in_channels, cout = u->cfg.out_channels;

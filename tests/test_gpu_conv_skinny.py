@@ -81,3 +81,34 @@ def test_small_shape_primitives_still_pass_on_the_general_kernel():
     r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(ROOT, "tests", "test_gpu_primitives.py"), "-x", "-q", "-m", "gpu",
                         "-k", "conv1d or linear", "-p", "no:cacheprovider"], env=env, capture_output=True, text=True, timeout=1500, cwd=ROOT)
     assert r.returncode == 0, (r.stdout[-3000:], r.stderr[-2000:])
+
+
+def test_eval_forward_with_fused_groupnorm_matches_train_mode_forward():
+    """Eval-mode forward of a few windows (NetBase::eval_fuse, net.hip): conv1 of every ResBlock leaves the statistics of its output and
+    conv2 applies GroupNorm + SiLU on its operand load, so 22 GroupNorm launches per forward disappear.  The train-mode forward of the
+    same network runs the stand-alone GroupNorm kernels: both must agree to bf16 rounding, and the eval forward must refuse a backward."""
+    import torch
+    from eegldm.models import UNetModel
+    cfg = dict(image_size=768, in_channels=1, out_channels=1, model_channels=128, num_res_blocks=2, attention_resolutions=[8, 4],
+               channel_mult=[1, 2, 4], resblock_updown=True)
+    net = UNetModel(**cfg, dtype="bfloat16")
+    g = torch.Generator().manual_seed(0); sd = net.state_dict()
+    net.load_state_dict({k: (torch.randn(v.shape, generator=g) * 0.02 if float(v.abs().sum()) == 0 else v.cpu()) for k, v in sd.items()})
+    w = {k: v.cpu() for k, v in net.state_dict().items()}
+    nf = UNetModel(**cfg, dtype="float32"); nf.load_state_dict(w); nf.eval()
+    for B in (1, 2, 3):
+        x = torch.randn(B, 1, 768, generator=g); t = torch.randint(0, 1000, (B,), generator=g)
+        yf = nf(x, timesteps=t).float().cpu().clone()                     # fp32 engine: the common yardstick
+        net.train(); yt = net(x, timesteps=t).float().cpu().clone()
+        net.eval(); ye = net(x, timesteps=t).float().cpu().clone()
+        assert torch.isfinite(ye).all()
+        rel = lambda a, b: float((a - b).norm() / b.norm())
+        # the two bf16 forwards differ by rounding flips compounded over ~50 layers (the same class as batch 256 vs batch 3 in
+        # test_gpu_fullsize.py: < 1.5e-2); against the fp32 engine the fused forward must be no worse than the unfused one
+        assert rel(ye, yt) < 1.5e-2, (B, rel(ye, yt))
+        assert rel(ye, yf) < 4e-2 and rel(ye, yf) < 1.25 * rel(yt, yf) + 2e-3, (B, rel(ye, yf), rel(yt, yf))
+        ye2 = net(x, timesteps=t).float().cpu()
+        assert torch.equal(ye, ye2), "eval forward not reproducible"     # fp64 atomics of ~12 partials per group: order-independent to fp32
+    with pytest.raises(RuntimeError):
+        net.backward(torch.zeros(3, 1, 768))
+    net.train(); net(x, timesteps=t); net.zero_grad(); net.backward(torch.zeros(3, 1, 768))       # a train-mode forward restores the tape
