@@ -205,7 +205,10 @@ int eegldm_unet_set_grad_hook(eegldm_unet*, eegldm_grad_hook fn, void* user);
 /* Refresh the compute-dtype weight copies after `params` changed (no-op for fp32). */
 int eegldm_unet_sync_weights(eegldm_unet*);
 /* forward(x, timesteps): x, y are NCL fp32 (B, C, L); t int64 (B).  training != 0 keeps
- * activations for eegldm_unet_backward. */
+ * activations for eegldm_unet_backward.  training == 0 (model.eval(): sampling) MAY skip them: for launches of a few hundred rows
+ * (one window per call, sample_trials.py:149-163) the second GroupNorm of each ResBlock is applied inside the next conv and neither
+ * its output nor its statistics are stored -- eegldm_unet_backward then fails with an error instead of using a partial tape.  The
+ * reference has the same contract in another form: its sampling runs under torch.no_grad() (sample_trials.py:147). */
 int eegldm_unet_forward(eegldm_unet*, const float* x, const int64_t* t, float* y, int B, int L, int training);
 /* grads += d loss / d params; dx (nullable) = d loss / d x.  Gradients accumulate: zero the
  * flat gradient buffer (eegldm_fill) between steps, as optimizer.zero_grad does. */
