@@ -27,3 +27,88 @@ def test_ldm_training_converges_and_bf16_follows_fp32():
         assert abs(cb[i] - cf[i]) / cf[i] < 0.03, (i, cb[i], cf[i])                  # measured: 0.05 % at step 25, 0.8 % at step 50 (B=256)
     assert b["alloc_first_last"][1] <= b["alloc_first_last"][0] and f["alloc_first_last"][1] <= f["alloc_first_last"][0]
     assert b["sample"]["finite"], b["sample"]       # 40 steps do not make a usable epsilon model (latent std ~40; 1.4 after 500 steps): only finiteness
+
+
+def _golden(name):
+    import json
+    with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", name)) as fh:
+        return json.load(fh)
+
+
+@pytest.mark.parametrize("dtype,tol", [("float32", 2e-3), ("bfloat16", 6e-2)])
+def test_ldm_training_trajectory_matches_the_oracle(dtype, tol):
+    """30 optimiser steps of the config_ldm.yaml UNet (add_noise -> UNet -> MSE -> Adam, training.py:419-443) on seeded weights, latents,
+    noise and timesteps: the loss of EVERY step against the CPU oracle's trajectory (tests/golden/make_ldm_traj.py -> ldm_traj_c2.json).
+    A gradient or optimiser defect that a one-step parity test tolerates compounds here: the fp32 engine must stay within 0.2 %
+    of the oracle over the whole run (measured: 1.7e-5 while the loss falls 1.75 -> 0.016), the bf16 engine within 6 % (measured: 1.0 %)."""
+    import torch
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden"))
+    from param_gen import gen_param, eeg_windows, normal, timesteps
+    from eegldm.models import UNetModel
+    from eegldm.schedulers import DDPMScheduler
+    from eegldm.training import Adam, ldm_train_step
+    g = _golden("ldm_traj_c2.json")
+    cfg = dict(image_size=768, in_channels=1, out_channels=1, model_channels=128, num_res_blocks=2, attention_resolutions=[8, 4],
+               channel_mult=[1, 2, 4], resblock_updown=True)
+    net = UNetModel(**cfg, dtype=dtype)
+    net.load_state_dict({k: torch.from_numpy(gen_param(g["param_seed"], k, tuple(v.shape))) for k, v in net.state_dict().items()})
+    sched = DDPMScheduler(num_train_timesteps=1000, schedule="linear_beta", beta_start=0.0015, beta_end=0.0195)
+    opt = Adam(net, lr=g["lr"])
+    B, POOL = g["batch"], g["pool"]
+    pool = torch.from_numpy(eeg_windows(POOL, seed=g["latent_seed"], length=768)).cuda()
+    loss = torch.zeros(1, device="cuda")
+    worst = 0.0
+    for i in range(1, g["steps"] + 1):
+        s = ((i - 1) * B) % POOL
+        nz = torch.from_numpy(normal((B, 1, 768), seed=g["noise_seed_base"] + i)).cuda()
+        t = torch.from_numpy(timesteps(B, seed=g["t_seed_base"] + i)).cuda()
+        net.zero_grad()
+        ldm_train_step(net, sched, pool[s:s + B], nz, t, loss_out=loss)
+        opt.step()
+        want = g["loss"][i - 1]; got = float(loss)
+        worst = max(worst, abs(got - want) / want)
+        assert abs(got - want) <= tol * want + 1e-6, (dtype, i, got, want)
+    print(f"LDM trajectory [{dtype}]: worst relative loss gap over {g['steps']} steps {worst:.2e}")
+
+
+@pytest.mark.parametrize("dtype,tol", [("float32", 2e-3), ("bfloat16", 8e-2)])
+def test_aekl_gan_training_trajectory_matches_the_oracle(dtype, tol):
+    """40 optimiser steps of the AutoencoderKL [32,32,64] + PatchDiscriminator GAN training (train_autoencoderkl.py:203-234, reference
+    loss weights incl. the 1e4 x spectral term, both Adam updates, BatchNorm running statistics): reconstruction L1, spectral, KL, generator
+    and discriminator losses of EVERY step against the CPU oracle's trajectory (tests/golden/make_aekl_traj.py -> aekl_traj_c1.json).
+    Measured: fp32 engine within 1.6e-5 (L1), 4e-5 (spectral), 3e-3 (adversarial terms) over all 40 steps while L1 falls 1.22 -> 0.10;
+    bf16 within 1-5 % (spectral 3-9 %)."""
+    import torch
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden"))
+    from param_gen import gen_param, eeg_windows, normal
+    from eegldm.models import AutoencoderKL, PatchDiscriminator
+    from eegldm.training import Adam, aekl_train_step
+    g = _golden("aekl_traj_c1.json")
+    ae = AutoencoderKL(spatial_dims=1, in_channels=1, out_channels=1, num_channels=[32, 32, 64], latent_channels=1, num_res_blocks=2,
+                       norm_num_groups=1, attention_levels=[False, False, False], dtype=dtype, device=0)
+    disc = PatchDiscriminator(spatial_dims=1, num_layers_d=3, num_channels=64, in_channels=1, out_channels=1, kernel_size=3,
+                              norm="BATCH", bias=False, padding=1, dtype=dtype, device=0)
+    ae.load_state_dict({k: torch.from_numpy(gen_param(g["param_seeds"][0], k, tuple(v.shape))) for k, v in ae.state_dict().items()})
+    disc.load_state_dict({k: (torch.from_numpy(gen_param(g["param_seeds"][1], k, tuple(v.shape)))
+                              if v.dtype.is_floating_point and "running" not in k and "num_batches" not in k else v) for k, v in disc.state_dict().items()})
+    og, od = Adam(ae, lr=g["lr"][0]), Adam(disc, lr=g["lr"][1])
+    B, POOL, w = g["batch"], g["pool"], g["weights"]
+    xs = torch.from_numpy(eeg_windows(POOL, seed=g["window_seed"])).cuda()
+    lo = torch.zeros(6, device="cuda")
+    worst = {}
+    for i in range(1, g["steps"] + 1):
+        s = ((i - 1) * B) % POOL
+        ew = torch.from_numpy(normal((B, 1, 768), seed=g["eps_seed_base"] + i)).cuda()
+        ae.zero_grad(); disc.zero_grad()
+        aekl_train_step(ae, disc, xs[s:s + B], ew, w["adv"], w["kl"], w["spectral"], True, losses_out=lo)
+        og.step(); od.step()
+        v = [float(x) for x in lo.cpu()]
+        got = {"recons": v[0], "spectral": v[1], "kl": v[2], "gen": v[3], "disc": 0.5 * (v[4] + v[5])}
+        want = g["losses"][i - 1]
+        for k in got:
+            # the adversarial terms are O(1) numbers that wander as D and G chase each other: absolute floor next to the relative bound
+            # (and the spectral term, a sum of squared amplitude differences x 1e4 in the loss, is the most rounding-sensitive: the bf16 run sits 3-9 % below)
+            rel = 2 * tol if (k == "spectral" and dtype == "bfloat16") else tol
+            assert abs(got[k] - want[k]) <= rel * abs(want[k]) + (2e-2 if dtype == "bfloat16" else 2e-4), (dtype, i, k, got[k], want[k])
+            worst[k] = max(worst.get(k, 0.0), abs(got[k] - want[k]) / (abs(want[k]) + 1e-12))
+    print(f"AEKL/GAN trajectory [{dtype}]: worst relative gaps over {g['steps']} steps " + ", ".join(f"{k} {x:.1e}" for k, x in worst.items()))

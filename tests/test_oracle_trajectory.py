@@ -1,0 +1,52 @@
+"""CPU: the committed training-trajectory fixtures (tests/golden/ldm_traj_c2.json, aekl_traj_c1.json) are what the oracle produces --
+their first steps are recomputed here from the seeds stored in the files (the full runs are tests/golden/make_ldm_traj.py /
+make_aekl_traj.py; the HIP engines replay all steps in tests/test_gpu_convergence.py)."""
+import json
+import os
+import sys
+
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(HERE, "golden")); sys.path.insert(0, os.path.dirname(HERE))
+
+
+def _load(name):
+    with open(os.path.join(HERE, "golden", name)) as fh:
+        return json.load(fh)
+
+
+def test_ldm_trajectory_fixture_is_the_oracles():
+    import make_ldm_traj as M
+    from param_gen import gen_param, eeg_windows, normal, timesteps
+    import oracle.losses as Ls, oracle.steps as S, oracle.unet as U
+    g = _load("ldm_traj_c2.json")
+    assert g["steps"] == len(g["loss"]) == M.STEPS and g["batch"] == M.B
+    assert g["loss"][-1] < 0.05 * g["loss"][0]                      # the run it records does train
+    sd = {k: torch.from_numpy(gen_param(g["param_seed"], k, s)) for k, s in U.unet_param_shapes(M.CFG).items()}
+    acp = Ls.alphas_cumprod(*g["schedule"])
+    pool = torch.from_numpy(eeg_windows(g["pool"], seed=g["latent_seed"], length=768))
+    opt = {}
+    for i in (1, 2):
+        s = ((i - 1) * g["batch"]) % g["pool"]
+        nz = torch.from_numpy(normal((g["batch"], 1, 768), seed=g["noise_seed_base"] + i)); t = torch.from_numpy(timesteps(g["batch"], seed=g["t_seed_base"] + i))
+        l, grads, _ = S.ldm_train_step(sd, M.CFG, acp, pool[s:s + g["batch"]], nz, t)
+        sd = S.adam_update(sd, grads, opt, g["lr"], i)
+        assert abs(float(l) - g["loss"][i - 1]) <= 1e-4 * g["loss"][i - 1], (i, float(l), g["loss"][i - 1])     # thread-count dependent summation order only
+
+
+def test_aekl_trajectory_fixture_is_the_oracles():
+    import make_aekl_traj as M
+    from param_gen import gen_param, eeg_windows, normal
+    import oracle.aekl as A, oracle.steps as S
+    g = _load("aekl_traj_c1.json")
+    assert g["steps"] == len(g["losses"]) == M.STEPS
+    assert g["losses"][-1]["recons"] < 0.15 * g["losses"][0]["recons"]
+    st = {"ae": {k: torch.from_numpy(gen_param(g["param_seeds"][0], k, s)) for k, s in A.aekl_param_shapes(M.ACFG).items()},
+          "d": {k: torch.from_numpy(gen_param(g["param_seeds"][1], k, s)) for k, s in A.disc_param_shapes(M.DCFG).items()}}
+    xs = torch.from_numpy(eeg_windows(g["pool"], seed=g["window_seed"]))
+    ew = torch.from_numpy(normal((g["batch"], 1, 768), seed=g["eps_seed_base"] + 1))
+    w = g["weights"]
+    l, *_ = S.aekl_train_step(st["ae"], M.ACFG, st["d"], M.DCFG, xs[:g["batch"]], ew, w["adv"], w["kl"], w["spectral"], True, g["lr"][0], g["lr"][1], 1, {}, {})
+    for k, v in g["losses"][0].items():
+        assert abs(float(l[k]) - v) <= 1e-4 * abs(v) + 1e-6, (k, float(l[k]), v)
