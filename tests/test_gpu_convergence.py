@@ -112,3 +112,38 @@ def test_aekl_gan_training_trajectory_matches_the_oracle(dtype, tol):
             assert abs(got[k] - want[k]) <= rel * abs(want[k]) + (2e-2 if dtype == "bfloat16" else 2e-4), (dtype, i, k, got[k], want[k])
             worst[k] = max(worst.get(k, 0.0), abs(got[k] - want[k]) / (abs(want[k]) + 1e-12))
     print(f"AEKL/GAN trajectory [{dtype}]: worst relative gaps over {g['steps']} steps " + ", ".join(f"{k} {x:.1e}" for k, x in worst.items()))
+
+
+@pytest.mark.parametrize("dtype,tol", [("float32", 2e-3), ("bfloat16", 8e-2)])
+def test_pixel_dm_training_trajectory_matches_the_oracle(dtype, tol):
+    """12 optimiser steps of the pixel-space diffusion model (training_diffusion.py:141-151: the config_dm.yaml UNet on raw (B,1,3072) windows,
+    T = 768 attention, epsilon MSE + 1e-6 x JukeboxLoss(sum), Adam 1e-4) against the CPU oracle's trajectory
+    (tests/golden/make_dm_traj.py -> dm_traj_c5.json), every step."""
+    import torch
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden"))
+    from param_gen import gen_param, eeg_windows, normal, timesteps
+    from eegldm.models import UNetModel
+    from eegldm.schedulers import DDPMScheduler
+    from eegldm.training import Adam, dm_train_step
+    g = _golden("dm_traj_c5.json")
+    cfg = dict(image_size=3072, in_channels=1, out_channels=1, model_channels=128, num_res_blocks=2, attention_resolutions=[8, 4],
+               channel_mult=[1, 2, 4], resblock_updown=True)
+    net = UNetModel(**cfg, dtype=dtype)
+    net.load_state_dict({k: torch.from_numpy(gen_param(g["param_seed"], k, tuple(v.shape))) for k, v in net.state_dict().items()})
+    sched = DDPMScheduler(num_train_timesteps=1000, schedule="linear_beta", beta_start=0.0015, beta_end=0.0195)
+    opt = Adam(net, lr=g["lr"])
+    B, POOL = g["batch"], g["pool"]
+    pool = torch.from_numpy(eeg_windows(POOL, seed=g["window_seed"])).cuda()
+    loss = torch.zeros(1, device="cuda")
+    worst = 0.0
+    for i in range(1, g["steps"] + 1):
+        s = ((i - 1) * B) % POOL
+        nz = torch.from_numpy(normal((B, 1, 3072), seed=g["noise_seed_base"] + i)).cuda()
+        t = torch.from_numpy(timesteps(B, seed=g["t_seed_base"] + i)).cuda()
+        net.zero_grad()
+        dm_train_step(net, sched, pool[s:s + B], nz, t, spectral_weight=g["spectral_weight"], spectral_loss=True, loss_out=loss)
+        opt.step()
+        want = g["loss"][i - 1]; got = float(loss)
+        worst = max(worst, abs(got - want) / want)
+        assert abs(got - want) <= tol * want + 1e-6, (dtype, i, got, want)
+    print(f"pixel-space DM trajectory [{dtype}]: worst relative loss gap over {g['steps']} steps {worst:.2e}")

@@ -50,3 +50,17 @@ def test_aekl_trajectory_fixture_is_the_oracles():
     l, *_ = S.aekl_train_step(st["ae"], M.ACFG, st["d"], M.DCFG, xs[:g["batch"]], ew, w["adv"], w["kl"], w["spectral"], True, g["lr"][0], g["lr"][1], 1, {}, {})
     for k, v in g["losses"][0].items():
         assert abs(float(l[k]) - v) <= 1e-4 * abs(v) + 1e-6, (k, float(l[k]), v)
+
+
+def test_dm_trajectory_fixture_is_the_oracles():
+    import make_dm_traj as M
+    from param_gen import gen_param, eeg_windows, normal, timesteps
+    import oracle.losses as Ls, oracle.steps as S, oracle.unet as U
+    g = _load("dm_traj_c5.json")
+    assert g["steps"] == len(g["loss"]) == M.STEPS and g["loss"][-1] < 0.05 * g["loss"][0]
+    sd = {k: torch.from_numpy(gen_param(g["param_seed"], k, s)) for k, s in U.unet_param_shapes(M.CFG).items()}
+    acp = Ls.alphas_cumprod(*g["schedule"])
+    pool = torch.from_numpy(eeg_windows(g["pool"], seed=g["window_seed"]))
+    nz = torch.from_numpy(normal((g["batch"], 1, 3072), seed=g["noise_seed_base"] + 1)); t = torch.from_numpy(timesteps(g["batch"], seed=g["t_seed_base"] + 1))
+    l, _grads, _ = S.dm_train_step(sd, M.CFG, acp, pool[:g["batch"]], nz, t, spectral_weight=g["spectral_weight"], spectral_loss=True)
+    assert abs(float(l) - g["loss"][0]) <= 1e-4 * g["loss"][0], (float(l), g["loss"][0])
