@@ -71,8 +71,9 @@ def test_ldm_training_trajectory_matches_the_oracle(dtype, tol):
     print(f"LDM trajectory [{dtype}]: worst relative loss gap over {g['steps']} steps {worst:.2e}")
 
 
+@pytest.mark.parametrize("fixture", ["aekl_traj_c1.json", "aekl_traj_thin.json"])      # [32,32,64] layer by layer; [2,2,4] = the whole-network aekl_thin kernels
 @pytest.mark.parametrize("dtype,tol", [("float32", 2e-3), ("bfloat16", 8e-2)])
-def test_aekl_gan_training_trajectory_matches_the_oracle(dtype, tol):
+def test_aekl_gan_training_trajectory_matches_the_oracle(dtype, tol, fixture):
     """40 optimiser steps of the AutoencoderKL [32,32,64] + PatchDiscriminator GAN training (train_autoencoderkl.py:203-234, reference
     loss weights incl. the 1e4 x spectral term, both Adam updates, BatchNorm running statistics): reconstruction L1, spectral, KL, generator
     and discriminator losses of EVERY step against the CPU oracle's trajectory (tests/golden/make_aekl_traj.py -> aekl_traj_c1.json).
@@ -83,8 +84,8 @@ def test_aekl_gan_training_trajectory_matches_the_oracle(dtype, tol):
     from param_gen import gen_param, eeg_windows, normal
     from eegldm.models import AutoencoderKL, PatchDiscriminator
     from eegldm.training import Adam, aekl_train_step
-    g = _golden("aekl_traj_c1.json")
-    ae = AutoencoderKL(spatial_dims=1, in_channels=1, out_channels=1, num_channels=[32, 32, 64], latent_channels=1, num_res_blocks=2,
+    g = _golden(fixture)
+    ae = AutoencoderKL(spatial_dims=1, in_channels=1, out_channels=1, num_channels=g["num_channels"], latent_channels=1, num_res_blocks=2,
                        norm_num_groups=1, attention_levels=[False, False, False], dtype=dtype, device=0)
     disc = PatchDiscriminator(spatial_dims=1, num_layers_d=3, num_channels=64, in_channels=1, out_channels=1, kernel_size=3,
                               norm="BATCH", bias=False, padding=1, dtype=dtype, device=0)
@@ -111,7 +112,7 @@ def test_aekl_gan_training_trajectory_matches_the_oracle(dtype, tol):
             rel = 2 * tol if (k == "spectral" and dtype == "bfloat16") else tol
             assert abs(got[k] - want[k]) <= rel * abs(want[k]) + (2e-2 if dtype == "bfloat16" else 2e-4), (dtype, i, k, got[k], want[k])
             worst[k] = max(worst.get(k, 0.0), abs(got[k] - want[k]) / (abs(want[k]) + 1e-12))
-    print(f"AEKL/GAN trajectory [{dtype}]: worst relative gaps over {g['steps']} steps " + ", ".join(f"{k} {x:.1e}" for k, x in worst.items()))
+    print(f"AEKL/GAN trajectory {g['num_channels']} [{dtype}]: worst relative gaps over {g['steps']} steps " + ", ".join(f"{k} {x:.1e}" for k, x in worst.items()))
 
 
 @pytest.mark.parametrize("dtype,tol", [("float32", 2e-3), ("bfloat16", 8e-2)])

@@ -35,19 +35,24 @@ def test_ldm_trajectory_fixture_is_the_oracles():
         assert abs(float(l) - g["loss"][i - 1]) <= 1e-4 * g["loss"][i - 1], (i, float(l), g["loss"][i - 1])     # thread-count dependent summation order only
 
 
-def test_aekl_trajectory_fixture_is_the_oracles():
+import pytest
+
+
+@pytest.mark.parametrize("fixture", ["aekl_traj_c1.json", "aekl_traj_thin.json"])
+def test_aekl_trajectory_fixture_is_the_oracles(fixture):
     import make_aekl_traj as M
     from param_gen import gen_param, eeg_windows, normal
     import oracle.aekl as A, oracle.steps as S
-    g = _load("aekl_traj_c1.json")
+    g = _load(fixture)
+    acfg = dict(M.ACFG, num_channels=g["num_channels"])
     assert g["steps"] == len(g["losses"]) == M.STEPS
-    assert g["losses"][-1]["recons"] < 0.15 * g["losses"][0]["recons"]
-    st = {"ae": {k: torch.from_numpy(gen_param(g["param_seeds"][0], k, s)) for k, s in A.aekl_param_shapes(M.ACFG).items()},
+    assert g["losses"][-1]["recons"] < 0.2 * g["losses"][0]["recons"]
+    st = {"ae": {k: torch.from_numpy(gen_param(g["param_seeds"][0], k, s)) for k, s in A.aekl_param_shapes(acfg).items()},
           "d": {k: torch.from_numpy(gen_param(g["param_seeds"][1], k, s)) for k, s in A.disc_param_shapes(M.DCFG).items()}}
     xs = torch.from_numpy(eeg_windows(g["pool"], seed=g["window_seed"]))
     ew = torch.from_numpy(normal((g["batch"], 1, 768), seed=g["eps_seed_base"] + 1))
     w = g["weights"]
-    l, *_ = S.aekl_train_step(st["ae"], M.ACFG, st["d"], M.DCFG, xs[:g["batch"]], ew, w["adv"], w["kl"], w["spectral"], True, g["lr"][0], g["lr"][1], 1, {}, {})
+    l, *_ = S.aekl_train_step(st["ae"], acfg, st["d"], M.DCFG, xs[:g["batch"]], ew, w["adv"], w["kl"], w["spectral"], True, g["lr"][0], g["lr"][1], 1, {}, {})
     for k, v in g["losses"][0].items():
         assert abs(float(l[k]) - v) <= 1e-4 * abs(v) + 1e-6, (k, float(l[k]), v)
 
