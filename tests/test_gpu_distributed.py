@@ -218,3 +218,64 @@ def test_entry_points_two_ranks_identical_replicas(tmp_path):
     assert r0[5] == r1[5] and r0[6] == r1[6] == 2                              # UNet replicas identical
     ck = torch.load(os.path.join(out, "ldm_eeg_no-spectral_edfx", "checkpoint.pth"))
     assert float(ck["scale_factor"]) == pytest.approx(r0[4], rel=1e-6)
+
+
+# ---------------------------------------------------------------- data-parallel TRAINING TRAJECTORY against the single-process oracle
+def _ldm_traj_worker(rank, world, port, q, nsteps):
+    """Each rank takes its quarter/half of every global batch of tests/golden/ldm_traj_c2.json (the CPU oracle's single-process run at
+    B = 8), back-propagates with the overlapped gradient sync, steps Adam: the mean of the ranks' losses must follow the oracle's
+    loss step by step -- gradient averaging, its overlap with the backward, and replica consistency over several optimiser steps."""
+    sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                      EEGLDM_DIST_BACKEND="gloo", EEGLDM_LOCAL_DEVICE="0")
+    import torch.distributed as dist
+    from param_gen import gen_param, eeg_windows, normal, timesteps
+    from eegldm import distributed as D
+    from eegldm.models import UNetModel
+    from eegldm.schedulers import DDPMScheduler
+    from eegldm.training import Adam, ldm_train_step
+    with open(os.path.join(ROOT, "tests", "golden", "ldm_traj_c2.json")) as fh:
+        g = json.load(fh)
+    D.init_from_env()
+    cfg = dict(image_size=768, in_channels=1, out_channels=1, model_channels=128, num_res_blocks=2, attention_resolutions=[8, 4],
+               channel_mult=[1, 2, 4], resblock_updown=True)
+    net = UNetModel(**cfg, dtype="float32")
+    if rank == 0:                                             # only rank 0 holds the fixture's weights: the broadcast hands them out
+        net.load_state_dict({k: torch.from_numpy(gen_param(g["param_seed"], k, tuple(v.shape))) for k, v in net.state_dict().items()})
+    D.broadcast_flat(net.flat); net.sync_weights()
+    sched = DDPMScheduler(num_train_timesteps=1000, schedule="linear_beta", beta_start=0.0015, beta_end=0.0195)
+    opt = Adam(net, lr=g["lr"])
+    gs = D.OverlappedGradSync(net.flat_grad, ctx=net.ctx)
+    B, POOL = g["batch"], g["pool"]; per = B // world
+    pool = torch.from_numpy(eeg_windows(POOL, seed=g["latent_seed"], length=768)).cuda()
+    loss = torch.zeros(1, device="cuda"); gaps = []
+    for i in range(1, nsteps + 1):
+        s = ((i - 1) * B) % POOL + rank * per
+        nz = torch.from_numpy(normal((B, 1, 768), seed=g["noise_seed_base"] + i))[rank * per:(rank + 1) * per].cuda()
+        t = torch.from_numpy(timesteps(B, seed=g["t_seed_base"] + i))[rank * per:(rank + 1) * per].cuda()
+        net.zero_grad()
+        ldm_train_step(net, sched, pool[s:s + per], nz, t, loss_out=loss, grad_sync=gs); gs.wait()
+        opt.step()
+        tot = loss.detach().clone().cpu(); dist.all_reduce(tot)
+        gaps.append(abs(float(tot) / world - g["loss"][i - 1]) / g["loss"][i - 1])
+    torch.cuda.synchronize()
+    q.put((rank, gaps, float(net.flat.double().sum())))
+    dist.destroy_process_group()
+
+
+def test_data_parallel_training_follows_the_single_process_oracle_trajectory():
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29800 + os.getpid() % 90
+    nsteps = 8
+    procs = [ctx.Process(target=_ldm_traj_worker, args=(r, 2, port, q, nsteps)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=600) for _ in procs], key=lambda v: v[0])
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    assert res[0][2] == res[1][2], "replicas drifted apart"    # identical parameters on both ranks after 8 synchronised steps
+    for rank, gaps, _s in res:
+        assert max(gaps) < 2e-3, (rank, gaps)                  # the single-GPU fp32 engine follows this fixture to 2e-5 (test_gpu_convergence.py)
