@@ -245,7 +245,7 @@ int conv_skinny_ex(eegldm_ctx* ctx, int dtype, const void* x, long ldx, const vo
   if (((size_t)x | (size_t)w) % 16 != 0 || (size_t)y % 8 != 0 || (resid && (size_t)resid % 8 != 0) || (bias && (size_t)bias % 16 != 0) ||
       (rowvec && (size_t)rowvec % 16 != 0)) return 0;
   // the fused forms need whole 32-row tiles inside one sample and 4-channel lane quads inside one group
-  if (gn && (taps != 3 || L % 32 != 0 || Cin > SK_GN_MAXC || gn->cpg < 4 || gn->cpg % 4 != 0 || Cin % gn->cpg != 0 || Cin / gn->cpg > 64)) return 0;
+  if (gn && (L % 32 != 0 || Cin > SK_GN_MAXC || gn->cpg < 4 || gn->cpg % 4 != 0 || Cin % gn->cpg != 0 || Cin / gn->cpg > 64)) return 0;
   if (part_out && L % 32 != 0) return 0;
   SkArgs a = {};
   a.x = (const bf16_t*)x; a.ldx = ldx; a.w = (const bf16_t*)w; a.sWt = (long)Cout * Cin; a.Cin = Cin;
@@ -267,7 +267,8 @@ int conv_skinny_ex(eegldm_ctx* ctx, int dtype, const void* x, long ldx, const vo
     HIP_TRY(hipEventCreate(&rec.a)); HIP_TRY(hipEventCreate(&rec.b));
     HIP_TRY(hipEventRecord(rec.a, ctx->stream));
   }
-  if (gn) sk_launch<3, true>(ctx, a, rf, cf); else if (taps == 3) sk_launch<3, false>(ctx, a, rf, cf); else sk_launch<1, false>(ctx, a, rf, cf);
+  if (gn && taps == 3) sk_launch<3, true>(ctx, a, rf, cf); else if (gn) sk_launch<1, true>(ctx, a, rf, cf);
+  else if (taps == 3) sk_launch<3, false>(ctx, a, rf, cf); else sk_launch<1, false>(ctx, a, rf, cf);
   LAUNCH_CHECK();
   if (prof) { HIP_TRY(hipEventRecord(rec.b, ctx->stream)); ctx->prof.push_back(rec); }
   return 1;

@@ -77,6 +77,8 @@ struct NetBase {
   // (conv_skinny.hip) leaves the (sum, sum of squares) of every 16-row x 4-channel piece of its output in `fuse_stats` and conv2 folds
   // them per group and normalises its operand on load.  The normalised tensor and the (mean, rstd) pairs are then NOT on the tape: such a forward cannot be back-propagated.
   bool eval_fuse = false, fused_used = false;
+  bool next_is_attn = false;                 // set by the block walk: the ResBlock being run feeds an AttentionBlock (its GroupNorm can take conv2's statistics)
+  const float2* attn_in_part = nullptr;      // statistics slots of the tensor the next AttentionBlock normalises (written by that ResBlock's conv2)
   float2* fuse_stats = nullptr; size_t fuse_cap = 0, fuse_used = 0;     // float2 slots; every slot of a used area is written by conv1
   std::vector<ResTape> rt; std::vector<AttnTape> at;
 

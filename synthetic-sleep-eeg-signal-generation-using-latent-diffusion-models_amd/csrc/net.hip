@@ -67,6 +67,7 @@ int res_forward(NetBase* u, const ResDesc& r, const View& x, int B, int Lin, con
   eegldm_ctx* ctx = u->ctx; const int dt = u->dtype;
   const int Lout = r.updown == 1 ? Lin / 2 : (r.updown == 2 ? Lin * 2 : Lin);
   ResTape t; t.x = x; t.B = B; t.Lin = Lin; t.Lout = Lout;
+  u->attn_in_part = nullptr;
   ALLOC_OR_FAIL(t.st1, (float*)u->arena.alloc(sizeof(float) * 2 * B * r.groups));
   ALLOC_OR_FAIL(t.st2, (float*)u->arena.alloc(sizeof(float) * 2 * B * r.groups));
   ALLOC_OR_FAIL(t.a1.p, u->alloc_act((long)B * Lout, r.cin)); t.a1.ld = r.cin; t.a1.C = r.cin;
@@ -91,10 +92,13 @@ int res_forward(NetBase* u, const ResDesc& r, const View& x, int B, int Lin, con
       if (r.sk_w >= 0)
         EEG_TRY(op_conv_fwd(ctx, dt, t.xr.p, t.xr.ld, u->W(r.sk_w), u->P(r.sk_b), out.p, out.ld, B, Lout, r.cin, r.cout, 1, 1, 0, 0, nullptr, 0, nullptr, 0));
       const View res = r.sk_w >= 0 ? out : t.xr;
+      // the block's output feeds an AttentionBlock: conv2 leaves the statistics for THAT GroupNorm the same way
+      float2* opart = nullptr;
+      if (u->next_is_attn && u->fuse_used + need <= u->fuse_cap) opart = u->fuse_stats + u->fuse_used;
       const int rc2 = conv_skinny_ex(ctx, dt, t.h1.p, t.h1.ld, u->W(r.c2_w), r.cout, r.cout, 3, u->P(r.c2_b), nullptr, 0, res.p, res.ld,
-                                     out.p, out.ld, B, Lout, &gn, nullptr);
+                                     out.p, out.ld, B, Lout, &gn, opart);
       if (rc2 < 0) return rc2;
-      if (rc2 == 1) { fused = true; u->fused_used = true; }
+      if (rc2 == 1) { fused = true; u->fused_used = true; if (opart) { u->fuse_used += need; u->attn_in_part = opart; } }
     } else {
       EEG_TRY(op_conv_fwd(ctx, dt, t.a1.p, t.a1.ld, u->W(r.c1_w), u->P(r.c1_b), t.h1.p, t.h1.ld, B, Lout, r.cin, r.cout, 3, 1, 1, 1, emb, u->emb_ld, nullptr, 0));
     }
@@ -215,9 +219,20 @@ int attn_forward(NetBase* u, const AttnDesc& a, const View& x, int B, int T, con
   AttnTape t; t.x = x; t.B = B; t.T = T;
   ALLOC_OR_FAIL(t.st, (float*)u->arena.alloc(sizeof(float) * 2 * B * AG));
   ALLOC_OR_FAIL(t.xn.p, u->alloc_act((long)B * T, C)); t.xn.ld = C;
-  EEG_TRY(eegldm_groupnorm_fwd(ctx, x.p, x.ld, u->P(a.n_w), u->P(a.n_b), t.xn.p, C, t.st, B, T, C, AG, GN_EPS, 0, 0, nullptr, 0, dt));
   ALLOC_OR_FAIL(t.qkv.p, u->alloc_act((long)B * T, 3 * C)); t.qkv.ld = 3 * C;
-  EEG_TRY(op_conv_fwd(ctx, dt, t.xn.p, C, u->W(a.qkv_w), u->P(a.qkv_b), t.qkv.p, 3 * C, B, T, C, 3 * C, 1, 1, 0, 0, nullptr, 0, nullptr, 0));
+  // eval, few rows: the preceding ResBlock's conv2 left this tensor's statistics; the qkv projection normalises on load (NetBase::eval_fuse)
+  const float2* in_part = u->attn_in_part; u->attn_in_part = nullptr;
+  int rcq = 0;
+  if (u->eval_fuse && in_part) {
+    const SkinnyGn gn = {in_part, u->P(a.n_w), u->P(a.n_b), C / AG, GN_EPS, 0};
+    rcq = conv_skinny_ex(ctx, dt, x.p, x.ld, u->W(a.qkv_w), C, 3 * C, 1, u->P(a.qkv_b), nullptr, 0, nullptr, 0, t.qkv.p, 3 * C, B, T, &gn, nullptr);
+    if (rcq < 0) return rcq;
+    if (rcq == 1) u->fused_used = true;
+  }
+  if (rcq != 1) {
+    EEG_TRY(eegldm_groupnorm_fwd(ctx, x.p, x.ld, u->P(a.n_w), u->P(a.n_b), t.xn.p, C, t.st, B, T, C, AG, GN_EPS, 0, 0, nullptr, 0, dt));
+    EEG_TRY(op_conv_fwd(ctx, dt, t.xn.p, C, u->W(a.qkv_w), u->P(a.qkv_b), t.qkv.p, 3 * C, B, T, C, 3 * C, 1, 1, 0, 0, nullptr, 0, nullptr, 0));
+  }
   ALLOC_OR_FAIL(t.probs, u->alloc_act((long)B * T, T));
   ALLOC_OR_FAIL(t.o.p, u->alloc_act((long)B * T, C)); t.o.ld = C;
   Arena::Mark mk = u->arena.mark();

@@ -167,6 +167,7 @@ int block_forward(eegldm_unet* u, const Block& b, View x, int B, int& L, const V
     const int Lo = l.kind == 0 ? (l.r.updown == 1 ? L / 2 : (l.r.updown == 2 ? L * 2 : L)) : L;
     View y = out;
     if (!last) { ALLOC_OR_FAIL(y.p, u->alloc_act((long)B * Lo, cout)); y.ld = cout; y.C = cout; }
+    u->next_is_attn = l.kind == 0 && !last && b.layers[j + 1].kind == 1;
     if (l.kind == 0) EEG_TRY(res_forward(u, l.r, x, B, L, y)); else EEG_TRY(attn_forward(u, l.a, x, B, L, y));
     x = y; L = Lo;
   }
@@ -280,7 +281,7 @@ extern "C" int eegldm_unet_forward(eegldm_unet* u, const float* x, const int64_t
     if (u->eval_fuse) {
       // slots: B * L_out / 16 * cout / 4 per ResBlock; an upper bound from the widest / longest block keeps this simple
       size_t nres = 0; int cmax = 0;
-      auto count = [&](const Block& b) { for (auto& l : b.layers) if (l.kind == 0) { nres++; if (l.r.cout > cmax) cmax = l.r.cout; } };
+      auto count = [&](const Block& b) { for (auto& l : b.layers) { nres++; if (l.kind == 0 && l.r.cout > cmax) cmax = l.r.cout; } };   // one area per ResBlock, one more per AttentionBlock
       for (auto& b : u->in_blocks) count(b);
       count(u->mid);
       for (auto& b : u->out_blocks) count(b);
