@@ -82,23 +82,30 @@ extern "C" int eegldm_sample(eegldm_unet* u, eegldm_aekl* ae, const float* noise
   // it waits for the caller's stream first and the caller's stream waits for it at the end
   hipStream_t caller = ctx->stream;
   struct Restore { eegldm_ctx* c; hipStream_t s; ~Restore() { c->stream = s; } } restore{ctx, caller};
-  HIP_TRY(hipEventRecord(s.ev_in, caller));
-  HIP_TRY(hipStreamWaitEvent(s.stream, s.ev_in, 0));
-  ctx->stream = s.stream;
-  HIP_TRY(hipMemcpyAsync(s.x, noise, sizeof(float) * n, hipMemcpyDeviceToDevice, s.stream));
+  // Eager launches (the default) stay on the caller's stream: a second stream is a second hardware queue, and alternating queues
+  // measured +8 % on the one-window chain (47.5 vs 51.8 ms, the same as GPU_MAX_HW_QUEUES=1 gives with the own stream).
+  static const bool force_own = getenv("EEGLDM_SAMPLE_OWN_STREAM") != nullptr;
+  const bool own = use_graph || force_own;
+  const hipStream_t run = own ? s.stream : caller;
+  if (own) {
+    HIP_TRY(hipEventRecord(s.ev_in, caller));
+    HIP_TRY(hipStreamWaitEvent(s.stream, s.ev_in, 0));
+  }
+  ctx->stream = run;
+  HIP_TRY(hipMemcpyAsync(s.x, noise, sizeof(float) * n, hipMemcpyDeviceToDevice, run));
 
-  auto set_t = [&](int64_t t) { hipLaunchKernelGGL(fill_i64_kernel, dim3((B + 255) / 256), dim3(256), 0, s.stream, s.tt, B, t); };
+  auto set_t = [&](int64_t t) { hipLaunchKernelGGL(fill_i64_kernel, dim3((B + 255) / 256), dim3(256), 0, run, s.tt, B, t); };
   bool graph_ok = false;
   if (use_graph && !ctx->prof_on && !s.capture_failed) {
     if (!s.exec) {
       // eager warm-up: grows the arena / workspaces (hipMalloc is not capturable), then capture the identical launch sequence
       set_t(timesteps_host[0]);
       EEG_TRY(eegldm_unet_forward(u, s.x, s.tt, s.out, B, L, 0));
-      HIP_TRY(hipStreamSynchronize(s.stream));
+      HIP_TRY(hipStreamSynchronize(run));
       int rc = 0;
-      if (hipStreamBeginCapture(s.stream, hipStreamCaptureModeThreadLocal) == hipSuccess) {
+      if (hipStreamBeginCapture(run, hipStreamCaptureModeThreadLocal) == hipSuccess) {
         rc = eegldm_unet_forward(u, s.x, s.tt, s.out, B, L, 0);
-        hipError_t e = hipStreamEndCapture(s.stream, &s.graph);
+        hipError_t e = hipStreamEndCapture(run, &s.graph);
         if (rc == 0 && e == hipSuccess && s.graph && hipGraphInstantiate(&s.exec, s.graph, nullptr, nullptr, 0) == hipSuccess) graph_ok = true;
       }
       if (!graph_ok) {
@@ -120,7 +127,7 @@ extern "C" int eegldm_sample(eegldm_unet* u, eegldm_aekl* ae, const float* noise
   const int etot = unet_emb_width(u);
   if (table) {
     if (s.emb_cap < n_steps) {
-      HIP_TRY(hipStreamSynchronize(s.stream));
+      HIP_TRY(hipStreamSynchronize(run));
       if (s.emb_table) (void)hipFree(s.emb_table);
       if (s.emb_work) (void)hipFree(s.emb_work);
       if (s.steps_dev) (void)hipFree(s.steps_dev);
@@ -130,7 +137,7 @@ extern "C" int eegldm_sample(eegldm_unet* u, eegldm_aekl* ae, const float* noise
       HIP_TRY(hipMalloc(&s.steps_dev, sizeof(int64_t) * n_steps));
       s.emb_cap = n_steps;
     }
-    HIP_TRY(hipMemcpyAsync(s.steps_dev, timesteps_host, sizeof(int64_t) * n_steps, hipMemcpyHostToDevice, s.stream));
+    HIP_TRY(hipMemcpyAsync(s.steps_dev, timesteps_host, sizeof(int64_t) * n_steps, hipMemcpyHostToDevice, run));
     EEG_TRY(unet_embed_table(u, s.steps_dev, n_steps, s.emb_table, s.emb_work));
     set_t(timesteps_host[0]);                       // s.tt is not read on this path; keep it defined
   }
@@ -138,7 +145,7 @@ extern "C" int eegldm_sample(eegldm_unet* u, eegldm_aekl* ae, const float* noise
   for (int i = 0; i < n_steps; i++) {
     if (table) unet_set_shared_emb(u, s.emb_table + (size_t)i * etot);
     else set_t(timesteps_host[i]);
-    if (graph_ok) HIP_TRY(hipGraphLaunch(s.exec, s.stream));
+    if (graph_ok) HIP_TRY(hipGraphLaunch(s.exec, run));
     else EEG_TRY(eegldm_unet_forward(u, s.x, s.tt, s.out, B, L, 0));
     if (ancestral) {
       const bool last = a_prev_host[i] >= 1.0f;
@@ -148,16 +155,18 @@ extern "C" int eegldm_sample(eegldm_unet* u, eegldm_aekl* ae, const float* noise
       EEG_TRY(eegldm_ddim_step(ctx, s.out, s.x, a_t_host[i], a_prev_host[i], pred_type, clip_sample, s.x, nullptr, n));
     }
   }
-  if (latents_out) HIP_TRY(hipMemcpyAsync(latents_out, s.x, sizeof(float) * n, hipMemcpyDeviceToDevice, s.stream));
+  if (latents_out) HIP_TRY(hipMemcpyAsync(latents_out, s.x, sizeof(float) * n, hipMemcpyDeviceToDevice, run));
   if (windows_out) {
     if (ae) {
       if (inv_scale_factor != 1.0f) EEG_TRY(eegldm_axpy(ctx, s.x, s.x, inv_scale_factor - 1.0f, n));     // z / scale_factor (sample_trials.py:166)
       EEG_TRY(eegldm_aekl_decode(ae, s.x, windows_out, B, L));
     } else {
-      HIP_TRY(hipMemcpyAsync(windows_out, s.x, sizeof(float) * n, hipMemcpyDeviceToDevice, s.stream));    // pixel-space model: x IS the window
+      HIP_TRY(hipMemcpyAsync(windows_out, s.x, sizeof(float) * n, hipMemcpyDeviceToDevice, run));    // pixel-space model: x IS the window
     }
   }
-  HIP_TRY(hipEventRecord(s.ev_out, s.stream));
-  HIP_TRY(hipStreamWaitEvent(caller, s.ev_out, 0));
+  if (own) {
+    HIP_TRY(hipEventRecord(s.ev_out, run));
+    HIP_TRY(hipStreamWaitEvent(caller, s.ev_out, 0));
+  }
   return 0;
 }
