@@ -54,6 +54,14 @@ __device__ __forceinline__ uint4 sk_norm8(uint4 a, const float* sc, const float*
   return make_uint4(out[0], out[1], out[2], out[3]);
 }
 
+// rotate a fragment by one lane inside every 16-lane row (the 16 rows of a fragment): CTRL 0x121 = row_ror:1 (lane i <- lane i - 1),
+// 0x12F = row_ror:15 (lane i <- lane i + 1).  A 3-tap conv's shifted operand fragments are rotations of the centre ones.
+template <int CTRL>
+__device__ __forceinline__ uint4 sk_rot(uint4 v) {
+  return make_uint4((unsigned)__builtin_amdgcn_update_dpp(0, (int)v.x, CTRL, 0xf, 0xf, false), (unsigned)__builtin_amdgcn_update_dpp(0, (int)v.y, CTRL, 0xf, 0xf, false),
+                    (unsigned)__builtin_amdgcn_update_dpp(0, (int)v.z, CTRL, 0xf, 0xf, false), (unsigned)__builtin_amdgcn_update_dpp(0, (int)v.w, CTRL, 0xf, 0xf, false));
+}
+
 template <int TAPS, int RF, int CF, bool GN>
 __global__ __launch_bounds__(64 * SK_WAVES) void conv_skinny_kernel(const SkArgs p) {
   __shared__ f32x4 part[SK_WAVES][RF * CF][64];
@@ -101,26 +109,47 @@ __global__ __launch_bounds__(64 * SK_WAVES) void conv_skinny_kernel(const SkArgs
       xrow[t][rf] = p.x + (long)r * p.ldx + q * 8;
     }
 
+  // 3 taps: only the CENTRE rows and one halo fragment are loaded (lane 0 of every 16-lane row: the row above the tile, lane 15: the
+  // row below it); the two shifted operand fragments of a tap are lane rotations of the centre ones (a third of the activation
+  // loads, and of the GroupNorm / SiLU work when the operand is normalised on load)
+  const bf16_t* xhalo;
+  {
+    int r = lm == 0 ? row[0] - 1 : (lm == 15 ? row[RF - 1] + 1 : row[0]); r = r < 0 ? 0 : (r >= p.M ? p.M - 1 : r);
+    xhalo = p.x + (long)r * p.ldx + q * 8;
+  }
   f32x4 acc[RF][CF];
 #pragma unroll
   for (int rf = 0; rf < RF; rf++)
 #pragma unroll
     for (int cf = 0; cf < CF; cf++) acc[rf][cf] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-  // wave w reduces the 32-channel chunks w, w + 8, ... (all taps of a chunk); CH chunks = CH * TAPS * (RF + CF) loads per round
-  constexpr int CH = SK_LOADS / (TAPS * (RF + CF)) < 1 ? 1 : SK_LOADS / (TAPS * (RF + CF));
+  // wave w reduces the 32-channel chunks w, w + 8, ... (all taps of a chunk); CH chunks per round
+  constexpr int LPC = TAPS == 3 ? RF + 1 + 3 * CF : RF + CF;           // loads per chunk
+  // (at most 2 chunks per round for 3 taps: with 16 chunks -- 512 channels -- a wave owns exactly two, and a longer round would only
+  // fetch clamped duplicates: the loads are unconditional)
+  constexpr int CH0 = SK_LOADS / LPC < 1 ? 1 : SK_LOADS / LPC, CH = (TAPS == 3 && CH0 > 2) ? 2 : CH0;
+  // GroupNorm on load: gamma / beta of this thread's channels now, so that only ONE memory latency (the statistics slots, overlapped
+  // with the operand loads) lies between the loads and the first MFMA
+  float g_ga[2] = {0.f, 0.f}, g_be[2] = {0.f, 0.f};
+  if (GN) {
+#pragma unroll
+    for (int j = 0; j < 2; j++) {
+      const int ch = tid + j * 64 * SK_WAVES;
+      if (ch < p.Cin) { g_ga[j] = p.gn_gamma[ch]; g_be[j] = p.gn_beta[ch]; }
+    }
+  }
   // Rounds: the first one is straight-line code (a loop header costs a conservative vmcnt(0) before the loads), the rest -- only
   // reductions longer than 8 * CH chunks have any -- is a loop.
 #define SK_ROUND(C0, FIRST)                                                                                                          \
   {                                                                                                                                  \
     const int c0 = (C0);                                                                                                             \
-    uint4 xa[CH][TAPS][RF], wb[CH][TAPS][CF];                                                                                        \
+    uint4 xc[CH][RF], xh[CH], wb[CH][TAPS][CF];                                                                                      \
     _Pragma("unroll") for (int i = 0; i < CH; i++) {                                                                                 \
       int c = c0 + i * SK_WAVES; if (c >= kchunks) c = kchunks - 1; if (c < 0) c = 0; /* clamped: surplus products are skipped */    \
-      _Pragma("unroll") for (int t = 0; t < TAPS; t++) {                                                                             \
-        _Pragma("unroll") for (int rf = 0; rf < RF; rf++) xa[i][t][rf] = *(const uint4*)(xrow[t][rf] + c * 32);                      \
+      _Pragma("unroll") for (int rf = 0; rf < RF; rf++) xc[i][rf] = *(const uint4*)(xrow[TAPS / 2][rf] + c * 32);                    \
+      if (TAPS == 3) xh[i] = *(const uint4*)(xhalo + c * 32);                                                                        \
+      _Pragma("unroll") for (int t = 0; t < TAPS; t++)                                                                               \
         _Pragma("unroll") for (int cf = 0; cf < CF; cf++) wb[i][t][cf] = *(const uint4*)(wrow[cf] + (long)t * p.sWt + c * 32);      \
-      }                                                                                                                              \
     }                                                                                                                                \
     if (FIRST) {                                                                                                                     \
       asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(e_bias) : "v"(pb) : "memory");                                          \
@@ -146,10 +175,13 @@ __global__ __launch_bounds__(64 * SK_WAVES) void conv_skinny_kernel(const SkArgs
         }                                                                                                                            \
       }                                                                                                                              \
       __syncthreads();                                                                                                               \
-      for (int ch = tid; ch < p.Cin; ch += 64 * SK_WAVES) {                                                                          \
-        const float2 mr = gn_mr[ch / p.gn_cpg];                                                                                      \
-        const float ga = p.gn_gamma[ch] * mr.y;                                                                                      \
-        gn_ss[ch] = make_float2(ga, p.gn_beta[ch] - mr.x * ga);                                                                      \
+      _Pragma("unroll") for (int j = 0; j < 2; j++) { /* Cin <= SK_GN_MAXC = 2 x 512 */                                              \
+        const int ch = tid + j * 64 * SK_WAVES;                                                                                      \
+        if (ch < p.Cin) {                                                                                                            \
+          const float2 mr = gn_mr[ch / p.gn_cpg];                                                                                    \
+          const float ga = g_ga[j] * mr.y;                                                                                           \
+          gn_ss[ch] = make_float2(ga, g_be[j] - mr.x * ga);                                                                          \
+        }                                                                                                                            \
       }                                                                                                                              \
       __syncthreads();                                                                                                               \
     }                                                                                                                                \
@@ -162,10 +194,17 @@ __global__ __launch_bounds__(64 * SK_WAVES) void conv_skinny_kernel(const SkArgs
             const float4 v = sp[j]; nsc[2 * j] = v.x; nsh[2 * j] = v.y; nsc[2 * j + 1] = v.z; nsh[2 * j + 1] = v.w;                  \
           }                                                                                                                          \
         }                                                                                                                            \
+        uint4 ctr[RF], up[RF], dn[RF], hal = make_uint4(0u, 0u, 0u, 0u);                                                             \
+        _Pragma("unroll") for (int rf = 0; rf < RF; rf++) ctr[rf] = GN ? sk_norm8(xc[i][rf], nsc, nsh, p.gn_silu != 0) : xc[i][rf];  \
+        if (TAPS == 3) {                                                                                                             \
+          hal = GN ? sk_norm8(xh[i], nsc, nsh, p.gn_silu != 0) : xh[i];                                                              \
+          _Pragma("unroll") for (int rf = 0; rf < RF; rf++) { up[rf] = sk_rot<0x121>(ctr[rf]); dn[rf] = sk_rot<0x12F>(ctr[rf]); }    \
+        }                                                                                                                            \
         _Pragma("unroll") for (int t = 0; t < TAPS; t++)                                                                             \
           _Pragma("unroll") for (int rf = 0; rf < RF; rf++) {                                                                        \
-            uint4 a = xa[i][t][rf];                                                                                                  \
-            if (GN) a = sk_norm8(a, nsc, nsh, p.gn_silu != 0);                                                                       \
+            uint4 a = ctr[rf];                                                                                                       \
+            if (TAPS == 3 && t == 0) { a = up[rf]; if (lm == 0) a = rf == 0 ? hal : up[rf > 0 ? rf - 1 : 0]; }   /* row above */     \
+            if (TAPS == 3 && t == 2) { a = dn[rf]; if (lm == 15) a = rf == RF - 1 ? hal : dn[rf + 1 < RF ? rf + 1 : RF - 1]; } /* below */ \
             if (TAPS == 3 && !xok[t][rf]) a = make_uint4(0u, 0u, 0u, 0u);                                                            \
             _Pragma("unroll") for (int cf = 0; cf < CF; cf++)                                                                        \
               acc[rf][cf] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, wb[i][t][cf]),                        \
