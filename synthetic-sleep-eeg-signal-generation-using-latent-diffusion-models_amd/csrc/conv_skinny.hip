@@ -125,9 +125,9 @@ __global__ __launch_bounds__(64 * SK_WAVES) void conv_skinny_kernel(const SkArgs
 
   // wave w reduces the 32-channel chunks w, w + 8, ... (all taps of a chunk); CH chunks per round
   constexpr int LPC = TAPS == 3 ? RF + 1 + 3 * CF : RF + CF;           // loads per chunk
-  // (at most 2 chunks per round for 3 taps: with 16 chunks -- 512 channels -- a wave owns exactly two, and a longer round would only
-  // fetch clamped duplicates: the loads are unconditional)
-  constexpr int CH0 = SK_LOADS / LPC < 1 ? 1 : SK_LOADS / LPC, CH = (TAPS == 3 && CH0 > 2) ? 2 : CH0;
+  // (at most 2 chunks per round: with 16 chunks -- 512 channels -- a wave owns exactly two, and a longer round would only fetch
+  // clamped duplicates: the loads are unconditional.  1 x 1 kernels ran rounds of 6-8 chunks before: 7.4 -> see DESIGN.md 3.3)
+  constexpr int CH0 = SK_LOADS / LPC < 1 ? 1 : SK_LOADS / LPC, CH = CH0 > 2 ? 2 : CH0;
   // GroupNorm on load: gamma / beta of this thread's channels now, so that only ONE memory latency (the statistics slots, overlapped
   // with the operand loads) lies between the loads and the first MFMA
   float g_ga[2] = {0.f, 0.f}, g_be[2] = {0.f, 0.f};
