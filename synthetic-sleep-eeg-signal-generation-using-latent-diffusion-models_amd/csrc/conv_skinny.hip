@@ -131,11 +131,21 @@ __global__ __launch_bounds__(64 * SK_WAVES) void conv_skinny_kernel(const SkArgs
   // GroupNorm on load: gamma / beta of this thread's channels now, so that only ONE memory latency (the statistics slots, overlapped
   // with the operand loads) lies between the loads and the first MFMA
   float g_ga[2] = {0.f, 0.f}, g_be[2] = {0.f, 0.f};
+  // ... and the first 48 statistics slots of this thread's group (16 threads per group, 3 each: all of them for this UNet) go out
+  // BEFORE the operand loads: they come back first, and the fold runs while the operands are still in flight
+  float2 pv[3] = {make_float2(0.f, 0.f), make_float2(0.f, 0.f), make_float2(0.f, 0.f)};
   if (GN) {
 #pragma unroll
     for (int j = 0; j < 2; j++) {
       const int ch = tid + j * 64 * SK_WAVES;
       if (ch < p.Cin) { g_ga[j] = p.gn_gamma[ch]; g_be[j] = p.gn_beta[ch]; }
+    }
+    const int G = p.Cin / p.gn_cpg, qpg = p.gn_cpg >> 2, rts = p.L >> 4, S = rts * qpg, nq = p.Cin >> 2, g = tid >> 4;
+    const float2* pb0 = p.gn_part + (long)(m0 / p.L) * rts * nq;
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+      const int i = (tid & 15) + 16 * k;
+      if (g < G && i < S) { const int rt = i / qpg; pv[k] = pb0[(long)rt * nq + g * qpg + (i - rt * qpg)]; }
     }
   }
   // Rounds: the first one is straight-line code (a loop header costs a conservative vmcnt(0) before the loads), the rest -- only
@@ -163,8 +173,10 @@ __global__ __launch_bounds__(64 * SK_WAVES) void conv_skinny_kernel(const SkArgs
       const double cnt = (double)p.gn_cpg * (double)p.L;                                                                             \
       const float2* pb = p.gn_part + (long)(m0 / p.L) * rts * nq;                                                                    \
       for (int g = tid >> 4; g < G; g += 4 * SK_WAVES) { /* 16 threads per group */                                                   \
-        double s1 = 0.0, s2 = 0.0;                                                                                                   \
-        for (int i = tid & 15; i < S; i += 16) {                                                                                     \
+        const bool pre = g == (tid >> 4);            /* first pass: the three prefetched slots (zeros where there was none) */        \
+        double s1 = pre ? (double)pv[0].x + (double)pv[1].x + (double)pv[2].x : 0.0;                                                 \
+        double s2 = pre ? (double)pv[0].y + (double)pv[1].y + (double)pv[2].y : 0.0;                                                 \
+        for (int i = (tid & 15) + (pre ? 48 : 0); i < S; i += 16) {                                                                  \
           const int rt = i / qpg; const float2 v = pb[(long)rt * nq + g * qpg + (i - rt * qpg)];                                     \
           s1 += (double)v.x; s2 += (double)v.y;                                                                                      \
         }                                                                                                                            \
