@@ -37,8 +37,15 @@ struct SkArgs {
   // plain stores, no zeroing, no contention (fp64 atomics on the 64 (sample, group) sums cost the producer +6 us: ~125 ns per same-address atomic)
   float2* part_out;
   // GroupNorm (+ SiLU) on the activation operand (consumer side, GN kernels): x is the RAW tensor, gn_part its producer's slots
-  const float2* gn_part; const float* gn_gamma; const float* gn_beta; int gn_cpg; float gn_eps; int gn_silu;
+  // (a concatenated operand [h | skip] has two producers: quads below gn_nqa come from gn_part, the others from gn_part_b)
+  const float2* gn_part; const float2* gn_part_b; int gn_nqa; const float* gn_gamma; const float* gn_beta; int gn_cpg; float gn_eps; int gn_silu;
 };
+
+// statistics slot of (16-row fragment rt, 4-channel quad qd) of sample `b` of a tensor whose channels [0, 4 nqa) were written by one producer
+// (slots pa, nqa quads per row fragment) and the rest by another (pb, nqb)
+__device__ __forceinline__ float2 sk_slot(const float2* pa, const float2* pb, int nqa, int nqb, long b, int rts, int rt, int qd) {
+  return qd < nqa ? pa[(b * rts + rt) * nqa + qd] : pb[(b * rts + rt) * nqb + (qd - nqa)];
+}
 
 constexpr int SK_GN_MAXC = 1024;            // widest normalised operand (scale / shift table in LDS)
 
@@ -141,11 +148,10 @@ __global__ __launch_bounds__(64 * SK_WAVES) void conv_skinny_kernel(const SkArgs
       if (ch < p.Cin) { g_ga[j] = p.gn_gamma[ch]; g_be[j] = p.gn_beta[ch]; }
     }
     const int G = p.Cin / p.gn_cpg, qpg = p.gn_cpg >> 2, rts = p.L >> 4, S = rts * qpg, nq = p.Cin >> 2, g = tid >> 4;
-    const float2* pb0 = p.gn_part + (long)(m0 / p.L) * rts * nq;
 #pragma unroll
     for (int k = 0; k < 3; k++) {
       const int i = (tid & 15) + 16 * k;
-      if (g < G && i < S) { const int rt = i / qpg; pv[k] = pb0[(long)rt * nq + g * qpg + (i - rt * qpg)]; }
+      if (g < G && i < S) { const int rt = i / qpg; pv[k] = sk_slot(p.gn_part, p.gn_part_b, p.gn_nqa, nq - p.gn_nqa, m0 / p.L, rts, rt, g * qpg + (i - rt * qpg)); }
     }
   }
   // Rounds: the first one is straight-line code (a loop header costs a conservative vmcnt(0) before the loads), the rest -- only
@@ -171,13 +177,13 @@ __global__ __launch_bounds__(64 * SK_WAVES) void conv_skinny_kernel(const SkArgs
                           under the operand loads' latency */                                                                        \
       const int G = p.Cin / p.gn_cpg, qpg = p.gn_cpg >> 2, rts = p.L >> 4, S = rts * qpg, nq = p.Cin >> 2;                           \
       const double cnt = (double)p.gn_cpg * (double)p.L;                                                                             \
-      const float2* pb = p.gn_part + (long)(m0 / p.L) * rts * nq;                                                                    \
       for (int g = tid >> 4; g < G; g += 4 * SK_WAVES) { /* 16 threads per group */                                                   \
         const bool pre = g == (tid >> 4);            /* first pass: the three prefetched slots (zeros where there was none) */        \
         double s1 = pre ? (double)pv[0].x + (double)pv[1].x + (double)pv[2].x : 0.0;                                                 \
         double s2 = pre ? (double)pv[0].y + (double)pv[1].y + (double)pv[2].y : 0.0;                                                 \
         for (int i = (tid & 15) + (pre ? 48 : 0); i < S; i += 16) {                                                                  \
-          const int rt = i / qpg; const float2 v = pb[(long)rt * nq + g * qpg + (i - rt * qpg)];                                     \
+          const int rt = i / qpg;                                                                                                    \
+          const float2 v = sk_slot(p.gn_part, p.gn_part_b, p.gn_nqa, nq - p.gn_nqa, m0 / p.L, rts, rt, g * qpg + (i - rt * qpg));    \
           s1 += (double)v.x; s2 += (double)v.y;                                                                                      \
         }                                                                                                                            \
         _Pragma("unroll") for (int o = 1; o < 16; o <<= 1) { s1 += __shfl_xor(s1, o); s2 += __shfl_xor(s2, o); }                     \
@@ -303,7 +309,7 @@ int conv_skinny_ex(eegldm_ctx* ctx, int dtype, const void* x, long ldx, const vo
   a.bias = bias; a.rowvec = rowvec; a.ld_rowvec = ld_rowvec; a.resid = (const bf16_t*)resid; a.ldr = ldr;
   a.y = (bf16_t*)y; a.ldy = ldy; a.M = (int)M; a.L = L; a.N = Cout;
   a.part_out = part_out;
-  if (gn) { a.gn_part = gn->part; a.gn_gamma = gn->gamma; a.gn_beta = gn->beta; a.gn_cpg = gn->cpg; a.gn_eps = gn->eps; a.gn_silu = gn->silu; }
+  if (gn) { a.gn_part = gn->part; a.gn_part_b = gn->part_b ? gn->part_b : gn->part; a.gn_nqa = gn->part_b ? gn->nqa : Cin / 4; a.gn_gamma = gn->gamma; a.gn_beta = gn->beta; a.gn_cpg = gn->cpg; a.gn_eps = gn->eps; a.gn_silu = gn->silu; }
   // widest register tile that still gives every CU most of a block (fewer re-reads of the operands through L2)
   static const int force = getenv("EEGLDM_CONV_SKINNY_TILE") ? atoi(getenv("EEGLDM_CONV_SKINNY_TILE")) : 0;   // 11 / 21 / 22
   const long want = ctx->num_cu * 3 / 4;

@@ -77,9 +77,14 @@ struct NetBase {
   // (conv_skinny.hip) leaves the (sum, sum of squares) of every 16-row x 4-channel piece of its output in `fuse_stats` and conv2 folds
   // them per group and normalises its operand on load.  The normalised tensor and the (mean, rstd) pairs are then NOT on the tape: such a forward cannot be back-propagated.
   bool eval_fuse = false, fused_used = false;
-  bool next_is_attn = false;                 // set by the block walk: the ResBlock being run feeds an AttentionBlock (its GroupNorm can take conv2's statistics)
-  const float2* attn_in_part = nullptr;      // statistics slots of the tensor the next AttentionBlock normalises (written by that ResBlock's conv2)
-  float2* fuse_stats = nullptr; size_t fuse_cap = 0, fuse_used = 0;     // float2 slots; every slot of a used area is written by conv1
+  // statistics slots by tensor: every few-row conv that writes a block output registers (output pointer -> slots); the GroupNorm that
+  // reads that tensor later -- the next ResBlock's first norm, an AttentionBlock's norm, or, for the output path's concatenations
+  // [h | skip], two producers at x and x + c1 -- finds them by address.  Cleared at the start of every forward.
+  struct PartReg { const void* p; const float2* slots; int nq; };
+  std::vector<PartReg> part_reg;
+  const PartReg* find_part(const void* p) const { for (auto it = part_reg.rbegin(); it != part_reg.rend(); ++it) if (it->p == p) return &*it; return nullptr; }
+  float2* fuse_alloc(size_t slots) { if (fuse_used + slots > fuse_cap) return nullptr; float2* a = fuse_stats + fuse_used; fuse_used += slots; return a; }
+  float2* fuse_stats = nullptr; size_t fuse_cap = 0, fuse_used = 0;     // float2 slots; every slot of a used area is written by its producer
   std::vector<ResTape> rt; std::vector<AttnTape> at;
 
   const void* W(long off) const { return (const char*)wT + (size_t)off * dtype_size(dtype); }

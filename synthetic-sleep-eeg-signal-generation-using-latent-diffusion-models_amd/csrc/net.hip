@@ -67,46 +67,60 @@ int res_forward(NetBase* u, const ResDesc& r, const View& x, int B, int Lin, con
   eegldm_ctx* ctx = u->ctx; const int dt = u->dtype;
   const int Lout = r.updown == 1 ? Lin / 2 : (r.updown == 2 ? Lin * 2 : Lin);
   ResTape t; t.x = x; t.B = B; t.Lin = Lin; t.Lout = Lout;
-  u->attn_in_part = nullptr;
   ALLOC_OR_FAIL(t.st1, (float*)u->arena.alloc(sizeof(float) * 2 * B * r.groups));
   ALLOC_OR_FAIL(t.st2, (float*)u->arena.alloc(sizeof(float) * 2 * B * r.groups));
-  ALLOC_OR_FAIL(t.a1.p, u->alloc_act((long)B * Lout, r.cin)); t.a1.ld = r.cin; t.a1.C = r.cin;
-  if (r.updown) { ALLOC_OR_FAIL(t.xr.p, u->alloc_act((long)B * Lout, r.cin)); t.xr.ld = r.cin; t.xr.C = r.cin; } else t.xr = x;
-  EEG_TRY(eegldm_groupnorm_fwd(ctx, x.p, x.ld, u->P(r.gn1_w), u->P(r.gn1_b), t.a1.p, t.a1.ld, t.st1, B, Lin, r.cin, r.groups, GN_EPS, 1,
-                               r.updown, r.updown ? t.xr.p : nullptr, t.xr.ld, dt));
-  ALLOC_OR_FAIL(t.h1.p, u->alloc_act((long)B * Lout, r.cout)); t.h1.ld = r.cout; t.h1.C = r.cout;
   const float* emb = r.emb_col >= 0 ? u->emb_all + r.emb_col : nullptr;
-  // ---- eval, few rows: conv1 leaves GroupNorm 2's statistics, conv2 normalises on load (see NetBase::eval_fuse)
-  const int cpg2 = r.cout / r.groups;
-  const size_t need = (size_t)B * (Lout / 16) * (r.cout / 4);       // float2 slots
+  // ---- eval, few rows (NetBase::eval_fuse): conv1 leaves GroupNorm 2's statistics and conv2 normalises on load; conv2 leaves the
+  // statistics of the block output; and when the producers of THIS block's input left theirs, GroupNorm 1 is folded into conv1 too
+  const int cpg1 = r.cin / r.groups, cpg2 = r.cout / r.groups;
+  const size_t need = (size_t)B * (Lout / 16) * (r.cout / 4);       // float2 slots of a (B * Lout) x cout tensor
+  const bool fuse2 = u->eval_fuse && Lout % 32 == 0 && cpg2 >= 4 && cpg2 % 4 == 0 && r.cout % r.groups == 0 &&
+                     conv_skinny_takes(dt, r.cin, r.cout, 3, B, Lout) && conv_skinny_takes(dt, r.cout, r.cout, 3, B, Lout);
+  const NetBase::PartReg *pa = nullptr, *pb = nullptr;
+  bool fuse1 = false;
+  if (fuse2 && !r.updown && cpg1 >= 4 && cpg1 % 4 == 0 && r.cin % r.groups == 0) {
+    pa = u->find_part(x.p);
+    if (pa && pa->nq * 4 < r.cin) pb = u->find_part((const char*)x.p + (size_t)pa->nq * 4 * dtype_size(dt));
+    fuse1 = pa && (pa->nq * 4 == r.cin || (pb && (pa->nq + pb->nq) * 4 == r.cin));
+  }
+  auto norm1 = [&]() -> int {       // the stand-alone first GroupNorm (+ resampling)
+    ALLOC_OR_FAIL(t.a1.p, u->alloc_act((long)B * Lout, r.cin)); t.a1.ld = r.cin; t.a1.C = r.cin;
+    return eegldm_groupnorm_fwd(ctx, x.p, x.ld, u->P(r.gn1_w), u->P(r.gn1_b), t.a1.p, t.a1.ld, t.st1, B, Lin, r.cin, r.groups, GN_EPS, 1,
+                                r.updown, r.updown ? t.xr.p : nullptr, t.xr.ld, dt);
+  };
+  if (r.updown) { ALLOC_OR_FAIL(t.xr.p, u->alloc_act((long)B * Lout, r.cin)); t.xr.ld = r.cin; t.xr.C = r.cin; } else t.xr = x;
+  if (!fuse1) EEG_TRY(norm1());
+  ALLOC_OR_FAIL(t.h1.p, u->alloc_act((long)B * Lout, r.cout)); t.h1.ld = r.cout; t.h1.C = r.cout;
   bool fused = false;
-  if (u->eval_fuse && u->fuse_used + need <= u->fuse_cap && Lout % 32 == 0 && cpg2 >= 4 && cpg2 % 4 == 0 && r.cout % r.groups == 0 &&
-      conv_skinny_takes(dt, r.cin, r.cout, 3, B, Lout) && conv_skinny_takes(dt, r.cout, r.cout, 3, B, Lout)) {
-    float2* area = u->fuse_stats + u->fuse_used;
-    const int rc1 = conv_skinny_ex(ctx, dt, t.a1.p, t.a1.ld, u->W(r.c1_w), r.cin, r.cout, 3, u->P(r.c1_b), emb, u->emb_ld, nullptr, 0,
-                                   t.h1.p, t.h1.ld, B, Lout, nullptr, area);
+  float2* area = fuse2 ? u->fuse_alloc(need) : nullptr;
+  if (!area && fuse1) { fuse1 = false; EEG_TRY(norm1()); }        // no room for the statistics: the plain path below needs the normalised tensor
+  if (area) {
+    SkinnyGn gn1 = {pa ? pa->slots : nullptr, u->P(r.gn1_w), u->P(r.gn1_b), cpg1, GN_EPS, 1};
+    if (pb) { gn1.part_b = pb->slots; gn1.nqa = pa->nq; }
+    int rc1 = conv_skinny_ex(ctx, dt, fuse1 ? x.p : t.a1.p, fuse1 ? x.ld : t.a1.ld, u->W(r.c1_w), r.cin, r.cout, 3, u->P(r.c1_b), emb, u->emb_ld,
+                             nullptr, 0, t.h1.p, t.h1.ld, B, Lout, fuse1 ? &gn1 : nullptr, area);
     if (rc1 < 0) return rc1;
+    if (rc1 == 1 && fuse1) u->fused_used = true;
+    if (rc1 == 0 && fuse1) EEG_TRY(norm1());           // declined (alignment): the stand-alone norm after all
     if (rc1 == 1) {
-      u->fuse_used += need;
       const SkinnyGn gn = {area, u->P(r.gn2_w), u->P(r.gn2_b), cpg2, GN_EPS, 1};
       if (r.sk_w >= 0)
         EEG_TRY(op_conv_fwd(ctx, dt, t.xr.p, t.xr.ld, u->W(r.sk_w), u->P(r.sk_b), out.p, out.ld, B, Lout, r.cin, r.cout, 1, 1, 0, 0, nullptr, 0, nullptr, 0));
       const View res = r.sk_w >= 0 ? out : t.xr;
-      // the block's output feeds an AttentionBlock: conv2 leaves the statistics for THAT GroupNorm the same way
-      float2* opart = nullptr;
-      if (u->next_is_attn && u->fuse_used + need <= u->fuse_cap) opart = u->fuse_stats + u->fuse_used;
+      float2* opart = u->fuse_alloc(need);              // statistics of the block output, for whoever normalises it next
       const int rc2 = conv_skinny_ex(ctx, dt, t.h1.p, t.h1.ld, u->W(r.c2_w), r.cout, r.cout, 3, u->P(r.c2_b), nullptr, 0, res.p, res.ld,
                                      out.p, out.ld, B, Lout, &gn, opart);
       if (rc2 < 0) return rc2;
-      if (rc2 == 1) { fused = true; u->fused_used = true; if (opart) { u->fuse_used += need; u->attn_in_part = opart; } }
+      if (rc2 == 1) { fused = true; u->fused_used = true; if (opart) u->part_reg.push_back({out.p, opart, r.cout / 4}); }
     } else {
       EEG_TRY(op_conv_fwd(ctx, dt, t.a1.p, t.a1.ld, u->W(r.c1_w), u->P(r.c1_b), t.h1.p, t.h1.ld, B, Lout, r.cin, r.cout, 3, 1, 1, 1, emb, u->emb_ld, nullptr, 0));
     }
+    const int rc1_done = rc1;
     if (!fused) {      // conv2 declined (alignment): the stand-alone GroupNorm and the plain conv, as below (the skip conv already ran)
       ALLOC_OR_FAIL(t.a2.p, u->alloc_act((long)B * Lout, r.cout)); t.a2.ld = r.cout; t.a2.C = r.cout;
       EEG_TRY(eegldm_groupnorm_fwd(ctx, t.h1.p, t.h1.ld, u->P(r.gn2_w), u->P(r.gn2_b), t.a2.p, t.a2.ld, t.st2, B, Lout, r.cout, r.groups, GN_EPS, 1,
                                    0, nullptr, 0, dt));
-      const bool skip_done = rc1 == 1 && r.sk_w >= 0;
+      const bool skip_done = rc1_done == 1 && r.sk_w >= 0;
       if (r.sk_w >= 0 && !skip_done)
         EEG_TRY(op_conv_fwd(ctx, dt, t.xr.p, t.xr.ld, u->W(r.sk_w), u->P(r.sk_b), out.p, out.ld, B, Lout, r.cin, r.cout, 1, 1, 0, 0, nullptr, 0, nullptr, 0));
       const View res = r.sk_w >= 0 ? out : t.xr;
@@ -221,10 +235,10 @@ int attn_forward(NetBase* u, const AttnDesc& a, const View& x, int B, int T, con
   ALLOC_OR_FAIL(t.xn.p, u->alloc_act((long)B * T, C)); t.xn.ld = C;
   ALLOC_OR_FAIL(t.qkv.p, u->alloc_act((long)B * T, 3 * C)); t.qkv.ld = 3 * C;
   // eval, few rows: the preceding ResBlock's conv2 left this tensor's statistics; the qkv projection normalises on load (NetBase::eval_fuse)
-  const float2* in_part = u->attn_in_part; u->attn_in_part = nullptr;
+  const NetBase::PartReg* in_part = u->eval_fuse ? u->find_part(x.p) : nullptr;
   int rcq = 0;
-  if (u->eval_fuse && in_part) {
-    const SkinnyGn gn = {in_part, u->P(a.n_w), u->P(a.n_b), C / AG, GN_EPS, 0};
+  if (in_part && in_part->nq * 4 == C) {
+    const SkinnyGn gn = {in_part->slots, u->P(a.n_w), u->P(a.n_b), C / AG, GN_EPS, 0};
     rcq = conv_skinny_ex(ctx, dt, x.p, x.ld, u->W(a.qkv_w), C, 3 * C, 1, u->P(a.qkv_b), nullptr, 0, nullptr, 0, t.qkv.p, 3 * C, B, T, &gn, nullptr);
     if (rcq < 0) return rcq;
     if (rcq == 1) u->fused_used = true;
@@ -239,7 +253,17 @@ int attn_forward(NetBase* u, const AttnDesc& a, const View& x, int B, int T, con
   float* logits; ALLOC_OR_FAIL(logits, (float*)u->arena.alloc(sizeof(float) * (size_t)B * T * T));
   EEG_TRY(op_attention_fwd(ctx, dt, t.qkv.p, 3 * C, t.o.p, C, t.probs, logits, B, T, C));
   u->arena.release(mk);
-  EEG_TRY(op_conv_fwd(ctx, dt, t.o.p, C, u->W(a.pr_w), u->P(a.pr_b), out.p, out.ld, B, T, C, C, 1, 1, 0, 0, nullptr, 0, x.p, x.ld));
+  // eval, few rows: the projection leaves the statistics of the block output for the next ResBlock's first GroupNorm
+  int rcp = 0;
+  if (u->eval_fuse && T % 32 == 0 && conv_skinny_takes(dt, C, C, 1, B, T)) {
+    float2* opart = u->fuse_alloc((size_t)B * (T / 16) * (C / 4));
+    if (opart) {
+      rcp = conv_skinny_ex(ctx, dt, t.o.p, C, u->W(a.pr_w), C, C, 1, u->P(a.pr_b), nullptr, 0, x.p, x.ld, out.p, out.ld, B, T, nullptr, opart);
+      if (rcp < 0) return rcp;
+      if (rcp == 1) u->part_reg.push_back({out.p, opart, C / 4});
+    }
+  }
+  if (rcp != 1) EEG_TRY(op_conv_fwd(ctx, dt, t.o.p, C, u->W(a.pr_w), u->P(a.pr_b), out.p, out.ld, B, T, C, C, 1, 1, 0, 0, nullptr, 0, x.p, x.ld));
   u->at.push_back(t);
   return 0;
 }

@@ -167,7 +167,6 @@ int block_forward(eegldm_unet* u, const Block& b, View x, int B, int& L, const V
     const int Lo = l.kind == 0 ? (l.r.updown == 1 ? L / 2 : (l.r.updown == 2 ? L * 2 : L)) : L;
     View y = out;
     if (!last) { ALLOC_OR_FAIL(y.p, u->alloc_act((long)B * Lo, cout)); y.ld = cout; y.C = cout; }
-    u->next_is_attn = l.kind == 0 && !last && b.layers[j + 1].kind == 1;
     if (l.kind == 0) EEG_TRY(res_forward(u, l.r, x, B, L, y)); else EEG_TRY(attn_forward(u, l.a, x, B, L, y));
     x = y; L = Lo;
   }
@@ -277,7 +276,7 @@ extern "C" int eegldm_unet_forward(eegldm_unet* u, const float* x, const int64_t
   // ---- eval-mode GroupNorm fusion for few-row launches (NetBase::eval_fuse): one statistics area per ResBlock
   {
     static const bool no_fuse = getenv("EEGLDM_NO_EVAL_GN_FUSE") != nullptr;
-    u->eval_fuse = !training && !no_fuse && dt == EEGLDM_BF16; u->fused_used = false; u->fuse_used = 0;
+    u->eval_fuse = !training && !no_fuse && dt == EEGLDM_BF16; u->fused_used = false; u->fuse_used = 0; u->part_reg.clear();
     if (u->eval_fuse) {
       // slots: B * L_out / 16 * cout / 4 per ResBlock; an upper bound from the widest / longest block keeps this simple
       size_t nres = 0; int cmax = 0;
@@ -285,7 +284,7 @@ extern "C" int eegldm_unet_forward(eegldm_unet* u, const float* x, const int64_t
       for (auto& b : u->in_blocks) count(b);
       count(u->mid);
       for (auto& b : u->out_blocks) count(b);
-      const size_t need = nres * (size_t)B * (L / 16 + 1) * (cmax / 4);
+      const size_t need = 2 * nres * (size_t)B * (L / 16 + 1) * (cmax / 4);      // a ResBlock uses two areas (conv1's output, its own output)
       if (need > (size_t)4 << 20) u->eval_fuse = false;               // few-row launches only (32 MB of slots at most)
       else if (u->fuse_cap < need) {
         HIP_TRY(hipStreamSynchronize(ctx->stream));
