@@ -112,3 +112,47 @@ def test_eval_forward_with_fused_groupnorm_matches_train_mode_forward():
     with pytest.raises(RuntimeError):
         net.backward(torch.zeros(3, 1, 768))
     net.train(); net(x, timesteps=t); net.zero_grad(); net.backward(torch.zeros(3, 1, 768))       # a train-mode forward restores the tape
+
+
+DDIM_SCRIPT = r'''
+import sys, numpy as np, torch
+sys.path.insert(0, %r)
+import eegldm
+from eegldm.models import UNetModel, AutoencoderKL
+from eegldm.training import randn
+from eegldm.sampling import ddim_sample, make_sampling_scheduler
+dt = sys.argv[2]
+ctx = eegldm.default_context(0)
+torch.manual_seed(0)      # the module's default init draws from torch's global generator: same weights in every process
+u = UNetModel(image_size=768, in_channels=1, out_channels=1, model_channels=128, num_res_blocks=2, attention_resolutions=[8, 4], channel_mult=[1, 2, 4],
+              resblock_updown=True, dtype=dt)
+g = torch.Generator().manual_seed(42); sd = u.state_dict()
+u.load_state_dict({k: (torch.randn(v.shape, generator=g) * 0.02 if float(v.abs().sum()) == 0.0 else v) for k, v in sd.items()})
+ae = AutoencoderKL(spatial_dims=1, in_channels=1, out_channels=1, num_channels=[32, 32, 64], latent_channels=1, num_res_blocks=2, norm_num_groups=1,
+                   attention_levels=[False] * 3, dtype=dt)
+x, z = ddim_sample(u, ae, make_sampling_scheduler(50), randn(ctx, (2, 1, 768), seed=4242))
+np.savez(sys.argv[1], x=x.float().cpu().numpy(), z=z.float().cpu().numpy())
+''' % ROOT
+
+
+def test_ddim50_of_two_windows_few_row_chain_against_general_kernels_and_fp32(tmp_path):
+    """The whole one-window chain (few-row convs, GroupNorm folded into them, per-run embedding table, caller-stream launches) over a full
+    DDIM-50 run + decode: 50 UNet forwards feed each other, so this is where a small systematic error of the fused forward would grow.
+    Same seeded weights and noise in three processes: fp32 engine, bf16 with the few-row chain (default), bf16 with every few-row switch off.
+    Measured (tools/debug/ddim_ab.py): final latents few-row vs general 5.0e-4, both 8e-4 from the fp32 engine."""
+    off = {"EEGLDM_NO_CONV_SKINNY": "1", "EEGLDM_NO_EVAL_GN_FUSE": "1", "EEGLDM_SAMPLE_NO_EMB_TABLE": "1", "EEGLDM_GN_NO_FEW_SLAB_NARROW": "1",
+           "EEGLDM_SAMPLE_OWN_STREAM": "1"}
+    z, x = {}, {}
+    for name, env_extra, dt in [("fp32", {}, "float32"), ("few_row", {}, "bfloat16"), ("general", off, "bfloat16")]:
+        out = tmp_path / (name + ".npz")
+        env = dict(os.environ); env.update(env_extra)
+        r = subprocess.run([sys.executable, "-c", DDIM_SCRIPT, str(out), dt], env=env, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, (name, r.stderr[-3000:])
+        d = np.load(out)
+        assert np.isfinite(d["x"]).all() and np.isfinite(d["z"]).all(), name
+        z[name] = d["z"]; x[name] = d["x"]
+    rel = lambda a, b: float(np.linalg.norm(a - b) / (np.linalg.norm(b) + 1e-12))
+    print(f"DDIM-50 final latents: few-row vs general {rel(z['few_row'], z['general']):.2e}, few-row vs fp32 {rel(z['few_row'], z['fp32']):.2e}, "
+          f"general vs fp32 {rel(z['general'], z['fp32']):.2e}; decoded windows few-row vs general {rel(x['few_row'], x['general']):.2e}")
+    assert rel(z["few_row"], z["general"]) < 5e-3 and rel(z["few_row"], z["fp32"]) < 5e-3 and rel(z["general"], z["fp32"]) < 5e-3
+    assert rel(x["few_row"], x["general"]) < 2e-2
