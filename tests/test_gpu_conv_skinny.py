@@ -83,21 +83,22 @@ def test_small_shape_primitives_still_pass_on_the_general_kernel():
     assert r.returncode == 0, (r.stdout[-3000:], r.stderr[-2000:])
 
 
-def test_eval_forward_with_fused_groupnorm_matches_train_mode_forward():
+@pytest.mark.parametrize("L,batches", [(768, (1, 2, 3)), (3072, (1,))])      # latent model; pixel-space model (192 statistics slots per group: the loop path)
+def test_eval_forward_with_fused_groupnorm_matches_train_mode_forward(L, batches):
     """Eval-mode forward of a few windows (NetBase::eval_fuse, net.hip): conv1 of every ResBlock leaves the statistics of its output and
     conv2 applies GroupNorm + SiLU on its operand load, so 22 GroupNorm launches per forward disappear.  The train-mode forward of the
     same network runs the stand-alone GroupNorm kernels: both must agree to bf16 rounding, and the eval forward must refuse a backward."""
     import torch
     from eegldm.models import UNetModel
-    cfg = dict(image_size=768, in_channels=1, out_channels=1, model_channels=128, num_res_blocks=2, attention_resolutions=[8, 4],
+    cfg = dict(image_size=L, in_channels=1, out_channels=1, model_channels=128, num_res_blocks=2, attention_resolutions=[8, 4],
                channel_mult=[1, 2, 4], resblock_updown=True)
     net = UNetModel(**cfg, dtype="bfloat16")
     g = torch.Generator().manual_seed(0); sd = net.state_dict()
     net.load_state_dict({k: (torch.randn(v.shape, generator=g) * 0.02 if float(v.abs().sum()) == 0 else v.cpu()) for k, v in sd.items()})
     w = {k: v.cpu() for k, v in net.state_dict().items()}
     nf = UNetModel(**cfg, dtype="float32"); nf.load_state_dict(w); nf.eval()
-    for B in (1, 2, 3):
-        x = torch.randn(B, 1, 768, generator=g); t = torch.randint(0, 1000, (B,), generator=g)
+    for B in batches:
+        x = torch.randn(B, 1, L, generator=g); t = torch.randint(0, 1000, (B,), generator=g)
         yf = nf(x, timesteps=t).float().cpu().clone()                     # fp32 engine: the common yardstick
         net.train(); yt = net(x, timesteps=t).float().cpu().clone()
         net.eval(); ye = net(x, timesteps=t).float().cpu().clone()
@@ -110,8 +111,8 @@ def test_eval_forward_with_fused_groupnorm_matches_train_mode_forward():
         ye2 = net(x, timesteps=t).float().cpu()
         assert torch.equal(ye, ye2), "eval forward not reproducible"     # fp64 atomics of ~12 partials per group: order-independent to fp32
     with pytest.raises(RuntimeError):
-        net.backward(torch.zeros(3, 1, 768))
-    net.train(); net(x, timesteps=t); net.zero_grad(); net.backward(torch.zeros(3, 1, 768))       # a train-mode forward restores the tape
+        net.backward(torch.zeros(x.shape[0], 1, L))
+    net.train(); net(x, timesteps=t); net.zero_grad(); net.backward(torch.zeros(x.shape[0], 1, L))       # a train-mode forward restores the tape
 
 
 DDIM_SCRIPT = r'''
