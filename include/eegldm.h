@@ -35,7 +35,7 @@ extern "C" {
 #endif
 
 /* 4: + eegldm_ctx_stream, eegldm_linear_bwd, eegldm_disc_feature, eegldm_usleep_*, eegldm_feature_moments (additive). */
-#define EEGLDM_ABI_VERSION 4
+#define EEGLDM_ABI_VERSION 5
 
 enum { EEGLDM_F32 = 0, EEGLDM_BF16 = 1 };
 enum {
@@ -80,6 +80,15 @@ int eegldm_prof_summary(eegldm_ctx* ctx, int kernel_class, double* flops_host, d
 int eegldm_prof_bracket_overhead_ms(eegldm_ctx* ctx, double* ms_host);
 /* developer aid: CSV of every profiled launch (class,M,N,K,taps,splitk,ms,gflop) */
 int eegldm_prof_dump(eegldm_ctx* ctx, const char* path_host);
+/* Developer switches (EEGLDM_* environment variables, README "Developer switches") are cached on first use;
+ * eegldm_debug_reload_env() makes every one of them be read again on its next use (returns the new epoch).  Tests use it to
+ * A/B an execution path against its predecessor inside one process.  Models / contexts created BEFORE the call keep whatever
+ * they built from the old values (weight copies, streams).  No reference counterpart. */
+int eegldm_debug_reload_env(void);
+/* 1 when EEGLDM_DETERMINISTIC=1 is in effect: every cross-workgroup fp32 sum of the training paths (split-K weight
+ * gradients, bias / GroupNorm / BatchNorm parameter gradients, loss scalars) is formed from written partials folded in a
+ * fixed order instead of fp32 atomics, so a run is bit-reproducible.  Slower (a few %); meant for parity regressions. */
+int eegldm_deterministic(void);
 
 /* ------------------------------------------------------------------ layout / packing */
 int eegldm_ncl_to_nlc(eegldm_ctx*, const float* src_ncl, void* dst_nlc, long ld_dst, int B, int C, int L, int dst_dtype);

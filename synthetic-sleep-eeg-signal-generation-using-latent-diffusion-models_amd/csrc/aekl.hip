@@ -192,7 +192,7 @@ struct eegldm_aekl : SeqNet {
 namespace {
 // ---- thin whole-network path: compile enc / heads / dec into micro-ops over four LDS tensors (aekl_thin.h)
 bool thin_eligible(const eegldm_aekl* a, int L) {
-  static const bool off = getenv("EEGLDM_AEKL_NO_THIN") != nullptr;
+  EEG_ENV_VAR(bool, off, getenv("EEGLDM_AEKL_NO_THIN") != nullptr);
   const eegldm_aekl_cfg& c = a->cfg;
   auto ok_c = [](int v) { return v == 1 || v == 2 || v == 4; };           // the kernels are specialised on channel counts of 1, 2 and 4
   if (off || c.norm_num_groups != 1 || !ok_c(c.in_channels) || !ok_c(c.out_channels) || !ok_c(c.latent_channels)) return false;
@@ -758,7 +758,7 @@ extern "C" int eegldm_aekl_train_step(eegldm_aekl* a, eegldm_disc* d, const floa
   // fake-sample loss (:225).  Between the two only the GENERATOR's parameters change, so activations and logits are identical:
   // the second forward is replaced by a second backward over the kept tape (other dlogits, this time into D's gradients) plus the
   // repeat of the BatchNorm running-statistics update that a second forward would have made (same batch statistics).
-  static const bool refwd = getenv("EEGLDM_AEKL_REFORWARD_D") != nullptr;       // developer switch: the literal three-forward sequence
+  EEG_ENV_VAR(bool, refwd, getenv("EEGLDM_AEKL_REFORWARD_D") != nullptr);       // developer switch: the literal three-forward sequence
   EEG_TRY(disc_backward_impl(d, dlogits, dxd, 0, !refwd));
   EEG_TRY(eegldm_axpy(ctx, drecon, dxd, 1.0f, n));
   EEG_TRY(eegldm_aekl_backward(a, drecon, kl_weight, nullptr));

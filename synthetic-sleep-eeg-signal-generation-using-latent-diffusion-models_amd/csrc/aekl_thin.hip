@@ -658,7 +658,7 @@ size_t lds_bytes(const ThinProgram& p) {
 }
 // backward kernel: up to two spare LDS tensors behind everything else for the tape prefetch (as many as the 160 KB allow)
 size_t lds_bytes_bwd(const ThinProgram& p, int* sp_off, int* nspare) {
-  static const bool off = getenv("EEGLDM_THIN_NO_DMA_PREFETCH") != nullptr;
+  EEG_ENV_VAR(bool, off, getenv("EEGLDM_THIN_NO_DMA_PREFETCH") != nullptr);
   const size_t base = (lds_bytes(p) + 15) & ~(size_t)15, one = sizeof(float) * ((size_t)p.maxt + 256);
   int n = off ? 0 : 2;
   while (n > 0 && base + n * one > 160 * 1024) n--;
@@ -669,7 +669,7 @@ size_t lds_bytes_bwd(const ThinProgram& p, int* sp_off, int* nspare) {
 
 // developer aid (EEGLDM_THIN_PROF=1): per-op shader cycles of workgroup 0, summed per op kind, printed after every launch
 static unsigned long long* prof_buf() {
-  static const bool on = getenv("EEGLDM_THIN_PROF") != nullptr;
+  EEG_ENV_VAR(bool, on, getenv("EEGLDM_THIN_PROF") != nullptr);
   static unsigned long long* buf = nullptr;
   if (on && !buf) (void)hipMalloc(&buf, 8 * 1024);
   return on ? buf : nullptr;

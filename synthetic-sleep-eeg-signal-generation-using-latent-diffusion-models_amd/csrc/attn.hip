@@ -502,9 +502,9 @@ int launch_chain_q(eegldm_ctx* ctx, const ChainArgs& a, int B) {
   static bool attr = false;
   if (!attr && LDS > 48 * 1024) { HIP_TRY(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS)); attr = true; }
   ChainArgs ax = a;
-  static const bool no_xcd = getenv("EEGLDM_ATTN_NO_XCD") != nullptr;
+  EEG_ENV_VAR(bool, no_xcd, getenv("EEGLDM_ATTN_NO_XCD") != nullptr);
   ax.xcd = (!no_xcd && T / QR > 1 && B % 8 == 0) ? 1 : 0;
-  static const bool stamps = getenv("EEGLDM_ATTN_STAMPS") != nullptr;
+  EEG_ENV_VAR(bool, stamps, getenv("EEGLDM_ATTN_STAMPS") != nullptr);
   static unsigned long long* sbuf = nullptr;
   if (stamps && !sbuf) HIP_TRY(hipMalloc(&sbuf, 64));
   ax.stamps = stamps ? sbuf : nullptr;
@@ -519,7 +519,7 @@ int launch_chain_q(eegldm_ctx* ctx, const ChainArgs& a, int B) {
 template <int NJ, int MODE>
 int launch_chain(eegldm_ctx* ctx, const ChainArgs& a, int B) {
   // whole-sample blocks (12 waves at T = 192) when the batch alone fills the chip; 64-row blocks otherwise (more blocks)
-  static const bool no_whole = getenv("EEGLDM_ATTN_NO_WHOLE") != nullptr;
+  EEG_ENV_VAR(bool, no_whole, getenv("EEGLDM_ATTN_NO_WHOLE") != nullptr);
   if constexpr (NJ == 3) { if (!no_whole && B >= ctx->num_cu / 2) return launch_chain_q<NJ, MODE, NJ>(ctx, a, B); }
   return launch_chain_q<NJ, MODE, 1>(ctx, a, B);
 }
@@ -527,8 +527,8 @@ int launch_chain(eegldm_ctx* ctx, const ChainArgs& a, int B) {
 }  // namespace
 
 bool attn_chain_ok(int dtype, int T, int C, long ldq, long ldo) {
-  static const bool off = getenv("EEGLDM_NO_FUSED_ATTENTION") != nullptr;
-  static const bool no_long = getenv("EEGLDM_ATTN_NO_LONG") != nullptr;      // T = 768 back to the GEMM + softmax composition
+  EEG_ENV_VAR(bool, off, getenv("EEGLDM_NO_FUSED_ATTENTION") != nullptr);
+  EEG_ENV_VAR(bool, no_long, getenv("EEGLDM_ATTN_NO_LONG") != nullptr);      // T = 768 back to the GEMM + softmax composition
   return !off && dtype == EEGLDM_BF16 && (T == 64 || T == 128 || T == 192 || T == 256 || (T == 768 && !no_long && (C == 256 || C == 512))) && C % 256 == 0 && ldq % 8 == 0 && ldo % 8 == 0;
 }
 
@@ -549,7 +549,7 @@ int attn_chain_fwd(eegldm_ctx* ctx, const void* qkv, long ldq, void* out, long l
 // backward part: dS (scaled) written, dq = dS k
 // whole-sample blocks (T = 192, batch >= half the CUs): the backward kernel can also produce dK
 bool attn_chain_bwd_fuses_kv(eegldm_ctx* ctx, int B, int T) {
-  static const bool off = getenv("EEGLDM_ATTN_NO_FUSED_KV") != nullptr, no_whole = getenv("EEGLDM_ATTN_NO_WHOLE") != nullptr;
+  EEG_ENV_VAR(bool, off, getenv("EEGLDM_ATTN_NO_FUSED_KV") != nullptr); EEG_ENV_VAR(bool, no_whole, getenv("EEGLDM_ATTN_NO_WHOLE") != nullptr);
   return !off && !no_whole && T == 192 && B >= ctx->num_cu / 2;
 }
 int attn_chain_bwd(eegldm_ctx* ctx, const void* qkv, long ldq, const void* probs, const void* dout, long lddo, void* dq, long lddq,

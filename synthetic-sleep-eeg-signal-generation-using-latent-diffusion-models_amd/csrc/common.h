@@ -33,6 +33,19 @@ void eegldm_set_error(const std::string& msg);
 #define EEG_TRY(expr) do { int _r = (expr); if (_r != 0) return _r; } while (0)
 #define LAUNCH_CHECK() HIP_TRY(hipGetLastError())
 
+// ---------------------------------------------------------------- developer switches (environment variables)
+// Every EEGLDM_* switch is cached in a function-local static and re-read only when eegldm_debug_reload_env() has bumped the epoch:
+// production pays one integer compare per use, tests A/B a fast path against its predecessor inside ONE process
+// (os.environ[...] = ...; lib.eegldm_debug_reload_env()) instead of spawning an interpreter per switch.
+extern int g_eeg_env_epoch;
+#define EEG_ENV_VAR(T, name, ...)                                                                       \
+  static T name;                                                                                        \
+  do { static int _ep_##name = -1;                                                                      \
+       if (_ep_##name != g_eeg_env_epoch) { name = (__VA_ARGS__); _ep_##name = g_eeg_env_epoch; } } while (0)
+// EEGLDM_DETERMINISTIC=1: every cross-block fp32 sum of the training paths goes through written partials + a fixed-order fold
+// (no fp32 atomics whose arrival order could change a rounding): results are bit-identical run to run and box to box.
+bool eeg_deterministic();
+
 // ---------------------------------------------------------------- context
 struct WgradRec;      // one deferred weight-gradient problem (defined below, after GemmArgs)
 struct GemmGroup;

@@ -277,12 +277,12 @@ void sk_launch(eegldm_ctx* ctx, const SkArgs& a, int rf, int cf) {
 }  // namespace
 
 static long sk_max_tiles() {
-  static const long v = getenv("EEGLDM_CONV_SKINNY_MAX_TILES") ? atol(getenv("EEGLDM_CONV_SKINNY_MAX_TILES")) : 32;
+  EEG_ENV_VAR(long, v, getenv("EEGLDM_CONV_SKINNY_MAX_TILES") ? atol(getenv("EEGLDM_CONV_SKINNY_MAX_TILES")) : 32);
   return v;
 }
 // shape test shared by conv_skinny_try and the callers that want to plan a fused GroupNorm around it (net.hip)
 bool conv_skinny_takes(int dtype, int Cin, int Cout, int taps, int B, int L) {
-  static const bool off = getenv("EEGLDM_NO_CONV_SKINNY") != nullptr;
+  EEG_ENV_VAR(bool, off, getenv("EEGLDM_NO_CONV_SKINNY") != nullptr);
   const long M = (long)B * L;
   if (off || dtype != EEGLDM_BF16 || (taps != 1 && taps != 3) || Cin % 32 != 0 || Cout % 4 != 0 || Cout < 16) return false;
   // only launches the general kernel cannot spread over the chip: at most `max_tiles` of its 128 x 128 tiles
@@ -311,7 +311,7 @@ int conv_skinny_ex(eegldm_ctx* ctx, int dtype, const void* x, long ldx, const vo
   a.part_out = part_out;
   if (gn) { a.gn_part = gn->part; a.gn_part_b = gn->part_b ? gn->part_b : gn->part; a.gn_nqa = gn->part_b ? gn->nqa : Cin / 4; a.gn_gamma = gn->gamma; a.gn_beta = gn->beta; a.gn_cpg = gn->cpg; a.gn_eps = gn->eps; a.gn_silu = gn->silu; }
   // widest register tile that still gives every CU most of a block (fewer re-reads of the operands through L2)
-  static const int force = getenv("EEGLDM_CONV_SKINNY_TILE") ? atoi(getenv("EEGLDM_CONV_SKINNY_TILE")) : 0;   // 11 / 21 / 22
+  EEG_ENV_VAR(int, force, getenv("EEGLDM_CONV_SKINNY_TILE") ? atoi(getenv("EEGLDM_CONV_SKINNY_TILE")) : 0);   // 11 / 21 / 22
   const long want = ctx->num_cu * 3 / 4;
   int rf = 1, cf = 1;
   if (((M + 31) / 32) * ((Cout + 31) / 32) >= want) { rf = 2; cf = 2; }

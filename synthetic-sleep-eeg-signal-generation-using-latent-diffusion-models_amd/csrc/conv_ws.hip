@@ -214,23 +214,23 @@ __global__ __launch_bounds__(256, 2) void conv3_ws_kernel(const WsArgs p) {
 // general kernel), < 0 on error.  transposed != 0: the data gradient -- X = dY, W(t, n, k) = w[2 - t][k][n] (w packed [tap][Cout][Cin]).
 int conv_ws_try(eegldm_ctx* ctx, int dtype, const void* x, long ldx, const void* w, int Cin, int Cout, int transposed, const float* bias,
                 const float* rowvec, long ld_rowvec, const void* resid, long ldr, void* y, long ldy, int B, int L) {
-  static const bool off = getenv("EEGLDM_NO_CONV_WS") != nullptr;
+  EEG_ENV_VAR(bool, off, getenv("EEGLDM_NO_CONV_WS") != nullptr);
   const int Kred = transposed ? Cout : Cin, N = transposed ? Cin : Cout;
   const long M = (long)B * L;
   if (off || dtype != EEGLDM_BF16 || Kred != 128 || N % 128 != 0 || L % WS_ROWS != 0 || M >= (1L << 31)) return 0;
   if (ldx % 8 != 0 || ldy % 8 != 0 || (resid && ldr % 4 != 0) || (rowvec && ld_rowvec % 4 != 0)) return 0;
   if (((size_t)x | (size_t)y | (size_t)w) % 16 != 0 || (resid && (size_t)resid % 8 != 0)) return 0;
-  static const long min_rows = getenv("EEGLDM_CONV_WS_MIN_ROWS") ? atol(getenv("EEGLDM_CONV_WS_MIN_ROWS")) : 16384;
+  EEG_ENV_VAR(long, min_rows, getenv("EEGLDM_CONV_WS_MIN_ROWS") ? atol(getenv("EEGLDM_CONV_WS_MIN_ROWS")) : 16384);
   if (M < min_rows) return 0;                      // few tiles per block: the weight fetch is not amortised
   WsArgs a = {};
   a.x = (const bf16_t*)x; a.ldx = ldx; a.w = (const bf16_t*)w;
   if (!transposed) { a.sWt = (long)Cout * Cin; a.sWn = Cin; a.sWk = 1; a.tflip = 0; }
   else { a.sWt = (long)Cout * Cin; a.sWn = 1; a.sWk = Cin; a.tflip = 1; }
   a.bias = bias; a.rowvec = rowvec; a.ld_rowvec = ld_rowvec; a.resid = (const bf16_t*)resid; a.ldr = ldr;
-  static const int dbg = getenv("EEGLDM_CONV_WS_DBG") ? atoi(getenv("EEGLDM_CONV_WS_DBG")) : 0;
+  EEG_ENV_VAR(int, dbg, getenv("EEGLDM_CONV_WS_DBG") ? atoi(getenv("EEGLDM_CONV_WS_DBG")) : 0);
   a.dbg = dbg;
   a.y = (bf16_t*)y; a.ldy = ldy; a.M = (int)M; a.L = L; a.N = N; a.ntiles = (int)(M / WS_ROWS); a.zero_page = ctx->zero_page;
-  static const int bpc = getenv("EEGLDM_CONV_WS_BLOCKS_PER_CU") ? atoi(getenv("EEGLDM_CONV_WS_BLOCKS_PER_CU")) : 2;
+  EEG_ENV_VAR(int, bpc, getenv("EEGLDM_CONV_WS_BLOCKS_PER_CU") ? atoi(getenv("EEGLDM_CONV_WS_BLOCKS_PER_CU")) : 2);
   const int ny = N / 128;
   long nbx = (long)ctx->num_cu * bpc / ny; if (nbx < 1) nbx = 1; if (nbx > a.ntiles) nbx = a.ntiles;
   a.tiles_per_block = (int)((a.ntiles + nbx - 1) / nbx);

@@ -429,7 +429,7 @@ int ew_fold_partials(eegldm_ctx* ctx, const float* parts, int nparts, int n, flo
   LAUNCH_CHECK(); return 0;
 }
 int ew_softmax(eegldm_ctx* ctx, const float* S, void* P, long rows, int n, int dtype) {
-  static const bool no_reg = getenv("EEGLDM_SOFTMAX_NO_REG") != nullptr;
+  EEG_ENV_VAR(bool, no_reg, getenv("EEGLDM_SOFTMAX_NO_REG") != nullptr);
   if (!no_reg && n % 4 == 0 && n >= 4 && n <= 1024) {
     const dim3 g((unsigned)((rows + 3) / 4));
 #define SMX(K_) DISPATCH_T(dtype, hipLaunchKernelGGL((softmax_reg_kernel<T, K_>), g, dim3(NT), 0, ctx->stream, S, (T*)P, rows, n))
@@ -441,7 +441,7 @@ int ew_softmax(eegldm_ctx* ctx, const float* S, void* P, long rows, int n, int d
   LAUNCH_CHECK(); return 0;
 }
 int ew_softmax_bwd(eegldm_ctx* ctx, const float* dP, const void* P, void* dS, long rows, int n, float alpha, int dtype) {
-  static const bool no_reg = getenv("EEGLDM_SOFTMAX_NO_REG") != nullptr;
+  EEG_ENV_VAR(bool, no_reg, getenv("EEGLDM_SOFTMAX_NO_REG") != nullptr);
   if (!no_reg && n % 4 == 0 && n >= 4 && n <= 1024) {
     const dim3 g((unsigned)((rows + 3) / 4));
 #define SMB(K_) DISPATCH_T(dtype, hipLaunchKernelGGL((softmax_bwd_reg_kernel<T, K_>), g, dim3(NT), 0, ctx->stream, dP, (const T*)P, (T*)dS, rows, n, alpha))

@@ -970,7 +970,7 @@ int launch_k(eegldm_ctx* ctx, const GemmArgs& a_in) {
   a.xcd_swizzle = 0;
   if (a_in.xcd_swizzle) {
     if (AMODE == GA_TR && a.splitk > 1) {
-      static const bool no_any = getenv("EEGLDM_GEMM_NO_SPLITK_SWIZZLE_ANY") != nullptr;
+      EEG_ENV_VAR(bool, no_any, getenv("EEGLDM_GEMM_NO_SPLITK_SWIZZLE_ANY") != nullptr);
       if ((a.batch == 1 || a.ngroup) && a.k_skew == 0.f && !no_any && (long)grid.x * grid.y * a.ztaps > 1) a.xcd_swizzle = 3;   // (also wgrad-by-tap: ztaps = 3; grouped problems)
       else if (a.batch * a.ztaps == 1 && grid.x * grid.y > 1) {
         if (a.k_skew == 0.f && !no_any) a.xcd_swizzle = 3;          // equal chunks: contiguous runs, any split count
@@ -980,7 +980,7 @@ int launch_k(eegldm_ctx* ctx, const GemmArgs& a_in) {
     else if (grid.x > 1 && grid.y % 8 == 0) a.xcd_swizzle = 1;
   }
 #ifdef EEG_STAGE_TIMING
-  static const int lds_pad = getenv("EEGLDM_GEMM_LDS_PAD") ? atoi(getenv("EEGLDM_GEMM_LDS_PAD")) : 0;   // occupancy experiments
+  EEG_ENV_VAR(int, lds_pad, getenv("EEGLDM_GEMM_LDS_PAD") ? atoi(getenv("EEGLDM_GEMM_LDS_PAD")) : 0);   // occupancy experiments
   if (lds_pad) {
     HIP_TRY(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_TOTAL + lds_pad));
     hipLaunchKernelGGL(kern, grid, dim3(C::NTHREADS), C::LDS_TOTAL + lds_pad, ctx->stream, a);
@@ -1002,13 +1002,13 @@ int launch_t(eegldm_ctx* ctx, const GemmArgs& a) {
   }
   if constexpr (AMODE == GA_PLAIN && (WMT == 2 || WMT == 3)) {
     // 1x1 conv / Linear / attention products: same double-buffered DMA ring (K % KSTAGE == 0 on all production shapes)
-    static const bool no_dma1 = getenv("EEGLDM_GEMM1_NO_DMA") != nullptr;
+    EEG_ENV_VAR(bool, no_dma1, getenv("EEGLDM_GEMM1_NO_DMA") != nullptr);
     if (!no_dma1 && a.K % KSTAGE == 0 && a.splitk == 1) return launch_k<T, AMODE, BMODE, TAPS, KSUB, BN, STRIDE, WMT, true>(ctx, a);
   }
   if constexpr (AMODE == GA_TR && BMODE == GB_TR && (WMT == 2 || WMT == 3)) {
     // weight gradients (fused 3-tap and 1-tap / Linear): every split is a whole number of stages when K is, and the source
     // of a chunk moves by a constant per stage unless the K index is remapped per tap (conv_map: unfused strided wgrad)
-    static const bool no_dma = getenv("EEGLDM_WGRAD_NO_DMA") != nullptr;
+    EEG_ENV_VAR(bool, no_dma, getenv("EEGLDM_WGRAD_NO_DMA") != nullptr);
     if (!no_dma && a.K % KSTAGE == 0 && !a.conv_map) return launch_k<T, AMODE, BMODE, TAPS, KSUB, BN, STRIDE, WMT, true>(ctx, a);
   }
   return launch_k<T, AMODE, BMODE, TAPS, KSUB, BN, STRIDE, WMT, false>(ctx, a);
@@ -1018,11 +1018,11 @@ int launch_t(eegldm_ctx* ctx, const GemmArgs& a) {
 // at 2 blocks per CU on the UNet's shapes (profiles/r01_gemm_tile_sweep.txt), so it is opt-in (EEGLDM_GEMM_BIG_TILES=1).
 template <typename T, int AMODE, int BMODE, int TAPS, int KSUB, int STRIDE>
 int launch_bn(eegldm_ctx* ctx, const GemmArgs& a) {
-  static const bool big_ok = getenv("EEGLDM_GEMM_BIG_TILES") != nullptr;
+  EEG_ENV_VAR(bool, big_ok, getenv("EEGLDM_GEMM_BIG_TILES") != nullptr);
   const bool big = big_ok && a.M >= 256 && !(AMODE == GA_CONV && STRIDE == 2);
   if constexpr (AMODE == GA_CONV && TAPS == 3 && STRIDE == 1 && sizeof(T) == 2) {
     // 192-row tiles (two waves x six fragments along M) for the bf16 3-tap kernels
-    static const int t192 = getenv("EEGLDM_GEMM_TILE192") ? atoi(getenv("EEGLDM_GEMM_TILE192")) : 0;   // opt-in: no gain at step level
+    EEG_ENV_VAR(int, t192, getenv("EEGLDM_GEMM_TILE192") ? atoi(getenv("EEGLDM_GEMM_TILE192")) : 0);   // opt-in: no gain at step level
     // measured (tools/debug/gemm_bench.py): wins for the forward (NT) kernels from K = 512 up (+5..8 %), loses on short K loops
     // (the 192-row epilogue / prologue weigh more) and on the transposed-weight dgrad (register spills)
     if (t192 && BMODE == GB_NT && a.N > 64 && a.M >= 192 && a.K >= 512 * t192 && a.K % 32 == 0 && a.splitk == 1) return launch_t<T, AMODE, BMODE, TAPS, KSUB, 128, STRIDE, 3>(ctx, a);
@@ -1058,9 +1058,9 @@ int launch_modes(eegldm_ctx* ctx, const GemmArgs& a) {
   // products at T = 192 additionally stop computing half-empty tiles (one sample = 1.5 tiles of 128 rows; 64-wide N tiles for
   // the 192-wide QK^T output)
   if constexpr (sizeof(T) == 2) {
-    static const bool no192 = getenv("EEGLDM_GEMM_NO_ATTN192") != nullptr;
-    static const int all192 = getenv("EEGLDM_GEMM1_TILE192") ? atoi(getenv("EEGLDM_GEMM1_TILE192")) : 1;   // 1-tap kernels: +2..8 % on every UNet shape
-    static const bool attn192_all = getenv("EEGLDM_GEMM_NO_ATTN192_ALL") == nullptr;   // also when 128 divides M (T = 384 / 768, pixel-space model): +0.7 % of that step
+    EEG_ENV_VAR(bool, no192, getenv("EEGLDM_GEMM_NO_ATTN192") != nullptr);
+    EEG_ENV_VAR(int, all192, getenv("EEGLDM_GEMM1_TILE192") ? atoi(getenv("EEGLDM_GEMM1_TILE192")) : 1);   // 1-tap kernels: +2..8 % on every UNet shape
+    EEG_ENV_VAR(bool, attn192_all, getenv("EEGLDM_GEMM_NO_ATTN192_ALL") == nullptr);   // also when 128 divides M (T = 384 / 768, pixel-space model): +0.7 % of that step
     const bool attn192 = a.batch > 1 && a.M % 192 == 0 && (a.M % 128 != 0 || attn192_all);
     const bool conv192 = all192 && a.batch == 1 && a.M % 192 == 0 && a.K >= 64 * all192;
     if (!no192 && a.amode == GA_PLAIN && (attn192 || conv192) && a.splitk == 1 && a.K % 64 == 0) {
@@ -1071,13 +1071,13 @@ int launch_modes(eegldm_ctx* ctx, const GemmArgs& a) {
   if constexpr (sizeof(T) == 2) {
     // transposed-operand (TN) products whose M is a multiple of 192 but not of 128: the attention dK / dV gradients (192-row
     // samples, batched) stop computing a half-empty second 128-row tile; 1-tap weight gradients with 192 k output channels
-    static const bool no_tn192 = getenv("EEGLDM_GEMM_NO_TN192") != nullptr;
-    static const bool tn192_all = getenv("EEGLDM_GEMM_TN192_ALL") != nullptr;   // experiment: also when 128 divides M
-    static const bool tn192_batched = getenv("EEGLDM_GEMM_TN192_BATCHED") != nullptr;   // experiment: batched products (dK / dV at T = 768)
+    EEG_ENV_VAR(bool, no_tn192, getenv("EEGLDM_GEMM_NO_TN192") != nullptr);
+    EEG_ENV_VAR(bool, tn192_all, getenv("EEGLDM_GEMM_TN192_ALL") != nullptr);   // experiment: also when 128 divides M
+    EEG_ENV_VAR(bool, tn192_batched, getenv("EEGLDM_GEMM_TN192_BATCHED") != nullptr);   // experiment: batched products (dK / dV at T = 768)
     if (!no_tn192 && a.amode == GA_TR && a.bmode == GB_TR && a.taps == 1 && !a.conv_map && a.M % 192 == 0 && (a.M % 128 != 0 || tn192_all || (a.batch > 1 && tn192_batched)) && a.K % 64 == 0 && a.N % 64 == 0)
       return (a.N % 128 == 0) ? launch_t<T, GA_TR, GB_TR, 1, 2, 128, 1, 3>(ctx, a) : launch_t<T, GA_TR, GB_TR, 1, 2, 64, 1, 3>(ctx, a);
   }
-  static const bool deep1 = getenv("EEGLDM_GEMM1_DEEP") != nullptr;   // short stages, 4-deep DMA ring (see Cfg::NSTG)
+  EEG_ENV_VAR(bool, deep1, getenv("EEGLDM_GEMM1_DEEP") != nullptr);   // short stages, 4-deep DMA ring (see Cfg::NSTG)
   if (deep1 && a.amode == GA_PLAIN && a.splitk == 1 && a.K % Tr<T>::KC == 0) {
     if (a.bmode == GB_NT) return launch_bn<T, GA_PLAIN, GB_NT, 1, 1, 1>(ctx, a);
     return launch_bn<T, GA_PLAIN, GB_TR, 1, 1, 1>(ctx, a);
@@ -1184,7 +1184,7 @@ int gemm_launch_grouped(eegldm_ctx* ctx, const GemmArgs& a_in, const GemmGroup& 
   }
   a.C = ctx->splitk_ws; a.sCk = fold_n; a.sCb = (long)a.splitk * fold_n; a.atomic_out = 0; a.k_skew = 0.f;
   a.zero_page = ctx->zero_page;
-  { static const bool no_swz = getenv("EEGLDM_GEMM_NO_XCD_SWIZZLE") != nullptr; a.xcd_swizzle = no_swz ? 0 : 1; }
+  { EEG_ENV_VAR(bool, no_swz, getenv("EEGLDM_GEMM_NO_XCD_SWIZZLE") != nullptr); a.xcd_swizzle = no_swz ? 0 : 1; }
   ProfRec rec; const bool prof = ctx->prof_on;
   if (prof) {
     rec.cls = a.taps == 3 ? PROF_CONV_WGRAD : PROF_GEMM_TN;
@@ -1228,7 +1228,7 @@ int gemm_launch(eegldm_ctx* ctx, const GemmArgs& a_in) {
   // LDS epilogue) and folded into dW afterwards, instead of draining millions of fp32 atomics at ~370 G/s
   // (profiles/r01_gemm_stage_timing.txt); the fused 3-tap kernel keeps its register atomics (three accumulator sets).
   float* fold_dst = nullptr; long fold_n = 0;
-  static const bool fused_ws = getenv("EEGLDM_GEMM_FUSED3_ATOMIC") == nullptr;   // fused 3-tap kernel: workspace partials (plain stores from the accumulators) + fold; =1 restores the register atomics
+  EEG_ENV_VAR(bool, fused_ws, getenv("EEGLDM_GEMM_FUSED3_ATOMIC") == nullptr);   // fused 3-tap kernel: workspace partials (plain stores from the accumulators) + fold; =1 restores the register atomics
   if (a.splitk > 1 && a.amode == GA_TR && a.bmode == GB_TR && (a.taps == 1 || (a.taps == 3 && a.sCt == (long)a.M * a.N && fused_ws)) && a.ztaps == 1 && a.batch == 1 && a.atomic_out && a.ldc == a.N &&
       !getenv("EEGLDM_GEMM_NO_SPLITK_WS")) {
     const size_t need = (size_t)a.splitk * a.taps * a.M * a.N * sizeof(float);
@@ -1247,7 +1247,7 @@ int gemm_launch(eegldm_ctx* ctx, const GemmArgs& a_in) {
   }
   if (a.splitk > 1 && !fold_dst) a.atomic_out = 1;
   a.zero_page = ctx->zero_page;
-  { static const bool no_swz = getenv("EEGLDM_GEMM_NO_XCD_SWIZZLE") != nullptr; a.xcd_swizzle = no_swz ? 0 : 1; }
+  { EEG_ENV_VAR(bool, no_swz, getenv("EEGLDM_GEMM_NO_XCD_SWIZZLE") != nullptr); a.xcd_swizzle = no_swz ? 0 : 1; }
   ProfRec rec; bool prof = ctx->prof_on;
   if (prof) {
     rec.cls = a.amode == GA_CONV ? (a.bmode == GB_NT ? PROF_CONV_FWD : PROF_CONV_DGRAD)
@@ -1261,7 +1261,7 @@ int gemm_launch(eegldm_ctx* ctx, const GemmArgs& a_in) {
   // skewed K chunks for the atomic split-K epilogue (see gemm_kernel); the workspace path writes plain stores and keeps equal chunks.
   // The atomics per block are constant (3 x 128 x 64), so the skew that pays shrinks with the stages per block (measured, B=256:
   // 12 or 24 stages per block -11 % at 0.5; 48 stages -3 % at 0.25; 73+ stages: any skew loses) -> (66 - stages) / 84, clamped.
-  static const float wgrad_skew = getenv("EEGLDM_WGRAD_SKEW") ? (float)atof(getenv("EEGLDM_WGRAD_SKEW")) : -1.0f;
+  EEG_ENV_VAR(float, wgrad_skew, getenv("EEGLDM_WGRAD_SKEW") ? (float)atof(getenv("EEGLDM_WGRAD_SKEW")) : -1.0f);
   a.k_skew = 0.f;
   if (a.splitk > 1 && a.amode == GA_TR && a.atomic_out && !fold_dst && wgrad_skew != 0.f) {
     const int kst = (a.dtype == EEGLDM_F32 ? 16 : 32) * 2;
@@ -1275,7 +1275,7 @@ int gemm_launch(eegldm_ctx* ctx, const GemmArgs& a_in) {
   if (a.dtype == EEGLDM_F32) rc = launch_modes<float>(ctx, a);
   else if (a.dtype == EEGLDM_BF16) rc = launch_modes<bf16_t>(ctx, a);
   else EEG_FAIL(EEGLDM_ERR_UNSUPPORTED, "dtype %d", a.dtype);
-  static const bool dbg_skip_fold = getenv("EEGLDM_DBG_SKIP_FOLDS") != nullptr;      // timing experiment only: weight gradients stay in the workspace
+  EEG_ENV_VAR(bool, dbg_skip_fold, getenv("EEGLDM_DBG_SKIP_FOLDS") != nullptr);      // timing experiment only: weight gradients stay in the workspace
   if (rc == 0 && fold_dst && !dbg_skip_fold) {
     hipLaunchKernelGGL(splitk_fold_kernel, dim3((unsigned)((fold_n / 4 + 63) / 64)), dim3(256), 0, ctx->stream, (const float*)ctx->splitk_ws, a.splitk, fold_n, fold_dst);
     LAUNCH_CHECK();

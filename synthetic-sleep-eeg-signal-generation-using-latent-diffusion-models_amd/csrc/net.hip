@@ -13,7 +13,7 @@ int NetBase::bind(float* p, float* g) {
   params = p; grads = g;
   if (dtype == EEGLDM_F32) { wT = p; owns_wT = false; }
   else if (!wT) { HIP_TRY(hipMalloc(&wT, (size_t)nparams * 2)); owns_wT = true; }
-  static const bool no_kblk = getenv("EEGLDM_NO_KBLOCKED_WEIGHTS") != nullptr;
+  EEG_ENV_VAR(bool, no_kblk, getenv("EEGLDM_NO_KBLOCKED_WEIGHTS") != nullptr);
   if (dtype != EEGLDM_F32 && !wK && !no_kblk) {
     std::vector<KbDesc> tab; long chunks = 0;
     for (const Entry& e : entries) {

@@ -709,27 +709,27 @@ template <typename T, int V>
 int gn_fwd_t(eegldm_ctx* ctx, const void* x, long ldx, const float* gamma, const float* beta, void* y, long ldy,
              float* stats, int B, int L, int C, int G, float eps, int silu, int resample, void* xr, long ldxr) {
   if constexpr (V == 4) {
-    static const bool off = getenv("EEGLDM_GN_NO_RESIDENT") != nullptr;
+    EEG_ENV_VAR(bool, off, getenv("EEGLDM_GN_NO_RESIDENT") != nullptr);
     // 12 rows per thread (56 VGPRs: two 1024-thread blocks per CU) measured faster than 24 (one block per CU): 24 vs 35 us
-    static const int fwd_rpt_max = getenv("EEGLDM_GN_FWD_RPT") ? atoi(getenv("EEGLDM_GN_FWD_RPT")) : 12;
+    EEG_ENV_VAR(int, fwd_rpt_max, getenv("EEGLDM_GN_FWD_RPT") ? atoi(getenv("EEGLDM_GN_FWD_RPT")) : 12);
     // threads per block: 1024 = one (sample, 64-channel) slab per block; 512 / 256 = narrower slabs (32 / 16 channels), 2 / 4x as many
     // independent blocks per CU whose load / reduce / store phases interleave (EEGLDM_GN_FWD_NTH; narrow slabs use the XCD-aware order)
-    static const int fwd_nth = getenv("EEGLDM_GN_FWD_NTH") ? atoi(getenv("EEGLDM_GN_FWD_NTH")) : 1024;
+    EEG_ENV_VAR(int, fwd_nth, getenv("EEGLDM_GN_FWD_NTH") ? atoi(getenv("EEGLDM_GN_FWD_NTH")) : 1024);
     int nth = (fwd_nth == 512 || fwd_nth == 256) ? fwd_nth : 1024;
     int rpt = 0; int cc = off ? 0 : resident_chunk(L, C, G, resample == 1, fwd_rpt_max, &rpt, nth);
     // a launch that leaves most of the chip idle (sampling one window per call: 1-8 slabs) is a latency chain, not a bandwidth problem:
     // 16-channel slabs on 256 threads are 4x as many, shorter blocks (DDIM-50 at B = 1: 71.5 -> 64.5 ms).  The fp64 group sums make
     // the statistics independent of the slab shape, so the outputs do not change.
-    static const bool no_few = getenv("EEGLDM_GN_NO_FEW_SLAB_NARROW") != nullptr;
+    EEG_ENV_VAR(bool, no_few, getenv("EEGLDM_GN_NO_FEW_SLAB_NARROW") != nullptr);
     if (!no_few && cc && nth == 1024 && (long)(C / cc) * B <= ctx->num_cu / 4) {
       int rpt2 = 0; const int cc2 = resident_chunk(L, C, G, resample == 1, fwd_rpt_max, &rpt2, 256);
       if (cc2 && cc2 * (int)sizeof(T) >= 32) { nth = 256; cc = cc2; rpt = rpt2; }
     }
     // measured (tools/debug/gn_bench.py): wins while the rows are at least a 128-byte line and the blocks fit two rounds
     // (1024 blocks = the 100 MB concat tensors of the up path: 47-48 us one-pass vs 51 us split)
-    static const long fwd_bpc = getenv("EEGLDM_GN_FWD_BLOCKS_PER_CU") ? atol(getenv("EEGLDM_GN_FWD_BLOCKS_PER_CU")) : 4;
-    static const bool no_xcd = getenv("EEGLDM_GN_NO_XCD") != nullptr;
-    static const int narrow_min = getenv("EEGLDM_GN_NARROW_MIN_ROW") ? atoi(getenv("EEGLDM_GN_NARROW_MIN_ROW")) : 32;    // 32-byte rows (16-channel slabs) are fine under the XCD-aware order: L = 3072 runs one-pass (pixel-space step 22.84 -> 22.64 ms); 128 = round-2 behaviour
+    EEG_ENV_VAR(long, fwd_bpc, getenv("EEGLDM_GN_FWD_BLOCKS_PER_CU") ? atol(getenv("EEGLDM_GN_FWD_BLOCKS_PER_CU")) : 4);
+    EEG_ENV_VAR(bool, no_xcd, getenv("EEGLDM_GN_NO_XCD") != nullptr);
+    EEG_ENV_VAR(int, narrow_min, getenv("EEGLDM_GN_NARROW_MIN_ROW") ? atoi(getenv("EEGLDM_GN_NARROW_MIN_ROW")) : 32);    // 32-byte rows (16-channel slabs) are fine under the XCD-aware order: L = 3072 runs one-pass (pixel-space step 22.84 -> 22.64 ms); 128 = round-2 behaviour
     const bool can_xcd = !no_xcd && B % 8 == 0;
     const int min_row = nth == 1024 ? (can_xcd ? narrow_min : 128) : 32;
     if (cc && (cc * (int)sizeof(T) < min_row || (long)(C / cc) * B > fwd_bpc * ctx->num_cu * (1024 / nth))) cc = 0;
@@ -768,11 +768,11 @@ int gn_bwd_t(eegldm_ctx* ctx, const void* x, long ldx, const float* gamma, const
   if (colsum_done) *colsum_done = 0;
   if (dxr2_done) *dxr2_done = 0;
   if (slots_deferred) *slots_deferred = 0;
-  static const bool no_dxr2 = getenv("EEGLDM_GN_NO_DXR2") != nullptr;
+  EEG_ENV_VAR(bool, no_dxr2, getenv("EEGLDM_GN_NO_DXR2") != nullptr);
   if (!dxr2_done || lddxr2 % 4 != 0 || no_dxr2) dxr2 = nullptr;      // only a caller that can fall back may hand over a second addend
   if constexpr (V == 4) {
-    static const bool off = getenv("EEGLDM_GN_NO_RESIDENT") != nullptr;
-    static const int bwd_nth = getenv("EEGLDM_GN_BWD_NTH") ? atoi(getenv("EEGLDM_GN_BWD_NTH")) : 1024;      // see gn_fwd_t
+    EEG_ENV_VAR(bool, off, getenv("EEGLDM_GN_NO_RESIDENT") != nullptr);
+    EEG_ENV_VAR(int, bwd_nth, getenv("EEGLDM_GN_BWD_NTH") ? atoi(getenv("EEGLDM_GN_BWD_NTH")) : 1024);      // see gn_fwd_t
     // 256-thread blocks (EEGLDM_GN_BWD_NTH=256) measure 42-44 vs 47-49 us on the 50 MB tensors at L <= 384 (tools/debug/gn_nth.py) and
     // are bit-exact and deterministic in isolation and beside foreign kernels (tools/debug/gn_det2.py .. gn_det4.py, gn_conc.py) -- but
     // with the fused 3-tap weight-gradient GEMM (LDS-DMA build) of a second stream co-resident on the CU, their group sums come out
@@ -785,10 +785,10 @@ int gn_bwd_t(eegldm_ctx* ctx, const void* x, long ldx, const float* gamma, const
     int rpt = 0; int cc = off ? 0 : resident_chunk(L, C, G, 0, sizeof(T) == 2 ? 12 : 8, &rpt, nth);
     // measured (tools/debug/gn_bench.py): the one-pass kernel wins while its blocks fit two rounds of one block per CU
     // (1024 blocks: 112 us one-pass vs 117-120 us split on the 100 MB tensors; 2048 blocks of 96-channel chunks lose)
-    static const long bwd_bpc = getenv("EEGLDM_GN_BWD_BLOCKS_PER_CU") ? atol(getenv("EEGLDM_GN_BWD_BLOCKS_PER_CU")) : 8;
-    static const int bwd_minrow = getenv("EEGLDM_GN_BWD_MIN_ROW_BYTES") ? atoi(getenv("EEGLDM_GN_BWD_MIN_ROW_BYTES")) : 128;
-    static const bool no_xcd = getenv("EEGLDM_GN_NO_XCD") != nullptr;
-    static const int narrow_min = getenv("EEGLDM_GN_NARROW_MIN_ROW") ? atoi(getenv("EEGLDM_GN_NARROW_MIN_ROW")) : 32;
+    EEG_ENV_VAR(long, bwd_bpc, getenv("EEGLDM_GN_BWD_BLOCKS_PER_CU") ? atol(getenv("EEGLDM_GN_BWD_BLOCKS_PER_CU")) : 8);
+    EEG_ENV_VAR(int, bwd_minrow, getenv("EEGLDM_GN_BWD_MIN_ROW_BYTES") ? atoi(getenv("EEGLDM_GN_BWD_MIN_ROW_BYTES")) : 128);
+    EEG_ENV_VAR(bool, no_xcd, getenv("EEGLDM_GN_NO_XCD") != nullptr);
+    EEG_ENV_VAR(int, narrow_min, getenv("EEGLDM_GN_NARROW_MIN_ROW") ? atoi(getenv("EEGLDM_GN_NARROW_MIN_ROW")) : 32);
     const bool can_xcd = !no_xcd && B % 8 == 0;
     const int min_row = nth == 1024 ? (can_xcd && narrow_min < bwd_minrow ? narrow_min : bwd_minrow) : 32;
     if (cc && (cc * (int)sizeof(T) < min_row || (long)(C / cc) * B > bwd_bpc * ctx->num_cu * (1024 / nth))) cc = 0;
@@ -797,12 +797,12 @@ int gn_bwd_t(eegldm_ctx* ctx, const void* x, long ldx, const float* gamma, const
       const dim3 grid((unsigned)((long)(C / cc) * B));
       // a caller that can run the 7-us fold of the dgamma / dbeta partial slots elsewhere (side stream) gets them in the second slot
       // region and calls op_gn_slot_reduce_deferred itself
-      static const bool no_defer = getenv("EEGLDM_GN_NO_DEFER") != nullptr;
+      EEG_ENV_VAR(bool, no_defer, getenv("EEGLDM_GN_NO_DEFER") != nullptr);
       const bool defer = slots_deferred && dgamma && !no_defer;
       float* slots = dgamma ? (float*)((char*)ctx->scratch + (defer ? gn_slot_region(defer_region) : GN_SLOT_OFFSET)) : nullptr;
       // batched mode (the UNet backward with grouped weight gradients): this launch gets its OWN slot region and is folded together with
       // all the others by op_gn_fold_flush -- 49 folds of 7 us become one launch
-      static const bool no_batch = getenv("EEGLDM_GN_NO_BATCHED_FOLD") != nullptr;
+      EEG_ENV_VAR(bool, no_batch, getenv("EEGLDM_GN_NO_BATCHED_FOLD") != nullptr);
       const bool batched = defer && ctx->defer_wgrad && !no_batch && C <= 1024 && ctx->gn_fold_count < GN_FOLD_MAX;
       if (batched) {
         if (!ctx->gn_slot_arena) {
@@ -816,7 +816,7 @@ int gn_bwd_t(eegldm_ctx* ctx, const void* x, long ldx, const float* gamma, const
 #define GN_BWD_RES3(R, RAW, SL, N) hipLaunchKernelGGL((gn_bwd_resident_kernel<T, R, RAW, SL, N>), grid, dim3(N), 0, ctx->stream, (const T*)x, ldx, gamma, beta, stats, \
                                          (const T*)dy, lddy, (T*)dx, lddx, (const T*)dxr, lddxr, slots, colsum_ps, ldps, L, C, G, silu, resample, cc, (const T*)dxr2, lddxr2, xcd)
 #define GN_BWD_RES2(R, RAW, SL) do { if (nth == 1024) GN_BWD_RES3(R, RAW, SL, 1024); else if (nth == 512) GN_BWD_RES3(R, RAW, SL, 512); else GN_BWD_RES3(R, RAW, SL, 256); } while (0)
-      static const bool raw0 = getenv("EEGLDM_GN_NO_RAW0") == nullptr;
+      EEG_ENV_VAR(bool, raw0, getenv("EEGLDM_GN_NO_RAW0") == nullptr);
 #define GN_BWD_RES1(R, RAW) do { if (silu) GN_BWD_RES2(R, RAW, true); else GN_BWD_RES2(R, RAW, false); } while (0)
 #define GN_BWD_RES(R) do { if (resample == 0 && raw0) GN_BWD_RES1(R, true); else GN_BWD_RES1(R, false); } while (0)
       constexpr int RLO = sizeof(T) == 2 ? 6 : 4, RHI = sizeof(T) == 2 ? 12 : 8;
@@ -1085,7 +1085,7 @@ __global__ __launch_bounds__(WIDE_NT) void gn_flat_fwd_wide_kernel(const T* __re
   }
 }
 bool gn_flat_wide_ok(int L, int C, int G, int resample, long l0, long l1) {
-  static const bool off = getenv("EEGLDM_GN_NO_FLAT") != nullptr;
+  EEG_ENV_VAR(bool, off, getenv("EEGLDM_GN_NO_FLAT") != nullptr);
   const long n = (long)L * C;
   return !off && G == 1 && resample == 0 && C >= 16 && C % 8 == 0 && (WIDE_NT * 8) % C == 0 && n % 8 == 0 &&
          n <= (long)WIDE_NT * 8 * 12 && l0 == C && l1 == C;
@@ -1100,7 +1100,7 @@ int gn_flat_fwd_wide(eegldm_ctx* ctx, const void* x, const float* gamma, const f
 }
 
 bool gn_flat_ok(int L, int C, int G, int resample, long l0, long l1, long l2, long l3) {
-  static const bool off = getenv("EEGLDM_GN_NO_FLAT") != nullptr;
+  EEG_ENV_VAR(bool, off, getenv("EEGLDM_GN_NO_FLAT") != nullptr);
   const long n = (long)L * C;
   return !off && G == 1 && resample == 0 && (C == 1 || C == 2 || C == 4 || C == 8) && n % 8 == 0 && n <= (long)FLAT_NT * 8 * 12 &&
          l0 == C && l1 == C && (l2 == 0 || l2 == C) && (l3 == 0 || l3 == C);
@@ -1245,7 +1245,7 @@ int op_gn_fold_flush(eegldm_ctx* ctx) {
 }
 
 int op_gn_slot_reduce_deferred(eegldm_ctx* ctx, float* dgamma, float* dbeta, int C, int region) {
-  static const bool dbg_skip = getenv("EEGLDM_DBG_SKIP_FOLDS") != nullptr;      // timing experiment only: leaves dgamma / dbeta unfolded
+  EEG_ENV_VAR(bool, dbg_skip, getenv("EEGLDM_DBG_SKIP_FOLDS") != nullptr);      // timing experiment only: leaves dgamma / dbeta unfolded
   if (dbg_skip) return 0;
   float* slots = (float*)((char*)ctx->scratch + gn_slot_region(region));
   hipLaunchKernelGGL(gn_slot_reduce_kernel, dim3((2 * C + 255) / 256), dim3(256), 0, ctx->stream, slots, dgamma, dbeta, C, (double*)ctx->scratch, 0);

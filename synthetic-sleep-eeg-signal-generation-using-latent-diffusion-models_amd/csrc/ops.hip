@@ -76,7 +76,7 @@ int op_conv_dgrad(eegldm_ctx* ctx, int dtype, const void* dy, long lddy, const v
 // true when op_conv_wgrad produces the bias gradient inside its weight-gradient kernel (no shared context scratch: safe on the
 // side stream): the split-K GEMM with 16-bit operands, or the tiny direct kernel of the [2,2,4] autoencoder layers
 bool op_wgrad_fuses_bias(int dtype, int Cin, int Cout) {
-  static const bool fuse_bias = getenv("EEGLDM_NO_FUSED_BIAS_GRAD") == nullptr;
+  EEG_ENV_VAR(bool, fuse_bias, getenv("EEGLDM_NO_FUSED_BIAS_GRAD") == nullptr);
   if (!fuse_bias) return false;
   if (conv_is_thin(Cin, Cout, dtype)) return dconv_wgrad_tinyv_ok(Cin, Cout, 3);
   return dtype != EEGLDM_F32;
@@ -89,7 +89,7 @@ int op_conv_wgrad(eegldm_ctx* ctx, int dtype, const void* x, long ldx, const voi
   // the tiny direct kernel from the dy rows it reads; fp32 parity mode and the other thin shapes keep the separate column-sum kernel.
   const bool thin = conv_is_thin(Cin, Cout, dtype);
   if (thin) {
-    static const bool fuse_bias = getenv("EEGLDM_NO_FUSED_BIAS_GRAD") == nullptr;
+    EEG_ENV_VAR(bool, fuse_bias, getenv("EEGLDM_NO_FUSED_BIAS_GRAD") == nullptr);
     int done = 0;
     EEG_TRY(dconv_wgrad(ctx, dtype, x, ldx, dy, lddy, dw, B, Lin, Lout, Cin, Cout, K, stride, pad_l, fuse_bias ? dbias : nullptr, &done));
     if (dbias && !done) EEG_TRY(ew_colsum(ctx, dy, lddy, nullptr, 0, dbias, B, Lout, Cout, dtype));
@@ -116,7 +116,7 @@ int op_conv_wgrad(eegldm_ctx* ctx, int dtype, const void* x, long ldx, const voi
     // opt-in experiment (EEGLDM_WGRAD_WIDE_MIN=128): the 128 x 128 x 3 tile as ONE 8-wave block per CU.  Measured (round 2, B=256):
     // 5-8 % SLOWER than two independent 128 x 64 blocks per CU although it stages a third fewer bytes -- with one barrier domain per
     // CU every wave waits at every stage, two independent blocks overlap each other's waits
-    static const int wide_min = getenv("EEGLDM_WGRAD_WIDE_MIN") ? atoi(getenv("EEGLDM_WGRAD_WIDE_MIN")) : 0;
+    EEG_ENV_VAR(int, wide_min, getenv("EEGLDM_WGRAD_WIDE_MIN") ? atoi(getenv("EEGLDM_WGRAD_WIDE_MIN")) : 0);
     if (dtype != EEGLDM_F32 && wide_min > 0 && Cin % 128 == 0 && Cout % 128 == 0 && Cin >= wide_min) { a.wide_n = 1; bn = 128; blocks_per_cu = 1; }
     tiles = (long)((Cout + 127) / 128) * ((Cin + bn - 1) / bn);
   } else {
@@ -124,9 +124,9 @@ int op_conv_wgrad(eegldm_ctx* ctx, int dtype, const void* x, long ldx, const voi
   }
   // fill the resident blocks of every CU in ONE round: rounding the split count up (11 x 48 tiles = 528 blocks on 512 slots) leaves a
   // second round of 16 blocks that costs as much as the first
-  static const bool split_ceil = getenv("EEGLDM_WGRAD_SPLIT_CEIL") != nullptr;
+  EEG_ENV_VAR(bool, split_ceil, getenv("EEGLDM_WGRAD_SPLIT_CEIL") != nullptr);
   long want = split_ceil ? ((long)ctx->num_cu * blocks_per_cu + tiles - 1) / tiles : ((long)ctx->num_cu * blocks_per_cu) / tiles;
-  static const int split_div = getenv("EEGLDM_WGRAD_SPLIT_DIV") ? atoi(getenv("EEGLDM_WGRAD_SPLIT_DIV")) : 1;   // experiment: fewer, longer splits (smaller launches that co-run with the main stream)
+  EEG_ENV_VAR(int, split_div, getenv("EEGLDM_WGRAD_SPLIT_DIV") ? atoi(getenv("EEGLDM_WGRAD_SPLIT_DIV")) : 1);   // experiment: fewer, longer splits (smaller launches that co-run with the main stream)
   if (split_div > 1 && ctx->side_on) want = (want + split_div - 1) / split_div;
   long maxs = ((long)a.K + 8 * kstage - 1) / (8 * kstage);     // at least 8 stages per split
   if (want > maxs) want = maxs;
@@ -141,7 +141,7 @@ int op_conv_wgrad(eegldm_ctx* ctx, int dtype, const void* x, long ldx, const voi
     ctx->wgrad_pending.push_back(r);
     return 0;
   }
-  { static const bool dbg_groups = getenv("EEGLDM_DBG_GROUPS") != nullptr;
+  { EEG_ENV_VAR(bool, dbg_groups, getenv("EEGLDM_DBG_GROUPS") != nullptr);
     if (dbg_groups && ctx->defer_wgrad) fprintf(stderr, "wgrad NOT deferred: K %d stride %d pads %d %d Cin %d Cout %d rows %d fused3 %d kstage %d wide %d\n", K, stride, pad_l, pad_r, Cin, Cout, a.K, (int)fused3, kstage, a.wide_n); }
   return gemm_launch(ctx, a);
 }
@@ -180,7 +180,7 @@ int op_wgrad_flush(eegldm_ctx* ctx) {
       if (cost < best) { best = cost; bs = (int)sp; }
     }
     g.splitk = bs; g.batch = g.ngroup;
-    static const bool dbg_groups = getenv("EEGLDM_DBG_GROUPS") != nullptr;
+    EEG_ENV_VAR(bool, dbg_groups, getenv("EEGLDM_DBG_GROUPS") != nullptr);
     if (dbg_groups) fprintf(stderr, "wgrad group: taps %d M %d N %d K %d x%d tiles %ld -> splitk %d\n", g.taps, g.M, g.N, g.K, g.ngroup, recs[i].tiles, bs);
     EEG_TRY(gemm_launch_grouped(ctx, g, tab, ctx->grp_slot++));
   }

@@ -84,7 +84,7 @@ extern "C" int eegldm_sample(eegldm_unet* u, eegldm_aekl* ae, const float* noise
   struct Restore { eegldm_ctx* c; hipStream_t s; ~Restore() { c->stream = s; } } restore{ctx, caller};
   // Eager launches (the default) stay on the caller's stream: a second stream is a second hardware queue, and alternating queues
   // measured +8 % on the one-window chain (47.5 vs 51.8 ms, the same as GPU_MAX_HW_QUEUES=1 gives with the own stream).
-  static const bool force_own = getenv("EEGLDM_SAMPLE_OWN_STREAM") != nullptr;
+  EEG_ENV_VAR(bool, force_own, getenv("EEGLDM_SAMPLE_OWN_STREAM") != nullptr);
   const bool own = use_graph || force_own;
   const hipStream_t run = own ? s.stream : caller;
   if (own) {
@@ -121,7 +121,7 @@ extern "C" int eegldm_sample(eegldm_unet* u, eegldm_aekl* ae, const float* noise
   // Eager path: the timesteps are known up front and shared by all samples, so the timestep-embedding MLP and the ResBlocks' embedding
   // projections run ONCE for all n_steps (one batch of n_steps rows) instead of six launches (~100 us at B = 1) inside every step;
   // each forward then reads its step's row with row stride 0.  EEGLDM_SAMPLE_NO_EMB_TABLE=1 restores the per-step computation.
-  static const bool no_table = getenv("EEGLDM_SAMPLE_NO_EMB_TABLE") != nullptr;
+  EEG_ENV_VAR(bool, no_table, getenv("EEGLDM_SAMPLE_NO_EMB_TABLE") != nullptr);
   const bool table = !graph_ok && !no_table;
   struct ClearEmb { eegldm_unet* u; ~ClearEmb() { unet_set_shared_emb(u, nullptr); } } clear_emb{u};
   const int etot = unet_emb_width(u);

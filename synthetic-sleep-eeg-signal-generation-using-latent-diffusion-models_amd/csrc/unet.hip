@@ -275,7 +275,7 @@ extern "C" int eegldm_unet_forward(eegldm_unet* u, const float* x, const int64_t
 
   // ---- eval-mode GroupNorm fusion for few-row launches (NetBase::eval_fuse): one statistics area per ResBlock
   {
-    static const bool no_fuse = getenv("EEGLDM_NO_EVAL_GN_FUSE") != nullptr;
+    EEG_ENV_VAR(bool, no_fuse, getenv("EEGLDM_NO_EVAL_GN_FUSE") != nullptr);
     u->eval_fuse = !training && !no_fuse && dt == EEGLDM_BF16; u->fused_used = false; u->fuse_used = 0; u->part_reg.clear();
     if (u->eval_fuse) {
       // slots: B * L_out / 16 * cout / 4 per ResBlock; an upper bound from the widest / longest block keeps this simple
@@ -369,7 +369,7 @@ extern "C" int eegldm_unet_backward(eegldm_unet* u, const float* dy, float* dx_o
   // Weight gradients of the GEMM-path convs are RECORDED during the backward chain and launched grouped by shape (ops.hip:
   // op_wgrad_flush) when their slice of the gradient buffer is due: at the all-reduce hook (out / output_blocks / middle_block) and
   // at the end.  EEGLDM_NO_GROUPED_WGRAD=1 restores one launch per layer on the side stream.
-  static const bool no_grouped = getenv("EEGLDM_NO_GROUPED_WGRAD") != nullptr;
+  EEG_ENV_VAR(bool, no_grouped, getenv("EEGLDM_NO_GROUPED_WGRAD") != nullptr);
   struct DeferGuard {
     eegldm_ctx* c; bool on;
     DeferGuard(eegldm_ctx* ctx_, bool on_) : c(ctx_), on(on_) { if (on) { c->defer_wgrad = true; c->grp_slot = 0; c->gn_fold_count = 0; c->gn_fold_pending.clear(); } }

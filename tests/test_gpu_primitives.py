@@ -49,7 +49,7 @@ CONV_CASES = [
 
 @pytest.mark.parametrize("dtype", [0, 1])
 @pytest.mark.parametrize("case", CONV_CASES)
-def test_conv1d_fwd_bwd(case, dtype):
+def test_conv1d_fwd_bwd(case, dtype, conv_kernel_path):
     G = _imports()
     B, L, Cin, Cout, K, stride, pl, pr = case
     x = torch.from_numpy(normal((B, Cin, L), seed=1)).requires_grad_(True)
@@ -133,7 +133,7 @@ def test_conv1d_pack_kblocked_rejects_bad_arguments():
 
 
 @pytest.mark.parametrize("dtype", [0, 1])
-def test_conv1d_epilogue_rowvec_resid(dtype):
+def test_conv1d_epilogue_rowvec_resid(dtype, conv_kernel_path):
     """bias + per-sample embedding row + residual in the GEMM epilogue; L = 192 puts a sample boundary inside a 128-row tile
     (fp32: LDS fp32 tile path; bf16: fragment-layout addends, packed-bf16 LDS transpose, prefetch under the last K stage)."""
     G = _imports()
@@ -298,7 +298,7 @@ LINEAR_CASES = [(8, 512, 128), (256, 512, 512), (256, 7168, 512), (5, 96, 40), (
 
 @pytest.mark.parametrize("dtype", [0, 1])
 @pytest.mark.parametrize("case", LINEAR_CASES)
-def test_linear_fwd_bwd(case, dtype):
+def test_linear_fwd_bwd(case, dtype, conv_kernel_path):
     """nn.Linear (unet.py:373-377, 277-285) forward and its autograd backward through eegldm_linear_fwd / eegldm_linear_bwd."""
     G = _imports()
     M, N, K = case

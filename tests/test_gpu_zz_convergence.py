@@ -1,4 +1,7 @@
-"""-m gpu: the production train step TRAINS -- 40 optimiser steps of the config_ldm.yaml UNet over frozen AutoencoderKL latents
+"""-m gpu, collected LAST (zz): the long / chaotic tests.  A GAN trajectory amplifies one-ulp differences, so nothing here may sit in front
+of the deterministic parity tests under `pytest -x` (round 3 lost 219 tests to one assertion of this file).
+
+The production train step TRAINS -- 40 optimiser steps of the config_ldm.yaml UNet over frozen AutoencoderKL latents
 (train_ldm.py:199-204 schedule and scale factor; training.py:399-452 loop) on a fixed pool of synthetic windows:
 
 * the epsilon-MSE falls from ~1.0 (zero-initialised output conv) to well below it,
@@ -35,22 +38,19 @@ def _golden(name):
         return json.load(fh)
 
 
-@pytest.mark.parametrize("dtype,tol", [("float32", 2e-3), ("bfloat16", 6e-2)])
-def test_ldm_training_trajectory_matches_the_oracle(dtype, tol):
-    """30 optimiser steps of the config_ldm.yaml UNet (add_noise -> UNet -> MSE -> Adam, training.py:419-443) on seeded weights, latents,
-    noise and timesteps: the loss of EVERY step against the CPU oracle's trajectory (tests/golden/make_ldm_traj.py -> ldm_traj_c2.json).
-    A gradient or optimiser defect that a one-step parity test tolerates compounds here: the fp32 engine must stay within 0.2 %
-    of the oracle over the whole run (measured: 1.7e-5 while the loss falls 1.75 -> 0.016), the bf16 engine within 6 % (measured: 1.0 %)."""
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden"))
+UCFG = dict(in_channels=1, out_channels=1, model_channels=128, num_res_blocks=2, attention_resolutions=[8, 4], channel_mult=[1, 2, 4], resblock_updown=True)
+
+
+def replay_ldm(dtype, tol=None):
+    """30 optimiser steps of ldm_traj_c2.json on the engine; returns the worst relative loss gap (asserts per step when tol is given)."""
     import torch
-    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden"))
     from param_gen import gen_param, eeg_windows, normal, timesteps
     from eegldm.models import UNetModel
     from eegldm.schedulers import DDPMScheduler
     from eegldm.training import Adam, ldm_train_step
     g = _golden("ldm_traj_c2.json")
-    cfg = dict(image_size=768, in_channels=1, out_channels=1, model_channels=128, num_res_blocks=2, attention_resolutions=[8, 4],
-               channel_mult=[1, 2, 4], resblock_updown=True)
-    net = UNetModel(**cfg, dtype=dtype)
+    net = UNetModel(image_size=768, **UCFG, dtype=dtype)
     net.load_state_dict({k: torch.from_numpy(gen_param(g["param_seed"], k, tuple(v.shape))) for k, v in net.state_dict().items()})
     sched = DDPMScheduler(num_train_timesteps=1000, schedule="linear_beta", beta_start=0.0015, beta_end=0.0195)
     opt = Adam(net, lr=g["lr"])
@@ -67,20 +67,24 @@ def test_ldm_training_trajectory_matches_the_oracle(dtype, tol):
         opt.step()
         want = g["loss"][i - 1]; got = float(loss)
         worst = max(worst, abs(got - want) / want)
-        assert abs(got - want) <= tol * want + 1e-6, (dtype, i, got, want)
-    print(f"LDM trajectory [{dtype}]: worst relative loss gap over {g['steps']} steps {worst:.2e}")
+        if tol is not None:
+            assert abs(got - want) <= tol * want + 1e-6, (dtype, i, got, want)
+    return worst
 
 
-@pytest.mark.parametrize("fixture", ["aekl_traj_c1.json", "aekl_traj_thin.json"])      # [32,32,64] layer by layer; [2,2,4] = the whole-network aekl_thin kernels
-@pytest.mark.parametrize("dtype,tol", [("float32", 2e-3), ("bfloat16", 8e-2)])
-def test_aekl_gan_training_trajectory_matches_the_oracle(dtype, tol, fixture):
-    """40 optimiser steps of the AutoencoderKL [32,32,64] + PatchDiscriminator GAN training (train_autoencoderkl.py:203-234, reference
-    loss weights incl. the 1e4 x spectral term, both Adam updates, BatchNorm running statistics): reconstruction L1, spectral, KL, generator
-    and discriminator losses of EVERY step against the CPU oracle's trajectory (tests/golden/make_aekl_traj.py -> aekl_traj_c1.json).
-    Measured: fp32 engine within 1.6e-5 (L1), 4e-5 (spectral), 3e-3 (adversarial terms) over all 40 steps while L1 falls 1.22 -> 0.10;
-    bf16 within 1-5 % (spectral 3-9 %)."""
+@pytest.mark.parametrize("dtype,tol", [("float32", 2e-3), ("bfloat16", 6e-2)])
+def test_ldm_training_trajectory_matches_the_oracle(dtype, tol):
+    """30 optimiser steps of the config_ldm.yaml UNet (add_noise -> UNet -> MSE -> Adam, training.py:419-443) on seeded weights, latents,
+    noise and timesteps: the loss of EVERY step against the CPU oracle's trajectory (tests/golden/make_ldm_traj.py -> ldm_traj_c2.json).
+    A gradient or optimiser defect that a one-step parity test tolerates compounds here: the fp32 engine must stay within 0.2 %
+    of the oracle over the whole run (measured: 1.7e-5 while the loss falls 1.75 -> 0.016; 100x margin), the bf16 engine within 6 % (measured: 1.0 %)."""
+    worst = replay_ldm(dtype, tol)
+    print(f"LDM trajectory [{dtype}]: worst relative loss gap over 30 steps {worst:.2e}")
+
+
+def replay_aekl(fixture, dtype):
+    """The 40 GAN steps of an aekl_traj_*.json fixture on the engine.  Returns {"rel": {term: [per-step |got-want|/|want|]}, "got": ..., "want": ...}."""
     import torch
-    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden"))
     from param_gen import gen_param, eeg_windows, normal
     from eegldm.models import AutoencoderKL, PatchDiscriminator
     from eegldm.training import Adam, aekl_train_step
@@ -96,7 +100,8 @@ def test_aekl_gan_training_trajectory_matches_the_oracle(dtype, tol, fixture):
     B, POOL, w = g["batch"], g["pool"], g["weights"]
     xs = torch.from_numpy(eeg_windows(POOL, seed=g["window_seed"])).cuda()
     lo = torch.zeros(6, device="cuda")
-    worst = {}
+    terms = ("recons", "spectral", "kl", "gen", "disc")
+    out = {"rel": {k: [] for k in terms}, "got": {k: [] for k in terms}, "want": {k: [] for k in terms}}
     for i in range(1, g["steps"] + 1):
         s = ((i - 1) * B) % POOL
         ew = torch.from_numpy(normal((B, 1, 768), seed=g["eps_seed_base"] + i)).cuda()
@@ -106,30 +111,56 @@ def test_aekl_gan_training_trajectory_matches_the_oracle(dtype, tol, fixture):
         v = [float(x) for x in lo.cpu()]
         got = {"recons": v[0], "spectral": v[1], "kl": v[2], "gen": v[3], "disc": 0.5 * (v[4] + v[5])}
         want = g["losses"][i - 1]
-        for k in got:
-            # the adversarial terms are O(1) numbers that wander as D and G chase each other: absolute floor next to the relative bound
-            # (and the spectral term, a sum of squared amplitude differences x 1e4 in the loss, is the most rounding-sensitive: the bf16 run sits 3-9 % below)
-            rel = 2 * tol if (k == "spectral" and dtype == "bfloat16") else tol
-            assert abs(got[k] - want[k]) <= rel * abs(want[k]) + (2e-2 if dtype == "bfloat16" else 2e-4), (dtype, i, k, got[k], want[k])
-            worst[k] = max(worst.get(k, 0.0), abs(got[k] - want[k]) / (abs(want[k]) + 1e-12))
-    print(f"AEKL/GAN trajectory {g['num_channels']} [{dtype}]: worst relative gaps over {g['steps']} steps " + ", ".join(f"{k} {x:.1e}" for k, x in worst.items()))
+        for k in terms:
+            out["got"][k].append(got[k]); out["want"][k].append(want[k])
+            out["rel"][k].append(abs(got[k] - want[k]) / (abs(want[k]) + 1e-12))
+    return out
 
 
-@pytest.mark.parametrize("dtype,tol", [("float32", 2e-3), ("bfloat16", 8e-2)])
-def test_pixel_dm_training_trajectory_matches_the_oracle(dtype, tol):
-    """12 optimiser steps of the pixel-space diffusion model (training_diffusion.py:141-151: the config_dm.yaml UNet on raw (B,1,3072) windows,
-    T = 768 attention, epsilon MSE + 1e-6 x JukeboxLoss(sum), Adam 1e-4) against the CPU oracle's trajectory
-    (tests/golden/make_dm_traj.py -> dm_traj_c5.json), every step."""
+# Bounds of the AEKL / GAN trajectories (profiles/r04_traj_spread_*.txt: 5 replays on each of 2 boxes).
+#  * reconstruction L1, spectral, KL: smooth functionals of the generator -- tight relative bound at EVERY step.
+#  * generator / discriminator adversarial terms: D and G chase each other, a one-ulp difference in a weight gradient (the engine's fp32
+#    sums run in another order than torch's) is amplified step after step.  Round 3 bounded them by ONE measured run x 1.6 and went red on
+#    the next box.  Now: the first ADV_TIGHT_STEPS steps, before the amplification sets in, keep the tight bound (a wrong adversarial
+#    gradient shows there at O(1)); later steps get an envelope that grows geometrically from the tight bound, capped at ADV_CAP.
+ADV_TIGHT_STEPS = 10
+ADV_GROWTH = 1.12
+ADV_CAP = {"float32": 3e-2, "bfloat16": 0.25}
+TIGHT = {"float32": (2e-3, 2e-4), "bfloat16": (8e-2, 2e-2)}        # (relative, absolute floor)
+
+
+def aekl_bound(dtype, term, step, want):
+    rel, floor = TIGHT[dtype]
+    if term == "spectral" and dtype == "bfloat16":
+        rel = 2 * rel          # a sum of squared amplitude differences (x 1e4 in the loss): the most rounding-sensitive term, the bf16 run sits 3-9 % below
+    if term in ("gen", "disc") and step > ADV_TIGHT_STEPS:
+        rel = min(rel * ADV_GROWTH ** (step - ADV_TIGHT_STEPS), ADV_CAP[dtype])
+        floor = min(floor * ADV_GROWTH ** (step - ADV_TIGHT_STEPS), 10 * floor)
+    return rel * abs(want) + floor
+
+
+@pytest.mark.parametrize("fixture", ["aekl_traj_c1.json", "aekl_traj_thin.json"])      # [32,32,64] layer by layer; [2,2,4] = the whole-network aekl_thin kernels
+@pytest.mark.parametrize("dtype", ["float32", "bfloat16"])
+def test_aekl_gan_training_trajectory_matches_the_oracle(dtype, fixture):
+    """40 optimiser steps of the AutoencoderKL + PatchDiscriminator GAN training (train_autoencoderkl.py:203-234, reference
+    loss weights incl. the 1e4 x spectral term, both Adam updates, BatchNorm running statistics): reconstruction L1, spectral, KL, generator
+    and discriminator losses of EVERY step against the CPU oracle's trajectory (tests/golden/make_aekl_traj.py -> aekl_traj_*.json).
+    Bounds: aekl_bound above; measured spread: profiles/r04_traj_spread_*.txt."""
+    r = replay_aekl(fixture, dtype)
+    for k in r["rel"]:
+        for i, (got, want) in enumerate(zip(r["got"][k], r["want"][k]), start=1):
+            assert abs(got - want) <= aekl_bound(dtype, k, i, want), (dtype, fixture, i, k, got, want, aekl_bound(dtype, k, i, want))
+    print(f"AEKL/GAN trajectory {fixture} [{dtype}]: worst relative gaps over 40 steps " + ", ".join(f"{k} {max(x):.1e}" for k, x in r["rel"].items()))
+
+
+def replay_dm(dtype, tol=None):
     import torch
-    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden"))
     from param_gen import gen_param, eeg_windows, normal, timesteps
     from eegldm.models import UNetModel
     from eegldm.schedulers import DDPMScheduler
     from eegldm.training import Adam, dm_train_step
     g = _golden("dm_traj_c5.json")
-    cfg = dict(image_size=3072, in_channels=1, out_channels=1, model_channels=128, num_res_blocks=2, attention_resolutions=[8, 4],
-               channel_mult=[1, 2, 4], resblock_updown=True)
-    net = UNetModel(**cfg, dtype=dtype)
+    net = UNetModel(image_size=3072, **UCFG, dtype=dtype)
     net.load_state_dict({k: torch.from_numpy(gen_param(g["param_seed"], k, tuple(v.shape))) for k, v in net.state_dict().items()})
     sched = DDPMScheduler(num_train_timesteps=1000, schedule="linear_beta", beta_start=0.0015, beta_end=0.0195)
     opt = Adam(net, lr=g["lr"])
@@ -146,5 +177,15 @@ def test_pixel_dm_training_trajectory_matches_the_oracle(dtype, tol):
         opt.step()
         want = g["loss"][i - 1]; got = float(loss)
         worst = max(worst, abs(got - want) / want)
-        assert abs(got - want) <= tol * want + 1e-6, (dtype, i, got, want)
-    print(f"pixel-space DM trajectory [{dtype}]: worst relative loss gap over {g['steps']} steps {worst:.2e}")
+        if tol is not None:
+            assert abs(got - want) <= tol * want + 1e-6, (dtype, i, got, want)
+    return worst
+
+
+@pytest.mark.parametrize("dtype,tol", [("float32", 2e-3), ("bfloat16", 8e-2)])
+def test_pixel_dm_training_trajectory_matches_the_oracle(dtype, tol):
+    """12 optimiser steps of the pixel-space diffusion model (training_diffusion.py:141-151: the config_dm.yaml UNet on raw (B,1,3072) windows,
+    T = 768 attention, epsilon MSE + 1e-6 x JukeboxLoss(sum), Adam 1e-4) against the CPU oracle's trajectory
+    (tests/golden/make_dm_traj.py -> dm_traj_c5.json), every step.  Measured: fp32 7.6e-6 (260x margin), bf16 1.2 %."""
+    worst = replay_dm(dtype, tol)
+    print(f"pixel-space DM trajectory [{dtype}]: worst relative loss gap over 12 steps {worst:.2e}")
