@@ -106,6 +106,12 @@ int eegldm_cast(eegldm_ctx*, const float* src, void* dst, long n, int dst_dtype)
  * (before freeing either buffer).  No reference counterpart: layout plumbing behind nn.Conv1d (unet.py:263). */
 int eegldm_conv1d_pack_kblocked(eegldm_ctx*, const void* w, void* w_kblocked, int Cout, int Cin, int dtype);
 int eegldm_conv1d_forget_kblocked(eegldm_ctx*, const void* w);
+/* Data-gradient copy of a 3-tap conv weight, [3][Cout/32][Cin][32] (16-bit dtypes, Cout % 32 == 0): written to w_dgrad (same size as w)
+ * and registered with the context, after which eegldm_conv1d_bwd_data(.., w, ..) may run the input gradient as a plain NT product on
+ * the 192 x 256 tile (shapes with Cin % 256 == 0, Cout % 64 == 0, L % 192 == 0; other shapes are unaffected).  The model executors do
+ * this for their own weights; eegldm_conv1d_forget_kblocked removes this registration too.  No reference counterpart: layout
+ * plumbing behind the backward of nn.Conv1d (unet.py:263). */
+int eegldm_conv1d_pack_dgrad(eegldm_ctx*, const void* w, void* w_dgrad, int Cout, int Cin, int dtype);
 
 /* ------------------------------------------------------------------ primitives (NLC)
  * nn.Conv1d as used at unet.py:263,291,302,385,504 and inside MONAI AutoencoderKL /

@@ -72,6 +72,8 @@ struct eegldm_ctx {
   std::vector<ProfRec> prof;
   // K-blocked copies of 3-tap conv weights, keyed by the address of the plain [tap][Cout][Cin] bf16 weight (registered by NetBase)
   std::unordered_map<const void*, const void*> kblk;
+  // data-gradient copies of 3-tap conv weights, [tap][Cout / 32][Cin][32] (the reduction index of the data gradient, Cout, K-blocked): keyed like kblk
+  std::unordered_map<const void*, const void*> kblk_t;
   // fused train steps zero ALL their loss scalars with one memset and set this: the loss entry points then skip their own 4-byte memset
   // (every tiny launch costs ~5 us of dispatch: 22 memsets were 2.5 % of the AutoencoderKL / GAN step)
   bool loss_prezeroed = false;
@@ -175,6 +177,7 @@ struct GemmArgs {
   float* colsum;         // GA_TR, 16-bit operands, batch 1: colsum[m] += sum_k A[k][m] (bias gradient of a conv whose dY is A), or null
   int b_kblk;            // GB_NT: B is K-BLOCKED, [tap][K / KC][N][KC] (KC = 32 16-bit elements = 64 bytes): a stage's B tile is one contiguous run
                          //  (op_conv_fwd with a packed weight copy, see kblk_pack); 0 = plain [tap][N][K]
+  const void* B_alt;     // GA_CONV + GB_TR (data gradient): the [tap][K / 32][N][32] copy of the same weight, or null; lets gemm_big.hip run the product as an NT one
   int wide_n;            // fused 3-tap weight gradient: use the 128-wide N tile (one block per CU)
   int xcd_swizzle;       // set by the launcher: XCD-aware tile order (see gemm_kernel)
   const void* zero_page; // >= 16 zero bytes in device memory (set by gemm_launch)
@@ -191,6 +194,7 @@ struct GemmGroup {      // per problem: operands, their leading dimensions (dY i
 };
 struct WgradRec { GemmArgs a; long tiles; int kstage; float* dst; float* dbias; };
 int gemm_launch(eegldm_ctx* ctx, const GemmArgs& a);
+int gemm_big_try(eegldm_ctx* ctx, const GemmArgs& a);      // gemm_big.hip: 1 = launched, 0 = not its shape, < 0 = error
 // grouped split-K weight gradient: a.ngroup problems whose pointers are in the HOST table `g` (a.batch / a.grp are set here), partial
 // tiles to the context workspace, ONE batched fold into the Dst buffers.  `slot` = position of this launch in the step's flush order:
 // the device copy of the table is cached per slot and re-uploaded only when its contents change (addresses repeat step after step).

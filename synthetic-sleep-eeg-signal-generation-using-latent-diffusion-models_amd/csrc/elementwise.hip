@@ -506,6 +506,41 @@ __global__ void kblk_pack1_kernel(const uint4* __restrict__ src, uint4* __restri
   const int co = (int)(tc % cout), t = (int)(tc / cout);
   dst[(((long)t * (cin / 32) + ci8 / 4) * cout + co) * 4 + (ci8 & 3)] = src[r];
 }
+// [3][Cout][Cin] -> [3][Cout / 32][Cin][32]: one 16-byte OUTPUT chunk (8 consecutive co of one ci) per thread, threads consecutive in ci
+// (the eight 2-byte reads of a thread are each coalesced across the wave)
+__device__ __forceinline__ void kblk_t_chunk(const bf16_t* __restrict__ src, uint4* __restrict__ dst, int cout, int cin, long r) {
+  const int ci = (int)(r % cin); long x = r / cin;
+  const int c4 = (int)(x & 3); x >>= 2;
+  const int cb = (int)(x % (cout / 32)), t = (int)(x / (cout / 32));
+  const bf16_t* s = src + ((long)t * cout + cb * 32 + c4 * 8) * cin + ci;
+  unsigned v[4];
+#pragma unroll
+  for (int k = 0; k < 4; k++) v[k] = (unsigned)s[(long)(2 * k) * cin] | ((unsigned)s[(long)(2 * k + 1) * cin] << 16);
+  dst[(((long)t * (cout / 32) + cb) * cin + ci) * 4 + c4] = make_uint4(v[0], v[1], v[2], v[3]);
+}
+__global__ void kblk_pack_t_kernel(const bf16_t* __restrict__ src, uint4* __restrict__ dst, const KbDesc* __restrict__ tab, int n, long total) {
+  const long c = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= total) return;
+  int e = 0;
+  while (e + 1 < n && tab[e + 1].chunk0 <= c) e++;
+  const KbDesc d = tab[e];
+  kblk_t_chunk(src + d.off, dst + d.off / 8, d.cout, d.cin, c - d.chunk0);
+}
+__global__ void kblk_pack_t1_kernel(const bf16_t* __restrict__ src, uint4* __restrict__ dst, int cout, int cin, long total) {
+  const long r = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (r < total) kblk_t_chunk(src, dst, cout, cin, r);
+}
+int kblk_pack_t_one(eegldm_ctx* ctx, const void* w_plain, void* w_packed, int Cout, int Cin) {
+  const long total = 3l * Cout * Cin / 8;
+  hipLaunchKernelGGL(kblk_pack_t1_kernel, dim3((unsigned)((total + NT - 1) / NT)), dim3(NT), 0, ctx->stream, (const bf16_t*)w_plain, (uint4*)w_packed, Cout, Cin, total);
+  LAUNCH_CHECK(); return 0;
+}
+int kblk_pack_t(eegldm_ctx* ctx, const void* w_plain, void* w_packed, const KbDesc* d_table, int n, long total_chunks) {
+  if (n <= 0) return 0;
+  hipLaunchKernelGGL(kblk_pack_t_kernel, dim3((unsigned)((total_chunks + NT - 1) / NT)), dim3(NT), 0, ctx->stream, (const bf16_t*)w_plain, (uint4*)w_packed,
+                     d_table, n, total_chunks);
+  LAUNCH_CHECK(); return 0;
+}
 int kblk_pack_one(eegldm_ctx* ctx, const void* w_plain, void* w_packed, int Cout, int Cin) {
   const long total = 3l * Cout * Cin / 8;
   hipLaunchKernelGGL(kblk_pack1_kernel, dim3((unsigned)((total + NT - 1) / NT)), dim3(NT), 0, ctx->stream, (const uint4*)w_plain, (uint4*)w_packed, Cout, Cin, total);

@@ -1271,8 +1271,16 @@ int gemm_launch(eegldm_ctx* ctx, const GemmArgs& a_in) {
     sk = sk < 0.f ? 0.f : (sk > 0.5f ? 0.5f : sk);
     if (sk > 0.f && spb * (1.0f - sk) >= 2.0f) a.k_skew = sk;      // every chunk keeps at least two stages
   }
-  int rc;
-  if (a.dtype == EEGLDM_F32) rc = launch_modes<float>(ctx, a);
+  int rc = 0;
+  // 192 x 256 tile, one workgroup per CU (gemm_big.hip): 3-tap convs of the 256- / 512-channel levels, forward and (through the
+  // transposed K-blocked weight copy B_alt) data gradient
+  if (a.amode == GA_CONV && a.dtype == EEGLDM_BF16 && !fold_dst) {
+    if (a.bmode == GB_NT) rc = gemm_big_try(ctx, a);
+    else if (a.B_alt) { GemmArgs b = a; b.B = a.B_alt; b.bmode = GB_NT; b.b_kblk = 1; rc = gemm_big_try(ctx, b); }
+    if (rc < 0) return rc;
+  }
+  if (rc == 1) rc = 0;
+  else if (a.dtype == EEGLDM_F32) rc = launch_modes<float>(ctx, a);
   else if (a.dtype == EEGLDM_BF16) rc = launch_modes<bf16_t>(ctx, a);
   else EEG_FAIL(EEGLDM_ERR_UNSUPPORTED, "dtype %d", a.dtype);
   EEG_ENV_VAR(bool, dbg_skip_fold, getenv("EEGLDM_DBG_SKIP_FOLDS") != nullptr);      // timing experiment only: weight gradients stay in the workspace

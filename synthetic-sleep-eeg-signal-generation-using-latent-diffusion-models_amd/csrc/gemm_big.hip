@@ -1,0 +1,306 @@
+// 192 x 256 output tile, 8 waves, ONE workgroup per CU: the implicit-GEMM 3-tap convolution (forward and data gradient) and the
+// 1-tap NT products of the UNet's 256- and 512-channel levels (bf16 storage, fp32 accumulate).
+//   Y[r][n] = sum_t sum_k A[r + t - pad][k] * W_t[n][k]   (+ bias[n] + rowvec[sample(r)][n] + resid[r][n])
+// (reference ops: nn.Conv1d of /root/reference/src/models/unet.py:263,291,302 -- in_layers / out_layers / skip_connection -- and
+//  their input gradients; the data gradient runs as the same product over dY with the taps flipped and a [tap][Cin][Cout] weight copy)
+//
+// Why a second GEMM kernel (gemm.hip keeps every other shape): the 128 x 128 tile of gemm.hip moves 1 byte from L2 to LDS per 48 MACs
+// and its K loop is bound by exactly that path (~29 B/clk/CU, MFMA pipe 62 % busy in the loop, 0.32 of the MFMA peak over
+// the step).  This tile moves 1 byte per 77 (3 taps) / 110 (1 tap) MACs in 128-byte row segments (the L2 -> LDS path runs 64-byte
+// segments at half the rate, tools/probes/fill_pattern_probe.hip), and 192 rows divide every sequence length of the model (192 / 384 /
+// 768; 768 / 1536 / 3072), so a tile never straddles two samples: the conv's zero padding is two halo rows per tile, decided per tile,
+// instead of a per-lane row mask.  M tiles x N tiles = 512 workgroups for every 256- / 512-channel layer at B = 256: two full rounds of
+// the 256 CUs (a 256 x 256 tile would give 384 = 1.5 rounds).
+//
+// Structure (one K stage = 64 reduction channels, 128 bytes per tile row):
+//   LDS      2 x A tile  (192 rows + 2 halo rows + DMA padding, 26 KB each)  +  3 x B piece (256 rows of ONE tap, 32 KB each)  = 148 KB
+//   pieces   p = 3 * stage + tap;  piece p = B(stage, tap)  [+ A(stage) when tap == 0]  filled by LDS-DMA (global_load_lds_dwordx4),
+//            lane-linear 1 KB per wave instruction, XOR-swizzled on the SOURCE side (gemm.hip nt_swz<2>: conflict-free ds_read_b128)
+//   phase p  s_waitcnt vmcnt(0) (piece p+1, issued one phase ago, has landed)  ->  s_barrier  ->  issue piece p+2 between the MFMAs
+//            ->  48 MFMAs per wave (6 x 4 fragments x 2 k-steps of 32) with the fragment reads running ONE k-step ahead, across the
+//            phase boundary: the first k-step of phase p+1 is read from LDS under the last MFMAs of phase p, so the matrix pipe has
+//            work in registers when the barrier releases.
+//   epilogue bias / embedding row / residual added in the fragment layout (fp32), packed to bf16, transposed through LDS, 16-byte
+//            row-contiguous stores.
+#include <stdlib.h>
+
+#include "common.h"
+#include "internal.h"
+
+namespace {
+
+constexpr int BM = 192, BN = 256, BK = 64, NWAVE = 8, NTHR = 512;
+constexpr int FM = 6, FN = 4;                       // 16 x 16 fragments per wave: 96 rows x 64 columns (waves: 2 along M x 4 along N)
+constexpr int ROWB = BK * 2;                        // bytes per tile row
+constexpr int A_MAIN = BM * ROWB;                   // 24 KB = 24 wave instructions (3 per wave)
+// A tile in LDS: [896 B pad][halo row above the tile][192 rows][halo row below][896 B pad] -- the 194 rows are LINEAR (tap t of tile row
+// r is physical row r + t, so a fragment address is one per-lane base + immediates), and each halo row is the tail / head of a 1 KB
+// DMA instruction whose other lanes land in the padding (wave 0: the row above, wave 1: the row below)
+constexpr int A_PAD = 896;
+constexpr int A_ALLOC = A_PAD + (BM + 2) * ROWB + A_PAD;      // 26 624
+constexpr int B_ALLOC = BN * ROWB;                  // 32 KB = 32 wave instructions (4 per wave)
+constexpr int RING = 2 * A_ALLOC + 3 * B_ALLOC;     // 151 552 bytes
+constexpr int PITCH16 = BN * 2 + 16;                // packed bf16 epilogue tile
+constexpr int EPI_BYTES = BM * PITCH16;
+constexpr int LDS_BYTES = RING > EPI_BYTES ? RING : EPI_BYTES;
+static_assert(LDS_BYTES <= 160 * 1024, "tile does not fit the 160 KiB LDS");
+
+struct BigArgs {
+  const bf16_t* A; long lda;
+  const bf16_t* B; long ldb; long sBt;     // plain: [tap][N][K] (ldb = K stride of a row); K-blocked: [tap][K/32][N][32]
+  int tap_flip;                           // tap t reads weight slice 2 - t (data gradient)
+  bf16_t* C; long ldc;
+  int M, N, K, L;                         // L = rows per sample (conv zero padding at its edges); M % 192 == 0, L % 192 == 0, N % 256 == 0, K % 64 == 0
+  const float* bias; const float* rowvec; long ld_rowvec; int rows_per_vec;
+  const bf16_t* resid; long ldr;
+  const void* zero_page;
+  int tiles_m, tiles_n;
+};
+
+typedef __attribute__((address_space(3))) void* lds_void_ptr;
+
+__device__ __forceinline__ void dma16(const void* g, unsigned lds_off) {       // see gemm.hip: inline asm so that hipcc does not order ds_reads behind it
+  asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off" ::"s"(__builtin_amdgcn_readfirstlane(lds_off)), "v"(g) : "memory", "m0");
+}
+// the same with a scalar base and a 32-bit per-lane byte offset
+__device__ __forceinline__ void dma16s(const void* base, unsigned voff, unsigned lds_off) {
+  // (readfirstlane: the "s" constraint needs a value the compiler KNOWS to be wave-uniform; the tile origin comes from blockIdx arithmetic it does not always prove)
+  const unsigned long long u = (unsigned long long)base;
+  const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)u), hi = __builtin_amdgcn_readfirstlane((unsigned)(u >> 32));
+  const unsigned long long b = ((unsigned long long)hi << 32) | lo;
+  asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" ::"s"(__builtin_amdgcn_readfirstlane(lds_off)), "v"(voff), "s"(b) : "memory", "m0");
+}
+__device__ __forceinline__ int swz2(int row) { return 2 * ((row >> 1) & 3); }     // 16-byte slot ^= swz2(row) (128-byte rows)
+
+template <int TAPS, bool KBLK>      // TAPS = 3 only: with one tap every piece carries an A tile and the two-buffer A ring would be overwritten while it is read
+__global__ __launch_bounds__(NTHR, 2) void gemm_big_kernel(const BigArgs p) {
+  static_assert(TAPS == 3, "ring layout assumes three pieces per A tile");
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int lm = lane & 15, q = lane >> 4;
+  const int wm = wave >> 2, wn = wave & 3;
+  // XCD-aware tile order (workgroups are dealt round-robin to the 8 XCDs): XCD x walks M tiles x, x + 8, ... and runs all N tiles of
+  // an M tile back to back, so an A row panel is fetched into ONE L2
+  int tile_m, tile_n;
+  {
+    const int w = blockIdx.x;
+    if ((p.tiles_m & 7) == 0) { const int xcd = w & 7, slot = w >> 3; tile_n = slot % p.tiles_n; tile_m = (slot / p.tiles_n) * 8 + xcd; }
+    else { tile_n = w % p.tiles_n; tile_m = w / p.tiles_n; }
+  }
+  const int m0 = tile_m * BM, n0 = tile_n * BN;
+  const int S = p.K / BK;
+  const bf16_t* zeros = (const bf16_t*)p.zero_page;
+
+  // ---- LDS-DMA sources, decoded once: LDS chunk c of a tile receives the 16 bytes its swizzled position stands for.
+  // 32-bit per-lane byte offsets against a SCALAR base that the K loop advances (global_load_lds with an SGPR base): one VGPR per
+  // DMA instruction instead of a 64-bit pointer, no per-lane address arithmetic in the loop.
+  unsigned ao_src[3], bo_src[4], ah_src = 0;
+  bool ah_ok = false;
+#pragma unroll
+  for (int j = 0; j < 3; j++) {
+    const int c = (wave + NWAVE * j) * 64 + lane, pr = 1 + (c >> 3), lc = (c & 7) ^ swz2(pr);      // physical row 1 + tile row
+    ao_src[j] = (unsigned)(((long)(pr - 1) * p.lda + lc * 8) * 2);
+  }
+  // halo rows (rows of another sample = the conv's zero padding): wave 0, lanes 56-63 -> physical row 0 (the row above the tile);
+  // wave 1, lanes 0-7 -> physical row 193 (the row below); the other lanes of both instructions fetch zeros into the padding
+  if (wave == 0 && lane >= 56) { ah_ok = m0 % p.L != 0; ah_src = (unsigned)((((lane & 7) ^ swz2(0)) * 8) * 2); }
+  if (wave == 1 && lane < 8) { ah_ok = (m0 + BM) % p.L != 0; ah_src = (unsigned)((((long)(BM + 1) * p.lda) + ((lane & 7) ^ swz2(BM + 1)) * 8) * 2); }
+#pragma unroll
+  for (int j = 0; j < 4; j++) {
+    const int c = (wave + NWAVE * j) * 64 + lane, nr = c >> 3, lc = (c & 7) ^ swz2(nr);
+    bo_src[j] = KBLK ? (unsigned)((((long)(lc >> 2) * p.N + nr) * 32 + (lc & 3) * 8) * 2) : (unsigned)(((long)nr * p.ldb + lc * 8) * 2);
+  }
+  const long bstep = KBLK ? (long)2 * p.N * 32 : (long)BK;      // elements per K stage
+  const bf16_t* const a_base = p.A + (long)m0 * p.lda;
+  const bf16_t* const b_base = p.B + (KBLK ? (long)n0 * 32 : (long)n0 * p.ldb);
+  const unsigned lds0 = (unsigned)(size_t)(lds_void_ptr)smem;
+  const unsigned wave_u = __builtin_amdgcn_readfirstlane(wave);
+  constexpr int B0 = 2 * A_ALLOC;          // B pieces behind the two A tiles
+  // DMA instruction k of piece (s, t): k < 4 the B piece; 4..6 the A tile of stage s and 7 its halo rows (pieces with t == 0 only)
+  auto issue = [&](int s, int t, int k) __attribute__((always_inline)) {
+    if (k < 4) {
+      const int tw = p.tap_flip ? 2 - t : t;
+      dma16s(b_base + s * bstep + tw * p.sBt, bo_src[k], lds0 + B0 + t * B_ALLOC + (wave_u + NWAVE * k) * 1024);
+    } else if (k < 7) {
+      dma16s(a_base + (long)s * BK, ao_src[k - 4], lds0 + (s & 1) * A_ALLOC + A_PAD + ROWB + (wave_u + NWAVE * (k - 4)) * 1024);
+    } else {
+      if (wave_u < 2) {
+        const bf16_t* hb = a_base - p.lda + (long)s * BK;         // base of the row above the tile
+        const void* src = ah_ok ? (const void*)((const char*)hb + ah_src) : (const void*)zeros;
+        dma16(src, lds0 + (s & 1) * A_ALLOC + (wave_u == 0 ? 0 : A_PAD + (BM + 1) * ROWB));
+      }
+    }
+  };
+  auto issue_all = [&](int pc) __attribute__((always_inline)) {
+    const int s = pc / TAPS, t = pc % TAPS;
+#pragma unroll
+    for (int k = 0; k < 8; k++) if (k < 4 || t == 0) issue(s, t, k);
+  };
+
+  // ---- fragment addresses: one per-lane base per tap (A: physical row wm*96 + lm + t) and one for B; fragment i / j adds the
+  // immediate 16 rows x 128 B = 2048 (the swizzle only looks at row bits 1-2), k-step 1 flips byte-offset bit 6
+  unsigned aof[TAPS];
+#pragma unroll
+  for (int t = 0; t < TAPS; t++) { const int pr = wm * (FM * 16) + lm + t; aof[t] = A_PAD + pr * ROWB + ((q ^ swz2(pr)) << 4); }
+  const unsigned bof = (wn * 64 + lm) * ROWB + ((q ^ swz2(lm)) << 4);
+
+  f32x4 acc[FM][FN];
+#pragma unroll
+  for (int i = 0; i < FM; i++)
+#pragma unroll
+    for (int j = 0; j < FN; j++) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  issue_all(0);
+  issue_all(1);
+
+  // Fragment registers: ONE set of A fragments (af[i] is re-loaded for the next k-step as soon as row i's MFMAs of this k-step are
+  // issued) and two sets of B fragments (all four are needed until the last row) -- 56 registers instead of 80 for full double buffering
+  uint4 af[FM], bf0[FN], bf1[FN];
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
+#pragma unroll
+  for (int j = 0; j < FN; j++) bf0[j] = *(const uint4*)(smem + B0 + bof + j * 2048);
+#pragma unroll
+  for (int i = 0; i < FM; i++) af[i] = *(const uint4*)(smem + aof[0] + i * 2048);
+  // one phase; t (tap), has1 (piece p + 1 exists) and has2 (piece p + 2 exists) are compile-time constants after unrolling, s is wave-uniform
+  auto phase = [&](const int s, const int t, const bool has1, const bool has2) __attribute__((always_inline)) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // this wave's part of piece p+1 (and p) has landed
+    __builtin_amdgcn_s_barrier();                            // ... and everyone's; every wave is done reading piece p-1
+    asm volatile("" ::: "memory");
+    const char* smA = smem + (s & 1) * A_ALLOC;
+    const char* smB = smem + B0 + t * B_ALLOC;
+    const int t2 = (t + 2) % TAPS, s2 = s + (t + 2) / TAPS;                       // piece p + 2
+    const int t1 = (t + 1) % TAPS, s1 = s + (t + 1) / TAPS;                       // piece p + 1
+    // ---- k-step 0 (fragments already in registers); reads of k-step 1 run behind the MFMAs.  Row 0 goes first, bare: its operands
+    // were read a whole k-step ago, while the reads issued just before the barrier (row 5 of this k-step) may still be in flight
+#pragma unroll
+    for (int i = 0; i < FM; i++) {
+#pragma unroll
+      for (int j = 0; j < FN; j++) {
+        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, bf0[j]), __builtin_bit_cast(bf16x8, af[i]), acc[i][j], 0, 0, 0);
+        if (has2 && i >= 1 && i <= 4) {            // DMA instructions 2(i-1), 2(i-1)+1 of piece p+2 go out behind MFMAs 1 and 3 of rows 1..4
+          const int k = 2 * (i - 1) + (j >> 1);
+          if ((j & 1) && (k < 4 || t2 == 0)) issue(s2, t2, k);
+        }
+      }
+      if (i == 0) {
+        __builtin_amdgcn_sched_barrier(0);     // (keeps the reads below behind row 0's MFMAs: the compiler's wait in front of the first MFMA after an LDS read is lgkmcnt(0))
+#pragma unroll
+        for (int j = 0; j < FN; j++) bf1[j] = *(const uint4*)(smB + (bof ^ 64) + j * 2048);
+      }
+      af[i] = *(const uint4*)(smA + (aof[t] ^ 64) + i * 2048);
+      __builtin_amdgcn_sched_barrier(0);       // pin the order: hipcc otherwise sinks every fragment read to just before its first use
+    }
+    // ---- k-step 1; the first k-step of the next phase (piece p+1: landed before this phase's barrier) is read behind its MFMAs
+    const char* smA1 = smem + (s1 & 1) * A_ALLOC;
+    const char* smB1 = smem + B0 + t1 * B_ALLOC;
+    if (has1) {
+#pragma unroll
+      for (int j = 0; j < FN; j++) bf0[j] = *(const uint4*)(smB1 + bof + j * 2048);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int i = 0; i < FM; i++) {
+#pragma unroll
+      for (int j = 0; j < FN; j++)
+        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, bf1[j]), __builtin_bit_cast(bf16x8, af[i]), acc[i][j], 0, 0, 0);
+      if (has1) af[i] = *(const uint4*)(smA1 + aof[t1] + i * 2048);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  };
+#pragma unroll 1
+  for (int s = 0; s + 1 < S; s++) {
+    phase(s, 0, true, true); phase(s, 1, true, true); phase(s, 2, true, true);
+  }
+  phase(S - 1, 0, true, true); phase(S - 1, 1, true, false); phase(S - 1, 2, false, false);
+  __syncthreads();       // all waves done with the ring before the epilogue tile reuses it
+
+  // ---- epilogue: acc[i][j][r] = C[wm*96 + i*16 + lm][wn*64 + j*16 + q*4 + r] (operands were swapped: 4 consecutive columns per lane)
+  float4 add[FN];
+#pragma unroll
+  for (int j = 0; j < FN; j++) {
+    const int nj = n0 + wn * 64 + j * 16 + q * 4;
+    add[j] = p.bias ? *(const float4*)(p.bias + nj) : make_float4(0.f, 0.f, 0.f, 0.f);
+    if (p.rowvec) {           // a tile lies inside one sample (rows_per_vec % 192 == 0)
+      const float4 e = *(const float4*)(p.rowvec + (long)(m0 / p.rows_per_vec) * p.ld_rowvec + nj);
+      add[j].x += e.x; add[j].y += e.y; add[j].z += e.z; add[j].w += e.w;
+    }
+  }
+  uint2 res[2][FN];
+  auto load_res = [&](int i, uint2 (&r)[FN]) __attribute__((always_inline)) {
+    const bf16_t* rp = p.resid + (long)(m0 + wm * (FM * 16) + i * 16 + lm) * p.ldr + n0 + wn * 64 + q * 4;
+#pragma unroll
+    for (int j = 0; j < FN; j++) r[j] = *(const uint2*)(rp + j * 16);
+  };
+  if (p.resid) load_res(0, res[0]);
+#pragma unroll
+  for (int i = 0; i < FM; i++) {
+    if (p.resid && i + 1 < FM) load_res(i + 1, res[(i + 1) & 1]);
+#pragma unroll
+    for (int j = 0; j < FN; j++) {
+      float4 a = add[j];
+      if (p.resid) {
+        const uint2 r = res[i & 1][j];
+        a.x += __uint_as_float(r.x << 16); a.y += __uint_as_float(r.x & 0xffff0000u);
+        a.z += __uint_as_float(r.y << 16); a.w += __uint_as_float(r.y & 0xffff0000u);
+      }
+      uint2 o;
+      o.x = pack_bf16x2(acc[i][j][0] + a.x, acc[i][j][1] + a.y);
+      o.y = pack_bf16x2(acc[i][j][2] + a.z, acc[i][j][3] + a.w);
+      *(uint2*)(smem + (wm * (FM * 16) + i * 16 + lm) * PITCH16 + (wn * 64 + j * 16 + q * 4) * 2) = o;
+    }
+  }
+  __syncthreads();
+  constexpr int CH8 = BN / 8, RSTEP = NTHR / CH8, NIT = BM / RSTEP;      // 32 chunks per row, 16 rows per pass, 12 passes
+  const int cs8 = tid % CH8, r0 = tid / CH8;
+  uint4 v8[NIT];
+#pragma unroll
+  for (int cc = 0; cc < NIT; cc++) v8[cc] = *(const uint4*)(smem + (r0 + cc * RSTEP) * PITCH16 + cs8 * 16);
+#pragma unroll
+  for (int cc = 0; cc < NIT; cc++) *(uint4*)(p.C + (long)(m0 + r0 + cc * RSTEP) * p.ldc + n0 + cs8 * 8) = v8[cc];
+}
+
+template <int TAPS, bool KBLK>
+int launch_big(eegldm_ctx* ctx, const BigArgs& a) {
+  auto kern = gemm_big_kernel<TAPS, KBLK>;
+  static int attr_dev = -1;      // the dynamic-LDS attribute is per device
+  if (attr_dev != ctx->device) {
+    HIP_TRY(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
+    attr_dev = ctx->device;
+  }
+  hipLaunchKernelGGL(kern, dim3(a.tiles_m * a.tiles_n), dim3(NTHR), LDS_BYTES, ctx->stream, a);
+  LAUNCH_CHECK();
+  return 0;
+}
+
+}  // namespace
+
+// 1 = launched, 0 = not this kernel's shape (the caller takes gemm.hip), < 0 = error.
+// GemmArgs of a forward-style product: A rows (GA_CONV with 3 taps, stride 1, pad 1; or GA_PLAIN with 1 tap), B = GB_NT weights (plain or
+// K-blocked), bf16 in and out.
+int gemm_big_try(eegldm_ctx* ctx, const GemmArgs& g) {
+  EEG_ENV_VAR(bool, off, getenv("EEGLDM_NO_GEMM_BIG") != nullptr);
+  EEG_ENV_VAR(int, min_tiles, getenv("EEGLDM_GEMM_BIG_MIN_TILES") ? atoi(getenv("EEGLDM_GEMM_BIG_MIN_TILES")) : 128);
+  if (off || g.dtype != EEGLDM_BF16 || g.bmode != GB_NT || g.batch != 1 || g.splitk > 1 || g.ztaps > 1 || g.out_f32 || g.atomic_out || g.colsum || g.ngroup) return 0;
+  if (g.alpha != 1.0f || g.ups > 1) return 0;
+  const bool conv3 = g.amode == GA_CONV && g.taps == 3 && g.stride == 1 && g.pad_l == 1 && g.Lin == g.Lout;
+  if (!conv3) return 0;      // (1-tap products: the A tile would need a third ring buffer, see the header; gemm.hip keeps them)
+  const int L = conv3 ? g.Lout : BM;
+  if (g.M % BM != 0 || L % BM != 0 || g.N % BN != 0 || g.K % BK != 0 || g.lda % 8 != 0 || g.ldc % 8 != 0) return 0;
+  if (!g.b_kblk && g.ldb % 8 != 0) return 0;
+  if (g.rowvec && (g.rows_per_vec % BM != 0 || g.ld_rowvec % 4 != 0)) return 0;
+  if (g.resid && g.ldr % 4 != 0) return 0;
+  if (((size_t)g.A | (size_t)g.B | (size_t)g.C) & 15) return 0;
+  if (g.resid && ((size_t)g.resid & 7)) return 0;
+  const int tm = g.M / BM, tn = g.N / BN;
+  if ((long)tm * tn < min_tiles) return 0;         // small problems: the 128-row tiles fill the chip better
+  BigArgs a;
+  a.A = (const bf16_t*)g.A; a.lda = g.lda; a.B = (const bf16_t*)g.B; a.ldb = g.ldb; a.sBt = g.sBt; a.tap_flip = g.tap_flip;
+  a.C = (bf16_t*)g.C; a.ldc = g.ldc; a.M = g.M; a.N = g.N; a.K = g.K; a.L = L;
+  a.bias = g.bias; a.rowvec = g.rowvec; a.ld_rowvec = g.ld_rowvec; a.rows_per_vec = g.rows_per_vec > 0 ? g.rows_per_vec : 1;
+  a.resid = (const bf16_t*)g.resid; a.ldr = g.ldr; a.zero_page = ctx->zero_page; a.tiles_m = tm; a.tiles_n = tn;
+  int rc;
+  rc = g.b_kblk ? launch_big<3, true>(ctx, a) : launch_big<3, false>(ctx, a);
+  return rc < 0 ? rc : 1;
+}

@@ -64,6 +64,8 @@ struct NetBase {
   // moves 64-byte segments at half the rate of >= 128-byte ones (tools/probes/fill_pattern_probe.hip: 29 vs 48-58 B/clk/CU).
   // Same offsets as wT; refreshed by sync_weights(); registered in ctx->kblk so that op_conv_fwd finds it by the plain weight's address.
   void* wK = nullptr; void* d_kb = nullptr; int n_kb = 0; long kb_chunks = 0;
+  // data-gradient copies [tap][Cout / 32][Cin][32] of the 3-tap weights whose data gradient fits the 192 x 256 tile (gemm_big.hip): same offsets, ctx->kblk_t
+  void* wKT = nullptr; void* d_kbt = nullptr; int n_kbt = 0; long kbt_chunks = 0;
   // dgamma / dbeta folds of a ResBlock's first GroupNorm, launched one block later on the side stream (see res_backward)
   struct GnFold { float* dgamma; float* dbeta; int C, region; };
   std::vector<GnFold> gn_pending; int gn_parity = 0;

@@ -30,6 +30,22 @@ int NetBase::bind(float* p, float* g) {
       for (const KbDesc& d : tab) ctx->kblk[W(d.off)] = (const char*)wK + (size_t)d.off * 2;
     }
   }
+  if (dtype != EEGLDM_F32 && !wKT && !no_kblk) {
+    std::vector<KbDesc> tab; long chunks = 0;
+    for (const Entry& e : entries) {
+      // data gradient as an NT product on the big tile: N = Cin a multiple of 256, K = Cout a multiple of 64
+      if (e.ndim != 3 || e.shape[2] != 3 || e.shape[1] % 256 != 0 || e.shape[0] % 64 != 0 || e.offset % 8 != 0) continue;
+      KbDesc d; d.off = e.offset; d.chunk0 = chunks; d.cout = e.shape[0]; d.cin = e.shape[1];
+      chunks += e.numel / 8; tab.push_back(d);
+    }
+    if (!tab.empty()) {
+      HIP_TRY(hipMalloc(&wKT, (size_t)nparams * 2));
+      HIP_TRY(hipMalloc(&d_kbt, tab.size() * sizeof(KbDesc)));
+      HIP_TRY(hipMemcpy(d_kbt, tab.data(), tab.size() * sizeof(KbDesc), hipMemcpyHostToDevice));
+      n_kbt = (int)tab.size(); kbt_chunks = chunks;
+      for (const KbDesc& d : tab) ctx->kblk_t[W(d.off)] = (const char*)wKT + (size_t)d.off * 2;
+    }
+  }
   return sync_weights();
 }
 int NetBase::flush_gn_folds() {
@@ -44,12 +60,20 @@ void NetBase::release_kblk() {
     if (v >= (const char*)wK && v < (const char*)wK + (size_t)nparams * 2) it = ctx->kblk.erase(it); else ++it;
   }
   (void)hipFree(wK); (void)hipFree(d_kb); wK = nullptr; d_kb = nullptr; n_kb = 0;
+  if (wKT) {
+    for (auto it = ctx->kblk_t.begin(); it != ctx->kblk_t.end();) {
+      const char* v = (const char*)it->second;
+      if (v >= (const char*)wKT && v < (const char*)wKT + (size_t)nparams * 2) it = ctx->kblk_t.erase(it); else ++it;
+    }
+    (void)hipFree(wKT); (void)hipFree(d_kbt); wKT = nullptr; d_kbt = nullptr; n_kbt = 0;
+  }
 }
 int NetBase::sync_weights() {
   EEG_CHECK(params, "bind parameters first");
   if (dtype == EEGLDM_F32) return 0;
   EEG_TRY(eegldm_cast(ctx, params, wT, nparams, dtype));
-  return kblk_pack(ctx, wT, wK, (const KbDesc*)d_kb, n_kb, kb_chunks);
+  EEG_TRY(kblk_pack(ctx, wT, wK, (const KbDesc*)d_kb, n_kb, kb_chunks));
+  return kblk_pack_t(ctx, wT, wKT, (const KbDesc*)d_kbt, n_kbt, kbt_chunks);
 }
 int entry_query(const NetBase* u, int i, char* name, int cap, long* offset, long* numel, int* ndim, int shape[3]) {
   EEG_CHECK(u && i >= 0 && i < (int)u->entries.size(), "entry index %d out of range", i);

@@ -69,6 +69,10 @@ int op_conv_dgrad(eegldm_ctx* ctx, int dtype, const void* dy, long lddy, const v
     // transposed conv as a stride-1 conv over the (virtually zero-upsampled) gradient, taps flipped
     a.amode = GA_CONV; a.tap_flip = 1; a.Lout = Lin; a.Lin = Lin; a.stride = 1; a.pad_l = K - 1 - pad_l;
     a.ups = stride; a.Lsrc = Lout;
+    if (dtype != EEGLDM_F32 && stride == 1 && !ctx->kblk_t.empty()) {      // [tap][Cout / 32][Cin][32] copy (NetBase::bind): the big-tile kernel runs the data gradient as an NT product
+      auto it = ctx->kblk_t.find(w);
+      if (it != ctx->kblk_t.end()) a.B_alt = it->second;
+    }
   }
   return gemm_launch(ctx, a);
 }
@@ -295,9 +299,17 @@ extern "C" int eegldm_conv1d_pack_kblocked(eegldm_ctx* ctx, const void* w, void*
   ctx->kblk[w] = w_kblocked;
   return 0;
 }
+extern "C" int eegldm_conv1d_pack_dgrad(eegldm_ctx* ctx, const void* w, void* w_t, int Cout, int Cin, int dtype) {
+  EEG_CHECK(ctx && w && w_t && w != w_t, "null or aliased pointer");
+  EEG_CHECK(dtype != EEGLDM_F32 && Cin > 0 && Cout > 0 && Cout % 32 == 0, "data-gradient weight copy: 16-bit dtype and Cout %% 32 == 0 (got dtype %d, Cout %d)", dtype, Cout);
+  EEG_CHECK(((size_t)w % 16 == 0) && ((size_t)w_t % 16 == 0), "weights must be 16-byte aligned");
+  EEG_TRY(kblk_pack_t_one(ctx, w, w_t, Cout, Cin));
+  ctx->kblk_t[w] = w_t;
+  return 0;
+}
 extern "C" int eegldm_conv1d_forget_kblocked(eegldm_ctx* ctx, const void* w) {
   EEG_CHECK(ctx && w, "null pointer");
-  ctx->kblk.erase(w);
+  ctx->kblk.erase(w); ctx->kblk_t.erase(w);
   return 0;
 }
 extern "C" int eegldm_conv1d_bwd_data(eegldm_ctx* ctx, const void* dy, long lddy, const void* w, void* dx, long lddx, int B, int Lin,
