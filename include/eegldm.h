@@ -276,6 +276,10 @@ int eegldm_aekl_forward(eegldm_aekl*, const float* x, const float* eps, float* r
                         float* kl, int B, int L);
 /* grads += d/dparams [ <d_recon, recon> + kl_weight * KL ]; dx nullable */
 int eegldm_aekl_backward(eegldm_aekl*, const float* d_recon, float kl_weight, float* dx);
+/* The same plus <d_mu, z_mu> + <d_sigma, z_sigma>: gradients a caller's own loss put on the z_mu / z_sigma tensors eegldm_aekl_forward
+ * returned (fp32 (B, lat, L/2^(levels-1)), each nullable) -- what an autograd engine hands back when the KL term is written with tensor
+ * ops on those outputs, as train_autoencoderkl.py:210-211 does (eegldm.autograd). */
+int eegldm_aekl_backward_ex(eegldm_aekl*, const float* d_recon, const float* d_mu, const float* d_sigma, float kl_weight, float* dx);
 
 /* ------------------------------------------------------------------ quality metrics (fp32 NCL tensors, results on the device)
  * 1-D multi-scale SSIM -- the reference's local adaptation of MONAI's MultiScaleSSIMMetric (compute_mmds.py:214-408; used with
@@ -341,7 +345,8 @@ long eegldm_disc_num_buffers(const eegldm_disc*);
 int eegldm_disc_buffer_entry(const eegldm_disc*, int i, char* name, int name_cap, long* offset, long* numel, int* ndim, int shape[3]);
 int eegldm_disc_bind(eegldm_disc*, float* params, float* grads, float* buffers);
 int eegldm_disc_sync_weights(eegldm_disc*);
-/* training != 0: batch statistics + running-stat update (momentum 0.1); else running statistics */
+/* training == 1: batch statistics + running-stat update (momentum 0.1); training == 2: batch statistics, running statistics left
+ * untouched (a re-forward of an earlier input for its backward); 0: running statistics */
 int eegldm_disc_forward(eegldm_disc*, const float* x, float* logits, int B, int L, int training);
 /* MONAI PatchDiscriminator.forward returns the list of per-block feature maps (callers index [-1] = the logits,
  * train_autoencoderkl.py:213).  Feature `index` (0 = initial conv + LeakyReLU, then one per conv + BatchNorm + LeakyReLU layer)

@@ -112,6 +112,7 @@ SIGNATURES = {
     "eegldm_aekl_decode": [_vp, _vp, _vp, _i, _i],
     "eegldm_aekl_forward": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i],
     "eegldm_aekl_backward": [_vp, _vp, _f, _vp],
+    "eegldm_aekl_backward_ex": [_vp, _vp, _vp, _vp, _f, _vp],
     "eegldm_ms_ssim_1d": [_vp, _vp, _vp, _vp, _i, _i, _i, C.POINTER(_f), _i, C.POINTER(_f), _i, _f, _f, _f],
     "eegldm_psd_multitaper": [_vp, _vp, _vp, C.POINTER(_f), _i, _f, _i, _vp, _i, _i],
     "eegldm_sample": [_vp, _vp, _vp, C.POINTER(C.c_int64), C.POINTER(_f), C.POINTER(_f), C.POINTER(_f), _i, _i, _i, _i, _f, C.c_uint64, _vp, _vp,

@@ -25,7 +25,7 @@ int ls_upsample2(eegldm_ctx*, const void* x, long ldx, void* y, long ldy, long r
 int ls_upsample2_bwd(eegldm_ctx*, const void* dy, long lddy, void* dx, long lddx, long rows_in, int C, int dtype);
 int ls_reparam(eegldm_ctx*, const void* mu, const void* lv, const float* eps, void* z, float* sigma, float* kl, long n, int B, int dtype);
 int ls_reparam_bwd(eegldm_ctx*, const void* mu, const void* lv, const float* eps, const float* sigma, const void* dz, void* dmu, void* dlv, long n,
-                   float klw_over_B, int dtype);
+                   float klw_over_B, int dtype, const float* dmu_ext = nullptr, const float* dsg_ext = nullptr, int lat = 1, int Ll = 1);
 
 namespace {
 
@@ -83,8 +83,9 @@ int SeqNet::forward_seq(const std::vector<Op>& ops, View x, int B, int& L, View*
       ALLOC_OR_FAIL(y.p, alloc_act((long)B * L, x.C)); y.ld = x.C; y.C = x.C;
       if (o.bn_w >= 0) {
         ALLOC_OR_FAIL(t.st, arena.alloc(sizeof(float) * 2 * x.C));
-        EEG_TRY(ls_bn_lrelu_fwd(ctx, x.p, x.ld, P(o.bn_w), P(o.bn_b), t.st, buffers ? buffers + o.rm : nullptr, buffers ? buffers + o.rv : nullptr,
-                                buffers ? buffers + o.nbt : nullptr, y.p, y.ld, (long)B * L, x.C, o.slope, training, dt));
+        const bool upd = buffers && training != 2;      // training == 2: batch statistics, running statistics left alone (a re-forward for a second backward)
+        EEG_TRY(ls_bn_lrelu_fwd(ctx, x.p, x.ld, P(o.bn_w), P(o.bn_b), t.st, upd ? buffers + o.rm : nullptr, upd ? buffers + o.rv : nullptr,
+                                upd ? buffers + o.nbt : nullptr, y.p, y.ld, (long)B * L, x.C, o.slope, training, dt));
       } else {
         EEG_TRY(ls_bn_lrelu_fwd(ctx, x.p, x.ld, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, y.p, y.ld, (long)B * L, x.C, o.slope, training, dt));
       }
@@ -570,13 +571,19 @@ extern "C" int eegldm_aekl_forward(eegldm_aekl* a, const float* x, const float* 
 }
 // grads += d/dparams [ <d_recon, recon> + kl_weight * KL ]; dx nullable
 extern "C" int eegldm_aekl_backward(eegldm_aekl* a, const float* d_recon, float kl_weight, float* dx) {
+  return eegldm_aekl_backward_ex(a, d_recon, nullptr, nullptr, kl_weight, dx);
+}
+// ... + <d_mu, z_mu> + <d_sigma, z_sigma>: gradients a caller's own loss put on the z_mu / z_sigma tensors eegldm_aekl_forward returned
+// (fp32 (B, lat, L / 2^(levels-1)), nullable) -- what torch.autograd hands back when the KL term is written with tensor ops on the
+// outputs, as train_autoencoderkl.py:210-211 does (eegldm.autograd)
+extern "C" int eegldm_aekl_backward_ex(eegldm_aekl* a, const float* d_recon, const float* d_mu, const float* d_sigma, float kl_weight, float* dx) {
   EEG_CHECK(a && d_recon, "null argument");
   EEG_CHECK(a->have_tape, "call eegldm_aekl_forward first");
   EEG_CHECK(a->grads, "no gradient buffer bound");
   a->have_tape = false;
   if (a->thin_tape) {
     a->thin_tape = false;
-    return thin_backward(a->ctx, a->thin, a->params, a->grads, d_recon, a->thin_eps, kl_weight / (float)a->B, dx, a->B);
+    return thin_backward(a->ctx, a->thin, a->params, a->grads, d_recon, a->thin_eps, kl_weight / (float)a->B, dx, a->B, d_mu, d_sigma);
   }
   eegldm_ctx* ctx = a->ctx; const int dt = a->dtype, lat = a->cfg.latent_channels, B = a->B, L = a->L, Ll = a->Ll, co = a->cfg.out_channels;
   View dy; ALLOC_OR_FAIL(dy.p, a->alloc_act((long)B * L, co)); dy.ld = co; dy.C = co;
@@ -586,7 +593,7 @@ extern "C" int eegldm_aekl_backward(eegldm_aekl* a, const float* d_recon, float 
   const long n = (long)B * Ll * lat;
   View dmu, dlv; ALLOC_OR_FAIL(dmu.p, a->alloc_act((long)B * Ll, lat)); ALLOC_OR_FAIL(dlv.p, a->alloc_act((long)B * Ll, lat));
   dmu.ld = dlv.ld = lat;
-  EEG_TRY(ls_reparam_bwd(ctx, a->mu.p, a->lv.p, a->eps_nlc, a->sigma, dz.p, dmu.p, dlv.p, n, kl_weight / (float)B, dt));
+  EEG_TRY(ls_reparam_bwd(ctx, a->mu.p, a->lv.p, a->eps_nlc, a->sigma, dz.p, dmu.p, dlv.p, n, kl_weight / (float)B, dt, d_mu, d_sigma, lat, Ll));
   const int ce = a->h_enc.C;
   EEG_TRY(op_conv_wgrad(ctx, dt, a->h_enc.p, a->h_enc.ld, dmu.p, lat, a->G(a->q_mu.w), a->G(a->q_mu.b), B, Ll, lat, lat, 1, 1, 0, 0));
   EEG_TRY(op_conv_wgrad(ctx, dt, a->h_enc.p, a->h_enc.ld, dlv.p, lat, a->G(a->q_lv.w), a->G(a->q_lv.b), B, Ll, lat, lat, 1, 1, 0, 0));

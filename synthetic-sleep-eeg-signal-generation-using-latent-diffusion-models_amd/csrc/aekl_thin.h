@@ -57,4 +57,4 @@ void thin_free(ThinProgram* p);
 int thin_forward(eegldm_ctx* ctx, const ThinProgram& p, const float* params, const float* x, const float* eps, float* recon, float* z_mu,
                  float* z_sigma, float* kl, int B);
 int thin_backward(eegldm_ctx* ctx, const ThinProgram& p, const float* params, float* grads, const float* d_recon, const float* eps,
-                  float klw_over_B, float* dx, int B);
+                  float klw_over_B, float* dx, int B, const float* dmu_ext = nullptr, const float* dsg_ext = nullptr);

@@ -434,7 +434,8 @@ __device__ void b_gn(const ThinOp& o, const float* P, float* G, const Bufs& B, c
 
 template <int LAT>
 __device__ void b_heads_t(const ThinOp& o, const float* P, float* __restrict__ G, const Bufs& B, const float* __restrict__ tape,
-                          const int* __restrict__ tape_off, const float* __restrict__ eps, float klw_over_B) {
+                          const int* __restrict__ tape_off, const float* __restrict__ eps, float klw_over_B,
+                          const float* __restrict__ dme, const float* __restrict__ dse) {      // dme / dse: external gradients on z_mu / z_sigma of this window (nullable)
   float* DZ = B.b[o.src]; float* DH = B.b[o.dst]; const float* H = B.b[o.act];
   const int L = o.Lin;
   const float* tmu = tape + tape_off[o.save]; const float* tlv = tape + tape_off[o.save + 1];
@@ -453,9 +454,9 @@ __device__ void b_heads_t(const ThinOp& o, const float* P, float* __restrict__ G
       const float lvc = fminf(20.f, fmaxf(-30.f, lv));
       const float sg = __expf(0.5f * lvc);
       const float e = eps ? eps[co * L + l] : 0.f;
-      dmu[co] = fmaf(klw_over_B, mu, dz);                       // z = mu + eps sigma ; KL: d/dmu = mu
-      // d/dlv: z -> dz * eps * sigma / 2 ; KL 0.5 (sigma^2 - lv - 1) -> 0.5 (sigma^2 - 1)
-      dlv[co] = inside ? fmaf(dz * e, 0.5f * sg, klw_over_B * 0.5f * (sg * sg - 1.0f)) : 0.f;
+      dmu[co] = fmaf(klw_over_B, mu, dz) + (dme ? dme[co * L + l] : 0.f);       // z = mu + eps sigma ; KL: d/dmu = mu
+      // d/dlv: z -> dz * eps * sigma / 2 ; KL 0.5 (sigma^2 - lv - 1) -> 0.5 (sigma^2 - 1) ; external d/dsigma -> * sigma / 2
+      dlv[co] = inside ? fmaf(dz * e + (dse ? dse[co * L + l] : 0.f), 0.5f * sg, klw_over_B * 0.5f * (sg * sg - 1.0f)) : 0.f;
     }
 #pragma unroll
     for (int co = 0; co < LAT; co++) {
@@ -480,10 +481,11 @@ __device__ void b_heads_t(const ThinOp& o, const float* P, float* __restrict__ G
   else if (t < NV) G[o.b2 + (t - 2 * LAT * LAT - LAT)] += R[t];
   lds_barrier();
 }
-__device__ void b_heads(const ThinOp& o, const float* P, float* G, const Bufs& B, const float* tape, const int* tape_off, const float* eps, float klw_over_B) {
-  if (o.cin == 1) b_heads_t<1>(o, P, G, B, tape, tape_off, eps, klw_over_B);
-  else if (o.cin == 2) b_heads_t<2>(o, P, G, B, tape, tape_off, eps, klw_over_B);
-  else if (o.cin == 4) b_heads_t<4>(o, P, G, B, tape, tape_off, eps, klw_over_B);
+__device__ void b_heads(const ThinOp& o, const float* P, float* G, const Bufs& B, const float* tape, const int* tape_off, const float* eps, float klw_over_B,
+                        const float* dme, const float* dse) {
+  if (o.cin == 1) b_heads_t<1>(o, P, G, B, tape, tape_off, eps, klw_over_B, dme, dse);
+  else if (o.cin == 2) b_heads_t<2>(o, P, G, B, tape, tape_off, eps, klw_over_B, dme, dse);
+  else if (o.cin == 4) b_heads_t<4>(o, P, G, B, tape, tape_off, eps, klw_over_B, dme, dse);
 }
 
 __device__ __forceinline__ Bufs make_bufs(char* smem, int maxt) {
@@ -544,7 +546,7 @@ __global__ __launch_bounds__(NT) void thin_bwd_kernel(const ThinOp* ops, int nop
                                                       int maxt, const float* P, float* __restrict__ G, const float* __restrict__ d_recon,
                                                       const float* __restrict__ eps, float* __restrict__ dx_out, const float* __restrict__ tape_all,
                                                       const float* __restrict__ stats_all, int lat, int Ll, float klw_over_B, int nparams, unsigned long long* __restrict__ prof,
-                                                      int sp_off, int nspare) {
+                                                      int sp_off, int nspare, const float* __restrict__ dmu_ext, const float* __restrict__ dsg_ext) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const Bufs B = make_bufs(smem, maxt);
   float* PL = B.red + RED_FLOATS;
@@ -638,7 +640,8 @@ __global__ __launch_bounds__(NT) void thin_bwd_kernel(const ThinOp* ops, int nop
         for (int j = threadIdx.x; j < (o.cin * o.Lin) >> 2; j += NT) D[j] = S[j];
         lds_barrier();
       } break;
-      case TB_HEADS: b_heads(o, P, G, B, tape, tape_off, eps ? eps + (size_t)b * lat * Ll : nullptr, klw_over_B); break;
+      case TB_HEADS: b_heads(o, P, G, B, tape, tape_off, eps ? eps + (size_t)b * lat * Ll : nullptr, klw_over_B,
+                             dmu_ext ? dmu_ext + (size_t)b * lat * Ll : nullptr, dsg_ext ? dsg_ext + (size_t)b * lat * Ll : nullptr); break;
       case TB_STOREDX: {
         if (dx_out) {
           const float* S = B.b[o.src]; float* D = dx_out + (size_t)b * o.cin * o.Lin;
@@ -717,13 +720,13 @@ int thin_forward(eegldm_ctx* ctx, const ThinProgram& p, const float* params, con
   return 0;
 }
 int thin_backward(eegldm_ctx* ctx, const ThinProgram& p, const float* params, float* grads, const float* d_recon, const float* eps, float klw_over_B,
-                  float* dx, int B) {
+                  float* dx, int B, const float* dmu_ext, const float* dsg_ext) {
   EEG_CHECK(p.d_bwd && p.tape && p.stats, "thin program not prepared");
   unsigned long long* prof = prof_buf();
   int sp_off = 0, nspare = 0;
   const size_t lds = lds_bytes_bwd(p, &sp_off, &nspare);
   hipLaunchKernelGGL(thin_bwd_kernel, dim3(B), dim3(NT), lds, ctx->stream, p.d_bwd, (int)p.bwd.size(), p.d_tape_off, p.tape_stride, p.nstat, p.maxt,
-                     params, grads, d_recon, eps, dx, p.tape, p.stats, p.lat, p.Ll, klw_over_B, p.nparams, prof, sp_off, nspare);
+                     params, grads, d_recon, eps, dx, p.tape, p.stats, p.lat, p.Ll, klw_over_B, p.nparams, prof, sp_off, nspare, dmu_ext, dsg_ext);
   LAUNCH_CHECK();
   if (prof) prof_dump(ctx, p.bwd, prof, "bwd");
   return 0;

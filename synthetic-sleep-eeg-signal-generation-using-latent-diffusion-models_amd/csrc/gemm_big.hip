@@ -48,7 +48,6 @@ static_assert(LDS_BYTES <= 160 * 1024, "tile does not fit the 160 KiB LDS");
 struct BigArgs {
   const bf16_t* A; long lda;
   const bf16_t* B; long ldb; long sBt;     // plain: [tap][N][K] (ldb = K stride of a row); K-blocked: [tap][K/32][N][32]
-  int tap_flip;                           // tap t reads weight slice 2 - t (data gradient)
   bf16_t* C; long ldc;
   int M, N, K, L;                         // L = rows per sample (conv zero padding at its edges); M % 192 == 0, L % 192 == 0, N % 256 == 0, K % 64 == 0
   const float* bias; const float* rowvec; long ld_rowvec; int rows_per_vec;
@@ -72,7 +71,7 @@ __device__ __forceinline__ void dma16s(const void* base, unsigned voff, unsigned
 }
 __device__ __forceinline__ int swz2(int row) { return 2 * ((row >> 1) & 3); }     // 16-byte slot ^= swz2(row) (128-byte rows)
 
-template <int TAPS, bool KBLK>      // TAPS = 3 only: with one tap every piece carries an A tile and the two-buffer A ring would be overwritten while it is read
+template <int TAPS, bool KBLK, bool FLIP>      // FLIP: tap t reads weight slice 2 - t (data gradient; also tells the two apart in a kernel trace).  TAPS = 3 only: with one tap every piece carries an A tile and the two-buffer A ring would be overwritten while it is read
 __global__ __launch_bounds__(NTHR, 2) void gemm_big_kernel(const BigArgs p) {
   static_assert(TAPS == 3, "ring layout assumes three pieces per A tile");
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -119,7 +118,7 @@ __global__ __launch_bounds__(NTHR, 2) void gemm_big_kernel(const BigArgs p) {
   // DMA instruction k of piece (s, t): k < 4 the B piece; 4..6 the A tile of stage s and 7 its halo rows (pieces with t == 0 only)
   auto issue = [&](int s, int t, int k) __attribute__((always_inline)) {
     if (k < 4) {
-      const int tw = p.tap_flip ? 2 - t : t;
+      const int tw = FLIP ? 2 - t : t;
       dma16s(b_base + s * bstep + tw * p.sBt, bo_src[k], lds0 + B0 + t * B_ALLOC + (wave_u + NWAVE * k) * 1024);
     } else if (k < 7) {
       dma16s(a_base + (long)s * BK, ao_src[k - 4], lds0 + (s & 1) * A_ALLOC + A_PAD + ROWB + (wave_u + NWAVE * (k - 4)) * 1024);
@@ -261,9 +260,9 @@ __global__ __launch_bounds__(NTHR, 2) void gemm_big_kernel(const BigArgs p) {
   for (int cc = 0; cc < NIT; cc++) *(uint4*)(p.C + (long)(m0 + r0 + cc * RSTEP) * p.ldc + n0 + cs8 * 8) = v8[cc];
 }
 
-template <int TAPS, bool KBLK>
+template <int TAPS, bool KBLK, bool FLIP>
 int launch_big(eegldm_ctx* ctx, const BigArgs& a) {
-  auto kern = gemm_big_kernel<TAPS, KBLK>;
+  auto kern = gemm_big_kernel<TAPS, KBLK, FLIP>;
   static int attr_dev = -1;      // the dynamic-LDS attribute is per device
   if (attr_dev != ctx->device) {
     HIP_TRY(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
@@ -296,11 +295,12 @@ int gemm_big_try(eegldm_ctx* ctx, const GemmArgs& g) {
   const int tm = g.M / BM, tn = g.N / BN;
   if ((long)tm * tn < min_tiles) return 0;         // small problems: the 128-row tiles fill the chip better
   BigArgs a;
-  a.A = (const bf16_t*)g.A; a.lda = g.lda; a.B = (const bf16_t*)g.B; a.ldb = g.ldb; a.sBt = g.sBt; a.tap_flip = g.tap_flip;
+  a.A = (const bf16_t*)g.A; a.lda = g.lda; a.B = (const bf16_t*)g.B; a.ldb = g.ldb; a.sBt = g.sBt;
   a.C = (bf16_t*)g.C; a.ldc = g.ldc; a.M = g.M; a.N = g.N; a.K = g.K; a.L = L;
   a.bias = g.bias; a.rowvec = g.rowvec; a.ld_rowvec = g.ld_rowvec; a.rows_per_vec = g.rows_per_vec > 0 ? g.rows_per_vec : 1;
   a.resid = (const bf16_t*)g.resid; a.ldr = g.ldr; a.zero_page = ctx->zero_page; a.tiles_m = tm; a.tiles_n = tn;
   int rc;
-  rc = g.b_kblk ? launch_big<3, true>(ctx, a) : launch_big<3, false>(ctx, a);
+  if (g.tap_flip) rc = g.b_kblk ? launch_big<3, true, true>(ctx, a) : launch_big<3, false, true>(ctx, a);
+  else rc = g.b_kblk ? launch_big<3, true, false>(ctx, a) : launch_big<3, false, false>(ctx, a);
   return rc < 0 ? rc : 1;
 }

@@ -290,14 +290,24 @@ __global__ __launch_bounds__(NT) void reparam_kernel(const T* __restrict__ mu, c
     if (threadIdx.x == 0) atomicAdd(kl, (red[0] + red[1] + red[2] + red[3]) * inv_B);
   }
 }
-// dmu = dz + klw*mu/B ; dlv = [ -30 < lv < 20 ] * (dz*eps + klw*(sigma - 1/sigma)/B) * sigma/2
+// dmu = dz + klw*mu/B [+ dmu_ext] ; dlv = [ -30 < lv < 20 ] * (dz*eps + klw*(sigma - 1/sigma)/B [+ dsigma_ext]) * sigma/2
+// dmu_ext / dsg_ext (nullable): gradients a caller's own loss put on the returned z_mu / z_sigma tensors, fp32 (B, lat, Ll) -- the
+// autograd bridge (eegldm_aekl_backward_ex); element i of the NLC tensors is (row = i / lat, channel = i % lat)
 template <typename T>
 __global__ void reparam_bwd_kernel(const T* __restrict__ mu, const T* __restrict__ lv, const float* __restrict__ eps, const float* __restrict__ sigma,
-                                   const T* __restrict__ dz, T* __restrict__ dmu, T* __restrict__ dlv, long n, float klw_over_B) {
+                                   const T* __restrict__ dz, T* __restrict__ dmu, T* __restrict__ dlv, long n, float klw_over_B,
+                                   const float* __restrict__ dmu_ext, const float* __restrict__ dsg_ext, int lat, int Ll) {
   GRID_STRIDE(i, n) {
     const float d = dz ? ld_f32(dz + i) : 0.f, m = ld_f32(mu + i), l = ld_f32(lv + i), sg = sigma[i];
-    st_f32(dmu + i, d + klw_over_B * m);
-    const float dsg = d * (eps ? eps[i] : 0.f) + klw_over_B * (sg - 1.0f / sg);
+    float em = 0.f, es = 0.f;
+    if (dmu_ext || dsg_ext) {
+      const long row = i / lat; const int c = (int)(i - row * lat); const long b = row / Ll; const int pos = (int)(row - b * Ll);
+      const long e = (b * lat + c) * Ll + pos;
+      if (dmu_ext) em = dmu_ext[e];
+      if (dsg_ext) es = dsg_ext[e];
+    }
+    st_f32(dmu + i, d + klw_over_B * m + em);
+    const float dsg = d * (eps ? eps[i] : 0.f) + klw_over_B * (sg - 1.0f / sg) + es;
     st_f32(dlv + i, (l > -30.0f && l < 20.0f) ? dsg * sg * 0.5f : 0.f);
   }
 }
@@ -446,9 +456,9 @@ int ls_reparam(eegldm_ctx* ctx, const void* mu, const void* lv, const float* eps
   LAUNCH_CHECK(); return 0;
 }
 int ls_reparam_bwd(eegldm_ctx* ctx, const void* mu, const void* lv, const float* eps, const float* sigma, const void* dz, void* dmu, void* dlv, long n,
-                   float klw_over_B, int dtype) {
+                   float klw_over_B, int dtype, const float* dmu_ext, const float* dsg_ext, int lat, int Ll) {
   DISPATCH_T(dtype, hipLaunchKernelGGL((reparam_bwd_kernel<T>), dim3(grid1d(n, ctx)), dim3(NT), 0, ctx->stream, (const T*)mu, (const T*)lv, eps, sigma, (const T*)dz,
-                                       (T*)dmu, (T*)dlv, n, klw_over_B));
+                                       (T*)dmu, (T*)dlv, n, klw_over_B, dmu_ext, dsg_ext, lat, Ll));
   LAUNCH_CHECK(); return 0;
 }
 

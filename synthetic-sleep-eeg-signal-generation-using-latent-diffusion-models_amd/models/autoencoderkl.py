@@ -9,9 +9,10 @@ import torch
 
 from .._lib import lib, check, ptr, default_context, AeklCfg, DiscCfg
 from ._flat import DT, read_entries, unpack, pack_into
+from ..autograd import FlatModule, _AeklFn, _DiscFn
 
 
-class _Flat:
+class _Flat(FlatModule):
     def _init_flat(self, n_params):
         self.flat = torch.zeros(n_params, device=self.device, dtype=torch.float32)
         self.flat_grad = torch.zeros(n_params, device=self.device, dtype=torch.float32)
@@ -22,9 +23,6 @@ class _Flat:
 
     def grad_dict(self):
         return unpack(self.flat_grad, self.entries)
-
-    def parameters(self):
-        return [self.flat]
 
     def zero_grad(self, set_to_none=True):
         self.flat_grad.zero_()
@@ -91,10 +89,11 @@ class AutoencoderKL(_Flat):
 
     def load_state_dict(self, sd, strict=True):
         pack_into(self.flat, self.entries, sd, strict)
-        check(lib.eegldm_aekl_sync_weights(self.h))
+        self.sync_weights()
 
     def sync_weights(self):
         check(lib.eegldm_aekl_sync_weights(self.h))
+        self._mark_synced()
 
     def _x(self, x):
         return x.to(self.device, torch.float32).contiguous()
@@ -150,6 +149,9 @@ class AutoencoderKL(_Flat):
         return self.decode(mu)
 
     def forward(self, x, eps=None, kl_out=None):
+        """(reconstruction, z_mu, z_sigma) as the reference's call at train_autoencoderkl.py:204.  With a torch optimizer on `parameters()`
+        the three outputs carry a grad_fn (eegldm.autograd): the KL written with tensor ops on z_mu / z_sigma (train_autoencoderkl.py:210-211)
+        back-propagates through the native backward."""
         x = self._win(x, self.in_channels); B, _c, L = x.shape
         if B == 0:
             e = torch.empty(0, self.latent_channels, L // self.down, device=self.device)
@@ -157,6 +159,13 @@ class AutoencoderKL(_Flat):
         if eps is None:
             eps = torch.randn(B, self.latent_channels, L // self.down, device=self.device)
         eps = self._x(eps)
+        self._sync_if_stale()
+        if kl_out is None and self.training and self._wants_graph(x):
+            return _AeklFn.apply(self, x, eps, self._flat_param())
+        return self._forward_native(x, eps, kl_out)
+
+    def _forward_native(self, x, eps, kl_out=None):
+        B, _c, L = x.shape
         recon = torch.empty(B, self.out_channels, L, device=self.device)
         mu = torch.empty(B, self.latent_channels, L // self.down, device=self.device); sg = torch.empty_like(mu)
         check(lib.eegldm_aekl_forward(self.h, ptr(x), ptr(eps), ptr(recon), ptr(mu), ptr(sg), ptr(kl_out), B, L))
@@ -221,10 +230,11 @@ class PatchDiscriminator(_Flat):
         for k, (o, n, _s) in self.buf_entries.items():
             if k in sd:
                 self.buffers[o:o + n].copy_(torch.as_tensor(sd[k]).to(torch.float32).reshape(-1).to(self.device))
-        check(lib.eegldm_disc_sync_weights(self.h))
+        self.sync_weights()
 
     def sync_weights(self):
         check(lib.eegldm_disc_sync_weights(self.h))
+        self._mark_synced()
 
     def forward(self, x, features=True):
         """The reference's return value: the list of per-block feature maps -- initial conv + LeakyReLU, one per conv + BatchNorm +
@@ -232,11 +242,11 @@ class PatchDiscriminator(_Flat):
         copied out of the native forward's tape as fp32 (B, C, L) tensors; `features=False` skips those copies and leaves None in
         their places (the train step itself is one native call and never comes through here)."""
         x = x.to(self.device, torch.float32).contiguous(); B, _c, L = x.shape
-        Lo = L
-        for _ in range(self.num_layers_d):
-            Lo = (Lo + 2 * self.padding - self.kernel_size) // 2 + 1          # initial + (num_layers_d - 1) stride-2 convs; the rest keep L
-        logits = torch.empty(B, self.out_channels, Lo, device=self.device)
-        check(lib.eegldm_disc_forward(self.h, ptr(x), ptr(logits), B, L, 1 if self.training else 0))
+        self._sync_if_stale()
+        if self._wants_graph(x):            # the logits carry a grad_fn (the feature maps below are copies, as before)
+            logits = _DiscFn.apply(self, x, self._flat_param())
+        else:
+            logits = self._forward_native(x, 1 if self.training else 0)
         feats = [None] * (self.num_layers_d + 1)
         if features:
             Cc, Lf = C.c_int(), C.c_int()
@@ -248,6 +258,15 @@ class PatchDiscriminator(_Flat):
         return feats + [logits]
 
     __call__ = forward
+
+    def _forward_native(self, x, training):
+        B, _c, L = x.shape
+        Lo = L
+        for _ in range(self.num_layers_d):
+            Lo = (Lo + 2 * self.padding - self.kernel_size) // 2 + 1          # initial + (num_layers_d - 1) stride-2 convs; the rest keep L
+        logits = torch.empty(B, self.out_channels, Lo, device=self.device)
+        check(lib.eegldm_disc_forward(self.h, ptr(x), ptr(logits), B, L, int(training)))
+        return logits
 
     def backward(self, dlogits, need_dx=False, param_grads=True, in_shape=None):
         d = dlogits.to(self.device, torch.float32).contiguous()

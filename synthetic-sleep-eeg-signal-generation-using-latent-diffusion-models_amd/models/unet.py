@@ -3,9 +3,11 @@
 `forward(x, timesteps=...)`, same 278-key `state_dict()`), executing on the
 hand-written HIP kernels of libeegldm.so through the C ABI.
 
-torch is used for device memory only.  There is no autograd graph: call
-`backward(dy)` (or use eegldm.training.ldm_train_step, which fuses add_noise +
-forward + MSE + backward in one native call).
+torch is used for device memory only.  Two ways to train: the fused native step
+(eegldm.training.ldm_train_step: add_noise + forward + MSE + backward in one call, the
+fast path), or -- once `parameters()` has been handed to a torch optimizer -- the
+reference's own loop body: `model(x=..., timesteps=...)` then returns a tensor with a
+grad_fn whose backward is the hand-written native backward (eegldm.autograd).
 """
 import ctypes as C
 import math
@@ -14,12 +16,13 @@ from collections import OrderedDict
 import torch
 
 from .._lib import lib, check, ptr, default_context, UNetCfg, F32, BF16
+from ..autograd import FlatModule, _UNetFn
 
 _DT = {"float32": F32, "fp32": F32, torch.float32: F32, "bfloat16": BF16, "bf16": BF16, torch.bfloat16: BF16, F32: F32, BF16: BF16}
 _ZERO_INIT_SUFFIX = ("out_layers.3.weight", "out_layers.3.bias", "proj_out.weight", "proj_out.bias", "out.2.weight", "out.2.bias")
 
 
-class UNetModel:
+class UNetModel(FlatModule):
     def __init__(self, image_size, in_channels, model_channels, out_channels, num_res_blocks, attention_resolutions,
                  dropout=0, channel_mult=(1, 2, 4, 8), conv_resample=True, num_classes=None, num_heads=1,
                  num_head_channels=-1, num_heads_upsample=-1, use_scale_shift_norm=False, resblock_updown=False,
@@ -115,9 +118,7 @@ class UNetModel:
 
     def sync_weights(self):
         check(lib.eegldm_unet_sync_weights(self.h))
-
-    def parameters(self):
-        return [self.flat]
+        self._mark_synced()
 
     def zero_grad(self, set_to_none=True):
         self.flat_grad.zero_()
@@ -144,9 +145,8 @@ class UNetModel:
             raise ValueError(f"UNetModel was built with in_channels={self.in_channels}, got x with {Cc} channels")
         if tuple(t.shape) != (B,):
             raise ValueError(f"timesteps must have shape ({B},) to match the batch, got {tuple(t.shape)}")
-        out = torch.empty(B, self.out_channels, L, device=self.device, dtype=torch.float32)
         if B == 0:
-            return out                                   # empty batch in, empty batch out (as the reference modules do)
+            return torch.empty(B, self.out_channels, L, device=self.device, dtype=torch.float32)      # empty batch in, empty batch out (as the reference modules do)
         levels = len(self.channel_mult)
         if L % (1 << (levels - 1)) != 0:
             raise ValueError(f"L={L} must be divisible by {1 << (levels - 1)} (one halving per resolution level; the reference's "
@@ -156,6 +156,14 @@ class UNetModel:
             if (1 << lvl) in self.attention_resolutions and (L >> lvl) % vec != 0:
                 raise ValueError(f"attention at downsample rate {1 << lvl} sees T={L >> lvl} positions; this engine needs T to be a "
                                  f"multiple of {vec} ({'fp32' if vec == 4 else 'bf16'}): use L divisible by {vec << lvl}")
+        self._sync_if_stale()                            # a torch optimizer updated the flat parameter in place: refresh the compute copies
+        if self.training and self._wants_graph(x):
+            return _UNetFn.apply(self, x, t, self._flat_param())
+        return self._forward_native(x, t)
+
+    def _forward_native(self, x, t):
+        B, _c, L = x.shape
+        out = torch.empty(B, self.out_channels, L, device=self.device, dtype=torch.float32)
         check(lib.eegldm_unet_forward(self.h, ptr(x), ptr(t), ptr(out), B, L, 1 if self.training else 0))
         return out
 

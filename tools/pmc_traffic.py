@@ -22,7 +22,7 @@ import re
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-RND = os.environ.get("EEGLDM_PROFILE_ROUND", "r03")        # prefix of the files written under profiles/
+RND = os.environ.get("EEGLDM_PROFILE_ROUND", "r04")        # prefix of the files written under profiles/
 GEMM = {("1", "0", "3"): "conv3_fwd_implicit_gemm", ("1", "1", "3"): "conv3_dgrad_implicit_gemm", ("2", "1", "3"): "conv_wgrad_splitk_gemm",
         ("0", "0", "1"): "gemm_nt", ("0", "1", "1"): "gemm_nn", ("2", "1", "1"): "gemm_tn"}
 
@@ -42,6 +42,10 @@ def family(name):
     m = re.search(r"conv3_ws_kernel<(\w+)>", name)      # weight-stationary 3-tap conv (conv_ws.hip): forward / data gradient
     if m:
         return ("conv3_dgrad_implicit_gemm" if m.group(1) in ("true", "1") else "conv3_fwd_implicit_gemm"), True
+    m = re.search(r"gemm_big_kernel<([^>]*)>", name)      # 192 x 256 tile (gemm_big.hip): <TAPS, KBLK, FLIP>, FLIP = data gradient
+    if m:
+        a = [x.strip() for x in m.group(1).split(",")]
+        return ("conv3_dgrad_implicit_gemm" if a[2] in ("true", "1") else "conv3_fwd_implicit_gemm"), True
     m = re.search(r"gemm_kernel<([^>]*)>", name)
     if m:
         a = [x.strip() for x in m.group(1).split(",")]
