@@ -10,6 +10,7 @@ struct TimerState { hipEvent_t a = nullptr, b = nullptr; };
 static thread_local TimerState g_timer;
 
 int g_eeg_env_epoch = 0;
+int g_eeg_live_ctx = 0;
 bool eeg_deterministic() { EEG_ENV_VAR(bool, det, getenv("EEGLDM_DETERMINISTIC") && atoi(getenv("EEGLDM_DETERMINISTIC")) != 0); return det; }
 extern "C" int eegldm_abi_version(void) { return EEGLDM_ABI_VERSION; }
 extern "C" int eegldm_debug_reload_env(void) { return ++g_eeg_env_epoch; }
@@ -49,6 +50,7 @@ extern "C" int eegldm_ctx_create(int device, void* stream, int own_stream, eegld
   }
   HIP_TRY(hipMalloc(&c->zero_page, zp_bytes));
   HIP_TRY(hipMemset(c->zero_page, 0, zp_bytes));
+  g_eeg_live_ctx++;
   *out = c;
   return 0;
 }
@@ -79,6 +81,7 @@ extern "C" int eegldm_ctx_destroy(eegldm_ctx* c) {
   if (c->owns_stream) hipStreamDestroy(c->stream);
   if (c->side) { hipStreamDestroy(c->side); hipEventDestroy(c->ev_fork); hipEventDestroy(c->ev_join); }
   delete c;
+  if (g_eeg_live_ctx > 0) g_eeg_live_ctx--;
   return 0;
 }
 extern "C" int eegldm_ctx_sync(eegldm_ctx* c) {

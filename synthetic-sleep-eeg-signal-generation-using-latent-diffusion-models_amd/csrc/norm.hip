@@ -781,7 +781,9 @@ int gn_bwd_t(eegldm_ctx* ctx, const void* x, long ldx, const float* gamma, const
     // unfinished LDS atomics were ruled out (tools/probes/lds_dma_stomp_probe*.hip); the cause is open.  At step level the narrow
     // blocks no longer gain anything either (19.76 vs 19.67 ms), so the default stays at 1024 threads.
     // (narrow blocks only while nothing of this library runs beside them: never with the opt-in side stream)
-    const int nth = ((bwd_nth == 512 || bwd_nth == 256) && !ctx->side_on) ? bwd_nth : 1024;
+    // FENCE (tests/test_gpu_concurrency.py pins it): narrow blocks are refused whenever anything of this library can run beside
+    // them -- the opt-in side stream, or a second live context in this process (g_eeg_live_ctx, api.hip)
+    const int nth = ((bwd_nth == 512 || bwd_nth == 256) && !ctx->side_on && g_eeg_live_ctx <= 1) ? bwd_nth : 1024;
     int rpt = 0; int cc = off ? 0 : resident_chunk(L, C, G, 0, sizeof(T) == 2 ? 12 : 8, &rpt, nth);
     // measured (tools/debug/gn_bench.py): the one-pass kernel wins while its blocks fit two rounds of one block per CU
     // (1024 blocks: 112 us one-pass vs 117-120 us split on the 100 MB tensors; 2048 blocks of 96-channel chunks lose)

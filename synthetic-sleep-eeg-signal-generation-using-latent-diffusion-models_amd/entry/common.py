@@ -166,6 +166,6 @@ class WindowLoader:
 
 def rng_seed(base_seed, role, rank=0, world=1):
     """Distinct Philox key per (role, rank): base * 2^20 + role * 4096 + rank.  Roles: 1 timesteps, 2 posterior eps, 3 diffusion
-    noise, 4 autoencoder eps.  (seed + role + rank collides across ranks: rank r's noise stream == rank r+1's eps stream.)"""
+    noise, 4 autoencoder eps, 5-7 validation draws, 8 training loader (crop / shuffle / synthetic windows), 9 validation loader.  (seed + role + rank collides across ranks: rank r's noise stream == rank r+1's eps stream.)"""
     assert 0 <= rank < 4096 and 0 <= role < 256
     return (int(base_seed) << 20) + (int(role) << 12) + int(rank)

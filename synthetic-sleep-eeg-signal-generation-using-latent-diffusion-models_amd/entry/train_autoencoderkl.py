@@ -54,24 +54,30 @@ def main(args):
     adv_w, kl_w = config.models.adv_weight, config.models.kl_weight
     spec_w = config.models.get("spectral_weight", 0.0)
     bs = max(1, config.train.batch_size // world)
-    train = WindowLoader(args.path_pre_processed, bs, args.synthetic_windows, seed=config.train.seed + rank, drop_last=config.train.drop_last,
+    train = WindowLoader(args.path_pre_processed, bs, args.synthetic_windows, seed=rng_seed(config.train.seed, 8, rank, world), drop_last=config.train.drop_last,
                          path_ids=args.path_train_ids, dataset=args.type_dataset, shard=(rank, world))
     # validation reads the VALID split (dataset.py:83-99); without id CSVs (synthetic / bare directory runs) it is a held-out synthetic set
     # or, as a last resort, the same directory.  Every rank scores its shard; (sum, count) are added over ranks
     val = WindowLoader(args.path_pre_processed, bs, max(args.synthetic_windows // 4, config.train.batch_size) // world if args.synthetic_windows else 0,
-                       seed=config.train.seed + 1 + 7919 * rank, shuffle=False, path_ids=args.path_valid_ids, dataset=args.type_dataset, shard=(rank, world))
+                       seed=rng_seed(config.train.seed, 9, rank, world), shuffle=False, path_ids=args.path_valid_ids, dataset=args.type_dataset, shard=(rank, world))
     start_epoch, best, steps = 0, float("inf"), 0
+    init_batch = None
     if resume:
         ck = torch.load(os.path.join(run_dir, "checkpoint.pth"), map_location="cpu")
         model.load_state_dict(ck["state_dict"]); disc.load_state_dict(ck["discriminator"])
         opt_g.load_state_dict(ck["optimizer_g"]); opt_d.load_state_dict(ck["optimizer_d"])
         start_epoch, best = ck["epoch"], ck["best_loss"]
         steps = int(ck.get("steps", 0))       # global step = the RNG offset of the reparameterisation noise: a resumed run must not replay it
+        init_batch = ck.get("init_batch")     # written by the reference (train_autoencoderkl.py:327) and read unconditionally on its resume (:182)
     # identical replicas: parameters of both networks and the discriminator's BatchNorm running statistics come from rank 0
     D.broadcast_flat(model.flat); model.sync_weights()
     D.broadcast_flat(disc.flat); D.broadcast_flat(disc.buffers); disc.sync_weights()
     dev, ctx = model.device, model.ctx
     losses = torch.zeros(6, device=dev)
+    if init_batch is None:                    # first(train_loader)['eeg'][:, :, 36:-36] (train_autoencoderkl.py:188): the batch the reference logs reconstructions of
+        for b0 in train:
+            init_batch = b0["eeg"][:, :, 36:-36].clone().cpu()
+            break
     t0, seen, steps_run = time.time(), 0, 0
     s_eps = rng_seed(config.train.seed, 4, rank, world)
     for epoch in range(start_epoch, config.train.n_epochs):
@@ -107,7 +113,7 @@ def main(args):
                     torch.save({k: v.cpu() for k, v in model.state_dict().items()}, os.path.join(run_dir, "best_model.pth"))
                 torch.save({"epoch": epoch + 1, "state_dict": {k: v.cpu() for k, v in model.state_dict().items()},
                             "discriminator": {k: v.cpu() for k, v in disc.state_dict().items()}, "optimizer_g": opt_g.state_dict(),
-                            "optimizer_d": opt_d.state_dict(), "best_loss": best, "steps": steps}, os.path.join(run_dir, "checkpoint.pth"))
+                            "optimizer_d": opt_d.state_dict(), "best_loss": best, "init_batch": init_batch, "steps": steps}, os.path.join(run_dir, "checkpoint.pth"))
             best = D.broadcast_scalar(best, src=0, like=losses)
         if args.max_steps and steps_run >= args.max_steps:
             break

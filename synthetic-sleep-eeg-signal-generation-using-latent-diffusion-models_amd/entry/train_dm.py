@@ -41,7 +41,7 @@ def main(args):
     opt = Adam(unet, lr=1e-4)
     spectral = args.spe == "spectral"
     bs = max(1, config.train.batch_size // world)
-    train = WindowLoader(args.path_pre_processed, bs, args.synthetic_windows, seed=config.train.seed + rank, drop_last=config.train.drop_last,
+    train = WindowLoader(args.path_pre_processed, bs, args.synthetic_windows, seed=rng_seed(config.train.seed, 8, rank, world), drop_last=config.train.drop_last,
                          path_ids=args.path_train_ids, dataset=args.type_dataset, shard=(rank, world))
     s_t, s_noise = rng_seed(config.train.seed, 1, rank, world), rng_seed(config.train.seed, 3, rank, world)
     dev, ctx = unet.device, unet.ctx

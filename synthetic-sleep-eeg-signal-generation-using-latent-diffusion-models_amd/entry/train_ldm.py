@@ -87,11 +87,11 @@ def main(args):
     opt = Adam(unet, lr=config.train.get("base_lr", 1e-4))
     scaler = GradScaler(enabled=args.grad_scaler)
     bs = max(1, config.train.batch_size // world)
-    train = WindowLoader(args.path_pre_processed, bs, args.synthetic_windows, seed=config.train.seed + rank, drop_last=config.train.drop_last,
+    train = WindowLoader(args.path_pre_processed, bs, args.synthetic_windows, seed=rng_seed(config.train.seed, 8, rank, world), drop_last=config.train.drop_last,
                          path_ids=args.path_train_ids, dataset=args.type_dataset, shard=(rank, world))
     # validation: every rank scores its own shard (equal lengths, wrap-around: a recording may be scored twice when N % world != 0)
     # and the (sum, count) pairs are added over ranks -- model selection sees the WHOLE validation split, as the reference's does
-    valid = WindowLoader(args.path_pre_processed, bs, 0, seed=config.train.seed + 7919, shuffle=False, path_ids=args.path_valid_ids,
+    valid = WindowLoader(args.path_pre_processed, bs, 0, seed=rng_seed(config.train.seed, 9, 0, world), shuffle=False, path_ids=args.path_valid_ids,
                          dataset=args.type_dataset, shard=(rank, world)) if args.path_valid_ids else None
     v_seeds = tuple(rng_seed(config.train.seed, role, rank, world) for role in (5, 6, 7))
     s_t, s_eps, s_noise = (rng_seed(config.train.seed, role, rank, world) for role in (1, 2, 3))

@@ -1,0 +1,63 @@
+"""-m gpu: the one-pass GroupNorm backward beside the library's own LDS-DMA weight-gradient GEMM on ANOTHER context / stream.
+
+Round 3 found (tools/debug/gn_conc2.py .. gn_conc4.py, DESIGN.md "concurrent-kernel hazard") that the NARROW-block variant of
+gn_bwd_resident (256 / 512 threads, opt-in through EEGLDM_GN_BWD_NTH) returns group sums that are off by one contribution per reduction
+when it shares a CU with the fused 3-tap weight-gradient kernel (LDS-DMA build) of another stream; the cause is open.  The fence, pinned here:
+  * the default 1024-thread blocks own a CU -- results beside the noisy neighbour are BIT-identical to a quiet run;
+  * with a second context alive (or the side stream on) the library refuses the narrow blocks whatever EEGLDM_GN_BWD_NTH says, so the same
+    bit-identity holds with the switch set."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _scenario(neighbour="wgrad"):
+    import eegldm
+    from eegldm._lib import lib, ptr, check, Context
+    ctx = eegldm.default_context(0)
+    ctx2 = Context(0, use_torch_stream=False)          # second live context with its own stream
+    torch.manual_seed(0)
+    B, Lw, Cw = 256, 192, 512
+    xw = torch.randn(B * Lw, Cw, device="cuda").bfloat16(); dyw = torch.randn(B * Lw, Cw, device="cuda").bfloat16()
+    dw = torch.zeros(3 * Cw * Cw, device="cuda"); dbw = torch.zeros(Cw, device="cuda")
+    ww = (torch.randn(3, Cw, Cw, device="cuda") * 0.02).bfloat16(); yw = torch.empty(B * Lw, Cw, device="cuda", dtype=torch.bfloat16)
+    bad = []
+    for (L, C) in [(192, 512), (384, 256), (768, 128)]:
+        R = B * L
+        x = torch.randn(R, C, device="cuda").bfloat16(); dy = torch.randn(R, C, device="cuda").bfloat16(); ad = torch.randn(R, C, device="cuda").bfloat16()
+        ga = torch.rand(C, device="cuda") + 0.5; be = torch.randn(C, device="cuda"); st = torch.empty(B * 32 * 2, device="cuda"); y = torch.empty_like(x)
+        check(lib.eegldm_groupnorm_fwd(ctx.h, ptr(x), C, ptr(ga), ptr(be), ptr(y), C, ptr(st), B, L, C, 32, 1e-6, 1, 0, None, 0, 1))
+
+        def run(noise):
+            dx = torch.empty_like(x); dg = torch.zeros(C, device="cuda"); db = torch.zeros(C, device="cuda")
+            torch.cuda.synchronize(); ctx2.sync()
+            if noise:
+                for _ in range(12):
+                    if neighbour == "wgrad":
+                        check(lib.eegldm_conv1d_bwd_weight(ctx2.h, ptr(xw), Cw, ptr(dyw), Cw, ptr(dw), ptr(dbw), B, Lw, Cw, Cw, 3, 1, 1, 1, 1))
+                    else:       # the 192 x 256 big-tile conv forward (gemm_big.hip: 148 KB of LDS, all of it filled by LDS-DMA)
+                        check(lib.eegldm_conv1d_fwd(ctx2.h, ptr(xw), Cw, ptr(ww), None, ptr(yw), Cw, B, Lw, Cw, Cw, 3, 1, 1, 1, None, 0, None, 0, 1))
+            for _ in range(8):
+                check(lib.eegldm_groupnorm_bwd(ctx.h, ptr(x), C, ptr(ga), ptr(be), ptr(st), ptr(dy), C, ptr(dx), C, ptr(dg), ptr(db), B, L, C, 32, 1, 0, ptr(ad), C, 1))
+            torch.cuda.synchronize(); ctx2.sync()
+            return dx, dg
+        quiet, qg = run(False)
+        for k in range(3):
+            dx, dg = run(True)
+            nd = int((quiet.view(torch.int16) != dx.view(torch.int16)).sum())
+            rel = float((dg - qg).norm() / qg.norm())
+            if nd or rel > 1e-6:
+                bad.append((L, C, k, nd, rel))
+    del ctx2
+    return bad
+
+
+@pytest.mark.parametrize("neighbour", ["wgrad", "conv_big"])
+def test_default_groupnorm_backward_is_bit_exact_beside_the_lds_dma_gemms_of_another_context(neighbour):
+    assert _scenario(neighbour) == []
+
+
+def test_narrow_blocks_are_refused_while_a_second_context_is_alive(env_switches):
+    env_switches(EEGLDM_GN_BWD_NTH="256")
+    assert _scenario() == []

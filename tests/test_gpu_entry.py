@@ -39,7 +39,8 @@ def test_train_aekl_train_ldm_sample(tmp_path):
     for f in ("best_model.pth", "checkpoint.pth", "final_model.pth"):
         assert os.path.exists(os.path.join(run_a, f))
     ck = torch.load(os.path.join(run_a, "checkpoint.pth"))
-    assert set(ck) >= {"epoch", "state_dict", "discriminator", "optimizer_g", "optimizer_d", "best_loss"}      # train_autoencoderkl.py:320-328
+    assert set(ck) >= {"epoch", "state_dict", "discriminator", "optimizer_g", "optimizer_d", "best_loss", "init_batch"}      # train_autoencoderkl.py:320-328
+    assert tuple(ck["init_batch"].shape[1:]) == (1, 3000)      # first(train_loader)['eeg'][:, :, 36:-36] (:188); the reference's resume reads it unconditionally (:182)
     # resume path
     TA.main(TA.parse_args(["--config_file", a_yaml, "--spe", "spectral", "--synthetic_windows", "16", "--latent_channels", "1"]))
     run_l = TL.main(TL.parse_args(["--config_file", l_yaml, "--autoencoderkl_config_file_path", a_yaml, "--best_model_path", run_a,
