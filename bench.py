@@ -332,7 +332,14 @@ def main():
         D.broadcast_flat(unet.flat); unet.sync_weights()        # the un-synchronised steps let the replicas drift: realign before anything else
         dist.barrier()
         ms_step = 1e3 * elapsed / args.steps
-        comm_info = {"backend": dist.get_backend(), "rccl_ranks": int(round(float(probe))), "world_size": dist.get_world_size(),
+        # self-diagnosis of the first real multi-GPU run: with one visible GPU per rank the collectives MUST be RCCL ("nccl" on ROCm).
+        # gloo is legal only under the single-GPU test hook (EEGLDM_LOCAL_DEVICE: several ranks share one device).
+        backend = dist.get_backend()
+        if torch.cuda.device_count() >= world and "EEGLDM_LOCAL_DEVICE" not in os.environ:
+            assert backend == "nccl", f"{world} ranks on {torch.cuda.device_count()} visible GPUs must use RCCL, got backend {backend!r}"
+        assert int(round(float(probe))) == world, f"the probe all-reduce spanned {float(probe)} ranks, expected {world}"
+        comm_info = {"backend": backend, "collective_ranks": int(round(float(probe))), "collective_is_rccl": backend == "nccl",
+                     "world_size": dist.get_world_size(),
                      "native_collectives": bool(gsync is not None and gsync.comm is not None),
                      "native_comm_world": (int(eegldm._lib.lib.eegldm_comm_world(gsync.comm.h)) if gsync is not None and gsync.comm is not None else None),
                      "grad_bytes_per_rank": 4 * n_grad, "bucket_bytes": 4 * D.BUCKET_ELEMS,
@@ -525,7 +532,8 @@ def main():
         }
         if comm_info is not None:
             out["comm"] = comm_info
-            out["rccl_ranks"] = comm_info["rccl_ranks"]; out["allreduce_ms_per_step"] = comm_info["allreduce_ms_bare"]
+            out["collective_ranks"] = comm_info["collective_ranks"]; out["collective_backend"] = comm_info["backend"]
+            out["allreduce_ms_per_step"] = comm_info["allreduce_ms_bare"]
             out["exposed_comm_ms_per_step"] = comm_info["exposed_comm_ms_per_step"]
         print(json.dumps(out))
     if world > 1:

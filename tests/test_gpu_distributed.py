@@ -279,3 +279,47 @@ def test_data_parallel_training_follows_the_single_process_oracle_trajectory():
     assert res[0][2] == res[1][2], "replicas drifted apart"    # identical parameters on both ranks after 8 synchronised steps
     for rank, gaps, _s in res:
         assert max(gaps) < 2e-3, (rank, gaps)                  # the single-GPU fp32 engine follows this fixture to 2e-5 (test_gpu_convergence.py)
+
+
+# ---------------------------------------------------------------- real RCCL, one GPU per rank (auto-skips on a single-GPU box)
+def _rccl_worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                      HSA_ENABLE_IPC_MODE_LEGACY="0")
+    os.environ.pop("EEGLDM_DIST_BACKEND", None); os.environ.pop("EEGLDM_LOCAL_DEVICE", None)
+    import torch.distributed as dist
+    import eegldm
+    from eegldm import distributed as D
+    r, local, w = D.init_from_env()
+    assert dist.get_backend() == "nccl" and local == rank
+    ctx = eegldm.default_context(local)
+    dev = torch.device("cuda", local)
+    g = torch.full((3_000_001,), float(rank + 1), device=dev)
+    D.allreduce_mean_flat(g, bucket_elems=1_000_000)                               # torch.distributed (RCCL) path
+    ok_torch = bool(torch.allclose(g, torch.full_like(g, (world + 1) / 2.0)))
+    comm = D.NativeComm.from_process_group(ctx)                                    # unique id from rank 0 through the initialised group
+    h = torch.full((2_000_003,), float(rank + 1), device=dev)
+    comm.allreduce_mean(h, bucket_elems=700_001); comm.wait(); torch.cuda.synchronize()
+    ok_native = bool(torch.allclose(h, torch.full_like(h, (world + 1) / 2.0)))
+    comm.close()
+    q.put((rank, ok_torch, ok_native))
+    dist.destroy_process_group()
+
+
+@pytest.mark.skipif(torch.cuda.device_count() < 2, reason="native RCCL with more than one rank needs one GPU per rank (the driver's multi-GPU node)")
+def test_rccl_two_ranks_one_gpu_each():
+    """The first place RCCL runs with world > 1: backend must resolve to nccl, the bucketed gradient mean must be exact for both the
+    torch.distributed path and the C-ABI communicator (eegldm_comm_*)."""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29700 + os.getpid() % 90
+    procs = [ctx.Process(target=_rccl_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=300) for _ in procs], key=lambda v: v[0])
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    for rank, ok_torch, ok_native in res:
+        assert ok_torch and ok_native, (rank, ok_torch, ok_native)
