@@ -112,6 +112,8 @@ int eegldm_conv1d_forget_kblocked(eegldm_ctx*, const void* w);
  * this for their own weights; eegldm_conv1d_forget_kblocked removes this registration too.  No reference counterpart: layout
  * plumbing behind the backward of nn.Conv1d (unet.py:263). */
 int eegldm_conv1d_pack_dgrad(eegldm_ctx*, const void* w, void* w_dgrad, int Cout, int Cin, int dtype);
+/* the same for a weight of K taps, [K][Cout][Cin] -> [K][Cout/32][Cin][32] (K = 1: 1 x 1 convs; K = 3 is eegldm_conv1d_pack_dgrad) */
+int eegldm_conv1d_pack_dgrad_k(eegldm_ctx*, const void* w, void* w_dgrad, int Cout, int Cin, int K, int dtype);
 
 /* ------------------------------------------------------------------ primitives (NLC)
  * nn.Conv1d as used at unet.py:263,291,302,385,504 and inside MONAI AutoencoderKL /

@@ -530,8 +530,8 @@ __global__ void kblk_pack_t1_kernel(const bf16_t* __restrict__ src, uint4* __res
   const long r = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (r < total) kblk_t_chunk(src, dst, cout, cin, r);
 }
-int kblk_pack_t_one(eegldm_ctx* ctx, const void* w_plain, void* w_packed, int Cout, int Cin) {
-  const long total = 3l * Cout * Cin / 8;
+int kblk_pack_t_one(eegldm_ctx* ctx, const void* w_plain, void* w_packed, int Cout, int Cin, int taps) {
+  const long total = (long)taps * Cout * Cin / 8;
   hipLaunchKernelGGL(kblk_pack_t1_kernel, dim3((unsigned)((total + NT - 1) / NT)), dim3(NT), 0, ctx->stream, (const bf16_t*)w_plain, (uint4*)w_packed, Cout, Cin, total);
   LAUNCH_CHECK(); return 0;
 }

@@ -16,10 +16,9 @@
 //   LDS      2 x A tile  (192 rows + 2 halo rows + DMA padding, 26 KB each)  +  3 x B piece (256 rows of ONE tap, 32 KB each)  = 148 KB
 //   pieces   p = 3 * stage + tap;  piece p = B(stage, tap)  [+ A(stage) when tap == 0]  filled by LDS-DMA (global_load_lds_dwordx4),
 //            lane-linear 1 KB per wave instruction, XOR-swizzled on the SOURCE side (gemm.hip nt_swz<2>: conflict-free ds_read_b128)
-//   phase p  s_waitcnt vmcnt(0) (piece p+1, issued one phase ago, has landed)  ->  s_barrier  ->  issue piece p+2 between the MFMAs
-//            ->  48 MFMAs per wave (6 x 4 fragments x 2 k-steps of 32) with the fragment reads running ONE k-step ahead, across the
-//            phase boundary: the first k-step of phase p+1 is read from LDS under the last MFMAs of phase p, so the matrix pipe has
-//            work in registers when the barrier releases.
+//   phase p  48 MFMAs per wave (6 x 4 fragments x 2 k-steps of 32) with the fragment reads running ONE k-step ahead, across the phase
+//            boundary; ONE barrier per phase, between the two k-steps, in front of which a wave waits (counted vmcnt) for ITS part of
+//            piece p+1 and behind which the DMAs of piece p+3 are issued: every piece has two full phases to land (see the kernel).
 //   epilogue bias / embedding row / residual added in the fragment layout (fp32), packed to bf16, transposed through LDS, 16-byte
 //            row-contiguous stores.
 #include <stdlib.h>
@@ -28,6 +27,13 @@
 #include "internal.h"
 
 namespace {
+
+// developer ablation builds (tools/debug/gemm_big_ablate.sh): -DEEG_BIG_DBG=<bits>, compile-time so that the loop keeps its shape
+#ifdef EEG_BIG_DBG
+#define BIG_DBG(bit) ((EEG_BIG_DBG) & (bit))
+#else
+#define BIG_DBG(bit) 0
+#endif
 
 constexpr int BM = 192, BN = 256, BK = 64, NWAVE = 8, NTHR = 512;
 constexpr int FM = 6, FN = 4;                       // 16 x 16 fragments per wave: 96 rows x 64 columns (waves: 2 along M x 4 along N)
@@ -70,6 +76,55 @@ __device__ __forceinline__ void dma16s(const void* base, unsigned voff, unsigned
   asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" ::"s"(__builtin_amdgcn_readfirstlane(lds_off)), "v"(voff), "s"(b) : "memory", "m0");
 }
 __device__ __forceinline__ int swz2(int row) { return 2 * ((row >> 1) & 3); }     // 16-byte slot ^= swz2(row) (128-byte rows)
+
+// ---- epilogue shared by both kernels: acc[i][j][r] = C[wm*96 + i*16 + lm][wn*64 + j*16 + q*4 + r] (operands were swapped: 4 consecutive
+// columns per lane).  bias / embedding row / residual are added in fp32 in the fragment layout, the sum is rounded to bf16 ONCE, the
+// packed tile goes through LDS and leaves as 16-byte row-contiguous stores.
+__device__ __forceinline__ void big_epilogue(const BigArgs& p, f32x4 (&acc)[FM][FN], char* smem, int m0, int n0, int tid, int lm, int q, int wm, int wn) {
+
+  float4 add[FN];
+#pragma unroll
+  for (int j = 0; j < FN; j++) {
+    const int nj = n0 + wn * 64 + j * 16 + q * 4;
+    add[j] = p.bias ? *(const float4*)(p.bias + nj) : make_float4(0.f, 0.f, 0.f, 0.f);
+    if (p.rowvec) {           // a tile lies inside one sample (rows_per_vec % 192 == 0)
+      const float4 e = *(const float4*)(p.rowvec + (long)(m0 / p.rows_per_vec) * p.ld_rowvec + nj);
+      add[j].x += e.x; add[j].y += e.y; add[j].z += e.z; add[j].w += e.w;
+    }
+  }
+  uint2 res[2][FN];
+  auto load_res = [&](int i, uint2 (&r)[FN]) __attribute__((always_inline)) {
+    const bf16_t* rp = p.resid + (long)(m0 + wm * (FM * 16) + i * 16 + lm) * p.ldr + n0 + wn * 64 + q * 4;
+#pragma unroll
+    for (int j = 0; j < FN; j++) r[j] = *(const uint2*)(rp + j * 16);
+  };
+  if (p.resid) load_res(0, res[0]);
+#pragma unroll
+  for (int i = 0; i < FM; i++) {
+    if (p.resid && i + 1 < FM) load_res(i + 1, res[(i + 1) & 1]);
+#pragma unroll
+    for (int j = 0; j < FN; j++) {
+      float4 a = add[j];
+      if (p.resid) {
+        const uint2 r = res[i & 1][j];
+        a.x += __uint_as_float(r.x << 16); a.y += __uint_as_float(r.x & 0xffff0000u);
+        a.z += __uint_as_float(r.y << 16); a.w += __uint_as_float(r.y & 0xffff0000u);
+      }
+      uint2 o;
+      o.x = pack_bf16x2(acc[i][j][0] + a.x, acc[i][j][1] + a.y);
+      o.y = pack_bf16x2(acc[i][j][2] + a.z, acc[i][j][3] + a.w);
+      *(uint2*)(smem + (wm * (FM * 16) + i * 16 + lm) * PITCH16 + (wn * 64 + j * 16 + q * 4) * 2) = o;
+    }
+  }
+  __syncthreads();
+  constexpr int CH8 = BN / 8, RSTEP = NTHR / CH8, NIT = BM / RSTEP;      // 32 chunks per row, 16 rows per pass, 12 passes
+  const int cs8 = tid % CH8, r0 = tid / CH8;
+  uint4 v8[NIT];
+#pragma unroll
+  for (int cc = 0; cc < NIT; cc++) v8[cc] = *(const uint4*)(smem + (r0 + cc * RSTEP) * PITCH16 + cs8 * 16);
+#pragma unroll
+  for (int cc = 0; cc < NIT; cc++) *(uint4*)(p.C + (long)(m0 + r0 + cc * RSTEP) * p.ldc + n0 + cs8 * 8) = v8[cc];
+}
 
 template <int TAPS, bool KBLK, bool FLIP>      // FLIP: tap t reads weight slice 2 - t (data gradient; also tells the two apart in a kernel trace).  TAPS = 3 only: with one tap every piece carries an A tile and the two-buffer A ring would be overwritten while it is read
 __global__ __launch_bounds__(NTHR, 2) void gemm_big_kernel(const BigArgs p) {
@@ -149,115 +204,215 @@ __global__ __launch_bounds__(NTHR, 2) void gemm_big_kernel(const BigArgs p) {
 #pragma unroll
     for (int j = 0; j < FN; j++) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
+  // ---- schedule.  ONE barrier per phase, placed between its two k-steps:
+  //   k-step 0 of phase p    24 MFMAs on the fragments read during phase p-1; the k-step-1 fragments of piece p stream in behind them
+  //   wait + barrier B_p     each wave: its DMAs of piece p+1 have landed (counted vmcnt: piece p+2 may stay in flight) and its LDS
+  //                          reads of piece p have returned; the barrier makes both true for the whole workgroup
+  //   k-step 1 of phase p    issue the DMAs of piece p+3 into the buffer piece p just vacated; 24 MFMAs; the k-step-0 fragments of
+  //                          piece p+1 stream in behind them
+  // A piece is therefore issued TWO full phases before the barrier that needs it (B_{p+2} for piece p+3) with three B buffers --
+  // putting the barrier at the top of the phase (round-4 first version) left it one phase, and the top-of-phase vmcnt(0) then waited on
+  // DMAs issued ~0.6 us earlier: 2600 cycles per phase against 1536 of MFMA work.
   issue_all(0);
   issue_all(1);
+  issue_all(2);
 
   // Fragment registers: ONE set of A fragments (af[i] is re-loaded for the next k-step as soon as row i's MFMAs of this k-step are
   // issued) and two sets of B fragments (all four are needed until the last row) -- 56 registers instead of 80 for full double buffering
   uint4 af[FM], bf0[FN], bf1[FN];
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  // counted wait: at most `n` of this wave's DMA instructions still in flight.  Pieces with an A tile carry 7 instructions, 8 in
+  // waves 0 and 1 (the halo rows); the others 4.
+  auto wait_dma = [&](const int t_inflight, const bool any) __attribute__((always_inline)) {
+    if (!any) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    else if (t_inflight != 0) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    else if (wave_u < 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(7)" ::: "memory");
+  };
+  // prologue: piece 0 landed (pieces 1 and 2 may still fly), first fragments
+  asm volatile("s_waitcnt vmcnt(8)" ::: "memory");     // pieces 1 + 2 = 4 + 4 instructions may stay in flight
   __builtin_amdgcn_s_barrier();
   asm volatile("" ::: "memory");
 #pragma unroll
   for (int j = 0; j < FN; j++) bf0[j] = *(const uint4*)(smem + B0 + bof + j * 2048);
 #pragma unroll
   for (int i = 0; i < FM; i++) af[i] = *(const uint4*)(smem + aof[0] + i * 2048);
-  // one phase; t (tap), has1 (piece p + 1 exists) and has2 (piece p + 2 exists) are compile-time constants after unrolling, s is wave-uniform
-  auto phase = [&](const int s, const int t, const bool has1, const bool has2) __attribute__((always_inline)) {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // this wave's part of piece p+1 (and p) has landed
-    __builtin_amdgcn_s_barrier();                            // ... and everyone's; every wave is done reading piece p-1
-    asm volatile("" ::: "memory");
+  // one phase; t (tap), has1 / has2 / has3 (piece p + 1 / 2 / 3 exists) are compile-time constants after unrolling, s is wave-uniform
+  auto phase = [&](const int s, const int t, const bool has1, const bool has2, const bool has3) __attribute__((always_inline)) {
     const char* smA = smem + (s & 1) * A_ALLOC;
     const char* smB = smem + B0 + t * B_ALLOC;
-    const int t2 = (t + 2) % TAPS, s2 = s + (t + 2) / TAPS;                       // piece p + 2
     const int t1 = (t + 1) % TAPS, s1 = s + (t + 1) / TAPS;                       // piece p + 1
-    // ---- k-step 0 (fragments already in registers); reads of k-step 1 run behind the MFMAs.  Row 0 goes first, bare: its operands
-    // were read a whole k-step ago, while the reads issued just before the barrier (row 5 of this k-step) may still be in flight
+    const int t2 = (t + 2) % TAPS;                                                 // piece p + 2 (in flight across the barrier)
+    // ---- k-step 0 (fragments already in registers); the k-step-1 fragments of this piece are read behind the MFMAs
 #pragma unroll
     for (int i = 0; i < FM; i++) {
 #pragma unroll
-      for (int j = 0; j < FN; j++) {
-        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, bf0[j]), __builtin_bit_cast(bf16x8, af[i]), acc[i][j], 0, 0, 0);
-        if (has2 && i >= 1 && i <= 4) {            // DMA instructions 2(i-1), 2(i-1)+1 of piece p+2 go out behind MFMAs 1 and 3 of rows 1..4
-          const int k = 2 * (i - 1) + (j >> 1);
-          if ((j & 1) && (k < 4 || t2 == 0)) issue(s2, t2, k);
-        }
-      }
+      for (int j = 0; j < FN; j++)
+        if (!BIG_DBG(4)) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, bf0[j]), __builtin_bit_cast(bf16x8, af[i]), acc[i][j], 0, 0, 0);
       if (i == 0) {
         __builtin_amdgcn_sched_barrier(0);     // (keeps the reads below behind row 0's MFMAs: the compiler's wait in front of the first MFMA after an LDS read is lgkmcnt(0))
 #pragma unroll
-        for (int j = 0; j < FN; j++) bf1[j] = *(const uint4*)(smB + (bof ^ 64) + j * 2048);
+        for (int j = 0; j < FN; j++) if (!BIG_DBG(2)) bf1[j] = *(const uint4*)(smB + (bof ^ 64) + j * 2048);
       }
-      af[i] = *(const uint4*)(smA + (aof[t] ^ 64) + i * 2048);
+      if (!BIG_DBG(2)) af[i] = *(const uint4*)(smA + (aof[t] ^ 64) + i * 2048);
       __builtin_amdgcn_sched_barrier(0);       // pin the order: hipcc otherwise sinks every fragment read to just before its first use
     }
-    // ---- k-step 1; the first k-step of the next phase (piece p+1: landed before this phase's barrier) is read behind its MFMAs
+    // ---- B_p: piece p+1 landed everywhere, piece p read by everyone
+    if (has1) wait_dma(t2, has2);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    // ---- k-step 1; piece p+3 = (s + 1, t) goes into the buffers piece p vacates; the first k-step of piece p+1 is read behind the MFMAs
     const char* smA1 = smem + (s1 & 1) * A_ALLOC;
     const char* smB1 = smem + B0 + t1 * B_ALLOC;
     if (has1) {
 #pragma unroll
-      for (int j = 0; j < FN; j++) bf0[j] = *(const uint4*)(smB1 + bof + j * 2048);
+      for (int j = 0; j < FN; j++) if (!BIG_DBG(2)) bf0[j] = *(const uint4*)(smB1 + bof + j * 2048);
     }
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int i = 0; i < FM; i++) {
 #pragma unroll
-      for (int j = 0; j < FN; j++)
-        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, bf1[j]), __builtin_bit_cast(bf16x8, af[i]), acc[i][j], 0, 0, 0);
-      if (has1) af[i] = *(const uint4*)(smA1 + aof[t1] + i * 2048);
+      for (int j = 0; j < FN; j++) {
+        if (!BIG_DBG(4)) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, bf1[j]), __builtin_bit_cast(bf16x8, af[i]), acc[i][j], 0, 0, 0);
+        if (has3 && i <= 3 && !BIG_DBG(1)) {                  // DMA instructions 2i, 2i + 1 of piece p+3 go out behind MFMAs 1 and 3 of rows 0..3
+          const int k = 2 * i + (j >> 1);
+          if ((j & 1) && (k < 4 || t == 0)) issue(s + 1, t, k);
+        }
+      }
+      if (has1 && !BIG_DBG(2)) af[i] = *(const uint4*)(smA1 + aof[t1] + i * 2048);
       __builtin_amdgcn_sched_barrier(0);
     }
   };
 #pragma unroll 1
   for (int s = 0; s + 1 < S; s++) {
-    phase(s, 0, true, true); phase(s, 1, true, true); phase(s, 2, true, true);
+    phase(s, 0, true, true, true); phase(s, 1, true, true, true); phase(s, 2, true, true, true);
   }
-  phase(S - 1, 0, true, true); phase(S - 1, 1, true, false); phase(S - 1, 2, false, false);
+  phase(S - 1, 0, true, true, false); phase(S - 1, 1, true, false, false); phase(S - 1, 2, false, false, false);
   __syncthreads();       // all waves done with the ring before the epilogue tile reuses it
+  if (BIG_DBG(8)) { if (acc[0][0][0] == 123.456f) p.C[0] = 0; return; }
+  big_epilogue(p, acc, smem, m0, n0, tid, lm, q, wm, wn);
+}
 
-  // ---- epilogue: acc[i][j][r] = C[wm*96 + i*16 + lm][wn*64 + j*16 + q*4 + r] (operands were swapped: 4 consecutive columns per lane)
-  float4 add[FN];
-#pragma unroll
-  for (int j = 0; j < FN; j++) {
-    const int nj = n0 + wn * 64 + j * 16 + q * 4;
-    add[j] = p.bias ? *(const float4*)(p.bias + nj) : make_float4(0.f, 0.f, 0.f, 0.f);
-    if (p.rowvec) {           // a tile lies inside one sample (rows_per_vec % 192 == 0)
-      const float4 e = *(const float4*)(p.rowvec + (long)(m0 / p.rows_per_vec) * p.ld_rowvec + nj);
-      add[j].x += e.x; add[j].y += e.y; add[j].z += e.z; add[j].w += e.w;
-    }
+// ---- one tap (1 x 1 convs / NT products): Y[r][n] = sum_k A[r][k] * W[n][k].  Every K stage carries its own A tile, so the ring is
+// two (A, B) stage buffers (112 KB); same phase shape as the 3-tap kernel (barrier between the two k-steps, fragment reads one k-step
+// ahead), with stage s + 2 issued behind B_s into the buffer stage s vacates: one phase of DMA lead.  Measured (tools/debug/
+// gemm_big_check.py): equal to the 192 x 128 / 2-blocks-per-CU kernel of gemm.hip on the model's 1 x 1 shapes (their K loops are 8-16
+// stages, so prologue + epilogue weigh as much as the loop and two co-resident blocks overlap them); kept for the data gradients,
+// which it runs as NT products on the transposed weight copy (+3 % over the transposed-operand kernel).
+constexpr int S1_BYTES = A_MAIN + B_ALLOC;          // 56 KB per stage
+constexpr int LDS1_BYTES = 2 * S1_BYTES > EPI_BYTES ? 2 * S1_BYTES : EPI_BYTES;
+template <bool KBLK>      // KBLK: B is [K / 32][N][32] (the data-gradient copy of a 1 x 1 conv weight), else plain [N][ldb]
+__global__ __launch_bounds__(NTHR, 2) void gemm_big1_kernel(const BigArgs p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int lm = lane & 15, q = lane >> 4;
+  const int wm = wave >> 2, wn = wave & 3;
+  int tile_m, tile_n;
+  {
+    const int w = blockIdx.x;
+    if ((p.tiles_m & 7) == 0) { const int xcd = w & 7, slot = w >> 3; tile_n = slot % p.tiles_n; tile_m = (slot / p.tiles_n) * 8 + xcd; }
+    else { tile_n = w % p.tiles_n; tile_m = w / p.tiles_n; }
   }
-  uint2 res[2][FN];
-  auto load_res = [&](int i, uint2 (&r)[FN]) __attribute__((always_inline)) {
-    const bf16_t* rp = p.resid + (long)(m0 + wm * (FM * 16) + i * 16 + lm) * p.ldr + n0 + wn * 64 + q * 4;
+  const int m0 = tile_m * BM, n0 = tile_n * BN;
+  const int S = p.K / BK;
+  unsigned ao_src[3], bo_src[4];
 #pragma unroll
-    for (int j = 0; j < FN; j++) r[j] = *(const uint2*)(rp + j * 16);
+  for (int j = 0; j < 3; j++) {
+    const int c = (wave + NWAVE * j) * 64 + lane, pr = c >> 3, lc = (c & 7) ^ swz2(pr);
+    ao_src[j] = (unsigned)(((long)pr * p.lda + lc * 8) * 2);
+  }
+#pragma unroll
+  for (int j = 0; j < 4; j++) {
+    const int c = (wave + NWAVE * j) * 64 + lane, nr = c >> 3, lc = (c & 7) ^ swz2(nr);
+    bo_src[j] = KBLK ? (unsigned)((((long)(lc >> 2) * p.N + nr) * 32 + (lc & 3) * 8) * 2) : (unsigned)(((long)nr * p.ldb + lc * 8) * 2);
+  }
+  const long bstep = KBLK ? (long)2 * p.N * 32 : (long)BK;      // elements per K stage
+  const bf16_t* const a_base = p.A + (long)m0 * p.lda;
+  const bf16_t* const b_base = p.B + (KBLK ? (long)n0 * 32 : (long)n0 * p.ldb);
+  const unsigned lds0 = (unsigned)(size_t)(lds_void_ptr)smem;
+  const unsigned wave_u = __builtin_amdgcn_readfirstlane(wave);
+  auto issue = [&](int s, int k) __attribute__((always_inline)) {       // DMA instruction k (0..3 B, 4..6 A) of stage s
+    if (k < 4) dma16s(b_base + s * bstep, bo_src[k], lds0 + (s & 1) * S1_BYTES + A_MAIN + (wave_u + NWAVE * k) * 1024);
+    else dma16s(a_base + (long)s * BK, ao_src[k - 4], lds0 + (s & 1) * S1_BYTES + (wave_u + NWAVE * (k - 4)) * 1024);
   };
-  if (p.resid) load_res(0, res[0]);
+  const int pr0 = wm * (FM * 16) + lm;
+  const unsigned aof = pr0 * ROWB + ((q ^ swz2(pr0)) << 4);
+  const unsigned bof = A_MAIN + (wn * 64 + lm) * ROWB + ((q ^ swz2(lm)) << 4);
+
+  f32x4 acc[FM][FN];
 #pragma unroll
-  for (int i = 0; i < FM; i++) {
-    if (p.resid && i + 1 < FM) load_res(i + 1, res[(i + 1) & 1]);
+  for (int i = 0; i < FM; i++)
 #pragma unroll
-    for (int j = 0; j < FN; j++) {
-      float4 a = add[j];
-      if (p.resid) {
-        const uint2 r = res[i & 1][j];
-        a.x += __uint_as_float(r.x << 16); a.y += __uint_as_float(r.x & 0xffff0000u);
-        a.z += __uint_as_float(r.y << 16); a.w += __uint_as_float(r.y & 0xffff0000u);
-      }
-      uint2 o;
-      o.x = pack_bf16x2(acc[i][j][0] + a.x, acc[i][j][1] + a.y);
-      o.y = pack_bf16x2(acc[i][j][2] + a.z, acc[i][j][3] + a.w);
-      *(uint2*)(smem + (wm * (FM * 16) + i * 16 + lm) * PITCH16 + (wn * 64 + j * 16 + q * 4) * 2) = o;
-    }
+    for (int j = 0; j < FN; j++) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int k = 0; k < 7; k++) issue(0, k);
+  if (S > 1) {
+#pragma unroll
+    for (int k = 0; k < 7; k++) issue(1, k);
   }
+  uint4 af[FM], bf0[FN], bf1[FN];
+  if (S > 1) asm volatile("s_waitcnt vmcnt(7)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // stage 0 landed
+  __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
+#pragma unroll
+  for (int j = 0; j < FN; j++) bf0[j] = *(const uint4*)(smem + bof + j * 2048);
+#pragma unroll
+  for (int i = 0; i < FM; i++) af[i] = *(const uint4*)(smem + aof + i * 2048);
+  // phase s (same shape as the 3-tap kernel): k-step 0 | wait stage s+1 + barrier | issue stage s+2 into the buffer stage s vacates, k-step 1
+  auto phase = [&](const int s, const bool has1, const bool has2) __attribute__((always_inline)) {
+    const char* sm = smem + (s & 1) * S1_BYTES;
+#pragma unroll
+    for (int i = 0; i < FM; i++) {
+#pragma unroll
+      for (int j = 0; j < FN; j++)
+        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, bf0[j]), __builtin_bit_cast(bf16x8, af[i]), acc[i][j], 0, 0, 0);
+      if (i == 0) {
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int j = 0; j < FN; j++) bf1[j] = *(const uint4*)(sm + (bof ^ 64) + j * 2048);
+      }
+      af[i] = *(const uint4*)(sm + (aof ^ 64) + i * 2048);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");      // stage s+1 (the only DMA in flight) landed; reads of stage s returned
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    const char* sm1 = smem + ((s + 1) & 1) * S1_BYTES;
+    if (has1) {
+#pragma unroll
+      for (int j = 0; j < FN; j++) bf0[j] = *(const uint4*)(sm1 + bof + j * 2048);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int i = 0; i < FM; i++) {
+#pragma unroll
+      for (int j = 0; j < FN; j++) {
+        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, bf1[j]), __builtin_bit_cast(bf16x8, af[i]), acc[i][j], 0, 0, 0);
+        if (has2 && i <= 3) { const int k = 2 * i + (j >> 1); if ((j & 1) && k < 7) issue(s + 2, k); }
+      }
+      if (has1) af[i] = *(const uint4*)(sm1 + aof + i * 2048);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  };
+#pragma unroll 1
+  for (int s = 0; s + 2 < S; s++) phase(s, true, true);
+  if (S > 1) phase(S - 2, true, false);
+  phase(S - 1, false, false);
   __syncthreads();
-  constexpr int CH8 = BN / 8, RSTEP = NTHR / CH8, NIT = BM / RSTEP;      // 32 chunks per row, 16 rows per pass, 12 passes
-  const int cs8 = tid % CH8, r0 = tid / CH8;
-  uint4 v8[NIT];
-#pragma unroll
-  for (int cc = 0; cc < NIT; cc++) v8[cc] = *(const uint4*)(smem + (r0 + cc * RSTEP) * PITCH16 + cs8 * 16);
-#pragma unroll
-  for (int cc = 0; cc < NIT; cc++) *(uint4*)(p.C + (long)(m0 + r0 + cc * RSTEP) * p.ldc + n0 + cs8 * 8) = v8[cc];
+  big_epilogue(p, acc, smem, m0, n0, tid, lm, q, wm, wn);
+}
+
+template <bool KBLK>
+int launch_big1(eegldm_ctx* ctx, const BigArgs& a) {
+  auto kern = gemm_big1_kernel<KBLK>;
+  static int attr_dev = -1;
+  if (attr_dev != ctx->device) {
+    HIP_TRY(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS1_BYTES));
+    attr_dev = ctx->device;
+  }
+  hipLaunchKernelGGL(kern, dim3(a.tiles_m * a.tiles_n), dim3(NTHR), LDS1_BYTES, ctx->stream, a);
+  LAUNCH_CHECK();
+  return 0;
 }
 
 template <int TAPS, bool KBLK, bool FLIP>
@@ -284,7 +439,9 @@ int gemm_big_try(eegldm_ctx* ctx, const GemmArgs& g) {
   if (off || g.dtype != EEGLDM_BF16 || g.bmode != GB_NT || g.batch != 1 || g.splitk > 1 || g.ztaps > 1 || g.out_f32 || g.atomic_out || g.colsum || g.ngroup) return 0;
   if (g.alpha != 1.0f || g.ups > 1) return 0;
   const bool conv3 = g.amode == GA_CONV && g.taps == 3 && g.stride == 1 && g.pad_l == 1 && g.Lin == g.Lout;
-  if (!conv3) return 0;      // (1-tap products: the A tile would need a third ring buffer, see the header; gemm.hip keeps them)
+  const bool plain1 = g.amode == GA_PLAIN && g.taps == 1;
+  EEG_ENV_VAR(bool, no1, getenv("EEGLDM_NO_GEMM_BIG1") != nullptr);
+  if (!conv3 && !(plain1 && !no1)) return 0;
   const int L = conv3 ? g.Lout : BM;
   if (g.M % BM != 0 || L % BM != 0 || g.N % BN != 0 || g.K % BK != 0 || g.lda % 8 != 0 || g.ldc % 8 != 0) return 0;
   if (!g.b_kblk && g.ldb % 8 != 0) return 0;
@@ -300,7 +457,8 @@ int gemm_big_try(eegldm_ctx* ctx, const GemmArgs& g) {
   a.bias = g.bias; a.rowvec = g.rowvec; a.ld_rowvec = g.ld_rowvec; a.rows_per_vec = g.rows_per_vec > 0 ? g.rows_per_vec : 1;
   a.resid = (const bf16_t*)g.resid; a.ldr = g.ldr; a.zero_page = ctx->zero_page; a.tiles_m = tm; a.tiles_n = tn;
   int rc;
-  if (g.tap_flip) rc = g.b_kblk ? launch_big<3, true, true>(ctx, a) : launch_big<3, false, true>(ctx, a);
+  if (!conv3) rc = g.b_kblk ? launch_big1<true>(ctx, a) : launch_big1<false>(ctx, a);
+  else if (g.tap_flip) rc = g.b_kblk ? launch_big<3, true, true>(ctx, a) : launch_big<3, false, true>(ctx, a);
   else rc = g.b_kblk ? launch_big<3, true, false>(ctx, a) : launch_big<3, false, false>(ctx, a);
   return rc < 0 ? rc : 1;
 }

@@ -20,7 +20,7 @@ int kblk_pack(eegldm_ctx* ctx, const void* w_plain, void* w_packed, const KbDesc
 int kblk_pack_one(eegldm_ctx* ctx, const void* w_plain, void* w_packed, int Cout, int Cin);
 // data-gradient copies: [3][Cout][Cin] -> [3][Cout / 32][Cin][32] (Cout, the data gradient's reduction index, K-blocked)
 int kblk_pack_t(eegldm_ctx* ctx, const void* w_plain, void* w_packed, const KbDesc* d_table, int n, long total_chunks);
-int kblk_pack_t_one(eegldm_ctx* ctx, const void* w_plain, void* w_packed, int Cout, int Cin);   // one weight, both pointers at its first element
+int kblk_pack_t_one(eegldm_ctx* ctx, const void* w_plain, void* w_packed, int Cout, int Cin, int taps = 3);   // one weight, both pointers at its first element
 int dconv_run(eegldm_ctx*, int dtype, bool dgrad, const void* in, long ldin, const void* w, const float* bias,
               const void* resid, long ldr, void* out, long ldout, int B, int Lin, int Lout, int Cin, int Cout, int K,
               int stride, int pad_l, float act_slope = 0.f);

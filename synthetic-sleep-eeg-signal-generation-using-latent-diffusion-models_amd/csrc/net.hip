@@ -34,7 +34,7 @@ int NetBase::bind(float* p, float* g) {
     std::vector<KbDesc> tab; long chunks = 0;
     for (const Entry& e : entries) {
       // data gradient as an NT product on the big tile: N = Cin a multiple of 256, K = Cout a multiple of 64
-      if (e.ndim != 3 || e.shape[2] != 3 || e.shape[1] % 256 != 0 || e.shape[0] % 64 != 0 || e.offset % 8 != 0) continue;
+      if (e.ndim != 3 || (e.shape[2] != 3 && e.shape[2] != 1) || e.shape[1] % 256 != 0 || e.shape[0] % 64 != 0 || e.offset % 8 != 0) continue;      // (3-tap and 1 x 1 convs)
       KbDesc d; d.off = e.offset; d.chunk0 = chunks; d.cout = e.shape[0]; d.cin = e.shape[1];
       chunks += e.numel / 8; tab.push_back(d);
     }

@@ -64,6 +64,10 @@ int op_conv_dgrad(eegldm_ctx* ctx, int dtype, const void* dy, long lddy, const v
   a.bmode = GB_TR;
   if (K == 1) {
     a.amode = GA_PLAIN;
+    if (dtype != EEGLDM_F32 && !ctx->kblk_t.empty()) {      // [Cout / 32][Cin][32] copy: the data gradient of a 1 x 1 conv as an NT product on the big tile
+      auto it = ctx->kblk_t.find(w);
+      if (it != ctx->kblk_t.end()) a.B_alt = it->second;
+    }
   } else {
     EEG_CHECK(Lin == Lout * stride, "k3 dgrad geometry not supported");
     // transposed conv as a stride-1 conv over the (virtually zero-upsampled) gradient, taps flipped
@@ -300,10 +304,14 @@ extern "C" int eegldm_conv1d_pack_kblocked(eegldm_ctx* ctx, const void* w, void*
   return 0;
 }
 extern "C" int eegldm_conv1d_pack_dgrad(eegldm_ctx* ctx, const void* w, void* w_t, int Cout, int Cin, int dtype) {
+  return eegldm_conv1d_pack_dgrad_k(ctx, w, w_t, Cout, Cin, 3, dtype);
+}
+extern "C" int eegldm_conv1d_pack_dgrad_k(eegldm_ctx* ctx, const void* w, void* w_t, int Cout, int Cin, int K, int dtype) {
+  EEG_CHECK(K == 1 || K == 3, "kernel size 1 or 3");
   EEG_CHECK(ctx && w && w_t && w != w_t, "null or aliased pointer");
   EEG_CHECK(dtype != EEGLDM_F32 && Cin > 0 && Cout > 0 && Cout % 32 == 0, "data-gradient weight copy: 16-bit dtype and Cout %% 32 == 0 (got dtype %d, Cout %d)", dtype, Cout);
   EEG_CHECK(((size_t)w % 16 == 0) && ((size_t)w_t % 16 == 0), "weights must be 16-byte aligned");
-  EEG_TRY(kblk_pack_t_one(ctx, w, w_t, Cout, Cin));
+  EEG_TRY(kblk_pack_t_one(ctx, w, w_t, Cout, Cin, K));
   ctx->kblk_t[w] = w_t;
   return 0;
 }
