@@ -85,10 +85,6 @@ int eegldm_prof_dump(eegldm_ctx* ctx, const char* path_host);
  * A/B an execution path against its predecessor inside one process.  Models / contexts created BEFORE the call keep whatever
  * they built from the old values (weight copies, streams).  No reference counterpart. */
 int eegldm_debug_reload_env(void);
-/* 1 when EEGLDM_DETERMINISTIC=1 is in effect: every cross-workgroup fp32 sum of the training paths (split-K weight
- * gradients, bias / GroupNorm / BatchNorm parameter gradients, loss scalars) is formed from written partials folded in a
- * fixed order instead of fp32 atomics, so a run is bit-reproducible.  Slower (a few %); meant for parity regressions. */
-int eegldm_deterministic(void);
 
 /* ------------------------------------------------------------------ layout / packing */
 int eegldm_ncl_to_nlc(eegldm_ctx*, const float* src_ncl, void* dst_nlc, long ld_dst, int B, int C, int L, int dst_dtype);

@@ -50,7 +50,6 @@ SIGNATURES = {
     "eegldm_prof_bracket_overhead_ms": [_vp, C.POINTER(C.c_double)],
     "eegldm_prof_dump": [_vp, C.c_char_p],
     "eegldm_debug_reload_env": [],
-    "eegldm_deterministic": [],
     "eegldm_ncl_to_nlc": [_vp, _vp, _vp, _l, _i, _i, _i, _i],
     "eegldm_nlc_to_ncl": [_vp, _vp, _l, _vp, _i, _i, _i, _i],
     "eegldm_pack_conv_weight": [_vp, _vp, _vp, _i, _i, _i],

@@ -11,10 +11,9 @@ static thread_local TimerState g_timer;
 
 int g_eeg_env_epoch = 0;
 int g_eeg_live_ctx = 0;
-bool eeg_deterministic() { EEG_ENV_VAR(bool, det, getenv("EEGLDM_DETERMINISTIC") && atoi(getenv("EEGLDM_DETERMINISTIC")) != 0); return det; }
 extern "C" int eegldm_abi_version(void) { return EEGLDM_ABI_VERSION; }
 extern "C" int eegldm_debug_reload_env(void) { return ++g_eeg_env_epoch; }
-extern "C" int eegldm_deterministic(void) { return eeg_deterministic() ? 1 : 0; }
+
 extern "C" const char* eegldm_last_error(void) { return g_err.c_str(); }
 
 extern "C" int eegldm_ctx_create(int device, void* stream, int own_stream, eegldm_ctx** out) {

@@ -42,9 +42,6 @@ extern int g_eeg_env_epoch;
   static T name;                                                                                        \
   do { static int _ep_##name = -1;                                                                      \
        if (_ep_##name != g_eeg_env_epoch) { name = (__VA_ARGS__); _ep_##name = g_eeg_env_epoch; } } while (0)
-// EEGLDM_DETERMINISTIC=1: every cross-block fp32 sum of the training paths goes through written partials + a fixed-order fold
-// (no fp32 atomics whose arrival order could change a rounding): results are bit-identical run to run and box to box.
-bool eeg_deterministic();
 extern int g_eeg_live_ctx;      // contexts alive in this process (eegldm_ctx_create / _destroy): kernels that are only safe alone on a CU ask
 
 // ---------------------------------------------------------------- context

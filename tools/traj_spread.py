@@ -11,7 +11,7 @@ import test_gpu_zz_convergence as T  # noqa: E402
 
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 5
 import socket  # noqa: E402
-print("host", socket.gethostname(), "deterministic", os.environ.get("EEGLDM_DETERMINISTIC", "0"))
+print("host", socket.gethostname())
 for fixture in ("aekl_traj_c1.json", "aekl_traj_thin.json"):
     for dtype in ("float32", "bfloat16"):
         rows = [T.replay_aekl(fixture, dtype) for _ in range(N)]
