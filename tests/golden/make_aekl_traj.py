@@ -1,7 +1,7 @@
 """Generates tests/golden/aekl_traj_c1.json: the loss trajectory of 40 optimiser steps of the AutoencoderKL [32,32,64] +
 PatchDiscriminator GAN training (train_autoencoderkl.py:203-234; reference loss weights adv 0.01, kl 1e-9, spectral 1e4; Adam 1e-3 /
 5e-4) computed by the CPU oracle (oracle/steps.py::aekl_train_step, fp32 torch autograd) on seeded parameters, windows and
-posterior noise.  tests/test_gpu_convergence.py replays the same 40 steps through the HIP engines.  ~1 minute on 16 cores.
+posterior noise.  tests/test_gpu_zz_convergence.py replays the same 40 steps through the HIP engines.  ~1 minute on 16 cores.
 
     python tests/golden/make_aekl_traj.py          # [32,32,64] -> aekl_traj_c1.json
     python tests/golden/make_aekl_traj.py thin     # [2,2,4] (the whole-network aekl_thin kernels, Adam 5e-3 / 5e-4) -> aekl_traj_thin.json

@@ -1,7 +1,7 @@
 """Generates tests/golden/ldm_traj_c2.json: the epsilon-MSE trajectory of 30 optimiser steps of the config_ldm.yaml UNet
 (training.py:419-443: add_noise -> UNet -> MSE -> Adam 1e-4; linear betas 0.0015-0.0195 as train_ldm.py:199-200) computed by the
 CPU oracle (oracle/steps.py::ldm_train_step + adam_update, fp32 torch autograd) on seeded parameters, latents, noise and timesteps.
-tests/test_gpu_convergence.py replays the same steps through the HIP engines.  ~20 s on 16 cores.
+tests/test_gpu_zz_convergence.py replays the same steps through the HIP engines.  ~20 s on 16 cores.
 
     python tests/golden/make_ldm_traj.py
 """

@@ -278,7 +278,7 @@ def test_data_parallel_training_follows_the_single_process_oracle_trajectory():
         assert p.exitcode == 0
     assert res[0][2] == res[1][2], "replicas drifted apart"    # identical parameters on both ranks after 8 synchronised steps
     for rank, gaps, _s in res:
-        assert max(gaps) < 2e-3, (rank, gaps)                  # the single-GPU fp32 engine follows this fixture to 2e-5 (test_gpu_convergence.py)
+        assert max(gaps) < 2e-3, (rank, gaps)                  # the single-GPU fp32 engine follows this fixture to 2e-5 (test_gpu_zz_convergence.py)
 
 
 # ---------------------------------------------------------------- real RCCL, one GPU per rank (auto-skips on a single-GPU box)

@@ -1,6 +1,6 @@
 """CPU: the committed training-trajectory fixtures (tests/golden/ldm_traj_c2.json, aekl_traj_c1.json) are what the oracle produces --
 their first steps are recomputed here from the seeds stored in the files (the full runs are tests/golden/make_ldm_traj.py /
-make_aekl_traj.py; the HIP engines replay all steps in tests/test_gpu_convergence.py)."""
+make_aekl_traj.py; the HIP engines replay all steps in tests/test_gpu_zz_convergence.py)."""
 import json
 import os
 import sys
