@@ -1,0 +1,161 @@
+"""-m gpu: the 192 x 256 big-tile conv kernels (csrc/gemm_big.hip) -- 3-tap conv forward, its data gradient through the transposed K-blocked
+weight copy, the 1 x 1 variant -- against torch's fp32 conv on bf16-rounded operands (the oracle's building block) AND, bit for bit, against
+the 128 x 128 kernel of gemm.hip (same products, same k order per output), including bias + time-embedding row + residual (also in place),
+halo rows at sample edges (tiles at the first / last rows of a sample and in its interior), plain and K-blocked weights; then a race screen:
+the LDS-DMA ring is ordered only by counted waits and one barrier per phase, so repeated launches on production-size problems must
+reproduce the first result bit for bit."""
+import math
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+from param_gen import normal  # noqa: E402
+
+#        B, L,   Cin,  Cout, rowvec, resid
+CASES3 = [(4, 192, 512, 512, 1, 0), (2, 384, 768, 256, 1, 1), (3, 192, 64, 256, 0, 0), (2, 768, 256, 256, 0, 1), (1, 192, 1024, 512, 1, 1)]
+CASES1 = [(4, 192, 512, 1536, 0), (2, 384, 768, 256, 1), (3, 192, 1024, 512, 1)]
+
+
+def _fwd(G, c, x, w, b, e, r, K, kblk, inplace=False):
+    dt = G.BF16
+    B, Cin, L = x.shape; Cout = w.shape[0]
+    xd, wd, bd = G.nlc(x, dt), G.pack_w(w, dt), b.to(G.DEV)
+    ed = e.to(G.DEV) if e is not None else None
+    rd = G.nlc(r, dt) if r is not None else None
+    yd = rd.clone() if inplace else torch.full((B * L, Cout), float("nan"), device=G.DEV, dtype=torch.bfloat16)
+    wk = None
+    if kblk:
+        wk = torch.empty_like(wd); G.check(G.lib.eegldm_conv1d_pack_kblocked(c.h, G.ptr(wd), G.ptr(wk), Cout, Cin, dt))
+    try:
+        G.check(G.lib.eegldm_conv1d_fwd(c.h, G.ptr(xd), Cin, G.ptr(wd), G.ptr(bd), G.ptr(yd), Cout, B, L, Cin, Cout, K, 1, K // 2, K // 2,
+                                        G.ptr(ed) if e is not None else None, Cout if e is not None else 0,
+                                        G.ptr(yd if inplace else rd) if r is not None else None, Cout if r is not None else 0, dt))
+        torch.cuda.synchronize()
+    finally:
+        if kblk: G.check(G.lib.eegldm_conv1d_forget_kblocked(c.h, G.ptr(wd)))
+    return yd
+
+
+def _dgrad(G, c, dy, w, r, K, packed):
+    dt = G.BF16
+    B, Cout, L = dy.shape; Cin = w.shape[1]
+    dyd, wd = G.nlc(dy, dt), G.pack_w(w, dt)
+    rd = G.nlc(r, dt) if r is not None else None
+    dxd = torch.full((B * L, Cin), float("nan"), device=G.DEV, dtype=torch.bfloat16)
+    if packed:
+        wt = torch.empty_like(wd); G.check(G.lib.eegldm_conv1d_pack_dgrad_k(c.h, G.ptr(wd), G.ptr(wt), Cout, Cin, K, dt))
+    try:
+        G.check(G.lib.eegldm_conv1d_bwd_data(c.h, G.ptr(dyd), Cout, G.ptr(wd), G.ptr(dxd), Cin, B, L, Cin, Cout, K, 1, K // 2, K // 2,
+                                             G.ptr(rd) if r is not None else None, Cin if r is not None else 0, dt))
+        torch.cuda.synchronize()
+    finally:
+        if packed: G.check(G.lib.eegldm_conv1d_forget_kblocked(c.h, G.ptr(wd)))
+    return dxd
+
+
+def _same_up_to_rounding_flips(a, b, what):
+    """The data gradient runs as an NT product on a transposed weight copy: same products as the transposed-operand kernel of gemm.hip, but
+    the MFMA steps visit the reduction in another order, so individual bf16 roundings may flip: few elements, one bf16 ulp each, anywhere."""
+    af, bf = a.float(), b.float()
+    nd = int((a.view(torch.int16) != b.view(torch.int16)).sum())
+    worst = float(((af - bf).abs() / (bf.abs() + 1e-3)).max())
+    print(f"{what}: {nd} of {a.numel()} elements differ from the gemm.hip kernel, worst relative difference {worst:.2e}")
+    assert nd <= 2e-3 * a.numel() and worst < 2.0 ** -6, (what, nd, a.numel(), worst)
+
+
+@pytest.mark.parametrize("case", CASES3)
+def test_big_tile_conv3_forward_and_data_gradient(case, env_switches):
+    import gpu_util as G
+    c = G.ctx(); dt = G.BF16
+    B, L, Cin, Cout, rv, rs = case
+    x = torch.from_numpy(normal((B, Cin, L), seed=10)).bfloat16().float()
+    w = (torch.from_numpy(normal((Cout, Cin, 3), seed=40)) / math.sqrt(Cin * 3)).bfloat16().float()
+    b = torch.from_numpy(normal((Cout,), seed=70))
+    e = torch.from_numpy(normal((B, Cout), seed=100)) if rv else None
+    r = torch.from_numpy(normal((B, Cout, L), seed=130)).bfloat16().float() if rs else None
+    ref = F.conv1d(x, w, b, padding=1)
+    if rv: ref = ref + e[:, :, None]
+    if rs: ref = ref + r
+    dy = torch.from_numpy(normal((B, Cout, L), seed=160)).bfloat16().float()
+    rr = torch.from_numpy(normal((B, Cin, L), seed=190)).bfloat16().float() if rs else None
+    refd = F.conv_transpose1d(dy, w, padding=1)
+    if rs: refd = refd + rr
+    env_switches(EEGLDM_NO_GEMM_BIG="1")
+    y_old = _fwd(G, c, x, w, b, e, r, 3, 0); dx_old = _dgrad(G, c, dy, w, rr, 3, 0)
+    env_switches(EEGLDM_NO_GEMM_BIG=None, EEGLDM_GEMM_BIG_MIN_TILES="1")       # force the big tile on these small problems
+    for kblk in (0, 1):
+        y = _fwd(G, c, x, w, b, e, r, 3, kblk)
+        G.assert_close(G.ncl(y, B, L), ref, **G.TOL[dt], name=f"fwd kblk={kblk}")
+        assert torch.equal(y.view(torch.int16), y_old.view(torch.int16)), f"big tile != 128 x 128 kernel (kblk={kblk})"
+    if rs:
+        yi = _fwd(G, c, x, w, b, e, r, 3, 1, inplace=True)            # the residual IS the output buffer (net.hip: out = conv2(h) + out)
+        assert torch.equal(yi.view(torch.int16), y_old.view(torch.int16)), "in-place residual"
+    if Cin % 256 == 0:                                                 # data gradient on the big tile: N = Cin
+        dx = _dgrad(G, c, dy, w, rr, 3, 1)
+        G.assert_close(G.ncl(dx, B, L), refd, **G.GTOL[dt], name="dgrad")
+        _same_up_to_rounding_flips(dx, dx_old, "3-tap data gradient")
+
+
+@pytest.mark.parametrize("case", CASES1)
+def test_big_tile_conv1_forward_and_data_gradient(case, env_switches):
+    import gpu_util as G
+    c = G.ctx(); dt = G.BF16
+    B, L, Cin, Cout, rs = case
+    x = torch.from_numpy(normal((B, Cin, L), seed=310)).bfloat16().float()
+    w = (torch.from_numpy(normal((Cout, Cin, 1), seed=340)) / math.sqrt(Cin)).bfloat16().float()
+    b = torch.from_numpy(normal((Cout,), seed=370))
+    r = torch.from_numpy(normal((B, Cout, L), seed=430)).bfloat16().float() if rs else None
+    ref = F.conv1d(x, w, b) + (r if rs else 0)
+    dy = torch.from_numpy(normal((B, Cout, L), seed=460)).bfloat16().float()
+    refd = F.conv_transpose1d(dy, w)
+    env_switches(EEGLDM_NO_GEMM_BIG="1")
+    y_old = _fwd(G, c, x, w, b, None, r, 1, 0); dx_old = _dgrad(G, c, dy, w, None, 1, 0)
+    env_switches(EEGLDM_NO_GEMM_BIG=None, EEGLDM_GEMM_BIG_MIN_TILES="1")
+    y = _fwd(G, c, x, w, b, None, r, 1, 0)
+    G.assert_close(G.ncl(y, B, L), ref, **G.TOL[dt], name="1x1 fwd")
+    assert torch.equal(y.view(torch.int16), y_old.view(torch.int16))
+    if Cin % 256 == 0:
+        dx = _dgrad(G, c, dy, w, None, 1, 1)
+        G.assert_close(G.ncl(dx, B, L), refd, **G.GTOL[dt], name="1x1 dgrad")
+        _same_up_to_rounding_flips(dx, dx_old, "1x1 data gradient")
+
+
+@pytest.mark.parametrize("shape", [(256, 192, 512, 512), (256, 384, 256, 256), (64, 768, 256, 512)])
+def test_big_tile_race_screen_at_production_size(shape):
+    """512 workgroups x 24-48 phases per launch, 30 launches per kernel: every launch must reproduce the first one bit for bit (a DMA that
+    lands after the read it should precede shows up as a rare wrong tile), and the first one must equal the 128 x 128 kernel."""
+    import os
+    import gpu_util as G
+    c = G.ctx(); dt = G.BF16
+    B, L, Cin, Cout = shape
+    g = torch.Generator(device="cuda").manual_seed(0)
+    xd = torch.randn(B * L, Cin, device=G.DEV, generator=g).bfloat16(); wd = (torch.randn(3, Cout, Cin, device=G.DEV, generator=g) / math.sqrt(3 * Cin)).bfloat16()
+    bd = torch.randn(Cout, device=G.DEV, generator=g); dyd = torch.randn(B * L, Cout, device=G.DEV, generator=g).bfloat16()
+    wk = torch.empty_like(wd); G.check(G.lib.eegldm_conv1d_pack_kblocked(c.h, G.ptr(wd), G.ptr(wk), Cout, Cin, dt))
+    wt = torch.empty_like(wd); G.check(G.lib.eegldm_conv1d_pack_dgrad(c.h, G.ptr(wd), G.ptr(wt), Cout, Cin, dt))
+    try:
+        def fwd():
+            y = torch.empty(B * L, Cout, device=G.DEV, dtype=torch.bfloat16)
+            G.check(G.lib.eegldm_conv1d_fwd(c.h, G.ptr(xd), Cin, G.ptr(wd), G.ptr(bd), G.ptr(y), Cout, B, L, Cin, Cout, 3, 1, 1, 1, None, 0, None, 0, dt))
+            return y
+
+        def dgrad():
+            dx = torch.empty(B * L, Cin, device=G.DEV, dtype=torch.bfloat16)
+            G.check(G.lib.eegldm_conv1d_bwd_data(c.h, G.ptr(dyd), Cout, G.ptr(wd), G.ptr(dx), Cin, B, L, Cin, Cout, 3, 1, 1, 1, None, 0, dt))
+            return dx
+        os.environ["EEGLDM_NO_GEMM_BIG"] = "1"; G.lib.eegldm_debug_reload_env()
+        y_old, dx_old = fwd(), dgrad()
+        os.environ.pop("EEGLDM_NO_GEMM_BIG"); G.lib.eegldm_debug_reload_env()
+        y0, dx0 = fwd(), dgrad()
+        _same_up_to_rounding_flips(y0, y_old, "forward")          # (at this size gemm.hip walks the reduction in another order than at the small sizes above)
+        _same_up_to_rounding_flips(dx0, dx_old, "data gradient")
+        for it in range(30):
+            y, dx = fwd(), dgrad()
+            assert torch.equal(y.view(torch.int16), y0.view(torch.int16)), ("forward", it, int((y.view(torch.int16) != y0.view(torch.int16)).sum()))
+            assert torch.equal(dx.view(torch.int16), dx0.view(torch.int16)), ("data gradient", it)
+    finally:
+        os.environ.pop("EEGLDM_NO_GEMM_BIG", None); G.lib.eegldm_debug_reload_env()
+        G.check(G.lib.eegldm_conv1d_forget_kblocked(c.h, G.ptr(wd)))
