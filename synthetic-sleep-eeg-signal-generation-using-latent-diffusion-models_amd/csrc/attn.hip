@@ -499,8 +499,8 @@ int launch_chain_q(eegldm_ctx* ctx, const ChainArgs& a, int B) {
   constexpr int LDS = (NCW == 8) ? ((STAGE_AREA > LONG2) ? STAGE_AREA : LONG2) : STAGE_AREA + TILE;
   static_assert(LDS <= 160 * 1024, "attention tile does not fit the LDS");
   auto kern = attn_chain_kernel<NJ, MODE, NQ, NCW, NC2>;
-  static bool attr = false;
-  if (!attr && LDS > 48 * 1024) { HIP_TRY(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS)); attr = true; }
+  static DevOnce attr;
+  if (LDS > 48 * 1024 && attr.need(ctx->device)) HIP_TRY(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
   ChainArgs ax = a;
   EEG_ENV_VAR(bool, no_xcd, getenv("EEGLDM_ATTN_NO_XCD") != nullptr);
   ax.xcd = (!no_xcd && T / QR > 1 && B % 8 == 0) ? 1 : 0;

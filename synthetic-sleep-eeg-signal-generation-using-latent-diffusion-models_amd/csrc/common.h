@@ -91,6 +91,9 @@ struct eegldm_ctx {
   float* gn_slot_arena = nullptr; GnFoldRec* gn_fold_dev = nullptr; int gn_fold_count = 0;
 };
 
+// per-DEVICE once flag (hipFuncSetAttribute and friends are per device; a process may drive several GPUs through several contexts)
+struct DevOnce { unsigned long long done = 0; bool need(int dev) { const unsigned long long b = 1ull << (dev & 63); if (done & b) return false; done |= b; return true; } };
+
 static inline size_t dtype_size(int dt) { return dt == EEGLDM_F32 ? 4 : 2; }
 // side waits for everything enqueued on the main stream so far / main waits for everything enqueued on the side stream
 int ctx_fork(eegldm_ctx* c);

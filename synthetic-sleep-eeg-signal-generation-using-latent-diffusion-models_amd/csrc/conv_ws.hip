@@ -235,11 +235,10 @@ int conv_ws_try(eegldm_ctx* ctx, int dtype, const void* x, long ldx, const void*
   long nbx = (long)ctx->num_cu * bpc / ny; if (nbx < 1) nbx = 1; if (nbx > a.ntiles) nbx = a.ntiles;
   a.tiles_per_block = (int)((a.ntiles + nbx - 1) / nbx);
   nbx = (a.ntiles + a.tiles_per_block - 1) / a.tiles_per_block;
-  static bool attr_set = false;
-  if (!attr_set) {
+  static DevOnce attr_once;      // (per device, not per process)
+  if (attr_once.need(ctx->device)) {
     HIP_TRY(hipFuncSetAttribute((const void*)conv3_ws_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, WS_LDS));
     HIP_TRY(hipFuncSetAttribute((const void*)conv3_ws_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, WS_LDS));
-    attr_set = true;
   }
   ProfRec rec; const bool prof = ctx->prof_on;          // same per-class accounting as gemm_launch (bench.py roofline leg)
   if (prof) {

@@ -959,11 +959,10 @@ template <typename T, int AMODE, int BMODE, int TAPS, int KSUB, int BN, int STRI
 int launch_k(eegldm_ctx* ctx, const GemmArgs& a_in) {
   using C = Cfg<T, AMODE, BMODE, TAPS, KSUB, BN, STRIDE, WMT, DMA>;
   auto kern = gemm_kernel<T, AMODE, BMODE, TAPS, KSUB, BN, STRIDE, WMT, DMA>;
-  static bool attr_set = false;
+  static DevOnce attr_once;
   static_assert(C::LDS_TOTAL <= 160 * 1024, "tile does not fit the 160 KiB LDS");
-  if (!attr_set && C::LDS_TOTAL > 48 * 1024) {
+  if (C::LDS_TOTAL > 48 * 1024 && attr_once.need(ctx->device)) {
     HIP_TRY(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_TOTAL));
-    attr_set = true;
   }
   GemmArgs a = a_in;
   dim3 grid((a.N + BN - 1) / BN, (a.M + C::BM - 1) / C::BM, a.batch * a.ztaps * a.splitk);

@@ -405,11 +405,8 @@ __global__ __launch_bounds__(NTHR, 2) void gemm_big1_kernel(const BigArgs p) {
 template <bool KBLK>
 int launch_big1(eegldm_ctx* ctx, const BigArgs& a) {
   auto kern = gemm_big1_kernel<KBLK>;
-  static int attr_dev = -1;
-  if (attr_dev != ctx->device) {
-    HIP_TRY(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS1_BYTES));
-    attr_dev = ctx->device;
-  }
+  static DevOnce attr_once;
+  if (attr_once.need(ctx->device)) HIP_TRY(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS1_BYTES));
   hipLaunchKernelGGL(kern, dim3(a.tiles_m * a.tiles_n), dim3(NTHR), LDS1_BYTES, ctx->stream, a);
   LAUNCH_CHECK();
   return 0;
@@ -418,11 +415,8 @@ int launch_big1(eegldm_ctx* ctx, const BigArgs& a) {
 template <int TAPS, bool KBLK, bool FLIP>
 int launch_big(eegldm_ctx* ctx, const BigArgs& a) {
   auto kern = gemm_big_kernel<TAPS, KBLK, FLIP>;
-  static int attr_dev = -1;      // the dynamic-LDS attribute is per device
-  if (attr_dev != ctx->device) {
-    HIP_TRY(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
-    attr_dev = ctx->device;
-  }
+  static DevOnce attr_once;      // the dynamic-LDS attribute is per device
+  if (attr_once.need(ctx->device)) HIP_TRY(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
   hipLaunchKernelGGL(kern, dim3(a.tiles_m * a.tiles_n), dim3(NTHR), LDS_BYTES, ctx->stream, a);
   LAUNCH_CHECK();
   return 0;

@@ -112,8 +112,8 @@ template <int N1, int N2>
 int launch(eegldm_ctx* ctx, const float* recon, const float* target, float* loss, float* drecon, int B, float w) {
   auto kern = spectral_kernel<N1, N2>;
   constexpr int lds = FFT<N1, N2>::LDS_BYTES;
-  static bool attr = false;
-  if (!attr) { HIP_TRY(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds)); attr = true; }
+  static DevOnce attr;
+  if (attr.need(ctx->device)) HIP_TRY(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
   hipLaunchKernelGGL(kern, dim3(B), dim3(NT), lds, ctx->stream, recon, target, loss, drecon, w);
   LAUNCH_CHECK();
   return 0;

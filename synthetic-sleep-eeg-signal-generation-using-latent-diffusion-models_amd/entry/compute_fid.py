@@ -25,11 +25,15 @@ def parse_args(argv=None):
     p.add_argument("--type_dataset", default="shhs"); p.add_argument("--synthetic_windows", type=int, default=0)
     p.add_argument("--samples", required=True, help="glob of generated windows, each (n, 1, 3000) float32 (sample_trials.py:166-170)")
     p.add_argument("--batch_size", type=int, default=256); p.add_argument("--seed", type=int, default=42)
-    p.add_argument("--batch_stats", action="store_true")
+    p.add_argument("--batch_stats", action="store_true", help="BatchNorm with batch statistics: the reference never calls model.eval() (compute_fid.py:357-372)")
+    p.add_argument("--reference_literal", action="store_true",
+                   help="the quantity the reference script prints: batch-statistics BatchNorm AND only the last 64 generated windows (its loop keeps the last batch, compute_fid.py:395-414)")
     return p.parse_args(argv)
 
 
 def main(args):
+    if getattr(args, "reference_literal", False):
+        args.batch_stats = True
     torch.manual_seed(args.seed)
     model = USleep(in_chans=2, sfreq=100, depth=12, with_skip_connection=True, n_classes=5, input_size_s=30, apply_softmax=False)   # compute_fid.py:357-365
     if args.params_path:
@@ -44,6 +48,13 @@ def main(args):
     files = sorted(glob.glob(args.samples))
     if not files:
         raise FileNotFoundError(f"no generated windows match {args.samples!r}")
+    if getattr(args, "reference_literal", False):          # the last 64 generated windows only
+        keep, n = [], 0
+        for f in reversed(files):
+            keep.append(f); n += int(np.load(f, mmap_mode="r").reshape(-1, 3000).shape[0])
+            if n >= 64:
+                break
+        files = sorted(keep)
     fake = FeatureMoments(dim, ctx=model.ctx)
     pending = []
     for i, f in enumerate(files):
@@ -51,7 +62,9 @@ def main(args):
         if sum(len(a) for a in pending) >= args.batch_size or i == len(files) - 1:
             fake.update(fid_features(model, torch.from_numpy(np.concatenate(pending, 0)), batch_stats=args.batch_stats)); pending = []
     fid = frechet_distance(*fake.finalize(), *real.finalize())
-    print(f"FID: {fid}  ({real.n} real windows, {fake.n} generated windows, {dim} features)")
+    mode = ("reference-literal: batch-statistics BatchNorm, last 64 generated windows" if getattr(args, "reference_literal", False)
+            else ("batch-statistics BatchNorm" if args.batch_stats else "eval-mode BatchNorm (running statistics), all generated windows"))
+    print(f"FID: {fid}  ({real.n} real windows, {fake.n} generated windows, {dim} features; mode: {mode})")
     return fid
 
 
