@@ -23,6 +23,8 @@
 //            row-contiguous stores.
 #include <stdlib.h>
 
+#include <type_traits>
+
 #include "common.h"
 #include "internal.h"
 
@@ -293,6 +295,287 @@ __global__ __launch_bounds__(NTHR, 2) void gemm_big_kernel(const BigArgs p) {
   big_epilogue(p, acc, smem, m0, n0, tid, lm, q, wm, wn);
 }
 
+// ---- persistent variant's epilogue: no LDS.  The fragment layout gives a lane 4 consecutive columns (8 bytes as bf16) of row lm;
+// v_permlane16_swap (gfx950) trades the packed halves of two neighbouring fragments between lane rows q and q ^ 1, after which a lane
+// holds 8 consecutive columns (16 bytes) and a wave instruction writes 64 contiguous bytes of each of 16 rows.  EXACTLY NST store
+// instructions per wave: the next tile's counted vmcnt waits step over them.
+constexpr int NST = FM * (FN / 2);
+__device__ __forceinline__ void big_store(const BigArgs& p, f32x4 (&acc)[FM][FN], int m0, int n0, int lm, int q, int wm, int wn) {
+  bf16_t* cp = p.C + (long)(m0 + wm * (FM * 16) + lm) * p.ldc + n0 + wn * 64 + (q & 1) * 16 + (q >> 1) * 8;
+#pragma unroll
+  for (int i = 0; i < FM; i++)
+#pragma unroll
+    for (int jp = 0; jp < FN / 2; jp++) {
+      const unsigned x0 = pack_bf16x2(acc[i][2 * jp][0], acc[i][2 * jp][1]), x1 = pack_bf16x2(acc[i][2 * jp][2], acc[i][2 * jp][3]);
+      const unsigned y0 = pack_bf16x2(acc[i][2 * jp + 1][0], acc[i][2 * jp + 1][1]), y1 = pack_bf16x2(acc[i][2 * jp + 1][2], acc[i][2 * jp + 1][3]);
+      // odd lane rows of x <-> even lane rows of y: q even keeps its fragment 2jp columns and receives the next four from q + 1;
+      // q odd receives fragment 2jp + 1's previous four from q - 1 and keeps its own
+      const auto s0 = __builtin_amdgcn_permlane16_swap(x0, y0, false, false);
+      const auto s1 = __builtin_amdgcn_permlane16_swap(x1, y1, false, false);
+      uint4 o; o.x = s0[0]; o.y = s1[0]; o.z = s0[1]; o.w = s1[1];
+      if (!BIG_DBG(16) || o.x == 0x12345u) *(uint4*)(cp + (long)i * 16 * p.ldc + jp * 32) = o;      // (bit 16: ablation build without the output stores)
+    }
+}
+
+// ---- persistent form of the 3-tap kernel: one workgroup per CU walks tiles blockIdx.x, + gridDim.x, ...
+// What it is for: in the one-tile-per-workgroup form every CU reaches its epilogue at the same time, the 25 MB of a round drain at
+// HBM rate while nothing computes (4.3 us per round measured: K sweep in tools/debug/gemm_big_check.py), and the next round's first
+// pieces are requested only after that.  Here the next tile's first three pieces are requested BEFORE this tile's output leaves.
+// gfx950 retires loads and stores through ONE in-order vmcnt, so (a) the first counted waits of the next tile step over the NST
+// stores (`carry`), and (b) a wave that waits for a DMA issued behind its stores waits for the stores too -- therefore only waves 0-3
+// (one per SIMD) issue DMAs and wait for them; waves 4-7 never wait on vmcnt in the loop, their half of the output drains under the
+// next tile's K loop, and the loaders' half has until the third barrier of the next tile.
+// Loader addressing: DMA instruction k of loader wave w fills LDS chunks ((w + 4k) * 64 + lane) = 8 tile rows; k advances the source
+// by 32 rows -- a SCALAR step on the base -- so the per-lane part (row within the 8, swizzled 16-byte slot) is ONE VGPR per operand.
+template <bool KBLK, bool FLIP, int NLOAD>      // NLOAD loader waves (4 or 2)
+__global__ __launch_bounds__(NTHR, 2) void gemm_bigp_kernel(const BigArgs p) {
+  constexpr int TAPS = 3;
+  static_assert(NLOAD == 2 || NLOAD == 4, "halo rows belong to waves 0 and 1; vmcnt holds 63");
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int lm = lane & 15, q = lane >> 4;
+  const int wm = wave >> 2, wn = wave & 3;
+  const int ntiles = p.tiles_m * p.tiles_n;
+  // XCD-aware tile order as in gemm_big_kernel (gridDim.x is a multiple of 8, so a workgroup's tiles stay on its XCD)
+  auto decode = [&](int w, int& tm0, int& tn0) __attribute__((always_inline)) {
+    int tile_m, tile_n;
+    if ((p.tiles_m & 7) == 0) { const int xcd = w & 7, slot = w >> 3; tile_n = slot % p.tiles_n; tile_m = (slot / p.tiles_n) * 8 + xcd; }
+    else { tile_n = w % p.tiles_n; tile_m = w / p.tiles_n; }
+    tm0 = tile_m * BM; tn0 = tile_n * BN;
+  };
+  const int S = p.K / BK;
+  const unsigned lds0 = (unsigned)(size_t)(lds_void_ptr)smem;
+  const unsigned wave_u = __builtin_amdgcn_readfirstlane(wave);
+  constexpr int B0 = 2 * A_ALLOC;          // B pieces behind the two A tiles
+
+  // ---- fragment addresses (as in gemm_big_kernel)
+  unsigned aof[TAPS];
+#pragma unroll
+  for (int t = 0; t < TAPS; t++) { const int pr = wm * (FM * 16) + lm + t; aof[t] = A_PAD + pr * ROWB + ((q ^ swz2(pr)) << 4); }
+  const unsigned bof = (wn * 64 + lm) * ROWB + ((q ^ swz2(lm)) << 4);
+
+  auto run = [&](auto loader_tag) __attribute__((always_inline)) {
+    constexpr bool LOADER = decltype(loader_tag)::value;
+    // ---- loader state
+    const int r8 = lane >> 3;
+    const int a_lc = (lane & 7) ^ swz2(1 + r8), b_lc = (lane & 7) ^ swz2(r8);           // (physical A row = 1 + tile row)
+    const unsigned a_voff = (unsigned)(((long)r8 * p.lda + a_lc * 8) * 2);
+    const unsigned b_voff = KBLK ? (unsigned)((((long)(b_lc >> 2) * p.N + r8) * 32 + (b_lc & 3) * 8) * 2) : (unsigned)(((long)r8 * p.ldb + b_lc * 8) * 2);
+    const long a_kstep = 8 * NLOAD * p.lda, b_kstep = KBLK ? (long)8 * NLOAD * 32 : 8 * NLOAD * p.ldb;       // elements per DMA instruction step (8 NLOAD rows)
+    const long bstep = KBLK ? (long)2 * p.N * 32 : (long)BK;                             // elements per K stage
+    // halo rows (rows of another sample = the conv's zero padding): wave 0, lanes 56-63 -> physical row 0 (the row above the tile);
+    // wave 1, lanes 0-7 -> physical row 193 (the row below); the other lanes of both instructions fetch zeros into the padding
+    const bool ah_top = wave == 0 && lane >= 56, ah_bot = wave == 1 && lane < 8;
+    unsigned ah_src = 0;
+    if (ah_top) ah_src = (unsigned)((((lane & 7) ^ swz2(0)) * 8) * 2);
+    if (ah_bot) ah_src = (unsigned)((((long)(BM + 1) * p.lda) + ((lane & 7) ^ swz2(BM + 1)) * 8) * 2);
+    bool ah_ok = false;
+    const bf16_t* a_base = nullptr; const bf16_t* b_base = nullptr; const bf16_t* h_base = nullptr;
+    auto set_tile = [&](int tm0, int tn0) __attribute__((always_inline)) {
+      h_base = p.A + (long)tm0 * p.lda - p.lda;
+      a_base = p.A + (long)tm0 * p.lda + (long)(8 * wave_u) * p.lda;
+      b_base = p.B + (KBLK ? (long)tn0 * 32 : (long)tn0 * p.ldb) + (long)(8 * wave_u) * (KBLK ? 32 : p.ldb);
+      const bool top_ok = tm0 % p.L != 0, bot_ok = (tm0 + BM) % p.L != 0;       // wave-uniform
+      ah_ok = (ah_top && top_ok) || (ah_bot && bot_ok);
+    };
+    // DMA instruction k of piece (s, t), per loader wave: k < 8 the B piece; 8..13 the A tile of stage s, 14 its halo rows (t == 0 only).
+    // The source bases are RUNNING scalar pointers (begin_piece, then one step per instruction): written as base + k * step the
+    // compiler hoists one 64-bit base per (tap, k) out of the K loop -- 60 SGPRs, spilled.
+    constexpr int NB = 32 / NLOAD, NA = 24 / NLOAD;
+    const bf16_t* bcur = nullptr; const bf16_t* acur = nullptr;
+    auto begin_piece = [&](int s, int t) __attribute__((always_inline)) {
+      const int tw = FLIP ? 2 - t : t;
+      unsigned long long b = (unsigned long long)(b_base + s * bstep + tw * p.sBt), a = (unsigned long long)(a_base + (long)s * BK);
+      asm volatile("" : "+s"(b), "+s"(a));
+      bcur = (const bf16_t*)b; acur = (const bf16_t*)a;
+    };
+    auto issue = [&](int s, int t, int k) __attribute__((always_inline)) {
+      if (k < NB) {
+        dma16s(bcur, b_voff, lds0 + B0 + t * B_ALLOC + (wave_u + NLOAD * k) * 1024);
+        bcur += b_kstep;
+      } else if (k < NB + NA) {
+        const int ka = k - NB;
+        dma16s(acur, a_voff, lds0 + (s & 1) * A_ALLOC + A_PAD + ROWB + (wave_u + NLOAD * ka) * 1024);
+        acur += a_kstep;
+      } else if (wave_u < 2) {
+        const bf16_t* hb = h_base + (long)s * BK;         // base of the row above the tile
+        const void* src = ah_ok ? (const void*)((const char*)hb + ah_src) : p.zero_page;
+        dma16(src, lds0 + (s & 1) * A_ALLOC + (wave_u == 0 ? 0 : A_PAD + (BM + 1) * ROWB));
+      }
+    };
+    auto issue_all = [&](int pc) __attribute__((always_inline)) {
+      const int s = pc / TAPS, t = pc % TAPS;
+      begin_piece(s, t);
+#pragma unroll
+      for (int k = 0; k < NB + NA + 1; k++) if (k < NB || t == 0) issue(s, t, k);
+    };
+    // counted wait of a loader: at most the instructions of piece p+2 (tap `t_inflight`) still in flight; pieces with an A tile carry
+    // 14 instructions, 15 in waves 0 and 1; the others 8.  `c`: the previous tile's NST stores sit between pieces 0-2 and piece 3.
+    auto wait_dma = [&](const int t_inflight, const bool any, const bool c) __attribute__((always_inline)) {
+      if (!any) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      else if (t_inflight != 0) {
+        if (c) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NB + NST) : "memory");
+        else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NB) : "memory");
+      } else if (c) {
+        if (wave_u < 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NB + NA + 1 + NST) : "memory");
+        else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NB + NA + NST) : "memory");
+      } else {
+        if (wave_u < 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NB + NA + 1) : "memory");
+        else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NB + NA) : "memory");
+      }
+    };
+
+    f32x4 acc[FM][FN];
+    auto zero_acc = [&]() __attribute__((always_inline)) {
+#pragma unroll
+      for (int i = 0; i < FM; i++)
+#pragma unroll
+        for (int j = 0; j < FN; j++) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    };
+    // bias / embedding row / residual, added in the fragment layout (fp32) right behind the K loop and BEFORE the next tile's pieces
+    // are requested (in-order vmcnt: a load issued behind the DMAs would wait for them)
+    float4 add[FN];
+    auto load_operands = [&](int tm0, int tn0) __attribute__((always_inline)) {
+#pragma unroll
+      for (int j = 0; j < FN; j++) {
+        const int nj = tn0 + wn * 64 + j * 16 + q * 4;
+        add[j] = p.bias ? *(const float4*)(p.bias + nj) : make_float4(0.f, 0.f, 0.f, 0.f);
+        if (p.rowvec) {           // a tile lies inside one sample (rows_per_vec % 192 == 0)
+          const float4 e = *(const float4*)(p.rowvec + (long)(tm0 / p.rows_per_vec) * p.ld_rowvec + nj);
+          add[j].x += e.x; add[j].y += e.y; add[j].z += e.z; add[j].w += e.w;
+        }
+      }
+      // the whole residual tile is requested at once (48 registers: the fragment registers are idle here) -- with a one-row lookahead
+      // the six rows cost six HBM round trips: 15 us of a 76 us launch (tools/debug/gemm_big_ablate.sh, bits 32)
+    };
+    auto apply_operands = [&](int tm0, int tn0) __attribute__((always_inline)) {
+      uint2 res[FM][FN];
+      if (p.resid) {      // (one block for the loads and their use: split over two `if (p.resid)` the tile stays live across the K loop)
+#pragma unroll
+        for (int i = 0; i < FM; i++) {
+          const bf16_t* rp = p.resid + (long)(tm0 + wm * (FM * 16) + i * 16 + lm) * p.ldr + tn0 + wn * 64 + q * 4;
+#pragma unroll
+          for (int j = 0; j < FN; j++) res[i][j] = *(const uint2*)(rp + j * 16);
+        }
+      }
+      // (bias + embedding row + residual) first, then onto the accumulator: the summation order of big_epilogue / gemm.hip, bit for bit
+      if (p.resid) {
+#pragma unroll
+        for (int i = 0; i < FM; i++)
+#pragma unroll
+          for (int j = 0; j < FN; j++) {
+            const uint2 r = res[i][j];
+            acc[i][j][0] += add[j].x + __uint_as_float(r.x << 16); acc[i][j][1] += add[j].y + __uint_as_float(r.x & 0xffff0000u);
+            acc[i][j][2] += add[j].z + __uint_as_float(r.y << 16); acc[i][j][3] += add[j].w + __uint_as_float(r.y & 0xffff0000u);
+          }
+      } else {
+#pragma unroll
+        for (int i = 0; i < FM; i++)
+#pragma unroll
+          for (int j = 0; j < FN; j++) { acc[i][j][0] += add[j].x; acc[i][j][1] += add[j].y; acc[i][j][2] += add[j].z; acc[i][j][3] += add[j].w; }
+      }
+    };
+
+    int tile_m0 = 0, tile_n0 = 0;      // the current tile, for the operand prefetch inside its last phase
+    uint4 af[FM], bf0[FN], bf1[FN];
+    // one phase (schedule of gemm_big_kernel: k-step 0 | wait piece p+1 + barrier | issue piece p+3, k-step 1)
+    auto phase = [&](const int s, const int t, const bool has1, const bool has2, const bool has3, const bool c, const bool pre = false) __attribute__((always_inline)) {
+      const char* smA = smem + (s & 1) * A_ALLOC;
+      const char* smB = smem + B0 + t * B_ALLOC;
+      const int t1 = (t + 1) % TAPS, s1 = s + (t + 1) / TAPS;
+      const int t2 = (t + 2) % TAPS;
+#pragma unroll
+      for (int i = 0; i < FM; i++) {
+#pragma unroll
+        for (int j = 0; j < FN; j++)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, bf0[j]), __builtin_bit_cast(bf16x8, af[i]), acc[i][j], 0, 0, 0);
+        if (i == 0) {
+          __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+          for (int j = 0; j < FN; j++) bf1[j] = *(const uint4*)(smB + (bof ^ 64) + j * 2048);
+        }
+        af[i] = *(const uint4*)(smA + (aof[t] ^ 64) + i * 2048);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      if (LOADER && has1) wait_dma(t2, has2, c);
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      asm volatile("" ::: "memory");
+      const char* smA1 = smem + (s1 & 1) * A_ALLOC;
+      const char* smB1 = smem + B0 + t1 * B_ALLOC;
+      if (has1) {
+#pragma unroll
+        for (int j = 0; j < FN; j++) bf0[j] = *(const uint4*)(smB1 + bof + j * 2048);
+      }
+      // last phase of a tile: nothing is in flight and nothing is read any more -- the epilogue operands are requested here and arrive
+      // under the last 24 MFMAs
+      if (pre && !BIG_DBG(32)) load_operands(tile_m0, tile_n0);
+      __builtin_amdgcn_sched_barrier(0);
+      const int n_dma = t == 0 ? NB + NA + 1 : NB;        // instructions of piece p+3 = (s + 1, t), spread over the 24 MFMA slots
+      if (LOADER && has3) begin_piece(s + 1, t);
+#pragma unroll
+      for (int i = 0; i < FM; i++) {
+#pragma unroll
+        for (int j = 0; j < FN; j++) {
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, bf1[j]), __builtin_bit_cast(bf16x8, af[i]), acc[i][j], 0, 0, 0);
+          if (LOADER && has3) {
+#pragma unroll
+            for (int k = 0; k < NB + NA + 1; k++) if (k < n_dma && (k * (FM * FN)) / n_dma == i * FN + j) issue(s + 1, t, k);
+          }
+        }
+        if (has1) af[i] = *(const uint4*)(smA1 + aof[t1] + i * 2048);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    };
+
+    int m0, n0;
+    decode(blockIdx.x, m0, n0);
+    if (LOADER) { set_tile(m0, n0); issue_all(0); issue_all(1); issue_all(2); }
+    zero_acc();
+    bool carry = false;
+    int w = blockIdx.x;
+#pragma unroll 1
+    for (;;) {
+      // piece 0 landed (pieces 1 and 2 and the previous tile's stores may still fly); first fragments
+      if (LOADER) {
+        if (carry) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * NB + NST) : "memory");
+        else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * NB) : "memory");
+      }
+      __builtin_amdgcn_s_barrier();
+      asm volatile("" ::: "memory");
+#pragma unroll
+      for (int j = 0; j < FN; j++) bf0[j] = *(const uint4*)(smem + B0 + bof + j * 2048);
+#pragma unroll
+      for (int i = 0; i < FM; i++) af[i] = *(const uint4*)(smem + aof[0] + i * 2048);
+      bool c = carry;
+#pragma unroll 1
+      for (int s = 0; s + 1 < S; s++) {
+        phase(s, 0, true, true, true, c); phase(s, 1, true, true, true, c); phase(s, 2, true, true, true, false);
+        c = false;
+      }
+      tile_m0 = m0; tile_n0 = n0;
+      phase(S - 1, 0, true, true, false, c); phase(S - 1, 1, true, false, false, false); phase(S - 1, 2, false, false, false, false, true);
+      // nobody reads the ring behind the last barrier
+      const int w1 = w + (int)gridDim.x;
+      const bool more = w1 < ntiles;
+      int m1 = 0, n1 = 0;
+      if (!BIG_DBG(32)) apply_operands(m0, n0);
+      __builtin_amdgcn_sched_barrier(0);
+      if (more) {
+        decode(w1, m1, n1);
+        if (LOADER) { set_tile(m1, n1); issue_all(0); issue_all(1); issue_all(2); }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      big_store(p, acc, m0, n0, lm, q, wm, wn);
+      if (!more) return;
+      __builtin_amdgcn_sched_barrier(0);
+      zero_acc();
+      m0 = m1; n0 = n1; w = w1; carry = true;
+    }
+  };
+  if (wave_u < NLOAD) run(std::true_type{}); else run(std::false_type{});
+}
+
 // ---- one tap (1 x 1 convs / NT products): Y[r][n] = sum_k A[r][k] * W[n][k].  Every K stage carries its own A tile, so the ring is
 // two (A, B) stage buffers (112 KB); same phase shape as the 3-tap kernel (barrier between the two k-steps, fragment reads one k-step
 // ahead), with stage s + 2 issued behind B_s into the buffer stage s vacates: one phase of DMA lead.  Measured (tools/debug/
@@ -402,8 +685,229 @@ __global__ __launch_bounds__(NTHR, 2) void gemm_big1_kernel(const BigArgs p) {
   big_epilogue(p, acc, smem, m0, n0, tid, lm, q, wm, wn);
 }
 
+// ---- persistent form of the 1-tap kernel (structure and reasons: gemm_bigp_kernel).  Ring = two (A, B) stage buffers; behind the last
+// barrier of a tile both are free, so stages 0 and 1 of the next tile are requested before the output leaves; stage 2 follows behind
+// the first barrier of the next tile, and the loaders' stores have until its second barrier.
+template <bool KBLK, int NLOAD>
+__global__ __launch_bounds__(NTHR, 2) void gemm_big1p_kernel(const BigArgs p) {
+  static_assert(NLOAD == 2 || NLOAD == 4, "vmcnt holds 63");
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int lm = lane & 15, q = lane >> 4;
+  const int wm = wave >> 2, wn = wave & 3;
+  const int ntiles = p.tiles_m * p.tiles_n;
+  auto decode = [&](int w, int& tm0, int& tn0) __attribute__((always_inline)) {
+    int tile_m, tile_n;
+    if ((p.tiles_m & 7) == 0) { const int xcd = w & 7, slot = w >> 3; tile_n = slot % p.tiles_n; tile_m = (slot / p.tiles_n) * 8 + xcd; }
+    else { tile_n = w % p.tiles_n; tile_m = w / p.tiles_n; }
+    tm0 = tile_m * BM; tn0 = tile_n * BN;
+  };
+  const int S = p.K / BK;
+  const unsigned lds0 = (unsigned)(size_t)(lds_void_ptr)smem;
+  const unsigned wave_u = __builtin_amdgcn_readfirstlane(wave);
+  const int pr0 = wm * (FM * 16) + lm;
+  const unsigned aof = pr0 * ROWB + ((q ^ swz2(pr0)) << 4);
+  const unsigned bof = A_MAIN + (wn * 64 + lm) * ROWB + ((q ^ swz2(lm)) << 4);
+
+  auto run = [&](auto loader_tag) __attribute__((always_inline)) {
+    constexpr bool LOADER = decltype(loader_tag)::value;
+    const int r8 = lane >> 3;
+    const int lc = (lane & 7) ^ swz2(r8);
+    const unsigned a_voff = (unsigned)(((long)r8 * p.lda + lc * 8) * 2);
+    const unsigned b_voff = KBLK ? (unsigned)((((long)(lc >> 2) * p.N + r8) * 32 + (lc & 3) * 8) * 2) : (unsigned)(((long)r8 * p.ldb + lc * 8) * 2);
+    const long a_kstep = 8 * NLOAD * p.lda, b_kstep = KBLK ? (long)8 * NLOAD * 32 : 8 * NLOAD * p.ldb;
+    const long bstep = KBLK ? (long)2 * p.N * 32 : (long)BK;
+    const bf16_t* a_base = nullptr; const bf16_t* b_base = nullptr;
+    auto set_tile = [&](int tm0, int tn0) __attribute__((always_inline)) {
+      a_base = p.A + (long)tm0 * p.lda + (long)(8 * wave_u) * p.lda;
+      b_base = p.B + (KBLK ? (long)tn0 * 32 : (long)tn0 * p.ldb) + (long)(8 * wave_u) * (KBLK ? 32 : p.ldb);
+    };
+    constexpr int NB = 32 / NLOAD, NA = 24 / NLOAD, NS = NB + NA;       // DMA instructions of one stage per loader wave
+    const bf16_t* bcur = nullptr; const bf16_t* acur = nullptr;
+    auto begin_stage = [&](int s) __attribute__((always_inline)) {
+      unsigned long long b = (unsigned long long)(b_base + s * bstep), a = (unsigned long long)(a_base + (long)s * BK);
+      asm volatile("" : "+s"(b), "+s"(a));
+      bcur = (const bf16_t*)b; acur = (const bf16_t*)a;
+    };
+    auto issue = [&](int s, int k) __attribute__((always_inline)) {
+      if (k < NB) {
+        dma16s(bcur, b_voff, lds0 + (s & 1) * S1_BYTES + A_MAIN + (wave_u + NLOAD * k) * 1024);
+        bcur += b_kstep;
+      } else {
+        dma16s(acur, a_voff, lds0 + (s & 1) * S1_BYTES + (wave_u + NLOAD * (k - NB)) * 1024);
+        acur += a_kstep;
+      }
+    };
+    auto issue_all = [&](int s) __attribute__((always_inline)) {
+      begin_stage(s);
+#pragma unroll
+      for (int k = 0; k < NS; k++) issue(s, k);
+    };
+
+    f32x4 acc[FM][FN];
+    auto zero_acc = [&]() __attribute__((always_inline)) {
+#pragma unroll
+      for (int i = 0; i < FM; i++)
+#pragma unroll
+        for (int j = 0; j < FN; j++) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    };
+    float4 add[FN];
+    auto load_operands = [&](int tm0, int tn0) __attribute__((always_inline)) {
+#pragma unroll
+      for (int j = 0; j < FN; j++) {
+        const int nj = tn0 + wn * 64 + j * 16 + q * 4;
+        add[j] = p.bias ? *(const float4*)(p.bias + nj) : make_float4(0.f, 0.f, 0.f, 0.f);
+        if (p.rowvec) {
+          const float4 e = *(const float4*)(p.rowvec + (long)(tm0 / p.rows_per_vec) * p.ld_rowvec + nj);
+          add[j].x += e.x; add[j].y += e.y; add[j].z += e.z; add[j].w += e.w;
+        }
+      }
+      // the whole residual tile is requested at once (48 registers: the fragment registers are idle here) -- with a one-row lookahead
+      // the six rows cost six HBM round trips: 15 us of a 76 us launch (tools/debug/gemm_big_ablate.sh, bits 32)
+    };
+    auto apply_operands = [&](int tm0, int tn0) __attribute__((always_inline)) {
+      uint2 res[FM][FN];
+      if (p.resid) {      // (one block for the loads and their use: split over two `if (p.resid)` the tile stays live across the K loop)
+#pragma unroll
+        for (int i = 0; i < FM; i++) {
+          const bf16_t* rp = p.resid + (long)(tm0 + wm * (FM * 16) + i * 16 + lm) * p.ldr + tn0 + wn * 64 + q * 4;
+#pragma unroll
+          for (int j = 0; j < FN; j++) res[i][j] = *(const uint2*)(rp + j * 16);
+        }
+      }
+      // (bias + embedding row + residual) first, then onto the accumulator: the summation order of big_epilogue / gemm.hip, bit for bit
+      if (p.resid) {
+#pragma unroll
+        for (int i = 0; i < FM; i++)
+#pragma unroll
+          for (int j = 0; j < FN; j++) {
+            const uint2 r = res[i][j];
+            acc[i][j][0] += add[j].x + __uint_as_float(r.x << 16); acc[i][j][1] += add[j].y + __uint_as_float(r.x & 0xffff0000u);
+            acc[i][j][2] += add[j].z + __uint_as_float(r.y << 16); acc[i][j][3] += add[j].w + __uint_as_float(r.y & 0xffff0000u);
+          }
+      } else {
+#pragma unroll
+        for (int i = 0; i < FM; i++)
+#pragma unroll
+          for (int j = 0; j < FN; j++) { acc[i][j][0] += add[j].x; acc[i][j][1] += add[j].y; acc[i][j][2] += add[j].z; acc[i][j][3] += add[j].w; }
+      }
+    };
+
+    int tile_m0 = 0, tile_n0 = 0;
+    uint4 af[FM], bf0[FN], bf1[FN];
+    // phase s: k-step 0 | wait stage s+1 + barrier | issue stage s+2 into the buffer stage s vacates, k-step 1.  `c`: the previous tile's
+    // stores are the only instructions younger than stage s+1 (phase 0 of a tile)
+    auto phase = [&](const int s, const bool has1, const bool has2, const bool c, const bool pre = false) __attribute__((always_inline)) {
+      const char* sm = smem + (s & 1) * S1_BYTES;
+#pragma unroll
+      for (int i = 0; i < FM; i++) {
+#pragma unroll
+        for (int j = 0; j < FN; j++)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, bf0[j]), __builtin_bit_cast(bf16x8, af[i]), acc[i][j], 0, 0, 0);
+        if (i == 0) {
+          __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+          for (int j = 0; j < FN; j++) bf1[j] = *(const uint4*)(sm + (bof ^ 64) + j * 2048);
+        }
+        af[i] = *(const uint4*)(sm + (aof ^ 64) + i * 2048);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      if (LOADER && has1) {
+        if (c) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NST) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      asm volatile("" ::: "memory");
+      const char* sm1 = smem + ((s + 1) & 1) * S1_BYTES;
+      if (has1) {
+#pragma unroll
+        for (int j = 0; j < FN; j++) bf0[j] = *(const uint4*)(sm1 + bof + j * 2048);
+      }
+      if (pre) load_operands(tile_m0, tile_n0);      // (see gemm_bigp_kernel)
+      __builtin_amdgcn_sched_barrier(0);
+      if (LOADER && has2) begin_stage(s + 2);
+#pragma unroll
+      for (int i = 0; i < FM; i++) {
+#pragma unroll
+        for (int j = 0; j < FN; j++) {
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, bf1[j]), __builtin_bit_cast(bf16x8, af[i]), acc[i][j], 0, 0, 0);
+          if (LOADER && has2) {
+#pragma unroll
+            for (int k = 0; k < NS; k++) if ((k * (FM * FN)) / NS == i * FN + j) issue(s + 2, k);
+          }
+        }
+        if (has1) af[i] = *(const uint4*)(sm1 + aof + i * 2048);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    };
+
+    int m0, n0;
+    decode(blockIdx.x, m0, n0);
+    if (LOADER) { set_tile(m0, n0); issue_all(0); if (S > 1) issue_all(1); }
+    zero_acc();
+    bool carry = false;
+    int w = blockIdx.x;
+#pragma unroll 1
+    for (;;) {
+      if (LOADER) {      // stage 0 landed (stage 1 and the previous tile's stores may still fly)
+        if (S > 1) {
+          if (carry) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NS + NST) : "memory");
+          else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NS) : "memory");
+        } else {
+          if (carry) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NST) : "memory");
+          else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+      }
+      __builtin_amdgcn_s_barrier();
+      asm volatile("" ::: "memory");
+#pragma unroll
+      for (int j = 0; j < FN; j++) bf0[j] = *(const uint4*)(smem + bof + j * 2048);
+#pragma unroll
+      for (int i = 0; i < FM; i++) af[i] = *(const uint4*)(smem + aof + i * 2048);
+      bool c = carry;
+#pragma unroll 1
+      for (int s = 0; s + 2 < S; s++) { phase(s, true, true, c); c = false; }
+      if (S > 1) { phase(S - 2, true, false, c); c = false; }
+      tile_m0 = m0; tile_n0 = n0;
+      phase(S - 1, false, false, false, true);
+      const int w1 = w + (int)gridDim.x;
+      const bool more = w1 < ntiles;
+      int m1 = 0, n1 = 0;
+      apply_operands(m0, n0);
+      __builtin_amdgcn_sched_barrier(0);
+      if (more) {
+        decode(w1, m1, n1);
+        if (LOADER) { set_tile(m1, n1); issue_all(0); if (S > 1) issue_all(1); }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      big_store(p, acc, m0, n0, lm, q, wm, wn);
+      if (!more) return;
+      __builtin_amdgcn_sched_barrier(0);
+      zero_acc();
+      m0 = m1; n0 = n1; w = w1; carry = true;
+    }
+  };
+  if (wave_u < NLOAD) run(std::true_type{}); else run(std::false_type{});
+}
+
+template <bool KBLK, int NLOAD>
+int launch_big1p(eegldm_ctx* ctx, const BigArgs& a) {
+  auto kern = gemm_big1p_kernel<KBLK, NLOAD>;
+  static DevOnce attr_once;
+  if (attr_once.need(ctx->device)) HIP_TRY(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * S1_BYTES));
+  int grid = a.tiles_m * a.tiles_n;
+  const int cus = ctx->num_cu & ~7;
+  if (grid > cus) grid = cus;
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(NTHR), 2 * S1_BYTES, ctx->stream, a);
+  LAUNCH_CHECK();
+  return 0;
+}
+
 template <bool KBLK>
 int launch_big1(eegldm_ctx* ctx, const BigArgs& a) {
+  EEG_ENV_VAR(bool, no_persist, getenv("EEGLDM_GEMM_BIG_NO_PERSIST") != nullptr || getenv("EEGLDM_GEMM_BIG1_NO_PERSIST") != nullptr);
+  if (!no_persist) return launch_big1p<KBLK, 4>(ctx, a);
   auto kern = gemm_big1_kernel<KBLK>;
   static DevOnce attr_once;
   if (attr_once.need(ctx->device)) HIP_TRY(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS1_BYTES));
@@ -412,8 +916,23 @@ int launch_big1(eegldm_ctx* ctx, const BigArgs& a) {
   return 0;
 }
 
+template <bool KBLK, bool FLIP, int NLOAD>
+int launch_bigp(eegldm_ctx* ctx, const BigArgs& a) {
+  auto kern = gemm_bigp_kernel<KBLK, FLIP, NLOAD>;
+  static DevOnce attr_once;      // the dynamic-LDS attribute is per device
+  if (attr_once.need(ctx->device)) HIP_TRY(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, RING));
+  int grid = a.tiles_m * a.tiles_n;
+  const int cus = ctx->num_cu & ~7;      // a multiple of 8 keeps a workgroup's tiles on its XCD
+  if (grid > cus) grid = cus;
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(NTHR), RING, ctx->stream, a);
+  LAUNCH_CHECK();
+  return 0;
+}
+
 template <int TAPS, bool KBLK, bool FLIP>
 int launch_big(eegldm_ctx* ctx, const BigArgs& a) {
+  EEG_ENV_VAR(bool, no_persist, getenv("EEGLDM_GEMM_BIG_NO_PERSIST") != nullptr);
+  if (!no_persist) return launch_bigp<KBLK, FLIP, 4>(ctx, a);      // (2 loader waves measured equal: tools/debug/gemm_big_check.py, round 4)
   auto kern = gemm_big_kernel<TAPS, KBLK, FLIP>;
   static DevOnce attr_once;      // the dynamic-LDS attribute is per device
   if (attr_once.need(ctx->device)) HIP_TRY(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));

@@ -1,7 +1,9 @@
 """-m gpu: the 192 x 256 big-tile conv kernels (csrc/gemm_big.hip) -- 3-tap conv forward, its data gradient through the transposed K-blocked
 weight copy, the 1 x 1 variant -- against torch's fp32 conv on bf16-rounded operands (the oracle's building block) AND, bit for bit, against
 the 128 x 128 kernel of gemm.hip (same products, same k order per output), including bias + time-embedding row + residual (also in place),
-halo rows at sample edges (tiles at the first / last rows of a sample and in its interior), plain and K-blocked weights; then a race screen:
+halo rows at sample edges (tiles at the first / last rows of a sample and in its interior), plain and K-blocked weights; the persistent form
+(one workgroup per CU walking several tiles, next tile's pieces requested before this tile's stores) against the one-tile-per-workgroup
+form on problems of 1.2 - 2 rounds with every epilogue operand; then a race screen:
 the LDS-DMA ring is ordered only by counted waits and one barrier per phase, so repeated launches on production-size problems must
 reproduce the first result bit for bit."""
 import math
@@ -121,6 +123,38 @@ def test_big_tile_conv1_forward_and_data_gradient(case, env_switches):
         dx = _dgrad(G, c, dy, w, None, 1, 1)
         G.assert_close(G.ncl(dx, B, L), refd, **G.GTOL[dt], name="1x1 dgrad")
         _same_up_to_rounding_flips(dx, dx_old, "1x1 data gradient")
+
+
+#         B,  L,   Cin, Cout   -> tiles: 512 = two full rounds; 384 = 1.5 rounds (some workgroups walk two tiles, some one);
+#                                 300 with tiles_m % 8 != 0 (the plain tile order)
+@pytest.mark.parametrize("shape", [(64, 768, 256, 512), (48, 768, 512, 512), (25, 768, 256, 768)])
+def test_persistent_form_equals_one_tile_per_workgroup(shape, env_switches):
+    """The persistent kernels carry state from tile to tile (counted waits that step over the previous tile's stores, scalar DMA bases,
+    the halo decision); with more tiles than CUs every workgroup goes round the loop.  Same arithmetic in the same order as the
+    one-tile-per-workgroup kernels, so: bit for bit, with bias + embedding row + residual (forward), residual (data gradient), 3 taps and 1."""
+    import gpu_util as G
+    c = G.ctx(); dt = G.BF16
+    B, L, Cin, Cout = shape
+    assert (B * L // 192) * (Cout // 256) > 256      # (the data gradient of the third shape has 100 tiles: gemm.hip runs it in both forms)
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(B, Cin, L, generator=g).bfloat16().float(); dy = torch.randn(B, Cout, L, generator=g).bfloat16().float()
+    e = torch.randn(B, Cout, generator=g); b = torch.randn(Cout, generator=g)
+    r = torch.randn(B, Cout, L, generator=g).bfloat16().float(); rr = torch.randn(B, Cin, L, generator=g).bfloat16().float()
+    out = {}
+    for K in (3, 1):
+        w = (torch.randn(Cout, Cin, K, generator=g) / math.sqrt(Cin * K)).bfloat16().float()
+        for form in ("persistent", "one tile"):
+            env_switches(EEGLDM_GEMM_BIG_NO_PERSIST=None if form == "persistent" else "1")
+            out[(K, form)] = (_fwd(G, c, x, w, b, e if K == 3 else None, r, K, 1 if K == 3 else 0), _dgrad(G, c, dy, w, rr if K == 3 else None, K, 1),
+                              _fwd(G, c, x, w, b, None, None, K, 0))
+        for what, a_, b_ in zip(("forward + all operands", "data gradient", "forward, bias only"), out[(K, "persistent")], out[(K, "one tile")]):
+            assert torch.isfinite(a_.float()).all()
+            assert torch.equal(a_.view(torch.int16), b_.view(torch.int16)), (K, what, int((a_.view(torch.int16) != b_.view(torch.int16)).sum()))
+    # and against torch's fp32 conv on the same bf16-rounded operands (3 taps, all operands): the halo rows of every tile position
+    w3 = (torch.randn(Cout, Cin, 3, generator=torch.Generator().manual_seed(6)) / math.sqrt(Cin * 3)).bfloat16().float()
+    env_switches(EEGLDM_GEMM_BIG_NO_PERSIST=None)
+    y = _fwd(G, c, x, w3, b, e, r, 3, 1)
+    G.assert_close(G.ncl(y, B, L), F.conv1d(x, w3, b, padding=1) + e[:, :, None] + r, **G.TOL[dt], name="persistent forward vs torch")
 
 
 @pytest.mark.parametrize("shape", [(256, 192, 512, 512), (256, 384, 256, 256), (64, 768, 256, 512)])

@@ -4,7 +4,7 @@
 #   bash tools/debug/gemm_big_ablate.sh run        (on the GPU box)
 cd "$(dirname "$0")/../.." || exit 1
 PKG=synthetic-sleep-eeg-signal-generation-using-latent-diffusion-models_amd
-VARIANTS="0 8 1 2 4 3 6 7 15"
+VARIANTS="${VARIANTS:-0 8 1 2 4 3 6 7 15}"
 if [ "$1" = build ]; then
   for b in $VARIANTS; do
     /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wno-unused-result -Iinclude -DEEG_BIG_DBG=$b -c $PKG/csrc/gemm_big.hip -o /tmp/gemm_big_$b.o 2>/dev/null || exit 1

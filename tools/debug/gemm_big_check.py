@@ -98,7 +98,9 @@ if mode == "check":
             G.assert_close(dx, refd, **G.GTOL[dt], name=f"1x1 dgrad {ci}")
     print("check ok")
 else:
-    SHAPES = [(256, 192, 512, 512), (256, 192, 1024, 512), (256, 192, 768, 512), (256, 384, 256, 256), (256, 384, 512, 256), (256, 384, 768, 256), (256, 384, 128, 256), (256, 192, 256, 512)]
+    if os.environ.get("BIG_SHAPES"):      # "B,L,Cin,Cout;..." : only these 3-tap shapes
+        SHAPES = [tuple(int(v) for v in t.split(",")) for t in os.environ["BIG_SHAPES"].split(";")]
+    else: SHAPES = [(256, 192, 512, 512), (256, 192, 1024, 512), (256, 192, 768, 512), (256, 384, 256, 256), (256, 384, 512, 256), (256, 384, 768, 256), (256, 384, 128, 256), (256, 192, 256, 512)]
     for (B, L, Cin, Cout) in SHAPES:
         xd = torch.randn(B * L, Cin, device=G.DEV).bfloat16(); wd = (torch.randn(3, Cout, Cin, device=G.DEV) / math.sqrt(3 * Cin)).bfloat16()
         bd = torch.randn(Cout, device=G.DEV); yd = torch.empty(B * L, Cout, device=G.DEV, dtype=torch.bfloat16)
@@ -106,31 +108,36 @@ else:
         dyd = torch.randn(B * L, Cout, device=G.DEV).bfloat16(); dxd = torch.empty(B * L, Cin, device=G.DEV, dtype=torch.bfloat16)
         wt = torch.empty_like(wd); G.check(lib.eegldm_conv1d_pack_dgrad(c.h, G.ptr(wd), G.ptr(wt), Cout, Cin, dt))
         res = {}
-        for name, env in (("big", None), ("old", 1)):
-            setenv(EEGLDM_NO_GEMM_BIG=env)
+        ed = torch.randn(B, Cout, device=G.DEV); rd = torch.randn(B * L, Cout, device=G.DEV).bfloat16(); rdx = torch.randn(B * L, Cin, device=G.DEV).bfloat16()
+        full = os.environ.get("BIG_TIME_FULL") is not None      # with the embedding row and the residual (the ResBlock's second conv)
+        for name, env, envp in (("bigp", None, None), ("big", None, 1), ("old", 1, None)):
+            setenv(EEGLDM_NO_GEMM_BIG=env, EEGLDM_GEMM_BIG_NO_PERSIST=envp)
             for kind in ("fwd", "dgrad"):
                 def call():
                     if kind == "fwd":
-                        G.check(lib.eegldm_conv1d_fwd(c.h, G.ptr(xd), Cin, G.ptr(wd), G.ptr(bd), G.ptr(yd), Cout, B, L, Cin, Cout, 3, 1, 1, 1, None, 0, None, 0, dt))
+                        G.check(lib.eegldm_conv1d_fwd(c.h, G.ptr(xd), Cin, G.ptr(wd), G.ptr(bd), G.ptr(yd), Cout, B, L, Cin, Cout, 3, 1, 1, 1,
+                                                      G.ptr(ed) if full else None, Cout if full else 0, G.ptr(rd) if full else None, Cout if full else 0, dt))
                     else:
-                        G.check(lib.eegldm_conv1d_bwd_data(c.h, G.ptr(dyd), Cout, G.ptr(wd), G.ptr(dxd), Cin, B, L, Cin, Cout, 3, 1, 1, 1, None, 0, dt))
+                        G.check(lib.eegldm_conv1d_bwd_data(c.h, G.ptr(dyd), Cout, G.ptr(wd), G.ptr(dxd), Cin, B, L, Cin, Cout, 3, 1, 1, 1, G.ptr(rdx) if full else None, Cin if full else 0, dt))
                 for _ in range(3): call()
                 torch.cuda.synchronize(); t0 = time.perf_counter()
                 for _ in range(20): call()
                 torch.cuda.synchronize(); us = (time.perf_counter() - t0) / 20 * 1e6
                 res[(name, kind)] = us
+        setenv(EEGLDM_NO_GEMM_BIG=None, EEGLDM_GEMM_BIG_NO_PERSIST=None)
         fl = 2.0 * B * L * Cin * Cout * 3
-        print(f"B={B} L={L} Cin={Cin} Cout={Cout}: fwd big {res[('big','fwd')]:.1f} us ({fl/res[('big','fwd')]/1e6:.0f} TF/s) old {res[('old','fwd')]:.1f} us ({fl/res[('old','fwd')]/1e6:.0f});  "
-              f"dgrad big {res[('big','dgrad')]:.1f} us ({fl/res[('big','dgrad')]/1e6:.0f}) old {res[('old','dgrad')]:.1f} us ({fl/res[('old','dgrad')]/1e6:.0f})", flush=True)
+        print(f"B={B} L={L} Cin={Cin} Cout={Cout}{' full' if full else ''}: " + ";  ".join(
+            f"{kind} " + " ".join(f"{n} {res[(n, kind)]:.1f} us ({fl / res[(n, kind)] / 1e6:.0f})" for n in ("bigp", "big", "old")) for kind in ("fwd", "dgrad")), flush=True)
         G.check(lib.eegldm_conv1d_forget_kblocked(c.h, G.ptr(wd)))
-    for (B, L, Cin, Cout) in [(256, 192, 512, 1536), (256, 192, 512, 512), (256, 192, 1024, 512), (256, 384, 768, 256), (256, 384, 512, 256)]:
+    for (B, L, Cin, Cout) in ([] if os.environ.get("BIG_SHAPES") else [(256, 192, 512, 1536), (256, 192, 512, 512), (256, 192, 1024, 512), (256, 384, 768, 256), (256, 384, 512, 256), (256, 768, 256, 256)]):
         xd = torch.randn(B * L, Cin, device=G.DEV).bfloat16(); wd = (torch.randn(1, Cout, Cin, device=G.DEV) / math.sqrt(Cin)).bfloat16()
         bd = torch.randn(Cout, device=G.DEV); yd = torch.empty(B * L, Cout, device=G.DEV, dtype=torch.bfloat16)
         dyd = torch.randn(B * L, Cout, device=G.DEV).bfloat16(); dxd = torch.empty(B * L, Cin, device=G.DEV, dtype=torch.bfloat16)
         wt = torch.empty_like(wd); G.check(lib.eegldm_conv1d_pack_dgrad_k(c.h, G.ptr(wd), G.ptr(wt), Cout, Cin, 1, dt))
         res = {}
-        for name, env in (("big", None), ("old", 1)):
-            setenv(EEGLDM_NO_GEMM_BIG=env)
+        V = (("bigp", None, None), ("big", None, 1), ("old", 1, None))
+        for name, env, envp in V:
+            setenv(EEGLDM_NO_GEMM_BIG=env, EEGLDM_GEMM_BIG_NO_PERSIST=envp)
             for kind in ("fwd", "dgrad"):
                 def call():
                     if kind == "fwd":
@@ -141,7 +148,8 @@ else:
                 torch.cuda.synchronize(); t0 = time.perf_counter()
                 for _ in range(20): call()
                 torch.cuda.synchronize(); res[(name, kind)] = (time.perf_counter() - t0) / 20 * 1e6
+        setenv(EEGLDM_NO_GEMM_BIG=None, EEGLDM_GEMM_BIG_NO_PERSIST=None)
         fl = 2.0 * B * L * Cin * Cout
-        print(f"1x1 B={B} L={L} Cin={Cin} Cout={Cout}: fwd big {res[('big','fwd')]:.1f} us ({fl/res[('big','fwd')]/1e6:.0f} TF/s) old {res[('old','fwd')]:.1f} us ({fl/res[('old','fwd')]/1e6:.0f});  "
-              f"dgrad big {res[('big','dgrad')]:.1f} us ({fl/res[('big','dgrad')]/1e6:.0f}) old {res[('old','dgrad')]:.1f} us ({fl/res[('old','dgrad')]/1e6:.0f})", flush=True)
+        print(f"1x1 B={B} L={L} Cin={Cin} Cout={Cout}: " + ";  ".join(
+            f"{kind} " + " ".join(f"{n} {res[(n, kind)]:.1f} us ({fl / res[(n, kind)] / 1e6:.0f})" for n, *_ in V) for kind in ("fwd", "dgrad")), flush=True)
         G.check(lib.eegldm_conv1d_forget_kblocked(c.h, G.ptr(wd)))
