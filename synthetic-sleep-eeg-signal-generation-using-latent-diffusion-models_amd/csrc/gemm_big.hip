@@ -897,7 +897,7 @@ int launch_big1p(eegldm_ctx* ctx, const BigArgs& a) {
   static DevOnce attr_once;
   if (attr_once.need(ctx->device)) HIP_TRY(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * S1_BYTES));
   int grid = a.tiles_m * a.tiles_n;
-  const int cus = ctx->num_cu & ~7;
+  const int cus = ctx->num_cu >= 8 ? ctx->num_cu & ~7 : ctx->num_cu;
   if (grid > cus) grid = cus;
   hipLaunchKernelGGL(kern, dim3(grid), dim3(NTHR), 2 * S1_BYTES, ctx->stream, a);
   LAUNCH_CHECK();
@@ -922,7 +922,7 @@ int launch_bigp(eegldm_ctx* ctx, const BigArgs& a) {
   static DevOnce attr_once;      // the dynamic-LDS attribute is per device
   if (attr_once.need(ctx->device)) HIP_TRY(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, RING));
   int grid = a.tiles_m * a.tiles_n;
-  const int cus = ctx->num_cu & ~7;      // a multiple of 8 keeps a workgroup's tiles on its XCD
+  const int cus = ctx->num_cu >= 8 ? ctx->num_cu & ~7 : ctx->num_cu;      // a multiple of 8 keeps a workgroup's tiles on its XCD
   if (grid > cus) grid = cus;
   hipLaunchKernelGGL(kern, dim3(grid), dim3(NTHR), RING, ctx->stream, a);
   LAUNCH_CHECK();
