@@ -524,6 +524,9 @@ __global__ __launch_bounds__(NTH) void gn_bwd_resident_kernel(const T* __restric
   // difference in the group sums flips bf16 roundings of dx and the flips compound through the remaining layers
   __shared__ double redg[2 * RES_MAXG];
   __shared__ double redc[3 * RES_MAXC];
+#ifdef EEG_GN_BWD_NO_LDS_ATOMICS
+  __shared__ float gn_part[NTH * 8];
+#endif
   GN_TSTAMP(0);
   const int cpg = C / G;
   const ResMap m = resmap<NTH>(CC, C, cpg, xcd);
@@ -583,9 +586,46 @@ __global__ __launch_bounds__(NTH) void gn_bwd_resident_kernel(const T* __restric
         }
       }
     }
+#ifdef EEG_GN_BWD_NO_LDS_ATOMICS
+    // developer build (tools/debug/gn_hazard.sh): no LDS atomics anywhere in this kernel -- per-thread partials to LDS, one writer per sum
+#pragma unroll
+    for (int j = 0; j < 4; j++) { gn_part[(m.ty * m.TX + m.tx) * 8 + j] = dg[j]; gn_part[(m.ty * m.TX + m.tx) * 8 + 4 + j] = db[j]; }
+#ifdef EEG_GN_HAZ_VERIFY      // (1) does a thread read back what it just wrote?
+    {
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      bool mism = false;
+#pragma unroll
+      for (int j = 0; j < 4; j++) mism = mism || ((volatile float*)gn_part)[(m.ty * m.TX + m.tx) * 8 + j] != dg[j] || ((volatile float*)gn_part)[(m.ty * m.TX + m.tx) * 8 + 4 + j] != db[j];
+      if (mism) printf("HAZ1 own write not read back: block %d thread %d\n", (int)blockIdx.x, (int)threadIdx.x);
+    }
+#endif
+#else
 #pragma unroll
     for (int j = 0; j < 4; j++) { atomicAdd(&redc[m.tx * 4 + j], (double)dg[j]); atomicAdd(&redc[RES_MAXC + m.tx * 4 + j], (double)db[j]); }
+#endif
   }
+#ifdef EEG_GN_BWD_NO_LDS_ATOMICS
+  __syncthreads();
+  if (m.act && m.ty == 0) {
+    double sg[4] = {0.0, 0.0, 0.0, 0.0}, sb[4] = {0.0, 0.0, 0.0, 0.0};
+    for (int r = 0; r < m.TY; r++)
+#pragma unroll
+      for (int j = 0; j < 4; j++) { sg[j] += (double)gn_part[(r * m.TX + m.tx) * 8 + j]; sb[j] += (double)gn_part[(r * m.TX + m.tx) * 8 + 4 + j]; }
+#pragma unroll
+    for (int j = 0; j < 4; j++) { redc[m.tx * 4 + j] = sg[j]; redc[RES_MAXC + m.tx * 4 + j] = sb[j]; }
+#ifdef EEG_GN_HAZ_VERIFY      // (2) do the partials still read the same a little later?  (3) were they all written: own row 0 equals the registers
+    __builtin_amdgcn_s_sleep(64);
+    double sg2[4] = {0.0, 0.0, 0.0, 0.0}, sb2[4] = {0.0, 0.0, 0.0, 0.0};
+    for (int r = 0; r < m.TY; r++)
+#pragma unroll
+      for (int j = 0; j < 4; j++) { sg2[j] += (double)((volatile float*)gn_part)[(r * m.TX + m.tx) * 8 + j]; sb2[j] += (double)((volatile float*)gn_part)[(r * m.TX + m.tx) * 8 + 4 + j]; }
+    bool diff = false;
+#pragma unroll
+    for (int j = 0; j < 4; j++) diff = diff || sg2[j] != sg[j] || sb2[j] != sb[j];
+    if (diff) printf("HAZ2 partials changed after the barrier: block %d column %d (TY %d): %.9g -> %.9g\n", (int)blockIdx.x, m.tx, m.TY, sg[0], sg2[0]);
+#endif
+  }
+#endif
   // the residual-path addend(s) of dx are fetched HERE, packed and unconditionally (clamped row), so their round trip runs under the
   // two barriers and the group-sum phase: loaded inside pass 2 they were twelve load-wait-use chains per thread (the first GroupNorm of
   // every ResBlock has such an addend: those launches took ~70 us against 45 us without)
@@ -599,12 +639,20 @@ __global__ __launch_bounds__(NTH) void gn_bwd_resident_kernel(const T* __restric
     }
   }
   __syncthreads();
+#ifdef EEG_GN_BWD_NO_LDS_ATOMICS
+  if (m.act && m.ty == 0 && (m.tx * 4) % cpg == 0) {       // one writer per group: its channels' sums in channel order
+    double p1 = 0.0, p2 = 0.0;
+    for (int i = 0; i < cpg; i++) { const double g = (double)gamma[m.c + i]; p1 += g * redc[RES_MAXC + m.tx * 4 + i]; p2 += g * redc[m.tx * 4 + i]; }
+    redg[2 * m.gl] = p1; redg[2 * m.gl + 1] = p2;
+  }
+#else
   if (m.act && m.ty == 0) {
     double p1 = 0.0, p2 = 0.0;
 #pragma unroll
     for (int j = 0; j < 4; j++) { p1 += (double)ga[j] * redc[RES_MAXC + m.tx * 4 + j]; p2 += (double)ga[j] * redc[m.tx * 4 + j]; }
     atomicAdd(&redg[2 * m.gl], p1); atomicAdd(&redg[2 * m.gl + 1], p2);
   }
+#endif
   GN_TSTAMP(3);
   __syncthreads();
   GN_TSTAMP(4);
@@ -773,17 +821,24 @@ int gn_bwd_t(eegldm_ctx* ctx, const void* x, long ldx, const float* gamma, const
   if constexpr (V == 4) {
     EEG_ENV_VAR(bool, off, getenv("EEGLDM_GN_NO_RESIDENT") != nullptr);
     EEG_ENV_VAR(int, bwd_nth, getenv("EEGLDM_GN_BWD_NTH") ? atoi(getenv("EEGLDM_GN_BWD_NTH")) : 1024);      // see gn_fwd_t
-    // 256-thread blocks (EEGLDM_GN_BWD_NTH=256) measure 42-44 vs 47-49 us on the 50 MB tensors at L <= 384 (tools/debug/gn_nth.py) and
-    // are bit-exact and deterministic in isolation and beside foreign kernels (tools/debug/gn_det2.py .. gn_det4.py, gn_conc.py) -- but
-    // with the fused 3-tap weight-gradient GEMM (LDS-DMA build) of a second stream co-resident on the CU, their group sums come out
-    // wrong by ~1e-3 (bf16 rounding flips over whole slabs, tools/debug/gn_conc2.py .. gn_conc4.py: only that neighbour, only the
-    // backward kernel, 512-thread blocks too; 1024-thread blocks own a CU and never share it).  LDS / register stomping, late DMA and
-    // unfinished LDS atomics were ruled out (tools/probes/lds_dma_stomp_probe*.hip); the cause is open.  At step level the narrow
-    // blocks no longer gain anything either (19.76 vs 19.67 ms), so the default stays at 1024 threads.
-    // (narrow blocks only while nothing of this library runs beside them: never with the opt-in side stream)
-    // FENCE (tests/test_gpu_concurrency.py pins it): narrow blocks are refused whenever anything of this library can run beside
-    // them -- the opt-in side stream, or a second live context in this process (g_eeg_live_ctx, api.hip)
-    const int nth = ((bwd_nth == 512 || bwd_nth == 256) && !ctx->side_on && g_eeg_live_ctx <= 1) ? bwd_nth : 1024;
+    // 256-thread blocks (EEGLDM_GN_BWD_NTH=256) measure 42-44 vs 47-49 us on the 50 MB tensors at L <= 384 (tools/debug/gn_nth.py); at step
+    // level they gain nothing (19.76 vs 19.67 ms), so the default stays at 1024 threads.
+    // HAZARD: until round 4 these blocks returned wrong sums (~1e-3, bf16 rounding flips over whole slabs) whenever they
+    // shared a CU with the fused 3-tap weight-gradient GEMM (LDS-DMA build) of another stream -- 1024-thread blocks own a CU and never
+    // share it.  Round-4 diagnosis (tools/debug/gn_hazard.sh, gn_hazard_diag.py): the errors sit in EVEN channels only = the low lane of
+    // the v_pk_fma_f32 / v_pk_add_f32 / v_pk_mul_f32 instructions hipcc's SLP vectoriser makes of the per-channel math; LDS atomics,
+    // LDS stomping and late DMA are not involved (the sums are wrong with the atomics replaced by single-writer stores; right with
+    // the packed instructions gone).  The library is now built with -fno-slp-vectorize -fno-vectorize (Makefile), which removes the error
+    // (0 of 108 noisy runs against 27 of 27).  The fence below stays as a second line: narrow blocks are refused whenever anything of this
+    // library can run beside them -- the opt-in side stream, or a second live context in this process (g_eeg_live_ctx, api.hip).
+    // EEGLDM_GN_NARROW_UNFENCED=1 (developer / regression switch): narrow blocks even beside a second context -- the configuration that
+    // returned wrong sums until the library was built without packed-fp32 instructions (tests/test_gpu_concurrency.py runs it)
+    EEG_ENV_VAR(bool, unfenced, getenv("EEGLDM_GN_NARROW_UNFENCED") != nullptr);
+#ifdef EEG_GN_NO_FENCE      // developer build (tools/debug/gn_hazard.sh)
+    const int nth = (bwd_nth == 512 || bwd_nth == 256) ? bwd_nth : 1024;
+#else
+    const int nth = ((bwd_nth == 512 || bwd_nth == 256) && (unfenced || (!ctx->side_on && g_eeg_live_ctx <= 1))) ? bwd_nth : 1024;
+#endif
     int rpt = 0; int cc = off ? 0 : resident_chunk(L, C, G, 0, sizeof(T) == 2 ? 12 : 8, &rpt, nth);
     // measured (tools/debug/gn_bench.py): the one-pass kernel wins while its blocks fit two rounds of one block per CU
     // (1024 blocks: 112 us one-pass vs 117-120 us split on the 100 MB tensors; 2048 blocks of 96-channel chunks lose)

@@ -1,11 +1,14 @@
 """-m gpu: the one-pass GroupNorm backward beside the library's own LDS-DMA weight-gradient GEMM on ANOTHER context / stream.
 
 Round 3 found (tools/debug/gn_conc2.py .. gn_conc4.py, DESIGN.md "concurrent-kernel hazard") that the NARROW-block variant of
-gn_bwd_resident (256 / 512 threads, opt-in through EEGLDM_GN_BWD_NTH) returns group sums that are off by one contribution per reduction
-when it shares a CU with the fused 3-tap weight-gradient kernel (LDS-DMA build) of another stream; the cause is open.  The fence, pinned here:
+gn_bwd_resident (256 / 512 threads, opt-in through EEGLDM_GN_BWD_NTH) returns wrong sums when it shares a CU with the fused 3-tap
+weight-gradient kernel (LDS-DMA build) of another stream.  Round 4 (tools/debug/gn_hazard.sh): the wrong values are the LOW lanes of the
+packed-fp32 VALU instructions the compiler's SLP vectoriser had made of the per-channel math; the library is now built without them.  Pinned here:
   * the default 1024-thread blocks own a CU -- results beside the noisy neighbour are BIT-identical to a quiet run;
-  * with a second context alive (or the side stream on) the library refuses the narrow blocks whatever EEGLDM_GN_BWD_NTH says, so the same
-    bit-identity holds with the switch set."""
+  * with a second context alive (or the side stream on) the library refuses the narrow blocks whatever EEGLDM_GN_BWD_NTH says (the fence,
+    kept as a second line), so the same bit-identity holds with the switch set;
+  * THE FIX: with the fence lifted (EEGLDM_GN_NARROW_UNFENCED=1) the narrow blocks really run beside the neighbour -- 27 of 27 such runs
+    were wrong with packed instructions in the kernel -- and must now be bit-identical too."""
 import pytest
 import torch
 
@@ -60,4 +63,10 @@ def test_default_groupnorm_backward_is_bit_exact_beside_the_lds_dma_gemms_of_ano
 
 def test_narrow_blocks_are_refused_while_a_second_context_is_alive(env_switches):
     env_switches(EEGLDM_GN_BWD_NTH="256")
+    assert _scenario() == []
+
+
+@pytest.mark.parametrize("nth", ["256", "512"])
+def test_narrow_blocks_beside_the_weight_gradient_gemm_are_exact_without_packed_fp32(nth, env_switches):
+    env_switches(EEGLDM_GN_BWD_NTH=nth, EEGLDM_GN_NARROW_UNFENCED="1")
     assert _scenario() == []

@@ -1,0 +1,54 @@
+"""Which side is wrong, and how: quiet vs noisy dgamma / dbeta / dx of the narrow GroupNorm backward against an fp64 torch reference.
+   EEGLDM_LIB=tools/debug/libeegldm_gnA.so EEGLDM_GN_BWD_NTH=256 python tools/debug/gn_hazard_diag.py"""
+import os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+import torch
+import eegldm
+from eegldm._lib import lib, ptr, check, Context
+ctx = eegldm.default_context(0)
+ctx2 = Context(0, use_torch_stream=False)
+torch.manual_seed(0)
+B, Lw, Cw = 256, 192, 512
+xw = torch.randn(B * Lw, Cw, device="cuda").bfloat16(); dyw = torch.randn(B * Lw, Cw, device="cuda").bfloat16()
+dw = torch.zeros(3 * Cw * Cw, device="cuda"); dbw = torch.zeros(Cw, device="cuda")
+L, C, G = 192, 512, 32
+R = B * L
+x = torch.randn(R, C, device="cuda").bfloat16(); dy = torch.randn(R, C, device="cuda").bfloat16(); ad = torch.randn(R, C, device="cuda").bfloat16()
+ga = torch.rand(C, device="cuda") + 0.5; be = torch.randn(C, device="cuda"); st = torch.empty(B * G * 2, device="cuda"); y = torch.empty_like(x)
+check(lib.eegldm_groupnorm_fwd(ctx.h, ptr(x), C, ptr(ga), ptr(be), ptr(y), C, ptr(st), B, L, C, G, 1e-6, 1, 0, None, 0, 1))
+# fp64 reference of ONE call's dgamma / dbeta (silu = 1)
+xs = x.double().view(B, L, G, C // G); stv = st.double().view(B, G, 2)
+xh = ((xs - stv[:, None, :, 0:1]) * stv[:, None, :, 1:2]).reshape(B, L, C)
+z = xh * ga.double() + be.double(); sg = torch.sigmoid(z)
+dz = dy.double().view(B, L, C) * (sg * (1 + z * (1 - sg)))
+ref_dg, ref_db = (dz * xh).sum((0, 1)), dz.sum((0, 1))
+NCALL = int(os.environ.get("NCALL", "1"))
+
+
+def run(noise):
+    dx = torch.empty_like(x); dg = torch.zeros(C, device="cuda"); db = torch.zeros(C, device="cuda")
+    torch.cuda.synchronize(); ctx2.sync()
+    if noise:
+        for _ in range(12):
+            check(lib.eegldm_conv1d_bwd_weight(ctx2.h, ptr(xw), Cw, ptr(dyw), Cw, ptr(dw), ptr(dbw), B, Lw, Cw, Cw, 3, 1, 1, 1, 1))
+    for _ in range(NCALL):
+        check(lib.eegldm_groupnorm_bwd(ctx.h, ptr(x), C, ptr(ga), ptr(be), ptr(st), ptr(dy), C, ptr(dx), C, ptr(dg), ptr(db), B, L, C, G, 1, 0, ptr(ad), C, 1))
+    torch.cuda.synchronize(); ctx2.sync()
+    return dx, dg.double() / NCALL, db.double() / NCALL
+
+
+for name, noise in (("quiet", False), ("quiet", False), ("noisy", True), ("noisy", True), ("noisy", True), ("quiet", False)):
+    dx, dg, db = run(noise)
+    if name == "quiet" and "dxq" not in globals(): dxq = dx.clone()
+    eg, eb = (dg - ref_dg), (db - ref_db)
+    thr = 1e-4 * ref_dg.abs().mean()
+    bad_g = (eg.abs() > thr); bad_b = (eb.abs() > 1e-4 * ref_db.abs().mean())
+    dd = (dx.view(torch.int16) != dxq.view(torch.int16)).view(R, C)
+    print(f"   parity: dgamma errors even/odd channel {int(bad_g[0::2].sum())}/{int(bad_g[1::2].sum())}  dbeta {int(bad_b[0::2].sum())}/{int(bad_b[1::2].sum())}  "
+          f"dx elements differing from the quiet run even/odd {int(dd[:, 0::2].sum())}/{int(dd[:, 1::2].sum())}; by channel mod 4: {[int(dd[:, k::4].sum()) for k in range(4)]}; "
+          f"dgamma bad by chunk of 64: {[int(bad_g[k * 64:(k + 1) * 64].sum()) for k in range(8)]}")
+    # one block = one (sample, 256-channel chunk): its share of a channel sum is ~1/256 of the total in rms terms
+    worst = torch.argsort(eg.abs(), descending=True)[:4].tolist()
+    print(f"{name}: dgamma rel err vs fp64 {float(eg.norm() / ref_dg.norm()):.2e}  dbeta {float(eb.norm() / ref_db.norm()):.2e}  channels with |err| > 1e-4 |ref|: "
+          f"{int((eg.abs() > 1e-4 * ref_dg.abs().mean()).sum())} / {C}   worst channels {worst} err {[round(float(eg[c]), 3) for c in worst]} ref {[round(float(ref_dg[c]), 1) for c in worst]}", flush=True)
