@@ -46,6 +46,13 @@ def family(name):
     if m:
         a = [x.strip() for x in m.group(1).split(",")]
         return ("conv3_dgrad_implicit_gemm" if a[2] in ("true", "1") else "conv3_fwd_implicit_gemm"), True
+    m = re.search(r"gemm_bigp_kernel<([^>]*)>", name)      # persistent form: <KBLK, FLIP, loader waves>
+    if m:
+        a = [x.strip() for x in m.group(1).split(",")]
+        return ("conv3_dgrad_implicit_gemm" if a[1] in ("true", "1") else "conv3_fwd_implicit_gemm"), True
+    m = re.search(r"gemm_big1p_kernel<(\w+),", name)      # persistent 1-tap form: <KBLK, loader waves>
+    if m:
+        return ("gemm_nn" if m.group(1) in ("true", "1") else "gemm_nt"), True
     m = re.search(r"gemm_big1_kernel<(\w+)>", name)      # 1 x 1 convs on the big tile: plain weights = forward (NT), K-blocked transposed copy = data gradient (the NN class)
     if m:
         return ("gemm_nn" if m.group(1) in ("true", "1") else "gemm_nt"), True
