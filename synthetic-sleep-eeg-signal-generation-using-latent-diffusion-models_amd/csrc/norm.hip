@@ -512,8 +512,13 @@ __global__ __launch_bounds__(NTH) void gn_fwd_resident_kernel(const T* __restric
 // the per-sample column sums of the written dx -- the block owns (sample, channels) over all of L, so no atomics.
 // RAW0: resample == 0 specialisation that fetches the gradient rows packed, in the same predicated block as the x rows (the
 // conversion in place makes hipcc wait for every load separately: 12 serialised HBM latencies, 19 k of the block's 57 k cycles)
+#ifdef EEG_GN_W4      // developer build (tools/debug/gn_hazard.sh): at most 128 VGPRs, whatever else the build flags do
+#define GN_BWD_ATTR __attribute__((amdgpu_waves_per_eu(4, 4)))
+#else
+#define GN_BWD_ATTR
+#endif
 template <typename T, int RPT, bool RAW0, bool SILU, int NTH>
-__global__ __launch_bounds__(NTH) void gn_bwd_resident_kernel(const T* __restrict__ x, long ldx, const float* __restrict__ gamma,
+__global__ __launch_bounds__(NTH) GN_BWD_ATTR void gn_bwd_resident_kernel(const T* __restrict__ x, long ldx, const float* __restrict__ gamma,
                                                               const float* __restrict__ beta, const float* __restrict__ stats,
                                                               const T* __restrict__ dy, long lddy, T* __restrict__ dx, long lddx,
                                                               const T* __restrict__ dxr, long lddxr, float* __restrict__ slots,

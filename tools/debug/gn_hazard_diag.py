@@ -24,6 +24,15 @@ z = xh * ga.double() + be.double(); sg = torch.sigmoid(z)
 dz = dy.double().view(B, L, C) * (sg * (1 + z * (1 - sg)))
 ref_dg, ref_db = (dz * xh).sum((0, 1)), dz.sum((0, 1))
 NCALL = int(os.environ.get("NCALL", "1"))
+# AGGRESSOR=synthetic:<lds_kb>:<mode>: the fill loop of tools/probes/dma_writer_lib.hip instead of the library's weight-gradient GEMM
+# (mode bits: 1 LDS-DMA fill (else load + ds_write), 2 MFMAs between the fills, 4 LDS reads of the ring)
+AGG = os.environ.get("AGGRESSOR", "wgrad")
+if AGG.startswith("synthetic"):
+    import ctypes
+    wl = ctypes.CDLL(os.path.join(ROOT, "tools", "probes", "libdma_writer.so"))
+    wl.dma_writer_launch.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int]
+    _, s_kb, s_mode = AGG.split(":")
+    side = torch.cuda.Stream()
 
 
 def run(noise):
@@ -31,7 +40,8 @@ def run(noise):
     torch.cuda.synchronize(); ctx2.sync()
     if noise:
         for _ in range(12):
-            check(lib.eegldm_conv1d_bwd_weight(ctx2.h, ptr(xw), Cw, ptr(dyw), Cw, ptr(dw), ptr(dbw), B, Lw, Cw, Cw, 3, 1, 1, 1, 1))
+            if AGG == "wgrad": check(lib.eegldm_conv1d_bwd_weight(ctx2.h, ptr(xw), Cw, ptr(dyw), Cw, ptr(dw), ptr(dbw), B, Lw, Cw, Cw, 3, 1, 1, 1, 1))
+            else: assert wl.dma_writer_launch(ctypes.c_void_p(side.cuda_stream), int(s_kb), 200, int(s_mode), 512) == 0
     for _ in range(NCALL):
         check(lib.eegldm_groupnorm_bwd(ctx.h, ptr(x), C, ptr(ga), ptr(be), ptr(st), ptr(dy), C, ptr(dx), C, ptr(dg), ptr(db), B, L, C, G, 1, 0, ptr(ad), C, 1))
     torch.cuda.synchronize(); ctx2.sync()
