@@ -18,3 +18,11 @@ print("dx(2dy) vs 2dx", rel(dx3, 2 * dx1), " grads", rel(g3, 2 * g1))
 ks = list(net.entries.items())
 worst = sorted(((rel(g2[o:o+n], g1[o:o+n]), k) for k, (o, n, _s) in ks), reverse=True)[:6]
 print("worst repeat params", worst)
+import collections
+cls = collections.Counter(); tot = collections.Counter()
+for k, (o, n, _s) in ks:
+    kind = ("norm" if (".in_layers.0." in k or ".out_layers.0." in k or k.startswith("out.0") or ".norm." in k) else "emb" if ("emb" in k) else "conv/linear") + (".bias" if k.endswith("bias") else ".weight")
+    tot[kind] += 1
+    if not torch.equal(g1[o:o+n], g2[o:o+n]): cls[kind] += 1
+print("parameters whose gradient differs between two identical runs, by kind:", {k: f"{cls[k]}/{tot[k]}" for k in tot})
+print("names:", [k for k, (o, n, _s) in ks if not torch.equal(g1[o:o+n], g2[o:o+n])][:60])
