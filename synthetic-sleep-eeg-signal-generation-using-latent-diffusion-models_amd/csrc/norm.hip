@@ -722,6 +722,210 @@ __global__ __launch_bounds__(NTH) GN_BWD_ATTR void gn_bwd_resident_kernel(const 
   }
 }
 
+// ------------------------------------------------------------------ pipelined form of the one-pass backward (round 4; bf16, resample 0)
+// gn_bwd_resident_kernel is a chain per workgroup -- load the slab, pass 1, two barrier rounds, pass 2, store -- and with one 1024-thread
+// workgroup per CU nothing overlaps the chain: HBM idles while the VALU runs and the other way round (in the LDM step 47 us per 50 MB
+// tensor, 3.2 TB/s for x + dy + dx).  Here ONE persistent workgroup per CU walks slabs of the same size in threads (6 rows of 4 channels
+// per thread = 48 KB per tensor), and the NEXT slab's x, dy, residual-path addend and (mean, rstd) pairs are fetched by LDS-DMA into a
+// 3 x 48 KB landing area while the current slab is processed from registers: the loads of slab k+1 and the stores of slab k both run
+// under the VALU phases.  gfx950 retires loads and stores through one in-order vmcnt, so "slab k+1 has landed" is vmcnt(#stores of slab k)
+// = vmcnt(6): every vector-memory instruction a wave issues behind its DMAs is a store or a no-return atomic (gamma / beta are loaded
+// once in front of the loop -- a block keeps its channel chunk -- and the statistics arrive by DMA as well), so the compiler never waits on
+// vmcnt inside the loop and extra stores of some waves (column sums, slot atomics) only make the counted wait stricter.  Barriers are
+// raw s_barrier with lgkmcnt(0): __syncthreads() carries a release fence = s_waitcnt vmcnt(0) = wait for the prefetch.
+// Same arithmetic and the same fp64 LDS accumulators as the resident kernel: dx and the per-sample column sums are bit-identical to it.
+constexpr int PIPE_RPT = 6;
+constexpr int PIPE_SLAB = PIPE_RPT * NTB * 8;                 // bytes of one tensor's slab: 49 152
+constexpr int PIPE_OFF_ST = 3 * PIPE_SLAB;                    // 1 KB landing area of the statistics DMA
+constexpr int PIPE_OFF_RED = PIPE_OFF_ST + 1024;              // redg[2 * RES_MAXG] | redc[3 * RES_MAXC] (doubles)
+constexpr int PIPE_LDS = PIPE_OFF_RED + (2 * RES_MAXG + 3 * RES_MAXC) * 8;      // 155 648 of 163 840
+
+__device__ __forceinline__ void pipe_dma(const void* base, unsigned voff, unsigned lds_off) {      // as gemm_big.hip's dma16s
+  const unsigned long long u = (unsigned long long)base;
+  const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)u), hi = __builtin_amdgcn_readfirstlane((unsigned)(u >> 32));
+  const unsigned long long b = ((unsigned long long)hi << 32) | lo;
+  asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" ::"s"(__builtin_amdgcn_readfirstlane(lds_off)), "v"(voff), "s"(b) : "memory", "m0");
+}
+#define PIPE_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
+#ifdef EEG_STAGE_TIMING      // (make dbg, tools/debug/gn_pipe_timing.py) eight stamps per slab, thread 0, NO memory waits of their own
+#define PIPE_TSTAMP(k, i) do { if (threadIdx.x == 0 && (k) < 8) gn_tlog[(size_t)(blockIdx.x % 512) * 64 + (k) * 8 + (i)] = __builtin_readcyclecounter(); } while (0)
+#else
+#define PIPE_TSTAMP(k, i) do {} while (0)
+#endif
+
+template <bool SILU, bool HAS_ER>
+__global__ __launch_bounds__(NTB) void gn_bwd_pipe_kernel(const bf16_t* __restrict__ x, long ldx, const float* __restrict__ gamma,
+                                                          const float* __restrict__ beta, const float* __restrict__ stats,
+                                                          const bf16_t* __restrict__ dy, long lddy, bf16_t* __restrict__ dx, long lddx,
+                                                          const bf16_t* __restrict__ dxr, long lddxr, float* __restrict__ slots,
+                                                          float* __restrict__ colsum_ps, long ldps, int B, int L, int C, int G, int CC) {
+  extern __shared__ __attribute__((aligned(16))) char psm[];
+  typedef __attribute__((address_space(3))) void* lds_ptr_t;
+  double* const redg = (double*)(psm + PIPE_OFF_RED);
+  double* const redc = redg + 2 * RES_MAXG;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const unsigned wave_u = __builtin_amdgcn_readfirstlane((unsigned)(tid >> 6));
+  const unsigned lds0 = (unsigned)(size_t)(lds_ptr_t)psm;
+  const int cpg = C / G, nchunk = C / CC;
+  const int TX = CC >> 2, TY = NTB / TX;                  // L == PIPE_RPT * TY: every thread owns exactly PIPE_RPT rows
+  const int tx = tid % TX, ty = tid / TX;
+  // slab list: workgroup ids = xc (mod 8) run on XCD xc; within an XCD the chunks of one sample are neighbours (they share 128-byte lines
+  // when a chunk row is 64 bytes) and a workgroup keeps its chunk for all its samples
+  const int xc = blockIdx.x & 7, mb = blockIdx.x >> 3, MB = gridDim.x >> 3;
+  const int chunk = mb % nchunk, slot = mb / nchunk, nslot = MB / nchunk;
+  const int c = chunk * CC + tx * 4, gl = (tx * 4) / cpg;
+  const int noct = B >> 3;
+  const int nk = slot < noct ? (noct - slot + nslot - 1) / nslot : 0;
+  float ga[4], gl2[4], bl2[4];
+#pragma unroll
+  for (int j = 0; j < 4; j++) { ga[j] = gamma[c + j]; gl2[j] = ga[j] * 1.4426950408889634f; bl2[j] = beta[c + j] * 1.4426950408889634f; }
+  for (int i = tid; i < 2 * RES_MAXG + 3 * RES_MAXC; i += NTB) redg[i] = 0.0;
+  // the loads above have to be back before the first DMA: a compiler wait for them behind it would wait for the DMA too
+  asm volatile("" :: "v"(ga[0]), "v"(ga[1]), "v"(ga[2]), "v"(ga[3]), "v"(bl2[0]), "v"(bl2[1]), "v"(bl2[2]), "v"(bl2[3]));
+  // DMA lane map: 16-byte piece q = (i * 16 + wave) * 64 + lane of the slab, row q / LPR, piece q % LPR; LDS keeps the pieces in q order
+  const int LPR = CC >> 3;
+  const int drow = (int)(wave_u * 64 + lane) / LPR, dcol = lane % LPR;
+  const unsigned vx = (unsigned)drow * (unsigned)ldx * 2u + (unsigned)dcol * 16u, sx = (unsigned)(1024 / LPR) * (unsigned)ldx * 2u;
+  const unsigned vd = (unsigned)drow * (unsigned)lddy * 2u + (unsigned)dcol * 16u, sd = (unsigned)(1024 / LPR) * (unsigned)lddy * 2u;
+  const unsigned ve = (unsigned)drow * (unsigned)lddxr * 2u + (unsigned)dcol * 16u, se = (unsigned)(1024 / LPR) * (unsigned)lddxr * 2u;
+  const unsigned st_bytes = (unsigned)B * (unsigned)G * 8u;
+  const unsigned st_sub = ((unsigned)(chunk * (CC / cpg)) * 8u) & 15u;        // (b G + g0) * 8 mod 16: G = 32 makes it independent of b
+  // x, dy and the (mean, rstd) pairs of a slab: 7 DMA instructions per wave (every wave fetches the same statistics pieces to the same
+  // place, so that all waves count alike); the residual-path addend goes separately: it is read from LDS in pass 2 only
+  auto issue_xd = [&](int b) __attribute__((always_inline)) {
+    const char* xs = (const char*)(x + (long)b * L * ldx + chunk * CC);
+    const char* ds = (const char*)(dy + (long)b * L * lddy + chunk * CC);
+#pragma unroll
+    for (int i = 0; i < 3; i++) pipe_dma(xs, vx + i * sx, lds0 + (unsigned)(i * 16 + wave_u) * 1024u);
+#pragma unroll
+    for (int i = 0; i < 3; i++) pipe_dma(ds, vd + i * sd, lds0 + PIPE_SLAB + (unsigned)(i * 16 + wave_u) * 1024u);
+    {       // 16-byte pieces from the aligned-down address of the chunk's first pair, clamped to the buffer (the needed pieces never are)
+      const unsigned a0 = (((unsigned)b * (unsigned)G + (unsigned)(chunk * (CC / cpg))) * 8u) & ~15u;
+      unsigned a = a0 + (unsigned)lane * 16u; if (a > st_bytes - 16u) a = st_bytes - 16u;
+      pipe_dma(stats, a, lds0 + PIPE_OFF_ST);
+    }
+  };
+  auto issue_e = [&](int b) __attribute__((always_inline)) {
+    const char* es = (const char*)(dxr + (long)b * L * lddxr + chunk * CC);
+#pragma unroll
+    for (int i = 0; i < 3; i++) pipe_dma(es, ve + i * se, lds0 + 2 * PIPE_SLAB + (unsigned)(i * 16 + wave_u) * 1024u);
+  };
+  if (nk > 0) { issue_xd(slot * 8 + xc); if constexpr (HAS_ER) issue_e(slot * 8 + xc); }
+  const float inv_n = 1.0f / ((float)cpg * (float)L);
+  const unsigned rowb = (unsigned)CC * 2u;
+  const unsigned lrd0 = (unsigned)ty * rowb + (unsigned)tx * 8u, lrds = (unsigned)TY * rowb;      // this thread's piece of row ty; rows step by TY
+  const unsigned lddxb = (unsigned)lddx * 2u;
+  const unsigned st0 = (unsigned)ty * lddxb + (unsigned)c * 2u, sts = (unsigned)TY * lddxb;      // the same for the dx rows (32-bit offsets off a uniform base)
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  for (int k = 0; k < nk; k++) {
+    const int b = (slot + k * nslot) * 8 + xc;
+    PIPE_TSTAMP(k, 0);
+    PIPE_BARRIER();                                           // every wave's pieces of slab k have landed (counted wait at the bottom of slab k-1)
+    PIPE_TSTAMP(k, 1);
+    uint2 raw[PIPE_RPT], dr[PIPE_RPT];
+#pragma unroll
+    for (int r = 0; r < PIPE_RPT; r++) {
+      const unsigned off = lrd0 + (unsigned)r * lrds;
+      raw[r] = *(const uint2*)(psm + off); dr[r] = *(const uint2*)(psm + PIPE_SLAB + off);
+    }
+    const float2 mr = *(const float2*)(psm + PIPE_OFF_ST + st_sub + (unsigned)gl * 8u);
+    PIPE_BARRIER();                                           // everybody holds its copy: the x / dy landing areas may be refilled
+    PIPE_TSTAMP(k, 2);
+    if (k + 1 < nk) issue_xd((slot + (k + 1) * nslot) * 8 + xc);
+    PIPE_TSTAMP(k, 3);
+    const float mean = mr.x, rstd = mr.y, nmr = -mean * rstd;
+    float d[PIPE_RPT][4];
+    {
+      // the kernel is VALU-bound (tools/debug/gn_pipe_timing.py: pass 1 is 8 k of a slab's 12.5 k cycles), so SiLU' is taken from
+      // t = z log2(e) directly: s = 1 / (1 + 2^-t), SiLU' = s (1 + z (1 - s)) = s fma(t, ln2 (1 - s), 1) -- one multiply less per element
+      float dg[4] = {0.f, 0.f, 0.f, 0.f}, db[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int r = 0; r < PIPE_RPT; r++) {
+        float v[4]; unpack4<bf16_t>(raw[r], v); unpack4<bf16_t>(dr[r], d[r]);
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+          const float xh = fmaf(v[j], rstd, nmr);
+          float dz = d[r][j];
+          if constexpr (SILU) {
+            const float t = fmaf(gl2[j], xh, bl2[j]);
+            const float sg = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-t));
+            dz *= sg * fmaf(t, fmaf(-0.6931471805599453f, sg, 0.6931471805599453f), 1.0f);
+          }
+          d[r][j] = dz;
+          dg[j] = fmaf(dz, xh, dg[j]); db[j] += dz;
+        }
+      }
+#pragma unroll
+      for (int j = 0; j < 4; j++) { atomicAdd(&redc[tx * 4 + j], (double)dg[j]); atomicAdd(&redc[RES_MAXC + tx * 4 + j], (double)db[j]); }
+    }
+    PIPE_TSTAMP(k, 4);
+    PIPE_BARRIER();
+    if (ty == 0) {
+      double p1 = 0.0, p2 = 0.0;
+#pragma unroll
+      for (int j = 0; j < 4; j++) { p1 += (double)ga[j] * redc[RES_MAXC + tx * 4 + j]; p2 += (double)ga[j] * redc[tx * 4 + j]; }
+      atomicAdd(&redg[2 * gl], p1); atomicAdd(&redg[2 * gl + 1], p2);
+    }
+    if constexpr (HAS_ER) {       // this slab's addend (issued at the end of slab k-1) is older than the 7 DMAs of slab k+1
+      if (k + 1 < nk) asm volatile("s_waitcnt vmcnt(7)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    PIPE_BARRIER();
+    PIPE_TSTAMP(k, 5);
+    {
+      const float m1 = (float)(redg[2 * gl] * (double)inv_n), m2 = (float)(redg[2 * gl + 1] * (double)inv_n);
+      if (slots && ty == 0) {
+        float* sl = slots + (size_t)(b % GN_NSLOT) * 2 * C;
+#pragma unroll
+        for (int j = 0; j < 4; j++) { atomicAdd(&sl[c + j], (float)redc[tx * 4 + j]); atomicAdd(&sl[C + c + j], (float)redc[RES_MAXC + tx * 4 + j]); }
+      }
+      // dx = rstd (dz gamma - m1 - xhat m2), xhat = x rstd + nmr, as two FMAs per element on the raw x: the per-thread constants carry the rest
+      const float rm1 = rstd * m1, rm2 = rstd * m2;
+      const float a2 = -rm2 * rstd, b2 = fmaf(-rm2, nmr, -rm1);
+      float gr[4];
+#pragma unroll
+      for (int j = 0; j < 4; j++) gr[j] = ga[j] * rstd;
+      float cs[4] = {0.f, 0.f, 0.f, 0.f};
+      char* dxs = (char*)(dx + (long)b * L * lddx);
+#pragma unroll
+      for (int r = 0; r < PIPE_RPT; r++) {
+        float v[4], o[4]; unpack4<bf16_t>(raw[r], v);
+#pragma unroll
+        for (int j = 0; j < 4; j++) o[j] = fmaf(d[r][j], gr[j], fmaf(v[j], a2, b2));
+        if constexpr (HAS_ER) {
+          float e[4]; unpack4<bf16_t>(*(const uint2*)(psm + 2 * PIPE_SLAB + lrd0 + (unsigned)r * lrds), e);
+#pragma unroll
+          for (int j = 0; j < 4; j++) o[j] += e[j];
+        }
+        if (colsum_ps) {
+#pragma unroll
+          for (int j = 0; j < 4; j++) cs[j] += o[j];
+        }
+        store4<bf16_t>((bf16_t*)(dxs + (st0 + (unsigned)r * sts)), o);
+      }
+      if (colsum_ps) {
+#pragma unroll
+        for (int j = 0; j < 4; j++) atomicAdd(&redc[2 * RES_MAXC + tx * 4 + j], (double)cs[j]);
+      }
+    }
+    PIPE_TSTAMP(k, 6);
+    PIPE_BARRIER();
+    if (ty == 0) {       // column sums out, this thread's accumulators back to zero (next touched behind the two barriers at the top of slab k+1)
+#pragma unroll
+      for (int j = 0; j < 4; j++) {
+        if (colsum_ps) colsum_ps[(long)b * ldps + c + j] = (float)redc[2 * RES_MAXC + tx * 4 + j];
+        redc[tx * 4 + j] = 0.0; redc[RES_MAXC + tx * 4 + j] = 0.0; redc[2 * RES_MAXC + tx * 4 + j] = 0.0;
+      }
+    }
+    if (tid < 2 * RES_MAXG) redg[tid] = 0.0;
+    // x / dy of slab k+1 have landed when at most this slab's PIPE_RPT stores and the three addend DMAs, all issued behind them, are in flight
+    if (k + 1 < nk) {
+      if constexpr (HAS_ER) { issue_e((slot + (k + 1) * nslot) * 8 + xc); asm volatile("s_waitcnt vmcnt(9)" ::: "memory"); }
+      else asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    }
+    PIPE_TSTAMP(k, 7);
+  }
+}
+
 // chunk width for the resident kernels: the widest whole-group chunk (<= 256 channels, dividing C) whose rows fit the
 // per-thread register budget; 0 = not eligible (fall back to the split kernels)
 int resident_chunk(int L, int C, int G, int resample_pair, int rpt_max, int* rpt_out, int nth = NTB) {
@@ -844,6 +1048,64 @@ int gn_bwd_t(eegldm_ctx* ctx, const void* x, long ldx, const float* gamma, const
 #else
     const int nth = ((bwd_nth == 512 || bwd_nth == 256) && (unfenced || (!ctx->side_on && g_eeg_live_ctx <= 1))) ? bwd_nth : 1024;
 #endif
+    if constexpr (sizeof(T) == 2) {
+      // pipelined persistent form (gn_bwd_pipe_kernel): slabs of exactly 6 rows x 4 channels per thread, L * CC = 24 576, CC a power of two
+      EEG_ENV_VAR(bool, no_pipe, getenv("EEGLDM_GN_NO_PIPE") != nullptr);
+      EEG_ENV_VAR(int, pipe_min_row, getenv("EEGLDM_GN_PIPE_MIN_ROW") ? atoi(getenv("EEGLDM_GN_PIPE_MIN_ROW")) : 64);
+      EEG_ENV_VAR(int, pipe_min_slabs, getenv("EEGLDM_GN_PIPE_MIN_SLABS") ? atoi(getenv("EEGLDM_GN_PIPE_MIN_SLABS")) : 2);
+      EEG_ENV_VAR(int, pipe_max_slot, getenv("EEGLDM_GN_PIPE_MAX_SLOT") ? atoi(getenv("EEGLDM_GN_PIPE_MAX_SLOT")) : 1 << 20);
+      // with a residual-path addend (a fourth 48 KB stream per slab) the kernel is bandwidth-bound like the resident one and measures
+      // 3-5 % slower than it (tools/debug/gn_pipe_bench.py): those launches keep the resident kernel unless EEGLDM_GN_PIPE_ADDEND=1
+      EEG_ENV_VAR(bool, pipe_addend, getenv("EEGLDM_GN_PIPE_ADDEND") != nullptr);
+      const int cpg = C / G;
+      const int pcc = (L > 0 && (PIPE_RPT * NTB * 4) % L == 0) ? (PIPE_RPT * NTB * 4) / L : 0;
+      const bool pow2 = pcc >= 16 && pcc <= RES_MAXC && (pcc & (pcc - 1)) == 0;
+      auto al16 = [](const void* p) { return ((size_t)p & 15) == 0; };
+      if (!no_pipe && !off && resample == 0 && !dxr2 && (!dxr || pipe_addend) && pow2 && pcc * 2 >= pipe_min_row && C % pcc == 0 && C % G == 0 && pcc % cpg == 0 &&
+          pcc / cpg <= RES_MAXG && cpg % 4 == 0 && (G * 8) % 16 == 0 && B % 8 == 0 && ldx % 8 == 0 && lddy % 8 == 0 && lddx % 4 == 0 &&
+          (!dxr || lddxr % 8 == 0) && al16(x) && al16(dy) && al16(stats) && (!dxr || al16(dxr)) && (long)L * (ldx > lddy ? ldx : lddy) * 2 < (1l << 31)) {
+        const int nchunk = C / pcc, per_xcd = ctx->num_cu / 8;
+        int nslot = per_xcd / nchunk; if (nslot > B / 8) nslot = B / 8; if (nslot > pipe_max_slot) nslot = pipe_max_slot;
+        if (nslot >= 1 && (long)nchunk * B >= (long)pipe_min_slabs * 8 * nslot * nchunk) {
+          float* slots = nullptr;
+          EEG_ENV_VAR(bool, no_defer_p, getenv("EEGLDM_GN_NO_DEFER") != nullptr);
+          const bool defer = slots_deferred && dgamma && !no_defer_p;
+          if (dgamma) slots = (float*)((char*)ctx->scratch + (defer ? gn_slot_region(defer_region) : GN_SLOT_OFFSET));
+          EEG_ENV_VAR(bool, no_batch_p, getenv("EEGLDM_GN_NO_BATCHED_FOLD") != nullptr);
+          const bool batched = defer && ctx->defer_wgrad && !no_batch_p && C <= 1024 && ctx->gn_fold_count < GN_FOLD_MAX;
+          if (batched) {
+            if (!ctx->gn_slot_arena) {
+              HIP_TRY(hipMalloc(&ctx->gn_slot_arena, (size_t)GN_FOLD_MAX * GN_REGION_FLOATS * sizeof(float)));
+              HIP_TRY(hipMemsetAsync(ctx->gn_slot_arena, 0, (size_t)GN_FOLD_MAX * GN_REGION_FLOATS * sizeof(float), ctx->stream));
+            }
+            slots = ctx->gn_slot_arena + (size_t)ctx->gn_fold_count * GN_REGION_FLOATS;
+            ctx->gn_fold_pending.push_back({slots, dgamma, dbeta, C});
+            ctx->gn_fold_count++;
+          }
+          static DevOnce attr_once;
+          if (attr_once.need(ctx->device)) {
+            HIP_TRY(hipFuncSetAttribute((const void*)gn_bwd_pipe_kernel<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, PIPE_LDS));
+            HIP_TRY(hipFuncSetAttribute((const void*)gn_bwd_pipe_kernel<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, PIPE_LDS));
+            HIP_TRY(hipFuncSetAttribute((const void*)gn_bwd_pipe_kernel<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, PIPE_LDS));
+            HIP_TRY(hipFuncSetAttribute((const void*)gn_bwd_pipe_kernel<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, PIPE_LDS));
+          }
+          const dim3 grid((unsigned)(8 * nslot * nchunk));
+#define GN_BWD_PIPE(SL, ER) hipLaunchKernelGGL((gn_bwd_pipe_kernel<SL, ER>), grid, dim3(NTB), PIPE_LDS, ctx->stream, (const bf16_t*)x, ldx, gamma, beta, stats, \
+                                           (const bf16_t*)dy, lddy, (bf16_t*)dx, lddx, (const bf16_t*)dxr, lddxr, slots, colsum_ps, ldps, B, L, C, G, pcc)
+          if (silu) { if (dxr) GN_BWD_PIPE(true, true); else GN_BWD_PIPE(true, false); }
+          else { if (dxr) GN_BWD_PIPE(false, true); else GN_BWD_PIPE(false, false); }
+#undef GN_BWD_PIPE
+          LAUNCH_CHECK();
+          if (slots && !defer) {
+            hipLaunchKernelGGL(gn_slot_reduce_kernel, dim3((2 * C + 255) / 256), dim3(256), 0, ctx->stream, slots, dgamma, dbeta, C, (double*)ctx->scratch, 0);
+            LAUNCH_CHECK();
+          }
+          if (defer) *slots_deferred = batched ? 2 : 1;
+          if (colsum_done && colsum_ps) *colsum_done = 1;
+          return 0;
+        }
+      }
+    }
     int rpt = 0; int cc = off ? 0 : resident_chunk(L, C, G, 0, sizeof(T) == 2 ? 12 : 8, &rpt, nth);
     // measured (tools/debug/gn_bench.py): the one-pass kernel wins while its blocks fit two rounds of one block per CU
     // (1024 blocks: 112 us one-pass vs 117-120 us split on the 100 MB tensors; 2048 blocks of 96-channel chunks lose)

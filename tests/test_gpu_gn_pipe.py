@@ -1,0 +1,113 @@
+"""Pipelined one-pass GroupNorm backward (csrc/norm.hip, gn_bwd_pipe_kernel: persistent workgroups, the next slab prefetched by LDS-DMA
+under the current slab's arithmetic, counted vmcnt) against torch's fp32 autograd of nn.GroupNorm(32, C, eps=1e-6) + SiLU
+(/root/reference/src/models/unet.py:71-74,260-262,286-288) and, up to isolated one-ulp rounding flips, against the register-resident kernel it replaces
+(EEGLDM_GN_NO_PIPE=1).  The developer switches force several slabs per workgroup at test size (the production launch has 4-8)."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+
+def _imports():
+    import gpu_util as G
+    return G
+
+
+def normal(shape, seed):
+    return np.random.default_rng(seed).standard_normal(shape).astype(np.float32)
+
+
+# B, L, C, silu, residual-path addend, slabs per workgroup wanted
+PIPE_CASES = [
+    (24, 384, 256, 1, 1, 3),       # level 1: 64-channel chunks (128-byte rows)
+    (24, 192, 512, 1, 0, 3),       # level 2: 128-channel chunks
+    (16, 768, 128, 1, 1, 2),       # level 0: 32-channel chunks (64-byte rows, two chunks share a line)
+    (16, 192, 1024, 0, 1, 2),      # concatenated input of the up path, no SiLU (attention norm form)
+    (32, 384, 512, 1, 1, 4),
+    (8, 96, 256, 1, 0, 1),         # 256-channel chunk, one slab per workgroup (no prefetch at all)
+    (40, 384, 256, 1, 1, 2),       # 5 sample octets over 2 slots: workgroups with 3 and with 2 slabs
+]
+
+
+def _same_up_to_rounding_flips(a, b):
+    """Both kernels add fp32 per-thread partial sums (6 rows here, 12 there) into fp64 block accumulators, so the group sums agree to ~1e-7
+    and dx is the same up to isolated one-ulp bf16 rounding flips (measured: 0-13 per 2.4 M elements)."""
+    diff = a.view(torch.int16) != b.view(torch.int16)
+    nbad = int(diff.sum())
+    assert nbad <= max(8, 1e-4 * a.numel()), f"dx differs from the resident kernel in {nbad} of {a.numel()} elements"
+    if nbad:      # one bf16 ulp of the value, or -- where dx is a small difference of O(1) terms -- the fp32 noise of those terms
+        fa, fb = a.float()[diff], b.float()[diff]
+        excess = (fa - fb).abs() - torch.maximum(2.0 ** -7 * torch.maximum(fa.abs(), fb.abs()), torch.full_like(fa, 1e-5))
+        assert float(excess.max()) <= 0, f"a difference larger than one bf16 ulp: {fa[:4].tolist()} vs {fb[:4].tolist()}"
+
+
+def _run(G, c, xd, gad, bed, st, dyd, dxrd, B, L, Cc, silu):
+    dxd = torch.empty_like(xd); dga = torch.zeros(Cc, device=G.DEV); dbe = torch.zeros(Cc, device=G.DEV)
+    G.check(G.lib.eegldm_groupnorm_bwd(c.h, G.ptr(xd), Cc, G.ptr(gad), G.ptr(bed), G.ptr(st), G.ptr(dyd), Cc, G.ptr(dxd), Cc, G.ptr(dga), G.ptr(dbe),
+                                       B, L, Cc, 32, silu, 0, G.ptr(dxrd) if dxrd is not None else None, Cc, G.BF16))
+    torch.cuda.synchronize()
+    return dxd, dga, dbe
+
+
+@pytest.mark.parametrize("case", PIPE_CASES)
+def test_pipelined_groupnorm_backward_matches_torch_and_the_resident_kernel(case, env_switches):
+    G = _imports()
+    B, L, Cc, silu, has_r, nk = case
+    x = (torch.from_numpy(normal((B, Cc, L), seed=11)) * 1.5 + 0.7).bfloat16().float().requires_grad_(True)
+    ga = (1 + 0.1 * torch.from_numpy(normal((Cc,), seed=12))).requires_grad_(True)
+    be = (0.1 * torch.from_numpy(normal((Cc,), seed=13))).requires_grad_(True)
+    h = F.group_norm(x, 32, ga, be, eps=1e-6)
+    if silu:
+        h = F.silu(h)
+    dy = torch.from_numpy(normal((B, Cc, L), seed=14)).bfloat16().float()
+    dxr = torch.from_numpy(normal((B, Cc, L), seed=15)).bfloat16().float() if has_r else None
+    loss = (h * dy).sum()
+    if has_r:
+        loss = loss + (x * dxr).sum()
+    loss.backward()
+
+    c = G.ctx()
+    xd = G.nlc(x.detach(), G.BF16); gad, bed = ga.detach().to(G.DEV), be.detach().to(G.DEV)
+    yd = torch.empty_like(xd); st = torch.empty(B * 32 * 2, device=G.DEV)
+    G.check(G.lib.eegldm_groupnorm_fwd(c.h, G.ptr(xd), Cc, G.ptr(gad), G.ptr(bed), G.ptr(yd), Cc, G.ptr(st), B, L, Cc, 32, 1e-6, silu, 0, None, 0, G.BF16))
+    dyd = G.nlc(dy, G.BF16); dxrd = G.nlc(dxr, G.BF16) if has_r else None
+
+    # slabs per workgroup = sample octets / slots: hold the slots down so that the prefetch loop runs `nk` times
+    slots = max(1, (B // 8) // nk)
+    env_switches(EEGLDM_GN_PIPE_MIN_SLABS="1", EEGLDM_GN_PIPE_MAX_SLOT=str(slots), EEGLDM_GN_NO_PIPE=None)
+    dx_p, dga_p, dbe_p = _run(G, c, xd, gad, bed, st, dyd, dxrd, B, L, Cc, silu)
+    dx_p2, _, _ = _run(G, c, xd, gad, bed, st, dyd, dxrd, B, L, Cc, silu)
+    env_switches(EEGLDM_GN_NO_PIPE="1")
+    dx_r, dga_r, dbe_r = _run(G, c, xd, gad, bed, st, dyd, dxrd, B, L, Cc, silu)
+
+    assert torch.equal(dx_p.view(torch.int16), dx_p2.view(torch.int16)), "pipelined kernel is not reproducible run to run"
+    _same_up_to_rounding_flips(dx_p, dx_r)
+    G.assert_close(G.ncl(dx_p, B, L), x.grad, **G.GTOL[G.BF16], name="dx")
+    sc = max(1.0, float(ga.grad.abs().max()))
+    for got, ref, want, name in ((dga_p, dga_r, ga.grad, "dgamma"), (dbe_p, dbe_r, be.grad, "dbeta")):
+        G.assert_close(got, want, rtol=G.GTOL[G.BF16]["rtol"], atol=G.GTOL[G.BF16]["atol"] * sc, name=name)
+        # same per-channel fp64 block sums in both kernels; only the order of the fp32 slot atomics differs
+        assert float((got - ref).abs().max()) <= 2e-5 * max(1.0, float(ref.abs().max())), name + " vs the resident kernel"
+
+
+def test_pipelined_groupnorm_backward_is_the_default_at_production_shapes(env_switches):
+    """B = 64 rows of the LDM step's three levels: the launch takes the pipelined kernel by itself (no switches) and agrees with the
+    resident kernel."""
+    G = _imports()
+    c = G.ctx()
+    for (L, Cc) in ((768, 128), (384, 256), (192, 512), (192, 1024)):
+        B = 64
+        g = torch.Generator(device="cuda").manual_seed(L + Cc)
+        xd = (torch.randn(B * L, Cc, device=G.DEV, generator=g) * 1.3 + 0.4).bfloat16()
+        dyd = torch.randn(B * L, Cc, device=G.DEV, generator=g).bfloat16(); dxrd = torch.randn(B * L, Cc, device=G.DEV, generator=g).bfloat16()
+        gad = 1 + 0.1 * torch.randn(Cc, device=G.DEV, generator=g); bed = 0.1 * torch.randn(Cc, device=G.DEV, generator=g)
+        yd = torch.empty_like(xd); st = torch.empty(B * 32 * 2, device=G.DEV)
+        G.check(G.lib.eegldm_groupnorm_fwd(c.h, G.ptr(xd), Cc, G.ptr(gad), G.ptr(bed), G.ptr(yd), Cc, G.ptr(st), B, L, Cc, 32, 1e-6, 1, 0, None, 0, G.BF16))
+        env_switches(EEGLDM_GN_NO_PIPE=None)
+        dx_p, dga_p, _ = _run(G, c, xd, gad, bed, st, dyd, dxrd, B, L, Cc, 1)
+        env_switches(EEGLDM_GN_NO_PIPE="1")
+        dx_r, dga_r, _ = _run(G, c, xd, gad, bed, st, dyd, dxrd, B, L, Cc, 1)
+        _same_up_to_rounding_flips(dx_p, dx_r)
+        assert float((dga_p - dga_r).abs().max()) <= 2e-5 * max(1.0, float(dga_r.abs().max()))
