@@ -12,6 +12,15 @@ static thread_local TimerState g_timer;
 int g_eeg_env_epoch = 0;
 int g_eeg_live_ctx = 0;
 extern "C" int eegldm_abi_version(void) { return EEGLDM_ABI_VERSION; }
+int eeg_det_buffer(eegldm_ctx* ctx, size_t bytes, float** out) {
+  if (ctx->det_buf_bytes < bytes) {
+    if (ctx->det_buf) { HIP_TRY(hipStreamSynchronize(ctx->stream)); HIP_TRY(hipFree(ctx->det_buf)); ctx->det_buf = nullptr; ctx->det_buf_bytes = 0; }
+    const size_t want = bytes < ((size_t)32 << 20) ? ((size_t)32 << 20) : bytes;
+    HIP_TRY(hipMalloc(&ctx->det_buf, want)); ctx->det_buf_bytes = want;
+  }
+  *out = ctx->det_buf;
+  return 0;
+}
 extern "C" int eegldm_debug_reload_env(void) { return ++g_eeg_env_epoch; }
 
 extern "C" const char* eegldm_last_error(void) { return g_err.c_str(); }
@@ -77,6 +86,7 @@ extern "C" int eegldm_ctx_destroy(eegldm_ctx* c) {
   if (c->grp_dev) hipFree(c->grp_dev);
   if (c->gn_slot_arena) hipFree(c->gn_slot_arena);
   if (c->gn_fold_dev) hipFree(c->gn_fold_dev);
+  if (c->det_buf) hipFree(c->det_buf);
   if (c->owns_stream) hipStreamDestroy(c->stream);
   if (c->side) { hipStreamDestroy(c->side); hipEventDestroy(c->ev_fork); hipEventDestroy(c->ev_join); }
   delete c;

@@ -1,5 +1,6 @@
 // Shared declarations for the eegldm HIP library (gfx950 only).
 #pragma once
+#include <stdlib.h>
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdio.h>
@@ -42,6 +43,13 @@ extern int g_eeg_env_epoch;
   static T name;                                                                                        \
   do { static int _ep_##name = -1;                                                                      \
        if (_ep_##name != g_eeg_env_epoch) { name = (__VA_ARGS__); _ep_##name = g_eeg_env_epoch; } } while (0)
+// EEGLDM_DETERMINISTIC=1: bit-reproducible gradients and losses run to run.  Every reduction whose order depends on timing (fp32 global atomics
+// of the bias / GroupNorm / thin-conv gradients and the loss sums; the fused column sums inside the weight-gradient GEMM; split-K without
+// a workspace) takes a written-partials + fixed-order-fold route instead.  Slower by a few per cent; the default stays off.
+static inline bool eeg_deterministic() {
+  EEG_ENV_VAR(bool, det, getenv("EEGLDM_DETERMINISTIC") != nullptr && atoi(getenv("EEGLDM_DETERMINISTIC")) != 0);
+  return det;
+}
 extern int g_eeg_live_ctx;      // contexts alive in this process (eegldm_ctx_create / _destroy): kernels that are only safe alone on a CU ask
 
 // ---------------------------------------------------------------- context
@@ -89,6 +97,8 @@ struct eegldm_ctx {
   struct GnFoldRec { float* slots; float* dgamma; float* dbeta; int C; };
   std::vector<GnFoldRec> gn_fold_pending, gn_fold_host;
   float* gn_slot_arena = nullptr; GnFoldRec* gn_fold_dev = nullptr; int gn_fold_count = 0;
+  // deterministic mode: one private buffer for written partial sums (grown on demand, zero where the consumer expects zeros)
+  float* det_buf = nullptr; size_t det_buf_bytes = 0;
 };
 
 // per-DEVICE once flag (hipFuncSetAttribute and friends are per device; a process may drive several GPUs through several contexts)

@@ -855,16 +855,22 @@ int dconv_wgrad(eegldm_ctx* ctx, int dtype, const void* x, long ldx, const void*
 #undef DWV_CO
 #undef DWV
       LAUNCH_CHECK();
-      hipLaunchKernelGGL(dconv_tiny_fold_kernel, dim3(blocks >= 64 ? 8 : 1), dim3(NT), 0, ctx->stream, parts, blocks, EP, K * Cout * Cin, EW, Cout, dw, dbias);
-      LAUNCH_CHECK();
+      if (eeg_deterministic()) {      // partial rows in block order, one thread per element
+        EEG_TRY(ew_fold_partials_det(ctx, parts, blocks, EP, 0, K * Cout * Cin, dw));
+        if (dbias) EEG_TRY(ew_fold_partials_det(ctx, parts, blocks, EP, EW, Cout, dbias));
+      } else {
+        hipLaunchKernelGGL(dconv_tiny_fold_kernel, dim3(blocks >= 64 ? 8 : 1), dim3(NT), 0, ctx->stream, parts, blocks, EP, K * Cout * Cin, EW, Cout, dw, dbias);
+        LAUNCH_CHECK();
+      }
       if (bias_done && dbias) *bias_done = 1;
       return 0;
     }
+    const int tb = eeg_deterministic() ? 1 : blocks;      // one atomic per element and block: a single block is a single writer
     if (dtype == EEGLDM_F32)
-      hipLaunchKernelGGL((dconv_wgrad_tiny_kernel<float>), dim3(blocks), dim3(NT), 0, ctx->stream, (const float*)x, ldx, (const float*)dy, lddy,
+      hipLaunchKernelGGL((dconv_wgrad_tiny_kernel<float>), dim3(tb), dim3(NT), 0, ctx->stream, (const float*)x, ldx, (const float*)dy, lddy,
                          dw, B, Lout, Lin, Cout, Cin, K, stride, pad_l);
     else
-      hipLaunchKernelGGL((dconv_wgrad_tiny_kernel<bf16_t>), dim3(blocks), dim3(NT), 0, ctx->stream, (const bf16_t*)x, ldx, (const bf16_t*)dy, lddy,
+      hipLaunchKernelGGL((dconv_wgrad_tiny_kernel<bf16_t>), dim3(tb), dim3(NT), 0, ctx->stream, (const bf16_t*)x, ldx, (const bf16_t*)dy, lddy,
                          dw, B, Lout, Lin, Cout, Cin, K, stride, pad_l);
     LAUNCH_CHECK();
     return 0;
@@ -891,6 +897,7 @@ int dconv_wgrad(eegldm_ctx* ctx, int dtype, const void* x, long ldx, const void*
       }
       long nb = (rows + rpb - 1) / rpb; const long capb = (long)ctx->num_cu * 4; if (nb > capb) nb = capb;   // 48 KB of LDS per block: 3 per CU
       float* parts = ((size_t)nb * E * sizeof(float) <= (16u << 20)) ? (float*)((char*)ctx->scratch + (8u << 20)) : nullptr;
+      if (!parts && eeg_deterministic()) EEG_TRY(eeg_det_buffer(ctx, (size_t)nb * E * sizeof(float), &parts));
       if (!parts) { const long cap2 = (long)ctx->num_cu * 2; if (nb > cap2) nb = cap2; }
 #define DWT(T_, WO_) hipLaunchKernelGGL((dconv_wgrad_wt_kernel<T_, WO_>), dim3((unsigned)nb), dim3(NT), 0, ctx->stream, (const T_*)x, ldx, (const T_*)dy, lddy, \
                                         dw, parts, B, Lout, Lin, Cout, Cin, K, stride, pad_l)
@@ -906,6 +913,7 @@ int dconv_wgrad(eegldm_ctx* ctx, int dtype, const void* x, long ldx, const void*
   long blocks = (rows + rpc - 1) / rpc;
   const long cap = (long)ctx->num_cu * 4;
   if (blocks > cap) blocks = cap;
+  if (eeg_deterministic()) blocks = 1;      // one atomic per element and block (generic fallback shape: rare, slow, ordered)
   if (dtype == EEGLDM_F32)
     hipLaunchKernelGGL((dconv_wgrad_kernel<float>), dim3((unsigned)blocks), dim3(NT), 0, ctx->stream, (const float*)x, ldx,
                        (const float*)dy, lddy, dw, B, Lout, Lin, Cout, Cin, K, stride, pad_l, rpc);

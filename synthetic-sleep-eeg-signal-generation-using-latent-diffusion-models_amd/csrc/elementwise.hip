@@ -405,7 +405,53 @@ int ew_silu_bwd(eegldm_ctx* ctx, const float* dy, const float* x, void* dx, long
   LAUNCH_CHECK(); return 0;
 }
 // out_ps: per-sample sums [B][ldo] fp32 (written; single L split) or NULL; total: fp32 [C] accumulated (+=) or NULL
+// ---- deterministic column sums (EEGLDM_DETERMINISTIC=1): no atomics anywhere.  Stage 1: thread = channel, block = (row segment, sample):
+// the rows of the segment are added in order and the partial row is written.  Stage 2: thread = channel, the partial rows are added in order
+// (segments of a sample, then samples) in fp64.
+template <typename T>
+__global__ __launch_bounds__(NT) void colsum_det_kernel(const T* __restrict__ x, long ldx, float* __restrict__ parts, int L, int C, int rows_per_seg) {
+  const int c = blockIdx.z * NT + threadIdx.x;
+  if (c >= C) return;
+  const int b = blockIdx.y, l0 = blockIdx.x * rows_per_seg, l1 = min(L, l0 + rows_per_seg);
+  float s = 0.f;
+  for (int l = l0; l < l1; l++) s += ld_f32(x + ((long)b * L + l) * ldx + c);
+  parts[((long)b * gridDim.x + blockIdx.x) * C + c] = s;
+}
+__global__ __launch_bounds__(NT) void colsum_det_fold_kernel(const float* __restrict__ parts, int B, int nseg, int C, float* __restrict__ out_ps, long ldo,
+                                                             float* __restrict__ total) {
+  const int c = blockIdx.x * NT + threadIdx.x;
+  if (c >= C) return;
+  double t = 0.0;
+  for (int b = 0; b < B; b++) {
+    double s = 0.0;
+    for (int g = 0; g < nseg; g++) s += (double)parts[((long)b * nseg + g) * C + c];
+    if (out_ps) out_ps[(long)b * ldo + c] = (float)s;
+    t += s;
+  }
+  if (total) total[c] += (float)t;
+}
+__global__ __launch_bounds__(NT) void fold_partials_det_kernel(const float* __restrict__ parts, int nparts, long stride, int off, int n, float* __restrict__ total) {
+  const int i = blockIdx.x * NT + threadIdx.x;
+  if (i >= n) return;
+  double s = 0.0;
+  for (int p = 0; p < nparts; p++) s += (double)parts[(long)p * stride + off + i];
+  total[i] += (float)s;
+}
+int ew_fold_partials_det(eegldm_ctx* ctx, const float* parts, int nparts, long stride, int off, int n, float* total) {
+  hipLaunchKernelGGL(fold_partials_det_kernel, dim3((n + NT - 1) / NT), dim3(NT), 0, ctx->stream, parts, nparts, stride, off, n, total);
+  LAUNCH_CHECK(); return 0;
+}
 int ew_colsum(eegldm_ctx* ctx, const void* x, long ldx, float* out_ps, long ldo, float* total, int B, int L, int C, int dtype) {
+  if (eeg_deterministic()) {
+    long nseg = ((size_t)16 << 20) / ((size_t)B * C * sizeof(float)); if (nseg > (L + 7) / 8) nseg = (L + 7) / 8; if (nseg > 64) nseg = 64; if (nseg < 1) nseg = 1;
+    int rps = (int)((L + nseg - 1) / nseg); nseg = (L + rps - 1) / rps;
+    float* parts = nullptr; EEG_TRY(eeg_det_buffer(ctx, (size_t)B * nseg * C * sizeof(float), &parts));
+    const dim3 grid((unsigned)nseg, (unsigned)B, (unsigned)((C + NT - 1) / NT));
+    DISPATCH_T(dtype, hipLaunchKernelGGL((colsum_det_kernel<T>), grid, dim3(NT), 0, ctx->stream, (const T*)x, ldx, parts, L, C, rps));
+    LAUNCH_CHECK();
+    hipLaunchKernelGGL(colsum_det_fold_kernel, dim3((C + NT - 1) / NT), dim3(NT), 0, ctx->stream, parts, B, (int)nseg, C, out_ps, ldo, total);
+    LAUNCH_CHECK(); return 0;
+  }
   int lsplit = 1, rpb = L;
   if (!out_ps) {  // free to split L when only the fp32 atomic total is wanted
     int want = (ctx->num_cu * 8 + B - 1) / B; if (want < 1) want = 1;   // 8 blocks (2048 threads) per CU: enough loads in flight to stream
@@ -425,6 +471,7 @@ int ew_colsum(eegldm_ctx* ctx, const void* x, long ldx, float* out_ps, long ldo,
 }
 // total[i] += sum over nparts rows of parts[r][i] (i < n): the finishing pass of the written-partials reductions
 int ew_fold_partials(eegldm_ctx* ctx, const float* parts, int nparts, int n, float* total) {
+  if (eeg_deterministic()) return ew_fold_partials_det(ctx, parts, nparts, n, 0, n, total);
   hipLaunchKernelGGL(colsum_finish_kernel, dim3((n + 63) / 64, 32), dim3(NT), 0, ctx->stream, parts, nparts, n, total);
   LAUNCH_CHECK(); return 0;
 }
@@ -596,7 +643,8 @@ extern "C" int eegldm_ddpm_step(eegldm_ctx* ctx, const float* mo, const float* x
 }
 extern "C" int eegldm_mse_loss(eegldm_ctx* ctx, const float* p, const float* t, float* loss, float* dp, long n, float gscale) {
   HIP_TRY(hipMemsetAsync(loss, 0, sizeof(float), ctx->stream));
-  hipLaunchKernelGGL(mse_kernel, dim3(grid1d(n, ctx, 4)), dim3(NT), 0, ctx->stream, p, t, loss, dp, n, 1.0f / (float)n, gscale);
+  // (deterministic mode: ONE block, so the loss is one fixed-order sum instead of a race of per-block atomics)
+  hipLaunchKernelGGL(mse_kernel, dim3(eeg_deterministic() ? 1 : grid1d(n, ctx, 4)), dim3(NT), 0, ctx->stream, p, t, loss, dp, n, 1.0f / (float)n, gscale);
   LAUNCH_CHECK(); return 0;
 }
 extern "C" int eegldm_adam_step(eegldm_ctx* ctx, float* p, const float* g, float* m, float* v, long n, float lr, float b1, float b2,

@@ -1244,6 +1244,7 @@ int gemm_launch(eegldm_ctx* ctx, const GemmArgs& a_in) {
       a.C = ctx->splitk_ws; a.sCk = fold_n; a.atomic_out = 0;
     }
   }
+  if (a.splitk > 1 && !fold_dst && eeg_deterministic()) a.splitk = 1;      // no workspace route for this product: one writer per output element instead of racing K splits
   if (a.splitk > 1 && !fold_dst) a.atomic_out = 1;
   a.zero_page = ctx->zero_page;
   { EEG_ENV_VAR(bool, no_swz, getenv("EEGLDM_GEMM_NO_XCD_SWIZZLE") != nullptr); a.xcd_swizzle = no_swz ? 0 : 1; }

@@ -6,6 +6,10 @@
 int ew_temb(eegldm_ctx*, const int64_t* t, void* out, int B, int dim, int dtype);
 int ew_silu(eegldm_ctx*, const float* x, void* y, long n, int dtype);
 int ew_silu_bwd(eegldm_ctx*, const float* dy, const float* x, void* dx, long n, int dtype);
+// deterministic mode (common.h eeg_deterministic): a private buffer of at least `bytes` for written partial sums (contents undefined)
+int eeg_det_buffer(eegldm_ctx*, size_t bytes, float** out);
+// total[i] += sum_p parts[p * stride + off + i], i < n, in the order p = 0, 1, ... (one thread per element, fp64 accumulator)
+int ew_fold_partials_det(eegldm_ctx*, const float* parts, int nparts, long stride, int off, int n, float* total);
 int ew_colsum(eegldm_ctx*, const void* x, long ldx, float* out_ps, long ldo, float* total, int B, int L, int C, int dtype);
 int ew_softmax(eegldm_ctx*, const float* S, void* P, long rows, int n, int dtype);
 int ew_softmax_bwd(eegldm_ctx*, const float* dP, const void* P, void* dS, long rows, int n, float alpha, int dtype);

@@ -219,7 +219,7 @@ __global__ __launch_bounds__(NT) void gn_bwd_reduce_kernel(const T* __restrict__
                                                            const float* __restrict__ beta, const float* __restrict__ stats,
                                                            const T* __restrict__ dy, long lddy, double* __restrict__ gsums,
                                                            float* __restrict__ slots,
-                                                           int L, int C, int G, int silu, int rows_per_block) {
+                                                           int L, int C, int G, int silu, int rows_per_block, int nslot) {
   __shared__ double accg[2 * MAXG_LDS];  // group sums feed dx: fp64 so that the thread arrival order does not show (see gn_stats_kernel)
   __shared__ double accc[2 * MAXG_LDS];
   const int b = blockIdx.y, tid = threadIdx.x;
@@ -261,19 +261,19 @@ __global__ __launch_bounds__(NT) void gn_bwd_reduce_kernel(const T* __restrict__
   for (int i = tid; i < 2 * G; i += NT) atomicAdd(&gsums[(long)b * G * 2 + i], accg[i]);
   // per-channel sums go to one of NSLOT partial buffers (thousands of blocks hammering 2C addresses serialise in L2)
   if (slots) {
-    float* sl = slots + (size_t)((blockIdx.y * gridDim.x + blockIdx.x) % GN_NSLOT) * 2 * C;
+    float* sl = slots + (size_t)((blockIdx.y * gridDim.x + blockIdx.x) % nslot) * 2 * C;
     for (int i = tid; i < 2 * C; i += NT) atomicAdd(&sl[i], (float)accc[i]);
   }
 }
 
 // runs AFTER the backward apply kernel: folds the slots into dgamma/dbeta and re-zeroes slots and group sums
 __global__ void gn_slot_reduce_kernel(float* __restrict__ slots, float* __restrict__ dgamma, float* __restrict__ dbeta, int C,
-                                      double* __restrict__ gsums, int n_gsums) {
+                                      double* __restrict__ gsums, int n_gsums, int nslot = GN_NSLOT) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   for (int k = i; k < n_gsums; k += gridDim.x * blockDim.x) gsums[k] = 0.0;
   if (i >= 2 * C || !slots) return;
   float s = 0.f;
-  for (int k = 0; k < GN_NSLOT; k++) { s += slots[(size_t)k * 2 * C + i]; slots[(size_t)k * 2 * C + i] = 0.f; }
+  for (int k = 0; k < nslot; k++) { s += slots[(size_t)k * 2 * C + i]; slots[(size_t)k * 2 * C + i] = 0.f; }
   if (i < C) dgamma[i] += s; else dbeta[i - C] += s;
 }
 
@@ -524,7 +524,7 @@ __global__ __launch_bounds__(NTH) GN_BWD_ATTR void gn_bwd_resident_kernel(const 
                                                               const T* __restrict__ dxr, long lddxr, float* __restrict__ slots,
                                                               float* __restrict__ colsum_ps, long ldps,
                                                               int L, int C, int G, int silu, int resample, int CC,
-                                                              const T* __restrict__ dxr2, long lddxr2, int xcd) {
+                                                              const T* __restrict__ dxr2, long lddxr2, int xcd, int nslot) {
   // fp64 LDS accumulators (as in the forward): dx must not depend on the order in which the waves arrive -- an fp32 one-ulp
   // difference in the group sums flips bf16 roundings of dx and the flips compound through the remaining layers
   __shared__ double redg[2 * RES_MAXG];
@@ -665,7 +665,7 @@ __global__ __launch_bounds__(NTH) GN_BWD_ATTR void gn_bwd_resident_kernel(const 
     const float inv_n = 1.0f / ((float)cpg * (float)L);
     const float m1 = (float)(redg[2 * m.gl] * (double)inv_n), m2 = (float)(redg[2 * m.gl + 1] * (double)inv_n);
     if (slots && m.ty == 0) {
-      float* sl = slots + (size_t)(b % GN_NSLOT) * 2 * C;
+      float* sl = slots + (size_t)(b % nslot) * 2 * C;
 #pragma unroll
       for (int j = 0; j < 4; j++) { atomicAdd(&sl[m.c + j], (float)redc[m.tx * 4 + j]); atomicAdd(&sl[C + m.c + j], (float)redc[RES_MAXC + m.tx * 4 + j]); }
     }
@@ -758,7 +758,7 @@ __global__ __launch_bounds__(NTB) void gn_bwd_pipe_kernel(const bf16_t* __restri
                                                           const float* __restrict__ beta, const float* __restrict__ stats,
                                                           const bf16_t* __restrict__ dy, long lddy, bf16_t* __restrict__ dx, long lddx,
                                                           const bf16_t* __restrict__ dxr, long lddxr, float* __restrict__ slots,
-                                                          float* __restrict__ colsum_ps, long ldps, int B, int L, int C, int G, int CC) {
+                                                          float* __restrict__ colsum_ps, long ldps, int B, int L, int C, int G, int CC, int ndg) {
   extern __shared__ __attribute__((aligned(16))) char psm[];
   typedef __attribute__((address_space(3))) void* lds_ptr_t;
   double* const redg = (double*)(psm + PIPE_OFF_RED);
@@ -874,7 +874,7 @@ __global__ __launch_bounds__(NTB) void gn_bwd_pipe_kernel(const bf16_t* __restri
     {
       const float m1 = (float)(redg[2 * gl] * (double)inv_n), m2 = (float)(redg[2 * gl + 1] * (double)inv_n);
       if (slots && ty == 0) {
-        float* sl = slots + (size_t)(b % GN_NSLOT) * 2 * C;
+        float* sl = slots + (size_t)(b % ndg) * 2 * C;
 #pragma unroll
         for (int j = 0; j < 4; j++) { atomicAdd(&sl[c + j], (float)redc[tx * 4 + j]); atomicAdd(&sl[C + c + j], (float)redc[RES_MAXC + tx * 4 + j]); }
       }
@@ -1069,8 +1069,15 @@ int gn_bwd_t(eegldm_ctx* ctx, const void* x, long ldx, const float* gamma, const
         if (nslot >= 1 && (long)nchunk * B >= (long)pipe_min_slabs * 8 * nslot * nchunk) {
           float* slots = nullptr;
           EEG_ENV_VAR(bool, no_defer_p, getenv("EEGLDM_GN_NO_DEFER") != nullptr);
-          const bool defer = slots_deferred && dgamma && !no_defer_p;
+          const bool det = eeg_deterministic() && dgamma;      // a slot per sample (one writer each), folded right behind the launch in sample order
+          const bool defer = slots_deferred && dgamma && !no_defer_p && !det;
+          int ndg = GN_NSLOT;
           if (dgamma) slots = (float*)((char*)ctx->scratch + (defer ? gn_slot_region(defer_region) : GN_SLOT_OFFSET));
+          if (det) {
+            ndg = B;
+            EEG_TRY(eeg_det_buffer(ctx, (size_t)ndg * 2 * C * sizeof(float), &slots));
+            HIP_TRY(hipMemsetAsync(slots, 0, (size_t)ndg * 2 * C * sizeof(float), ctx->stream));
+          }
           EEG_ENV_VAR(bool, no_batch_p, getenv("EEGLDM_GN_NO_BATCHED_FOLD") != nullptr);
           const bool batched = defer && ctx->defer_wgrad && !no_batch_p && C <= 1024 && ctx->gn_fold_count < GN_FOLD_MAX;
           if (batched) {
@@ -1091,13 +1098,13 @@ int gn_bwd_t(eegldm_ctx* ctx, const void* x, long ldx, const float* gamma, const
           }
           const dim3 grid((unsigned)(8 * nslot * nchunk));
 #define GN_BWD_PIPE(SL, ER) hipLaunchKernelGGL((gn_bwd_pipe_kernel<SL, ER>), grid, dim3(NTB), PIPE_LDS, ctx->stream, (const bf16_t*)x, ldx, gamma, beta, stats, \
-                                           (const bf16_t*)dy, lddy, (bf16_t*)dx, lddx, (const bf16_t*)dxr, lddxr, slots, colsum_ps, ldps, B, L, C, G, pcc)
+                                           (const bf16_t*)dy, lddy, (bf16_t*)dx, lddx, (const bf16_t*)dxr, lddxr, slots, colsum_ps, ldps, B, L, C, G, pcc, ndg)
           if (silu) { if (dxr) GN_BWD_PIPE(true, true); else GN_BWD_PIPE(true, false); }
           else { if (dxr) GN_BWD_PIPE(false, true); else GN_BWD_PIPE(false, false); }
 #undef GN_BWD_PIPE
           LAUNCH_CHECK();
           if (slots && !defer) {
-            hipLaunchKernelGGL(gn_slot_reduce_kernel, dim3((2 * C + 255) / 256), dim3(256), 0, ctx->stream, slots, dgamma, dbeta, C, (double*)ctx->scratch, 0);
+            hipLaunchKernelGGL(gn_slot_reduce_kernel, dim3((2 * C + 255) / 256), dim3(256), 0, ctx->stream, slots, dgamma, dbeta, C, (double*)ctx->scratch, 0, ndg);
             LAUNCH_CHECK();
           }
           if (defer) *slots_deferred = batched ? 2 : 1;
@@ -1122,8 +1129,15 @@ int gn_bwd_t(eegldm_ctx* ctx, const void* x, long ldx, const float* gamma, const
       // a caller that can run the 7-us fold of the dgamma / dbeta partial slots elsewhere (side stream) gets them in the second slot
       // region and calls op_gn_slot_reduce_deferred itself
       EEG_ENV_VAR(bool, no_defer, getenv("EEGLDM_GN_NO_DEFER") != nullptr);
-      const bool defer = slots_deferred && dgamma && !no_defer;
+      const bool det = eeg_deterministic() && dgamma;      // see the pipelined launch above
+      const bool defer = slots_deferred && dgamma && !no_defer && !det;
       float* slots = dgamma ? (float*)((char*)ctx->scratch + (defer ? gn_slot_region(defer_region) : GN_SLOT_OFFSET)) : nullptr;
+      int nslot = GN_NSLOT;
+      if (det) {
+        nslot = B;
+        EEG_TRY(eeg_det_buffer(ctx, (size_t)nslot * 2 * C * sizeof(float), &slots));
+        HIP_TRY(hipMemsetAsync(slots, 0, (size_t)nslot * 2 * C * sizeof(float), ctx->stream));
+      }
       // batched mode (the UNet backward with grouped weight gradients): this launch gets its OWN slot region and is folded together with
       // all the others by op_gn_fold_flush -- 49 folds of 7 us become one launch
       EEG_ENV_VAR(bool, no_batch, getenv("EEGLDM_GN_NO_BATCHED_FOLD") != nullptr);
@@ -1138,7 +1152,7 @@ int gn_bwd_t(eegldm_ctx* ctx, const void* x, long ldx, const float* gamma, const
         ctx->gn_fold_count++;
       }
 #define GN_BWD_RES3(R, RAW, SL, N) hipLaunchKernelGGL((gn_bwd_resident_kernel<T, R, RAW, SL, N>), grid, dim3(N), 0, ctx->stream, (const T*)x, ldx, gamma, beta, stats, \
-                                         (const T*)dy, lddy, (T*)dx, lddx, (const T*)dxr, lddxr, slots, colsum_ps, ldps, L, C, G, silu, resample, cc, (const T*)dxr2, lddxr2, xcd)
+                                         (const T*)dy, lddy, (T*)dx, lddx, (const T*)dxr, lddxr, slots, colsum_ps, ldps, L, C, G, silu, resample, cc, (const T*)dxr2, lddxr2, xcd, nslot)
 #define GN_BWD_RES2(R, RAW, SL) do { if (nth == 1024) GN_BWD_RES3(R, RAW, SL, 1024); else if (nth == 512) GN_BWD_RES3(R, RAW, SL, 512); else GN_BWD_RES3(R, RAW, SL, 256); } while (0)
       EEG_ENV_VAR(bool, raw0, getenv("EEGLDM_GN_NO_RAW0") == nullptr);
 #define GN_BWD_RES1(R, RAW) do { if (silu) GN_BWD_RES2(R, RAW, true); else GN_BWD_RES2(R, RAW, false); } while (0)
@@ -1151,7 +1165,7 @@ int gn_bwd_t(eegldm_ctx* ctx, const void* x, long ldx, const float* gamma, const
 #undef GN_BWD_RES3
       LAUNCH_CHECK();
       if (slots && !defer) {
-        hipLaunchKernelGGL(gn_slot_reduce_kernel, dim3((2 * C + 255) / 256), dim3(256), 0, ctx->stream, slots, dgamma, dbeta, C, (double*)ctx->scratch, 0);
+        hipLaunchKernelGGL(gn_slot_reduce_kernel, dim3((2 * C + 255) / 256), dim3(256), 0, ctx->stream, slots, dgamma, dbeta, C, (double*)ctx->scratch, 0, nslot);
         LAUNCH_CHECK();
       }
       if (defer) *slots_deferred = batched ? 2 : 1;       // 2: nothing left for the caller to fold
@@ -1163,9 +1177,15 @@ int gn_bwd_t(eegldm_ctx* ctx, const void* x, long ldx, const float* gamma, const
   double* gsums = (double*)ctx->scratch;     // zero on entry; shared with the forward sums (stream-ordered)
   int rpb; int ls = pick_lsplit(B, L, C, ctx, &rpb);
   float* slots = dgamma ? (float*)((char*)ctx->scratch + GN_SLOT_OFFSET) : nullptr;
+  int nslot = GN_NSLOT;
+  if (slots && eeg_deterministic()) {      // a slot per block: every partial row has one writer, the fold adds the rows in order
+    nslot = ls * B;
+    EEG_TRY(eeg_det_buffer(ctx, (size_t)nslot * 2 * C * sizeof(float), &slots));
+    HIP_TRY(hipMemsetAsync(slots, 0, (size_t)nslot * 2 * C * sizeof(float), ctx->stream));
+  }
 #define GN_BWD_SPLIT(RS) do { \
     hipLaunchKernelGGL((gn_bwd_reduce_kernel<T, V, RS>), dim3(ls, B), dim3(NT), 0, ctx->stream, (const T*)x, ldx, gamma, beta, stats, \
-                       (const T*)dy, lddy, gsums, slots, L, C, G, silu, rpb); \
+                       (const T*)dy, lddy, gsums, slots, L, C, G, silu, rpb, nslot); \
     hipLaunchKernelGGL((gn_bwd_apply_kernel<T, V, RS>), dim3(ls2, B), dim3(NT), 0, ctx->stream, (const T*)x, ldx, gamma, \
                        beta, stats, (const T*)dy, lddy, gsums, (T*)dx, lddx, (const T*)dxr, lddxr, L, C, G, silu, rpb2); } while (0)
   int rpb2; int ls2 = pick_lsplit(B, L, C, ctx, &rpb2, 16, 8);
@@ -1173,7 +1193,7 @@ int gn_bwd_t(eegldm_ctx* ctx, const void* x, long ldx, const float* gamma, const
 #undef GN_BWD_SPLIT
   LAUNCH_CHECK();
   const int n_gs = 2 * B * G;
-  hipLaunchKernelGGL(gn_slot_reduce_kernel, dim3(((2 * C > n_gs ? 2 * C : n_gs) + 255) / 256), dim3(256), 0, ctx->stream, slots, dgamma, dbeta, C, gsums, n_gs);
+  hipLaunchKernelGGL(gn_slot_reduce_kernel, dim3(((2 * C > n_gs ? 2 * C : n_gs) + 255) / 256), dim3(256), 0, ctx->stream, slots, dgamma, dbeta, C, gsums, n_gs, nslot);
   LAUNCH_CHECK();
   return 0;
 }
@@ -1282,7 +1302,7 @@ __global__ __launch_bounds__(FLAT_NT) void gn_flat_fwd_kernel(const T* __restric
 template <typename T, int C, int MAXCH>
 __global__ __launch_bounds__(FLAT_NT) void gn_flat_bwd_kernel(const T* __restrict__ x, const float* __restrict__ gamma, const float* __restrict__ beta,
                                                               const float* __restrict__ stats, const T* __restrict__ dy, T* __restrict__ dx,
-                                                              const T* __restrict__ dxr, float* __restrict__ slots, int n, int silu) {
+                                                              const T* __restrict__ dxr, float* __restrict__ slots, int n, int silu, int nslot) {
   __shared__ float sm[4 * 2 * C];
   const int b = blockIdx.x, tid = threadIdx.x, nch = n >> 3;
   const T* xs = x + (long)b * n; const T* dys = dy + (long)b * n; T* dxs = dx + (long)b * n;
@@ -1325,7 +1345,7 @@ __global__ __launch_bounds__(FLAT_NT) void gn_flat_bwd_kernel(const T* __restric
 #pragma unroll
   for (int c = 0; c < C; c++) { s1 = fmaf(ga[c], r[C + c], s1); s2 = fmaf(ga[c], r[c], s2); }
   if (slots && tid == 0) {
-    float* sl = slots + (size_t)(b % GN_NSLOT) * 2 * C;
+    float* sl = slots + (size_t)(b % nslot) * 2 * C;
 #pragma unroll
     for (int c = 0; c < 2 * C; c++) atomicAdd(&sl[c], r[c]);
   }
@@ -1447,9 +1467,9 @@ int gn_flat_fwd(eegldm_ctx* ctx, const void* x, const float* gamma, const float*
 }
 template <typename T, int C>
 int gn_flat_bwd_c(eegldm_ctx* ctx, const void* x, const float* gamma, const float* beta, const float* stats, const void* dy, void* dx, const void* dxr,
-                  float* slots, int B, int n, int silu) {
-  if (n <= FLAT_NT * 8 * 3) hipLaunchKernelGGL((gn_flat_bwd_kernel<T, C, 3>), dim3(B), dim3(FLAT_NT), 0, ctx->stream, (const T*)x, gamma, beta, stats, (const T*)dy, (T*)dx, (const T*)dxr, slots, n, silu);
-  else hipLaunchKernelGGL((gn_flat_bwd_kernel<T, C, 12>), dim3(B), dim3(FLAT_NT), 0, ctx->stream, (const T*)x, gamma, beta, stats, (const T*)dy, (T*)dx, (const T*)dxr, slots, n, silu);
+                  float* slots, int B, int n, int silu, int nslot) {
+  if (n <= FLAT_NT * 8 * 3) hipLaunchKernelGGL((gn_flat_bwd_kernel<T, C, 3>), dim3(B), dim3(FLAT_NT), 0, ctx->stream, (const T*)x, gamma, beta, stats, (const T*)dy, (T*)dx, (const T*)dxr, slots, n, silu, nslot);
+  else hipLaunchKernelGGL((gn_flat_bwd_kernel<T, C, 12>), dim3(B), dim3(FLAT_NT), 0, ctx->stream, (const T*)x, gamma, beta, stats, (const T*)dy, (T*)dx, (const T*)dxr, slots, n, silu, nslot);
   LAUNCH_CHECK();
   return 0;
 }
@@ -1457,16 +1477,22 @@ template <typename T>
 int gn_flat_bwd(eegldm_ctx* ctx, const void* x, const float* gamma, const float* beta, const float* stats, const void* dy, void* dx, const void* dxr,
                 float* dgamma, float* dbeta, int B, int L, int C, int silu) {
   float* slots = dgamma ? (float*)((char*)ctx->scratch + GN_SLOT_OFFSET) : nullptr;
+  int nslot = GN_NSLOT;
+  if (slots && eeg_deterministic()) {
+    nslot = B;
+    EEG_TRY(eeg_det_buffer(ctx, (size_t)nslot * 2 * C * sizeof(float), &slots));
+    HIP_TRY(hipMemsetAsync(slots, 0, (size_t)nslot * 2 * C * sizeof(float), ctx->stream));
+  }
   int rc;
   switch (C) {
-    case 1: rc = gn_flat_bwd_c<T, 1>(ctx, x, gamma, beta, stats, dy, dx, dxr, slots, B, L * C, silu); break;
-    case 2: rc = gn_flat_bwd_c<T, 2>(ctx, x, gamma, beta, stats, dy, dx, dxr, slots, B, L * C, silu); break;
-    case 4: rc = gn_flat_bwd_c<T, 4>(ctx, x, gamma, beta, stats, dy, dx, dxr, slots, B, L * C, silu); break;
-    default: rc = gn_flat_bwd_c<T, 8>(ctx, x, gamma, beta, stats, dy, dx, dxr, slots, B, L * C, silu); break;
+    case 1: rc = gn_flat_bwd_c<T, 1>(ctx, x, gamma, beta, stats, dy, dx, dxr, slots, B, L * C, silu, nslot); break;
+    case 2: rc = gn_flat_bwd_c<T, 2>(ctx, x, gamma, beta, stats, dy, dx, dxr, slots, B, L * C, silu, nslot); break;
+    case 4: rc = gn_flat_bwd_c<T, 4>(ctx, x, gamma, beta, stats, dy, dx, dxr, slots, B, L * C, silu, nslot); break;
+    default: rc = gn_flat_bwd_c<T, 8>(ctx, x, gamma, beta, stats, dy, dx, dxr, slots, B, L * C, silu, nslot); break;
   }
   if (rc) return rc;
   if (slots) {
-    hipLaunchKernelGGL(gn_slot_reduce_kernel, dim3(1), dim3(256), 0, ctx->stream, slots, dgamma, dbeta, C, (double*)ctx->scratch, 0);
+    hipLaunchKernelGGL(gn_slot_reduce_kernel, dim3(1), dim3(256), 0, ctx->stream, slots, dgamma, dbeta, C, (double*)ctx->scratch, 0, nslot);
     LAUNCH_CHECK();
   }
   return 0;

@@ -87,6 +87,7 @@ bool op_wgrad_fuses_bias(int dtype, int Cin, int Cout) {
   EEG_ENV_VAR(bool, fuse_bias, getenv("EEGLDM_NO_FUSED_BIAS_GRAD") == nullptr);
   if (!fuse_bias) return false;
   if (conv_is_thin(Cin, Cout, dtype)) return dconv_wgrad_tinyv_ok(Cin, Cout, 3);
+  if (eeg_deterministic()) return false;      // the fused column sums are one fp32 atomic per row and K split: bias gradients by the ordered column-sum kernels
   return dtype != EEGLDM_F32;
 }
 
