@@ -85,6 +85,11 @@ int eegldm_prof_dump(eegldm_ctx* ctx, const char* path_host);
  * A/B an execution path against its predecessor inside one process.  Models / contexts created BEFORE the call keep whatever
  * they built from the old values (weight copies, streams).  No reference counterpart. */
 int eegldm_debug_reload_env(void);
+/* EEGLDM_DETERMINISTIC=1 (environment variable, read like the developer switches; eegldm.set_deterministic() in the Python mirror):
+ * bit-reproducible losses, parameter gradients and optimiser steps run to run.  Every order-dependent reduction -- fp32 atomics of
+ * the bias / GroupNorm / thin-conv gradients and of the loss sums, fused column sums inside the weight-gradient GEMM, split-K without
+ * a workspace -- takes a written-partials + fixed-order-fold route; forward results are unchanged.  Reference counterpart:
+ * torch.use_deterministic_algorithms(True) around src/train_ldm.py / src/train_autoencoderkl.py (the reference itself does not set it). */
 
 /* ------------------------------------------------------------------ layout / packing */
 int eegldm_ncl_to_nlc(eegldm_ctx*, const float* src_ncl, void* dst_nlc, long ld_dst, int B, int C, int L, int dst_dtype);

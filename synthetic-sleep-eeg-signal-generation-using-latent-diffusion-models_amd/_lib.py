@@ -245,6 +245,18 @@ class Context:
 _default = {}
 
 
+def set_deterministic(on=True):
+    """Bit-reproducible train steps (EEGLDM_DETERMINISTIC): every order-dependent reduction of the library -- fp32 atomics of the bias /
+    GroupNorm / thin-conv gradients and of the loss sums, fused column sums inside the weight-gradient GEMM, split-K without a workspace --
+    takes a written-partials + fixed-order-fold route.  Same arithmetic up to summation order; a few per cent slower.  The reference's
+    counterpart is `torch.use_deterministic_algorithms(True)` around /root/reference/src/train_ldm.py / train_autoencoderkl.py."""
+    if on:
+        os.environ["EEGLDM_DETERMINISTIC"] = "1"
+    else:
+        os.environ.pop("EEGLDM_DETERMINISTIC", None)
+    lib.eegldm_debug_reload_env()
+
+
 def default_context(device=0):
     if device not in _default:
         _default[device] = Context(device)

@@ -12,6 +12,7 @@
 // in global memory, conv inputs that are GroupNorm+SiLU outputs are recomputed from it.  Parameter gradients are reduced inside
 // the workgroup and added to the flat gradient buffer with one atomic per parameter and window.
 #include "aekl_thin.h"
+#include "internal.h"
 
 #include <stdlib.h>
 
@@ -498,7 +499,8 @@ __device__ __forceinline__ Bufs make_bufs(char* smem, int maxt) {
 __global__ __launch_bounds__(NT) void thin_fwd_kernel(const ThinOp* ops, int nops, const int* __restrict__ tape_off, int tape_stride, int nstat,
                                                       int maxt, const float* P, const float* __restrict__ x, const float* __restrict__ eps,
                                                       float* __restrict__ recon, float* __restrict__ z_mu, float* __restrict__ z_sigma, float* __restrict__ kl,
-                                                      float* __restrict__ tape_all, float* __restrict__ stats_all, int lat, int Ll, float inv_B, int nparams, unsigned long long* __restrict__ prof) {
+                                                      float* __restrict__ tape_all, float* __restrict__ stats_all, int lat, int Ll, float inv_B, int nparams, unsigned long long* __restrict__ prof,
+                                                      int kl_stride) {      // deterministic mode: 1 = a KL partial per window (folded in order afterwards), else 0
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const Bufs B = make_bufs(smem, maxt);
   // the whole parameter set (934 values for [2,2,4]) is copied to LDS once: every micro-op starts by reading its weights, and a
@@ -531,7 +533,7 @@ __global__ __launch_bounds__(NT) void thin_fwd_kernel(const ThinOp* ops, int nop
       } break;
       case TF_HEADS:
         f_heads(o, P, B, tape, tape_off, eps ? eps + (size_t)b * lat * Ll : nullptr, z_mu ? z_mu + (size_t)b * lat * Ll : nullptr,
-                z_sigma ? z_sigma + (size_t)b * lat * Ll : nullptr, kl, inv_B);
+                z_sigma ? z_sigma + (size_t)b * lat * Ll : nullptr, kl ? kl + (size_t)b * kl_stride : nullptr, inv_B);
         break;
       case TF_STORE: {
         const float* S = B.b[o.src]; float* D = recon + (size_t)b * o.cin * o.Lin;
@@ -546,7 +548,8 @@ __global__ __launch_bounds__(NT) void thin_bwd_kernel(const ThinOp* ops, int nop
                                                       int maxt, const float* P, float* __restrict__ G, const float* __restrict__ d_recon,
                                                       const float* __restrict__ eps, float* __restrict__ dx_out, const float* __restrict__ tape_all,
                                                       const float* __restrict__ stats_all, int lat, int Ll, float klw_over_B, int nparams, unsigned long long* __restrict__ prof,
-                                                      int sp_off, int nspare, const float* __restrict__ dmu_ext, const float* __restrict__ dsg_ext) {
+                                                      int sp_off, int nspare, const float* __restrict__ dmu_ext, const float* __restrict__ dsg_ext,
+                                                      int g_stride) {       // deterministic mode: nparams = a gradient row per window (zeroed, folded in order afterwards), else 0
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const Bufs B = make_bufs(smem, maxt);
   float* PL = B.red + RED_FLOATS;
@@ -652,7 +655,7 @@ __global__ __launch_bounds__(NT) void thin_bwd_kernel(const ThinOp* ops, int nop
     if (prof && blockIdx.x == 0 && threadIdx.x == 0) prof[i] = __builtin_readcyclecounter() - t0;
   }
   lds_barrier();
-  for (int j = threadIdx.x; j < nparams; j += NT) atomicAdd(Gglobal + j, GL[j]);
+  for (int j = threadIdx.x; j < nparams; j += NT) atomicAdd(Gglobal + (size_t)blockIdx.x * g_stride + j, GL[j]);
 }
 
 size_t lds_bytes(const ThinProgram& p) {
@@ -713,9 +716,15 @@ int thin_forward(eegldm_ctx* ctx, const ThinProgram& p, const float* params, con
                  float* z_sigma, float* kl, int B) {
   EEG_CHECK(p.d_fwd && p.tape && p.stats, "thin program not prepared");
   unsigned long long* prof = prof_buf();
+  float* kl_dst = kl; int kl_stride = 0;
+  if (kl && eeg_deterministic()) {
+    EEG_TRY(eeg_det_buffer(ctx, (size_t)B * sizeof(float), &kl_dst)); kl_stride = 1;
+    HIP_TRY(hipMemsetAsync(kl_dst, 0, (size_t)B * sizeof(float), ctx->stream));
+  }
   hipLaunchKernelGGL(thin_fwd_kernel, dim3(B), dim3(NT), lds_bytes(p), ctx->stream, p.d_fwd, (int)p.fwd.size(), p.d_tape_off, p.tape_stride, p.nstat, p.maxt,
-                     params, x, eps, recon, z_mu, z_sigma, kl, p.tape, p.stats, p.lat, p.Ll, 1.0f / (float)B, p.nparams, prof);
+                     params, x, eps, recon, z_mu, z_sigma, kl_dst, p.tape, p.stats, p.lat, p.Ll, 1.0f / (float)B, p.nparams, prof, kl_stride);
   LAUNCH_CHECK();
+  if (kl_stride) EEG_TRY(ew_fold_partials_det(ctx, kl_dst, B, 1, 0, 1, kl));
   if (prof) prof_dump(ctx, p.fwd, prof, "fwd");
   return 0;
 }
@@ -725,9 +734,15 @@ int thin_backward(eegldm_ctx* ctx, const ThinProgram& p, const float* params, fl
   unsigned long long* prof = prof_buf();
   int sp_off = 0, nspare = 0;
   const size_t lds = lds_bytes_bwd(p, &sp_off, &nspare);
+  float* g_dst = grads; int g_stride = 0;
+  if (eeg_deterministic()) {
+    EEG_TRY(eeg_det_buffer(ctx, (size_t)B * p.nparams * sizeof(float), &g_dst)); g_stride = p.nparams;
+    HIP_TRY(hipMemsetAsync(g_dst, 0, (size_t)B * p.nparams * sizeof(float), ctx->stream));
+  }
   hipLaunchKernelGGL(thin_bwd_kernel, dim3(B), dim3(NT), lds, ctx->stream, p.d_bwd, (int)p.bwd.size(), p.d_tape_off, p.tape_stride, p.nstat, p.maxt,
-                     params, grads, d_recon, eps, dx, p.tape, p.stats, p.lat, p.Ll, klw_over_B, p.nparams, prof, sp_off, nspare, dmu_ext, dsg_ext);
+                     params, g_dst, d_recon, eps, dx, p.tape, p.stats, p.lat, p.Ll, klw_over_B, p.nparams, prof, sp_off, nspare, dmu_ext, dsg_ext, g_stride);
   LAUNCH_CHECK();
+  if (g_stride) EEG_TRY(ew_fold_partials_det(ctx, g_dst, B, p.nparams, 0, p.nparams, grads));
   if (prof) prof_dump(ctx, p.bwd, prof, "bwd");
   return 0;
 }

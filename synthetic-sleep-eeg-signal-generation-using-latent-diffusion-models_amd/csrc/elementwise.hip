@@ -319,7 +319,7 @@ __global__ void ddpm_step_kernel(const float* __restrict__ mo, const float* __re
 
 // ------------------------------------------------------------------ MSE (training.py:437)
 __global__ __launch_bounds__(NT) void mse_kernel(const float* __restrict__ p, const float* __restrict__ t, float* __restrict__ loss,
-                                                 float* __restrict__ dp, long n, float inv_n, float gscale) {
+                                                 float* __restrict__ dp, long n, float inv_n, float gscale, float* __restrict__ parts) {
   float s = 0.f;
   GRID_STRIDE(i, n) {
     const float d = p[i] - t[i];
@@ -330,7 +330,7 @@ __global__ __launch_bounds__(NT) void mse_kernel(const float* __restrict__ p, co
   __shared__ float red[4];
   if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
   __syncthreads();
-  if (threadIdx.x == 0) atomicAdd(loss, (red[0] + red[1] + red[2] + red[3]) * inv_n);
+  if (threadIdx.x == 0) { const float v = (red[0] + red[1] + red[2] + red[3]) * inv_n; if (parts) parts[blockIdx.x] = v; else atomicAdd(loss, v); }
 }
 
 // ------------------------------------------------------------------ Adam (torch.optim.Adam defaults, train_ldm.py:208)
@@ -417,28 +417,35 @@ __global__ __launch_bounds__(NT) void colsum_det_kernel(const T* __restrict__ x,
   for (int l = l0; l < l1; l++) s += ld_f32(x + ((long)b * L + l) * ldx + c);
   parts[((long)b * gridDim.x + blockIdx.x) * C + c] = s;
 }
-__global__ __launch_bounds__(NT) void colsum_det_fold_kernel(const float* __restrict__ parts, int B, int nseg, int C, float* __restrict__ out_ps, long ldo,
-                                                             float* __restrict__ total) {
-  const int c = blockIdx.x * NT + threadIdx.x;
+// out_ps[b][c] = sum over the nseg partial rows of sample b, in segment order (thread = (sample, channel))
+__global__ __launch_bounds__(NT) void colsum_det_ps_kernel(const float* __restrict__ parts, int nseg, int C, float* __restrict__ out_ps, long ldo) {
+  const int c = blockIdx.x * NT + threadIdx.x, b = blockIdx.y;
   if (c >= C) return;
-  double t = 0.0;
-  for (int b = 0; b < B; b++) {
-    double s = 0.0;
-    for (int g = 0; g < nseg; g++) s += (double)parts[((long)b * nseg + g) * C + c];
-    if (out_ps) out_ps[(long)b * ldo + c] = (float)s;
-    t += s;
-  }
-  if (total) total[c] += (float)t;
-}
-__global__ __launch_bounds__(NT) void fold_partials_det_kernel(const float* __restrict__ parts, int nparts, long stride, int off, int n, float* __restrict__ total) {
-  const int i = blockIdx.x * NT + threadIdx.x;
-  if (i >= n) return;
   double s = 0.0;
-  for (int p = 0; p < nparts; p++) s += (double)parts[(long)p * stride + off + i];
-  total[i] += (float)s;
+  for (int g = 0; g < nseg; g++) s += (double)parts[((long)b * nseg + g) * C + c];
+  out_ps[(long)b * ldo + c] = (float)s;
+}
+// total[i] += sum_p parts[p * stride + off + i] with a FIXED two-level shape: 16 lanes per element, lane q adds the rows q, q + 16, ... in
+// order (fp64), then the 16 lane sums are added in lane order.  A block serves 16 elements; the result does not depend on timing.
+__global__ __launch_bounds__(NT) void fold_partials_det_kernel(const float* __restrict__ parts, int nparts, long stride, int off, int n, float* __restrict__ total) {
+  __shared__ double red[16][17];
+  const int e = threadIdx.x & 15, q = threadIdx.x >> 4, i = blockIdx.x * 16 + e;
+  double s = 0.0;
+  if (i < n) {
+#pragma unroll 4
+    for (int p = q; p < nparts; p += 16) s += (double)parts[(long)p * stride + off + i];
+  }
+  red[q][e] = s;
+  __syncthreads();
+  if (q == 0 && i < n) {
+    double t = 0.0;
+#pragma unroll
+    for (int k = 0; k < 16; k++) t += red[k][e];
+    total[i] += (float)t;
+  }
 }
 int ew_fold_partials_det(eegldm_ctx* ctx, const float* parts, int nparts, long stride, int off, int n, float* total) {
-  hipLaunchKernelGGL(fold_partials_det_kernel, dim3((n + NT - 1) / NT), dim3(NT), 0, ctx->stream, parts, nparts, stride, off, n, total);
+  hipLaunchKernelGGL(fold_partials_det_kernel, dim3((n + 15) / 16), dim3(NT), 0, ctx->stream, parts, nparts, stride, off, n, total);
   LAUNCH_CHECK(); return 0;
 }
 int ew_colsum(eegldm_ctx* ctx, const void* x, long ldx, float* out_ps, long ldo, float* total, int B, int L, int C, int dtype) {
@@ -449,8 +456,12 @@ int ew_colsum(eegldm_ctx* ctx, const void* x, long ldx, float* out_ps, long ldo,
     const dim3 grid((unsigned)nseg, (unsigned)B, (unsigned)((C + NT - 1) / NT));
     DISPATCH_T(dtype, hipLaunchKernelGGL((colsum_det_kernel<T>), grid, dim3(NT), 0, ctx->stream, (const T*)x, ldx, parts, L, C, rps));
     LAUNCH_CHECK();
-    hipLaunchKernelGGL(colsum_det_fold_kernel, dim3((C + NT - 1) / NT), dim3(NT), 0, ctx->stream, parts, B, (int)nseg, C, out_ps, ldo, total);
-    LAUNCH_CHECK(); return 0;
+    if (out_ps) {
+      hipLaunchKernelGGL(colsum_det_ps_kernel, dim3((C + NT - 1) / NT, B), dim3(NT), 0, ctx->stream, parts, (int)nseg, C, out_ps, ldo);
+      LAUNCH_CHECK();
+      if (total) EEG_TRY(ew_fold_partials_det(ctx, out_ps, B, ldo, 0, C, total));
+    } else if (total) EEG_TRY(ew_fold_partials_det(ctx, parts, (int)(B * nseg), C, 0, C, total));
+    return 0;
   }
   int lsplit = 1, rpb = L;
   if (!out_ps) {  // free to split L when only the fp32 atomic total is wanted
@@ -643,9 +654,14 @@ extern "C" int eegldm_ddpm_step(eegldm_ctx* ctx, const float* mo, const float* x
 }
 extern "C" int eegldm_mse_loss(eegldm_ctx* ctx, const float* p, const float* t, float* loss, float* dp, long n, float gscale) {
   HIP_TRY(hipMemsetAsync(loss, 0, sizeof(float), ctx->stream));
-  // (deterministic mode: ONE block, so the loss is one fixed-order sum instead of a race of per-block atomics)
-  hipLaunchKernelGGL(mse_kernel, dim3(eeg_deterministic() ? 1 : grid1d(n, ctx, 4)), dim3(NT), 0, ctx->stream, p, t, loss, dp, n, 1.0f / (float)n, gscale);
-  LAUNCH_CHECK(); return 0;
+  // (deterministic mode: a written partial per block and an ordered fold instead of a race of per-block atomics)
+  const int nb = grid1d(n, ctx, 4);
+  float* parts = nullptr;
+  if (eeg_deterministic()) EEG_TRY(eeg_det_buffer(ctx, (size_t)nb * sizeof(float), &parts));
+  hipLaunchKernelGGL(mse_kernel, dim3(nb), dim3(NT), 0, ctx->stream, p, t, loss, dp, n, 1.0f / (float)n, gscale, parts);
+  LAUNCH_CHECK();
+  if (parts) EEG_TRY(ew_fold_partials_det(ctx, parts, nb, 1, 0, 1, loss));
+  return 0;
 }
 extern "C" int eegldm_adam_step(eegldm_ctx* ctx, float* p, const float* g, float* m, float* v, long n, float lr, float b1, float b2,
                                 float eps, int step, float ginv) {

@@ -1228,9 +1228,12 @@ int gemm_launch(eegldm_ctx* ctx, const GemmArgs& a_in) {
   // (profiles/r01_gemm_stage_timing.txt); the fused 3-tap kernel keeps its register atomics (three accumulator sets).
   float* fold_dst = nullptr; long fold_n = 0;
   EEG_ENV_VAR(bool, fused_ws, getenv("EEGLDM_GEMM_FUSED3_ATOMIC") == nullptr);   // fused 3-tap kernel: workspace partials (plain stores from the accumulators) + fold; =1 restores the register atomics
-  if (a.splitk > 1 && a.amode == GA_TR && a.bmode == GB_TR && (a.taps == 1 || (a.taps == 3 && a.sCt == (long)a.M * a.N && fused_ws)) && a.ztaps == 1 && a.batch == 1 && a.atomic_out && a.ldc == a.N &&
+  // (deterministic mode: also the tap-by-tap weight gradients of strided convs, ztaps > 1 with contiguous taps -- their atomics are the only
+  // other split-K route, and a single split is one block per tile walking all of B x L)
+  const bool det_zt = eeg_deterministic() && a.ztaps > 1 && a.taps == 1 && a.sCt == (long)a.M * a.N;
+  if (a.splitk > 1 && a.amode == GA_TR && a.bmode == GB_TR && (a.taps == 1 || (a.taps == 3 && a.sCt == (long)a.M * a.N && fused_ws)) && (a.ztaps == 1 || det_zt) && a.batch == 1 && a.atomic_out && a.ldc == a.N &&
       !getenv("EEGLDM_GEMM_NO_SPLITK_WS")) {
-    const size_t need = (size_t)a.splitk * a.taps * a.M * a.N * sizeof(float);
+    const size_t need = (size_t)a.splitk * a.taps * a.ztaps * a.M * a.N * sizeof(float);
     if (need <= (size_t)512 << 20) {
       if (ctx->splitk_ws_bytes < need) {
         if (ctx->splitk_ws) { HIP_TRY(hipStreamSynchronize(ctx->stream)); HIP_TRY(hipFree(ctx->splitk_ws)); ctx->splitk_ws = nullptr; ctx->splitk_ws_bytes = 0; }
@@ -1240,8 +1243,9 @@ int gemm_launch(eegldm_ctx* ctx, const GemmArgs& a_in) {
       const int KST = 2 * (a.dtype == EEGLDM_F32 ? 16 : 32);
       int per = (a.K + a.splitk - 1) / a.splitk; per = (per + KST - 1) / KST * KST;
       a.splitk = (a.K + per - 1) / per;
-      fold_dst = (float*)a.C; fold_n = (long)a.taps * a.M * a.N;
+      fold_dst = (float*)a.C; fold_n = (long)a.taps * a.ztaps * a.M * a.N;
       a.C = ctx->splitk_ws; a.sCk = fold_n; a.atomic_out = 0;
+      if (det_zt) HIP_TRY(hipMemsetAsync(ctx->splitk_ws, 0, (size_t)a.splitk * fold_n * sizeof(float), ctx->stream));      // (edge tiles of a strided map: nothing unwritten is ever folded)
     }
   }
   if (a.splitk > 1 && !fold_dst && eeg_deterministic()) a.splitk = 1;      // no workspace route for this product: one writer per output element instead of racing K splits

@@ -199,6 +199,26 @@ __global__ void bn_fold_kernel(const float* __restrict__ parts, int nparts, int 
   __syncthreads();
   if (seg == 0 && i < n2c) atomicAdd(&sums[i], red[threadIdx.x] + red[threadIdx.x + 64] + red[threadIdx.x + 128] + red[threadIdx.x + 192]);
 }
+// deterministic mode: the same fold with a fixed two-level shape (16 lanes per element add the rows q, q + 16, ... in order, then the lane
+// sums in lane order) and no atomics -- fp64 sums of fp32 partials are order-independent only as long as nothing is rounded
+__global__ __launch_bounds__(NT) void bn_fold_det_kernel(const float* __restrict__ parts, int nparts, int n2c, double* __restrict__ sums, double* __restrict__ zero_next, int n_zero) {
+  __shared__ double red[16][17];
+  for (int j = blockIdx.x * NT + threadIdx.x; j < n_zero; j += gridDim.x * NT) zero_next[j] = 0.0;
+  const int e = threadIdx.x & 15, q = threadIdx.x >> 4, i = blockIdx.x * 16 + e;
+  double s = 0.0;
+  if (i < n2c) {
+#pragma unroll 4
+    for (int r = q; r < nparts; r += 16) s += (double)parts[(size_t)r * n2c + i];
+  }
+  red[q][e] = s;
+  __syncthreads();
+  if (q == 0 && i < n2c) {
+    double t = 0.0;
+#pragma unroll
+    for (int k = 0; k < 16; k++) t += red[k][e];
+    sums[i] = t;
+  }
+}
 // MODE 0: y = lrelu(bn(x));  MODE 1: dx of the same (sums = per-channel S1, S2)
 template <typename T, int MODE>
 __global__ __launch_bounds__(NT) void bn_apply4_kernel(const T* __restrict__ x, long ldx, const float* __restrict__ gamma, const float* __restrict__ beta,
@@ -272,7 +292,7 @@ __global__ void upsample2_bwd_kernel(const T* __restrict__ dy, long lddy, T* __r
 // accumulates KL = 0.5 * sum(mu^2 + sigma^2 - log sigma^2 - 1) / B into *kl.
 template <typename T>
 __global__ __launch_bounds__(NT) void reparam_kernel(const T* __restrict__ mu, const T* __restrict__ lv, const float* __restrict__ eps,
-                                                     T* __restrict__ z, float* __restrict__ sigma, float* __restrict__ kl, long n, float inv_B) {
+                                                     T* __restrict__ z, float* __restrict__ sigma, float* __restrict__ kl, long n, float inv_B, float* __restrict__ parts) {
   float s = 0.f;
   GRID_STRIDE(i, n) {
     const float m = ld_f32(mu + i);
@@ -287,7 +307,7 @@ __global__ __launch_bounds__(NT) void reparam_kernel(const T* __restrict__ mu, c
     __shared__ float red[4];
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
     __syncthreads();
-    if (threadIdx.x == 0) atomicAdd(kl, (red[0] + red[1] + red[2] + red[3]) * inv_B);
+    if (threadIdx.x == 0) { const float v = (red[0] + red[1] + red[2] + red[3]) * inv_B; if (parts) parts[blockIdx.x] = v; else atomicAdd(kl, v); }
   }
 }
 // dmu = dz + klw*mu/B [+ dmu_ext] ; dlv = [ -30 < lv < 20 ] * (dz*eps + klw*(sigma - 1/sigma)/B [+ dsigma_ext]) * sigma/2
@@ -315,7 +335,7 @@ __global__ void reparam_bwd_kernel(const T* __restrict__ mu, const T* __restrict
 // ------------------------------------------------------------------ losses on fp32 NCL tensors
 // L1: loss += w_loss * mean|a-b| ; da += w_grad * sign(a-b)/n
 __global__ __launch_bounds__(NT) void l1_kernel(const float* __restrict__ a, const float* __restrict__ b, float* __restrict__ loss,
-                                                float* __restrict__ da, long n, float inv_n, float wgrad, int overwrite) {
+                                                float* __restrict__ da, long n, float inv_n, float wgrad, int overwrite, float* __restrict__ parts) {
   float s = 0.f;
   GRID_STRIDE(i, n) {
     const float d = a[i] - b[i];
@@ -326,11 +346,11 @@ __global__ __launch_bounds__(NT) void l1_kernel(const float* __restrict__ a, con
   __shared__ float red[4];
   if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
   __syncthreads();
-  if (threadIdx.x == 0) atomicAdd(loss, (red[0] + red[1] + red[2] + red[3]) * inv_n);
+  if (threadIdx.x == 0) { const float v = (red[0] + red[1] + red[2] + red[3]) * inv_n; if (parts) parts[blockIdx.x] = v; else atomicAdd(loss, v); }
 }
 // least-squares GAN: a = lrelu(logit, 0.05); loss = mean((a - target)^2); dlogit = w * 2(a-target)/n * lrelu'
 __global__ __launch_bounds__(NT) void lsgan_kernel(const float* __restrict__ lg, float target, float* __restrict__ loss, float* __restrict__ dlg,
-                                                   long n, float inv_n, float wgrad) {
+                                                   long n, float inv_n, float wgrad, float* __restrict__ parts) {
   float s = 0.f;
   GRID_STRIDE(i, n) {
     const float x = lg[i], a = x > 0.f ? x : 0.05f * x, d = a - target;
@@ -341,13 +361,14 @@ __global__ __launch_bounds__(NT) void lsgan_kernel(const float* __restrict__ lg,
   __shared__ float red[4];
   if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
   __syncthreads();
-  if (threadIdx.x == 0) atomicAdd(loss, (red[0] + red[1] + red[2] + red[3]) * inv_n);
+  if (threadIdx.x == 0) { const float v = (red[0] + red[1] + red[2] + red[3]) * inv_n; if (parts) parts[blockIdx.x] = v; else atomicAdd(loss, v); }
 }
 __global__ void axpy_kernel(float* __restrict__ y, const float* __restrict__ x, float a, long n) { GRID_STRIDE(i, n) y[i] += a * x[i]; }
 
 inline void pick_rsplit(long rows, int C, eegldm_ctx* ctx, int* rsplit, long* rpb) {
   long want = ((long)ctx->num_cu * 8) / ((C + 63) / 64); if (want < 1) want = 1;
   long maxs = (rows + 63) / 64; if (want > maxs) want = maxs;
+  if (eeg_deterministic()) want = 1;      // the row splits add with fp64 atomics: one split = one writer per channel
   *rpb = (rows + want - 1) / want; *rsplit = (int)((rows + *rpb - 1) / *rpb);
 }
 }  // namespace
@@ -370,7 +391,10 @@ static double* bn_area(eegldm_ctx* ctx, int i) { return (double*)((char*)ctx->sc
 static int bn_fold_launch(eegldm_ctx* ctx, const void* parts, int nb, int C, double** sums_out) {
   const int cur = ctx->bn_flip, oth = cur ^ 1;
   double* sums = bn_area(ctx, cur);
-  hipLaunchKernelGGL(bn_fold_kernel, dim3((2 * C + 63) / 64, 32), dim3(NT), 0, ctx->stream, (const float*)parts, nb, 2 * C, sums, bn_area(ctx, oth), ctx->bn_dirty[oth]);
+  if (eeg_deterministic())
+    hipLaunchKernelGGL(bn_fold_det_kernel, dim3((2 * C + 15) / 16), dim3(NT), 0, ctx->stream, (const float*)parts, nb, 2 * C, sums, bn_area(ctx, oth), ctx->bn_dirty[oth]);
+  else
+    hipLaunchKernelGGL(bn_fold_kernel, dim3((2 * C + 63) / 64, 32), dim3(NT), 0, ctx->stream, (const float*)parts, nb, 2 * C, sums, bn_area(ctx, oth), ctx->bn_dirty[oth]);
   LAUNCH_CHECK();
   ctx->bn_dirty[cur] = 2 * C; ctx->bn_dirty[oth] = 0; ctx->bn_flip = oth;
   *sums_out = sums;
@@ -452,8 +476,13 @@ int ls_upsample2_bwd(eegldm_ctx* ctx, const void* dy, long lddy, void* dx, long 
   LAUNCH_CHECK(); return 0;
 }
 int ls_reparam(eegldm_ctx* ctx, const void* mu, const void* lv, const float* eps, void* z, float* sigma, float* kl, long n, int B, int dtype) {
-  DISPATCH_T(dtype, hipLaunchKernelGGL((reparam_kernel<T>), dim3(grid1d(n, ctx)), dim3(NT), 0, ctx->stream, (const T*)mu, (const T*)lv, eps, (T*)z, sigma, kl, n, 1.0f / (float)B));
-  LAUNCH_CHECK(); return 0;
+  const int nb = grid1d(n, ctx);
+  float* parts = nullptr;      // deterministic mode: a KL partial per block + an ordered fold
+  if (kl && eeg_deterministic()) EEG_TRY(eeg_det_buffer(ctx, (size_t)nb * sizeof(float), &parts));
+  DISPATCH_T(dtype, hipLaunchKernelGGL((reparam_kernel<T>), dim3(nb), dim3(NT), 0, ctx->stream, (const T*)mu, (const T*)lv, eps, (T*)z, sigma, kl, n, 1.0f / (float)B, parts));
+  LAUNCH_CHECK();
+  if (parts) EEG_TRY(ew_fold_partials_det(ctx, parts, nb, 1, 0, 1, kl));
+  return 0;
 }
 int ls_reparam_bwd(eegldm_ctx* ctx, const void* mu, const void* lv, const float* eps, const float* sigma, const void* dz, void* dmu, void* dlv, long n,
                    float klw_over_B, int dtype, const float* dmu_ext, const float* dsg_ext, int lat, int Ll) {
@@ -466,14 +495,24 @@ int ls_reparam_bwd(eegldm_ctx* ctx, const void* mu, const void* lv, const float*
 extern "C" int eegldm_l1_loss(eegldm_ctx* ctx, const float* a, const float* b, float* loss, float* da_accum, long n, float grad_weight) {
   EEG_CHECK(ctx && a && b && loss && n > 0, "bad argument");
   if (!ctx->loss_prezeroed) HIP_TRY(hipMemsetAsync(loss, 0, sizeof(float), ctx->stream));
-  hipLaunchKernelGGL(l1_kernel, dim3(grid1d(n / 4 + 1, ctx)), dim3(NT), 0, ctx->stream, a, b, loss, da_accum, n, 1.0f / (float)n, grad_weight, ctx->l1_overwrite ? 1 : 0);
-  LAUNCH_CHECK(); return 0;
+  const int nb = grid1d(n / 4 + 1, ctx);
+  float* parts = nullptr;
+  if (eeg_deterministic()) EEG_TRY(eeg_det_buffer(ctx, (size_t)nb * sizeof(float), &parts));
+  hipLaunchKernelGGL(l1_kernel, dim3(nb), dim3(NT), 0, ctx->stream, a, b, loss, da_accum, n, 1.0f / (float)n, grad_weight, ctx->l1_overwrite ? 1 : 0, parts);
+  LAUNCH_CHECK();
+  if (parts) EEG_TRY(ew_fold_partials_det(ctx, parts, nb, 1, 0, 1, loss));
+  return 0;
 }
 extern "C" int eegldm_lsgan_loss(eegldm_ctx* ctx, const float* logits, int target_is_real, float* loss, float* dlogits, long n, float grad_weight) {
   EEG_CHECK(ctx && logits && loss && n > 0, "bad argument");
   if (!ctx->loss_prezeroed) HIP_TRY(hipMemsetAsync(loss, 0, sizeof(float), ctx->stream));
-  hipLaunchKernelGGL(lsgan_kernel, dim3(grid1d(n, ctx)), dim3(NT), 0, ctx->stream, logits, target_is_real ? 1.0f : 0.0f, loss, dlogits, n, 1.0f / (float)n, grad_weight);
-  LAUNCH_CHECK(); return 0;
+  const int nb = grid1d(n, ctx);
+  float* parts = nullptr;
+  if (eeg_deterministic()) EEG_TRY(eeg_det_buffer(ctx, (size_t)nb * sizeof(float), &parts));
+  hipLaunchKernelGGL(lsgan_kernel, dim3(nb), dim3(NT), 0, ctx->stream, logits, target_is_real ? 1.0f : 0.0f, loss, dlogits, n, 1.0f / (float)n, grad_weight, parts);
+  LAUNCH_CHECK();
+  if (parts) EEG_TRY(ew_fold_partials_det(ctx, parts, nb, 1, 0, 1, loss));
+  return 0;
 }
 extern "C" int eegldm_axpy(eegldm_ctx* ctx, float* y, const float* x, float a, long n) {
   EEG_CHECK(ctx && y && x, "null argument");

@@ -1103,7 +1103,9 @@ int gn_bwd_t(eegldm_ctx* ctx, const void* x, long ldx, const float* gamma, const
           else { if (dxr) GN_BWD_PIPE(false, true); else GN_BWD_PIPE(false, false); }
 #undef GN_BWD_PIPE
           LAUNCH_CHECK();
-          if (slots && !defer) {
+          if (det) {
+            EEG_TRY(ew_fold_partials_det(ctx, slots, ndg, 2 * C, 0, C, dgamma)); EEG_TRY(ew_fold_partials_det(ctx, slots, ndg, 2 * C, C, C, dbeta));
+          } else if (slots && !defer) {
             hipLaunchKernelGGL(gn_slot_reduce_kernel, dim3((2 * C + 255) / 256), dim3(256), 0, ctx->stream, slots, dgamma, dbeta, C, (double*)ctx->scratch, 0, ndg);
             LAUNCH_CHECK();
           }
@@ -1164,7 +1166,9 @@ int gn_bwd_t(eegldm_ctx* ctx, const void* x, long ldx, const float* gamma, const
 #undef GN_BWD_RES2
 #undef GN_BWD_RES3
       LAUNCH_CHECK();
-      if (slots && !defer) {
+      if (det) {
+        EEG_TRY(ew_fold_partials_det(ctx, slots, nslot, 2 * C, 0, C, dgamma)); EEG_TRY(ew_fold_partials_det(ctx, slots, nslot, 2 * C, C, C, dbeta));
+      } else if (slots && !defer) {
         hipLaunchKernelGGL(gn_slot_reduce_kernel, dim3((2 * C + 255) / 256), dim3(256), 0, ctx->stream, slots, dgamma, dbeta, C, (double*)ctx->scratch, 0, nslot);
         LAUNCH_CHECK();
       }

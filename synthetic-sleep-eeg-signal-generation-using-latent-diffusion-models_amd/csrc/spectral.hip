@@ -16,6 +16,7 @@
 //      README.md:17 notes that instability.  Deviation stated in INTEGRATION.md, tested in tests/test_gpu_aekl.py).
 // HBM traffic = the two windows in, one gradient window out: HBM-bound, ~36 KB per window.
 #include "common.h"
+#include "internal.h"
 
 namespace {
 constexpr int NT = 256;
@@ -62,7 +63,7 @@ struct FFT {
 
 template <int N1, int N2>
 __global__ __launch_bounds__(NT) void spectral_kernel(const float* __restrict__ recon, const float* __restrict__ target, float* __restrict__ loss,
-                                                      float* __restrict__ drecon, float gweight) {
+                                                      float* __restrict__ drecon, float gweight, int loss_stride) {
   using F = FFT<N1, N2>;
   constexpr int N = F::N;
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -101,7 +102,7 @@ __global__ __launch_bounds__(NT) void spectral_kernel(const float* __restrict__ 
   __syncthreads();                       // red[] was read for zero_thr above
   if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = part;
   __syncthreads();
-  if (threadIdx.x == 0) atomicAdd(loss, red[0] + red[1] + red[2] + red[3]);
+  if (threadIdx.x == 0) atomicAdd(loss + (size_t)blockIdx.x * loss_stride, red[0] + red[1] + red[2] + red[3]);
   if (drecon) {
     F::run(bufA, bufX, bufY, tw);
     for (int n = threadIdx.x; n < N; n += NT) drecon[base + n] += gweight * scale * bufX[n].x;
@@ -114,8 +115,14 @@ int launch(eegldm_ctx* ctx, const float* recon, const float* target, float* loss
   constexpr int lds = FFT<N1, N2>::LDS_BYTES;
   static DevOnce attr;
   if (attr.need(ctx->device)) HIP_TRY(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-  hipLaunchKernelGGL(kern, dim3(B), dim3(NT), lds, ctx->stream, recon, target, loss, drecon, w);
+  float* dst = loss; int stride = 0;
+  if (eeg_deterministic()) {      // a partial per window (zeroed: one writer each), then the windows in order
+    EEG_TRY(eeg_det_buffer(ctx, (size_t)B * sizeof(float), &dst)); stride = 1;
+    HIP_TRY(hipMemsetAsync(dst, 0, (size_t)B * sizeof(float), ctx->stream));
+  }
+  hipLaunchKernelGGL(kern, dim3(B), dim3(NT), lds, ctx->stream, recon, target, dst, drecon, w, stride);
   LAUNCH_CHECK();
+  if (stride) EEG_TRY(ew_fold_partials_det(ctx, dst, B, 1, 0, 1, loss));
   return 0;
 }
 }  // namespace

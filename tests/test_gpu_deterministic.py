@@ -1,0 +1,111 @@
+"""EEGLDM_DETERMINISTIC=1: the train steps are bit-reproducible run to run (losses, every parameter gradient, parameters after Adam), and
+the ordered reductions compute the same numbers as the default (atomic) ones up to fp32 rounding.
+
+The steps are those of /root/reference/src/training/training.py:419-443 (LDM), src/train_autoencoderkl.py:203-234 (AEKL / GAN) and
+src/training/training_diffusion.py:141-151 (pixel-space model).  By default the engine's parameter gradients depend on the order of fp32
+atomics at ~2e-7 (bias column sums, GroupNorm slot sums beyond 64 samples, thin-conv weight gradients, loss sums); the deterministic mode
+routes each of them through written partials + a fixed-order fold."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+UCFG = dict(in_channels=1, out_channels=1, model_channels=128, num_res_blocks=2, attention_resolutions=[8, 4], channel_mult=[1, 2, 4], resblock_updown=True)
+
+
+def _ldm_setup(dtype, B, L):
+    from eegldm.models import UNetModel
+    from eegldm.schedulers import DDPMScheduler
+    net = UNetModel(image_size=L, dtype=dtype, **UCFG)
+    sd0 = {k: v.cpu().clone() for k, v in net.state_dict().items()}
+    g = torch.Generator().manual_seed(3)
+    sd0 = {k: (torch.randn(v.shape, generator=g) * 0.02 if float(v.abs().sum()) == 0 else v) for k, v in sd0.items()}
+    sched = DDPMScheduler(1000, schedule="scaled_linear_beta", beta_start=0.0015, beta_end=0.0195)
+    x = torch.randn(B, 1, L, generator=g).cuda(); nz = torch.randn(B, 1, L, generator=g).cuda(); t = torch.randint(0, 1000, (B,), generator=g).cuda()
+    return net, sd0, sched, x, nz, t
+
+
+def _ldm_runs(setup, steps, n_runs, pixel=False):
+    from eegldm.training import Adam, dm_train_step, ldm_train_step
+    net, sd0, sched, x, nz, t = setup
+    out = []
+    for _ in range(n_runs):
+        net.load_state_dict(sd0); opt = Adam(net, lr=1e-4); losses = []
+        for _s in range(steps):
+            net.zero_grad()
+            if pixel:
+                losses.append(float(dm_train_step(net, sched, x, nz, t, spectral_weight=1e-6, spectral_loss=True)))
+            else:
+                losses.append(float(ldm_train_step(net, sched, x, nz, t)))
+            opt.step()
+        torch.cuda.synchronize()
+        out.append((losses, net.flat_grad.clone(), net.flat.clone()))
+    return out
+
+
+def _aekl_runs(dtype, channels, B, steps, n_runs):
+    import eegldm
+    from eegldm.models import AutoencoderKL, PatchDiscriminator
+    from eegldm.training import Adam, aekl_train_step, randn
+    ctx = eegldm.default_context(0)
+    L = 3072
+    ae = AutoencoderKL(spatial_dims=1, in_channels=1, out_channels=1, num_channels=channels, latent_channels=1, num_res_blocks=2, norm_num_groups=1,
+                       attention_levels=[False, False, False], dtype=dtype, device=0)
+    disc = PatchDiscriminator(spatial_dims=1, num_layers_d=3, num_channels=64, in_channels=1, out_channels=1, kernel_size=3, norm="BATCH", bias=False, padding=1,
+                              dtype=dtype, device=0)
+    a0, d0 = {k: v.cpu().clone() for k, v in ae.state_dict().items()}, {k: v.cpu().clone() for k, v in disc.state_dict().items()}
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(B, 1, L, generator=g).cuda(); lo = torch.zeros(6, device="cuda")
+    out = []
+    for _ in range(n_runs):
+        ae.load_state_dict(a0); disc.load_state_dict(d0); og, od = Adam(ae, lr=5e-3), Adam(disc, lr=5e-4); hist = []
+        for i in range(steps):
+            eps = randn(ctx, (B, 1, L // 4), seed=5, offset=i * B * L)
+            ae.zero_grad(); disc.zero_grad()
+            aekl_train_step(ae, disc, x, eps, 0.01, 1e-9, 1e4, True, losses_out=lo)
+            hist.append(lo.cpu().clone()); og.step(); od.step()
+        torch.cuda.synchronize()
+        out.append((hist, ae.flat_grad.clone(), disc.flat_grad.clone(), ae.flat.clone(), disc.flat.clone()))
+    return out
+
+
+def _assert_identical(runs, what):
+    ref = runs[0]
+    for r in runs[1:]:
+        for i, (a, b) in enumerate(zip(ref, r)):
+            if isinstance(a, list):
+                same = all((torch.equal(p, q) if torch.is_tensor(p) else p == q) for p, q in zip(a, b))
+            else:
+                same = torch.equal(a, b)
+            assert same, f"{what}: output {i} differs between two runs of the deterministic mode"
+
+
+@pytest.mark.parametrize("dtype,B", [("float32", 16), ("bfloat16", 16), ("bfloat16", 128)])
+def test_ldm_step_is_bit_reproducible_and_equals_the_default_path(dtype, B, env_switches):
+    """B = 128 puts two samples into each of the default path's 64 GroupNorm slots (a slot per sample in the deterministic mode)."""
+    setup = _ldm_setup(dtype, B, 768)
+    env_switches(EEGLDM_DETERMINISTIC="1")
+    det = _ldm_runs(setup, 3, 3)
+    _assert_identical(det, f"LDM step {dtype} B={B}")
+    det1 = _ldm_runs(setup, 1, 1)[0]
+    env_switches(EEGLDM_DETERMINISTIC=None)
+    dflt = _ldm_runs(setup, 1, 1)[0]
+    # the same first-step loss and gradient up to the rounding of differently ordered fp32 sums
+    assert abs(det1[0][0] - dflt[0][0]) <= 2e-6 * abs(dflt[0][0])
+    scale = float(dflt[1].abs().max())
+    assert float((det1[1] - dflt[1]).abs().max()) <= 2e-5 * scale, "deterministic and default gradients differ by more than reduction-order rounding"
+
+
+@pytest.mark.parametrize("dtype,channels,B", [("float32", [2, 2, 4], 16), ("bfloat16", [2, 2, 4], 72), ("bfloat16", [32, 32, 64], 8), ("float32", [32, 32, 64], 4)])
+def test_aekl_gan_step_is_bit_reproducible(dtype, channels, B, env_switches):
+    """[2,2,4]: the whole-network kernels (a gradient row and a KL partial per window); [32,32,64]: the layer-by-layer autoencoder (flat GroupNorm
+    slots, thin-conv folds, GEMM weight gradients); both with the PatchDiscriminator (BatchNorm sums, edge-layer convs) and the spectral loss."""
+    env_switches(EEGLDM_DETERMINISTIC="1")
+    _assert_identical(_aekl_runs(dtype, channels, B, 3, 3), f"AEKL/GAN step {dtype} {channels} B={B}")
+
+
+def test_pixel_space_step_is_bit_reproducible(env_switches):
+    """config_dm.yaml UNet on raw windows: T = 768 attention (fused chain kernel in bf16), 1 x 1 skip convs at L = 3072, MSE + spectral term."""
+    env_switches(EEGLDM_DETERMINISTIC="1")
+    _assert_identical(_ldm_runs(_ldm_setup("bfloat16", 8, 3072), 2, 3, pixel=True), "pixel-space step bf16")
+    _assert_identical(_ldm_runs(_ldm_setup("float32", 2, 3072), 2, 2, pixel=True), "pixel-space step fp32")
