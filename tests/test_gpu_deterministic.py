@@ -101,7 +101,8 @@ def test_aekl_gan_step_is_bit_reproducible(dtype, channels, B, env_switches):
     """[2,2,4]: the whole-network kernels (a gradient row and a KL partial per window); [32,32,64]: the layer-by-layer autoencoder (flat GroupNorm
     slots, thin-conv folds, GEMM weight gradients); both with the PatchDiscriminator (BatchNorm sums, edge-layer convs) and the spectral loss."""
     env_switches(EEGLDM_DETERMINISTIC="1")
-    _assert_identical(_aekl_runs(dtype, channels, B, 3, 3), f"AEKL/GAN step {dtype} {channels} B={B}")
+    steps = 12 if (channels == [2, 2, 4] and dtype == "float32") else 3      # the GAN amplifies a last-bit difference within ~10 steps (DESIGN 6): 12 identical steps = none arose
+    _assert_identical(_aekl_runs(dtype, channels, B, steps, 3), f"AEKL/GAN step {dtype} {channels} B={B}")
 
 
 def test_pixel_space_step_is_bit_reproducible(env_switches):
