@@ -31,6 +31,8 @@ def parse_args(argv=None):
     # additions (not in the reference): synthetic data, engine dtype, short runs, output override
     p.add_argument("--synthetic_windows", type=int, default=0); p.add_argument("--dtype", default="float32")
     p.add_argument("--max_steps", type=int, default=0); p.add_argument("--output_dir", default=None)
+    p.add_argument("--deterministic", action="store_true", help="bit-reproducible steps (eegldm.set_deterministic(): ordered reductions instead of fp32 atomics; "
+                   "what torch.use_deterministic_algorithms(True) would be for the reference's loop)")
     return p.parse_args(argv)
 
 
@@ -38,6 +40,9 @@ LAST_RUN = {}      # what the most recent main() ended with (rank-local): read b
 
 
 def main(args):
+    if getattr(args, "deterministic", False):
+        from .._lib import set_deterministic
+        set_deterministic(True)
     rank, local, world = D.init_from_env()
     torch.cuda.set_device(local)
     config = load_config(args.config_file)

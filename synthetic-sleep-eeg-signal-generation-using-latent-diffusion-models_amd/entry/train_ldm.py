@@ -29,6 +29,8 @@ def parse_args(argv=None):
     p.add_argument("--schedule", default="linear_beta", choices=["linear_beta", "scaled_linear_beta"],
                    help="training noise schedule; the reference builds DDPMScheduler(beta_schedule='linear') = plain linspace (train_ldm.py:199-200)")
     p.add_argument("--grad_scaler", action="store_true", help="dynamic loss scaling as in the reference loop (training.py:334,441-443); bf16/fp32 do not need it")
+    p.add_argument("--deterministic", action="store_true", help="bit-reproducible steps (eegldm.set_deterministic(): ordered reductions instead of fp32 atomics; "
+                   "what torch.use_deterministic_algorithms(True) would be for the reference's loop)")
     return p.parse_args(argv)
 
 
@@ -62,6 +64,9 @@ LAST_RUN = {}      # what the most recent main() ended with (rank-local): read b
 
 
 def main(args):
+    if getattr(args, "deterministic", False):
+        from .._lib import set_deterministic
+        set_deterministic(True)
     rank, local, world = D.init_from_env()
     torch.cuda.set_device(local)
     config = load_config(args.config_file)
