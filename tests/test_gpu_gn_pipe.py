@@ -111,3 +111,38 @@ def test_pipelined_groupnorm_backward_is_the_default_at_production_shapes(env_sw
         dx_r, dga_r, _ = _run(G, c, xd, gad, bed, st, dyd, dxrd, B, L, Cc, 1)
         _same_up_to_rounding_flips(dx_p, dx_r)
         assert float((dga_p - dga_r).abs().max()) <= 2e-5 * max(1.0, float(dga_r.abs().max()))
+
+
+def test_pipelined_groupnorm_backward_on_column_views_of_wider_buffers(env_switches):
+    """The UNet hands GroupNorm column ranges of wider tensors (concatenations are views: DESIGN 2): x, dy, dx and the addend with leading
+    dimensions larger than C and a non-zero column origin."""
+    G = _imports()
+    c = G.ctx()
+    B, L, Cc, pad = 16, 384, 256, 64
+    g = torch.Generator(device="cuda").manual_seed(7)
+    wide = lambda: torch.randn(B * L, Cc + 2 * pad, device=G.DEV, generator=g).bfloat16()
+    xw, dyw, ew, dxw_p, dxw_r = wide(), wide(), wide(), wide(), None
+    dxw_r = dxw_p.clone()
+    col = slice(pad, pad + Cc); ld = Cc + 2 * pad
+    gad = 1 + 0.1 * torch.randn(Cc, device=G.DEV, generator=g); bed = 0.1 * torch.randn(Cc, device=G.DEV, generator=g)
+    st = torch.empty(B * 32 * 2, device=G.DEV); yd = torch.empty(B * L, Cc, device=G.DEV, dtype=torch.bfloat16)
+    G.check(G.lib.eegldm_groupnorm_fwd(c.h, G.ptr(xw[:, col]), ld, G.ptr(gad), G.ptr(bed), G.ptr(yd), Cc, G.ptr(st), B, L, Cc, 32, 1e-6, 1, 0, None, 0, G.BF16))
+
+    def run(dxw, with_e):
+        dga = torch.zeros(Cc, device=G.DEV); dbe = torch.zeros(Cc, device=G.DEV)
+        G.check(G.lib.eegldm_groupnorm_bwd(c.h, G.ptr(xw[:, col]), ld, G.ptr(gad), G.ptr(bed), G.ptr(st), G.ptr(dyw[:, col]), ld, G.ptr(dxw[:, col]), ld,
+                                           G.ptr(dga), G.ptr(dbe), B, L, Cc, 32, 1, 0, G.ptr(ew[:, col]) if with_e else None, ld, G.BF16))
+        torch.cuda.synchronize()
+        return dga, dbe
+
+    for with_e in (False, True):
+        env_switches(EEGLDM_GN_PIPE_MIN_SLABS="1", EEGLDM_GN_PIPE_MAX_SLOT="1", EEGLDM_GN_PIPE_ADDEND="1", EEGLDM_GN_NO_PIPE=None)
+        before = dxw_p.clone()
+        dga_p, dbe_p = run(dxw_p, with_e)
+        env_switches(EEGLDM_GN_NO_PIPE="1")
+        dga_r, dbe_r = run(dxw_r, with_e)
+        _same_up_to_rounding_flips(dxw_p[:, col].contiguous(), dxw_r[:, col].contiguous())
+        # nothing outside the column range was touched
+        assert torch.equal(dxw_p[:, :pad], before[:, :pad]) and torch.equal(dxw_p[:, pad + Cc:], before[:, pad + Cc:])
+        assert float((dga_p - dga_r).abs().max()) <= 2e-5 * max(1.0, float(dga_r.abs().max()))
+        assert float((dbe_p - dbe_r).abs().max()) <= 2e-5 * max(1.0, float(dbe_r.abs().max()))
