@@ -111,7 +111,7 @@ int ctx_join(eegldm_ctx* c);
 // RAII: launches inside the scope go to the side stream (pure GEMM work only: the context scratch belongs to the main stream)
 struct SideScope {
   eegldm_ctx* c; hipStream_t saved;
-  explicit SideScope(eegldm_ctx* ctx) : c(ctx), saved(ctx->stream) { if (c->side_on && !c->prof_on && !c->defer_wgrad) c->stream = c->side; }   // serial while kernels are being timed / in the grouped-weight-gradient mode
+  explicit SideScope(eegldm_ctx* ctx) : c(ctx), saved(ctx->stream) { if (c->side_on && !c->prof_on && !c->defer_wgrad && !eeg_deterministic()) c->stream = c->side; }   // serial while kernels are being timed / in the grouped-weight-gradient mode / in the deterministic mode (its partial-sum buffer belongs to one stream)
   ~SideScope() { c->stream = saved; }
 };
 
