@@ -10,7 +10,13 @@ SRCS  := $(wildcard $(CSRC)/*.hip)
 OBJS  := $(patsubst $(CSRC)/%.hip,$(CSRC)/build/%.o,$(SRCS))
 LIB   := $(PKG)/libeegldm.so
 
-all: $(LIB)
+# test infrastructure (NOT linked into the product): call-recording librccl stand-in for tests/test_gpu_comm_fake.py
+FAKE  := tests/fake_rccl/libfake_rccl.so
+
+all: $(LIB) $(FAKE)
+
+$(FAKE): tests/fake_rccl/fake_rccl.hip
+	$(HIPCC) --offload-arch=gfx950 -O2 -std=c++17 -fPIC -shared $< -o $@
 
 $(CSRC)/build/%.o: $(CSRC)/%.hip $(wildcard $(CSRC)/*.h) include/eegldm.h
 	@mkdir -p $(CSRC)/build
@@ -26,5 +32,5 @@ dbg:
 	$(HIPCC) --offload-arch=gfx950 -shared -fPIC $(CSRC)/build_dbg/*.o -o tools/debug/libeegldm_dbg.so
 
 clean:
-	rm -rf $(CSRC)/build $(CSRC)/build_dbg $(LIB)
+	rm -rf $(CSRC)/build $(CSRC)/build_dbg $(LIB) $(FAKE)
 .PHONY: all clean dbg

@@ -70,6 +70,14 @@ class FlatModule:
         elif p.grad.data_ptr() != self.flat_grad.data_ptr():
             raise RuntimeError("the flat parameter's .grad was replaced by another tensor; the native backward accumulates into model.flat_grad")
 
+    def _bump_tape(self):
+        """Every native entry that rewrites or consumes the executor's single tape calls this (forward in any mode, encode / decode,
+        the fused train steps, the sampler, backward): a bridge backward whose forward is no longer the latest one then sees a different
+        id and re-runs its forward first -- also when the intervening call never went through a torch.autograd.Function (a validation
+        forward under no_grad, an eval-mode call, a fused step)."""
+        self._tape_id = getattr(self, "_tape_id", 0) + 1
+        return self._tape_id
+
     def _wants_graph(self, *tensors):
         if not torch.is_grad_enabled():
             return False
@@ -81,8 +89,7 @@ class FlatModule:
 class _UNetFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, net, x, t, _p):
-        out = net._forward_native(x, t)
-        net._tape_id = getattr(net, "_tape_id", 0) + 1
+        out = net._forward_native(x, t)                 # (bumps net._tape_id)
         ctx.net, ctx.tape = net, net._tape_id
         ctx.save_for_backward(x, t)
         return out
@@ -91,12 +98,10 @@ class _UNetFn(torch.autograd.Function):
     def backward(ctx, dy):
         net = ctx.net
         x, t = ctx.saved_tensors
-        if net._tape_id != ctx.tape:             # another forward ran since: rebuild this call's tape
+        if net._tape_id != ctx.tape:             # another native call rewrote the tape since: rebuild this call's tape
             net._forward_native(x, t)
-            net._tape_id += 1
         net._adopt_grad()
-        dx = net.backward(dy.contiguous(), need_dx=ctx.needs_input_grad[1])
-        net._tape_id += 1                        # the tape is consumed
+        dx = net.backward(dy.contiguous(), need_dx=ctx.needs_input_grad[1])      # (bumps: the tape is consumed)
         return None, dx, None, None
 
 
@@ -105,7 +110,6 @@ class _AeklFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, net, x, eps, _p):
         recon, mu, sg = net._forward_native(x, eps)
-        net._tape_id = getattr(net, "_tape_id", 0) + 1
         ctx.net, ctx.tape = net, net._tape_id
         ctx.save_for_backward(x, eps)
         return recon, mu, sg
@@ -116,7 +120,6 @@ class _AeklFn(torch.autograd.Function):
         x, eps = ctx.saved_tensors
         if net._tape_id != ctx.tape:
             net._forward_native(x, eps)
-            net._tape_id += 1
         net._adopt_grad()
         dev = net.device
         f = lambda g: None if g is None else g.to(dev, torch.float32).contiguous()
@@ -124,7 +127,7 @@ class _AeklFn(torch.autograd.Function):
         d_mu, d_sigma = f(d_mu), f(d_sigma)
         dx = torch.empty_like(x) if ctx.needs_input_grad[1] else None
         check(lib.eegldm_aekl_backward_ex(net.h, ptr(d_recon), ptr(d_mu), ptr(d_sigma), 0.0, ptr(dx)))
-        net._tape_id += 1
+        net._bump_tape()
         return None, dx, None, None
 
 
@@ -133,7 +136,6 @@ class _DiscFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, net, x, _p):
         logits = net._forward_native(x, 1 if net.training else 0)
-        net._tape_id = getattr(net, "_tape_id", 0) + 1
         ctx.net, ctx.tape, ctx.was_training = net, net._tape_id, net.training
         ctx.save_for_backward(x)
         return logits
@@ -144,11 +146,9 @@ class _DiscFn(torch.autograd.Function):
         (x,) = ctx.saved_tensors
         if net._tape_id != ctx.tape:             # e.g. D(fake) then D(real) before loss_d.backward(): re-forward, running statistics untouched
             net._forward_native(x, 2 if ctx.was_training else 0)
-            net._tape_id += 1
         net._adopt_grad()
         p = net._flat_param()
         dx = net.backward(dlogits.contiguous(), need_dx=ctx.needs_input_grad[1], param_grads=p.requires_grad, in_shape=tuple(x.shape))
-        net._tape_id += 1
         return None, dx, None
 
 

@@ -9,8 +9,8 @@ void eegldm_set_error(const std::string& msg) { g_err = msg; }
 struct TimerState { hipEvent_t a = nullptr, b = nullptr; };
 static thread_local TimerState g_timer;
 
-int g_eeg_env_epoch = 0;
-int g_eeg_live_ctx = 0;
+std::atomic<int> g_eeg_env_epoch{0};
+std::atomic<int> g_eeg_live_ctx{0};
 extern "C" int eegldm_abi_version(void) { return EEGLDM_ABI_VERSION; }
 int eeg_det_buffer(eegldm_ctx* ctx, size_t bytes, float** out) {
   if (ctx->det_buf_bytes < bytes) {
@@ -90,7 +90,7 @@ extern "C" int eegldm_ctx_destroy(eegldm_ctx* c) {
   if (c->owns_stream) hipStreamDestroy(c->stream);
   if (c->side) { hipStreamDestroy(c->side); hipEventDestroy(c->ev_fork); hipEventDestroy(c->ev_join); }
   delete c;
-  if (g_eeg_live_ctx > 0) g_eeg_live_ctx--;
+  if (g_eeg_live_ctx.load() > 0) g_eeg_live_ctx--;
   return 0;
 }
 extern "C" int eegldm_ctx_sync(eegldm_ctx* c) {

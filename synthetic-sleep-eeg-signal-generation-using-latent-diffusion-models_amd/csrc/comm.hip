@@ -9,6 +9,7 @@
 // and the CPU-side ABI checks never touch it, and a process that already holds torch's RCCL binds to that same copy.
 #include <dlfcn.h>
 #include <rccl/rccl.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include "common.h"
@@ -31,6 +32,9 @@ struct eegldm_comm {
 
 namespace {
 void* open_rccl() {
+  // EEGLDM_RCCL_LIB=<path>: bind to a specific build of the library (a newer RCCL than the process already holds; the call-recording
+  // stand-in of tests/fake_rccl, which lets the bucket arithmetic below run for world sizes no single-GPU box can provide)
+  if (const char* over = getenv("EEGLDM_RCCL_LIB")) { if (*over) return dlopen(over, RTLD_NOW | RTLD_LOCAL); }
   const char* names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
   for (const char* n : names) { void* h = dlopen(n, RTLD_NOW | RTLD_GLOBAL); if (h) return h; }
   return nullptr;

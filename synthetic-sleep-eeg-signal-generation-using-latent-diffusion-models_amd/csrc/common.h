@@ -1,6 +1,7 @@
 // Shared declarations for the eegldm HIP library (gfx950 only).
 #pragma once
 #include <stdlib.h>
+#include <atomic>
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdio.h>
@@ -38,11 +39,16 @@ void eegldm_set_error(const std::string& msg);
 // Every EEGLDM_* switch is cached in a function-local static and re-read only when eegldm_debug_reload_env() has bumped the epoch:
 // production pays one integer compare per use, tests A/B a fast path against its predecessor inside ONE process
 // (os.environ[...] = ...; lib.eegldm_debug_reload_env()) instead of spawning an interpreter per switch.
-extern int g_eeg_env_epoch;
+// Threading: the epoch and the live-context counter are atomics (one host thread per context / GPU may run concurrently); the cached value
+// itself is re-written only with the value every thread would compute.  eegldm_debug_reload_env() / eegldm_set_deterministic() may only be
+// called while no call of this library is in flight on any thread (a switch flipped in the middle of a backward would be read by some
+// ops and not by others).
+extern std::atomic<int> g_eeg_env_epoch;
 #define EEG_ENV_VAR(T, name, ...)                                                                       \
   static T name;                                                                                        \
-  do { static int _ep_##name = -1;                                                                      \
-       if (_ep_##name != g_eeg_env_epoch) { name = (__VA_ARGS__); _ep_##name = g_eeg_env_epoch; } } while (0)
+  do { static std::atomic<int> _ep_##name{-1};                                                          \
+       const int _now_##name = g_eeg_env_epoch.load(std::memory_order_acquire);                         \
+       if (_ep_##name.load(std::memory_order_acquire) != _now_##name) { name = (__VA_ARGS__); _ep_##name.store(_now_##name, std::memory_order_release); } } while (0)
 // EEGLDM_DETERMINISTIC=1: bit-reproducible gradients and losses run to run.  Every reduction whose order depends on timing (fp32 global atomics
 // of the bias / GroupNorm / thin-conv gradients and the loss sums; the fused column sums inside the weight-gradient GEMM; split-K without
 // a workspace) takes a written-partials + fixed-order-fold route instead.  Slower by a few per cent; the default stays off.
@@ -50,7 +56,7 @@ static inline bool eeg_deterministic() {
   EEG_ENV_VAR(bool, det, getenv("EEGLDM_DETERMINISTIC") != nullptr && atoi(getenv("EEGLDM_DETERMINISTIC")) != 0);
   return det;
 }
-extern int g_eeg_live_ctx;      // contexts alive in this process (eegldm_ctx_create / _destroy): kernels that are only safe alone on a CU ask
+extern std::atomic<int> g_eeg_live_ctx;      // contexts alive in this process (eegldm_ctx_create / _destroy): kernels that are only safe alone on a CU ask
 
 // ---------------------------------------------------------------- context
 struct WgradRec;      // one deferred weight-gradient problem (defined below, after GemmArgs)

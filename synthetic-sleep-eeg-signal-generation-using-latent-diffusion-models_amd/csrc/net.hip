@@ -53,13 +53,14 @@ int NetBase::flush_gn_folds() {
   gn_pending.clear();
   return 0;
 }
-void NetBase::release_kblk() {
-  if (!wK) return;
-  for (auto it = ctx->kblk.begin(); it != ctx->kblk.end();) {
-    const char* v = (const char*)it->second;
-    if (v >= (const char*)wK && v < (const char*)wK + (size_t)nparams * 2) it = ctx->kblk.erase(it); else ++it;
+void NetBase::release_kblk() {      // the two copies are independent: a model may own either without the other
+  if (wK) {
+    for (auto it = ctx->kblk.begin(); it != ctx->kblk.end();) {
+      const char* v = (const char*)it->second;
+      if (v >= (const char*)wK && v < (const char*)wK + (size_t)nparams * 2) it = ctx->kblk.erase(it); else ++it;
+    }
+    (void)hipFree(wK); (void)hipFree(d_kb); wK = nullptr; d_kb = nullptr; n_kb = 0;
   }
-  (void)hipFree(wK); (void)hipFree(d_kb); wK = nullptr; d_kb = nullptr; n_kb = 0;
   if (wKT) {
     for (auto it = ctx->kblk_t.begin(); it != ctx->kblk_t.end();) {
       const char* v = (const char*)it->second;

@@ -65,17 +65,27 @@ def allreduce_sum_scalars(values, like=None):
     return [float(v) for v in t.tolist()]
 
 
+def _mean_op(t):
+    """(reduce op, needs a separate 1/world pass).  RCCL has the mean as a collective (ncclAvg = ReduceOp.AVG): no extra read + write of
+    the 122 MB gradient buffer per step; gloo (the CPU tests, ranks sharing one GPU) only sums."""
+    if dist.get_backend() == "nccl" and t.is_cuda and os.environ.get("EEGLDM_NO_NCCL_AVG") is None:
+        return dist.ReduceOp.AVG, False
+    return dist.ReduceOp.SUM, True
+
+
 def allreduce_mean_flat(t, bucket_elems=BUCKET_ELEMS):
     """In-place mean over ranks of a flat tensor, bucketed; async ops are all issued before the first wait."""
     if not dist.is_initialized() or dist.get_world_size() == 1:
         return
     world = dist.get_world_size()
+    op, post = _mean_op(t)
     works = []
     for s in range(0, t.numel(), bucket_elems):
-        works.append(dist.all_reduce(t[s:s + bucket_elems], op=dist.ReduceOp.SUM, async_op=True))
+        works.append(dist.all_reduce(t[s:s + bucket_elems], op=op, async_op=True))
     for w in works:
         w.wait()
-    t.mul_(1.0 / world)
+    if post:
+        t.mul_(1.0 / world)
 
 
 class NativeComm:
@@ -165,6 +175,7 @@ class OverlappedGradSync:
         self.bucket = int(bucket_elems)
         self.works = []
         self.done = []          # (start, end) ranges already launched
+        self._post_scale = True
 
     @property
     def active(self):
@@ -179,9 +190,11 @@ class OverlappedGradSync:
         if self.comm is not None:     # ordered after the Context's stream inside the library; one group of bucketed ncclAvg collectives
             self.comm.allreduce_mean(self.g[a:b], self.bucket)
             return
+        op, post = _mean_op(self.g)
+        self._post_scale = post
         for s in range(a, b, self.bucket):
             e = min(b, s + self.bucket)
-            self.works.append(dist.all_reduce(self.g[s:e], op=dist.ReduceOp.SUM, async_op=True))
+            self.works.append(dist.all_reduce(self.g[s:e], op=op, async_op=True))
 
     def on_ready(self, offset, numel):
         if not self.active or numel <= 0:
@@ -216,7 +229,8 @@ class OverlappedGradSync:
         for w in self.works:
             w.wait()
         self.works = []
-        self.g.mul_(1.0 / dist.get_world_size())
+        if self._post_scale:          # gloo: sum, then one pass; RCCL: the mean was the collective (ReduceOp.AVG)
+            self.g.mul_(1.0 / dist.get_world_size())
 
 
 def shard_range(n, rank, world):

@@ -114,6 +114,7 @@ class AutoencoderKL(_Flat):
         if B == 0:
             return mu, sg
         check(lib.eegldm_aekl_encode(self.h, ptr(x), None, None, ptr(mu), ptr(sg), B, L))
+        self._bump_tape()
         return mu, sg
 
     def sampling(self, z_mu, z_sigma, eps=None):
@@ -130,6 +131,7 @@ class AutoencoderKL(_Flat):
             eps = torch.randn(z.shape, device=self.device)
         eps = self._x(eps)
         check(lib.eegldm_aekl_encode(self.h, ptr(x), ptr(eps), ptr(z), None, None, B, L))
+        self._bump_tape()
         if scale_factor is not None and float(scale_factor) != 1.0:
             check(lib.eegldm_axpy(self.ctx.h, ptr(z), ptr(z), float(scale_factor) - 1.0, z.numel()))
         return z
@@ -140,6 +142,7 @@ class AutoencoderKL(_Flat):
         if B == 0:
             return out
         check(lib.eegldm_aekl_decode(self.h, ptr(z), ptr(out), B, Ll))
+        self._bump_tape()
         return out
 
     decode_stage_2_outputs = decode
@@ -169,6 +172,7 @@ class AutoencoderKL(_Flat):
         recon = torch.empty(B, self.out_channels, L, device=self.device)
         mu = torch.empty(B, self.latent_channels, L // self.down, device=self.device); sg = torch.empty_like(mu)
         check(lib.eegldm_aekl_forward(self.h, ptr(x), ptr(eps), ptr(recon), ptr(mu), ptr(sg), ptr(kl_out), B, L))
+        self._bump_tape()
         return recon, mu, sg
 
     __call__ = forward
@@ -177,6 +181,7 @@ class AutoencoderKL(_Flat):
         d = self._x(d_recon)
         dx = torch.empty(d.shape[0], self.in_channels, d.shape[2], device=self.device) if need_dx else None
         check(lib.eegldm_aekl_backward(self.h, ptr(d), float(kl_weight), ptr(dx)))
+        self._bump_tape()
         return dx
 
     def __del__(self):
@@ -266,12 +271,14 @@ class PatchDiscriminator(_Flat):
             Lo = (Lo + 2 * self.padding - self.kernel_size) // 2 + 1          # initial + (num_layers_d - 1) stride-2 convs; the rest keep L
         logits = torch.empty(B, self.out_channels, Lo, device=self.device)
         check(lib.eegldm_disc_forward(self.h, ptr(x), ptr(logits), B, L, int(training)))
+        self._bump_tape()
         return logits
 
     def backward(self, dlogits, need_dx=False, param_grads=True, in_shape=None):
         d = dlogits.to(self.device, torch.float32).contiguous()
         dx = torch.empty(in_shape, device=self.device) if need_dx else None
         check(lib.eegldm_disc_backward(self.h, ptr(d), ptr(dx), 1 if param_grads else 0))
+        self._bump_tape()
         return dx
 
     def __del__(self):

@@ -165,6 +165,7 @@ class UNetModel(FlatModule):
         B, _c, L = x.shape
         out = torch.empty(B, self.out_channels, L, device=self.device, dtype=torch.float32)
         check(lib.eegldm_unet_forward(self.h, ptr(x), ptr(t), ptr(out), B, L, 1 if self.training else 0))
+        self._bump_tape()                                # the executor's single tape now belongs to THIS call (eegldm.autograd)
         return out
 
     __call__ = forward
@@ -173,6 +174,7 @@ class UNetModel(FlatModule):
         dy = dy.to(self.device, torch.float32).contiguous()
         dx = torch.empty(dy.shape[0], self.in_channels, dy.shape[2], device=self.device) if need_dx else None
         check(lib.eegldm_unet_backward(self.h, ptr(dy), ptr(dx)))
+        self._bump_tape()                                # consumed
         return dx
 
     def __del__(self):

@@ -61,6 +61,9 @@ def ddim_sample(unet, autoencoder, scheduler, noise, scale_factor=1.0, crop=36, 
                             (C.c_float * n)(*a_t), (C.c_float * n)(*a_prev), (C.c_float * n)(*beta), n, 1 if ancestral else 0,
                             PRED[scheduler.prediction_type], int(scheduler.clip_sample), 1.0 / float(scale_factor), int(seed),
                             ptr(lat), ptr(win), B, L, 1 if use_graph else 0, C.byref(used)))
+    unet._bump_tape()
+    if autoencoder is not None:
+        autoencoder._bump_tape()
     if info is not None:
         info["graph"] = bool(used.value)
     return (win[:, :, crop:-crop] if crop else win), lat

@@ -202,6 +202,7 @@ def ldm_train_step(unet, scheduler, latents, noise, timesteps, loss_out=None, gr
         check(lib.eegldm_ldm_train_step(unet.h, ptr(latents), ptr(noise), ptr(timesteps), ptr(scheduler._acp_dev),
                                         PRED[scheduler.prediction_type], B, L, grad_scale, ptr(loss_out)))
     finally:
+        unet._bump_tape()                    # forward + backward ran inside the call: an older autograd graph's tape is gone
         if grad_sync is not None:
             set_grad_hook(unet, None)
     if grad_sync is not None:
@@ -264,4 +265,5 @@ def aekl_train_step(autoencoder, discriminator, x, eps, adv_weight, kl_weight, s
     B, _c, L = x.shape
     check(lib.eegldm_aekl_train_step(autoencoder.h, discriminator.h, ptr(x), ptr(eps), float(adv_weight), float(kl_weight),
                                      float(spectral_weight), 1 if use_spectral else 0, ptr(losses_out), ptr(recon_out), B, L))
+    autoencoder._bump_tape(); discriminator._bump_tape()
     return losses_out

@@ -204,3 +204,71 @@ def test_discriminator_backward_of_an_older_forward_reforwards_without_touching_
     for k in s1:
         if "running" in k or "num_batches" in k:
             assert torch.allclose(s1[k].float(), s2[k].float(), rtol=1e-6, atol=1e-7), k
+
+
+def test_intervening_native_calls_do_not_corrupt_an_older_graphs_backward():
+    """ADVICE r4 (autograd.py): a forward that does not go through the autograd Function (torch.no_grad() validation call, eval mode,
+    the fused train step) overwrites the executor's single tape; the bridge must notice and rebuild the tape of the graph being
+    back-propagated.  Gradients after such an intervening call == gradients of an undisturbed forward / backward."""
+    from eegldm.models import UNetModel, AutoencoderKL
+    from eegldm.schedulers import DDPMScheduler
+    from eegldm.training import ldm_train_step
+    import eegldm
+    eegldm.set_deterministic(True)
+    try:
+        small = dict(in_channels=1, out_channels=1, model_channels=32, num_res_blocks=1, attention_resolutions=[2], channel_mult=[1, 2], resblock_updown=True)
+        net = UNetModel(image_size=64, **small, dtype="float32")
+        sd = {k: torch.from_numpy(gen_param(7, k, tuple(v.shape))) for k, v in net.state_dict().items()}
+        net.load_state_dict(sd)
+        (p,) = net.parameters()
+        x = torch.from_numpy(normal((4, 1, 64), seed=11)).cuda(); t = torch.from_numpy(timesteps(4, seed=12)).cuda()
+        x2 = torch.from_numpy(normal((4, 1, 64), seed=13)).cuda() * 3.0; t2 = torch.from_numpy(timesteps(4, seed=14)).cuda()
+        tgt = torch.from_numpy(normal((4, 1, 64), seed=15)).cuda()
+        sched = DDPMScheduler(num_train_timesteps=1000, schedule="linear_beta", beta_start=0.0015, beta_end=0.0195)
+
+        def grads(disturb):
+            net.train(); net.flat_grad.zero_(); p.grad = net.flat_grad
+            loss = F.mse_loss(net(x, timesteps=t), tgt)
+            if disturb == "no_grad":
+                with torch.no_grad():
+                    net(x2, timesteps=t2)
+            elif disturb == "eval":
+                net.eval(); net(x2, timesteps=t2); net.train()
+            elif disturb == "fused":
+                keep = net.flat_grad.clone()
+                ldm_train_step(net, sched, x2, tgt, t2)
+                net.flat_grad.copy_(keep)
+            loss.backward()
+            return net.flat_grad.clone()
+
+        ref = grads(None)
+        assert float(ref.abs().max()) > 0
+        for d in ("no_grad", "eval", "fused"):
+            g = grads(d)
+            assert torch.equal(g, ref), f"{d}: max diff {float((g - ref).abs().max()):.3e}"
+
+        # the autoencoder: encode() / decode() between forward and backward
+        ae = AutoencoderKL(spatial_dims=1, in_channels=1, out_channels=1, num_channels=[32, 32, 64], latent_channels=1, num_res_blocks=2,
+                           norm_num_groups=1, attention_levels=[False, False, False], dtype="float32")
+        sd = {k: torch.from_numpy(gen_param(8, k, tuple(v.shape))) for k, v in ae.state_dict().items()}
+        ae.load_state_dict(sd)
+        (pa,) = ae.parameters()
+        w = torch.from_numpy(eeg_windows(2, seed=5, length=256)).cuda(); eps = torch.from_numpy(normal((2, 1, 64), seed=6)).cuda()
+        w2 = torch.from_numpy(eeg_windows(2, seed=9, length=256)).cuda() * 2.0
+
+        def ae_grads(disturb):
+            ae.train(); ae.flat_grad.zero_(); pa.grad = ae.flat_grad
+            recon, mu, sg = ae(w, eps=eps)
+            loss = F.l1_loss(recon, w) + 1e-3 * (mu.pow(2) + sg.pow(2)).sum()
+            if disturb:
+                with torch.no_grad():
+                    m2, _ = ae.encode(w2); ae.decode(m2)
+            loss.backward()
+            return ae.flat_grad.clone()
+
+        ref = ae_grads(False)
+        assert float(ref.abs().max()) > 0
+        g = ae_grads(True)
+        assert torch.equal(g, ref), f"aekl: max diff {float((g - ref).abs().max()):.3e}"
+    finally:
+        eegldm.set_deterministic(False)
