@@ -106,6 +106,8 @@ int eegldm_cast(eegldm_ctx*, const float* src, void* dst, long n, int dst_dtype)
  * a caller of the primitives who updates w must pack again.  eegldm_conv1d_forget_kblocked removes the registration
  * (before freeing either buffer).  No reference counterpart: layout plumbing behind nn.Conv1d (unet.py:263). */
 int eegldm_conv1d_pack_kblocked(eegldm_ctx*, const void* w, void* w_kblocked, int Cout, int Cin, int dtype);
+/* the same for a weight of K taps (K = 1: [1][Cin/32][Cout][32], the copy eegldm_conv1d_skip_fwd reads its 1 x 1 weight from) */
+int eegldm_conv1d_pack_kblocked_k(eegldm_ctx*, const void* w, void* w_kblocked, int Cout, int Cin, int K, int dtype);
 int eegldm_conv1d_forget_kblocked(eegldm_ctx*, const void* w);
 /* Data-gradient copy of a 3-tap conv weight, [3][Cout/32][Cin][32] (16-bit dtypes, Cout % 32 == 0): written to w_dgrad (same size as w)
  * and registered with the context, after which eegldm_conv1d_bwd_data(.., w, ..) may run the input gradient as a plain NT product on
@@ -127,6 +129,25 @@ int eegldm_conv1d_fwd(eegldm_ctx*, const void* x, long ldx, const void* w, const
                       void* y, long ldy, int B, int Lin, int Cin, int Cout, int K, int stride,
                       int pad_l, int pad_r, const float* rowvec, long ld_rowvec,
                       const void* resid, long ld_resid, int dtype);
+/* eegldm_conv1d_fwd that also leaves the per-(sample, channel quad) moments of its output: qstats[(b * Cout/4 + c/4) * 2 + {0,1}] +=
+ * (sum, sum of squares) over the sample's Lout positions of output channels c .. c+3 (doubles, ADDED: zero them first).  Produced in
+ * the epilogue of the big-tile kernels only (16-bit, stride 1, Cout % 256 == 0, B*Lout and Lout multiples of 192; taken from the
+ * fp32 values in front of the 16-bit rounding); *filled (host) says whether the kernel that ran did.  Consumer:
+ * eegldm_groupnorm_fwd_qstats.  No reference counterpart: it is how `normalization(channels)` behind a conv (unet.py:261-263,
+ * 287-291) becomes one streaming pass. */
+int eegldm_conv1d_fwd_qstats(eegldm_ctx*, const void* x, long ldx, const void* w, const float* bias,
+                             void* y, long ldy, int B, int Lin, int Cin, int Cout, int K, int stride,
+                             int pad_l, int pad_r, const float* rowvec, long ld_rowvec,
+                             const void* resid, long ld_resid, int dtype, double* qstats, int* filled);
+/* The ResBlock tail `self.skip_connection(x) + h` with h = out_layers' conv (unet.py:302,327) as one operator:
+ *   y = conv1d(x; w [3][Cout][Cin], pad 1) + bias + conv1d(x2; w2 [1][Cout][Cin2]) + bias2 (+ rowvec per sample)
+ * With 16-bit operands, Cout % 256 == 0, B*L and L multiples of 192 and K-blocked copies of BOTH weights registered
+ * (eegldm_conv1d_pack_kblocked / _k) it is ONE launch -- the 1 x 1 conv runs as further reduction stages of the 3-tap kernel: one
+ * fp32 accumulator, one rounding, no intermediate tensor; otherwise the two convs are launched one after the other (y is then
+ * rounded twice in 16-bit storage).  y must not alias x or x2. */
+int eegldm_conv1d_skip_fwd(eegldm_ctx*, const void* x, long ldx, const void* w, const float* bias,
+                           const void* x2, long ldx2, const void* w2, const float* bias2, void* y, long ldy,
+                           int B, int L, int Cin, int Cin2, int Cout, const float* rowvec, long ld_rowvec, int dtype);
 int eegldm_conv1d_bwd_data(eegldm_ctx*, const void* dy, long lddy, const void* w, void* dx, long lddx,
                            int B, int Lin, int Cin, int Cout, int K, int stride, int pad_l, int pad_r,
                            const void* resid, long ld_resid, int dtype);
@@ -151,6 +172,12 @@ int eegldm_linear_bwd(eegldm_ctx*, const void* x, long ldx, const void* w, const
 int eegldm_groupnorm_fwd(eegldm_ctx*, const void* x, long ldx, const float* gamma, const float* beta,
                          void* y, long ldy, float* stats, int B, int L, int C, int G, float eps,
                          int fuse_silu, int resample, void* xr, long ldxr, int dtype);
+/* GroupNorm(+SiLU) forward (no resampling) of a 16-bit tensor from the moments its producer(s) left (eegldm_conv1d_fwd_qstats): qs_a
+ * covers channel quads [0, nq_a), qs_b (optional: a concatenated input [h | skip], unet.py:553) quads [nq_a, nq_a + nq_b); one
+ * streaming pass, writes y and the (mean, rstd) pairs `stats` exactly like eegldm_groupnorm_fwd.  Error if not eligible. */
+int eegldm_groupnorm_fwd_qstats(eegldm_ctx*, const void* x, long ldx, const float* gamma, const float* beta,
+                                void* y, long ldy, float* stats, int B, int L, int C, int G, float eps,
+                                int fuse_silu, const double* qs_a, int nq_a, const double* qs_b, int nq_b, int dtype);
 int eegldm_groupnorm_bwd(eegldm_ctx*, const void* x, long ldx, const float* gamma, const float* beta,
                          const float* stats, const void* dy, long lddy, void* dx, long lddx,
                          float* dgamma, float* dbeta, int B, int L, int C, int G, int fuse_silu,

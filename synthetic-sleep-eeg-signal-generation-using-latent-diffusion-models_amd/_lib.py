@@ -54,6 +54,10 @@ SIGNATURES = {
     "eegldm_nlc_to_ncl": [_vp, _vp, _l, _vp, _i, _i, _i, _i],
     "eegldm_pack_conv_weight": [_vp, _vp, _vp, _i, _i, _i],
     "eegldm_conv1d_pack_kblocked": [_vp, _vp, _vp, _i, _i, _i],
+    "eegldm_conv1d_pack_kblocked_k": [_vp, _vp, _vp, _i, _i, _i, _i],
+    "eegldm_conv1d_fwd_qstats": [_vp, _vp, _l, _vp, _vp, _vp, _l, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _l, _vp, _l, _i, _vp, C.POINTER(_i)],
+    "eegldm_groupnorm_fwd_qstats": [_vp, _vp, _l, _vp, _vp, _vp, _l, _vp, _i, _i, _i, _i, _f, _i, _vp, _i, _vp, _i, _i],
+    "eegldm_conv1d_skip_fwd": [_vp, _vp, _l, _vp, _vp, _vp, _l, _vp, _vp, _vp, _l, _i, _i, _i, _i, _i, _vp, _l, _i],
     "eegldm_comm_unique_id": [_vp],
     "eegldm_comm_create": [_vp, _vp, _i, _i, _vp],
     "eegldm_comm_destroy": [_vp],

@@ -70,7 +70,9 @@ struct ChainArgs {
   unsigned long long* stamps;          // developer aid (EEGLDM_ATTN_STAMPS=1): shader-clock stamps of block 0's phases, else null
   // backward, whole-sample blocks only (fuse_kv): dK = dS^T Q as a second pass of product 2 over the score tile, read TRANSPOSED;
   // Q3 = the query rows of the sample; the result goes to dK (same leading dimension as O)
-  int fuse_kv; const bf16_t* Q3; long ldq3, sQ3; bf16_t* dK;
+  // fuse_kv == 2 (round 5): a THIRD pass dV = P^T dO behind it -- the probabilities are fetched again (73 KB per sample, L2) at the end of
+  // the dK pass and overwrite the dS tile, tiles = rows of dO (= A1); the result goes to dV
+  int fuse_kv; const bf16_t* Q3; long ldq3, sQ3; bf16_t* dK; bf16_t* dV;
 };
 #define ATTN_STAMP(k) do { if (p.stamps && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) p.stamps[k] = __builtin_readcyclecounter(); } while (0)
 
@@ -134,9 +136,11 @@ __global__ __launch_bounds__(64 * NCW * NQ) void attn_chain_kernel(const ChainAr
   // (every field is copied to a local first: selecting between members of the by-value argument struct at run time made hipcc keep
   //  a copy of the struct in scratch -- 320 bytes per lane)
   const bool fuse_kv = MODE == 1 && p.fuse_kv != 0;
+  const bool fuse_v = MODE == 1 && p.fuse_kv == 2;
   const bf16_t* const src1 = fuse_kv ? p.Q3 + (long)b * p.sQ3 : B2;
-  const long ld0 = p.ldb2, ld1 = fuse_kv ? p.ldq3 : p.ldb2;
-  bf16_t* const dst0 = p.O; bf16_t* const dst1 = fuse_kv ? p.dK : p.O;
+  const bf16_t* const src2 = A1;                               // third pass: rows of dO (whole-sample blocks: m0 = 0)
+  const long ld0 = p.ldb2, ld1 = fuse_kv ? p.ldq3 : p.ldb2, ld2 = p.lda1;
+  bf16_t* const dst0 = p.O; bf16_t* const dst1 = fuse_kv ? p.dK : p.O; bf16_t* const dst2 = fuse_v ? p.dV : p.O;
   const long sO = p.sO, ldo = p.ldo;
   // (sources / destinations are switched at pass boundaries through two-way selects only: a three-way `pass == 0 ? a : pass == 1 ? b : c`
   //  became a lookup table on the stack -- 160 bytes of scratch per lane in every instantiation)
@@ -423,10 +427,12 @@ __global__ __launch_bounds__(64 * NCW * NQ) void attn_chain_kernel(const ChainAr
   }
   // ---------------- passes over the score tile as ONE unit sequence (the tile ring prefetches across the pass boundary) ----------------
   // pass 0: out (forward) / dQ = dS K (backward); pass 1 (backward, whole-sample blocks, fuse_kv): dK = dS^T Q -- the score tile read
-  // TRANSPOSED, tiles = rows of Q.  (dV = P^T dO stays a batched TN GEMM: as a third pass it has to run BEFORE product 1 while P is
-  // still in registers and the tile is free, and the loop around two call sites of this code cost 30 registers -- 700 bytes of spills
-  // at the 168 registers a 12-wave block leaves each lane.)
-  const int pr_count = fuse_kv ? 2 : 1;
+  // TRANSPOSED, tiles = rows of Q; pass 2 (fuse_kv == 2, round 5): dV = P^T dO, tiles = rows of dO.  (Round 4 tried dV as a pass BEFORE
+  // product 1, while P is still in registers: a second call site of this loop cost 30 registers -- 700 bytes of spills at the 168
+  // registers a 12-wave block leaves each lane.  Here the loop stays one call site: the probabilities are fetched AGAIN at the end of
+  // the dK pass -- 73 KB per sample from L2, behind the output stores of that pass, which the next unit waits for anyway -- and
+  // overwrite the dS tile behind the barrier of the first dV unit.)
+  const int pr_count = fuse_v ? 3 : (fuse_kv ? 2 : 1);
   bool stores_pending = true;                      // the P / dS stores of the row operation
   f32x4 acc2[RF2][4];
   const int nut = pr_count * nu;
@@ -434,11 +440,16 @@ __global__ __launch_bounds__(64 * NCW * NQ) void attn_chain_kernel(const ChainAr
   const bf16_t* isrc = B2; long ild = ld0; int iuu = 0;
   auto issue_next = [&](int buf) __attribute__((always_inline)) {
     issue_tile(isrc, ild, iuu, buf);
-    if (++iuu == nu) { iuu = 0; isrc = src1; ild = ld1; }        // second pass: dK, tiles = rows of Q
+    if (++iuu == nu) {                                           // next pass: dK (tiles = rows of Q), then dV (tiles = rows of dO)
+      iuu = 0;
+      const bool first = isrc == B2;
+      isrc = first ? src1 : src2; ild = first ? ld1 : ld2;
+    }
   };
   iuu = (DO2 - 1 < nu) ? DO2 - 1 : nu;             // the first tiles were issued before the row operation
   if (iuu == nu) { iuu = 0; isrc = src1; ild = ld1; }
   bf16_t* cdst = dst0; bool ctr = false;
+  bool refill = false;                             // the score tile is to be overwritten with P before this unit (first unit of the dV pass)
   int uu = 0;
   for (int u = 0; u < nut; u++) {
     const int nc = uu / nks, ks = uu - nc * nks;
@@ -457,6 +468,14 @@ __global__ __launch_bounds__(64 * NCW * NQ) void attn_chain_kernel(const ChainAr
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     stores_pending = false;
     __syncthreads();                               // (for u = 0 also: the score tile is complete in LDS)
+    if (MODE == 1 && refill) {                     // every wave is done with dS (barrier above); the P fragments arrived with the vmcnt(0) of this unit
+#pragma unroll
+      for (int i = 0; i < 4; i++)
+#pragma unroll
+        for (int j = 0; j < NJ; j++) *(uint2*)(pt + (mq + i * 16 + lm) * PP + ((w * NJ + j) * 16 + q * 4) * 2) = pr[i][j];
+      refill = false;
+      __syncthreads();
+    }
     const char* sv = sm + (u % DO2) * 16384;
     uint4 af[RF2], bfr[4];
     if (MODE == 1 && ctr) {
@@ -484,7 +503,18 @@ __global__ __launch_bounds__(64 * NCW * NQ) void attn_chain_kernel(const ChainAr
         }
       stores_pending = true;
     }
-    if (++uu == nu) { uu = 0; cdst = dst1; ctr = true; }      // second pass
+    if (++uu == nu) {                              // next pass
+      uu = 0;
+      if (MODE == 1 && ctr && fuse_v) {            // dK done -> dV: fetch this lane's probabilities again (the next unit waits for vmcnt(0): stores_pending)
+        refill = true;
+#pragma unroll
+        for (int i = 0; i < 4; i++)
+#pragma unroll
+          for (int j = 0; j < NJ; j++)
+            pr[i][j] = *(const uint2*)(p.P + (long)b * p.sP + (long)(m0 + mq + i * 16 + lm) * T + (w * NJ + j) * 16 + q * 4);
+      }
+      cdst = ctr ? dst2 : dst1; ctr = true;
+    }
   }
   ATTN_STAMP(3);
 }
@@ -561,7 +591,7 @@ int attn_chain_bwd(eegldm_ctx* ctx, const void* qkv, long ldq, const void* probs
   a.O = (bf16_t*)dq; a.ldo = lddq; a.sO = (long)T * lddq; a.T = T; a.C = C; a.alpha = 1.0f / sqrtf((float)C);
   if (fuse_kv) {
     EEG_CHECK(attn_chain_bwd_fuses_kv(ctx, B, T), "fused dK / dV needs whole-sample blocks");
-    a.fuse_kv = 1; a.Q3 = q; a.ldq3 = ldq; a.sQ3 = (long)T * ldq; a.dK = (bf16_t*)dq + C;
+    a.fuse_kv = fuse_kv == 2 ? 2 : 1; a.Q3 = q; a.ldq3 = ldq; a.sQ3 = (long)T * ldq; a.dK = (bf16_t*)dq + C; a.dV = (bf16_t*)dq + 2 * C;
   }
   switch (T / 64) {
     case 1: return launch_chain<1, 1>(ctx, a, B);

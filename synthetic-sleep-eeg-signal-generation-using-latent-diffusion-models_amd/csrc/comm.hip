@@ -102,7 +102,7 @@ extern "C" int eegldm_comm_world(const eegldm_comm* c) { return c ? c->world : 0
 // context's stream so far; runs on the communication stream; eegldm_comm_wait() makes the context's stream wait for it.  ncclAvg: the
 // 1 / world scaling is part of the collective (no separate pass over the buffer).
 extern "C" int eegldm_comm_allreduce_mean_f32(eegldm_comm* c, float* buf, long n, long bucket_elems) {
-  EEG_CHECK(c && buf && n >= 0, "bad argument");
+  EEG_CHECK(c && n >= 0 && (buf || n == 0), "bad argument");
   if (n == 0) return 0;
   HIP_TRY(hipEventRecord(c->ev_ready, c->ctx->stream));
   HIP_TRY(hipStreamWaitEvent(c->stream, c->ev_ready, 0));

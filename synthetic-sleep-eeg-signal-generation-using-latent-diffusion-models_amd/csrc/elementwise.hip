@@ -599,8 +599,8 @@ int kblk_pack_t(eegldm_ctx* ctx, const void* w_plain, void* w_packed, const KbDe
                      d_table, n, total_chunks);
   LAUNCH_CHECK(); return 0;
 }
-int kblk_pack_one(eegldm_ctx* ctx, const void* w_plain, void* w_packed, int Cout, int Cin) {
-  const long total = 3l * Cout * Cin / 8;
+int kblk_pack_one(eegldm_ctx* ctx, const void* w_plain, void* w_packed, int Cout, int Cin, int taps) {
+  const long total = (long)taps * Cout * Cin / 8;
   hipLaunchKernelGGL(kblk_pack1_kernel, dim3((unsigned)((total + NT - 1) / NT)), dim3(NT), 0, ctx->stream, (const uint4*)w_plain, (uint4*)w_packed, Cout, Cin, total);
   LAUNCH_CHECK(); return 0;
 }

@@ -62,6 +62,15 @@ struct BigArgs {
   const bf16_t* resid; long ldr;
   const void* zero_page;
   int tiles_m, tiles_n;
+  // K extension (gemm_bigp_kernel<.., XT = true>): K2 / 64 further 1-tap stages over a SECOND operand pair behind the 3-tap stages --
+  //   Y[r][n] += sum_k A2[r][k] * W2[n][k]  (+ bias2[n])
+  // = the ResBlock's skip_connection 1 x 1 conv folded into out_layers' conv (h = skip(x) + conv2(a2), unet.py:302,327): one launch, one
+  // fp32 accumulator, one rounding, no intermediate tensor.  W2 is K-blocked [K2 / 32][N][32]; K2 % 64 == 0, K2 >= 128.
+  const bf16_t* A2; long lda2; const bf16_t* B2; int K2; const float* bias2;
+  // statistics epilogue (kernels with ST = true): qstats[(r / qL) * (N / 4) + n / 4] += (sum, sum of squares) of the four output columns
+  // n .. n + 3 over the tile's rows, fp64 atomics -- the per-(sample, channel quad) moments the NEXT GroupNorm folds into its group
+  // statistics, so that it runs as one streaming pass (norm.hip gn_apply_q_kernel).  qL = rows per sample (a multiple of 192).
+  double* qstats; int qL;
 };
 
 typedef __attribute__((address_space(3))) void* lds_void_ptr;
@@ -317,6 +326,48 @@ __device__ __forceinline__ void big_store(const BigArgs& p, f32x4 (&acc)[FM][FN]
     }
 }
 
+// ---- statistics epilogue shared by the persistent kernels.  A lane holds columns q * 4 .. q * 4 + 3 of fragment column j = one channel quad,
+// for rows lm of the six fragment rows: 24 values per quad in the lane, 16 lanes (lm) per quad and wave, two waves (wm = 0 / 1) per quad.
+// Taken from the fp32 values in front of the bf16 rounding (they differ from the moments of the stored tensor by the rounding noise of
+// 96 x 4 values per partial sum, ~1e-5 of a standard deviation: far below the bf16 resolution of anything computed from them).
+// Who issues the atomics matters: gfx950 retires a wave's vector-memory instructions through one in-order counter, the loader waves'
+// counted vmcnt waits at the top of the next tile therefore wait for every older instruction -- and a device-scope fp64 atomic is acknowledged
+// by the memory side microseconds later (first version, atomics from all eight waves: +7 us per launch, two tiles per workgroup).
+// So the loader waves (0-3 = the wm = 0 half of the tile) hand their partial sums to their wm = 1 partners (waves 4-7, same columns,
+// never wait on vmcnt inside the K loop) through 512 bytes of LDS behind the ring, and the partners add both halves into the global
+// moments after the next barrier (the top of the next tile, or one extra barrier behind the last tile).
+constexpr int QST_BYTES = 4 * (FN * 4) * 2 * 4;      // per loader wave: FN x 4 quads x (sum, sum of squares)
+__device__ __forceinline__ float big_row16_sum(float v) {      // sum over the 16 lanes of a row: four full-rate DPP adds, no LDS
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, true));     // quad_perm [1,0,3,2]
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xF, 0xF, true));     // quad_perm [2,3,0,1]
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x141, 0xF, 0xF, true));    // row_half_mirror
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x140, 0xF, 0xF, true));    // row_mirror
+  return v;
+}
+__device__ __forceinline__ void big_qpartial(f32x4 (&acc)[FM][FN], float (&s)[2 * FN]) {
+#pragma unroll
+  for (int j = 0; j < FN; j++) {
+    float a = 0.f, b = 0.f;
+#pragma unroll
+    for (int i = 0; i < FM; i++) {
+#pragma unroll
+      for (int r = 0; r < 4; r++) { const float v = acc[i][j][r]; a += v; b = fmaf(v, v, b); }
+    }
+    s[j] = big_row16_sum(a); s[FN + j] = big_row16_sum(b);
+  }
+}
+__device__ __forceinline__ void big_qflush(const BigArgs& p, const float (&s)[2 * FN], const float* part, int m0, int n0, int lm, int q, int wn) {
+  if (lm == 0) {
+    double* dst = p.qstats + ((long)(m0 / p.qL) * (p.N / 4) + (n0 + wn * 64 + q * 4) / 4) * 2;
+#pragma unroll
+    for (int j = 0; j < FN; j++) {
+      const float2 o = *(const float2*)(part + (j * 4 + q) * 2);
+      __hip_atomic_fetch_add(dst + j * 8, (double)(s[j] + o.x), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_fetch_add(dst + j * 8 + 1, (double)(s[FN + j] + o.y), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+  }
+}
+
 // ---- persistent form of the 3-tap kernel: one workgroup per CU walks tiles blockIdx.x, + gridDim.x, ...
 // What it is for: in the one-tile-per-workgroup form every CU reaches its epilogue at the same time, the 25 MB of a round drain at
 // HBM rate while nothing computes (4.3 us per round measured: K sweep in tools/debug/gemm_big_check.py), and the next round's first
@@ -327,9 +378,17 @@ __device__ __forceinline__ void big_store(const BigArgs& p, f32x4 (&acc)[FM][FN]
 // next tile's K loop, and the loaders' half has until the third barrier of the next tile.
 // Loader addressing: DMA instruction k of loader wave w fills LDS chunks ((w + 4k) * 64 + lane) = 8 tile rows; k advances the source
 // by 32 rows -- a SCALAR step on the base -- so the per-lane part (row within the 8, swizzled 16-byte slot) is ONE VGPR per operand.
-template <bool KBLK, bool FLIP, int NLOAD>      // NLOAD loader waves (4 or 2)
+// K extension (XT): the S2 = K2 / 64 extra pieces X_e = (A2 tile of stage e, W2 piece of stage e) follow the 3 S main pieces.  Every X
+// piece carries an A tile, and the ring has two A buffers, so X_e can only be requested once X_{e-2} (or, for X_1, the last main A tile)
+// has been read: X pieces run TWO phases ahead instead of three (X_0 is requested behind the barrier of phase (S-1, 1), X_1 behind that
+// of (S-1, 2), X_{e+2} behind that of X_e) and every barrier of that region waits for vmcnt(0) -- the schedule of gemm_big1p_kernel.
+// A2 tiles land where the main tiles land (physical row = tile row + 1) and are read with the centre tap's fragment addresses; B pieces
+// keep walking the three B buffers (X_e in buffer e % 3 = where piece 3 S + e would go).
+template <bool KBLK, bool FLIP, int NLOAD, bool XT = false, bool ST = false>      // NLOAD loader waves (4 or 2); ST: statistics epilogue (big_qstats)
 __global__ __launch_bounds__(NTHR, 2) void gemm_bigp_kernel(const BigArgs p) {
   constexpr int TAPS = 3;
+  static_assert(!XT || (KBLK && !FLIP), "the K extension is a forward product on K-blocked weights");
+  static_assert(!ST || NLOAD == 4, "statistics hand-over: loader wave w and its partner w + 4 own the same columns");
   static_assert(NLOAD == 2 || NLOAD == 4, "halo rows belong to waves 0 and 1; vmcnt holds 63");
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -344,6 +403,7 @@ __global__ __launch_bounds__(NTHR, 2) void gemm_bigp_kernel(const BigArgs p) {
     tm0 = tile_m * BM; tn0 = tile_n * BN;
   };
   const int S = p.K / BK;
+  const int S2 = XT ? p.K2 / BK : 0;
   const unsigned lds0 = (unsigned)(size_t)(lds_void_ptr)smem;
   const unsigned wave_u = __builtin_amdgcn_readfirstlane(wave);
   constexpr int B0 = 2 * A_ALLOC;          // B pieces behind the two A tiles
@@ -371,10 +431,15 @@ __global__ __launch_bounds__(NTHR, 2) void gemm_bigp_kernel(const BigArgs p) {
     if (ah_bot) ah_src = (unsigned)((((long)(BM + 1) * p.lda) + ((lane & 7) ^ swz2(BM + 1)) * 8) * 2);
     bool ah_ok = false;
     const bf16_t* a_base = nullptr; const bf16_t* b_base = nullptr; const bf16_t* h_base = nullptr;
+    const bf16_t* a2_base = nullptr; const bf16_t* b2_base = nullptr;      // K extension
     auto set_tile = [&](int tm0, int tn0) __attribute__((always_inline)) {
       h_base = p.A + (long)tm0 * p.lda - p.lda;
       a_base = p.A + (long)tm0 * p.lda + (long)(8 * wave_u) * p.lda;
       b_base = p.B + (KBLK ? (long)tn0 * 32 : (long)tn0 * p.ldb) + (long)(8 * wave_u) * (KBLK ? 32 : p.ldb);
+      if (XT) {
+        a2_base = p.A2 + (long)tm0 * p.lda2 + (long)(8 * wave_u) * p.lda2;
+        b2_base = p.B2 + (long)tn0 * 32 + (long)(8 * wave_u) * 32;
+      }
       const bool top_ok = tm0 % p.L != 0, bot_ok = (tm0 + BM) % p.L != 0;       // wave-uniform
       ah_ok = (ah_top && top_ok) || (ah_bot && bot_ok);
     };
@@ -409,6 +474,24 @@ __global__ __launch_bounds__(NTHR, 2) void gemm_bigp_kernel(const BigArgs p) {
 #pragma unroll
       for (int k = 0; k < NB + NA + 1; k++) if (k < NB || t == 0) issue(s, t, k);
     };
+    // K extension: X piece e = NB weight instructions into B buffer `bb` + NA instructions of the A2 tile into A buffer `ab` (no halo rows:
+    // one tap).  The per-lane A2 offset differs from a_voff only by the leading dimension.
+    const unsigned a2_voff = XT ? (unsigned)(((long)r8 * p.lda2 + a_lc * 8) * 2) : 0u;
+    const long a2_kstep = XT ? 8 * NLOAD * p.lda2 : 0;
+    auto begin_xpiece = [&](int e) __attribute__((always_inline)) {
+      unsigned long long b = (unsigned long long)(b2_base + e * bstep), a = (unsigned long long)(a2_base + (long)e * BK);
+      asm volatile("" : "+s"(b), "+s"(a));
+      bcur = (const bf16_t*)b; acur = (const bf16_t*)a;
+    };
+    auto issue_x = [&](unsigned ab_off, unsigned bb_off, int k) __attribute__((always_inline)) {
+      if (k < NB) {
+        dma16s(bcur, b_voff, lds0 + B0 + bb_off + (wave_u + NLOAD * k) * 1024);
+        bcur += b_kstep;
+      } else {
+        dma16s(acur, a2_voff, lds0 + ab_off + A_PAD + ROWB + (wave_u + NLOAD * (k - NB)) * 1024);
+        acur += a2_kstep;
+      }
+    };
     // counted wait of a loader: at most the instructions of piece p+2 (tap `t_inflight`) still in flight; pieces with an A tile carry
     // 14 instructions, 15 in waves 0 and 1; the others 8.  `c`: the previous tile's NST stores sit between pieces 0-2 and piece 3.
     auto wait_dma = [&](const int t_inflight, const bool any, const bool c) __attribute__((always_inline)) {
@@ -440,6 +523,7 @@ __global__ __launch_bounds__(NTHR, 2) void gemm_bigp_kernel(const BigArgs p) {
       for (int j = 0; j < FN; j++) {
         const int nj = tn0 + wn * 64 + j * 16 + q * 4;
         add[j] = p.bias ? *(const float4*)(p.bias + nj) : make_float4(0.f, 0.f, 0.f, 0.f);
+        if (XT && p.bias2) { const float4 e = *(const float4*)(p.bias2 + nj); add[j].x += e.x; add[j].y += e.y; add[j].z += e.z; add[j].w += e.w; }
         if (p.rowvec) {           // a tile lies inside one sample (rows_per_vec % 192 == 0)
           const float4 e = *(const float4*)(p.rowvec + (long)(tm0 / p.rows_per_vec) * p.ld_rowvec + nj);
           add[j].x += e.x; add[j].y += e.y; add[j].z += e.z; add[j].w += e.w;
@@ -479,7 +563,8 @@ __global__ __launch_bounds__(NTHR, 2) void gemm_bigp_kernel(const BigArgs p) {
     int tile_m0 = 0, tile_n0 = 0;      // the current tile, for the operand prefetch inside its last phase
     uint4 af[FM], bf0[FN], bf1[FN];
     // one phase (schedule of gemm_big_kernel: k-step 0 | wait piece p+1 + barrier | issue piece p+3, k-step 1)
-    auto phase = [&](const int s, const int t, const bool has1, const bool has2, const bool has3, const bool c, const bool pre = false) __attribute__((always_inline)) {
+    // xi >= 0 (K extension): X piece xi is requested in the second half of this phase (instead of main piece p + 3); nx: the NEXT piece is X_0
+    auto phase = [&](const int s, const int t, const bool has1, const bool has2, const bool has3, const bool c, const bool pre = false, const int xi = -1, const bool nx = false) __attribute__((always_inline)) {
       const char* smA = smem + (s & 1) * A_ALLOC;
       const char* smB = smem + B0 + t * B_ALLOC;
       const int t1 = (t + 1) % TAPS, s1 = s + (t + 1) / TAPS;
@@ -511,23 +596,75 @@ __global__ __launch_bounds__(NTHR, 2) void gemm_bigp_kernel(const BigArgs p) {
       // under the last 24 MFMAs
       if (pre && !BIG_DBG(32)) load_operands(tile_m0, tile_n0);
       __builtin_amdgcn_sched_barrier(0);
-      const int n_dma = t == 0 ? NB + NA + 1 : NB;        // instructions of piece p+3 = (s + 1, t), spread over the 24 MFMA slots
+      const int n_dma = xi >= 0 ? NB + NA : (t == 0 ? NB + NA + 1 : NB);        // instructions of piece p+3 = (s + 1, t) / of X piece xi, spread over the 24 MFMA slots
       if (LOADER && has3) begin_piece(s + 1, t);
+      if (XT && LOADER && xi >= 0) begin_xpiece(xi);
+      const unsigned x_ab = (unsigned)(((S + xi) & 1) * A_ALLOC), x_bb = (unsigned)((xi % 3) * B_ALLOC);
 #pragma unroll
       for (int i = 0; i < FM; i++) {
 #pragma unroll
         for (int j = 0; j < FN; j++) {
           acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, bf1[j]), __builtin_bit_cast(bf16x8, af[i]), acc[i][j], 0, 0, 0);
-          if (LOADER && has3) {
+          if (LOADER && (has3 || (XT && xi >= 0))) {
 #pragma unroll
-            for (int k = 0; k < NB + NA + 1; k++) if (k < n_dma && (k * (FM * FN)) / n_dma == i * FN + j) issue(s + 1, t, k);
+            for (int k = 0; k < NB + NA + 1; k++) if (k < n_dma && (k * (FM * FN)) / n_dma == i * FN + j) { if (XT && xi >= 0) issue_x(x_ab, x_bb, k); else issue(s + 1, t, k); }
           }
         }
-        if (has1) af[i] = *(const uint4*)(smA1 + aof[t1] + i * 2048);
+        if (has1) af[i] = *(const uint4*)(smA1 + aof[nx ? 1 : t1] + i * 2048);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    };
+    // K extension, phase of X piece e (A buffer (S + e) & 1 at byte offset `ab`, B buffer e % 3 at `bb`; centre-tap fragment addresses):
+    // k-step 0 | X_{e+1} landed (vmcnt(0): it is the only piece in flight) + barrier | request X_{e+2} into the buffers X_e vacates, k-step 1
+    auto xphase = [&](const int e, const unsigned ab, const unsigned bb, const unsigned bb1, const bool has1, const bool has2, const bool pre) __attribute__((always_inline)) {
+      const char* smA = smem + ab;
+      const char* smB = smem + B0 + bb;
+#pragma unroll
+      for (int i = 0; i < FM; i++) {
+#pragma unroll
+        for (int j = 0; j < FN; j++)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, bf0[j]), __builtin_bit_cast(bf16x8, af[i]), acc[i][j], 0, 0, 0);
+        if (i == 0) {
+          __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+          for (int j = 0; j < FN; j++) bf1[j] = *(const uint4*)(smB + (bof ^ 64) + j * 2048);
+        }
+        af[i] = *(const uint4*)(smA + (aof[1] ^ 64) + i * 2048);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      if (LOADER && has1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      asm volatile("" ::: "memory");
+      const char* smA1 = smem + (A_ALLOC - ab);        // the other A buffer
+      const char* smB1 = smem + B0 + bb1;
+      if (has1) {
+#pragma unroll
+        for (int j = 0; j < FN; j++) bf0[j] = *(const uint4*)(smB1 + bof + j * 2048);
+      }
+      if (pre && !BIG_DBG(32)) load_operands(tile_m0, tile_n0);
+      __builtin_amdgcn_sched_barrier(0);
+      constexpr int n_dma = NB + NA;
+      if (LOADER && has2) begin_xpiece(e + 2);
+      const unsigned bb2 = bb == 0 ? 2u * B_ALLOC : bb - B_ALLOC;      // (e + 2) % 3 = (e - 1) % 3
+#pragma unroll
+      for (int i = 0; i < FM; i++) {
+#pragma unroll
+        for (int j = 0; j < FN; j++) {
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, bf1[j]), __builtin_bit_cast(bf16x8, af[i]), acc[i][j], 0, 0, 0);
+          if (LOADER && has2) {
+#pragma unroll
+            for (int k = 0; k < n_dma; k++) if ((k * (FM * FN)) / n_dma == i * FN + j) issue_x(ab, bb2, k);
+          }
+        }
+        if (has1) af[i] = *(const uint4*)(smA1 + aof[1] + i * 2048);
         __builtin_amdgcn_sched_barrier(0);
       }
     };
 
+    // statistics epilogue state: the wave's partial moments of the tile just finished; partner area in LDS (column group wn)
+    float qs[2 * FN]; int q_m0 = 0, q_n0 = 0; bool q_pend = false;
+    float* const q_lds = (float*)(smem + RING) + wn * (FN * 4 * 2);
     int m0, n0;
     decode(blockIdx.x, m0, n0);
     if (LOADER) { set_tile(m0, n0); issue_all(0); issue_all(1); issue_all(2); }
@@ -541,8 +678,10 @@ __global__ __launch_bounds__(NTHR, 2) void gemm_bigp_kernel(const BigArgs p) {
         if (carry) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * NB + NST) : "memory");
         else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * NB) : "memory");
       }
+      if constexpr (ST) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // (the loaders' partial sums of the previous tile are in LDS)
       __builtin_amdgcn_s_barrier();
       asm volatile("" ::: "memory");
+      if constexpr (ST && !LOADER) { if (q_pend) { big_qflush(p, qs, q_lds, q_m0, q_n0, lm, q, wn); q_pend = false; } }
 #pragma unroll
       for (int j = 0; j < FN; j++) bf0[j] = *(const uint4*)(smem + B0 + bof + j * 2048);
 #pragma unroll
@@ -554,12 +693,35 @@ __global__ __launch_bounds__(NTHR, 2) void gemm_bigp_kernel(const BigArgs p) {
         c = false;
       }
       tile_m0 = m0; tile_n0 = n0;
-      phase(S - 1, 0, true, true, false, c); phase(S - 1, 1, true, false, false, false); phase(S - 1, 2, false, false, false, false, true);
+      if constexpr (!XT) {
+        phase(S - 1, 0, true, true, false, c); phase(S - 1, 1, true, false, false, false); phase(S - 1, 2, false, false, false, false, true);
+      } else {
+        // X_0 is requested behind the barrier of (S-1, 1), X_1 behind that of (S-1, 2) (their A buffers are free only then); S2 >= 2
+        phase(S - 1, 0, true, true, false, c); phase(S - 1, 1, true, false, false, false, false, 0); phase(S - 1, 2, true, false, false, false, false, 1, true);
+        unsigned ab = (unsigned)((S & 1) * A_ALLOC), bb = 0;
+#pragma unroll 1
+        for (int e = 0; e + 2 < S2; e++) {
+          const unsigned bb1 = bb == 2u * B_ALLOC ? 0u : bb + B_ALLOC;
+          xphase(e, ab, bb, bb1, true, true, false);
+          ab = A_ALLOC - ab; bb = bb1;
+        }
+        {
+          const unsigned bb1 = bb == 2u * B_ALLOC ? 0u : bb + B_ALLOC;
+          xphase(S2 - 2, ab, bb, bb1, true, false, false);
+          ab = A_ALLOC - ab; bb = bb1;
+          xphase(S2 - 1, ab, bb, 0u, false, false, true);
+        }
+      }
       // nobody reads the ring behind the last barrier
       const int w1 = w + (int)gridDim.x;
       const bool more = w1 < ntiles;
       int m1 = 0, n1 = 0;
       if (!BIG_DBG(32)) apply_operands(m0, n0);
+      if constexpr (ST) {
+        big_qpartial(acc, qs);
+        if (LOADER) { if (lm == 0) { _Pragma("unroll") for (int j = 0; j < FN; j++) *(float2*)(q_lds + (j * 4 + q) * 2) = make_float2(qs[j], qs[FN + j]); } }
+        else { q_m0 = m0; q_n0 = n0; q_pend = true; }
+      }
       __builtin_amdgcn_sched_barrier(0);
       if (more) {
         decode(w1, m1, n1);
@@ -567,7 +729,15 @@ __global__ __launch_bounds__(NTHR, 2) void gemm_bigp_kernel(const BigArgs p) {
         __builtin_amdgcn_sched_barrier(0);
       }
       big_store(p, acc, m0, n0, lm, q, wm, wn);
-      if (!more) return;
+      if (!more) {
+        if constexpr (ST) {      // the last tile's partials: one more barrier, then the partners flush
+          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+          __builtin_amdgcn_s_barrier();
+          asm volatile("" ::: "memory");
+          if (!LOADER) big_qflush(p, qs, q_lds, q_m0, q_n0, lm, q, wn);
+        }
+        return;
+      }
       __builtin_amdgcn_sched_barrier(0);
       zero_acc();
       m0 = m1; n0 = n1; w = w1; carry = true;
@@ -688,7 +858,7 @@ __global__ __launch_bounds__(NTHR, 2) void gemm_big1_kernel(const BigArgs p) {
 // ---- persistent form of the 1-tap kernel (structure and reasons: gemm_bigp_kernel).  Ring = two (A, B) stage buffers; behind the last
 // barrier of a tile both are free, so stages 0 and 1 of the next tile are requested before the output leaves; stage 2 follows behind
 // the first barrier of the next tile, and the loaders' stores have until its second barrier.
-template <bool KBLK, int NLOAD>
+template <bool KBLK, int NLOAD, bool ST = false>
 __global__ __launch_bounds__(NTHR, 2) void gemm_big1p_kernel(const BigArgs p) {
   static_assert(NLOAD == 2 || NLOAD == 4, "vmcnt holds 63");
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -842,6 +1012,8 @@ __global__ __launch_bounds__(NTHR, 2) void gemm_big1p_kernel(const BigArgs p) {
       }
     };
 
+    float qs[2 * FN]; int q_m0 = 0, q_n0 = 0; bool q_pend = false;      // statistics epilogue (see gemm_bigp_kernel)
+    float* const q_lds = (float*)(smem + 2 * S1_BYTES) + wn * (FN * 4 * 2);
     int m0, n0;
     decode(blockIdx.x, m0, n0);
     if (LOADER) { set_tile(m0, n0); issue_all(0); if (S > 1) issue_all(1); }
@@ -859,8 +1031,10 @@ __global__ __launch_bounds__(NTHR, 2) void gemm_big1p_kernel(const BigArgs p) {
           else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
       }
+      if constexpr (ST) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       __builtin_amdgcn_s_barrier();
       asm volatile("" ::: "memory");
+      if constexpr (ST && !LOADER) { if (q_pend) { big_qflush(p, qs, q_lds, q_m0, q_n0, lm, q, wn); q_pend = false; } }
 #pragma unroll
       for (int j = 0; j < FN; j++) bf0[j] = *(const uint4*)(smem + bof + j * 2048);
 #pragma unroll
@@ -875,6 +1049,11 @@ __global__ __launch_bounds__(NTHR, 2) void gemm_big1p_kernel(const BigArgs p) {
       const bool more = w1 < ntiles;
       int m1 = 0, n1 = 0;
       apply_operands(m0, n0);
+      if constexpr (ST) {
+        big_qpartial(acc, qs);
+        if (LOADER) { if (lm == 0) { _Pragma("unroll") for (int j = 0; j < FN; j++) *(float2*)(q_lds + (j * 4 + q) * 2) = make_float2(qs[j], qs[FN + j]); } }
+        else { q_m0 = m0; q_n0 = n0; q_pend = true; }
+      }
       __builtin_amdgcn_sched_barrier(0);
       if (more) {
         decode(w1, m1, n1);
@@ -882,7 +1061,15 @@ __global__ __launch_bounds__(NTHR, 2) void gemm_big1p_kernel(const BigArgs p) {
         __builtin_amdgcn_sched_barrier(0);
       }
       big_store(p, acc, m0, n0, lm, q, wm, wn);
-      if (!more) return;
+      if (!more) {
+        if constexpr (ST) {
+          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+          __builtin_amdgcn_s_barrier();
+          asm volatile("" ::: "memory");
+          if (!LOADER) big_qflush(p, qs, q_lds, q_m0, q_n0, lm, q, wn);
+        }
+        return;
+      }
       __builtin_amdgcn_sched_barrier(0);
       zero_acc();
       m0 = m1; n0 = n1; w = w1; carry = true;
@@ -891,15 +1078,16 @@ __global__ __launch_bounds__(NTHR, 2) void gemm_big1p_kernel(const BigArgs p) {
   if (wave_u < NLOAD) run(std::true_type{}); else run(std::false_type{});
 }
 
-template <bool KBLK, int NLOAD>
+template <bool KBLK, int NLOAD, bool ST = false>
 int launch_big1p(eegldm_ctx* ctx, const BigArgs& a) {
-  auto kern = gemm_big1p_kernel<KBLK, NLOAD>;
+  auto kern = gemm_big1p_kernel<KBLK, NLOAD, ST>;
   static DevOnce attr_once;
-  if (attr_once.need(ctx->device)) HIP_TRY(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * S1_BYTES));
+  constexpr int LDSB = 2 * S1_BYTES + (ST ? QST_BYTES : 0);
+  if (attr_once.need(ctx->device)) HIP_TRY(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDSB));
   int grid = a.tiles_m * a.tiles_n;
   const int cus = ctx->num_cu >= 8 ? ctx->num_cu & ~7 : ctx->num_cu;
   if (grid > cus) grid = cus;
-  hipLaunchKernelGGL(kern, dim3(grid), dim3(NTHR), 2 * S1_BYTES, ctx->stream, a);
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(NTHR), LDSB, ctx->stream, a);
   LAUNCH_CHECK();
   return 0;
 }
@@ -907,7 +1095,7 @@ int launch_big1p(eegldm_ctx* ctx, const BigArgs& a) {
 template <bool KBLK>
 int launch_big1(eegldm_ctx* ctx, const BigArgs& a) {
   EEG_ENV_VAR(bool, no_persist, getenv("EEGLDM_GEMM_BIG_NO_PERSIST") != nullptr || getenv("EEGLDM_GEMM_BIG1_NO_PERSIST") != nullptr);
-  if (!no_persist) return launch_big1p<KBLK, 4>(ctx, a);
+  if (!no_persist) return a.qstats ? launch_big1p<KBLK, 4, true>(ctx, a) : launch_big1p<KBLK, 4>(ctx, a);
   auto kern = gemm_big1_kernel<KBLK>;
   static DevOnce attr_once;
   if (attr_once.need(ctx->device)) HIP_TRY(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS1_BYTES));
@@ -916,15 +1104,30 @@ int launch_big1(eegldm_ctx* ctx, const BigArgs& a) {
   return 0;
 }
 
-template <bool KBLK, bool FLIP, int NLOAD>
+template <bool KBLK, bool FLIP, int NLOAD, bool ST = false>
 int launch_bigp(eegldm_ctx* ctx, const BigArgs& a) {
-  auto kern = gemm_bigp_kernel<KBLK, FLIP, NLOAD>;
+  auto kern = gemm_bigp_kernel<KBLK, FLIP, NLOAD, false, ST>;
   static DevOnce attr_once;      // the dynamic-LDS attribute is per device
-  if (attr_once.need(ctx->device)) HIP_TRY(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, RING));
+  constexpr int LDSB = RING + (ST ? QST_BYTES : 0);
+  if (attr_once.need(ctx->device)) HIP_TRY(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDSB));
   int grid = a.tiles_m * a.tiles_n;
   const int cus = ctx->num_cu >= 8 ? ctx->num_cu & ~7 : ctx->num_cu;      // a multiple of 8 keeps a workgroup's tiles on its XCD
   if (grid > cus) grid = cus;
-  hipLaunchKernelGGL(kern, dim3(grid), dim3(NTHR), RING, ctx->stream, a);
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(NTHR), LDSB, ctx->stream, a);
+  LAUNCH_CHECK();
+  return 0;
+}
+
+template <bool ST>
+int launch_bigx(eegldm_ctx* ctx, const BigArgs& a) {      // K extension: persistent form only
+  auto kern = gemm_bigp_kernel<true, false, 4, true, ST>;
+  static DevOnce attr_once;
+  constexpr int LDSB = RING + (ST ? QST_BYTES : 0);
+  if (attr_once.need(ctx->device)) HIP_TRY(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDSB));
+  int grid = a.tiles_m * a.tiles_n;
+  const int cus = ctx->num_cu >= 8 ? ctx->num_cu & ~7 : ctx->num_cu;
+  if (grid > cus) grid = cus;
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(NTHR), LDSB, ctx->stream, a);
   LAUNCH_CHECK();
   return 0;
 }
@@ -932,7 +1135,10 @@ int launch_bigp(eegldm_ctx* ctx, const BigArgs& a) {
 template <int TAPS, bool KBLK, bool FLIP>
 int launch_big(eegldm_ctx* ctx, const BigArgs& a) {
   EEG_ENV_VAR(bool, no_persist, getenv("EEGLDM_GEMM_BIG_NO_PERSIST") != nullptr);
-  if (!no_persist) return launch_bigp<KBLK, FLIP, 4>(ctx, a);      // (2 loader waves measured equal: tools/debug/gemm_big_check.py, round 4)
+  if (!no_persist) {      // (2 loader waves measured equal: tools/debug/gemm_big_check.py, round 4)
+    if constexpr (KBLK && !FLIP) { if (a.qstats) return launch_bigp<KBLK, FLIP, 4, true>(ctx, a); }
+    return launch_bigp<KBLK, FLIP, 4>(ctx, a);
+  }
   auto kern = gemm_big_kernel<TAPS, KBLK, FLIP>;
   static DevOnce attr_once;      // the dynamic-LDS attribute is per device
   if (attr_once.need(ctx->device)) HIP_TRY(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
@@ -969,9 +1175,50 @@ int gemm_big_try(eegldm_ctx* ctx, const GemmArgs& g) {
   a.C = (bf16_t*)g.C; a.ldc = g.ldc; a.M = g.M; a.N = g.N; a.K = g.K; a.L = L;
   a.bias = g.bias; a.rowvec = g.rowvec; a.ld_rowvec = g.ld_rowvec; a.rows_per_vec = g.rows_per_vec > 0 ? g.rows_per_vec : 1;
   a.resid = (const bf16_t*)g.resid; a.ldr = g.ldr; a.zero_page = ctx->zero_page; a.tiles_m = tm; a.tiles_n = tn;
+  a.A2 = nullptr; a.lda2 = 0; a.B2 = nullptr; a.K2 = 0; a.bias2 = nullptr;
+  // statistics epilogue: persistent kernels only, forward products (K-blocked 3-tap weights / plain 1-tap weights), whole tiles inside one sample
+  EEG_ENV_VAR(bool, no_persist_q, getenv("EEGLDM_GEMM_BIG_NO_PERSIST") != nullptr || getenv("EEGLDM_GEMM_BIG1_NO_PERSIST") != nullptr);
+  a.qstats = nullptr; a.qL = 0;
+  if (g.qstats && g.qstats_done && !no_persist_q && g.qstats_L > 0 && g.qstats_L % BM == 0 && !g.tap_flip && (conv3 ? g.b_kblk != 0 : !g.b_kblk)) {
+    a.qstats = g.qstats; a.qL = g.qstats_L; *g.qstats_done = 1;
+  }
   int rc;
   if (!conv3) rc = g.b_kblk ? launch_big1<true>(ctx, a) : launch_big1<false>(ctx, a);
   else if (g.tap_flip) rc = g.b_kblk ? launch_big<3, true, true>(ctx, a) : launch_big<3, false, true>(ctx, a);
   else rc = g.b_kblk ? launch_big<3, true, false>(ctx, a) : launch_big<3, false, false>(ctx, a);
+  return rc < 0 ? rc : 1;
+}
+
+// The ResBlock tail  out = conv3(a2; W) + bias + skip_1x1(x2; W2) + bias2  as ONE launch (K extension of the persistent 3-tap kernel).
+// g: the 3-tap forward conv (GA_CONV, stride 1, pad 1, K-blocked weight, no residual); w2_kblk: [K2 / 32][N][32] copy of the 1 x 1 weight.
+// 1 = launched, 0 = not eligible (the caller launches the two convs separately), < 0 = error.
+int gemm_big_skip_try(eegldm_ctx* ctx, const GemmArgs& g, const void* x2, long ldx2, const void* w2_kblk, int K2, const float* bias2) {
+  EEG_ENV_VAR(bool, off, getenv("EEGLDM_NO_GEMM_BIG") != nullptr || getenv("EEGLDM_NO_FUSED_SKIP") != nullptr || getenv("EEGLDM_GEMM_BIG_NO_PERSIST") != nullptr);
+  EEG_ENV_VAR(int, min_tiles, getenv("EEGLDM_GEMM_BIG_MIN_TILES") ? atoi(getenv("EEGLDM_GEMM_BIG_MIN_TILES")) : 128);
+  if (off || g.dtype != EEGLDM_BF16 || g.bmode != GB_NT || !g.b_kblk || g.batch > 1 || g.splitk > 1 || g.out_f32 || g.atomic_out || g.resid) return 0;
+  if (!(g.amode == GA_CONV && g.taps == 3 && g.stride == 1 && g.pad_l == 1 && g.Lin == g.Lout) || g.ups > 1 || g.alpha != 1.0f) return 0;
+  if (g.M % BM != 0 || g.Lout % BM != 0 || g.N % BN != 0 || g.K % BK != 0 || g.K < 2 * BK || g.lda % 8 != 0 || g.ldc % 8 != 0) return 0;
+  if (!x2 || !w2_kblk || K2 % BK != 0 || K2 < 2 * BK || ldx2 % 8 != 0) return 0;
+  if (g.rowvec && (g.rows_per_vec % BM != 0 || g.ld_rowvec % 4 != 0)) return 0;
+  if (((size_t)g.A | (size_t)g.B | (size_t)g.C | (size_t)x2 | (size_t)w2_kblk) & 15) return 0;
+  const int tm = g.M / BM, tn = g.N / BN;
+  if ((long)tm * tn < min_tiles) return 0;
+  BigArgs a;
+  a.A = (const bf16_t*)g.A; a.lda = g.lda; a.B = (const bf16_t*)g.B; a.ldb = g.ldb; a.sBt = g.sBt;
+  a.C = (bf16_t*)g.C; a.ldc = g.ldc; a.M = g.M; a.N = g.N; a.K = g.K; a.L = g.Lout;
+  a.bias = g.bias; a.rowvec = g.rowvec; a.ld_rowvec = g.ld_rowvec; a.rows_per_vec = g.rows_per_vec > 0 ? g.rows_per_vec : 1;
+  a.resid = nullptr; a.ldr = 0; a.zero_page = ctx->zero_page; a.tiles_m = tm; a.tiles_n = tn;
+  a.A2 = (const bf16_t*)x2; a.lda2 = ldx2; a.B2 = (const bf16_t*)w2_kblk; a.K2 = K2; a.bias2 = bias2;
+  a.qstats = nullptr; a.qL = 0;
+  if (g.qstats && g.qstats_done) { a.qstats = g.qstats; a.qL = g.Lout; *g.qstats_done = 1; }
+  ProfRec rec; const bool prof = ctx->prof_on;
+  if (prof) {
+    rec.cls = PROF_CONV_FWD; rec.flops = 2.0 * g.M * g.N * ((double)g.K * 3 + K2);
+    rec.M = g.M; rec.N = g.N; rec.K = g.K + K2 / 3; rec.taps = 3; rec.splitk = 1;
+    HIP_TRY(hipEventCreate(&rec.a)); HIP_TRY(hipEventCreate(&rec.b));
+    HIP_TRY(hipEventRecord(rec.a, ctx->stream));
+  }
+  const int rc = a.qstats ? launch_bigx<true>(ctx, a) : launch_bigx<false>(ctx, a);
+  if (prof) { HIP_TRY(hipEventRecord(rec.b, ctx->stream)); ctx->prof.push_back(rec); }
   return rc < 0 ? rc : 1;
 }

@@ -926,6 +926,65 @@ __global__ __launch_bounds__(NTB) void gn_bwd_pipe_kernel(const bf16_t* __restri
   }
 }
 
+// ------------------------------------------------------------------ forward from the producer's moments (round 5)
+// GroupNorm(+SiLU) forward of a 16-bit tensor as ONE streaming pass: the per-(sample, channel quad) sums / sums of squares were left by the
+// epilogue of the conv that wrote the tensor (gemm_big.hip big_qstats; a concatenated input [h | skip] has two producers, quads >= nqa
+// come from the second one), so nothing has to be resident and nothing is reduced here -- a thread folds the cpg / 4 quads of its group
+// (<= 8 pairs of doubles, L2-resident), scales its 8 channels and streams its rows.  The resident kernel is one load phase, two
+// barrier rounds and one store phase per block (3.9-4.6 TB/s); this one keeps loads and stores in flight together (the stand-alone
+// apply kernel of the split path measures 5.4 TB/s).  grid (row chunks, B); blockIdx.x == 0 writes the (mean, rstd) pairs of the tape.
+// Reference op: normalization(channels) + SiLU of /root/reference/src/models/unet.py:71-74,261-262,287-288.
+__global__ __launch_bounds__(NT) void gn_apply_q_kernel(const bf16_t* __restrict__ x, long ldx, const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                        const double* __restrict__ qsA, int nqa, const double* __restrict__ qsB, int nqb,
+                                                        float* __restrict__ stats, bf16_t* __restrict__ y, long ldy, int L, int C, int G, float eps,
+                                                        int silu, int rows_per_block) {
+  const int b = blockIdx.y, tid = threadIdx.x, cpg = C / G, ncols = C / 8;
+  const int TX = ncols < NT ? ncols : NT, TY = NT / TX;
+  if (tid >= TX * TY) return;
+  const int tx = tid % TX, ty = tid / TX;
+  const int l0 = blockIdx.x * rows_per_block, l1 = min(L, l0 + rows_per_block);
+  const double inv_n = 1.0 / ((double)cpg * (double)L);
+  for (int col = tx; col < ncols; col += TX) {
+    const int c = col * 8;
+    float ga[8], be[8];
+#pragma unroll
+    for (int h = 0; h < 2; h++) {
+      const int g = (c + 4 * h) / cpg;
+      float mean, rstd;
+      {
+        const int q0 = g * (cpg / 4), nq = cpg / 4;
+        double s1 = 0.0, s2 = 0.0;
+        for (int k = 0; k < nq; k++) {
+          const int qi = q0 + k;
+          const double* sp = qi < nqa ? qsA + ((long)b * nqa + qi) * 2 : qsB + ((long)b * nqb + (qi - nqa)) * 2;
+          s1 += sp[0]; s2 += sp[1];
+        }
+        const double mu = s1 * inv_n;
+        double var = s2 * inv_n - mu * mu; if (var < 0.0) var = 0.0;
+        mean = (float)mu; rstd = (float)(1.0 / sqrt(var + (double)eps));
+      }
+      if (blockIdx.x == 0 && ty == 0 && (c + 4 * h) % cpg == 0) { float* st = stats + ((long)b * G + g) * 2; st[0] = mean; st[1] = rstd; }
+#pragma unroll
+      for (int k = 0; k < 4; k++) { const float gm = gamma[c + 4 * h + k] * rstd; ga[4 * h + k] = gm; be[4 * h + k] = beta[c + 4 * h + k] - mean * gm; }
+    }
+    const bf16_t* xb = x + (long)b * L * ldx + c;
+    bf16_t* yb = y + (long)b * L * ldy + c;
+#pragma unroll 4
+    for (int l = l0 + ty; l < l1; l += TY) {
+      const uint4 r = *(const uint4*)(xb + (long)l * ldx);
+      const unsigned w[4] = {r.x, r.y, r.z, r.w};
+      unsigned o[4];
+#pragma unroll
+      for (int k = 0; k < 4; k++) {
+        float z0 = __uint_as_float(w[k] << 16) * ga[2 * k] + be[2 * k], z1 = __uint_as_float(w[k] & 0xffff0000u) * ga[2 * k + 1] + be[2 * k + 1];
+        if (silu) { z0 = silu_f(z0); z1 = silu_f(z1); }
+        o[k] = pack_bf16x2(z0, z1);
+      }
+      *(uint4*)(yb + (long)l * ldy) = make_uint4(o[0], o[1], o[2], o[3]);
+    }
+  }
+}
+
 // chunk width for the resident kernels: the widest whole-group chunk (<= 256 channels, dividing C) whose rows fit the
 // per-thread register budget; 0 = not eligible (fall back to the split kernels)
 int resident_chunk(int L, int C, int G, int resample_pair, int rpt_max, int* rpt_out, int nth = NTB) {
@@ -1516,6 +1575,35 @@ bool vec4_ok(int C, int G, long a, long b, long c, long d) {
 
 }  // namespace
 
+// 1 = launched, 0 = not this path's shape (the caller runs the ordinary forward)
+int gn_fwd_from_qstats(eegldm_ctx* ctx, const void* x, long ldx, const float* gamma, const float* beta, void* y, long ldy, float* stats,
+                       int B, int L, int C, int G, float eps, int silu, const double* qsA, int nqa, const double* qsB, int nqb) {
+  EEG_ENV_VAR(bool, off, getenv("EEGLDM_GN_NO_QSTATS") != nullptr);
+  if (off || eeg_deterministic() || !qsA || (nqa + nqb) * 4 != C || (nqb > 0 && !qsB) || C % 8 != 0 || G <= 0 || C % G != 0 || (C / G) % 4 != 0) return 0;
+  if (ldx % 8 != 0 || ldy % 8 != 0 || (((size_t)x | (size_t)y) & 15) || !stats) return 0;
+  // row chunks: a block's prologue (fold of the group moments, 16 scale / shift values per thread) is ~2 us of dependent L2 loads, so a
+  // thread streams at least 8 rows (first version: 12-row chunks = 3 rows per thread, 30 us on the 50 MB tensors against the resident
+  // kernel's 27); ~6 blocks per CU keep enough loads in flight
+  EEG_ENV_VAR(int, q_per_cu, getenv("EEGLDM_GN_Q_BLOCKS_PER_CU") ? atoi(getenv("EEGLDM_GN_Q_BLOCKS_PER_CU")) : 6);
+  const int ncols = C / 8, ty = ncols < NT ? NT / ncols : 1;
+  int rpb; const int ls = pick_lsplit(B, L, C, ctx, &rpb, q_per_cu, 8 * ty);
+  hipLaunchKernelGGL(gn_apply_q_kernel, dim3(ls, B), dim3(NT), 0, ctx->stream, (const bf16_t*)x, ldx, gamma, beta, qsA, nqa, qsB, nqb, stats,
+                     (bf16_t*)y, ldy, L, C, G, eps, silu, rpb);
+  LAUNCH_CHECK();
+  return 1;
+}
+
+extern "C" int eegldm_groupnorm_fwd_qstats(eegldm_ctx* ctx, const void* x, long ldx, const float* gamma, const float* beta, void* y, long ldy,
+                                           float* stats, int B, int L, int C, int G, float eps, int fuse_silu, const double* qs_a, int nq_a,
+                                           const double* qs_b, int nq_b, int dtype) {
+  EEG_CHECK(ctx && x && gamma && beta && y && stats && qs_a, "null pointer");
+  EEG_CHECK(dtype == EEGLDM_BF16, "the streaming forward from producer moments is a 16-bit path");
+  EEG_TRY(gn_check(ctx, B, L, C, G, 0, ldx));
+  const int rc = gn_fwd_from_qstats(ctx, x, ldx, gamma, beta, y, ldy, stats, B, L, C, G, eps, fuse_silu, qs_a, nq_a, qs_b, nq_b);
+  if (rc < 0) return rc;
+  EEG_CHECK(rc == 1, "not eligible: C %% 8, (C / G) %% 4, 16-byte rows, (nq_a + nq_b) * 4 == C, deterministic mode off");
+  return 0;
+}
 extern "C" int eegldm_groupnorm_fwd(eegldm_ctx* ctx, const void* x, long ldx, const float* gamma, const float* beta,
                                     void* y, long ldy, float* stats, int B, int L, int C, int G, float eps,
                                     int fuse_silu, int resample, void* xr, long ldxr, int dtype) {

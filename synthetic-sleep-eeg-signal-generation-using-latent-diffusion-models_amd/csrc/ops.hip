@@ -12,7 +12,8 @@ static inline int conv_lout(int Lin, int K, int stride, int pad_l, int pad_r) { 
 bool op_conv_fuses_act(int dtype, int Cin, int Cout, int K, long ldy) { return conv_is_thin(Cin, Cout, dtype) && dconv_fuses_act(dtype, Cin, Cout, K, ldy); }
 int op_conv_fwd(eegldm_ctx* ctx, int dtype, const void* x, long ldx, const void* w, const float* bias, void* y, long ldy,
                 int B, int Lin, int Cin, int Cout, int K, int stride, int pad_l, int pad_r,
-                const float* rowvec, long ld_rowvec, const void* resid, long ldr, float act_slope) {
+                const float* rowvec, long ld_rowvec, const void* resid, long ldr, float act_slope, double* qstats, int* qstats_done) {
+  if (qstats_done) *qstats_done = 0;
   EEG_CHECK(B > 0 && Lin > 0 && Cin > 0 && Cout > 0 && (K == 1 || K == 3) && (stride == 1 || stride == 2),
             "unsupported conv B=%d Lin=%d Cin=%d Cout=%d K=%d stride=%d", B, Lin, Cin, Cout, K, stride);
   const int Lout = conv_lout(Lin, K, stride, pad_l, pad_r);
@@ -35,6 +36,7 @@ int op_conv_fwd(eegldm_ctx* ctx, int dtype, const void* x, long ldx, const void*
   a.M = B * Lout; a.N = Cout; a.K = Cin; a.batch = 1; a.taps = K; a.alpha = 1.0f; a.bias = bias;
   a.rowvec = rowvec; a.ld_rowvec = ld_rowvec; a.rows_per_vec = Lout; a.resid = resid; a.ldr = ldr;
   a.bmode = GB_NT;
+  if (qstats && qstats_done && stride == 1) { a.qstats = qstats; a.qstats_L = Lout; a.qstats_done = qstats_done; }
   if (K == 1) {
     EEG_CHECK(stride == 1 && pad_l == 0 && pad_r == 0, "1x1 conv must be stride 1, no padding");
     a.amode = GA_PLAIN;
@@ -47,6 +49,27 @@ int op_conv_fwd(eegldm_ctx* ctx, int dtype, const void* x, long ldx, const void*
     }
   }
   return gemm_launch(ctx, a);
+}
+
+int op_conv3_skip_fwd(eegldm_ctx* ctx, int dtype, const void* x, long ldx, const void* w, const float* bias, const void* x2, long ldx2,
+                      const void* w2, const float* bias2, void* y, long ldy, int B, int L, int Cin, int Cin2, int Cout,
+                      const float* rowvec, long ld_rowvec, double* qstats, int* qstats_done) {
+  if (qstats_done) *qstats_done = 0;
+  if (dtype != EEGLDM_F32 && !ctx->kblk.empty() && !conv_is_thin(Cin, Cout, dtype)) {
+    auto it = ctx->kblk.find(w), it2 = ctx->kblk.find(w2);
+    if (it != ctx->kblk.end() && it2 != ctx->kblk.end()) {
+      GemmArgs a = {};
+      a.dtype = dtype; a.A = x; a.lda = ldx; a.B = it->second; a.b_kblk = 1; a.ldb = Cin; a.sBt = (long)Cout * Cin; a.C = y; a.ldc = ldy;
+      a.M = B * L; a.N = Cout; a.K = Cin; a.batch = 1; a.taps = 3; a.alpha = 1.0f; a.bias = bias; a.splitk = 1; a.ups = 1;
+      a.rowvec = rowvec; a.ld_rowvec = ld_rowvec; a.rows_per_vec = L; a.bmode = GB_NT;
+      a.amode = GA_CONV; a.Lout = L; a.Lin = L; a.stride = 1; a.pad_l = 1;
+      if (qstats && qstats_done) { a.qstats = qstats; a.qstats_L = L; a.qstats_done = qstats_done; }
+      const int rc = gemm_big_skip_try(ctx, a, x2, ldx2, it2->second, Cin2, bias2);
+      if (rc != 0) return rc < 0 ? rc : 0;
+    }
+  }
+  EEG_TRY(op_conv_fwd(ctx, dtype, x2, ldx2, w2, bias2, y, ldy, B, L, Cin2, Cout, 1, 1, 0, 0, nullptr, 0, nullptr, 0));
+  return op_conv_fwd(ctx, dtype, x, ldx, w, bias, y, ldy, B, L, Cin, Cout, 3, 1, 1, 1, rowvec, ld_rowvec, y, ldy, 0.f, qstats, qstats_done);
 }
 
 int op_conv_dgrad(eegldm_ctx* ctx, int dtype, const void* dy, long lddy, const void* w, void* dx, long lddx,
@@ -183,9 +206,11 @@ int op_wgrad_flush(eegldm_ctx* ctx) {
     const long tiles_total = recs[i].tiles * g.ngroup, S = ((long)g.K + recs[i].kstage - 1) / recs[i].kstage;
     long maxs = S / 8; if (maxs < 1) maxs = 1; if (maxs > 256) maxs = 256;
     double best = 1e30; int bs = 1;
+    EEG_ENV_VAR(double, c_fixed, getenv("EEGLDM_WGRAD_COST_FIXED") ? atof(getenv("EEGLDM_WGRAD_COST_FIXED")) : 8.0);
+    EEG_ENV_VAR(double, c_block, getenv("EEGLDM_WGRAD_COST_BLOCK") ? atof(getenv("EEGLDM_WGRAD_COST_BLOCK")) : 0.05);
     for (long sp = 1; sp <= maxs; sp++) {
       const long blocks = tiles_total * sp, rounds = (blocks + slots - 1) / slots;
-      const double cost = (double)rounds * ((double)S / (double)sp + 8.0) + 0.004 * (double)blocks;
+      const double cost = (double)rounds * ((double)S / (double)sp + c_fixed) + c_block * (double)blocks;
       if (cost < best) { best = cost; bs = (int)sp; }
     }
     g.splitk = bs; g.batch = g.ngroup;
@@ -257,15 +282,20 @@ int op_attention_bwd(eegldm_ctx* ctx, int dtype, const void* qkv, long ldq, cons
   const float alpha = 1.0f / sqrtf((float)C);
   GemmArgs g = {};
   const bool fused = attn_chain_ok(dtype, T, C, ldq, lddo) && lddq % 8 == 0;
+  // whole-sample blocks: the fused backward kernel also produces dK and (round 5) dV -- no batched TN GEMMs with K = T = 192 (three K
+  // stages per tile: 220-260 TF/s, 43 us per launch x 6)
+  EEG_ENV_VAR(bool, no_fused_v, getenv("EEGLDM_ATTN_NO_FUSED_DV") != nullptr);
+  const int fk = (fused && attn_chain_bwd_fuses_kv(ctx, B, T)) ? (no_fused_v ? 1 : 2) : 0;
+  if (fk != 2) {
   // dV[s][c] = sum_t P[t][s] dO[t][c]
   g.dtype = dtype; g.amode = GA_TR; g.bmode = GB_TR; g.A = probs; g.lda = T; g.sAb = (long)T * T; g.B = dout; g.ldb = lddo;
   g.sBb = (long)T * lddo; g.C = dv; g.ldc = lddq; g.sCb = (long)T * lddq; g.M = T; g.N = C; g.K = T; g.batch = B; g.taps = 1; g.alpha = 1.f;
   EEG_TRY(gemm_launch(ctx, g));
+  }
   if (fused) {
     // dP = dO V^T, dS = alpha P o (dP - rowsum(dP o P)), dQ = dS K in one launch; whole-sample blocks also produce dK = dS^T Q (a second
     // pass over the score tile in LDS, read transposed: no batched TN GEMM with K = T = 192 -- three K stages per tile, 260 TF/s -- and
     // no re-read of dS); otherwise dK below from the written dS
-    const int fk = attn_chain_bwd_fuses_kv(ctx, B, T) ? 1 : 0;
     EEG_TRY(attn_chain_bwd(ctx, qkv, ldq, probs, dout, lddo, dq, lddq, dlogits, B, T, C, fk));
     if (fk) return 0;
   } else {
@@ -297,10 +327,14 @@ extern "C" int eegldm_conv1d_fwd(eegldm_ctx* ctx, const void* x, long ldx, const
   return op_conv_fwd(ctx, dtype, x, ldx, w, bias, y, ldy, B, Lin, Cin, Cout, K, stride, pad_l, pad_r, rowvec, ld_rowvec, resid, ld_resid);
 }
 extern "C" int eegldm_conv1d_pack_kblocked(eegldm_ctx* ctx, const void* w, void* w_kblocked, int Cout, int Cin, int dtype) {
+  return eegldm_conv1d_pack_kblocked_k(ctx, w, w_kblocked, Cout, Cin, 3, dtype);
+}
+extern "C" int eegldm_conv1d_pack_kblocked_k(eegldm_ctx* ctx, const void* w, void* w_kblocked, int Cout, int Cin, int K, int dtype) {
+  EEG_CHECK(K == 1 || K == 3, "kernel size 1 or 3");
   EEG_CHECK(ctx && w && w_kblocked && w != w_kblocked, "null or aliased pointer");
   EEG_CHECK(dtype != EEGLDM_F32 && Cin > 0 && Cout > 0 && Cin % 32 == 0, "K-blocked weights: 16-bit dtype and Cin %% 32 == 0 (got dtype %d, Cin %d)", dtype, Cin);
   EEG_CHECK(((size_t)w % 16 == 0) && ((size_t)w_kblocked % 16 == 0), "weights must be 16-byte aligned");
-  EEG_TRY(kblk_pack_one(ctx, w, w_kblocked, Cout, Cin));
+  EEG_TRY(kblk_pack_one(ctx, w, w_kblocked, Cout, Cin, K));
   ctx->kblk[w] = w_kblocked;
   return 0;
 }
@@ -320,6 +354,19 @@ extern "C" int eegldm_conv1d_forget_kblocked(eegldm_ctx* ctx, const void* w) {
   EEG_CHECK(ctx && w, "null pointer");
   ctx->kblk.erase(w); ctx->kblk_t.erase(w);
   return 0;
+}
+extern "C" int eegldm_conv1d_fwd_qstats(eegldm_ctx* ctx, const void* x, long ldx, const void* w, const float* bias, void* y, long ldy,
+                                        int B, int Lin, int Cin, int Cout, int K, int stride, int pad_l, int pad_r,
+                                        const float* rowvec, long ld_rowvec, const void* resid, long ld_resid, int dtype, double* qstats, int* filled) {
+  EEG_CHECK(ctx && x && w && y && qstats && filled, "null pointer");
+  return op_conv_fwd(ctx, dtype, x, ldx, w, bias, y, ldy, B, Lin, Cin, Cout, K, stride, pad_l, pad_r, rowvec, ld_rowvec, resid, ld_resid, 0.f, qstats, filled);
+}
+extern "C" int eegldm_conv1d_skip_fwd(eegldm_ctx* ctx, const void* x, long ldx, const void* w, const float* bias, const void* x2, long ldx2,
+                                      const void* w2, const float* bias2, void* y, long ldy, int B, int L, int Cin, int Cin2, int Cout,
+                                      const float* rowvec, long ld_rowvec, int dtype) {
+  EEG_CHECK(ctx && x && w && x2 && w2 && y, "null pointer");
+  EEG_CHECK(B > 0 && L > 0 && Cin > 0 && Cin2 > 0 && Cout > 0, "bad sizes");
+  return op_conv3_skip_fwd(ctx, dtype, x, ldx, w, bias, x2, ldx2, w2, bias2, y, ldy, B, L, Cin, Cin2, Cout, rowvec, ld_rowvec);
 }
 extern "C" int eegldm_conv1d_bwd_data(eegldm_ctx* ctx, const void* dy, long lddy, const void* w, void* dx, long lddx, int B, int Lin,
                                       int Cin, int Cout, int K, int stride, int pad_l, int pad_r, const void* resid, long ld_resid, int dtype) {

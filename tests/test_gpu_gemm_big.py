@@ -193,3 +193,101 @@ def test_big_tile_race_screen_at_production_size(shape):
     finally:
         os.environ.pop("EEGLDM_NO_GEMM_BIG", None); G.lib.eegldm_debug_reload_env()
         G.check(G.lib.eegldm_conv1d_forget_kblocked(c.h, G.ptr(wd)))
+
+
+#          B, L,   Cmid, Cin2, Cout, rowvec      (Cmid -> Cout 3 taps over h; Cin2 -> Cout 1 tap over x: unet.py:302,327)
+CASES_SKIP = [(4, 192, 512, 1024, 512, 0), (2, 384, 256, 768, 256, 1), (3, 192, 256, 128, 256, 0), (2, 768, 256, 384, 256, 0), (5, 192, 512, 768, 512, 1),
+              (1, 192, 512, 192, 512, 0), (2, 192, 256, 96, 256, 0)]
+
+
+@pytest.mark.parametrize("case", CASES_SKIP)
+def test_skip_connection_as_further_k_stages_of_the_second_conv(case, env_switches):
+    """eegldm_conv1d_skip_fwd: conv3(h) + skip_1x1(x) in ONE launch (K extension of the persistent big-tile kernel) against torch's fp32 convs on
+    bf16-rounded operands, against the two separate launches (which round the intermediate to bf16: the fused result must be at least
+    as close to the fp32 reference), halo rows at sample edges, odd / even numbers of extra stages (2, 3, 6, 12, 16), odd numbers of
+    tiles per workgroup, and a race screen (the extra pieces run two phases ahead on counted waits)."""
+    import gpu_util as G
+    c = G.ctx(); dt = G.BF16
+    B, L, Cmid, Cin2, Cout, rv = case
+    h = torch.from_numpy(normal((B, Cmid, L), seed=11)).bfloat16().float()
+    x = torch.from_numpy(normal((B, Cin2, L), seed=12)).bfloat16().float()
+    w = (torch.from_numpy(normal((Cout, Cmid, 3), seed=41)) / math.sqrt(Cmid * 3)).bfloat16().float()
+    w2 = (torch.from_numpy(normal((Cout, Cin2, 1), seed=42)) / math.sqrt(Cin2)).bfloat16().float()
+    b = torch.from_numpy(normal((Cout,), seed=71)); b2 = torch.from_numpy(normal((Cout,), seed=72))
+    e = torch.from_numpy(normal((B, Cout), seed=101)) if rv else None
+    ref = F.conv1d(h, w, b, padding=1) + F.conv1d(x, w2, b2)
+    if rv: ref = ref + e[:, :, None]
+    hd, xd, wd, w2d = G.nlc(h, dt), G.nlc(x, dt), G.pack_w(w, dt), G.pack_w(w2, dt)
+    bd, b2d = b.to(G.DEV), b2.to(G.DEV); ed = e.to(G.DEV) if rv else None
+
+    def run(pack):
+        yd = torch.full((B * L, Cout), float("nan"), device=G.DEV, dtype=torch.bfloat16)
+        wk = w2k = None
+        if pack:
+            wk = torch.empty_like(wd); w2k = torch.empty_like(w2d)
+            G.check(G.lib.eegldm_conv1d_pack_kblocked(c.h, G.ptr(wd), G.ptr(wk), Cout, Cmid, dt))
+            G.check(G.lib.eegldm_conv1d_pack_kblocked_k(c.h, G.ptr(w2d), G.ptr(w2k), Cout, Cin2, 1, dt))
+        try:
+            G.check(G.lib.eegldm_conv1d_skip_fwd(c.h, G.ptr(hd), Cmid, G.ptr(wd), G.ptr(bd), G.ptr(xd), Cin2, G.ptr(w2d), G.ptr(b2d), G.ptr(yd), Cout,
+                                                 B, L, Cmid, Cin2, Cout, G.ptr(ed) if rv else None, Cout if rv else 0, dt))
+            torch.cuda.synchronize()
+        finally:
+            if pack:
+                G.check(G.lib.eegldm_conv1d_forget_kblocked(c.h, G.ptr(wd))); G.check(G.lib.eegldm_conv1d_forget_kblocked(c.h, G.ptr(w2d)))
+        return yd
+
+    env_switches(EEGLDM_GEMM_BIG_MIN_TILES="1")
+    c.prof_enable(True)
+    y_two = run(False)                                   # no K-blocked copies registered: two launches
+    n_two = len(_prof_rows(G, c))
+    y_one = run(True)
+    n_one = len(_prof_rows(G, c)) - n_two
+    c.prof_enable(False)
+    fused_ok = Cin2 % 64 == 0 and Cin2 >= 128
+    assert n_two == 2 and n_one == (1 if fused_ok else 2), (n_two, n_one)
+    G.assert_close(G.ncl(y_one, B, L), ref, **G.TOL[dt], name="fused")
+    G.assert_close(G.ncl(y_two, B, L), ref, **G.TOL[dt], name="two launches")
+    err_one = float((G.ncl(y_one, B, L) - ref).abs().mean()); err_two = float((G.ncl(y_two, B, L) - ref).abs().mean())
+    print(f"mean |error| vs fp32: fused {err_one:.3e}, two launches {err_two:.3e}")
+    if fused_ok:
+        assert err_one <= err_two * 1.02
+        # one rounding of the exact fp32 sum: every element within half a bf16 ulp (+ accumulation-order slack) of the fp32 reference
+        rel = ((G.ncl(y_one, B, L) - ref).abs() / (ref.abs() + 1e-2)).max()
+        assert float(rel) < 2.0 ** -7, float(rel)
+        for _ in range(10):                              # race screen
+            assert torch.equal(run(True).view(torch.int16), y_one.view(torch.int16))
+
+
+def _prof_rows(G, c):
+    import csv, os, tempfile
+    path = os.path.join(tempfile.gettempdir(), "eegldm_prof_rows.csv")
+    G.check(G.lib.eegldm_prof_dump(c.h, path.encode()))
+    with open(path) as fh:
+        return list(csv.DictReader(fh))
+
+
+def test_resblock_with_skip_connection_uses_the_fused_launch_and_matches_the_unfused_path(env_switches):
+    """Model level: a UNet forward with the fused ResBlock tails against the same forward with EEGLDM_NO_FUSED_SKIP=1 (bf16): equal up to the
+    one rounding the fusion removes; gradients (the backward does not change) equal up to what that input difference propagates."""
+    import gpu_util as G
+    from eegldm.models import UNetModel
+    from param_gen import gen_param, timesteps
+    cfg = dict(in_channels=1, out_channels=1, model_channels=128, num_res_blocks=1, attention_resolutions=[4], channel_mult=[1, 2, 4], resblock_updown=True)
+    net = UNetModel(image_size=768, **cfg, dtype="bfloat16")
+    net.load_state_dict({k: torch.from_numpy(gen_param(5, k, tuple(v.shape))) for k, v in net.state_dict().items()})
+    x = torch.from_numpy(normal((8, 1, 768), seed=3)).cuda(); t = torch.from_numpy(timesteps(8, seed=4)).cuda()
+    dy = torch.from_numpy(normal((8, 1, 768), seed=6)).cuda()
+    outs = {}
+    for name, sw in (("fused", None), ("plain", "1")):
+        env_switches(EEGLDM_NO_FUSED_SKIP=sw, EEGLDM_GEMM_BIG_MIN_TILES="1")
+        net.train(); net.zero_grad()
+        c = net.ctx; c.prof_enable(True)
+        y = net._forward_native(x, t)
+        rows = _prof_rows(G, c); c.prof_enable(False)
+        net.backward(dy)
+        outs[name] = (y.clone(), net.flat_grad.clone(), len(rows))
+    assert outs["fused"][2] < outs["plain"][2], (outs["fused"][2], outs["plain"][2])          # fewer GEMM launches
+    ya, yb = outs["fused"][0], outs["plain"][0]
+    assert float((ya - yb).abs().max()) <= 2e-2 * float(yb.abs().max())
+    ga, gb = outs["fused"][1], outs["plain"][1]
+    assert float((ga - gb).norm() / gb.norm()) < 2e-2
