@@ -265,6 +265,29 @@ int eegldm_fill(eegldm_ctx*, float* p, long n, float value);
 int eegldm_ldm_train_step(eegldm_unet*, const float* latents, const float* noise, const int64_t* t,
                           const float* acp, int pred_type, int B, int L, float grad_scale, float* loss);
 
+/* ------------------------------------------------------------------ AutoencoderKL / PatchDiscriminator primitives
+ * MONAI PatchDiscriminator layer `Convolution(.., norm=BATCH, act=LEAKYRELU(0.2))` (config/config_aekl_eeg.yaml:30-40; twin
+ * src/models/discriminator.py:47-66): y = LeakyReLU_slope(BatchNorm1d(x)) on NLC rows [rows][C].  training != 0: batch statistics
+ * (biased variance, eps 1e-5) and, when running_mean is given, the running-statistics update (momentum 0.1, unbiased variance,
+ * num_batches_tracked += 1 -- a float count); training == 0: running statistics.  stats [C][2] fp32 receives (mean, rstd) -- the
+ * tape of the backward.  gamma == NULL: plain LeakyReLU (no statistics).
+ * Backward: dx, and dgamma / dbeta ACCUMULATED (fp32 [C]); the statistics of the forward. */
+int eegldm_batchnorm_lrelu_fwd(eegldm_ctx*, const void* x, long ldx, const float* gamma, const float* beta, float* stats,
+                               float* running_mean, float* running_var, float* num_batches_tracked, void* y, long ldy,
+                               long rows, int C, float slope, int training, int dtype);
+int eegldm_batchnorm_lrelu_bwd(eegldm_ctx*, const void* x, long ldx, const float* gamma, const float* beta, const float* stats,
+                               const void* dy, long lddy, void* dx, long lddx, float* dgamma, float* dbeta, long rows, int C,
+                               float slope, int dtype);
+/* AutoencoderKL.sampling + the KL term of train_autoencoderkl.py:210-211 in one pass over n = B * latent * L' elements:
+ * sigma = exp(clamp(log_var, -30, 20) / 2) (fp32 out), z = mu + eps * sigma (eps NULL: z = mu), and
+ * *kl += (1 / B) * sum 0.5 * (mu^2 + sigma^2 - log sigma^2 - 1) when kl != NULL (zero it first).
+ * Backward of  <dz, z> + kl_weight * KL : dmu = dz + (kl_weight / B) mu;
+ * dlog_var = [-30 < log_var < 20] * (dz eps + (kl_weight / B)(sigma - 1 / sigma)) * sigma / 2.  dz NULL: the KL part alone. */
+int eegldm_kl_reparam_fwd(eegldm_ctx*, const void* mu, const void* log_var, const float* eps, void* z, float* sigma, float* kl,
+                          long n, int B, int dtype);
+int eegldm_kl_reparam_bwd(eegldm_ctx*, const void* mu, const void* log_var, const float* eps, const float* sigma, const void* dz,
+                          void* dmu, void* dlog_var, long n, float kl_weight_over_B, int dtype);
+
 /* ------------------------------------------------------------------ losses of the AEKL step (fp32 NCL tensors)
  * L1Loss (train_autoencoderkl.py:155,206): *loss = mean|a-b|; da_accum (nullable) += grad_weight * d/da.
  * PatchAdversarialLoss("least_squares") (:156,214,226,228): LeakyReLU(0.05) on the logits, MSE against 1 / 0;

@@ -55,6 +55,10 @@ SIGNATURES = {
     "eegldm_pack_conv_weight": [_vp, _vp, _vp, _i, _i, _i],
     "eegldm_conv1d_pack_kblocked": [_vp, _vp, _vp, _i, _i, _i],
     "eegldm_conv1d_pack_kblocked_k": [_vp, _vp, _vp, _i, _i, _i, _i],
+    "eegldm_batchnorm_lrelu_fwd": [_vp, _vp, _l, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _l, _l, _i, _f, _i, _i],
+    "eegldm_batchnorm_lrelu_bwd": [_vp, _vp, _l, _vp, _vp, _vp, _vp, _l, _vp, _l, _vp, _vp, _l, _i, _f, _i],
+    "eegldm_kl_reparam_fwd": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _l, _i, _i],
+    "eegldm_kl_reparam_bwd": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _l, _f, _i],
     "eegldm_conv1d_fwd_qstats": [_vp, _vp, _l, _vp, _vp, _vp, _l, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _l, _vp, _l, _i, _vp, C.POINTER(_i)],
     "eegldm_groupnorm_fwd_qstats": [_vp, _vp, _l, _vp, _vp, _vp, _l, _vp, _i, _i, _i, _i, _f, _i, _vp, _i, _vp, _i, _i],
     "eegldm_conv1d_skip_fwd": [_vp, _vp, _l, _vp, _vp, _vp, _l, _vp, _vp, _vp, _l, _i, _i, _i, _i, _i, _vp, _l, _i],

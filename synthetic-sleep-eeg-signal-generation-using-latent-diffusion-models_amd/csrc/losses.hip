@@ -491,6 +491,34 @@ int ls_reparam_bwd(eegldm_ctx* ctx, const void* mu, const void* lv, const float*
   LAUNCH_CHECK(); return 0;
 }
 
+// ================================================================== C ABI (primitives of the AutoencoderKL / PatchDiscriminator path)
+// BatchNorm1d (train: batch statistics + running-statistics update; eval: running statistics) + LeakyReLU(slope), NLC rows
+extern "C" int eegldm_batchnorm_lrelu_fwd(eegldm_ctx* ctx, const void* x, long ldx, const float* gamma, const float* beta, float* stats,
+                                          float* running_mean, float* running_var, float* num_batches_tracked, void* y, long ldy,
+                                          long rows, int C, float slope, int training, int dtype) {
+  EEG_CHECK(ctx && x && y && rows > 0 && C > 0, "bad argument");
+  EEG_CHECK(!gamma || (beta && stats), "BatchNorm needs gamma, beta and the statistics buffer");
+  return ls_bn_lrelu_fwd(ctx, x, ldx, gamma, beta, stats, running_mean, running_var, num_batches_tracked, y, ldy, rows, C, slope, training, dtype);
+}
+extern "C" int eegldm_batchnorm_lrelu_bwd(eegldm_ctx* ctx, const void* x, long ldx, const float* gamma, const float* beta, const float* stats,
+                                          const void* dy, long lddy, void* dx, long lddx, float* dgamma, float* dbeta, long rows, int C,
+                                          float slope, int dtype) {
+  EEG_CHECK(ctx && x && dy && dx && rows > 0 && C > 0, "bad argument");
+  EEG_CHECK(!gamma || (beta && stats && dgamma && dbeta), "BatchNorm backward needs gamma, beta, the forward statistics and both gradient buffers");
+  return ls_bn_lrelu_bwd(ctx, x, ldx, gamma, beta, stats, dy, lddy, dx, lddx, dgamma, dbeta, rows, C, slope, dtype);
+}
+// z = mu + eps * sigma, sigma = exp(clamp(log_var, -30, 20) / 2); kl (nullable) += KL(N(mu, sigma) || N(0, 1)) summed over elements / B
+extern "C" int eegldm_kl_reparam_fwd(eegldm_ctx* ctx, const void* mu, const void* log_var, const float* eps, void* z, float* sigma, float* kl,
+                                     long n, int B, int dtype) {
+  EEG_CHECK(ctx && mu && log_var && z && sigma && n > 0 && B > 0, "bad argument");
+  return ls_reparam(ctx, mu, log_var, eps, z, sigma, kl, n, B, dtype);
+}
+extern "C" int eegldm_kl_reparam_bwd(eegldm_ctx* ctx, const void* mu, const void* log_var, const float* eps, const float* sigma, const void* dz,
+                                     void* dmu, void* dlog_var, long n, float kl_weight_over_B, int dtype) {
+  EEG_CHECK(ctx && mu && log_var && sigma && dmu && dlog_var && n > 0, "bad argument");
+  return ls_reparam_bwd(ctx, mu, log_var, eps, sigma, dz, dmu, dlog_var, n, kl_weight_over_B, dtype, nullptr, nullptr, 1, 1);
+}
+
 // ================================================================== C ABI (losses)
 extern "C" int eegldm_l1_loss(eegldm_ctx* ctx, const float* a, const float* b, float* loss, float* da_accum, long n, float grad_weight) {
   EEG_CHECK(ctx && a && b && loss && n > 0, "bad argument");

@@ -217,6 +217,36 @@ def test_aekl_oracle_vs_reference_local_autoencoder(golden_dir):
         np.testing.assert_allclose(gr[:16].float().numpy(), g["g_head:" + k], rtol=2e-3, atol=2e-4 * max(1.0, gscale / 100))
 
 
+@pytest.mark.parametrize("fixture", ["aekl_twin_32_32_64_g1.npz", "aekl_twin_2_2_4_g1.npz"])
+def test_aekl_oracle_one_group_vs_reference_local_autoencoder(golden_dir, fixture):
+    """The same twin with the reference's Normalize (ae_kl.py:15-16) patched to ONE group (norm_num_groups: 1, what every AutoencoderKL
+    config asks for), at the production width and at [2,2,4] (config_aekl_eeg_2_2_4_spec.yaml): tests/golden/make_golden_r5.py."""
+    from oracle import aekl as A
+    from param_gen import eeg_windows
+    g = _load(golden_dir, fixture)
+    nc = [int(v) for v in g["num_channels"]]; B, L = int(g["B"]), int(g["L"])
+    cfg = dict(num_channels=nc, latent_channels=1, in_channels=1, out_channels=1, num_res_blocks=2, norm_num_groups=1)
+    sw, sx, se, sdy = [int(v) for v in g["seeds"]]
+    shapes = A.aekl_param_shapes(cfg)
+    assert list(shapes.keys()) == [str(k) for k in g["keys"]]
+    sd = {k: torch.from_numpy(gen_param(sw, k, s)).requires_grad_(True) for k, s in shapes.items()}
+    x = torch.from_numpy(eeg_windows(B, seed=sx, length=L, pad=8)).requires_grad_(True)
+    eps = torch.from_numpy(normal((B, 1, L // 4), seed=se)); dy = torch.from_numpy(normal((B, 1, L), seed=sdy))
+    recon, mu, sg = A.forward(sd, cfg, x, eps)
+    kl = Ls.kl_loss(mu, sg)
+    ((recon * dy).sum() + 0.3 * kl).backward()
+    np.testing.assert_allclose(recon.detach().numpy(), g["recon"], rtol=2e-4, atol=2e-5)
+    np.testing.assert_allclose(mu.detach().numpy(), g["z_mu"], rtol=2e-4, atol=2e-5)
+    np.testing.assert_allclose(sg.detach().numpy(), g["z_sigma"], rtol=2e-4, atol=2e-5)
+    assert abs(float(kl) - float(g["kl"])) < 1e-5 * abs(float(g["kl"]))
+    np.testing.assert_allclose(x.grad.numpy(), g["dx"], rtol=2e-3, atol=2e-4)
+    gscale = max(float(g["g_l2:" + k]) for k in shapes)
+    for k in shapes:
+        gr = sd[k].grad.double().reshape(-1); l2 = float(g["g_l2:" + k])
+        assert abs(float(gr.norm()) - l2) <= 1e-3 * l2 + 1e-5 * gscale, k
+        np.testing.assert_allclose(gr[:16].float().numpy(), g["g_head:" + k], rtol=2e-3, atol=2e-4 * max(1.0, gscale / 100))
+
+
 def _disc_twin_inputs(g):
     from oracle import aekl as A
     dcfg = dict(spatial_dims=1, num_layers_d=3, num_channels=64, in_channels=1, out_channels=1, kernel_size=3, norm="BATCH", bias=False, padding=1)
