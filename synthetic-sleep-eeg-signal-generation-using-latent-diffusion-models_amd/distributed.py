@@ -91,8 +91,9 @@ def allreduce_mean_flat(t, bucket_elems=BUCKET_ELEMS):
 class NativeComm:
     """RCCL communicator behind the C ABI (csrc/comm.hip, `eegldm_comm_*`): the gradient mean runs as ncclAvg collectives on the
     communicator's own stream, ordered after the Context's stream by an event, without going through torch.distributed.
-    Opt-in (`EEGLDM_NATIVE_COLLECTIVES=1`, see `make_comm`): it has only ever run with ONE rank -- no multi-GPU node was available to
-    the builder -- whereas the torch.distributed path is exercised with two processes (gloo) by the tests."""
+    Opt-in (`EEGLDM_NATIVE_COLLECTIVES=1`, see `make_comm`): with real RCCL it has only ever run with ONE rank -- no multi-GPU node was
+    available to the builder; its bucket arithmetic / stream ordering run for world 2 / 4 / 8 against a call-recording stand-in
+    (tests/test_gpu_comm_fake.py) -- whereas the torch.distributed path is exercised with two processes (gloo) by the tests."""
 
     def __init__(self, ctx, rank, world, unique_id):
         import ctypes as C
@@ -152,12 +153,30 @@ class NativeComm:
 
 def make_comm(ctx):
     """The native communicator when asked for (EEGLDM_NATIVE_COLLECTIVES=1) and more than one GPU rank is running, else None
-    (callers then use the torch.distributed collectives)."""
+    (callers then use the torch.distributed collectives -- ReduceOp.AVG on RCCL, so neither path makes a separate 1/world pass).
+
+    Why it is not the default: RCCL with more than one rank has never executed for this builder (no multi-GPU node), and the first run that
+    does is the driver's scaling bench.  torch.distributed's "nccl" backend IS RCCL over xGMI and is the path thousands of jobs exercise;
+    the C-ABI communicator binds to the same library but its multi-rank bring-up (ncclCommInitRank inside a process that already holds
+    torch's communicator) is only covered by a call-recording stand-in (tests/test_gpu_comm_fake.py).  `tools/first_multigpu.sh` runs both
+    on the first node that has two GPUs.  Creation is collective: every rank reports success and ALL fall back together if any failed."""
     if os.environ.get("EEGLDM_NATIVE_COLLECTIVES", "0") != "1" or not dist.is_initialized() or dist.get_world_size() == 1:
         return None
     if not torch.cuda.is_available():
         return None
-    return NativeComm.from_process_group(ctx)
+    comm, ok = None, 1
+    try:
+        comm = NativeComm.from_process_group(ctx)
+    except Exception as e:      # noqa: BLE001  (any failure on any rank: everybody falls back)
+        print(f"[eegldm] rank {dist.get_rank()}: native RCCL communicator failed ({e}); falling back to torch.distributed", flush=True)
+        ok = 0
+    flag = torch.tensor([ok], dtype=torch.int32, device=_comm_device())
+    dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+    if int(flag.item()) == 0:
+        if comm is not None:
+            comm.close()
+        return None
+    return comm
 
 
 class OverlappedGradSync:
