@@ -25,6 +25,7 @@ struct SamplerState {
   bool capture_failed = false;
   // embedding rows of all timesteps of a run (eager path): table [emb_cap][etot], scratch of the embedding MLP, timesteps on the device
   float *emb_table = nullptr, *emb_work = nullptr; int64_t* steps_dev = nullptr; int emb_cap = 0;
+  float* emb_row = nullptr;      // graph path: the ONE row the captured forward reads; the step's table row is copied here before every replay
 };
 std::map<GraphKey, SamplerState>& states() { static std::map<GraphKey, SamplerState> m; return m; }
 // guards the map AND serialises eegldm_sample: a call swaps ctx->stream for its duration, so two concurrent calls on contexts that
@@ -50,6 +51,7 @@ void sampler_release(const eegldm_unet* u) {
     if (s.emb_table) (void)hipFree(s.emb_table);
     if (s.emb_work) (void)hipFree(s.emb_work);
     if (s.steps_dev) (void)hipFree(s.steps_dev);
+    if (s.emb_row) (void)hipFree(s.emb_row);
     if (s.ev_in) (void)hipEventDestroy(s.ev_in);
     if (s.ev_out) (void)hipEventDestroy(s.ev_out);
     if (s.stream) (void)hipStreamDestroy(s.stream);
@@ -96,7 +98,17 @@ extern "C" int eegldm_sample(eegldm_unet* u, eegldm_aekl* ae, const float* noise
 
   auto set_t = [&](int64_t t) { hipLaunchKernelGGL(fill_i64_kernel, dim3((B + 255) / 256), dim3(256), 0, run, s.tt, B, t); };
   bool graph_ok = false;
+  const int etot = unet_emb_width(u);
+  struct ClearEmb { eegldm_unet* u; ~ClearEmb() { unet_set_shared_emb(u, nullptr); } } clear_emb{u};
+  EEG_ENV_VAR(bool, no_table, getenv("EEGLDM_SAMPLE_NO_EMB_TABLE") != nullptr);
   if (use_graph && !ctx->prof_on && !s.capture_failed) {
+    // Round 5: the captured forward reads its embedding projections from ONE fixed row (s.emb_row) that the loop below refills from the
+    // table of all timesteps before every replay -- until round 4 the graph path recomputed the embedding MLP and the 21 projections
+    // inside every replay (six launches, ~100 us at B = 1: 5 of the 10.6 ms by which the replayed DDIM-50 trailed the eager one).
+    if (!no_table) {
+      if (!s.emb_row) HIP_TRY(hipMalloc(&s.emb_row, sizeof(float) * (size_t)etot));
+      unet_set_shared_emb(u, s.emb_row);
+    }
     if (!s.exec) {
       // eager warm-up: grows the arena / workspaces (hipMalloc is not capturable), then capture the identical launch sequence
       set_t(timesteps_host[0]);
@@ -121,10 +133,8 @@ extern "C" int eegldm_sample(eegldm_unet* u, eegldm_aekl* ae, const float* noise
   // Eager path: the timesteps are known up front and shared by all samples, so the timestep-embedding MLP and the ResBlocks' embedding
   // projections run ONCE for all n_steps (one batch of n_steps rows) instead of six launches (~100 us at B = 1) inside every step;
   // each forward then reads its step's row with row stride 0.  EEGLDM_SAMPLE_NO_EMB_TABLE=1 restores the per-step computation.
-  EEG_ENV_VAR(bool, no_table, getenv("EEGLDM_SAMPLE_NO_EMB_TABLE") != nullptr);
-  const bool table = !graph_ok && !no_table;
-  struct ClearEmb { eegldm_unet* u; ~ClearEmb() { unet_set_shared_emb(u, nullptr); } } clear_emb{u};
-  const int etot = unet_emb_width(u);
+  const bool table = !no_table;
+  if (!graph_ok) unet_set_shared_emb(u, nullptr);      // (a failed capture falls back to the eager path below)
   if (table) {
     if (s.emb_cap < n_steps) {
       HIP_TRY(hipStreamSynchronize(run));
@@ -143,7 +153,8 @@ extern "C" int eegldm_sample(eegldm_unet* u, eegldm_aekl* ae, const float* noise
   }
 
   for (int i = 0; i < n_steps; i++) {
-    if (table) unet_set_shared_emb(u, s.emb_table + (size_t)i * etot);
+    if (table && graph_ok) HIP_TRY(hipMemcpyAsync(s.emb_row, s.emb_table + (size_t)i * etot, sizeof(float) * (size_t)etot, hipMemcpyDeviceToDevice, run));
+    else if (table) unet_set_shared_emb(u, s.emb_table + (size_t)i * etot);
     else set_t(timesteps_host[i]);
     if (graph_ok) HIP_TRY(hipGraphLaunch(s.exec, run));
     else EEG_TRY(eegldm_unet_forward(u, s.x, s.tt, s.out, B, L, 0));
