@@ -15,7 +15,7 @@ import torch
 pytestmark = pytest.mark.gpu
 
 
-def _scenario(neighbour="wgrad"):
+def _scenario(neighbour="wgrad", addend=True):
     import eegldm
     from eegldm._lib import lib, ptr, check, Context
     ctx = eegldm.default_context(0)
@@ -42,7 +42,7 @@ def _scenario(neighbour="wgrad"):
                     else:       # the 192 x 256 big-tile conv forward (gemm_big.hip: 148 KB of LDS, all of it filled by LDS-DMA)
                         check(lib.eegldm_conv1d_fwd(ctx2.h, ptr(xw), Cw, ptr(ww), None, ptr(yw), Cw, B, Lw, Cw, Cw, 3, 1, 1, 1, None, 0, None, 0, 1))
             for _ in range(8):
-                check(lib.eegldm_groupnorm_bwd(ctx.h, ptr(x), C, ptr(ga), ptr(be), ptr(st), ptr(dy), C, ptr(dx), C, ptr(dg), ptr(db), B, L, C, 32, 1, 0, ptr(ad), C, 1))
+                check(lib.eegldm_groupnorm_bwd(ctx.h, ptr(x), C, ptr(ga), ptr(be), ptr(st), ptr(dy), C, ptr(dx), C, ptr(dg), ptr(db), B, L, C, 32, 1, 0, ptr(ad) if addend else None, C if addend else 0, 1))
             torch.cuda.synchronize(); ctx2.sync()
             return dx, dg
         quiet, qg = run(False)
@@ -59,6 +59,13 @@ def _scenario(neighbour="wgrad"):
 @pytest.mark.parametrize("neighbour", ["wgrad", "conv_big"])
 def test_default_groupnorm_backward_is_bit_exact_beside_the_lds_dma_gemms_of_another_context(neighbour):
     assert _scenario(neighbour) == []
+
+
+@pytest.mark.parametrize("neighbour", ["wgrad", "conv_big"])
+def test_pipelined_groupnorm_backward_is_bit_exact_beside_the_lds_dma_gemms_of_another_context(neighbour):
+    """without a residual-path addend the backward is the persistent LDS-DMA kernel gn_bwd_pipe_kernel (one workgroup per CU, 155 KB of
+    LDS) -- the standing co-run screen for it beside the weight-gradient GEMM and the big-tile conv of a second context, bit for bit."""
+    assert _scenario(neighbour, addend=False) == []
 
 
 def test_narrow_blocks_are_refused_while_a_second_context_is_alive(env_switches):
