@@ -367,13 +367,13 @@ def main():
         # were collected on and `traffic_stale` says whether that is still the build being timed.
         traffic, traffic_src, traffic_stale, mfma_util = None, None, None, None
         if args.dtype == "bf16" and args.batch == 256:
-            for fname in ("r04_pmc_hbm_traffic.json", "r03_pmc_hbm_traffic.json", "r02_pmc_hbm_traffic.json", "r01_pmc_hbm_traffic.json"):
+            for fname in ("r05_pmc_hbm_traffic.json", "r04_pmc_hbm_traffic.json", "r03_pmc_hbm_traffic.json", "r02_pmc_hbm_traffic.json", "r01_pmc_hbm_traffic.json"):
                 pj, stale = load_pmc(fname)
                 if pj and k in pj.get("classes", {}):
                     traffic = round(pj["classes"][k]["hbm_bytes_per_launch"]); traffic_stale = bool(stale)
                     traffic_src = f"profiles/{fname} (bytes per launch, B=256 bf16)"
                     break
-            for fname in ("r04_pmc_mfma_busy.json", "r03_pmc_mfma_busy.json", "r02_pmc_mfma_busy.json", "r01_pmc_mfma_busy.json"):
+            for fname in ("r05_pmc_mfma_busy.json", "r04_pmc_mfma_busy.json", "r03_pmc_mfma_busy.json", "r02_pmc_mfma_busy.json", "r01_pmc_mfma_busy.json"):
                 pm, _st = load_pmc(fname)
                 if pm and k in pm.get("classes", {}):
                     mfma_util = pm["classes"][k]["MfmaUtil_pct"]
@@ -418,7 +418,7 @@ def main():
         fbytes = aekl_gan_step_bytes([2, 2, 4], 4 * L, esz, fused=True) * Ba + 16 * (int(ae2.flat.numel()) + int(disc.flat.numel()))
         fused_ach = fbytes / dtg / 1e9
         pj, stale = None, None
-        for aekl_pmc_name in ("r04_pmc_aekl_step.json", "r03_pmc_aekl_step.json", "r02_pmc_aekl_step.json"):
+        for aekl_pmc_name in ("r05_pmc_aekl_step.json", "r04_pmc_aekl_step.json", "r03_pmc_aekl_step.json", "r02_pmc_aekl_step.json"):
             pj, stale = load_pmc(aekl_pmc_name)
             if pj is not None:
                 break
