@@ -34,10 +34,16 @@
 extern "C" {
 #endif
 
-/* 4: + eegldm_ctx_stream, eegldm_linear_bwd, eegldm_disc_feature, eegldm_usleep_*, eegldm_feature_moments (additive). */
-#define EEGLDM_ABI_VERSION 5
+/* 4: + eegldm_ctx_stream, eegldm_linear_bwd, eegldm_disc_feature, eegldm_usleep_*, eegldm_feature_moments (additive).
+ * 6 (round 5): + EEGLDM_F16, eegldm_conv1d_skip_fwd, eegldm_conv1d_fwd_qstats, eegldm_groupnorm_fwd_qstats, eegldm_batchnorm_lrelu_*,
+ *    eegldm_kl_reparam_*, eegldm_conv1d_pack_kblocked_k (additive). */
+#define EEGLDM_ABI_VERSION 6
 
-enum { EEGLDM_F32 = 0, EEGLDM_BF16 = 1 };
+/* Storage / operand type of activations and compute-copy weights (accumulation, statistics, master weights and optimizer state are
+ * always fp32).  EEGLDM_F16 = IEEE half: the type the reference trains in under `autocast` (src/training/training.py:423) with its
+ * GradScaler (:334,441-443); it runs on the general kernels (gemm.hip, direct_conv.hip, norm.hip, elementwise.hip, losses.hip) --
+ * the bf16-only fast paths (192 x 256 tiles, weight-stationary / few-row convs, fused attention, fused frozen encoder) are not taken. */
+enum { EEGLDM_F32 = 0, EEGLDM_BF16 = 1, EEGLDM_F16 = 2 };
 enum {
   EEGLDM_OK = 0,
   EEGLDM_ERR_INVALID = -1,

@@ -14,16 +14,17 @@ import contextlib
 import torch
 
 _ON = False
+_FMT = torch.bfloat16          # storage format being emulated (round 5: torch.float16 for the engine's EEGLDM_F16 mode)
 
 
-class _RoundBF16(torch.autograd.Function):
+class _RoundBF16(torch.autograd.Function):      # (name kept: rounds to the CURRENT storage format)
     @staticmethod
     def forward(ctx, x):
-        return x.to(torch.bfloat16).to(torch.float32)
+        return x.to(_FMT).to(torch.float32)
 
     @staticmethod
     def backward(ctx, g):
-        return g.to(torch.bfloat16).to(torch.float32)
+        return g.to(_FMT).to(torch.float32)
 
 
 def q(x):
@@ -35,14 +36,20 @@ def qw(w):
     """Weight read point: the engine's GEMMs read a bf16 copy of the fp32 master weights (the gradient stays fp32)."""
     if not _ON or w.dtype != torch.float32:
         return w
-    return w + (w.to(torch.bfloat16).to(torch.float32) - w).detach()
+    return w + (w.to(_FMT).to(torch.float32) - w).detach()
 
 
 @contextlib.contextmanager
-def bf16_storage(on=True):
-    global _ON
-    prev, _ON = _ON, bool(on)
+def bf16_storage(on=True, fmt=torch.bfloat16):
+    global _ON, _FMT
+    prev, prev_fmt = _ON, _FMT
+    _ON, _FMT = bool(on), fmt
     try:
         yield
     finally:
-        _ON = prev
+        _ON, _FMT = prev, prev_fmt
+
+
+def f16_storage(on=True):
+    """The same emulation with IEEE half as the storage format (the reference's autocast dtype, src/training/training.py:423)."""
+    return bf16_storage(on, torch.float16)

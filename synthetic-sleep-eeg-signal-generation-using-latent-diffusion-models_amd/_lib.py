@@ -9,7 +9,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("EEGLDM_LIB") or os.path.join(_HERE, "libeegldm.so")   # EEGLDM_LIB: developer override (instrumented builds)
 
-F32, BF16 = 0, 1
+F32, BF16, F16 = 0, 1, 2
 PRED = {"epsilon": 0, "v_prediction": 1, "sample": 2}
 
 

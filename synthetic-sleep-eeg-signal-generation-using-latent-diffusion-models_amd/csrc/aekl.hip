@@ -363,7 +363,7 @@ bool thin_ready(eegldm_aekl* a, int L) {
 extern "C" int eegldm_aekl_create(eegldm_ctx* ctx, const eegldm_aekl_cfg* cfg, eegldm_aekl** out) {
   EEG_CHECK(ctx && cfg && out, "null argument");
   EEG_CHECK(cfg->n_levels >= 1 && cfg->n_levels <= 8 && cfg->num_res_blocks >= 1, "bad num_channels / num_res_blocks");
-  EEG_CHECK(cfg->dtype == EEGLDM_F32 || cfg->dtype == EEGLDM_BF16, "bad dtype");
+  EEG_CHECK(cfg->dtype == EEGLDM_F32 || cfg->dtype == EEGLDM_BF16 || cfg->dtype == EEGLDM_F16, "bad dtype");
   for (int i = 0; i < cfg->n_levels; i++)
     EEG_CHECK(cfg->num_channels[i] % cfg->norm_num_groups == 0, "num_channels[%d]=%d not divisible by norm_num_groups=%d", i, cfg->num_channels[i], cfg->norm_num_groups);
   eegldm_aekl* a = new eegldm_aekl();

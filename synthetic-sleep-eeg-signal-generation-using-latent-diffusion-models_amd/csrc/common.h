@@ -138,17 +138,44 @@ __device__ __forceinline__ float bf16_to_f32(bf16_t v) { return __uint_as_float(
 // and every other epilogue was correct only because enough instructions happened to sit in between.
 typedef float eeg_f32x2 __attribute__((ext_vector_type(2)));
 typedef __bf16 eeg_bf16x2 __attribute__((ext_vector_type(2)));
+typedef _Float16 eeg_f16x2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ unsigned pack_bf16x2(float lo, float hi) {
   const eeg_f32x2 v = {lo, hi};
   return __builtin_bit_cast(unsigned, __builtin_convertvector(v, eeg_bf16x2));     // one v_cvt_pk_bf16_f32 on gfx950
 }
 __device__ __forceinline__ bf16_t f32_to_bf16(float f) { return (bf16_t)(pack_bf16x2(f, f) & 0xffffu); }
+// IEEE half storage (EEGLDM_F16, round 5): a DISTINCT type so that templates can tell the two 16-bit formats apart (bf16_t is a plain
+// unsigned short).  Same size and alignment: every layout / tiling decision keyed on sizeof(T) == 2 holds for both.
+struct f16_t { unsigned short v; };
+__device__ __forceinline__ unsigned pack_f16x2(float lo, float hi) {
+  const eeg_f32x2 v = {lo, hi};
+  return __builtin_bit_cast(unsigned, __builtin_convertvector(v, eeg_f16x2));      // round-to-nearest-even
+}
+// 16-bit pairs packed in a 32-bit word (element 0 in the low half), by storage type
+template <typename T> __device__ __forceinline__ float w16_lo(unsigned w);
+template <typename T> __device__ __forceinline__ float w16_hi(unsigned w);
+template <typename T> __device__ __forceinline__ unsigned pack16x2(float lo, float hi);
+template <> __device__ __forceinline__ float w16_lo<bf16_t>(unsigned w) { return __uint_as_float(w << 16); }
+template <> __device__ __forceinline__ float w16_hi<bf16_t>(unsigned w) { return __uint_as_float(w & 0xffff0000u); }
+template <> __device__ __forceinline__ unsigned pack16x2<bf16_t>(float lo, float hi) { return pack_bf16x2(lo, hi); }
+template <> __device__ __forceinline__ float w16_lo<f16_t>(unsigned w) { return (float)__builtin_bit_cast(eeg_f16x2, w)[0]; }
+template <> __device__ __forceinline__ float w16_hi<f16_t>(unsigned w) { return (float)__builtin_bit_cast(eeg_f16x2, w)[1]; }
+template <> __device__ __forceinline__ unsigned pack16x2<f16_t>(float lo, float hi) { return pack_f16x2(lo, hi); }
+// (so that code under `if constexpr (sizeof(T) == 2)` also parses for T = float)
+template <> __device__ __forceinline__ float w16_lo<float>(unsigned w) { return __uint_as_float(w); }
+template <> __device__ __forceinline__ float w16_hi<float>(unsigned w) { return __uint_as_float(w); }
+template <> __device__ __forceinline__ unsigned pack16x2<float>(float lo, float) { return __float_as_uint(lo); }
+template <typename T> struct Is16 { static constexpr bool bf16 = false, f16 = false; };
+template <> struct Is16<bf16_t> { static constexpr bool bf16 = true, f16 = false; };
+template <> struct Is16<f16_t> { static constexpr bool bf16 = false, f16 = true; };
 template <typename T> __device__ __forceinline__ float ld_f32(const T* p);
 template <> __device__ __forceinline__ float ld_f32<float>(const float* p) { return *p; }
 template <> __device__ __forceinline__ float ld_f32<bf16_t>(const bf16_t* p) { return bf16_to_f32(*p); }
+template <> __device__ __forceinline__ float ld_f32<f16_t>(const f16_t* p) { return (float)__builtin_bit_cast(_Float16, p->v); }
 template <typename T> __device__ __forceinline__ void st_f32(T* p, float v);
 template <> __device__ __forceinline__ void st_f32<float>(float* p, float v) { *p = v; }
 template <> __device__ __forceinline__ void st_f32<bf16_t>(bf16_t* p, float v) { *p = f32_to_bf16(v); }
+template <> __device__ __forceinline__ void st_f32<f16_t>(f16_t* p, float v) { p->v = __builtin_bit_cast(unsigned short, (_Float16)v); }
 
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll

@@ -759,7 +759,7 @@ int dconv_run(eegldm_ctx* ctx, int dtype, bool dgrad, const void* in, long ldin,
 #define DROW(T_, CI_, CO_) hipLaunchKernelGGL((dconv_row_kernel<T_, CI_, CO_>), g, dim3(NT), 0, ctx->stream, a)
 #define DROW_CO(T_, CI_) do { if (co == 1) DROW(T_, CI_, 1); else if (co == 2) DROW(T_, CI_, 2); else if (co == 4) DROW(T_, CI_, 4); else DROW(T_, CI_, 8); } while (0)
 #define DROW_T(T_) do { if (ci == 1) DROW_CO(T_, 1); else if (ci == 2) DROW_CO(T_, 2); else if (ci == 4) DROW_CO(T_, 4); else DROW_CO(T_, 8); } while (0)
-    if (dtype == EEGLDM_F32) DROW_T(float); else DROW_T(bf16_t);
+    if (dtype == EEGLDM_F32) DROW_T(float); else if (dtype == EEGLDM_F16) DROW_T(f16_t); else DROW_T(bf16_t);
 #undef DROW_T
 #undef DROW_CO
 #undef DROW
@@ -779,6 +779,7 @@ int dconv_run(eegldm_ctx* ctx, int dtype, bool dgrad, const void* in, long ldin,
         constexpr int SEG = 128;
         const dim3 gs((a.Lo + SEG - 1) / SEG, a.B);
         if (dtype == EEGLDM_F32) hipLaunchKernelGGL((dconv_in1_seg_kernel<float, SEG>), gs, dim3(NT), 0, ctx->stream, a);
+        else if (dtype == EEGLDM_F16) hipLaunchKernelGGL((dconv_in1_seg_kernel<f16_t, SEG>), gs, dim3(NT), 0, ctx->stream, a);
         else hipLaunchKernelGGL((dconv_in1_seg_kernel<bf16_t, SEG>), gs, dim3(NT), 0, ctx->stream, a);
         LAUNCH_CHECK();
         return 0;
@@ -786,7 +787,7 @@ int dconv_run(eegldm_ctx* ctx, int dtype, bool dgrad, const void* in, long ldin,
       if (reg_ok && a.Ci <= 4 && gpr <= NT && NT % gpr == 0 && rows < (1L << 30)) {
 #define DTI(T_, CI_) hipLaunchKernelGGL((dconv_thin_in_reg_kernel<T_, CI_>), g, dim3(NT), 0, ctx->stream, a)
 #define DTI_T(T_) do { if (a.Ci == 1) DTI(T_, 1); else if (a.Ci == 2) DTI(T_, 2); else DTI(T_, 4); } while (0)
-        if (dtype == EEGLDM_F32) DTI_T(float); else DTI_T(bf16_t);
+        if (dtype == EEGLDM_F32) DTI_T(float); else if (dtype == EEGLDM_F16) DTI_T(f16_t); else DTI_T(bf16_t);
 #undef DTI_T
 #undef DTI
         LAUNCH_CHECK();
@@ -794,6 +795,7 @@ int dconv_run(eegldm_ctx* ctx, int dtype, bool dgrad, const void* in, long ldin,
       }
       const size_t sh = ((size_t)K * a.Ci * a.Co + a.Co) * sizeof(float);
       if (dtype == EEGLDM_F32) hipLaunchKernelGGL((dconv_thin_in_kernel<float>), g, dim3(NT), sh, ctx->stream, a);
+      else if (dtype == EEGLDM_F16) hipLaunchKernelGGL((dconv_thin_in_kernel<f16_t>), g, dim3(NT), sh, ctx->stream, a);
       else hipLaunchKernelGGL((dconv_thin_in_kernel<bf16_t>), g, dim3(NT), sh, ctx->stream, a);
       LAUNCH_CHECK();
       return 0;
@@ -807,6 +809,7 @@ int dconv_run(eegldm_ctx* ctx, int dtype, bool dgrad, const void* in, long ldin,
         const long nruns = rows / RUN;
         const dim3 gr(grid_cap((nruns + rpb - 1) / rpb, ctx));
         if (dtype == EEGLDM_F32) hipLaunchKernelGGL((dconv_thin_out_run_kernel<float, RUN>), gr, dim3(NT), 0, ctx->stream, a);
+        else if (dtype == EEGLDM_F16) hipLaunchKernelGGL((dconv_thin_out_run_kernel<f16_t, RUN>), gr, dim3(NT), 0, ctx->stream, a);
         else hipLaunchKernelGGL((dconv_thin_out_run_kernel<bf16_t, RUN>), gr, dim3(NT), 0, ctx->stream, a);
         LAUNCH_CHECK();
         return 0;
@@ -814,6 +817,7 @@ int dconv_run(eegldm_ctx* ctx, int dtype, bool dgrad, const void* in, long ldin,
       const dim3 g(grid_cap((rows + rpb - 1) / rpb, ctx));
       const size_t sh = (size_t)K * a.Co * a.Ci * sizeof(float);
       if (dtype == EEGLDM_F32) hipLaunchKernelGGL((dconv_thin_out_kernel<float>), g, dim3(NT), sh, ctx->stream, a);
+      else if (dtype == EEGLDM_F16) hipLaunchKernelGGL((dconv_thin_out_kernel<f16_t>), g, dim3(NT), sh, ctx->stream, a);
       else hipLaunchKernelGGL((dconv_thin_out_kernel<bf16_t>), g, dim3(NT), sh, ctx->stream, a);
       LAUNCH_CHECK();
       return 0;
@@ -822,6 +826,9 @@ int dconv_run(eegldm_ctx* ctx, int dtype, bool dgrad, const void* in, long ldin,
   if (dtype == EEGLDM_F32) {
     if (rowdot) hipLaunchKernelGGL((dconv_rowdot_kernel<float>), dim3(grid_cap((rows + 3) / 4, ctx)), dim3(NT), 0, ctx->stream, a);
     else hipLaunchKernelGGL((dconv_point_kernel<float>), dim3(grid_cap((rows * a.Co + NT - 1) / NT, ctx)), dim3(NT), 0, ctx->stream, a);
+  } else if (dtype == EEGLDM_F16) {
+    if (rowdot) hipLaunchKernelGGL((dconv_rowdot_kernel<f16_t>), dim3(grid_cap((rows + 3) / 4, ctx)), dim3(NT), 0, ctx->stream, a);
+    else hipLaunchKernelGGL((dconv_point_kernel<f16_t>), dim3(grid_cap((rows * a.Co + NT - 1) / NT, ctx)), dim3(NT), 0, ctx->stream, a);
   } else {
     if (rowdot) hipLaunchKernelGGL((dconv_rowdot_kernel<bf16_t>), dim3(grid_cap((rows + 3) / 4, ctx)), dim3(NT), 0, ctx->stream, a);
     else hipLaunchKernelGGL((dconv_point_kernel<bf16_t>), dim3(grid_cap((rows * a.Co + NT - 1) / NT, ctx)), dim3(NT), 0, ctx->stream, a);
@@ -850,7 +857,7 @@ int dconv_wgrad(eegldm_ctx* ctx, int dtype, const void* x, long ldx, const void*
                                              parts, B, Lout, Lin, K, stride, pad_l)
 #define DWV_CO(T_, CI_) do { if (Cout == 1) DWV(T_, CI_, 1); else if (Cout == 2) DWV(T_, CI_, 2); else DWV(T_, CI_, 4); } while (0)
 #define DWV_T(T_) do { if (Cin == 1) DWV_CO(T_, 1); else if (Cin == 2) DWV_CO(T_, 2); else DWV_CO(T_, 4); } while (0)
-      if (dtype == EEGLDM_F32) DWV_T(float); else DWV_T(bf16_t);
+      if (dtype == EEGLDM_F32) DWV_T(float); else if (dtype == EEGLDM_F16) DWV_T(f16_t); else DWV_T(bf16_t);
 #undef DWV_T
 #undef DWV_CO
 #undef DWV
@@ -868,6 +875,9 @@ int dconv_wgrad(eegldm_ctx* ctx, int dtype, const void* x, long ldx, const void*
     const int tb = eeg_deterministic() ? 1 : blocks;      // one atomic per element and block: a single block is a single writer
     if (dtype == EEGLDM_F32)
       hipLaunchKernelGGL((dconv_wgrad_tiny_kernel<float>), dim3(tb), dim3(NT), 0, ctx->stream, (const float*)x, ldx, (const float*)dy, lddy,
+                         dw, B, Lout, Lin, Cout, Cin, K, stride, pad_l);
+    else if (dtype == EEGLDM_F16)
+      hipLaunchKernelGGL((dconv_wgrad_tiny_kernel<f16_t>), dim3(tb), dim3(NT), 0, ctx->stream, (const f16_t*)x, ldx, (const f16_t*)dy, lddy,
                          dw, B, Lout, Lin, Cout, Cin, K, stride, pad_l);
     else
       hipLaunchKernelGGL((dconv_wgrad_tiny_kernel<bf16_t>), dim3(tb), dim3(NT), 0, ctx->stream, (const bf16_t*)x, ldx, (const bf16_t*)dy, lddy,
@@ -888,7 +898,7 @@ int dconv_wgrad(eegldm_ctx* ctx, int dtype, const void* x, long ldx, const void*
       // blocks per sample: enough blocks to fill the chip four times over (each thread then has <= 8-16 independent row loads in flight)
       int nsegs = (int)((4L * ctx->num_cu + B - 1) / B); if (nsegs < 1) nsegs = 1;
       int segr = (Lout + nsegs - 1) / nsegs; segr = (segr + rpb - 1) / rpb * rpb; nsegs = (Lout + segr - 1) / segr;
-      if (in1out_ok && wide_in && Cout == 1 && stride == 1 && Lin == Lout && Lout <= 1024 && pad_l <= 2 && K - 1 - pad_l <= 2 && dtype != EEGLDM_F32 && B <= 65535 &&
+      if (in1out_ok && wide_in && Cout == 1 && stride == 1 && Lin == Lout && Lout <= 1024 && pad_l <= 2 && K - 1 - pad_l <= 2 && dtype == EEGLDM_BF16 && B <= 65535 &&
           (size_t)B * nsegs * K * Cin * sizeof(float) <= (16u << 20)) {
         float* parts1 = (float*)((char*)ctx->scratch + (8u << 20));
         hipLaunchKernelGGL((dconv_wgrad_in1out_kernel<bf16_t>), dim3(B, nsegs), dim3(NT), 0, ctx->stream, (const bf16_t*)x, ldx, (const bf16_t*)dy, lddy, parts1, Lout, Cin, K, pad_l, segr);
@@ -902,6 +912,7 @@ int dconv_wgrad(eegldm_ctx* ctx, int dtype, const void* x, long ldx, const void*
 #define DWT(T_, WO_) hipLaunchKernelGGL((dconv_wgrad_wt_kernel<T_, WO_>), dim3((unsigned)nb), dim3(NT), 0, ctx->stream, (const T_*)x, ldx, (const T_*)dy, lddy, \
                                         dw, parts, B, Lout, Lin, Cout, Cin, K, stride, pad_l)
       if (dtype == EEGLDM_F32) { if (wide_out) DWT(float, true); else DWT(float, false); }
+      else if (dtype == EEGLDM_F16) { if (wide_out) DWT(f16_t, true); else DWT(f16_t, false); }
       else { if (wide_out) DWT(bf16_t, true); else DWT(bf16_t, false); }
 #undef DWT
       LAUNCH_CHECK();
@@ -917,6 +928,9 @@ int dconv_wgrad(eegldm_ctx* ctx, int dtype, const void* x, long ldx, const void*
   if (dtype == EEGLDM_F32)
     hipLaunchKernelGGL((dconv_wgrad_kernel<float>), dim3((unsigned)blocks), dim3(NT), 0, ctx->stream, (const float*)x, ldx,
                        (const float*)dy, lddy, dw, B, Lout, Lin, Cout, Cin, K, stride, pad_l, rpc);
+  else if (dtype == EEGLDM_F16)
+    hipLaunchKernelGGL((dconv_wgrad_kernel<f16_t>), dim3((unsigned)blocks), dim3(NT), 0, ctx->stream, (const f16_t*)x, ldx,
+                       (const f16_t*)dy, lddy, dw, B, Lout, Lin, Cout, Cin, K, stride, pad_l, rpc);
   else
     hipLaunchKernelGGL((dconv_wgrad_kernel<bf16_t>), dim3((unsigned)blocks), dim3(NT), 0, ctx->stream, (const bf16_t*)x, ldx,
                        (const bf16_t*)dy, lddy, dw, B, Lout, Lin, Cout, Cin, K, stride, pad_l, rpc);

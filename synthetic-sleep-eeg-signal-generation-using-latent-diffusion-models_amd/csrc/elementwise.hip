@@ -114,8 +114,8 @@ __global__ __launch_bounds__(NT) void colsum_kernel(const T* __restrict__ x, lon
         const T* p = x + ((long)b * L + l) * ldx + c;
         if constexpr (V == 4 && sizeof(T) == 2) {
           const uint2 t = *(const uint2*)p;
-          s[0] += __uint_as_float(t.x << 16); s[1] += __uint_as_float(t.x & 0xffff0000u);
-          s[2] += __uint_as_float(t.y << 16); s[3] += __uint_as_float(t.y & 0xffff0000u);
+          s[0] += w16_lo<T>(t.x); s[1] += w16_hi<T>(t.x);
+          s[2] += w16_lo<T>(t.y); s[3] += w16_hi<T>(t.y);
         } else if constexpr (V == 4) {
           const float4 t = *(const float4*)p; s[0] += t.x; s[1] += t.y; s[2] += t.z; s[3] += t.w;
         } else {
@@ -152,11 +152,11 @@ __global__ void colsum_finish_kernel(const float* __restrict__ parts, int nparts
 // 4-byte lane-strided loads (98 / 95 us on the 151 MB logits of the T = 768 attention, 2.3 / 3.2 TB/s)
 template <typename T> __device__ __forceinline__ void sm_ld4(const T* p, float v[4]) {
   if constexpr (sizeof(T) == 4) { const float4 t = *(const float4*)p; v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w; }
-  else { const uint2 t = *(const uint2*)p; v[0] = __uint_as_float(t.x << 16); v[1] = __uint_as_float(t.x & 0xffff0000u); v[2] = __uint_as_float(t.y << 16); v[3] = __uint_as_float(t.y & 0xffff0000u); }
+  else { const uint2 t = *(const uint2*)p; v[0] = w16_lo<T>(t.x); v[1] = w16_hi<T>(t.x); v[2] = w16_lo<T>(t.y); v[3] = w16_hi<T>(t.y); }
 }
 template <typename T> __device__ __forceinline__ void sm_st4(T* p, const float v[4]) {
   if constexpr (sizeof(T) == 4) *(float4*)p = make_float4(v[0], v[1], v[2], v[3]);
-  else { uint2 t; t.x = pack_bf16x2(v[0], v[1]); t.y = pack_bf16x2(v[2], v[3]); *(uint2*)p = t; }
+  else { uint2 t; t.x = pack16x2<T>(v[0], v[1]); t.y = pack16x2<T>(v[2], v[3]); *(uint2*)p = t; }
 }
 template <typename T, int K>
 __global__ __launch_bounds__(NT) void softmax_reg_kernel(const float* __restrict__ S, T* __restrict__ P, long rows, int n) {
@@ -255,8 +255,8 @@ __global__ void add_rows_kernel(T* __restrict__ dst, long ldd, const T* __restri
       if constexpr (sizeof(T) == 2) {
         const uint2 a = *(const uint2*)d, b = *(const uint2*)sp;
         uint2 o;
-        o.x = pack_bf16x2(__uint_as_float(a.x << 16) + __uint_as_float(b.x << 16), __uint_as_float(a.x & 0xffff0000u) + __uint_as_float(b.x & 0xffff0000u));
-        o.y = pack_bf16x2(__uint_as_float(a.y << 16) + __uint_as_float(b.y << 16), __uint_as_float(a.y & 0xffff0000u) + __uint_as_float(b.y & 0xffff0000u));
+        o.x = pack16x2<T>(w16_lo<T>(a.x) + w16_lo<T>(b.x), w16_hi<T>(a.x) + w16_hi<T>(b.x));
+        o.y = pack16x2<T>(w16_lo<T>(a.y) + w16_lo<T>(b.y), w16_hi<T>(a.y) + w16_hi<T>(b.y));
         *(uint2*)d = o;
       } else {
         float4 a = *(const float4*)d; const float4 b = *(const float4*)sp;
@@ -389,6 +389,7 @@ __global__ void randint_kernel(int64_t* __restrict__ out, long n, int64_t high, 
   do {                                                                    \
     if ((dtype) == EEGLDM_F32) { typedef float T; __VA_ARGS__; }          \
     else if ((dtype) == EEGLDM_BF16) { typedef bf16_t T; __VA_ARGS__; }   \
+    else if ((dtype) == EEGLDM_F16) { typedef f16_t T; __VA_ARGS__; }     \
     else EEG_FAIL(EEGLDM_ERR_UNSUPPORTED, "dtype %d", (int)(dtype));      \
   } while (0)
 

@@ -38,6 +38,7 @@ namespace {
 template <typename T> struct Tr;
 template <> struct Tr<float> { static constexpr int KC = 16; static constexpr int EPC = 4; };
 template <> struct Tr<bf16_t> { static constexpr int KC = 32; static constexpr int EPC = 8; };
+template <> struct Tr<f16_t> { static constexpr int KC = 32; static constexpr int EPC = 8; };
 
 template <typename T> __device__ __forceinline__ void mma(const uint4& a, const uint4& b, f32x4& acc);
 template <> __device__ __forceinline__ void mma<float>(const uint4& a, const uint4& b, f32x4& acc) {
@@ -48,6 +49,11 @@ template <> __device__ __forceinline__ void mma<float>(const uint4& a, const uin
 }
 template <> __device__ __forceinline__ void mma<bf16_t>(const uint4& a, const uint4& b, f32x4& acc) {
   acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), acc, 0, 0, 0);
+}
+
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+template <> __device__ __forceinline__ void mma<f16_t>(const uint4& a, const uint4& b, f32x4& acc) {      // EEGLDM_F16: v_mfma_f32_16x16x32_f16
+  acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), acc, 0, 0, 0);
 }
 
 typedef s16x4 __attribute__((address_space(3))) * lds_s16x4_ptr;
@@ -70,6 +76,7 @@ template <int BX> __device__ __forceinline__ int tr_swz(int row, int colbyte) {
 template <typename T, int BX> struct TrPitch;
 template <int BX> struct TrPitch<float, BX> { static constexpr int v = BX * 4 + 16; };
 template <int BX> struct TrPitch<bf16_t, BX> { static constexpr int v = BX * 2; };
+template <int BX> struct TrPitch<f16_t, BX> { static constexpr int v = BX * 2; };
 
 template <int BX>
 __device__ __forceinline__ uint4 read_tr_f32(const char* tile, int ks, int x0, int lm, int q, int rowoff) {
@@ -657,7 +664,8 @@ void gemm_kernel(const GemmArgs p) {   // >= 2 waves per SIMD: <= 256 VGPR+AGPR
       // A separate pass over the stage's A tile (one wave in 16 takes it) -- a branch inside the unrolled MFMA steps cost every
       // wave 8 % (512 x 512 x 49152: 1.03 -> 1.11 ms).
       if (do_cs) {
-        const uint4 ones = make_uint4(0x3F803F80u, 0x3F803F80u, 0x3F803F80u, 0x3F803F80u);
+        constexpr unsigned ONE2 = Is16<T>::f16 ? 0x3C003C00u : 0x3F803F80u;      // 1.0 | 1.0 in the operand format
+        const uint4 ones = make_uint4(ONE2, ONE2, ONE2, ONE2);
 #pragma unroll
         for (int ks = 0; ks < KSUB; ks++)
 #pragma unroll
@@ -796,12 +804,12 @@ void gemm_kernel(const GemmArgs p) {   // >= 2 waves per SIMD: <= 256 VGPR+AGPR
             a.z += hi ? pf_rv[1][j].z : pf_rv[0][j].z; a.w += hi ? pf_rv[1][j].w : pf_rv[0][j].w;
           }
           if (p.resid) {
-            a.x += __uint_as_float(pf_res[i][j].x << 16); a.y += __uint_as_float(pf_res[i][j].x & 0xffff0000u);
-            a.z += __uint_as_float(pf_res[i][j].y << 16); a.w += __uint_as_float(pf_res[i][j].y & 0xffff0000u);
+            a.x += w16_lo<T>(pf_res[i][j].x); a.y += w16_hi<T>(pf_res[i][j].x);
+            a.z += w16_lo<T>(pf_res[i][j].y); a.w += w16_hi<T>(pf_res[i][j].y);
           }
           uint2 o;
-          o.x = pack_bf16x2(acc[0][i][j][0] * p.alpha + a.x, acc[0][i][j][1] * p.alpha + a.y);
-          o.y = pack_bf16x2(acc[0][i][j][2] * p.alpha + a.z, acc[0][i][j][3] * p.alpha + a.w);
+          o.x = pack16x2<T>(acc[0][i][j][0] * p.alpha + a.x, acc[0][i][j][1] * p.alpha + a.y);
+          o.y = pack16x2<T>(acc[0][i][j][2] * p.alpha + a.z, acc[0][i][j][3] * p.alpha + a.w);
           *(uint2*)(smem + (wm * (C::FM * 16) + i * 16 + lm) * PITCH16 + (wn * C::BNW + j * 16 + q * 4) * 2) = o;
         }
       }
@@ -913,8 +921,8 @@ void gemm_kernel(const GemmArgs p) {   // >= 2 waves per SIMD: <= 256 VGPR+AGPR
           for (int cc = 0; cc < NIT; cc++) rv[cc] = *(const uint2*)((const T*)p.resid + (long)(mm[cc] < 0 ? m0 : mm[cc]) * p.ldr + nc);
 #pragma unroll
           for (int cc = 0; cc < NIT; cc++) {
-            add[cc].x += __uint_as_float(rv[cc].x << 16); add[cc].y += __uint_as_float(rv[cc].x & 0xffff0000u);
-            add[cc].z += __uint_as_float(rv[cc].y << 16); add[cc].w += __uint_as_float(rv[cc].y & 0xffff0000u);
+            add[cc].x += w16_lo<T>(rv[cc].x); add[cc].y += w16_hi<T>(rv[cc].x);
+            add[cc].z += w16_lo<T>(rv[cc].y); add[cc].w += w16_hi<T>(rv[cc].y);
           }
         }
       }
@@ -939,8 +947,8 @@ void gemm_kernel(const GemmArgs p) {   // >= 2 waves per SIMD: <= 256 VGPR+AGPR
         for (int cc = 0; cc < NIT; cc++)
           if (mm[cc] >= 0) {
             uint2 o;
-            o.x = pack_bf16x2(v[cc].x, v[cc].y);
-            o.y = pack_bf16x2(v[cc].z, v[cc].w);
+            o.x = pack16x2<T>(v[cc].x, v[cc].y);
+            o.y = pack16x2<T>(v[cc].z, v[cc].w);
             *(uint2*)((bf16_t*)Cb + cbase_a + (long)mm[cc] * p.ldc + n) = o;
           }
       }
@@ -1195,6 +1203,7 @@ int gemm_launch_grouped(eegldm_ctx* ctx, const GemmArgs& a_in, const GemmGroup& 
   int rc;
   if (a.dtype == EEGLDM_F32) rc = launch_modes<float>(ctx, a);
   else if (a.dtype == EEGLDM_BF16) rc = launch_modes<bf16_t>(ctx, a);
+  else if (a.dtype == EEGLDM_F16) rc = launch_modes<f16_t>(ctx, a);
   else EEG_FAIL(EEGLDM_ERR_UNSUPPORTED, "dtype %d", a.dtype);
   if (rc == 0) {
     hipLaunchKernelGGL(splitk_fold_grouped_kernel, dim3((unsigned)((fold_n / 4 + 63) / 64), a.ngroup), dim3(256), 0, ctx->stream, (const float*)ctx->splitk_ws, a.splitk, fold_n, a.grp);
@@ -1286,6 +1295,7 @@ int gemm_launch(eegldm_ctx* ctx, const GemmArgs& a_in) {
   if (rc == 1) rc = 0;
   else if (a.dtype == EEGLDM_F32) rc = launch_modes<float>(ctx, a);
   else if (a.dtype == EEGLDM_BF16) rc = launch_modes<bf16_t>(ctx, a);
+  else if (a.dtype == EEGLDM_F16) rc = launch_modes<f16_t>(ctx, a);
   else EEG_FAIL(EEGLDM_ERR_UNSUPPORTED, "dtype %d", a.dtype);
   EEG_ENV_VAR(bool, dbg_skip_fold, getenv("EEGLDM_DBG_SKIP_FOLDS") != nullptr);      // timing experiment only: weight gradients stay in the workspace
   if (rc == 0 && fold_dst && !dbg_skip_fold) {

@@ -131,7 +131,12 @@ template <> __device__ __forceinline__ void ldv4<bf16_t>(const bf16_t* p, float 
   const uint2 t = *(const uint2*)p;
   v[0] = __uint_as_float(t.x << 16); v[1] = __uint_as_float(t.x & 0xffff0000u); v[2] = __uint_as_float(t.y << 16); v[3] = __uint_as_float(t.y & 0xffff0000u);
 }
+template <> __device__ __forceinline__ void ldv4<f16_t>(const f16_t* p, float v[4]) {
+  const uint2 t = *(const uint2*)p;
+  v[0] = w16_lo<f16_t>(t.x); v[1] = w16_hi<f16_t>(t.x); v[2] = w16_lo<f16_t>(t.y); v[3] = w16_hi<f16_t>(t.y);
+}
 template <typename T> __device__ __forceinline__ void stv4(T* p, const float v[4]);
+template <> __device__ __forceinline__ void stv4<f16_t>(f16_t* p, const float v[4]) { uint2 t; t.x = pack_f16x2(v[0], v[1]); t.y = pack_f16x2(v[2], v[3]); *(uint2*)p = t; }
 template <> __device__ __forceinline__ void stv4<float>(float* p, const float v[4]) { *(float4*)p = make_float4(v[0], v[1], v[2], v[3]); }
 template <> __device__ __forceinline__ void stv4<bf16_t>(bf16_t* p, const float v[4]) { uint2 t; t.x = pack_bf16x2(v[0], v[1]); t.y = pack_bf16x2(v[2], v[3]); *(uint2*)p = t; }
 
@@ -377,6 +382,7 @@ inline void pick_rsplit(long rows, int C, eegldm_ctx* ctx, int* rsplit, long* rp
   do {                                                                    \
     if ((dtype) == EEGLDM_F32) { typedef float T; __VA_ARGS__; }          \
     else if ((dtype) == EEGLDM_BF16) { typedef bf16_t T; __VA_ARGS__; }   \
+    else if ((dtype) == EEGLDM_F16) { typedef f16_t T; __VA_ARGS__; }     \
     else EEG_FAIL(EEGLDM_ERR_UNSUPPORTED, "dtype %d", (int)(dtype));      \
   } while (0)
 

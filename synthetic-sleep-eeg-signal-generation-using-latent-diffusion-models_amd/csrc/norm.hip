@@ -27,6 +27,7 @@ static inline size_t gn_slot_region(int region) { return region == 0 ? GN_SLOT_O
 template <typename T, int V> struct Vec;
 template <> struct Vec<float, 4> { typedef float4 type; };
 template <> struct Vec<bf16_t, 4> { typedef uint2 type; };
+template <> struct Vec<f16_t, 4> { typedef uint2 type; };
 
 template <typename T> __device__ __forceinline__ void load4(const T* p, float v[4]);
 template <> __device__ __forceinline__ void load4<float>(const float* p, float v[4]) {
@@ -37,7 +38,14 @@ template <> __device__ __forceinline__ void load4<bf16_t>(const bf16_t* p, float
   v[0] = __uint_as_float(t.x << 16); v[1] = __uint_as_float(t.x & 0xffff0000u);
   v[2] = __uint_as_float(t.y << 16); v[3] = __uint_as_float(t.y & 0xffff0000u);
 }
+template <> __device__ __forceinline__ void load4<f16_t>(const f16_t* p, float v[4]) {
+  uint2 t = *(const uint2*)p;
+  v[0] = w16_lo<f16_t>(t.x); v[1] = w16_hi<f16_t>(t.x); v[2] = w16_lo<f16_t>(t.y); v[3] = w16_hi<f16_t>(t.y);
+}
 template <typename T> __device__ __forceinline__ void unpack4(const typename Vec<T, 4>::type& t, float v[4]);
+template <> __device__ __forceinline__ void unpack4<f16_t>(const uint2& t, float v[4]) {
+  v[0] = w16_lo<f16_t>(t.x); v[1] = w16_hi<f16_t>(t.x); v[2] = w16_lo<f16_t>(t.y); v[3] = w16_hi<f16_t>(t.y);
+}
 template <> __device__ __forceinline__ void unpack4<float>(const float4& t, float v[4]) { v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w; }
 template <> __device__ __forceinline__ void unpack4<bf16_t>(const uint2& t, float v[4]) {
   v[0] = __uint_as_float(t.x << 16); v[1] = __uint_as_float(t.x & 0xffff0000u);
@@ -52,6 +60,9 @@ template <> __device__ __forceinline__ void store4<bf16_t>(bf16_t* p, const floa
   t.x = pack_bf16x2(v[0], v[1]);
   t.y = pack_bf16x2(v[2], v[3]);
   *(uint2*)p = t;
+}
+template <> __device__ __forceinline__ void store4<f16_t>(f16_t* p, const float v[4]) {
+  uint2 t; t.x = pack_f16x2(v[0], v[1]); t.y = pack_f16x2(v[2], v[3]); *(uint2*)p = t;
 }
 template <typename T, int V> __device__ __forceinline__ void loadv(const T* p, float v[V]) {
   if constexpr (V == 4) load4<T>(p, v); else v[0] = ld_f32(p);
@@ -1107,7 +1118,7 @@ int gn_bwd_t(eegldm_ctx* ctx, const void* x, long ldx, const float* gamma, const
 #else
     const int nth = ((bwd_nth == 512 || bwd_nth == 256) && (unfenced || (!ctx->side_on && g_eeg_live_ctx <= 1))) ? bwd_nth : 1024;
 #endif
-    if constexpr (sizeof(T) == 2) {
+    if constexpr (Is16<T>::bf16) {
       // pipelined persistent form (gn_bwd_pipe_kernel): slabs of exactly 6 rows x 4 channels per thread, L * CC = 24 576, CC a power of two
       EEG_ENV_VAR(bool, no_pipe, getenv("EEGLDM_GN_NO_PIPE") != nullptr);
       EEG_ENV_VAR(int, pipe_min_row, getenv("EEGLDM_GN_PIPE_MIN_ROW") ? atoi(getenv("EEGLDM_GN_PIPE_MIN_ROW")) : 64);
@@ -1279,6 +1290,19 @@ template <> struct Chunk8<bf16_t> {
   static __device__ __forceinline__ void touch(raw_t& r) { asm volatile("" : "+v"(r.x), "+v"(r.y), "+v"(r.z), "+v"(r.w)); }
   static __device__ __forceinline__ void store(bf16_t* p, const float v[8]) {
     uint4 t; t.x = pack_bf16x2(v[0], v[1]); t.y = pack_bf16x2(v[2], v[3]); t.z = pack_bf16x2(v[4], v[5]); t.w = pack_bf16x2(v[6], v[7]);
+    *(uint4*)p = t;
+  }
+};
+template <> struct Chunk8<f16_t> {
+  typedef uint4 raw_t;
+  static __device__ __forceinline__ raw_t load(const f16_t* p) { return *(const uint4*)p; }
+  static __device__ __forceinline__ void unpack(const raw_t& r, float v[8]) {
+    v[0] = w16_lo<f16_t>(r.x); v[1] = w16_hi<f16_t>(r.x); v[2] = w16_lo<f16_t>(r.y); v[3] = w16_hi<f16_t>(r.y);
+    v[4] = w16_lo<f16_t>(r.z); v[5] = w16_hi<f16_t>(r.z); v[6] = w16_lo<f16_t>(r.w); v[7] = w16_hi<f16_t>(r.w);
+  }
+  static __device__ __forceinline__ void touch(raw_t& r) { asm volatile("" : "+v"(r.x), "+v"(r.y), "+v"(r.z), "+v"(r.w)); }
+  static __device__ __forceinline__ void store(f16_t* p, const float v[8]) {
+    uint4 t; t.x = pack_f16x2(v[0], v[1]); t.y = pack_f16x2(v[2], v[3]); t.z = pack_f16x2(v[4], v[5]); t.w = pack_f16x2(v[6], v[7]);
     *(uint4*)p = t;
   }
 };
@@ -1611,10 +1635,12 @@ extern "C" int eegldm_groupnorm_fwd(eegldm_ctx* ctx, const void* x, long ldx, co
   if (gn_flat_ok(L, C, G, resample, ldx, ldy, 0, 0)) {
     if (dtype == EEGLDM_F32) return gn_flat_fwd<float>(ctx, x, gamma, beta, y, stats, B, L, C, eps, fuse_silu);
     if (dtype == EEGLDM_BF16) return gn_flat_fwd<bf16_t>(ctx, x, gamma, beta, y, stats, B, L, C, eps, fuse_silu);
+    if (dtype == EEGLDM_F16) return gn_flat_fwd<f16_t>(ctx, x, gamma, beta, y, stats, B, L, C, eps, fuse_silu);
   }
   if (gn_flat_wide_ok(L, C, G, resample, ldx, ldy) && (dtype != EEGLDM_F32 || (long)L * C <= (long)WIDE_NT * 8 * 6)) {   // fp32: 12 chunks of 8 floats would spill
     if (dtype == EEGLDM_F32) return gn_flat_fwd_wide<float>(ctx, x, gamma, beta, y, stats, B, L, C, eps, fuse_silu);
     if (dtype == EEGLDM_BF16) return gn_flat_fwd_wide<bf16_t>(ctx, x, gamma, beta, y, stats, B, L, C, eps, fuse_silu);
+    if (dtype == EEGLDM_F16) return gn_flat_fwd_wide<f16_t>(ctx, x, gamma, beta, y, stats, B, L, C, eps, fuse_silu);
   }
   const bool v4 = vec4_ok(C, G, ldx, ldy, xr ? ldxr : 0, 0);
   if (dtype == EEGLDM_F32) {
@@ -1623,6 +1649,9 @@ extern "C" int eegldm_groupnorm_fwd(eegldm_ctx* ctx, const void* x, long ldx, co
   } else if (dtype == EEGLDM_BF16) {
     return v4 ? gn_fwd_t<bf16_t, 4>(ctx, x, ldx, gamma, beta, y, ldy, stats, B, L, C, G, eps, fuse_silu, resample, xr, ldxr)
               : gn_fwd_t<bf16_t, 1>(ctx, x, ldx, gamma, beta, y, ldy, stats, B, L, C, G, eps, fuse_silu, resample, xr, ldxr);
+  } else if (dtype == EEGLDM_F16) {
+    return v4 ? gn_fwd_t<f16_t, 4>(ctx, x, ldx, gamma, beta, y, ldy, stats, B, L, C, G, eps, fuse_silu, resample, xr, ldxr)
+              : gn_fwd_t<f16_t, 1>(ctx, x, ldx, gamma, beta, y, ldy, stats, B, L, C, G, eps, fuse_silu, resample, xr, ldxr);
   }
   EEG_FAIL(EEGLDM_ERR_UNSUPPORTED, "dtype %d", dtype);
 }
@@ -1641,11 +1670,13 @@ int op_groupnorm_bwd(eegldm_ctx* ctx, const void* x, long ldx, const float* gamm
     if (colsum_done) *colsum_done = 0;
     if (dtype == EEGLDM_F32) return gn_flat_bwd<float>(ctx, x, gamma, beta, stats, dy, dx, dxr, dgamma, dbeta, B, L, C, fuse_silu);
     if (dtype == EEGLDM_BF16) return gn_flat_bwd<bf16_t>(ctx, x, gamma, beta, stats, dy, dx, dxr, dgamma, dbeta, B, L, C, fuse_silu);
+    if (dtype == EEGLDM_F16) return gn_flat_bwd<f16_t>(ctx, x, gamma, beta, stats, dy, dx, dxr, dgamma, dbeta, B, L, C, fuse_silu);
   }
   const bool v4 = vec4_ok(C, G, ldx, lddy, lddx, dxr ? lddxr : 0);
 #define GN_BWD_ARGS ctx, x, ldx, gamma, beta, stats, dy, lddy, dx, lddx, dgamma, dbeta, B, L, C, G, fuse_silu, resample, dxr, lddxr, colsum_ps, ldps, colsum_done, dxr2, lddxr2, dxr2_done, slots_deferred, defer_region
   if (dtype == EEGLDM_F32) return v4 ? gn_bwd_t<float, 4>(GN_BWD_ARGS) : gn_bwd_t<float, 1>(GN_BWD_ARGS);
   if (dtype == EEGLDM_BF16) return v4 ? gn_bwd_t<bf16_t, 4>(GN_BWD_ARGS) : gn_bwd_t<bf16_t, 1>(GN_BWD_ARGS);
+  if (dtype == EEGLDM_F16) return v4 ? gn_bwd_t<f16_t, 4>(GN_BWD_ARGS) : gn_bwd_t<f16_t, 1>(GN_BWD_ARGS);
 #undef GN_BWD_ARGS
   EEG_FAIL(EEGLDM_ERR_UNSUPPORTED, "dtype %d", dtype);
 }

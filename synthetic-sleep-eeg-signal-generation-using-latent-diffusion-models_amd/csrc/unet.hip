@@ -203,7 +203,7 @@ extern "C" int eegldm_unet_create(eegldm_ctx* ctx, const eegldm_unet_cfg* cfg, e
   EEG_CHECK(cfg->num_heads == 1, "only num_heads=1 is implemented (every reference config)");
   EEG_CHECK(cfg->model_channels % 32 == 0, "model_channels must be a multiple of 32 (GroupNorm(32))");
   EEG_CHECK(cfg->n_mult >= 1 && cfg->n_mult <= 8 && cfg->n_attn >= 0 && cfg->n_attn <= 8, "bad channel_mult / attention_resolutions");
-  EEG_CHECK(cfg->dtype == EEGLDM_F32 || cfg->dtype == EEGLDM_BF16, "bad dtype");
+  EEG_CHECK(cfg->dtype == EEGLDM_F32 || cfg->dtype == EEGLDM_BF16 || cfg->dtype == EEGLDM_F16, "bad dtype");
   eegldm_unet* u = new eegldm_unet();
   u->ctx = ctx; u->cfg = *cfg; u->dtype = cfg->dtype;
   int rc = build_plan(u);

@@ -28,7 +28,7 @@ def parse_args(argv=None):
     p.add_argument("--prediction_type", default="epsilon")
     p.add_argument("--schedule", default="linear_beta", choices=["linear_beta", "scaled_linear_beta"],
                    help="training noise schedule; the reference builds DDPMScheduler(beta_schedule='linear') = plain linspace (train_ldm.py:199-200)")
-    p.add_argument("--grad_scaler", action="store_true", help="dynamic loss scaling as in the reference loop (training.py:334,441-443); bf16/fp32 do not need it")
+    p.add_argument("--grad_scaler", action="store_true", help="dynamic loss scaling as in the reference loop (training.py:334,441-443); always on with --dtype float16 (the reference's autocast dtype), bf16/fp32 do not need it")
     p.add_argument("--deterministic", action="store_true", help="bit-reproducible steps (eegldm.set_deterministic(): ordered reductions instead of fp32 atomics; "
                    "what torch.use_deterministic_algorithms(True) would be for the reference's loop)")
     return p.parse_args(argv)
@@ -90,7 +90,7 @@ def main(args):
     sched = DDPMScheduler(num_train_timesteps=1000, schedule=args.schedule, beta_start=0.0015, beta_end=0.0195,
                           prediction_type=args.prediction_type, device=local)
     opt = Adam(unet, lr=config.train.get("base_lr", 1e-4))
-    scaler = GradScaler(enabled=args.grad_scaler)
+    scaler = GradScaler(enabled=args.grad_scaler or str(args.dtype) in ("float16", "fp16", "half"))      # fp16 activations: the loss scale is what keeps their gradients out of the subnormal range
     bs = max(1, config.train.batch_size // world)
     train = WindowLoader(args.path_pre_processed, bs, args.synthetic_windows, seed=rng_seed(config.train.seed, 8, rank, world), drop_last=config.train.drop_last,
                          path_ids=args.path_train_ids, dataset=args.type_dataset, shard=(rank, world))

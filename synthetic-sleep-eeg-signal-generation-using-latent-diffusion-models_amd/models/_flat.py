@@ -5,9 +5,9 @@ from collections import OrderedDict
 
 import torch
 
-from .._lib import F32, BF16
+from .._lib import F32, BF16, F16
 
-DT = {"float32": F32, "fp32": F32, torch.float32: F32, "bfloat16": BF16, "bf16": BF16, torch.bfloat16: BF16, F32: F32, BF16: BF16}
+DT = {"float32": F32, "fp32": F32, torch.float32: F32, "bfloat16": BF16, "bf16": BF16, torch.bfloat16: BF16, "float16": F16, "fp16": F16, "half": F16, torch.float16: F16, F32: F32, BF16: BF16, F16: F16}
 
 
 def read_entries(h, n_fn, entry_fn):

@@ -15,10 +15,10 @@ from collections import OrderedDict
 
 import torch
 
-from .._lib import lib, check, ptr, default_context, UNetCfg, F32, BF16
+from .._lib import lib, check, ptr, default_context, UNetCfg, F32, BF16, F16
 from ..autograd import FlatModule, _UNetFn
 
-_DT = {"float32": F32, "fp32": F32, torch.float32: F32, "bfloat16": BF16, "bf16": BF16, torch.bfloat16: BF16, F32: F32, BF16: BF16}
+_DT = {"float32": F32, "fp32": F32, torch.float32: F32, "bfloat16": BF16, "bf16": BF16, torch.bfloat16: BF16, "float16": F16, "fp16": F16, "half": F16, torch.float16: F16, F32: F32, BF16: BF16, F16: F16}
 _ZERO_INIT_SUFFIX = ("out_layers.3.weight", "out_layers.3.bias", "proj_out.weight", "proj_out.bias", "out.2.weight", "out.2.bias")
 
 
