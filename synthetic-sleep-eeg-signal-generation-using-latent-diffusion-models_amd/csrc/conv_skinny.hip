@@ -39,6 +39,10 @@ struct SkArgs {
   // GroupNorm (+ SiLU) on the activation operand (consumer side, GN kernels): x is the RAW tensor, gn_part its producer's slots
   // (a concatenated operand [h | skip] has two producers: quads below gn_nqa come from gn_part, the others from gn_part_b)
   const float2* gn_part; const float2* gn_part_b; int gn_nqa; const float* gn_gamma; const float* gn_beta; int gn_cpg; float gn_eps; int gn_silu;
+  // K extension (round 5): + sum_k x2[r][k] * w2[n][k] + bias2[n] -- the ResBlock's skip_connection 1 x 1 conv inside its second conv's launch
+  // (h = skip_connection(x) + out_layers(h), unet.py:302,327): a second, one-tap reduction over a RAW second operand into the same accumulators.
+  // One launch less per skip block in the 72-83-launch chain of a one-window forward; no intermediate tensor, one rounding.
+  const bf16_t* x2; long ldx2; const bf16_t* w2; int Cin2; const float* bias2;
 };
 
 // statistics slot of (16-row fragment rt, 4-channel quad qd) of sample `b` of a tensor whose channels [0, 4 nqa) were written by one producer
@@ -89,7 +93,8 @@ __global__ __launch_bounds__(64 * SK_WAVES) void conv_skinny_kernel(const SkArgs
   // issued as inline assembly AFTER the first round's operand loads: as compiler-visible loads in front of the reduction they were
   // retired with a vmcnt(0) before the first operand load went out (one full memory latency).  Loads retire in order, so hipcc's
   // counted waits for its own (older) loads stay sufficient with these three behind them; the explicit wait is before the epilogue.
-  f32x4 e_bias, e_row; sk_u32x2 e_res;
+  f32x4 e_bias, e_row, e_bias2; sk_u32x2 e_res;
+  const void* pb2 = p.bias2 ? (const void*)(p.bias2 + nc) : (const void*)p.x;
   const void* pb = p.bias ? (const void*)(p.bias + nc) : (const void*)p.x;
   const void* pr = p.rowvec ? (const void*)(p.rowvec + (long)(mc / p.L) * p.ld_rowvec + nc) : (const void*)p.x;
   const void* ps = p.resid ? (const void*)(p.resid + (long)mc * p.ldr + nc) : (const void*)p.x;
@@ -171,6 +176,7 @@ __global__ __launch_bounds__(64 * SK_WAVES) void conv_skinny_kernel(const SkArgs
       asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(e_bias) : "v"(pb) : "memory");                                          \
       asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(e_row) : "v"(pr) : "memory");                                           \
       asm volatile("global_load_dwordx2 %0, %1, off" : "=v"(e_res) : "v"(ps) : "memory");                                           \
+      asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(e_bias2) : "v"(pb2) : "memory");                                        \
     }                                                                                                                                \
     __builtin_amdgcn_sched_barrier(0); /* all loads of the round ahead of its first MFMA */                                          \
     if (GN && FIRST) { /* the sample's group statistics from the producer's slots, then scale / shift per input channel; all of it    \
@@ -234,6 +240,36 @@ __global__ __launch_bounds__(64 * SK_WAVES) void conv_skinny_kernel(const SkArgs
   SK_ROUND(wave, true)
   for (int cr = wave + SK_WAVES * CH; cr < kchunks; cr += SK_WAVES * CH) SK_ROUND(cr, false)
 #undef SK_ROUND
+  // ---- K extension: the second (one-tap, un-normalised) reduction; wave w takes chunks w, w + 8, ... of Cin2, two per round
+  if (p.x2) {
+    const int kc2 = p.Cin2 >> 5;
+    const bf16_t* x2row[RF]; const bf16_t* w2row[CF];
+#pragma unroll
+    for (int rf = 0; rf < RF; rf++) x2row[rf] = p.x2 + (long)row[rf] * p.ldx2 + q * 8;
+#pragma unroll
+    for (int cf = 0; cf < CF; cf++) { const int n = n0 + cf * 16 + lm; w2row[cf] = p.w2 + (long)(n < p.N ? n : p.N - 1) * p.Cin2 + q * 8; }
+    for (int c0 = wave; c0 < kc2; c0 += 2 * SK_WAVES) {
+      uint4 xa[2][RF], wb2[2][CF];
+#pragma unroll
+      for (int i = 0; i < 2; i++) {
+        int c = c0 + i * SK_WAVES; if (c >= kc2) c = kc2 - 1;
+#pragma unroll
+        for (int rf = 0; rf < RF; rf++) xa[i][rf] = *(const uint4*)(x2row[rf] + c * 32);
+#pragma unroll
+        for (int cf = 0; cf < CF; cf++) wb2[i][cf] = *(const uint4*)(w2row[cf] + c * 32);
+      }
+#pragma unroll
+      for (int i = 0; i < 2; i++) {
+        if (c0 + i * SK_WAVES < kc2) {
+#pragma unroll
+          for (int rf = 0; rf < RF; rf++)
+#pragma unroll
+            for (int cf = 0; cf < CF; cf++)
+              acc[rf][cf] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, wb2[i][cf]), __builtin_bit_cast(bf16x8, xa[i][rf]), acc[rf][cf], 0, 0, 0);
+        }
+      }
+    }
+  }
 #pragma unroll
   for (int rf = 0; rf < RF; rf++)
 #pragma unroll
@@ -244,9 +280,10 @@ __global__ __launch_bounds__(64 * SK_WAVES) void conv_skinny_kernel(const SkArgs
     f32x4 s = part[0][f_own][lane];
 #pragma unroll
     for (int w = 1; w < SK_WAVES; w++) { const f32x4 v = part[w][f_own][lane]; s[0] += v[0]; s[1] += v[1]; s[2] += v[2]; s[3] += v[3]; }
-    asm volatile("s_waitcnt vmcnt(0)" : "+v"(e_bias), "+v"(e_row), "+v"(e_res) :: "memory");
+    asm volatile("s_waitcnt vmcnt(0)" : "+v"(e_bias), "+v"(e_row), "+v"(e_res), "+v"(e_bias2) :: "memory");
     if (own_ok) {
       if (p.bias) { s[0] += e_bias[0]; s[1] += e_bias[1]; s[2] += e_bias[2]; s[3] += e_bias[3]; }
+      if (p.bias2) { s[0] += e_bias2[0]; s[1] += e_bias2[1]; s[2] += e_bias2[2]; s[3] += e_bias2[3]; }
       if (p.rowvec) { s[0] += e_row[0]; s[1] += e_row[1]; s[2] += e_row[2]; s[3] += e_row[3]; }
       if (p.resid) {
         s[0] += __uint_as_float(e_res[0] << 16); s[1] += __uint_as_float(e_res[0] & 0xffff0000u);
@@ -295,9 +332,11 @@ bool conv_skinny_takes(int dtype, int Cin, int Cout, int taps, int B, int L) {
 // Returns 1 when this kernel took the launch, 0 when the shape is not its (the caller goes on to the general kernels), < 0 on error.
 int conv_skinny_ex(eegldm_ctx* ctx, int dtype, const void* x, long ldx, const void* w, int Cin, int Cout, int taps, const float* bias,
                    const float* rowvec, long ld_rowvec, const void* resid, long ldr, void* y, long ldy, int B, int L,
-                   const SkinnyGn* gn, float2* part_out) {
+                   const SkinnyGn* gn, float2* part_out, const SkinnyExt* ext) {
   const long M = (long)B * L;
   if (!conv_skinny_takes(dtype, Cin, Cout, taps, B, L)) return 0;
+  if (ext && (!ext->x2 || !ext->w2 || ext->Cin2 % 32 != 0 || ext->ldx2 % 8 != 0 || (((size_t)ext->x2 | (size_t)ext->w2) % 16) != 0 ||
+              (ext->bias2 && (size_t)ext->bias2 % 16 != 0) || resid)) return 0;
   if (ldx % 8 != 0 || ldy % 4 != 0 || (resid && ldr % 4 != 0) || (rowvec && ld_rowvec % 4 != 0)) return 0;
   if (((size_t)x | (size_t)w) % 16 != 0 || (size_t)y % 8 != 0 || (resid && (size_t)resid % 8 != 0) || (bias && (size_t)bias % 16 != 0) ||
       (rowvec && (size_t)rowvec % 16 != 0)) return 0;
@@ -309,6 +348,7 @@ int conv_skinny_ex(eegldm_ctx* ctx, int dtype, const void* x, long ldx, const vo
   a.bias = bias; a.rowvec = rowvec; a.ld_rowvec = ld_rowvec; a.resid = (const bf16_t*)resid; a.ldr = ldr;
   a.y = (bf16_t*)y; a.ldy = ldy; a.M = (int)M; a.L = L; a.N = Cout;
   a.part_out = part_out;
+  if (ext) { a.x2 = (const bf16_t*)ext->x2; a.ldx2 = ext->ldx2; a.w2 = (const bf16_t*)ext->w2; a.Cin2 = ext->Cin2; a.bias2 = ext->bias2; }
   if (gn) { a.gn_part = gn->part; a.gn_part_b = gn->part_b ? gn->part_b : gn->part; a.gn_nqa = gn->part_b ? gn->nqa : Cin / 4; a.gn_gamma = gn->gamma; a.gn_beta = gn->beta; a.gn_cpg = gn->cpg; a.gn_eps = gn->eps; a.gn_silu = gn->silu; }
   // widest register tile that still gives every CU most of a block (fewer re-reads of the operands through L2)
   EEG_ENV_VAR(int, force, getenv("EEGLDM_CONV_SKINNY_TILE") ? atoi(getenv("EEGLDM_CONV_SKINNY_TILE")) : 0);   // 11 / 21 / 22
@@ -319,7 +359,7 @@ int conv_skinny_ex(eegldm_ctx* ctx, int dtype, const void* x, long ldx, const vo
   if (force) { rf = force / 10; cf = force % 10; if (rf < 1 || rf > 2 || cf < 1 || cf > rf) { rf = 1; cf = 1; } }
   ProfRec rec; const bool prof = ctx->prof_on;
   if (prof) {
-    rec.cls = taps == 3 ? PROF_CONV_FWD : PROF_GEMM_NT; rec.flops = 2.0 * (double)M * Cout * Cin * taps;
+    rec.cls = taps == 3 ? PROF_CONV_FWD : PROF_GEMM_NT; rec.flops = 2.0 * (double)M * Cout * ((double)Cin * taps + (ext ? ext->Cin2 : 0));
     rec.M = (int)M; rec.N = Cout; rec.K = Cin; rec.taps = taps; rec.splitk = 1;
     HIP_TRY(hipEventCreate(&rec.a)); HIP_TRY(hipEventCreate(&rec.b));
     HIP_TRY(hipEventRecord(rec.a, ctx->stream));
@@ -333,5 +373,5 @@ int conv_skinny_ex(eegldm_ctx* ctx, int dtype, const void* x, long ldx, const vo
 
 int conv_skinny_try(eegldm_ctx* ctx, int dtype, const void* x, long ldx, const void* w, int Cin, int Cout, int taps, const float* bias,
                     const float* rowvec, long ld_rowvec, const void* resid, long ldr, void* y, long ldy, int B, int L) {
-  return conv_skinny_ex(ctx, dtype, x, ldx, w, Cin, Cout, taps, bias, rowvec, ld_rowvec, resid, ldr, y, ldy, B, L, nullptr, nullptr);
+  return conv_skinny_ex(ctx, dtype, x, ldx, w, Cin, Cout, taps, bias, rowvec, ld_rowvec, resid, ldr, y, ldy, B, L, nullptr, nullptr, nullptr);
 }

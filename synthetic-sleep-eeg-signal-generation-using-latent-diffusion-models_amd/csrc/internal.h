@@ -36,10 +36,12 @@ bool dconv_wgrad_tinyv_ok(int Cin, int Cout, int K);
 // conv_ws.hip: weight-stationary 3-tap conv for 128 reduction channels (1 = handled, 0 = not this kernel's shape, < 0 = error)
 struct SkinnyGn { const float2* part; const float* gamma; const float* beta; int cpg; float eps; int silu;
                   const float2* part_b = nullptr; int nqa = 0; };   // part_b: second producer of a concatenated operand (quads >= nqa)
+// K extension of the few-row conv: + conv1x1(x2; w2 [Cout][Cin2]) + bias2 in the same launch (the ResBlock's skip_connection); excludes a residual
+struct SkinnyExt { const void* x2; long ldx2; const void* w2; int Cin2; const float* bias2; };
 bool conv_skinny_takes(int dtype, int Cin, int Cout, int taps, int B, int L);
 int conv_skinny_ex(eegldm_ctx* ctx, int dtype, const void* x, long ldx, const void* w, int Cin, int Cout, int taps, const float* bias,
                    const float* rowvec, long ld_rowvec, const void* resid, long ldr, void* y, long ldy, int B, int L,
-                   const SkinnyGn* gn, float2* part_out);
+                   const SkinnyGn* gn, float2* part_out, const SkinnyExt* ext = nullptr);
 int conv_skinny_try(eegldm_ctx* ctx, int dtype, const void* x, long ldx, const void* w, int Cin, int Cout, int taps, const float* bias,
                     const float* rowvec, long ld_rowvec, const void* resid, long ldr, void* y, long ldy, int B, int L);
 int conv_ws_try(eegldm_ctx*, int dtype, const void* x, long ldx, const void* w, int Cin, int Cout, int transposed, const float* bias,

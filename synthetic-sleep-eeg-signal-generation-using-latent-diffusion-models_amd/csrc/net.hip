@@ -167,13 +167,28 @@ int res_forward(NetBase* u, const ResDesc& r, const View& x, int B, int Lin, con
     if (rc1 == 0 && fuse1) EEG_TRY(norm1());           // declined (alignment): the stand-alone norm after all
     if (rc1 == 1) {
       const SkinnyGn gn = {area, u->P(r.gn2_w), u->P(r.gn2_b), cpg2, GN_EPS, 1};
-      if (r.sk_w >= 0)
-        EEG_TRY(op_conv_fwd(ctx, dt, t.xr.p, t.xr.ld, u->W(r.sk_w), u->P(r.sk_b), out.p, out.ld, B, Lout, r.cin, r.cout, 1, 1, 0, 0, nullptr, 0, nullptr, 0));
-      const View res = r.sk_w >= 0 ? out : t.xr;
       float2* opart = u->fuse_alloc(need);              // statistics of the block output, for whoever normalises it next
-      const int rc2 = conv_skinny_ex(ctx, dt, t.h1.p, t.h1.ld, u->W(r.c2_w), r.cout, r.cout, 3, u->P(r.c2_b), nullptr, 0, res.p, res.ld,
-                                     out.p, out.ld, B, Lout, &gn, opart);
-      if (rc2 < 0) return rc2;
+      // skip_connection(x) + conv2(h): ONE launch with the 1 x 1 conv as a second reduction of the few-row kernel (round 5); the two-launch
+      // form (the 1 x 1 conv writes `out`, conv2 adds it as its residual) when the extension does not apply
+      EEG_ENV_VAR(bool, no_ext, getenv("EEGLDM_NO_FUSED_SKIP") != nullptr);
+      int rc2 = 0; bool skip_done = false;
+      if (r.sk_w >= 0 && !no_ext && r.cin % 32 == 0) {
+        const SkinnyExt ext = {t.xr.p, t.xr.ld, u->W(r.sk_w), r.cin, u->P(r.sk_b)};
+        rc2 = conv_skinny_ex(ctx, dt, t.h1.p, t.h1.ld, u->W(r.c2_w), r.cout, r.cout, 3, u->P(r.c2_b), nullptr, 0, nullptr, 0,
+                             out.p, out.ld, B, Lout, &gn, opart, &ext);
+        if (rc2 < 0) return rc2;
+        skip_done = rc2 == 1;
+      }
+      if (rc2 != 1) {
+        if (r.sk_w >= 0)
+          EEG_TRY(op_conv_fwd(ctx, dt, t.xr.p, t.xr.ld, u->W(r.sk_w), u->P(r.sk_b), out.p, out.ld, B, Lout, r.cin, r.cout, 1, 1, 0, 0, nullptr, 0, nullptr, 0));
+        const View res = r.sk_w >= 0 ? out : t.xr;
+        rc2 = conv_skinny_ex(ctx, dt, t.h1.p, t.h1.ld, u->W(r.c2_w), r.cout, r.cout, 3, u->P(r.c2_b), nullptr, 0, res.p, res.ld,
+                             out.p, out.ld, B, Lout, &gn, opart);
+        if (rc2 < 0) return rc2;
+        skip_done = r.sk_w >= 0;
+      }
+      (void)skip_done;
       if (rc2 == 1) { fused = true; u->fused_used = true; if (opart) u->part_reg.push_back({out.p, opart, r.cout / 4}); }
     } else {
       EEG_TRY(op_conv_fwd(ctx, dt, t.a1.p, t.a1.ld, u->W(r.c1_w), u->P(r.c1_b), t.h1.p, t.h1.ld, B, Lout, r.cin, r.cout, 3, 1, 1, 1, emb, u->emb_ld, nullptr, 0));

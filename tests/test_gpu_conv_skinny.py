@@ -177,3 +177,29 @@ def test_ddim50_of_two_windows_few_row_chain_against_the_oracle_general_kernels_
         assert rel(x[name], xo) < G.bf16_gap_bound(gap_x), (name, rel(x[name], xo), gap_x)
     assert rel(z["few_row"], z["general"]) < 5e-3 and rel(z["few_row"], z["fp32"]) < 5e-3 and rel(z["general"], z["fp32"]) < 5e-3
     assert rel(x["few_row"], x["general"]) < 2e-2
+
+
+def test_skip_connection_inside_the_second_convs_few_row_launch(env_switches):
+    """Round 5: at one window per call the ResBlock tail skip_connection(x) + conv2(h) (unet.py:302,327) is ONE few-row launch -- the 1 x 1 conv
+    runs as a second reduction of conv2's kernel (conv_skinny.hip K extension) -- instead of two: 11 launches fewer per forward, the same
+    output up to the one bf16 rounding of the intermediate that the fusion removes."""
+    import csv, os, tempfile
+    from eegldm._lib import lib, check
+    net, _w = _seeded_unet(768, "bfloat16", seed=42)
+    net.eval()
+    x = torch.from_numpy(normal((1, 1, 768), seed=31)).cuda(); t = torch.full((1,), 431, dtype=torch.int64).cuda()
+    outs = {}
+    for name, sw in (("fused", None), ("two", "1")):
+        env_switches(EEGLDM_NO_FUSED_SKIP=sw)
+        net(x, timesteps=t)
+        net.ctx.prof_enable(True)
+        y = net(x, timesteps=t)
+        path = os.path.join(tempfile.gettempdir(), "eegldm_sk_rows.csv")
+        check(lib.eegldm_prof_dump(net.ctx.h, path.encode()))
+        net.ctx.prof_enable(False)
+        with open(path) as fh:
+            n = len(list(csv.DictReader(fh)))
+        outs[name] = (y.clone(), n)
+    assert outs["two"][1] - outs["fused"][1] == 11, (outs["fused"][1], outs["two"][1])       # one per ResBlock with a skip_connection
+    ya, yb = outs["fused"][0], outs["two"][0]
+    assert float((ya - yb).abs().max()) <= 2e-2 * float(yb.abs().max()), float((ya - yb).abs().max()) / float(yb.abs().max())
