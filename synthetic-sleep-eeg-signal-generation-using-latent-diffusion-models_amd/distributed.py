@@ -65,11 +65,26 @@ def allreduce_sum_scalars(values, like=None):
     return [float(v) for v in t.tolist()]
 
 
+_AVG_OK = None      # ReduceOp.AVG usable on this backend build (probed once, collectively: every rank takes the same branch)
+
+
 def _mean_op(t):
     """(reduce op, needs a separate 1/world pass).  RCCL has the mean as a collective (ncclAvg = ReduceOp.AVG): no extra read + write of
-    the 122 MB gradient buffer per step; gloo (the CPU tests, ranks sharing one GPU) only sums."""
+    the 122 MB gradient buffer per step; gloo (the CPU tests, ranks sharing one GPU) only sums.  The first call probes AVG with a
+    one-element all-reduce -- this path has never run with more than one rank for the builder, so an unsupported-op error must cost a
+    fallback to SUM + scale, not the run."""
+    global _AVG_OK
     if dist.get_backend() == "nccl" and t.is_cuda and os.environ.get("EEGLDM_NO_NCCL_AVG") is None:
-        return dist.ReduceOp.AVG, False
+        if _AVG_OK is None:
+            try:
+                probe = torch.full((1,), 3.0, device=t.device)
+                dist.all_reduce(probe, op=dist.ReduceOp.AVG)
+                _AVG_OK = abs(float(probe) - 3.0) < 1e-6
+            except Exception as e:      # noqa: BLE001
+                print(f"[eegldm] ReduceOp.AVG unavailable ({e}); gradient mean as SUM + scale", flush=True)
+                _AVG_OK = False
+        if _AVG_OK:
+            return dist.ReduceOp.AVG, False
     return dist.ReduceOp.SUM, True
 
 
