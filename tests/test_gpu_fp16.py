@@ -274,3 +274,51 @@ def test_ldm_training_in_fp16_with_the_grad_scaler_guarding_half_precision():
         assert abs(got - want) <= 1e-2 * want + 1e-6, (i, got, want)
     assert opt.step_count == 12 and scaler.get_scale() == 2.0 ** 12
     print(f"fp16 LDM trajectory with GradScaler(2^12): worst relative loss gap over 12 steps {worst:.2e}")
+
+
+def test_gan_step_and_ddim_sampling_in_fp16_follow_the_fp32_engine():
+    """The remaining callers on the path in half precision: the fused AutoencoderKL [32,32,64] + PatchDiscriminator GAN step
+    (train_autoencoderkl.py:203-234) and DDIM sampling + decode (sample_trials.py:149-170), against the fp32 engine on the same seeds --
+    every entry point that takes a dtype must either run its fp16 instantiation or decline its bf16-only fast path."""
+    import eegldm
+    from eegldm.models import AutoencoderKL, PatchDiscriminator, UNetModel
+    from eegldm.training import aekl_train_step
+    from eegldm.sampling import ddim_sample, make_sampling_scheduler
+    from oracle import aekl as A
+    cfg = dict(num_channels=[32, 32, 64], latent_channels=1, in_channels=1, out_channels=1, num_res_blocks=2, norm_num_groups=1)
+    D_CFG = dict(spatial_dims=1, num_layers_d=3, num_channels=64, in_channels=1, out_channels=1, kernel_size=3, norm="BATCH", bias=False, padding=1)
+    B, L = 8, 3072
+    x = torch.from_numpy(eeg_windows(B, seed=41, length=L)).cuda(); eps = torch.from_numpy(normal((B, 1, L // 4), seed=42)).cuda()
+    ae_sd = {k: torch.from_numpy(gen_param(31, k, s)) for k, s in A.aekl_param_shapes(cfg).items()}
+    d_sd = {k: torch.from_numpy(gen_param(32, k, s)) for k, s in A.disc_param_shapes(D_CFG).items()}
+    out = {}
+    for dt in ("float32", "float16"):
+        ae = AutoencoderKL(spatial_dims=1, attention_levels=[False] * 3, dtype=dt, **cfg); ae.load_state_dict(ae_sd)
+        disc = PatchDiscriminator(**D_CFG, dtype=dt); disc.load_state_dict(d_sd)
+        ae.zero_grad(); disc.zero_grad()
+        lo = aekl_train_step(ae, disc, x, eps, 0.01, 1e-6, 1.0, True).cpu()
+        out[dt] = (lo, ae.flat_grad.clone(), disc.flat_grad.clone())
+    lo32, lo16 = out["float32"][0], out["float16"][0]
+    assert torch.isfinite(lo16).all()
+    assert torch.allclose(lo16, lo32, rtol=2e-2, atol=1e-4), (lo16, lo32)
+    for k in (1, 2):
+        rel = float((out["float16"][k] - out["float32"][k]).norm() / out["float32"][k].norm())
+        assert rel < 6e-2, (k, rel)
+    # sampling: 10 DDIM steps + decode of two windows
+    ucfg = dict(in_channels=1, out_channels=1, model_channels=128, num_res_blocks=2, attention_resolutions=[8, 4], channel_mult=[1, 2, 4], resblock_updown=True)
+    noise = torch.from_numpy(normal((2, 1, 768), seed=77)).cuda()
+    res = {}
+    wsd = None
+    for dt in ("float32", "float16"):
+        u = UNetModel(image_size=768, **ucfg, dtype=dt)
+        if wsd is None:
+            wsd = {k: torch.from_numpy(gen_param(5, k, tuple(v.shape))) for k, v in u.state_dict().items()}
+        u.load_state_dict(wsd)
+        ae = AutoencoderKL(spatial_dims=1, attention_levels=[False] * 3, dtype=dt, **cfg); ae.load_state_dict(ae_sd)
+        win, lat = ddim_sample(u, ae, make_sampling_scheduler(10), noise)
+        res[dt] = (win.float().cpu(), lat.float().cpu())
+    assert torch.isfinite(res["float16"][0]).all()
+    rl = float((res["float16"][1] - res["float32"][1]).norm() / res["float32"][1].norm())
+    rw = float((res["float16"][0] - res["float32"][0]).norm() / res["float32"][0].norm())
+    print(f"fp16 vs fp32 engine: GAN losses {lo16.tolist()} vs {lo32.tolist()}; DDIM-10 latents {rl:.2e}, windows {rw:.2e}")
+    assert rl < 2e-2 and rw < 3e-2, (rl, rw)

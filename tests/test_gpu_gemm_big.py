@@ -197,7 +197,8 @@ def test_big_tile_race_screen_at_production_size(shape):
 
 #          B, L,   Cmid, Cin2, Cout, rowvec      (Cmid -> Cout 3 taps over h; Cin2 -> Cout 1 tap over x: unet.py:302,327)
 CASES_SKIP = [(4, 192, 512, 1024, 512, 0), (2, 384, 256, 768, 256, 1), (3, 192, 256, 128, 256, 0), (2, 768, 256, 384, 256, 0), (5, 192, 512, 768, 512, 1),
-              (1, 192, 512, 192, 512, 0), (2, 192, 256, 96, 256, 0)]
+              (1, 192, 512, 192, 512, 0), (2, 192, 256, 96, 256, 0),
+              (160, 192, 256, 256, 512, 1), (72, 384, 256, 384, 256, 0)]      # 320 / 144 x 2... tiles: more tiles than CUs -> workgroups walk several tiles (the `carry` waits of the persistent form with the K extension)
 
 
 @pytest.mark.parametrize("case", CASES_SKIP)
