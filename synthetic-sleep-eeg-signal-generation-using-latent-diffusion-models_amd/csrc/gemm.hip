@@ -1287,7 +1287,7 @@ int gemm_launch(eegldm_ctx* ctx, const GemmArgs& a_in) {
   int rc = 0;
   // 192 x 256 tile, one workgroup per CU (gemm_big.hip): 3-tap and 1 x 1 convs of the 256- / 512-channel levels, forward and (through the
   // transposed K-blocked weight copy B_alt) data gradient
-  if ((a.amode == GA_CONV || (a.amode == GA_PLAIN && a.taps == 1 && a.batch == 1)) && a.dtype == EEGLDM_BF16 && !fold_dst) {
+  if ((a.amode == GA_CONV || (a.amode == GA_PLAIN && a.taps == 1 && a.batch == 1)) && (a.dtype == EEGLDM_BF16 || a.dtype == EEGLDM_F16) && !fold_dst) {
     if (a.bmode == GB_NT) rc = gemm_big_try(ctx, a);
     else if (a.B_alt) { GemmArgs b = a; b.B = a.B_alt; b.bmode = GB_NT; b.b_kblk = 1; rc = gemm_big_try(ctx, b); }
     if (rc < 0) return rc;

@@ -86,12 +86,18 @@ __device__ __forceinline__ void dma16s(const void* base, unsigned voff, unsigned
   const unsigned long long b = ((unsigned long long)hi << 32) | lo;
   asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" ::"s"(__builtin_amdgcn_readfirstlane(lds_off)), "v"(voff), "s"(b) : "memory", "m0");
 }
+// one 16 x 16 x 32 MFMA step in the operand format of storage type T (bf16_t: v_mfma_f32_16x16x32_bf16; f16_t, round 5: ..._f16)
+typedef _Float16 big_f16x8 __attribute__((ext_vector_type(8)));
+template <typename T> __device__ __forceinline__ f32x4 big_mma(const uint4& a, const uint4& b, const f32x4& c) {
+  if constexpr (Is16<T>::f16) return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(big_f16x8, a), __builtin_bit_cast(big_f16x8, b), c, 0, 0, 0);
+  else return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+}
 __device__ __forceinline__ int swz2(int row) { return 2 * ((row >> 1) & 3); }     // 16-byte slot ^= swz2(row) (128-byte rows)
 
 // ---- epilogue shared by both kernels: acc[i][j][r] = C[wm*96 + i*16 + lm][wn*64 + j*16 + q*4 + r] (operands were swapped: 4 consecutive
 // columns per lane).  bias / embedding row / residual are added in fp32 in the fragment layout, the sum is rounded to bf16 ONCE, the
 // packed tile goes through LDS and leaves as 16-byte row-contiguous stores.
-__device__ __forceinline__ void big_epilogue(const BigArgs& p, f32x4 (&acc)[FM][FN], char* smem, int m0, int n0, int tid, int lm, int q, int wm, int wn) {
+template <typename T> __device__ __forceinline__ void big_epilogue(const BigArgs& p, f32x4 (&acc)[FM][FN], char* smem, int m0, int n0, int tid, int lm, int q, int wm, int wn) {
 
   float4 add[FN];
 #pragma unroll
@@ -118,12 +124,12 @@ __device__ __forceinline__ void big_epilogue(const BigArgs& p, f32x4 (&acc)[FM][
       float4 a = add[j];
       if (p.resid) {
         const uint2 r = res[i & 1][j];
-        a.x += __uint_as_float(r.x << 16); a.y += __uint_as_float(r.x & 0xffff0000u);
-        a.z += __uint_as_float(r.y << 16); a.w += __uint_as_float(r.y & 0xffff0000u);
+        a.x += w16_lo<T>(r.x); a.y += w16_hi<T>(r.x);
+        a.z += w16_lo<T>(r.y); a.w += w16_hi<T>(r.y);
       }
       uint2 o;
-      o.x = pack_bf16x2(acc[i][j][0] + a.x, acc[i][j][1] + a.y);
-      o.y = pack_bf16x2(acc[i][j][2] + a.z, acc[i][j][3] + a.w);
+      o.x = pack16x2<T>(acc[i][j][0] + a.x, acc[i][j][1] + a.y);
+      o.y = pack16x2<T>(acc[i][j][2] + a.z, acc[i][j][3] + a.w);
       *(uint2*)(smem + (wm * (FM * 16) + i * 16 + lm) * PITCH16 + (wn * 64 + j * 16 + q * 4) * 2) = o;
     }
   }
@@ -137,7 +143,7 @@ __device__ __forceinline__ void big_epilogue(const BigArgs& p, f32x4 (&acc)[FM][
   for (int cc = 0; cc < NIT; cc++) *(uint4*)(p.C + (long)(m0 + r0 + cc * RSTEP) * p.ldc + n0 + cs8 * 8) = v8[cc];
 }
 
-template <int TAPS, bool KBLK, bool FLIP>      // FLIP: tap t reads weight slice 2 - t (data gradient; also tells the two apart in a kernel trace).  TAPS = 3 only: with one tap every piece carries an A tile and the two-buffer A ring would be overwritten while it is read
+template <int TAPS, bool KBLK, bool FLIP, typename T = bf16_t>      // FLIP: tap t reads weight slice 2 - t (data gradient; also tells the two apart in a kernel trace).  TAPS = 3 only: with one tap every piece carries an A tile and the two-buffer A ring would be overwritten while it is read
 __global__ __launch_bounds__(NTHR, 2) void gemm_big_kernel(const BigArgs p) {
   static_assert(TAPS == 3, "ring layout assumes three pieces per A tile");
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -258,7 +264,7 @@ __global__ __launch_bounds__(NTHR, 2) void gemm_big_kernel(const BigArgs p) {
     for (int i = 0; i < FM; i++) {
 #pragma unroll
       for (int j = 0; j < FN; j++)
-        if (!BIG_DBG(4)) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, bf0[j]), __builtin_bit_cast(bf16x8, af[i]), acc[i][j], 0, 0, 0);
+        if (!BIG_DBG(4)) acc[i][j] = big_mma<T>(bf0[j], af[i], acc[i][j]);
       if (i == 0) {
         __builtin_amdgcn_sched_barrier(0);     // (keeps the reads below behind row 0's MFMAs: the compiler's wait in front of the first MFMA after an LDS read is lgkmcnt(0))
 #pragma unroll
@@ -284,7 +290,7 @@ __global__ __launch_bounds__(NTHR, 2) void gemm_big_kernel(const BigArgs p) {
     for (int i = 0; i < FM; i++) {
 #pragma unroll
       for (int j = 0; j < FN; j++) {
-        if (!BIG_DBG(4)) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, bf1[j]), __builtin_bit_cast(bf16x8, af[i]), acc[i][j], 0, 0, 0);
+        if (!BIG_DBG(4)) acc[i][j] = big_mma<T>(bf1[j], af[i], acc[i][j]);
         if (has3 && i <= 3 && !BIG_DBG(1)) {                  // DMA instructions 2i, 2i + 1 of piece p+3 go out behind MFMAs 1 and 3 of rows 0..3
           const int k = 2 * i + (j >> 1);
           if ((j & 1) && (k < 4 || t == 0)) issue(s + 1, t, k);
@@ -301,7 +307,7 @@ __global__ __launch_bounds__(NTHR, 2) void gemm_big_kernel(const BigArgs p) {
   phase(S - 1, 0, true, true, false); phase(S - 1, 1, true, false, false); phase(S - 1, 2, false, false, false);
   __syncthreads();       // all waves done with the ring before the epilogue tile reuses it
   if (BIG_DBG(8)) { if (acc[0][0][0] == 123.456f) p.C[0] = 0; return; }
-  big_epilogue(p, acc, smem, m0, n0, tid, lm, q, wm, wn);
+  big_epilogue<T>(p, acc, smem, m0, n0, tid, lm, q, wm, wn);
 }
 
 // ---- persistent variant's epilogue: no LDS.  The fragment layout gives a lane 4 consecutive columns (8 bytes as bf16) of row lm;
@@ -309,14 +315,14 @@ __global__ __launch_bounds__(NTHR, 2) void gemm_big_kernel(const BigArgs p) {
 // holds 8 consecutive columns (16 bytes) and a wave instruction writes 64 contiguous bytes of each of 16 rows.  EXACTLY NST store
 // instructions per wave: the next tile's counted vmcnt waits step over them.
 constexpr int NST = FM * (FN / 2);
-__device__ __forceinline__ void big_store(const BigArgs& p, f32x4 (&acc)[FM][FN], int m0, int n0, int lm, int q, int wm, int wn) {
+template <typename T> __device__ __forceinline__ void big_store(const BigArgs& p, f32x4 (&acc)[FM][FN], int m0, int n0, int lm, int q, int wm, int wn) {
   bf16_t* cp = p.C + (long)(m0 + wm * (FM * 16) + lm) * p.ldc + n0 + wn * 64 + (q & 1) * 16 + (q >> 1) * 8;
 #pragma unroll
   for (int i = 0; i < FM; i++)
 #pragma unroll
     for (int jp = 0; jp < FN / 2; jp++) {
-      const unsigned x0 = pack_bf16x2(acc[i][2 * jp][0], acc[i][2 * jp][1]), x1 = pack_bf16x2(acc[i][2 * jp][2], acc[i][2 * jp][3]);
-      const unsigned y0 = pack_bf16x2(acc[i][2 * jp + 1][0], acc[i][2 * jp + 1][1]), y1 = pack_bf16x2(acc[i][2 * jp + 1][2], acc[i][2 * jp + 1][3]);
+      const unsigned x0 = pack16x2<T>(acc[i][2 * jp][0], acc[i][2 * jp][1]), x1 = pack16x2<T>(acc[i][2 * jp][2], acc[i][2 * jp][3]);
+      const unsigned y0 = pack16x2<T>(acc[i][2 * jp + 1][0], acc[i][2 * jp + 1][1]), y1 = pack16x2<T>(acc[i][2 * jp + 1][2], acc[i][2 * jp + 1][3]);
       // odd lane rows of x <-> even lane rows of y: q even keeps its fragment 2jp columns and receives the next four from q + 1;
       // q odd receives fragment 2jp + 1's previous four from q - 1 and keeps its own
       const auto s0 = __builtin_amdgcn_permlane16_swap(x0, y0, false, false);
@@ -384,7 +390,7 @@ __device__ __forceinline__ void big_qflush(const BigArgs& p, const float (&s)[2 
 // of (S-1, 2), X_{e+2} behind that of X_e) and every barrier of that region waits for vmcnt(0) -- the schedule of gemm_big1p_kernel.
 // A2 tiles land where the main tiles land (physical row = tile row + 1) and are read with the centre tap's fragment addresses; B pieces
 // keep walking the three B buffers (X_e in buffer e % 3 = where piece 3 S + e would go).
-template <bool KBLK, bool FLIP, int NLOAD, bool XT = false, bool ST = false>      // NLOAD loader waves (4 or 2); ST: statistics epilogue (big_qstats)
+template <bool KBLK, bool FLIP, int NLOAD, bool XT = false, bool ST = false, typename T = bf16_t>      // NLOAD loader waves (4 or 2); ST: statistics epilogue (big_qstats)
 __global__ __launch_bounds__(NTHR, 2) void gemm_bigp_kernel(const BigArgs p) {
   constexpr int TAPS = 3;
   static_assert(!XT || (KBLK && !FLIP), "the K extension is a forward product on K-blocked weights");
@@ -549,8 +555,8 @@ __global__ __launch_bounds__(NTHR, 2) void gemm_bigp_kernel(const BigArgs p) {
 #pragma unroll
           for (int j = 0; j < FN; j++) {
             const uint2 r = res[i][j];
-            acc[i][j][0] += add[j].x + __uint_as_float(r.x << 16); acc[i][j][1] += add[j].y + __uint_as_float(r.x & 0xffff0000u);
-            acc[i][j][2] += add[j].z + __uint_as_float(r.y << 16); acc[i][j][3] += add[j].w + __uint_as_float(r.y & 0xffff0000u);
+            acc[i][j][0] += add[j].x + w16_lo<T>(r.x); acc[i][j][1] += add[j].y + w16_hi<T>(r.x);
+            acc[i][j][2] += add[j].z + w16_lo<T>(r.y); acc[i][j][3] += add[j].w + w16_hi<T>(r.y);
           }
       } else {
 #pragma unroll
@@ -573,7 +579,7 @@ __global__ __launch_bounds__(NTHR, 2) void gemm_bigp_kernel(const BigArgs p) {
       for (int i = 0; i < FM; i++) {
 #pragma unroll
         for (int j = 0; j < FN; j++)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, bf0[j]), __builtin_bit_cast(bf16x8, af[i]), acc[i][j], 0, 0, 0);
+          acc[i][j] = big_mma<T>(bf0[j], af[i], acc[i][j]);
         if (i == 0) {
           __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -604,7 +610,7 @@ __global__ __launch_bounds__(NTHR, 2) void gemm_bigp_kernel(const BigArgs p) {
       for (int i = 0; i < FM; i++) {
 #pragma unroll
         for (int j = 0; j < FN; j++) {
-          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, bf1[j]), __builtin_bit_cast(bf16x8, af[i]), acc[i][j], 0, 0, 0);
+          acc[i][j] = big_mma<T>(bf1[j], af[i], acc[i][j]);
           if (LOADER && (has3 || (XT && xi >= 0))) {
 #pragma unroll
             for (int k = 0; k < NB + NA + 1; k++) if (k < n_dma && (k * (FM * FN)) / n_dma == i * FN + j) { if (XT && xi >= 0) issue_x(x_ab, x_bb, k); else issue(s + 1, t, k); }
@@ -623,7 +629,7 @@ __global__ __launch_bounds__(NTHR, 2) void gemm_bigp_kernel(const BigArgs p) {
       for (int i = 0; i < FM; i++) {
 #pragma unroll
         for (int j = 0; j < FN; j++)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, bf0[j]), __builtin_bit_cast(bf16x8, af[i]), acc[i][j], 0, 0, 0);
+          acc[i][j] = big_mma<T>(bf0[j], af[i], acc[i][j]);
         if (i == 0) {
           __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -651,7 +657,7 @@ __global__ __launch_bounds__(NTHR, 2) void gemm_bigp_kernel(const BigArgs p) {
       for (int i = 0; i < FM; i++) {
 #pragma unroll
         for (int j = 0; j < FN; j++) {
-          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, bf1[j]), __builtin_bit_cast(bf16x8, af[i]), acc[i][j], 0, 0, 0);
+          acc[i][j] = big_mma<T>(bf1[j], af[i], acc[i][j]);
           if (LOADER && has2) {
 #pragma unroll
             for (int k = 0; k < n_dma; k++) if ((k * (FM * FN)) / n_dma == i * FN + j) issue_x(ab, bb2, k);
@@ -728,7 +734,7 @@ __global__ __launch_bounds__(NTHR, 2) void gemm_bigp_kernel(const BigArgs p) {
         if (LOADER) { set_tile(m1, n1); issue_all(0); issue_all(1); issue_all(2); }
         __builtin_amdgcn_sched_barrier(0);
       }
-      big_store(p, acc, m0, n0, lm, q, wm, wn);
+      big_store<T>(p, acc, m0, n0, lm, q, wm, wn);
       if (!more) {
         if constexpr (ST) {      // the last tile's partials: one more barrier, then the partners flush
           asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -754,7 +760,7 @@ __global__ __launch_bounds__(NTHR, 2) void gemm_bigp_kernel(const BigArgs p) {
 // which it runs as NT products on the transposed weight copy (+3 % over the transposed-operand kernel).
 constexpr int S1_BYTES = A_MAIN + B_ALLOC;          // 56 KB per stage
 constexpr int LDS1_BYTES = 2 * S1_BYTES > EPI_BYTES ? 2 * S1_BYTES : EPI_BYTES;
-template <bool KBLK>      // KBLK: B is [K / 32][N][32] (the data-gradient copy of a 1 x 1 conv weight), else plain [N][ldb]
+template <bool KBLK, typename T = bf16_t>      // KBLK: B is [K / 32][N][32] (the data-gradient copy of a 1 x 1 conv weight), else plain [N][ldb]
 __global__ __launch_bounds__(NTHR, 2) void gemm_big1_kernel(const BigArgs p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -818,7 +824,7 @@ __global__ __launch_bounds__(NTHR, 2) void gemm_big1_kernel(const BigArgs p) {
     for (int i = 0; i < FM; i++) {
 #pragma unroll
       for (int j = 0; j < FN; j++)
-        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, bf0[j]), __builtin_bit_cast(bf16x8, af[i]), acc[i][j], 0, 0, 0);
+        acc[i][j] = big_mma<T>(bf0[j], af[i], acc[i][j]);
       if (i == 0) {
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -840,7 +846,7 @@ __global__ __launch_bounds__(NTHR, 2) void gemm_big1_kernel(const BigArgs p) {
     for (int i = 0; i < FM; i++) {
 #pragma unroll
       for (int j = 0; j < FN; j++) {
-        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, bf1[j]), __builtin_bit_cast(bf16x8, af[i]), acc[i][j], 0, 0, 0);
+        acc[i][j] = big_mma<T>(bf1[j], af[i], acc[i][j]);
         if (has2 && i <= 3) { const int k = 2 * i + (j >> 1); if ((j & 1) && k < 7) issue(s + 2, k); }
       }
       if (has1) af[i] = *(const uint4*)(sm1 + aof + i * 2048);
@@ -852,13 +858,13 @@ __global__ __launch_bounds__(NTHR, 2) void gemm_big1_kernel(const BigArgs p) {
   if (S > 1) phase(S - 2, true, false);
   phase(S - 1, false, false);
   __syncthreads();
-  big_epilogue(p, acc, smem, m0, n0, tid, lm, q, wm, wn);
+  big_epilogue<T>(p, acc, smem, m0, n0, tid, lm, q, wm, wn);
 }
 
 // ---- persistent form of the 1-tap kernel (structure and reasons: gemm_bigp_kernel).  Ring = two (A, B) stage buffers; behind the last
 // barrier of a tile both are free, so stages 0 and 1 of the next tile are requested before the output leaves; stage 2 follows behind
 // the first barrier of the next tile, and the loaders' stores have until its second barrier.
-template <bool KBLK, int NLOAD, bool ST = false>
+template <bool KBLK, int NLOAD, bool ST = false, typename T = bf16_t>
 __global__ __launch_bounds__(NTHR, 2) void gemm_big1p_kernel(const BigArgs p) {
   static_assert(NLOAD == 2 || NLOAD == 4, "vmcnt holds 63");
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -952,8 +958,8 @@ __global__ __launch_bounds__(NTHR, 2) void gemm_big1p_kernel(const BigArgs p) {
 #pragma unroll
           for (int j = 0; j < FN; j++) {
             const uint2 r = res[i][j];
-            acc[i][j][0] += add[j].x + __uint_as_float(r.x << 16); acc[i][j][1] += add[j].y + __uint_as_float(r.x & 0xffff0000u);
-            acc[i][j][2] += add[j].z + __uint_as_float(r.y << 16); acc[i][j][3] += add[j].w + __uint_as_float(r.y & 0xffff0000u);
+            acc[i][j][0] += add[j].x + w16_lo<T>(r.x); acc[i][j][1] += add[j].y + w16_hi<T>(r.x);
+            acc[i][j][2] += add[j].z + w16_lo<T>(r.y); acc[i][j][3] += add[j].w + w16_hi<T>(r.y);
           }
       } else {
 #pragma unroll
@@ -973,7 +979,7 @@ __global__ __launch_bounds__(NTHR, 2) void gemm_big1p_kernel(const BigArgs p) {
       for (int i = 0; i < FM; i++) {
 #pragma unroll
         for (int j = 0; j < FN; j++)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, bf0[j]), __builtin_bit_cast(bf16x8, af[i]), acc[i][j], 0, 0, 0);
+          acc[i][j] = big_mma<T>(bf0[j], af[i], acc[i][j]);
         if (i == 0) {
           __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -1001,7 +1007,7 @@ __global__ __launch_bounds__(NTHR, 2) void gemm_big1p_kernel(const BigArgs p) {
       for (int i = 0; i < FM; i++) {
 #pragma unroll
         for (int j = 0; j < FN; j++) {
-          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, bf1[j]), __builtin_bit_cast(bf16x8, af[i]), acc[i][j], 0, 0, 0);
+          acc[i][j] = big_mma<T>(bf1[j], af[i], acc[i][j]);
           if (LOADER && has2) {
 #pragma unroll
             for (int k = 0; k < NS; k++) if ((k * (FM * FN)) / NS == i * FN + j) issue(s + 2, k);
@@ -1060,7 +1066,7 @@ __global__ __launch_bounds__(NTHR, 2) void gemm_big1p_kernel(const BigArgs p) {
         if (LOADER) { set_tile(m1, n1); issue_all(0); if (S > 1) issue_all(1); }
         __builtin_amdgcn_sched_barrier(0);
       }
-      big_store(p, acc, m0, n0, lm, q, wm, wn);
+      big_store<T>(p, acc, m0, n0, lm, q, wm, wn);
       if (!more) {
         if constexpr (ST) {
           asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -1078,9 +1084,9 @@ __global__ __launch_bounds__(NTHR, 2) void gemm_big1p_kernel(const BigArgs p) {
   if (wave_u < NLOAD) run(std::true_type{}); else run(std::false_type{});
 }
 
-template <bool KBLK, int NLOAD, bool ST = false>
+template <bool KBLK, int NLOAD, bool ST = false, typename T = bf16_t>
 int launch_big1p(eegldm_ctx* ctx, const BigArgs& a) {
-  auto kern = gemm_big1p_kernel<KBLK, NLOAD, ST>;
+  auto kern = gemm_big1p_kernel<KBLK, NLOAD, ST, T>;
   static DevOnce attr_once;
   constexpr int LDSB = 2 * S1_BYTES + (ST ? QST_BYTES : 0);
   if (attr_once.need(ctx->device)) HIP_TRY(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDSB));
@@ -1092,21 +1098,24 @@ int launch_big1p(eegldm_ctx* ctx, const BigArgs& a) {
   return 0;
 }
 
-template <bool KBLK>
+template <bool KBLK, typename T = bf16_t>
 int launch_big1(eegldm_ctx* ctx, const BigArgs& a) {
   EEG_ENV_VAR(bool, no_persist, getenv("EEGLDM_GEMM_BIG_NO_PERSIST") != nullptr || getenv("EEGLDM_GEMM_BIG1_NO_PERSIST") != nullptr);
-  if (!no_persist) return a.qstats ? launch_big1p<KBLK, 4, true>(ctx, a) : launch_big1p<KBLK, 4>(ctx, a);
-  auto kern = gemm_big1_kernel<KBLK>;
-  static DevOnce attr_once;
-  if (attr_once.need(ctx->device)) HIP_TRY(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS1_BYTES));
-  hipLaunchKernelGGL(kern, dim3(a.tiles_m * a.tiles_n), dim3(NTHR), LDS1_BYTES, ctx->stream, a);
-  LAUNCH_CHECK();
+  // (fp16 runs the persistent form only: the one-tile-per-workgroup kernels are a bf16 developer A/B)
+  if (!no_persist || !Is16<T>::bf16) { if constexpr (Is16<T>::bf16) { if (a.qstats) return launch_big1p<KBLK, 4, true, T>(ctx, a); } return launch_big1p<KBLK, 4, false, T>(ctx, a); }
+  if constexpr (Is16<T>::bf16) {
+    auto kern = gemm_big1_kernel<KBLK, T>;
+    static DevOnce attr_once;
+    if (attr_once.need(ctx->device)) HIP_TRY(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS1_BYTES));
+    hipLaunchKernelGGL(kern, dim3(a.tiles_m * a.tiles_n), dim3(NTHR), LDS1_BYTES, ctx->stream, a);
+    LAUNCH_CHECK();
+  }
   return 0;
 }
 
-template <bool KBLK, bool FLIP, int NLOAD, bool ST = false>
+template <bool KBLK, bool FLIP, int NLOAD, bool ST = false, typename T = bf16_t>
 int launch_bigp(eegldm_ctx* ctx, const BigArgs& a) {
-  auto kern = gemm_bigp_kernel<KBLK, FLIP, NLOAD, false, ST>;
+  auto kern = gemm_bigp_kernel<KBLK, FLIP, NLOAD, false, ST, T>;
   static DevOnce attr_once;      // the dynamic-LDS attribute is per device
   constexpr int LDSB = RING + (ST ? QST_BYTES : 0);
   if (attr_once.need(ctx->device)) HIP_TRY(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDSB));
@@ -1118,9 +1127,9 @@ int launch_bigp(eegldm_ctx* ctx, const BigArgs& a) {
   return 0;
 }
 
-template <bool ST>
+template <bool ST, typename T = bf16_t>
 int launch_bigx(eegldm_ctx* ctx, const BigArgs& a) {      // K extension: persistent form only
-  auto kern = gemm_bigp_kernel<true, false, 4, true, ST>;
+  auto kern = gemm_bigp_kernel<true, false, 4, true, ST, T>;
   static DevOnce attr_once;
   constexpr int LDSB = RING + (ST ? QST_BYTES : 0);
   if (attr_once.need(ctx->device)) HIP_TRY(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDSB));
@@ -1132,18 +1141,20 @@ int launch_bigx(eegldm_ctx* ctx, const BigArgs& a) {      // K extension: persis
   return 0;
 }
 
-template <int TAPS, bool KBLK, bool FLIP>
+template <int TAPS, bool KBLK, bool FLIP, typename T = bf16_t>
 int launch_big(eegldm_ctx* ctx, const BigArgs& a) {
   EEG_ENV_VAR(bool, no_persist, getenv("EEGLDM_GEMM_BIG_NO_PERSIST") != nullptr);
-  if (!no_persist) {      // (2 loader waves measured equal: tools/debug/gemm_big_check.py, round 4)
-    if constexpr (KBLK && !FLIP) { if (a.qstats) return launch_bigp<KBLK, FLIP, 4, true>(ctx, a); }
-    return launch_bigp<KBLK, FLIP, 4>(ctx, a);
+  if (!no_persist || !Is16<T>::bf16) {      // (2 loader waves measured equal: tools/debug/gemm_big_check.py, round 4)
+    if constexpr (KBLK && !FLIP && Is16<T>::bf16) { if (a.qstats) return launch_bigp<KBLK, FLIP, 4, true, T>(ctx, a); }
+    return launch_bigp<KBLK, FLIP, 4, false, T>(ctx, a);
   }
-  auto kern = gemm_big_kernel<TAPS, KBLK, FLIP>;
-  static DevOnce attr_once;      // the dynamic-LDS attribute is per device
-  if (attr_once.need(ctx->device)) HIP_TRY(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
-  hipLaunchKernelGGL(kern, dim3(a.tiles_m * a.tiles_n), dim3(NTHR), LDS_BYTES, ctx->stream, a);
-  LAUNCH_CHECK();
+  if constexpr (Is16<T>::bf16) {
+    auto kern = gemm_big_kernel<TAPS, KBLK, FLIP, T>;
+    static DevOnce attr_once;      // the dynamic-LDS attribute is per device
+    if (attr_once.need(ctx->device)) HIP_TRY(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
+    hipLaunchKernelGGL(kern, dim3(a.tiles_m * a.tiles_n), dim3(NTHR), LDS_BYTES, ctx->stream, a);
+    LAUNCH_CHECK();
+  }
   return 0;
 }
 
@@ -1155,7 +1166,7 @@ int launch_big(eegldm_ctx* ctx, const BigArgs& a) {
 int gemm_big_try(eegldm_ctx* ctx, const GemmArgs& g) {
   EEG_ENV_VAR(bool, off, getenv("EEGLDM_NO_GEMM_BIG") != nullptr);
   EEG_ENV_VAR(int, min_tiles, getenv("EEGLDM_GEMM_BIG_MIN_TILES") ? atoi(getenv("EEGLDM_GEMM_BIG_MIN_TILES")) : 128);
-  if (off || g.dtype != EEGLDM_BF16 || g.bmode != GB_NT || g.batch != 1 || g.splitk > 1 || g.ztaps > 1 || g.out_f32 || g.atomic_out || g.colsum || g.ngroup) return 0;
+  if (off || (g.dtype != EEGLDM_BF16 && g.dtype != EEGLDM_F16) || g.bmode != GB_NT || g.batch != 1 || g.splitk > 1 || g.ztaps > 1 || g.out_f32 || g.atomic_out || g.colsum || g.ngroup) return 0;
   if (g.alpha != 1.0f || g.ups > 1) return 0;
   const bool conv3 = g.amode == GA_CONV && g.taps == 3 && g.stride == 1 && g.pad_l == 1 && g.Lin == g.Lout;
   const bool plain1 = g.amode == GA_PLAIN && g.taps == 1;
@@ -1179,11 +1190,16 @@ int gemm_big_try(eegldm_ctx* ctx, const GemmArgs& g) {
   // statistics epilogue: persistent kernels only, forward products (K-blocked 3-tap weights / plain 1-tap weights), whole tiles inside one sample
   EEG_ENV_VAR(bool, no_persist_q, getenv("EEGLDM_GEMM_BIG_NO_PERSIST") != nullptr || getenv("EEGLDM_GEMM_BIG1_NO_PERSIST") != nullptr);
   a.qstats = nullptr; a.qL = 0;
-  if (g.qstats && g.qstats_done && !no_persist_q && g.qstats_L > 0 && g.qstats_L % BM == 0 && !g.tap_flip && (conv3 ? g.b_kblk != 0 : !g.b_kblk)) {
+  if (g.dtype == EEGLDM_BF16 && g.qstats && g.qstats_done && !no_persist_q && g.qstats_L > 0 && g.qstats_L % BM == 0 && !g.tap_flip && (conv3 ? g.b_kblk != 0 : !g.b_kblk)) {
     a.qstats = g.qstats; a.qL = g.qstats_L; *g.qstats_done = 1;
   }
   int rc;
-  if (!conv3) rc = g.b_kblk ? launch_big1<true>(ctx, a) : launch_big1<false>(ctx, a);
+  if (g.dtype == EEGLDM_F16) {      // round 5: the same kernels on IEEE-half operands (persistent forms)
+    if (!conv3) rc = g.b_kblk ? launch_big1<true, f16_t>(ctx, a) : launch_big1<false, f16_t>(ctx, a);
+    else if (g.tap_flip) rc = g.b_kblk ? launch_big<3, true, true, f16_t>(ctx, a) : launch_big<3, false, true, f16_t>(ctx, a);
+    else rc = g.b_kblk ? launch_big<3, true, false, f16_t>(ctx, a) : launch_big<3, false, false, f16_t>(ctx, a);
+  }
+  else if (!conv3) rc = g.b_kblk ? launch_big1<true>(ctx, a) : launch_big1<false>(ctx, a);
   else if (g.tap_flip) rc = g.b_kblk ? launch_big<3, true, true>(ctx, a) : launch_big<3, false, true>(ctx, a);
   else rc = g.b_kblk ? launch_big<3, true, false>(ctx, a) : launch_big<3, false, false>(ctx, a);
   return rc < 0 ? rc : 1;
@@ -1195,7 +1211,7 @@ int gemm_big_try(eegldm_ctx* ctx, const GemmArgs& g) {
 int gemm_big_skip_try(eegldm_ctx* ctx, const GemmArgs& g, const void* x2, long ldx2, const void* w2_kblk, int K2, const float* bias2) {
   EEG_ENV_VAR(bool, off, getenv("EEGLDM_NO_GEMM_BIG") != nullptr || getenv("EEGLDM_NO_FUSED_SKIP") != nullptr || getenv("EEGLDM_GEMM_BIG_NO_PERSIST") != nullptr);
   EEG_ENV_VAR(int, min_tiles, getenv("EEGLDM_GEMM_BIG_MIN_TILES") ? atoi(getenv("EEGLDM_GEMM_BIG_MIN_TILES")) : 128);
-  if (off || g.dtype != EEGLDM_BF16 || g.bmode != GB_NT || !g.b_kblk || g.batch > 1 || g.splitk > 1 || g.out_f32 || g.atomic_out || g.resid) return 0;
+  if (off || (g.dtype != EEGLDM_BF16 && g.dtype != EEGLDM_F16) || g.bmode != GB_NT || !g.b_kblk || g.batch > 1 || g.splitk > 1 || g.out_f32 || g.atomic_out || g.resid) return 0;
   if (!(g.amode == GA_CONV && g.taps == 3 && g.stride == 1 && g.pad_l == 1 && g.Lin == g.Lout) || g.ups > 1 || g.alpha != 1.0f) return 0;
   if (g.M % BM != 0 || g.Lout % BM != 0 || g.N % BN != 0 || g.K % BK != 0 || g.K < 2 * BK || g.lda % 8 != 0 || g.ldc % 8 != 0) return 0;
   if (!x2 || !w2_kblk || K2 % BK != 0 || K2 < 2 * BK || ldx2 % 8 != 0) return 0;
@@ -1210,7 +1226,7 @@ int gemm_big_skip_try(eegldm_ctx* ctx, const GemmArgs& g, const void* x2, long l
   a.resid = nullptr; a.ldr = 0; a.zero_page = ctx->zero_page; a.tiles_m = tm; a.tiles_n = tn;
   a.A2 = (const bf16_t*)x2; a.lda2 = ldx2; a.B2 = (const bf16_t*)w2_kblk; a.K2 = K2; a.bias2 = bias2;
   a.qstats = nullptr; a.qL = 0;
-  if (g.qstats && g.qstats_done) { a.qstats = g.qstats; a.qL = g.Lout; *g.qstats_done = 1; }
+  if (g.dtype == EEGLDM_BF16 && g.qstats && g.qstats_done) { a.qstats = g.qstats; a.qL = g.Lout; *g.qstats_done = 1; }
   ProfRec rec; const bool prof = ctx->prof_on;
   if (prof) {
     rec.cls = PROF_CONV_FWD; rec.flops = 2.0 * g.M * g.N * ((double)g.K * 3 + K2);
@@ -1218,7 +1234,7 @@ int gemm_big_skip_try(eegldm_ctx* ctx, const GemmArgs& g, const void* x2, long l
     HIP_TRY(hipEventCreate(&rec.a)); HIP_TRY(hipEventCreate(&rec.b));
     HIP_TRY(hipEventRecord(rec.a, ctx->stream));
   }
-  const int rc = a.qstats ? launch_bigx<true>(ctx, a) : launch_bigx<false>(ctx, a);
+  const int rc = g.dtype == EEGLDM_F16 ? launch_bigx<false, f16_t>(ctx, a) : (a.qstats ? launch_bigx<true>(ctx, a) : launch_bigx<false>(ctx, a));
   if (prof) { HIP_TRY(hipEventRecord(rec.b, ctx->stream)); ctx->prof.push_back(rec); }
   return rc < 0 ? rc : 1;
 }

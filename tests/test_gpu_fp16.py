@@ -327,3 +327,44 @@ def test_gan_step_and_ddim_sampling_in_fp16_follow_the_fp32_engine():
     rw = float((res["float16"][0] - res["float32"][0]).norm() / res["float32"][0].norm())
     print(f"fp16 vs fp32 engine: GAN losses {lo16.tolist()} vs {lo32.tolist()}; DDIM-10 latents {rl:.2e}, windows {rw:.2e}")
     assert rl < 2e-2 and rw < 3e-2, (rl, rw)
+
+
+@pytest.mark.parametrize("case", [(4, 192, 512, 512, 3), (2, 384, 768, 256, 3), (3, 192, 512, 1536, 1), (160, 192, 256, 512, 3)])
+def test_big_tile_kernels_on_half_precision_operands(case, env_switches):
+    """The 192 x 256 persistent kernels (gemm_big.hip) instantiated for f16_t: 3-tap conv forward (bias + embedding row + residual), data
+    gradient through the transposed K-blocked copy, 1 x 1 conv, and the fused skip-connection tail, against torch's fp32 convs on
+    fp16-rounded operands; the last case has more tiles than CUs (workgroups walk several tiles)."""
+    import gpu_util as G
+    c = G.ctx(); dt = G.F16
+    B, L, Cin, Cout, K = case
+    env_switches(EEGLDM_GEMM_BIG_MIN_TILES="1", EEGLDM_NO_CONV_SKINNY="1")
+    x = h(torch.from_numpy(normal((B, Cin, L), seed=1))); w = h(torch.from_numpy(normal((Cout, Cin, K), seed=2)) / math.sqrt(Cin * K))
+    b = torch.from_numpy(normal((Cout,), seed=3)); e = torch.from_numpy(normal((B, Cout), seed=5)); r = h(torch.from_numpy(normal((B, Cout, L), seed=6)))
+    ref = F.conv1d(x, w, b, padding=K // 2) + e[:, :, None] + r
+    xd, wd, bd, ed, rd = G.nlc(x, dt), G.pack_w(w, dt), b.to(G.DEV), e.to(G.DEV), G.nlc(r, dt)
+    wk = torch.empty_like(wd); wt = torch.empty_like(wd)
+    c.prof_enable(True)
+    if K == 3: G.check(G.lib.eegldm_conv1d_pack_kblocked(c.h, G.ptr(wd), G.ptr(wk), Cout, Cin, dt))
+    if Cin % 256 == 0: G.check(G.lib.eegldm_conv1d_pack_dgrad_k(c.h, G.ptr(wd), G.ptr(wt), Cout, Cin, K, dt))
+    try:
+        yd = torch.full((B * L, Cout), float("nan"), device=G.DEV, dtype=torch.float16)
+        G.check(G.lib.eegldm_conv1d_fwd(c.h, G.ptr(xd), Cin, G.ptr(wd), G.ptr(bd), G.ptr(yd), Cout, B, L, Cin, Cout, K, 1, K // 2, K // 2, G.ptr(ed), Cout, G.ptr(rd), Cout, dt))
+        G.assert_close(G.ncl(yd, B, L), ref, **G.TOL[dt], name="y")
+        if Cin % 256 == 0:
+            dy = h(torch.from_numpy(normal((B, Cout, L), seed=7)))
+            refd = F.conv_transpose1d(dy, w, padding=K // 2)
+            dxd = torch.full((B * L, Cin), float("nan"), device=G.DEV, dtype=torch.float16)
+            G.check(G.lib.eegldm_conv1d_bwd_data(c.h, G.ptr(G.nlc(dy, dt)), Cout, G.ptr(wd), G.ptr(dxd), Cin, B, L, Cin, Cout, K, 1, K // 2, K // 2, None, 0, dt))
+            G.assert_close(G.ncl(dxd, B, L), refd, **G.GTOL[dt], name="dx")
+        if K == 3 and B <= 8:      # fused ResBlock tail: conv3(x) + conv1(x2)
+            C2 = 256
+            x2 = h(torch.from_numpy(normal((B, C2, L), seed=8))); w2 = h(torch.from_numpy(normal((Cout, C2, 1), seed=9)) / math.sqrt(C2)); b2 = torch.from_numpy(normal((Cout,), seed=10))
+            x2d, w2d, b2d = G.nlc(x2, dt), G.pack_w(w2, dt), b2.to(G.DEV)
+            w2k = torch.empty_like(w2d); G.check(G.lib.eegldm_conv1d_pack_kblocked_k(c.h, G.ptr(w2d), G.ptr(w2k), Cout, C2, 1, dt))
+            y2 = torch.full((B * L, Cout), float("nan"), device=G.DEV, dtype=torch.float16)
+            G.check(G.lib.eegldm_conv1d_skip_fwd(c.h, G.ptr(xd), Cin, G.ptr(wd), G.ptr(bd), G.ptr(x2d), C2, G.ptr(w2d), G.ptr(b2d), G.ptr(y2), Cout, B, L, Cin, C2, Cout, None, 0, dt))
+            G.assert_close(G.ncl(y2, B, L), F.conv1d(x, w, b, padding=1) + F.conv1d(x2, w2, b2), **G.TOL[dt], name="fused skip")
+            G.check(G.lib.eegldm_conv1d_forget_kblocked(c.h, G.ptr(w2d)))
+    finally:
+        G.check(G.lib.eegldm_conv1d_forget_kblocked(c.h, G.ptr(wd)))
+        c.prof_enable(False)
