@@ -26,8 +26,10 @@ __device__ __forceinline__ void dma16a(const void* g, unsigned lds_off) {
   const unsigned off_s = __builtin_amdgcn_readfirstlane(lds_off);      // wave-uniform by construction; M0 must come from an SGPR
   asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off" ::"s"(off_s), "v"(g) : "memory", "m0");
 }
+template <typename T>
 __device__ __forceinline__ void mma16(const uint4& a, const uint4& b, f32x4& acc) {
-  acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), acc, 0, 0, 0);
+  if constexpr (Is16<T>::f16) acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), acc, 0, 0, 0);
+  else acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), acc, 0, 0, 0);
 }
 // K-strided 16-column fragment of a [32 k rows][256 cols] bf16 tile (see gemm.hip read_tr_bf16)
 __device__ __forceinline__ uint4 read_tr256(const char* tile, int x0, int lm, int q) {
@@ -80,7 +82,7 @@ constexpr int NTA = 256;
 
 // NQ = 64-row query tiles per block: 1 (grid = T/64 x B) or NJ (one block = one whole sample: K / V tiles are staged once
 // for all query rows and, at B = 256, the grid is exactly one block per CU -- no 1.5-round tail).
-template <int NJT, int MODE, int NQ, int NCW, int NC2T>
+template <int NJT, int MODE, int NQ, int NCW, int NC2T, typename T16>
 __global__ __launch_bounds__(64 * NCW * NQ) void attn_chain_kernel(const ChainArgs p) {
   constexpr int T = 64 * NJT;                     // keys
   constexpr int NJ = 4 * NJT / NCW;               // 16-column key fragments per column wave
@@ -213,7 +215,7 @@ __global__ __launch_bounds__(64 * NCW * NQ) void attn_chain_kernel(const ChainAr
     for (int i = 0; i < 4; i++)
 #pragma unroll
       for (int j = 0; j < NJ; j++) {
-        mma16(bfr[j], af[i], acc[i][j]);     // swapped: acc[i][j][r] = S[i*16+lm][(w*NJ+j)*16 + q*4 + r]
+        mma16<T16>(bfr[j], af[i], acc[i][j]);     // swapped: acc[i][j][r] = S[i*16+lm][(w*NJ+j)*16 + q*4 + r]
         const int m = i * NJ + j;              // compile-time after unrolling
         if ((m + 1) % EVERY1 == 0 && (m + 1) / EVERY1 - 1 < PER1) {
           const int k = (m + 1) / EVERY1 - 1;
@@ -302,7 +304,7 @@ __global__ __launch_bounds__(64 * NCW * NQ) void attn_chain_kernel(const ChainAr
       const float inv = 1.0f / sum[i];
 #pragma unroll
       for (int j = 0; j < NJ; j++) {
-        uint2 o; o.x = pack_bf16x2(acc[i][j][0] * inv, acc[i][j][1] * inv); o.y = pack_bf16x2(acc[i][j][2] * inv, acc[i][j][3] * inv);
+        uint2 o; o.x = pack16x2<T16>(acc[i][j][0] * inv, acc[i][j][1] * inv); o.y = pack16x2<T16>(acc[i][j][2] * inv, acc[i][j][3] * inv);
         const int col = (w * NJ + j) * 16 + q * 4;
         if constexpr (NCW == 8) pk[i][j] = o; else *(uint2*)(pt + (mq + i * 16 + lm) * PP + col * 2) = o;
         *(uint2*)(p.P + (long)b * p.sP + (long)(m0 + mq + i * 16 + lm) * T + col) = o;
@@ -315,8 +317,8 @@ __global__ __launch_bounds__(64 * NCW * NQ) void attn_chain_kernel(const ChainAr
       float s = 0.f;
 #pragma unroll
       for (int j = 0; j < NJ; j++) {
-        const float p0 = __uint_as_float(pr[i][j].x << 16), p1 = __uint_as_float(pr[i][j].x & 0xffff0000u);
-        const float p2 = __uint_as_float(pr[i][j].y << 16), p3 = __uint_as_float(pr[i][j].y & 0xffff0000u);
+        const float p0 = w16_lo<T16>(pr[i][j].x), p1 = w16_hi<T16>(pr[i][j].x);
+        const float p2 = w16_lo<T16>(pr[i][j].y), p3 = w16_hi<T16>(pr[i][j].y);
         s += acc[i][j][0] * p0 + acc[i][j][1] * p1 + acc[i][j][2] * p2 + acc[i][j][3] * p3;
       }
       dl[i] = s;
@@ -326,11 +328,11 @@ __global__ __launch_bounds__(64 * NCW * NQ) void attn_chain_kernel(const ChainAr
     for (int i = 0; i < 4; i++)
 #pragma unroll
       for (int j = 0; j < NJ; j++) {
-        const float p0 = __uint_as_float(pr[i][j].x << 16), p1 = __uint_as_float(pr[i][j].x & 0xffff0000u);
-        const float p2 = __uint_as_float(pr[i][j].y << 16), p3 = __uint_as_float(pr[i][j].y & 0xffff0000u);
+        const float p0 = w16_lo<T16>(pr[i][j].x), p1 = w16_hi<T16>(pr[i][j].x);
+        const float p2 = w16_lo<T16>(pr[i][j].y), p3 = w16_hi<T16>(pr[i][j].y);
         uint2 o;
-        o.x = pack_bf16x2(p.alpha * p0 * (acc[i][j][0] - dl[i]), p.alpha * p1 * (acc[i][j][1] - dl[i]));
-        o.y = pack_bf16x2(p.alpha * p2 * (acc[i][j][2] - dl[i]), p.alpha * p3 * (acc[i][j][3] - dl[i]));
+        o.x = pack16x2<T16>(p.alpha * p0 * (acc[i][j][0] - dl[i]), p.alpha * p1 * (acc[i][j][1] - dl[i]));
+        o.y = pack16x2<T16>(p.alpha * p2 * (acc[i][j][2] - dl[i]), p.alpha * p3 * (acc[i][j][3] - dl[i]));
         const int col = (w * NJ + j) * 16 + q * 4;
         if constexpr (NCW == 8) pk[i][j] = o; else *(uint2*)(pt + (mq + i * 16 + lm) * PP + col * 2) = o;
         *(uint2*)(p.dS + (long)b * p.sdS + (long)(m0 + mq + i * 16 + lm) * T + col) = o;
@@ -402,7 +404,7 @@ __global__ __launch_bounds__(64 * NCW * NQ) void attn_chain_kernel(const ChainAr
           for (int i = 0; i < 2; i++)
 #pragma unroll
             for (int j = 0; j < 4; j++) {
-              mma16(bfr[nc][j], af[i], o2[nc][i][j]);
+              mma16<T16>(bfr[nc][j], af[i], o2[nc][i][j]);
               const int m = nc * 8 + i * 4 + j;       // compile-time after unrolling: DMA piece m / 4 after every fourth MFMA
               if (m % 4 == 3 && more) {
                 const int pc = m / 4, nn = pc >> 1, ii = (int)wv + 8 * (pc & 1);
@@ -419,7 +421,7 @@ __global__ __launch_bounds__(64 * NCW * NQ) void attn_chain_kernel(const ChainAr
       for (int i = 0; i < 2; i++)
 #pragma unroll
         for (int j = 0; j < 4; j++) {
-          uint2 o; o.x = pack_bf16x2(o2[c][i][j][0], o2[c][i][j][1]); o.y = pack_bf16x2(o2[c][i][j][2], o2[c][i][j][3]);
+          uint2 o; o.x = pack16x2<T16>(o2[c][i][j][0], o2[c][i][j][1]); o.y = pack16x2<T16>(o2[c][i][j][2], o2[c][i][j][3]);
           *(uint2*)(p.O + (long)b * p.sO + (long)(m0 + mr + i * 16 + lm) * p.ldo + c * 256 + wc * 64 + j * 16 + q * 4) = o;
         }
     ATTN_STAMP(3);
@@ -491,14 +493,14 @@ __global__ __launch_bounds__(64 * NCW * NQ) void attn_chain_kernel(const ChainAr
 #pragma unroll
     for (int i = 0; i < RF2; i++)
 #pragma unroll
-      for (int j = 0; j < 4; j++) mma16(bfr[j], af[i], acc2[i][j]);
+      for (int j = 0; j < 4; j++) mma16<T16>(bfr[j], af[i], acc2[i][j]);
     if (u + DO2 - 1 < nut) issue_next((u + DO2 - 1) % DO2);      // behind the MFMAs: the matrix pipe works while the DMA instructions issue
     if (ks == nks - 1) {
 #pragma unroll
       for (int i = 0; i < RF2; i++)
 #pragma unroll
         for (int j = 0; j < 4; j++) {
-          uint2 o; o.x = pack_bf16x2(acc2[i][j][0], acc2[i][j][1]); o.y = pack_bf16x2(acc2[i][j][2], acc2[i][j][3]);
+          uint2 o; o.x = pack16x2<T16>(acc2[i][j][0], acc2[i][j][1]); o.y = pack16x2<T16>(acc2[i][j][2], acc2[i][j][3]);
           *(uint2*)(cdst + (long)b * sO + (long)(m0 + mq2 + i * 16 + lm) * ldo + nc * 256 + wc2 * 64 + j * 16 + q * 4) = o;
         }
       stores_pending = true;
@@ -519,7 +521,7 @@ __global__ __launch_bounds__(64 * NCW * NQ) void attn_chain_kernel(const ChainAr
   ATTN_STAMP(3);
 }
 
-template <int NJ, int MODE, int NQ, int NCW = 4, int NC2 = 1>
+template <int NJ, int MODE, int NQ, int NCW = 4, int NC2 = 1, typename T16 = bf16_t>
 int launch_chain_q(eegldm_ctx* ctx, const ChainArgs& a, int B) {
   constexpr int T = 64 * NJ, QR = 64 * NQ;
   constexpr int STG = QR * 64 + T * 64;
@@ -528,7 +530,7 @@ int launch_chain_q(eegldm_ctx* ctx, const ChainArgs& a, int B) {
   constexpr int LONG2 = 8 * 16384 + 2 * 4096 + QR * NCW * 4;      // long variant after product 1: tile ring, two score slices, row-reduction scratch
   constexpr int LDS = (NCW == 8) ? ((STAGE_AREA > LONG2) ? STAGE_AREA : LONG2) : STAGE_AREA + TILE;
   static_assert(LDS <= 160 * 1024, "attention tile does not fit the LDS");
-  auto kern = attn_chain_kernel<NJ, MODE, NQ, NCW, NC2>;
+  auto kern = attn_chain_kernel<NJ, MODE, NQ, NCW, NC2, T16>;
   static DevOnce attr;
   if (LDS > 48 * 1024 && attr.need(ctx->device)) HIP_TRY(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
   ChainArgs ax = a;
@@ -546,12 +548,12 @@ int launch_chain_q(eegldm_ctx* ctx, const ChainArgs& a, int B) {
   }
   return 0;
 }
-template <int NJ, int MODE>
+template <int NJ, int MODE, typename T16>
 int launch_chain(eegldm_ctx* ctx, const ChainArgs& a, int B) {
   // whole-sample blocks (12 waves at T = 192) when the batch alone fills the chip; 64-row blocks otherwise (more blocks)
   EEG_ENV_VAR(bool, no_whole, getenv("EEGLDM_ATTN_NO_WHOLE") != nullptr);
-  if constexpr (NJ == 3) { if (!no_whole && B >= ctx->num_cu / 2) return launch_chain_q<NJ, MODE, NJ>(ctx, a, B); }
-  return launch_chain_q<NJ, MODE, 1>(ctx, a, B);
+  if constexpr (NJ == 3) { if (!no_whole && B >= ctx->num_cu / 2) return launch_chain_q<NJ, MODE, NJ, 4, 1, T16>(ctx, a, B); }
+  return launch_chain_q<NJ, MODE, 1, 4, 1, T16>(ctx, a, B);
 }
 
 }  // namespace
@@ -559,21 +561,22 @@ int launch_chain(eegldm_ctx* ctx, const ChainArgs& a, int B) {
 bool attn_chain_ok(int dtype, int T, int C, long ldq, long ldo) {
   EEG_ENV_VAR(bool, off, getenv("EEGLDM_NO_FUSED_ATTENTION") != nullptr);
   EEG_ENV_VAR(bool, no_long, getenv("EEGLDM_ATTN_NO_LONG") != nullptr);      // T = 768 back to the GEMM + softmax composition
-  return !off && dtype == EEGLDM_BF16 && (T == 64 || T == 128 || T == 192 || T == 256 || (T == 768 && !no_long && (C == 256 || C == 512))) && C % 256 == 0 && ldq % 8 == 0 && ldo % 8 == 0;
+  return !off && (dtype == EEGLDM_BF16 || dtype == EEGLDM_F16) && (T == 64 || T == 128 || T == 192 || T == 256 || (T == 768 && !no_long && (C == 256 || C == 512))) && C % 256 == 0 && ldq % 8 == 0 && ldo % 8 == 0;
 }
 
 // forward: probs written, out = softmax(alpha q k^T) v
-int attn_chain_fwd(eegldm_ctx* ctx, const void* qkv, long ldq, void* out, long ldo, void* probs, int B, int T, int C) {
+template <typename T16>
+static int chain_fwd_t(eegldm_ctx* ctx, const void* qkv, long ldq, void* out, long ldo, void* probs, int B, int T, int C) {
   ChainArgs a = {};
   const bf16_t* q = (const bf16_t*)qkv;
   a.A1 = q; a.lda1 = ldq; a.sA1 = (long)T * ldq; a.B1 = q + C; a.ldb1 = ldq; a.sB1 = (long)T * ldq; a.B2 = q + 2 * C; a.ldb2 = ldq; a.sB2 = (long)T * ldq;
   a.P = (bf16_t*)probs; a.sP = (long)T * T; a.O = (bf16_t*)out; a.ldo = ldo; a.sO = (long)T * ldo; a.T = T; a.C = C; a.alpha = 1.0f / sqrtf((float)C);
   switch (T / 64) {
-    case 1: return launch_chain<1, 0>(ctx, a, B);
-    case 2: return launch_chain<2, 0>(ctx, a, B);
-    case 3: return launch_chain<3, 0>(ctx, a, B);
-    case 12: return C == 256 ? launch_chain_q<12, 0, 1, 8, 1>(ctx, a, B) : launch_chain_q<12, 0, 1, 8, 2>(ctx, a, B);
-    default: return launch_chain<4, 0>(ctx, a, B);
+    case 1: return launch_chain<1, 0, T16>(ctx, a, B);
+    case 2: return launch_chain<2, 0, T16>(ctx, a, B);
+    case 3: return launch_chain<3, 0, T16>(ctx, a, B);
+    case 12: return C == 256 ? launch_chain_q<12, 0, 1, 8, 1, T16>(ctx, a, B) : launch_chain_q<12, 0, 1, 8, 2, T16>(ctx, a, B);
+    default: return launch_chain<4, 0, T16>(ctx, a, B);
   }
 }
 // backward part: dS (scaled) written, dq = dS k
@@ -582,8 +585,9 @@ bool attn_chain_bwd_fuses_kv(eegldm_ctx* ctx, int B, int T) {
   EEG_ENV_VAR(bool, off, getenv("EEGLDM_ATTN_NO_FUSED_KV") != nullptr); EEG_ENV_VAR(bool, no_whole, getenv("EEGLDM_ATTN_NO_WHOLE") != nullptr);
   return !off && !no_whole && T == 192 && B >= ctx->num_cu / 2;
 }
-int attn_chain_bwd(eegldm_ctx* ctx, const void* qkv, long ldq, const void* probs, const void* dout, long lddo, void* dq, long lddq,
-                   void* dS, int B, int T, int C, int fuse_kv) {
+template <typename T16>
+static int chain_bwd_t(eegldm_ctx* ctx, const void* qkv, long ldq, const void* probs, const void* dout, long lddo, void* dq, long lddq,
+                       void* dS, int B, int T, int C, int fuse_kv) {
   ChainArgs a = {};
   const bf16_t* q = (const bf16_t*)qkv;
   a.A1 = (const bf16_t*)dout; a.lda1 = lddo; a.sA1 = (long)T * lddo; a.B1 = q + 2 * C; a.ldb1 = ldq; a.sB1 = (long)T * ldq;
@@ -594,10 +598,19 @@ int attn_chain_bwd(eegldm_ctx* ctx, const void* qkv, long ldq, const void* probs
     a.fuse_kv = fuse_kv == 2 ? 2 : 1; a.Q3 = q; a.ldq3 = ldq; a.sQ3 = (long)T * ldq; a.dK = (bf16_t*)dq + C; a.dV = (bf16_t*)dq + 2 * C;
   }
   switch (T / 64) {
-    case 1: return launch_chain<1, 1>(ctx, a, B);
-    case 2: return launch_chain<2, 1>(ctx, a, B);
-    case 3: return launch_chain<3, 1>(ctx, a, B);
-    case 12: return C == 256 ? launch_chain_q<12, 1, 1, 8, 1>(ctx, a, B) : launch_chain_q<12, 1, 1, 8, 2>(ctx, a, B);
-    default: return launch_chain<4, 1>(ctx, a, B);
+    case 1: return launch_chain<1, 1, T16>(ctx, a, B);
+    case 2: return launch_chain<2, 1, T16>(ctx, a, B);
+    case 3: return launch_chain<3, 1, T16>(ctx, a, B);
+    case 12: return C == 256 ? launch_chain_q<12, 1, 1, 8, 1, T16>(ctx, a, B) : launch_chain_q<12, 1, 1, 8, 2, T16>(ctx, a, B);
+    default: return launch_chain<4, 1, T16>(ctx, a, B);
   }
+}
+
+int attn_chain_fwd(eegldm_ctx* ctx, const void* qkv, long ldq, void* out, long ldo, void* probs, int B, int T, int C, int dtype) {
+  return dtype == EEGLDM_F16 ? chain_fwd_t<f16_t>(ctx, qkv, ldq, out, ldo, probs, B, T, C) : chain_fwd_t<bf16_t>(ctx, qkv, ldq, out, ldo, probs, B, T, C);
+}
+int attn_chain_bwd(eegldm_ctx* ctx, const void* qkv, long ldq, const void* probs, const void* dout, long lddo, void* dq, long lddq,
+                   void* dS, int B, int T, int C, int fuse_kv, int dtype) {
+  return dtype == EEGLDM_F16 ? chain_bwd_t<f16_t>(ctx, qkv, ldq, probs, dout, lddo, dq, lddq, dS, B, T, C, fuse_kv)
+                             : chain_bwd_t<bf16_t>(ctx, qkv, ldq, probs, dout, lddo, dq, lddq, dS, B, T, C, fuse_kv);
 }

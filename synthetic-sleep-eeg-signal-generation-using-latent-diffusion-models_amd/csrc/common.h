@@ -13,6 +13,7 @@
 
 typedef __attribute__((ext_vector_type(4))) float f32x4;
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef __attribute__((ext_vector_type(4))) short s16x4;
 typedef unsigned short bf16_t;  // storage type for bf16 tensors
 

@@ -51,7 +51,6 @@ template <> __device__ __forceinline__ void mma<bf16_t>(const uint4& a, const ui
   acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), acc, 0, 0, 0);
 }
 
-typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 template <> __device__ __forceinline__ void mma<f16_t>(const uint4& a, const uint4& b, f32x4& acc) {      // EEGLDM_F16: v_mfma_f32_16x16x32_f16
   acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), acc, 0, 0, 0);
 }

@@ -93,7 +93,7 @@ int pre_conv3_launch(eegldm_ctx*, const void* x, const double* in_stats, const f
 int sample_stats_launch(eegldm_ctx*, const void* x, long n_per_sample, int B, double* stats);
 // fused short-sequence attention (attn.hip)
 bool attn_chain_ok(int dtype, int T, int C, long ldq, long ldo);
-int attn_chain_fwd(eegldm_ctx*, const void* qkv, long ldq, void* out, long ldo, void* probs, int B, int T, int C);
+int attn_chain_fwd(eegldm_ctx*, const void* qkv, long ldq, void* out, long ldo, void* probs, int B, int T, int C, int dtype);
 int attn_chain_bwd(eegldm_ctx*, const void* qkv, long ldq, const void* probs, const void* dout, long lddo, void* dq, long lddq,
-                   void* dS, int B, int T, int C, int fuse_kv = 0);
+                   void* dS, int B, int T, int C, int fuse_kv, int dtype);
 bool attn_chain_bwd_fuses_kv(eegldm_ctx*, int B, int T);      // whole-sample blocks: the backward kernel also writes dK and dV (no TN GEMMs)

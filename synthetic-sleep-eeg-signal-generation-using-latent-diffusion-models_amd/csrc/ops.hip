@@ -257,7 +257,7 @@ int op_linear_wgrad(eegldm_ctx* ctx, int dtype, const void* x, long ldx, const v
 // ------------------------------------------------------------------ attention (unet.py:107-125)
 int op_attention_fwd(eegldm_ctx* ctx, int dtype, const void* qkv, long ldq, void* out, long ldo, void* probs, float* logits,
                      int B, int T, int C) {
-  if (attn_chain_ok(dtype, T, C, ldq, ldo)) return attn_chain_fwd(ctx, qkv, ldq, out, ldo, probs, B, T, C);
+  if (attn_chain_ok(dtype, T, C, ldq, ldo)) return attn_chain_fwd(ctx, qkv, ldq, out, ldo, probs, B, T, C, dtype);
   const size_t es = dtype_size(dtype);
   const char* q = (const char*)qkv; const char* k = q + (size_t)C * es; const char* v = q + (size_t)2 * C * es;
   GemmArgs a = {};
@@ -296,7 +296,7 @@ int op_attention_bwd(eegldm_ctx* ctx, int dtype, const void* qkv, long ldq, cons
     // dP = dO V^T, dS = alpha P o (dP - rowsum(dP o P)), dQ = dS K in one launch; whole-sample blocks also produce dK = dS^T Q (a second
     // pass over the score tile in LDS, read transposed: no batched TN GEMM with K = T = 192 -- three K stages per tile, 260 TF/s -- and
     // no re-read of dS); otherwise dK below from the written dS
-    EEG_TRY(attn_chain_bwd(ctx, qkv, ldq, probs, dout, lddo, dq, lddq, dlogits, B, T, C, fk));
+    EEG_TRY(attn_chain_bwd(ctx, qkv, ldq, probs, dout, lddo, dq, lddq, dlogits, B, T, C, fk, dtype));
     if (fk) return 0;
   } else {
   // dP[t][s] = sum_c dO[t][c] V[s][c]

@@ -106,10 +106,13 @@ def test_groupnorm_forward_backward(case):
     assert float((db.cpu() - beta.grad).abs().max()) < 8e-3 * float(beta.grad.abs().max()) + 1e-4
 
 
-def test_attention_forward_backward():
+@pytest.mark.parametrize("case", [(3, 192, 256), (136, 192, 256), (2, 768, 256), (2, 768, 512), (3, 64, 512), (2, 256, 256), (2, 96, 128)])
+def test_attention_forward_backward(case):
+    """fused chain kernels on f16 operands: 64-row blocks, whole-sample blocks with dK / dV in the same launch (B >= half the CUs),
+    the T = 768 register-resident variant, and (last case) the GEMM + softmax composition for shapes the fused kernel does not take."""
     import gpu_util as G
     c = G.ctx(); dt = G.F16
-    B, T, C = 3, 192, 256
+    B, T, C = case
     qkv = h(torch.from_numpy(normal((B, 3 * C, T), seed=9)) * 0.7).requires_grad_(True)
     q, k, v = qkv.reshape(B, 3 * C, T).split(C, dim=1)
     s = 1 / math.sqrt(math.sqrt(C))
