@@ -41,8 +41,9 @@ extern "C" {
 
 /* Storage / operand type of activations and compute-copy weights (accumulation, statistics, master weights and optimizer state are
  * always fp32).  EEGLDM_F16 = IEEE half: the type the reference trains in under `autocast` (src/training/training.py:423) with its
- * GradScaler (:334,441-443); it runs on the general kernels (gemm.hip, direct_conv.hip, norm.hip, elementwise.hip, losses.hip) --
- * the bf16-only fast paths (192 x 256 tiles, weight-stationary / few-row convs, fused attention, fused frozen encoder) are not taken. */
+ * GradScaler (:334,441-443); it runs on the general kernels (gemm.hip, direct_conv.hip, norm.hip, elementwise.hip, losses.hip), the
+ * 192 x 256 big-tile kernels and the fused attention chain -- the remaining bf16-only fast paths (weight-stationary / few-row convs,
+ * fused frozen encoder, pipelined GroupNorm backward) fall back to the general kernels. */
 enum { EEGLDM_F32 = 0, EEGLDM_BF16 = 1, EEGLDM_F16 = 2 };
 enum {
   EEGLDM_OK = 0,
@@ -233,7 +234,7 @@ typedef struct {
   int n_mult; int channel_mult[8];
   int n_attn; int attention_resolutions[8];
   int num_heads;           /* only 1 is implemented (all reference configs) */
-  int dtype;               /* storage/compute dtype of activations: EEGLDM_F32 or EEGLDM_BF16 */
+  int dtype;               /* storage/compute dtype of activations: EEGLDM_F32, EEGLDM_BF16 or EEGLDM_F16 */
 } eegldm_unet_cfg;
 
 int eegldm_unet_create(eegldm_ctx*, const eegldm_unet_cfg* cfg, eegldm_unet** out);

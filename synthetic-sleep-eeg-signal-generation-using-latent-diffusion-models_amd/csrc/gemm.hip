@@ -620,6 +620,65 @@ void gemm_kernel(const GemmArgs p) {   // >= 2 waves per SIMD: <= 256 VGPR+AGPR
         }
       }
     };
+#ifdef EEG_WG3_VALU_TAPS      // developer builds only: measured and NOT adopted (round 5)
+    if constexpr (C::WG3 && sizeof(T) == 2) {
+      // Experiment: fewer LDS reads in the fused 3-tap weight gradient.  Per k-sub a wave issues 8 transposed reads for its dY fragments and 12
+      // for the X fragments of the three taps against 24 MFMAs.  A lane's X fragment holds 8 CONSECUTIVE rows of one column, and the
+      // tap-0 / tap-2 fragments are the centre one moved by one row: here only the centre fragment is read transposed, the two rows that
+      // slide in (tile rows R and R + 9) come as 2-byte reads, and the shifted fragments are five v_alignbit per fragment (three shared by
+      // both taps): 24 transposed + 8 short reads per stage instead of 40.  Bit-identical, and 2 % SLOWER over the UNet's shapes (790-800 vs
+      // 808-817 TF/s alternating on one box; per stage 2140 + 520 cycles against 2050 + 460, tools/debug/stage_timing.py): the loop is not
+      // bound by the number of transposed reads -- with two waves per SIMD the matrix pipe is busy 58 % of the loop at a measured 1.87-1.90 GHz
+      // shader clock.
+      auto load_ks = [&](int ks, uint4 (&af)[C::FM], uint4 (&bc)[FN], unsigned (&hl)[FN], unsigned (&hh)[FN]) __attribute__((always_inline)) {
+#pragma unroll
+        for (int i = 0; i < C::FM; i++) af[i] = read_tr_t<T, BM>(smA, ks, wm * (C::FM * 16) + i * 16, lm, q);
+#pragma unroll
+        for (int j = 0; j < FN; j++) {
+          const int x0 = wn * C::BNW + j * 16;
+          bc[j] = read_tr_t<T, BN>(smB, ks, x0, lm, q, 1);
+          const int r0 = ks * 32 + 8 * q, r9 = r0 + 9, cb = (x0 + lm) * 2;
+          hl[j] = *(const unsigned short*)(smB + r0 * C::PITCH_B_TR + tr_swz<BN>(r0, cb));
+          hh[j] = *(const unsigned short*)(smB + r9 * C::PITCH_B_TR + tr_swz<BN>(r9, cb));
+        }
+      };
+      uint4 af[2][C::FM], bc[2][FN]; unsigned hl[2][FN], hh[2][FN];
+      load_ks(0, af[0], bc[0], hl[0], hh[0]);
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int ks = 0; ks < KSUB; ks++) {
+        const int cur = ks & 1;
+        if (ks + 1 < KSUB) load_ks(ks + 1, af[cur ^ 1], bc[cur ^ 1], hl[cur ^ 1], hh[cur ^ 1]);
+        __builtin_amdgcn_sched_barrier(0);
+        uint4 b0[FN], b2[FN];
+#pragma unroll
+        for (int j = 0; j < FN; j++) {
+          const uint4 c = bc[cur][j];
+          const unsigned m1 = __builtin_amdgcn_alignbit(c.y, c.x, 16), m2 = __builtin_amdgcn_alignbit(c.z, c.y, 16), m3 = __builtin_amdgcn_alignbit(c.w, c.z, 16);
+          b0[j] = make_uint4((c.x << 16) | hl[cur][j], m1, m2, m3);
+          b2[j] = make_uint4(m1, m2, m3, __builtin_amdgcn_alignbit(hh[cur][j], c.w, 16));
+        }
+#pragma unroll
+        for (int t = 0; t < 3; t++)
+#pragma unroll
+          for (int i = 0; i < C::FM; i++)
+#pragma unroll
+            for (int j = 0; j < FN; j++) {
+              mma<T>(af[cur][i], t == 0 ? b0[j] : (t == 1 ? bc[cur][j] : b2[j]), acc[t][i][j]);
+              if constexpr (INTERLEAVE) {
+                constexpr int MPS = C::FM * FN;
+                const int m = (ks * 3 + t) * MPS + i * FN + j;
+                if (!last && m >= DMA_FIRST && (m - DMA_FIRST) % DMA_EVERY == 0 && (m - DMA_FIRST) / DMA_EVERY < PER) {
+                  __builtin_amdgcn_sched_barrier(0);
+                  if (C::NSTG == 2 || s + C::NSTG - 1 < nstages) issue_piece(s + C::NSTG - 1, (s + C::NSTG - 1) % C::NSTG, (m - DMA_FIRST) / DMA_EVERY);
+                  __builtin_amdgcn_sched_barrier(0);
+                }
+              }
+            }
+      }
+    } else
+#endif
+    {
     uint4 af[2][C::FM], bf[2][FN];
     load_frags(0, af[0], bf[0]);
     __builtin_amdgcn_sched_barrier(0);
@@ -657,6 +716,7 @@ void gemm_kernel(const GemmArgs p) {   // >= 2 waves per SIMD: <= 256 VGPR+AGPR
 #endif
           }
         }
+    }
     }
     if constexpr (C::COLSUM) {
       // bias gradient for free: A (dY, transposed) times an all-ones B fragment = the row sums of this stage in every column.

@@ -62,3 +62,5 @@ for (ci, co, L) in [(128, 128, 768), (256, 256, 384), (512, 512, 192)]:
     print(f"wgrad k3 {ci}->{co} L={L}: blocks {nblk} (tiles {tiles} x splitk {splitk}), stamps {n}, stages {nst}")
     print(f"  first wait {med(d[:,0]):.0f}; per-stage wait {med(d[:,2:2*nst:2]):.0f}; per-stage MFMA {med(d[:,1:2*nst:2]):.0f}")
     print(f"  tail: {[int(med(c)) for c in d[:, 2*nst:].T]}  (final sync, atomics issued, atomics retired); total {med(t[:,n-1]-t[:,0]):.0f}")
+    w0 = t[:, 62]; w1 = t[:, 63]; cyc = t[:, n - 1] - t[:, 0]
+    print(f"  stamped span: {med(cyc):.0f} cycles in {med(w1 - w0) / 100.0:.1f} us -> {med(cyc / np.maximum(w1 - w0, 1)) * 100 / 1e3:.2f} GHz shader clock; kernel span {(w1.max() - w0.min()) / 100.0:.1f} us")
