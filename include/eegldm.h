@@ -41,9 +41,8 @@ extern "C" {
 
 /* Storage / operand type of activations and compute-copy weights (accumulation, statistics, master weights and optimizer state are
  * always fp32).  EEGLDM_F16 = IEEE half: the type the reference trains in under `autocast` (src/training/training.py:423) with its
- * GradScaler (:334,441-443); it runs on the general kernels (gemm.hip, direct_conv.hip, norm.hip, elementwise.hip, losses.hip), the
- * 192 x 256 big-tile kernels and the fused attention chain -- the remaining bf16-only fast paths (weight-stationary / few-row convs,
- * fused frozen encoder, pipelined GroupNorm backward) fall back to the general kernels. */
+ * GradScaler (:334,441-443); every kernel family is instantiated for it (general, big-tile, fused attention, weight-stationary and
+ * few-row convs, fused frozen encoder, pipelined GroupNorm backward) and it runs at bf16 speed. */
 enum { EEGLDM_F32 = 0, EEGLDM_BF16 = 1, EEGLDM_F16 = 2 };
 enum {
   EEGLDM_OK = 0,

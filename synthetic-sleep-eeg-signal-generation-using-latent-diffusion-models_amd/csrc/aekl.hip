@@ -456,7 +456,7 @@ int aekl_encode_impl(eegldm_aekl* a, const float* x, const float* eps, int B, in
 // (eegldm_aekl_encode = Stage1Wrapper / encode_stage_2_inputs under no_grad, train_ldm.py:145-148, training.py:417-421).
 bool enc_fused_eligible(const eegldm_aekl* a, int L) {
   if (getenv("EEGLDM_AEKL_NO_FUSED_ENC") != nullptr) return false;      // (read per call: tests toggle it inside one process)
-  if (a->dtype != EEGLDM_BF16 || a->cfg.norm_num_groups != 1) return false;
+  if ((a->dtype != EEGLDM_BF16 && a->dtype != EEGLDM_F16) || a->cfg.norm_num_groups != 1) return false;
   int Lc = L; bool any = false;
   for (const Op& o : a->enc) {
     if (o.kind == OP_CONV) Lc = (Lc + o.pl + o.pr - o.k) / o.stride + 1;
@@ -484,13 +484,13 @@ int aekl_encode_fused_seq(eegldm_aekl* a, View x, int B, int& L, View* out) {
       EEG_TRY(op_conv_fwd(ctx, dt, x.p, x.ld, a->W(o.w), o.b >= 0 ? a->P(o.b) : nullptr, y.p, y.ld, B, L, o.cin, o.cout, o.k, o.stride, o.pl, o.pr,
                           nullptr, 0, nullptr, 0));
       L = Lo; x = y; cur_stats = nullptr;
-      if (next_res) { cur_stats = next_slot(); EEG_TRY(sample_stats_launch(ctx, x.p, (long)L * x.C, B, cur_stats)); }
+      if (next_res) { cur_stats = next_slot(); EEG_TRY(sample_stats_launch(ctx, x.p, (long)L * x.C, B, cur_stats, a->dtype)); }
     } else if (o.kind == OP_RES) {
       const ResDesc& r = o.r;
       EEG_CHECK(cur_stats, "fused encoder: no statistics for a ResBlock input");
       View h1; ALLOC_OR_FAIL(h1.p, a->alloc_act((long)B * L, r.cout)); h1.ld = r.cout; h1.C = r.cout;
       double* st_h1 = next_slot();
-      EEG_TRY(pre_conv3_launch(ctx, x.p, cur_stats, a->P(r.gn1_w), a->P(r.gn1_b), a->W(r.c1_w), a->P(r.c1_b), nullptr, h1.p, st_h1, B, L, r.cin, r.cout, GN_EPS));
+      EEG_TRY(pre_conv3_launch(ctx, x.p, cur_stats, a->P(r.gn1_w), a->P(r.gn1_b), a->W(r.c1_w), a->P(r.c1_b), nullptr, h1.p, st_h1, B, L, r.cin, r.cout, GN_EPS, a->dtype));
       View res = x;
       if (r.sk_w >= 0) {
         ALLOC_OR_FAIL(res.p, a->alloc_act((long)B * L, r.cout)); res.ld = r.cout; res.C = r.cout;
@@ -498,7 +498,7 @@ int aekl_encode_fused_seq(eegldm_aekl* a, View x, int B, int& L, View* out) {
       }
       View y; ALLOC_OR_FAIL(y.p, a->alloc_act((long)B * L, r.cout)); y.ld = r.cout; y.C = r.cout;
       double* st_y = next_res ? next_slot() : nullptr;          // (a ResBlock followed by a conv / the final norm: nobody reads them)
-      EEG_TRY(pre_conv3_launch(ctx, h1.p, st_h1, a->P(r.gn2_w), a->P(r.gn2_b), a->W(r.c2_w), a->P(r.c2_b), res.p, y.p, st_y, B, L, r.cout, r.cout, GN_EPS));
+      EEG_TRY(pre_conv3_launch(ctx, h1.p, st_h1, a->P(r.gn2_w), a->P(r.gn2_b), a->W(r.c2_w), a->P(r.c2_b), res.p, y.p, st_y, B, L, r.cout, r.cout, GN_EPS, a->dtype));
       x = y; cur_stats = st_y;
     } else {  // OP_GN (the final norm, no activation): the flat one-launch kernel
       View y; ALLOC_OR_FAIL(y.p, a->alloc_act((long)B * L, x.C)); y.ld = x.C; y.C = x.C;

@@ -1,4 +1,4 @@
-// Few-row convolution / linear layer (bf16, 1 or 3 taps, stride 1): the forward GEMMs of the UNet when a launch has only a few
+// Few-row convolution / linear layer (bf16 or fp16 operands, 1 or 3 taps, stride 1): the forward GEMMs of the UNet when a launch has only a few
 // hundred rows -- sampling ONE window per call, as the reference's sampler does (sample_trials.py:149-163: 50 DDIM steps on a
 // (1, 1, 768) latent).
 //
@@ -54,13 +54,19 @@ __device__ __forceinline__ float2 sk_slot(const float2* pa, const float2* pb, in
 constexpr int SK_GN_MAXC = 1024;            // widest normalised operand (scale / shift table in LDS)
 
 // 8 bf16 activations -> GroupNorm scale / shift (+ SiLU) -> 8 bf16, the rounding the stand-alone GroupNorm kernel applies to its output
+template <typename T16>
+__device__ __forceinline__ f32x4 sk_mma(const uint4& a, const uint4& b, const f32x4& c) {
+  if constexpr (Is16<T16>::f16) return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+  else return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+}
+template <typename T16>
 __device__ __forceinline__ uint4 sk_norm8(uint4 a, const float* sc, const float* sh, bool silu) {
   const unsigned in[4] = {a.x, a.y, a.z, a.w}; unsigned out[4];
 #pragma unroll
   for (int j = 0; j < 4; j++) {
-    float z0 = __uint_as_float(in[j] << 16) * sc[2 * j] + sh[2 * j], z1 = __uint_as_float(in[j] & 0xffff0000u) * sc[2 * j + 1] + sh[2 * j + 1];
+    float z0 = w16_lo<T16>(in[j]) * sc[2 * j] + sh[2 * j], z1 = w16_hi<T16>(in[j]) * sc[2 * j + 1] + sh[2 * j + 1];
     if (silu) { z0 = silu_f(z0); z1 = silu_f(z1); }
-    out[j] = pack_bf16x2(z0, z1);
+    out[j] = pack16x2<T16>(z0, z1);
   }
   return make_uint4(out[0], out[1], out[2], out[3]);
 }
@@ -73,7 +79,7 @@ __device__ __forceinline__ uint4 sk_rot(uint4 v) {
                     (unsigned)__builtin_amdgcn_update_dpp(0, (int)v.z, CTRL, 0xf, 0xf, false), (unsigned)__builtin_amdgcn_update_dpp(0, (int)v.w, CTRL, 0xf, 0xf, false));
 }
 
-template <int TAPS, int RF, int CF, bool GN>
+template <int TAPS, int RF, int CF, bool GN, typename T16 = bf16_t>
 __global__ __launch_bounds__(64 * SK_WAVES) void conv_skinny_kernel(const SkArgs p) {
   __shared__ f32x4 part[SK_WAVES][RF * CF][64];
   __shared__ float2 gn_ss[GN ? SK_GN_MAXC : 1];            // (scale, shift) per input channel of this block's sample
@@ -219,9 +225,9 @@ __global__ __launch_bounds__(64 * SK_WAVES) void conv_skinny_kernel(const SkArgs
           }                                                                                                                          \
         }                                                                                                                            \
         uint4 ctr[RF], up[RF], dn[RF], hal = make_uint4(0u, 0u, 0u, 0u);                                                             \
-        _Pragma("unroll") for (int rf = 0; rf < RF; rf++) ctr[rf] = GN ? sk_norm8(xc[i][rf], nsc, nsh, p.gn_silu != 0) : xc[i][rf];  \
+        _Pragma("unroll") for (int rf = 0; rf < RF; rf++) ctr[rf] = GN ? sk_norm8<T16>(xc[i][rf], nsc, nsh, p.gn_silu != 0) : xc[i][rf];  \
         if (TAPS == 3) {                                                                                                             \
-          hal = GN ? sk_norm8(xh[i], nsc, nsh, p.gn_silu != 0) : xh[i];                                                              \
+          hal = GN ? sk_norm8<T16>(xh[i], nsc, nsh, p.gn_silu != 0) : xh[i];                                                              \
           _Pragma("unroll") for (int rf = 0; rf < RF; rf++) { up[rf] = sk_rot<0x121>(ctr[rf]); dn[rf] = sk_rot<0x12F>(ctr[rf]); }    \
         }                                                                                                                            \
         _Pragma("unroll") for (int t = 0; t < TAPS; t++)                                                                             \
@@ -231,8 +237,7 @@ __global__ __launch_bounds__(64 * SK_WAVES) void conv_skinny_kernel(const SkArgs
             if (TAPS == 3 && t == 2) { a = dn[rf]; if (lm == 15) a = rf == RF - 1 ? hal : dn[rf + 1 < RF ? rf + 1 : RF - 1]; } /* below */ \
             if (TAPS == 3 && !xok[t][rf]) a = make_uint4(0u, 0u, 0u, 0u);                                                            \
             _Pragma("unroll") for (int cf = 0; cf < CF; cf++)                                                                        \
-              acc[rf][cf] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, wb[i][t][cf]),                        \
-                                                                    __builtin_bit_cast(bf16x8, a), acc[rf][cf], 0, 0, 0);            \
+              acc[rf][cf] = sk_mma<T16>(wb[i][t][cf], a, acc[rf][cf]);            \
           }                                                                                                                          \
       }                                                                                                                              \
     }                                                                                                                                \
@@ -265,7 +270,7 @@ __global__ __launch_bounds__(64 * SK_WAVES) void conv_skinny_kernel(const SkArgs
           for (int rf = 0; rf < RF; rf++)
 #pragma unroll
             for (int cf = 0; cf < CF; cf++)
-              acc[rf][cf] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, wb2[i][cf]), __builtin_bit_cast(bf16x8, xa[i][rf]), acc[rf][cf], 0, 0, 0);
+              acc[rf][cf] = sk_mma<T16>(wb2[i][cf], xa[i][rf], acc[rf][cf]);
         }
       }
     }
@@ -286,14 +291,14 @@ __global__ __launch_bounds__(64 * SK_WAVES) void conv_skinny_kernel(const SkArgs
       if (p.bias2) { s[0] += e_bias2[0]; s[1] += e_bias2[1]; s[2] += e_bias2[2]; s[3] += e_bias2[3]; }
       if (p.rowvec) { s[0] += e_row[0]; s[1] += e_row[1]; s[2] += e_row[2]; s[3] += e_row[3]; }
       if (p.resid) {
-        s[0] += __uint_as_float(e_res[0] << 16); s[1] += __uint_as_float(e_res[0] & 0xffff0000u);
-        s[2] += __uint_as_float(e_res[1] << 16); s[3] += __uint_as_float(e_res[1] & 0xffff0000u);
+        s[0] += w16_lo<T16>(e_res[0]); s[1] += w16_hi<T16>(e_res[0]);
+        s[2] += w16_lo<T16>(e_res[1]); s[3] += w16_hi<T16>(e_res[1]);
       }
-      *(uint2*)(p.y + (long)m_own * p.ldy + n_own) = make_uint2(pack_bf16x2(s[0], s[1]), pack_bf16x2(s[2], s[3]));
+      *(uint2*)(p.y + (long)m_own * p.ldy + n_own) = make_uint2(pack16x2<T16>(s[0], s[1]), pack16x2<T16>(s[2], s[3]));
     }
     if (p.part_out) {       // GroupNorm statistics of the tensor just written (rounded values): one slot per 16-row x 4-channel lane quad
-      const unsigned lo = pack_bf16x2(s[0], s[1]), hi = pack_bf16x2(s[2], s[3]);
-      const float r0 = __uint_as_float(lo << 16), r1 = __uint_as_float(lo & 0xffff0000u), r2 = __uint_as_float(hi << 16), r3 = __uint_as_float(hi & 0xffff0000u);
+      const unsigned lo = pack16x2<T16>(s[0], s[1]), hi = pack16x2<T16>(s[2], s[3]);
+      const float r0 = w16_lo<T16>(lo), r1 = w16_hi<T16>(lo), r2 = w16_lo<T16>(hi), r3 = w16_hi<T16>(hi);
       float a1 = own_ok ? (r0 + r1) + (r2 + r3) : 0.f, a2 = own_ok ? (r0 * r0 + r1 * r1) + (r2 * r2 + r3 * r3) : 0.f;
 #pragma unroll
       for (int o = 1; o < 16; o <<= 1) { a1 += __shfl_xor(a1, o); a2 += __shfl_xor(a2, o); }
@@ -304,12 +309,16 @@ __global__ __launch_bounds__(64 * SK_WAVES) void conv_skinny_kernel(const SkArgs
   }
 }
 
-template <int TAPS, bool GN>
-void sk_launch(eegldm_ctx* ctx, const SkArgs& a, int rf, int cf) {
+template <int TAPS, bool GN, typename T16>
+void sk_launch_t(eegldm_ctx* ctx, const SkArgs& a, int rf, int cf) {
   const dim3 blk(64 * SK_WAVES);
-  if (rf == 2 && cf == 2) hipLaunchKernelGGL((conv_skinny_kernel<TAPS, 2, 2, GN>), dim3((a.M + 31) / 32, (a.N + 31) / 32), blk, 0, ctx->stream, a);
-  else if (rf == 2) hipLaunchKernelGGL((conv_skinny_kernel<TAPS, 2, 1, GN>), dim3((a.M + 31) / 32, (a.N + 15) / 16), blk, 0, ctx->stream, a);
-  else hipLaunchKernelGGL((conv_skinny_kernel<TAPS, 1, 1, GN>), dim3((a.M + 15) / 16, (a.N + 15) / 16), blk, 0, ctx->stream, a);
+  if (rf == 2 && cf == 2) hipLaunchKernelGGL((conv_skinny_kernel<TAPS, 2, 2, GN, T16>), dim3((a.M + 31) / 32, (a.N + 31) / 32), blk, 0, ctx->stream, a);
+  else if (rf == 2) hipLaunchKernelGGL((conv_skinny_kernel<TAPS, 2, 1, GN, T16>), dim3((a.M + 31) / 32, (a.N + 15) / 16), blk, 0, ctx->stream, a);
+  else hipLaunchKernelGGL((conv_skinny_kernel<TAPS, 1, 1, GN, T16>), dim3((a.M + 15) / 16, (a.N + 15) / 16), blk, 0, ctx->stream, a);
+}
+template <int TAPS, bool GN>
+void sk_launch(eegldm_ctx* ctx, const SkArgs& a, int rf, int cf, int dtype) {
+  if (dtype == EEGLDM_F16) sk_launch_t<TAPS, GN, f16_t>(ctx, a, rf, cf); else sk_launch_t<TAPS, GN, bf16_t>(ctx, a, rf, cf);
 }
 }  // namespace
 
@@ -321,7 +330,7 @@ static long sk_max_tiles() {
 bool conv_skinny_takes(int dtype, int Cin, int Cout, int taps, int B, int L) {
   EEG_ENV_VAR(bool, off, getenv("EEGLDM_NO_CONV_SKINNY") != nullptr);
   const long M = (long)B * L;
-  if (off || dtype != EEGLDM_BF16 || (taps != 1 && taps != 3) || Cin % 32 != 0 || Cout % 4 != 0 || Cout < 16) return false;
+  if (off || (dtype != EEGLDM_BF16 && dtype != EEGLDM_F16) || (taps != 1 && taps != 3) || Cin % 32 != 0 || Cout % 4 != 0 || Cout < 16) return false;
   // only launches the general kernel cannot spread over the chip: at most `max_tiles` of its 128 x 128 tiles
   return ((M + 127) / 128) * (((long)Cout + 127) / 128) <= sk_max_tiles();
 }
@@ -364,8 +373,8 @@ int conv_skinny_ex(eegldm_ctx* ctx, int dtype, const void* x, long ldx, const vo
     HIP_TRY(hipEventCreate(&rec.a)); HIP_TRY(hipEventCreate(&rec.b));
     HIP_TRY(hipEventRecord(rec.a, ctx->stream));
   }
-  if (gn && taps == 3) sk_launch<3, true>(ctx, a, rf, cf); else if (gn) sk_launch<1, true>(ctx, a, rf, cf);
-  else if (taps == 3) sk_launch<3, false>(ctx, a, rf, cf); else sk_launch<1, false>(ctx, a, rf, cf);
+  if (gn && taps == 3) sk_launch<3, true>(ctx, a, rf, cf, dtype); else if (gn) sk_launch<1, true>(ctx, a, rf, cf, dtype);
+  else if (taps == 3) sk_launch<3, false>(ctx, a, rf, cf, dtype); else sk_launch<1, false>(ctx, a, rf, cf, dtype);
   LAUNCH_CHECK();
   if (prof) { HIP_TRY(hipEventRecord(rec.b, ctx->stream)); ctx->prof.push_back(rec); }
   return 1;

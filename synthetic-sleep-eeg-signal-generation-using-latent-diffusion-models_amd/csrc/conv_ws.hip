@@ -66,7 +66,7 @@ __device__ __forceinline__ u32x2 ws_load8(const void* g) {
 //   top of iteration t    : everything up to DMA(t) must have landed; younger loads = DMA(t+1) only          -> vmcnt(4) / vmcnt(0) at the tail
 //   before the epilogue   : residual(t) must have landed; younger loads = DMA(t+2) only                      -> vmcnt(4) / vmcnt(0)
 // (wave 0's fifth DMA instruction is waited for one step early; the stores are a tile old by the time a count could include them)
-template <bool TR>      // TR: weight fragments gathered with a stride (the data gradient reads the packed weights transposed)
+template <bool TR, typename T16 = bf16_t>      // TR: weight fragments gathered with a stride (the data gradient reads the packed weights transposed)
 __global__ __launch_bounds__(256, 2) void conv3_ws_kernel(const WsArgs p) {
   extern __shared__ __attribute__((aligned(1024))) char smem[];
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, lm = lane & 15, q = lane >> 4;
@@ -179,7 +179,8 @@ __global__ __launch_bounds__(256, 2) void conv3_ws_kernel(const WsArgs p) {
           const uint4 xf = *(const uint4*)(sA + j * WS_ROW_BYTES + (((kk * 4 + q) ^ (j & 15)) * 16));
 #pragma unroll
           for (int cf = 0; cf < 2; cf++)
-            acc[rf][cf] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, wf[tp][kk][cf]), __builtin_bit_cast(bf16x8, xf), acc[rf][cf], 0, 0, 0);
+            if constexpr (Is16<T16>::f16) acc[rf][cf] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, wf[tp][kk][cf]), __builtin_bit_cast(f16x8, xf), acc[rf][cf], 0, 0, 0);
+            else acc[rf][cf] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, wf[tp][kk][cf]), __builtin_bit_cast(bf16x8, xf), acc[rf][cf], 0, 0, 0);
         }
       }
     if (p.resid) {
@@ -197,11 +198,11 @@ __global__ __launch_bounds__(256, 2) void conv3_ws_kernel(const WsArgs p) {
       for (int cf = 0; cf < 2; cf++) {
         float v0 = acc[rf][cf][0] + ev[cf].x, v1 = acc[rf][cf][1] + ev[cf].y, v2 = acc[rf][cf][2] + ev[cf].z, v3 = acc[rf][cf][3] + ev[cf].w;
         if (p.resid) {
-          v0 += __uint_as_float(rr[rf][cf].x << 16); v1 += __uint_as_float(rr[rf][cf].x & 0xffff0000u);
-          v2 += __uint_as_float(rr[rf][cf].y << 16); v3 += __uint_as_float(rr[rf][cf].y & 0xffff0000u);
+          v0 += w16_lo<T16>(rr[rf][cf].x); v1 += w16_hi<T16>(rr[rf][cf].x);
+          v2 += w16_lo<T16>(rr[rf][cf].y); v3 += w16_hi<T16>(rr[rf][cf].y);
         }
         const int row = rf * 16 + lm, ch = wave * 4 + cf * 2 + (q >> 1);
-        *(uint2*)(sOut + row * WS_ROW_BYTES + ((ch ^ (row & 15)) * 16) + (q & 1) * 8) = make_uint2(pack_bf16x2(v0, v1), pack_bf16x2(v2, v3));
+        *(uint2*)(sOut + row * WS_ROW_BYTES + ((ch ^ (row & 15)) * 16) + (q & 1) * 8) = make_uint2(pack16x2<T16>(v0, v1), pack16x2<T16>(v2, v3));
       }
   }
   if (p.dbg & 4) __syncthreads(); else ws_barrier();
@@ -217,7 +218,7 @@ int conv_ws_try(eegldm_ctx* ctx, int dtype, const void* x, long ldx, const void*
   EEG_ENV_VAR(bool, off, getenv("EEGLDM_NO_CONV_WS") != nullptr);
   const int Kred = transposed ? Cout : Cin, N = transposed ? Cin : Cout;
   const long M = (long)B * L;
-  if (off || dtype != EEGLDM_BF16 || Kred != 128 || N % 128 != 0 || L % WS_ROWS != 0 || M >= (1L << 31)) return 0;
+  if (off || (dtype != EEGLDM_BF16 && dtype != EEGLDM_F16) || Kred != 128 || N % 128 != 0 || L % WS_ROWS != 0 || M >= (1L << 31)) return 0;
   if (ldx % 8 != 0 || ldy % 8 != 0 || (resid && ldr % 4 != 0) || (rowvec && ld_rowvec % 4 != 0)) return 0;
   if (((size_t)x | (size_t)y | (size_t)w) % 16 != 0 || (resid && (size_t)resid % 8 != 0)) return 0;
   EEG_ENV_VAR(long, min_rows, getenv("EEGLDM_CONV_WS_MIN_ROWS") ? atol(getenv("EEGLDM_CONV_WS_MIN_ROWS")) : 16384);
@@ -239,6 +240,8 @@ int conv_ws_try(eegldm_ctx* ctx, int dtype, const void* x, long ldx, const void*
   if (attr_once.need(ctx->device)) {
     HIP_TRY(hipFuncSetAttribute((const void*)conv3_ws_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, WS_LDS));
     HIP_TRY(hipFuncSetAttribute((const void*)conv3_ws_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, WS_LDS));
+    HIP_TRY(hipFuncSetAttribute((const void*)conv3_ws_kernel<false, f16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, WS_LDS));
+    HIP_TRY(hipFuncSetAttribute((const void*)conv3_ws_kernel<true, f16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, WS_LDS));
   }
   ProfRec rec; const bool prof = ctx->prof_on;          // same per-class accounting as gemm_launch (bench.py roofline leg)
   if (prof) {
@@ -247,7 +250,10 @@ int conv_ws_try(eegldm_ctx* ctx, int dtype, const void* x, long ldx, const void*
     HIP_TRY(hipEventCreate(&rec.a)); HIP_TRY(hipEventCreate(&rec.b));
     HIP_TRY(hipEventRecord(rec.a, ctx->stream));
   }
-  if (transposed) hipLaunchKernelGGL(conv3_ws_kernel<true>, dim3((unsigned)nbx, ny), dim3(256), WS_LDS, ctx->stream, a);
+  if (dtype == EEGLDM_F16) {
+    if (transposed) hipLaunchKernelGGL((conv3_ws_kernel<true, f16_t>), dim3((unsigned)nbx, ny), dim3(256), WS_LDS, ctx->stream, a);
+    else hipLaunchKernelGGL((conv3_ws_kernel<false, f16_t>), dim3((unsigned)nbx, ny), dim3(256), WS_LDS, ctx->stream, a);
+  } else if (transposed) hipLaunchKernelGGL(conv3_ws_kernel<true>, dim3((unsigned)nbx, ny), dim3(256), WS_LDS, ctx->stream, a);
   else hipLaunchKernelGGL(conv3_ws_kernel<false>, dim3((unsigned)nbx, ny), dim3(256), WS_LDS, ctx->stream, a);
   LAUNCH_CHECK();
   if (prof) { HIP_TRY(hipEventRecord(rec.b, ctx->stream)); ctx->prof.push_back(rec); }

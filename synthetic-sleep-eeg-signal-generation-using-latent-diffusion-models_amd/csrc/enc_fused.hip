@@ -11,19 +11,21 @@
 // run of 16-byte chunks (rows are CI * 2 bytes), transformed in registers, written once to LDS as bf16 (the same rounding point as the
 // unfused path, which stores the activated tensor as bf16), and read as MFMA A fragments with the tap as a row shift; the weights
 // ([3][CO][CI], 6-24 KB) are register B fragments, 32 output channels at a time.  HBM traffic per layer: x once, y once (was: GroupNorm x -> a, conv a -> y).
-// bf16 only; channel counts {32, 64}; L % 256 == 0.  Everything else keeps the layer-by-layer path (aekl.hip).
+// bf16 / fp16 (T16); channel counts {32, 64}; L % 256 == 0.  Everything else keeps the layer-by-layer path (aekl.hip).
 #include "common.h"
 #include "internal.h"
 
 namespace {
 
+template <typename T16>
 __device__ __forceinline__ void mma16e(const uint4& a, const uint4& b, f32x4& acc) {
-  acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), acc, 0, 0, 0);
+  if constexpr (Is16<T16>::f16) acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), acc, 0, 0, 0);
+  else acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), acc, 0, 0, 0);
 }
 
 constexpr int TR = 256;            // positions per block
 
-template <int CI, int CO>
+template <int CI, int CO, typename T16 = bf16_t>
 __global__ __launch_bounds__(256) void pre_conv3_kernel(const bf16_t* __restrict__ x, const double* __restrict__ in_stats,
                                                         const float* __restrict__ gamma, const float* __restrict__ beta,
                                                         const bf16_t* __restrict__ w, const float* __restrict__ bias,
@@ -79,8 +81,8 @@ __global__ __launch_bounds__(256) void pre_conv3_kernel(const bf16_t* __restrict
           unsigned ov[4];
 #pragma unroll
           for (int e = 0; e < 4; e++) {
-            const float v0 = __uint_as_float(in[e] << 16), v1 = __uint_as_float(in[e] & 0xffff0000u);
-            ov[e] = pack_bf16x2(silu_f(fmaf(v0, sc[2 * e], sh[2 * e])), silu_f(fmaf(v1, sc[2 * e + 1], sh[2 * e + 1])));
+            const float v0 = w16_lo<T16>(in[e]), v1 = w16_hi<T16>(in[e]);
+            ov[e] = pack16x2<T16>(silu_f(fmaf(v0, sc[2 * e], sh[2 * e])), silu_f(fmaf(v1, sc[2 * e + 1], sh[2 * e + 1])));
           }
           o = make_uint4(ov[0], ov[1], ov[2], ov[3]);
         }
@@ -114,7 +116,7 @@ __global__ __launch_bounds__(256) void pre_conv3_kernel(const bf16_t* __restrict
 #pragma unroll
           for (int i = 0; i < 4; i++)
 #pragma unroll
-            for (int j = 0; j < NFH; j++) mma16e(wf[t][ks][j], af[i], acc[i][j]);     // acc[i][j][r] = y[row i*16+lm][col h*32 + j*16 + q*4 + r]
+            for (int j = 0; j < NFH; j++) mma16e<T16>(wf[t][ks][j], af[i], acc[i][j]);     // acc[i][j][r] = y[row i*16+lm][col h*32 + j*16 + q*4 + r]
         }
       // ---- epilogue: bias (+ residual), round, statistics of the rounded values, store
 #pragma unroll
@@ -127,13 +129,13 @@ __global__ __launch_bounds__(256) void pre_conv3_kernel(const bf16_t* __restrict
           float v[4] = {acc[i][j][0] + bv.x, acc[i][j][1] + bv.y, acc[i][j][2] + bv.z, acc[i][j][3] + bv.w};
           if (resid) {
             const uint2 rr = *(const uint2*)(resid + row * CO + col);
-            v[0] += __uint_as_float(rr.x << 16); v[1] += __uint_as_float(rr.x & 0xffff0000u);
-            v[2] += __uint_as_float(rr.y << 16); v[3] += __uint_as_float(rr.y & 0xffff0000u);
+            v[0] += w16_lo<T16>(rr.x); v[1] += w16_hi<T16>(rr.x);
+            v[2] += w16_lo<T16>(rr.y); v[3] += w16_hi<T16>(rr.y);
           }
-          uint2 o; o.x = pack_bf16x2(v[0], v[1]); o.y = pack_bf16x2(v[2], v[3]);
+          uint2 o; o.x = pack16x2<T16>(v[0], v[1]); o.y = pack16x2<T16>(v[2], v[3]);
           *(uint2*)(y + row * CO + col) = o;
-          const float r0 = __uint_as_float(o.x << 16), r1 = __uint_as_float(o.x & 0xffff0000u);
-          const float r2 = __uint_as_float(o.y << 16), r3 = __uint_as_float(o.y & 0xffff0000u);
+          const float r0 = w16_lo<T16>(o.x), r1 = w16_hi<T16>(o.x);
+          const float r2 = w16_lo<T16>(o.y), r3 = w16_hi<T16>(o.y);
           s1 += (r0 + r1) + (r2 + r3);
           s2 += fmaf(r0, r0, r1 * r1) + fmaf(r2, r2, r3 * r3);
         }
@@ -149,6 +151,7 @@ __global__ __launch_bounds__(256) void pre_conv3_kernel(const bf16_t* __restrict
 
 // per-sample (sum, sum of squares) of a stored [B][n] bf16 tensor (n = L * C contiguous): the producers this file does not cover
 // (conv_in, the stride-2 downsampling convs) -- read-only, one pass
+template <typename T16 = bf16_t>
 __global__ __launch_bounds__(256) void sample_stats_kernel(const bf16_t* __restrict__ x, long n, double* __restrict__ stats) {
   const int b = blockIdx.y;
   const uint4* p = (const uint4*)(x + (long)b * n);
@@ -159,7 +162,7 @@ __global__ __launch_bounds__(256) void sample_stats_kernel(const bf16_t* __restr
     const unsigned in[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
     for (int e = 0; e < 4; e++) {
-      const float v0 = __uint_as_float(in[e] << 16), v1 = __uint_as_float(in[e] & 0xffff0000u);
+      const float v0 = w16_lo<T16>(in[e]), v1 = w16_hi<T16>(in[e]);
       s1 += v0 + v1; s2 += fmaf(v0, v0, v1 * v1);
     }
   }
@@ -177,28 +180,31 @@ __global__ __launch_bounds__(256) void sample_stats_kernel(const bf16_t* __restr
 }  // namespace
 
 bool pre_conv3_ok(int dtype, int Cin, int Cout, int L) {
-  return dtype == EEGLDM_BF16 && (Cin == 32 || Cin == 64) && (Cout == 32 || Cout == 64) && L % TR == 0;
+  return (dtype == EEGLDM_BF16 || dtype == EEGLDM_F16) && (Cin == 32 || Cin == 64) && (Cout == 32 || Cout == 64) && L % TR == 0;
 }
 
 int pre_conv3_launch(eegldm_ctx* ctx, const void* x, const double* in_stats, const float* gamma, const float* beta, const void* w,
-                     const float* bias, const void* resid, void* y, double* out_stats, int B, int L, int Cin, int Cout, float eps) {
-  EEG_CHECK(pre_conv3_ok(EEGLDM_BF16, Cin, Cout, L), "pre_conv3: unsupported shape %d -> %d, L %d", Cin, Cout, L);
+                     const float* bias, const void* resid, void* y, double* out_stats, int B, int L, int Cin, int Cout, float eps, int dtype) {
+  EEG_CHECK(pre_conv3_ok(dtype, Cin, Cout, L), "pre_conv3: unsupported shape %d -> %d, L %d", Cin, Cout, L);
   const int ntiles = (L / TR) * B;
-#define PRE3(CI, CO) hipLaunchKernelGGL((pre_conv3_kernel<CI, CO>), dim3(ntiles), dim3(256), 0, ctx->stream, (const bf16_t*)x, in_stats, gamma, beta, \
-                                        (const bf16_t*)w, bias, (const bf16_t*)resid, (bf16_t*)y, out_stats, L, ntiles, eps)
+#define PRE3T(CI, CO, T) hipLaunchKernelGGL((pre_conv3_kernel<CI, CO, T>), dim3(ntiles), dim3(256), 0, ctx->stream, (const bf16_t*)x, in_stats, gamma, beta, \
+                                           (const bf16_t*)w, bias, (const bf16_t*)resid, (bf16_t*)y, out_stats, L, ntiles, eps)
+#define PRE3(CI, CO) do { if (dtype == EEGLDM_F16) PRE3T(CI, CO, f16_t); else PRE3T(CI, CO, bf16_t); } while (0)
   if (Cin == 32 && Cout == 32) PRE3(32, 32);
   else if (Cin == 32 && Cout == 64) PRE3(32, 64);
   else if (Cin == 64 && Cout == 64) PRE3(64, 64);
   else PRE3(64, 32);
 #undef PRE3
+#undef PRE3T
   LAUNCH_CHECK();
   return 0;
 }
 
-int sample_stats_launch(eegldm_ctx* ctx, const void* x, long n_per_sample, int B, double* stats) {
+int sample_stats_launch(eegldm_ctx* ctx, const void* x, long n_per_sample, int B, double* stats, int dtype) {
   EEG_CHECK(n_per_sample % 8 == 0, "sample_stats: samples must be whole 16-byte chunks");
   long per = (n_per_sample / 8 + 255) / 256; if (per > 64) per = 64; if (per < 1) per = 1;
-  hipLaunchKernelGGL(sample_stats_kernel, dim3((unsigned)per, B), dim3(256), 0, ctx->stream, (const bf16_t*)x, n_per_sample, stats);
+  if (dtype == EEGLDM_F16) hipLaunchKernelGGL(sample_stats_kernel<f16_t>, dim3((unsigned)per, B), dim3(256), 0, ctx->stream, (const bf16_t*)x, n_per_sample, stats);
+  else hipLaunchKernelGGL(sample_stats_kernel<bf16_t>, dim3((unsigned)per, B), dim3(256), 0, ctx->stream, (const bf16_t*)x, n_per_sample, stats);
   LAUNCH_CHECK();
   return 0;
 }

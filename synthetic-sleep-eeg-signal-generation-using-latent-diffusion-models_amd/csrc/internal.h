@@ -89,8 +89,8 @@ int gn_fwd_from_qstats(eegldm_ctx*, const void* x, long ldx, const float* gamma,
 // frozen-encoder fusion (enc_fused.hip): GroupNorm(G = 1) + SiLU on the operand load of a 3-tap conv, next layer's statistics from its epilogue
 bool pre_conv3_ok(int dtype, int Cin, int Cout, int L);
 int pre_conv3_launch(eegldm_ctx*, const void* x, const double* in_stats, const float* gamma, const float* beta, const void* w,
-                     const float* bias, const void* resid, void* y, double* out_stats, int B, int L, int Cin, int Cout, float eps);
-int sample_stats_launch(eegldm_ctx*, const void* x, long n_per_sample, int B, double* stats);
+                     const float* bias, const void* resid, void* y, double* out_stats, int B, int L, int Cin, int Cout, float eps, int dtype);
+int sample_stats_launch(eegldm_ctx*, const void* x, long n_per_sample, int B, double* stats, int dtype);
 // fused short-sequence attention (attn.hip)
 bool attn_chain_ok(int dtype, int T, int C, long ldq, long ldo);
 int attn_chain_fwd(eegldm_ctx*, const void* qkv, long ldq, void* out, long ldo, void* probs, int B, int T, int C, int dtype);

@@ -764,7 +764,7 @@ __device__ __forceinline__ void pipe_dma(const void* base, unsigned voff, unsign
 #define PIPE_TSTAMP(k, i) do {} while (0)
 #endif
 
-template <bool SILU, bool HAS_ER>
+template <bool SILU, bool HAS_ER, typename T16 = bf16_t>
 __global__ __launch_bounds__(NTB) void gn_bwd_pipe_kernel(const bf16_t* __restrict__ x, long ldx, const float* __restrict__ gamma,
                                                           const float* __restrict__ beta, const float* __restrict__ stats,
                                                           const bf16_t* __restrict__ dy, long lddy, bf16_t* __restrict__ dx, long lddx,
@@ -852,7 +852,7 @@ __global__ __launch_bounds__(NTB) void gn_bwd_pipe_kernel(const bf16_t* __restri
       float dg[4] = {0.f, 0.f, 0.f, 0.f}, db[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
       for (int r = 0; r < PIPE_RPT; r++) {
-        float v[4]; unpack4<bf16_t>(raw[r], v); unpack4<bf16_t>(dr[r], d[r]);
+        float v[4]; unpack4<T16>(raw[r], v); unpack4<T16>(dr[r], d[r]);
 #pragma unroll
         for (int j = 0; j < 4; j++) {
           const float xh = fmaf(v[j], rstd, nmr);
@@ -899,11 +899,11 @@ __global__ __launch_bounds__(NTB) void gn_bwd_pipe_kernel(const bf16_t* __restri
       char* dxs = (char*)(dx + (long)b * L * lddx);
 #pragma unroll
       for (int r = 0; r < PIPE_RPT; r++) {
-        float v[4], o[4]; unpack4<bf16_t>(raw[r], v);
+        float v[4], o[4]; unpack4<T16>(raw[r], v);
 #pragma unroll
         for (int j = 0; j < 4; j++) o[j] = fmaf(d[r][j], gr[j], fmaf(v[j], a2, b2));
         if constexpr (HAS_ER) {
-          float e[4]; unpack4<bf16_t>(*(const uint2*)(psm + 2 * PIPE_SLAB + lrd0 + (unsigned)r * lrds), e);
+          float e[4]; unpack4<T16>(*(const uint2*)(psm + 2 * PIPE_SLAB + lrd0 + (unsigned)r * lrds), e);
 #pragma unroll
           for (int j = 0; j < 4; j++) o[j] += e[j];
         }
@@ -911,7 +911,7 @@ __global__ __launch_bounds__(NTB) void gn_bwd_pipe_kernel(const bf16_t* __restri
 #pragma unroll
           for (int j = 0; j < 4; j++) cs[j] += o[j];
         }
-        store4<bf16_t>((bf16_t*)(dxs + (st0 + (unsigned)r * sts)), o);
+        store4<T16>((T16*)(dxs + (st0 + (unsigned)r * sts)), o);
       }
       if (colsum_ps) {
 #pragma unroll
@@ -1118,7 +1118,7 @@ int gn_bwd_t(eegldm_ctx* ctx, const void* x, long ldx, const float* gamma, const
 #else
     const int nth = ((bwd_nth == 512 || bwd_nth == 256) && (unfenced || (!ctx->side_on && g_eeg_live_ctx <= 1))) ? bwd_nth : 1024;
 #endif
-    if constexpr (Is16<T>::bf16) {
+    if constexpr (sizeof(T) == 2) {
       // pipelined persistent form (gn_bwd_pipe_kernel): slabs of exactly 6 rows x 4 channels per thread, L * CC = 24 576, CC a power of two
       EEG_ENV_VAR(bool, no_pipe, getenv("EEGLDM_GN_NO_PIPE") != nullptr);
       EEG_ENV_VAR(int, pipe_min_row, getenv("EEGLDM_GN_PIPE_MIN_ROW") ? atoi(getenv("EEGLDM_GN_PIPE_MIN_ROW")) : 64);
@@ -1161,13 +1161,13 @@ int gn_bwd_t(eegldm_ctx* ctx, const void* x, long ldx, const float* gamma, const
           }
           static DevOnce attr_once;
           if (attr_once.need(ctx->device)) {
-            HIP_TRY(hipFuncSetAttribute((const void*)gn_bwd_pipe_kernel<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, PIPE_LDS));
-            HIP_TRY(hipFuncSetAttribute((const void*)gn_bwd_pipe_kernel<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, PIPE_LDS));
-            HIP_TRY(hipFuncSetAttribute((const void*)gn_bwd_pipe_kernel<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, PIPE_LDS));
-            HIP_TRY(hipFuncSetAttribute((const void*)gn_bwd_pipe_kernel<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, PIPE_LDS));
+            HIP_TRY(hipFuncSetAttribute((const void*)gn_bwd_pipe_kernel<true, true, T>, hipFuncAttributeMaxDynamicSharedMemorySize, PIPE_LDS));
+            HIP_TRY(hipFuncSetAttribute((const void*)gn_bwd_pipe_kernel<true, false, T>, hipFuncAttributeMaxDynamicSharedMemorySize, PIPE_LDS));
+            HIP_TRY(hipFuncSetAttribute((const void*)gn_bwd_pipe_kernel<false, true, T>, hipFuncAttributeMaxDynamicSharedMemorySize, PIPE_LDS));
+            HIP_TRY(hipFuncSetAttribute((const void*)gn_bwd_pipe_kernel<false, false, T>, hipFuncAttributeMaxDynamicSharedMemorySize, PIPE_LDS));
           }
           const dim3 grid((unsigned)(8 * nslot * nchunk));
-#define GN_BWD_PIPE(SL, ER) hipLaunchKernelGGL((gn_bwd_pipe_kernel<SL, ER>), grid, dim3(NTB), PIPE_LDS, ctx->stream, (const bf16_t*)x, ldx, gamma, beta, stats, \
+#define GN_BWD_PIPE(SL, ER) hipLaunchKernelGGL((gn_bwd_pipe_kernel<SL, ER, T>), grid, dim3(NTB), PIPE_LDS, ctx->stream, (const bf16_t*)x, ldx, gamma, beta, stats, \
                                            (const bf16_t*)dy, lddy, (bf16_t*)dx, lddx, (const bf16_t*)dxr, lddxr, slots, colsum_ps, ldps, B, L, C, G, pcc, ndg)
           if (silu) { if (dxr) GN_BWD_PIPE(true, true); else GN_BWD_PIPE(true, false); }
           else { if (dxr) GN_BWD_PIPE(false, true); else GN_BWD_PIPE(false, false); }
