@@ -68,6 +68,18 @@ template <int BX> __device__ __forceinline__ int tr_swz(int row, int colbyte) {
   // the XOR must stay inside the row: the whole row when its size is a power of two, else 128-byte windows (192-row tiles: 384 B)
   constexpr int WIN = ((BX * 2) & (BX * 2 - 1)) == 0 ? BX * 2 - 1 : 127;
   static_assert((BX * 2) % (WIN + 1) == 0, "TR rows must be whole swizzle windows");
+  // ds_read_b64_tr_b16 is served in two 32-lane groups over 64 banks (MI355X_MICROARCH.md, LDS): lanes 0-15 read rows r .. r+3, lanes 16-31 rows
+  // r+8 .. r+11.  Rows of 256 B or more: bit 3 of the row flips a 128-byte half and the two 16-lane groups land on different bank halves.
+  // Rows of 128 B (64-wide tiles; 384-byte rows swizzle inside 128-byte windows too): the XOR is confined to (row & 3) and rows r and r+8 meet on
+  // the same 32 B -- a 2-way conflict on every B-fragment read of the fused 3-tap weight gradient (SQ_LDS_BANK_CONFLICT = 1.2 cycles per LDS
+  // instruction, 37 % of its LDS-array cycles, tools/r05/s18.sh).  -DEEG_TR_SWZ_NOCONFLICT lets bit 3 of the row flip the low chunk bit there
+  // (rows r+8 .. r+11 take the chunks rows r .. r+3 leave free): conflicts 4.7 M -> 0, LDS-array cycles 12.6 M -> 7.9 M per launch -- and the
+  // kernel is 2 % SLOWER (785-795 vs 809-815 TF/s over the UNet's shapes, LDM step +0.07 ms, tools/r05/s19.sh): the LDS array is 21-34 %
+  // busy either way and is not what the loop waits for.  Measured, not adopted.
+#ifdef EEG_TR_SWZ_NOCONFLICT
+  if constexpr (WIN == 127) return colbyte ^ (((row & 3) ^ ((row >> 3) & 1)) * 32);
+  else
+#endif
   return colbyte ^ ((((row & 3) | (((row >> 3) & 1) << 2)) * 32) & WIN);
 }
 
@@ -170,7 +182,7 @@ struct Cfg {
   // ~2500-cycle DMA latency, so three stages are kept in flight
   // (the 128 x 128 fused 3-tap weight-gradient tile is one 8-wave block per CU: 3-deep ring of 36 KB stages)
   static constexpr bool WG3_WIDE = WG3 && BN == 128;
-  static constexpr int NSTG = !USE_DMA ? 1 : (((WMT == 4 || WG3_WIDE) && 3 * STAGE_BYTES <= 160 * 1024) ? 3 : ((TAPS == 1 && KSUB == 1 && AMODE != GA_CONV) ? 4 : 2));
+  static constexpr int NSTG = !USE_DMA ? 1 : (((WMT == 4 || WG3_WIDE) && 3 * STAGE_BYTES <= 160 * 1024) ? 3 : (((TAPS == 1 || WG3) && KSUB == 1 && AMODE != GA_CONV) ? 4 : 2));
   static constexpr int CA = (A_CHUNKS + NTHREADS - 1) / NTHREADS;  // register-staged 16-byte chunks per thread
   static constexpr int CB = (B_CHUNKS + NTHREADS - 1) / NTHREADS;
   static constexpr int NSTG_BYTES_HINT = NSTG * STAGE_BYTES;
@@ -1115,6 +1127,10 @@ int launch_modes(eegldm_ctx* ctx, const GemmArgs& a) {
   if (a.amode == GA_TR && a.bmode == GB_TR && a.taps == 3) {   // fused 3-tap wgrad (see Cfg::WG3); BN <= 64 keeps 3 accumulator sets in registers
     // 128 x 128 x 3-tap tile, one 8-wave block per CU (see Cfg::WN); chosen by op_conv_wgrad through GemmArgs::wide_n
     if constexpr (sizeof(T) == 2) { if (a.wide_n && a.N % 128 == 0 && a.M % 128 == 0) return launch_t<T, GA_TR, GB_TR, 3, 2, 128, 1, 2>(ctx, a); }
+    if constexpr (sizeof(T) == 2) {      // experiment (round 5): 32-deep stages in a 4-deep LDS-DMA ring (64 KB per block, still two blocks per CU)
+      EEG_ENV_VAR(bool, wg3_deep, getenv("EEGLDM_WG3_DEEP") != nullptr);
+      if (wg3_deep && a.N > 32) return launch_t<T, GA_TR, GB_TR, 3, 1, 64, 1, 2>(ctx, a);
+    }
     if (a.N > 32) return launch_t<T, GA_TR, GB_TR, 3, 2, 64, 1, 2>(ctx, a);
     return launch_t<T, GA_TR, GB_TR, 3, 2, 32, 1, 2>(ctx, a);
   }
