@@ -36,7 +36,7 @@ extern "C" {
 
 /* 4: + eegldm_ctx_stream, eegldm_linear_bwd, eegldm_disc_feature, eegldm_usleep_*, eegldm_feature_moments (additive).
  * 6 (round 5): + EEGLDM_F16, eegldm_conv1d_skip_fwd, eegldm_conv1d_fwd_qstats, eegldm_groupnorm_fwd_qstats, eegldm_batchnorm_lrelu_*,
- *    eegldm_kl_reparam_*, eegldm_conv1d_pack_kblocked_k (additive). */
+ *    eegldm_kl_reparam_*, eegldm_conv1d_pack_kblocked_k, eegldm_avgpool2_*, eegldm_nearest2_* (additive). */
 #define EEGLDM_ABI_VERSION 6
 
 /* Storage / operand type of activations and compute-copy weights (accumulation, statistics, master weights and optimizer state are
@@ -293,6 +293,16 @@ int eegldm_kl_reparam_fwd(eegldm_ctx*, const void* mu, const void* log_var, cons
                           long n, int B, int dtype);
 int eegldm_kl_reparam_bwd(eegldm_ctx*, const void* mu, const void* log_var, const float* eps, const float* sigma, const void* dz,
                           void* dmu, void* dlog_var, long n, float kl_weight_over_B, int dtype);
+
+/* Stand-alone resampling in the NLC layout (rows = B * L, leading dimensions in elements): Downsample / Upsample with use_conv = False
+ * (src/models/unet.py:177-224: nn.AvgPool1d(2, 2) / F.interpolate(scale_factor = 2, mode = "nearest")), the ops a ResBlock applies to h
+ * and x when up / down is set (unet.py:308-313).  The executors fuse them into the GroupNorm kernels (`resample` above); these four are
+ * the same arithmetic at primitive granularity.  L is the length of the op's INPUT (x for _fwd, the op's input for _bwd as well:
+ * avgpool2_bwd takes dy [B][L/2][C] -> dx [B][L][C]; nearest2_bwd takes dy [B][2L][C] -> dx [B][L][C]). */
+int eegldm_avgpool2_fwd(eegldm_ctx*, const void* x, long ldx, void* y, long ldy, int B, int L, int C, int dtype);
+int eegldm_avgpool2_bwd(eegldm_ctx*, const void* dy, long lddy, void* dx, long lddx, int B, int L, int C, int dtype);
+int eegldm_nearest2_fwd(eegldm_ctx*, const void* x, long ldx, void* y, long ldy, int B, int L, int C, int dtype);
+int eegldm_nearest2_bwd(eegldm_ctx*, const void* dy, long lddy, void* dx, long lddx, int B, int L, int C, int dtype);
 
 /* ------------------------------------------------------------------ losses of the AEKL step (fp32 NCL tensors)
  * L1Loss (train_autoencoderkl.py:155,206): *loss = mean|a-b|; da_accum (nullable) += grad_weight * d/da.

@@ -59,6 +59,10 @@ SIGNATURES = {
     "eegldm_batchnorm_lrelu_bwd": [_vp, _vp, _l, _vp, _vp, _vp, _vp, _l, _vp, _l, _vp, _vp, _l, _i, _f, _i],
     "eegldm_kl_reparam_fwd": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _l, _i, _i],
     "eegldm_kl_reparam_bwd": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _l, _f, _i],
+    "eegldm_avgpool2_fwd": [_vp, _vp, _l, _vp, _l, _i, _i, _i, _i],
+    "eegldm_avgpool2_bwd": [_vp, _vp, _l, _vp, _l, _i, _i, _i, _i],
+    "eegldm_nearest2_fwd": [_vp, _vp, _l, _vp, _l, _i, _i, _i, _i],
+    "eegldm_nearest2_bwd": [_vp, _vp, _l, _vp, _l, _i, _i, _i, _i],
     "eegldm_conv1d_fwd_qstats": [_vp, _vp, _l, _vp, _vp, _vp, _l, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _l, _vp, _l, _i, _vp, C.POINTER(_i)],
     "eegldm_groupnorm_fwd_qstats": [_vp, _vp, _l, _vp, _vp, _vp, _l, _vp, _i, _i, _i, _i, _f, _i, _vp, _i, _vp, _i, _i],
     "eegldm_conv1d_skip_fwd": [_vp, _vp, _l, _vp, _vp, _vp, _l, _vp, _vp, _vp, _l, _i, _i, _i, _i, _i, _vp, _l, _i],

@@ -274,6 +274,27 @@ __global__ void copy_rows_kernel(T* __restrict__ dst, long ldd, const T* __restr
   }
 }
 
+// ------------------------------------------------------------------ stand-alone resampling (unet.py:177-224: Downsample / Upsample with use_conv = False)
+// The executors never launch these: inside a ResBlock the resampling rides the GroupNorm kernels (norm.hip `resample`).  They are the
+// primitive-granularity form of the same two ops behind the C ABI.  Rows are (sample, position) flattened; L is even, so the pair
+// (2r, 2r + 1) never straddles two samples.  MODE 0: y[r] = (x[2r] + x[2r+1]) / 2   (AvgPool1d(2, 2) forward)
+//                                            MODE 1: y[r] = x[2r] + x[2r+1]           (nearest x 2 backward)
+//                                            MODE 2: y[2r] = y[2r+1] = x[r] / 2       (AvgPool1d(2, 2) backward)
+//                                            MODE 3: y[2r] = y[2r+1] = x[r]           (nearest x 2 forward)
+template <typename T, int MODE>
+__global__ __launch_bounds__(NT) void resample2_kernel(const T* __restrict__ x, long ldx, T* __restrict__ y, long ldy, long rows_small, int C) {
+  GRID_STRIDE(i, rows_small * C) {
+    const long r = i / C; const int c = (int)(i - r * C);
+    if constexpr (MODE <= 1) {
+      const float a = ld_f32(x + (2 * r) * ldx + c), b = ld_f32(x + (2 * r + 1) * ldx + c);
+      st_f32(y + r * ldy + c, MODE == 0 ? (a + b) * 0.5f : a + b);
+    } else {
+      const float a = ld_f32(x + r * ldx + c), v = MODE == 2 ? a * 0.5f : a;
+      st_f32(y + (2 * r) * ldy + c, v); st_f32(y + (2 * r + 1) * ldy + c, v);
+    }
+  }
+}
+
 // ------------------------------------------------------------------ schedulers (training.py:429-436, sample_trials.py:163)
 __global__ void add_noise_kernel(const float* __restrict__ x, const float* __restrict__ nz, const int64_t* __restrict__ t,
                                  const float* __restrict__ acp, float* __restrict__ out, long n, long per, int velocity) {
@@ -699,4 +720,28 @@ extern "C" int eegldm_randint(eegldm_ctx* ctx, int64_t* out, long n, int64_t hig
   EEG_CHECK(high > 0, "high must be positive");
   hipLaunchKernelGGL(randint_kernel, dim3(grid1d(n, ctx)), dim3(NT), 0, ctx->stream, out, n, high, seed, offset);
   LAUNCH_CHECK(); return 0;
+}
+
+// ---- stand-alone AvgPool1d(2,2) / nearest x 2 (include/eegldm.h)
+static int resample2(eegldm_ctx* ctx, int mode, const void* x, long ldx, void* y, long ldy, int B, int L_small, int C, int dtype) {
+  EEG_CHECK(ctx && x && y && B > 0 && L_small > 0 && C > 0 && ldx >= C && ldy >= C, "bad argument");
+  const long rows = (long)B * L_small;
+#define RS2(M) DISPATCH_T(dtype, hipLaunchKernelGGL((resample2_kernel<T, M>), dim3(grid1d(rows * C, ctx)), dim3(NT), 0, ctx->stream, (const T*)x, ldx, (T*)y, ldy, rows, C))
+  if (mode == 0) RS2(0); else if (mode == 1) RS2(1); else if (mode == 2) RS2(2); else RS2(3);
+#undef RS2
+  LAUNCH_CHECK(); return 0;
+}
+extern "C" int eegldm_avgpool2_fwd(eegldm_ctx* ctx, const void* x, long ldx, void* y, long ldy, int B, int L, int C, int dtype) {
+  EEG_CHECK(L % 2 == 0, "AvgPool1d(2, 2): even length expected, got %d", L);
+  return resample2(ctx, 0, x, ldx, y, ldy, B, L / 2, C, dtype);
+}
+extern "C" int eegldm_avgpool2_bwd(eegldm_ctx* ctx, const void* dy, long lddy, void* dx, long lddx, int B, int L, int C, int dtype) {
+  EEG_CHECK(L % 2 == 0, "AvgPool1d(2, 2): even length expected, got %d", L);
+  return resample2(ctx, 2, dy, lddy, dx, lddx, B, L / 2, C, dtype);
+}
+extern "C" int eegldm_nearest2_fwd(eegldm_ctx* ctx, const void* x, long ldx, void* y, long ldy, int B, int L, int C, int dtype) {
+  return resample2(ctx, 3, x, ldx, y, ldy, B, L, C, dtype);
+}
+extern "C" int eegldm_nearest2_bwd(eegldm_ctx* ctx, const void* dy, long lddy, void* dx, long lddx, int B, int L, int C, int dtype) {
+  return resample2(ctx, 1, dy, lddy, dx, lddx, B, L, C, dtype);
 }
