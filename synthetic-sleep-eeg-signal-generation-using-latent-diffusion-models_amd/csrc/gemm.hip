@@ -134,8 +134,10 @@ struct Cfg {
   // WMT encodes the M geometry: 2 / 4 = that many waves along M with four 16-row fragments each (128 / 256 rows);
   // 3 = two waves along M with SIX fragments each (192 rows): 25 % fewer L2->LDS bytes per MFMA than the 128-row tile at
   // the same 2 blocks per CU (the K loop is bound by L2->LDS queueing), and every UNet length (192/384/768) divides
-  static constexpr int WM = (WMT == 3) ? 2 : WMT;                 // waves along M (2 along N)
-  static constexpr int FM = (WMT == 3) ? 6 : 4;                   // 16-row fragments per wave along M
+  // 5 = FOUR waves along M with TWO fragments each (128 rows, 8 waves per block at 2 along N): the 128 x 64 x 3-tap weight-gradient tile cut into
+  // 32 x 32 wave tiles -- 48 accumulator registers per lane instead of 96, so that two blocks per CU are four waves per SIMD instead of two
+  static constexpr int WM = (WMT == 3) ? 2 : (WMT == 5 ? 4 : WMT);                 // waves along M (2 along N)
+  static constexpr int FM = (WMT == 3) ? 6 : (WMT == 5 ? 2 : 4);                   // 16-row fragments per wave along M
   static constexpr int BM = WM * FM * 16;                         // block rows
   // waves along N: 2, except the wide fused 3-tap weight-gradient tile (AMODE = BMODE = TR, TAPS = 3, BN = 128): FOUR, i.e. one 8-wave
   // block per CU computing 128 x 128 x 3 taps.  It is two of the 128 x 64 blocks that used to share a CU merged into one: the dY
@@ -219,7 +221,7 @@ __device__ __forceinline__ void dma16(const void* g, unsigned lds_off) {
 __device__ __forceinline__ void dma_wait_all() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 
 template <typename T, int AMODE, int BMODE, int TAPS, int KSUB, int BN, int STRIDE, int WMT, bool DMA>
-__global__ __launch_bounds__((Cfg<T, AMODE, BMODE, TAPS, KSUB, BN, STRIDE, WMT, DMA>::NTHREADS), 2)
+__global__ __launch_bounds__((Cfg<T, AMODE, BMODE, TAPS, KSUB, BN, STRIDE, WMT, DMA>::NTHREADS), (WMT == 5 ? 4 : 2))
 void gemm_kernel(const GemmArgs p) {   // >= 2 waves per SIMD: <= 256 VGPR+AGPR
   using C = Cfg<T, AMODE, BMODE, TAPS, KSUB, BN, STRIDE, WMT, DMA>;
   constexpr int FN = C::FN;
@@ -591,6 +593,9 @@ void gemm_kernel(const GemmArgs p) {   // >= 2 waves per SIMD: <= 256 VGPR+AGPR
     } else {
       // vmcnt(0) + barrier: stage s has landed in buffer s&1, and every wave is done reading buffer (s+1)&1
       dma_wait_all();
+#ifdef EEG_STAGE_SPLIT      // (developer build: DMA wait and barrier stamped separately, tools/debug/stage_split.py)
+      TSTAMP();
+#endif
       __syncthreads();
       if constexpr (!INTERLEAVE) { if (s + 1 < nstages) issue_stage(s + 1, (s + 1) & 1); }
     }
@@ -694,6 +699,10 @@ void gemm_kernel(const GemmArgs p) {   // >= 2 waves per SIMD: <= 256 VGPR+AGPR
     uint4 af[2][C::FM], bf[2][FN];
     load_frags(0, af[0], bf[0]);
     __builtin_amdgcn_sched_barrier(0);
+#ifdef EEG_STAGE_SPLIT
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); TSTAMP();      // the first fragments of the stage have arrived
+    __builtin_amdgcn_sched_barrier(0);
+#endif
 #ifdef EEG_SETPRIO
     __builtin_amdgcn_s_setprio(EEG_SETPRIO);      // experiment: the wave in its MFMA phase wins issue arbitration against the co-resident block's wave
 #endif
@@ -1083,7 +1092,7 @@ int launch_t(eegldm_ctx* ctx, const GemmArgs& a) {
     EEG_ENV_VAR(bool, no_dma1, getenv("EEGLDM_GEMM1_NO_DMA") != nullptr);
     if (!no_dma1 && a.K % KSTAGE == 0 && a.splitk == 1) return launch_k<T, AMODE, BMODE, TAPS, KSUB, BN, STRIDE, WMT, true>(ctx, a);
   }
-  if constexpr (AMODE == GA_TR && BMODE == GB_TR && (WMT == 2 || WMT == 3)) {
+  if constexpr (AMODE == GA_TR && BMODE == GB_TR && (WMT == 2 || WMT == 3 || WMT == 5)) {
     // weight gradients (fused 3-tap and 1-tap / Linear): every split is a whole number of stages when K is, and the source
     // of a chunk moves by a constant per stage unless the K index is remapped per tap (conv_map: unfused strided wgrad)
     EEG_ENV_VAR(bool, no_dma, getenv("EEGLDM_WGRAD_NO_DMA") != nullptr);
@@ -1127,10 +1136,9 @@ int launch_modes(eegldm_ctx* ctx, const GemmArgs& a) {
   if (a.amode == GA_TR && a.bmode == GB_TR && a.taps == 3) {   // fused 3-tap wgrad (see Cfg::WG3); BN <= 64 keeps 3 accumulator sets in registers
     // 128 x 128 x 3-tap tile, one 8-wave block per CU (see Cfg::WN); chosen by op_conv_wgrad through GemmArgs::wide_n
     if constexpr (sizeof(T) == 2) { if (a.wide_n && a.N % 128 == 0 && a.M % 128 == 0) return launch_t<T, GA_TR, GB_TR, 3, 2, 128, 1, 2>(ctx, a); }
-    if constexpr (sizeof(T) == 2) {      // experiment (round 5): 32-deep stages in a 4-deep LDS-DMA ring (64 KB per block, still two blocks per CU)
-      EEG_ENV_VAR(bool, wg3_deep, getenv("EEGLDM_WG3_DEEP") != nullptr);
-      if (wg3_deep && a.N > 32) return launch_t<T, GA_TR, GB_TR, 3, 1, 64, 1, 2>(ctx, a);
-    }
+    // (Round 5 measured two more forms of this tile, both equal to it within 1 % over the UNet's shapes and since removed from the dispatch:
+    //  32-deep stages in a 4-deep LDS-DMA ring -- launch_t<T, GA_TR, GB_TR, 3, 1, 64, 1, 2> -- and eight waves of 32 x 32 x 3 taps, four per
+    //  SIMD at 128 VGPRs -- WMT = 5.  DESIGN.md section 9.)
     if (a.N > 32) return launch_t<T, GA_TR, GB_TR, 3, 2, 64, 1, 2>(ctx, a);
     return launch_t<T, GA_TR, GB_TR, 3, 2, 32, 1, 2>(ctx, a);
   }
