@@ -21,7 +21,7 @@ def run(dtype, steps, B, L, pool, every, lr, sample):
     import eegldm
     from eegldm.models import UNetModel, AutoencoderKL
     from eegldm.schedulers import DDPMScheduler
-    from eegldm.training import Adam, ldm_train_step, randint, randn
+    from eegldm.training import Adam, GradScaler, ldm_train_step, randint, randn
     from eegldm.sampling import ddim_sample, make_sampling_scheduler
     from param_gen import eeg_windows
     from bench import UNET_CFG
@@ -34,6 +34,8 @@ def run(dtype, steps, B, L, pool, every, lr, sample):
                        norm_num_groups=1, attention_levels=[False, False, False], dtype=dtype, device=0)
     sched = DDPMScheduler(num_train_timesteps=1000, schedule="linear_beta", beta_start=0.0015, beta_end=0.0195, device=0)
     opt = Adam(unet, lr=lr)
+    scaler = GradScaler(enabled=(dtype == "float16"))       # the reference's AMP recipe (training.py:334,441-443): fp16 storage needs it
+    skipped = 0
     loss = torch.zeros(1, device=dev)
     windows = torch.from_numpy(eeg_windows(pool, seed=4321, length=4 * L)).to(dev)
     sf = 1.0 / float(ae.encode_stage_2_inputs(windows[:B], eps=randn(ctx, (B, 1, L), seed=99)).std())
@@ -47,13 +49,16 @@ def run(dtype, steps, B, L, pool, every, lr, sample):
         eps = randn(ctx, (B, 1, L), seed=13, offset=i * B * L)
         lat = ae.encode_stage_2_inputs(xb, eps=eps, scale_factor=sf)
         unet.zero_grad()
-        ldm_train_step(unet, sched, lat, noise, t, loss_out=loss)
-        opt.step()
+        ldm_train_step(unet, sched, lat, noise, t, loss_out=loss, grad_scale=scaler.get_scale())
+        scaler.step(opt)
+        if scaler.is_enabled() and scaler._found_inf: skipped += 1
+        scaler.update()
         if i % every == 0 or i == steps - 1:
             curve.append((i, float(loss))); mem.append((torch.cuda.memory_allocated(), torch.cuda.memory_reserved()))
             print(f"[{dtype}] step {i:5d} loss {curve[-1][1]:.5f} alloc {mem[-1][0] / 2**20:.0f} MiB reserved {mem[-1][1] / 2**20:.0f} MiB "
                   f"{time.time() - t0:.1f}s", flush=True)
-    out = {"dtype": dtype, "curve": curve, "alloc_first_last": [mem[0][0], mem[-1][0]], "reserved_first_last": [mem[0][1], mem[-1][1]]}
+    if scaler.is_enabled(): print(f"[{dtype}] GradScaler: final scale {scaler.get_scale():.0f}, {skipped} skipped steps", flush=True)
+    out = {"dtype": dtype, "curve": curve, "grad_scaler": {"enabled": scaler.is_enabled(), "final_scale": scaler.get_scale(), "skipped_steps": skipped}, "alloc_first_last": [mem[0][0], mem[-1][0]], "reserved_first_last": [mem[0][1], mem[-1][1]]}
     if sample:
         unet.eval()
         ss = make_sampling_scheduler(50, device=0)
@@ -74,14 +79,14 @@ def main():
     p.add_argument("--batch", type=int, default=256); p.add_argument("--length", type=int, default=768)
     p.add_argument("--pool", type=int, default=2048); p.add_argument("--every", type=int, default=25)
     p.add_argument("--lr", type=float, default=1e-4); p.add_argument("--no_sample", action="store_true")
-    p.add_argument("--out", default=None)
+    p.add_argument("--out", default=None); p.add_argument("--dtype", default="bfloat16", choices=["bfloat16", "float16"])
     a = p.parse_args()
-    res = [run("bfloat16", a.steps, a.batch, a.length, a.pool, a.every, a.lr, not a.no_sample)]
+    res = [run(a.dtype, a.steps, a.batch, a.length, a.pool, a.every, a.lr, not a.no_sample)]
     if a.fp32_steps:
         res.append(run("float32", a.fp32_steps, a.batch, a.length, a.pool, a.every, a.lr, False))
         f = dict(res[1]["curve"]); b = dict(res[0]["curve"])
         gaps = [(i, b[i], f[i], abs(b[i] - f[i]) / f[i]) for i in sorted(set(f) & set(b))]
-        print("bf16 vs fp32 loss on common steps (step, bf16, fp32, rel gap):")
+        print(f"{a.dtype} vs fp32 loss on common steps (step, {a.dtype}, fp32, rel gap):")
         for g in gaps:
             print("  %5d %.5f %.5f %.4f" % g)
         res.append({"max_rel_gap": max(g[3] for g in gaps)})
