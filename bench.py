@@ -31,7 +31,7 @@ for p in (ROOT, os.path.join(ROOT, "tests", "golden")):
 
 UNET_CFG = dict(image_size=768, in_channels=1, out_channels=1, model_channels=128, num_res_blocks=2,
                 attention_resolutions=[8, 4], channel_mult=[1, 2, 4], resblock_updown=True)   # config_ldm.yaml:30-43, latent_channels=1
-MFMA_PEAK_TFLOPS = {"bf16": 2500.0, "f32": 157.3}     # dense, /opt/skills/guides/MI355X_MICROARCH.md
+MFMA_PEAK_TFLOPS = {"bf16": 2500.0, "f16": 2500.0, "f32": 157.3}     # dense, /opt/skills/guides/MI355X_MICROARCH.md
 HBM_PEAK_GBS = 8000.0                                  # HBM3E spec peak (same guide; ~6.3 TB/s is what a streaming kernel reaches)
 PKG = os.path.join(ROOT, "synthetic-sleep-eeg-signal-generation-using-latent-diffusion-models_amd")
 
@@ -100,7 +100,8 @@ def parse():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=256, help="windows per GPU per step (C4: 2048 / 8 GPUs)")
     ap.add_argument("--length", type=int, default=768, help="latent length (3072 / 4)")
-    ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "f16", "f32"],
+                    help="storage / operand type; f16 = the reference's autocast dtype, run with its GradScaler (training.py:334,441-443) inside the timed step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-parts", action="store_true", help="skip the secondary AEKL-GAN / DDIM-50 measurements")
@@ -240,7 +241,7 @@ def main():
     from eegldm import distributed as D
     from eegldm.models import UNetModel, AutoencoderKL, PatchDiscriminator
     from eegldm.schedulers import DDPMScheduler
-    from eegldm.training import Adam, ldm_train_step, aekl_train_step, randint, randn
+    from eegldm.training import Adam, GradScaler, ldm_train_step, aekl_train_step, randint, randn
     from eegldm.sampling import ddim_sample, make_sampling_scheduler
     from param_gen import eeg_windows
 
@@ -250,7 +251,7 @@ def main():
     ctx = eegldm.default_context(local)
     dev = torch.device("cuda", local)
     B, L = args.batch, args.length
-    dtype = {"bf16": "bfloat16", "f32": "float32"}[args.dtype]
+    dtype = {"bf16": "bfloat16", "f16": "float16", "f32": "float32"}[args.dtype]
 
     unet = UNetModel(**UNET_CFG, dtype=dtype, device=local)
     g = torch.Generator().manual_seed(42)
@@ -260,6 +261,7 @@ def main():
     D.broadcast_flat(unet.flat); unet.sync_weights()
     sched = DDPMScheduler(num_train_timesteps=1000, schedule="linear_beta", beta_start=0.0015, beta_end=0.0195, device=local)   # train_ldm.py:199-200
     opt = Adam(unet, lr=1e-4)
+    scaler = GradScaler(enabled=(args.dtype == "f16"))      # fp16 storage: loss scaling, finite check and skip logic are part of the step
     loss = torch.zeros(1, device=dev)
     # frozen stage-1 autoencoder (production channels [32,32,64], latent 1: clusters/run_aekl_shhs_1.sh:8-10)
     ae = AutoencoderKL(spatial_dims=1, in_channels=1, out_channels=1, num_channels=[32, 32, 64], latent_channels=1, num_res_blocks=2,
@@ -281,10 +283,10 @@ def main():
         # N > 1: the all-reduce of out / output_blocks / middle_block gradients starts inside the native backward (grad hook)
         # and overlaps the input blocks' backward; the rest follows the call
         gs = gsync if sync else None          # the rank-0-only profiling leg below must not enter a collective
-        ldm_train_step(unet, sched, latents, noise, t, loss_out=loss, grad_sync=gs)
+        ldm_train_step(unet, sched, latents, noise, t, loss_out=loss, grad_scale=scaler.get_scale(), grad_sync=gs)
         if gs is not None:
             gs.wait()
-        opt.step()
+        scaler.step(opt); scaler.update()      # disabled scaler: plain opt.step()
 
     for i in range(args.warmup):
         step(i)
@@ -412,7 +414,7 @@ def main():
         for i in range(n_gan):
             gan_step(2 + i)
         torch.cuda.synchronize(); dtg = (time.time() - t1) / n_gan
-        esz = 2 if args.dtype == "bf16" else 4
+        esz = 2 if args.dtype in ("bf16", "f16") else 4
         abytes = aekl_gan_step_bytes([2, 2, 4], 4 * L, esz) * Ba + 16 * (int(ae2.flat.numel()) + int(disc.flat.numel()))
         hbm_ach = abytes / dtg / 1e9
         fbytes = aekl_gan_step_bytes([2, 2, 4], 4 * L, esz, fused=True) * Ba + 16 * (int(ae2.flat.numel()) + int(disc.flat.numel()))
