@@ -136,7 +136,10 @@ struct Cfg {
   // the same 2 blocks per CU (the K loop is bound by L2->LDS queueing), and every UNet length (192/384/768) divides
   // 5 = FOUR waves along M with TWO fragments each (128 rows, 8 waves per block at 2 along N): the 128 x 64 x 3-tap weight-gradient tile cut into
   // 32 x 32 wave tiles -- 48 accumulator registers per lane instead of 96, so that two blocks per CU are four waves per SIMD instead of two
-  static constexpr int WM = (WMT == 3) ? 2 : (WMT == 5 ? 4 : WMT);                 // waves along M (2 along N)
+  // 6 = the geometry of 2 (two waves along M, four fragments each) with a THREE-deep LDS-DMA ring in the fused 3-tap weight gradient: the X
+  // tile is allocated by the 9 DMA instructions it needs instead of whole rounds of 4 waves (9 KB, not 12), the three padding instructions of
+  // the last round land in one shared 1 KB dump slot, and three 25 KB stages + the slot are 76 KB: two blocks per CU still fit the 160 KB LDS
+  static constexpr int WM = (WMT == 3 || WMT == 6) ? 2 : (WMT == 5 ? 4 : WMT);                 // waves along M (2 along N)
   static constexpr int FM = (WMT == 3) ? 6 : (WMT == 5 ? 2 : 4);                   // 16-row fragments per wave along M
   static constexpr int BM = WM * FM * 16;                         // block rows
   // waves along N: 2, except the wide fused 3-tap weight-gradient tile (AMODE = BMODE = TR, TAPS = 3, BN = 128): FOUR, i.e. one 8-wave
@@ -173,7 +176,8 @@ struct Cfg {
   static constexpr int IA = (A_INSTR + NW - 1) / NW;              // DMA instructions per wave per stage (uniform over waves:
   static constexpr int IB = (B_INSTR + NW - 1) / NW;              //  the tail instructions fill padding from the zero page)
   static constexpr int A_ALLOC = IA * NW * 1024;
-  static constexpr int B_ALLOC = IB * NW * 1024;
+  static constexpr bool TIGHT3 = (AMODE == GA_TR && BMODE == GB_TR && TAPS == 3 && WMT == 6);
+  static constexpr int B_ALLOC = TIGHT3 ? B_INSTR * 1024 : IB * NW * 1024;
   static constexpr int STAGE_BYTES = A_ALLOC + B_ALLOC;
   // Staging engine, chosen by measurement (profiles/r01_gemm_tile_sweep.txt): the 3-tap conv kernels are fastest with
   // LDS-DMA into a double-buffered ring (one barrier per stage); the 1-tap kernels (1x1 / Linear / attention / wgrad)
@@ -184,7 +188,7 @@ struct Cfg {
   // ~2500-cycle DMA latency, so three stages are kept in flight
   // (the 128 x 128 fused 3-tap weight-gradient tile is one 8-wave block per CU: 3-deep ring of 36 KB stages)
   static constexpr bool WG3_WIDE = WG3 && BN == 128;
-  static constexpr int NSTG = !USE_DMA ? 1 : (((WMT == 4 || WG3_WIDE) && 3 * STAGE_BYTES <= 160 * 1024) ? 3 : (((TAPS == 1 || WG3) && KSUB == 1 && AMODE != GA_CONV) ? 4 : 2));
+  static constexpr int NSTG = !USE_DMA ? 1 : (((WMT == 4 || WG3_WIDE || TIGHT3) && 3 * STAGE_BYTES <= 160 * 1024) ? 3 : (((TAPS == 1 || WG3) && KSUB == 1 && AMODE != GA_CONV) ? 4 : 2));
   static constexpr int CA = (A_CHUNKS + NTHREADS - 1) / NTHREADS;  // register-staged 16-byte chunks per thread
   static constexpr int CB = (B_CHUNKS + NTHREADS - 1) / NTHREADS;
   static constexpr int NSTG_BYTES_HINT = NSTG * STAGE_BYTES;
@@ -198,7 +202,9 @@ struct Cfg {
   static constexpr int EPI_ROWS = EPI_I * 16 * WM;
   static constexpr int EPI_BYTES = EPI_ROWS * EPI_PITCH;
   static constexpr int EPI16_BYTES = (sizeof(T) == 2 && AMODE != GA_TR) ? BM * (BN * 2 + 16) : 0;   // packed bf16 output tile (one pass)
-  static constexpr int LDS_BYTES0 = (NSTG * STAGE_BYTES) > EPI_BYTES ? (NSTG * STAGE_BYTES) : EPI_BYTES;
+  static constexpr int DUMP_OFF = NSTG * STAGE_BYTES;             // TIGHT3: where the padding DMA instructions of the last B round land
+  static constexpr int RING_BYTES = NSTG * STAGE_BYTES + (TIGHT3 ? 1024 : 0);
+  static constexpr int LDS_BYTES0 = RING_BYTES > EPI_BYTES ? RING_BYTES : EPI_BYTES;
   static constexpr int LDS_BYTES = LDS_BYTES0 > EPI16_BYTES ? LDS_BYTES0 : EPI16_BYTES;
   // 16 zero bytes for conv rows of a neighbouring sample: the first padding chunk behind the A tile of buffer 0 when the
   // DMA pads that tile (it is then refilled from the zero page every stage), else a slot behind the tiles
@@ -412,6 +418,11 @@ void gemm_kernel(const GemmArgs p) {   // >= 2 waves per SIMD: <= 256 VGPR+AGPR
   }
   const unsigned lds0 = (unsigned)(size_t)(lds_void_ptr)smem;           // LDS byte address of the tile area
   const unsigned wave_u = __builtin_amdgcn_readfirstlane(wave);   // scalar copy (M0 must come from an SGPR)
+  auto b_dst = [&](int buf, int i) __attribute__((always_inline)) -> unsigned {      // LDS byte offset of this wave's B instruction i (wave-uniform)
+    const unsigned idx = wave_u + NW * i;
+    if constexpr (C::TIGHT3) { if (idx >= (unsigned)C::B_INSTR) return (unsigned)C::DUMP_OFF; }
+    return (unsigned)(buf * C::STAGE_BYTES + C::A_ALLOC) + idx * 1024u;
+  };
   auto issue_stage = [&](int s, int buf) __attribute__((always_inline)) {
     unsigned bdead = 0;
     if constexpr (C::WG3) {   // k=3, pad 1: the row above the first / below the last row of a sample is the conv's zero padding
@@ -427,7 +438,7 @@ void gemm_kernel(const GemmArgs p) {   // >= 2 waves per SIMD: <= 256 VGPR+AGPR
 #pragma unroll
     for (int i = 0; i < C::IB; i++) {
       const T* src = (bpre[i] && !((bdead >> i) & 1)) ? bpre[i] + s * bstep : zeros;
-      dma16(src, lds0 + buf * C::STAGE_BYTES + C::A_ALLOC + (wave_u + NW * i) * 1024);
+      dma16(src, lds0 + b_dst(buf, i));
     }
   };
 
@@ -448,7 +459,7 @@ void gemm_kernel(const GemmArgs p) {   // >= 2 waves per SIMD: <= 256 VGPR+AGPR
         dead = dead || (((bbot >> i) & 1) && ((k0 + C::KSTAGE) % p.Lout == 0));
       }
       const T* src = (bpre[i] && !dead) ? bpre[i] + s * bstep : zeros;
-      dma16(src, lds0 + buf * C::STAGE_BYTES + C::A_ALLOC + (wave_u + NW * i) * 1024);
+      dma16(src, lds0 + b_dst(buf, i));
     }
   };
 
@@ -1092,7 +1103,7 @@ int launch_t(eegldm_ctx* ctx, const GemmArgs& a) {
     EEG_ENV_VAR(bool, no_dma1, getenv("EEGLDM_GEMM1_NO_DMA") != nullptr);
     if (!no_dma1 && a.K % KSTAGE == 0 && a.splitk == 1) return launch_k<T, AMODE, BMODE, TAPS, KSUB, BN, STRIDE, WMT, true>(ctx, a);
   }
-  if constexpr (AMODE == GA_TR && BMODE == GB_TR && (WMT == 2 || WMT == 3 || WMT == 5)) {
+  if constexpr (AMODE == GA_TR && BMODE == GB_TR && (WMT == 2 || WMT == 3 || WMT == 5 || WMT == 6)) {
     // weight gradients (fused 3-tap and 1-tap / Linear): every split is a whole number of stages when K is, and the source
     // of a chunk moves by a constant per stage unless the K index is remapped per tap (conv_map: unfused strided wgrad)
     EEG_ENV_VAR(bool, no_dma, getenv("EEGLDM_WGRAD_NO_DMA") != nullptr);
@@ -1138,7 +1149,7 @@ int launch_modes(eegldm_ctx* ctx, const GemmArgs& a) {
     if constexpr (sizeof(T) == 2) { if (a.wide_n && a.N % 128 == 0 && a.M % 128 == 0) return launch_t<T, GA_TR, GB_TR, 3, 2, 128, 1, 2>(ctx, a); }
     // (Round 5 measured two more forms of this tile, both equal to it within 1 % over the UNet's shapes and since removed from the dispatch:
     //  32-deep stages in a 4-deep LDS-DMA ring -- launch_t<T, GA_TR, GB_TR, 3, 1, 64, 1, 2> -- and eight waves of 32 x 32 x 3 taps, four per
-    //  SIMD at 128 VGPRs -- WMT = 5.  DESIGN.md section 9.)
+    //  SIMD at 128 VGPRs -- WMT = 5; and a third, 15 % SLOWER: a three-deep ring at two blocks per CU -- WMT = 6, Cfg::TIGHT3.  DESIGN.md section 9.)
     if (a.N > 32) return launch_t<T, GA_TR, GB_TR, 3, 2, 64, 1, 2>(ctx, a);
     return launch_t<T, GA_TR, GB_TR, 3, 2, 32, 1, 2>(ctx, a);
   }

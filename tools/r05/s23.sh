@@ -1,0 +1,15 @@
+#!/bin/bash
+# fused 3-tap weight gradient: three-deep LDS-DMA ring at two blocks per CU (tight X-tile allocation, EEGLDM_WG3_RING3=1) against the double buffer
+set -u
+cd "$(dirname "$0")/../.." || exit 1
+export TMPDIR=/tmp
+OUT=gpurun_out/r05_s23; rm -rf $OUT; mkdir -p $OUT
+EEGLDM_WG3_RING3=1 timeout 900 python -m pytest tests/test_gpu_primitives.py tests/test_gpu_unet.py tests/test_gpu_fp16.py -x -q -k "conv or wgrad or weight or unet" > $OUT/t.log 2>&1; tail -3 $OUT/t.log
+for i in 1 2; do
+  python tools/debug/gemm_bench.py bf16 2>&1 | grep -E "TOTAL" | sed "s/^/base /" | tee -a $OUT/gb.log
+  EEGLDM_WG3_RING3=1 python tools/debug/gemm_bench.py bf16 2>&1 | grep -E "wgrad|TOTAL" | sed "s/^/ring3 /" | tee -a $OUT/gb.log
+done
+for i in 1 2; do
+  python tools/debug/quick_bench.py bfloat16 256 768 8 2>&1 | grep -E "ms/step" | sed "s/^/base /" | tee -a $OUT/qb.log
+  EEGLDM_WG3_RING3=1 python tools/debug/quick_bench.py bfloat16 256 768 8 2>&1 | grep -E "ms/step" | sed "s/^/ring3 /" | tee -a $OUT/qb.log
+done
