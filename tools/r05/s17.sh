@@ -1,5 +1,6 @@
 #!/bin/bash
 # fused 3-tap weight gradient: 32-deep stages in a 4-deep LDS-DMA ring (EEGLDM_WG3_DEEP=1) against the 64-deep double buffer
+# NOTE: the switch this script toggles was taken out of the dispatch after the measurement; the numbers are in gpurun_out of that run and in DESIGN.
 set -u
 cd "$(dirname "$0")/../.." || exit 1
 export TMPDIR=/tmp

@@ -1,5 +1,6 @@
 #!/bin/bash
 # fused 3-tap weight gradient: eight waves of 32 x 32 x 3 taps per 128 x 64 tile, four waves per SIMD (EEGLDM_WG3_W8=1) against four waves of 64 x 32
+# NOTE: the switch this script toggles was taken out of the dispatch after the measurement; the numbers are in gpurun_out of that run and in DESIGN.
 set -u
 cd "$(dirname "$0")/../.." || exit 1
 export TMPDIR=/tmp

@@ -1,5 +1,6 @@
 #!/bin/bash
 # fused 3-tap weight gradient: three-deep LDS-DMA ring at two blocks per CU (tight X-tile allocation, EEGLDM_WG3_RING3=1) against the double buffer
+# NOTE: the switch this script toggles was taken out of the dispatch after the measurement; the numbers are in gpurun_out of that run and in DESIGN.
 set -u
 cd "$(dirname "$0")/../.." || exit 1
 export TMPDIR=/tmp
