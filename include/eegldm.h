@@ -37,7 +37,7 @@ extern "C" {
 /* 4: + eegldm_ctx_stream, eegldm_linear_bwd, eegldm_disc_feature, eegldm_usleep_*, eegldm_feature_moments (additive).
  * 6 (round 5): + EEGLDM_F16, eegldm_conv1d_skip_fwd, eegldm_conv1d_fwd_qstats, eegldm_groupnorm_fwd_qstats, eegldm_batchnorm_lrelu_*,
  *    eegldm_kl_reparam_*, eegldm_conv1d_pack_kblocked_k, eegldm_avgpool2_*, eegldm_nearest2_* (additive). */
-#define EEGLDM_ABI_VERSION 6
+#define EEGLDM_ABI_VERSION 7
 
 /* Storage / operand type of activations and compute-copy weights (accumulation, statistics, master weights and optimizer state are
  * always fp32).  EEGLDM_F16 = IEEE half: the type the reference trains in under `autocast` (src/training/training.py:423) with its
@@ -57,6 +57,7 @@ typedef struct eegldm_ctx eegldm_ctx;
 typedef struct eegldm_unet eegldm_unet;
 typedef struct eegldm_aekl eegldm_aekl;
 typedef struct eegldm_disc eegldm_disc;
+typedef struct eegldm_block eegldm_block;
 
 /* ------------------------------------------------------------------ library / context */
 int eegldm_abi_version(void);
@@ -270,6 +271,29 @@ int eegldm_fill(eegldm_ctx*, float* p, long n, float value);
  * UNet forward, MSE vs noise / velocity, backward.  loss: device scalar. */
 int eegldm_ldm_train_step(eegldm_unet*, const float* latents, const float* noise, const int64_t* t,
                           const float* acp, int pred_type, int B, int L, float grad_scale, float* loss);
+
+/* ------------------------------------------------------------------ UNet building blocks at primitive granularity (ABI 7)
+ * ONE ResBlock(channels, emb_channels, dropout=0, out_channels, up / down) -- /root/reference/src/models/unet.py:227-327 -- or ONE
+ * AttentionBlock(channels, num_heads=1) -- unet.py:132-174 -- run through exactly the kernel sequences the UNet executor runs per block
+ * (csrc/net.hip res_forward / res_backward / attn_forward / attn_backward), plus timestep_embedding(t, dim) -- unet.py:12-36.
+ * They exist so that the reference's per-primitive goldens are checked against the kernels, not only whole models
+ * (tests/test_gpu_primitive_goldens.py).  Entry names are the reference module's state_dict keys; parameters / gradients are flat fp32
+ * buffers as for the models; conv weights packed [K][Cout][Cin].  updown: 0 none, 1 down (AvgPool1d(2)), 2 up (nearest x2).
+ * forward: x (B, channels, L) and y (B, out_channels, L') fp32 NCL; emb (B, emb_channels) fp32 -- the ResBlock's `emb` argument
+ * (emb_layers = SiLU -> Linear runs inside); NULL for an AttentionBlock.  backward: grads += d<dy, y>/dparams; dx and demb are
+ * WRITTEN (both nullable). */
+int eegldm_resblock_create(eegldm_ctx*, int channels, int out_channels, int emb_channels, int groups, int updown, int dtype,
+                           eegldm_block** out);
+int eegldm_attnblock_create(eegldm_ctx*, int channels, int dtype, eegldm_block** out);
+int eegldm_block_destroy(eegldm_block*);
+int eegldm_block_num_entries(const eegldm_block*);
+long eegldm_block_num_params(const eegldm_block*);
+int eegldm_block_entry(const eegldm_block*, int i, char* name, int name_cap, long* offset, long* numel, int* ndim, int shape[3]);
+int eegldm_block_bind(eegldm_block*, float* params, float* grads);
+int eegldm_block_forward(eegldm_block*, const float* x, const float* emb, float* y, int B, int L);
+int eegldm_block_backward(eegldm_block*, const float* dy, float* dx, float* demb);
+/* out (B, dim) fp32 = [cos(t f_0) .. cos(t f_{h-1}), sin(t f_0) .. sin(t f_{h-1})], f_i = exp(-ln(10000) i / h), h = dim / 2; t int64 on the device */
+int eegldm_timestep_embedding(eegldm_ctx*, const int64_t* t, float* out, int B, int dim);
 
 /* ------------------------------------------------------------------ AutoencoderKL / PatchDiscriminator primitives
  * MONAI PatchDiscriminator layer `Convolution(.., norm=BATCH, act=LEAKYRELU(0.2))` (config/config_aekl_eeg.yaml:30-40; twin

@@ -153,8 +153,18 @@ SIGNATURES = {
     "eegldm_usleep_bind": [_vp, _vp, _vp],
     "eegldm_usleep_forward": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i],
     "eegldm_feature_moments": [_vp, _vp, _l, _i, _vp, _vp],
+    "eegldm_resblock_create": [_vp, _i, _i, _i, _i, _i, _i, C.POINTER(_vp)],
+    "eegldm_attnblock_create": [_vp, _i, _i, C.POINTER(_vp)],
+    "eegldm_block_destroy": [_vp],
+    "eegldm_block_num_entries": [_vp],
+    "eegldm_block_num_params": [_vp],
+    "eegldm_block_entry": [_vp, _i, C.c_char_p, _i, C.POINTER(_l), C.POINTER(_l), C.POINTER(_i), C.POINTER(_i)],
+    "eegldm_block_bind": [_vp, _vp, _vp],
+    "eegldm_block_forward": [_vp, _vp, _vp, _vp, _i, _i],
+    "eegldm_block_backward": [_vp, _vp, _vp, _vp],
+    "eegldm_timestep_embedding": [_vp, _vp, _vp, _i, _i],
 }
-for _n in ("eegldm_aekl_num_params", "eegldm_disc_num_params", "eegldm_disc_num_buffers", "eegldm_usleep_num_params", "eegldm_usleep_num_buffers"):
+for _n in ("eegldm_block_num_params", "eegldm_aekl_num_params", "eegldm_disc_num_params", "eegldm_disc_num_buffers", "eegldm_usleep_num_params", "eegldm_usleep_num_buffers"):
     if hasattr(lib, _n):
         getattr(lib, _n).restype = C.c_long
 

@@ -62,7 +62,7 @@ double* NetBase::qalloc(int B, int C) {
   // tensors against 26.8 us for the resident one-pass kernel (at this size launch + ramp + tail weigh as much as the second barrier round it
   // saves), while the statistics epilogue costs the producing conv +6 us per launch: 17.70 vs 17.65 ms per step.  Kept for the record.
   EEG_ENV_VAR(bool, off, getenv("EEGLDM_GN_QSTATS") == nullptr || atoi(getenv("EEGLDM_GN_QSTATS")) == 0 || getenv("EEGLDM_GN_NO_QSTATS") != nullptr);
-  if (off || !q_on || dtype == EEGLDM_F32 || eeg_deterministic() || C % 4 != 0) return nullptr;
+  if (off || !q_on || dtype != EEGLDM_BF16 || eeg_deterministic() || C % 4 != 0) return nullptr;      // (gn_apply_q_kernel unpacks bf16 only)
   const size_t n = (size_t)B * (C / 4) * 2;
   if (!qarena) {
     qcap = (size_t)8 << 20;          // 64 MB of doubles: the config_ldm UNet at B = 256 uses ~25 MB

@@ -26,6 +26,7 @@ struct SamplerState {
   // embedding rows of all timesteps of a run (eager path): table [emb_cap][etot], scratch of the embedding MLP, timesteps on the device
   float *emb_table = nullptr, *emb_work = nullptr; int64_t* steps_dev = nullptr; int emb_cap = 0;
   float* emb_row = nullptr;      // graph path: the ONE row the captured forward reads; the step's table row is copied here before every replay
+  bool exec_reads_row = false;   // how `exec` was captured: reading emb_row (table mode) or recomputing the embedding from s.tt -- a replay in the other mode would use a stale timestep
 };
 std::map<GraphKey, SamplerState>& states() { static std::map<GraphKey, SamplerState> m; return m; }
 // guards the map AND serialises eegldm_sample: a call swaps ctx->stream for its duration, so two concurrent calls on contexts that
@@ -109,6 +110,10 @@ extern "C" int eegldm_sample(eegldm_unet* u, eegldm_aekl* ae, const float* noise
       if (!s.emb_row) HIP_TRY(hipMalloc(&s.emb_row, sizeof(float) * (size_t)etot));
       unet_set_shared_emb(u, s.emb_row);
     }
+    if (s.exec && s.exec_reads_row != !no_table) {      // captured in the other embedding mode (the switch was flipped in-process): capture again
+      (void)hipGraphExecDestroy(s.exec); s.exec = nullptr;
+      if (s.graph) { (void)hipGraphDestroy(s.graph); s.graph = nullptr; }
+    }
     if (!s.exec) {
       // eager warm-up: grows the arena / workspaces (hipMalloc is not capturable), then capture the identical launch sequence
       set_t(timesteps_host[0]);
@@ -118,7 +123,7 @@ extern "C" int eegldm_sample(eegldm_unet* u, eegldm_aekl* ae, const float* noise
       if (hipStreamBeginCapture(run, hipStreamCaptureModeThreadLocal) == hipSuccess) {
         rc = eegldm_unet_forward(u, s.x, s.tt, s.out, B, L, 0);
         hipError_t e = hipStreamEndCapture(run, &s.graph);
-        if (rc == 0 && e == hipSuccess && s.graph && hipGraphInstantiate(&s.exec, s.graph, nullptr, nullptr, 0) == hipSuccess) graph_ok = true;
+        if (rc == 0 && e == hipSuccess && s.graph && hipGraphInstantiate(&s.exec, s.graph, nullptr, nullptr, 0) == hipSuccess) { graph_ok = true; s.exec_reads_row = !no_table; }
       }
       if (!graph_ok) {
         (void)hipGetLastError();

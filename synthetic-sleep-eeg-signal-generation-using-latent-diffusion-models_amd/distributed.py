@@ -68,23 +68,40 @@ def allreduce_sum_scalars(values, like=None):
 _AVG_OK = None      # ReduceOp.AVG usable on this backend build (probed once, collectively: every rank takes the same branch)
 
 
-def _mean_op(t):
-    """(reduce op, needs a separate 1/world pass).  RCCL has the mean as a collective (ncclAvg = ReduceOp.AVG): no extra read + write of
-    the 122 MB gradient buffer per step; gloo (the CPU tests, ranks sharing one GPU) only sums.  The first call probes AVG with a
-    one-element all-reduce -- this path has never run with more than one rank for the builder, so an unsupported-op error must cost a
-    fallback to SUM + scale, not the run."""
+def probe_mean_op(like=None):
+    """Decide ONCE, at set-up time and collectively, whether the gradient mean runs as ReduceOp.AVG (RCCL's ncclAvg: no extra read + write
+    of the 122 MB gradient buffer per step) or as SUM + one 1/world pass (gloo; an RCCL build without AVG; EEGLDM_NO_NCCL_AVG set).
+
+    Called from OverlappedGradSync.__init__ / the first allreduce_mean_flat -- i.e. OUTSIDE the native backward's gradient hook, where a
+    blocking all-reduce plus a host read would sit in the middle of the backward.  Every rank contributes its own verdict (its
+    environment override included) to a MIN all-reduce, so a switch set on only some ranks can no longer mix AVG and SUM on one buffer."""
     global _AVG_OK
-    if dist.get_backend() == "nccl" and t.is_cuda and os.environ.get("EEGLDM_NO_NCCL_AVG") is None:
-        if _AVG_OK is None:
-            try:
-                probe = torch.full((1,), 3.0, device=t.device)
-                dist.all_reduce(probe, op=dist.ReduceOp.AVG)
-                _AVG_OK = abs(float(probe) - 3.0) < 1e-6
-            except Exception as e:      # noqa: BLE001
-                print(f"[eegldm] ReduceOp.AVG unavailable ({e}); gradient mean as SUM + scale", flush=True)
-                _AVG_OK = False
-        if _AVG_OK:
-            return dist.ReduceOp.AVG, False
+    if _AVG_OK is not None or not dist.is_initialized() or dist.get_world_size() == 1:
+        return bool(_AVG_OK)
+    dev = _comm_device(like)      # nccl: the rank's GPU; gloo: the CPU
+    mine = 0
+    if dist.get_backend() == "nccl" and dev.type == "cuda":
+        mine = 0 if os.environ.get("EEGLDM_NO_NCCL_AVG") is not None else 1
+        try:      # every nccl rank runs the probe collective, whatever its override says: the call sequence is the same on all ranks
+            probe = torch.full((1,), 3.0, device=dev)
+            dist.all_reduce(probe, op=dist.ReduceOp.AVG)
+            if abs(float(probe) - 3.0) >= 1e-6:
+                mine = 0
+        except Exception as e:      # noqa: BLE001
+            print(f"[eegldm] ReduceOp.AVG unavailable ({e}); gradient mean as SUM + scale", flush=True)
+            mine = 0
+    flag = torch.tensor([mine], dtype=torch.int32, device=dev)
+    dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+    _AVG_OK = bool(int(flag.item()))
+    return _AVG_OK
+
+
+def _mean_op(t):
+    """(reduce op, needs a separate 1/world pass) -- the verdict of probe_mean_op (made at set-up; probed here only if nobody did)."""
+    if _AVG_OK is None:
+        probe_mean_op(t)
+    if _AVG_OK and t.is_cuda and dist.get_backend() == "nccl":
+        return dist.ReduceOp.AVG, False
     return dist.ReduceOp.SUM, True
 
 
@@ -131,9 +148,19 @@ class NativeComm:
     def from_process_group(cls, ctx):
         """One id made by rank 0 and handed round through the initialised torch.distributed group (any backend)."""
         rank, world = (dist.get_rank(), dist.get_world_size()) if dist.is_initialized() else (0, 1)
-        box = [cls.unique_id() if rank == 0 else None]
+        # rank 0 may fail to make the id (librccl / EEGLDM_RCCL_LIB not loadable): it still takes part in the broadcast, with the error as the
+        # payload, so that every rank leaves this function the same way (an exception that make_comm turns into a collective fallback)
+        # instead of rank 0 moving on to the next collective while the others wait in this one
+        box = [None]
+        if rank == 0:
+            try:
+                box = [cls.unique_id()]
+            except Exception as e:      # noqa: BLE001
+                box = [("error", str(e))]
         if world > 1:
             dist.broadcast_object_list(box, src=0)
+        if not isinstance(box[0], (bytes, bytearray)):
+            raise RuntimeError(f"rank 0 could not create the RCCL unique id: {box[0][1] if box[0] else 'no id'}")
         return cls(ctx, rank, world, box[0])
 
     def _chk(self, t):
@@ -210,6 +237,8 @@ class OverlappedGradSync:
         self.works = []
         self.done = []          # (start, end) ranges already launched
         self._post_scale = True
+        if comm is None:        # AVG-or-SUM is agreed on here, once and by all ranks -- not inside the backward's gradient hook
+            probe_mean_op(flat_grad)
 
     @property
     def active(self):

@@ -53,6 +53,11 @@ def main(args):
         ae_args["num_channels"] = args.num_channels
     if args.latent_channels is not None:
         ae_args["latent_channels"] = args.latent_channels
+    if str(args.dtype) in ("float16", "fp16", "half"):
+        # The reference runs this loop in fp32 without autocast (train_autoencoderkl.py:200-234; the GradScaler variant in
+        # training/training.py:52-207 is commented out) and the fused native step has no loss-scale argument: fp16 activation
+        # gradients would under- / overflow unguarded.  bfloat16 (fp32's exponent range) is the 16-bit mode of this entry point.
+        raise ValueError("--dtype float16 is not supported by train_autoencoderkl (no loss scaling in the AEKL / GAN step): use bfloat16 or float32")
     model = AutoencoderKL(**ae_args, dtype=args.dtype, device=local)
     disc = PatchDiscriminator(**dict(config.patchdiscriminator.params), dtype=args.dtype, device=local)
     opt_g, opt_d = Adam(model, lr=config.models.optimizer_g_lr), Adam(disc, lr=config.models.optimizer_d_lr)

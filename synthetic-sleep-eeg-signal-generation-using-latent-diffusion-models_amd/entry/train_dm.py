@@ -12,7 +12,7 @@ import torch
 from .. import distributed as D
 from ..models import UNetModel
 from ..schedulers import DDPMScheduler
-from ..training import Adam, dm_train_step, randint, randn
+from ..training import Adam, GradScaler, dm_train_step, randint, randn
 from .common import WindowLoader, load_config, rng_seed, setup_run_dir
 
 
@@ -24,6 +24,7 @@ def parse_args(argv=None):
     p.add_argument("--spe", default="no-spectral"); p.add_argument("--type_dataset", default="edfx"); p.add_argument("--dataset", default="edfx")
     p.add_argument("--synthetic_windows", type=int, default=0); p.add_argument("--dtype", default="float32")
     p.add_argument("--max_steps", type=int, default=0); p.add_argument("--output_dir", default=None)
+    p.add_argument("--grad_scaler", action="store_true", help="dynamic loss scaling as training_diffusion.py:37 does (always on with --dtype float16)")
     p.add_argument("--deterministic", action="store_true", help="bit-reproducible steps (eegldm.set_deterministic(): ordered reductions instead of fp32 atomics; "
                    "what torch.use_deterministic_algorithms(True) would be for the reference's loop)")
     return p.parse_args(argv)
@@ -44,6 +45,8 @@ def main(args):
     D.broadcast_flat(unet.flat); unet.sync_weights()
     sched = DDPMScheduler(num_train_timesteps=1000, schedule="linear_beta", beta_start=0.0015, beta_end=0.0195, device=local)
     opt = Adam(unet, lr=1e-4)
+    # training_diffusion.py:37,149-151 pairs its fp16 autocast with a GradScaler: fp16 activation gradients under- / overflow without the loss scale
+    scaler = GradScaler(enabled=args.grad_scaler or str(args.dtype) in ("float16", "fp16", "half"))
     spectral = args.spe == "spectral"
     bs = max(1, config.train.batch_size // world)
     train = WindowLoader(args.path_pre_processed, bs, args.synthetic_windows, seed=rng_seed(config.train.seed, 8, rank, world), drop_last=config.train.drop_last,
@@ -56,6 +59,8 @@ def main(args):
     if resume:      # continue from {run_dir}/checkpoint.pth
         ck = torch.load(os.path.join(run_dir, "checkpoint.pth"), map_location="cpu")
         unet.load_state_dict(ck["diffusion"]); opt.load_state_dict(ck["optimizer"])
+        if "scaler" in ck:
+            scaler.load_state_dict(ck["scaler"])
         start_epoch, best, gstep = int(ck["epoch"]), float(ck["best_loss"]), int(ck.get("steps", 0))
         if rank == 0:
             print(f"Resuming from epoch {start_epoch} (best loss {best:.5f})")
@@ -67,9 +72,10 @@ def main(args):
             t = randint(ctx, B, sched.num_train_timesteps, seed=s_t, offset=gstep * B)
             noise = randn(ctx, tuple(x.shape), seed=s_noise, offset=gstep * x.numel())
             opt.zero_grad()
-            dm_train_step(unet, sched, x, noise, t, spectral_weight=1e-6, spectral_loss=spectral, loss_out=loss, grad_sync=gsync)
+            dm_train_step(unet, sched, x, noise, t, spectral_weight=1e-6, spectral_loss=spectral, loss_out=loss, grad_sync=gsync,
+                          grad_scale=scaler.get_scale())
             gsync.wait()
-            opt.step()
+            scaler.step(opt); scaler.update()
             steps += 1; gstep += 1; seen += B * world
             if args.max_steps and steps >= args.max_steps:
                 break
@@ -80,7 +86,7 @@ def main(args):
                 best = cur
                 torch.save({k: v.cpu() for k, v in unet.state_dict().items()}, os.path.join(run_dir, "best_model.pth"))
             torch.save({"epoch": epoch + 1, "diffusion": {k: v.cpu() for k, v in unet.state_dict().items()}, "optimizer": opt.state_dict(),
-                        "best_loss": best, "steps": gstep}, os.path.join(run_dir, "checkpoint.pth"))
+                        "best_loss": best, "steps": gstep, "scaler": scaler.state_dict()}, os.path.join(run_dir, "checkpoint.pth"))
         if args.max_steps and steps >= args.max_steps:
             break
     if rank == 0:

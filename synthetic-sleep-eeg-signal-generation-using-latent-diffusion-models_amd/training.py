@@ -210,11 +210,13 @@ def ldm_train_step(unet, scheduler, latents, noise, timesteps, loss_out=None, gr
     return loss_out
 
 
-def dm_train_step(unet, scheduler, images, noise, timesteps, spectral_weight=0.0, spectral_loss=False, loss_out=None, grad_sync=None):
+def dm_train_step(unet, scheduler, images, noise, timesteps, spectral_weight=0.0, spectral_loss=False, loss_out=None, grad_sync=None, grad_scale=1.0):
     """Pixel-space diffusion step of /root/reference/src/training/training_diffusion.py:141-151 (config_dm.yaml, BASELINE C5):
     epsilon prediction directly on the (B,1,3072) windows, loss = mse(noise_pred, noise) [+ spectral_weight *
     JukeboxLoss(sum)(noise_pred, noise)].  Composed from the same native calls as the latent step: add_noise, UNet forward,
-    MSE (writes d pred), spectral loss (accumulates its gradient into d pred), hand-written backward.  Returns the loss tensor."""
+    MSE (writes d pred), spectral loss (accumulates its gradient into d pred), hand-written backward.  Returns the loss tensor.
+    grad_scale: the GradScaler's loss scale (training_diffusion.py:37,149-151 -- `scaler.scale(loss).backward()`): it multiplies d pred, i.e.
+    every gradient of the backward; the reported loss stays unscaled and the optimizer step divides the scale out again (GradScaler.step)."""
     dev = unet.device
     if loss_out is None:
         loss_out = torch.zeros(1, device=dev)
@@ -224,10 +226,10 @@ def dm_train_step(unet, scheduler, images, noise, timesteps, spectral_weight=0.0
     noisy = scheduler.add_noise(original_samples=x, noise=nz, timesteps=timesteps)
     pred = unet(noisy, timesteps=timesteps)
     dpred = torch.empty_like(pred)
-    check(lib.eegldm_mse_loss(unet.ctx.h, ptr(pred), ptr(nz), ptr(loss_out), ptr(dpred), pred.numel(), 1.0))
+    check(lib.eegldm_mse_loss(unet.ctx.h, ptr(pred), ptr(nz), ptr(loss_out), ptr(dpred), pred.numel(), float(grad_scale)))
     if spectral_loss:
         spec = torch.zeros(1, device=dev)
-        check(lib.eegldm_spectral_loss(unet.ctx.h, ptr(pred), ptr(nz), ptr(spec), ptr(dpred), B, Cc, L, float(spectral_weight)))
+        check(lib.eegldm_spectral_loss(unet.ctx.h, ptr(pred), ptr(nz), ptr(spec), ptr(dpred), B, Cc, L, float(spectral_weight) * float(grad_scale)))
         loss_out.add_(spec, alpha=float(spectral_weight))
     if grad_sync is not None:
         grad_sync.begin()
