@@ -22,7 +22,7 @@ import re
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-RND = os.environ.get("EEGLDM_PROFILE_ROUND", "r05")        # prefix of the files written under profiles/
+RND = os.environ.get("EEGLDM_PROFILE_ROUND", "r06")        # prefix of the files written under profiles/
 GEMM = {("1", "0", "3"): "conv3_fwd_implicit_gemm", ("1", "1", "3"): "conv3_dgrad_implicit_gemm", ("2", "1", "3"): "conv_wgrad_splitk_gemm",
         ("0", "0", "1"): "gemm_nt", ("0", "1", "1"): "gemm_nn", ("2", "1", "1"): "gemm_tn"}
 
@@ -138,8 +138,14 @@ def main(prof, tag):
     corr = "FETCH_SIZE x2 (gfx950: 128-byte requests tallied at 64 B), units of 1024 B; WRITE_SIZE as reported (uncalibrated)"
     fam, _tf, _tw = per_family(os.path.join(prof, "pmc_ldm_FETCH_SIZE"), os.path.join(prof, "pmc_ldm_WRITE_SIZE"))
     if fam:
+        # whole-step traffic: every kernel of the run except the model set-up (state-dict copies, torch's init fills), divided by the number of
+        # steps the run made (= Adam launches: one per step)
+        n_steps = max(1, fam.get("adam", {}).get("launches_sampled", 1))
+        setup = ("__amd_rocclr_copyBuffer", "vectorized_elementwise", "__amd_rocclr_fillBufferAligned")
+        step_bytes = sum(v["hbm_bytes_per_launch"] * v["launches_sampled"] for k, v in fam.items() if k not in setup) / n_steps
         json.dump({"source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes, --kernel-trace), tools/debug/quick_bench.py bfloat16 256 768 2 "
                              "(LDM train step B=256 bf16), EEGLDM_NO_SIDE_STREAM=1", "corrections": corr, "kernel_source_sha16": sha,
+                   "steps_sampled": n_steps, "hbm_bytes_per_step": round(step_bytes),
                    "classes": {k: v for k, v in fam.items() if k in GEMM.values()},
                    "hbm_bound_families": {k: v for k, v in sorted(fam.items(), key=lambda kv: -kv[1]["hbm_bytes_per_launch"] * kv[1]["launches_sampled"])
                                           if k not in GEMM.values() and v["launches_sampled"] >= 2}},
