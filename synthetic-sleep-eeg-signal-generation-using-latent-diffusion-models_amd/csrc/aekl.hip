@@ -21,6 +21,14 @@ int ls_bn_lrelu_fwd(eegldm_ctx*, const void* x, long ldx, const float* gamma, co
 int ls_bn_lrelu_bwd(eegldm_ctx*, const void* x, long ldx, const float* gamma, const float* beta, const float* stats, const void* dy, long lddy,
                     void* dx, long lddx, float* dgamma, float* dbeta, long rows, int C, float slope, int dtype);
 int ls_bn_repeat_running(eegldm_ctx*, const float* stats, float* rmean, float* rvar, float* nbt, long rows, int C);
+int ls_bn_stats(eegldm_ctx*, const void* x, long ldx, float* stats, float* rmean, float* rvar, float* nbt, long rows, int C, int training, int dtype);
+int ls_bn_apply(eegldm_ctx*, const void* x, long ldx, const float* gamma, const float* beta, const float* stats, void* y, long ldy, long rows, int C, float slope, int dtype);
+// fused tail of the discriminator (disc_tail.hip): BatchNorm + LeakyReLU of the last hidden layer + the one-channel final conv, forward and backward
+bool disc_tail_ok(int dtype, int C, long ldy);
+int disc_tail_fwd(eegldm_ctx*, int dtype, const void* y, long ldy, const float* gamma, const float* beta, const float* stats, const float* w3,
+                  const float* bias, float slope, float* logits, int B, int L, int C);
+int disc_tail_bwd(eegldm_ctx*, int dtype, const void* y, long ldy, const float* gamma, const float* beta, const float* stats, const float* w3,
+                  float slope, const float* dlogits, void* dy, long lddy, float* dgamma, float* dbeta, float* dw3, float* dbias, int B, int L, int C);
 int ls_upsample2(eegldm_ctx*, const void* x, long ldx, void* y, long ldy, long rows_in, int C, int dtype);
 int ls_upsample2_bwd(eegldm_ctx*, const void* dy, long lddy, void* dx, long lddx, long rows_in, int C, int dtype);
 int ls_reparam(eegldm_ctx*, const void* mu, const void* lv, const float* eps, void* z, float* sigma, float* kl, long n, int B, int dtype);
@@ -613,7 +621,22 @@ struct eegldm_disc : SeqNet {
   std::vector<OpTape> tape;
   std::vector<Entry> buf_entries; long nbuffers = 0;
   int B = 0, L = 0, Lo = 0; bool have_tape = false;
+  // Fused tail (disc_tail.hip): the last hidden layer's BatchNorm + LeakyReLU and the one-channel final conv run as one pass over the last
+  // hidden conv's output y (forward) / two passes (backward); `ops` minus those two = `head`, whose tape is `tape`; the tail keeps (y, statistics).
+  std::vector<Op> head;
+  bool tail_on = false; View tail_y; float* tail_st = nullptr;
+  size_t tape_ops() const { return ops.size() - (tail_on ? 2 : 0); }
 };
+namespace {
+bool disc_tail_eligible(const eegldm_disc* d) {
+  EEG_ENV_VAR(bool, off, getenv("EEGLDM_DISC_NO_FUSED_TAIL") != nullptr);
+  const size_t n = d->ops.size();
+  if (off || eeg_deterministic() || n < 4) return false;      // (deterministic mode: the tail's per-channel sums meet in fp64 LDS atomics, its parameter gradients in fp32 atomics)
+  const Op& act = d->ops[n - 2]; const Op& fin = d->ops[n - 1]; const Op& hc = d->ops[n - 3];
+  return hc.kind == OP_CONV && act.kind == OP_ACT && act.bn_w >= 0 && fin.kind == OP_CONV && fin.cout == 1 && fin.k == 3 && fin.stride == 1 &&
+         fin.pl == 1 && fin.pr == 1 && fin.cin == hc.cout && disc_tail_ok(d->dtype, fin.cin, fin.cin);
+}
+}  // namespace
 
 extern "C" int eegldm_disc_create(eegldm_ctx* ctx, const eegldm_disc_cfg* cfg, eegldm_disc** out) {
   EEG_CHECK(ctx && cfg && out, "null argument");
@@ -642,6 +665,7 @@ extern "C" int eegldm_disc_create(eegldm_ctx* ctx, const eegldm_disc_cfg* cfg, e
   }
   d->ops.push_back(make_conv(d, lay, "final_conv.conv", ic, cfg->out_channels, 3, 1, 1, 1, true));
   d->nparams = lay.off; d->nbuffers = blay.off;
+  d->head.assign(d->ops.begin(), d->ops.end() - 2);
   *out = d;
   return 0;
 }
@@ -674,6 +698,20 @@ extern "C" int eegldm_disc_forward(eegldm_disc* d, const float* x, float* logits
   View x0; ALLOC_OR_FAIL(x0.p, d->alloc_act((long)B * L, cin)); x0.ld = cin; x0.C = cin;
   EEG_TRY(eegldm_ncl_to_nlc(d->ctx, x, x0.p, cin, B, cin, L, d->dtype));
   int Lc = L; View y;
+  d->tail_on = disc_tail_eligible(d);
+  if (d->tail_on) {
+    const Op& act = d->ops[d->ops.size() - 2]; const Op& fin = d->ops.back();
+    EEG_TRY(d->forward_seq(d->head, x0, B, Lc, &y, d->tape, training));
+    const int C = y.C;
+    ALLOC_OR_FAIL(d->tail_st, (float*)d->arena.alloc(sizeof(float) * 2 * C));
+    const bool upd = d->buffers && training != 2;      // as SeqNet::forward_seq: training == 2 leaves the running statistics alone
+    EEG_TRY(ls_bn_stats(d->ctx, y.p, y.ld, d->tail_st, upd ? d->buffers + act.rm : nullptr, upd ? d->buffers + act.rv : nullptr,
+                        upd ? d->buffers + act.nbt : nullptr, (long)B * Lc, C, training, d->dtype));
+    d->tail_y = y;
+    d->B = B; d->L = L; d->Lo = Lc; d->have_tape = true;      // (the final conv keeps the length: k = 3, stride 1, padding 1)
+    return disc_tail_fwd(d->ctx, d->dtype, y.p, y.ld, d->P(act.bn_w), d->P(act.bn_b), d->tail_st, d->P(fin.w), fin.b >= 0 ? d->P(fin.b) : nullptr,
+                         act.slope, logits, B, Lc, C);
+  }
   EEG_TRY(d->forward_seq(d->ops, x0, B, Lc, &y, d->tape, training));
   d->B = B; d->L = L; d->Lo = Lc; d->have_tape = true;
   return eegldm_nlc_to_ncl(d->ctx, y.p, y.ld, logits, B, d->cfg.out_channels, Lc, d->dtype);
@@ -683,11 +721,22 @@ extern "C" int eegldm_disc_forward(eegldm_disc* d, const float* x, float* logits
 // are the activation ops' outputs, which the tape of the most recent forward still holds: feature `index` (0 .. num_layers_d) is
 // copied out as fp32 (B, C, L); out == NULL only reports the shape.  The last entry of the list is the logits eegldm_disc_forward wrote.
 extern "C" int eegldm_disc_feature(eegldm_disc* d, int index, float* out, int* C, int* L) {
-  EEG_CHECK(d && d->have_tape && d->tape.size() == d->ops.size(), "call eegldm_disc_forward first");
+  EEG_CHECK(d && d->have_tape && d->tape.size() == d->tape_ops(), "call eegldm_disc_forward first");
   int seen = -1;
   for (size_t i = 0; i + 1 < d->ops.size(); i++) {
     if (d->ops[i].kind != OP_ACT) continue;
     if (++seen != index) continue;
+    if (d->tail_on && i == d->ops.size() - 2) {      // the fused tail never stores this activation: apply the layer's BatchNorm + LeakyReLU to its input now
+      const Op& act = d->ops[i]; const int Cc = d->tail_y.C;
+      if (C) *C = Cc;
+      if (L) *L = d->Lo;
+      if (out) {
+        void* a; ALLOC_OR_FAIL(a, d->alloc_act((long)d->B * d->Lo, Cc));
+        EEG_TRY(ls_bn_apply(d->ctx, d->tail_y.p, d->tail_y.ld, d->P(act.bn_w), d->P(act.bn_b), d->tail_st, a, Cc, (long)d->B * d->Lo, Cc, act.slope, d->dtype));
+        EEG_TRY(eegldm_nlc_to_ncl(d->ctx, a, Cc, out, d->B, Cc, d->Lo, d->dtype));
+      }
+      return 0;
+    }
     const OpTape& nx = d->tape[i + 1];                    // the next op's input IS this activation's output
     if (C) *C = nx.x.C;
     if (L) *L = nx.Lin;
@@ -705,12 +754,23 @@ static int disc_backward_impl(eegldm_disc* d, const float* dlogits, float* dx, i
   EEG_CHECK(!param_grads || d->grads, "no gradient buffer bound");
   d->have_tape = keep_tape;
   const int co = d->cfg.out_channels, B = d->B;
-  View dy; ALLOC_OR_FAIL(dy.p, d->alloc_act((long)B * d->Lo, co)); dy.ld = co; dy.C = co;
-  EEG_TRY(eegldm_ncl_to_nlc(d->ctx, dlogits, dy.p, co, B, co, d->Lo, d->dtype));
-  d->param_grads = param_grads != 0;
-  View dx0;
   EEG_CHECK(!keep_tape || d->rt.empty(), "tape reuse is for ResBlock-free stacks");
-  int rc = d->backward_seq(d->ops, d->tape, B, dy, &dx0, dx != nullptr, keep_tape);
+  View dx0; int rc;
+  if (d->tail_on) {
+    // gradient of the last hidden conv's output straight from the fp32 logit gradients (the final conv's data gradient is recomputed inside)
+    const Op& act = d->ops[d->ops.size() - 2]; const Op& fin = d->ops.back(); const int C = d->tail_y.C; const bool pg = param_grads != 0;
+    View dy; ALLOC_OR_FAIL(dy.p, d->alloc_act((long)B * d->Lo, C)); dy.ld = C; dy.C = C;
+    EEG_TRY(disc_tail_bwd(d->ctx, d->dtype, d->tail_y.p, d->tail_y.ld, d->P(act.bn_w), d->P(act.bn_b), d->tail_st, d->P(fin.w), act.slope, dlogits,
+                          dy.p, C, pg ? d->G(act.bn_w) : nullptr, pg ? d->G(act.bn_b) : nullptr, pg ? d->G(fin.w) : nullptr,
+                          pg && fin.b >= 0 ? d->G(fin.b) : nullptr, B, d->Lo, C));
+    d->param_grads = pg;
+    rc = d->backward_seq(d->head, d->tape, B, dy, &dx0, dx != nullptr, keep_tape);
+  } else {
+    View dy; ALLOC_OR_FAIL(dy.p, d->alloc_act((long)B * d->Lo, co)); dy.ld = co; dy.C = co;
+    EEG_TRY(eegldm_ncl_to_nlc(d->ctx, dlogits, dy.p, co, B, co, d->Lo, d->dtype));
+    d->param_grads = param_grads != 0;
+    rc = d->backward_seq(d->ops, d->tape, B, dy, &dx0, dx != nullptr, keep_tape);
+  }
   d->param_grads = true;
   EEG_TRY(rc);
   if (dx) EEG_TRY(eegldm_nlc_to_ncl(d->ctx, dx0.p, dx0.ld, dx, B, d->cfg.in_channels, d->L, d->dtype));
@@ -719,10 +779,14 @@ static int disc_backward_impl(eegldm_disc* d, const float* dlogits, float* dx, i
 
 // second running-statistics update of every BatchNorm layer with the batch statistics of the forward whose tape is still held
 static int disc_repeat_running(eegldm_disc* d) {
-  EEG_CHECK(d->have_tape && d->tape.size() == d->ops.size() && d->buffers, "no forward tape to repeat the BatchNorm update from");
+  EEG_CHECK(d->have_tape && d->tape.size() == d->tape_ops() && d->buffers, "no forward tape to repeat the BatchNorm update from");
   for (size_t i = 0; i < d->ops.size(); i++) {
     const Op& o = d->ops[i];
     if (o.kind != OP_ACT || o.bn_w < 0) continue;
+    if (d->tail_on && i == d->ops.size() - 2) {      // the fused tail's layer: its statistics live beside the tape
+      EEG_TRY(ls_bn_repeat_running(d->ctx, d->tail_st, d->buffers + o.rm, d->buffers + o.rv, d->buffers + o.nbt, (long)d->B * d->Lo, d->tail_y.C));
+      continue;
+    }
     const OpTape& t = d->tape[i];
     EEG_TRY(ls_bn_repeat_running(d->ctx, t.st, d->buffers + o.rm, d->buffers + o.rv, d->buffers + o.nbt, (long)d->B * t.Lin, t.x.C));
   }

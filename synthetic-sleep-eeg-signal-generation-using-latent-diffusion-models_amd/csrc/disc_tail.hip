@@ -1,0 +1,303 @@
+// Fused tail of the PatchDiscriminator: BatchNorm1d + LeakyReLU of the last hidden layer and the final 3-tap conv to ONE logit channel
+// (MONAI PatchDiscriminator: `Convolution(.., norm=BATCH, act=LEAKYRELU(0.2))` x num_layers_d, then `final_conv` with out_channels = 1;
+//  config/config_aekl_eeg.yaml:30-40; twin /root/reference/src/models/discriminator.py:47-84; step body train_autoencoderkl.py:213-228).
+//
+// Layer-by-layer the tail of one forward + backward moved, per B = 256 pass over y = conv3's output (98 MB in bf16):
+//   forward   apply (read y, write a)                 + final conv (read a)                                            = 3 |y|
+//   backward  final dgrad (write da) + final wgrad (read a, da) + BatchNorm reduce (read y, da) + apply (read y, da, write dy) = 9 |y|
+// The final conv has ONE output channel, so its data gradient is a rank-3 outer product that costs nothing to recompute,
+//   da[b, l, c] = dl[b, l + 1] w0[c] + dl[b, l] w1[c] + dl[b, l - 1] w2[c]        (dl = gradient of the logits, zero outside the sample)
+// and its forward / weight gradient are per-row dot products / per-channel sums that fit in the passes BatchNorm makes anyway:
+//   forward   logits[b, l] = bias + sum_t sum_c w_t[c] a[b, l + t - 1, c],   a = lrelu(gamma (y - mean) rstd + beta)     reads y          = 1 |y|
+//   backward  reduce: S1 = sum dz, S2 = sum dz xhat, dW_t[c] = sum_rows a[row, c] dl[row - t + 1], dbias = sum dl        reads y          = 1 |y|
+//             apply:  dy = gamma rstd (dz - S1 / N - xhat S2 / N),   dz = lrelu'(z) da                                  reads y, writes dy = 2 |y|
+// `a` and `da` never exist.  One wave covers whole rows (G lanes per row, 16 bytes per lane and chunk); per-row dot products are reduced
+// with DPP adds inside 16 lanes and two cross-row shuffles; per-channel sums are kept in registers over the rows a wave walks.
+#include "common.h"
+#include "internal.h"
+
+int ls_bn_fold(eegldm_ctx* ctx, const void* parts, int nb, int nvals, double** sums_out);      // losses.hip
+
+namespace {
+constexpr int NT = 256;
+constexpr int MAXR = 128;      // output rows per block of the forward kernel (+ 2 halo rows)
+
+template <typename T> struct Ch { static constexpr int E = 8; };
+template <> struct Ch<float> { static constexpr int E = 4; };
+
+template <typename T> __device__ __forceinline__ void unpack16(const uint4& v, float* o) {
+  if constexpr (sizeof(T) == 4) { o[0] = __uint_as_float(v.x); o[1] = __uint_as_float(v.y); o[2] = __uint_as_float(v.z); o[3] = __uint_as_float(v.w); }
+  else {
+    o[0] = w16_lo<T>(v.x); o[1] = w16_hi<T>(v.x); o[2] = w16_lo<T>(v.y); o[3] = w16_hi<T>(v.y);
+    o[4] = w16_lo<T>(v.z); o[5] = w16_hi<T>(v.z); o[6] = w16_lo<T>(v.w); o[7] = w16_hi<T>(v.w);
+  }
+}
+template <typename T> __device__ __forceinline__ uint4 pack16(const float* o) {
+  uint4 v;
+  if constexpr (sizeof(T) == 4) { v.x = __float_as_uint(o[0]); v.y = __float_as_uint(o[1]); v.z = __float_as_uint(o[2]); v.w = __float_as_uint(o[3]); }
+  else { v.x = pack16x2<T>(o[0], o[1]); v.y = pack16x2<T>(o[2], o[3]); v.z = pack16x2<T>(o[4], o[5]); v.w = pack16x2<T>(o[6], o[7]); }
+  return v;
+}
+// sum over the G lanes (G a power of two, 4 .. 64) that share a row; every lane of the group ends up with the total
+template <int G> __device__ __forceinline__ float group_sum(float v) {
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, true));      // quad_perm [1,0,3,2]
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xF, 0xF, true));      // quad_perm [2,3,0,1]
+  if constexpr (G >= 8) v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x141, 0xF, 0xF, true));   // row_half_mirror
+  if constexpr (G >= 16) v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x140, 0xF, 0xF, true));  // row_mirror
+  if constexpr (G >= 32) v += __shfl_xor(v, 16, 64);
+  if constexpr (G >= 64) v += __shfl_xor(v, 32, 64);
+  return v;
+}
+
+struct TailArgs {
+  const void* y; long ldy;
+  const float* gamma; const float* beta; const float* stats;      // BatchNorm: [C], [C], [C][2] = (mean, rstd)
+  const float* w; const float* bias;                              // final conv, fp32 master weights [3][C]; bias [1] or null
+  float slope;
+  int B, L, C;
+};
+
+// per-lane constants of one 16-byte chunk (E channels starting at c0)
+template <int E> struct ChunkK { float sc[E], sh[E], w0[E], w1[E], w2[E]; };
+template <int E> __device__ __forceinline__ void load_k(const TailArgs& p, int c0, ChunkK<E>& k) {
+#pragma unroll
+  for (int e = 0; e < E; e++) {
+    const int c = c0 + e;
+    const float mean = p.stats[2 * c], rstd = p.stats[2 * c + 1];
+    k.sc[e] = p.gamma[c] * rstd; k.sh[e] = p.beta[c] - mean * k.sc[e];
+    k.w0[e] = p.w[c]; k.w1[e] = p.w[p.C + c]; k.w2[e] = p.w[2 * p.C + c];
+  }
+}
+
+// ---------------------------------------------------------------- forward: logits (fp32, [B][L]) from y
+// block = RBLK output rows of one sample; the RBLK + 2 rows l0 - 1 .. l0 + RBLK each give three partial logits p_t = <w_t, a[row]>, which
+// land in LDS; logits[l] = bias + p_0[l - 1] + p_1[l] + p_2[l + 1]
+template <typename T, int G, int NJ>
+__global__ __launch_bounds__(NT) void tail_fwd_kernel(const TailArgs p, float* __restrict__ logits, int RBLK) {
+  constexpr int E = Ch<T>::E, RPW = 64 / G;
+  __shared__ float ps[MAXR + 2][3];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane % G, rg = lane / G;
+  const int b = blockIdx.y, l0 = blockIdx.x * RBLK, nrow = min(RBLK, p.L - l0) + 2;
+  ChunkK<E> k[NJ];
+#pragma unroll
+  for (int j = 0; j < NJ; j++) load_k<E>(p, (g + G * j) * E, k[j]);
+  const char* yb = (const char*)p.y + (size_t)b * p.L * p.ldy * sizeof(T);
+  for (int rb = wave * RPW; rb < nrow; rb += 4 * RPW) {
+    const int r = rb + rg, l = l0 - 1 + r;
+    const bool ok = r < nrow && l >= 0 && l < p.L;
+    float p0 = 0.f, p1 = 0.f, p2 = 0.f;
+    if (ok) {
+#pragma unroll
+      for (int j = 0; j < NJ; j++) {
+        const uint4 v = *(const uint4*)(yb + ((size_t)l * p.ldy + (g + G * j) * E) * sizeof(T));
+        float x[E]; unpack16<T>(v, x);
+#pragma unroll
+        for (int e = 0; e < E; e++) {
+          const float z = x[e] * k[j].sc[e] + k[j].sh[e];
+          const float a = z > 0.f ? z : p.slope * z;
+          p0 = fmaf(a, k[j].w0[e], p0); p1 = fmaf(a, k[j].w1[e], p1); p2 = fmaf(a, k[j].w2[e], p2);
+        }
+      }
+    }
+    p0 = group_sum<G>(p0); p1 = group_sum<G>(p1); p2 = group_sum<G>(p2);
+    if (g == 0 && r < nrow) { ps[r][0] = p0; ps[r][1] = p1; ps[r][2] = p2; }
+  }
+  __syncthreads();
+  const float bias = p.bias ? p.bias[0] : 0.f;
+  for (int i = tid; i < nrow - 2; i += NT)      // output row l0 + i = LDS row i + 1: tap t reads a[l + t - 1] = LDS row i + t
+    logits[(size_t)b * p.L + l0 + i] = bias + ps[i][0] + ps[i + 1][1] + ps[i + 2][2];
+}
+
+// ---------------------------------------------------------------- backward, shared per-row arithmetic
+struct RowDl { float dn, d0, dp; };      // dl[l + 1], dl[l], dl[l - 1] of this row (zero outside the sample)
+__device__ __forceinline__ RowDl load_dl(const float* __restrict__ dl, long row, int l, int L) {      // l = row % L (kept by the caller: no division per row)
+  RowDl r; r.d0 = dl[row]; r.dn = l + 1 < L ? dl[row + 1] : 0.f; r.dp = l > 0 ? dl[row - 1] : 0.f;
+  return r;
+}
+
+// sums layout (planar): S1 [0, C), S2 [C, 2C), dW0 [2C, 3C), dW1 [3C, 4C), dW2 [4C, 5C), dbias [5C]
+template <typename T, int G, int NJ, bool PG>
+__global__ __launch_bounds__(NT) void tail_bwd_reduce_kernel(const TailArgs p, const float* __restrict__ dl, float* __restrict__ parts, long rows_per_block) {
+  constexpr int E = Ch<T>::E, RPW = 64 / G, NV = PG ? 5 : 2;
+  extern __shared__ double red[];      // [5 C + 1] (fp64 LDS atomics: order-independent)
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane % G, rg = lane / G;
+  const int nvals = 5 * p.C + 1;
+  for (int i = tid; i < nvals; i += NT) red[i] = 0.0;
+  __syncthreads();
+  const long rows = (long)p.B * p.L, r0 = (long)blockIdx.x * rows_per_block, r1 = min(rows, r0 + rows_per_block);
+  float sc[NJ][E], sh[NJ][E], mean[NJ][E], rstd[NJ][E], w0[NJ][E], w1[NJ][E], w2[NJ][E];
+  float acc[NJ][E][NV];
+#pragma unroll
+  for (int j = 0; j < NJ; j++)
+#pragma unroll
+    for (int e = 0; e < E; e++) {
+      const int c = (g + G * j) * E + e;
+      mean[j][e] = p.stats[2 * c]; rstd[j][e] = p.stats[2 * c + 1];
+      sc[j][e] = p.gamma[c] * rstd[j][e]; sh[j][e] = p.beta[c] - mean[j][e] * sc[j][e];
+      w0[j][e] = p.w[c]; w1[j][e] = p.w[p.C + c]; w2[j][e] = p.w[2 * p.C + c];
+#pragma unroll
+      for (int v = 0; v < NV; v++) acc[j][e][v] = 0.f;
+    }
+  float sdl = 0.f;
+  int l = (int)((r0 + wave * RPW + rg) % p.L);
+  for (long row = r0 + wave * RPW + rg; row < r1; row += 4 * RPW) {
+    const RowDl d = load_dl(dl, row, l, p.L);
+    l += 4 * RPW; while (l >= p.L) l -= p.L;
+    if (g == 0) sdl += d.d0;
+#pragma unroll
+    for (int j = 0; j < NJ; j++) {
+      const uint4 v = *(const uint4*)((const char*)p.y + ((size_t)row * p.ldy + (g + G * j) * E) * sizeof(T));
+      float x[E]; unpack16<T>(v, x);
+#pragma unroll
+      for (int e = 0; e < E; e++) {
+        const float z = x[e] * sc[j][e] + sh[j][e];
+        const float xh = (x[e] - mean[j][e]) * rstd[j][e];
+        const float da = fmaf(d.dn, w0[j][e], fmaf(d.d0, w1[j][e], d.dp * w2[j][e]));
+        const float dz = z > 0.f ? da : p.slope * da;
+        acc[j][e][0] += dz; acc[j][e][1] = fmaf(dz, xh, acc[j][e][1]);
+        if constexpr (PG) {
+          const float a = z > 0.f ? z : p.slope * z;
+          acc[j][e][2] = fmaf(a, d.dn, acc[j][e][2]); acc[j][e][3] = fmaf(a, d.d0, acc[j][e][3]); acc[j][e][4] = fmaf(a, d.dp, acc[j][e][4]);
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < NJ; j++)
+#pragma unroll
+    for (int e = 0; e < E; e++) {
+      const int c = (g + G * j) * E + e;
+#pragma unroll
+      for (int v = 0; v < NV; v++) atomicAdd(&red[v * p.C + c], (double)acc[j][e][v]);
+    }
+  if (PG && g == 0) atomicAdd(&red[5 * p.C], (double)sdl);
+  __syncthreads();
+  float* part = parts + (size_t)blockIdx.x * nvals;
+  for (int i = tid; i < nvals; i += NT) part[i] = (float)red[i];
+}
+
+// dy = gamma rstd (dz - S1 / N - xhat S2 / N); block 0 also adds the parameter gradients from the folded sums
+template <typename T, int G, int NJ>
+__global__ __launch_bounds__(NT) void tail_bwd_apply_kernel(const TailArgs p, const float* __restrict__ dl, const double* __restrict__ sums,
+                                                            T* __restrict__ dy, long lddy, float* __restrict__ dgamma, float* __restrict__ dbeta,
+                                                            float* __restrict__ dw, float* __restrict__ dbias, long rows_per_block) {
+  constexpr int E = Ch<T>::E, RPW = 64 / G;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane % G, rg = lane / G;
+  const long rows = (long)p.B * p.L, r0 = (long)blockIdx.x * rows_per_block, r1 = min(rows, r0 + rows_per_block);
+  if (blockIdx.x == 0 && dgamma) {
+    for (int c = tid; c < p.C; c += NT) {
+      atomicAdd(&dbeta[c], (float)sums[c]); atomicAdd(&dgamma[c], (float)sums[p.C + c]);
+      if (dw) { atomicAdd(&dw[c], (float)sums[2 * p.C + c]); atomicAdd(&dw[p.C + c], (float)sums[3 * p.C + c]); atomicAdd(&dw[2 * p.C + c], (float)sums[4 * p.C + c]); }
+    }
+    if (tid == 0 && dbias) atomicAdd(dbias, (float)sums[5 * p.C]);
+  }
+  const float inv_n = 1.0f / (float)rows;
+  float sc[NJ][E], sh[NJ][E], mean[NJ][E], rstd[NJ][E], w0[NJ][E], w1[NJ][E], w2[NJ][E], k1[NJ][E], k2[NJ][E];
+#pragma unroll
+  for (int j = 0; j < NJ; j++)
+#pragma unroll
+    for (int e = 0; e < E; e++) {
+      const int c = (g + G * j) * E + e;
+      mean[j][e] = p.stats[2 * c]; rstd[j][e] = p.stats[2 * c + 1];
+      sc[j][e] = p.gamma[c] * rstd[j][e]; sh[j][e] = p.beta[c] - mean[j][e] * sc[j][e];
+      w0[j][e] = p.w[c]; w1[j][e] = p.w[p.C + c]; w2[j][e] = p.w[2 * p.C + c];
+      k1[j][e] = (float)sums[c] * inv_n; k2[j][e] = (float)sums[p.C + c] * inv_n;
+    }
+  int l = (int)((r0 + wave * RPW + rg) % p.L);
+  for (long row = r0 + wave * RPW + rg; row < r1; row += 4 * RPW) {
+    const RowDl d = load_dl(dl, row, l, p.L);
+    l += 4 * RPW; while (l >= p.L) l -= p.L;
+#pragma unroll
+    for (int j = 0; j < NJ; j++) {
+      const uint4 v = *(const uint4*)((const char*)p.y + ((size_t)row * p.ldy + (g + G * j) * E) * sizeof(T));
+      float x[E], o[E]; unpack16<T>(v, x);
+#pragma unroll
+      for (int e = 0; e < E; e++) {
+        const float z = x[e] * sc[j][e] + sh[j][e];
+        const float xh = (x[e] - mean[j][e]) * rstd[j][e];
+        const float da = fmaf(d.dn, w0[j][e], fmaf(d.d0, w1[j][e], d.dp * w2[j][e]));
+        const float dz = z > 0.f ? da : p.slope * da;
+        o[e] = sc[j][e] * (dz - k1[j][e] - xh * k2[j][e]);
+      }
+      *(uint4*)((char*)dy + ((size_t)row * lddy + (g + G * j) * E) * sizeof(T)) = pack16<T>(o);
+    }
+  }
+}
+
+// lanes per row / chunks per lane for a channel count: C / E chunks per row, at most 64 lanes per row
+inline bool tail_shape(int C, int E, int* G, int* NJ) {
+  if (C % E != 0) return false;
+  const int ch = C / E;
+  if (ch >= 64) { if (ch % 64 != 0 || ch / 64 > 2) return false; *G = 64; *NJ = ch / 64; return true; }
+  if (ch != 4 && ch != 8 && ch != 16 && ch != 32) return false;
+  *G = ch; *NJ = 1;
+  return true;
+}
+}  // namespace
+
+bool disc_tail_ok(int dtype, int C, long ldy) {
+  int G, NJ;
+  const int E = dtype == EEGLDM_F32 ? 4 : 8;
+  return tail_shape(C, E, &G, &NJ) && ldy % E == 0 && C <= 1024;
+}
+
+#define TAIL_DISPATCH(dtype, G, NJ, ...)                                                                     \
+  do {                                                                                                         \
+    if ((dtype) == EEGLDM_F32) { typedef float T; TAIL_G(G, NJ, __VA_ARGS__); }                                       \
+    else if ((dtype) == EEGLDM_BF16) { typedef bf16_t T; TAIL_G(G, NJ, __VA_ARGS__); }                                \
+    else { typedef f16_t T; TAIL_G(G, NJ, __VA_ARGS__); }                                                             \
+  } while (0)
+#define TAIL_G(G, NJ, ...)                                                                                     \
+  do {                                                                                                         \
+    if (G == 64 && NJ == 1) { constexpr int G_ = 64, NJ_ = 1; __VA_ARGS__; }                                          \
+    else if (G == 64 && NJ == 2) { constexpr int G_ = 64, NJ_ = 2; __VA_ARGS__; }                                     \
+    else if (G == 32) { constexpr int G_ = 32, NJ_ = 1; __VA_ARGS__; }                                                \
+    else if (G == 16) { constexpr int G_ = 16, NJ_ = 1; __VA_ARGS__; }                                                \
+    else if (G == 8) { constexpr int G_ = 8, NJ_ = 1; __VA_ARGS__; }                                                  \
+    else { constexpr int G_ = 4, NJ_ = 1; __VA_ARGS__; }                                                              \
+  } while (0)
+
+// logits: fp32 [B][L] (= NCL with one channel).  stats as left by ls_bn_stats.
+int disc_tail_fwd(eegldm_ctx* ctx, int dtype, const void* y, long ldy, const float* gamma, const float* beta, const float* stats, const float* w3,
+                  const float* bias, float slope, float* logits, int B, int L, int C) {
+  int G, NJ;
+  EEG_CHECK(tail_shape(C, dtype == EEGLDM_F32 ? 4 : 8, &G, &NJ), "fused discriminator tail: unsupported channel count %d", C);
+  TailArgs p = {y, ldy, gamma, beta, stats, w3, bias, slope, B, L, C};
+  // rows per block: enough blocks to keep ~12 per CU in flight, 2 halo rows per block
+  long want = ((long)B * L + (long)ctx->num_cu * 12 - 1) / ((long)ctx->num_cu * 12);
+  int rblk = (int)(want < 16 ? 16 : (want > MAXR ? MAXR : want));
+  if (rblk > L) rblk = L;
+  const dim3 grid((L + rblk - 1) / rblk, B);
+  TAIL_DISPATCH(dtype, G, NJ, hipLaunchKernelGGL((tail_fwd_kernel<T, G_, NJ_>), grid, dim3(NT), 0, ctx->stream, p, logits, rblk));
+  LAUNCH_CHECK();
+  return 0;
+}
+
+// dlogits: fp32 [B][L].  dy: [B * L][lddy] in `dtype`.  dgamma / dbeta / dw3 ([3][C]) / dbias are ACCUMULATED; all four NULL = no parameter gradients.
+int disc_tail_bwd(eegldm_ctx* ctx, int dtype, const void* y, long ldy, const float* gamma, const float* beta, const float* stats, const float* w3,
+                  float slope, const float* dlogits, void* dy, long lddy, float* dgamma, float* dbeta, float* dw3, float* dbias, int B, int L, int C) {
+  int G, NJ;
+  EEG_CHECK(tail_shape(C, dtype == EEGLDM_F32 ? 4 : 8, &G, &NJ), "fused discriminator tail: unsupported channel count %d", C);
+  TailArgs p = {y, ldy, gamma, beta, stats, w3, nullptr, slope, B, L, C};
+  const long rows = (long)B * L;
+  const int nvals = 5 * C + 1;
+  long nb = (long)ctx->num_cu * 4; if (nb > (rows + 63) / 64) nb = (rows + 63) / 64;
+  while ((size_t)nb * nvals * sizeof(float) > (16u << 20)) nb /= 2;
+  if (nb < 1) nb = 1;
+  const long rpb = (rows + nb - 1) / nb; nb = (rows + rpb - 1) / rpb;
+  float* parts = (float*)((char*)ctx->scratch + (8u << 20));
+  const size_t sh = (size_t)nvals * sizeof(double);
+  const bool pg = dgamma != nullptr;
+  if (pg) TAIL_DISPATCH(dtype, G, NJ, hipLaunchKernelGGL((tail_bwd_reduce_kernel<T, G_, NJ_, true>), dim3((unsigned)nb), dim3(NT), sh, ctx->stream, p, dlogits, parts, rpb));
+  else TAIL_DISPATCH(dtype, G, NJ, hipLaunchKernelGGL((tail_bwd_reduce_kernel<T, G_, NJ_, false>), dim3((unsigned)nb), dim3(NT), sh, ctx->stream, p, dlogits, parts, rpb));
+  LAUNCH_CHECK();
+  double* sums;
+  EEG_TRY(ls_bn_fold(ctx, parts, (int)nb, nvals, &sums));
+  long nba = (long)ctx->num_cu * 16; if (nba > (rows + 15) / 16) nba = (rows + 15) / 16;
+  if (nba < 1) nba = 1;
+  const long rpa = (rows + nba - 1) / nba; nba = (rows + rpa - 1) / rpa;
+  TAIL_DISPATCH(dtype, G, NJ, hipLaunchKernelGGL((tail_bwd_apply_kernel<T, G_, NJ_>), dim3((unsigned)nba), dim3(NT), 0, ctx->stream, p, dlogits, sums, (T*)dy, lddy,
+                                                 dgamma, dbeta, dw3, dbias, rpa));
+  LAUNCH_CHECK();
+  return 0;
+}

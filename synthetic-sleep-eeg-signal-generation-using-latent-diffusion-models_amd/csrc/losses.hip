@@ -394,46 +394,51 @@ int ls_bn_repeat_running(eegldm_ctx* ctx, const float* stats, float* rmean, floa
 // Sum areas in the context scratch: two alternating ones for the partials + fold path (the fold kernel of a call re-zeroes the area
 // the PREVIOUS call used -- all of that call's consumers precede it in stream order), a third, memset per call, for the atomic path.
 static double* bn_area(eegldm_ctx* ctx, int i) { return (double*)((char*)ctx->scratch + (2u << 20) + (size_t)i * (256u << 10)); }
-static int bn_fold_launch(eegldm_ctx* ctx, const void* parts, int nb, int C, double** sums_out) {
+// parts: [nb][nvals] fp32 partial sums -> sums[nvals] (fp64) in the current sum area; shared with the fused discriminator tail (disc_tail.hip)
+int ls_bn_fold(eegldm_ctx* ctx, const void* parts, int nb, int nvals, double** sums_out) {
+  EEG_CHECK((size_t)nvals * sizeof(double) <= (256u << 10), "BatchNorm sum area too small for %d values", nvals);
   const int cur = ctx->bn_flip, oth = cur ^ 1;
   double* sums = bn_area(ctx, cur);
   if (eeg_deterministic())
-    hipLaunchKernelGGL(bn_fold_det_kernel, dim3((2 * C + 15) / 16), dim3(NT), 0, ctx->stream, (const float*)parts, nb, 2 * C, sums, bn_area(ctx, oth), ctx->bn_dirty[oth]);
+    hipLaunchKernelGGL(bn_fold_det_kernel, dim3((nvals + 15) / 16), dim3(NT), 0, ctx->stream, (const float*)parts, nb, nvals, sums, bn_area(ctx, oth), ctx->bn_dirty[oth]);
   else
-    hipLaunchKernelGGL(bn_fold_kernel, dim3((2 * C + 63) / 64, 32), dim3(NT), 0, ctx->stream, (const float*)parts, nb, 2 * C, sums, bn_area(ctx, oth), ctx->bn_dirty[oth]);
+    hipLaunchKernelGGL(bn_fold_kernel, dim3((nvals + 63) / 64, 32), dim3(NT), 0, ctx->stream, (const float*)parts, nb, nvals, sums, bn_area(ctx, oth), ctx->bn_dirty[oth]);
   LAUNCH_CHECK();
-  ctx->bn_dirty[cur] = 2 * C; ctx->bn_dirty[oth] = 0; ctx->bn_flip = oth;
+  ctx->bn_dirty[cur] = nvals; ctx->bn_dirty[oth] = 0; ctx->bn_flip = oth;
   *sums_out = sums;
   return 0;
 }
-// BatchNorm1d + LeakyReLU forward.  training: batch statistics (and running-stat update when rmean != null);
-// eval: running statistics.  stats: [C][2] fp32 out.  gamma == null: plain LeakyReLU (stats unused).
-int ls_bn_lrelu_fwd(eegldm_ctx* ctx, const void* x, long ldx, const float* gamma, const float* beta, float* stats, float* rmean, float* rvar,
-                    float* nbt, void* y, long ldy, long rows, int C, float slope, int training, int dtype) {
-  if (gamma) {
-    if (training) {
-      double* sums = bn_area(ctx, 2);   // BatchNorm region of the context scratch (GroupNorm owns [0, 1 MiB) self-cleaning)
-      EEG_CHECK((size_t)C * 2 * sizeof(double) <= (256u << 10), "scratch too small");
-      if (C % 4 == 0 && ldx % 4 == 0 && C <= 1024) {
-        int nb; long rpb4; bn_split(rows, ctx, 8, &nb, &rpb4);
-        void* parts = (char*)ctx->scratch + (8u << 20);
-        DISPATCH_T(dtype, hipLaunchKernelGGL((bn_reduce4_kernel<T, 0>), dim3(nb), dim3(NT), 0, ctx->stream, (const T*)x, ldx, nullptr, nullptr, nullptr,
-                                             (const T*)nullptr, 0, parts, rows, C, rpb4, 0.f));
-        EEG_TRY(bn_fold_launch(ctx, parts, nb, C, &sums));
-      } else {
-        HIP_TRY(hipMemsetAsync(sums, 0, sizeof(double) * 2 * C, ctx->stream));
-        int rs; long rpb; pick_rsplit(rows, C, ctx, &rs, &rpb);
-        DISPATCH_T(dtype, hipLaunchKernelGGL((bn_stats_kernel<T>), dim3((C + 63) / 64, rs), dim3(NT), 0, ctx->stream, (const T*)x, ldx, sums, rows, C, rpb));
-      }
-      LAUNCH_CHECK();
-      hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 255) / 256), dim3(256), 0, ctx->stream, sums, stats, rmean, rvar, nbt, C, (double)rows, 1e-5f, 0.1f);
-      LAUNCH_CHECK();
+static int bn_fold_launch(eegldm_ctx* ctx, const void* parts, int nb, int C, double** sums_out) { return ls_bn_fold(ctx, parts, nb, 2 * C, sums_out); }
+// the statistics half of the forward: stats[C][2] = (mean, rstd) of the batch (training; running statistics updated when rmean != null) or of
+// the running statistics (eval)
+int ls_bn_stats(eegldm_ctx* ctx, const void* x, long ldx, float* stats, float* rmean, float* rvar, float* nbt, long rows, int C, int training, int dtype) {
+  if (training) {
+    double* sums = bn_area(ctx, 2);   // BatchNorm region of the context scratch (GroupNorm owns [0, 1 MiB) self-cleaning)
+    EEG_CHECK((size_t)C * 2 * sizeof(double) <= (256u << 10), "scratch too small");
+    if (C % 4 == 0 && ldx % 4 == 0 && C <= 1024) {
+      int nb; long rpb4; bn_split(rows, ctx, 8, &nb, &rpb4);
+      void* parts = (char*)ctx->scratch + (8u << 20);
+      DISPATCH_T(dtype, hipLaunchKernelGGL((bn_reduce4_kernel<T, 0>), dim3(nb), dim3(NT), 0, ctx->stream, (const T*)x, ldx, nullptr, nullptr, nullptr,
+                                           (const T*)nullptr, 0, parts, rows, C, rpb4, 0.f));
+      EEG_TRY(bn_fold_launch(ctx, parts, nb, C, &sums));
     } else {
-      EEG_CHECK(rmean && rvar, "eval-mode BatchNorm needs running statistics");
-      hipLaunchKernelGGL(bn_eval_stats_kernel, dim3((C + 255) / 256), dim3(256), 0, ctx->stream, rmean, rvar, stats, C, 1e-5f);
-      LAUNCH_CHECK();
+      HIP_TRY(hipMemsetAsync(sums, 0, sizeof(double) * 2 * C, ctx->stream));
+      int rs; long rpb; pick_rsplit(rows, C, ctx, &rs, &rpb);
+      DISPATCH_T(dtype, hipLaunchKernelGGL((bn_stats_kernel<T>), dim3((C + 63) / 64, rs), dim3(NT), 0, ctx->stream, (const T*)x, ldx, sums, rows, C, rpb));
     }
+    LAUNCH_CHECK();
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 255) / 256), dim3(256), 0, ctx->stream, sums, stats, rmean, rvar, nbt, C, (double)rows, 1e-5f, 0.1f);
+    LAUNCH_CHECK();
+  } else {
+    EEG_CHECK(rmean && rvar, "eval-mode BatchNorm needs running statistics");
+    hipLaunchKernelGGL(bn_eval_stats_kernel, dim3((C + 255) / 256), dim3(256), 0, ctx->stream, rmean, rvar, stats, C, 1e-5f);
+    LAUNCH_CHECK();
   }
+  return 0;
+}
+// the apply half: y = lrelu(gamma * (x - mean) * rstd + beta) from given statistics (gamma == null: plain LeakyReLU)
+int ls_bn_apply(eegldm_ctx* ctx, const void* x, long ldx, const float* gamma, const float* beta, const float* stats, void* y, long ldy, long rows, int C,
+                float slope, int dtype) {
   if (C % 4 == 0 && ldx % 4 == 0 && ldy % 4 == 0) {
     int nb; long rpb4; bn_split(rows, ctx, 16, &nb, &rpb4);
     DISPATCH_T(dtype, hipLaunchKernelGGL((bn_apply4_kernel<T, 0>), dim3(nb), dim3(NT), 0, ctx->stream, (const T*)x, ldx, gamma, beta, stats, (const T*)nullptr, 0,
@@ -443,6 +448,13 @@ int ls_bn_lrelu_fwd(eegldm_ctx* ctx, const void* x, long ldx, const float* gamma
   }
   LAUNCH_CHECK();
   return 0;
+}
+// BatchNorm1d + LeakyReLU forward.  training: batch statistics (and running-stat update when rmean != null);
+// eval: running statistics.  stats: [C][2] fp32 out.  gamma == null: plain LeakyReLU (stats unused).
+int ls_bn_lrelu_fwd(eegldm_ctx* ctx, const void* x, long ldx, const float* gamma, const float* beta, float* stats, float* rmean, float* rvar,
+                    float* nbt, void* y, long ldy, long rows, int C, float slope, int training, int dtype) {
+  if (gamma) EEG_TRY(ls_bn_stats(ctx, x, ldx, stats, rmean, rvar, nbt, rows, C, training, dtype));
+  return ls_bn_apply(ctx, x, ldx, gamma, beta, stats, y, ldy, rows, C, slope, dtype);
 }
 int ls_bn_lrelu_bwd(eegldm_ctx* ctx, const void* x, long ldx, const float* gamma, const float* beta, const float* stats, const void* dy, long lddy,
                     void* dx, long lddx, float* dgamma, float* dbeta, long rows, int C, float slope, int dtype) {

@@ -1,0 +1,96 @@
+"""-m gpu: the fused discriminator tail (csrc/disc_tail.hip: last BatchNorm + LeakyReLU + one-channel final conv in one forward pass and two
+backward passes over the last hidden conv's output) against the layer-by-layer path of the same library (EEGLDM_DISC_NO_FUSED_TAIL=1) and
+against the oracle.  The oracle / reference-twin comparisons of tests/test_gpu_aekl.py run on the fused path by default; this file pins the two
+paths to each other on shapes that exercise every lane mapping (C = 512: one wave per row; C = 128: 16 / 32 lanes per row), rows-per-block
+boundaries that fall inside samples, a length that is not a multiple of the block's row count, and the no-parameter-gradient backward the
+generator step uses (MONAI PatchDiscriminator, config/config_aekl_eeg.yaml:30-40; train_autoencoderkl.py:213-228)."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from param_gen import gen_param, normal  # noqa: E402
+from gpu_util import rel_l2  # noqa: E402
+
+
+def _run(cfg, dtype, x, dy, sd, param_grads=True):
+    from eegldm.models import PatchDiscriminator
+    net = PatchDiscriminator(**cfg, dtype=dtype)
+    net.load_state_dict(sd)
+    feats = net(x)
+    net.zero_grad()
+    dx = net.backward(dy, need_dx=True, in_shape=tuple(x.shape), param_grads=param_grads)
+    return [f.clone() for f in feats], dx.clone(), {k: v.clone() for k, v in net.grad_dict().items()}, {k: v.clone() for k, v in net.state_dict().items()}
+
+
+@pytest.mark.parametrize("dtype", ["float32", "bfloat16", "float16"])
+@pytest.mark.parametrize("nch,B,L", [(64, 3, 200), (16, 5, 136), (64, 2, 3000)])
+def test_fused_tail_matches_layerwise(env_switches, dtype, nch, B, L):
+    from eegldm.models import PatchDiscriminator
+    cfg = dict(spatial_dims=1, num_layers_d=3, num_channels=nch, in_channels=1, out_channels=1, kernel_size=3, norm="BATCH", bias=False, padding=1)
+    probe = PatchDiscriminator(**cfg, dtype=dtype)
+    sd = {}
+    for k, (_o, _n, shape) in list(probe.entries.items()) + list(probe.buf_entries.items()):
+        v = torch.from_numpy(gen_param(31, k, shape))
+        sd[k] = v * 2.0 if k.endswith("conv.weight") else v
+    del probe
+    x = torch.from_numpy(normal((B, 1, L), seed=5))
+    Lo = L
+    for _ in range(3):
+        Lo = (Lo + 2 - 3) // 2 + 1
+    dy = torch.from_numpy(normal((B, 1, Lo), seed=6))
+    f1, dx1, g1, s1 = _run(cfg, dtype, x, dy, sd)
+    env_switches(EEGLDM_DISC_NO_FUSED_TAIL="1")
+    f0, dx0, g0, s0 = _run(cfg, dtype, x, dy, sd)
+    f32 = dtype == "float32"
+    # fp32: the same arithmetic up to summation order.  16-bit: the layer-wise path rounds the activation, the logits and the final conv's data
+    # gradient to the storage type, the fused path keeps them in fp32 -- they differ by that rounding (one part in 2^8 / 2^11 per tensor)
+    tol = 2e-5 if f32 else (3e-2 if dtype == "bfloat16" else 4e-3)
+    assert len(f1) == len(f0) == 5
+    for i, (a, b) in enumerate(zip(f1, f0)):
+        assert a.shape == b.shape and rel_l2(a, b) < tol, (i, rel_l2(a, b))
+    assert rel_l2(dx1, dx0) < (1e-4 if f32 else 3 * tol), rel_l2(dx1, dx0)
+    gscale = max(float(v.double().norm()) for v in g0.values())
+    for k in g0:
+        err = float((g1[k].double() - g0[k].double()).norm()) / (float(g0[k].double().norm()) + 1e-3 * gscale)
+        assert err < (1e-4 if f32 else 3 * tol), (k, err)
+    for k in s0:
+        if "running" in k or "num_batches" in k:
+            assert rel_l2(s1[k].float(), s0[k].float()) < (1e-5 if f32 else 2e-2), k
+
+
+@pytest.mark.parametrize("dtype", ["float32", "bfloat16"])
+def test_fused_tail_vs_oracle_and_generator_backward(dtype):
+    """Fused path against the CPU oracle (logits, input gradient, the tail's own parameter gradients), and the backward without parameter
+    gradients (the generator's pass through D, train_autoencoderkl.py:213-215) must give the same input gradient and leave the gradient buffer alone."""
+    from eegldm.models import PatchDiscriminator
+    from oracle import aekl as A
+    cfg = dict(spatial_dims=1, num_layers_d=3, num_channels=64, in_channels=1, out_channels=1, kernel_size=3, norm="BATCH", bias=False, padding=1)
+    B, L = 3, 264
+    sd = {}
+    for k, s in A.disc_param_shapes(cfg).items():
+        v = torch.from_numpy(gen_param(21, k, s))
+        sd[k] = (v * 2.0 if k.endswith("conv.weight") else v)
+    sdr = {k: (v.clone().requires_grad_(True) if v.is_floating_point() and "running" not in k else v.clone()) for k, v in sd.items()}
+    x = torch.from_numpy(normal((B, 1, L), seed=8)).requires_grad_(True)
+    logits = A.disc_forward(sdr, cfg, x, True, {})[-1]
+    dy = torch.from_numpy(normal(tuple(logits.shape), seed=9))
+    (logits * dy).sum().backward()
+    net = PatchDiscriminator(**cfg, dtype=dtype); net.load_state_dict(sd)
+    out = net(x.detach())[-1]
+    f32 = dtype == "float32"
+    assert rel_l2(out, logits.detach()) < (2e-5 if f32 else 5e-2)
+    net.zero_grad()
+    dx = net.backward(dy, need_dx=True, in_shape=tuple(x.shape))
+    assert rel_l2(dx, x.grad) < (2e-4 if f32 else 0.15), rel_l2(dx, x.grad)
+    g = net.grad_dict()
+    for k in ("final_conv.conv.weight", "final_conv.conv.bias", "2.adn.N.weight", "2.adn.N.bias"):
+        # bf16: y (the last hidden conv's output) is stored rounded, so a share of the LeakyReLU masks near z = 0 flips against the fp32 oracle --
+        # the BatchNorm shift gradient (a plain sum of masked terms) is the most exposed: 0.08 measured, the layer-wise path the same
+        assert rel_l2(g[k], sdr[k].grad) < (2e-4 if f32 else 0.12), (k, rel_l2(g[k], sdr[k].grad))
+    # generator pass: same forward, backward without parameter gradients
+    net.zero_grad(); net(x.detach())
+    dx2 = net.backward(dy, need_dx=True, in_shape=tuple(x.shape), param_grads=False)
+    assert rel_l2(dx2, dx) < 1e-6 if f32 else rel_l2(dx2, dx) < 1e-3
+    assert float(net.flat_grad.abs().max()) == 0.0

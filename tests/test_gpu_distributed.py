@@ -88,6 +88,29 @@ def test_bench_self_spawns_two_ranks():
     assert j["value"] > 0 and j["steps"] == 2 and j["unit"] == "windows/s" and j["roofline"]["bound"] == "mfma"
 
 
+def test_bench_self_spawns_eight_ranks_on_one_gpu():
+    """The driver's 8-GPU line at its REAL world size: `python bench.py --gpus 8` respawns itself under torch.distributed.run
+    with 8 ranks -- all on GPU 0 over gloo here (EEGLDM_LOCAL_DEVICE), tiny per-rank batch -- so the respawn, the rank-sharded seeds, the walk over
+    the gradient buckets in 8 ranks' hooks, the max-over-ranks timing and every `comm` key of the record run with world = 8 before a node does."""
+    env = dict(os.environ, EEGLDM_DIST_BACKEND="gloo", EEGLDM_LOCAL_DEVICE="0")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--steps", "2", "--warmup", "1", "--batch", "2",
+                          "--no-cpu-baseline", "--no-roofline"], capture_output=True, text=True, timeout=1500, env=env, cwd=ROOT)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, out.stdout[-2000:]
+    j = json.loads(lines[0])
+    assert j["n_gpus"] == 8 and j["config"]["global_batch"] == 16 and j["config"]["parallelism"] == "dp8" and j["scaling"] == "weak"
+    assert j["value"] > 0 and j["steps"] == 2 and j["unit"] == "windows/s"
+    c = j["comm"]
+    assert c["world_size"] == 8 and c["collective_ranks"] == 8 and c["backend"] == "gloo" and c["collective_is_rccl"] is False
+    assert c["grad_bytes_per_rank"] == 4 * 30533121 or c["grad_bytes_per_rank"] > 4 * 30_000_000      # the flat gradient buffer of the config_ldm UNet (padded layout)
+    for key in ("allreduce_ms_bare", "allreduce_busbw_GBs", "compute_only_ms_per_step", "exposed_comm_ms_per_step", "bucket_bytes", "native_collectives"):
+        assert key in c, key
+    assert j["collective_ranks"] == 8 and j["collective_backend"] == "gloo"
+
+
 def test_native_rccl_communicator_one_rank():
     """eegldm_comm_* (csrc/comm.hip): RCCL resolved with dlopen, communicator of ONE rank on this GPU.  With one rank the mean / broadcast
     are identities, so this checks the plumbing only -- id exchange, stream ordering against the Context, bucketing, ncclAvg, wait.
