@@ -29,6 +29,10 @@ int disc_tail_fwd(eegldm_ctx*, int dtype, const void* y, long ldy, const float* 
                   const float* bias, float slope, float* logits, int B, int L, int C);
 int disc_tail_bwd(eegldm_ctx*, int dtype, const void* y, long ldy, const float* gamma, const float* beta, const float* stats, const float* w3,
                   float slope, const float* dlogits, void* dy, long lddy, float* dgamma, float* dbeta, float* dw3, float* dbias, int B, int L, int C);
+// fused head of the discriminator (disc_tail.hip): LeakyReLU backward + the one-input-channel first conv's weight / bias / data gradients from da0 alone
+bool disc_head_ok(int dtype, int C0, long ldda, int stride, int L, int Lo);
+int disc_head_bwd(eegldm_ctx*, int dtype, const void* da, long ldda, const void* x, const void* w, const float* bias, float slope,
+                  float* dw, float* db, float* dx, int B, int L, int Lo, int C0, int stride);
 int ls_upsample2(eegldm_ctx*, const void* x, long ldx, void* y, long ldy, long rows_in, int C, int dtype);
 int ls_upsample2_bwd(eegldm_ctx*, const void* dy, long lddy, void* dx, long lddx, long rows_in, int C, int dtype);
 int ls_reparam(eegldm_ctx*, const void* mu, const void* lv, const float* eps, void* z, float* sigma, float* kl, long n, int B, int dtype);
@@ -51,7 +55,8 @@ struct SeqNet : NetBase {
   float* buffers = nullptr;     // BatchNorm running statistics (discriminator)
   int forward_seq(const std::vector<Op>& ops, View x, int B, int& L, View* out, std::vector<OpTape>& tape, int training);
   // keep_tape: the tape (and the activations it points to) stays valid for another backward over the same forward
-  int backward_seq(const std::vector<Op>& ops, std::vector<OpTape>& tape, int B, View dy, View* dx, bool need_dx, bool keep_tape = false);
+  // first: stop in front of op `first` (its output gradient is returned in *dx; the caller handles ops [0, first) itself)
+  int backward_seq(const std::vector<Op>& ops, std::vector<OpTape>& tape, int B, View dy, View* dx, bool need_dx, bool keep_tape = false, int first = 0);
 };
 
 int SeqNet::forward_seq(const std::vector<Op>& ops, View x, int B, int& L, View* out, std::vector<OpTape>& tape, int training) {
@@ -106,13 +111,13 @@ int SeqNet::forward_seq(const std::vector<Op>& ops, View x, int B, int& L, View*
   return 0;
 }
 
-int SeqNet::backward_seq(const std::vector<Op>& ops, std::vector<OpTape>& tape, int B, View dy, View* dx_out, bool need_dx, bool keep_tape) {
+int SeqNet::backward_seq(const std::vector<Op>& ops, std::vector<OpTape>& tape, int B, View dy, View* dx_out, bool need_dx, bool keep_tape, int first) {
   const int dt = dtype;
-  for (int i = (int)ops.size() - 1; i >= 0; i--) {
+  for (int i = (int)ops.size() - 1; i >= first; i--) {
     const Op& o = ops[i];
     const OpTape t = keep_tape ? tape[tape.size() - (ops.size() - i)] : tape.back();
     if (!keep_tape) tape.pop_back();
-    const bool want_dx = need_dx || i > 0;
+    const bool want_dx = need_dx || i > first;
     View dx; dx.ld = t.x.C; dx.C = t.x.C;
     if (want_dx) ALLOC_OR_FAIL(dx.p, alloc_act((long)B * t.Lin, t.x.C));
     if (o.kind == OP_CONV) {
@@ -636,6 +641,15 @@ bool disc_tail_eligible(const eegldm_disc* d) {
   return hc.kind == OP_CONV && act.kind == OP_ACT && act.bn_w >= 0 && fin.kind == OP_CONV && fin.cout == 1 && fin.k == 3 && fin.stride == 1 &&
          fin.pl == 1 && fin.pr == 1 && fin.cin == hc.cout && disc_tail_ok(d->dtype, fin.cin, fin.cin);
 }
+// the first layer: conv (one input channel, k 3, padding 1) + plain LeakyReLU, both on the tape
+bool disc_head_eligible(const eegldm_disc* d, const std::vector<Op>& ops) {
+  EEG_ENV_VAR(bool, off, getenv("EEGLDM_DISC_NO_FUSED_HEAD") != nullptr);
+  if (off || eeg_deterministic() || ops.size() < 3 || d->tape.size() < 2) return false;
+  const Op& c0 = ops[0]; const Op& a0 = ops[1];
+  if (c0.kind != OP_CONV || c0.cin != 1 || c0.k != 3 || c0.pl != 1 || c0.pr != 1 || a0.kind != OP_ACT || a0.bn_w >= 0) return false;
+  const OpTape& t0 = d->tape[0];
+  return t0.x.ld == 1 && disc_head_ok(d->dtype, c0.cout, c0.cout, c0.stride, t0.Lin, t0.Lout);
+}
 }  // namespace
 
 extern "C" int eegldm_disc_create(eegldm_ctx* ctx, const eegldm_disc_cfg* cfg, eegldm_disc** out) {
@@ -755,7 +769,7 @@ static int disc_backward_impl(eegldm_disc* d, const float* dlogits, float* dx, i
   d->have_tape = keep_tape;
   const int co = d->cfg.out_channels, B = d->B;
   EEG_CHECK(!keep_tape || d->rt.empty(), "tape reuse is for ResBlock-free stacks");
-  View dx0; int rc;
+  View dx0; int rc, first = 0;
   if (d->tail_on) {
     // gradient of the last hidden conv's output straight from the fp32 logit gradients (the final conv's data gradient is recomputed inside)
     const Op& act = d->ops[d->ops.size() - 2]; const Op& fin = d->ops.back(); const int C = d->tail_y.C; const bool pg = param_grads != 0;
@@ -764,15 +778,25 @@ static int disc_backward_impl(eegldm_disc* d, const float* dlogits, float* dx, i
                           dy.p, C, pg ? d->G(act.bn_w) : nullptr, pg ? d->G(act.bn_b) : nullptr, pg ? d->G(fin.w) : nullptr,
                           pg && fin.b >= 0 ? d->G(fin.b) : nullptr, B, d->Lo, C));
     d->param_grads = pg;
-    rc = d->backward_seq(d->head, d->tape, B, dy, &dx0, dx != nullptr, keep_tape);
+    first = disc_head_eligible(d, d->head) ? 2 : 0;
+    rc = d->backward_seq(d->head, d->tape, B, dy, &dx0, dx != nullptr || first > 0, keep_tape, first);
   } else {
     View dy; ALLOC_OR_FAIL(dy.p, d->alloc_act((long)B * d->Lo, co)); dy.ld = co; dy.C = co;
     EEG_TRY(eegldm_ncl_to_nlc(d->ctx, dlogits, dy.p, co, B, co, d->Lo, d->dtype));
     d->param_grads = param_grads != 0;
-    rc = d->backward_seq(d->ops, d->tape, B, dy, &dx0, dx != nullptr, keep_tape);
+    first = disc_head_eligible(d, d->ops) ? 2 : 0;
+    rc = d->backward_seq(d->ops, d->tape, B, dy, &dx0, dx != nullptr || first > 0, keep_tape, first);
   }
   d->param_grads = true;
   EEG_TRY(rc);
+  if (first > 0) {
+    // first layer fused (disc_tail.hip): dx0 is the gradient of the ACTIVATED first-layer output; mask, weight / bias gradients and the input
+    // gradient come from it and the window itself in one pass each; dx leaves as fp32 NCL directly
+    const Op& c0 = d->ops[0]; const Op& a0 = d->ops[1]; const OpTape t0 = d->tape[0]; const bool pg = param_grads != 0;
+    if (!keep_tape) d->tape.clear();
+    return disc_head_bwd(d->ctx, d->dtype, dx0.p, dx0.ld, t0.x.p, d->W(c0.w), c0.b >= 0 ? d->P(c0.b) : nullptr, a0.slope, pg ? d->G(c0.w) : nullptr,
+                         pg && c0.b >= 0 ? d->G(c0.b) : nullptr, dx, B, t0.Lin, t0.Lout, c0.cout, c0.stride);
+  }
   if (dx) EEG_TRY(eegldm_nlc_to_ncl(d->ctx, dx0.p, dx0.ld, dx, B, d->cfg.in_channels, d->L, d->dtype));
   return 0;
 }

@@ -224,6 +224,137 @@ __global__ __launch_bounds__(NT) void tail_bwd_apply_kernel(const TailArgs p, co
   }
 }
 
+// ================================================================ fused HEAD backward: LeakyReLU + the first conv (1 -> C0 channels, k 3)
+// Layer by layer the first layer's backward was: LeakyReLU backward (read a0, da0, write dy0), conv0 weight gradient (read dy0), bias column
+// sums (read dy0), and -- generator pass -- conv0 data gradient (read dy0) + an NLC -> NCL pass: 4-5 |a0| of traffic for an input with ONE
+// channel.  Everything the layer needs besides da0 can be recomputed from the window itself: the pre-activation z = b + w0 x[sl-1] + w1 x[sl]
+// + w2 x[sl+1] (three FMAs per element, in the forward kernel's own order, so the mask is the forward's), hence
+//   dy0 = da0 (z > 0 ? 1 : slope),   dW_t[c] = sum dy0[b, l, c] x[b, s l + t - 1],   db[c] = sum dy0,   dx[b, i] = sum_{t, l: s l + t - 1 = i} <dy0[b, l, :], w_t>
+// in ONE pass over da0 each (parameter gradients: the discriminator passes; dx: the generator pass).
+struct HeadArgs {
+  const void* da; long ldda;          // gradient of the activated first-layer output, [B * Lo][C0]
+  const void* x;                      // the layer's input as the forward saw it: [B * L] elements of the engine dtype (one channel, ld 1)
+  const void* w; const float* bias;   // [3][C0][1] in the engine dtype (the copy the forward conv read), bias fp32 [C0] or null
+  float slope;
+  int B, L, Lo, C0, stride;           // input / output positions per sample; pad_l = 1
+};
+template <typename T> __device__ __forceinline__ float head_x(const HeadArgs& p, long base, int i) {      // x[b][i], zero outside the sample
+  return (i >= 0 && i < p.L) ? ld_f32((const T*)p.x + base + i) : 0.f;
+}
+
+// parameter gradients: partial sums per block, planar [dW0 | dW1 | dW2 | db] (4 C0 values)
+template <typename T, int G, int NJ>
+__global__ __launch_bounds__(NT) void head_bwd_pg_kernel(const HeadArgs p, float* __restrict__ parts, long rows_per_block) {
+  constexpr int E = Ch<T>::E, RPW = 64 / G;
+  extern __shared__ double red[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane % G, rg = lane / G;
+  const int nvals = 4 * p.C0;
+  for (int i = tid; i < nvals; i += NT) red[i] = 0.0;
+  __syncthreads();
+  const long rows = (long)p.B * p.Lo, r0 = (long)blockIdx.x * rows_per_block, r1 = min(rows, r0 + rows_per_block);
+  float w0[NJ][E], w1[NJ][E], w2[NJ][E], bs[NJ][E], acc[NJ][E][4];
+#pragma unroll
+  for (int j = 0; j < NJ; j++)
+#pragma unroll
+    for (int e = 0; e < E; e++) {
+      const int c = (g + G * j) * E + e;
+      w0[j][e] = ld_f32((const T*)p.w + c); w1[j][e] = ld_f32((const T*)p.w + p.C0 + c); w2[j][e] = ld_f32((const T*)p.w + 2 * p.C0 + c);
+      bs[j][e] = p.bias ? p.bias[c] : 0.f;
+#pragma unroll
+      for (int v = 0; v < 4; v++) acc[j][e][v] = 0.f;
+    }
+  long row = r0 + wave * RPW + rg;
+  int b = (int)(row / p.Lo), l = (int)(row - (long)b * p.Lo);
+  for (; row < r1; row += 4 * RPW) {
+    const long xb = (long)b * p.L; const int i0 = l * p.stride - 1;
+    const float xm = head_x<T>(p, xb, i0), x0 = head_x<T>(p, xb, i0 + 1), xp = head_x<T>(p, xb, i0 + 2);
+#pragma unroll
+    for (int j = 0; j < NJ; j++) {
+      const uint4 v = *(const uint4*)((const char*)p.da + ((size_t)row * p.ldda + (g + G * j) * E) * sizeof(T));
+      float d[E]; unpack16<T>(v, d);
+#pragma unroll
+      for (int e = 0; e < E; e++) {
+        const float z = fmaf(xp, w2[j][e], fmaf(x0, w1[j][e], fmaf(xm, w0[j][e], bs[j][e])));
+        const float dy = z > 0.f ? d[e] : p.slope * d[e];
+        acc[j][e][0] = fmaf(dy, xm, acc[j][e][0]); acc[j][e][1] = fmaf(dy, x0, acc[j][e][1]); acc[j][e][2] = fmaf(dy, xp, acc[j][e][2]);
+        acc[j][e][3] += dy;
+      }
+    }
+    l += 4 * RPW; while (l >= p.Lo) { l -= p.Lo; b++; }
+  }
+#pragma unroll
+  for (int j = 0; j < NJ; j++)
+#pragma unroll
+    for (int e = 0; e < E; e++) {
+      const int c = (g + G * j) * E + e;
+#pragma unroll
+      for (int v = 0; v < 4; v++) atomicAdd(&red[v * p.C0 + c], (double)acc[j][e][v]);
+    }
+  __syncthreads();
+  float* part = parts + (size_t)blockIdx.x * nvals;
+  for (int i = tid; i < nvals; i += NT) part[i] = (float)red[i];
+}
+__global__ void head_finish_kernel(const double* __restrict__ sums, float* __restrict__ dw, float* __restrict__ db, int C0) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < 3 * C0) dw[i] += (float)sums[i];
+  else if (i < 4 * C0 && db) db[i - 3 * C0] += (float)sums[i];
+}
+
+// input gradient, fp32 [B][L] (NCL with one channel): block = RBLK output rows l0 .. of one sample (+ one halo row); row l gives the three dot
+// products q_t[l] = <dy0[l, :], w_t>, and dx[s l + t - 1] collects q_t[l].  stride 2: dx[2l] = q_1[l], dx[2l + 1] = q_2[l] + q_0[l + 1];
+// stride 1: dx[l] = q_0[l + 1] + q_1[l] + q_2[l - 1]  (two halo rows).
+template <typename T, int G, int NJ>
+__global__ __launch_bounds__(NT) void head_bwd_dx_kernel(const HeadArgs p, float* __restrict__ dx, int RBLK) {
+  constexpr int E = Ch<T>::E, RPW = 64 / G;
+  __shared__ float qs[MAXR + 2][3];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane % G, rg = lane / G;
+  const int b = blockIdx.y, l0 = blockIdx.x * RBLK, nout = min(RBLK, p.Lo - l0), nrow = nout + 2;      // LDS row r <-> output row l0 - 1 + r
+  float w0[NJ][E], w1[NJ][E], w2[NJ][E], bs[NJ][E];
+#pragma unroll
+  for (int j = 0; j < NJ; j++)
+#pragma unroll
+    for (int e = 0; e < E; e++) {
+      const int c = (g + G * j) * E + e;
+      w0[j][e] = ld_f32((const T*)p.w + c); w1[j][e] = ld_f32((const T*)p.w + p.C0 + c); w2[j][e] = ld_f32((const T*)p.w + 2 * p.C0 + c);
+      bs[j][e] = p.bias ? p.bias[c] : 0.f;
+    }
+  const long xb = (long)b * p.L;
+  for (int rb = wave * RPW; rb < nrow; rb += 4 * RPW) {
+    const int r = rb + rg, l = l0 - 1 + r;
+    const bool ok = r < nrow && l >= 0 && l < p.Lo;
+    float q0 = 0.f, q1 = 0.f, q2 = 0.f;
+    if (ok) {
+      const int i0 = l * p.stride - 1;
+      const float xm = head_x<T>(p, xb, i0), x0 = head_x<T>(p, xb, i0 + 1), xp = head_x<T>(p, xb, i0 + 2);
+#pragma unroll
+      for (int j = 0; j < NJ; j++) {
+        const uint4 v = *(const uint4*)((const char*)p.da + (((size_t)b * p.Lo + l) * p.ldda + (g + G * j) * E) * sizeof(T));
+        float d[E]; unpack16<T>(v, d);
+#pragma unroll
+        for (int e = 0; e < E; e++) {
+          const float z = fmaf(xp, w2[j][e], fmaf(x0, w1[j][e], fmaf(xm, w0[j][e], bs[j][e])));
+          const float dy = z > 0.f ? d[e] : p.slope * d[e];
+          q0 = fmaf(dy, w0[j][e], q0); q1 = fmaf(dy, w1[j][e], q1); q2 = fmaf(dy, w2[j][e], q2);
+        }
+      }
+    }
+    q0 = group_sum<G>(q0); q1 = group_sum<G>(q1); q2 = group_sum<G>(q2);
+    if (g == 0 && r < nrow) { qs[r][0] = q0; qs[r][1] = q1; qs[r][2] = q2; }
+  }
+  __syncthreads();
+  float* dxb = dx + xb;
+  if (p.stride == 2) {
+    for (int i = tid; i < nout; i += NT) {      // output row l = l0 + i = LDS row i + 1
+      const int l = l0 + i;
+      if (2 * l < p.L) dxb[2 * l] = qs[i + 1][1];
+      if (2 * l + 1 < p.L) dxb[2 * l + 1] = qs[i + 1][2] + qs[i + 2][0];      // (row l + 1 beyond the sample: its q is zero)
+    }
+    // the position in front of the sample's first output row (index -1) does not exist; odd lengths end on an even index (handled above)
+  } else {
+    for (int i = tid; i < nout; i += NT) dxb[l0 + i] = qs[i + 2][0] + qs[i + 1][1] + qs[i][2];
+  }
+}
+
 // lanes per row / chunks per lane for a channel count: C / E chunks per row, at most 64 lanes per row
 inline bool tail_shape(int C, int E, int* G, int* NJ) {
   if (C % E != 0) return false;
@@ -299,5 +430,46 @@ int disc_tail_bwd(eegldm_ctx* ctx, int dtype, const void* y, long ldy, const flo
   TAIL_DISPATCH(dtype, G, NJ, hipLaunchKernelGGL((tail_bwd_apply_kernel<T, G_, NJ_>), dim3((unsigned)nba), dim3(NT), 0, ctx->stream, p, dlogits, sums, (T*)dy, lddy,
                                                  dgamma, dbeta, dw3, dbias, rpa));
   LAUNCH_CHECK();
+  return 0;
+}
+
+// ---------------------------------------------------------------- fused head (first layer) backward
+bool disc_head_ok(int dtype, int C0, long ldda, int stride, int L, int Lo) {
+  int G, NJ;
+  const int E = dtype == EEGLDM_F32 ? 4 : 8;
+  if (!tail_shape(C0, E, &G, &NJ) || ldda % E != 0 || C0 > 1024) return false;
+  if (stride == 2) return Lo == (L + 2 - 3) / 2 + 1 && L == 2 * Lo;      // every input position 0 .. 2 Lo - 1 is written by exactly one output row
+  return stride == 1 && Lo == L;
+}
+// da: [B * Lo][ldda] gradient of the ACTIVATED first-layer output; x: [B * L] input elements (engine dtype); w: the engine-dtype weight copy
+// [3][C0]; dw / db (fp32, ACCUMULATED, both NULL = none); dx (fp32 [B][L], WRITTEN, NULL = none)
+int disc_head_bwd(eegldm_ctx* ctx, int dtype, const void* da, long ldda, const void* x, const void* w, const float* bias, float slope,
+                  float* dw, float* db, float* dx, int B, int L, int Lo, int C0, int stride) {
+  int G, NJ;
+  EEG_CHECK(tail_shape(C0, dtype == EEGLDM_F32 ? 4 : 8, &G, &NJ), "fused discriminator head: unsupported channel count %d", C0);
+  HeadArgs p = {da, ldda, x, w, bias, slope, B, L, Lo, C0, stride};
+  const long rows = (long)B * Lo;
+  if (dw) {
+    const int nvals = 4 * C0;
+    long nb = (long)ctx->num_cu * 4; if (nb > (rows + 63) / 64) nb = (rows + 63) / 64;
+    if (nb < 1) nb = 1;
+    const long rpb = (rows + nb - 1) / nb; nb = (rows + rpb - 1) / rpb;
+    float* parts = (float*)((char*)ctx->scratch + (8u << 20));
+    EEG_CHECK((size_t)nb * nvals * sizeof(float) <= (16u << 20), "partials area too small");
+    TAIL_DISPATCH(dtype, G, NJ, hipLaunchKernelGGL((head_bwd_pg_kernel<T, G_, NJ_>), dim3((unsigned)nb), dim3(NT), (size_t)nvals * sizeof(double), ctx->stream, p, parts, rpb));
+    LAUNCH_CHECK();
+    double* sums;
+    EEG_TRY(ls_bn_fold(ctx, parts, (int)nb, nvals, &sums));
+    hipLaunchKernelGGL(head_finish_kernel, dim3((nvals + 255) / 256), dim3(256), 0, ctx->stream, sums, dw, db, C0);
+    LAUNCH_CHECK();
+  }
+  if (dx) {
+    long want = (rows + (long)ctx->num_cu * 12 - 1) / ((long)ctx->num_cu * 12);
+    int rblk = (int)(want < 16 ? 16 : (want > MAXR ? MAXR : want));
+    if (rblk > Lo) rblk = Lo;
+    const dim3 grid((Lo + rblk - 1) / rblk, B);
+    TAIL_DISPATCH(dtype, G, NJ, hipLaunchKernelGGL((head_bwd_dx_kernel<T, G_, NJ_>), grid, dim3(NT), 0, ctx->stream, p, dx, rblk));
+    LAUNCH_CHECK();
+  }
   return 0;
 }

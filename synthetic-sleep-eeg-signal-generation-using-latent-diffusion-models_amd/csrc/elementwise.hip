@@ -47,6 +47,23 @@ __global__ __launch_bounds__(NT) void nlc_to_ncl_kernel(const T* __restrict__ sr
     if (c0 + cc < C && l0 + ll < L) dst[((long)b * C + c0 + cc) * L + l0 + ll] = tile[cc][ll];
   }
 }
+// Few channels (C <= 8: the 1-channel windows, logits and latents at the models' ends): the 64 x 64 tile above would run 4096 iterations
+// per block for 64 * C elements (24 us for the 3 MB of a (256, 1, 3072) batch).  Here a thread owns one position (b, l) and walks its C
+// channels: reads are coalesced along l for every channel, writes are C consecutive elements per thread.
+template <typename T>
+__global__ __launch_bounds__(NT) void ncl_to_nlc_small_kernel(const float* __restrict__ src, T* __restrict__ dst, long ld, int C, int L, long n) {
+  GRID_STRIDE(i, n) {
+    const long b = i / L; const int l = (int)(i - b * L);
+    for (int c = 0; c < C; c++) st_f32(dst + i * ld + c, src[(b * C + c) * L + l]);
+  }
+}
+template <typename T>
+__global__ __launch_bounds__(NT) void nlc_to_ncl_small_kernel(const T* __restrict__ src, long ld, float* __restrict__ dst, int C, int L, long n) {
+  GRID_STRIDE(i, n) {
+    const long b = i / L; const int l = (int)(i - b * L);
+    for (int c = 0; c < C; c++) dst[(b * C + c) * L + l] = ld_f32(src + i * ld + c);
+  }
+}
 
 __global__ void pack_w_kernel(const float* __restrict__ w, float* __restrict__ p, int Cout, int Cin, int K, int unpack) {
   const long n = (long)Cout * Cin * K;
@@ -548,12 +565,22 @@ int ew_copy_rows(eegldm_ctx* ctx, void* dst, long ldd, const void* src, long lds
 // ================================================================== C ABI
 extern "C" int eegldm_ncl_to_nlc(eegldm_ctx* ctx, const float* src, void* dst, long ld, int B, int C, int L, int dtype) {
   EEG_CHECK(B > 0 && C > 0 && L > 0 && ld >= C, "bad shape");
+  if (C <= 8) {
+    const long n = (long)B * L;
+    DISPATCH_T(dtype, hipLaunchKernelGGL((ncl_to_nlc_small_kernel<T>), dim3(grid1d(n, ctx)), dim3(NT), 0, ctx->stream, src, (T*)dst, ld, C, L, n));
+    LAUNCH_CHECK(); return 0;
+  }
   dim3 grid((L + 63) / 64, (C + 63) / 64, B);
   DISPATCH_T(dtype, hipLaunchKernelGGL((ncl_to_nlc_kernel<T>), grid, dim3(NT), 0, ctx->stream, src, (T*)dst, ld, C, L));
   LAUNCH_CHECK(); return 0;
 }
 extern "C" int eegldm_nlc_to_ncl(eegldm_ctx* ctx, const void* src, long ld, float* dst, int B, int C, int L, int dtype) {
   EEG_CHECK(B > 0 && C > 0 && L > 0 && ld >= C, "bad shape");
+  if (C <= 8) {
+    const long n = (long)B * L;
+    DISPATCH_T(dtype, hipLaunchKernelGGL((nlc_to_ncl_small_kernel<T>), dim3(grid1d(n, ctx)), dim3(NT), 0, ctx->stream, (const T*)src, ld, dst, C, L, n));
+    LAUNCH_CHECK(); return 0;
+  }
   dim3 grid((L + 63) / 64, (C + 63) / 64, B);
   DISPATCH_T(dtype, hipLaunchKernelGGL((nlc_to_ncl_kernel<T>), grid, dim3(NT), 0, ctx->stream, (const T*)src, ld, dst, C, L));
   LAUNCH_CHECK(); return 0;

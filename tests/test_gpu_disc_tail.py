@@ -1,5 +1,6 @@
 """-m gpu: the fused discriminator tail (csrc/disc_tail.hip: last BatchNorm + LeakyReLU + one-channel final conv in one forward pass and two
-backward passes over the last hidden conv's output) against the layer-by-layer path of the same library (EEGLDM_DISC_NO_FUSED_TAIL=1) and
+backward passes over the last hidden conv's output) and the fused head (first layer's LeakyReLU backward + weight / bias / input gradients of the
+one-input-channel conv in one pass over the gradient of its activated output; EEGLDM_DISC_NO_FUSED_HEAD=1) against the layer-by-layer path of the same library (EEGLDM_DISC_NO_FUSED_TAIL=1) and
 against the oracle.  The oracle / reference-twin comparisons of tests/test_gpu_aekl.py run on the fused path by default; this file pins the two
 paths to each other on shapes that exercise every lane mapping (C = 512: one wave per row; C = 128: 16 / 32 lanes per row), rows-per-block
 boundaries that fall inside samples, a length that is not a multiple of the block's row count, and the no-parameter-gradient backward the
@@ -41,7 +42,7 @@ def test_fused_tail_matches_layerwise(env_switches, dtype, nch, B, L):
         Lo = (Lo + 2 - 3) // 2 + 1
     dy = torch.from_numpy(normal((B, 1, Lo), seed=6))
     f1, dx1, g1, s1 = _run(cfg, dtype, x, dy, sd)
-    env_switches(EEGLDM_DISC_NO_FUSED_TAIL="1")
+    env_switches(EEGLDM_DISC_NO_FUSED_TAIL="1", EEGLDM_DISC_NO_FUSED_HEAD="1")
     f0, dx0, g0, s0 = _run(cfg, dtype, x, dy, sd)
     f32 = dtype == "float32"
     # fp32: the same arithmetic up to summation order.  16-bit: the layer-wise path rounds the activation, the logits and the final conv's data
@@ -85,7 +86,7 @@ def test_fused_tail_vs_oracle_and_generator_backward(dtype):
     dx = net.backward(dy, need_dx=True, in_shape=tuple(x.shape))
     assert rel_l2(dx, x.grad) < (2e-4 if f32 else 0.15), rel_l2(dx, x.grad)
     g = net.grad_dict()
-    for k in ("final_conv.conv.weight", "final_conv.conv.bias", "2.adn.N.weight", "2.adn.N.bias"):
+    for k in ("final_conv.conv.weight", "final_conv.conv.bias", "2.adn.N.weight", "2.adn.N.bias", "initial_conv.conv.weight", "initial_conv.conv.bias"):
         # bf16: y (the last hidden conv's output) is stored rounded, so a share of the LeakyReLU masks near z = 0 flips against the fp32 oracle --
         # the BatchNorm shift gradient (a plain sum of masked terms) is the most exposed: 0.08 measured, the layer-wise path the same
         assert rel_l2(g[k], sdr[k].grad) < (2e-4 if f32 else 0.12), (k, rel_l2(g[k], sdr[k].grad))
