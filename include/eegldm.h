@@ -272,6 +272,15 @@ int eegldm_fill(eegldm_ctx*, float* p, long n, float value);
 int eegldm_ldm_train_step(eegldm_unet*, const float* latents, const float* noise, const int64_t* t,
                           const float* acp, int pred_type, int B, int L, float grad_scale, float* loss);
 
+/* Round-6 prototype: nn.Conv1d(k 3, padding 1) over SiLU(GroupNorm(x)) -- the in_layers / out_layers pair of
+ * /root/reference/src/models/unet.py:261-263,287-291 -- with the normalisation applied to the conv's operand tile inside LDS, so the
+ * normalised tensor is never written (no-grad forward only: nothing is kept for a backward).  gn_stats: fp32 [B][G][2] = (mean, rstd) of x, as
+ * eegldm_groupnorm_fwd leaves them.  bf16, silu = 1, B * L and L multiples of 192, Cout a multiple of 256, Cin of 64 (<= 1024), weight
+ * registered with eegldm_conv1d_pack_kblocked; anything else is an error (there is no fallback inside this entry). */
+int eegldm_conv1d_fwd_gn(eegldm_ctx*, const void* x, long ldx, const void* w, const float* bias, const float* gn_gamma, const float* gn_beta,
+                         const float* gn_stats, int G, int silu, void* y, long ldy, int B, int L, int Cin, int Cout,
+                         const float* rowvec, long ld_rowvec, const void* resid, long ld_resid, int dtype);
+
 /* ------------------------------------------------------------------ UNet building blocks at primitive granularity (ABI 7)
  * ONE ResBlock(channels, emb_channels, dropout=0, out_channels, up / down) -- /root/reference/src/models/unet.py:227-327 -- or ONE
  * AttentionBlock(channels, num_heads=1) -- unet.py:132-174 -- run through exactly the kernel sequences the UNet executor runs per block

@@ -163,6 +163,7 @@ SIGNATURES = {
     "eegldm_block_forward": [_vp, _vp, _vp, _vp, _i, _i],
     "eegldm_block_backward": [_vp, _vp, _vp, _vp],
     "eegldm_timestep_embedding": [_vp, _vp, _vp, _i, _i],
+    "eegldm_conv1d_fwd_gn": [_vp, _vp, _l, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp, _l, _i, _i, _i, _i, _vp, _l, _vp, _l, _i],
 }
 for _n in ("eegldm_block_num_params", "eegldm_aekl_num_params", "eegldm_disc_num_params", "eegldm_disc_num_buffers", "eegldm_usleep_num_params", "eegldm_usleep_num_buffers"):
     if hasattr(lib, _n):

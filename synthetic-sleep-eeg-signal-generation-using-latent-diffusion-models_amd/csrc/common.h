@@ -252,6 +252,8 @@ int gemm_launch(eegldm_ctx* ctx, const GemmArgs& a);
 int gemm_big_try(eegldm_ctx* ctx, const GemmArgs& a);      // gemm_big.hip: 1 = launched, 0 = not its shape, < 0 = error
 // 3-tap conv + 1 x 1 skip conv over a second operand in ONE launch (K extension, gemm_big.hip): 1 = launched, 0 = not eligible, < 0 = error
 int gemm_big_skip_try(eegldm_ctx* ctx, const GemmArgs& conv3, const void* x2, long ldx2, const void* w2_kblk, int K2, const float* bias2);
+// 3-tap forward conv with act(x * scale + shift) applied to the operand tile in LDS (round-6 prototype, gemm_big.hip): 1 = launched, 0 = not eligible
+int gemm_big_xf_try(eegldm_ctx* ctx, const GemmArgs& conv3, const float* scale, const float* shift, long ld, int act, float slope);
 // grouped split-K weight gradient: a.ngroup problems whose pointers are in the HOST table `g` (a.batch / a.grp are set here), partial
 // tiles to the context workspace, ONE batched fold into the Dst buffers.  `slot` = position of this launch in the step's flush order:
 // the device copy of the table is cached per slot and re-uploaded only when its contents change (addresses repeat step after step).

@@ -282,13 +282,20 @@ __global__ __launch_bounds__(NT) void head_bwd_pg_kernel(const HeadArgs p, float
     }
     l += 4 * RPW; while (l >= p.Lo) { l -= p.Lo; b++; }
   }
+  // the 64 / G row groups of a wave hold partial sums of the SAME channels: add them with shuffles first (lanes g, g + G, ...), so that only
+  // one lane per channel and wave reaches the LDS accumulator (with G = 8 the direct form was 32 lanes serialising on every address)
 #pragma unroll
   for (int j = 0; j < NJ; j++)
 #pragma unroll
     for (int e = 0; e < E; e++) {
       const int c = (g + G * j) * E + e;
 #pragma unroll
-      for (int v = 0; v < 4; v++) atomicAdd(&red[v * p.C0 + c], (double)acc[j][e][v]);
+      for (int v = 0; v < 4; v++) {
+        float a = acc[j][e][v];
+#pragma unroll
+        for (int d = G; d < 64; d <<= 1) a += __shfl_xor(a, d, 64);
+        if (rg == 0) atomicAdd(&red[v * p.C0 + c], (double)a);
+      }
     }
   __syncthreads();
   float* part = parts + (size_t)blockIdx.x * nvals;
@@ -451,7 +458,7 @@ int disc_head_bwd(eegldm_ctx* ctx, int dtype, const void* da, long ldda, const v
   const long rows = (long)B * Lo;
   if (dw) {
     const int nvals = 4 * C0;
-    long nb = (long)ctx->num_cu * 4; if (nb > (rows + 63) / 64) nb = (rows + 63) / 64;
+    long nb = (long)ctx->num_cu * 2; if (nb > (rows + 63) / 64) nb = (rows + 63) / 64;      // long blocks: a block's constants, its zeroing, its LDS fold and its partial row cost as much as ~400 rows of the loop
     if (nb < 1) nb = 1;
     const long rpb = (rows + nb - 1) / nb; nb = (rows + rpb - 1) / rpb;
     float* parts = (float*)((char*)ctx->scratch + (8u << 20));

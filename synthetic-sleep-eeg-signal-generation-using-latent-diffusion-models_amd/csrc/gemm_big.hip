@@ -71,6 +71,11 @@ struct BigArgs {
   // n .. n + 3 over the tile's rows, fp64 atomics -- the per-(sample, channel quad) moments the NEXT GroupNorm folds into its group
   // statistics, so that it runs as one streaming pass (norm.hip gn_apply_q_kernel).  qL = rows per sample (a multiple of 192).
   double* qstats; int qL;
+  // operand transform (gemm_big_kernel<.., XF != 0>, round 6): the A tile of every K stage is rewritten IN LDS, once it has landed, as
+  //   a[r][k] <- act(a[r][k] * xf_scale[sample(r)][k] + xf_shift[sample(r)][k])          (act: XF 1 = SiLU, 2 = LeakyReLU(xf_slope))
+  // = GroupNorm(+SiLU) / BatchNorm + LeakyReLU applied on the consuming conv's operand load: the normalised tensor is never written.
+  // Tables are fp32 [M / L][xf_ld] (xf_ld = 0: one row for every sample); zero-padding rows of the conv stay zero.
+  const float* xf_scale = nullptr; const float* xf_shift = nullptr; long xf_ld = 0; float xf_slope = 0.f;
 };
 
 typedef __attribute__((address_space(3))) void* lds_void_ptr;
@@ -143,7 +148,10 @@ template <typename T> __device__ __forceinline__ void big_epilogue(const BigArgs
   for (int cc = 0; cc < NIT; cc++) *(uint4*)(p.C + (long)(m0 + r0 + cc * RSTEP) * p.ldc + n0 + cs8 * 8) = v8[cc];
 }
 
-template <int TAPS, bool KBLK, bool FLIP, typename T = bf16_t>      // FLIP: tap t reads weight slice 2 - t (data gradient; also tells the two apart in a kernel trace).  TAPS = 3 only: with one tap every piece carries an A tile and the two-buffer A ring would be overwritten while it is read
+// XF (round 6, measured prototype of normalise-on-operand-load): 0 = none; 1 / 2 = the A tile of stage s + 1 is transformed in
+// LDS (scale, shift, SiLU / LeakyReLU) between the barriers of phases (s, 1) and (s, 2).  That needs the tile landed one barrier earlier
+// than the plain schedule asks (vmcnt(0) at the barrier of phase (s, 1): one phase of DMA lead for the A-carrying piece instead of two).
+template <int TAPS, bool KBLK, bool FLIP, typename T = bf16_t, int XF = 0>      // FLIP: tap t reads weight slice 2 - t (data gradient; also tells the two apart in a kernel trace).  TAPS = 3 only: with one tap every piece carries an A tile and the two-buffer A ring would be overwritten while it is read
 __global__ __launch_bounds__(NTHR, 2) void gemm_big_kernel(const BigArgs p) {
   static_assert(TAPS == 3, "ring layout assumes three pieces per A tile");
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -161,6 +169,52 @@ __global__ __launch_bounds__(NTHR, 2) void gemm_big_kernel(const BigArgs p) {
   const int m0 = tile_m * BM, n0 = tile_n * BN;
   const int S = p.K / BK;
   const bf16_t* zeros = (const bf16_t*)p.zero_page;
+
+  // ---- XF: scale / shift rows of this tile's sample into LDS behind the ring (2 K floats), before any DMA is in flight
+  float* const xs = (float*)(smem + RING);
+  bool xf_top = false, xf_bot = false;
+  if constexpr (XF != 0) {
+    const long smp = m0 / p.L;
+    const float* gsc = p.xf_scale + smp * p.xf_ld; const float* gsh = p.xf_shift + smp * p.xf_ld;
+    for (int i = tid; i < p.K; i += NTHR) { xs[i] = gsc[i]; xs[p.K + i] = gsh[i]; }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    xf_top = m0 % p.L != 0; xf_bot = (m0 + BM) % p.L != 0;      // halo rows that are real rows of the sample (else: the conv's zero padding, left alone)
+  }
+  // chunk k of this thread (16 bytes = 8 channels of one tile row) of A buffer `buf`, K stage s
+  // developer ablations of the transform (tools/r06/gn_onload_ablate.sh): -DEEG_BIG_XF_ABL=1 the LDS round trip without the arithmetic,
+  // =2 no transform at all (what the earlier "tile landed" wait costs by itself); -DEEG_BIG_DBG=4 removes the MFMAs as for the plain kernel
+#ifndef EEG_BIG_XF_ABL
+#define EEG_BIG_XF_ABL 0
+#endif
+  auto xform = [&](const int buf, const int s, const int k) __attribute__((always_inline)) {
+    if constexpr (XF != 0 && EEG_BIG_XF_ABL != 2) {
+      const int c = tid + NTHR * k;
+      if (c < (BM + 2) * 8) {
+        const int pr = c >> 3;
+        if (!((pr == 0 && !xf_top) || (pr == BM + 1 && !xf_bot))) {
+          char* ptr = smem + buf * A_ALLOC + A_PAD + c * 16;
+          const uint4 v = *(const uint4*)ptr;
+#if EEG_BIG_XF_ABL == 1
+          *(uint4*)ptr = v;      // ablation: the LDS round trip of the transform without its arithmetic
+#else
+          const int ch = s * BK + (((c & 7) ^ swz2(pr)) << 3);
+          const float4 s0 = *(const float4*)(xs + ch), s1 = *(const float4*)(xs + ch + 4);
+          const float4 h0 = *(const float4*)(xs + p.K + ch), h1 = *(const float4*)(xs + p.K + ch + 4);
+          const float x[8] = {w16_lo<T>(v.x), w16_hi<T>(v.x), w16_lo<T>(v.y), w16_hi<T>(v.y), w16_lo<T>(v.z), w16_hi<T>(v.z), w16_lo<T>(v.w), w16_hi<T>(v.w)};
+          const float scv[8] = {s0.x, s0.y, s0.z, s0.w, s1.x, s1.y, s1.z, s1.w}, shv[8] = {h0.x, h0.y, h0.z, h0.w, h1.x, h1.y, h1.z, h1.w};
+          float y[8];
+#pragma unroll
+          for (int e = 0; e < 8; e++) {
+            const float z = fmaf(x[e], scv[e], shv[e]);
+            y[e] = XF == 1 ? silu_f(z) : (z > 0.f ? z : p.xf_slope * z);
+          }
+          uint4 o; o.x = pack16x2<T>(y[0], y[1]); o.y = pack16x2<T>(y[2], y[3]); o.z = pack16x2<T>(y[4], y[5]); o.w = pack16x2<T>(y[6], y[7]);
+          *(uint4*)ptr = o;
+#endif
+        }
+      }
+    }
+  };
 
   // ---- LDS-DMA sources, decoded once: LDS chunk c of a tile receives the 16 bytes its swizzled position stands for.
   // 32-bit per-lane byte offsets against a SCALAR base that the K loop advances (global_load_lds with an SGPR base): one VGPR per
@@ -249,6 +303,13 @@ __global__ __launch_bounds__(NTHR, 2) void gemm_big_kernel(const BigArgs p) {
   asm volatile("s_waitcnt vmcnt(8)" ::: "memory");     // pieces 1 + 2 = 4 + 4 instructions may stay in flight
   __builtin_amdgcn_s_barrier();
   asm volatile("" ::: "memory");
+  if constexpr (XF != 0) {      // the first A tile: transformed here, behind one more barrier
+#pragma unroll
+    for (int k = 0; k < 4; k++) xform(0, 0, k);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+  }
 #pragma unroll
   for (int j = 0; j < FN; j++) bf0[j] = *(const uint4*)(smem + B0 + bof + j * 2048);
 #pragma unroll
@@ -272,9 +333,13 @@ __global__ __launch_bounds__(NTHR, 2) void gemm_big_kernel(const BigArgs p) {
       }
       if (!BIG_DBG(2)) af[i] = *(const uint4*)(smA + (aof[t] ^ 64) + i * 2048);
       __builtin_amdgcn_sched_barrier(0);       // pin the order: hipcc otherwise sinks every fragment read to just before its first use
+      if constexpr (XF != 0) {                 // second half of the transform of A(s + 1) (landed since the barrier of phase (s, 1))
+        if (t == 2 && has1) { if (i == 1) xform((s + 1) & 1, s + 1, 2); if (i == 3) xform((s + 1) & 1, s + 1, 3); __builtin_amdgcn_sched_barrier(0); }
+      }
     }
     // ---- B_p: piece p+1 landed everywhere, piece p read by everyone
-    if (has1) wait_dma(t2, has2);
+    if (XF != 0 && t == 1 && has2) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // XF: piece p+2 = the next A tile has to be in LDS now: it is transformed behind this barrier
+    else if (has1) wait_dma(t2, has2);
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
@@ -298,6 +363,9 @@ __global__ __launch_bounds__(NTHR, 2) void gemm_big_kernel(const BigArgs p) {
       }
       if (has1 && !BIG_DBG(2)) af[i] = *(const uint4*)(smA1 + aof[t1] + i * 2048);
       __builtin_amdgcn_sched_barrier(0);
+      if constexpr (XF != 0) {                 // first half of the transform of A(s + 1)
+        if (t == 1 && has2) { if (i == 1) xform((s + 1) & 1, s + 1, 0); if (i == 3) xform((s + 1) & 1, s + 1, 1); __builtin_amdgcn_sched_barrier(0); }
+      }
     }
   };
 #pragma unroll 1
@@ -1203,6 +1271,45 @@ int gemm_big_try(eegldm_ctx* ctx, const GemmArgs& g) {
   else if (g.tap_flip) rc = g.b_kblk ? launch_big<3, true, true>(ctx, a) : launch_big<3, false, true>(ctx, a);
   else rc = g.b_kblk ? launch_big<3, true, false>(ctx, a) : launch_big<3, false, false>(ctx, a);
   return rc < 0 ? rc : 1;
+}
+
+// Round-6 prototype: the 3-tap forward conv with act(x * scale + shift) applied to its operand tile IN LDS -- GroupNorm(+SiLU) /
+// BatchNorm + LeakyReLU on the consumer's load.  g: as for gemm_big_try (GA_CONV, 3 taps, stride 1, pad 1, K-blocked weight), bf16.
+// scale / shift: fp32 [M / L][ld] (ld = 0: one row for all samples).  act: 1 SiLU, 2 LeakyReLU(slope).  1 = launched, 0 = not eligible, < 0 = error.
+int gemm_big_xf_try(eegldm_ctx* ctx, const GemmArgs& g, const float* scale, const float* shift, long ld, int act, float slope) {
+  if (g.dtype != EEGLDM_BF16 || g.bmode != GB_NT || !g.b_kblk || g.batch != 1 || g.splitk > 1 || g.ztaps > 1 || g.out_f32 || g.atomic_out || g.colsum || g.ngroup || g.tap_flip) return 0;
+  if (g.alpha != 1.0f || g.ups > 1 || !(g.amode == GA_CONV && g.taps == 3 && g.stride == 1 && g.pad_l == 1 && g.Lin == g.Lout)) return 0;
+  if (g.M % BM != 0 || g.Lout % BM != 0 || g.N % BN != 0 || g.K % BK != 0 || g.lda % 8 != 0 || g.ldc % 8 != 0) return 0;
+  if (g.rowvec && (g.rows_per_vec % BM != 0 || g.ld_rowvec % 4 != 0)) return 0;
+  if (g.resid && (g.ldr % 4 != 0 || ((size_t)g.resid & 7))) return 0;
+  if (((size_t)g.A | (size_t)g.B | (size_t)g.C) & 15) return 0;
+  const int ldsb = (RING > EPI_BYTES ? RING : EPI_BYTES) + 2 * g.K * (int)sizeof(float);
+  if (ldsb > 160 * 1024 || (act != 1 && act != 2) || !scale || !shift) return 0;
+  BigArgs a;
+  a.A = (const bf16_t*)g.A; a.lda = g.lda; a.B = (const bf16_t*)g.B; a.ldb = g.ldb; a.sBt = g.sBt;
+  a.C = (bf16_t*)g.C; a.ldc = g.ldc; a.M = g.M; a.N = g.N; a.K = g.K; a.L = g.Lout;
+  a.bias = g.bias; a.rowvec = g.rowvec; a.ld_rowvec = g.ld_rowvec; a.rows_per_vec = g.rows_per_vec > 0 ? g.rows_per_vec : 1;
+  a.resid = (const bf16_t*)g.resid; a.ldr = g.ldr; a.zero_page = ctx->zero_page; a.tiles_m = g.M / BM; a.tiles_n = g.N / BN;
+  a.A2 = nullptr; a.lda2 = 0; a.B2 = nullptr; a.K2 = 0; a.bias2 = nullptr; a.qstats = nullptr; a.qL = 0;
+  a.xf_scale = scale; a.xf_shift = shift; a.xf_ld = ld; a.xf_slope = slope;
+  static DevOnce once1, once2;
+  ProfRec rec; const bool prof = ctx->prof_on;
+  if (prof) {
+    rec.cls = PROF_CONV_FWD; rec.flops = 2.0 * g.M * g.N * (double)g.K * 3; rec.M = g.M; rec.N = g.N; rec.K = g.K; rec.taps = 3; rec.splitk = 1;
+    HIP_TRY(hipEventCreate(&rec.a)); HIP_TRY(hipEventCreate(&rec.b)); HIP_TRY(hipEventRecord(rec.a, ctx->stream));
+  }
+  if (act == 1) {
+    auto kern = gemm_big_kernel<3, true, false, bf16_t, 1>;
+    if (once1.need(ctx->device)) HIP_TRY(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    hipLaunchKernelGGL(kern, dim3(a.tiles_m * a.tiles_n), dim3(NTHR), ldsb, ctx->stream, a);
+  } else {
+    auto kern = gemm_big_kernel<3, true, false, bf16_t, 2>;
+    if (once2.need(ctx->device)) HIP_TRY(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    hipLaunchKernelGGL(kern, dim3(a.tiles_m * a.tiles_n), dim3(NTHR), ldsb, ctx->stream, a);
+  }
+  LAUNCH_CHECK();
+  if (prof) { HIP_TRY(hipEventRecord(rec.b, ctx->stream)); ctx->prof.push_back(rec); }
+  return 1;
 }
 
 // The ResBlock tail  out = conv3(a2; W) + bias + skip_1x1(x2; W2) + bias2  as ONE launch (K extension of the persistent 3-tap kernel).

@@ -361,6 +361,40 @@ extern "C" int eegldm_conv1d_fwd_qstats(eegldm_ctx* ctx, const void* x, long ldx
   EEG_CHECK(ctx && x && w && y && qstats && filled, "null pointer");
   return op_conv_fwd(ctx, dtype, x, ldx, w, bias, y, ldy, B, Lin, Cin, Cout, K, stride, pad_l, pad_r, rowvec, ld_rowvec, resid, ld_resid, 0.f, qstats, filled);
 }
+// ---- round-6 prototype: GroupNorm(+SiLU) on the consuming conv's operand load (gemm_big.hip XF kernels)
+// scale[b][c] = gamma[c] rstd[b, g(c)], shift[b][c] = beta[c] - mean[b, g(c)] scale[b][c] from the (mean, rstd) pairs a GroupNorm statistics pass
+// (or a producer's epilogue moments) left: B x C floats each, a few hundred KB
+__global__ void gn_affine_table_kernel(const float* __restrict__ stats, const float* __restrict__ gamma, const float* __restrict__ beta,
+                                       float* __restrict__ scale, float* __restrict__ shift, int B, int C, int G) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (long)B * C) return;
+  const int b = (int)(i / C), c = (int)(i - (long)b * C), g = c / (C / G);
+  const float mean = stats[((long)b * G + g) * 2], rstd = stats[((long)b * G + g) * 2 + 1];
+  const float sc = gamma[c] * rstd;
+  scale[i] = sc; shift[i] = beta[c] - mean * sc;
+}
+// y = conv3(act(GroupNorm(x))) + bias (+ rowvec + resid): the normalised operand is never written.  gn_stats: [B][G][2] = (mean, rstd) of x.
+extern "C" int eegldm_conv1d_fwd_gn(eegldm_ctx* ctx, const void* x, long ldx, const void* w, const float* bias, const float* gn_gamma,
+                                    const float* gn_beta, const float* gn_stats, int G, int silu, void* y, long ldy, int B, int L, int Cin, int Cout,
+                                    const float* rowvec, long ld_rowvec, const void* resid, long ld_resid, int dtype) {
+  EEG_CHECK(ctx && x && w && y && gn_gamma && gn_beta && gn_stats, "null pointer");
+  EEG_CHECK(dtype == EEGLDM_BF16 && silu == 1, "prototype: bf16, GroupNorm + SiLU");
+  EEG_CHECK(G > 0 && Cin % G == 0 && (size_t)B * Cin * 2 * sizeof(float) <= (16u << 20), "bad GroupNorm shape");
+  auto it = ctx->kblk.find(w);
+  EEG_CHECK(it != ctx->kblk.end(), "the weight needs its K-blocked copy (eegldm_conv1d_pack_kblocked)");
+  float* scale = (float*)((char*)ctx->scratch + (8u << 20)); float* shift = scale + (size_t)B * Cin;
+  hipLaunchKernelGGL(gn_affine_table_kernel, dim3((unsigned)(((long)B * Cin + 255) / 256)), dim3(256), 0, ctx->stream, gn_stats, gn_gamma, gn_beta, scale, shift, B, Cin, G);
+  LAUNCH_CHECK();
+  GemmArgs a = {};
+  a.dtype = dtype; a.A = x; a.lda = ldx; a.B = it->second; a.b_kblk = 1; a.ldb = Cin; a.sBt = (long)Cout * Cin; a.C = y; a.ldc = ldy;
+  a.M = B * L; a.N = Cout; a.K = Cin; a.batch = 1; a.taps = 3; a.alpha = 1.0f; a.bias = bias; a.splitk = 1; a.ups = 1;
+  a.rowvec = rowvec; a.ld_rowvec = ld_rowvec; a.rows_per_vec = L; a.resid = resid; a.ldr = ld_resid; a.bmode = GB_NT;
+  a.amode = GA_CONV; a.Lout = L; a.Lin = L; a.stride = 1; a.pad_l = 1;
+  const int rc = gemm_big_xf_try(ctx, a, scale, shift, Cin, 1, 0.f);
+  if (rc < 0) return rc;
+  EEG_CHECK(rc == 1, "not eligible: B * L %% 192, L %% 192, Cout %% 256, Cin %% 64, 16-byte aligned operands, Cin <= 1024");
+  return 0;
+}
 extern "C" int eegldm_conv1d_skip_fwd(eegldm_ctx* ctx, const void* x, long ldx, const void* w, const float* bias, const void* x2, long ldx2,
                                       const void* w2, const float* bias2, void* y, long ldy, int B, int L, int Cin, int Cin2, int Cout,
                                       const float* rowvec, long ld_rowvec, int dtype) {
