@@ -116,6 +116,11 @@ int eegldm_conv1d_pack_kblocked(eegldm_ctx*, const void* w, void* w_kblocked, in
 /* the same for a weight of K taps (K = 1: [1][Cin/32][Cout][32], the copy eegldm_conv1d_skip_fwd reads its 1 x 1 weight from) */
 int eegldm_conv1d_pack_kblocked_k(eegldm_ctx*, const void* w, void* w_kblocked, int Cout, int Cin, int K, int dtype);
 int eegldm_conv1d_forget_kblocked(eegldm_ctx*, const void* w);
+/* Stride-2 Conv1d(64 -> 128, k 3, padding 1) -- the PatchDiscriminator's second layer (config/config_aekl_eeg.yaml:30-40) -- as a stride-1
+ * conv of the weight-stationary kernel over PAIRS of rows: fills w_fwd / w_dgrad ([3][128][128] elements each, caller-owned) from the packed
+ * weight w ([3][128][64]) and registers them; eegldm_conv1d_fwd / _bwd_data then take that route for contiguous operands (ld = channels),
+ * whole 64-row tiles per sample and >= 16 384 output rows.  eegldm_conv1d_forget_kblocked drops the registration. */
+int eegldm_conv1d_pack_stride2(eegldm_ctx*, const void* w, void* w_fwd, void* w_dgrad, int Cout, int Cin, int dtype);
 /* Data-gradient copy of a 3-tap conv weight, [3][Cout/32][Cin][32] (16-bit dtypes, Cout % 32 == 0): written to w_dgrad (same size as w)
  * and registered with the context, after which eegldm_conv1d_bwd_data(.., w, ..) may run the input gradient as a plain NT product on
  * the 192 x 256 tile (shapes with Cin % 256 == 0, Cout % 64 == 0, L % 192 == 0; other shapes are unaffected).  The model executors do

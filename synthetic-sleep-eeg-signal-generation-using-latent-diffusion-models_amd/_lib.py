@@ -75,6 +75,7 @@ SIGNATURES = {
     "eegldm_comm_broadcast_f32": [_vp, _vp, _l, _i],
     "eegldm_comm_wait": [_vp],
     "eegldm_conv1d_forget_kblocked": [_vp, _vp],
+    "eegldm_conv1d_pack_stride2": [_vp, _vp, _vp, _vp, _i, _i, _i],
     "eegldm_conv1d_pack_dgrad": [_vp, _vp, _vp, _i, _i, _i],
     "eegldm_conv1d_pack_dgrad_k": [_vp, _vp, _vp, _i, _i, _i, _i],
     "eegldm_unpack_conv_weight": [_vp, _vp, _vp, _i, _i, _i],

@@ -92,6 +92,9 @@ struct eegldm_ctx {
   std::unordered_map<const void*, const void*> kblk;
   // data-gradient copies of 3-tap conv weights, [tap][Cout / 32][Cin][32] (the reduction index of the data gradient, Cout, K-blocked): keyed like kblk
   std::unordered_map<const void*, const void*> kblk_t;
+  // stride-2 convs (Cin 64 -> Cout 128, k 3) as stride-1 weight-stationary convs over paired rows (elementwise.hip s2ws_pack): the repacked
+  // [3][128][128] weights of the forward / the data gradient, keyed like kblk
+  std::unordered_map<const void*, const void*> s2ws_f, s2ws_d;
   // fused train steps zero ALL their loss scalars with one memset and set this: the loss entry points then skip their own 4-byte memset
   // (every tiny launch costs ~5 us of dispatch: 22 memsets were 2.5 % of the AutoencoderKL / GAN step)
   bool loss_prezeroed = false;

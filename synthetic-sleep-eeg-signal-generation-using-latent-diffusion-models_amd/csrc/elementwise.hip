@@ -661,6 +661,33 @@ int kblk_pack(eegldm_ctx* ctx, const void* w_plain, void* w_packed, const KbDesc
                      d_table, n, total_chunks);
   LAUNCH_CHECK(); return 0;
 }
+// ---- stride-2 3-tap convs of 64 input channels as STRIDE-1 convs of the weight-stationary kernel (conv_ws.hip), round 6.
+// Two consecutive input rows of an NLC tensor with ld = Cin are one row of 2 Cin channels, so with x'[m] = [x[2m] | x[2m + 1]]
+//   forward   y[m]   = W0 x[2m - 1] + W1 x[2m] + W2 x[2m + 1]            = [0 | W0] x'[m - 1] + [W1 | W2] x'[m]
+//   backward  [dx[2m] | dx[2m + 1]] = [W1^T | W2^T] dy[m] + [0 | W0^T] dy[m + 1]                         (dx' = the paired view of dx)
+// i.e. both are 3-tap stride-1 convs with one structurally empty tap and 128 reduction channels when Cin = 64, Cout = 128 -- the shape
+// conv3_ws_kernel keeps in registers.  wf / wd: [3][128][128] 16-bit, element (tap, n, k); w: the packed conv weight [3][Cout][Cin].
+__global__ void s2ws_pack_kernel(const bf16_t* __restrict__ w, bf16_t* __restrict__ wf, bf16_t* __restrict__ wd, int Cout, int Cin) {
+  const int N = 2 * Cin;      // = Cout = 128 (checked by the launcher): both repacked weights are [3][N][N]
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= 3 * N * N) return;
+  const int tp = i / (N * N), n = (i / N) % N, k = i % N;
+  auto W = [&](int t, int co, int ci) { return w[((long)t * Cout + co) * Cin + ci]; };
+  bf16_t f = 0, d = 0;
+  // forward: n = output channel co, k = channel of the paired input row
+  if (tp == 0) { if (k >= Cin) f = W(0, n, k - Cin); }
+  else if (tp == 1) f = k < Cin ? W(1, n, k) : W(2, n, k - Cin);
+  // data gradient: n = column of the paired dx row (ci, or Cin + ci), k = output channel co
+  if (tp == 1) d = n < Cin ? W(1, k, n) : W(2, k, n - Cin);
+  else if (tp == 2) { if (n >= Cin) d = W(0, k, n - Cin); }
+  wf[i] = f; wd[i] = d;
+}
+int s2ws_pack(eegldm_ctx* ctx, const void* w, void* wf, void* wd, int Cout, int Cin) {
+  EEG_CHECK(Cin == 64 && Cout == 128, "stride-2 -> weight-stationary mapping: Cin 64, Cout 128");
+  const int n = 3 * 128 * 128;
+  hipLaunchKernelGGL(s2ws_pack_kernel, dim3((n + NT - 1) / NT), dim3(NT), 0, ctx->stream, (const bf16_t*)w, (bf16_t*)wf, (bf16_t*)wd, Cout, Cin);
+  LAUNCH_CHECK(); return 0;
+}
 extern "C" int eegldm_cast(eegldm_ctx* ctx, const float* s, void* d, long n, int dtype) {
   if (n <= 0) return 0;
   DISPATCH_T(dtype, hipLaunchKernelGGL((cast_kernel<T>), dim3(grid1d(n, ctx)), dim3(NT), 0, ctx->stream, s, (T*)d, n));

@@ -25,6 +25,7 @@ int kblk_pack_one(eegldm_ctx* ctx, const void* w_plain, void* w_packed, int Cout
 // data-gradient copies: [3][Cout][Cin] -> [3][Cout / 32][Cin][32] (Cout, the data gradient's reduction index, K-blocked)
 int kblk_pack_t(eegldm_ctx* ctx, const void* w_plain, void* w_packed, const KbDesc* d_table, int n, long total_chunks);
 int kblk_pack_t_one(eegldm_ctx* ctx, const void* w_plain, void* w_packed, int Cout, int Cin, int taps = 3);   // one weight, both pointers at its first element
+int s2ws_pack(eegldm_ctx* ctx, const void* w, void* wf, void* wd, int Cout, int Cin);      // elementwise.hip
 int dconv_run(eegldm_ctx*, int dtype, bool dgrad, const void* in, long ldin, const void* w, const float* bias,
               const void* resid, long ldr, void* out, long ldout, int B, int Lin, int Lout, int Cin, int Cout, int K,
               int stride, int pad_l, float act_slope = 0.f);

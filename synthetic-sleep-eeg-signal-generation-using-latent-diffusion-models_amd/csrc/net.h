@@ -66,6 +66,9 @@ struct NetBase {
   void* wK = nullptr; void* d_kb = nullptr; int n_kb = 0; long kb_chunks = 0;
   // data-gradient copies [tap][Cout / 32][Cin][32] of the 3-tap weights whose data gradient fits the 192 x 256 tile (gemm_big.hip): same offsets, ctx->kblk_t
   void* wKT = nullptr; void* d_kbt = nullptr; int n_kbt = 0; long kbt_chunks = 0;
+  // stride-2 64 -> 128 convs (the PatchDiscriminator's second layer) on the weight-stationary kernel: per eligible weight a forward and a
+  // data-gradient copy of [3][128][128] elements (elementwise.hip s2ws_pack), refreshed by sync_weights(), registered in ctx->s2ws_f / _d
+  void* wS2 = nullptr; std::vector<long> s2_offs;
   // dgamma / dbeta folds of a ResBlock's first GroupNorm, launched one block later on the side stream (see res_backward)
   struct GnFold { float* dgamma; float* dbeta; int C, region; };
   std::vector<GnFold> gn_pending; int gn_parity = 0;
@@ -111,7 +114,7 @@ struct NetBase {
   int bind(float* p, float* g);
   int sync_weights();
   void release_kblk();
-  ~NetBase() { release_kblk(); if (owns_wT && wT) (void)hipFree(wT); if (qarena) (void)hipFree(qarena); }
+  ~NetBase() { release_kblk(); if (owns_wT && wT) (void)hipFree(wT); if (qarena) (void)hipFree(qarena); }      // (release_kblk also drops the s2ws copies)
 };
 
 #define ALLOC_OR_FAIL(var, expr)                                                     \

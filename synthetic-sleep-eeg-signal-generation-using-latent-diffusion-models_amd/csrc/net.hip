@@ -48,6 +48,18 @@ int NetBase::bind(float* p, float* g) {
       for (const KbDesc& d : tab) ctx->kblk_t[W(d.off)] = (const char*)wKT + (size_t)d.off * 2;
     }
   }
+  if (dtype != EEGLDM_F32 && !wS2 && !no_kblk) {
+    for (const Entry& e : entries)
+      if (e.ndim == 3 && e.shape[2] == 3 && e.shape[0] == 128 && e.shape[1] == 64 && e.offset % 8 == 0) s2_offs.push_back(e.offset);
+    if (!s2_offs.empty()) {
+      constexpr size_t ONE = (size_t)3 * 128 * 128 * 2;      // bytes of one repacked weight
+      HIP_TRY(hipMalloc(&wS2, s2_offs.size() * 2 * ONE));
+      for (size_t i = 0; i < s2_offs.size(); i++) {
+        ctx->s2ws_f[W(s2_offs[i])] = (const char*)wS2 + (2 * i) * ONE;
+        ctx->s2ws_d[W(s2_offs[i])] = (const char*)wS2 + (2 * i + 1) * ONE;
+      }
+    }
+  }
   return sync_weights();
 }
 int NetBase::qbegin() {
@@ -83,6 +95,10 @@ int NetBase::flush_gn_folds() {
   return 0;
 }
 void NetBase::release_kblk() {      // the two copies are independent: a model may own either without the other
+  if (wS2) {
+    for (long o : s2_offs) { ctx->s2ws_f.erase(W(o)); ctx->s2ws_d.erase(W(o)); }
+    (void)hipFree(wS2); wS2 = nullptr; s2_offs.clear();
+  }
   if (wK) {
     for (auto it = ctx->kblk.begin(); it != ctx->kblk.end();) {
       const char* v = (const char*)it->second;
@@ -103,6 +119,10 @@ int NetBase::sync_weights() {
   if (dtype == EEGLDM_F32) return 0;
   EEG_TRY(eegldm_cast(ctx, params, wT, nparams, dtype));
   EEG_TRY(kblk_pack(ctx, wT, wK, (const KbDesc*)d_kb, n_kb, kb_chunks));
+  for (size_t i = 0; i < s2_offs.size(); i++) {
+    constexpr size_t ONE = (size_t)3 * 128 * 128 * 2;
+    EEG_TRY(s2ws_pack(ctx, W(s2_offs[i]), (char*)wS2 + (2 * i) * ONE, (char*)wS2 + (2 * i + 1) * ONE, 128, 64));
+  }
   return kblk_pack_t(ctx, wT, wKT, (const KbDesc*)d_kbt, n_kbt, kbt_chunks);
 }
 int entry_query(const NetBase* u, int i, char* name, int cap, long* offset, long* numel, int* ndim, int shape[3]) {

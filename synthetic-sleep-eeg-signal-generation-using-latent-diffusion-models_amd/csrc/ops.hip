@@ -23,6 +23,16 @@ int op_conv_fwd(eegldm_ctx* ctx, int dtype, const void* x, long ldx, const void*
     return dconv_run(ctx, dtype, false, x, ldx, w, bias, resid, ldr, y, ldy, B, Lin, Lout, Cin, Cout, K, stride, pad_l, act_slope);
   }
   EEG_CHECK(act_slope <= 0.f, "fused activation is only available on the thin-input direct conv");
+  // stride 2, 64 -> 128 channels (the discriminator's second layer, config_aekl_eeg.yaml:30-40): a stride-1 conv of the weight-stationary kernel
+  // over pairs of input rows (elementwise.hip s2ws_pack) -- HBM-bound at 3+ TB/s where the general implicit GEMM's 6-k-step tiles reach 2
+  if (K == 3 && stride == 2 && pad_l == 1 && pad_r == 1 && Cin == 64 && Cout == 128 && ldx == Cin && Lin == 2 * Lout && !rowvec && !resid &&
+      dtype != EEGLDM_F32 && !ctx->s2ws_f.empty()) {
+    auto it = ctx->s2ws_f.find(w);
+    if (it != ctx->s2ws_f.end()) {
+      const int rc = conv_ws_try(ctx, dtype, x, 2 * Cin, it->second, 128, 128, 0, bias, nullptr, 0, nullptr, 0, y, ldy, B, Lout);
+      if (rc != 0) return rc < 0 ? rc : 0;
+    }
+  }
   if (stride == 1 && ((K == 3 && pad_l == 1 && pad_r == 1) || (K == 1 && pad_l == 0 && pad_r == 0))) {   // a few hundred rows (one window per call): conv_skinny.hip
     const int rc = conv_skinny_try(ctx, dtype, x, ldx, w, Cin, Cout, K, bias, rowvec, ld_rowvec, resid, ldr, y, ldy, B, Lin);
     if (rc != 0) return rc < 0 ? rc : 0;
@@ -80,6 +90,15 @@ int op_conv_dgrad(eegldm_ctx* ctx, int dtype, const void* dy, long lddy, const v
   if (K == 3 && stride == 1 && pad_l == 1 && pad_r == 1) {
     const int rc = conv_ws_try(ctx, dtype, dy, lddy, w, Cin, Cout, 1, nullptr, nullptr, 0, resid, ldr, dx, lddx, B, Lin);
     if (rc != 0) return rc < 0 ? rc : 0;
+  }
+  // data gradient of the stride-2 64 -> 128 conv: a stride-1 weight-stationary conv over dy that writes PAIRS of dx rows (see op_conv_fwd)
+  if (K == 3 && stride == 2 && pad_l == 1 && pad_r == 1 && Cin == 64 && Cout == 128 && lddx == Cin && Lin == 2 * Lout && !resid &&
+      dtype != EEGLDM_F32 && !ctx->s2ws_d.empty()) {
+    auto it = ctx->s2ws_d.find(w);
+    if (it != ctx->s2ws_d.end()) {
+      const int rc = conv_ws_try(ctx, dtype, dy, lddy, it->second, 128, 128, 0, nullptr, nullptr, 0, nullptr, 0, dx, 2 * Cin, B, Lout);
+      if (rc != 0) return rc < 0 ? rc : 0;
+    }
   }
   GemmArgs a = {};
   a.dtype = dtype; a.A = dy; a.lda = lddy; a.B = w; a.ldb = Cin; a.sBt = (long)Cout * Cin; a.C = dx; a.ldc = lddx;
@@ -350,9 +369,16 @@ extern "C" int eegldm_conv1d_pack_dgrad_k(eegldm_ctx* ctx, const void* w, void* 
   ctx->kblk_t[w] = w_t;
   return 0;
 }
+extern "C" int eegldm_conv1d_pack_stride2(eegldm_ctx* ctx, const void* w, void* w_fwd, void* w_dgrad, int Cout, int Cin, int dtype) {
+  EEG_CHECK(ctx && w && w_fwd && w_dgrad, "null pointer");
+  EEG_CHECK(dtype != EEGLDM_F32 && Cin == 64 && Cout == 128, "stride-2 weight-stationary copies: 16-bit dtype, Cin 64, Cout 128");
+  EEG_TRY(s2ws_pack(ctx, w, w_fwd, w_dgrad, Cout, Cin));
+  ctx->s2ws_f[w] = w_fwd; ctx->s2ws_d[w] = w_dgrad;
+  return 0;
+}
 extern "C" int eegldm_conv1d_forget_kblocked(eegldm_ctx* ctx, const void* w) {
   EEG_CHECK(ctx && w, "null pointer");
-  ctx->kblk.erase(w); ctx->kblk_t.erase(w);
+  ctx->kblk.erase(w); ctx->kblk_t.erase(w); ctx->s2ws_f.erase(w); ctx->s2ws_d.erase(w);
   return 0;
 }
 extern "C" int eegldm_conv1d_fwd_qstats(eegldm_ctx* ctx, const void* x, long ldx, const void* w, const float* bias, void* y, long ldy,

@@ -95,3 +95,47 @@ def test_fused_tail_vs_oracle_and_generator_backward(dtype):
     dx2 = net.backward(dy, need_dx=True, in_shape=tuple(x.shape), param_grads=False)
     assert rel_l2(dx2, dx) < 1e-6 if f32 else rel_l2(dx2, dx) < 1e-3
     assert float(net.flat_grad.abs().max()) == 0.0
+
+
+@pytest.mark.parametrize("dtype", ["bfloat16", "float16"])
+@pytest.mark.parametrize("B,L,bias", [(32, 1536, False), (24, 1408, True)])
+def test_stride2_conv_on_the_weight_stationary_kernel(dtype, B, L, bias):
+    """Conv1d(64 -> 128, k 3, stride 2, padding 1) -- the discriminator's second layer -- forward and data gradient as stride-1 convs of
+    conv3_ws_kernel over pairs of rows (eegldm_conv1d_pack_stride2) against torch fp32 on the rounded operands, and bit-for-bit layout checks
+    against the general kernel (same entry points without the registration)."""
+    import math
+    import torch.nn.functional as F
+    import gpu_util as G
+    dt = G.BF16 if dtype == "bfloat16" else G.F16
+    tdt = G.TDT[dt]
+    Cin, Cout = 64, 128
+    x = torch.from_numpy(normal((B, Cin, L), seed=1)).to(tdt).float()
+    w = (torch.from_numpy(normal((Cout, Cin, 3), seed=2)) / math.sqrt(3 * Cin)).to(tdt).float()
+    b = torch.from_numpy(normal((Cout,), seed=3)) if bias else None
+    xr = x.clone().requires_grad_(True)
+    y_ref = F.conv1d(F.pad(xr, (1, 1)), w, b, stride=2)
+    Lo = y_ref.shape[-1]
+    dy = torch.from_numpy(normal((B, Cout, Lo), seed=4)).to(tdt).float()
+    y_ref.backward(dy)
+    c = G.ctx()
+    xd, wd, dyd = G.nlc(x, dt), G.pack_w(w, dt), G.nlc(dy, dt)
+    bd = b.to(G.DEV) if bias else None
+    wf = torch.empty(3 * 128 * 128, device=G.DEV, dtype=tdt); wdg = torch.empty_like(wf)
+
+    def run():
+        y = torch.empty(B * Lo, Cout, device=G.DEV, dtype=tdt); dx = torch.empty(B * L, Cin, device=G.DEV, dtype=tdt)
+        G.check(G.lib.eegldm_conv1d_fwd(c.h, G.ptr(xd), Cin, G.ptr(wd), G.ptr(bd), G.ptr(y), Cout, B, L, Cin, Cout, 3, 2, 1, 1, None, 0, None, 0, dt))
+        G.check(G.lib.eegldm_conv1d_bwd_data(c.h, G.ptr(dyd), Cout, G.ptr(wd), G.ptr(dx), Cin, B, L, Cin, Cout, 3, 2, 1, 1, None, 0, dt))
+        torch.cuda.synchronize()
+        return y, dx
+    y0, dx0 = run()                                   # general implicit GEMM
+    G.check(G.lib.eegldm_conv1d_pack_stride2(c.h, G.ptr(wd), G.ptr(wf), G.ptr(wdg), Cout, Cin, dt))
+    try:
+        y1, dx1 = run()                               # weight-stationary route (L / 2 a multiple of 64, >= 16 384 output rows)
+    finally:
+        G.lib.eegldm_conv1d_forget_kblocked(c.h, G.ptr(wd))
+    tol = G.TOL[dt]; gtol = G.GTOL[dt]
+    G.assert_close(G.ncl(y1, B, Lo), y_ref, **tol, name="y (weight-stationary route)")
+    G.assert_close(G.ncl(dx1, B, L), xr.grad, **gtol, name="dx (weight-stationary route)")
+    assert rel_l2(y1, y0) < 1e-2 and rel_l2(dx1, dx0) < 1e-2      # same product, other summation order
+    assert not torch.equal(y1, y0) or B * Lo < 16384              # (the two routes are different kernels: identical bits would mean the registration was not used)
