@@ -846,6 +846,10 @@ extern "C" int eegldm_aekl_train_step(eegldm_aekl* a, eegldm_disc* d, const floa
   ctx->l1_overwrite = true;
   EEG_TRY(eegldm_l1_loss(ctx, recon, x, losses + 0, drecon, n, 1.0f));
   ctx->l1_overwrite = false;
+  // (Round 6 tried this one latency-bound launch -- one workgroup per window, three 3072-point DFTs in LDS, ~100 us at B = 256 -- on the auxiliary
+  // stream beside the discriminator's forward / backward on the reconstruction: 3.20 against 3.13 ms serial on one box, like round 5's attempt
+  // with the thin autoencoder's backward.  Two streams are two hardware queues, and alternating between them costs more than the overlap
+  // returns.  Removed; HISTORY.md keeps the numbers.)
   EEG_TRY(eegldm_spectral_loss(ctx, recon, x, losses + 1, use_spectral ? drecon : nullptr, B, C, L, spectral_weight));
   EEG_TRY(eegldm_disc_forward(d, recon, logits, B, L, 1));
   EEG_TRY(eegldm_lsgan_loss(ctx, logits, 1, losses + 3, dlogits, nl, adv_weight));
@@ -856,23 +860,10 @@ extern "C" int eegldm_aekl_train_step(eegldm_aekl* a, eegldm_disc* d, const floa
   EEG_ENV_VAR(bool, refwd, getenv("EEGLDM_AEKL_REFORWARD_D") != nullptr);       // developer switch: the literal three-forward sequence
   EEG_TRY(disc_backward_impl(d, dlogits, dxd, 0, !refwd));
   EEG_TRY(eegldm_axpy(ctx, drecon, dxd, 1.0f, n));
-  // The generator's backward and the discriminator's own losses are independent from here on: a THIN autoencoder's backward is ONE
-  // latency-bound launch (one 512-thread workgroup per window = per CU, ~0.55 ms at B = 256 with the MFMA pipe and HBM idle) that touches
-  // nothing of the context (its tape, drecon, the autoencoder's gradient buffer by atomics), so it runs on the auxiliary stream beside
-  // the discriminator's launches and the main stream joins it before the call returns.  OPT-IN (EEGLDM_AEKL_OVERLAP=1): measured, round 5
-  // (tools/r05/s4.sh, B = 256): 3.86 ms against 3.77 ms serial -- the kernel's 256 workgroups take ~100 KB of LDS on every CU, the
-  // discriminator's GEMMs (64-148 KB) cannot become resident beside them and queue behind it anyway, and the small BatchNorm kernels that do
-  // fit only take issue slots from a kernel that is VALU-issue bound.  Serial in the deterministic mode and while launches are being timed.
-  EEG_ENV_VAR(bool, no_overlap, getenv("EEGLDM_AEKL_OVERLAP") == nullptr || atoi(getenv("EEGLDM_AEKL_OVERLAP")) == 0 || getenv("EEGLDM_AEKL_NO_OVERLAP") != nullptr);
-  const bool overlap = a->thin_tape && !no_overlap && !eeg_deterministic() && !ctx->prof_on && !getenv("EEGLDM_THIN_PROF");
-  if (overlap) {
-    EEG_TRY(ctx_aux_fork(ctx));
-    struct OnAux { eegldm_ctx* c; hipStream_t s; explicit OnAux(eegldm_ctx* cc) : c(cc), s(cc->stream) { c->stream = c->aux; } ~OnAux() { c->stream = s; } } on_aux(ctx);
-    EEG_TRY(eegldm_aekl_backward(a, drecon, kl_weight, nullptr));
-  } else {
-    EEG_TRY(eegldm_aekl_backward(a, drecon, kl_weight, nullptr));
-  }
-  struct JoinAux { eegldm_ctx* c; bool on; ~JoinAux() { if (on) (void)ctx_aux_join(c); } } join_aux{ctx, overlap};      // also on an error return below
+  // (Round 5 also tried the thin autoencoder's one-launch backward on the auxiliary stream beside the discriminator's launches: 3.86 against
+  // 3.77 ms -- its 256 workgroups hold ~100 KB of LDS on every CU and the GEMMs cannot become resident beside them.  Removed in round 6;
+  // HISTORY.md keeps the numbers.)
+  EEG_TRY(eegldm_aekl_backward(a, drecon, kl_weight, nullptr));
   // ---- discriminator: 0.5 * adv_weight * (fake->0 + real->1)
   if (refwd) EEG_TRY(eegldm_disc_forward(d, recon, logits, B, L, 1));
   else EEG_TRY(disc_repeat_running(d));

@@ -208,6 +208,146 @@ __global__ __launch_bounds__(256, 2) void conv3_ws_kernel(const WsArgs p) {
   if (p.dbg & 4) __syncthreads(); else ws_barrier();
   store_tile(t_end - 1);
 }
+
+// ================================================================ stride-2 Conv1d(128 -> 256, k 3, padding 1) over PAIRED rows (round 6)
+// The PatchDiscriminator's third layer (config_aekl_eeg.yaml:30-40) is 9.7 GMAC against 2 x 49 MB at B = 256: HBM-bound, and the general
+// implicit GEMM runs it at 2 TB/s (its 128 x 128 tiles have 12 K stages, prologue + epilogue as long as the loop).  With x'[m] = [x[2m] | x[2m + 1]]
+// (two input rows of 128 channels = one row of 256) the stride disappears:
+//   forward        y[m]                      = [0 | W0] x'[m - 1] + [W1 | W2] x'[m]                       (taps -1 and 0; 128 + 256 reduction elements)
+//   data gradient  [dx[2m] | dx[2m + 1]]     = [W1^T | W2^T] dy[m] + [0 | W0^T] dy[m + 1]                 (taps 0 and +1; 256 + 256 for the odd half)
+// Both are weight-stationary like conv3_ws_kernel: a wave keeps its 32 output columns x the NON-EMPTY (tap, 32-channel chunk) fragments in
+// registers for the whole launch (12 / 8 / 16 k-steps x 2 column fragments = 96 / 64 / 128 VGPRs; read straight from the packed weight
+// [3][256][128], the data gradient gathered transposed), only the activation tile streams: 32 rows x 512 B (+ 2 halo rows) by LDS-DMA into
+// a 3-deep ring, 64 KB of LDS per block, two blocks per CU.
+constexpr int W2_ROWS = 32, W2_BUF_ROWS = 36, W2_ROW_BYTES = 512;
+constexpr int W2_ABUF = W2_BUF_ROWS * W2_ROW_BYTES;      // 18 432 B = 18 wave instructions of 2 rows
+constexpr int W2_OUT = W2_ROWS * 256;                     // 32 rows x 128 output columns (one blockIdx.y half) x 2 B
+constexpr int W2_LDS = WS_RING * W2_ABUF + W2_OUT;        // 63 488 B
+
+struct Ws2Args {
+  const bf16_t* x; long ldx;           // paired view: [M][256]
+  const bf16_t* w;                     // packed conv weight [3][256][128]
+  const float* bias;                   // forward only
+  bf16_t* y; long ldy;                 // [M][256]
+  int M, L, ntiles, tiles_per_block;   // rows of the paired view, rows per sample
+  const void* zero_page;
+};
+
+// MODE 0: forward; 1 / 2: data gradient, even / odd half of the paired dx row (blockIdx.y).  SLOTS = non-empty (tap, k-step) pairs.
+template <int MODE> struct W2Map;
+template <> struct W2Map<0> { static constexpr int SLOTS = 12; static __device__ __forceinline__ void at(int s, int& tp, int& kk) { if (s < 4) { tp = 0; kk = 4 + s; } else { tp = 1; kk = s - 4; } } };
+template <> struct W2Map<1> { static constexpr int SLOTS = 8;  static __device__ __forceinline__ void at(int s, int& tp, int& kk) { tp = 1; kk = s; } };
+template <> struct W2Map<2> { static constexpr int SLOTS = 16; static __device__ __forceinline__ void at(int s, int& tp, int& kk) { tp = 1 + (s >> 3); kk = s & 7; } };
+
+template <int MODE, typename T16>
+__device__ __forceinline__ void ws2_body(const Ws2Args& p, char* smem) {
+  using Map = W2Map<MODE>;
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, lm = lane & 15, q = lane >> 4;
+  const int nb0 = blockIdx.y * 128, n0 = nb0 + wave * 32;      // this block's / wave's output columns
+  const int t_begin = blockIdx.x * p.tiles_per_block;
+  int t_end = t_begin + p.tiles_per_block; if (t_end > p.ntiles) t_end = p.ntiles;
+  if (t_begin >= t_end) return;
+  const unsigned lds_base = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem;
+  const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+  // activation tile: buffer row j <-> global row 32 t - 1 + j; a DMA instruction moves 2 rows (32 lanes x 16 B each); chunk c of row j
+  // lands at slot c ^ (j & 15) (32 slots per row: the XOR stays inside its 16-slot half)
+  auto issue_dma = [&](int t) {
+    const int buf = (t - t_begin) % WS_RING;
+    const long row0 = (long)t * W2_ROWS;
+    const bool has_left = (row0 % p.L) != 0, has_right = ((row0 + W2_ROWS) % p.L) != 0;
+    for (int i = wave_u; i < W2_BUF_ROWS / 2; i += 4) {
+      const int j = 2 * i + (lane >> 5), c = (lane & 31) ^ (j & 15);
+      const bool ok = (j >= 1 && j <= W2_ROWS) || (j == 0 && has_left) || (j == W2_ROWS + 1 && has_right);
+      const char* src = ok ? (const char*)(p.x + (row0 - 1 + j) * p.ldx) + c * 16 : (const char*)p.zero_page;
+      ws_dma16(src, __builtin_amdgcn_readfirstlane(lds_base + buf * W2_ABUF + i * 1024));
+    }
+  };
+  issue_dma(t_begin);
+  if (t_begin + 1 < t_end) issue_dma(t_begin + 1);
+
+  // ---- stationary weight fragments: wf[s][cf] = W'(tap, n0 + cf*16 + lm, kk*32 + q*8 .. +8) of slot s = (tap, kk)
+  uint4 wf[Map::SLOTS][2];
+#pragma unroll
+  for (int s_ = 0; s_ < Map::SLOTS; s_++) {
+    int tp, kk; Map::at(s_, tp, kk);
+#pragma unroll
+    for (int cf = 0; cf < 2; cf++) {
+      const int n = n0 + cf * 16 + lm, k0 = kk * 32 + q * 8;
+      if constexpr (MODE == 0) {
+        // n = output channel; paired-row channel k0 .. +8: first half = x[2m + (tp == 1 ? 0 : *)], second half = x[2m - 1] (tp 0) / x[2m + 1] (tp 1)
+        const int tap = k0 < 128 ? 1 : (tp == 0 ? 0 : 2), ci = k0 & 127;
+        wf[s_][cf] = *(const uint4*)(p.w + ((long)tap * 256 + n) * 128 + ci);
+      } else {
+        // n = column of the paired dx row (this half: ci = n & 127), k = output channel co: W[tap][co .. co + 8][ci], gathered
+        const int tap = MODE == 1 ? 1 : (tp == 1 ? 2 : 0), ci = n & 127;
+        const bf16_t* wp = p.w + ((long)tap * 256 + k0) * 128 + ci;
+        unsigned e[8];
+#pragma unroll
+        for (int i = 0; i < 8; i++) e[i] = wp[(long)i * 128];
+        wf[s_][cf] = make_uint4(e[0] | (e[1] << 16), e[2] | (e[3] << 16), e[4] | (e[5] << 16), e[6] | (e[7] << 16));
+      }
+    }
+  }
+  float4 bv[2];
+#pragma unroll
+  for (int cf = 0; cf < 2; cf++) bv[cf] = (MODE == 0 && p.bias) ? *(const float4*)(p.bias + n0 + cf * 16 + q * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+  __builtin_amdgcn_s_waitcnt(0x0F70);      // retire the compiler-visible loads here (see conv3_ws_kernel)
+
+  char* sOut = smem + WS_RING * W2_ABUF;
+  auto store_tile = [&](int t) {        // whole 256-byte row halves of tile t from the LDS output tile
+    const long row0 = (long)t * W2_ROWS;
+#pragma unroll
+    for (int i = 0; i < 2; i++) {
+      const int c = tid + 256 * i, row = c >> 4, ch = c & 15;
+      const uint4 v = *(const uint4*)(sOut + row * 256 + ((ch ^ (row & 15)) * 16));
+      *(uint4*)(p.y + (row0 + row) * p.ldy + nb0 + ch * 8) = v;
+    }
+  };
+  for (int t = t_begin; t < t_end; t++) {
+    const int buf = (t - t_begin) % WS_RING;
+    // everything up to DMA(t) landed; younger: the 2 stores of tile t - 2 and DMA(t + 1) (4 instructions, 5 in waves 0 and 1)
+    if (t + 1 < t_end) asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    ws_barrier();
+    if (t > t_begin) store_tile(t - 1);
+    if (t + 2 < t_end) issue_dma(t + 2);
+    const char* sA = smem + buf * W2_ABUF;
+    f32x4 acc[2][2];
+#pragma unroll
+    for (int rf = 0; rf < 2; rf++)
+#pragma unroll
+      for (int cf = 0; cf < 2; cf++) acc[rf][cf] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int rf = 0; rf < 2; rf++)
+#pragma unroll
+      for (int s_ = 0; s_ < Map::SLOTS; s_++) {
+        int tp, kk; Map::at(s_, tp, kk);
+        const int j = rf * 16 + lm + tp;
+        const uint4 xf = *(const uint4*)(sA + j * W2_ROW_BYTES + (((kk * 4 + q) ^ (j & 15)) * 16));
+#pragma unroll
+        for (int cf = 0; cf < 2; cf++)
+          if constexpr (Is16<T16>::f16) acc[rf][cf] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, wf[s_][cf]), __builtin_bit_cast(f16x8, xf), acc[rf][cf], 0, 0, 0);
+          else acc[rf][cf] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, wf[s_][cf]), __builtin_bit_cast(bf16x8, xf), acc[rf][cf], 0, 0, 0);
+      }
+    ws_barrier();             // every wave has read the previous output tile (store_tile above) before it is overwritten
+#pragma unroll
+    for (int rf = 0; rf < 2; rf++)
+#pragma unroll
+      for (int cf = 0; cf < 2; cf++) {
+        const float v0 = acc[rf][cf][0] + bv[cf].x, v1 = acc[rf][cf][1] + bv[cf].y, v2 = acc[rf][cf][2] + bv[cf].z, v3 = acc[rf][cf][3] + bv[cf].w;
+        const int row = rf * 16 + lm, ch = wave * 4 + cf * 2 + (q >> 1);
+        *(uint2*)(sOut + row * 256 + ((ch ^ (row & 15)) * 16) + (q & 1) * 8) = make_uint2(pack16x2<T16>(v0, v1), pack16x2<T16>(v2, v3));
+      }
+  }
+  ws_barrier();
+  store_tile(t_end - 1);
+}
+
+template <bool DGRAD, typename T16 = bf16_t>
+__global__ __launch_bounds__(256, 2) void conv3_ws2_kernel(const Ws2Args p) {
+  extern __shared__ __attribute__((aligned(1024))) char smem[];
+  if constexpr (!DGRAD) ws2_body<0, T16>(p, smem);
+  else { if (blockIdx.y == 0) ws2_body<1, T16>(p, smem); else ws2_body<2, T16>(p, smem); }
+}
 }  // namespace
 
 // Y[r][n] = sum_t sum_k X[r + t - 1][k] * W(t, n, k) (+ bias[n] + rowvec[sample(r)][n] + resid[r][n]), rows flattened (sample, position), zero
@@ -255,6 +395,43 @@ int conv_ws_try(eegldm_ctx* ctx, int dtype, const void* x, long ldx, const void*
     else hipLaunchKernelGGL((conv3_ws_kernel<false, f16_t>), dim3((unsigned)nbx, ny), dim3(256), WS_LDS, ctx->stream, a);
   } else if (transposed) hipLaunchKernelGGL(conv3_ws_kernel<true>, dim3((unsigned)nbx, ny), dim3(256), WS_LDS, ctx->stream, a);
   else hipLaunchKernelGGL(conv3_ws_kernel<false>, dim3((unsigned)nbx, ny), dim3(256), WS_LDS, ctx->stream, a);
+  LAUNCH_CHECK();
+  if (prof) { HIP_TRY(hipEventRecord(rec.b, ctx->stream)); ctx->prof.push_back(rec); }
+  return 1;
+}
+
+// Stride-2 Conv1d(128 -> 256, k 3, padding 1) on contiguous NLC operands: forward (x: [B * 2 Lo][128] -> y: [B * Lo][256] + bias) or data gradient
+// (x = dy: [B * Lo][256] -> y = dx: [B * 2 Lo][128]); w = the packed weight [3][256][128].  1 = launched, 0 = not this kernel's shape, < 0 = error.
+int conv_ws2_try(eegldm_ctx* ctx, int dtype, int dgrad, const void* x, const void* w, const float* bias, void* y, int B, int Lo) {
+  EEG_ENV_VAR(bool, off, getenv("EEGLDM_NO_CONV_WS") != nullptr);
+  const long M = (long)B * Lo;
+  if (off || (dtype != EEGLDM_BF16 && dtype != EEGLDM_F16) || Lo % W2_ROWS != 0 || M >= (1L << 31) || M < 8192) return 0;
+  if (((size_t)x | (size_t)y | (size_t)w) % 16 != 0) return 0;
+  Ws2Args a = {};
+  a.x = (const bf16_t*)x; a.ldx = 256; a.w = (const bf16_t*)w; a.bias = dgrad ? nullptr : bias; a.y = (bf16_t*)y; a.ldy = 256;
+  a.M = (int)M; a.L = Lo; a.ntiles = (int)(M / W2_ROWS); a.zero_page = ctx->zero_page;
+  long nbx = (long)ctx->num_cu * 2 / 2; if (nbx < 1) nbx = 1; if (nbx > a.ntiles) nbx = a.ntiles;      // 2 blocks per CU, 2 column halves
+  a.tiles_per_block = (int)((a.ntiles + nbx - 1) / nbx);
+  nbx = (a.ntiles + a.tiles_per_block - 1) / a.tiles_per_block;
+  static DevOnce attr_once;
+  if (attr_once.need(ctx->device)) {
+    HIP_TRY(hipFuncSetAttribute((const void*)conv3_ws2_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, W2_LDS));
+    HIP_TRY(hipFuncSetAttribute((const void*)conv3_ws2_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, W2_LDS));
+    HIP_TRY(hipFuncSetAttribute((const void*)conv3_ws2_kernel<false, f16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, W2_LDS));
+    HIP_TRY(hipFuncSetAttribute((const void*)conv3_ws2_kernel<true, f16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, W2_LDS));
+  }
+  ProfRec rec; const bool prof = ctx->prof_on;
+  if (prof) {
+    rec.cls = dgrad ? PROF_CONV_DGRAD : PROF_CONV_FWD; rec.flops = 2.0 * (double)M * 256 * 128 * 3.0;
+    rec.M = (int)M; rec.N = 256; rec.K = 128; rec.taps = 3; rec.splitk = 1;
+    HIP_TRY(hipEventCreate(&rec.a)); HIP_TRY(hipEventCreate(&rec.b)); HIP_TRY(hipEventRecord(rec.a, ctx->stream));
+  }
+  const dim3 grid((unsigned)nbx, 2);
+  if (dtype == EEGLDM_F16) {
+    if (dgrad) hipLaunchKernelGGL((conv3_ws2_kernel<true, f16_t>), grid, dim3(256), W2_LDS, ctx->stream, a);
+    else hipLaunchKernelGGL((conv3_ws2_kernel<false, f16_t>), grid, dim3(256), W2_LDS, ctx->stream, a);
+  } else if (dgrad) hipLaunchKernelGGL(conv3_ws2_kernel<true>, grid, dim3(256), W2_LDS, ctx->stream, a);
+  else hipLaunchKernelGGL(conv3_ws2_kernel<false>, grid, dim3(256), W2_LDS, ctx->stream, a);
   LAUNCH_CHECK();
   if (prof) { HIP_TRY(hipEventRecord(rec.b, ctx->stream)); ctx->prof.push_back(rec); }
   return 1;

@@ -110,8 +110,12 @@ __global__ __launch_bounds__(NT) void tail_fwd_kernel(const TailArgs p, float* _
 
 // ---------------------------------------------------------------- backward, shared per-row arithmetic
 struct RowDl { float dn, d0, dp; };      // dl[l + 1], dl[l], dl[l - 1] of this row (zero outside the sample)
-__device__ __forceinline__ RowDl load_dl(const float* __restrict__ dl, long row, int l, int L) {      // l = row % L (kept by the caller: no division per row)
-  RowDl r; r.d0 = dl[row]; r.dn = l + 1 < L ? dl[row + 1] : 0.f; r.dp = l > 0 ? dl[row - 1] : 0.f;
+// l = row % L (kept by the caller: no division per row).  Branch-free: every load is unconditional on a clamped index and zeroed by a select, so
+// that the U rows a lane requests per iteration are all in flight together (a load under a branch is a basic block with its own wait)
+__device__ __forceinline__ RowDl load_dl(const float* __restrict__ dl, long row, int l, int L, long nrows, bool ok) {
+  const long rc = row < nrows ? row : nrows - 1;
+  const float d0 = dl[rc], dn = dl[rc + 1 < nrows ? rc + 1 : rc], dp = dl[rc > 0 ? rc - 1 : 0];
+  RowDl r; r.d0 = ok ? d0 : 0.f; r.dn = (ok && l + 1 < L) ? dn : 0.f; r.dp = (ok && l > 0) ? dp : 0.f;
   return r;
 }
 
@@ -139,25 +143,41 @@ __global__ __launch_bounds__(NT) void tail_bwd_reduce_kernel(const TailArgs p, c
       for (int v = 0; v < NV; v++) acc[j][e][v] = 0.f;
     }
   float sdl = 0.f;
+  // (U rows of a lane in flight per iteration: measured 1 -> 4 on this kernel, 28 -> 29 us without and 44 -> 57 us with the weight-gradient
+  // sums -- it is VALU-bound, 12 / 17 operations per element, and the extra live registers cost occupancy; the first layer's kernel below,
+  // 9 operations per element, went 39 -> 21 us with U = 4)
+  constexpr int U = 1;
+  constexpr int STEP = 4 * RPW;
   int l = (int)((r0 + wave * RPW + rg) % p.L);
-  for (long row = r0 + wave * RPW + rg; row < r1; row += 4 * RPW) {
-    const RowDl d = load_dl(dl, row, l, p.L);
-    l += 4 * RPW; while (l >= p.L) l -= p.L;
-    if (g == 0) sdl += d.d0;
+  for (long row = r0 + wave * RPW + rg; row < r1; row += STEP * U) {
+    uint4 v[U][NJ]; RowDl d[U];
+    int lu = l;
 #pragma unroll
-    for (int j = 0; j < NJ; j++) {
-      const uint4 v = *(const uint4*)((const char*)p.y + ((size_t)row * p.ldy + (g + G * j) * E) * sizeof(T));
-      float x[E]; unpack16<T>(v, x);
+    for (int u = 0; u < U; u++) {
+      const long rr = row + (long)u * STEP; const bool ok = rr < r1; const long rc = ok ? rr : r1 - 1;
+      d[u] = load_dl(dl, rr, lu, p.L, rows, ok);
 #pragma unroll
-      for (int e = 0; e < E; e++) {
-        const float z = x[e] * sc[j][e] + sh[j][e];
-        const float xh = (x[e] - mean[j][e]) * rstd[j][e];
-        const float da = fmaf(d.dn, w0[j][e], fmaf(d.d0, w1[j][e], d.dp * w2[j][e]));
-        const float dz = z > 0.f ? da : p.slope * da;
-        acc[j][e][0] += dz; acc[j][e][1] = fmaf(dz, xh, acc[j][e][1]);
-        if constexpr (PG) {
-          const float a = z > 0.f ? z : p.slope * z;
-          acc[j][e][2] = fmaf(a, d.dn, acc[j][e][2]); acc[j][e][3] = fmaf(a, d.d0, acc[j][e][3]); acc[j][e][4] = fmaf(a, d.dp, acc[j][e][4]);
+      for (int j = 0; j < NJ; j++) v[u][j] = *(const uint4*)((const char*)p.y + ((size_t)rc * p.ldy + (g + G * j) * E) * sizeof(T));
+      lu += STEP; while (lu >= p.L) lu -= p.L;
+    }
+    l = lu;
+#pragma unroll
+    for (int u = 0; u < U; u++) {
+      if (g == 0) sdl += d[u].d0;
+#pragma unroll
+      for (int j = 0; j < NJ; j++) {
+        float x[E]; unpack16<T>(v[u][j], x);
+#pragma unroll
+        for (int e = 0; e < E; e++) {
+          const float z = x[e] * sc[j][e] + sh[j][e];
+          const float xh = (x[e] - mean[j][e]) * rstd[j][e];
+          const float da = fmaf(d[u].dn, w0[j][e], fmaf(d[u].d0, w1[j][e], d[u].dp * w2[j][e]));
+          const float dz = z > 0.f ? da : p.slope * da;
+          acc[j][e][0] += dz; acc[j][e][1] = fmaf(dz, xh, acc[j][e][1]);
+          if constexpr (PG) {
+            const float a = z > 0.f ? z : p.slope * z;
+            acc[j][e][2] = fmaf(a, d[u].dn, acc[j][e][2]); acc[j][e][3] = fmaf(a, d[u].d0, acc[j][e][3]); acc[j][e][4] = fmaf(a, d[u].dp, acc[j][e][4]);
+          }
         }
       }
     }
@@ -205,7 +225,7 @@ __global__ __launch_bounds__(NT) void tail_bwd_apply_kernel(const TailArgs p, co
     }
   int l = (int)((r0 + wave * RPW + rg) % p.L);
   for (long row = r0 + wave * RPW + rg; row < r1; row += 4 * RPW) {
-    const RowDl d = load_dl(dl, row, l, p.L);
+    const RowDl d = load_dl(dl, row, l, p.L, rows, true);
     l += 4 * RPW; while (l >= p.L) l -= p.L;
 #pragma unroll
     for (int j = 0; j < NJ; j++) {
@@ -238,8 +258,10 @@ struct HeadArgs {
   float slope;
   int B, L, Lo, C0, stride;           // input / output positions per sample; pad_l = 1
 };
-template <typename T> __device__ __forceinline__ float head_x(const HeadArgs& p, long base, int i) {      // x[b][i], zero outside the sample
-  return (i >= 0 && i < p.L) ? ld_f32((const T*)p.x + base + i) : 0.f;
+template <typename T> __device__ __forceinline__ float head_x(const HeadArgs& p, long base, int i) {      // x[b][i], zero outside the sample (branch-free: clamped load + select)
+  const int ic = i < 0 ? 0 : (i >= p.L ? p.L - 1 : i);
+  const float v = ld_f32((const T*)p.x + base + ic);
+  return (i >= 0 && i < p.L) ? v : 0.f;
 }
 
 // parameter gradients: partial sums per block, planar [dW0 | dW1 | dW2 | db] (4 C0 values)
@@ -263,24 +285,39 @@ __global__ __launch_bounds__(NT) void head_bwd_pg_kernel(const HeadArgs p, float
 #pragma unroll
       for (int v = 0; v < 4; v++) acc[j][e][v] = 0.f;
     }
+  // U rows per lane in flight (branch-free loads on clamped addresses); rows past the range carry a zero gradient chunk and contribute nothing
+  constexpr int U = 4;
+  constexpr int STEP = 4 * RPW;
   long row = r0 + wave * RPW + rg;
   int b = (int)(row / p.Lo), l = (int)(row - (long)b * p.Lo);
-  for (; row < r1; row += 4 * RPW) {
-    const long xb = (long)b * p.L; const int i0 = l * p.stride - 1;
-    const float xm = head_x<T>(p, xb, i0), x0 = head_x<T>(p, xb, i0 + 1), xp = head_x<T>(p, xb, i0 + 2);
+  for (; row < r1; row += STEP * U) {
+    uint4 v[U][NJ]; float xm[U], x0[U], xp[U];
 #pragma unroll
-    for (int j = 0; j < NJ; j++) {
-      const uint4 v = *(const uint4*)((const char*)p.da + ((size_t)row * p.ldda + (g + G * j) * E) * sizeof(T));
-      float d[E]; unpack16<T>(v, d);
+    for (int u = 0; u < U; u++) {
+      const long rr = row + (long)u * STEP; const bool ok = rr < r1; const long rc = ok ? rr : r1 - 1;
+      const int bc = b < p.B ? b : p.B - 1;
+      const long xb = (long)bc * p.L; const int i0 = l * p.stride - 1;
+      xm[u] = head_x<T>(p, xb, i0); x0[u] = head_x<T>(p, xb, i0 + 1); xp[u] = head_x<T>(p, xb, i0 + 2);
 #pragma unroll
-      for (int e = 0; e < E; e++) {
-        const float z = fmaf(xp, w2[j][e], fmaf(x0, w1[j][e], fmaf(xm, w0[j][e], bs[j][e])));
-        const float dy = z > 0.f ? d[e] : p.slope * d[e];
-        acc[j][e][0] = fmaf(dy, xm, acc[j][e][0]); acc[j][e][1] = fmaf(dy, x0, acc[j][e][1]); acc[j][e][2] = fmaf(dy, xp, acc[j][e][2]);
-        acc[j][e][3] += dy;
+      for (int j = 0; j < NJ; j++) {
+        const uint4 t = *(const uint4*)((const char*)p.da + ((size_t)rc * p.ldda + (g + G * j) * E) * sizeof(T));
+        v[u][j] = ok ? t : make_uint4(0u, 0u, 0u, 0u);
       }
+      l += STEP; while (l >= p.Lo) { l -= p.Lo; b++; }
     }
-    l += 4 * RPW; while (l >= p.Lo) { l -= p.Lo; b++; }
+#pragma unroll
+    for (int u = 0; u < U; u++)
+#pragma unroll
+      for (int j = 0; j < NJ; j++) {
+        float d[E]; unpack16<T>(v[u][j], d);
+#pragma unroll
+        for (int e = 0; e < E; e++) {
+          const float z = fmaf(xp[u], w2[j][e], fmaf(x0[u], w1[j][e], fmaf(xm[u], w0[j][e], bs[j][e])));
+          const float dy = z > 0.f ? d[e] : p.slope * d[e];
+          acc[j][e][0] = fmaf(dy, xm[u], acc[j][e][0]); acc[j][e][1] = fmaf(dy, x0[u], acc[j][e][1]); acc[j][e][2] = fmaf(dy, xp[u], acc[j][e][2]);
+          acc[j][e][3] += dy;
+        }
+      }
   }
   // the 64 / G row groups of a wave hold partial sums of the SAME channels: add them with shuffles first (lanes g, g + G, ...), so that only
   // one lane per channel and wave reaches the LDS accumulator (with G = 8 the direct form was 32 lanes serialising on every address)
@@ -329,13 +366,15 @@ __global__ __launch_bounds__(NT) void head_bwd_dx_kernel(const HeadArgs p, float
   for (int rb = wave * RPW; rb < nrow; rb += 4 * RPW) {
     const int r = rb + rg, l = l0 - 1 + r;
     const bool ok = r < nrow && l >= 0 && l < p.Lo;
+    const int lc = l < 0 ? 0 : (l >= p.Lo ? p.Lo - 1 : l);      // (branch-free loads: a row outside the sample reads a clamped one and is zeroed)
     float q0 = 0.f, q1 = 0.f, q2 = 0.f;
-    if (ok) {
-      const int i0 = l * p.stride - 1;
+    {
+      const int i0 = lc * p.stride - 1;
       const float xm = head_x<T>(p, xb, i0), x0 = head_x<T>(p, xb, i0 + 1), xp = head_x<T>(p, xb, i0 + 2);
 #pragma unroll
       for (int j = 0; j < NJ; j++) {
-        const uint4 v = *(const uint4*)((const char*)p.da + (((size_t)b * p.Lo + l) * p.ldda + (g + G * j) * E) * sizeof(T));
+        const uint4 t = *(const uint4*)((const char*)p.da + (((size_t)b * p.Lo + lc) * p.ldda + (g + G * j) * E) * sizeof(T));
+        const uint4 v = ok ? t : make_uint4(0u, 0u, 0u, 0u);
         float d[E]; unpack16<T>(v, d);
 #pragma unroll
         for (int e = 0; e < E; e++) {
@@ -458,7 +497,7 @@ int disc_head_bwd(eegldm_ctx* ctx, int dtype, const void* da, long ldda, const v
   const long rows = (long)B * Lo;
   if (dw) {
     const int nvals = 4 * C0;
-    long nb = (long)ctx->num_cu * 2; if (nb > (rows + 63) / 64) nb = (rows + 63) / 64;      // long blocks: a block's constants, its zeroing, its LDS fold and its partial row cost as much as ~400 rows of the loop
+    long nb = (long)ctx->num_cu * 4; if (nb > (rows + 63) / 64) nb = (rows + 63) / 64;
     if (nb < 1) nb = 1;
     const long rpb = (rows + nb - 1) / nb; nb = (rows + rpb - 1) / rpb;
     float* parts = (float*)((char*)ctx->scratch + (8u << 20));

@@ -45,6 +45,7 @@ int conv_skinny_ex(eegldm_ctx* ctx, int dtype, const void* x, long ldx, const vo
                    const SkinnyGn* gn, float2* part_out, const SkinnyExt* ext = nullptr);
 int conv_skinny_try(eegldm_ctx* ctx, int dtype, const void* x, long ldx, const void* w, int Cin, int Cout, int taps, const float* bias,
                     const float* rowvec, long ld_rowvec, const void* resid, long ldr, void* y, long ldy, int B, int L);
+int conv_ws2_try(eegldm_ctx*, int dtype, int dgrad, const void* x, const void* w, const float* bias, void* y, int B, int Lo);      // stride-2 128 -> 256 over paired rows
 int conv_ws_try(eegldm_ctx*, int dtype, const void* x, long ldx, const void* w, int Cin, int Cout, int transposed, const float* bias,
                 const float* rowvec, long ld_rowvec, const void* resid, long ldr, void* y, long ldy, int B, int L);
 

@@ -37,6 +37,11 @@ int op_conv_fwd(eegldm_ctx* ctx, int dtype, const void* x, long ldx, const void*
     const int rc = conv_skinny_try(ctx, dtype, x, ldx, w, Cin, Cout, K, bias, rowvec, ld_rowvec, resid, ldr, y, ldy, B, Lin);
     if (rc != 0) return rc < 0 ? rc : 0;
   }
+  // stride 2, 128 -> 256 channels (the discriminator's third layer): the paired-row weight-stationary kernel of conv_ws.hip
+  if (K == 3 && stride == 2 && pad_l == 1 && pad_r == 1 && Cin == 128 && Cout == 256 && ldx == Cin && ldy == Cout && Lin == 2 * Lout && !rowvec && !resid) {
+    const int rc = conv_ws2_try(ctx, dtype, 0, x, w, bias, y, B, Lout);
+    if (rc != 0) return rc < 0 ? rc : 0;
+  }
   if (K == 3 && stride == 1 && pad_l == 1 && pad_r == 1) {      // HBM-bound wide-and-shallow layers: weights stay in registers (conv_ws.hip)
     const int rc = conv_ws_try(ctx, dtype, x, ldx, w, Cin, Cout, 0, bias, rowvec, ld_rowvec, resid, ldr, y, ldy, B, Lin);
     if (rc != 0) return rc < 0 ? rc : 0;
@@ -89,6 +94,10 @@ int op_conv_dgrad(eegldm_ctx* ctx, int dtype, const void* dy, long lddy, const v
     return dconv_run(ctx, dtype, true, dy, lddy, w, nullptr, resid, ldr, dx, lddx, B, Lin, Lout, Cin, Cout, K, stride, pad_l);
   if (K == 3 && stride == 1 && pad_l == 1 && pad_r == 1) {
     const int rc = conv_ws_try(ctx, dtype, dy, lddy, w, Cin, Cout, 1, nullptr, nullptr, 0, resid, ldr, dx, lddx, B, Lin);
+    if (rc != 0) return rc < 0 ? rc : 0;
+  }
+  if (K == 3 && stride == 2 && pad_l == 1 && pad_r == 1 && Cin == 128 && Cout == 256 && lddx == Cin && lddy == Cout && Lin == 2 * Lout && !resid) {
+    const int rc = conv_ws2_try(ctx, dtype, 1, dy, w, nullptr, dx, B, Lout);
     if (rc != 0) return rc < 0 ? rc : 0;
   }
   // data gradient of the stride-2 64 -> 128 conv: a stride-1 weight-stationary conv over dy that writes PAIRS of dx rows (see op_conv_fwd)

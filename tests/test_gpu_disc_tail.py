@@ -139,3 +139,41 @@ def test_stride2_conv_on_the_weight_stationary_kernel(dtype, B, L, bias):
     G.assert_close(G.ncl(dx1, B, L), xr.grad, **gtol, name="dx (weight-stationary route)")
     assert rel_l2(y1, y0) < 1e-2 and rel_l2(dx1, dx0) < 1e-2      # same product, other summation order
     assert not torch.equal(y1, y0) or B * Lo < 16384              # (the two routes are different kernels: identical bits would mean the registration was not used)
+
+
+@pytest.mark.parametrize("dtype", ["bfloat16", "float16"])
+@pytest.mark.parametrize("B,L,bias", [(32, 768, False), (12, 1472, True), (3, 128, True)])
+def test_stride2_conv_128_256_on_the_paired_row_kernel(dtype, B, L, bias, env_switches):
+    """Conv1d(128 -> 256, k 3, stride 2, padding 1) -- the discriminator's third layer -- forward and data gradient on conv3_ws2_kernel (paired rows,
+    weight-stationary, 32-row tiles) against torch fp32 on the rounded operands and against the general kernel (EEGLDM_NO_CONV_WS=1).  The last
+    shape is below the kernel's row threshold and stays on the general path in both runs."""
+    import math
+    import torch.nn.functional as F
+    import gpu_util as G
+    dt = G.BF16 if dtype == "bfloat16" else G.F16
+    tdt = G.TDT[dt]
+    Cin, Cout = 128, 256
+    x = torch.from_numpy(normal((B, Cin, L), seed=1)).to(tdt).float()
+    w = (torch.from_numpy(normal((Cout, Cin, 3), seed=2)) / math.sqrt(3 * Cin)).to(tdt).float()
+    b = torch.from_numpy(normal((Cout,), seed=3)) if bias else None
+    xr = x.clone().requires_grad_(True)
+    y_ref = F.conv1d(F.pad(xr, (1, 1)), w, b, stride=2)
+    Lo = y_ref.shape[-1]
+    dy = torch.from_numpy(normal((B, Cout, Lo), seed=4)).to(tdt).float()
+    y_ref.backward(dy)
+    c = G.ctx()
+    xd, wd, dyd = G.nlc(x, dt), G.pack_w(w, dt), G.nlc(dy, dt)
+    bd = b.to(G.DEV) if bias else None
+
+    def run():
+        y = torch.empty(B * Lo, Cout, device=G.DEV, dtype=tdt); dx = torch.empty(B * L, Cin, device=G.DEV, dtype=tdt)
+        G.check(G.lib.eegldm_conv1d_fwd(c.h, G.ptr(xd), Cin, G.ptr(wd), G.ptr(bd), G.ptr(y), Cout, B, L, Cin, Cout, 3, 2, 1, 1, None, 0, None, 0, dt))
+        G.check(G.lib.eegldm_conv1d_bwd_data(c.h, G.ptr(dyd), Cout, G.ptr(wd), G.ptr(dx), Cin, B, L, Cin, Cout, 3, 2, 1, 1, None, 0, dt))
+        torch.cuda.synchronize()
+        return y, dx
+    y1, dx1 = run()
+    env_switches(EEGLDM_NO_CONV_WS="1")
+    y0, dx0 = run()
+    G.assert_close(G.ncl(y1, B, Lo), y_ref, **G.TOL[dt], name="y (paired-row kernel)")
+    G.assert_close(G.ncl(dx1, B, L), xr.grad, **G.GTOL[dt], name="dx (paired-row kernel)")
+    assert rel_l2(y1, y0) < 1e-2 and rel_l2(dx1, dx0) < 1e-2
