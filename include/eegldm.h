@@ -36,7 +36,10 @@ extern "C" {
 
 /* 4: + eegldm_ctx_stream, eegldm_linear_bwd, eegldm_disc_feature, eegldm_usleep_*, eegldm_feature_moments (additive).
  * 6 (round 5): + EEGLDM_F16, eegldm_conv1d_skip_fwd, eegldm_conv1d_fwd_qstats, eegldm_groupnorm_fwd_qstats, eegldm_batchnorm_lrelu_*,
- *    eegldm_kl_reparam_*, eegldm_conv1d_pack_kblocked_k, eegldm_avgpool2_*, eegldm_nearest2_* (additive). */
+ *    eegldm_kl_reparam_*, eegldm_conv1d_pack_kblocked_k, eegldm_avgpool2_*, eegldm_nearest2_* (additive).
+ * 7 (round 6): + eegldm_resblock_create / eegldm_attnblock_create / eegldm_block_*, eegldm_timestep_embedding (primitive-granular UNet blocks),
+ *    eegldm_conv1d_fwd_gn (GroupNorm + SiLU on the conv's operand load), eegldm_conv1d_pack_stride2; REMOVED: eegldm_conv1d_fwd_qstats and
+ *    eegldm_groupnorm_fwd_qstats (round 5's GroupNorm-from-producer-moments path measured no gain and was taken out, HISTORY.md). */
 #define EEGLDM_ABI_VERSION 7
 
 /* Storage / operand type of activations and compute-copy weights (accumulation, statistics, master weights and optimizer state are
@@ -141,16 +144,6 @@ int eegldm_conv1d_fwd(eegldm_ctx*, const void* x, long ldx, const void* w, const
                       void* y, long ldy, int B, int Lin, int Cin, int Cout, int K, int stride,
                       int pad_l, int pad_r, const float* rowvec, long ld_rowvec,
                       const void* resid, long ld_resid, int dtype);
-/* eegldm_conv1d_fwd that also leaves the per-(sample, channel quad) moments of its output: qstats[(b * Cout/4 + c/4) * 2 + {0,1}] +=
- * (sum, sum of squares) over the sample's Lout positions of output channels c .. c+3 (doubles, ADDED: zero them first).  Produced in
- * the epilogue of the big-tile kernels only (16-bit, stride 1, Cout % 256 == 0, B*Lout and Lout multiples of 192; taken from the
- * fp32 values in front of the 16-bit rounding); *filled (host) says whether the kernel that ran did.  Consumer:
- * eegldm_groupnorm_fwd_qstats.  No reference counterpart: it is how `normalization(channels)` behind a conv (unet.py:261-263,
- * 287-291) becomes one streaming pass. */
-int eegldm_conv1d_fwd_qstats(eegldm_ctx*, const void* x, long ldx, const void* w, const float* bias,
-                             void* y, long ldy, int B, int Lin, int Cin, int Cout, int K, int stride,
-                             int pad_l, int pad_r, const float* rowvec, long ld_rowvec,
-                             const void* resid, long ld_resid, int dtype, double* qstats, int* filled);
 /* The ResBlock tail `self.skip_connection(x) + h` with h = out_layers' conv (unet.py:302,327) as one operator:
  *   y = conv1d(x; w [3][Cout][Cin], pad 1) + bias + conv1d(x2; w2 [1][Cout][Cin2]) + bias2 (+ rowvec per sample)
  * With 16-bit operands, Cout % 256 == 0, B*L and L multiples of 192 and K-blocked copies of BOTH weights registered
@@ -184,12 +177,6 @@ int eegldm_linear_bwd(eegldm_ctx*, const void* x, long ldx, const void* w, const
 int eegldm_groupnorm_fwd(eegldm_ctx*, const void* x, long ldx, const float* gamma, const float* beta,
                          void* y, long ldy, float* stats, int B, int L, int C, int G, float eps,
                          int fuse_silu, int resample, void* xr, long ldxr, int dtype);
-/* GroupNorm(+SiLU) forward (no resampling) of a 16-bit tensor from the moments its producer(s) left (eegldm_conv1d_fwd_qstats): qs_a
- * covers channel quads [0, nq_a), qs_b (optional: a concatenated input [h | skip], unet.py:553) quads [nq_a, nq_a + nq_b); one
- * streaming pass, writes y and the (mean, rstd) pairs `stats` exactly like eegldm_groupnorm_fwd.  Error if not eligible. */
-int eegldm_groupnorm_fwd_qstats(eegldm_ctx*, const void* x, long ldx, const float* gamma, const float* beta,
-                                void* y, long ldy, float* stats, int B, int L, int C, int G, float eps,
-                                int fuse_silu, const double* qs_a, int nq_a, const double* qs_b, int nq_b, int dtype);
 int eegldm_groupnorm_bwd(eegldm_ctx*, const void* x, long ldx, const float* gamma, const float* beta,
                          const float* stats, const void* dy, long lddy, void* dx, long lddx,
                          float* dgamma, float* dbeta, int B, int L, int C, int G, int fuse_silu,

@@ -63,8 +63,6 @@ SIGNATURES = {
     "eegldm_avgpool2_bwd": [_vp, _vp, _l, _vp, _l, _i, _i, _i, _i],
     "eegldm_nearest2_fwd": [_vp, _vp, _l, _vp, _l, _i, _i, _i, _i],
     "eegldm_nearest2_bwd": [_vp, _vp, _l, _vp, _l, _i, _i, _i, _i],
-    "eegldm_conv1d_fwd_qstats": [_vp, _vp, _l, _vp, _vp, _vp, _l, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _l, _vp, _l, _i, _vp, C.POINTER(_i)],
-    "eegldm_groupnorm_fwd_qstats": [_vp, _vp, _l, _vp, _vp, _vp, _l, _vp, _i, _i, _i, _i, _f, _i, _vp, _i, _vp, _i, _i],
     "eegldm_conv1d_skip_fwd": [_vp, _vp, _l, _vp, _vp, _vp, _l, _vp, _vp, _vp, _l, _i, _i, _i, _i, _i, _vp, _l, _i],
     "eegldm_comm_unique_id": [_vp],
     "eegldm_comm_create": [_vp, _vp, _i, _i, _vp],

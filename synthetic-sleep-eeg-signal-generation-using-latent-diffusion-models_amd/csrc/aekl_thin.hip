@@ -664,9 +664,8 @@ size_t lds_bytes(const ThinProgram& p) {
 }
 // backward kernel: up to two spare LDS tensors behind everything else for the tape prefetch (as many as the 160 KB allow)
 size_t lds_bytes_bwd(const ThinProgram& p, int* sp_off, int* nspare) {
-  EEG_ENV_VAR(bool, off, getenv("EEGLDM_THIN_NO_DMA_PREFETCH") != nullptr);
   const size_t base = (lds_bytes(p) + 15) & ~(size_t)15, one = sizeof(float) * ((size_t)p.maxt + 256);
-  int n = off ? 0 : 2;
+  int n = 2;
   while (n > 0 && base + n * one > 160 * 1024) n--;
   *sp_off = (int)base; *nspare = n;
   return base + n * one;

@@ -77,22 +77,6 @@ int ctx_join(eegldm_ctx* c) {
   HIP_TRY(hipStreamWaitEvent(c->stream, c->ev_join, 0));
   return 0;
 }
-int ctx_aux_fork(eegldm_ctx* c) {
-  if (!c->aux) {
-    HIP_TRY(hipStreamCreateWithFlags(&c->aux, hipStreamNonBlocking));
-    HIP_TRY(hipEventCreateWithFlags(&c->ev_aux_fork, hipEventDisableTiming));
-    HIP_TRY(hipEventCreateWithFlags(&c->ev_aux_join, hipEventDisableTiming));
-  }
-  HIP_TRY(hipEventRecord(c->ev_aux_fork, c->stream));
-  HIP_TRY(hipStreamWaitEvent(c->aux, c->ev_aux_fork, 0));
-  return 0;
-}
-int ctx_aux_join(eegldm_ctx* c) {
-  if (!c->aux) return 0;
-  HIP_TRY(hipEventRecord(c->ev_aux_join, c->aux));
-  HIP_TRY(hipStreamWaitEvent(c->stream, c->ev_aux_join, 0));
-  return 0;
-}
 extern "C" int eegldm_ctx_destroy(eegldm_ctx* c) {
   if (!c) return 0;
   hipSetDevice(c->device);
@@ -105,7 +89,6 @@ extern "C" int eegldm_ctx_destroy(eegldm_ctx* c) {
   if (c->det_buf) hipFree(c->det_buf);
   if (c->owns_stream) hipStreamDestroy(c->stream);
   if (c->side) { hipStreamDestroy(c->side); hipEventDestroy(c->ev_fork); hipEventDestroy(c->ev_join); }
-  if (c->aux) { hipStreamSynchronize(c->aux); hipStreamDestroy(c->aux); hipEventDestroy(c->ev_aux_fork); hipEventDestroy(c->ev_aux_join); }
   delete c;
   if (g_eeg_live_ctx.load() > 0) g_eeg_live_ctx--;
   return 0;
@@ -113,7 +96,6 @@ extern "C" int eegldm_ctx_destroy(eegldm_ctx* c) {
 extern "C" int eegldm_ctx_sync(eegldm_ctx* c) {
   EEG_CHECK(c, "null ctx");
   HIP_TRY(hipStreamSynchronize(c->stream));
-  if (c->aux) HIP_TRY(hipStreamSynchronize(c->aux));      // (every call joins aux before it returns; belt and braces)
   return 0;
 }
 extern "C" int eegldm_timer_start(eegldm_ctx* c) {

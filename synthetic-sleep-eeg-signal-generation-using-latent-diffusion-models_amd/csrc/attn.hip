@@ -534,8 +534,7 @@ int launch_chain_q(eegldm_ctx* ctx, const ChainArgs& a, int B) {
   static DevOnce attr;
   if (LDS > 48 * 1024 && attr.need(ctx->device)) HIP_TRY(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
   ChainArgs ax = a;
-  EEG_ENV_VAR(bool, no_xcd, getenv("EEGLDM_ATTN_NO_XCD") != nullptr);
-  ax.xcd = (!no_xcd && T / QR > 1 && B % 8 == 0) ? 1 : 0;
+  ax.xcd = (T / QR > 1 && B % 8 == 0) ? 1 : 0;
   EEG_ENV_VAR(bool, stamps, getenv("EEGLDM_ATTN_STAMPS") != nullptr);
   static unsigned long long* sbuf = nullptr;
   if (stamps && !sbuf) HIP_TRY(hipMalloc(&sbuf, 64));

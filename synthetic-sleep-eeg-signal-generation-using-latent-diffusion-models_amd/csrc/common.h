@@ -80,11 +80,6 @@ struct eegldm_ctx {
   hipStream_t side = nullptr;
   hipEvent_t ev_fork = nullptr, ev_join = nullptr;
   bool side_on = false;
-  // auxiliary stream (created on first use, ctx_aux_fork): the one place the library overlaps two of its own kernels by default -- the
-  // whole-network backward kernel of a thin autoencoder (latency-bound: one 512-thread workgroup per CU, MFMA pipe and HBM idle) beside
-  // the discriminator's own forward / backward launches of the same GAN step (aekl.hip eegldm_aekl_train_step)
-  hipStream_t aux = nullptr;
-  hipEvent_t ev_aux_fork = nullptr, ev_aux_join = nullptr;
   // optional per-launch HIP-event profiling of the GEMM family (bench.py roofline leg)
   bool prof_on = false;
   std::vector<ProfRec> prof;
@@ -123,8 +118,6 @@ static inline size_t dtype_size(int dt) { return dt == EEGLDM_F32 ? 4 : 2; }
 // side waits for everything enqueued on the main stream so far / main waits for everything enqueued on the side stream
 int ctx_fork(eegldm_ctx* c);
 int ctx_join(eegldm_ctx* c);
-int ctx_aux_fork(eegldm_ctx* c);      // aux waits for everything enqueued on the main stream so far (creates the stream on first use)
-int ctx_aux_join(eegldm_ctx* c);      // the main stream waits for everything enqueued on aux so far
 // RAII: launches inside the scope go to the side stream (pure GEMM work only: the context scratch belongs to the main stream)
 struct SideScope {
   eegldm_ctx* c; hipStream_t saved;
@@ -239,9 +232,6 @@ struct GemmArgs {
   // GROUPED weight gradients (round 3): `batch` problems of identical shape and leading dimensions but unrelated addresses -- the same
   // conv shape in different layers of the network -- run as ONE launch.  ngroup > 0: problem b reads A = grpA[b], B = grpB[b] (instead
   // of A + b * sAb ...), adds its fused column sums into grpCS[b], and its folded result goes to grpDst[b] (gemm_launch_grouped).
-  // statistics epilogue (big-tile forward kernels only): per-(sample, channel quad) sums / sums of squares of the output, [M / qstats_L][N / 4][2]
-  // doubles, added atomically; *qstats_done is set to 1 by the launcher that takes it (every other kernel leaves both untouched)
-  double* qstats; int qstats_L; int* qstats_done;
   int ngroup;
   const struct GemmGroup* grp;       // DEVICE table of the group's pointers (a by-value array indexed by the block's problem number made
                                      // hipcc spill the whole argument struct to scratch: 672 bytes per lane in 20 instantiations)

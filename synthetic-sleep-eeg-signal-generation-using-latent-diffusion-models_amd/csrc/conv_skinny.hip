@@ -323,8 +323,7 @@ void sk_launch(eegldm_ctx* ctx, const SkArgs& a, int rf, int cf, int dtype) {
 }  // namespace
 
 static long sk_max_tiles() {
-  EEG_ENV_VAR(long, v, getenv("EEGLDM_CONV_SKINNY_MAX_TILES") ? atol(getenv("EEGLDM_CONV_SKINNY_MAX_TILES")) : 32);
-  return v;
+  return 32;
 }
 // shape test shared by conv_skinny_try and the callers that want to plan a fused GroupNorm around it (net.hip)
 bool conv_skinny_takes(int dtype, int Cin, int Cout, int taps, int B, int L) {

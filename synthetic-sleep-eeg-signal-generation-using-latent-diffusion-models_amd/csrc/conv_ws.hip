@@ -37,7 +37,6 @@ struct WsArgs {
   bf16_t* y; long ldy;
   int M, L, N, ntiles, tiles_per_block;
   const void* zero_page;
-  int dbg;
 };
 
 typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
@@ -127,15 +126,15 @@ __global__ __launch_bounds__(256, 2) void conv3_ws_kernel(const WsArgs p) {
     for (int i = 0; i < 4; i++) {
       const int c = tid + 256 * i, row = c >> 4, ch = c & 15;
       const uint4 v = *(const uint4*)(sOut + row * WS_ROW_BYTES + ((ch ^ (row & 15)) * 16));
-      if (!(p.dbg & 16)) *(uint4*)(p.y + (row0 + row) * p.ldy + blockIdx.y * 128 + ch * 8) = v;
+      *(uint4*)(p.y + (row0 + row) * p.ldy + blockIdx.y * 128 + ch * 8) = v;
     }
   };
 
   for (int t = t_begin; t < t_end; t++) {
     const int buf = (t - t_begin) % WS_RING;
     const long row0 = (long)t * WS_ROWS;
-    if (t + 1 < t_end && !(p.dbg & 2)) asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    if (p.dbg & 4) __syncthreads(); else ws_barrier();
+    if (t + 1 < t_end) asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    ws_barrier();
     if (t > t_begin) store_tile(t - 1);
     // per-sample addend (bias + time-embedding row): reloaded only when the tile enters another sample (a hipcc-visible load: its wait
     // drains the DMA queue, once per 12 tiles at L = 768)
@@ -160,7 +159,7 @@ __global__ __launch_bounds__(256, 2) void conv3_ws_kernel(const WsArgs p) {
         for (int cf = 0; cf < 2; cf++) rr[rf][cf] = ws_load8(p.resid + (row0 + rf * 16 + lm) * p.ldr + n0 + cf * 16 + q * 4);
     }
     const bool more = t + 2 < t_end;
-    if (more && !(p.dbg & 32)) issue_dma(t + 2);
+    if (more) issue_dma(t + 2);
 
     const char* sA = smem + buf * WS_ABUF;
     f32x4 acc[4][2];
@@ -168,7 +167,6 @@ __global__ __launch_bounds__(256, 2) void conv3_ws_kernel(const WsArgs p) {
     for (int rf = 0; rf < 4; rf++)
 #pragma unroll
       for (int cf = 0; cf < 2; cf++) acc[rf][cf] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    if (!(p.dbg & 8))
 #pragma unroll
     for (int rf = 0; rf < 4; rf++)
 #pragma unroll
@@ -187,10 +185,10 @@ __global__ __launch_bounds__(256, 2) void conv3_ws_kernel(const WsArgs p) {
       // residual(t) landed (DMA(t+2), issued after it, may stay in flight).  ONE statement names the registers ("+v" keeps every use
       // below it): two alternative statements in an if / else made hipcc reconcile their register assignments with v_mov copies
       // BEFORE the wait in one arm -- copies of registers whose data had not landed yet (wrong residuals in each block's last tiles)
-      if (!more || (p.dbg & 1)) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      if (!more) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       asm volatile("s_waitcnt vmcnt(4)" : "+v"(rr[0][0]), "+v"(rr[0][1]), "+v"(rr[1][0]), "+v"(rr[1][1]), "+v"(rr[2][0]), "+v"(rr[2][1]), "+v"(rr[3][0]), "+v"(rr[3][1]) :: "memory");
     }
-    if (p.dbg & 4) __syncthreads(); else ws_barrier();             // every wave has read the previous output tile (store_tile above) before it is overwritten
+    ws_barrier();             // every wave has read the previous output tile (store_tile above) before it is overwritten
     // ---- epilogue: one rounding to bf16 in the fragment layout, into the swizzled LDS output tile
 #pragma unroll
     for (int rf = 0; rf < 4; rf++)
@@ -205,7 +203,7 @@ __global__ __launch_bounds__(256, 2) void conv3_ws_kernel(const WsArgs p) {
         *(uint2*)(sOut + row * WS_ROW_BYTES + ((ch ^ (row & 15)) * 16) + (q & 1) * 8) = make_uint2(pack16x2<T16>(v0, v1), pack16x2<T16>(v2, v3));
       }
   }
-  if (p.dbg & 4) __syncthreads(); else ws_barrier();
+  ws_barrier();
   store_tile(t_end - 1);
 }
 
@@ -361,17 +359,15 @@ int conv_ws_try(eegldm_ctx* ctx, int dtype, const void* x, long ldx, const void*
   if (off || (dtype != EEGLDM_BF16 && dtype != EEGLDM_F16) || Kred != 128 || N % 128 != 0 || L % WS_ROWS != 0 || M >= (1L << 31)) return 0;
   if (ldx % 8 != 0 || ldy % 8 != 0 || (resid && ldr % 4 != 0) || (rowvec && ld_rowvec % 4 != 0)) return 0;
   if (((size_t)x | (size_t)y | (size_t)w) % 16 != 0 || (resid && (size_t)resid % 8 != 0)) return 0;
-  EEG_ENV_VAR(long, min_rows, getenv("EEGLDM_CONV_WS_MIN_ROWS") ? atol(getenv("EEGLDM_CONV_WS_MIN_ROWS")) : 16384);
+  constexpr long min_rows = 16384;
   if (M < min_rows) return 0;                      // few tiles per block: the weight fetch is not amortised
   WsArgs a = {};
   a.x = (const bf16_t*)x; a.ldx = ldx; a.w = (const bf16_t*)w;
   if (!transposed) { a.sWt = (long)Cout * Cin; a.sWn = Cin; a.sWk = 1; a.tflip = 0; }
   else { a.sWt = (long)Cout * Cin; a.sWn = 1; a.sWk = Cin; a.tflip = 1; }
   a.bias = bias; a.rowvec = rowvec; a.ld_rowvec = ld_rowvec; a.resid = (const bf16_t*)resid; a.ldr = ldr;
-  EEG_ENV_VAR(int, dbg, getenv("EEGLDM_CONV_WS_DBG") ? atoi(getenv("EEGLDM_CONV_WS_DBG")) : 0);
-  a.dbg = dbg;
   a.y = (bf16_t*)y; a.ldy = ldy; a.M = (int)M; a.L = L; a.N = N; a.ntiles = (int)(M / WS_ROWS); a.zero_page = ctx->zero_page;
-  EEG_ENV_VAR(int, bpc, getenv("EEGLDM_CONV_WS_BLOCKS_PER_CU") ? atoi(getenv("EEGLDM_CONV_WS_BLOCKS_PER_CU")) : 2);
+  constexpr int bpc = 2;
   const int ny = N / 128;
   long nbx = (long)ctx->num_cu * bpc / ny; if (nbx < 1) nbx = 1; if (nbx > a.ntiles) nbx = a.ntiles;
   a.tiles_per_block = (int)((a.ntiles + nbx - 1) / nbx);

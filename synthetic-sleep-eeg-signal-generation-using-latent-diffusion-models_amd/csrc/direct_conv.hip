@@ -735,7 +735,7 @@ bool conv_is_thin(int Cin, int Cout, int dtype) {
 // true when dconv_run takes the register-resident thin-input kernel for this forward conv (the one that can fuse a LeakyReLU)
 bool dconv_fuses_act(int dtype, int Cin, int Cout, int K, long ldout) {
   const int G = dtype == EEGLDM_F32 ? 4 : 8;
-  EEG_ENV_VAR(bool, reg_ok, getenv("EEGLDM_DCONV_NO_REG") == nullptr); EEG_ENV_VAR(bool, fuse_ok, getenv("EEGLDM_DCONV_NO_FUSED_ACT") == nullptr);
+  constexpr bool reg_ok = true, fuse_ok = true;
   const int gpr = Cout / G;
   return reg_ok && fuse_ok && Cin <= 4 && Cout % G == 0 && Cout >= 16 && K <= 3 && ldout % G == 0 && ((size_t)K * Cin * Cout + Cout) * 4 <= 48 * 1024 &&
          gpr <= NT && NT % gpr == 0;
@@ -772,9 +772,9 @@ int dconv_run(eegldm_ctx* ctx, int dtype, bool dgrad, const void* in, long ldin,
     if (a.Ci <= 8 && a.Co % G == 0 && a.Co >= 16 && K <= 3 && ldout % G == 0 && (!resid || ldr % G == 0) && ((size_t)K * a.Ci * a.Co + a.Co) * 4 <= 48 * 1024) {
       const long total = rows * (a.Co / G);
       const dim3 g(grid_cap((total + NT - 1) / NT, ctx));
-      EEG_ENV_VAR(bool, reg_ok, getenv("EEGLDM_DCONV_NO_REG") == nullptr);
+      constexpr bool reg_ok = true;
       const int gpr = a.Co / G;
-      EEG_ENV_VAR(bool, seg_ok, getenv("EEGLDM_DCONV_NO_IN1_SEG") == nullptr);
+      constexpr bool seg_ok = true;
       if (seg_ok && a.Ci == 1 && K <= 3 && (dgrad ? stride == 1 : stride <= 2) && gpr <= NT && NT % gpr == 0 && a.Lo >= 64 && a.B <= 65535) {
         constexpr int SEG = 128;
         const dim3 gs((a.Lo + SEG - 1) / SEG, a.B);
@@ -803,7 +803,7 @@ int dconv_run(eegldm_ctx* ctx, int dtype, bool dgrad, const void* in, long ldin,
     const int lpr = a.Ci / G;
     if (a.Co <= 8 && a.Ci % G == 0 && lpr >= 1 && lpr <= 64 && (lpr & (lpr - 1)) == 0 && ldin % G == 0 && (size_t)K * a.Co * a.Ci * 4 <= 48 * 1024 && al == al) {
       const int rpb = NT / lpr;
-      EEG_ENV_VAR(bool, run_ok, getenv("EEGLDM_DCONV_NO_RUN") == nullptr);
+      constexpr bool run_ok = true;
       constexpr int RUN = 8;
       if (run_ok && !dgrad && a.Co == 1 && stride == 1 && K <= 3 && a.Lo % RUN == 0 && a.Li == a.Lo && pad_l <= K - 1 && rows < (1L << 31)) {
         const long nruns = rows / RUN;
@@ -894,7 +894,7 @@ int dconv_wgrad(eegldm_ctx* ctx, int dtype, const void* x, long ldx, const void*
       const int rpb = NT / lpr;
       // few blocks: every block ends with one atomic per weight element on the SAME addresses (2048 blocks cost 460 us in atomics)
       const long E = (long)K * Cout * Cin;
-      EEG_ENV_VAR(bool, in1out_ok, getenv("EEGLDM_DCONV_NO_WGRAD_IN1OUT") == nullptr);
+      constexpr bool in1out_ok = true;
       // blocks per sample: enough blocks to fill the chip four times over (each thread then has <= 8-16 independent row loads in flight)
       int nsegs = (int)((4L * ctx->num_cu + B - 1) / B); if (nsegs < 1) nsegs = 1;
       int segr = (Lout + nsegs - 1) / nsegs; segr = (segr + rpb - 1) / rpb * rpb; nsegs = (Lout + segr - 1) / segr;

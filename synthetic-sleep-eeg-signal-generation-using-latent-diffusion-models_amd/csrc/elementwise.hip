@@ -528,8 +528,7 @@ int ew_fold_partials(eegldm_ctx* ctx, const float* parts, int nparts, int n, flo
   LAUNCH_CHECK(); return 0;
 }
 int ew_softmax(eegldm_ctx* ctx, const float* S, void* P, long rows, int n, int dtype) {
-  EEG_ENV_VAR(bool, no_reg, getenv("EEGLDM_SOFTMAX_NO_REG") != nullptr);
-  if (!no_reg && n % 4 == 0 && n >= 4 && n <= 1024) {
+  if (n % 4 == 0 && n >= 4 && n <= 1024) {
     const dim3 g((unsigned)((rows + 3) / 4));
 #define SMX(K_) DISPATCH_T(dtype, hipLaunchKernelGGL((softmax_reg_kernel<T, K_>), g, dim3(NT), 0, ctx->stream, S, (T*)P, rows, n))
     if (n <= 256) SMX(1); else if (n <= 512) SMX(2); else if (n <= 768) SMX(3); else SMX(4);
@@ -540,8 +539,7 @@ int ew_softmax(eegldm_ctx* ctx, const float* S, void* P, long rows, int n, int d
   LAUNCH_CHECK(); return 0;
 }
 int ew_softmax_bwd(eegldm_ctx* ctx, const float* dP, const void* P, void* dS, long rows, int n, float alpha, int dtype) {
-  EEG_ENV_VAR(bool, no_reg, getenv("EEGLDM_SOFTMAX_NO_REG") != nullptr);
-  if (!no_reg && n % 4 == 0 && n >= 4 && n <= 1024) {
+  if (n % 4 == 0 && n >= 4 && n <= 1024) {
     const dim3 g((unsigned)((rows + 3) / 4));
 #define SMB(K_) DISPATCH_T(dtype, hipLaunchKernelGGL((softmax_bwd_reg_kernel<T, K_>), g, dim3(NT), 0, ctx->stream, dP, (const T*)P, (T*)dS, rows, n, alpha))
     if (n <= 256) SMB(1); else if (n <= 512) SMB(2); else if (n <= 768) SMB(3); else SMB(4);

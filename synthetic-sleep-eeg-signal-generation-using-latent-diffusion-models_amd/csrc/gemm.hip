@@ -72,14 +72,10 @@ template <int BX> __device__ __forceinline__ int tr_swz(int row, int colbyte) {
   // r+8 .. r+11.  Rows of 256 B or more: bit 3 of the row flips a 128-byte half and the two 16-lane groups land on different bank halves.
   // Rows of 128 B (64-wide tiles; 384-byte rows swizzle inside 128-byte windows too): the XOR is confined to (row & 3) and rows r and r+8 meet on
   // the same 32 B -- a 2-way conflict on every B-fragment read of the fused 3-tap weight gradient (SQ_LDS_BANK_CONFLICT = 1.2 cycles per LDS
-  // instruction, 37 % of its LDS-array cycles, tools/r05/s18.sh).  -DEEG_TR_SWZ_NOCONFLICT lets bit 3 of the row flip the low chunk bit there
+  // instruction, 37 % of its LDS-array cycles, tools/r05/s18.sh).  A swizzle that lets bit 3 of the row flip the low chunk bit there
   // (rows r+8 .. r+11 take the chunks rows r .. r+3 leave free): conflicts 4.7 M -> 0, LDS-array cycles 12.6 M -> 7.9 M per launch -- and the
   // kernel is 2 % SLOWER (785-795 vs 809-815 TF/s over the UNet's shapes, LDM step +0.07 ms, tools/r05/s19.sh): the LDS array is 21-34 %
-  // busy either way and is not what the loop waits for.  Measured, not adopted.
-#ifdef EEG_TR_SWZ_NOCONFLICT
-  if constexpr (WIN == 127) return colbyte ^ (((row & 3) ^ ((row >> 3) & 1)) * 32);
-  else
-#endif
+  // busy either way and is not what the loop waits for.  Measured in round 5, not adopted; the variant was removed in round 6 (HISTORY.md).
   return colbyte ^ ((((row & 3) | (((row >> 3) & 1) << 2)) * 32) & WIN);
 }
 
@@ -556,18 +552,10 @@ void gemm_kernel(const GemmArgs p) {   // >= 2 waves per SIMD: <= 256 VGPR+AGPR
   // ring of NSTG stage buffers, loads run NSTG-1 stages ahead; each wave issues exactly IA+IB DMA instructions per
   // stage, so "stage s has landed" == at most (NSTG-2)*(IA+IB) of this wave's DMAs still outstanding.
   constexpr int PER = C::IA + C::IB;
-#ifdef EEG_DMA_BURST
-  constexpr bool INTERLEAVE = false;
-#else
   constexpr bool INTERLEAVE = C::USE_DMA && (C::NSTG == 2 || C::NSTG == 3);
-#endif
   constexpr int NMFMA_STAGE = TAPS * KSUB * C::FM * C::FN;                                  // MFMAs per wave and stage
   constexpr int DMA_FIRST = 1;
-#ifndef EEG_DMA_SPAN_NUM
-#define EEG_DMA_SPAN_NUM 2
-#define EEG_DMA_SPAN_DEN 3
-#endif
-  constexpr int DMA_EVERY = (EEG_DMA_SPAN_NUM * NMFMA_STAGE / EEG_DMA_SPAN_DEN) / PER > 1 ? (EEG_DMA_SPAN_NUM * NMFMA_STAGE / EEG_DMA_SPAN_DEN) / PER : 1;
+  constexpr int DMA_EVERY = (2 * NMFMA_STAGE / 3) / PER > 1 ? (2 * NMFMA_STAGE / 3) / PER : 1;      // the stage's DMA instructions spread over the first two thirds of its MFMAs
   static_assert(!INTERLEAVE || DMA_FIRST + (PER - 1) * DMA_EVERY < NMFMA_STAGE, "every DMA piece needs an MFMA slot");
   if constexpr (C::USE_DMA) {
     issue_stage(0, 0);
@@ -648,64 +636,6 @@ void gemm_kernel(const GemmArgs p) {   // >= 2 waves per SIMD: <= 256 VGPR+AGPR
         }
       }
     };
-#ifdef EEG_WG3_VALU_TAPS      // developer builds only: measured and NOT adopted (round 5)
-    if constexpr (C::WG3 && sizeof(T) == 2) {
-      // Experiment: fewer LDS reads in the fused 3-tap weight gradient.  Per k-sub a wave issues 8 transposed reads for its dY fragments and 12
-      // for the X fragments of the three taps against 24 MFMAs.  A lane's X fragment holds 8 CONSECUTIVE rows of one column, and the
-      // tap-0 / tap-2 fragments are the centre one moved by one row: here only the centre fragment is read transposed, the two rows that
-      // slide in (tile rows R and R + 9) come as 2-byte reads, and the shifted fragments are five v_alignbit per fragment (three shared by
-      // both taps): 24 transposed + 8 short reads per stage instead of 40.  Bit-identical, and 2 % SLOWER over the UNet's shapes (790-800 vs
-      // 808-817 TF/s alternating on one box; per stage 2140 + 520 cycles against 2050 + 460, tools/debug/stage_timing.py): the loop is not
-      // bound by the number of transposed reads -- with two waves per SIMD the matrix pipe is busy 58 % of the loop at a measured 1.87-1.90 GHz
-      // shader clock.
-      auto load_ks = [&](int ks, uint4 (&af)[C::FM], uint4 (&bc)[FN], unsigned (&hl)[FN], unsigned (&hh)[FN]) __attribute__((always_inline)) {
-#pragma unroll
-        for (int i = 0; i < C::FM; i++) af[i] = read_tr_t<T, BM>(smA, ks, wm * (C::FM * 16) + i * 16, lm, q);
-#pragma unroll
-        for (int j = 0; j < FN; j++) {
-          const int x0 = wn * C::BNW + j * 16;
-          bc[j] = read_tr_t<T, BN>(smB, ks, x0, lm, q, 1);
-          const int r0 = ks * 32 + 8 * q, r9 = r0 + 9, cb = (x0 + lm) * 2;
-          hl[j] = *(const unsigned short*)(smB + r0 * C::PITCH_B_TR + tr_swz<BN>(r0, cb));
-          hh[j] = *(const unsigned short*)(smB + r9 * C::PITCH_B_TR + tr_swz<BN>(r9, cb));
-        }
-      };
-      uint4 af[2][C::FM], bc[2][FN]; unsigned hl[2][FN], hh[2][FN];
-      load_ks(0, af[0], bc[0], hl[0], hh[0]);
-      __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-      for (int ks = 0; ks < KSUB; ks++) {
-        const int cur = ks & 1;
-        if (ks + 1 < KSUB) load_ks(ks + 1, af[cur ^ 1], bc[cur ^ 1], hl[cur ^ 1], hh[cur ^ 1]);
-        __builtin_amdgcn_sched_barrier(0);
-        uint4 b0[FN], b2[FN];
-#pragma unroll
-        for (int j = 0; j < FN; j++) {
-          const uint4 c = bc[cur][j];
-          const unsigned m1 = __builtin_amdgcn_alignbit(c.y, c.x, 16), m2 = __builtin_amdgcn_alignbit(c.z, c.y, 16), m3 = __builtin_amdgcn_alignbit(c.w, c.z, 16);
-          b0[j] = make_uint4((c.x << 16) | hl[cur][j], m1, m2, m3);
-          b2[j] = make_uint4(m1, m2, m3, __builtin_amdgcn_alignbit(hh[cur][j], c.w, 16));
-        }
-#pragma unroll
-        for (int t = 0; t < 3; t++)
-#pragma unroll
-          for (int i = 0; i < C::FM; i++)
-#pragma unroll
-            for (int j = 0; j < FN; j++) {
-              mma<T>(af[cur][i], t == 0 ? b0[j] : (t == 1 ? bc[cur][j] : b2[j]), acc[t][i][j]);
-              if constexpr (INTERLEAVE) {
-                constexpr int MPS = C::FM * FN;
-                const int m = (ks * 3 + t) * MPS + i * FN + j;
-                if (!last && m >= DMA_FIRST && (m - DMA_FIRST) % DMA_EVERY == 0 && (m - DMA_FIRST) / DMA_EVERY < PER) {
-                  __builtin_amdgcn_sched_barrier(0);
-                  if (C::NSTG == 2 || s + C::NSTG - 1 < nstages) issue_piece(s + C::NSTG - 1, (s + C::NSTG - 1) % C::NSTG, (m - DMA_FIRST) / DMA_EVERY);
-                  __builtin_amdgcn_sched_barrier(0);
-                }
-              }
-            }
-      }
-    } else
-#endif
     {
     uint4 af[2][C::FM], bf[2][FN];
     load_frags(0, af[0], bf[0]);
@@ -713,9 +643,6 @@ void gemm_kernel(const GemmArgs p) {   // >= 2 waves per SIMD: <= 256 VGPR+AGPR
 #ifdef EEG_STAGE_SPLIT
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); TSTAMP();      // the first fragments of the stage have arrived
     __builtin_amdgcn_sched_barrier(0);
-#endif
-#ifdef EEG_SETPRIO
-    __builtin_amdgcn_s_setprio(EEG_SETPRIO);      // experiment: the wave in its MFMA phase wins issue arbitration against the co-resident block's wave
 #endif
 #pragma unroll
     for (int st = 0; st < NSTEP; st++) {
@@ -766,9 +693,6 @@ void gemm_kernel(const GemmArgs p) {   // >= 2 waves per SIMD: <= 256 VGPR+AGPR
           }
       }
     }
-#ifdef EEG_SETPRIO
-    __builtin_amdgcn_s_setprio(0);
-#endif
     TSTAMP();   // after the MFMA phase of stage s
     if constexpr (!C::USE_DMA) __syncthreads();   // single buffer: reads of stage s done before stage s+1 is written
   };
@@ -1068,24 +992,14 @@ int launch_k(eegldm_ctx* ctx, const GemmArgs& a_in) {
   a.xcd_swizzle = 0;
   if (a_in.xcd_swizzle) {
     if (AMODE == GA_TR && a.splitk > 1) {
-      EEG_ENV_VAR(bool, no_any, getenv("EEGLDM_GEMM_NO_SPLITK_SWIZZLE_ANY") != nullptr);
-      if ((a.batch == 1 || a.ngroup) && a.k_skew == 0.f && !no_any && (long)grid.x * grid.y * a.ztaps > 1) a.xcd_swizzle = 3;   // (also wgrad-by-tap: ztaps = 3; grouped problems)
+      if ((a.batch == 1 || a.ngroup) && a.k_skew == 0.f && (long)grid.x * grid.y * a.ztaps > 1) a.xcd_swizzle = 3;   // (also wgrad-by-tap: ztaps = 3; grouped problems)
       else if (a.batch * a.ztaps == 1 && grid.x * grid.y > 1) {
-        if (a.k_skew == 0.f && !no_any) a.xcd_swizzle = 3;          // equal chunks: contiguous runs, any split count
+        if (a.k_skew == 0.f) a.xcd_swizzle = 3;                    // equal chunks: contiguous runs, any split count
         else if (a.splitk % 8 == 0) a.xcd_swizzle = 2;             // skewed chunks: interleave the splits over the XCDs (mixes chunk lengths)
       }
     }
     else if (grid.x > 1 && grid.y % 8 == 0) a.xcd_swizzle = 1;
   }
-#ifdef EEG_STAGE_TIMING
-  EEG_ENV_VAR(int, lds_pad, getenv("EEGLDM_GEMM_LDS_PAD") ? atoi(getenv("EEGLDM_GEMM_LDS_PAD")) : 0);   // occupancy experiments
-  if (lds_pad) {
-    HIP_TRY(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_TOTAL + lds_pad));
-    hipLaunchKernelGGL(kern, grid, dim3(C::NTHREADS), C::LDS_TOTAL + lds_pad, ctx->stream, a);
-    LAUNCH_CHECK();
-    return 0;
-  }
-#endif
   hipLaunchKernelGGL(kern, grid, dim3(C::NTHREADS), C::LDS_TOTAL, ctx->stream, a);
   LAUNCH_CHECK();
   return 0;
@@ -1100,32 +1014,22 @@ int launch_t(eegldm_ctx* ctx, const GemmArgs& a) {
   }
   if constexpr (AMODE == GA_PLAIN && (WMT == 2 || WMT == 3)) {
     // 1x1 conv / Linear / attention products: same double-buffered DMA ring (K % KSTAGE == 0 on all production shapes)
-    EEG_ENV_VAR(bool, no_dma1, getenv("EEGLDM_GEMM1_NO_DMA") != nullptr);
-    if (!no_dma1 && a.K % KSTAGE == 0 && a.splitk == 1) return launch_k<T, AMODE, BMODE, TAPS, KSUB, BN, STRIDE, WMT, true>(ctx, a);
+    if (a.K % KSTAGE == 0 && a.splitk == 1) return launch_k<T, AMODE, BMODE, TAPS, KSUB, BN, STRIDE, WMT, true>(ctx, a);
   }
-  if constexpr (AMODE == GA_TR && BMODE == GB_TR && (WMT == 2 || WMT == 3 || WMT == 5 || WMT == 6)) {
+  if constexpr (AMODE == GA_TR && BMODE == GB_TR && (WMT == 2 || WMT == 3)) {
     // weight gradients (fused 3-tap and 1-tap / Linear): every split is a whole number of stages when K is, and the source
     // of a chunk moves by a constant per stage unless the K index is remapped per tap (conv_map: unfused strided wgrad)
-    EEG_ENV_VAR(bool, no_dma, getenv("EEGLDM_WGRAD_NO_DMA") != nullptr);
-    if (!no_dma && a.K % KSTAGE == 0 && !a.conv_map) return launch_k<T, AMODE, BMODE, TAPS, KSUB, BN, STRIDE, WMT, true>(ctx, a);
+    if (a.K % KSTAGE == 0 && !a.conv_map) return launch_k<T, AMODE, BMODE, TAPS, KSUB, BN, STRIDE, WMT, true>(ctx, a);
   }
   return launch_k<T, AMODE, BMODE, TAPS, KSUB, BN, STRIDE, WMT, false>(ctx, a);
 }
 
-// tile selection.  The 256-row / 8-wave variant (WMT = 4) is kept compiled but measured no faster than 128-row blocks
-// at 2 blocks per CU on the UNet's shapes (profiles/r01_gemm_tile_sweep.txt), so it is opt-in (EEGLDM_GEMM_BIG_TILES=1).
+// tile selection.  (Measured and removed from the dispatch in round 6, numbers in HISTORY.md: the 256-row / 8-wave variant WMT = 4 -- no faster than
+// 128-row blocks at 2 blocks per CU, profiles/r01_gemm_tile_sweep.txt -- and 192-row tiles for the 3-tap kernels -- +5..8 % in isolation from K = 512
+// up, nothing at step level, spills in the transposed-weight data gradient.)
 template <typename T, int AMODE, int BMODE, int TAPS, int KSUB, int STRIDE>
 int launch_bn(eegldm_ctx* ctx, const GemmArgs& a) {
-  EEG_ENV_VAR(bool, big_ok, getenv("EEGLDM_GEMM_BIG_TILES") != nullptr);
-  const bool big = big_ok && a.M >= 256 && !(AMODE == GA_CONV && STRIDE == 2);
-  if constexpr (AMODE == GA_CONV && TAPS == 3 && STRIDE == 1 && sizeof(T) == 2) {
-    // 192-row tiles (two waves x six fragments along M) for the bf16 3-tap kernels
-    EEG_ENV_VAR(int, t192, getenv("EEGLDM_GEMM_TILE192") ? atoi(getenv("EEGLDM_GEMM_TILE192")) : 0);   // opt-in: no gain at step level
-    // measured (tools/debug/gemm_bench.py): wins for the forward (NT) kernels from K = 512 up (+5..8 %), loses on short K loops
-    // (the 192-row epilogue / prologue weigh more) and on the transposed-weight dgrad (register spills)
-    if (t192 && BMODE == GB_NT && a.N > 64 && a.M >= 192 && a.K >= 512 * t192 && a.K % 32 == 0 && a.splitk == 1) return launch_t<T, AMODE, BMODE, TAPS, KSUB, 128, STRIDE, 3>(ctx, a);
-  }
-  if (a.N > 64) return big ? launch_t<T, AMODE, BMODE, TAPS, KSUB, 128, STRIDE, 4>(ctx, a) : launch_t<T, AMODE, BMODE, TAPS, KSUB, 128, STRIDE, 2>(ctx, a);
+  if (a.N > 64) return launch_t<T, AMODE, BMODE, TAPS, KSUB, 128, STRIDE, 2>(ctx, a);
   if (a.N > 32) return launch_t<T, AMODE, BMODE, TAPS, KSUB, 64, STRIDE, 2>(ctx, a);
   return launch_t<T, AMODE, BMODE, TAPS, KSUB, 32, STRIDE, 2>(ctx, a);
 }
@@ -1145,9 +1049,8 @@ int launch_modes(eegldm_ctx* ctx, const GemmArgs& a) {
     EEG_FAIL(EEGLDM_ERR_UNSUPPORTED, "conv gemm: taps=%d stride=%d bmode=%d", a.taps, a.stride, a.bmode);
   }
   if (a.amode == GA_TR && a.bmode == GB_TR && a.taps == 3) {   // fused 3-tap wgrad (see Cfg::WG3); BN <= 64 keeps 3 accumulator sets in registers
-    // 128 x 128 x 3-tap tile, one 8-wave block per CU (see Cfg::WN); chosen by op_conv_wgrad through GemmArgs::wide_n
-    if constexpr (sizeof(T) == 2) { if (a.wide_n && a.N % 128 == 0 && a.M % 128 == 0) return launch_t<T, GA_TR, GB_TR, 3, 2, 128, 1, 2>(ctx, a); }
-    // (Round 5 measured two more forms of this tile, both equal to it within 1 % over the UNet's shapes and since removed from the dispatch:
+    // (The 128 x 128 x 3-tap tile as one 8-wave block per CU measured 5-8 % slower than two independent 128 x 64 blocks in round 2; removed in round 6.
+    //  Round 5 measured two more forms of this tile, both equal to it within 1 % over the UNet's shapes and since removed from the dispatch:
     //  32-deep stages in a 4-deep LDS-DMA ring -- launch_t<T, GA_TR, GB_TR, 3, 1, 64, 1, 2> -- and eight waves of 32 x 32 x 3 taps, four per
     //  SIMD at 128 VGPRs -- WMT = 5; and a third, 15 % SLOWER: a three-deep ring at two blocks per CU -- WMT = 6, Cfg::TIGHT3.  DESIGN.md section 9.)
     if (a.N > 32) return launch_t<T, GA_TR, GB_TR, 3, 2, 64, 1, 2>(ctx, a);
@@ -1159,12 +1062,10 @@ int launch_modes(eegldm_ctx* ctx, const GemmArgs& a) {
   // products at T = 192 additionally stop computing half-empty tiles (one sample = 1.5 tiles of 128 rows; 64-wide N tiles for
   // the 192-wide QK^T output)
   if constexpr (sizeof(T) == 2) {
-    EEG_ENV_VAR(bool, no192, getenv("EEGLDM_GEMM_NO_ATTN192") != nullptr);
-    EEG_ENV_VAR(int, all192, getenv("EEGLDM_GEMM1_TILE192") ? atoi(getenv("EEGLDM_GEMM1_TILE192")) : 1);   // 1-tap kernels: +2..8 % on every UNet shape
-    EEG_ENV_VAR(bool, attn192_all, getenv("EEGLDM_GEMM_NO_ATTN192_ALL") == nullptr);   // also when 128 divides M (T = 384 / 768, pixel-space model): +0.7 % of that step
-    const bool attn192 = a.batch > 1 && a.M % 192 == 0 && (a.M % 128 != 0 || attn192_all);
-    const bool conv192 = all192 && a.batch == 1 && a.M % 192 == 0 && a.K >= 64 * all192;
-    if (!no192 && a.amode == GA_PLAIN && (attn192 || conv192) && a.splitk == 1 && a.K % 64 == 0) {
+    // (1-tap kernels: +2..8 % on every UNet shape; batched attention products also when 128 divides M -- T = 384 / 768, pixel-space model: +0.7 % of that step)
+    const bool attn192 = a.batch > 1 && a.M % 192 == 0;
+    const bool conv192 = a.batch == 1 && a.M % 192 == 0 && a.K >= 64;
+    if (a.amode == GA_PLAIN && (attn192 || conv192) && a.splitk == 1 && a.K % 64 == 0) {
       if (a.bmode == GB_NT) return (a.N % 128 == 0) ? launch_t<T, GA_PLAIN, GB_NT, 1, 2, 128, 1, 3>(ctx, a) : launch_t<T, GA_PLAIN, GB_NT, 1, 2, 64, 1, 3>(ctx, a);
       return (a.N % 128 == 0) ? launch_t<T, GA_PLAIN, GB_TR, 1, 2, 128, 1, 3>(ctx, a) : launch_t<T, GA_PLAIN, GB_TR, 1, 2, 64, 1, 3>(ctx, a);
     }
@@ -1172,16 +1073,9 @@ int launch_modes(eegldm_ctx* ctx, const GemmArgs& a) {
   if constexpr (sizeof(T) == 2) {
     // transposed-operand (TN) products whose M is a multiple of 192 but not of 128: the attention dK / dV gradients (192-row
     // samples, batched) stop computing a half-empty second 128-row tile; 1-tap weight gradients with 192 k output channels
-    EEG_ENV_VAR(bool, no_tn192, getenv("EEGLDM_GEMM_NO_TN192") != nullptr);
-    EEG_ENV_VAR(bool, tn192_all, getenv("EEGLDM_GEMM_TN192_ALL") != nullptr);   // experiment: also when 128 divides M
-    EEG_ENV_VAR(bool, tn192_batched, getenv("EEGLDM_GEMM_TN192_BATCHED") != nullptr);   // experiment: batched products (dK / dV at T = 768)
-    if (!no_tn192 && a.amode == GA_TR && a.bmode == GB_TR && a.taps == 1 && !a.conv_map && a.M % 192 == 0 && (a.M % 128 != 0 || tn192_all || (a.batch > 1 && tn192_batched)) && a.K % 64 == 0 && a.N % 64 == 0)
+    // (also when 128 divides M, and for the batched dK / dV products at T = 768: measured, no gain -- round 4)
+    if (a.amode == GA_TR && a.bmode == GB_TR && a.taps == 1 && !a.conv_map && a.M % 192 == 0 && a.M % 128 != 0 && a.K % 64 == 0 && a.N % 64 == 0)
       return (a.N % 128 == 0) ? launch_t<T, GA_TR, GB_TR, 1, 2, 128, 1, 3>(ctx, a) : launch_t<T, GA_TR, GB_TR, 1, 2, 64, 1, 3>(ctx, a);
-  }
-  EEG_ENV_VAR(bool, deep1, getenv("EEGLDM_GEMM1_DEEP") != nullptr);   // short stages, 4-deep DMA ring (see Cfg::NSTG)
-  if (deep1 && a.amode == GA_PLAIN && a.splitk == 1 && a.K % Tr<T>::KC == 0) {
-    if (a.bmode == GB_NT) return launch_bn<T, GA_PLAIN, GB_NT, 1, 1, 1>(ctx, a);
-    return launch_bn<T, GA_PLAIN, GB_TR, 1, 1, 1>(ctx, a);
   }
   if (a.amode == GA_PLAIN && a.bmode == GB_NT) return launch_bn<T, GA_PLAIN, GB_NT, 1, 2, 1>(ctx, a);
   if (a.amode == GA_PLAIN && a.bmode == GB_TR) return launch_bn<T, GA_PLAIN, GB_TR, 1, 2, 1>(ctx, a);
@@ -1285,7 +1179,7 @@ int gemm_launch_grouped(eegldm_ctx* ctx, const GemmArgs& a_in, const GemmGroup& 
   }
   a.C = ctx->splitk_ws; a.sCk = fold_n; a.sCb = (long)a.splitk * fold_n; a.atomic_out = 0; a.k_skew = 0.f;
   a.zero_page = ctx->zero_page;
-  { EEG_ENV_VAR(bool, no_swz, getenv("EEGLDM_GEMM_NO_XCD_SWIZZLE") != nullptr); a.xcd_swizzle = no_swz ? 0 : 1; }
+  a.xcd_swizzle = 1;
   ProfRec rec; const bool prof = ctx->prof_on;
   if (prof) {
     rec.cls = a.taps == 3 ? PROF_CONV_WGRAD : PROF_GEMM_TN;
@@ -1330,12 +1224,11 @@ int gemm_launch(eegldm_ctx* ctx, const GemmArgs& a_in) {
   // LDS epilogue) and folded into dW afterwards, instead of draining millions of fp32 atomics at ~370 G/s
   // (profiles/r01_gemm_stage_timing.txt); the fused 3-tap kernel keeps its register atomics (three accumulator sets).
   float* fold_dst = nullptr; long fold_n = 0;
-  EEG_ENV_VAR(bool, fused_ws, getenv("EEGLDM_GEMM_FUSED3_ATOMIC") == nullptr);   // fused 3-tap kernel: workspace partials (plain stores from the accumulators) + fold; =1 restores the register atomics
+  constexpr bool fused_ws = true;      // fused 3-tap kernel: workspace partials (plain stores from the accumulators) + fold (the register atomics of round 2 drained at ~370 G/s)
   // (deterministic mode: also the tap-by-tap weight gradients of strided convs, ztaps > 1 with contiguous taps -- their atomics are the only
   // other split-K route, and a single split is one block per tile walking all of B x L)
   const bool det_zt = eeg_deterministic() && a.ztaps > 1 && a.taps == 1 && a.sCt == (long)a.M * a.N;
-  if (a.splitk > 1 && a.amode == GA_TR && a.bmode == GB_TR && (a.taps == 1 || (a.taps == 3 && a.sCt == (long)a.M * a.N && fused_ws)) && (a.ztaps == 1 || det_zt) && a.batch == 1 && a.atomic_out && a.ldc == a.N &&
-      !getenv("EEGLDM_GEMM_NO_SPLITK_WS")) {
+  if (a.splitk > 1 && a.amode == GA_TR && a.bmode == GB_TR && (a.taps == 1 || (a.taps == 3 && a.sCt == (long)a.M * a.N && fused_ws)) && (a.ztaps == 1 || det_zt) && a.batch == 1 && a.atomic_out && a.ldc == a.N) {
     const size_t need = (size_t)a.splitk * a.taps * a.ztaps * a.M * a.N * sizeof(float);
     if (need <= (size_t)512 << 20) {
       if (ctx->splitk_ws_bytes < need) {
@@ -1354,7 +1247,7 @@ int gemm_launch(eegldm_ctx* ctx, const GemmArgs& a_in) {
   if (a.splitk > 1 && !fold_dst && eeg_deterministic()) a.splitk = 1;      // no workspace route for this product: one writer per output element instead of racing K splits
   if (a.splitk > 1 && !fold_dst) a.atomic_out = 1;
   a.zero_page = ctx->zero_page;
-  { EEG_ENV_VAR(bool, no_swz, getenv("EEGLDM_GEMM_NO_XCD_SWIZZLE") != nullptr); a.xcd_swizzle = no_swz ? 0 : 1; }
+  a.xcd_swizzle = 1;
   ProfRec rec; bool prof = ctx->prof_on;
   if (prof) {
     rec.cls = a.amode == GA_CONV ? (a.bmode == GB_NT ? PROF_CONV_FWD : PROF_CONV_DGRAD)
@@ -1368,13 +1261,12 @@ int gemm_launch(eegldm_ctx* ctx, const GemmArgs& a_in) {
   // skewed K chunks for the atomic split-K epilogue (see gemm_kernel); the workspace path writes plain stores and keeps equal chunks.
   // The atomics per block are constant (3 x 128 x 64), so the skew that pays shrinks with the stages per block (measured, B=256:
   // 12 or 24 stages per block -11 % at 0.5; 48 stages -3 % at 0.25; 73+ stages: any skew loses) -> (66 - stages) / 84, clamped.
-  EEG_ENV_VAR(float, wgrad_skew, getenv("EEGLDM_WGRAD_SKEW") ? (float)atof(getenv("EEGLDM_WGRAD_SKEW")) : -1.0f);
   a.k_skew = 0.f;
-  if (a.splitk > 1 && a.amode == GA_TR && a.atomic_out && !fold_dst && wgrad_skew != 0.f) {
+  if (a.splitk > 1 && a.amode == GA_TR && a.atomic_out && !fold_dst) {
     const int kst = (a.dtype == EEGLDM_F32 ? 16 : 32) * 2;
     const long S = ((long)a.K + kst - 1) / kst;
     const float spb = (float)S / (float)a.splitk;
-    float sk = wgrad_skew > 0.f ? wgrad_skew : (66.0f - spb) / 84.0f;
+    float sk = (66.0f - spb) / 84.0f;
     sk = sk < 0.f ? 0.f : (sk > 0.5f ? 0.5f : sk);
     if (sk > 0.f && spb * (1.0f - sk) >= 2.0f) a.k_skew = sk;      // every chunk keeps at least two stages
   }
@@ -1391,8 +1283,7 @@ int gemm_launch(eegldm_ctx* ctx, const GemmArgs& a_in) {
   else if (a.dtype == EEGLDM_BF16) rc = launch_modes<bf16_t>(ctx, a);
   else if (a.dtype == EEGLDM_F16) rc = launch_modes<f16_t>(ctx, a);
   else EEG_FAIL(EEGLDM_ERR_UNSUPPORTED, "dtype %d", a.dtype);
-  EEG_ENV_VAR(bool, dbg_skip_fold, getenv("EEGLDM_DBG_SKIP_FOLDS") != nullptr);      // timing experiment only: weight gradients stay in the workspace
-  if (rc == 0 && fold_dst && !dbg_skip_fold) {
+  if (rc == 0 && fold_dst) {
     hipLaunchKernelGGL(splitk_fold_kernel, dim3((unsigned)((fold_n / 4 + 63) / 64)), dim3(256), 0, ctx->stream, (const float*)ctx->splitk_ws, a.splitk, fold_n, fold_dst);
     LAUNCH_CHECK();
   }

@@ -67,10 +67,6 @@ struct BigArgs {
   // = the ResBlock's skip_connection 1 x 1 conv folded into out_layers' conv (h = skip(x) + conv2(a2), unet.py:302,327): one launch, one
   // fp32 accumulator, one rounding, no intermediate tensor.  W2 is K-blocked [K2 / 32][N][32]; K2 % 64 == 0, K2 >= 128.
   const bf16_t* A2; long lda2; const bf16_t* B2; int K2; const float* bias2;
-  // statistics epilogue (kernels with ST = true): qstats[(r / qL) * (N / 4) + n / 4] += (sum, sum of squares) of the four output columns
-  // n .. n + 3 over the tile's rows, fp64 atomics -- the per-(sample, channel quad) moments the NEXT GroupNorm folds into its group
-  // statistics, so that it runs as one streaming pass (norm.hip gn_apply_q_kernel).  qL = rows per sample (a multiple of 192).
-  double* qstats; int qL;
   // operand transform (gemm_big_kernel<.., XF != 0>, round 6): the A tile of every K stage is rewritten IN LDS, once it has landed, as
   //   a[r][k] <- act(a[r][k] * xf_scale[sample(r)][k] + xf_shift[sample(r)][k])          (act: XF 1 = SiLU, 2 = LeakyReLU(xf_slope))
   // = GroupNorm(+SiLU) / BatchNorm + LeakyReLU applied on the consuming conv's operand load: the normalised tensor is never written.
@@ -400,48 +396,6 @@ template <typename T> __device__ __forceinline__ void big_store(const BigArgs& p
     }
 }
 
-// ---- statistics epilogue shared by the persistent kernels.  A lane holds columns q * 4 .. q * 4 + 3 of fragment column j = one channel quad,
-// for rows lm of the six fragment rows: 24 values per quad in the lane, 16 lanes (lm) per quad and wave, two waves (wm = 0 / 1) per quad.
-// Taken from the fp32 values in front of the bf16 rounding (they differ from the moments of the stored tensor by the rounding noise of
-// 96 x 4 values per partial sum, ~1e-5 of a standard deviation: far below the bf16 resolution of anything computed from them).
-// Who issues the atomics matters: gfx950 retires a wave's vector-memory instructions through one in-order counter, the loader waves'
-// counted vmcnt waits at the top of the next tile therefore wait for every older instruction -- and a device-scope fp64 atomic is acknowledged
-// by the memory side microseconds later (first version, atomics from all eight waves: +7 us per launch, two tiles per workgroup).
-// So the loader waves (0-3 = the wm = 0 half of the tile) hand their partial sums to their wm = 1 partners (waves 4-7, same columns,
-// never wait on vmcnt inside the K loop) through 512 bytes of LDS behind the ring, and the partners add both halves into the global
-// moments after the next barrier (the top of the next tile, or one extra barrier behind the last tile).
-constexpr int QST_BYTES = 4 * (FN * 4) * 2 * 4;      // per loader wave: FN x 4 quads x (sum, sum of squares)
-__device__ __forceinline__ float big_row16_sum(float v) {      // sum over the 16 lanes of a row: four full-rate DPP adds, no LDS
-  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, true));     // quad_perm [1,0,3,2]
-  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xF, 0xF, true));     // quad_perm [2,3,0,1]
-  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x141, 0xF, 0xF, true));    // row_half_mirror
-  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x140, 0xF, 0xF, true));    // row_mirror
-  return v;
-}
-__device__ __forceinline__ void big_qpartial(f32x4 (&acc)[FM][FN], float (&s)[2 * FN]) {
-#pragma unroll
-  for (int j = 0; j < FN; j++) {
-    float a = 0.f, b = 0.f;
-#pragma unroll
-    for (int i = 0; i < FM; i++) {
-#pragma unroll
-      for (int r = 0; r < 4; r++) { const float v = acc[i][j][r]; a += v; b = fmaf(v, v, b); }
-    }
-    s[j] = big_row16_sum(a); s[FN + j] = big_row16_sum(b);
-  }
-}
-__device__ __forceinline__ void big_qflush(const BigArgs& p, const float (&s)[2 * FN], const float* part, int m0, int n0, int lm, int q, int wn) {
-  if (lm == 0) {
-    double* dst = p.qstats + ((long)(m0 / p.qL) * (p.N / 4) + (n0 + wn * 64 + q * 4) / 4) * 2;
-#pragma unroll
-    for (int j = 0; j < FN; j++) {
-      const float2 o = *(const float2*)(part + (j * 4 + q) * 2);
-      __hip_atomic_fetch_add(dst + j * 8, (double)(s[j] + o.x), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      __hip_atomic_fetch_add(dst + j * 8 + 1, (double)(s[FN + j] + o.y), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
-  }
-}
-
 // ---- persistent form of the 3-tap kernel: one workgroup per CU walks tiles blockIdx.x, + gridDim.x, ...
 // What it is for: in the one-tile-per-workgroup form every CU reaches its epilogue at the same time, the 25 MB of a round drain at
 // HBM rate while nothing computes (4.3 us per round measured: K sweep in tools/debug/gemm_big_check.py), and the next round's first
@@ -458,11 +412,10 @@ __device__ __forceinline__ void big_qflush(const BigArgs& p, const float (&s)[2 
 // of (S-1, 2), X_{e+2} behind that of X_e) and every barrier of that region waits for vmcnt(0) -- the schedule of gemm_big1p_kernel.
 // A2 tiles land where the main tiles land (physical row = tile row + 1) and are read with the centre tap's fragment addresses; B pieces
 // keep walking the three B buffers (X_e in buffer e % 3 = where piece 3 S + e would go).
-template <bool KBLK, bool FLIP, int NLOAD, bool XT = false, bool ST = false, typename T = bf16_t>      // NLOAD loader waves (4 or 2); ST: statistics epilogue (big_qstats)
+template <bool KBLK, bool FLIP, int NLOAD, bool XT = false, typename T = bf16_t>      // NLOAD loader waves (4 or 2)
 __global__ __launch_bounds__(NTHR, 2) void gemm_bigp_kernel(const BigArgs p) {
   constexpr int TAPS = 3;
   static_assert(!XT || (KBLK && !FLIP), "the K extension is a forward product on K-blocked weights");
-  static_assert(!ST || NLOAD == 4, "statistics hand-over: loader wave w and its partner w + 4 own the same columns");
   static_assert(NLOAD == 2 || NLOAD == 4, "halo rows belong to waves 0 and 1; vmcnt holds 63");
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -737,8 +690,6 @@ __global__ __launch_bounds__(NTHR, 2) void gemm_bigp_kernel(const BigArgs p) {
     };
 
     // statistics epilogue state: the wave's partial moments of the tile just finished; partner area in LDS (column group wn)
-    float qs[2 * FN]; int q_m0 = 0, q_n0 = 0; bool q_pend = false;
-    float* const q_lds = (float*)(smem + RING) + wn * (FN * 4 * 2);
     int m0, n0;
     decode(blockIdx.x, m0, n0);
     if (LOADER) { set_tile(m0, n0); issue_all(0); issue_all(1); issue_all(2); }
@@ -752,10 +703,8 @@ __global__ __launch_bounds__(NTHR, 2) void gemm_bigp_kernel(const BigArgs p) {
         if (carry) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * NB + NST) : "memory");
         else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * NB) : "memory");
       }
-      if constexpr (ST) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // (the loaders' partial sums of the previous tile are in LDS)
       __builtin_amdgcn_s_barrier();
       asm volatile("" ::: "memory");
-      if constexpr (ST && !LOADER) { if (q_pend) { big_qflush(p, qs, q_lds, q_m0, q_n0, lm, q, wn); q_pend = false; } }
 #pragma unroll
       for (int j = 0; j < FN; j++) bf0[j] = *(const uint4*)(smem + B0 + bof + j * 2048);
 #pragma unroll
@@ -791,11 +740,6 @@ __global__ __launch_bounds__(NTHR, 2) void gemm_bigp_kernel(const BigArgs p) {
       const bool more = w1 < ntiles;
       int m1 = 0, n1 = 0;
       if (!BIG_DBG(32)) apply_operands(m0, n0);
-      if constexpr (ST) {
-        big_qpartial(acc, qs);
-        if (LOADER) { if (lm == 0) { _Pragma("unroll") for (int j = 0; j < FN; j++) *(float2*)(q_lds + (j * 4 + q) * 2) = make_float2(qs[j], qs[FN + j]); } }
-        else { q_m0 = m0; q_n0 = n0; q_pend = true; }
-      }
       __builtin_amdgcn_sched_barrier(0);
       if (more) {
         decode(w1, m1, n1);
@@ -803,15 +747,7 @@ __global__ __launch_bounds__(NTHR, 2) void gemm_bigp_kernel(const BigArgs p) {
         __builtin_amdgcn_sched_barrier(0);
       }
       big_store<T>(p, acc, m0, n0, lm, q, wm, wn);
-      if (!more) {
-        if constexpr (ST) {      // the last tile's partials: one more barrier, then the partners flush
-          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-          __builtin_amdgcn_s_barrier();
-          asm volatile("" ::: "memory");
-          if (!LOADER) big_qflush(p, qs, q_lds, q_m0, q_n0, lm, q, wn);
-        }
-        return;
-      }
+      if (!more) return;
       __builtin_amdgcn_sched_barrier(0);
       zero_acc();
       m0 = m1; n0 = n1; w = w1; carry = true;
@@ -932,7 +868,7 @@ __global__ __launch_bounds__(NTHR, 2) void gemm_big1_kernel(const BigArgs p) {
 // ---- persistent form of the 1-tap kernel (structure and reasons: gemm_bigp_kernel).  Ring = two (A, B) stage buffers; behind the last
 // barrier of a tile both are free, so stages 0 and 1 of the next tile are requested before the output leaves; stage 2 follows behind
 // the first barrier of the next tile, and the loaders' stores have until its second barrier.
-template <bool KBLK, int NLOAD, bool ST = false, typename T = bf16_t>
+template <bool KBLK, int NLOAD, typename T = bf16_t>
 __global__ __launch_bounds__(NTHR, 2) void gemm_big1p_kernel(const BigArgs p) {
   static_assert(NLOAD == 2 || NLOAD == 4, "vmcnt holds 63");
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -1086,8 +1022,6 @@ __global__ __launch_bounds__(NTHR, 2) void gemm_big1p_kernel(const BigArgs p) {
       }
     };
 
-    float qs[2 * FN]; int q_m0 = 0, q_n0 = 0; bool q_pend = false;      // statistics epilogue (see gemm_bigp_kernel)
-    float* const q_lds = (float*)(smem + 2 * S1_BYTES) + wn * (FN * 4 * 2);
     int m0, n0;
     decode(blockIdx.x, m0, n0);
     if (LOADER) { set_tile(m0, n0); issue_all(0); if (S > 1) issue_all(1); }
@@ -1105,10 +1039,8 @@ __global__ __launch_bounds__(NTHR, 2) void gemm_big1p_kernel(const BigArgs p) {
           else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
       }
-      if constexpr (ST) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       __builtin_amdgcn_s_barrier();
       asm volatile("" ::: "memory");
-      if constexpr (ST && !LOADER) { if (q_pend) { big_qflush(p, qs, q_lds, q_m0, q_n0, lm, q, wn); q_pend = false; } }
 #pragma unroll
       for (int j = 0; j < FN; j++) bf0[j] = *(const uint4*)(smem + bof + j * 2048);
 #pragma unroll
@@ -1123,11 +1055,6 @@ __global__ __launch_bounds__(NTHR, 2) void gemm_big1p_kernel(const BigArgs p) {
       const bool more = w1 < ntiles;
       int m1 = 0, n1 = 0;
       apply_operands(m0, n0);
-      if constexpr (ST) {
-        big_qpartial(acc, qs);
-        if (LOADER) { if (lm == 0) { _Pragma("unroll") for (int j = 0; j < FN; j++) *(float2*)(q_lds + (j * 4 + q) * 2) = make_float2(qs[j], qs[FN + j]); } }
-        else { q_m0 = m0; q_n0 = n0; q_pend = true; }
-      }
       __builtin_amdgcn_sched_barrier(0);
       if (more) {
         decode(w1, m1, n1);
@@ -1135,15 +1062,7 @@ __global__ __launch_bounds__(NTHR, 2) void gemm_big1p_kernel(const BigArgs p) {
         __builtin_amdgcn_sched_barrier(0);
       }
       big_store<T>(p, acc, m0, n0, lm, q, wm, wn);
-      if (!more) {
-        if constexpr (ST) {
-          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-          __builtin_amdgcn_s_barrier();
-          asm volatile("" ::: "memory");
-          if (!LOADER) big_qflush(p, qs, q_lds, q_m0, q_n0, lm, q, wn);
-        }
-        return;
-      }
+      if (!more) return;
       __builtin_amdgcn_sched_barrier(0);
       zero_acc();
       m0 = m1; n0 = n1; w = w1; carry = true;
@@ -1152,11 +1071,11 @@ __global__ __launch_bounds__(NTHR, 2) void gemm_big1p_kernel(const BigArgs p) {
   if (wave_u < NLOAD) run(std::true_type{}); else run(std::false_type{});
 }
 
-template <bool KBLK, int NLOAD, bool ST = false, typename T = bf16_t>
+template <bool KBLK, int NLOAD, typename T = bf16_t>
 int launch_big1p(eegldm_ctx* ctx, const BigArgs& a) {
-  auto kern = gemm_big1p_kernel<KBLK, NLOAD, ST, T>;
+  auto kern = gemm_big1p_kernel<KBLK, NLOAD, T>;
   static DevOnce attr_once;
-  constexpr int LDSB = 2 * S1_BYTES + (ST ? QST_BYTES : 0);
+  constexpr int LDSB = 2 * S1_BYTES;
   if (attr_once.need(ctx->device)) HIP_TRY(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDSB));
   int grid = a.tiles_m * a.tiles_n;
   const int cus = ctx->num_cu >= 8 ? ctx->num_cu & ~7 : ctx->num_cu;
@@ -1170,7 +1089,7 @@ template <bool KBLK, typename T = bf16_t>
 int launch_big1(eegldm_ctx* ctx, const BigArgs& a) {
   EEG_ENV_VAR(bool, no_persist, getenv("EEGLDM_GEMM_BIG_NO_PERSIST") != nullptr || getenv("EEGLDM_GEMM_BIG1_NO_PERSIST") != nullptr);
   // (fp16 runs the persistent form only: the one-tile-per-workgroup kernels are a bf16 developer A/B)
-  if (!no_persist || !Is16<T>::bf16) { if constexpr (Is16<T>::bf16) { if (a.qstats) return launch_big1p<KBLK, 4, true, T>(ctx, a); } return launch_big1p<KBLK, 4, false, T>(ctx, a); }
+  if (!no_persist || !Is16<T>::bf16) return launch_big1p<KBLK, 4, T>(ctx, a);
   if constexpr (Is16<T>::bf16) {
     auto kern = gemm_big1_kernel<KBLK, T>;
     static DevOnce attr_once;
@@ -1181,11 +1100,11 @@ int launch_big1(eegldm_ctx* ctx, const BigArgs& a) {
   return 0;
 }
 
-template <bool KBLK, bool FLIP, int NLOAD, bool ST = false, typename T = bf16_t>
+template <bool KBLK, bool FLIP, int NLOAD, typename T = bf16_t>
 int launch_bigp(eegldm_ctx* ctx, const BigArgs& a) {
-  auto kern = gemm_bigp_kernel<KBLK, FLIP, NLOAD, false, ST, T>;
+  auto kern = gemm_bigp_kernel<KBLK, FLIP, NLOAD, false, T>;
   static DevOnce attr_once;      // the dynamic-LDS attribute is per device
-  constexpr int LDSB = RING + (ST ? QST_BYTES : 0);
+  constexpr int LDSB = RING;
   if (attr_once.need(ctx->device)) HIP_TRY(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDSB));
   int grid = a.tiles_m * a.tiles_n;
   const int cus = ctx->num_cu >= 8 ? ctx->num_cu & ~7 : ctx->num_cu;      // a multiple of 8 keeps a workgroup's tiles on its XCD
@@ -1195,11 +1114,11 @@ int launch_bigp(eegldm_ctx* ctx, const BigArgs& a) {
   return 0;
 }
 
-template <bool ST, typename T = bf16_t>
+template <typename T = bf16_t>
 int launch_bigx(eegldm_ctx* ctx, const BigArgs& a) {      // K extension: persistent form only
-  auto kern = gemm_bigp_kernel<true, false, 4, true, ST, T>;
+  auto kern = gemm_bigp_kernel<true, false, 4, true, T>;
   static DevOnce attr_once;
-  constexpr int LDSB = RING + (ST ? QST_BYTES : 0);
+  constexpr int LDSB = RING;
   if (attr_once.need(ctx->device)) HIP_TRY(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDSB));
   int grid = a.tiles_m * a.tiles_n;
   const int cus = ctx->num_cu >= 8 ? ctx->num_cu & ~7 : ctx->num_cu;
@@ -1213,8 +1132,7 @@ template <int TAPS, bool KBLK, bool FLIP, typename T = bf16_t>
 int launch_big(eegldm_ctx* ctx, const BigArgs& a) {
   EEG_ENV_VAR(bool, no_persist, getenv("EEGLDM_GEMM_BIG_NO_PERSIST") != nullptr);
   if (!no_persist || !Is16<T>::bf16) {      // (2 loader waves measured equal: tools/debug/gemm_big_check.py, round 4)
-    if constexpr (KBLK && !FLIP && Is16<T>::bf16) { if (a.qstats) return launch_bigp<KBLK, FLIP, 4, true, T>(ctx, a); }
-    return launch_bigp<KBLK, FLIP, 4, false, T>(ctx, a);
+    return launch_bigp<KBLK, FLIP, 4, T>(ctx, a);
   }
   if constexpr (Is16<T>::bf16) {
     auto kern = gemm_big_kernel<TAPS, KBLK, FLIP, T>;
@@ -1255,12 +1173,6 @@ int gemm_big_try(eegldm_ctx* ctx, const GemmArgs& g) {
   a.bias = g.bias; a.rowvec = g.rowvec; a.ld_rowvec = g.ld_rowvec; a.rows_per_vec = g.rows_per_vec > 0 ? g.rows_per_vec : 1;
   a.resid = (const bf16_t*)g.resid; a.ldr = g.ldr; a.zero_page = ctx->zero_page; a.tiles_m = tm; a.tiles_n = tn;
   a.A2 = nullptr; a.lda2 = 0; a.B2 = nullptr; a.K2 = 0; a.bias2 = nullptr;
-  // statistics epilogue: persistent kernels only, forward products (K-blocked 3-tap weights / plain 1-tap weights), whole tiles inside one sample
-  EEG_ENV_VAR(bool, no_persist_q, getenv("EEGLDM_GEMM_BIG_NO_PERSIST") != nullptr || getenv("EEGLDM_GEMM_BIG1_NO_PERSIST") != nullptr);
-  a.qstats = nullptr; a.qL = 0;
-  if (g.dtype == EEGLDM_BF16 && g.qstats && g.qstats_done && !no_persist_q && g.qstats_L > 0 && g.qstats_L % BM == 0 && !g.tap_flip && (conv3 ? g.b_kblk != 0 : !g.b_kblk)) {
-    a.qstats = g.qstats; a.qL = g.qstats_L; *g.qstats_done = 1;
-  }
   int rc;
   if (g.dtype == EEGLDM_F16) {      // round 5: the same kernels on IEEE-half operands (persistent forms)
     if (!conv3) rc = g.b_kblk ? launch_big1<true, f16_t>(ctx, a) : launch_big1<false, f16_t>(ctx, a);
@@ -1290,7 +1202,7 @@ int gemm_big_xf_try(eegldm_ctx* ctx, const GemmArgs& g, const float* scale, cons
   a.C = (bf16_t*)g.C; a.ldc = g.ldc; a.M = g.M; a.N = g.N; a.K = g.K; a.L = g.Lout;
   a.bias = g.bias; a.rowvec = g.rowvec; a.ld_rowvec = g.ld_rowvec; a.rows_per_vec = g.rows_per_vec > 0 ? g.rows_per_vec : 1;
   a.resid = (const bf16_t*)g.resid; a.ldr = g.ldr; a.zero_page = ctx->zero_page; a.tiles_m = g.M / BM; a.tiles_n = g.N / BN;
-  a.A2 = nullptr; a.lda2 = 0; a.B2 = nullptr; a.K2 = 0; a.bias2 = nullptr; a.qstats = nullptr; a.qL = 0;
+  a.A2 = nullptr; a.lda2 = 0; a.B2 = nullptr; a.K2 = 0; a.bias2 = nullptr;
   a.xf_scale = scale; a.xf_shift = shift; a.xf_ld = ld; a.xf_slope = slope;
   static DevOnce once1, once2;
   ProfRec rec; const bool prof = ctx->prof_on;
@@ -1332,8 +1244,6 @@ int gemm_big_skip_try(eegldm_ctx* ctx, const GemmArgs& g, const void* x2, long l
   a.bias = g.bias; a.rowvec = g.rowvec; a.ld_rowvec = g.ld_rowvec; a.rows_per_vec = g.rows_per_vec > 0 ? g.rows_per_vec : 1;
   a.resid = nullptr; a.ldr = 0; a.zero_page = ctx->zero_page; a.tiles_m = tm; a.tiles_n = tn;
   a.A2 = (const bf16_t*)x2; a.lda2 = ldx2; a.B2 = (const bf16_t*)w2_kblk; a.K2 = K2; a.bias2 = bias2;
-  a.qstats = nullptr; a.qL = 0;
-  if (g.dtype == EEGLDM_BF16 && g.qstats && g.qstats_done) { a.qstats = g.qstats; a.qL = g.Lout; *g.qstats_done = 1; }
   ProfRec rec; const bool prof = ctx->prof_on;
   if (prof) {
     rec.cls = PROF_CONV_FWD; rec.flops = 2.0 * g.M * g.N * ((double)g.K * 3 + K2);
@@ -1341,7 +1251,7 @@ int gemm_big_skip_try(eegldm_ctx* ctx, const GemmArgs& g, const void* x2, long l
     HIP_TRY(hipEventCreate(&rec.a)); HIP_TRY(hipEventCreate(&rec.b));
     HIP_TRY(hipEventRecord(rec.a, ctx->stream));
   }
-  const int rc = g.dtype == EEGLDM_F16 ? launch_bigx<false, f16_t>(ctx, a) : (a.qstats ? launch_bigx<true>(ctx, a) : launch_bigx<false>(ctx, a));
+  const int rc = g.dtype == EEGLDM_F16 ? launch_bigx<f16_t>(ctx, a) : launch_bigx<bf16_t>(ctx, a);
   if (prof) { HIP_TRY(hipEventRecord(rec.b, ctx->stream)); ctx->prof.push_back(rec); }
   return rc < 0 ? rc : 1;
 }

@@ -52,14 +52,13 @@ int conv_ws_try(eegldm_ctx*, int dtype, const void* x, long ldx, const void* w, 
 // ops.hip
 int op_conv_fwd(eegldm_ctx*, int dtype, const void* x, long ldx, const void* w, const float* bias, void* y, long ldy,
                 int B, int Lin, int Cin, int Cout, int K, int stride, int pad_l, int pad_r,
-                const float* rowvec, long ld_rowvec, const void* resid, long ldr, float act_slope = 0.f,
-                double* qstats = nullptr, int* qstats_done = nullptr);      // qstats: [B][Cout / 4][2] zeroed doubles; *qstats_done = 1 when the kernel that ran filled them
+                const float* rowvec, long ld_rowvec, const void* resid, long ldr, float act_slope = 0.f);
 bool op_conv_fuses_act(int dtype, int Cin, int Cout, int K, long ldy);
 // y = conv3(x; w, pad 1) + bias + conv1(x2; w2) + bias2 (+ rowvec): the ResBlock tail h = skip_connection(x) + out_layers(h) (unet.py:302,327).
 // ONE launch when the big-tile kernel takes it (16-bit, Cout % 256 == 0, K-blocked copies of both weights registered), else the two convs.
 int op_conv3_skip_fwd(eegldm_ctx*, int dtype, const void* x, long ldx, const void* w, const float* bias, const void* x2, long ldx2,
                       const void* w2, const float* bias2, void* y, long ldy, int B, int L, int Cin, int Cin2, int Cout,
-                      const float* rowvec, long ld_rowvec, double* qstats = nullptr, int* qstats_done = nullptr);
+                      const float* rowvec, long ld_rowvec);
 int op_conv_dgrad(eegldm_ctx*, int dtype, const void* dy, long lddy, const void* w, void* dx, long lddx,
                   int B, int Lin, int Cin, int Cout, int K, int stride, int pad_l, int pad_r, const void* resid, long ldr);
 bool op_wgrad_fuses_bias(int dtype, int Cin, int Cout);
@@ -84,10 +83,6 @@ int op_groupnorm_bwd(eegldm_ctx*, const void* x, long ldx, const float* gamma, c
                      const void* dxr2 = nullptr, long lddxr2 = 0, int* dxr2_done = nullptr, int* slots_deferred = nullptr, int defer_region = 0);
 int op_gn_slot_reduce_deferred(eegldm_ctx*, float* dgamma, float* dbeta, int C, int region = 0);   // when *slots_deferred came back 1 (stream-ordered after the backward)   // dxr2: second, un-resampled addend [B*L][C] (skip gradient); *dxr2_done = 1 when the kernel added it
 int ew_fold_partials(eegldm_ctx*, const float* parts, int nparts, int n, float* total);
-// GroupNorm(+SiLU) forward as one streaming pass from the per-(sample, channel quad) moments the producing conv left (norm.hip, gemm_big.hip
-// big_qstats): 1 = launched, 0 = not eligible
-int gn_fwd_from_qstats(eegldm_ctx*, const void* x, long ldx, const float* gamma, const float* beta, void* y, long ldy, float* stats,
-                       int B, int L, int C, int G, float eps, int silu, const double* qsA, int nqa, const double* qsB, int nqb);
 // frozen-encoder fusion (enc_fused.hip): GroupNorm(G = 1) + SiLU on the operand load of a 3-tap conv, next layer's statistics from its epilogue
 bool pre_conv3_ok(int dtype, int Cin, int Cout, int L);
 int pre_conv3_launch(eegldm_ctx*, const void* x, const double* in_stats, const float* gamma, const float* beta, const void* w,

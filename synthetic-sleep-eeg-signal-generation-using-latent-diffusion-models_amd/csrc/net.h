@@ -90,16 +90,6 @@ struct NetBase {
   const PartReg* find_part(const void* p) const { for (auto it = part_reg.rbegin(); it != part_reg.rend(); ++it) if (it->p == p) return &*it; return nullptr; }
   float2* fuse_alloc(size_t slots) { if (fuse_used + slots > fuse_cap) return nullptr; float2* a = fuse_stats + fuse_used; fuse_used += slots; return a; }
   float2* fuse_stats = nullptr; size_t fuse_cap = 0, fuse_used = 0;     // float2 slots; every slot of a used area is written by its producer
-  // Round 5, full-size launches (16-bit): the big-tile convs leave the per-(sample, channel quad) moments of their output in `qarena`
-  // (gemm_big.hip big_qstats) and the GroupNorm that reads the tensor next runs as one streaming pass (norm.hip gn_apply_q_kernel).
-  // Registered by output pointer like part_reg; the arena is zeroed with ONE memset at the start of a forward (the high-water mark of the
-  // previous forward; an allocation beyond it -- the first forward -- zeroes itself).
-  struct QReg { const void* p; const double* slots; int nq; };
-  std::vector<QReg> qreg;
-  double* qarena = nullptr; size_t qcap = 0, qused = 0, qzeroed = 0, qhigh = 0; bool q_on = false;      // q_on: set by the executor that calls qbegin() every forward (UNet)
-  const QReg* find_q(const void* p) const { for (auto it = qreg.rbegin(); it != qreg.rend(); ++it) if (it->p == p) return &*it; return nullptr; }
-  double* qalloc(int B, int C);          // [B][C / 4][2] zeroed doubles, or null (disabled / no room)
-  int qbegin();                          // start of a forward
   std::vector<ResTape> rt; std::vector<AttnTape> at;
 
   const void* W(long off) const { return (const char*)wT + (size_t)off * dtype_size(dtype); }
@@ -114,7 +104,7 @@ struct NetBase {
   int bind(float* p, float* g);
   int sync_weights();
   void release_kblk();
-  ~NetBase() { release_kblk(); if (owns_wT && wT) (void)hipFree(wT); if (qarena) (void)hipFree(qarena); }      // (release_kblk also drops the s2ws copies)
+  ~NetBase() { release_kblk(); if (owns_wT && wT) (void)hipFree(wT); }      // (release_kblk also drops the s2ws copies)
 };
 
 #define ALLOC_OR_FAIL(var, expr)                                                     \

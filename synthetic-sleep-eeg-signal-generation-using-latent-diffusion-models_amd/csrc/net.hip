@@ -62,33 +62,6 @@ int NetBase::bind(float* p, float* g) {
   }
   return sync_weights();
 }
-int NetBase::qbegin() {
-  qreg.clear(); q_on = true;
-  if (qused > qhigh) qhigh = qused;
-  qused = 0; qzeroed = 0;
-  if (qarena && qhigh > 0) { HIP_TRY(hipMemsetAsync(qarena, 0, qhigh * sizeof(double), ctx->stream)); qzeroed = qhigh; }
-  return 0;
-}
-double* NetBase::qalloc(int B, int C) {
-  // OPT-IN (EEGLDM_GN_QSTATS=1).  Measured, round 5 (tools/r05/s4.sh, LDM step B = 256): the streaming GroupNorm pass runs 26.7 us on the 50 MB
-  // tensors against 26.8 us for the resident one-pass kernel (at this size launch + ramp + tail weigh as much as the second barrier round it
-  // saves), while the statistics epilogue costs the producing conv +6 us per launch: 17.70 vs 17.65 ms per step.  Kept for the record.
-  EEG_ENV_VAR(bool, off, getenv("EEGLDM_GN_QSTATS") == nullptr || atoi(getenv("EEGLDM_GN_QSTATS")) == 0 || getenv("EEGLDM_GN_NO_QSTATS") != nullptr);
-  if (off || !q_on || dtype != EEGLDM_BF16 || eeg_deterministic() || C % 4 != 0) return nullptr;      // (gn_apply_q_kernel unpacks bf16 only)
-  const size_t n = (size_t)B * (C / 4) * 2;
-  if (!qarena) {
-    qcap = (size_t)8 << 20;          // 64 MB of doubles: the config_ldm UNet at B = 256 uses ~25 MB
-    if (hipMalloc(&qarena, qcap * sizeof(double)) != hipSuccess) { qarena = nullptr; qcap = 0; return nullptr; }
-  }
-  if (qused + n > qcap) return nullptr;
-  double* r = qarena + qused; qused += n;
-  if (qused > qzeroed) {             // beyond what qbegin() zeroed (first forward of this shape): zero the rest of this allocation
-    const size_t from = qzeroed > (size_t)(r - qarena) ? qzeroed : (size_t)(r - qarena);
-    if (hipMemsetAsync(qarena + from, 0, (qused - from) * sizeof(double), ctx->stream) != hipSuccess) return nullptr;
-    qzeroed = qused;
-  }
-  return r;
-}
 int NetBase::flush_gn_folds() {
   for (const GnFold& f : gn_pending) EEG_TRY(op_gn_slot_reduce_deferred(ctx, f.dgamma, f.dbeta, f.C, f.region));
   gn_pending.clear();
@@ -159,15 +132,6 @@ int res_forward(NetBase* u, const ResDesc& r, const View& x, int B, int Lin, con
   }
   auto norm1 = [&]() -> int {       // the stand-alone first GroupNorm (+ resampling)
     ALLOC_OR_FAIL(t.a1.p, u->alloc_act((long)B * Lout, r.cin)); t.a1.ld = r.cin; t.a1.C = r.cin;
-    if (!r.updown && !u->qreg.empty()) {      // the producer(s) of x left its moments: one streaming pass
-      const NetBase::QReg* qa = u->find_q(x.p); const NetBase::QReg* qb = nullptr;
-      if (qa && qa->nq * 4 < r.cin) qb = u->find_q((const char*)x.p + (size_t)qa->nq * 4 * dtype_size(dt));
-      if (qa && (qa->nq * 4 == r.cin || (qb && (qa->nq + qb->nq) * 4 == r.cin))) {
-        const int rc = gn_fwd_from_qstats(ctx, x.p, x.ld, u->P(r.gn1_w), u->P(r.gn1_b), t.a1.p, t.a1.ld, t.st1, B, Lin, r.cin, r.groups, GN_EPS, 1,
-                                          qa->slots, qa->nq, qb ? qb->slots : nullptr, qb ? qb->nq : 0);
-        if (rc != 0) return rc < 0 ? rc : 0;
-      }
-    }
     return eegldm_groupnorm_fwd(ctx, x.p, x.ld, u->P(r.gn1_w), u->P(r.gn1_b), t.a1.p, t.a1.ld, t.st1, B, Lin, r.cin, r.groups, GN_EPS, 1,
                                 r.updown, r.updown ? t.xr.p : nullptr, t.xr.ld, dt);
   };
@@ -227,27 +191,17 @@ int res_forward(NetBase* u, const ResDesc& r, const View& x, int B, int Lin, con
     u->rt.push_back(t);
     return 0;
   }
-  double* q1 = u->qalloc(B, r.cout); int q1_done = 0;      // moments of h1 from conv1's epilogue -> GroupNorm 2 streams
   EEG_TRY(op_conv_fwd(ctx, dt, t.a1.p, t.a1.ld, u->W(r.c1_w), u->P(r.c1_b), t.h1.p, t.h1.ld, B, Lout, r.cin, r.cout, 3, 1, 1, 1,
-                      emb, u->emb_ld, nullptr, 0, 0.f, q1, &q1_done));
+                      emb, u->emb_ld, nullptr, 0));
   ALLOC_OR_FAIL(t.a2.p, u->alloc_act((long)B * Lout, r.cout)); t.a2.ld = r.cout; t.a2.C = r.cout;
-  int gn2 = 0;
-  if (q1_done) {
-    gn2 = gn_fwd_from_qstats(ctx, t.h1.p, t.h1.ld, u->P(r.gn2_w), u->P(r.gn2_b), t.a2.p, t.a2.ld, t.st2, B, Lout, r.cout, r.groups, GN_EPS, 1, q1, r.cout / 4, nullptr, 0);
-    if (gn2 < 0) return gn2;
-  }
-  if (!gn2)
   EEG_TRY(eegldm_groupnorm_fwd(ctx, t.h1.p, t.h1.ld, u->P(r.gn2_w), u->P(r.gn2_b), t.a2.p, t.a2.ld, t.st2, B, Lout, r.cout, r.groups, GN_EPS, 1,
                                0, nullptr, 0, dt));
-  double* q2 = u->qalloc(B, r.cout); int q2_done = 0;      // moments of the block output, for whoever normalises it next
   if (r.sk_w >= 0) {      // skip_connection(x) + conv2(a2): one launch with the 1 x 1 conv as further K stages where the big-tile kernel takes it
     EEG_TRY(op_conv3_skip_fwd(ctx, dt, t.a2.p, t.a2.ld, u->W(r.c2_w), u->P(r.c2_b), t.xr.p, t.xr.ld, u->W(r.sk_w), u->P(r.sk_b), out.p, out.ld,
-                              B, Lout, r.cout, r.cin, r.cout, nullptr, 0, q2, &q2_done));
+                              B, Lout, r.cout, r.cin, r.cout, nullptr, 0));
   } else {
-    EEG_TRY(op_conv_fwd(ctx, dt, t.a2.p, t.a2.ld, u->W(r.c2_w), u->P(r.c2_b), out.p, out.ld, B, Lout, r.cout, r.cout, 3, 1, 1, 1, nullptr, 0, t.xr.p, t.xr.ld,
-                        0.f, q2, &q2_done));
+    EEG_TRY(op_conv_fwd(ctx, dt, t.a2.p, t.a2.ld, u->W(r.c2_w), u->P(r.c2_b), out.p, out.ld, B, Lout, r.cout, r.cout, 3, 1, 1, 1, nullptr, 0, t.xr.p, t.xr.ld));
   }
-  if (q2_done) u->qreg.push_back({out.p, q2, r.cout / 4});
   u->rt.push_back(t);
   return 0;
 }
@@ -352,11 +306,6 @@ int attn_forward(NetBase* u, const AttnDesc& a, const View& x, int B, int T, con
     if (rcq == 1) u->fused_used = true;
   }
   if (rcq != 1) {
-    int gq = 0;
-    if (const NetBase::QReg* qa = u->find_q(x.p)) {
-      if (qa->nq * 4 == C) { gq = gn_fwd_from_qstats(ctx, x.p, x.ld, u->P(a.n_w), u->P(a.n_b), t.xn.p, C, t.st, B, T, C, AG, GN_EPS, 0, qa->slots, qa->nq, nullptr, 0); if (gq < 0) return gq; }
-    }
-    if (!gq)
     EEG_TRY(eegldm_groupnorm_fwd(ctx, x.p, x.ld, u->P(a.n_w), u->P(a.n_b), t.xn.p, C, t.st, B, T, C, AG, GN_EPS, 0, 0, nullptr, 0, dt));
     EEG_TRY(op_conv_fwd(ctx, dt, t.xn.p, C, u->W(a.qkv_w), u->P(a.qkv_b), t.qkv.p, 3 * C, B, T, C, 3 * C, 1, 1, 0, 0, nullptr, 0, nullptr, 0));
   }
@@ -377,9 +326,7 @@ int attn_forward(NetBase* u, const AttnDesc& a, const View& x, int B, int T, con
     }
   }
   if (rcp != 1) {
-    double* qo = u->qalloc(B, C); int qo_done = 0;
-    EEG_TRY(op_conv_fwd(ctx, dt, t.o.p, C, u->W(a.pr_w), u->P(a.pr_b), out.p, out.ld, B, T, C, C, 1, 1, 0, 0, nullptr, 0, x.p, x.ld, 0.f, qo, &qo_done));
-    if (qo_done) u->qreg.push_back({out.p, qo, C / 4});
+    EEG_TRY(op_conv_fwd(ctx, dt, t.o.p, C, u->W(a.pr_w), u->P(a.pr_b), out.p, out.ld, B, T, C, C, 1, 1, 0, 0, nullptr, 0, x.p, x.ld));
   }
   u->at.push_back(t);
   return 0;

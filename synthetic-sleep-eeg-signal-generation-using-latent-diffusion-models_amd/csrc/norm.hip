@@ -937,64 +937,6 @@ __global__ __launch_bounds__(NTB) void gn_bwd_pipe_kernel(const bf16_t* __restri
   }
 }
 
-// ------------------------------------------------------------------ forward from the producer's moments (round 5)
-// GroupNorm(+SiLU) forward of a 16-bit tensor as ONE streaming pass: the per-(sample, channel quad) sums / sums of squares were left by the
-// epilogue of the conv that wrote the tensor (gemm_big.hip big_qstats; a concatenated input [h | skip] has two producers, quads >= nqa
-// come from the second one), so nothing has to be resident and nothing is reduced here -- a thread folds the cpg / 4 quads of its group
-// (<= 8 pairs of doubles, L2-resident), scales its 8 channels and streams its rows.  The resident kernel is one load phase, two
-// barrier rounds and one store phase per block (3.9-4.6 TB/s); this one keeps loads and stores in flight together (the stand-alone
-// apply kernel of the split path measures 5.4 TB/s).  grid (row chunks, B); blockIdx.x == 0 writes the (mean, rstd) pairs of the tape.
-// Reference op: normalization(channels) + SiLU of /root/reference/src/models/unet.py:71-74,261-262,287-288.
-__global__ __launch_bounds__(NT) void gn_apply_q_kernel(const bf16_t* __restrict__ x, long ldx, const float* __restrict__ gamma, const float* __restrict__ beta,
-                                                        const double* __restrict__ qsA, int nqa, const double* __restrict__ qsB, int nqb,
-                                                        float* __restrict__ stats, bf16_t* __restrict__ y, long ldy, int L, int C, int G, float eps,
-                                                        int silu, int rows_per_block) {
-  const int b = blockIdx.y, tid = threadIdx.x, cpg = C / G, ncols = C / 8;
-  const int TX = ncols < NT ? ncols : NT, TY = NT / TX;
-  if (tid >= TX * TY) return;
-  const int tx = tid % TX, ty = tid / TX;
-  const int l0 = blockIdx.x * rows_per_block, l1 = min(L, l0 + rows_per_block);
-  const double inv_n = 1.0 / ((double)cpg * (double)L);
-  for (int col = tx; col < ncols; col += TX) {
-    const int c = col * 8;
-    float ga[8], be[8];
-#pragma unroll
-    for (int h = 0; h < 2; h++) {
-      const int g = (c + 4 * h) / cpg;
-      float mean, rstd;
-      {
-        const int q0 = g * (cpg / 4), nq = cpg / 4;
-        double s1 = 0.0, s2 = 0.0;
-        for (int k = 0; k < nq; k++) {
-          const int qi = q0 + k;
-          const double* sp = qi < nqa ? qsA + ((long)b * nqa + qi) * 2 : qsB + ((long)b * nqb + (qi - nqa)) * 2;
-          s1 += sp[0]; s2 += sp[1];
-        }
-        const double mu = s1 * inv_n;
-        double var = s2 * inv_n - mu * mu; if (var < 0.0) var = 0.0;
-        mean = (float)mu; rstd = (float)(1.0 / sqrt(var + (double)eps));
-      }
-      if (blockIdx.x == 0 && ty == 0 && (c + 4 * h) % cpg == 0) { float* st = stats + ((long)b * G + g) * 2; st[0] = mean; st[1] = rstd; }
-#pragma unroll
-      for (int k = 0; k < 4; k++) { const float gm = gamma[c + 4 * h + k] * rstd; ga[4 * h + k] = gm; be[4 * h + k] = beta[c + 4 * h + k] - mean * gm; }
-    }
-    const bf16_t* xb = x + (long)b * L * ldx + c;
-    bf16_t* yb = y + (long)b * L * ldy + c;
-#pragma unroll 4
-    for (int l = l0 + ty; l < l1; l += TY) {
-      const uint4 r = *(const uint4*)(xb + (long)l * ldx);
-      const unsigned w[4] = {r.x, r.y, r.z, r.w};
-      unsigned o[4];
-#pragma unroll
-      for (int k = 0; k < 4; k++) {
-        float z0 = __uint_as_float(w[k] << 16) * ga[2 * k] + be[2 * k], z1 = __uint_as_float(w[k] & 0xffff0000u) * ga[2 * k + 1] + be[2 * k + 1];
-        if (silu) { z0 = silu_f(z0); z1 = silu_f(z1); }
-        o[k] = pack_bf16x2(z0, z1);
-      }
-      *(uint4*)(yb + (long)l * ldy) = make_uint4(o[0], o[1], o[2], o[3]);
-    }
-  }
-}
 
 // chunk width for the resident kernels: the widest whole-group chunk (<= 256 channels, dividing C) whose rows fit the
 // per-thread register budget; 0 = not eligible (fall back to the split kernels)
@@ -1038,7 +980,7 @@ int gn_fwd_t(eegldm_ctx* ctx, const void* x, long ldx, const float* gamma, const
   if constexpr (V == 4) {
     EEG_ENV_VAR(bool, off, getenv("EEGLDM_GN_NO_RESIDENT") != nullptr);
     // 12 rows per thread (56 VGPRs: two 1024-thread blocks per CU) measured faster than 24 (one block per CU): 24 vs 35 us
-    EEG_ENV_VAR(int, fwd_rpt_max, getenv("EEGLDM_GN_FWD_RPT") ? atoi(getenv("EEGLDM_GN_FWD_RPT")) : 12);
+    constexpr int fwd_rpt_max = 12;
     // threads per block: 1024 = one (sample, 64-channel) slab per block; 512 / 256 = narrower slabs (32 / 16 channels), 2 / 4x as many
     // independent blocks per CU whose load / reduce / store phases interleave (EEGLDM_GN_FWD_NTH; narrow slabs use the XCD-aware order)
     EEG_ENV_VAR(int, fwd_nth, getenv("EEGLDM_GN_FWD_NTH") ? atoi(getenv("EEGLDM_GN_FWD_NTH")) : 1024);
@@ -1054,9 +996,9 @@ int gn_fwd_t(eegldm_ctx* ctx, const void* x, long ldx, const float* gamma, const
     }
     // measured (tools/debug/gn_bench.py): wins while the rows are at least a 128-byte line and the blocks fit two rounds
     // (1024 blocks = the 100 MB concat tensors of the up path: 47-48 us one-pass vs 51 us split)
-    EEG_ENV_VAR(long, fwd_bpc, getenv("EEGLDM_GN_FWD_BLOCKS_PER_CU") ? atol(getenv("EEGLDM_GN_FWD_BLOCKS_PER_CU")) : 4);
-    EEG_ENV_VAR(bool, no_xcd, getenv("EEGLDM_GN_NO_XCD") != nullptr);
-    EEG_ENV_VAR(int, narrow_min, getenv("EEGLDM_GN_NARROW_MIN_ROW") ? atoi(getenv("EEGLDM_GN_NARROW_MIN_ROW")) : 32);    // 32-byte rows (16-channel slabs) are fine under the XCD-aware order: L = 3072 runs one-pass (pixel-space step 22.84 -> 22.64 ms); 128 = round-2 behaviour
+    constexpr long fwd_bpc = 4;
+    constexpr bool no_xcd = false;
+    constexpr int narrow_min = 32;    // 32-byte rows (16-channel slabs) are fine under the XCD-aware order: L = 3072 runs one-pass (pixel-space step 22.84 -> 22.64 ms); 128 = round-2 behaviour
     const bool can_xcd = !no_xcd && B % 8 == 0;
     const int min_row = nth == 1024 ? (can_xcd ? narrow_min : 128) : 32;
     if (cc && (cc * (int)sizeof(T) < min_row || (long)(C / cc) * B > fwd_bpc * ctx->num_cu * (1024 / nth))) cc = 0;
@@ -1095,8 +1037,7 @@ int gn_bwd_t(eegldm_ctx* ctx, const void* x, long ldx, const float* gamma, const
   if (colsum_done) *colsum_done = 0;
   if (dxr2_done) *dxr2_done = 0;
   if (slots_deferred) *slots_deferred = 0;
-  EEG_ENV_VAR(bool, no_dxr2, getenv("EEGLDM_GN_NO_DXR2") != nullptr);
-  if (!dxr2_done || lddxr2 % 4 != 0 || no_dxr2) dxr2 = nullptr;      // only a caller that can fall back may hand over a second addend
+  if (!dxr2_done || lddxr2 % 4 != 0) dxr2 = nullptr;      // only a caller that can fall back may hand over a second addend
   if constexpr (V == 4) {
     EEG_ENV_VAR(bool, off, getenv("EEGLDM_GN_NO_RESIDENT") != nullptr);
     EEG_ENV_VAR(int, bwd_nth, getenv("EEGLDM_GN_BWD_NTH") ? atoi(getenv("EEGLDM_GN_BWD_NTH")) : 1024);      // see gn_fwd_t
@@ -1121,7 +1062,7 @@ int gn_bwd_t(eegldm_ctx* ctx, const void* x, long ldx, const float* gamma, const
     if constexpr (sizeof(T) == 2) {
       // pipelined persistent form (gn_bwd_pipe_kernel): slabs of exactly 6 rows x 4 channels per thread, L * CC = 24 576, CC a power of two
       EEG_ENV_VAR(bool, no_pipe, getenv("EEGLDM_GN_NO_PIPE") != nullptr);
-      EEG_ENV_VAR(int, pipe_min_row, getenv("EEGLDM_GN_PIPE_MIN_ROW") ? atoi(getenv("EEGLDM_GN_PIPE_MIN_ROW")) : 64);
+      constexpr int pipe_min_row = 64;
       EEG_ENV_VAR(int, pipe_min_slabs, getenv("EEGLDM_GN_PIPE_MIN_SLABS") ? atoi(getenv("EEGLDM_GN_PIPE_MIN_SLABS")) : 2);
       EEG_ENV_VAR(int, pipe_max_slot, getenv("EEGLDM_GN_PIPE_MAX_SLOT") ? atoi(getenv("EEGLDM_GN_PIPE_MAX_SLOT")) : 1 << 20);
       // with a residual-path addend (a fourth 48 KB stream per slab) the kernel is bandwidth-bound like the resident one and measures
@@ -1138,7 +1079,7 @@ int gn_bwd_t(eegldm_ctx* ctx, const void* x, long ldx, const float* gamma, const
         int nslot = per_xcd / nchunk; if (nslot > B / 8) nslot = B / 8; if (nslot > pipe_max_slot) nslot = pipe_max_slot;
         if (nslot >= 1 && (long)nchunk * B >= (long)pipe_min_slabs * 8 * nslot * nchunk) {
           float* slots = nullptr;
-          EEG_ENV_VAR(bool, no_defer_p, getenv("EEGLDM_GN_NO_DEFER") != nullptr);
+          constexpr bool no_defer_p = false;
           const bool det = eeg_deterministic() && dgamma;      // a slot per sample (one writer each), folded right behind the launch in sample order
           const bool defer = slots_deferred && dgamma && !no_defer_p && !det;
           int ndg = GN_NSLOT;
@@ -1148,7 +1089,7 @@ int gn_bwd_t(eegldm_ctx* ctx, const void* x, long ldx, const float* gamma, const
             EEG_TRY(eeg_det_buffer(ctx, (size_t)ndg * 2 * C * sizeof(float), &slots));
             HIP_TRY(hipMemsetAsync(slots, 0, (size_t)ndg * 2 * C * sizeof(float), ctx->stream));
           }
-          EEG_ENV_VAR(bool, no_batch_p, getenv("EEGLDM_GN_NO_BATCHED_FOLD") != nullptr);
+          constexpr bool no_batch_p = false;
           const bool batched = defer && ctx->defer_wgrad && !no_batch_p && C <= 1024 && ctx->gn_fold_count < GN_FOLD_MAX;
           if (batched) {
             if (!ctx->gn_slot_arena) {
@@ -1188,10 +1129,9 @@ int gn_bwd_t(eegldm_ctx* ctx, const void* x, long ldx, const float* gamma, const
     int rpt = 0; int cc = off ? 0 : resident_chunk(L, C, G, 0, sizeof(T) == 2 ? 12 : 8, &rpt, nth);
     // measured (tools/debug/gn_bench.py): the one-pass kernel wins while its blocks fit two rounds of one block per CU
     // (1024 blocks: 112 us one-pass vs 117-120 us split on the 100 MB tensors; 2048 blocks of 96-channel chunks lose)
-    EEG_ENV_VAR(long, bwd_bpc, getenv("EEGLDM_GN_BWD_BLOCKS_PER_CU") ? atol(getenv("EEGLDM_GN_BWD_BLOCKS_PER_CU")) : 8);
-    EEG_ENV_VAR(int, bwd_minrow, getenv("EEGLDM_GN_BWD_MIN_ROW_BYTES") ? atoi(getenv("EEGLDM_GN_BWD_MIN_ROW_BYTES")) : 128);
-    EEG_ENV_VAR(bool, no_xcd, getenv("EEGLDM_GN_NO_XCD") != nullptr);
-    EEG_ENV_VAR(int, narrow_min, getenv("EEGLDM_GN_NARROW_MIN_ROW") ? atoi(getenv("EEGLDM_GN_NARROW_MIN_ROW")) : 32);
+    constexpr long bwd_bpc = 8;
+    constexpr int bwd_minrow = 128, narrow_min = 32;
+    constexpr bool no_xcd = false;
     const bool can_xcd = !no_xcd && B % 8 == 0;
     const int min_row = nth == 1024 ? (can_xcd && narrow_min < bwd_minrow ? narrow_min : bwd_minrow) : 32;
     if (cc && (cc * (int)sizeof(T) < min_row || (long)(C / cc) * B > bwd_bpc * ctx->num_cu * (1024 / nth))) cc = 0;
@@ -1200,7 +1140,7 @@ int gn_bwd_t(eegldm_ctx* ctx, const void* x, long ldx, const float* gamma, const
       const dim3 grid((unsigned)((long)(C / cc) * B));
       // a caller that can run the 7-us fold of the dgamma / dbeta partial slots elsewhere (side stream) gets them in the second slot
       // region and calls op_gn_slot_reduce_deferred itself
-      EEG_ENV_VAR(bool, no_defer, getenv("EEGLDM_GN_NO_DEFER") != nullptr);
+      constexpr bool no_defer = false;
       const bool det = eeg_deterministic() && dgamma;      // see the pipelined launch above
       const bool defer = slots_deferred && dgamma && !no_defer && !det;
       float* slots = dgamma ? (float*)((char*)ctx->scratch + (defer ? gn_slot_region(defer_region) : GN_SLOT_OFFSET)) : nullptr;
@@ -1212,7 +1152,7 @@ int gn_bwd_t(eegldm_ctx* ctx, const void* x, long ldx, const float* gamma, const
       }
       // batched mode (the UNet backward with grouped weight gradients): this launch gets its OWN slot region and is folded together with
       // all the others by op_gn_fold_flush -- 49 folds of 7 us become one launch
-      EEG_ENV_VAR(bool, no_batch, getenv("EEGLDM_GN_NO_BATCHED_FOLD") != nullptr);
+      constexpr bool no_batch = false;
       const bool batched = defer && ctx->defer_wgrad && !no_batch && C <= 1024 && ctx->gn_fold_count < GN_FOLD_MAX;
       if (batched) {
         if (!ctx->gn_slot_arena) {
@@ -1226,7 +1166,7 @@ int gn_bwd_t(eegldm_ctx* ctx, const void* x, long ldx, const float* gamma, const
 #define GN_BWD_RES3(R, RAW, SL, N) hipLaunchKernelGGL((gn_bwd_resident_kernel<T, R, RAW, SL, N>), grid, dim3(N), 0, ctx->stream, (const T*)x, ldx, gamma, beta, stats, \
                                          (const T*)dy, lddy, (T*)dx, lddx, (const T*)dxr, lddxr, slots, colsum_ps, ldps, L, C, G, silu, resample, cc, (const T*)dxr2, lddxr2, xcd, nslot)
 #define GN_BWD_RES2(R, RAW, SL) do { if (nth == 1024) GN_BWD_RES3(R, RAW, SL, 1024); else if (nth == 512) GN_BWD_RES3(R, RAW, SL, 512); else GN_BWD_RES3(R, RAW, SL, 256); } while (0)
-      EEG_ENV_VAR(bool, raw0, getenv("EEGLDM_GN_NO_RAW0") == nullptr);
+      constexpr bool raw0 = true;
 #define GN_BWD_RES1(R, RAW) do { if (silu) GN_BWD_RES2(R, RAW, true); else GN_BWD_RES2(R, RAW, false); } while (0)
 #define GN_BWD_RES(R) do { if (resample == 0 && raw0) GN_BWD_RES1(R, true); else GN_BWD_RES1(R, false); } while (0)
       constexpr int RLO = sizeof(T) == 2 ? 6 : 4, RHI = sizeof(T) == 2 ? 12 : 8;
@@ -1599,35 +1539,6 @@ bool vec4_ok(int C, int G, long a, long b, long c, long d) {
 
 }  // namespace
 
-// 1 = launched, 0 = not this path's shape (the caller runs the ordinary forward)
-int gn_fwd_from_qstats(eegldm_ctx* ctx, const void* x, long ldx, const float* gamma, const float* beta, void* y, long ldy, float* stats,
-                       int B, int L, int C, int G, float eps, int silu, const double* qsA, int nqa, const double* qsB, int nqb) {
-  EEG_ENV_VAR(bool, off, getenv("EEGLDM_GN_NO_QSTATS") != nullptr);
-  if (off || eeg_deterministic() || !qsA || (nqa + nqb) * 4 != C || (nqb > 0 && !qsB) || C % 8 != 0 || G <= 0 || C % G != 0 || (C / G) % 4 != 0) return 0;
-  if (ldx % 8 != 0 || ldy % 8 != 0 || (((size_t)x | (size_t)y) & 15) || !stats) return 0;
-  // row chunks: a block's prologue (fold of the group moments, 16 scale / shift values per thread) is ~2 us of dependent L2 loads, so a
-  // thread streams at least 8 rows (first version: 12-row chunks = 3 rows per thread, 30 us on the 50 MB tensors against the resident
-  // kernel's 27); ~6 blocks per CU keep enough loads in flight
-  EEG_ENV_VAR(int, q_per_cu, getenv("EEGLDM_GN_Q_BLOCKS_PER_CU") ? atoi(getenv("EEGLDM_GN_Q_BLOCKS_PER_CU")) : 6);
-  const int ncols = C / 8, ty = ncols < NT ? NT / ncols : 1;
-  int rpb; const int ls = pick_lsplit(B, L, C, ctx, &rpb, q_per_cu, 8 * ty);
-  hipLaunchKernelGGL(gn_apply_q_kernel, dim3(ls, B), dim3(NT), 0, ctx->stream, (const bf16_t*)x, ldx, gamma, beta, qsA, nqa, qsB, nqb, stats,
-                     (bf16_t*)y, ldy, L, C, G, eps, silu, rpb);
-  LAUNCH_CHECK();
-  return 1;
-}
-
-extern "C" int eegldm_groupnorm_fwd_qstats(eegldm_ctx* ctx, const void* x, long ldx, const float* gamma, const float* beta, void* y, long ldy,
-                                           float* stats, int B, int L, int C, int G, float eps, int fuse_silu, const double* qs_a, int nq_a,
-                                           const double* qs_b, int nq_b, int dtype) {
-  EEG_CHECK(ctx && x && gamma && beta && y && stats && qs_a, "null pointer");
-  EEG_CHECK(dtype == EEGLDM_BF16, "the streaming forward from producer moments is a 16-bit path");
-  EEG_TRY(gn_check(ctx, B, L, C, G, 0, ldx));
-  const int rc = gn_fwd_from_qstats(ctx, x, ldx, gamma, beta, y, ldy, stats, B, L, C, G, eps, fuse_silu, qs_a, nq_a, qs_b, nq_b);
-  if (rc < 0) return rc;
-  EEG_CHECK(rc == 1, "not eligible: C %% 8, (C / G) %% 4, 16-byte rows, (nq_a + nq_b) * 4 == C, deterministic mode off");
-  return 0;
-}
 extern "C" int eegldm_groupnorm_fwd(eegldm_ctx* ctx, const void* x, long ldx, const float* gamma, const float* beta,
                                     void* y, long ldy, float* stats, int B, int L, int C, int G, float eps,
                                     int fuse_silu, int resample, void* xr, long ldxr, int dtype) {
@@ -1718,8 +1629,6 @@ int op_gn_fold_flush(eegldm_ctx* ctx) {
 }
 
 int op_gn_slot_reduce_deferred(eegldm_ctx* ctx, float* dgamma, float* dbeta, int C, int region) {
-  EEG_ENV_VAR(bool, dbg_skip, getenv("EEGLDM_DBG_SKIP_FOLDS") != nullptr);      // timing experiment only: leaves dgamma / dbeta unfolded
-  if (dbg_skip) return 0;
   float* slots = (float*)((char*)ctx->scratch + gn_slot_region(region));
   hipLaunchKernelGGL(gn_slot_reduce_kernel, dim3((2 * C + 255) / 256), dim3(256), 0, ctx->stream, slots, dgamma, dbeta, C, (double*)ctx->scratch, 0);
   LAUNCH_CHECK();

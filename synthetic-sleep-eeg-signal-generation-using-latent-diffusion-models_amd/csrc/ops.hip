@@ -12,8 +12,7 @@ static inline int conv_lout(int Lin, int K, int stride, int pad_l, int pad_r) { 
 bool op_conv_fuses_act(int dtype, int Cin, int Cout, int K, long ldy) { return conv_is_thin(Cin, Cout, dtype) && dconv_fuses_act(dtype, Cin, Cout, K, ldy); }
 int op_conv_fwd(eegldm_ctx* ctx, int dtype, const void* x, long ldx, const void* w, const float* bias, void* y, long ldy,
                 int B, int Lin, int Cin, int Cout, int K, int stride, int pad_l, int pad_r,
-                const float* rowvec, long ld_rowvec, const void* resid, long ldr, float act_slope, double* qstats, int* qstats_done) {
-  if (qstats_done) *qstats_done = 0;
+                const float* rowvec, long ld_rowvec, const void* resid, long ldr, float act_slope) {
   EEG_CHECK(B > 0 && Lin > 0 && Cin > 0 && Cout > 0 && (K == 1 || K == 3) && (stride == 1 || stride == 2),
             "unsupported conv B=%d Lin=%d Cin=%d Cout=%d K=%d stride=%d", B, Lin, Cin, Cout, K, stride);
   const int Lout = conv_lout(Lin, K, stride, pad_l, pad_r);
@@ -51,7 +50,6 @@ int op_conv_fwd(eegldm_ctx* ctx, int dtype, const void* x, long ldx, const void*
   a.M = B * Lout; a.N = Cout; a.K = Cin; a.batch = 1; a.taps = K; a.alpha = 1.0f; a.bias = bias;
   a.rowvec = rowvec; a.ld_rowvec = ld_rowvec; a.rows_per_vec = Lout; a.resid = resid; a.ldr = ldr;
   a.bmode = GB_NT;
-  if (qstats && qstats_done && stride == 1) { a.qstats = qstats; a.qstats_L = Lout; a.qstats_done = qstats_done; }
   if (K == 1) {
     EEG_CHECK(stride == 1 && pad_l == 0 && pad_r == 0, "1x1 conv must be stride 1, no padding");
     a.amode = GA_PLAIN;
@@ -68,8 +66,7 @@ int op_conv_fwd(eegldm_ctx* ctx, int dtype, const void* x, long ldx, const void*
 
 int op_conv3_skip_fwd(eegldm_ctx* ctx, int dtype, const void* x, long ldx, const void* w, const float* bias, const void* x2, long ldx2,
                       const void* w2, const float* bias2, void* y, long ldy, int B, int L, int Cin, int Cin2, int Cout,
-                      const float* rowvec, long ld_rowvec, double* qstats, int* qstats_done) {
-  if (qstats_done) *qstats_done = 0;
+                      const float* rowvec, long ld_rowvec) {
   if (dtype != EEGLDM_F32 && !ctx->kblk.empty() && !conv_is_thin(Cin, Cout, dtype)) {
     auto it = ctx->kblk.find(w), it2 = ctx->kblk.find(w2);
     if (it != ctx->kblk.end() && it2 != ctx->kblk.end()) {
@@ -78,13 +75,12 @@ int op_conv3_skip_fwd(eegldm_ctx* ctx, int dtype, const void* x, long ldx, const
       a.M = B * L; a.N = Cout; a.K = Cin; a.batch = 1; a.taps = 3; a.alpha = 1.0f; a.bias = bias; a.splitk = 1; a.ups = 1;
       a.rowvec = rowvec; a.ld_rowvec = ld_rowvec; a.rows_per_vec = L; a.bmode = GB_NT;
       a.amode = GA_CONV; a.Lout = L; a.Lin = L; a.stride = 1; a.pad_l = 1;
-      if (qstats && qstats_done) { a.qstats = qstats; a.qstats_L = L; a.qstats_done = qstats_done; }
       const int rc = gemm_big_skip_try(ctx, a, x2, ldx2, it2->second, Cin2, bias2);
       if (rc != 0) return rc < 0 ? rc : 0;
     }
   }
   EEG_TRY(op_conv_fwd(ctx, dtype, x2, ldx2, w2, bias2, y, ldy, B, L, Cin2, Cout, 1, 1, 0, 0, nullptr, 0, nullptr, 0));
-  return op_conv_fwd(ctx, dtype, x, ldx, w, bias, y, ldy, B, L, Cin, Cout, 3, 1, 1, 1, rowvec, ld_rowvec, y, ldy, 0.f, qstats, qstats_done);
+  return op_conv_fwd(ctx, dtype, x, ldx, w, bias, y, ldy, B, L, Cin, Cout, 3, 1, 1, 1, rowvec, ld_rowvec, y, ldy);
 }
 
 int op_conv_dgrad(eegldm_ctx* ctx, int dtype, const void* dy, long lddy, const void* w, void* dx, long lddx,
@@ -173,21 +169,14 @@ int op_conv_wgrad(eegldm_ctx* ctx, int dtype, const void* x, long ldx, const voi
   if (fused3) {   // one block = all three taps of a 128 x 64 (or 128 x 128) weight tile: dY and X staged once per K chunk
     a.taps = 3; a.ztaps = 1; a.conv_map = 0;
     bn = Cin > 32 ? 64 : 32;
-    // opt-in experiment (EEGLDM_WGRAD_WIDE_MIN=128): the 128 x 128 x 3 tile as ONE 8-wave block per CU.  Measured (round 2, B=256):
-    // 5-8 % SLOWER than two independent 128 x 64 blocks per CU although it stages a third fewer bytes -- with one barrier domain per
-    // CU every wave waits at every stage, two independent blocks overlap each other's waits
-    EEG_ENV_VAR(int, wide_min, getenv("EEGLDM_WGRAD_WIDE_MIN") ? atoi(getenv("EEGLDM_WGRAD_WIDE_MIN")) : 0);
-    if (dtype != EEGLDM_F32 && wide_min > 0 && Cin % 128 == 0 && Cout % 128 == 0 && Cin >= wide_min) { a.wide_n = 1; bn = 128; blocks_per_cu = 1; }
+    // (the 128 x 128 x 3 tile as ONE 8-wave block per CU measured 5-8 % slower than two independent 128 x 64 blocks, round 2; removed in round 6)
     tiles = (long)((Cout + 127) / 128) * ((Cin + bn - 1) / bn);
   } else {
     tiles = (long)((Cout + 127) / 128) * ((Cin + bn - 1) / bn) * K;
   }
   // fill the resident blocks of every CU in ONE round: rounding the split count up (11 x 48 tiles = 528 blocks on 512 slots) leaves a
   // second round of 16 blocks that costs as much as the first
-  EEG_ENV_VAR(bool, split_ceil, getenv("EEGLDM_WGRAD_SPLIT_CEIL") != nullptr);
-  long want = split_ceil ? ((long)ctx->num_cu * blocks_per_cu + tiles - 1) / tiles : ((long)ctx->num_cu * blocks_per_cu) / tiles;
-  EEG_ENV_VAR(int, split_div, getenv("EEGLDM_WGRAD_SPLIT_DIV") ? atoi(getenv("EEGLDM_WGRAD_SPLIT_DIV")) : 1);   // experiment: fewer, longer splits (smaller launches that co-run with the main stream)
-  if (split_div > 1 && ctx->side_on) want = (want + split_div - 1) / split_div;
+  long want = ((long)ctx->num_cu * blocks_per_cu) / tiles;
   long maxs = ((long)a.K + 8 * kstage - 1) / (8 * kstage);     // at least 8 stages per split
   if (want > maxs) want = maxs;
   a.splitk = (int)(want < 1 ? 1 : want);
@@ -201,8 +190,6 @@ int op_conv_wgrad(eegldm_ctx* ctx, int dtype, const void* x, long ldx, const voi
     ctx->wgrad_pending.push_back(r);
     return 0;
   }
-  { EEG_ENV_VAR(bool, dbg_groups, getenv("EEGLDM_DBG_GROUPS") != nullptr);
-    if (dbg_groups && ctx->defer_wgrad) fprintf(stderr, "wgrad NOT deferred: K %d stride %d pads %d %d Cin %d Cout %d rows %d fused3 %d kstage %d wide %d\n", K, stride, pad_l, pad_r, Cin, Cout, a.K, (int)fused3, kstage, a.wide_n); }
   return gemm_launch(ctx, a);
 }
 
@@ -234,16 +221,13 @@ int op_wgrad_flush(eegldm_ctx* ctx) {
     const long tiles_total = recs[i].tiles * g.ngroup, S = ((long)g.K + recs[i].kstage - 1) / recs[i].kstage;
     long maxs = S / 8; if (maxs < 1) maxs = 1; if (maxs > 256) maxs = 256;
     double best = 1e30; int bs = 1;
-    EEG_ENV_VAR(double, c_fixed, getenv("EEGLDM_WGRAD_COST_FIXED") ? atof(getenv("EEGLDM_WGRAD_COST_FIXED")) : 8.0);
-    EEG_ENV_VAR(double, c_block, getenv("EEGLDM_WGRAD_COST_BLOCK") ? atof(getenv("EEGLDM_WGRAD_COST_BLOCK")) : 0.05);
+    constexpr double c_fixed = 8.0, c_block = 0.05;      // (round 5 swept both 5-50x: the step moved by +-0.05 ms -- the partial writes hide behind the other blocks' K loops)
     for (long sp = 1; sp <= maxs; sp++) {
       const long blocks = tiles_total * sp, rounds = (blocks + slots - 1) / slots;
       const double cost = (double)rounds * ((double)S / (double)sp + c_fixed) + c_block * (double)blocks;
       if (cost < best) { best = cost; bs = (int)sp; }
     }
     g.splitk = bs; g.batch = g.ngroup;
-    EEG_ENV_VAR(bool, dbg_groups, getenv("EEGLDM_DBG_GROUPS") != nullptr);
-    if (dbg_groups) fprintf(stderr, "wgrad group: taps %d M %d N %d K %d x%d tiles %ld -> splitk %d\n", g.taps, g.M, g.N, g.K, g.ngroup, recs[i].tiles, bs);
     EEG_TRY(gemm_launch_grouped(ctx, g, tab, ctx->grp_slot++));
   }
   return 0;
@@ -389,12 +373,6 @@ extern "C" int eegldm_conv1d_forget_kblocked(eegldm_ctx* ctx, const void* w) {
   EEG_CHECK(ctx && w, "null pointer");
   ctx->kblk.erase(w); ctx->kblk_t.erase(w); ctx->s2ws_f.erase(w); ctx->s2ws_d.erase(w);
   return 0;
-}
-extern "C" int eegldm_conv1d_fwd_qstats(eegldm_ctx* ctx, const void* x, long ldx, const void* w, const float* bias, void* y, long ldy,
-                                        int B, int Lin, int Cin, int Cout, int K, int stride, int pad_l, int pad_r,
-                                        const float* rowvec, long ld_rowvec, const void* resid, long ld_resid, int dtype, double* qstats, int* filled) {
-  EEG_CHECK(ctx && x && w && y && qstats && filled, "null pointer");
-  return op_conv_fwd(ctx, dtype, x, ldx, w, bias, y, ldy, B, Lin, Cin, Cout, K, stride, pad_l, pad_r, rowvec, ld_rowvec, resid, ld_resid, 0.f, qstats, filled);
 }
 // ---- round-6 prototype: GroupNorm(+SiLU) on the consuming conv's operand load (gemm_big.hip XF kernels)
 // scale[b][c] = gamma[c] rstd[b, g(c)], shift[b][c] = beta[c] - mean[b, g(c)] scale[b][c] from the (mean, rstd) pairs a GroupNorm statistics pass

@@ -277,7 +277,6 @@ extern "C" int eegldm_unet_forward(eegldm_unet* u, const float* x, const int64_t
   {
     EEG_ENV_VAR(bool, no_fuse, getenv("EEGLDM_NO_EVAL_GN_FUSE") != nullptr);
     u->eval_fuse = !training && !no_fuse && (dt == EEGLDM_BF16 || dt == EEGLDM_F16); u->fused_used = false; u->fuse_used = 0; u->part_reg.clear();
-    EEG_TRY(u->qbegin());
     if (u->eval_fuse) {
       // slots: B * L_out / 16 * cout / 4 per ResBlock; an upper bound from the widest / longest block keeps this simple
       size_t nres = 0; int cmax = 0;
