@@ -22,6 +22,7 @@ int ls_bn_lrelu_bwd(eegldm_ctx*, const void* x, long ldx, const float* gamma, co
                     void* dx, long lddx, float* dgamma, float* dbeta, long rows, int C, float slope, int dtype);
 int ls_bn_repeat_running(eegldm_ctx*, const float* stats, float* rmean, float* rvar, float* nbt, long rows, int C);
 int ls_bn_stats(eegldm_ctx*, const void* x, long ldx, float* stats, float* rmean, float* rvar, float* nbt, long rows, int C, int training, int dtype);
+int ls_bn_stats_from_parts(eegldm_ctx*, const float* parts, int nb, float* stats, float* rmean, float* rvar, float* nbt, long rows, int C);
 int ls_bn_apply(eegldm_ctx*, const void* x, long ldx, const float* gamma, const float* beta, const float* stats, void* y, long ldy, long rows, int C, float slope, int dtype);
 // fused tail of the discriminator (disc_tail.hip): BatchNorm + LeakyReLU of the last hidden layer + the one-channel final conv, forward and backward
 bool disc_tail_ok(int dtype, int C, long ldy);
@@ -61,6 +62,7 @@ struct SeqNet : NetBase {
 
 int SeqNet::forward_seq(const std::vector<Op>& ops, View x, int B, int& L, View* out, std::vector<OpTape>& tape, int training) {
   const int dt = dtype;
+  int bn_parts_n = 0;      // > 0: the conv that just ran left that many rows of column partials in the context scratch for the BatchNorm that follows
   for (size_t i = 0; i < ops.size(); i++) {
     const Op& o = ops[i];
     OpTape t; t.x = x; t.Lin = L;
@@ -72,8 +74,13 @@ int SeqNet::forward_seq(const std::vector<Op>& ops, View x, int B, int& L, View*
       // ACTIVATED tensor as the activation op's input: LeakyReLU keeps the sign, so its backward mask (x > 0) is unchanged.
       const bool fuse_act = i + 1 < ops.size() && ops[i + 1].kind == OP_ACT && ops[i + 1].bn_w < 0 && (long)B * Lo < (1L << 30) &&
                             op_conv_fuses_act(dt, o.cin, o.cout, o.k, y.ld);
+      // a conv followed by a training-mode BatchNorm: kernels that can leave the column sums of their output do (conv_ws.hip), and the BatchNorm
+      // below folds those instead of reading y again
+      const bool bn_next = i + 1 < ops.size() && ops[i + 1].kind == OP_ACT && ops[i + 1].bn_w >= 0 && training != 0 && !eeg_deterministic();
+      float* cparts = bn_next ? (float*)((char*)ctx->scratch + (8u << 20)) : nullptr;
+      bn_parts_n = 0;
       EEG_TRY(op_conv_fwd(ctx, dt, x.p, x.ld, W(o.w), o.b >= 0 ? P(o.b) : nullptr, y.p, y.ld, B, L, o.cin, o.cout, o.k, o.stride, o.pl, o.pr,
-                          nullptr, 0, nullptr, 0, fuse_act ? ops[i + 1].slope : 0.f));
+                          nullptr, 0, nullptr, 0, fuse_act ? ops[i + 1].slope : 0.f, cparts, bn_next ? &bn_parts_n : nullptr));
       L = Lo;
       if (fuse_act) {
         t.Lout = L; tape.push_back(t);
@@ -97,8 +104,14 @@ int SeqNet::forward_seq(const std::vector<Op>& ops, View x, int B, int& L, View*
       if (o.bn_w >= 0) {
         ALLOC_OR_FAIL(t.st, arena.alloc(sizeof(float) * 2 * x.C));
         const bool upd = buffers && training != 2;      // training == 2: batch statistics, running statistics left alone (a re-forward for a second backward)
+        if (bn_parts_n > 0 && training != 0) {      // the conv in front of this layer left the column sums of x (= its output)
+          EEG_TRY(ls_bn_stats_from_parts(ctx, (const float*)((char*)ctx->scratch + (8u << 20)), bn_parts_n, t.st, upd ? buffers + o.rm : nullptr,
+                                         upd ? buffers + o.rv : nullptr, upd ? buffers + o.nbt : nullptr, (long)B * L, x.C));
+          EEG_TRY(ls_bn_apply(ctx, x.p, x.ld, P(o.bn_w), P(o.bn_b), t.st, y.p, y.ld, (long)B * L, x.C, o.slope, dt));
+        } else
         EEG_TRY(ls_bn_lrelu_fwd(ctx, x.p, x.ld, P(o.bn_w), P(o.bn_b), t.st, upd ? buffers + o.rm : nullptr, upd ? buffers + o.rv : nullptr,
                                 upd ? buffers + o.nbt : nullptr, y.p, y.ld, (long)B * L, x.C, o.slope, training, dt));
+        bn_parts_n = 0;
       } else {
         EEG_TRY(ls_bn_lrelu_fwd(ctx, x.p, x.ld, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, y.p, y.ld, (long)B * L, x.C, o.slope, training, dt));
       }

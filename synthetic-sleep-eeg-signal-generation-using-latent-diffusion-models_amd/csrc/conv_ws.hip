@@ -37,6 +37,10 @@ struct WsArgs {
   bf16_t* y; long ldy;
   int M, L, N, ntiles, tiles_per_block;
   const void* zero_page;
+  // statistics epilogue (ST kernels, round 6): per-block partial (sum, sum of squares) of every output column over the block's tiles, fp32 of the
+  // UNROUNDED outputs, row blockIdx.x of col_parts ([gridDim.x][2 N], interleaved) -- the batch statistics of the BatchNorm that reads this
+  // tensor next (MONAI PatchDiscriminator layer = conv -> BatchNorm -> LeakyReLU), folded by losses.hip ls_bn_fold: no separate read of y
+  float* col_parts;
 };
 
 typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
@@ -60,12 +64,30 @@ __device__ __forceinline__ u32x2 ws_load8(const void* g) {
   return r;
 }
 
+// ST epilogue: the 16 lanes of a row group (lm) hold the same columns -> four DPP adds each, then lane lm == 0 writes its 8 columns' pairs
+__device__ __forceinline__ float ws_row16_sum(float v) {
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, true));
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xF, 0xF, true));
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x141, 0xF, 0xF, true));
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x140, 0xF, 0xF, true));
+  return v;
+}
+__device__ __forceinline__ void ws_col_stats(float (&cs)[2][4], float (&cq)[2][4], float* __restrict__ row, int n0, int lm, int q) {
+#pragma unroll
+  for (int cf = 0; cf < 2; cf++)
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+      const float a = ws_row16_sum(cs[cf][r]), b = ws_row16_sum(cq[cf][r]);
+      if (lm == 0) *(float2*)(row + 2 * (n0 + cf * 16 + q * 4 + r)) = make_float2(a, b);
+    }
+}
+
 // VMEM bookkeeping (all waits below are by hand; loads retire in order):
 //   iteration t issues, in this order: stores of tile t-1 (4), residual loads of tile t (8, asm), DMA of tile t+2 (4; wave 0: 5)
 //   top of iteration t    : everything up to DMA(t) must have landed; younger loads = DMA(t+1) only          -> vmcnt(4) / vmcnt(0) at the tail
 //   before the epilogue   : residual(t) must have landed; younger loads = DMA(t+2) only                      -> vmcnt(4) / vmcnt(0)
 // (wave 0's fifth DMA instruction is waited for one step early; the stores are a tile old by the time a count could include them)
-template <bool TR, typename T16 = bf16_t>      // TR: weight fragments gathered with a stride (the data gradient reads the packed weights transposed)
+template <bool TR, typename T16 = bf16_t, bool ST = false>      // TR: weight fragments gathered with a stride (the data gradient reads the packed weights transposed); ST: column statistics (WsArgs::col_parts)
 __global__ __launch_bounds__(256, 2) void conv3_ws_kernel(const WsArgs p) {
   extern __shared__ __attribute__((aligned(1024))) char smem[];
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, lm = lane & 15, q = lane >> 4;
@@ -130,6 +152,11 @@ __global__ __launch_bounds__(256, 2) void conv3_ws_kernel(const WsArgs p) {
     }
   };
 
+  float cs[2][4], cq[2][4];      // ST: running column sums / sums of squares of this lane's rows (columns n0 + cf * 16 + q * 4 + r)
+#pragma unroll
+  for (int cf = 0; cf < 2; cf++)
+#pragma unroll
+    for (int r = 0; r < 4; r++) { cs[cf][r] = 0.f; cq[cf][r] = 0.f; }
   for (int t = t_begin; t < t_end; t++) {
     const int buf = (t - t_begin) % WS_RING;
     const long row0 = (long)t * WS_ROWS;
@@ -199,12 +226,17 @@ __global__ __launch_bounds__(256, 2) void conv3_ws_kernel(const WsArgs p) {
           v0 += w16_lo<T16>(rr[rf][cf].x); v1 += w16_hi<T16>(rr[rf][cf].x);
           v2 += w16_lo<T16>(rr[rf][cf].y); v3 += w16_hi<T16>(rr[rf][cf].y);
         }
+        if constexpr (ST) {
+          cs[cf][0] += v0; cs[cf][1] += v1; cs[cf][2] += v2; cs[cf][3] += v3;
+          cq[cf][0] = fmaf(v0, v0, cq[cf][0]); cq[cf][1] = fmaf(v1, v1, cq[cf][1]); cq[cf][2] = fmaf(v2, v2, cq[cf][2]); cq[cf][3] = fmaf(v3, v3, cq[cf][3]);
+        }
         const int row = rf * 16 + lm, ch = wave * 4 + cf * 2 + (q >> 1);
         *(uint2*)(sOut + row * WS_ROW_BYTES + ((ch ^ (row & 15)) * 16) + (q & 1) * 8) = make_uint2(pack16x2<T16>(v0, v1), pack16x2<T16>(v2, v3));
       }
   }
   ws_barrier();
   store_tile(t_end - 1);
+  if constexpr (ST) ws_col_stats(cs, cq, p.col_parts + (size_t)blockIdx.x * 2 * p.N, n0, lm, q);
 }
 
 // ================================================================ stride-2 Conv1d(128 -> 256, k 3, padding 1) over PAIRED rows (round 6)
@@ -229,6 +261,7 @@ struct Ws2Args {
   bf16_t* y; long ldy;                 // [M][256]
   int M, L, ntiles, tiles_per_block;   // rows of the paired view, rows per sample
   const void* zero_page;
+  float* col_parts;                    // forward, ST kernels: as WsArgs::col_parts, rows of 2 x 256
 };
 
 // MODE 0: forward; 1 / 2: data gradient, even / odd half of the paired dx row (blockIdx.y).  SLOTS = non-empty (tap, k-step) pairs.
@@ -237,7 +270,7 @@ template <> struct W2Map<0> { static constexpr int SLOTS = 12; static __device__
 template <> struct W2Map<1> { static constexpr int SLOTS = 8;  static __device__ __forceinline__ void at(int s, int& tp, int& kk) { tp = 1; kk = s; } };
 template <> struct W2Map<2> { static constexpr int SLOTS = 16; static __device__ __forceinline__ void at(int s, int& tp, int& kk) { tp = 1 + (s >> 3); kk = s & 7; } };
 
-template <int MODE, typename T16>
+template <int MODE, typename T16, bool ST = false>
 __device__ __forceinline__ void ws2_body(const Ws2Args& p, char* smem) {
   using Map = W2Map<MODE>;
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, lm = lane & 15, q = lane >> 4;
@@ -301,6 +334,11 @@ __device__ __forceinline__ void ws2_body(const Ws2Args& p, char* smem) {
       *(uint4*)(p.y + (row0 + row) * p.ldy + nb0 + ch * 8) = v;
     }
   };
+  float cs[2][4], cq[2][4];
+#pragma unroll
+  for (int cf = 0; cf < 2; cf++)
+#pragma unroll
+    for (int r = 0; r < 4; r++) { cs[cf][r] = 0.f; cq[cf][r] = 0.f; }
   for (int t = t_begin; t < t_end; t++) {
     const int buf = (t - t_begin) % WS_RING;
     // everything up to DMA(t) landed; younger: the 2 stores of tile t - 2 and DMA(t + 1) (4 instructions, 5 in waves 0 and 1)
@@ -332,18 +370,23 @@ __device__ __forceinline__ void ws2_body(const Ws2Args& p, char* smem) {
 #pragma unroll
       for (int cf = 0; cf < 2; cf++) {
         const float v0 = acc[rf][cf][0] + bv[cf].x, v1 = acc[rf][cf][1] + bv[cf].y, v2 = acc[rf][cf][2] + bv[cf].z, v3 = acc[rf][cf][3] + bv[cf].w;
+        if constexpr (ST) {
+          cs[cf][0] += v0; cs[cf][1] += v1; cs[cf][2] += v2; cs[cf][3] += v3;
+          cq[cf][0] = fmaf(v0, v0, cq[cf][0]); cq[cf][1] = fmaf(v1, v1, cq[cf][1]); cq[cf][2] = fmaf(v2, v2, cq[cf][2]); cq[cf][3] = fmaf(v3, v3, cq[cf][3]);
+        }
         const int row = rf * 16 + lm, ch = wave * 4 + cf * 2 + (q >> 1);
         *(uint2*)(sOut + row * 256 + ((ch ^ (row & 15)) * 16) + (q & 1) * 8) = make_uint2(pack16x2<T16>(v0, v1), pack16x2<T16>(v2, v3));
       }
   }
   ws_barrier();
   store_tile(t_end - 1);
+  if constexpr (ST) ws_col_stats(cs, cq, p.col_parts + (size_t)blockIdx.x * 2 * 256, n0, lm, q);
 }
 
-template <bool DGRAD, typename T16 = bf16_t>
+template <bool DGRAD, typename T16 = bf16_t, bool ST = false>
 __global__ __launch_bounds__(256, 2) void conv3_ws2_kernel(const Ws2Args p) {
   extern __shared__ __attribute__((aligned(1024))) char smem[];
-  if constexpr (!DGRAD) ws2_body<0, T16>(p, smem);
+  if constexpr (!DGRAD) ws2_body<0, T16, ST>(p, smem);
   else { if (blockIdx.y == 0) ws2_body<1, T16>(p, smem); else ws2_body<2, T16>(p, smem); }
 }
 }  // namespace
@@ -352,7 +395,8 @@ __global__ __launch_bounds__(256, 2) void conv3_ws2_kernel(const Ws2Args p) {
 // padding at sample boundaries.  Returns 1 when this kernel took the launch, 0 when the shape is not its (the caller falls back to the
 // general kernel), < 0 on error.  transposed != 0: the data gradient -- X = dY, W(t, n, k) = w[2 - t][k][n] (w packed [tap][Cout][Cin]).
 int conv_ws_try(eegldm_ctx* ctx, int dtype, const void* x, long ldx, const void* w, int Cin, int Cout, int transposed, const float* bias,
-                const float* rowvec, long ld_rowvec, const void* resid, long ldr, void* y, long ldy, int B, int L) {
+                const float* rowvec, long ld_rowvec, const void* resid, long ldr, void* y, long ldy, int B, int L, float* col_parts, int* col_nparts) {
+  if (col_nparts) *col_nparts = 0;
   EEG_ENV_VAR(bool, off, getenv("EEGLDM_NO_CONV_WS") != nullptr);
   const int Kred = transposed ? Cout : Cin, N = transposed ? Cin : Cout;
   const long M = (long)B * L;
@@ -374,6 +418,8 @@ int conv_ws_try(eegldm_ctx* ctx, int dtype, const void* x, long ldx, const void*
   nbx = (a.ntiles + a.tiles_per_block - 1) / a.tiles_per_block;
   static DevOnce attr_once;      // (per device, not per process)
   if (attr_once.need(ctx->device)) {
+    HIP_TRY(hipFuncSetAttribute((const void*)conv3_ws_kernel<false, bf16_t, true>, hipFuncAttributeMaxDynamicSharedMemorySize, WS_LDS));
+    HIP_TRY(hipFuncSetAttribute((const void*)conv3_ws_kernel<false, f16_t, true>, hipFuncAttributeMaxDynamicSharedMemorySize, WS_LDS));
     HIP_TRY(hipFuncSetAttribute((const void*)conv3_ws_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, WS_LDS));
     HIP_TRY(hipFuncSetAttribute((const void*)conv3_ws_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, WS_LDS));
     HIP_TRY(hipFuncSetAttribute((const void*)conv3_ws_kernel<false, f16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, WS_LDS));
@@ -386,7 +432,13 @@ int conv_ws_try(eegldm_ctx* ctx, int dtype, const void* x, long ldx, const void*
     HIP_TRY(hipEventCreate(&rec.a)); HIP_TRY(hipEventCreate(&rec.b));
     HIP_TRY(hipEventRecord(rec.a, ctx->stream));
   }
-  if (dtype == EEGLDM_F16) {
+  // column statistics for a following BatchNorm: forward products whose partial rows (nbx x 2 N floats) fit the caller's area (16 MB)
+  const bool st = col_parts && col_nparts && !transposed && (size_t)nbx * 2 * N * sizeof(float) <= (16u << 20);
+  if (st) {
+    a.col_parts = col_parts; *col_nparts = (int)nbx;
+    if (dtype == EEGLDM_F16) hipLaunchKernelGGL((conv3_ws_kernel<false, f16_t, true>), dim3((unsigned)nbx, ny), dim3(256), WS_LDS, ctx->stream, a);
+    else hipLaunchKernelGGL((conv3_ws_kernel<false, bf16_t, true>), dim3((unsigned)nbx, ny), dim3(256), WS_LDS, ctx->stream, a);
+  } else if (dtype == EEGLDM_F16) {
     if (transposed) hipLaunchKernelGGL((conv3_ws_kernel<true, f16_t>), dim3((unsigned)nbx, ny), dim3(256), WS_LDS, ctx->stream, a);
     else hipLaunchKernelGGL((conv3_ws_kernel<false, f16_t>), dim3((unsigned)nbx, ny), dim3(256), WS_LDS, ctx->stream, a);
   } else if (transposed) hipLaunchKernelGGL(conv3_ws_kernel<true>, dim3((unsigned)nbx, ny), dim3(256), WS_LDS, ctx->stream, a);
@@ -398,7 +450,8 @@ int conv_ws_try(eegldm_ctx* ctx, int dtype, const void* x, long ldx, const void*
 
 // Stride-2 Conv1d(128 -> 256, k 3, padding 1) on contiguous NLC operands: forward (x: [B * 2 Lo][128] -> y: [B * Lo][256] + bias) or data gradient
 // (x = dy: [B * Lo][256] -> y = dx: [B * 2 Lo][128]); w = the packed weight [3][256][128].  1 = launched, 0 = not this kernel's shape, < 0 = error.
-int conv_ws2_try(eegldm_ctx* ctx, int dtype, int dgrad, const void* x, const void* w, const float* bias, void* y, int B, int Lo) {
+int conv_ws2_try(eegldm_ctx* ctx, int dtype, int dgrad, const void* x, const void* w, const float* bias, void* y, int B, int Lo, float* col_parts, int* col_nparts) {
+  if (col_nparts) *col_nparts = 0;
   EEG_ENV_VAR(bool, off, getenv("EEGLDM_NO_CONV_WS") != nullptr);
   const long M = (long)B * Lo;
   if (off || (dtype != EEGLDM_BF16 && dtype != EEGLDM_F16) || Lo % W2_ROWS != 0 || M >= (1L << 31) || M < 8192) return 0;
@@ -411,6 +464,8 @@ int conv_ws2_try(eegldm_ctx* ctx, int dtype, int dgrad, const void* x, const voi
   nbx = (a.ntiles + a.tiles_per_block - 1) / a.tiles_per_block;
   static DevOnce attr_once;
   if (attr_once.need(ctx->device)) {
+    HIP_TRY(hipFuncSetAttribute((const void*)conv3_ws2_kernel<false, bf16_t, true>, hipFuncAttributeMaxDynamicSharedMemorySize, W2_LDS));
+    HIP_TRY(hipFuncSetAttribute((const void*)conv3_ws2_kernel<false, f16_t, true>, hipFuncAttributeMaxDynamicSharedMemorySize, W2_LDS));
     HIP_TRY(hipFuncSetAttribute((const void*)conv3_ws2_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, W2_LDS));
     HIP_TRY(hipFuncSetAttribute((const void*)conv3_ws2_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, W2_LDS));
     HIP_TRY(hipFuncSetAttribute((const void*)conv3_ws2_kernel<false, f16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, W2_LDS));
@@ -423,7 +478,12 @@ int conv_ws2_try(eegldm_ctx* ctx, int dtype, int dgrad, const void* x, const voi
     HIP_TRY(hipEventCreate(&rec.a)); HIP_TRY(hipEventCreate(&rec.b)); HIP_TRY(hipEventRecord(rec.a, ctx->stream));
   }
   const dim3 grid((unsigned)nbx, 2);
-  if (dtype == EEGLDM_F16) {
+  const bool st = col_parts && col_nparts && !dgrad && (size_t)nbx * 2 * 256 * sizeof(float) <= (16u << 20);
+  if (st) {
+    a.col_parts = col_parts; *col_nparts = (int)nbx;
+    if (dtype == EEGLDM_F16) hipLaunchKernelGGL((conv3_ws2_kernel<false, f16_t, true>), grid, dim3(256), W2_LDS, ctx->stream, a);
+    else hipLaunchKernelGGL((conv3_ws2_kernel<false, bf16_t, true>), grid, dim3(256), W2_LDS, ctx->stream, a);
+  } else if (dtype == EEGLDM_F16) {
     if (dgrad) hipLaunchKernelGGL((conv3_ws2_kernel<true, f16_t>), grid, dim3(256), W2_LDS, ctx->stream, a);
     else hipLaunchKernelGGL((conv3_ws2_kernel<false, f16_t>), grid, dim3(256), W2_LDS, ctx->stream, a);
   } else if (dgrad) hipLaunchKernelGGL(conv3_ws2_kernel<true>, grid, dim3(256), W2_LDS, ctx->stream, a);

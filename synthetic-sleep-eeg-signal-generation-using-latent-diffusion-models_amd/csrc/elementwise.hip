@@ -87,9 +87,7 @@ __global__ void temb_kernel(const int64_t* __restrict__ t, T* __restrict__ out, 
     float v = 0.f;
     if (j < 2 * half) {
       const int f = j < half ? j : j - half;
-      // the frequency table in fp64, rounded once: arguments reach ~1000, where ONE ulp of the frequency moves cos / sin by 6e-5 -- the
-      // device's expf may differ from the host libm by an ulp, the correctly rounded value does not depend on either
-      const float freq = (float)exp(-log(10000.0) * (double)f / (double)half);
+      const float freq = expf(-logf(10000.0f) * (float)f / (float)half);      // fp32 like the reference (unet.py:26-28); one ulp of it is 6e-5 in cos / sin at t ~ 1000
       const float a = (float)t[b] * freq;
       v = j < half ? cosf(a) : sinf(a);
     }

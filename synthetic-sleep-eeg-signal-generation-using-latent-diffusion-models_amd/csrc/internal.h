@@ -45,14 +45,19 @@ int conv_skinny_ex(eegldm_ctx* ctx, int dtype, const void* x, long ldx, const vo
                    const SkinnyGn* gn, float2* part_out, const SkinnyExt* ext = nullptr);
 int conv_skinny_try(eegldm_ctx* ctx, int dtype, const void* x, long ldx, const void* w, int Cin, int Cout, int taps, const float* bias,
                     const float* rowvec, long ld_rowvec, const void* resid, long ldr, void* y, long ldy, int B, int L);
-int conv_ws2_try(eegldm_ctx*, int dtype, int dgrad, const void* x, const void* w, const float* bias, void* y, int B, int Lo);      // stride-2 128 -> 256 over paired rows
+// col_parts / col_nparts (both optional): forward launches leave per-block (sum, sum of squares) of every output column in col_parts[nparts][2 N] for a
+// following BatchNorm (*col_nparts = rows written, 0 = not produced)
+int conv_ws2_try(eegldm_ctx*, int dtype, int dgrad, const void* x, const void* w, const float* bias, void* y, int B, int Lo,
+                 float* col_parts = nullptr, int* col_nparts = nullptr);      // stride-2 128 -> 256 over paired rows
 int conv_ws_try(eegldm_ctx*, int dtype, const void* x, long ldx, const void* w, int Cin, int Cout, int transposed, const float* bias,
-                const float* rowvec, long ld_rowvec, const void* resid, long ldr, void* y, long ldy, int B, int L);
+                const float* rowvec, long ld_rowvec, const void* resid, long ldr, void* y, long ldy, int B, int L,
+                float* col_parts = nullptr, int* col_nparts = nullptr);
 
 // ops.hip
 int op_conv_fwd(eegldm_ctx*, int dtype, const void* x, long ldx, const void* w, const float* bias, void* y, long ldy,
                 int B, int Lin, int Cin, int Cout, int K, int stride, int pad_l, int pad_r,
-                const float* rowvec, long ld_rowvec, const void* resid, long ldr, float act_slope = 0.f);
+                const float* rowvec, long ld_rowvec, const void* resid, long ldr, float act_slope = 0.f,
+                float* col_parts = nullptr, int* col_nparts = nullptr);      // column statistics for a following BatchNorm when the kernel that runs provides them (conv_ws.hip)
 bool op_conv_fuses_act(int dtype, int Cin, int Cout, int K, long ldy);
 // y = conv3(x; w, pad 1) + bias + conv1(x2; w2) + bias2 (+ rowvec): the ResBlock tail h = skip_connection(x) + out_layers(h) (unet.py:302,327).
 // ONE launch when the big-tile kernel takes it (16-bit, Cout % 256 == 0, K-blocked copies of both weights registered), else the two convs.

@@ -436,6 +436,14 @@ int ls_bn_stats(eegldm_ctx* ctx, const void* x, long ldx, float* stats, float* r
   }
   return 0;
 }
+// statistics from the per-block column partials the producing conv left (conv_ws.hip ST kernels): parts[nb][2 C] interleaved (sum, sum of squares)
+int ls_bn_stats_from_parts(eegldm_ctx* ctx, const float* parts, int nb, float* stats, float* rmean, float* rvar, float* nbt, long rows, int C) {
+  double* sums;
+  EEG_TRY(ls_bn_fold(ctx, parts, nb, 2 * C, &sums));
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 255) / 256), dim3(256), 0, ctx->stream, sums, stats, rmean, rvar, nbt, C, (double)rows, 1e-5f, 0.1f);
+  LAUNCH_CHECK();
+  return 0;
+}
 // the apply half: y = lrelu(gamma * (x - mean) * rstd + beta) from given statistics (gamma == null: plain LeakyReLU)
 int ls_bn_apply(eegldm_ctx* ctx, const void* x, long ldx, const float* gamma, const float* beta, const float* stats, void* y, long ldy, long rows, int C,
                 float slope, int dtype) {

@@ -12,7 +12,8 @@ static inline int conv_lout(int Lin, int K, int stride, int pad_l, int pad_r) { 
 bool op_conv_fuses_act(int dtype, int Cin, int Cout, int K, long ldy) { return conv_is_thin(Cin, Cout, dtype) && dconv_fuses_act(dtype, Cin, Cout, K, ldy); }
 int op_conv_fwd(eegldm_ctx* ctx, int dtype, const void* x, long ldx, const void* w, const float* bias, void* y, long ldy,
                 int B, int Lin, int Cin, int Cout, int K, int stride, int pad_l, int pad_r,
-                const float* rowvec, long ld_rowvec, const void* resid, long ldr, float act_slope) {
+                const float* rowvec, long ld_rowvec, const void* resid, long ldr, float act_slope, float* col_parts, int* col_nparts) {
+  if (col_nparts) *col_nparts = 0;
   EEG_CHECK(B > 0 && Lin > 0 && Cin > 0 && Cout > 0 && (K == 1 || K == 3) && (stride == 1 || stride == 2),
             "unsupported conv B=%d Lin=%d Cin=%d Cout=%d K=%d stride=%d", B, Lin, Cin, Cout, K, stride);
   const int Lout = conv_lout(Lin, K, stride, pad_l, pad_r);
@@ -28,7 +29,7 @@ int op_conv_fwd(eegldm_ctx* ctx, int dtype, const void* x, long ldx, const void*
       dtype != EEGLDM_F32 && !ctx->s2ws_f.empty()) {
     auto it = ctx->s2ws_f.find(w);
     if (it != ctx->s2ws_f.end()) {
-      const int rc = conv_ws_try(ctx, dtype, x, 2 * Cin, it->second, 128, 128, 0, bias, nullptr, 0, nullptr, 0, y, ldy, B, Lout);
+      const int rc = conv_ws_try(ctx, dtype, x, 2 * Cin, it->second, 128, 128, 0, bias, nullptr, 0, nullptr, 0, y, ldy, B, Lout, col_parts, col_nparts);
       if (rc != 0) return rc < 0 ? rc : 0;
     }
   }
@@ -38,7 +39,7 @@ int op_conv_fwd(eegldm_ctx* ctx, int dtype, const void* x, long ldx, const void*
   }
   // stride 2, 128 -> 256 channels (the discriminator's third layer): the paired-row weight-stationary kernel of conv_ws.hip
   if (K == 3 && stride == 2 && pad_l == 1 && pad_r == 1 && Cin == 128 && Cout == 256 && ldx == Cin && ldy == Cout && Lin == 2 * Lout && !rowvec && !resid) {
-    const int rc = conv_ws2_try(ctx, dtype, 0, x, w, bias, y, B, Lout);
+    const int rc = conv_ws2_try(ctx, dtype, 0, x, w, bias, y, B, Lout, col_parts, col_nparts);
     if (rc != 0) return rc < 0 ? rc : 0;
   }
   if (K == 3 && stride == 1 && pad_l == 1 && pad_r == 1) {      // HBM-bound wide-and-shallow layers: weights stay in registers (conv_ws.hip)

@@ -76,7 +76,7 @@ def test_timestep_embedding_kernel_vs_reference(golden_dir):
     out = torch.empty(len(g["t"]), 128, device=G.DEV)
     G.check(G.lib.eegldm_timestep_embedding(G.ctx().h, G.ptr(t), G.ptr(out), len(g["t"]), 128))
     # Arguments t * f reach ~1000 in fp32: one ulp of the argument (|a| 2^-23 = 1.2e-4 at a = 999) is the resolution of cos / sin there, and
-    # the reference's own table (torch CPU expf) and a correctly rounded one can differ by that ulp.  Elements with small arguments agree to 1e-6.
+    # the reference's frequency table (torch CPU expf) and the device's expf can differ by that ulp.  Elements with small arguments agree to 1e-6.
     G.assert_close(out, g["emb"], rtol=1e-5, atol=1.5e-4, name="timestep_embedding")
     small = (torch.from_numpy(g["t"]).float().reshape(-1, 1) * torch.exp(-np.log(10000.0) * torch.arange(64).float() / 64)).abs() < 8.0
     small = torch.cat([small, small], dim=1).numpy()
