@@ -361,7 +361,7 @@ def main():
         summ = ctx.prof_summary()
         ctx.prof_enable(False)
         # `roofline.kernel` is FIXED, not the class that happens to win this run: the single kernel with the largest total time in the committed
-        # rocprof table of this command (profiles/r05_ldm_step_bf16_B256_kernel_stats_v5.txt, profiles/r06_*: the fused 3-tap weight gradient
+        # rocprof table of this command (profiles/r06_ldm_step_bf16_B256_kernel_stats_v1.txt, r05_..._v5.txt: the fused 3-tap weight gradient
         # gemm_kernel<u16, 2, 1, 3, 2, 64, 1, 2, true>, 14-15 % of the step) = the class conv_wgrad_splitk_gemm.  The forward big-tile class is within
         # 1 % of it in total time and runs at a higher rate; picking "whichever is larger today" made the headline fraction flip between rounds.
         k = ROOFLINE_KERNEL_CLASS if summ.get(ROOFLINE_KERNEL_CLASS, {}).get("launches") else max(summ.items(), key=lambda kv: kv[1]["ms"])[0]
@@ -433,7 +433,7 @@ def main():
         fbytes = aekl_gan_step_bytes([2, 2, 4], 4 * L, esz, fused=True) * Ba + 16 * (int(ae2.flat.numel()) + int(disc.flat.numel()))
         fused_ach = fbytes / dtg / 1e9
         pj, stale = None, None
-        for aekl_pmc_name in ("r05_pmc_aekl_step.json", "r04_pmc_aekl_step.json", "r03_pmc_aekl_step.json", "r02_pmc_aekl_step.json"):
+        for aekl_pmc_name in ("r06_pmc_aekl_step.json", "r05_pmc_aekl_step.json", "r04_pmc_aekl_step.json", "r03_pmc_aekl_step.json", "r02_pmc_aekl_step.json"):
             pj, stale = load_pmc(aekl_pmc_name)
             if pj is not None:
                 break
