@@ -22,7 +22,7 @@ python - "$1" <<'P'
 import json, sys
 line = [l for l in open(sys.argv[1]) if l.lstrip().startswith("{")][-1]
 d = json.loads(line); c = d.get("comm") or d.get("config", {}).get("comm") or {}
-keys = ("collective_ranks", "collective_backend", "native_collectives", "allreduce_ms", "allreduce_busbw_GBs", "step_ms_without_exchange", "exposed_comm_ms_per_step")
+keys = ("collective_ranks", "backend", "native_collectives", "allreduce_ms_bare", "allreduce_busbw_GBs", "compute_only_ms_per_step", "exposed_comm_ms_per_step")      # the keys of bench.py's `comm` object
 print(f"  n_gpus {d['n_gpus']}: {d['value']:.0f} {d['unit']}, {d['ms_per_step']:.2f} ms/step | " + ", ".join(f"{k} {c.get(k, d.get(k))}" for k in keys))
 P
 }
