@@ -7,7 +7,7 @@ import pytest
 import torch
 
 from param_gen import gen_param, normal
-from make_golden_cases import UNET_CASES
+from make_golden_cases import UNET_CASES, UNET_OPTION_CASES
 from oracle import losses as Ls
 from oracle import unet as U
 
@@ -75,10 +75,58 @@ def test_attention_block(golden_dir):
         np.testing.assert_allclose(sd[k].grad.numpy(), g["g:" + k], rtol=1e-3, atol=1e-4)
 
 
-@pytest.mark.parametrize("name", list(UNET_CASES))
+RES_R6 = {"ssn_plain": (32, 32, ""), "ssn_skip": (32, 64, ""), "ssn_down": (32, 32, "down"), "ssn_up": (64, 64, "up")}
+
+
+@pytest.mark.parametrize("name", list(RES_R6))
+def test_resblock_scale_shift_norm(golden_dir, name):
+    """ResBlock(use_scale_shift_norm=True), unet.py:318-322 (tests/golden/make_golden_r6.py)"""
+    g = _load(golden_dir, "blocks_r6.npz")
+    ci, co, flag = RES_R6[name]
+    sw, sx, se, sdy = [int(v) for v in g[name + ":seeds"]]
+    shapes = {"in_layers.0.weight": (ci,), "in_layers.0.bias": (ci,), "in_layers.2.weight": (co, ci, 3),
+              "in_layers.2.bias": (co,), "emb_layers.1.weight": (2 * co, 128), "emb_layers.1.bias": (2 * co,),
+              "out_layers.0.weight": (co,), "out_layers.0.bias": (co,), "out_layers.3.weight": (co, co, 3),
+              "out_layers.3.bias": (co,)}
+    if ci != co:
+        shapes["skip_connection.weight"] = (co, ci, 1); shapes["skip_connection.bias"] = (co,)
+    sd = {k: torch.from_numpy(gen_param(sw, k, s)).requires_grad_(True) for k, s in shapes.items()}
+    x = torch.from_numpy(normal((2, ci, 32), seed=sx)).requires_grad_(True)
+    emb = torch.from_numpy(normal((2, 128), seed=se)).requires_grad_(True)
+    y = U.resblock(sd, "", x, emb, up=flag == "up", down=flag == "down", scale_shift=True)
+    y.backward(torch.from_numpy(normal(tuple(y.shape), seed=sdy)))
+    np.testing.assert_allclose(y.detach().numpy(), g[name + ":y"], **FWD)
+    np.testing.assert_allclose(x.grad.numpy(), g[name + ":dx"], **GRAD)
+    np.testing.assert_allclose(emb.grad.numpy(), g[name + ":demb"], **GRAD)
+    for k in shapes:
+        np.testing.assert_allclose(sd[k].grad.numpy(), g[name + ":g:" + k], rtol=1e-3, atol=1e-4)
+
+
+ATT_R6 = {"attn_heads4": (64, 4), "attn_headch16": (64, 4), "attn_heads2_c96": (96, 2)}
+
+
+@pytest.mark.parametrize("name", list(ATT_R6))
+def test_attention_block_heads(golden_dir, name):
+    """AttentionBlock with several heads (num_heads / num_head_channels, unet.py:132-166; QKVAttentionLegacy's per-head [q | k | v] layout)"""
+    g = _load(golden_dir, "blocks_r6.npz")
+    c, heads = ATT_R6[name]
+    sw, sx, sdy = [int(v) for v in g[name + ":seeds"]]
+    shapes = {"norm.weight": (c,), "norm.bias": (c,), "qkv.weight": (3 * c, c, 1), "qkv.bias": (3 * c,),
+              "proj_out.weight": (c, c, 1), "proj_out.bias": (c,)}
+    sd = {k: torch.from_numpy(gen_param(sw, k, s)).requires_grad_(True) for k, s in shapes.items()}
+    x = torch.from_numpy(normal((2, c, 24), seed=sx)).requires_grad_(True)
+    y = U.attention_block(sd, "", x, heads)
+    y.backward(torch.from_numpy(normal(tuple(y.shape), seed=sdy)))
+    np.testing.assert_allclose(y.detach().numpy(), g[name + ":y"], **FWD)
+    np.testing.assert_allclose(x.grad.numpy(), g[name + ":dx"], **GRAD)
+    for k in shapes:
+        np.testing.assert_allclose(sd[k].grad.numpy(), g[name + ":g:" + k], rtol=1e-3, atol=1e-4)
+
+
+@pytest.mark.parametrize("name", list(UNET_CASES) + list(UNET_OPTION_CASES))
 def test_unet_vs_reference(golden_dir, name):
     g = _load(golden_dir, f"unet_{name}.npz")
-    cfg, B, L = UNET_CASES[name]
+    cfg, B, L = (UNET_CASES.get(name) or UNET_OPTION_CASES[name])
     sw, sx, _st, sdy = [int(v) for v in g["seeds"]]
     shapes = U.unet_param_shapes(cfg)
     assert list(shapes.keys()) == [str(k) for k in g["keys"]]          # state-dict key order/naming pinned
