@@ -39,8 +39,10 @@ extern "C" {
  *    eegldm_kl_reparam_*, eegldm_conv1d_pack_kblocked_k, eegldm_avgpool2_*, eegldm_nearest2_* (additive).
  * 7 (round 6): + eegldm_resblock_create / eegldm_attnblock_create / eegldm_block_*, eegldm_timestep_embedding (primitive-granular UNet blocks),
  *    eegldm_conv1d_fwd_gn (GroupNorm + SiLU on the conv's operand load), eegldm_conv1d_pack_stride2; REMOVED: eegldm_conv1d_fwd_qstats and
- *    eegldm_groupnorm_fwd_qstats (round 5's GroupNorm-from-producer-moments path measured no gain and was taken out, HISTORY.md). */
-#define EEGLDM_ABI_VERSION 7
+ *    eegldm_groupnorm_fwd_qstats (round 5's GroupNorm-from-producer-moments path measured no gain and was taken out, HISTORY.md).
+ * 8 (round 6): eegldm_unet_cfg grows by num_head_channels, num_heads_upsample, use_scale_shift_norm, resample_layers, resample_pool_only
+ *    (zero = the config_ldm.yaml behaviour); eegldm_resblock_create gains use_scale_shift_norm, eegldm_attnblock_create gains num_heads. */
+#define EEGLDM_ABI_VERSION 8
 
 /* Storage / operand type of activations and compute-copy weights (accumulation, statistics, master weights and optimizer state are
  * always fp32).  EEGLDM_F16 = IEEE half: the type the reference trains in under `autocast` (src/training/training.py:423) with its
@@ -225,8 +227,16 @@ typedef struct {
   int in_channels, out_channels, model_channels, num_res_blocks;
   int n_mult; int channel_mult[8];
   int n_attn; int attention_resolutions[8];
-  int num_heads;           /* only 1 is implemented (all reference configs) */
+  int num_heads;           /* attention heads of the input / middle blocks (unet.py:344,146-153; 0 = 1).  QKVAttentionLegacy layout:
+                            * the qkv projection's channels are [q_0 | k_0 | v_0 | q_1 | ...] (unet.py:107-125) */
   int dtype;               /* storage/compute dtype of activations: EEGLDM_F32, EEGLDM_BF16 or EEGLDM_F16 */
+  /* ABI 8: the constructor branches every reference yaml leaves at the values of config_ldm.yaml; 0 = that default */
+  int num_head_channels;   /* > 0: heads = channels / num_head_channels in every attention block (unet.py:149-153); <= 0: num_heads */
+  int num_heads_upsample;  /* heads of the output blocks' attention (unet.py:354-355,481-487); <= 0: num_heads */
+  int use_scale_shift_norm;/* != 0: h = GroupNorm(h) * (1 + scale) + shift, emb_layers 2 x out_channels wide (unet.py:279-284,318-322) */
+  int resample_layers;     /* != 0: resblock_updown = False -- Downsample / Upsample layers instead of down / up ResBlocks (unet.py:462-470,493-498) */
+  int resample_pool_only;  /* with resample_layers: != 0 = conv_resample False (AvgPool1d(2,2) / nearest x 2 only, unet.py:192-195,221);
+                            * 0 = Conv1d(k 3, stride 2, padding 1) / nearest x 2 + Conv1d(k 3, padding 1) (unet.py:188-190,211-224) */
 } eegldm_unet_cfg;
 
 int eegldm_unet_create(eegldm_ctx*, const eegldm_unet_cfg* cfg, eegldm_unet** out);
@@ -283,9 +293,11 @@ int eegldm_conv1d_fwd_gn(eegldm_ctx*, const void* x, long ldx, const void* w, co
  * forward: x (B, channels, L) and y (B, out_channels, L') fp32 NCL; emb (B, emb_channels) fp32 -- the ResBlock's `emb` argument
  * (emb_layers = SiLU -> Linear runs inside); NULL for an AttentionBlock.  backward: grads += d<dy, y>/dparams; dx and demb are
  * WRITTEN (both nullable). */
-int eegldm_resblock_create(eegldm_ctx*, int channels, int out_channels, int emb_channels, int groups, int updown, int dtype,
-                           eegldm_block** out);
-int eegldm_attnblock_create(eegldm_ctx*, int channels, int dtype, eegldm_block** out);
+/* use_scale_shift_norm != 0: ResBlock(use_scale_shift_norm=True) -- emb_layers.1 is 2 x out_channels wide (unet.py:279-284,318-322).
+ * num_heads: AttentionBlock(channels, num_heads) (unet.py:132-166; pass channels / num_head_channels for the other spelling). */
+int eegldm_resblock_create(eegldm_ctx*, int channels, int out_channels, int emb_channels, int groups, int updown, int use_scale_shift_norm,
+                           int dtype, eegldm_block** out);
+int eegldm_attnblock_create(eegldm_ctx*, int channels, int num_heads, int dtype, eegldm_block** out);
 int eegldm_block_destroy(eegldm_block*);
 int eegldm_block_num_entries(const eegldm_block*);
 long eegldm_block_num_params(const eegldm_block*);

@@ -152,8 +152,8 @@ SIGNATURES = {
     "eegldm_usleep_bind": [_vp, _vp, _vp],
     "eegldm_usleep_forward": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i],
     "eegldm_feature_moments": [_vp, _vp, _l, _i, _vp, _vp],
-    "eegldm_resblock_create": [_vp, _i, _i, _i, _i, _i, _i, C.POINTER(_vp)],
-    "eegldm_attnblock_create": [_vp, _i, _i, C.POINTER(_vp)],
+    "eegldm_resblock_create": [_vp, _i, _i, _i, _i, _i, _i, _i, C.POINTER(_vp)],
+    "eegldm_attnblock_create": [_vp, _i, _i, _i, C.POINTER(_vp)],
     "eegldm_block_destroy": [_vp],
     "eegldm_block_num_entries": [_vp],
     "eegldm_block_num_params": [_vp],
@@ -187,7 +187,10 @@ class USleepCfg(C.Structure):
 class UNetCfg(C.Structure):
     _fields_ = [("in_channels", _i), ("out_channels", _i), ("model_channels", _i), ("num_res_blocks", _i),
                 ("n_mult", _i), ("channel_mult", _i * 8), ("n_attn", _i), ("attention_resolutions", _i * 8),
-                ("num_heads", _i), ("dtype", _i)]
+                ("num_heads", _i), ("dtype", _i),
+                # ABI 8 (zero = the config_ldm.yaml behaviour)
+                ("num_head_channels", _i), ("num_heads_upsample", _i), ("use_scale_shift_norm", _i), ("resample_layers", _i),
+                ("resample_pool_only", _i)]
 
 
 def _bind():

@@ -283,6 +283,46 @@ __global__ void add_rows_kernel(T* __restrict__ dst, long ldd, const T* __restri
     for (int c = nc * 4 + threadIdx.x; c < C; c += blockDim.x) { T* d = dst + r * ldd + c; st_f32(d, ld_f32(d) + ld_f32(src + r * lds + c)); }
   }
 }
+// ------------------------------------------------------------------ use_scale_shift_norm (unet.py:318-322)
+// a[r][c] = silu(u), u = hn[r][c] * (1 + scale[b][c]) + shift[b][c], b = r / L; one block column per sample, threads along the channels
+template <typename T>
+__global__ void film_silu_fwd_kernel(const T* __restrict__ hn, long ldh, const float* __restrict__ emb, long lde, T* __restrict__ a, long lda, int L, int C) {
+  const int b = blockIdx.y;
+  const float* e = emb + (long)b * lde;
+  for (int c = threadIdx.x; c < C; c += blockDim.x) {
+    const float s1 = 1.0f + e[c], sh = e[C + c];
+    for (int l = blockIdx.x; l < L; l += gridDim.x) {
+      const long r = (long)b * L + l;
+      const float u = fmaf(ld_f32(hn + r * ldh + c), s1, sh);
+      st_f32(a + r * lda + c, u / (1.0f + expf(-u)));
+    }
+  }
+}
+// backward: g = da * silu'(u); dhn = g * (1 + scale); demb[b] = [sum_l g * hn | sum_l g].  One block = 64 channels x 4 row lanes of one sample.
+template <typename T>
+__global__ __launch_bounds__(256) void film_silu_bwd_kernel(const T* __restrict__ hn, long ldh, const float* __restrict__ emb, long lde, const T* __restrict__ da,
+                                                            long ldda, T* __restrict__ dhn, long lddh, float* __restrict__ demb, long ldde, int L, int C) {
+  __shared__ float r1[4][64], r2[4][64];
+  const int b = blockIdx.y, cx = threadIdx.x & 63, ry = threadIdx.x >> 6, c = blockIdx.x * 64 + cx;
+  float s1 = 0.f, s2 = 0.f;
+  if (c < C) {
+    const float sc = 1.0f + emb[(long)b * lde + c], sh = emb[(long)b * lde + C + c];
+    for (int l = ry; l < L; l += 4) {
+      const long r = (long)b * L + l;
+      const float h = ld_f32(hn + r * ldh + c), u = fmaf(h, sc, sh);
+      const float sg = 1.0f / (1.0f + expf(-u));
+      const float g = ld_f32(da + r * ldda + c) * sg * (1.0f + u * (1.0f - sg));
+      st_f32(dhn + r * lddh + c, g * sc);
+      s1 = fmaf(g, h, s1); s2 += g;
+    }
+  }
+  r1[ry][cx] = s1; r2[ry][cx] = s2;
+  __syncthreads();
+  if (ry == 0 && c < C) {
+    demb[(long)b * ldde + c] = r1[0][cx] + r1[1][cx] + r1[2][cx] + r1[3][cx];
+    demb[(long)b * ldde + C + c] = r2[0][cx] + r2[1][cx] + r2[2][cx] + r2[3][cx];
+  }
+}
 template <typename T>
 __global__ void copy_rows_kernel(T* __restrict__ dst, long ldd, const T* __restrict__ src, long lds, long rows, int C) {
   GRID_STRIDE(i, rows * C) {
@@ -551,6 +591,17 @@ int ew_add_rows(eegldm_ctx* ctx, void* dst, long ldd, const void* src, long lds,
   EEG_CHECK(ldd % 4 == 0 && lds % 4 == 0, "add_rows: leading dimensions must be multiples of 4");
   const long cap = (long)ctx->num_cu * 32;
   DISPATCH_T(dtype, hipLaunchKernelGGL((add_rows_kernel<T>), dim3((unsigned)(rows < cap ? rows : cap)), dim3(C >= 512 ? 128 : 64), 0, ctx->stream, (T*)dst, ldd, (const T*)src, lds, rows, C));
+  LAUNCH_CHECK(); return 0;
+}
+int ew_film_silu_fwd(eegldm_ctx* ctx, const void* hn, long ldh, const float* emb, long lde, void* a, long lda, int B, int L, int C, int dtype) {
+  const int gx = L < 64 ? L : 64;
+  DISPATCH_T(dtype, hipLaunchKernelGGL((film_silu_fwd_kernel<T>), dim3(gx, B), dim3(C >= 256 ? 256 : (C >= 128 ? 128 : 64)), 0, ctx->stream, (const T*)hn, ldh, emb, lde, (T*)a, lda, L, C));
+  LAUNCH_CHECK(); return 0;
+}
+int ew_film_silu_bwd(eegldm_ctx* ctx, const void* hn, long ldh, const float* emb, long lde, const void* da, long ldda, void* dhn, long lddh,
+                     float* demb, long ldde, int B, int L, int C, int dtype) {
+  DISPATCH_T(dtype, hipLaunchKernelGGL((film_silu_bwd_kernel<T>), dim3((C + 63) / 64, B), dim3(256), 0, ctx->stream, (const T*)hn, ldh, emb, lde, (const T*)da, ldda,
+                                       (T*)dhn, lddh, demb, ldde, L, C));
   LAUNCH_CHECK(); return 0;
 }
 int ew_copy_rows(eegldm_ctx* ctx, void* dst, long ldd, const void* src, long lds, long rows, int C, int dtype) {

@@ -46,9 +46,17 @@ struct ResDesc {
   int groups;              // GroupNorm groups (32 in the UNet, norm_num_groups in the AutoencoderKL)
   long gn1_w, gn1_b, c1_w, c1_b, gn2_w, gn2_b, c2_w, c2_b, sk_w, sk_b;
   int emb_col;             // column in the batched embedding projection, or -1 (no timestep embedding)
+  // use_scale_shift_norm (unet.py:279-284,318-322): the projection is 2 * cout wide, columns [emb_col, emb_col + cout) = scale and
+  // [emb_col + cout, emb_col + 2 cout) = shift, and h = GroupNorm(conv1(..)) * (1 + scale) + shift ahead of SiLU + conv2 (no h + emb)
+  int ssn = 0;
 };
-struct AttnDesc { int c; long n_w, n_b, qkv_w, qkv_b, pr_w, pr_b; };
-struct ResTape { View x, a1, xr, h1, a2; float *st1, *st2; int B, Lin, Lout; };
+// heads: QKVAttentionLegacy (unet.py:97-125) -- the qkv projection's output channels are [q_0 | k_0 | v_0 | q_1 | k_1 | v_1 | ...], c / heads each
+struct AttnDesc { int c; long n_w, n_b, qkv_w, qkv_b, pr_w, pr_b; int heads = 1; };
+// Downsample / Upsample layers of resblock_updown = False (unet.py:177-224): conv != 0: Conv1d(c, c, 3, stride 2, padding 1) /
+// nearest x 2 + Conv1d(c, c, 3, padding 1); conv == 0: AvgPool1d(2, 2) / nearest x 2 only (w = b = -1)
+struct RsDesc { int c = 0, up = 0, conv = 0; long w = -1, b = -1; };
+struct RsTape { View x, xu; int B, Lin, Lout; };
+struct ResTape { View x, a1, xr, h1, a2, hn; float *st1, *st2; int B, Lin, Lout; };
 struct AttnTape { View x, xn, qkv, o; void* probs; float* st; int B, T; };
 
 struct NetBase {
@@ -118,6 +126,8 @@ int res_backward(NetBase* u, const ResDesc& r, const ResTape& t, const View& dou
                  const View* extra = nullptr, int* extra_done = nullptr);
 int attn_forward(NetBase* u, const AttnDesc& a, const View& x, int B, int T, const View& out);
 int attn_backward(NetBase* u, const AttnDesc& a, const AttnTape& t, const View& dout, const View& dx);
+int resample_forward(NetBase* u, const RsDesc& s, const View& x, int B, int Lin, const View& out, RsTape* tape);
+int resample_backward(NetBase* u, const RsDesc& s, const RsTape& t, const View& dout, const View& dx);
 // accessors for the sampler (sampler.hip); the struct itself is private to unet.hip
 eegldm_ctx* unet_ctx(const eegldm_unet* u);
 int unet_in_channels(const eegldm_unet* u);

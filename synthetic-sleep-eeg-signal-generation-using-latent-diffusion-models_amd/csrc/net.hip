@@ -116,12 +116,12 @@ int res_forward(NetBase* u, const ResDesc& r, const View& x, int B, int Lin, con
   ResTape t; t.x = x; t.B = B; t.Lin = Lin; t.Lout = Lout;
   ALLOC_OR_FAIL(t.st1, (float*)u->arena.alloc(sizeof(float) * 2 * B * r.groups));
   ALLOC_OR_FAIL(t.st2, (float*)u->arena.alloc(sizeof(float) * 2 * B * r.groups));
-  const float* emb = r.emb_col >= 0 ? u->emb_all + r.emb_col : nullptr;
+  const float* emb = (r.emb_col >= 0 && !r.ssn) ? u->emb_all + r.emb_col : nullptr;
   // ---- eval, few rows (NetBase::eval_fuse): conv1 leaves GroupNorm 2's statistics and conv2 normalises on load; conv2 leaves the
   // statistics of the block output; and when the producers of THIS block's input left theirs, GroupNorm 1 is folded into conv1 too
   const int cpg1 = r.cin / r.groups, cpg2 = r.cout / r.groups;
   const size_t need = (size_t)B * (Lout / 16) * (r.cout / 4);       // float2 slots of a (B * Lout) x cout tensor
-  const bool fuse2 = u->eval_fuse && Lout % 32 == 0 && cpg2 >= 4 && cpg2 % 4 == 0 && r.cout % r.groups == 0 &&
+  const bool fuse2 = u->eval_fuse && !r.ssn && Lout % 32 == 0 && cpg2 >= 4 && cpg2 % 4 == 0 && r.cout % r.groups == 0 &&
                      conv_skinny_takes(dt, r.cin, r.cout, 3, B, Lout) && conv_skinny_takes(dt, r.cout, r.cout, 3, B, Lout);
   const NetBase::PartReg *pa = nullptr, *pb = nullptr;
   bool fuse1 = false;
@@ -194,6 +194,13 @@ int res_forward(NetBase* u, const ResDesc& r, const View& x, int B, int Lin, con
   EEG_TRY(op_conv_fwd(ctx, dt, t.a1.p, t.a1.ld, u->W(r.c1_w), u->P(r.c1_b), t.h1.p, t.h1.ld, B, Lout, r.cin, r.cout, 3, 1, 1, 1,
                       emb, u->emb_ld, nullptr, 0));
   ALLOC_OR_FAIL(t.a2.p, u->alloc_act((long)B * Lout, r.cout)); t.a2.ld = r.cout; t.a2.C = r.cout;
+  if (r.ssn) {            // use_scale_shift_norm: hn = GroupNorm(h1) (no SiLU), a2 = SiLU(hn * (1 + scale) + shift); hn stays on the tape
+    EEG_CHECK(r.emb_col >= 0, "use_scale_shift_norm needs the embedding projection");
+    ALLOC_OR_FAIL(t.hn.p, u->alloc_act((long)B * Lout, r.cout)); t.hn.ld = r.cout; t.hn.C = r.cout;
+    EEG_TRY(eegldm_groupnorm_fwd(ctx, t.h1.p, t.h1.ld, u->P(r.gn2_w), u->P(r.gn2_b), t.hn.p, t.hn.ld, t.st2, B, Lout, r.cout, r.groups, GN_EPS, 0,
+                                 0, nullptr, 0, dt));
+    EEG_TRY(ew_film_silu_fwd(ctx, t.hn.p, t.hn.ld, u->emb_all + r.emb_col, u->emb_ld, t.a2.p, t.a2.ld, B, Lout, r.cout, dt));
+  } else
   EEG_TRY(eegldm_groupnorm_fwd(ctx, t.h1.p, t.h1.ld, u->P(r.gn2_w), u->P(r.gn2_b), t.a2.p, t.a2.ld, t.st2, B, Lout, r.cout, r.groups, GN_EPS, 1,
                                0, nullptr, 0, dt));
   if (r.sk_w >= 0) {      // skip_connection(x) + conv2(a2): one launch with the 1 x 1 conv as further K stages where the big-tile kernel takes it
@@ -253,11 +260,19 @@ int res_backward(NetBase* u, const ResDesc& r, const ResTape& t, const View& dou
   // h1 = conv(a1) + b1 + emb_out[b]: the per-sample column sums of dh1 feed the embedding MLP, their total is db1.
   // The one-pass GroupNorm backward produces them while dh1 is still in registers; otherwise a separate column sum.
   float* ps = nullptr; long ldps = 0;
-  if (r.emb_col >= 0) { ps = demb_all + r.emb_col; ldps = u->etot; }
+  const bool emb_add = r.emb_col >= 0 && !r.ssn;      // h1 = conv + b1 + emb: dh1's per-sample column sums are the embedding's gradient
+  if (emb_add) { ps = demb_all + r.emb_col; ldps = u->etot; }
   else if (pg && !fb1) { ALLOC_OR_FAIL(ps, (float*)u->arena.alloc(sizeof(float) * (size_t)B * r.cout)); ldps = r.cout; }
   int cs_done = 0, gn2_deferred = 0;
-  EEG_TRY(op_groupnorm_bwd(ctx, t.h1.p, t.h1.ld, u->P(r.gn2_w), u->P(r.gn2_b), t.st2, da2.p, da2.ld, dh1.p, dh1.ld, pg ? u->G(r.gn2_w) : nullptr, pg ? u->G(r.gn2_b) : nullptr,
-                           B, Lout, r.cout, r.groups, 1, 0, nullptr, 0, dt, ps, ldps, &cs_done, nullptr, 0, nullptr, pg ? &gn2_deferred : nullptr));
+  const void* gn2_dy = da2.p; long gn2_lddy = da2.ld;
+  if (r.ssn) {            // a2 = SiLU(hn (1 + scale) + shift): d(hn) and the (scale, shift) gradient rows first, then GroupNorm without SiLU
+    View dhn; ALLOC_OR_FAIL(dhn.p, u->alloc_act((long)B * Lout, r.cout)); dhn.ld = r.cout;
+    EEG_TRY(ew_film_silu_bwd(ctx, t.hn.p, t.hn.ld, u->emb_all + r.emb_col, u->emb_ld, da2.p, da2.ld, dhn.p, dhn.ld, demb_all + r.emb_col, u->etot,
+                             B, Lout, r.cout, dt));
+    gn2_dy = dhn.p; gn2_lddy = dhn.ld;
+  }
+  EEG_TRY(op_groupnorm_bwd(ctx, t.h1.p, t.h1.ld, u->P(r.gn2_w), u->P(r.gn2_b), t.st2, gn2_dy, gn2_lddy, dh1.p, dh1.ld, pg ? u->G(r.gn2_w) : nullptr, pg ? u->G(r.gn2_b) : nullptr,
+                           B, Lout, r.cout, r.groups, r.ssn ? 0 : 1, 0, nullptr, 0, dt, ps, ldps, &cs_done, nullptr, 0, nullptr, pg ? &gn2_deferred : nullptr));
   // few output channels = hundreds of K splits adding into the same bias entries (+17 us at 128 channels): when the one-pass
   // GroupNorm backward already produced per-sample sums, their total is cheaper
   const bool fb1e = fb1 && !(cs_done && ps && r.cout < 256);
@@ -270,7 +285,7 @@ int res_backward(NetBase* u, const ResDesc& r, const ResTape& t, const View& dou
   if (cs_done) {
     if (pg && !fb1e) EEG_TRY(ew_colsum(ctx, ps, ldps, nullptr, 0, u->G(r.c1_b), 1, B, r.cout, EEGLDM_F32));
   } else {
-    if (r.emb_col >= 0) EEG_TRY(ew_colsum(ctx, dh1.p, dh1.ld, ps, ldps, pg && !fb1e ? u->G(r.c1_b) : nullptr, B, Lout, r.cout, dt));
+    if (emb_add) EEG_TRY(ew_colsum(ctx, dh1.p, dh1.ld, ps, ldps, pg && !fb1e ? u->G(r.c1_b) : nullptr, B, Lout, r.cout, dt));
     else if (pg && !fb1e) EEG_TRY(ew_colsum(ctx, dh1.p, dh1.ld, nullptr, 0, u->G(r.c1_b), B, Lout, r.cout, dt));
   }
   View da1; ALLOC_OR_FAIL(da1.p, u->alloc_act((long)B * Lout, r.cin)); da1.ld = r.cin;
@@ -309,11 +324,16 @@ int attn_forward(NetBase* u, const AttnDesc& a, const View& x, int B, int T, con
     EEG_TRY(eegldm_groupnorm_fwd(ctx, x.p, x.ld, u->P(a.n_w), u->P(a.n_b), t.xn.p, C, t.st, B, T, C, AG, GN_EPS, 0, 0, nullptr, 0, dt));
     EEG_TRY(op_conv_fwd(ctx, dt, t.xn.p, C, u->W(a.qkv_w), u->P(a.qkv_b), t.qkv.p, 3 * C, B, T, C, 3 * C, 1, 1, 0, 0, nullptr, 0, nullptr, 0));
   }
-  ALLOC_OR_FAIL(t.probs, u->alloc_act((long)B * T, T));
+  // heads (QKVAttentionLegacy, unet.py:107-125): head h owns columns [3 h ch, 3 (h + 1) ch) = [q | k | v] of the qkv rows and columns
+  // [h ch, (h + 1) ch) of the output; one launch sequence per head on column views (the probabilities of all heads stay on the tape)
+  const int H = a.heads, ch = C / H; const size_t es = dtype_size(dt);
+  ALLOC_OR_FAIL(t.probs, u->alloc_act((long)H * B * T, T));
   ALLOC_OR_FAIL(t.o.p, u->alloc_act((long)B * T, C)); t.o.ld = C;
   Arena::Mark mk = u->arena.mark();
   float* logits; ALLOC_OR_FAIL(logits, (float*)u->arena.alloc(sizeof(float) * (size_t)B * T * T));
-  EEG_TRY(op_attention_fwd(ctx, dt, t.qkv.p, 3 * C, t.o.p, C, t.probs, logits, B, T, C));
+  for (int h = 0; h < H; h++)
+    EEG_TRY(op_attention_fwd(ctx, dt, (const char*)t.qkv.p + (size_t)h * 3 * ch * es, 3 * C, (char*)t.o.p + (size_t)h * ch * es, C,
+                             (char*)t.probs + (size_t)h * B * T * T * es, logits, B, T, ch));
   u->arena.release(mk);
   // eval, few rows: the projection leaves the statistics of the block output for the next ResBlock's first GroupNorm
   int rcp = 0;
@@ -344,7 +364,12 @@ int attn_backward(NetBase* u, const AttnDesc& a, const AttnTape& t, const View& 
   if (!dqkv) ALLOC_OR_FAIL(dqkv, u->alloc_act((long)B * T, 3 * C));
   float* dprobs; ALLOC_OR_FAIL(dprobs, (float*)u->arena.alloc(sizeof(float) * (size_t)B * T * T));
   void* dlogits; ALLOC_OR_FAIL(dlogits, u->alloc_act((long)B * T, T));
-  EEG_TRY(op_attention_bwd(ctx, dt, t.qkv.p, 3 * C, t.probs, d_o, C, dqkv, 3 * C, dprobs, dlogits, B, T, C));
+  {
+    const int H = a.heads, ch = C / H; const size_t es = dtype_size(dt);
+    for (int h = 0; h < H; h++)
+      EEG_TRY(op_attention_bwd(ctx, dt, (const char*)t.qkv.p + (size_t)h * 3 * ch * es, 3 * C, (const char*)t.probs + (size_t)h * B * T * T * es,
+                               (const char*)d_o + (size_t)h * ch * es, C, (char*)dqkv + (size_t)h * 3 * ch * es, 3 * C, dprobs, dlogits, B, T, ch));
+  }
   EEG_TRY(op_conv_wgrad(ctx, dt, t.xn.p, C, dqkv, 3 * C, u->G(a.qkv_w), u->G(a.qkv_b), B, T, C, 3 * C, 1, 1, 0, 0));
   void* dxn; ALLOC_OR_FAIL(dxn, u->alloc_act((long)B * T, C));
   EEG_TRY(op_conv_dgrad(ctx, dt, dqkv, 3 * C, u->W(a.qkv_w), dxn, C, B, T, C, 3 * C, 1, 1, 0, 0, nullptr, 0));
@@ -357,3 +382,42 @@ int attn_backward(NetBase* u, const AttnDesc& a, const AttnTape& t, const View& 
   return 0;
 }
 
+
+// ------------------------------------------------------------------ Downsample / Upsample layers (unet.py:177-224; resblock_updown = False)
+int resample_forward(NetBase* u, const RsDesc& s, const View& x, int B, int Lin, const View& out, RsTape* tape) {
+  eegldm_ctx* ctx = u->ctx; const int dt = u->dtype, C = s.c;
+  RsTape t; t.x = x; t.B = B; t.Lin = Lin; t.Lout = s.up ? 2 * Lin : Lin / 2;
+  if (!s.up) {
+    EEG_CHECK(Lin % 2 == 0, "Downsample needs an even length (got %d)", Lin);
+    if (s.conv) EEG_TRY(op_conv_fwd(ctx, dt, x.p, x.ld, u->W(s.w), u->P(s.b), out.p, out.ld, B, Lin, C, C, 3, 2, 1, 1, nullptr, 0, nullptr, 0));
+    else EEG_TRY(eegldm_avgpool2_fwd(ctx, x.p, x.ld, out.p, out.ld, B, Lin, C, dt));
+  } else if (s.conv) {
+    ALLOC_OR_FAIL(t.xu.p, u->alloc_act((long)B * t.Lout, C)); t.xu.ld = C; t.xu.C = C;
+    EEG_TRY(eegldm_nearest2_fwd(ctx, x.p, x.ld, t.xu.p, t.xu.ld, B, Lin, C, dt));
+    EEG_TRY(op_conv_fwd(ctx, dt, t.xu.p, t.xu.ld, u->W(s.w), u->P(s.b), out.p, out.ld, B, t.Lout, C, C, 3, 1, 1, 1, nullptr, 0, nullptr, 0));
+  } else {
+    EEG_TRY(eegldm_nearest2_fwd(ctx, x.p, x.ld, out.p, out.ld, B, Lin, C, dt));
+  }
+  if (tape) *tape = t;
+  return 0;
+}
+int resample_backward(NetBase* u, const RsDesc& s, const RsTape& t, const View& dout, const View& dx) {
+  eegldm_ctx* ctx = u->ctx; const int dt = u->dtype, C = s.c, B = t.B;
+  const bool pg = u->param_grads;
+  if (!s.up) {
+    if (s.conv) {
+      if (pg) EEG_TRY(op_conv_wgrad(ctx, dt, t.x.p, t.x.ld, dout.p, dout.ld, u->G(s.w), u->G(s.b), B, t.Lin, C, C, 3, 2, 1, 1));
+      EEG_TRY(op_conv_dgrad(ctx, dt, dout.p, dout.ld, u->W(s.w), dx.p, dx.ld, B, t.Lin, C, C, 3, 2, 1, 1, nullptr, 0));
+    } else {
+      EEG_TRY(eegldm_avgpool2_bwd(ctx, dout.p, dout.ld, dx.p, dx.ld, B, t.Lin, C, dt));
+    }
+  } else if (s.conv) {
+    if (pg) EEG_TRY(op_conv_wgrad(ctx, dt, t.xu.p, t.xu.ld, dout.p, dout.ld, u->G(s.w), u->G(s.b), B, t.Lout, C, C, 3, 1, 1, 1));
+    View dxu; ALLOC_OR_FAIL(dxu.p, u->alloc_act((long)B * t.Lout, C)); dxu.ld = C;       // (stays allocated: a deferred weight gradient may still read dout, not this)
+    EEG_TRY(op_conv_dgrad(ctx, dt, dout.p, dout.ld, u->W(s.w), dxu.p, dxu.ld, B, t.Lout, C, C, 3, 1, 1, 1, nullptr, 0));
+    EEG_TRY(eegldm_nearest2_bwd(ctx, dxu.p, dxu.ld, dx.p, dx.ld, B, t.Lin, C, dt));
+  } else {
+    EEG_TRY(eegldm_nearest2_bwd(ctx, dout.p, dout.ld, dx.p, dx.ld, B, t.Lin, C, dt));
+  }
+  return 0;
+}

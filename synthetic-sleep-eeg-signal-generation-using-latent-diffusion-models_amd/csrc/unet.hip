@@ -1,7 +1,9 @@
 // UNet denoiser executor: forward, hand-written backward and the LDM train-step body.
 // Mirrors UNetModel of /root/reference/src/models/unet.py:330-563 (constructor loops
-// :382-499, forward :512-563) with resblock_updown=True, use_scale_shift_norm=False,
-// dropout=0, num_heads=1 -- the configuration of config/config_ldm.yaml:30-43.
+// :382-499, forward :512-563), dropout=0.  The configuration of config/config_ldm.yaml:30-43 (resblock_updown=True,
+// use_scale_shift_norm=False, num_heads=1) is the one the fused fast paths are built for; the other constructor branches -- several
+// attention heads (num_heads / num_head_channels / num_heads_upsample), use_scale_shift_norm=True, resblock_updown=False with conv or
+// pool / nearest resampling layers -- run through the same kernels at layer granularity (round 6; goldens tests/golden/unet_opt_*.npz).
 //
 // Host side only: this file sequences kernels from gemm.hip / norm.hip / elementwise.hip
 // / direct_conv.hip on the context's stream.  All activations are NLC in the model dtype;
@@ -22,7 +24,14 @@
 
 namespace {
 constexpr int GN_G = 32;
-struct Layer { int kind; ResDesc r; AttnDesc a; };   // kind 0 = res, 1 = attn
+struct Layer { int kind; ResDesc r; AttnDesc a; RsDesc s; };   // kind 0 = res, 1 = attn, 2 = Downsample / Upsample layer (s.up)
+inline int layer_cin(const Layer& l) { return l.kind == 0 ? l.r.cin : (l.kind == 1 ? l.a.c : l.s.c); }
+inline int layer_cout(const Layer& l) { return l.kind == 0 ? l.r.cout : (l.kind == 1 ? l.a.c : l.s.c); }
+inline int layer_len(const Layer& l, int L) {
+  if (l.kind == 0) return l.r.updown == 1 ? L / 2 : (l.r.updown == 2 ? L * 2 : L);
+  if (l.kind == 2) return l.s.up ? L * 2 : L / 2;
+  return L;
+}
 struct Block { std::vector<Layer> layers; int cin, cout; };
 }  // namespace
 
@@ -40,6 +49,7 @@ struct eegldm_unet : NetBase {
   float *e0 = nullptr, *a1e = nullptr, *semb = nullptr, *h1e = nullptr, *emb = nullptr;   // embedding MLP runs in fp32
   std::vector<View> in_out;      // outputs of the input blocks (views into concat buffers)
   std::vector<View> cat;         // concat buffers per output block
+  std::vector<RsTape> st;        // tapes of the Downsample / Upsample layers
 };
 
 namespace {
@@ -52,7 +62,10 @@ int build_plan(eegldm_unet* u) {
   auto has_attn = [&](int ds) { for (int i = 0; i < c.n_attn; i++) if (c.attention_resolutions[i] == ds) return true; return false; };
 
   // ---- pass 1: structure
-  struct Tmp { int kind, cin, cout, updown; };
+  struct Tmp { int kind, cin, cout, updown; int heads = 1; };      // kind 2: updown = 1 down / 2 up
+  const bool rs_layers = c.resample_layers != 0, rs_conv = c.resample_pool_only == 0, ssn = c.use_scale_shift_norm != 0;
+  const int nh_in = c.num_heads > 0 ? c.num_heads : 1, nh_up = c.num_heads_upsample > 0 ? c.num_heads_upsample : nh_in;      // unet.py:354-355
+  auto heads_of = [&](int chn, int n) { return c.num_head_channels > 0 ? chn / c.num_head_channels : n; };                // unet.py:146-153
   std::vector<std::vector<Tmp>> inp, outp; std::vector<Tmp> mid;
   std::vector<int> chans{mc};
   inp.push_back({});   // block 0 = conv_in (handled separately)
@@ -62,12 +75,12 @@ int build_plan(eegldm_unet* u) {
     for (int r = 0; r < c.num_res_blocks; r++) {
       std::vector<Tmp> l{{0, ch, mult * mc, 0}};
       ch = mult * mc;
-      if (has_attn(ds)) l.push_back({1, ch, ch, 0});
+      if (has_attn(ds)) l.push_back({1, ch, ch, 0, heads_of(ch, nh_in)});
       inp.push_back(l); chans.push_back(ch);
     }
-    if (level != c.n_mult - 1) { inp.push_back({{0, ch, ch, 1}}); chans.push_back(ch); ds *= 2; }
+    if (level != c.n_mult - 1) { inp.push_back({{rs_layers ? 2 : 0, ch, ch, 1}}); chans.push_back(ch); ds *= 2; }
   }
-  mid = {{0, ch, ch, 0}, {1, ch, ch, 0}, {0, ch, ch, 0}};
+  mid = {{0, ch, ch, 0}, {1, ch, ch, 0, heads_of(ch, nh_in)}, {0, ch, ch, 0}};
   std::vector<int> chans_pop = chans;
   for (int level = c.n_mult - 1; level >= 0; level--) {
     const int mult = c.channel_mult[level];
@@ -76,8 +89,8 @@ int build_plan(eegldm_unet* u) {
       u->skip_c1.push_back(ch);
       std::vector<Tmp> l{{0, ch + ich, mc * mult, 0}};
       ch = mc * mult;
-      if (has_attn(ds)) l.push_back({1, ch, ch, 0});
-      if (level && i == c.num_res_blocks) { l.push_back({0, ch, ch, 2}); ds /= 2; }
+      if (has_attn(ds)) l.push_back({1, ch, ch, 0, heads_of(ch, nh_up)});
+      if (level && i == c.num_res_blocks) { l.push_back({rs_layers ? 2 : 0, ch, ch, 2}); ds /= 2; }
       outp.push_back(l);
     }
   }
@@ -85,7 +98,8 @@ int build_plan(eegldm_unet* u) {
 
   // ---- pass 2: flat layout.  Region A: all ResBlock emb Linear weights [etot][te] then biases [etot].
   int etot = 0;
-  auto count_emb = [&](const std::vector<Tmp>& l) { for (auto& t : l) if (t.kind == 0) etot += t.cout; };
+  const int ew = ssn ? 2 : 1;       // use_scale_shift_norm: every ResBlock's emb_layers yields (scale, shift) = 2 cout values (unet.py:279-284)
+  auto count_emb = [&](const std::vector<Tmp>& l) { for (auto& t : l) if (t.kind == 0) etot += ew * t.cout; };
   for (auto& l : inp) count_emb(l);
   count_emb(mid);
   for (auto& l : outp) count_emb(l);
@@ -113,9 +127,9 @@ int build_plan(eegldm_unet* u) {
         u->add_entry(p + "in_layers.0.weight", r.gn1_w, 1, r.cin); u->add_entry(p + "in_layers.0.bias", r.gn1_b, 1, r.cin);
         r.c1_w = take((long)r.cout * r.cin * 3); r.c1_b = take(r.cout);
         u->add_entry(p + "in_layers.2.weight", r.c1_w, 3, r.cout, r.cin, 3); u->add_entry(p + "in_layers.2.bias", r.c1_b, 1, r.cout);
-        r.emb_col = emb_col; emb_col += r.cout;
-        u->add_entry(p + "emb_layers.1.weight", u->off_emb_w + (long)r.emb_col * te, 2, r.cout, te);
-        u->add_entry(p + "emb_layers.1.bias", u->off_emb_b + r.emb_col, 1, r.cout);
+        r.emb_col = emb_col; emb_col += ew * r.cout; r.ssn = ssn ? 1 : 0;
+        u->add_entry(p + "emb_layers.1.weight", u->off_emb_w + (long)r.emb_col * te, 2, ew * r.cout, te);
+        u->add_entry(p + "emb_layers.1.bias", u->off_emb_b + r.emb_col, 1, ew * r.cout);
         r.gn2_w = take(r.cout); r.gn2_b = take(r.cout);
         u->add_entry(p + "out_layers.0.weight", r.gn2_w, 1, r.cout); u->add_entry(p + "out_layers.0.bias", r.gn2_b, 1, r.cout);
         r.c2_w = take((long)r.cout * r.cout * 3); r.c2_b = take(r.cout);
@@ -125,8 +139,15 @@ int build_plan(eegldm_unet* u) {
           r.sk_w = take((long)r.cout * r.cin); r.sk_b = take(r.cout);
           u->add_entry(p + "skip_connection.weight", r.sk_w, 3, r.cout, r.cin, 1); u->add_entry(p + "skip_connection.bias", r.sk_b, 1, r.cout);
         }
+      } else if (l[j].kind == 2) {
+        RsDesc& d = L.s; d.c = l[j].cin; d.up = l[j].updown == 2; d.conv = rs_conv ? 1 : 0;
+        if (d.conv) {      // Downsample.op / Upsample.conv (unet.py:188-190,211-213)
+          const std::string nm = d.up ? "conv" : "op";
+          d.w = take((long)d.c * d.c * 3); d.b = take(d.c);
+          u->add_entry(p + nm + ".weight", d.w, 3, d.c, d.c, 3); u->add_entry(p + nm + ".bias", d.b, 1, d.c);
+        }
       } else {
-        AttnDesc& a = L.a; a.c = l[j].cin;
+        AttnDesc& a = L.a; a.c = l[j].cin; a.heads = l[j].heads;
         a.n_w = take(a.c); a.n_b = take(a.c);
         u->add_entry(p + "norm.weight", a.n_w, 1, a.c); u->add_entry(p + "norm.bias", a.n_b, 1, a.c);
         a.qkv_w = take((long)3 * a.c * a.c); a.qkv_b = take(3 * a.c);
@@ -154,7 +175,7 @@ int build_plan(eegldm_unet* u) {
 
 int block_out_len(const Block& b, int Lin) {
   int L = Lin;
-  for (auto& l : b.layers) if (l.kind == 0) { if (l.r.updown == 1) L /= 2; else if (l.r.updown == 2) L *= 2; }
+  for (auto& l : b.layers) L = layer_len(l, L);
   return L;
 }
 
@@ -163,11 +184,13 @@ int block_forward(eegldm_unet* u, const Block& b, View x, int B, int& L, const V
   for (size_t j = 0; j < b.layers.size(); j++) {
     const Layer& l = b.layers[j];
     const bool last = j + 1 == b.layers.size();
-    const int cout = l.kind == 0 ? l.r.cout : l.a.c;
-    const int Lo = l.kind == 0 ? (l.r.updown == 1 ? L / 2 : (l.r.updown == 2 ? L * 2 : L)) : L;
+    const int cout = layer_cout(l);
+    const int Lo = layer_len(l, L);
     View y = out;
     if (!last) { ALLOC_OR_FAIL(y.p, u->alloc_act((long)B * Lo, cout)); y.ld = cout; y.C = cout; }
-    if (l.kind == 0) EEG_TRY(res_forward(u, l.r, x, B, L, y)); else EEG_TRY(attn_forward(u, l.a, x, B, L, y));
+    if (l.kind == 0) EEG_TRY(res_forward(u, l.r, x, B, L, y));
+    else if (l.kind == 1) EEG_TRY(attn_forward(u, l.a, x, B, L, y));
+    else { RsTape t; EEG_TRY(resample_forward(u, l.s, x, B, L, y, &t)); u->st.push_back(t); }
     x = y; L = Lo;
   }
   return 0;
@@ -182,13 +205,15 @@ int block_backward(eegldm_unet* u, const Block& b, View dout, const View& dx_des
     const Layer& l = b.layers[j];
     View dx = dx_dest;
     if (j > 0) {
-      const int cin = l.kind == 0 ? l.r.cin : l.a.c;
-      const long rows = l.kind == 0 ? (long)u->rt[ri - 1].B * u->rt[ri - 1].Lin : (long)u->at[ai - 1].B * u->at[ai - 1].T;
+      const int cin = layer_cin(l);
+      const long rows = l.kind == 0 ? (long)u->rt[ri - 1].B * u->rt[ri - 1].Lin
+                                    : (l.kind == 1 ? (long)u->at[ai - 1].B * u->at[ai - 1].T : (long)u->st.back().B * u->st.back().Lin);
       ALLOC_OR_FAIL(dx.p, u->alloc_act(rows, cin)); dx.ld = cin; dx.C = cin;
     }
     int fused = 0;
     if (l.kind == 0) { EEG_TRY(res_backward(u, l.r, u->rt[--ri], dout, dx, demb_all, j == 0 ? extra : nullptr, &fused)); }
-    else { EEG_TRY(attn_backward(u, l.a, u->at[--ai], dout, dx)); }
+    else if (l.kind == 1) { EEG_TRY(attn_backward(u, l.a, u->at[--ai], dout, dx)); }
+    else { const RsTape t = u->st.back(); u->st.pop_back(); EEG_TRY(resample_backward(u, l.s, t, dout, dx)); }      // (consumed from the back, like rt / at)
     if (j == 0 && extra && !fused) EEG_TRY(ew_add_rows(u->ctx, dx.p, dx.ld, extra->p, extra->ld, extra_rows, extra->C, u->dtype));
     dout = dx;
   }
@@ -200,7 +225,17 @@ int block_backward(eegldm_unet* u, const Block& b, View dout, const View& dx_des
 // ================================================================== C ABI
 extern "C" int eegldm_unet_create(eegldm_ctx* ctx, const eegldm_unet_cfg* cfg, eegldm_unet** out) {
   EEG_CHECK(ctx && cfg && out, "null argument");
-  EEG_CHECK(cfg->num_heads == 1, "only num_heads=1 is implemented (every reference config)");
+  EEG_CHECK(cfg->num_heads >= 0 && cfg->num_heads <= 64 && cfg->num_heads_upsample <= 64, "bad num_heads");
+  {      // every attention block: channels divisible by its head count, and head width a multiple of 8 (16-byte column views of the qkv rows)
+    const int nh = cfg->num_heads > 0 ? cfg->num_heads : 1, nu = cfg->num_heads_upsample > 0 ? cfg->num_heads_upsample : nh;
+    for (int i = 0; i < cfg->n_mult; i++) {
+      const int chn = cfg->channel_mult[i] * cfg->model_channels;
+      if (cfg->num_head_channels > 0) EEG_CHECK(chn % cfg->num_head_channels == 0 && cfg->num_head_channels % 8 == 0,
+                                                "num_head_channels=%d must divide %d channels and be a multiple of 8", cfg->num_head_channels, chn);
+      else EEG_CHECK(chn % nh == 0 && chn % nu == 0 && (chn / nh) % 8 == 0 && (chn / nu) % 8 == 0,
+                     "%d channels / %d (%d) heads: the head width must be a whole multiple of 8", chn, nh, nu);
+    }
+  }
   EEG_CHECK(cfg->model_channels % 32 == 0, "model_channels must be a multiple of 32 (GroupNorm(32))");
   EEG_CHECK(cfg->n_mult >= 1 && cfg->n_mult <= 8 && cfg->n_attn >= 0 && cfg->n_attn <= 8, "bad channel_mult / attention_resolutions");
   EEG_CHECK(cfg->dtype == EEGLDM_F32 || cfg->dtype == EEGLDM_BF16 || cfg->dtype == EEGLDM_F16, "bad dtype");
@@ -270,7 +305,7 @@ extern "C" int eegldm_unet_forward(eegldm_unet* u, const float* x, const int64_t
   EEG_CHECK(u->params, "bind parameters first");
   EEG_CHECK(B > 0 && L > 0 && (L % (1 << (u->cfg.n_mult - 1))) == 0, "L=%d must be divisible by 2^(levels-1)", L);
   eegldm_ctx* ctx = u->ctx; const int dt = u->dtype; const int mc = u->mc, te = u->te;
-  u->arena.reset(); u->rt.clear(); u->at.clear(); u->in_out.clear(); u->cat.clear();
+  u->arena.reset(); u->rt.clear(); u->at.clear(); u->st.clear(); u->in_out.clear(); u->cat.clear();
   u->B = B; u->L = L; u->have_tape = false;
 
   // ---- eval-mode GroupNorm fusion for few-row launches (NetBase::eval_fuse): one statistics area per ResBlock

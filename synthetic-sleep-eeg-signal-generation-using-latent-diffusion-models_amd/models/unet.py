@@ -31,10 +31,12 @@ class UNetModel(FlatModule):
             raise NotImplementedError("dropout > 0 is not on the hot path (config_ldm.yaml:38 uses 0.0)")
         if num_classes is not None or n_embed is not None:
             raise NotImplementedError("class-conditional / codebook heads are not used by the reference configs")
-        if use_scale_shift_norm or not resblock_updown:
-            raise NotImplementedError("reference configs use use_scale_shift_norm=False, resblock_updown=True")
-        if num_heads != 1 or num_head_channels != -1:
-            raise NotImplementedError("reference configs use a single attention head")
+        num_heads, num_head_channels, num_heads_upsample = int(num_heads), int(num_head_channels), int(num_heads_upsample)
+        if num_heads < 1 or num_head_channels == 0:
+            raise ValueError("num_heads >= 1 and num_head_channels = -1 or > 0 (unet.py:146-153)")
+        self.conv_resample, self.num_heads, self.num_head_channels = bool(conv_resample), num_heads, num_head_channels
+        self.num_heads_upsample = num_heads if num_heads_upsample == -1 else num_heads_upsample      # unet.py:354-355
+        self.use_scale_shift_norm, self.resblock_updown = bool(use_scale_shift_norm), bool(resblock_updown)
         self.image_size, self.in_channels, self.model_channels, self.out_channels = image_size, in_channels, model_channels, out_channels
         self.num_res_blocks, self.attention_resolutions, self.channel_mult = num_res_blocks, list(attention_resolutions), list(channel_mult)
         self.dtype = _DT[dtype]
@@ -48,7 +50,12 @@ class UNetModel(FlatModule):
         cfg.n_attn = len(self.attention_resolutions)
         for i, a in enumerate(self.attention_resolutions):
             cfg.attention_resolutions[i] = int(a)
-        cfg.num_heads, cfg.dtype = 1, self.dtype
+        cfg.num_heads, cfg.dtype = self.num_heads, self.dtype
+        cfg.num_head_channels = self.num_head_channels if self.num_head_channels > 0 else 0
+        cfg.num_heads_upsample = self.num_heads_upsample
+        cfg.use_scale_shift_norm = int(self.use_scale_shift_norm)
+        cfg.resample_layers = 0 if self.resblock_updown else 1                          # Downsample / Upsample layers (unet.py:462-470,493-498)
+        cfg.resample_pool_only = 0 if self.conv_resample else 1
         h = C.c_void_p()
         check(lib.eegldm_unet_create(self.ctx.h, C.byref(cfg), C.byref(h)))
         self.h = h

@@ -21,7 +21,7 @@ def test_library_exports_every_declared_symbol():
     assert len(syms) > 60
     missing = [s for s in syms if not hasattr(lib, s)]
     assert not missing, f"declared in eegldm.h but not exported: {missing}"
-    assert lib.eegldm_abi_version() == 7
+    assert lib.eegldm_abi_version() == 8
 
 
 def test_ctypes_table_covers_header():

@@ -112,7 +112,7 @@ def test_resblock_kernels_vs_reference(golden_dir, name):
     ci, co, updown = RES[name]
     sw, sx, se, sdy = [int(v) for v in g[name + ":seeds"]]
     h = C.c_void_p()
-    G.check(G.lib.eegldm_resblock_create(G.ctx().h, ci, co, 128, 32, updown, G.F32, C.byref(h)))
+    G.check(G.lib.eegldm_resblock_create(G.ctx().h, ci, co, 128, 32, updown, 0, G.F32, C.byref(h)))
     blk = _Block(h)
     try:
         blk.load({k: gen_param(sw, k, shape) for k, (_o, _n, shape) in blk.entries.items()})
@@ -138,7 +138,7 @@ def test_attention_block_kernels_vs_reference(golden_dir):
     g = _load(golden_dir, "attention_block.npz")
     sw, sx, sdy = [int(v) for v in g["seeds"]]
     h = C.c_void_p()
-    G.check(G.lib.eegldm_attnblock_create(G.ctx().h, 64, G.F32, C.byref(h)))
+    G.check(G.lib.eegldm_attnblock_create(G.ctx().h, 64, 1, G.F32, C.byref(h)))
     blk = _Block(h)
     try:
         blk.load({k: gen_param(sw, k, shape) for k, (_o, _n, shape) in blk.entries.items()})
@@ -152,6 +152,88 @@ def test_attention_block_kernels_vs_reference(golden_dir):
         G.assert_close(dx, g["dx"], **GRAD, name="AttentionBlock dx")
         for k, v in blk.grads().items():
             G.assert_close(v, g["g:" + k], **PGRAD, name=f"AttentionBlock grad {k}")
+    finally:
+        blk.close()
+
+
+RES_R6 = {"ssn_plain": (32, 32, 0), "ssn_skip": (32, 64, 0), "ssn_down": (32, 32, 1), "ssn_up": (64, 64, 2)}
+
+
+@pytest.mark.parametrize("dtype", ["float32", "bfloat16"])
+@pytest.mark.parametrize("name", list(RES_R6))
+def test_resblock_scale_shift_norm_vs_reference(golden_dir, name, dtype):
+    """ResBlock(use_scale_shift_norm=True) (unet.py:318-322) on the kernels against the imported reference (tests/golden/make_golden_r6.py);
+    the bf16 engine within the bound the bf16-storage oracle gives."""
+    G = _G()
+    g = _load(golden_dir, "blocks_r6.npz")
+    ci, co, updown = RES_R6[name]
+    sw, sx, se, sdy = [int(v) for v in g[name + ":seeds"]]
+    f32 = dtype == "float32"
+    h = C.c_void_p()
+    G.check(G.lib.eegldm_resblock_create(G.ctx().h, ci, co, 128, 32, updown, 1, G.F32 if f32 else G.BF16, C.byref(h)))
+    blk = _Block(h)
+    try:
+        assert blk.entries["emb_layers.1.weight"][2] == (2 * co, 128)
+        params = {k: gen_param(sw, k, shape) for k, (_o, _n, shape) in blk.entries.items()}
+        blk.load(params)
+        B, L = 2, 32
+        Lo = L // 2 if updown == 1 else (2 * L if updown == 2 else L)
+        xh, eh, dyh = normal((B, ci, L), seed=sx), normal((B, 128), seed=se), normal((B, co, Lo), seed=sdy)
+        x, emb, dy = (torch.from_numpy(a).to(G.DEV) for a in (xh, eh, dyh))
+        y = torch.empty(B, co, Lo, device=G.DEV); dx = torch.empty(B, ci, L, device=G.DEV); demb = torch.empty(B, 128, device=G.DEV)
+        G.check(G.lib.eegldm_block_forward(blk.h, G.ptr(x), G.ptr(emb), G.ptr(y), B, L))
+        G.check(G.lib.eegldm_block_backward(blk.h, G.ptr(dy), G.ptr(dx), G.ptr(demb)))
+        if f32:
+            G.assert_close(y, g[name + ":y"], **FWD, name=f"{name} y")
+            G.assert_close(dx, g[name + ":dx"], **GRAD, name=f"{name} dx")
+            G.assert_close(demb, g[name + ":demb"], **GRAD, name=f"{name} demb")
+            for k, v in blk.grads().items():
+                G.assert_close(v, g[name + ":g:" + k], **PGRAD, name=f"{name} grad {k}")
+        else:
+            from oracle import quant as Q, unet as U
+            def run(emul):
+                sd = {k: torch.from_numpy(v).clone().requires_grad_(True) for k, v in params.items()}
+                xr = torch.from_numpy(xh).clone().requires_grad_(True); er = torch.from_numpy(eh).clone().requires_grad_(True)
+                with Q.bf16_storage(emul):
+                    yo = U.resblock(sd, "", xr, er, up=updown == 2, down=updown == 1, scale_shift=True)
+                    yo.backward(torch.from_numpy(dyh))
+                return yo.detach(), xr.grad, er.grad
+            def rel(a, b):
+                a = torch.as_tensor(a).double().cpu().reshape(-1); b = torch.as_tensor(b).double().reshape(-1)
+                return float((a - b).norm() / (b.norm() + 1e-12))
+            y32, dx32, de32 = run(False); yq, dxq, deq = run(True)
+            np.testing.assert_allclose(y32.numpy(), g[name + ":y"], rtol=1e-4, atol=2e-5)
+            for got, ref, q, what in ((y, y32, yq, "y"), (dx, dx32, dxq, "dx"), (demb, de32, deq, "demb")):
+                assert rel(got, ref) < G.bf16_gap_bound(rel(q, ref)), (name, what, rel(got, ref), rel(q, ref))
+    finally:
+        blk.close()
+
+
+ATT_R6 = {"attn_heads4": (64, 4), "attn_headch16": (64, 4), "attn_heads2_c96": (96, 2)}
+
+
+@pytest.mark.parametrize("name", list(ATT_R6))
+def test_attention_block_heads_vs_reference(golden_dir, name):
+    """AttentionBlock(channels, num_heads / num_head_channels): several heads in QKVAttentionLegacy's per-head [q | k | v] channel order"""
+    G = _G()
+    g = _load(golden_dir, "blocks_r6.npz")
+    Cc, heads = ATT_R6[name]
+    sw, sx, sdy = [int(v) for v in g[name + ":seeds"]]
+    h = C.c_void_p()
+    G.check(G.lib.eegldm_attnblock_create(G.ctx().h, Cc, heads, G.F32, C.byref(h)))
+    blk = _Block(h)
+    try:
+        blk.load({k: gen_param(sw, k, shape) for k, (_o, _n, shape) in blk.entries.items()})
+        B, T = 2, 24
+        x = torch.from_numpy(normal((B, Cc, T), seed=sx)).to(G.DEV)
+        dy = torch.from_numpy(normal((B, Cc, T), seed=sdy)).to(G.DEV)
+        y = torch.empty(B, Cc, T, device=G.DEV); dx = torch.empty(B, Cc, T, device=G.DEV)
+        G.check(G.lib.eegldm_block_forward(blk.h, G.ptr(x), None, G.ptr(y), B, T))
+        G.assert_close(y, g[name + ":y"], **FWD, name=f"{name} y")
+        G.check(G.lib.eegldm_block_backward(blk.h, G.ptr(dy), G.ptr(dx), None))
+        G.assert_close(dx, g[name + ":dx"], **GRAD, name=f"{name} dx")
+        for k, v in blk.grads().items():
+            G.assert_close(v, g[name + ":g:" + k], **PGRAD, name=f"{name} grad {k}")
     finally:
         blk.close()
 

@@ -9,17 +9,17 @@ import torch
 
 pytestmark = pytest.mark.gpu
 
-from make_golden_cases import UNET_CASES  # noqa: E402
+from make_golden_cases import UNET_CASES, UNET_OPTION_CASES  # noqa: E402
 from param_gen import gen_param, normal  # noqa: E402
 
 
 @pytest.mark.parametrize("dtype", ["float32", "bfloat16"])
-@pytest.mark.parametrize("name", list(UNET_CASES))
+@pytest.mark.parametrize("name", list(UNET_CASES) + list(UNET_OPTION_CASES))
 def test_unet_vs_reference_golden(golden_dir, name, dtype):
     import gpu_util as G
     from eegldm.models import UNetModel
     g = np.load(os.path.join(golden_dir, f"unet_{name}.npz"))
-    cfg, B, L = UNET_CASES[name]
+    cfg, B, L = UNET_CASES.get(name) or UNET_OPTION_CASES[name]
     sw, sx, _st, sdy = [int(v) for v in g["seeds"]]
     net = UNetModel(**cfg, dtype=dtype)
     assert list(net.entries.keys()) == [str(k) for k in g["keys"]]
@@ -149,3 +149,20 @@ def test_unet_edge_inputs():
         net(torch.randn(2, 1, 64), timesteps=torch.tensor([5]))
     with pytest.raises(ValueError, match="in_channels=1"):
         net(torch.randn(2, 2, 64), timesteps=torch.tensor([5, 6]))
+
+
+@pytest.mark.parametrize("name", list(UNET_OPTION_CASES))
+def test_unet_option_eval_forward_matches_training_forward(name):
+    """The no-grad forward of a 16-bit engine takes the few-row fused path where it can (GroupNorm folded into the consuming conv,
+    statistics handed from producer to consumer by tensor address); with the optional constructor branches some producers are layers
+    that leave no statistics (Downsample / Upsample layers, scale-shift ResBlocks): those must fall back, not read stale slots."""
+    from eegldm.models import UNetModel
+    cfg, B, L = UNET_OPTION_CASES[name]
+    net = UNetModel(**cfg, dtype="bfloat16")
+    net.load_state_dict({k: torch.from_numpy(gen_param(7, k, shape)) for k, (_o, _n, shape) in net.entries.items()})
+    x = torch.from_numpy(normal((1, cfg["in_channels"], L), seed=5)); t = torch.tensor([321])
+    net.train(); y_tr = net(x, timesteps=t).float().cpu()
+    net.eval(); y_ev = net(x, timesteps=t).float().cpu(); y_ev2 = net(x, timesteps=t).float().cpu()
+    assert torch.isfinite(y_ev).all() and torch.equal(y_ev, y_ev2)
+    rel = float((y_ev - y_tr).norm() / (y_tr.norm() + 1e-12))
+    assert rel < 3e-2, (name, rel)
