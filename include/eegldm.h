@@ -41,7 +41,8 @@ extern "C" {
  *    eegldm_conv1d_fwd_gn (GroupNorm + SiLU on the conv's operand load), eegldm_conv1d_pack_stride2; REMOVED: eegldm_conv1d_fwd_qstats and
  *    eegldm_groupnorm_fwd_qstats (round 5's GroupNorm-from-producer-moments path measured no gain and was taken out, HISTORY.md).
  * 8 (round 6): eegldm_unet_cfg grows by num_head_channels, num_heads_upsample, use_scale_shift_norm, resample_layers, resample_pool_only
- *    (zero = the config_ldm.yaml behaviour); eegldm_resblock_create gains use_scale_shift_norm, eegldm_attnblock_create gains num_heads. */
+ *    (zero = the config_ldm.yaml behaviour); eegldm_resblock_create gains use_scale_shift_norm, eegldm_attnblock_create gains num_heads;
+ *    + eegldm_ddim_step_eta, eegldm_ddpm_step_var. */
 #define EEGLDM_ABI_VERSION 8
 
 /* Storage / operand type of activations and compute-copy weights (accumulation, statistics, master weights and optimizer state are
@@ -203,12 +204,20 @@ int eegldm_get_velocity(eegldm_ctx*, const float* x, const float* noise, const i
                         float* out, int B, long n_per_sample);
 int eegldm_ddim_step(eegldm_ctx*, const float* model_out, const float* sample, float a_t, float a_prev,
                      int pred_type, int clip_sample, float* prev_sample, float* pred_x0, long n);
+/* DDIMScheduler.step with eta >= 0 (the reference samples with eta = 0, sample_trials.py:163; eta > 0 is the scheduler's stochastic form):
+ * sigma = eta sqrt((1 - a_prev) / (1 - a_t) (1 - a_t / a_prev)), prev = sqrt(a_prev) x0 + sqrt(1 - a_prev - sigma^2) eps + sigma noise.
+ * eta == 0 is eegldm_ddim_step (noise may be NULL); eta == 1 over consecutive timesteps is the ancestral DDPM step (tests). (ABI 8) */
+int eegldm_ddim_step_eta(eegldm_ctx*, const float* model_out, const float* sample, const float* noise, float a_t, float a_prev, float eta,
+                         int pred_type, int clip_sample, float* prev_sample, float* pred_x0, long n);
 /* DDPMScheduler.step (variance_type "fixed_small"; the ancestral sampler of util.py:241-243,261-285 and sample_trials_ddpm.py:99-102;
  * arithmetic pinned against DDPM.p_sample, /root/reference/src/models/ldm.py:311-357): x0 from the prediction type, optional clamp
  * to [-1,1], prev = c0*x0 + ct*sample + sqrt(max(var,1e-20))*noise with the posterior coefficients of (a_t, a_prev, beta_t);
  * a_prev == 1 (t == 0) adds no noise and `noise` may be NULL there.  pred_x0 nullable. */
 int eegldm_ddpm_step(eegldm_ctx*, const float* model_out, const float* sample, const float* noise, float a_t, float a_prev,
                      float beta_t, int pred_type, int clip_sample, float* prev_sample, float* pred_x0, long n);
+/* the same step with variance_type "fixed_large" when variance_large != 0: sigma^2 = beta_t instead of the posterior variance (ABI 8) */
+int eegldm_ddpm_step_var(eegldm_ctx*, const float* model_out, const float* sample, const float* noise, float a_t, float a_prev,
+                         float beta_t, int variance_large, int pred_type, int clip_sample, float* prev_sample, float* pred_x0, long n);
 /* loss = mean((pred-target)^2); dpred = 2 (pred-target) / n * grad_scale (nullable) */
 int eegldm_mse_loss(eegldm_ctx*, const float* pred, const float* target, float* loss, float* dpred, long n, float grad_scale);
 int eegldm_adam_step(eegldm_ctx*, float* p, const float* g, float* m, float* v, long n, float lr, float beta1,

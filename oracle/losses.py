@@ -76,9 +76,8 @@ def ddim_timesteps(num_train_timesteps, num_inference_steps):
 
 
 def ddim_step(acp, model_output, t, sample, num_train_timesteps, num_inference_steps,
-              prediction_type="epsilon", clip_sample=True, eta=0.0):
-    """DDIM (eta=0) step; returns (prev_sample, pred_original)."""
-    assert eta == 0.0
+              prediction_type="epsilon", clip_sample=True, eta=0.0, noise=None):
+    """DDIM step (Song et al. 2021, eq. 12 with sigma_t(eta) of eq. 16; the reference samples with eta = 0); returns (prev_sample, pred_original)."""
     prev_t = t - num_train_timesteps // num_inference_steps
     a_t = acp[t]
     a_prev = acp[prev_t] if prev_t >= 0 else torch.tensor(1.0)
@@ -96,11 +95,15 @@ def ddim_step(acp, model_output, t, sample, num_train_timesteps, num_inference_s
         raise ValueError(prediction_type)
     if clip_sample:
         x0 = torch.clamp(x0, -1, 1)
-    prev = a_prev ** 0.5 * x0 + (1 - a_prev) ** 0.5 * e
+    if eta == 0.0:
+        return a_prev ** 0.5 * x0 + (1 - a_prev) ** 0.5 * e, x0
+    var = (1 - a_prev) / (1 - a_t) * (1 - a_t / a_prev)
+    sigma = eta * var ** 0.5
+    prev = a_prev ** 0.5 * x0 + (1 - a_prev - sigma ** 2) ** 0.5 * e + sigma * noise
     return prev, x0
 
 
-def ddpm_step(acp, betas, model_output, t, sample, noise, prediction_type="epsilon", clip_sample=True):
+def ddpm_step(acp, betas, model_output, t, sample, noise, prediction_type="epsilon", clip_sample=True, variance_type="fixed_small"):
     """DDPM ancestral step (variance_type fixed_small), used only by the
     reference's logging sampler (/root/reference/src/util.py:241-243)."""
     a_t = acp[t]
@@ -119,6 +122,6 @@ def ddpm_step(acp, betas, model_output, t, sample, noise, prediction_type="epsil
     ct = alpha_t ** 0.5 * b_prev / b_t
     mean = c0 * x0 + ct * sample
     if t > 0:
-        var = torch.clamp(b_prev / b_t * betas[t], min=1e-20)
+        var = betas[t] if variance_type == "fixed_large" else torch.clamp(b_prev / b_t * betas[t], min=1e-20)
         mean = mean + var ** 0.5 * noise
     return mean, x0

@@ -91,6 +91,8 @@ SIGNATURES = {
     "eegldm_get_velocity": [_vp, _vp, _vp, _vp, _vp, _vp, _i, _l],
     "eegldm_ddim_step": [_vp, _vp, _vp, _f, _f, _i, _i, _vp, _vp, _l],
     "eegldm_ddpm_step": [_vp, _vp, _vp, _vp, _f, _f, _f, _i, _i, _vp, _vp, _l],
+    "eegldm_ddim_step_eta": [_vp, _vp, _vp, _vp, _f, _f, _f, _i, _i, _vp, _vp, _l],
+    "eegldm_ddpm_step_var": [_vp, _vp, _vp, _vp, _f, _f, _f, _i, _i, _i, _vp, _vp, _l],
     "eegldm_mse_loss": [_vp, _vp, _vp, _vp, _vp, _l, _f],
     "eegldm_adam_step": [_vp, _vp, _vp, _vp, _vp, _l, _f, _f, _f, _f, _i, _f],
     "eegldm_grad_check_finite": [_vp, _vp, _l, _vp],

@@ -376,6 +376,23 @@ __global__ void ddim_step_kernel(const float* __restrict__ mo, const float* __re
   }
 }
 
+// DDIMScheduler.step with eta > 0 (Song et al. eq. 12 / 16): sigma = eta sqrt((1 - a_prev) / (1 - a_t) (1 - a_t / a_prev)),
+// prev = sqrt(a_prev) x0 + sqrt(1 - a_prev - sigma^2) e + sigma noise; eta = 0 is ddim_step_kernel
+__global__ void ddim_step_eta_kernel(const float* __restrict__ mo, const float* __restrict__ x, const float* __restrict__ nz, float a_t, float a_prev,
+                                     float sigma, float dir, int pred, int clip, float* __restrict__ prev, float* __restrict__ x0o, long n) {
+  const float sa = sqrtf(a_t), sb = sqrtf(1.0f - a_t), sap = sqrtf(a_prev);
+  GRID_STRIDE(i, n) {
+    const float o = mo[i], s = x[i];
+    float x0, e;
+    if (pred == EEGLDM_PRED_EPSILON) { x0 = (s - sb * o) / sa; e = o; }
+    else if (pred == EEGLDM_PRED_V) { x0 = sa * s - sb * o; e = sa * o + sb * s; }
+    else { x0 = o; e = (s - sa * x0) / sb; }
+    if (clip) x0 = fminf(1.0f, fmaxf(-1.0f, x0));
+    prev[i] = fmaf(sigma, nz[i], fmaf(sap, x0, dir * e));
+    if (x0o) x0o[i] = x0;
+  }
+}
+
 // DDPM ancestral step (DDPMScheduler.step, variance_type fixed_small: the 1000-step logging sampler of util.py:241-243,261-285 and
 // sample_trials_ddpm.py:99-102; same arithmetic as DDPM.p_sample, /root/reference/src/models/ldm.py:311-357):
 //   x0 from the prediction type, optional clamp, mean = c0 * x0 + ct * x_t, plus sigma * noise when t > 0 (sigma = 0 at t = 0)
@@ -760,15 +777,35 @@ extern "C" int eegldm_ddim_step(eegldm_ctx* ctx, const float* mo, const float* x
   hipLaunchKernelGGL(ddim_step_kernel, dim3(grid1d(n, ctx)), dim3(NT), 0, ctx->stream, mo, x, a_t, a_prev, pred, clip, prev, x0, n);
   LAUNCH_CHECK(); return 0;
 }
+extern "C" int eegldm_ddim_step_eta(eegldm_ctx* ctx, const float* mo, const float* x, const float* noise, float a_t, float a_prev, float eta,
+                                    int pred, int clip, float* prev, float* x0, long n) {
+  EEG_CHECK(ctx && mo && x && prev, "null argument");
+  EEG_CHECK(pred >= 0 && pred <= 2, "prediction type %d", pred);
+  EEG_CHECK(eta >= 0.0f && a_t > 0.0f && a_t < 1.0f && a_prev > 0.0f && a_prev <= 1.0f, "bad eta / schedule values");
+  if (eta == 0.0f) return eegldm_ddim_step(ctx, mo, x, a_t, a_prev, pred, clip, prev, x0, n);
+  EEG_CHECK(noise, "eta > 0 needs a noise tensor");
+  // sigma_t(eta) and the direction coefficient in double on the host, like the schedulers' tables
+  const double var = (1.0 - (double)a_prev) / (1.0 - (double)a_t) * (1.0 - (double)a_t / (double)a_prev);
+  const double sigma = (double)eta * sqrt(var > 0.0 ? var : 0.0);
+  const double d2 = 1.0 - (double)a_prev - sigma * sigma;
+  hipLaunchKernelGGL(ddim_step_eta_kernel, dim3(grid1d(n, ctx)), dim3(NT), 0, ctx->stream, mo, x, noise, a_t, a_prev, (float)sigma,
+                     (float)sqrt(d2 > 0.0 ? d2 : 0.0), pred, clip, prev, x0, n);
+  LAUNCH_CHECK(); return 0;
+}
 extern "C" int eegldm_ddpm_step(eegldm_ctx* ctx, const float* mo, const float* x, const float* noise, float a_t, float a_prev, float beta_t,
                                 int pred, int clip, float* prev, float* x0, long n) {
+  return eegldm_ddpm_step_var(ctx, mo, x, noise, a_t, a_prev, beta_t, 0, pred, clip, prev, x0, n);
+}
+// variance_large != 0: DDPMScheduler(variance_type="fixed_large"): sigma^2 = beta_t instead of the posterior variance
+extern "C" int eegldm_ddpm_step_var(eegldm_ctx* ctx, const float* mo, const float* x, const float* noise, float a_t, float a_prev, float beta_t,
+                                    int variance_large, int pred, int clip, float* prev, float* x0, long n) {
   EEG_CHECK(ctx && mo && x && prev, "null argument");
   EEG_CHECK(pred >= 0 && pred <= 2, "prediction type %d", pred);
   EEG_CHECK(a_t > 0.0f && a_t < 1.0f && a_prev > 0.0f && a_prev <= 1.0f && beta_t > 0.0f && beta_t < 1.0f, "bad schedule values");
   // posterior q(x_{t-1} | x_t, x_0): coefficients in double on the host, as the schedulers build their tables
   const double bt = 1.0 - (double)a_t, bp = 1.0 - (double)a_prev;
   const double c0 = sqrt((double)a_prev) * (double)beta_t / bt, ct = sqrt(1.0 - (double)beta_t) * bp / bt;
-  double var = bp / bt * (double)beta_t;
+  double var = variance_large ? (double)beta_t : bp / bt * (double)beta_t;
   const bool last = a_prev >= 1.0f;                  // t == 0: no noise
   if (var < 1e-20) var = 1e-20;
   const float sigma = last ? 0.0f : (float)sqrt(var);

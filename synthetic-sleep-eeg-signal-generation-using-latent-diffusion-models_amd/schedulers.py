@@ -65,8 +65,8 @@ class DDPMScheduler(_Scheduler):
     the reference's own DDPM.p_sample (/root/reference/src/models/ldm.py:311-357; tests/golden/ddpm_steps.npz)."""
 
     def __init__(self, *a, variance_type="fixed_small", **k):
-        if variance_type != "fixed_small":
-            raise NotImplementedError("the reference uses DDPMScheduler's default variance_type='fixed_small'")
+        if variance_type not in ("fixed_small", "fixed_large"):      # "learned" / "learned_range" need a model with 2 x out_channels outputs
+            raise NotImplementedError("variance_type 'fixed_small' (the reference's, DDPMScheduler default) or 'fixed_large'")
         k.setdefault("clip_sample", True)
         super().__init__(*a, **k)
         self.variance_type = variance_type
@@ -98,8 +98,8 @@ class DDPMScheduler(_Scheduler):
                 check(lib.eegldm_randn(self.ctx.h, ptr(nz), nz.numel(), 0x5EED + t, self._step_calls * ((nz.numel() + 3) // 4)))
                 self._step_calls += 1
         prev, x0 = torch.empty_like(x), torch.empty_like(x)
-        check(lib.eegldm_ddpm_step(self.ctx.h, ptr(mo), ptr(x), ptr(nz), a_t, a_prev, float(self.betas[t]), PRED[self.prediction_type],
-                                   int(self.clip_sample), ptr(prev), ptr(x0), x.numel()))
+        check(lib.eegldm_ddpm_step_var(self.ctx.h, ptr(mo), ptr(x), ptr(nz), a_t, a_prev, float(self.betas[t]), int(self.variance_type == "fixed_large"),
+                                       PRED[self.prediction_type], int(self.clip_sample), ptr(prev), ptr(x0), x.numel()))
         return prev, x0
 
 
@@ -116,9 +116,9 @@ class DDIMScheduler(_Scheduler):
         ratio = self.num_train_timesteps // num_inference_steps
         self.timesteps = torch.from_numpy((np.arange(0, num_inference_steps) * ratio).round()[::-1].copy().astype(np.int64)) + self.steps_offset
 
-    def step(self, model_output, timestep, sample, eta=0.0, generator=None):
-        if eta != 0.0:
-            raise NotImplementedError("the reference samples with eta = 0 (sample_trials.py:163)")
+    def step(self, model_output, timestep, sample, eta=0.0, generator=None, noise=None):
+        """-> (pred_prev_sample, pred_original_sample).  eta = 0: the deterministic step the reference samples with (sample_trials.py:163);
+        eta > 0: sigma_t(eta) noise on top (`noise` given by the caller, else drawn from `generator` or the device Philox stream)."""
         t = int(timestep)
         prev_t = t - self.num_train_timesteps // self.num_inference_steps
         a_t = float(self.alphas_cumprod[t])
@@ -126,8 +126,23 @@ class DDIMScheduler(_Scheduler):
         mo = model_output.to(self.device, torch.float32).contiguous()
         x = sample.to(self.device, torch.float32).contiguous()
         prev, x0 = torch.empty_like(x), torch.empty_like(x)
-        check(lib.eegldm_ddim_step(self.ctx.h, ptr(mo), ptr(x), a_t, a_prev, PRED[self.prediction_type], int(self.clip_sample),
-                                   ptr(prev), ptr(x0), x.numel()))
+        if eta < 0:
+            raise ValueError("eta must be >= 0")
+        if eta == 0.0:
+            check(lib.eegldm_ddim_step(self.ctx.h, ptr(mo), ptr(x), a_t, a_prev, PRED[self.prediction_type], int(self.clip_sample),
+                                       ptr(prev), ptr(x0), x.numel()))
+            return prev, x0
+        if noise is not None:
+            nz = noise.to(self.device, torch.float32).contiguous()
+        elif generator is not None:
+            nz = torch.randn(x.shape, generator=generator, device=generator.device).to(self.device)
+        else:
+            nz = torch.empty_like(x)
+            self._step_calls = getattr(self, "_step_calls", 0)
+            check(lib.eegldm_randn(self.ctx.h, ptr(nz), nz.numel(), 0xD1D1 + t, self._step_calls * ((nz.numel() + 3) // 4)))
+            self._step_calls += 1
+        check(lib.eegldm_ddim_step_eta(self.ctx.h, ptr(mo), ptr(x), ptr(nz), a_t, a_prev, float(eta), PRED[self.prediction_type],
+                                       int(self.clip_sample), ptr(prev), ptr(x0), x.numel()))
         return prev, x0
 
 

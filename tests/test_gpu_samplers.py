@@ -174,3 +174,62 @@ def test_native_ancestral_sampler_pixel_space():
             eps = randn(net.ctx, (B, 1, L), seed=seed, offset=i * ((n + 3) // 4)).cpu()
             xr, _ = Ls.ddpm_step(acp, betas, U.unet_forward(sd, cfg, xr, torch.full((B,), tt)), tt, xr, eps, "epsilon", True)
     assert G.rel_l2(lat, xr) < 1e-4, G.rel_l2(lat, xr)
+
+
+@pytest.mark.parametrize("pred", ["epsilon", "sample", "v_prediction"])
+@pytest.mark.parametrize("clip", [False, True])
+@pytest.mark.parametrize("eta", [0.0, 0.3, 1.0])
+def test_ddim_step_eta_vs_oracle(pred, clip, eta):
+    """DDIMScheduler.step(eta) against the oracle's restatement of eq. 12 / 16; eta = 0 through the new entry equals the deterministic
+    kernel bit for bit."""
+    import gpu_util as G
+    from eegldm.schedulers import DDIMScheduler, PRED
+    from oracle import losses as Ls
+    s = DDIMScheduler(num_train_timesteps=1000, schedule="scaled_linear_beta", beta_start=0.0015, beta_end=0.0205, prediction_type=pred,
+                      clip_sample=clip)
+    s.set_timesteps(50)
+    acp = Ls.alphas_cumprod("scaled_linear_beta", 1000, 0.0015, 0.0205)
+    mo, x, nz = (torch.from_numpy(normal((3, 1, 96), seed=sd)) for sd in (31, 32, 33))
+    for t in (980, 500, 20, 0):
+        prev, x0 = s.step(mo, t, x, eta=eta, noise=nz)
+        rp, r0 = Ls.ddim_step(acp, mo, t, x, 1000, 50, prediction_type=pred, clip_sample=clip, eta=eta, noise=nz)
+        G.assert_close(prev, rp.numpy(), rtol=2e-5, atol=2e-5, name=f"prev t={t}")
+        G.assert_close(x0, r0.numpy(), rtol=2e-5, atol=2e-5, name=f"x0 t={t}")
+        if eta == 0.0:
+            md, xd, nd = (a.to(G.DEV).contiguous() for a in (mo, x, nz))
+            o1, o2 = torch.empty_like(md), torch.empty_like(md)
+            a_t = float(s.alphas_cumprod[t]); a_prev = float(s.alphas_cumprod[t - 20]) if t >= 20 else 1.0
+            G.check(G.lib.eegldm_ddim_step_eta(G.ctx().h, G.ptr(md), G.ptr(xd), None, a_t, a_prev, 0.0, PRED[pred],
+                                               int(clip), G.ptr(o1), None, md.numel()))
+            assert torch.equal(o1, prev.to(G.DEV))
+
+
+def test_ddim_eta_one_is_the_ancestral_ddpm_step():
+    """Size-independent property: with consecutive timesteps (50 -> 1000 inference steps: prev_t = t - 1) DDIM at eta = 1 IS the DDPM
+    ancestral step with the posterior variance (sigma_t(1)^2 = (1 - a_prev) / (1 - a_t) beta_t), for any model output and the same noise."""
+    import gpu_util as G
+    from eegldm.schedulers import DDIMScheduler, DDPMScheduler
+    kw = dict(num_train_timesteps=1000, schedule="scaled_linear_beta", beta_start=0.0015, beta_end=0.0205, clip_sample=False)
+    di, dp = DDIMScheduler(**kw), DDPMScheduler(**kw)
+    di.set_timesteps(1000); dp.set_timesteps(1000)
+    mo, x, nz = (torch.from_numpy(normal((256, 1, 768), seed=sd)) for sd in (41, 42, 43))
+    for t in (999, 640, 77, 1):
+        a, _ = di.step(mo, t, x, eta=1.0, noise=nz)
+        b, _ = dp.step(mo, t, x, noise=nz)
+        G.assert_close(a, b.cpu().numpy(), rtol=3e-5, atol=3e-5, name=f"t={t}")
+
+
+@pytest.mark.parametrize("tval", [0, 1, 500, 999])
+def test_ddpm_step_fixed_large_vs_oracle(tval):
+    import gpu_util as G
+    from eegldm.schedulers import DDPMScheduler
+    from oracle import losses as Ls
+    s = DDPMScheduler(num_train_timesteps=1000, schedule="scaled_linear_beta", beta_start=0.0015, beta_end=0.0195, variance_type="fixed_large")
+    acp = Ls.alphas_cumprod("scaled_linear_beta", 1000, 0.0015, 0.0195); betas = Ls.make_betas("scaled_linear_beta", 1000, 0.0015, 0.0195)
+    mo, x, nz = (torch.from_numpy(normal((2, 1, 64), seed=sd)) for sd in (51, 52, 53))
+    prev, x0 = s.step(mo, tval, x, noise=nz)
+    rp, r0 = Ls.ddpm_step(acp, betas, mo, tval, x, nz, variance_type="fixed_large")
+    G.assert_close(prev, rp.numpy(), rtol=2e-5, atol=2e-5, name="prev")
+    G.assert_close(x0, r0.numpy(), rtol=2e-5, atol=2e-5, name="x0")
+    with pytest.raises(NotImplementedError):
+        DDPMScheduler(num_train_timesteps=1000, variance_type="learned")
