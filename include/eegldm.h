@@ -42,7 +42,7 @@ extern "C" {
  *    eegldm_groupnorm_fwd_qstats (round 5's GroupNorm-from-producer-moments path measured no gain and was taken out, HISTORY.md).
  * 8 (round 6): eegldm_unet_cfg grows by num_head_channels, num_heads_upsample, use_scale_shift_norm, resample_layers, resample_pool_only
  *    (zero = the config_ldm.yaml behaviour); eegldm_resblock_create gains use_scale_shift_norm, eegldm_attnblock_create gains num_heads;
- *    + eegldm_ddim_step_eta, eegldm_ddpm_step_var. */
+ *    + eegldm_ddim_step_eta, eegldm_ddpm_step_var, eegldm_unet_set_dropout, eegldm_dropout. */
 #define EEGLDM_ABI_VERSION 8
 
 /* Storage / operand type of activations and compute-copy weights (accumulation, statistics, master weights and optimizer state are
@@ -250,6 +250,13 @@ typedef struct {
 
 int eegldm_unet_create(eegldm_ctx*, const eegldm_unet_cfg* cfg, eegldm_unet** out);
 int eegldm_unet_destroy(eegldm_unet*);
+/* nn.Dropout(p) of ResBlock.out_layers (unet.py:289; every reference yaml sets 0.0): active in forwards with training != 0 only; masks come
+ * from the on-device Philox stream (seed, running counter), are regenerated by the backward and never stored.  Calling it restarts the
+ * counter: the same seed reproduces the same masks for the same sequence of forwards.  (ABI 8) */
+int eegldm_unet_set_dropout(eegldm_unet*, float p, uint64_t seed);
+/* The mask kernel itself, in place on a [rows][C] tensor (leading dimension ld, elements): x <- keep ? x / (1 - p) : 0 with keep drawn from
+ * Philox(seed, offset + e / 4), e = row * C + column.  The same (seed, offset) gives the same mask: the backward applies it to the gradient. */
+int eegldm_dropout(eegldm_ctx*, void* x, long ld, long rows, int C, float p, uint64_t seed, uint64_t offset, int dtype);
 /* Parameter table: entry i <-> one reference state_dict key, stored at [offset, offset+numel)
  * of the flat fp32 parameter / gradient buffers.  Conv weights (ndim 3) are stored packed
  * [K][Cout][Cin]; `shape` reports the reference shape (Cout, Cin, K). */

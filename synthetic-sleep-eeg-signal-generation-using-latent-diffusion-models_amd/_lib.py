@@ -101,6 +101,8 @@ SIGNATURES = {
     "eegldm_fill": [_vp, _vp, _l, _f],
     "eegldm_unet_create": [_vp, _vp, C.POINTER(_vp)],
     "eegldm_unet_destroy": [_vp],
+    "eegldm_unet_set_dropout": [_vp, _f, C.c_uint64],
+    "eegldm_dropout": [_vp, _vp, _l, _l, _i, _f, C.c_uint64, C.c_uint64, _i],
     "eegldm_unet_num_entries": [_vp],
     "eegldm_unet_num_params": [_vp],
     "eegldm_unet_entry": [_vp, _i, C.c_char_p, _i, C.POINTER(_l), C.POINTER(_l), C.POINTER(_i), C.POINTER(_i)],

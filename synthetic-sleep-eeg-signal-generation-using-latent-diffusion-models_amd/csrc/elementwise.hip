@@ -470,6 +470,26 @@ __global__ void randn_kernel(float* __restrict__ out, long n, unsigned long long
     for (int k = 0; k < 4; k++) if (i * 4 + k < n) out[i * 4 + k] = z[k];
   }
 }
+// nn.Dropout(p) on a [rows][C] tensor in place (ResBlock.out_layers[2], unet.py:289): x <- keep ? x / (1 - p) : 0, keep from Philox(seed, offset + e / 4)
+// word e % 4 of element e = r * C + c.  The backward applies the SAME call (same seed / offset) to the incoming gradient: the mask is
+// regenerated, never stored.
+template <typename T>
+__global__ void dropout_rows_kernel(T* __restrict__ x, long ld, long rows, int C, float p, float inv_keep, unsigned long long seed, unsigned long long offset) {
+  const long nq = (rows * C + 3) / 4;
+  GRID_STRIDE(i, nq) {
+    unsigned r[4]; philox(seed, offset + (unsigned long long)i, r);
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+      const long e = i * 4 + k;
+      if (e < rows * C) {
+        const long row = e / C; const int c = (int)(e - row * C);
+        T* q = x + row * ld + c;
+        const bool keep = (float)r[k] * 2.3283064365386963e-10f >= p;
+        st_f32(q, keep ? ld_f32(q) * inv_keep : 0.0f);
+      }
+    }
+  }
+}
 __global__ void randint_kernel(int64_t* __restrict__ out, long n, int64_t high, unsigned long long seed, unsigned long long offset) {
   GRID_STRIDE(i, n) {
     unsigned r[4]; philox(seed, offset + (unsigned long long)i, r);
@@ -619,6 +639,13 @@ int ew_film_silu_bwd(eegldm_ctx* ctx, const void* hn, long ldh, const float* emb
                      float* demb, long ldde, int B, int L, int C, int dtype) {
   DISPATCH_T(dtype, hipLaunchKernelGGL((film_silu_bwd_kernel<T>), dim3((C + 63) / 64, B), dim3(256), 0, ctx->stream, (const T*)hn, ldh, emb, lde, (const T*)da, ldda,
                                        (T*)dhn, lddh, demb, ldde, L, C));
+  LAUNCH_CHECK(); return 0;
+}
+int ew_dropout_rows(eegldm_ctx* ctx, void* x, long ld, long rows, int C, float p, uint64_t seed, uint64_t offset, int dtype) {
+  EEG_CHECK(p >= 0.0f && p < 1.0f, "dropout probability %g outside [0, 1)", (double)p);
+  const long nq = (rows * C + 3) / 4;
+  DISPATCH_T(dtype, hipLaunchKernelGGL((dropout_rows_kernel<T>), dim3(grid1d(nq, ctx)), dim3(NT), 0, ctx->stream, (T*)x, ld, rows, C, p, 1.0f / (1.0f - p),
+                                       (unsigned long long)seed, (unsigned long long)offset));
   LAUNCH_CHECK(); return 0;
 }
 int ew_copy_rows(eegldm_ctx* ctx, void* dst, long ldd, const void* src, long lds, long rows, int C, int dtype) {
@@ -855,6 +882,11 @@ extern "C" int eegldm_grad_check_finite(eegldm_ctx* ctx, const float* g, long n,
 extern "C" int eegldm_randn(eegldm_ctx* ctx, float* out, long n, uint64_t seed, uint64_t offset) {
   hipLaunchKernelGGL(randn_kernel, dim3(grid1d((n + 3) / 4, ctx)), dim3(NT), 0, ctx->stream, out, n, seed, offset);
   LAUNCH_CHECK(); return 0;
+}
+extern "C" int eegldm_dropout(eegldm_ctx* ctx, void* x, long ld, long rows, int C, float p, uint64_t seed, uint64_t offset, int dtype) {
+  EEG_CHECK(ctx && x && rows >= 0 && C > 0 && ld >= C, "bad argument");
+  if (rows == 0 || p == 0.0f) return 0;
+  return ew_dropout_rows(ctx, x, ld, rows, C, p, seed, offset, dtype);
 }
 extern "C" int eegldm_randint(eegldm_ctx* ctx, int64_t* out, long n, int64_t high, uint64_t seed, uint64_t offset) {
   EEG_CHECK(high > 0, "high must be positive");

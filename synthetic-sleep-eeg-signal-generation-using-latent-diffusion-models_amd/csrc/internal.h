@@ -14,6 +14,8 @@ int ew_colsum(eegldm_ctx*, const void* x, long ldx, float* out_ps, long ldo, flo
 int ew_softmax(eegldm_ctx*, const float* S, void* P, long rows, int n, int dtype);
 int ew_softmax_bwd(eegldm_ctx*, const float* dP, const void* P, void* dS, long rows, int n, float alpha, int dtype);
 int ew_add_rows(eegldm_ctx*, void* dst, long ldd, const void* src, long lds, long rows, int C, int dtype);
+// nn.Dropout(p) in place with a regenerated Philox mask (the backward calls it on the gradient with the same seed / offset)
+int ew_dropout_rows(eegldm_ctx*, void* x, long ld, long rows, int C, float p, uint64_t seed, uint64_t offset, int dtype);
 // use_scale_shift_norm (unet.py:318-322): a = silu(hn * (1 + scale[b]) + shift[b]); emb row b = [scale (C) | shift (C)] at emb + b * lde
 int ew_film_silu_fwd(eegldm_ctx*, const void* hn, long ldh, const float* emb, long lde, void* a, long lda, int B, int L, int C, int dtype);
 // dhn = da * silu'(u) * (1 + scale); demb row b (ASSIGNED) = [sum_l g * hn | sum_l g], g = da * silu'(u)

@@ -56,7 +56,7 @@ struct AttnDesc { int c; long n_w, n_b, qkv_w, qkv_b, pr_w, pr_b; int heads = 1;
 // nearest x 2 + Conv1d(c, c, 3, padding 1); conv == 0: AvgPool1d(2, 2) / nearest x 2 only (w = b = -1)
 struct RsDesc { int c = 0, up = 0, conv = 0; long w = -1, b = -1; };
 struct RsTape { View x, xu; int B, Lin, Lout; };
-struct ResTape { View x, a1, xr, h1, a2, hn; float *st1, *st2; int B, Lin, Lout; };
+struct ResTape { View x, a1, xr, h1, a2, hn; float *st1, *st2; int B, Lin, Lout; unsigned long long drop_off = 0; bool dropped = false; };
 struct AttnTape { View x, xn, qkv, o; void* probs; float* st; int B, T; };
 
 struct NetBase {
@@ -82,6 +82,9 @@ struct NetBase {
   std::vector<GnFold> gn_pending; int gn_parity = 0;
   int flush_gn_folds();
   bool param_grads = true;       // false: backward propagates to the input only (G step through D)
+  // nn.Dropout(p) of ResBlock.out_layers (unet.py:289; every reference yaml: 0).  Active in training-mode forwards only; the mask of each
+  // block is Philox(drop_seed, counter) and is regenerated by the backward (ResTape::drop_off), never stored.
+  float dropout = 0.f; bool training = false; unsigned long long drop_seed = 0x0D50ull, drop_ctr = 0;
   Arena arena;
   float* emb_all = nullptr; int etot = 0;   // batched timestep-embedding projections (UNet)
   long emb_ld = 0;                           // row stride of emb_all: etot, or 0 when all samples share one precomputed row (sampler)

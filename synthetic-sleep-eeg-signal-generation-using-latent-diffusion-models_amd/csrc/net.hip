@@ -203,6 +203,11 @@ int res_forward(NetBase* u, const ResDesc& r, const View& x, int B, int Lin, con
   } else
   EEG_TRY(eegldm_groupnorm_fwd(ctx, t.h1.p, t.h1.ld, u->P(r.gn2_w), u->P(r.gn2_b), t.a2.p, t.a2.ld, t.st2, B, Lout, r.cout, r.groups, GN_EPS, 1,
                                0, nullptr, 0, dt));
+  if (u->dropout > 0.f && u->training) {      // out_layers[2] = nn.Dropout(p) between SiLU and conv2 (unet.py:286-294)
+    t.dropped = true; t.drop_off = u->drop_ctr;
+    EEG_TRY(ew_dropout_rows(ctx, t.a2.p, t.a2.ld, (long)B * Lout, r.cout, u->dropout, u->drop_seed, t.drop_off, dt));
+    u->drop_ctr += ((unsigned long long)B * Lout * r.cout + 3) / 4;
+  }
   if (r.sk_w >= 0) {      // skip_connection(x) + conv2(a2): one launch with the 1 x 1 conv as further K stages where the big-tile kernel takes it
     EEG_TRY(op_conv3_skip_fwd(ctx, dt, t.a2.p, t.a2.ld, u->W(r.c2_w), u->P(r.c2_b), t.xr.p, t.xr.ld, u->W(r.sk_w), u->P(r.sk_b), out.p, out.ld,
                               B, Lout, r.cout, r.cin, r.cout, nullptr, 0));
@@ -240,6 +245,7 @@ int res_backward(NetBase* u, const ResDesc& r, const ResTape& t, const View& dou
   }
   View da2; ALLOC_OR_FAIL(da2.p, u->alloc_act((long)B * Lout, r.cout)); da2.ld = r.cout;
   EEG_TRY(op_conv_dgrad(ctx, dt, dout.p, dout.ld, u->W(r.c2_w), da2.p, da2.ld, B, Lout, r.cout, r.cout, 3, 1, 1, 1, nullptr, 0));
+  if (t.dropped) EEG_TRY(ew_dropout_rows(ctx, da2.p, da2.ld, (long)B * Lout, r.cout, u->dropout, u->drop_seed, t.drop_off, dt));      // the forward's mask, regenerated
   if (pg) {
     // conv2's bias gradient = column sums of dout; the skip conv's bias gradient is the same vector
     if (fb2 && (r.sk_w < 0 || fbs)) {

@@ -256,6 +256,14 @@ extern "C" int eegldm_unet_destroy(eegldm_unet* u) {
   delete u;
   return 0;
 }
+// ResBlock dropout (unet.py:289; config_ldm.yaml:38 sets 0.0): probability for training-mode forwards and the seed of the mask stream
+// (the counter restarts, so the same seed reproduces the same masks for the same sequence of forwards)
+extern "C" int eegldm_unet_set_dropout(eegldm_unet* u, float p, uint64_t seed) {
+  EEG_CHECK(u, "null unet");
+  EEG_CHECK(p >= 0.f && p < 1.f, "dropout probability %g outside [0, 1)", (double)p);
+  u->dropout = p; u->drop_seed = seed; u->drop_ctr = 0;
+  return 0;
+}
 extern "C" int eegldm_unet_num_entries(const eegldm_unet* u) { return (int)u->entries.size(); }
 extern "C" long eegldm_unet_num_params(const eegldm_unet* u) { return u->nparams; }
 extern "C" int eegldm_unet_set_grad_hook(eegldm_unet* u, eegldm_grad_hook fn, void* user) {
@@ -306,7 +314,7 @@ extern "C" int eegldm_unet_forward(eegldm_unet* u, const float* x, const int64_t
   EEG_CHECK(B > 0 && L > 0 && (L % (1 << (u->cfg.n_mult - 1))) == 0, "L=%d must be divisible by 2^(levels-1)", L);
   eegldm_ctx* ctx = u->ctx; const int dt = u->dtype; const int mc = u->mc, te = u->te;
   u->arena.reset(); u->rt.clear(); u->at.clear(); u->st.clear(); u->in_out.clear(); u->cat.clear();
-  u->B = B; u->L = L; u->have_tape = false;
+  u->B = B; u->L = L; u->have_tape = false; u->training = training != 0;
 
   // ---- eval-mode GroupNorm fusion for few-row launches (NetBase::eval_fuse): one statistics area per ResBlock
   {

@@ -27,8 +27,9 @@ class UNetModel(FlatModule):
                  dropout=0, channel_mult=(1, 2, 4, 8), conv_resample=True, num_classes=None, num_heads=1,
                  num_head_channels=-1, num_heads_upsample=-1, use_scale_shift_norm=False, resblock_updown=False,
                  n_embed=None, dtype="float32", device=0, ctx=None):
-        if dropout not in (0, 0.0):
-            raise NotImplementedError("dropout > 0 is not on the hot path (config_ldm.yaml:38 uses 0.0)")
+        if not 0.0 <= float(dropout) < 1.0:
+            raise ValueError("dropout must be in [0, 1)")
+        self.dropout = float(dropout)
         if num_classes is not None or n_embed is not None:
             raise NotImplementedError("class-conditional / codebook heads are not used by the reference configs")
         num_heads, num_head_channels, num_heads_upsample = int(num_heads), int(num_head_channels), int(num_heads_upsample)
@@ -59,6 +60,8 @@ class UNetModel(FlatModule):
         h = C.c_void_p()
         check(lib.eegldm_unet_create(self.ctx.h, C.byref(cfg), C.byref(h)))
         self.h = h
+        if self.dropout > 0.0:      # nn.Dropout(p) of every ResBlock (unet.py:289): training-mode forwards only, masks from the device Philox stream
+            self.set_dropout_seed(0x0D50)
         self.n_flat = int(lib.eegldm_unet_num_params(self.h))
         self.entries = OrderedDict()
         name = C.create_string_buffer(256)
@@ -71,6 +74,11 @@ class UNetModel(FlatModule):
         check(lib.eegldm_unet_bind(self.h, ptr(self.flat), ptr(self.flat_grad)))
         self.training = True
         self.reset_parameters()
+
+    def set_dropout_seed(self, seed):
+        """(Re)start the dropout mask stream: the same seed gives the same masks for the same sequence of training forwards
+        (torch's counterpart is `torch.manual_seed` ahead of the loop)."""
+        check(lib.eegldm_unet_set_dropout(self.h, self.dropout, int(seed)))
 
     # ------------------------------------------------------------------ parameters
     def reset_parameters(self, generator=None):

@@ -166,3 +166,65 @@ def test_unet_option_eval_forward_matches_training_forward(name):
     assert torch.isfinite(y_ev).all() and torch.equal(y_ev, y_ev2)
     rel = float((y_ev - y_tr).norm() / (y_tr.norm() + 1e-12))
     assert rel < 3e-2, (name, rel)
+
+
+def test_unet_dropout_masks_are_consistent_between_forward_and_backward():
+    """dropout > 0 (unet.py:289; no reference yaml uses it): eval forwards ignore it; a training forward draws Philox masks that the
+    backward regenerates.  With the mask stream restarted before every forward, f(x) = <dy, net(x)> is a fixed function: its directional
+    derivative by central differences must equal <dx, d> from the hand-written backward (fp32), which only holds if forward and backward
+    use the same masks and the same 1 / (1 - p) scale."""
+    from eegldm.models import UNetModel
+    kw = dict(image_size=64, in_channels=1, out_channels=1, model_channels=32, num_res_blocks=1, attention_resolutions=[2], channel_mult=[1, 2],
+              resblock_updown=True)
+    net = UNetModel(**kw, dropout=0.25, dtype="float32")
+    ref = UNetModel(**kw, dropout=0.0, dtype="float32")
+    sd = {k: torch.from_numpy(gen_param(11, k, shape)) for k, (_o, _n, shape) in net.entries.items()}
+    net.load_state_dict(sd); ref.load_state_dict(sd)
+    x = torch.from_numpy(normal((2, 1, 64), seed=1)); t = torch.tensor([10, 700])
+    dy = torch.from_numpy(normal((2, 1, 64), seed=2)); d = torch.from_numpy(normal((2, 1, 64), seed=3))
+    net.eval(); ref.eval()
+    assert torch.equal(net(x, timesteps=t), ref(x, timesteps=t))                      # eval: identity
+    net.train(); ref.train()
+    def f(xx, seed=5):
+        net.set_dropout_seed(seed)
+        return net(xx, timesteps=t).double().cpu()
+    y1, y2, y3 = f(x), f(x), f(x, seed=6)
+    assert torch.equal(y1, y2) and not torch.equal(y1, y3)                           # same seed, same masks; another seed, other masks
+    assert not torch.allclose(y1.float(), ref(x, timesteps=t).double().cpu().float(), atol=1e-3)
+    net.set_dropout_seed(5); net.zero_grad()
+    y = net(x, timesteps=t)
+    dx = net.backward(dy, need_dx=True).double().cpu()
+    eps = 4e-3
+    fd = float(((f(x + eps * d) - f(x - eps * d)) * dy.double()).sum() / (2 * eps))
+    an = float((dx * d.double()).sum())
+    # central differences of an fp32 forward are good to a few 1e-3 here (the same check on the dropout-free twin sets the scale);
+    # masks that differed between forward and backward would be off by tens of percent
+    ref.zero_grad(); ref(x, timesteps=t)
+    an0 = float((ref.backward(dy, need_dx=True).double().cpu() * d.double()).sum())
+    fd0 = float(((ref(x + eps * d, timesteps=t).double().cpu() - ref(x - eps * d, timesteps=t).double().cpu()) * dy.double()).sum() / (2 * eps))
+    tol = max(1e-2, 4 * abs(fd0 - an0) / max(1.0, abs(an0)))
+    assert abs(fd - an) < tol * max(1.0, abs(an)), (fd, an, fd0, an0)
+    # and the expectation: the mean over many mask draws approaches the no-dropout ... is NOT expected (SiLU / GroupNorm are not linear);
+    # what must hold is the scale of the kept activations, which the derivative check above already pins
+    with pytest.raises(ValueError):
+        UNetModel(**kw, dropout=1.0)
+
+
+@pytest.mark.parametrize("dtype", ["float32", "bfloat16"])
+def test_dropout_kernel_keep_rate_scale_and_reproducibility(dtype):
+    import gpu_util as G
+    dt = G.F32 if dtype == "float32" else G.BF16
+    rows, Cc, ld, p = 4096, 96, 128, 0.3
+    def run(seed, off):
+        x = torch.ones(rows, ld, device=G.DEV, dtype=G.TDT[dt])
+        G.check(G.lib.eegldm_dropout(G.ctx().h, G.ptr(x), ld, rows, Cc, p, seed, off, dt))
+        return x.float().cpu()
+    a, b, c, d = run(1, 0), run(1, 0), run(1, 7), run(2, 0)
+    assert torch.equal(a, b) and not torch.equal(a, c) and not torch.equal(a, d)
+    assert torch.all(a[:, Cc:] == 1.0)                                                  # columns beyond C untouched
+    v = a[:, :Cc]
+    keep = 1.0 / (1.0 - p)
+    assert torch.all((v == 0) | ((v - keep).abs() < 1e-2 * keep))
+    frac = float((v == 0).float().mean()); n = rows * Cc
+    assert abs(frac - p) < 5 * (p * (1 - p) / n) ** 0.5, frac
+    assert abs(float(v.mean()) - 1.0) < 1e-2                                            # E[dropout(x)] = x
