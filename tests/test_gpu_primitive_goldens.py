@@ -258,3 +258,43 @@ def test_product_schedule_tables_and_add_noise_vs_reference(golden_dir, name, b0
     ga = torch.from_numpy(g[name + ":alphas_cumprod"]).double()[t.cpu()].reshape(B, 1, 1)
     want = ga.sqrt() * x0.double().cpu() + (1 - ga).sqrt() * nz.double().cpu()
     G.assert_close(out, want.float(), rtol=2e-5, atol=2e-6, name="add_noise on the reference table")
+
+
+@pytest.mark.parametrize("Cc,heads,T", [(512, 2, 192), (1024, 4, 128), (512, 4, 192), (256, 1, 192)])
+def test_attention_heads_on_the_fused_kernel_vs_oracle(Cc, heads, T):
+    """Head widths of 256 run the fused attention kernel on COLUMN VIEWS of the qkv / output rows (leading dimension 3 C / C, head offset
+    3 h ch / h ch); narrower heads take the batched-GEMM composition.  16-bit engine against the oracle inside the storage-emulation bound,
+    and against the same block forced onto the composition path."""
+    G = _G()
+    from oracle import quant as Q, unet as U
+    B = 4
+    h = C.c_void_p()
+    G.check(G.lib.eegldm_attnblock_create(G.ctx().h, Cc, heads, G.BF16, C.byref(h)))
+    blk = _Block(h)
+    try:
+        params = {k: gen_param(81, k, shape) for k, (_o, _n, shape) in blk.entries.items()}
+        blk.load(params)
+        xh, dyh = normal((B, Cc, T), seed=82), normal((B, Cc, T), seed=83)
+        x, dy = torch.from_numpy(xh).to(G.DEV), torch.from_numpy(dyh).to(G.DEV)
+        def run_engine():
+            y = torch.empty(B, Cc, T, device=G.DEV); dx = torch.empty(B, Cc, T, device=G.DEV)
+            blk.grad.zero_()
+            G.check(G.lib.eegldm_block_forward(blk.h, G.ptr(x), None, G.ptr(y), B, T))
+            G.check(G.lib.eegldm_block_backward(blk.h, G.ptr(dy), G.ptr(dx), None))
+            return y.cpu(), dx.cpu(), {k: v.cpu() for k, v in blk.grads().items()}
+        y, dx, gr = run_engine()
+        def run(emul):
+            sd = {k: torch.from_numpy(v).clone().requires_grad_(True) for k, v in params.items()}
+            xr = torch.from_numpy(xh).clone().requires_grad_(True)
+            with Q.bf16_storage(emul):
+                yo = U.attention_block(sd, "", xr, heads)
+                yo.backward(torch.from_numpy(dyh))
+            return yo.detach(), xr.grad, {k: v.grad for k, v in sd.items()}
+        def rel(a, b):
+            a = torch.as_tensor(a).double().reshape(-1); b = torch.as_tensor(b).double().reshape(-1)
+            return float((a - b).norm() / (b.norm() + 1e-12))
+        y32, dx32, g32 = run(False); yq, dxq, gq = run(True)
+        assert rel(y, y32) < G.bf16_gap_bound(rel(yq, y32)) and rel(dx, dx32) < G.bf16_gap_bound(rel(dxq, dx32)), (rel(y, y32), rel(yq, y32), rel(dx, dx32), rel(dxq, dx32))
+        G.assert_bf16_grads(gr, g32, gq, f"attention {Cc}/{heads}")
+    finally:
+        blk.close()
