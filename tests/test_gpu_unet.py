@@ -228,3 +228,31 @@ def test_dropout_kernel_keep_rate_scale_and_reproducibility(dtype):
     frac = float((v == 0).float().mean()); n = rows * Cc
     assert abs(frac - p) < 5 * (p * (1 - p) / n) ** 0.5, frac
     assert abs(float(v.mean()) - 1.0) < 1e-2                                            # E[dropout(x)] = x
+
+
+@pytest.mark.parametrize("name", ["opt_all", "opt_ssn", "opt_heads4"])
+def test_unet_options_fp16_and_deterministic_mode(name):
+    """The optional constructor branches under the other two engine modes: IEEE-half storage stays finite and close to the fp32 engine,
+    and deterministic mode gives bit-identical gradients run to run."""
+    import eegldm
+    from eegldm.models import UNetModel
+    cfg, B, L = UNET_OPTION_CASES[name]
+    x = torch.from_numpy(normal((B, cfg["in_channels"], L), seed=5)); t = torch.tensor([3, 871])[:B]
+    dy = torch.from_numpy(normal((B, cfg["out_channels"], L), seed=6))
+    def run(dtype):
+        net = UNetModel(**cfg, dtype=dtype)
+        net.load_state_dict({k: torch.from_numpy(gen_param(9, k, shape)) for k, (_o, _n, shape) in net.entries.items()})
+        net.zero_grad()
+        y = net(x, timesteps=t).float().cpu()
+        dx = net.backward(dy, need_dx=True).float().cpu()
+        return y, dx, net.flat_grad.clone().cpu()
+    y32, dx32, g32 = run("float32")
+    y16, dx16, g16 = run("float16")
+    rel = lambda a, b: float((a - b).norm() / (b.norm() + 1e-12))
+    assert torch.isfinite(g16).all() and rel(y16, y32) < 2e-2 and rel(dx16, dx32) < 3e-2 and rel(g16, g32) < 3e-2, (rel(y16, y32), rel(dx16, dx32), rel(g16, g32))
+    eegldm.set_deterministic(True)
+    try:
+        a = run("bfloat16"); b = run("bfloat16")
+    finally:
+        eegldm.set_deterministic(False)
+    assert all(torch.equal(p, q) for p, q in zip(a, b))
