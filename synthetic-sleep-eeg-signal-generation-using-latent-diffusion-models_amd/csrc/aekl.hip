@@ -20,7 +20,6 @@ int ls_bn_lrelu_fwd(eegldm_ctx*, const void* x, long ldx, const float* gamma, co
                     float* nbt, void* y, long ldy, long rows, int C, float slope, int training, int dtype);
 int ls_bn_lrelu_bwd(eegldm_ctx*, const void* x, long ldx, const float* gamma, const float* beta, const float* stats, const void* dy, long lddy,
                     void* dx, long lddx, float* dgamma, float* dbeta, long rows, int C, float slope, int dtype);
-int ls_bn_repeat_running(eegldm_ctx*, const float* stats, float* rmean, float* rvar, float* nbt, long rows, int C);
 int ls_bn_stats(eegldm_ctx*, const void* x, long ldx, float* stats, float* rmean, float* rvar, float* nbt, long rows, int C, int training, int dtype);
 int ls_bn_stats_from_parts(eegldm_ctx*, const float* parts, int nb, float* stats, float* rmean, float* rvar, float* nbt, long rows, int C);
 int ls_bn_apply(eegldm_ctx*, const void* x, long ldx, const float* gamma, const float* beta, const float* stats, void* y, long ldy, long rows, int C, float slope, int dtype);
@@ -814,22 +813,6 @@ static int disc_backward_impl(eegldm_disc* d, const float* dlogits, float* dx, i
   return 0;
 }
 
-// second running-statistics update of every BatchNorm layer with the batch statistics of the forward whose tape is still held
-static int disc_repeat_running(eegldm_disc* d) {
-  EEG_CHECK(d->have_tape && d->tape.size() == d->tape_ops() && d->buffers, "no forward tape to repeat the BatchNorm update from");
-  for (size_t i = 0; i < d->ops.size(); i++) {
-    const Op& o = d->ops[i];
-    if (o.kind != OP_ACT || o.bn_w < 0) continue;
-    if (d->tail_on && i == d->ops.size() - 2) {      // the fused tail's layer: its statistics live beside the tape
-      EEG_TRY(ls_bn_repeat_running(d->ctx, d->tail_st, d->buffers + o.rm, d->buffers + o.rv, d->buffers + o.nbt, (long)d->B * d->Lo, d->tail_y.C));
-      continue;
-    }
-    const OpTape& t = d->tape[i];
-    EEG_TRY(ls_bn_repeat_running(d->ctx, t.st, d->buffers + o.rm, d->buffers + o.rv, d->buffers + o.nbt, (long)d->B * t.Lin, t.x.C));
-  }
-  return 0;
-}
-
 // ================================================================== fused train step (train_autoencoderkl.py:200-234)
 extern "C" int eegldm_l1_loss(eegldm_ctx*, const float*, const float*, float*, float*, long, float);
 extern "C" int eegldm_lsgan_loss(eegldm_ctx*, const float*, int, float*, float*, long, float);
@@ -864,13 +847,15 @@ extern "C" int eegldm_aekl_train_step(eegldm_aekl* a, eegldm_disc* d, const floa
   // with the thin autoencoder's backward.  Two streams are two hardware queues, and alternating between them costs more than the overlap
   // returns.  Removed; HISTORY.md keeps the numbers.)
   EEG_TRY(eegldm_spectral_loss(ctx, recon, x, losses + 1, use_spectral ? drecon : nullptr, B, C, L, spectral_weight));
-  EEG_TRY(eegldm_disc_forward(d, recon, logits, B, L, 1));
+  // (this forward serves the generator loss AND the fake-sample loss below: its BatchNorm layers make both running-statistics updates at once)
+  EEG_ENV_VAR(bool, refwd, getenv("EEGLDM_AEKL_REFORWARD_D") != nullptr);       // developer switch: the literal three-forward sequence
+  struct Repeats { eegldm_ctx* c; Repeats(eegldm_ctx* cc, int n) : c(cc) { c->bn_running_repeats = n; } ~Repeats() { c->bn_running_repeats = 1; } };
+  { Repeats two(ctx, refwd ? 1 : 2); EEG_TRY(eegldm_disc_forward(d, recon, logits, B, L, 1)); }
   EEG_TRY(eegldm_lsgan_loss(ctx, logits, 1, losses + 3, dlogits, nl, adv_weight));
   // The reference forwards the discriminator on the reconstruction twice: for the generator loss (:213) and, detached, for the
   // fake-sample loss (:225).  Between the two only the GENERATOR's parameters change, so activations and logits are identical:
-  // the second forward is replaced by a second backward over the kept tape (other dlogits, this time into D's gradients) plus the
-  // repeat of the BatchNorm running-statistics update that a second forward would have made (same batch statistics).
-  EEG_ENV_VAR(bool, refwd, getenv("EEGLDM_AEKL_REFORWARD_D") != nullptr);       // developer switch: the literal three-forward sequence
+  // the second forward is replaced by a second backward over the kept tape (other dlogits, this time into D's gradients); the
+  // BatchNorm running-statistics update that a second forward would have made (same batch statistics) was made by the first (above).
   EEG_TRY(disc_backward_impl(d, dlogits, dxd, 0, !refwd));
   EEG_TRY(eegldm_axpy(ctx, drecon, dxd, 1.0f, n));
   // (Round 5 also tried the thin autoencoder's one-launch backward on the auxiliary stream beside the discriminator's launches: 3.86 against
@@ -879,7 +864,6 @@ extern "C" int eegldm_aekl_train_step(eegldm_aekl* a, eegldm_disc* d, const floa
   EEG_TRY(eegldm_aekl_backward(a, drecon, kl_weight, nullptr));
   // ---- discriminator: 0.5 * adv_weight * (fake->0 + real->1)
   if (refwd) EEG_TRY(eegldm_disc_forward(d, recon, logits, B, L, 1));
-  else EEG_TRY(disc_repeat_running(d));
   EEG_TRY(eegldm_lsgan_loss(ctx, logits, 0, losses + 4, dlogits, nl, 0.5f * adv_weight));
   EEG_TRY(eegldm_disc_backward(d, dlogits, nullptr, 1));
   EEG_TRY(eegldm_disc_forward(d, x, logits, B, L, 1));

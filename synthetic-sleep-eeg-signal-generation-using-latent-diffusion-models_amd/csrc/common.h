@@ -95,6 +95,9 @@ struct eegldm_ctx {
   bool loss_prezeroed = false;
   bool l1_overwrite = false;      // eegldm_l1_loss writes da instead of accumulating (the caller skipped zeroing it)
   int bn_flip = 0; int bn_dirty[2] = {0, 0};   // BatchNorm sum areas alternate; each call's fold kernel re-zeroes the other one (losses.hip)
+  // running-statistics updates per training-mode BatchNorm forward (1; the fused AEKL / GAN step sets 2 around the discriminator forward whose
+  // activations serve both the generator loss and the fake-sample loss: the reference runs that forward twice, train_autoencoderkl.py:213,225)
+  int bn_running_repeats = 1;
   double prof_bracket_ms = 0.0;   // elapsed time of an EMPTY event pair on this stream (calibrated by eegldm_prof_enable): subtracted per launch
   // deferred weight gradients (ops.hip: op_conv_wgrad records instead of launching while defer_wgrad is set; op_wgrad_flush groups the
   // records by shape and launches every group as one grouped GEMM).  Set by the UNet backward only.

@@ -33,33 +33,47 @@ __global__ __launch_bounds__(NT) void bn_stats_kernel(const T* __restrict__ x, l
   }
 }
 // stats[c] = (mean, rstd); running stats: momentum 0.1, unbiased variance (torch BatchNorm1d defaults)
-__global__ void bn_finalize_kernel(const double* __restrict__ sums, float* __restrict__ stats, float* __restrict__ rmean,
-                                   float* __restrict__ rvar, float* __restrict__ nbt, int C, double n, float eps, float momentum) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= C) return;
-  const double mean = sums[2 * c] / n;
-  double var = sums[2 * c + 1] / n - mean * mean;
+// (repeats: that many momentum updates with the same batch statistics -- eegldm_ctx::bn_running_repeats)
+__device__ __forceinline__ void bn_finalize_one(double s1, double s2, int c, float* __restrict__ stats, float* __restrict__ rmean, float* __restrict__ rvar,
+                                                float* __restrict__ nbt, double n, float eps, float momentum, int repeats) {
+  const double mean = s1 / n;
+  double var = s2 / n - mean * mean;
   if (var < 0) var = 0;
   stats[2 * c] = (float)mean; stats[2 * c + 1] = (float)(1.0 / sqrt(var + (double)eps));
   if (rmean) {
-    rmean[c] = (1.0f - momentum) * rmean[c] + momentum * (float)mean;
-    rvar[c] = (1.0f - momentum) * rvar[c] + momentum * (float)(var * n / (n > 1 ? n - 1 : 1));
-    if (c == 0 && nbt) nbt[0] += 1.0f;
+    float rm = rmean[c], rv = rvar[c];
+    const float ub = (float)(var * n / (n > 1 ? n - 1 : 1));
+    for (int k = 0; k < repeats; k++) { rm = (1.0f - momentum) * rm + momentum * (float)mean; rv = (1.0f - momentum) * rv + momentum * ub; }
+    rmean[c] = rm; rvar[c] = rv;
+    if (c == 0 && nbt) nbt[0] += (float)repeats;
   }
 }
-// A second running-statistics update with the SAME batch statistics (the fused AEKL/GAN step reuses the discriminator's forward on the
-// reconstruction for the generator loss and for the fake-sample loss; the reference runs that forward twice,
-// train_autoencoderkl.py:213,225, which only differs in this update).  stats = (mean, rstd): var = 1/rstd^2 - eps.
-__global__ void bn_repeat_running_kernel(const float* __restrict__ stats, float* __restrict__ rmean, float* __restrict__ rvar, float* __restrict__ nbt,
-                                         int C, double n, float eps, float momentum) {
+__global__ void bn_finalize_kernel(const double* __restrict__ sums, float* __restrict__ stats, float* __restrict__ rmean,
+                                   float* __restrict__ rvar, float* __restrict__ nbt, int C, double n, float eps, float momentum, int repeats) {
   const int c = blockIdx.x * blockDim.x + threadIdx.x;
   if (c >= C) return;
-  const double rstd = (double)stats[2 * c + 1];
-  double var = 1.0 / (rstd * rstd) - (double)eps;
-  if (var < 0) var = 0;
-  rmean[c] = (1.0f - momentum) * rmean[c] + momentum * stats[2 * c];
-  rvar[c] = (1.0f - momentum) * rvar[c] + momentum * (float)(var * n / (n > 1 ? n - 1 : 1));
-  if (c == 0 && nbt) nbt[0] += 1.0f;
+  bn_finalize_one(sums[2 * c], sums[2 * c + 1], c, stats, rmean, rvar, nbt, n, eps, momentum, repeats);
+}
+// fold of the per-block partial rows parts[nparts][2 C] (interleaved sum, sum of squares) AND the finalisation in one launch: a 1024-thread block
+// owns 64 consecutive values = 32 channels, 16 row lanes add their rows in fp64, the lanes meet in LDS in a fixed order (no atomics, no sum
+// area), the even lanes finalise their channel.  Replaces bn_fold_kernel + bn_finalize_kernel on the forward path (two ~5 us launches per layer).
+__global__ __launch_bounds__(1024) void bn_fold_finalize_kernel(const float* __restrict__ parts, int nparts, int C, float* __restrict__ stats, float* __restrict__ rmean,
+                                                                float* __restrict__ rvar, float* __restrict__ nbt, double n, float eps, float momentum, int repeats) {
+  __shared__ double red[16][64];
+  const int col = threadIdx.x & 63, seg = threadIdx.x >> 6, i = blockIdx.x * 64 + col, n2c = 2 * C;
+  double s = 0.0;
+  if (i < n2c) {
+#pragma unroll 4
+    for (int r = seg; r < nparts; r += 16) s += (double)parts[(size_t)r * n2c + i];
+  }
+  red[seg][col] = s;
+  __syncthreads();
+  if (seg == 0 && (col & 1) == 0 && i < n2c) {
+    double s1 = 0.0, s2 = 0.0;
+#pragma unroll
+    for (int k = 0; k < 16; k++) { s1 += red[k][col]; s2 += red[k][col + 1]; }
+    bn_finalize_one(s1, s2, i >> 1, stats, rmean, rvar, nbt, n, eps, momentum, repeats);
+  }
 }
 __global__ void bn_eval_stats_kernel(const float* __restrict__ rmean, const float* __restrict__ rvar, float* __restrict__ stats, int C, float eps) {
   const int c = blockIdx.x * blockDim.x + threadIdx.x;
@@ -386,11 +400,6 @@ inline void pick_rsplit(long rows, int C, eegldm_ctx* ctx, int* rsplit, long* rp
     else EEG_FAIL(EEGLDM_ERR_UNSUPPORTED, "dtype %d", (int)(dtype));      \
   } while (0)
 
-int ls_bn_repeat_running(eegldm_ctx* ctx, const float* stats, float* rmean, float* rvar, float* nbt, long rows, int C) {
-  hipLaunchKernelGGL(bn_repeat_running_kernel, dim3((C + 255) / 256), dim3(256), 0, ctx->stream, stats, rmean, rvar, nbt, C, (double)rows, 1e-5f, 0.1f);
-  LAUNCH_CHECK();
-  return 0;
-}
 // Sum areas in the context scratch: two alternating ones for the partials + fold path (the fold kernel of a call re-zeroes the area
 // the PREVIOUS call used -- all of that call's consumers precede it in stream order), a third, memset per call, for the atomic path.
 static double* bn_area(eegldm_ctx* ctx, int i) { return (double*)((char*)ctx->scratch + (2u << 20) + (size_t)i * (256u << 10)); }
@@ -420,6 +429,13 @@ int ls_bn_stats(eegldm_ctx* ctx, const void* x, long ldx, float* stats, float* r
       void* parts = (char*)ctx->scratch + (8u << 20);
       DISPATCH_T(dtype, hipLaunchKernelGGL((bn_reduce4_kernel<T, 0>), dim3(nb), dim3(NT), 0, ctx->stream, (const T*)x, ldx, nullptr, nullptr, nullptr,
                                            (const T*)nullptr, 0, parts, rows, C, rpb4, 0.f));
+      LAUNCH_CHECK();
+      if (!eeg_deterministic()) {      // fold + finalise in one launch (the deterministic mode keeps its ordered fold)
+        hipLaunchKernelGGL(bn_fold_finalize_kernel, dim3((2 * C + 63) / 64), dim3(1024), 0, ctx->stream, (const float*)parts, nb, C, stats, rmean, rvar, nbt,
+                           (double)rows, 1e-5f, 0.1f, ctx->bn_running_repeats);
+        LAUNCH_CHECK();
+        return 0;
+      }
       EEG_TRY(bn_fold_launch(ctx, parts, nb, C, &sums));
     } else {
       HIP_TRY(hipMemsetAsync(sums, 0, sizeof(double) * 2 * C, ctx->stream));
@@ -427,7 +443,8 @@ int ls_bn_stats(eegldm_ctx* ctx, const void* x, long ldx, float* stats, float* r
       DISPATCH_T(dtype, hipLaunchKernelGGL((bn_stats_kernel<T>), dim3((C + 63) / 64, rs), dim3(NT), 0, ctx->stream, (const T*)x, ldx, sums, rows, C, rpb));
     }
     LAUNCH_CHECK();
-    hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 255) / 256), dim3(256), 0, ctx->stream, sums, stats, rmean, rvar, nbt, C, (double)rows, 1e-5f, 0.1f);
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 255) / 256), dim3(256), 0, ctx->stream, sums, stats, rmean, rvar, nbt, C, (double)rows, 1e-5f, 0.1f,
+                       ctx->bn_running_repeats);
     LAUNCH_CHECK();
   } else {
     EEG_CHECK(rmean && rvar, "eval-mode BatchNorm needs running statistics");
@@ -438,9 +455,16 @@ int ls_bn_stats(eegldm_ctx* ctx, const void* x, long ldx, float* stats, float* r
 }
 // statistics from the per-block column partials the producing conv left (conv_ws.hip ST kernels): parts[nb][2 C] interleaved (sum, sum of squares)
 int ls_bn_stats_from_parts(eegldm_ctx* ctx, const float* parts, int nb, float* stats, float* rmean, float* rvar, float* nbt, long rows, int C) {
+  if (!eeg_deterministic()) {
+    hipLaunchKernelGGL(bn_fold_finalize_kernel, dim3((2 * C + 63) / 64), dim3(1024), 0, ctx->stream, parts, nb, C, stats, rmean, rvar, nbt, (double)rows, 1e-5f, 0.1f,
+                       ctx->bn_running_repeats);
+    LAUNCH_CHECK();
+    return 0;
+  }
   double* sums;
   EEG_TRY(ls_bn_fold(ctx, parts, nb, 2 * C, &sums));
-  hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 255) / 256), dim3(256), 0, ctx->stream, sums, stats, rmean, rvar, nbt, C, (double)rows, 1e-5f, 0.1f);
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 255) / 256), dim3(256), 0, ctx->stream, sums, stats, rmean, rvar, nbt, C, (double)rows, 1e-5f, 0.1f,
+                     ctx->bn_running_repeats);
   LAUNCH_CHECK();
   return 0;
 }
