@@ -256,3 +256,47 @@ def test_unet_options_fp16_and_deterministic_mode(name):
     finally:
         eegldm.set_deterministic(False)
     assert all(torch.equal(p, q) for p, q in zip(a, b))
+
+
+@pytest.mark.parametrize("name", list(UNET_CASES) + ["full_l768"])
+def test_bf16_engine_is_as_close_to_fp32_as_the_reference_autocast_run(golden_dir, name):
+    """tests/golden/make_golden_autocast.py ran the REFERENCE UNet under torch.autocast(bfloat16) -- its own reduced-precision execution -- and
+    recorded how far that run is from its fp32 run.  The bf16 engine (bf16 storage, fp32 accumulation and statistics) has to be about as
+    close to the fp32 result: output, input gradient, and the parameter gradient as one vector."""
+    import gpu_util as G
+    from make_golden_cases import UNET_FULL
+    from eegldm.models import UNetModel
+    from oracle import unet as U
+    a = np.load(os.path.join(golden_dir, "unet_autocast_bf16.npz"))
+    g = np.load(os.path.join(golden_dir, f"unet_{name}.npz"))
+    cfg, B, L = UNET_FULL if name == "full_l768" else UNET_CASES[name]
+    sw, sx, _st, sdy = [int(v) for v in g["seeds"]]
+    net = UNetModel(**cfg, dtype="bfloat16")
+    sd = {k: torch.from_numpy(gen_param(sw, k, shape)) for k, (_o, _n, shape) in net.entries.items()}
+    net.load_state_dict(sd)
+    x = torch.from_numpy(normal((B, cfg["in_channels"], L), seed=sx)); t = torch.from_numpy(g["t"])
+    dy = torch.from_numpy(normal((B, cfg["out_channels"], L), seed=sdy))
+    net.zero_grad()
+    y = net(x, timesteps=t).float().cpu()
+    dx = net.backward(dy, need_dx=True).float().cpu()
+    grads = {k: v.float().cpu() for k, v in net.grad_dict().items()}
+    # fp32 reference quantities: y / dx from the golden; full parameter gradients from the oracle's fp32 run (pinned to the same golden)
+    p = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+    xr = x.clone().requires_grad_(True)
+    yo = U.unet_forward(p, cfg, xr, t); yo.backward(dy)
+    np.testing.assert_allclose(yo.detach().numpy(), g["y"], rtol=1e-4, atol=2e-5)
+    rel = lambda u, v: float((u.double() - v.double()).norm() / (v.double().norm() + 1e-30))
+    e_y, e_dx = rel(y, torch.from_numpy(g["y"])), rel(dx, torch.from_numpy(g["dx"]))
+    num = sum(float((grads[k].double() - p[k].grad.double()).norm() ** 2) for k in p); den = sum(float(p[k].grad.double().norm() ** 2) for k in p)
+    e_g = (num / den) ** 0.5
+    keys = [str(k) for k in a[name + ":keys"]]
+    assert keys == list(p.keys())
+    ge, gl = a[name + ":g_err"].astype(np.float64), a[name + ":g_l2"].astype(np.float64)
+    r_g = float(np.sqrt(((ge * gl) ** 2).sum() / (gl ** 2).sum()))
+    r_y, r_dx = float(a[name + ":y_err"]), float(a[name + ":dx_err"])
+    print(f"{name}: engine bf16 vs fp32  y {e_y:.3e} dx {e_dx:.3e} grads {e_g:.3e}   |   reference autocast-bf16 vs fp32  y {r_y:.3e} dx {r_dx:.3e} grads {r_g:.3e}")
+    # Not the same rounding points: CPU autocast keeps the residual stream, GroupNorm outputs and softmax in fp32 and rounds conv / linear /
+    # matmul results only, the engine stores EVERY activation in bf16 -- so "as close" is held to a factor of 1.5, not to <= (measured:
+    # 0.6-1.2 x on the four cases).
+    F = 1.5
+    assert e_y <= F * r_y and e_dx <= F * r_dx and e_g <= F * r_g, (e_y, r_y, e_dx, r_dx, e_g, r_g)
