@@ -8,7 +8,9 @@ conv1d / linear / matmul through bf16 and keeps GroupNorm, softmax and the loss 
 to the fp32 vectors of make_golden.py, how far THAT run is from the reference's fp32 run: relative L2 error of y, dx and of every parameter
 gradient (unet_autocast_bf16.npz).  tests/test_gpu_unet.py holds the bf16 engine to those numbers: an engine that stores activations in bf16
 has to land at least as close to the fp32 result as the reference's own reduced-precision execution does.
-Inputs and weights are regenerated from seeds (param_gen.py); the file holds error figures and the autocast outputs only.
+aekl_autocast_bf16.npz / disc_autocast_bf16.npz: the same for the production stage-1 autoencoder and the PatchGAN discriminator (the reference's
+local twins: ae_kl.py with one-group Normalize, discriminator.py with kernel-3 convs).
+Inputs and weights are regenerated from seeds (param_gen.py); the files hold error figures and the autocast outputs only.
 """
 import os
 import sys
@@ -70,5 +72,99 @@ def main():
     np.savez_compressed(os.path.join(HERE, "unet_autocast_bf16.npz"), **out)
 
 
+def aekl():
+    """The production stage-1 autoencoder ([32,32,64], norm_num_groups 1: the frozen encoder of the LDM step and the decoder of sampling) as the
+    reference's local twin (make_golden_r5.build_twin_g1), fp32 against bf16 autocast: recon, z_mu, z_sigma, dx, every parameter gradient of
+    <recon, dy> + 0.3 KL (the quantities of aekl_twin_32_32_64_g1.npz)."""
+    sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
+    from make_golden_r5 import build_twin_g1
+    from param_gen import eeg_windows
+    g = np.load(os.path.join(HERE, "aekl_twin_32_32_64_g1.npz"))
+    sw, sx, se, sdy = [int(v) for v in g["seeds"]]; B, L = int(g["B"]), int(g["L"])
+    net, ref_param, shapes, _nc = build_twin_g1(32, L, sw)
+    x0 = torch.from_numpy(eeg_windows(B, seed=sx, length=L, pad=8)); eps = torch.from_numpy(normal((B, 1, L // 4), seed=se))
+    dy = torch.from_numpy(normal((B, 1, L), seed=sdy))
+
+    def run(autocast):
+        for k in shapes:
+            ref_param(k).grad = None
+        x = x0.clone().requires_grad_(True)
+        ctx = torch.autocast("cpu", dtype=torch.bfloat16) if autocast else torch.autocast("cpu", enabled=False)
+        with ctx:
+            z_mu, z_sigma = net.encode(x)
+            recon = net.decode(z_mu + eps * z_sigma)
+        z_mu, z_sigma, recon = z_mu.float(), z_sigma.float(), recon.float()
+        kl = 0.5 * torch.sum(z_mu.pow(2) + z_sigma.pow(2) - torch.log(z_sigma.pow(2)) - 1, dim=[1])
+        kl = torch.sum(kl) / kl.shape[0]
+        ((recon * dy).sum() + 0.3 * kl).backward()
+        return recon.detach(), z_mu.detach(), z_sigma.detach(), x.grad.clone(), {k: ref_param(k).grad.clone() for k in shapes}
+
+    r32 = run(False); ra = run(True)
+    np.testing.assert_allclose(r32[0].numpy(), g["recon"], rtol=2e-4, atol=5e-5)
+    out = {"recon_err": np.float64(rel(ra[0], r32[0])), "mu_err": np.float64(rel(ra[1], r32[1])), "sigma_err": np.float64(rel(ra[2], r32[2])),
+           "dx_err": np.float64(rel(ra[3], r32[3])), "keys": np.array(list(shapes.keys())),
+           "g_err": np.array([rel(ra[4][k], r32[4][k]) for k in shapes]), "g_l2": np.array([float(r32[4][k].double().norm()) for k in shapes])}
+    print("aekl [32,32,64] g1: autocast-bf16 vs fp32: recon %.3e mu %.3e sigma %.3e dx %.3e grads median %.3e" %
+          (out["recon_err"], out["mu_err"], out["sigma_err"], out["dx_err"], float(np.median(out["g_err"]))))
+    np.savez_compressed(os.path.join(HERE, "aekl_autocast_bf16.npz"), **out)
+
+
+def disc():
+    """The reference's local PatchGAN Discriminator with the kernel-3 convs of the config (the twin of make_golden_r2.case_disc_twin, same seeds),
+    training mode, fp32 against bf16 autocast: logits, dx, every parameter gradient of <logits, dy> (disc_twin_k3.npz's quantities)."""
+    sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
+    from models import discriminator as RD
+    from oracle import aekl as A
+    g = np.load(os.path.join(HERE, "disc_twin_k3.npz"))
+    sw, sx, sdy = [int(v) for v in g["seeds"]]
+    dcfg = dict(spatial_dims=1, num_layers_d=3, num_channels=64, in_channels=1, out_channels=1, kernel_size=3, norm="BATCH", bias=False, padding=1)
+    shapes = A.disc_param_shapes(dcfg)
+    pkeys = [k for k in shapes if "running" not in k and "num_batches" not in k]
+
+    def build():
+        net = RD.Discriminator(input_nc=1, ndf=64, n_layers=3)
+        main_ = net.main
+        for i in (0, 2, 5, 8, 11):
+            c = main_[i]
+            main_[i] = torch.nn.Conv1d(c.in_channels, c.out_channels, kernel_size=3, stride=c.stride, padding=1, bias=c.bias is not None)
+        def ref_tensor(key):
+            parts = key.split(".")
+            if parts[0] == "initial_conv":
+                return getattr(main_[0], parts[-1])
+            if parts[0] == "final_conv":
+                return getattr(main_[11], parts[-1])
+            l = int(parts[0])
+            return getattr(main_[2 + 3 * l], parts[-1]) if parts[1] == "conv" else getattr(main_[3 + 3 * l], parts[-1])
+        with torch.no_grad():
+            for k, shp in shapes.items():
+                v = torch.from_numpy(gen_param(sw, k, shp))
+                ref_tensor(k).copy_(v * 2.0 if k.endswith("conv.weight") else v)
+        net.train()
+        return net, ref_tensor
+
+    x0 = torch.from_numpy(normal((3, 1, 256), seed=sx))
+
+    def run(autocast):
+        net, ref_tensor = build()                       # fresh running statistics for each run
+        x = x0.clone().requires_grad_(True)
+        with (torch.autocast("cpu", dtype=torch.bfloat16) if autocast else torch.autocast("cpu", enabled=False)):
+            logits = net(x)
+        logits = logits.float()
+        dy = torch.from_numpy(normal(tuple(logits.shape), seed=sdy))
+        (logits * dy).sum().backward()
+        return logits.detach(), x.grad.clone(), {k: ref_tensor(k).grad.clone() for k in pkeys}
+
+    r32 = run(False); ra = run(True)
+    np.testing.assert_allclose(r32[0].numpy(), g["logits"], rtol=2e-4, atol=5e-5)
+    out = {"logits_err": np.float64(rel(ra[0], r32[0])), "dx_err": np.float64(rel(ra[1], r32[1])), "keys": np.array(pkeys),
+           "g_err": np.array([rel(ra[2][k], r32[2][k]) for k in pkeys]), "g_l2": np.array([float(r32[2][k].double().norm()) for k in pkeys])}
+    print("discriminator twin: autocast-bf16 vs fp32: logits %.3e dx %.3e grads median %.3e" % (out["logits_err"], out["dx_err"], float(np.median(out["g_err"]))))
+    np.savez_compressed(os.path.join(HERE, "disc_autocast_bf16.npz"), **out)
+
+
 if __name__ == "__main__":
-    main()
+    if "--aekl-only" not in sys.argv and "--disc-only" not in sys.argv:
+        main()
+    if "--disc-only" not in sys.argv:
+        aekl()
+    disc()

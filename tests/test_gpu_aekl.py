@@ -414,3 +414,87 @@ def test_patch_discriminator_vs_reference_local_discriminator_golden(golden_dir,
             assert abs(float(gr.norm()) - l2) / (l2 + floor) < (2e-3 if f32 else 8e-2), k
             head = g["g_head:" + k].astype(np.float64)
             assert float(np.linalg.norm(gr[:16].numpy() - head)) / (float(np.linalg.norm(head)) + floor) < (3e-3 if f32 else 0.15), k
+
+
+def test_bf16_autoencoder_is_as_close_to_fp32_as_the_reference_autocast_run(golden_dir):
+    """The production stage-1 autoencoder [32,32,64] (frozen encoder of the LDM step, decoder of sampling): the reference's local twin under
+    torch.autocast(bfloat16) is its own reduced-precision run (tests/golden/make_golden_autocast.py -> aekl_autocast_bf16.npz holds that
+    run's distance from the fp32 run); the bf16 engine is held to the same distance (factor 1.5: not the same rounding points)."""
+    import os
+    import gpu_util as G
+    from eegldm.models import AutoencoderKL
+    from oracle import aekl as A
+    a = np.load(os.path.join(golden_dir, "aekl_autocast_bf16.npz"))
+    g = np.load(os.path.join(golden_dir, "aekl_twin_32_32_64_g1.npz"))
+    nc = [int(v) for v in g["num_channels"]]; B, L = int(g["B"]), int(g["L"])
+    cfg = dict(num_channels=nc, latent_channels=1, in_channels=1, out_channels=1, num_res_blocks=2, norm_num_groups=1)
+    sw, sx, se, sdy = [int(v) for v in g["seeds"]]
+    x = torch.from_numpy(eeg_windows(B, seed=sx, length=L, pad=8)); eps = torch.from_numpy(normal((B, 1, L // 4), seed=se))
+    dy = torch.from_numpy(normal((B, 1, L), seed=sdy))
+    net = AutoencoderKL(spatial_dims=1, attention_levels=[False] * 3, dtype="bfloat16", **cfg)
+    sd = {k: torch.from_numpy(gen_param(sw, k, shape)) for k, (_o, _n, shape) in net.entries.items()}
+    net.load_state_dict(sd)
+    klo = torch.zeros(1, device=net.device)
+    recon, mu, sg = net(x, eps=eps, kl_out=klo)
+    net.zero_grad()
+    dx = net.backward(dy, kl_weight=0.3, need_dx=True)
+    grads = {k: v.float().cpu() for k, v in net.grad_dict().items()}
+    # full fp32 parameter gradients from the oracle (pinned to the same twin golden)
+    p = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+    xr = x.clone().requires_grad_(True)
+    ro, mo, so = A.forward(p, cfg, xr, eps)
+    kl = 0.5 * torch.sum(mo.pow(2) + so.pow(2) - torch.log(so.pow(2)) - 1, dim=[1]); kl = torch.sum(kl) / kl.shape[0]
+    ((ro * dy).sum() + 0.3 * kl).backward()
+    np.testing.assert_allclose(ro.detach().numpy(), g["recon"], rtol=2e-4, atol=5e-5)
+    rel = lambda u, v: float((torch.as_tensor(u).double().cpu() - torch.as_tensor(v).double()).norm() / (torch.as_tensor(v).double().norm() + 1e-30))
+    e = dict(recon=rel(recon, g["recon"]), mu=rel(mu, g["z_mu"]), sigma=rel(sg, g["z_sigma"]), dx=rel(dx, g["dx"]))
+    num = sum(float((grads[k].double() - p[k].grad.double()).norm() ** 2) for k in p); den = sum(float(p[k].grad.double().norm() ** 2) for k in p)
+    e["grads"] = (num / den) ** 0.5
+    assert [str(k) for k in a["keys"]] == list(p.keys())
+    ge, gl = a["g_err"].astype(np.float64), a["g_l2"].astype(np.float64)
+    r = dict(recon=float(a["recon_err"]), mu=float(a["mu_err"]), sigma=float(a["sigma_err"]), dx=float(a["dx_err"]),
+             grads=float(np.sqrt(((ge * gl) ** 2).sum() / (gl ** 2).sum())))
+    print("engine bf16 vs fp32:", {k: f"{v:.3e}" for k, v in e.items()}, "| reference autocast-bf16 vs fp32:", {k: f"{v:.3e}" for k, v in r.items()})
+    for k in e:
+        assert e[k] <= 1.5 * r[k], (k, e[k], r[k])
+
+
+def test_bf16_discriminator_is_as_close_to_fp32_as_the_reference_autocast_run(golden_dir):
+    """PatchDiscriminator (training-mode BatchNorm): the reference's local twin under torch.autocast(bfloat16) against its fp32 run
+    (disc_autocast_bf16.npz) beside the bf16 engine against the same fp32 numbers; factor 1.5 as for the UNet and the autoencoder."""
+    import os
+    import gpu_util as G
+    from eegldm.models import PatchDiscriminator
+    from oracle import aekl as A
+    a = np.load(os.path.join(golden_dir, "disc_autocast_bf16.npz"))
+    g = np.load(os.path.join(golden_dir, "disc_twin_k3.npz"))
+    sw, sx, sdy = [int(v) for v in g["seeds"]]
+    net = PatchDiscriminator(**D_CFG, dtype="bfloat16")
+    sd = {}
+    for k in [str(k) for k in g["keys"]]:
+        shape = net.entries[k][2] if k in net.entries else net.buf_entries[k][2]
+        v = torch.from_numpy(gen_param(sw, k, shape))
+        sd[k] = v * 2.0 if k.endswith("conv.weight") else v
+    net.load_state_dict(sd)
+    x = torch.from_numpy(normal((3, 1, 256), seed=sx))
+    logits = net(x)[-1]
+    dy = torch.from_numpy(normal(tuple(logits.shape), seed=sdy))
+    net.zero_grad()
+    dx = net.backward(dy, need_dx=True, in_shape=tuple(x.shape))
+    grads = {k: v.float().cpu() for k, v in net.grad_dict().items()}
+    pkeys = [str(k) for k in a["keys"]]
+    p = {k: (v.clone().requires_grad_(True) if k in pkeys else v.clone()) for k, v in sd.items()}
+    xr = x.clone().requires_grad_(True)
+    lo = A.disc_forward(p, D_CFG, xr, training=True)
+    lo = lo[-1] if isinstance(lo, (list, tuple)) else lo
+    (lo * dy).sum().backward()
+    np.testing.assert_allclose(lo.detach().numpy(), g["logits"], rtol=2e-4, atol=5e-5)
+    rel = lambda u, v: float((torch.as_tensor(u).double().cpu() - torch.as_tensor(v).double()).norm() / (torch.as_tensor(v).double().norm() + 1e-30))
+    e = dict(logits=rel(logits, g["logits"]), dx=rel(dx, g["dx"]))
+    num = sum(float((grads[k].double() - p[k].grad.double()).norm() ** 2) for k in pkeys); den = sum(float(p[k].grad.double().norm() ** 2) for k in pkeys)
+    e["grads"] = (num / den) ** 0.5
+    ge, gl = a["g_err"].astype(np.float64), a["g_l2"].astype(np.float64)
+    r = dict(logits=float(a["logits_err"]), dx=float(a["dx_err"]), grads=float(np.sqrt(((ge * gl) ** 2).sum() / (gl ** 2).sum())))
+    print("engine bf16 vs fp32:", {k: f"{v:.3e}" for k, v in e.items()}, "| reference autocast-bf16 vs fp32:", {k: f"{v:.3e}" for k, v in r.items()})
+    for k in e:
+        assert e[k] <= 1.5 * r[k], (k, e[k], r[k])
