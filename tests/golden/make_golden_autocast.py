@@ -3,7 +3,8 @@
     python tests/golden/make_golden_autocast.py
 
 The reference trains under `torch.autocast` (src/training/training.py:423; fp16 on its CUDA devices).  The same model code under
-`torch.autocast("cpu", dtype=torch.bfloat16)` is the closest thing to "a reference bf16 run" that exists: torch's CPU autocast policy sends
+`torch.autocast("cpu", dtype=torch.bfloat16)` -- and dtype=torch.float16, the reference's own type -- is the closest thing to "a reference
+reduced-precision run" that exists: torch's CPU autocast policy sends
 conv1d / linear / matmul through bf16 and keeps GroupNorm, softmax and the loss in fp32.  For every UNet golden case this script records, next
 to the fp32 vectors of make_golden.py, how far THAT run is from the reference's fp32 run: relative L2 error of y, dx and of every parameter
 gradient (unet_autocast_bf16.npz).  tests/test_gpu_unet.py holds the bf16 engine to those numbers: an engine that stores activations in bf16
@@ -34,12 +35,15 @@ def rel(a, b):
     return float((a - b).norm() / (b.norm() + 1e-30))
 
 
+DT, TAG = torch.bfloat16, "bf16"      # set by __main__: the script runs once per reduced-precision type (bf16, then fp16 -- the reference's own, training.py:423)
+
+
 def run(net, x0, t, dy, autocast):
     for p in net.parameters():
         p.grad = None
     x = x0.clone().requires_grad_(True)
     if autocast:
-        with torch.autocast("cpu", dtype=torch.bfloat16):
+        with torch.autocast("cpu", dtype=DT):
             y = net(x, timesteps=t)
     else:
         y = net(x, timesteps=t)
@@ -68,8 +72,8 @@ def main():
         out[name + ":g_err"] = np.array([rel(ga[k], g32[k]) for k in keys])
         out[name + ":g_l2"] = np.array([float(g32[k].double().norm()) for k in keys])
         ge = out[name + ":g_err"]
-        print(f"{name}: autocast-bf16 vs fp32: y {out[name + ':y_err']:.3e} dx {out[name + ':dx_err']:.3e} param grads median {np.median(ge):.3e} max {ge.max():.3e}")
-    np.savez_compressed(os.path.join(HERE, "unet_autocast_bf16.npz"), **out)
+        print(f"{name}: autocast-{TAG} vs fp32: y {out[name + ':y_err']:.3e} dx {out[name + ':dx_err']:.3e} param grads median {np.median(ge):.3e} max {ge.max():.3e}")
+    np.savez_compressed(os.path.join(HERE, f"unet_autocast_{TAG}.npz"), **out)
 
 
 def aekl():
@@ -89,7 +93,7 @@ def aekl():
         for k in shapes:
             ref_param(k).grad = None
         x = x0.clone().requires_grad_(True)
-        ctx = torch.autocast("cpu", dtype=torch.bfloat16) if autocast else torch.autocast("cpu", enabled=False)
+        ctx = torch.autocast("cpu", dtype=DT) if autocast else torch.autocast("cpu", enabled=False)
         with ctx:
             z_mu, z_sigma = net.encode(x)
             recon = net.decode(z_mu + eps * z_sigma)
@@ -104,9 +108,9 @@ def aekl():
     out = {"recon_err": np.float64(rel(ra[0], r32[0])), "mu_err": np.float64(rel(ra[1], r32[1])), "sigma_err": np.float64(rel(ra[2], r32[2])),
            "dx_err": np.float64(rel(ra[3], r32[3])), "keys": np.array(list(shapes.keys())),
            "g_err": np.array([rel(ra[4][k], r32[4][k]) for k in shapes]), "g_l2": np.array([float(r32[4][k].double().norm()) for k in shapes])}
-    print("aekl [32,32,64] g1: autocast-bf16 vs fp32: recon %.3e mu %.3e sigma %.3e dx %.3e grads median %.3e" %
+    print(f"aekl [32,32,64] g1: autocast-{TAG} vs fp32:" " recon %.3e mu %.3e sigma %.3e dx %.3e grads median %.3e" %
           (out["recon_err"], out["mu_err"], out["sigma_err"], out["dx_err"], float(np.median(out["g_err"]))))
-    np.savez_compressed(os.path.join(HERE, "aekl_autocast_bf16.npz"), **out)
+    np.savez_compressed(os.path.join(HERE, f"aekl_autocast_{TAG}.npz"), **out)
 
 
 def disc():
@@ -147,7 +151,7 @@ def disc():
     def run(autocast):
         net, ref_tensor = build()                       # fresh running statistics for each run
         x = x0.clone().requires_grad_(True)
-        with (torch.autocast("cpu", dtype=torch.bfloat16) if autocast else torch.autocast("cpu", enabled=False)):
+        with (torch.autocast("cpu", dtype=DT) if autocast else torch.autocast("cpu", enabled=False)):
             logits = net(x)
         logits = logits.float()
         dy = torch.from_numpy(normal(tuple(logits.shape), seed=sdy))
@@ -158,13 +162,14 @@ def disc():
     np.testing.assert_allclose(r32[0].numpy(), g["logits"], rtol=2e-4, atol=5e-5)
     out = {"logits_err": np.float64(rel(ra[0], r32[0])), "dx_err": np.float64(rel(ra[1], r32[1])), "keys": np.array(pkeys),
            "g_err": np.array([rel(ra[2][k], r32[2][k]) for k in pkeys]), "g_l2": np.array([float(r32[2][k].double().norm()) for k in pkeys])}
-    print("discriminator twin: autocast-bf16 vs fp32: logits %.3e dx %.3e grads median %.3e" % (out["logits_err"], out["dx_err"], float(np.median(out["g_err"]))))
-    np.savez_compressed(os.path.join(HERE, "disc_autocast_bf16.npz"), **out)
+    print(f"discriminator twin: autocast-{TAG} vs fp32:" " logits %.3e dx %.3e grads median %.3e" % (out["logits_err"], out["dx_err"], float(np.median(out["g_err"]))))
+    np.savez_compressed(os.path.join(HERE, f"disc_autocast_{TAG}.npz"), **out)
 
 
 if __name__ == "__main__":
-    if "--aekl-only" not in sys.argv and "--disc-only" not in sys.argv:
+    for DT, TAG in ((torch.bfloat16, "bf16"), (torch.float16, "f16")):
+        if "--f16-only" in sys.argv and TAG != "f16":
+            continue
         main()
-    if "--disc-only" not in sys.argv:
         aekl()
-    disc()
+        disc()

@@ -416,7 +416,8 @@ def test_patch_discriminator_vs_reference_local_discriminator_golden(golden_dir,
             assert float(np.linalg.norm(gr[:16].numpy() - head)) / (float(np.linalg.norm(head)) + floor) < (3e-3 if f32 else 0.15), k
 
 
-def test_bf16_autoencoder_is_as_close_to_fp32_as_the_reference_autocast_run(golden_dir):
+@pytest.mark.parametrize("dtype,tag", [("bfloat16", "bf16"), ("float16", "f16")])
+def test_16bit_autoencoder_is_as_close_to_fp32_as_the_reference_autocast_run(golden_dir, dtype, tag):
     """The production stage-1 autoencoder [32,32,64] (frozen encoder of the LDM step, decoder of sampling): the reference's local twin under
     torch.autocast(bfloat16) is its own reduced-precision run (tests/golden/make_golden_autocast.py -> aekl_autocast_bf16.npz holds that
     run's distance from the fp32 run); the bf16 engine is held to the same distance (factor 1.5: not the same rounding points)."""
@@ -424,14 +425,14 @@ def test_bf16_autoencoder_is_as_close_to_fp32_as_the_reference_autocast_run(gold
     import gpu_util as G
     from eegldm.models import AutoencoderKL
     from oracle import aekl as A
-    a = np.load(os.path.join(golden_dir, "aekl_autocast_bf16.npz"))
+    a = np.load(os.path.join(golden_dir, f"aekl_autocast_{tag}.npz"))
     g = np.load(os.path.join(golden_dir, "aekl_twin_32_32_64_g1.npz"))
     nc = [int(v) for v in g["num_channels"]]; B, L = int(g["B"]), int(g["L"])
     cfg = dict(num_channels=nc, latent_channels=1, in_channels=1, out_channels=1, num_res_blocks=2, norm_num_groups=1)
     sw, sx, se, sdy = [int(v) for v in g["seeds"]]
     x = torch.from_numpy(eeg_windows(B, seed=sx, length=L, pad=8)); eps = torch.from_numpy(normal((B, 1, L // 4), seed=se))
     dy = torch.from_numpy(normal((B, 1, L), seed=sdy))
-    net = AutoencoderKL(spatial_dims=1, attention_levels=[False] * 3, dtype="bfloat16", **cfg)
+    net = AutoencoderKL(spatial_dims=1, attention_levels=[False] * 3, dtype=dtype, **cfg)
     sd = {k: torch.from_numpy(gen_param(sw, k, shape)) for k, (_o, _n, shape) in net.entries.items()}
     net.load_state_dict(sd)
     klo = torch.zeros(1, device=net.device)
@@ -454,22 +455,23 @@ def test_bf16_autoencoder_is_as_close_to_fp32_as_the_reference_autocast_run(gold
     ge, gl = a["g_err"].astype(np.float64), a["g_l2"].astype(np.float64)
     r = dict(recon=float(a["recon_err"]), mu=float(a["mu_err"]), sigma=float(a["sigma_err"]), dx=float(a["dx_err"]),
              grads=float(np.sqrt(((ge * gl) ** 2).sum() / (gl ** 2).sum())))
-    print("engine bf16 vs fp32:", {k: f"{v:.3e}" for k, v in e.items()}, "| reference autocast-bf16 vs fp32:", {k: f"{v:.3e}" for k, v in r.items()})
+    print(f"engine {tag} vs fp32:", {k: f"{v:.3e}" for k, v in e.items()}, f"| reference autocast-{tag} vs fp32:", {k: f"{v:.3e}" for k, v in r.items()})
     for k in e:
         assert e[k] <= 1.5 * r[k], (k, e[k], r[k])
 
 
-def test_bf16_discriminator_is_as_close_to_fp32_as_the_reference_autocast_run(golden_dir):
+@pytest.mark.parametrize("dtype,tag", [("bfloat16", "bf16"), ("float16", "f16")])
+def test_16bit_discriminator_is_as_close_to_fp32_as_the_reference_autocast_run(golden_dir, dtype, tag):
     """PatchDiscriminator (training-mode BatchNorm): the reference's local twin under torch.autocast(bfloat16) against its fp32 run
     (disc_autocast_bf16.npz) beside the bf16 engine against the same fp32 numbers; factor 1.5 as for the UNet and the autoencoder."""
     import os
     import gpu_util as G
     from eegldm.models import PatchDiscriminator
     from oracle import aekl as A
-    a = np.load(os.path.join(golden_dir, "disc_autocast_bf16.npz"))
+    a = np.load(os.path.join(golden_dir, f"disc_autocast_{tag}.npz"))
     g = np.load(os.path.join(golden_dir, "disc_twin_k3.npz"))
     sw, sx, sdy = [int(v) for v in g["seeds"]]
-    net = PatchDiscriminator(**D_CFG, dtype="bfloat16")
+    net = PatchDiscriminator(**D_CFG, dtype=dtype)
     sd = {}
     for k in [str(k) for k in g["keys"]]:
         shape = net.entries[k][2] if k in net.entries else net.buf_entries[k][2]
@@ -495,6 +497,6 @@ def test_bf16_discriminator_is_as_close_to_fp32_as_the_reference_autocast_run(go
     e["grads"] = (num / den) ** 0.5
     ge, gl = a["g_err"].astype(np.float64), a["g_l2"].astype(np.float64)
     r = dict(logits=float(a["logits_err"]), dx=float(a["dx_err"]), grads=float(np.sqrt(((ge * gl) ** 2).sum() / (gl ** 2).sum())))
-    print("engine bf16 vs fp32:", {k: f"{v:.3e}" for k, v in e.items()}, "| reference autocast-bf16 vs fp32:", {k: f"{v:.3e}" for k, v in r.items()})
+    print(f"engine {tag} vs fp32:", {k: f"{v:.3e}" for k, v in e.items()}, f"| reference autocast-{tag} vs fp32:", {k: f"{v:.3e}" for k, v in r.items()})
     for k in e:
         assert e[k] <= 1.5 * r[k], (k, e[k], r[k])

@@ -258,20 +258,21 @@ def test_unet_options_fp16_and_deterministic_mode(name):
     assert all(torch.equal(p, q) for p, q in zip(a, b))
 
 
+@pytest.mark.parametrize("dtype,tag", [("bfloat16", "bf16"), ("float16", "f16")])
 @pytest.mark.parametrize("name", list(UNET_CASES) + ["full_l768"])
-def test_bf16_engine_is_as_close_to_fp32_as_the_reference_autocast_run(golden_dir, name):
-    """tests/golden/make_golden_autocast.py ran the REFERENCE UNet under torch.autocast(bfloat16) -- its own reduced-precision execution -- and
-    recorded how far that run is from its fp32 run.  The bf16 engine (bf16 storage, fp32 accumulation and statistics) has to be about as
+def test_16bit_engine_is_as_close_to_fp32_as_the_reference_autocast_run(golden_dir, name, dtype, tag):
+    """tests/golden/make_golden_autocast.py ran the REFERENCE UNet under torch.autocast (bfloat16, and float16 -- the type it trains in,
+    training.py:423) -- its own reduced-precision execution -- and recorded how far that run is from its fp32 run.  The bf16 engine (bf16 storage, fp32 accumulation and statistics) has to be about as
     close to the fp32 result: output, input gradient, and the parameter gradient as one vector."""
     import gpu_util as G
     from make_golden_cases import UNET_FULL
     from eegldm.models import UNetModel
     from oracle import unet as U
-    a = np.load(os.path.join(golden_dir, "unet_autocast_bf16.npz"))
+    a = np.load(os.path.join(golden_dir, f"unet_autocast_{tag}.npz"))
     g = np.load(os.path.join(golden_dir, f"unet_{name}.npz"))
     cfg, B, L = UNET_FULL if name == "full_l768" else UNET_CASES[name]
     sw, sx, _st, sdy = [int(v) for v in g["seeds"]]
-    net = UNetModel(**cfg, dtype="bfloat16")
+    net = UNetModel(**cfg, dtype=dtype)
     sd = {k: torch.from_numpy(gen_param(sw, k, shape)) for k, (_o, _n, shape) in net.entries.items()}
     net.load_state_dict(sd)
     x = torch.from_numpy(normal((B, cfg["in_channels"], L), seed=sx)); t = torch.from_numpy(g["t"])
@@ -294,7 +295,7 @@ def test_bf16_engine_is_as_close_to_fp32_as_the_reference_autocast_run(golden_di
     ge, gl = a[name + ":g_err"].astype(np.float64), a[name + ":g_l2"].astype(np.float64)
     r_g = float(np.sqrt(((ge * gl) ** 2).sum() / (gl ** 2).sum()))
     r_y, r_dx = float(a[name + ":y_err"]), float(a[name + ":dx_err"])
-    print(f"{name}: engine bf16 vs fp32  y {e_y:.3e} dx {e_dx:.3e} grads {e_g:.3e}   |   reference autocast-bf16 vs fp32  y {r_y:.3e} dx {r_dx:.3e} grads {r_g:.3e}")
+    print(f"{name}: engine {tag} vs fp32  y {e_y:.3e} dx {e_dx:.3e} grads {e_g:.3e}   |   reference autocast-{tag} vs fp32  y {r_y:.3e} dx {r_dx:.3e} grads {r_g:.3e}")
     # Not the same rounding points: CPU autocast keeps the residual stream, GroupNorm outputs and softmax in fp32 and rounds conv / linear /
     # matmul results only, the engine stores EVERY activation in bf16 -- so "as close" is held to a factor of 1.5, not to <= (measured:
     # 0.6-1.2 x on the four cases).
