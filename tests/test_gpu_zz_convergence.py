@@ -82,6 +82,59 @@ def test_ldm_training_trajectory_matches_the_oracle(dtype, tol):
     print(f"LDM trajectory [{dtype}]: worst relative loss gap over 30 steps {worst:.2e}")
 
 
+def test_16bit_ldm_trajectories_beside_the_reference_loops_autocast_runs():
+    """ldm_traj_c2_reference.json: the reference's own loop body on its own UNetModel, fp32 (= the oracle's fixture to 3.5e-7), under bf16
+    autocast, and under fp16 autocast + GradScaler (its production setting).  The bf16 engine's per-step loss stays as close to fp32 as the
+    reference's bf16 run does (factor 1.5 on the worst step), and so does the fp16 engine beside the reference's fp16 run."""
+    import torch
+    from param_gen import gen_param, eeg_windows, normal, timesteps
+    from eegldm.models import UNetModel
+    from eegldm.schedulers import DDPMScheduler
+    from eegldm.training import Adam, GradScaler, ldm_train_step
+    g, r = _golden("ldm_traj_c2.json"), _golden("ldm_traj_c2_reference.json")
+    ref32 = r["loss_fp32"]
+    worst_ref_bf16 = max(abs(a - b) / b for a, b in zip(r["loss_bf16"], ref32))
+    worst_bf16 = replay_ldm("bfloat16")
+    print(f"bf16: engine worst gap to fp32 {worst_bf16:.2e}; reference bf16-autocast worst gap {worst_ref_bf16:.2e}")
+    assert worst_bf16 <= 1.5 * worst_ref_bf16, (worst_bf16, worst_ref_bf16)
+    # fp16 + GradScaler.  At torch's default initial scale (65536, as the reference constructs it: training.py:334) torch's CPU fp16 kernels
+    # overflow twice and that curve runs two optimiser steps behind; the engine accumulates in fp32, rounds to fp16 only when it stores, and does
+    # not overflow there.  The step-by-step comparison is made at init_scale = 1024, where neither side backs off.
+    def fp16_run(init_scale):
+        net = UNetModel(image_size=768, **UCFG, dtype="float16")
+        net.load_state_dict({k: torch.from_numpy(gen_param(g["param_seed"], k, tuple(v.shape))) for k, v in net.state_dict().items()})
+        sched = DDPMScheduler(num_train_timesteps=1000, schedule="linear_beta", beta_start=0.0015, beta_end=0.0195)
+        opt, scaler = Adam(net, lr=g["lr"]), GradScaler(init_scale=init_scale)
+        B, POOL = g["batch"], g["pool"]
+        pool = torch.from_numpy(eeg_windows(POOL, seed=g["latent_seed"], length=768)).cuda()
+        loss = torch.zeros(1, device="cuda")
+        got, backoffs = [], []
+        for i in range(1, g["steps"] + 1):
+            s = ((i - 1) * B) % POOL
+            nz = torch.from_numpy(normal((B, 1, 768), seed=g["noise_seed_base"] + i)).cuda()
+            t = torch.from_numpy(timesteps(B, seed=g["t_seed_base"] + i)).cuda()
+            net.zero_grad()
+            before = scaler.get_scale()
+            ldm_train_step(net, sched, pool[s:s + B], nz, t, loss_out=loss, grad_scale=before)
+            scaler.step(opt); scaler.update()
+            if scaler.get_scale() < before:
+                backoffs.append(i)
+            got.append(float(loss))
+        return got, backoffs
+    got, backoffs = fp16_run(1024.0)
+    assert backoffs == [] and r["f16_scale1024_backoffs"] == 0
+    ref16 = r["loss_f16_scale1024"]
+    worst_ref_f16 = max(abs(a - b) / b for a, b in zip(ref16, ref32))
+    worst_f16 = max(abs(a - b) / b for a, b in zip(got, ref32))
+    print(f"fp16 (init_scale 1024): engine worst gap to fp32 {worst_f16:.2e}; reference fp16-autocast worst gap {worst_ref_f16:.2e}")
+    assert worst_f16 <= 1.5 * worst_ref_f16 + 1e-3, (worst_f16, worst_ref_f16)
+    got_d, backoffs_d = fp16_run(65536.0)
+    print("fp16 at the default scale: engine back-offs", backoffs_d, "| reference back-offs", r["f16_scaler_backoffs"])
+    assert r["f16_scaler_backoffs"] == 2 and len(backoffs_d) <= 2
+    if not backoffs_d:
+        assert max(abs(a - b) / b for a, b in zip(got_d, ref32)) <= 1.5 * worst_ref_f16 + 1e-3
+
+
 def replay_aekl(fixture, dtype):
     """The 40 GAN steps of an aekl_traj_*.json fixture on the engine.  Returns {"rel": {term: [per-step |got-want|/|want|]}, "got": ..., "want": ...}."""
     import torch
